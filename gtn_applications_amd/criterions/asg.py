@@ -1,0 +1,168 @@
+"""ASG criterion -- counterpart of /root/reference/criterions/asg.py.
+
+loss_b = forward_score(emissions o transitions) - forward_score(force_align o transitions o emissions)
+(asg.py:111-115).  The denominator runs on the dense-transition kernels (csrc/dense_kernels.hip),
+the numerator on the lattice engine with arcs that index the (C+1) x C transition matrix; the
+reference's per-sample rebuild of the C^2-arc transitions graph (asg.py:54-69,103) disappears: the
+transitions tensor is the graph.
+"""
+import itertools
+
+import torch
+
+from .. import engine as E
+from .. import graph as G
+
+
+def pack_replabels(tokens, num_replabels):
+    """asg.py:13-32: replace runs of a repeated token by a "repeat k times" label."""
+    if all(isinstance(t, list) for t in tokens):
+        return [pack_replabels(t, num_replabels) for t in tokens]
+    assert isinstance(tokens, list)
+    out, run, prev = [], 0, -1
+    for tok in tokens:
+        if tok == prev and run < num_replabels:
+            run += 1
+            continue
+        if run > 0:
+            out.append(run - 1)
+            run = 0
+        out.append(tok + num_replabels)
+        prev = tok
+    if run > 0:
+        out.append(run - 1)
+    return out
+
+
+def unpack_replabels(tokens, num_replabels):
+    """asg.py:35-49: inverse of pack_replabels."""
+    if all(isinstance(t, list) for t in tokens):
+        return [unpack_replabels(t, num_replabels) for t in tokens]
+    assert isinstance(tokens, list)
+    out, prev = [], -1
+    for tok in tokens:
+        if tok >= num_replabels:
+            out.append(tok - num_replabels)
+            prev = tok
+        elif prev != -1:
+            out.extend([prev - num_replabels] * (tok + 1))
+            prev = -1
+    return out
+
+
+class ASGLossFunction(torch.autograd.Function):
+    @staticmethod
+    def create_transitions_graph(transitions, calc_grad=False):
+        """asg.py:54-69 as a host graph: arc ids are the row-major index into transitions
+        [(C+1), C] (row 0: start -> i, row 1+i: j -> i).  Used when a Transducer is given ASG
+        transitions (tests/transducer_test.py:474-481); the ASG loss itself never builds it."""
+        import numpy as np
+
+        C = transitions.shape[1]
+        assert transitions.shape == (C + 1, C)
+        g = G.Graph(calc_grad)
+        g.add_nodes([1] + [0] * C, [0] + [1] * C)
+        i = np.repeat(np.arange(C, dtype=np.int32), C)
+        j = np.tile(np.arange(C, dtype=np.int32), C)
+        src = np.concatenate([np.zeros(C, np.int32), j + 1])
+        dst = np.concatenate([np.arange(1, C + 1, dtype=np.int32), i + 1])
+        lab = np.concatenate([np.arange(C, dtype=np.int32), i])
+        g.add_arcs(src, dst, lab, lab, transitions.detach().cpu().contiguous().view(-1).numpy())
+        return g
+
+    @staticmethod
+    def create_force_align_graph(target):
+        """asg.py:72-81 as a host graph (API parity)."""
+        g = G.Graph(False)
+        g.add_node(True)
+        L = len(target)
+        for l in range(1, L + 1):
+            g.add_node(False, l == L)
+            g.add_arc(l - 1, l, target[l - 1])
+            g.add_arc(l, l, target[l - 1])
+        g.arc_sort(True)
+        return g
+
+    @staticmethod
+    def forward(ctx, inputs, transitions, targets, reduction="none"):
+        B, T, C = inputs.shape
+        if reduction not in ("none", "mean"):  # asg.py:120-121
+            raise ValueError("invalid value for reduction '" + str(reduction) + "'")
+        if tuple(transitions.shape) != (C + 1, C):
+            raise ValueError(f"transitions must be [{C + 1}, {C}], got {tuple(transitions.shape)}")
+        if T == 0:
+            raise ValueError("ASGLoss: empty emissions (T == 0)")
+        dev = E.require_gpu()
+        x = E.as_device_f32(inputs.detach(), dev)
+        W = E.as_device_f32(transitions.detach(), dev)
+        tg = E.targets_on_device(targets, dev)
+        if tg.B != B:
+            raise ValueError(f"got {tg.B} targets for a batch of {B}")
+        scale, cpos, cneg = E.loss_factors(tg, reduction)
+        pack = tg.cache.get(("asg_fal", C))
+        if pack is None:
+            pack = tg.cache[("asg_fal", C)] = E.PackedLattice.asg_force_align(tg.flat, tg.offsets, C, dev)
+        need_grad = inputs.requires_grad or transitions.requires_grad
+        fcc = E.dense_forward(x, W, need_beta=need_grad)
+        fal = E.lattice_forward(x, pack, weights=W, need_beta=need_grad)
+        loss = E.reduce_loss(fcc.logz, scale, 1.0)
+        loss = E.reduce_loss(fal.logz, scale, -1.0, out=loss)
+        ctx.aux = (x, W, fcc, fal, cpos, cneg)
+        ctx.devices = (inputs.device, transitions.device)
+        return loss if inputs.is_cuda else loss.cpu()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, W, fcc, fal, cpos, cneg = ctx.aux
+        gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.zeros_like(W) if ctx.needs_input_grad[1] else None
+        if dx is not None or dW is not None:
+            # + posteriors of the fully connected graph, - posteriors of the force-aligned one
+            E.dense_grad(x, W, fcc, cpos, coef_w=cpos, gout=gout, dx=dx, accumulate=False, dW=dW)
+            E.lattice_grad(fal, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=True, dW=dW)
+        if dx is not None and ctx.devices[0].type != "cuda":
+            dx = dx.to(ctx.devices[0])
+        if dW is not None and ctx.devices[1].type != "cuda":
+            dW = dW.to(ctx.devices[1])
+        return dx, dW, None, None
+
+
+ASGLoss = ASGLossFunction.apply
+
+
+class ASG(torch.nn.Module):
+    def __init__(self, num_classes, num_replabels=1, use_garbage=True):
+        super(ASG, self).__init__()
+        self.num_classes = num_classes
+        self.num_replabels = num_replabels
+        assert self.num_replabels > 0
+        self.garbage_idx = (num_classes + num_replabels) if use_garbage else None
+        self.N = num_classes + num_replabels + int(use_garbage)
+        self.transitions = torch.nn.Parameter(torch.zeros(self.N + 1, self.N))
+
+    def forward(self, inputs, targets):
+        targets = [pack_replabels(t.tolist(), self.num_replabels) for t in targets]
+        if self.garbage_idx is not None:  # a garbage token between (and around) the labels: asg.py:203-208
+            for idx, tgt in enumerate(targets):
+                interleaved = [self.garbage_idx] * (2 * len(tgt) + 1)
+                interleaved[1::2] = tgt
+                targets[idx] = interleaved
+        return ASGLoss(inputs, self.transitions, targets, "mean")
+
+    def viterbi(self, outputs):
+        """asg.py:211-237: best label sequence under emissions + transitions, repeats collapsed,
+        garbage dropped, replabels unpacked."""
+        B, T, C = outputs.shape
+        assert C == self.N, "Wrong number of classes in output."
+        dev = E.require_gpu()
+        x = E.as_device_f32(outputs.detach(), dev)
+        W = E.as_device_f32(self.transitions.detach(), dev)
+        paths = E.dense_viterbi(x, W).cpu().tolist()
+        predictions = []
+        for path in paths:
+            collapsed = [p for p, _ in itertools.groupby(path)]
+            if self.garbage_idx is not None:
+                collapsed = [p for p in collapsed if p != self.garbage_idx]
+            predictions.append(torch.IntTensor(unpack_replabels(collapsed, self.num_replabels)))
+        return predictions

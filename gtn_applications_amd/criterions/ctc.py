@@ -1,0 +1,106 @@
+"""CTC criterion -- counterpart of /root/reference/criterions/ctc.py.
+
+`CTCLossFunction.forward/backward`, `CTCLoss` and `CTC` keep the reference's signatures
+(ctc.py:13-135).  Where the reference builds `gtn.intersect(g_emissions, g_criterion)` per sample
+on host threads (ctc.py:38-65), this sends the whole batch through the CTC fast-path kernels
+(csrc/ctc_kernels.hip) -- or, for targets longer than 63 labels, through the generic lattice
+engine (csrc/lattice_kernels.hip).  Both are HIP paths; there is no CPU path.
+"""
+import torch
+
+from .. import engine as E
+from .. import graph as G
+
+
+class CTCLossFunction(torch.autograd.Function):
+    @staticmethod
+    def create_ctc_graph(target, blank_idx):
+        """ctc.py:15-29 as a host graph (API parity; the kernels never need it)."""
+        g = G.Graph(False)
+        L = len(target)
+        S = 2 * L + 1
+        for s in range(S):
+            g.add_node(s == 0, s >= S - 2)
+            label = target[(s - 1) // 2] if s % 2 else blank_idx
+            g.add_arc(s, s, label)
+            if s > 0:
+                g.add_arc(s - 1, s, label)
+            if s % 2 and s > 1 and label != target[(s - 1) // 2 - 1]:
+                g.add_arc(s - 2, s, label)
+        g.arc_sort(False)
+        return g
+
+    @staticmethod
+    def forward(ctx, log_probs, targets, blank_idx=0, reduction="none"):
+        B, T, C = log_probs.shape
+        if T == 0:
+            raise ValueError("CTCLoss: empty emissions (T == 0)")
+        if reduction not in ("none", "mean"):  # ctc.py:57-58
+            raise ValueError("invalid value for reduction '" + str(reduction) + "'")
+        dev = E.require_gpu()
+        x = E.as_device_f32(log_probs.detach(), dev)
+        tg = E.targets_on_device(targets, dev)
+        if tg.B != B:
+            raise ValueError(f"got {tg.B} targets for a batch of {B}")
+        scale, _, coef = E.loss_factors(tg, reduction)  # loss scale; gradient coefficient -scale/B
+        need_grad = log_probs.requires_grad
+        if tg.max_len <= 63:
+            ws, nll = E.ctc_forward(x, tg, int(blank_idx))
+            loss = E.reduce_loss(nll, scale, 1.0)
+            ctx.aux = ("fast", x, tg, int(blank_idx), ws if need_grad else None, nll, coef)
+        else:
+            pack = tg.cache.get(("ctc_lattice", int(blank_idx), C))
+            if pack is None:
+                pack = tg.cache[("ctc_lattice", int(blank_idx), C)] = E.PackedLattice.ctc(
+                    tg.flat, tg.offsets, int(blank_idx), C, dev)
+            st = E.lattice_forward(x, pack, need_beta=need_grad)
+            loss = E.reduce_loss(st.logz, scale, -1.0)
+            ctx.aux = ("lattice", x, st, coef)
+        ctx.in_device = log_probs.device
+        return loss if log_probs.is_cuda else loss.cpu()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kind, x = ctx.aux[0], ctx.aux[1]
+        gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
+        dx = torch.empty_like(x)
+        if kind == "fast":
+            _, _, tg, blank, ws, nll, coef = ctx.aux
+            E.ctc_grad(x, tg, blank, ws, nll, coef, gout, dx)
+        else:
+            _, _, st, coef = ctx.aux
+            E.lattice_grad(st, coef, gout=gout, dx=dx)
+        if ctx.in_device.type != "cuda":
+            dx = dx.to(ctx.in_device)
+        return dx, None, None, None
+
+
+CTCLoss = CTCLossFunction.apply
+
+
+class CTC(torch.nn.Module):
+    def __init__(self, blank, use_pt):
+        super(CTC, self).__init__()
+        self.blank = blank  # index of blank label
+        self.use_pt = use_pt  # use torch.nn.functional.ctc_loss instead of the WFST engine
+
+    def forward(self, inputs, targets):
+        log_probs = torch.nn.functional.log_softmax(inputs, dim=2)
+        if self.use_pt:  # ctc.py:109-121
+            return torch.nn.functional.ctc_loss(
+                log_probs.permute(1, 0, 2), torch.cat(targets), [inputs.shape[1]] * inputs.shape[0],
+                [t.numel() for t in targets], blank=self.blank, zero_infinity=True,
+            )
+        return CTCLoss(log_probs, [t.tolist() for t in targets], self.blank, "mean")
+
+    def viterbi(self, outputs):
+        """Greedy decode (ctc.py:126-135): argmax, collapse repeats, drop blank."""
+        best = torch.argmax(outputs, dim=2).to("cpu")
+        result = []
+        for row in best:
+            if row.numel():
+                keep = torch.ones_like(row, dtype=torch.bool)
+                keep[1:] = row[1:] != row[:-1]
+                row = row[keep]
+            result.append(row[row != self.blank])
+        return result

@@ -1,0 +1,294 @@
+"""Transducer criterion -- counterpart of /root/reference/criterions/transducer.py.
+
+Graph factories (`make_*_graph`), the `Transducer` module and `TransducerLossFunction` keep the
+reference's names, arguments and error behaviour (transducer.py:15-348).  The small per-utterance
+graph algebra (target o lexicon, tokens o decompositions, transitions o alignments;
+transducer.py:265-281) runs in the C++ host library; everything that touches the [B,T,C] emissions
+-- `intersect(emissions, .)`, `forward_score`, `viterbi_path`, `backward`
+(transducer.py:283-288,321-336,216-221) -- runs on the lattice engine kernels.
+"""
+import itertools
+
+import numpy as np
+import torch
+
+from .. import engine as E
+from .. import graph as G
+
+
+def make_scalar_graph(weight):
+    """transducer.py:15-20."""
+    scalar = G.Graph()
+    scalar.add_node(True)
+    scalar.add_node(False, True)
+    scalar.add_arc(0, 1, 0, 0, weight)
+    return scalar
+
+
+def make_chain_graph(sequence):
+    """transducer.py:23-29."""
+    seq = [int(s) for s in sequence]
+    graph = G.Graph(False)
+    n = len(seq)
+    graph.add_nodes([1] + [0] * n, [0] * n + [1] if n else [0])
+    if n:
+        idx = np.arange(n, dtype=np.int32)
+        graph.add_arcs(idx, idx + 1, np.asarray(seq, dtype=np.int32))
+    return graph
+
+
+def make_transitions_graph(ngram, num_tokens, calc_grad=False):
+    """transducer.py:32-58: dense n-gram transition model; </s> is reached by epsilon arcs."""
+    transitions = G.Graph(calc_grad)
+    transitions.add_node(True, ngram == 1)
+    state_map = {(): 0}
+    for n in range(1, ngram):  # histories that still include <s>
+        for state in itertools.product(range(num_tokens), repeat=n):
+            state_map[state] = transitions.add_node(False, ngram == 1)
+            transitions.add_arc(state_map[state[:-1]], state_map[state], state[-1])
+    src, dst, lab = [], [], []
+    for state in itertools.product(range(num_tokens), repeat=ngram):
+        src.append(state_map[state[:-1]]), dst.append(state_map[state[1:]]), lab.append(state[-1])
+    transitions.add_arcs(src, dst, lab)
+    if ngram > 1:
+        end_idx = transitions.add_node(False, True)
+        idx = np.arange(end_idx, dtype=np.int32)
+        transitions.add_arcs(idx, np.full(end_idx, end_idx, np.int32), np.full(end_idx, G.epsilon, np.int32))
+    return transitions
+
+
+def make_lexicon_graph(word_pieces, graphemes_to_idx):
+    """transducer.py:61-75: letters -> word pieces."""
+    graph = G.Graph(False)
+    graph.add_node(True, True)
+    for i, wp in enumerate(word_pieces):
+        prev = 0
+        for letter in wp[:-1]:
+            n = graph.add_node()
+            graph.add_arc(prev, n, graphemes_to_idx[letter], G.epsilon)
+            prev = n
+        graph.add_arc(prev, 0, graphemes_to_idx[wp[-1]], i)
+    graph.arc_sort()
+    return graph
+
+
+def make_token_graph(token_list, blank="none", allow_repeats=True):
+    """transducer.py:78-123: emission labels -> tokens (one or more frames per token)."""
+    if not allow_repeats and blank != "optional":
+        raise ValueError("Must use blank='optional' if disallowing repeats.")
+    ntoks = len(token_list)
+    graph = G.Graph(False)
+    graph.add_node(True, True)
+    graph.add_nodes([0] * ntoks, [int(blank != "forced")] * ntoks)
+    if blank != "none":
+        graph.add_node()
+        graph.add_arc(0, ntoks + 1, ntoks, G.epsilon)  # blank index is assumed to be last (ntoks)
+        graph.add_arc(ntoks + 1, 0, G.epsilon)
+    entry = (ntoks + 1) if blank == "forced" else 0
+    arcs = []  # (src, dst, ilabel, olabel) in the reference's insertion order
+    for i in range(ntoks):
+        arcs.append((entry, i + 1, i, i))
+        arcs.append((i + 1, i + 1, i, G.epsilon))
+        if allow_repeats:
+            if blank == "forced":  # token -> blank only
+                arcs.append((i + 1, ntoks + 1, ntoks, G.epsilon))
+            else:  # token -> blank and every token
+                arcs.append((i + 1, 0, G.epsilon, G.epsilon))
+        else:  # token -> blank and every OTHER token
+            arcs.append((i + 1, ntoks + 1, ntoks, G.epsilon))
+            arcs.extend((i + 1, j + 1, j, j) for j in range(ntoks) if j != i)
+    src, dst, il, ol = (np.fromiter((a[k] for a in arcs), dtype=np.int32, count=len(arcs)) for k in range(4))
+    graph.add_arcs(src, dst, il, ol)
+    return graph
+
+
+def make_kernel_graph(x, blank_idx, blank_optional, spike=False, calc_grad=False):
+    """transducer.py:351-367."""
+    g = G.Graph(calc_grad)
+    g.add_node(True, len(x) == 0)  # start in blank
+    g.add_arc(0, 0, blank_idx)
+    for i, c in enumerate(x):
+        last = (i + 1) == len(x)
+        g.add_node(False, blank_optional and last)
+        g.add_node(False, last)
+        g.add_arc(2 * i, 2 * i + 1, c)
+        if not spike:
+            g.add_arc(2 * i + 1, 2 * i + 1, c)
+        g.add_arc(2 * i + 1, 2 * i + 2, blank_idx)
+        g.add_arc(2 * i + 2, 2 * i + 2, blank_idx)
+        if i > 0 and blank_optional and x[i - 1] != c:
+            g.add_arc(2 * i - 1, 2 * i + 1, c)
+    g.arc_sort(True)
+    g.arc_sort()
+    return g
+
+
+# alignment graphs per (tokens, lexicon, transitions, target) and packed batches: content-keyed LRUs
+_ALIGN_CACHE = E.LRU(4096)
+_PACK_CACHE = E.LRU(32)
+
+
+def _zero_weight_view(graph):
+    """Structure of `graph` with all arc weights 0: learnable weights are added on the device."""
+    a = graph.arrays()
+    g = G.Graph(False)
+    g.add_nodes(a["start"], a["accept"])
+    g.add_arcs(a["src"], a["dst"], a["ilabel"], a["olabel"])
+    return g
+
+
+def _alignment_graph(target, tokens, lexicon, transitions):
+    """transducer.py:265-281: every frame-level alignment of every decomposition of `target` into
+    tokens, optionally intersected with the transition model.  Returns (graph, weight ids)."""
+    key = (tuple(target), id(tokens), id(lexicon), id(transitions))
+
+    def build():
+        tgt = make_chain_graph(target)
+        tokens_target = G.remove(G.project_output(G.compose(tgt, lexicon)))
+        ali = G.project_input(G.remove(G.compose(tokens, tokens_target)))
+        if transitions is None:
+            return ali, None, (tokens, lexicon)
+        ali, from_trans, _ = G.compose(transitions, ali, provenance=True)
+        return ali, from_trans, (tokens, lexicon, transitions)  # keep operands alive: ids stay unique
+
+    return _ALIGN_CACHE.get(key, build)[:2]
+
+
+class Transducer(torch.nn.Module):
+    """A generic transducer loss (transducer.py:126-234).
+
+    tokens: list of iterables (strings, tuples, ...) -- the model's output units.
+    graphemes_to_idx: grapheme -> integer index.
+    ngram: order of the learned token-level transition model (0: none).
+    transitions: alternatively a ready transition graph (its arcs become `transition_params`).
+    blank: 'none' | 'optional' | 'forced'.   allow_repeats: allow the same token twice in a row.
+    """
+
+    def __init__(self, tokens, graphemes_to_idx, ngram=0, transitions=None, blank="none",
+                 allow_repeats=True, reduction="none"):
+        super(Transducer, self).__init__()
+        if blank not in ["optional", "forced", "none"]:
+            raise ValueError("Invalid value specificed for blank. Must be in ['optional', 'forced', 'none']")
+        self.tokens = make_token_graph(tokens, blank=blank, allow_repeats=allow_repeats)
+        self.lexicon = make_lexicon_graph(tokens, graphemes_to_idx)
+        self.ngram = ngram
+        if ngram > 0 and transitions is not None:
+            raise ValueError("Only one of ngram and transitions may be specified")
+        if ngram > 0:
+            transitions = make_transitions_graph(ngram, len(tokens) + int(blank != "none"), True)
+        if transitions is not None:
+            # the arc weights of the graph are replaced by the parameters on every call
+            # (transducer.py:255-256), so only its structure matters
+            self.transitions = _zero_weight_view(transitions)
+            self.transitions.arc_sort()
+            self.transition_params = torch.nn.Parameter(torch.zeros(self.transitions.num_arcs()))
+        else:
+            self.transitions = None
+            self.transition_params = None
+        self.reduction = reduction
+
+    def forward(self, inputs, targets):
+        if self.transitions is None:
+            inputs = torch.nn.functional.log_softmax(inputs, dim=2)
+        self.tokens.arc_sort(True)
+        return TransducerLoss(inputs, targets, self.tokens, self.lexicon, self.transition_params,
+                              self.transitions, self.reduction)
+
+    def viterbi(self, outputs):
+        """transducer.py:199-234: best frame-level path (under the transition model if any), then
+        the shortest token sequence that path can transduce to."""
+        B, T, C = outputs.shape
+        dev = E.require_gpu()
+        x = E.as_device_f32(outputs.detach(), dev)
+        if self.transitions is not None:
+            pack = _transitions_pack(self.transitions, B, C, dev)
+            params = E.as_device_f32(self.transition_params.detach(), dev)
+            arc_paths, _ = E.lattice_viterbi(x, pack, weights=params)
+            olab = self.transitions.arrays()["olabel"]
+            frame_paths = []
+            for p in arc_paths:
+                labs = olab[p] if p is not None else np.zeros(0, np.int32)
+                frame_paths.append([int(v) for v in labs if v != G.epsilon])  # gtn.remove of back-off arcs
+        else:
+            # viterbi_path of the bare emissions graph: per frame, the first maximal label
+            mx = x.max(dim=2, keepdim=True).values
+            cols = torch.arange(C, device=dev).expand(B, T, C)
+            frame_paths = torch.where(x == mx, cols, torch.full_like(cols, C)).min(dim=2).values.cpu().tolist()
+        self.tokens.arc_sort()
+        predictions = []
+        for labels in frame_paths:
+            path = G.compose(make_chain_graph(labels), self.tokens)
+            path = G.viterbi_path(path)  # ambiguous decodings: the shortest wins (transducer.py:226-228)
+            path = G.remove(G.project_output(path))
+            predictions.append(torch.IntTensor(path.labels_to_list()))
+        return predictions
+
+
+def _transitions_pack(transitions, B, C, device):
+    key = ("den", id(transitions), B, C, device.index)
+
+    def build():
+        wid = np.arange(transitions.num_arcs(), dtype=np.int32)
+        return E.PackedLattice.from_graphs([transitions], C, device, wids=[wid], B=B, shared=True), transitions
+
+    return _PACK_CACHE.get(key, build)[0]
+
+
+class TransducerLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets, tokens, lexicon, transition_params=None, transitions=None,
+                reduction="none"):
+        B, T, C = inputs.shape
+        if transitions is not None and transition_params is None:
+            raise ValueError("Specified transitions, but not transition params.")
+        if T == 0:
+            raise ValueError("TransducerLoss: empty emissions (T == 0)")
+        dev = E.require_gpu()
+        x = E.as_device_f32(inputs.detach(), dev)
+        rows = [t.tolist() if hasattr(t, "tolist") else [int(v) for v in t] for t in targets]
+        if len(rows) != B:
+            raise ValueError(f"got {len(rows)} targets for a batch of {B}")
+        params = E.as_device_f32(transition_params.detach(), dev) if transitions is not None else None
+
+        key = ("num", tuple(map(tuple, rows)), id(tokens), id(lexicon), id(transitions), C, dev.index)
+
+        def build():
+            graphs, wids = zip(*[_alignment_graph(r, tokens, lexicon, transitions) for r in rows])
+            pack = E.PackedLattice.from_graphs(list(graphs), C, dev, wids=list(wids) if transitions is not None else None)
+            if reduction == "mean":  # transducer.py:302-305: normalise by the (grapheme) target length
+                sc = [1.0 / len(r) if len(r) > 0 else 1.0 for r in rows]
+            else:
+                sc = [1.0] * B
+            scale = torch.tensor(sc, dtype=torch.float32, device=dev)
+            return pack, scale, scale / B, -scale / B, (tokens, lexicon, transitions)
+
+        pack, scale, cpos, cneg, _ = _PACK_CACHE.get(key + (reduction == "mean",), build)
+        need_grad = inputs.requires_grad or (transition_params is not None and transition_params.requires_grad)
+        num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad)
+        loss = E.reduce_loss(num.logz, scale, -1.0)
+        den = None
+        if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288
+            den = E.lattice_forward(x, _transitions_pack(transitions, B, C, dev), weights=params, need_beta=need_grad)
+            loss = E.reduce_loss(den.logz, scale, 1.0, out=loss)
+        ctx.aux = (x, params, num, den, cpos, cneg)
+        ctx.devices = (inputs.device, None if transition_params is None else transition_params.device)
+        return loss if inputs.is_cuda else loss.cpu()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, params, num, den, cpos, cneg = ctx.aux
+        gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.zeros_like(params) if (params is not None and ctx.needs_input_grad[4]) else None
+        if dx is not None or dW is not None:
+            E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=False, dW=dW)
+            if den is not None:
+                E.lattice_grad(den, cpos, coef_w=cpos, gout=gout, dx=dx, accumulate=True, dW=dW)
+        if dx is not None and ctx.devices[0].type != "cuda":
+            dx = dx.to(ctx.devices[0])
+        if dW is not None and ctx.devices[1].type != "cuda":
+            dW = dW.to(ctx.devices[1])
+        return dx, None, None, None, dW, None, None
+
+
+TransducerLoss = TransducerLossFunction.apply

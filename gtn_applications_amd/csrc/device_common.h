@@ -1,0 +1,59 @@
+// Device-side helpers shared by the gfx950 kernels of libwfl.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "common.h"
+
+#define WFL_NEG_INF (-__builtin_inff())
+
+#define WFL_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      wfl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return WFL_ERR_RUNTIME;                                                            \
+    }                                                                                    \
+  } while (0)
+
+#define WFL_LAUNCH_CHECK()                                                         \
+  do {                                                                             \
+    hipError_t _e = hipGetLastError();                                             \
+    if (_e != hipSuccess) {                                                        \
+      wfl::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return WFL_ERR_RUNTIME;                                                      \
+    }                                                                              \
+  } while (0)
+
+namespace wfl {
+
+constexpr int kWave = 64;           // gfx950 wavefront
+constexpr int kLdsBytes = 160 * 1024;  // per CU (and per workgroup) on MI355X
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_log(float x) { return __logf(x); }
+
+// NaN policy: a NaN score is an impossible arc.
+__device__ __forceinline__ float nan_to_neg(float v) { return (v != v) ? WFL_NEG_INF : v; }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// log(exp(a) + exp(b)) with -inf handled
+__device__ __forceinline__ float log_add(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == WFL_NEG_INF) return WFL_NEG_INF;
+  return m + fast_log(fast_exp(a - m) + fast_exp(b - m));
+}
+
+}  // namespace wfl

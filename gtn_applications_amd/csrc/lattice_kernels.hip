@@ -1,0 +1,605 @@
+// Generic lattice engine for gfx950 (MI355X): time-synchronous log-/max-plus forward-backward over
+// an arbitrary per-utterance acceptor A_b composed with the implicit emissions chain.
+//
+//   stage 1  wfl_lattice_gather   all CUs, one wave per (b,t) row: xg[b,t,k] = x[b,t,labels_b[k]]
+//   stage 2  wfl_lattice_forward  one workgroup per (utterance, direction); arcs of A_b staged in
+//                                 LDS as CSR lists, alpha/beta ping-pong in LDS, one barrier per
+//                                 frame (+1 per epsilon level), next xg row prefetched in registers
+//   stage 3  wfl_lattice_grad     all CUs, tiles of frames: arc posteriors -> LDS row buffer
+//                                 (ds_add_f32) -> dense coalesced gradient rows incl. zeros;
+//                                 learnable-weight grads reduced in LDS, one atomic per arc/block
+//
+// This replaces gtn.intersect(emissions, A) + gtn.forward_score / viterbi_path + gtn.backward
+// (criterions/ctc.py:49-51,78-81; asg.py:111-113; stc.py:85-87; transducer.py:283,321-325) without
+// ever materialising the T*|A| composed lattice.  Memory/latency-bound DP: no MFMA by design.
+#include "device_common.h"
+
+namespace wfl {
+
+struct UttView {
+  int Q, A, E, K, nlev;
+  int a0, e0;
+  const int32_t *in_ptr, *out_ptr, *out_arc, *ein_ptr, *eout_ptr, *eout_arc;
+  const int32_t *arc_src, *arc_dst, *arc_slot, *arc_lab, *arc_wid, *arc_orig;
+  const int32_t *eps_src, *eps_dst, *eps_wid, *eps_orig, *labels, *lvl_ptr;
+  const float *arc_w, *eps_w, *start_w, *accept_w;
+  int64_t ab_base, xg_base;
+};
+
+__device__ __forceinline__ UttView make_view(const wfl_lattice_desc& d, const int32_t* ints, const float* floats,
+                                             int b, int T) {
+  UttView v;
+  const int bb = d.shared ? 0 : b;
+  const int s0 = ints[d.state_off + bb];
+  v.Q = ints[d.state_off + bb + 1] - s0;
+  v.a0 = ints[d.arc_off + bb];
+  v.A = ints[d.arc_off + bb + 1] - v.a0;
+  v.e0 = ints[d.eps_off + bb];
+  v.E = ints[d.eps_off + bb + 1] - v.e0;
+  const int l0 = ints[d.lab_off + bb];
+  v.K = ints[d.lab_off + bb + 1] - l0;
+  const int lv0 = ints[d.lvl_off + bb];
+  v.nlev = ints[d.lvl_off + bb + 1] - lv0 - 1;
+  v.in_ptr = ints + d.in_ptr + s0 + bb;
+  v.out_ptr = ints + d.out_ptr + s0 + bb;
+  v.ein_ptr = ints + d.ein_ptr + s0 + bb;
+  v.eout_ptr = ints + d.eout_ptr + s0 + bb;
+  v.out_arc = ints + d.out_arc + v.a0;
+  v.eout_arc = ints + d.eout_arc + v.e0;
+  v.arc_src = ints + d.arc_src + v.a0, v.arc_dst = ints + d.arc_dst + v.a0;
+  v.arc_slot = ints + d.arc_slot + v.a0, v.arc_lab = ints + d.arc_lab + v.a0;
+  v.arc_wid = ints + d.arc_wid + v.a0, v.arc_orig = ints + d.arc_orig + v.a0;
+  v.eps_src = ints + d.eps_src + v.e0, v.eps_dst = ints + d.eps_dst + v.e0;
+  v.eps_wid = ints + d.eps_wid + v.e0, v.eps_orig = ints + d.eps_orig + v.e0;
+  v.labels = ints + d.labels + l0;
+  v.lvl_ptr = ints + d.lvl_ptr + lv0;
+  v.arc_w = floats + d.arc_w + v.a0, v.eps_w = floats + d.eps_w + v.e0;
+  v.start_w = floats + d.start_w + s0, v.accept_w = floats + d.accept_w + s0;
+  v.ab_base = d.shared ? (int64_t)b * (T + 1) * v.Q : (int64_t)(T + 1) * s0;
+  v.xg_base = (int64_t)b * T * d.max_labels;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1: gather
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints,
+                                                      const float* __restrict__ x, int T, int C,
+                                                      float* __restrict__ xg, float* __restrict__ row_lse) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bb = d.shared ? 0 : b;
+  const int l0 = ints[d.lab_off + bb];
+  const int K = ints[d.lab_off + bb + 1] - l0;
+  const int32_t* labels = ints + d.labels + l0;
+  const int Kmax = d.max_labels;
+  for (int t = blockIdx.x * 4 + wave; t < T; t += gridDim.x * 4) {
+    const float* row = x + ((int64_t)b * T + t) * C;
+    float lse = 0.f;
+    if (row_lse) {  // fused log_softmax (ctc.py:107, transducer.py:186-187)
+      float m = WFL_NEG_INF;
+      for (int c = lane; c < C; c += 64) m = fmaxf(m, nan_to_neg(row[c]));
+      m = wave_max(m);
+      float s = 0.f;
+      if (m > WFL_NEG_INF)
+        for (int c = lane; c < C; c += 64) s += fast_exp(nan_to_neg(row[c]) - m);
+      s = wave_sum(s);
+      lse = (m > WFL_NEG_INF) ? m + fast_log(s) : WFL_NEG_INF;
+      if (lane == 0) row_lse[(int64_t)b * T + t] = lse;
+    }
+    float* dst = xg + ((int64_t)b * T + t) * Kmax;
+    for (int k = lane; k < K; k += 64) dst[k] = nan_to_neg(row[labels[k]]) - lse;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2: chains
+// ------------------------------------------------------------------------------------------------
+struct ChainLds {
+  int2* arcs;   // [A] {other_state | slot << 16, weight bits}
+  int2* eps;    // [E] {other_state, weight bits}
+  int* ptr;     // [Q+1]
+  int* eptr;    // [Q+1]
+  float* buf0;  // [Q]
+  float* buf1;  // [Q]
+  float* row0;  // [K]
+  float* row1;  // [K]
+  float* red;   // [64]
+  int* lvl;     // [nlev+1]
+};
+
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
+  return r;
+}
+
+// one relaxation of state q over its labelled arcs k0..k1 (values read from `from`)
+template <int SR>
+__device__ __forceinline__ void relax_labelled(const ChainLds& L, const float* from, const float* row, int k0, int k1,
+                                               float& val, int& arg) {
+  float m = WFL_NEG_INF;
+  int am = -1;
+  for (int k = k0; k < k1; ++k) {
+    const int2 a = L.arcs[k];
+    const float v = from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
+    if (v > m) m = v, am = k;
+  }
+  if (SR == WFL_SEMIRING_LOG) {
+    if (m > WFL_NEG_INF && k1 - k0 > 1) {
+      float s = 0.f;
+      for (int k = k0; k < k1; ++k) {
+        const int2 a = L.arcs[k];
+        const float v = from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
+        s += fast_exp(v - m);
+      }
+      m += fast_log(s);
+    }
+  }
+  val = m, arg = am;
+}
+
+template <int SR>
+__device__ __forceinline__ void relax_eps(const ChainLds& L, float* vals, int q, int k0, int k1, int A, float& val,
+                                          int& arg) {
+  // combine the current value of q with its epsilon arcs (other endpoints are already final)
+  float m = val;
+  int am = arg;
+  for (int k = k0; k < k1; ++k) {
+    const int2 a = L.eps[k];
+    const float v = vals[a.x] + __int_as_float(a.y);
+    if (v > m) m = v, am = A + k;
+  }
+  if (SR == WFL_SEMIRING_LOG) {
+    if (m > WFL_NEG_INF) {
+      float s = fast_exp(val - m);
+      for (int k = k0; k < k1; ++k) {
+        const int2 a = L.eps[k];
+        s += fast_exp(vals[a.x] + __int_as_float(a.y) - m);
+      }
+      m += fast_log(s);
+    }
+  }
+  val = m, arg = am;
+}
+
+template <int SR, int DIR>
+__device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const ChainLds& L, int T,
+                          const float* __restrict__ xg, const float* __restrict__ weights, float* __restrict__ out,
+                          int32_t* __restrict__ bptr, float* __restrict__ logz, int b) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int Q = u.Q, A = u.A, E = u.E, K = u.K, nlev = u.nlev, Kmax = d.max_labels;
+  // ---- stage the acceptor into LDS in this direction's CSR order
+  for (int k = tid; k < A; k += NT) {
+    const int a = DIR == 0 ? k : u.out_arc[k];
+    const int other = DIR == 0 ? u.arc_src[a] : u.arc_dst[a];
+    float w = u.arc_w[a];
+    const int wid = u.arc_wid[a];
+    if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+    L.arcs[k] = make_int2(other | (u.arc_slot[a] << 16), __float_as_int(w));
+  }
+  for (int k = tid; k < E; k += NT) {
+    const int e = DIR == 0 ? k : u.eout_arc[k];
+    const int other = DIR == 0 ? u.eps_src[e] : u.eps_dst[e];
+    float w = u.eps_w[e];
+    const int wid = u.eps_wid[e];
+    if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+    L.eps[k] = make_int2(other, __float_as_int(w));
+  }
+  for (int q = tid; q <= Q; q += NT) {
+    L.ptr[q] = DIR == 0 ? u.in_ptr[q] : u.out_ptr[q];
+    L.eptr[q] = DIR == 0 ? u.ein_ptr[q] : u.eout_ptr[q];
+  }
+  for (int l = tid; l <= nlev; l += NT) L.lvl[l] = u.lvl_ptr[l];
+
+  // epsilon closure of `vals` for this direction; `tslot` is the time slot for back-pointers
+  auto closure = [&](float* vals, int tslot) {
+    if (nlev <= 1) return;
+    for (int step = 1; step < nlev; ++step) {
+      const int lev = DIR == 0 ? step : nlev - 1 - step;
+      __syncthreads();
+      for (int q = L.lvl[lev] + tid; q < L.lvl[lev + 1]; q += NT) {
+        float v = vals[q];
+        int arg = -2;
+        relax_eps<SR>(L, vals, q, L.eptr[q], L.eptr[q + 1], A, v, arg);
+        vals[q] = v;
+        if (SR == WFL_SEMIRING_TROPICAL && DIR == 0 && arg != -2) bptr[u.ab_base + (int64_t)tslot * Q + q] = arg;
+      }
+    }
+  };
+
+  const int t_first = DIR == 0 ? 0 : T;  // time slot of the boundary vector
+  float* cur = (t_first & 1) ? L.buf1 : L.buf0;
+  __syncthreads();
+  for (int q = tid; q < Q; q += NT) {
+    cur[q] = DIR == 0 ? u.start_w[q] : u.accept_w[q];
+    if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + q] = -1;
+  }
+  closure(cur, t_first);
+  // first emissions row
+  const int t_row0 = DIR == 0 ? 0 : T - 1;
+  if (T > 0) {
+    float* r = (t_row0 & 1) ? L.row1 : L.row0;
+    for (int k = tid; k < K; k += NT) r[k] = xg[u.xg_base + (int64_t)t_row0 * Kmax + k];
+  }
+  __syncthreads();
+  for (int q = tid; q < Q; q += NT) out[u.ab_base + (int64_t)t_first * Q + q] = cur[q];
+
+  for (int step = 0; step < T; ++step) {
+    // forward: consume frame t = step, produce slot t+1.  backward: consume frame t = T-1-step, produce slot t.
+    const int t = DIR == 0 ? step : T - 1 - step;
+    const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
+    const float* from = (slot_from & 1) ? L.buf1 : L.buf0;
+    float* to = (slot_to & 1) ? L.buf1 : L.buf0;
+    const float* row = (t & 1) ? L.row1 : L.row0;
+    const int tn = DIR == 0 ? t + 1 : t - 1;  // next frame to be consumed
+    const bool has_next = DIR == 0 ? (tn < T) : (tn >= 0);
+    float pre[4];
+    if (has_next) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = tid + j * NT;
+        if (k < K) pre[j] = xg[u.xg_base + (int64_t)tn * Kmax + k];
+      }
+    }
+    for (int q = tid; q < Q; q += NT) {
+      float v;
+      int arg;
+      relax_labelled<SR>(L, from, row, L.ptr[q], L.ptr[q + 1], v, arg);
+      to[q] = v;
+      if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+    }
+    closure(to, slot_to);
+    if (has_next) {
+      float* rn = (tn & 1) ? L.row1 : L.row0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = tid + j * NT;
+        if (k < K) rn[k] = pre[j];
+      }
+    }
+    __syncthreads();
+    for (int q = tid; q < Q; q += NT) out[u.ab_base + (int64_t)slot_to * Q + q] = to[q];
+  }
+  if (DIR == 0 && logz) {
+    const float* fin = (T & 1) ? L.buf1 : L.buf0;
+    float m = WFL_NEG_INF;
+    for (int q = tid; q < Q; q += NT) m = fmaxf(m, fin[q] + u.accept_w[q]);
+    m = block_reduce_max(m, L.red);
+    float z = m;
+    if (SR == WFL_SEMIRING_LOG && m > WFL_NEG_INF) {
+      float s = 0.f;
+      for (int q = tid; q < Q; q += NT) s += fast_exp(fin[q] + u.accept_w[q] - m);
+      s = block_reduce_sum(s, L.red);
+      z = m + fast_log(s);
+    }
+    if (tid == 0) logz[b] = z;
+  }
+}
+
+template <int SR>
+__global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                             const float* __restrict__ xg, int T, const float* __restrict__ weights,
+                             float* __restrict__ alpha, float* __restrict__ beta, int32_t* __restrict__ bptr,
+                             float* __restrict__ logz) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const UttView u = make_view(d, ints, floats, b, T);
+  ChainLds L;
+  char* p = smem;
+  L.arcs = (int2*)p, p += (size_t)d.max_arcs * 8;
+  L.eps = (int2*)p, p += (size_t)d.max_eps * 8;
+  L.ptr = (int*)p, p += (size_t)(d.max_states + 1) * 4;
+  L.eptr = (int*)p, p += (size_t)(d.max_states + 1) * 4;
+  L.buf0 = (float*)p, p += (size_t)d.max_states * 4;
+  L.buf1 = (float*)p, p += (size_t)d.max_states * 4;
+  L.row0 = (float*)p, p += (size_t)d.max_labels * 4;
+  L.row1 = (float*)p, p += (size_t)d.max_labels * 4;
+  L.red = (float*)p, p += 64 * 4;
+  L.lvl = (int*)p;
+  if (dir == 0)
+    run_chain<SR, 0>(d, u, L, T, xg, weights, alpha, bptr, logz, b);
+  else
+    run_chain<SR, 1>(d, u, L, T, xg, weights, beta, nullptr, nullptr, b);
+}
+
+static size_t chain_lds_bytes(const wfl_lattice_desc& d) {
+  return (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 8 +
+         (size_t)d.max_labels * 8 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 + 64;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 3: posteriors -> gradient rows
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    grad_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                const float* __restrict__ xg, int T, int C, const float* __restrict__ weights,
+                const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
+                const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
+                int accumulate, float* __restrict__ dx, float* __restrict__ dW, int rows_per_block, int TS) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
+  const UttView u = make_view(d, ints, floats, b, T);
+  const int Q = u.Q, A = u.A, E = u.E, K = u.K, Kmax = d.max_labels;
+  float* rows = (float*)smem;                               // [TS][C] (absent when dx == NULL)
+  float* al = rows + (dx ? (size_t)TS * C : 0);             // [TS+1][Qmax]
+  float* be = al + (size_t)(TS + 1) * d.max_states;         // [TS+1][Qmax]
+  float* xr = be + (size_t)(TS + 1) * d.max_states;         // [TS][Kmax]
+  float* dwacc = xr + (size_t)TS * Kmax;                    // [A + E] (only if dW)
+  const float g0 = gout ? gout[0] : 1.f;
+  const float cf = coef ? coef[b] * g0 : g0;
+  const float z = logz[b];
+  const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
+  const int t_begin = blockIdx.x * rows_per_block;
+  const int t_end = min(T, t_begin + rows_per_block);
+  if (dW)
+    for (int a = tid; a < A + E; a += NT) dwacc[a] = 0.f;
+  for (int ts0 = t_begin; ts0 < t_end; ts0 += TS) {
+    const int nr = min(TS, t_end - ts0);
+    __syncthreads();
+    for (int i = tid; i < (nr + 1) * Q; i += NT) {
+      const int r = i / Q, q = i - r * Q;
+      al[r * d.max_states + q] = alpha[u.ab_base + (int64_t)(ts0 + r) * Q + q];
+      be[r * d.max_states + q] = beta[u.ab_base + (int64_t)(ts0 + r) * Q + q];
+    }
+    for (int i = tid; i < nr * K; i += NT) {
+      const int r = i / K, k = i - r * K;
+      xr[r * Kmax + k] = xg[u.xg_base + (int64_t)(ts0 + r) * Kmax + k];
+    }
+    float* gdst = dx ? dx + ((int64_t)b * T + ts0) * C : nullptr;
+    if (dx) {
+      if (accumulate)
+        for (int i = tid; i < nr * C; i += NT) rows[i] = gdst[i];
+      else
+        for (int i = tid; i < nr * C; i += NT) rows[i] = 0.f;
+    }
+    __syncthreads();
+    if (!dead) {
+      for (int i = tid; i < nr * A; i += NT) {
+        const int r = i / A, a = i - r * A;
+        float w = u.arc_w[a];
+        const int wid = u.arc_wid[a];
+        if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+        const float v = al[r * d.max_states + u.arc_src[a]] + xr[r * Kmax + u.arc_slot[a]] + w +
+                        be[(r + 1) * d.max_states + u.arc_dst[a]] - z;
+        if (v > WFL_NEG_INF) {
+          const float g = fast_exp(v);
+          if (dx) atomicAdd(&rows[r * C + u.arc_lab[a]], g * cf);
+          if (dW && wid >= 0) atomicAdd(&dwacc[a], g);
+        }
+      }
+      if (dW && E > 0) {
+        const int nslots = nr + ((ts0 + nr == T) ? 1 : 0);  // epsilon slots t = ts0 .. (T included once)
+        for (int i = tid; i < nslots * E; i += NT) {
+          const int r = i / E, e = i - r * E;
+          const int wid = u.eps_wid[e];
+          if (wid < 0) continue;
+          const float w = u.eps_w[e] + (weights ? nan_to_neg(weights[wid]) : 0.f);
+          const float v = al[r * d.max_states + u.eps_src[e]] + w + be[r * d.max_states + u.eps_dst[e]] - z;
+          if (v > WFL_NEG_INF) atomicAdd(&dwacc[A + e], fast_exp(v));
+        }
+      }
+    }
+    __syncthreads();
+    if (dx)
+      for (int i = tid; i < nr * C; i += NT) gdst[i] = rows[i];
+  }
+  if (dW) {
+    __syncthreads();
+    const float cw = (coef_w ? coef_w[b] : 1.f) * g0;
+    for (int a = tid; a < A + E; a += NT) {
+      const int wid = a < A ? u.arc_wid[a] : u.eps_wid[a - A];
+      const float g = dwacc[a];
+      if (wid >= 0 && g != 0.f) atomicAdd(&dW[wid], g * cw);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tropical back-trace: one thread per utterance
+// ------------------------------------------------------------------------------------------------
+__global__ void backtrace_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                                 const float* __restrict__ alpha, const int32_t* __restrict__ bptr, int T,
+                                 int32_t* __restrict__ path, int32_t* __restrict__ path_len, int path_stride) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.B) return;
+  const UttView u = make_view(d, ints, floats, b, T);
+  const int Q = u.Q, A = u.A;
+  int best = -1;
+  float bs = WFL_NEG_INF;
+  for (int q = 0; q < Q; ++q) {
+    const float v = alpha[u.ab_base + (int64_t)T * Q + q] + u.accept_w[q];
+    if (v > bs) bs = v, best = q;
+  }
+  int32_t* out = path + (int64_t)b * path_stride;
+  int n = 0;
+  if (best >= 0) {
+    int q = best, t = T;
+    while (n < path_stride) {
+      const int bp = bptr[u.ab_base + (int64_t)t * Q + q];
+      if (bp < 0) break;
+      if (bp < A) {
+        out[n++] = u.arc_orig[bp];
+        q = u.arc_src[bp];
+        --t;
+      } else {
+        out[n++] = u.eps_orig[bp - A];
+        q = u.eps_src[bp - A];
+      }
+    }
+    for (int i = 0, j = n - 1; i < j; ++i, --j) {
+      const int tmp = out[i];
+      out[i] = out[j], out[j] = tmp;
+    }
+  } else {
+    n = -1;  // no accepting path
+  }
+  path_len[b] = n;
+}
+
+__global__ void reduce_loss_kernel(const float* __restrict__ vals, const float* __restrict__ scale, int B, float sign,
+                                   int accumulate, float* __restrict__ out) {
+  __shared__ float red[64];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) s += sign * (scale ? scale[b] : 1.f) * vals[b];
+  s = block_reduce_sum(s, red);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s / (float)B;
+}
+
+}  // namespace wfl
+
+using namespace wfl;
+
+extern "C" {
+
+int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, int64_t* ab_elems) {
+  if (!d || T < 0) {
+    set_error("lattice_workspace: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  if (xg_elems) *xg_elems = (int64_t)d->B * T * d->max_labels;
+  if (ab_elems) *ab_elems = d->shared ? (int64_t)d->B * (T + 1) * d->max_states : (int64_t)(T + 1) * d->total_states;
+  return WFL_OK;
+}
+
+static int check_desc(const wfl_lattice_desc* d, const char* who) {
+  if (!d || d->B <= 0) {
+    set_error("%s: empty batch", who);
+    return WFL_ERR_INVALID;
+  }
+  if (d->max_states > 65535 || d->max_labels > 65535) {
+    set_error("%s: lattice too large (states=%d labels=%d; limit 65535)", who, d->max_states, d->max_labels);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  return WFL_OK;
+}
+
+int wfl_lattice_gather(const wfl_lattice_desc* d, const int32_t* ints, const float* x, int T, int C, float* xg,
+                       float* row_lse, void* stream) {
+  if (int rc = check_desc(d, "lattice_gather")) return rc;
+  if (T <= 0) return WFL_OK;
+  dim3 grid((unsigned)std::min(1024, (T + 3) / 4), (unsigned)d->B);
+  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d, ints, x, T, C, xg, row_lse);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T,
+                        const float* weights, int semiring, float* alpha, float* beta, int32_t* bptr, float* logz,
+                        void* stream) {
+  if (int rc = check_desc(d, "lattice_forward")) return rc;
+  if (!alpha || !logz) {
+    set_error("lattice_forward: alpha and logz are required");
+    return WFL_ERR_INVALID;
+  }
+  if (d->max_labels > 4 * 256) {
+    set_error("lattice_forward: %d distinct labels per utterance (limit 1024)", d->max_labels);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  const size_t lds = chain_lds_bytes(*d);
+  if (lds > (size_t)kLdsBytes) {
+    set_error("lattice_forward: acceptor needs %zu B of LDS (limit %d): %d arcs, %d states", lds, kLdsBytes,
+              d->max_arcs, d->max_states);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  const int nt = d->max_states <= 64 ? 64 : (d->max_states <= 128 ? 128 : 256);
+  if (semiring == WFL_SEMIRING_LOG) {
+    dim3 grid((unsigned)d->B, beta ? 2u : 1u);
+    auto k = chain_kernel<WFL_SEMIRING_LOG>;
+    if (lds > 48 * 1024)
+      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, weights, alpha, beta,
+                       (int32_t*)nullptr, logz);
+  } else if (semiring == WFL_SEMIRING_TROPICAL) {
+    if (!bptr) {
+      set_error("lattice_forward: tropical semiring needs a back-pointer buffer");
+      return WFL_ERR_INVALID;
+    }
+    dim3 grid((unsigned)d->B, 1u);
+    auto k = chain_kernel<WFL_SEMIRING_TROPICAL>;
+    if (lds > 48 * 1024)
+      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, weights, alpha,
+                       (float*)nullptr, bptr, logz);
+  } else {
+    set_error("lattice_forward: unknown semiring %d", semiring);
+    return WFL_ERR_INVALID;
+  }
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T, int C,
+                     const float* weights, const float* alpha, const float* beta, const float* logz, const float* coef,
+                     const float* coef_w, const float* gout, int accumulate, const float* x, const float* row_lse,
+                     float* dx, float* dW, void* stream) {
+  if (int rc = check_desc(d, "lattice_grad")) return rc;
+  if (row_lse || x) {
+    set_error("lattice_grad: fused log-softmax backward is not built yet");
+    return WFL_ERR_UNSUPPORTED;
+  }
+  if (!alpha || !beta || !logz || (!dx && !dW)) {
+    set_error("lattice_grad: alpha, beta, logz and at least one output are required");
+    return WFL_ERR_INVALID;
+  }
+  if (T <= 0) return WFL_OK;
+  // frames per LDS sub-tile: keep the tile under ~56 KiB so that two workgroups fit per CU
+  const size_t row_bytes = 4 * ((size_t)(dx ? C : 0) + 2 * (size_t)d->max_states + (size_t)d->max_labels);
+  const size_t fixed = 4 * (2 * (size_t)d->max_states + (dW ? (size_t)d->max_arcs + d->max_eps : 0)) + 64;
+  int TS = fixed + row_bytes < 56 * 1024 ? (int)((56 * 1024 - fixed) / row_bytes) : 1;
+  TS = std::max(1, std::min(TS, 32));
+  const size_t lds = fixed + row_bytes * TS;
+  if (lds > (size_t)kLdsBytes) {
+    set_error("lattice_grad: needs %zu B of LDS (limit %d)", lds, kLdsBytes);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  // enough workgroups to fill 256 CUs several times over, but few enough that the per-block
+  // learnable-weight atomics stay cheap
+  int blocks_t = std::max(1, std::min((T + TS - 1) / TS, (2048 + d->B - 1) / d->B));
+  int rows_per_block = (T + blocks_t - 1) / blocks_t;
+  rows_per_block = ((rows_per_block + TS - 1) / TS) * TS;
+  blocks_t = (T + rows_per_block - 1) / rows_per_block;
+  if (lds > 48 * 1024)
+    WFL_HIP_CHECK(hipFuncSetAttribute((const void*)grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(grad_kernel, dim3((unsigned)blocks_t, (unsigned)d->B), dim3(256), lds, (hipStream_t)stream, *d,
+                     ints, floats, xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, dx, dW,
+                     rows_per_block, TS);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_lattice_backtrace(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* alpha,
+                          const int32_t* bptr, int T, int32_t* path, int32_t* path_len, int path_stride, void* stream) {
+  if (int rc = check_desc(d, "lattice_backtrace")) return rc;
+  hipLaunchKernelGGL(backtrace_kernel, dim3((unsigned)((d->B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *d, ints,
+                     floats, alpha, bptr, T, path, path_len, path_stride);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_reduce_loss(const float* vals, const float* scale, int B, float sign, int accumulate, float* out, void* stream) {
+  if (B <= 0 || !vals || !out) {
+    set_error("reduce_loss: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, vals, scale, B, sign, accumulate, out);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,324 @@
+"""Device orchestration for the WFST loss engine: owns the torch-allocated buffers, the packed
+lattices and the calls into libwfl.so.  torch is plumbing here (device memory + current stream);
+all arithmetic happens in the HIP kernels behind the C ABI (include/wfl.h).
+"""
+import ctypes
+import itertools
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+_F32 = torch.float32
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "gtn_applications_amd: no ROCm GPU visible. The criteria run on HIP kernels only; "
+            "there is deliberately no CPU fallback."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def as_device_f32(t, device):
+    """float32, contiguous, on `device` (the reference reads raw float32 too: ctc.py:43-44)."""
+    if t.dtype != _F32:
+        raise TypeError(f"expected a float32 tensor, got {t.dtype}")
+    if t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
+def flatten_targets(targets):
+    """list of int sequences (or 1-D tensors) -> (flat int32, offsets int64, lengths list)."""
+    rows = [t.tolist() if hasattr(t, "tolist") else list(t) for t in targets]
+    lens = [len(r) for r in rows]
+    flat = np.fromiter(itertools.chain.from_iterable(rows), dtype=np.int32, count=sum(lens))
+    offsets = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    return flat, offsets, lens
+
+
+class LRU:
+    def __init__(self, capacity=32):
+        self.capacity = capacity
+        self.data = OrderedDict()
+
+    def get(self, key, make):
+        hit = self.data.get(key)
+        if hit is not None:
+            self.data.move_to_end(key)
+            return hit
+        val = make()
+        self.data[key] = val
+        if len(self.data) > self.capacity:
+            self.data.popitem(last=False)
+        return val
+
+
+class PackedLattice:
+    """B acceptors in the flat device format of `wfl_lattice_desc`, resident in HBM."""
+
+    def __init__(self, host_handle, device):
+        N.check_handle(host_handle)
+        try:
+            d = N.lib.wfl_lattice_host_desc(host_handle).contents
+            self.desc = N.LatticeDesc.from_buffer_copy(d)
+            ni, nf = int(d.int_words), int(d.float_words)
+            ints = np.ctypeslib.as_array(
+                ctypes.cast(N.lib.wfl_lattice_host_ints(host_handle), ctypes.POINTER(ctypes.c_int32)), shape=(max(ni, 1),)
+            )
+            floats = np.ctypeslib.as_array(
+                ctypes.cast(N.lib.wfl_lattice_host_floats(host_handle), ctypes.POINTER(ctypes.c_float)),
+                shape=(max(nf, 1),),
+            )
+            self.host_ints = ints[:ni].copy()
+            self.host_floats = floats[:nf].copy()
+        finally:
+            N.lib.wfl_lattice_host_free(host_handle)
+        self.device = device
+        self.ints = torch.from_numpy(self.host_ints).to(device) if device is not None else None
+        self.floats = torch.from_numpy(self.host_floats).to(device) if device is not None else None
+        self._desc_ref = ctypes.byref(self.desc)
+
+    # -- constructors ---------------------------------------------------------------------------
+    @classmethod
+    def from_graphs(cls, graphs, C, device, wids=None, B=None, shared=False):
+        n = len(graphs)
+        B = n if B is None else B
+        handles = (ctypes.c_void_p * n)(*[g._h for g in graphs])
+        keep = []
+        wid_ptrs = None
+        if wids is not None:
+            arr = []
+            for g, w in zip(graphs, wids):
+                if w is None:
+                    arr.append(None)
+                    continue
+                w = np.ascontiguousarray(w, dtype=np.int32)
+                if w.size != g.num_arcs():
+                    raise ValueError("weight-id array must have one entry per arc")
+                keep.append(w)
+                arr.append(w.ctypes.data)
+            wid_ptrs = (ctypes.c_void_p * n)(*arr)
+        h = N.lib.wfl_lattice_pack(handles, wid_ptrs, n, B, int(bool(shared)), int(C))
+        return cls(h, device)
+
+    @classmethod
+    def ctc(cls, flat, offsets, blank, C, device):
+        return cls(N.lib.wfl_lattice_pack_ctc(flat.ctypes.data, offsets.ctypes.data, len(offsets) - 1, blank, C), device)
+
+    @classmethod
+    def asg_force_align(cls, flat, offsets, C, device):
+        return cls(N.lib.wfl_lattice_pack_asg_fal(flat.ctypes.data, offsets.ctypes.data, len(offsets) - 1, C), device)
+
+    @classmethod
+    def stc(cls, flat, offsets, star_idx, log_prob, C, device):
+        return cls(
+            N.lib.wfl_lattice_pack_stc(flat.ctypes.data, offsets.ctypes.data, len(offsets) - 1, star_idx, log_prob, C),
+            device,
+        )
+
+    # -- host-side views (tests, Viterbi post-processing) -----------------------------------------
+    def field(self, name, count):
+        off = getattr(self.desc, name)
+        src = self.host_floats if name in ("arc_w", "eps_w", "start_w", "accept_w") else self.host_ints
+        return src[off:off + count]
+
+
+class LatticeState:
+    """Everything the backward pass needs from a forward pass of the lattice engine."""
+
+    __slots__ = ("pack", "T", "C", "xg", "alpha", "beta", "logz", "weights", "bptr")
+
+
+def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_LOG):
+    """forward_score(intersect(emissions, A_b)) for every b: returns a LatticeState whose `logz`
+    holds the per-utterance score (gtn call sites: ctc.py:50, asg.py:111, stc.py:86,
+    transducer.py:283,287)."""
+    B, T, C = x.shape
+    d = pack.desc
+    if d.B != B:
+        raise ValueError(f"lattice batch has {d.B} utterances, emissions have {B}")
+    n_xg, n_ab = ctypes.c_int64(), ctypes.c_int64()
+    N.check(N.lib.wfl_lattice_workspace(pack._desc_ref, T, ctypes.byref(n_xg), ctypes.byref(n_ab)))
+    dev = x.device
+    st = LatticeState()
+    st.pack, st.T, st.C, st.weights = pack, T, C, weights
+    st.xg = torch.empty(max(n_xg.value, 1), dtype=_F32, device=dev)
+    st.alpha = torch.empty(max(n_ab.value, 1), dtype=_F32, device=dev)
+    tropical = semiring == N.SEMIRING_TROPICAL
+    st.beta = torch.empty(max(n_ab.value, 1), dtype=_F32, device=dev) if (need_beta and not tropical) else None
+    st.bptr = torch.empty(max(n_ab.value, 1), dtype=torch.int32, device=dev) if tropical else None
+    st.logz = torch.empty(B, dtype=_F32, device=dev)
+    s = stream_ptr()
+    N.check(N.lib.wfl_lattice_gather(pack._desc_ref, ptr(pack.ints), ptr(x), T, C, ptr(st.xg), None, s))
+    N.check(
+        N.lib.wfl_lattice_forward(
+            pack._desc_ref, ptr(pack.ints), ptr(pack.floats), ptr(st.xg), T, ptr(weights), semiring,
+            ptr(st.alpha), ptr(st.beta), ptr(st.bptr), ptr(st.logz), s,
+        )
+    )
+    return st
+
+
+def lattice_grad(st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None):
+    """Posteriors of the lattice -> dense emission gradient rows (and learnable-weight grads)."""
+    p = st.pack
+    N.check(
+        N.lib.wfl_lattice_grad(
+            p._desc_ref, ptr(p.ints), ptr(p.floats), ptr(st.xg), st.T, st.C, ptr(st.weights), ptr(st.alpha),
+            ptr(st.beta), ptr(st.logz), ptr(coef), ptr(coef_w), ptr(gout), int(bool(accumulate)), None, None,
+            ptr(dx), ptr(dW), stream_ptr(),
+        )
+    )
+
+
+def lattice_viterbi(x, pack, weights=None):
+    """viterbi_path(intersect(emissions, A_b)): list of numpy arrays of the caller's arc ids along
+    the best path of each utterance (None if no accepting path), plus the best scores tensor."""
+    B, T, C = x.shape
+    st = lattice_forward(x, pack, weights, need_beta=False, semiring=N.SEMIRING_TROPICAL)
+    stride = (T + 1) * max(1, pack.desc.max_levels) + 1
+    path = torch.empty((B, stride), dtype=torch.int32, device=x.device)
+    plen = torch.empty(B, dtype=torch.int32, device=x.device)
+    N.check(
+        N.lib.wfl_lattice_backtrace(
+            pack._desc_ref, ptr(pack.ints), ptr(pack.floats), ptr(st.alpha), ptr(st.bptr), T, ptr(path), ptr(plen),
+            stride, stream_ptr(),
+        )
+    )
+    path, plen = path.cpu().numpy(), plen.cpu().numpy()
+    return [None if plen[b] < 0 else path[b, :plen[b]].copy() for b in range(B)], st.logz
+
+
+def reduce_loss(vals, scale, sign=1.0, out=None):
+    """out = (1/B) sum_b sign * scale[b] * vals[b]   (ctc.py:68-69 and twins), on the device."""
+    B = vals.numel()
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((), dtype=_F32, device=vals.device)
+    N.check(N.lib.wfl_reduce_loss(ptr(vals), ptr(scale), B, float(sign), int(accumulate), ptr(out), stream_ptr()))
+    return out
+
+
+# -------------------------------------------------------------------------------------------------
+# dense transitions
+# -------------------------------------------------------------------------------------------------
+class DenseState:
+    __slots__ = ("alpha", "beta", "logz", "B", "T", "C")
+
+
+def dense_forward(x, W, need_beta=True):
+    B, T, C = x.shape
+    st = DenseState()
+    st.B, st.T, st.C = B, T, C
+    st.alpha = torch.empty((B, T, C), dtype=_F32, device=x.device)
+    st.beta = torch.empty((B, T, C), dtype=_F32, device=x.device) if need_beta else None
+    st.logz = torch.empty(B, dtype=_F32, device=x.device)
+    N.check(
+        N.lib.wfl_dense_forward(ptr(x), ptr(W), B, T, C, N.SEMIRING_LOG, ptr(st.alpha), ptr(st.beta), None,
+                                ptr(st.logz), stream_ptr())
+    )
+    return st
+
+
+def dense_grad(x, W, st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None):
+    part = None
+    if dW is not None:
+        n = ctypes.c_int64()
+        N.check(N.lib.wfl_dense_workspace(st.B, st.T, st.C, ctypes.byref(n)))
+        part = torch.empty(n.value, dtype=_F32, device=x.device)
+    N.check(
+        N.lib.wfl_dense_grad(ptr(x), ptr(W), st.B, st.T, st.C, ptr(st.alpha), ptr(st.beta), ptr(st.logz), ptr(coef),
+                             ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(dx), ptr(dW), ptr(part), stream_ptr())
+    )
+
+
+def dense_viterbi(x, W):
+    B, T, C = x.shape
+    alpha = torch.empty((B, T, C), dtype=_F32, device=x.device)
+    bptr = torch.empty((B, T, C), dtype=torch.int32, device=x.device)
+    path = torch.empty((B, T), dtype=torch.int32, device=x.device)
+    N.check(N.lib.wfl_dense_viterbi(ptr(x), ptr(W), B, T, C, ptr(alpha), ptr(bptr), ptr(path), stream_ptr()))
+    return path
+
+
+# -------------------------------------------------------------------------------------------------
+# CTC fast path
+# -------------------------------------------------------------------------------------------------
+class CtcTargets:
+    """Device-resident targets of a batch (flat labels + offsets) and the per-utterance factors."""
+
+    __slots__ = ("flat", "offsets", "lens", "max_len", "B", "dev_flat", "dev_offsets", "cache")
+
+    def __init__(self, targets, device):
+        self.cache = {}  # derived device objects (scale factors, packed lattices), keyed by the caller
+        self.flat, self.offsets, self.lens = flatten_targets(targets)
+        self.B = len(self.lens)
+        self.max_len = max(self.lens) if self.lens else 0
+        self.dev_flat = torch.from_numpy(self.flat if self.flat.size else np.zeros(1, np.int32)).to(device)
+        self.dev_offsets = torch.from_numpy(self.offsets).to(device)
+
+
+def ctc_forward(x, tg, blank):
+    B, T, C = x.shape
+    n = ctypes.c_int64()
+    N.check(N.lib.wfl_ctc_workspace(B, T, C, tg.max_len, ctypes.byref(n)))
+    ws = torch.empty(n.value, dtype=_F32, device=x.device)
+    nll = torch.empty(B, dtype=_F32, device=x.device)
+    N.check(
+        N.lib.wfl_ctc_forward(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank, ptr(ws),
+                              ptr(nll), stream_ptr())
+    )
+    return ws, nll
+
+
+def ctc_grad(x, tg, blank, ws, nll, coef, gout, dx):
+    B, T, C = x.shape
+    N.check(
+        N.lib.wfl_ctc_grad(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank, ptr(ws),
+                           ptr(nll), ptr(coef), ptr(gout), ptr(dx), stream_ptr())
+    )
+
+
+def loss_factors(tg, reduction, norm_lens=None):
+    """Per-utterance loss scale and gradient coefficients, cached on the target object.
+
+    scale_b = 1/len_b for "mean" (1 if len_b == 0), 1 for "none" (ctc.py:53-58, asg.py:116-121,
+    transducer.py:302-305); returns (scale, +scale/B, -scale/B) as device tensors."""
+    key = ("factors", reduction, None if norm_lens is None else tuple(norm_lens))
+    hit = tg.cache.get(key)
+    if hit is None:
+        lens = tg.lens if norm_lens is None else norm_lens
+        if reduction == "mean":
+            sc = [1.0 / n if n > 0 else 1.0 for n in lens]
+        elif reduction == "none":
+            sc = [1.0] * len(lens)
+        else:
+            raise ValueError("invalid value for reduction '" + str(reduction) + "'")
+        scale = torch.tensor(sc, dtype=_F32, device=tg.dev_offsets.device)
+        hit = (scale, scale / len(lens), -scale / len(lens))
+        tg.cache[key] = hit
+    return hit
+
+
+_TARGET_CACHE = LRU(64)
+
+
+def targets_on_device(targets, device):
+    """Upload (once per distinct content) the targets of a batch; content-keyed LRU."""
+    rows = [t.tolist() if hasattr(t, "tolist") else list(t) for t in targets]
+    key = (tuple(map(tuple, rows)), device.index)
+    return _TARGET_CACHE.get(key, lambda: CtcTargets(rows, device))

@@ -1,0 +1,240 @@
+/*
+ * wfl.h -- C ABI of libwfl.so, the MI355X-native differentiable-WFST loss engine.
+ *
+ * This is the drop-in boundary for the hot path of facebookresearch/gtn_applications:
+ * the criterion layer (criterions/{ctc,asg,stc,transducer}.py) reaches its arithmetic through the
+ * pybind11 bindings of the external `gtn` C++ library.  Every entry point below names the gtn call
+ * sites (file:line under /root/reference) whose work it replaces.  There is no reference header to
+ * mirror (gtn is not vendored), so the ABI is designed for the path:
+ *
+ *   - plain C symbols, plain pointers and sizes, no C++/torch types, no exceptions;
+ *   - every function returns an int status (WFL_OK == 0); wfl_last_error() gives a thread-local
+ *     message for the last failure on the calling thread;
+ *   - device entry points take caller-owned DEVICE buffers and a hipStream_t (passed as void*),
+ *     enqueue work asynchronously and never synchronise, allocate or free device memory;
+ *   - host graph entry points (wfl_graph_*) work on opaque handles and never touch the GPU;
+ *   - no hidden global state: re-entrant from several host threads (autograd worker threads).
+ *
+ * Emissions are always float32 [B, T, C] row-major ("the emissions graph": gtn.linear_graph +
+ * set_weights, ctc.py:40-44, asg.py:96-100, stc.py:74-78, transducer.py:262-264 -- here the
+ * tensor IS the graph, nothing is materialised).
+ */
+#ifndef WFL_H_
+#define WFL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFL_OK 0
+#define WFL_ERR_INVALID 1     /* bad argument (shape, null pointer, label out of range ...) */
+#define WFL_ERR_UNSUPPORTED 2 /* valid request this build cannot serve (e.g. lattice too large for LDS) */
+#define WFL_ERR_RUNTIME 3     /* HIP runtime error (message has the hipError string) */
+
+#define WFL_EPSILON (-1) /* gtn.epsilon; pinned by tests/trans_backoff_test.txt:3 */
+
+#define WFL_SEMIRING_LOG 0      /* forward_score  */
+#define WFL_SEMIRING_TROPICAL 1 /* viterbi_score / viterbi_path */
+
+const char* wfl_last_error(void);
+int wfl_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host WFST library (replaces gtn.Graph and the graph functions the criteria call)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct wfl_graph wfl_graph; /* opaque */
+
+/* gtn.Graph(calc_grad) -- ctc.py:16, asg.py:57,73, stc.py:34, transducer.py:16,24,33,65,87,352 */
+wfl_graph* wfl_graph_new(void);
+void wfl_graph_free(wfl_graph* g);
+wfl_graph* wfl_graph_clone(const wfl_graph* g);
+/* Graph.add_node(start, accept) -> node id */
+int wfl_graph_add_node(wfl_graph* g, int start, int accept);
+/* Graph.add_arc(src, dst, ilabel, olabel, weight) -> arc id (insertion order), <0 on error */
+int wfl_graph_add_arc(wfl_graph* g, int src, int dst, int ilabel, int olabel, float weight);
+/* bulk forms of the two calls above (same ordering semantics) */
+int wfl_graph_add_nodes(wfl_graph* g, int n, const uint8_t* start, const uint8_t* accept);
+int wfl_graph_add_arcs(wfl_graph* g, int64_t n, const int32_t* src, const int32_t* dst,
+                       const int32_t* ilabel, const int32_t* olabel, const float* weight);
+int wfl_graph_num_nodes(const wfl_graph* g);
+int64_t wfl_graph_num_arcs(const wfl_graph* g);
+/* copy out: any pointer may be NULL.  start/accept: [num_nodes] bytes; arcs: [num_arcs] each */
+int wfl_graph_get(const wfl_graph* g, uint8_t* start, uint8_t* accept, int32_t* src, int32_t* dst,
+                  int32_t* ilabel, int32_t* olabel, float* weight);
+/* Graph.set_weights(ptr): num_arcs float32 in arc-id order (ctc.py:44, asg.py:66, transducer.py:256) */
+int wfl_graph_set_weights(wfl_graph* g, const float* w);
+/* Graph.arc_sort(olabel): orders each node's in/out arc lists by label; arc ids are unchanged */
+int wfl_graph_arc_sort(wfl_graph* g, int olabel);
+/* gtn.compose / gtn.intersect (ctc.py:50, asg.py:112-114, stc.py:86, transducer.py:216-287):
+ * first.olabel is matched with second.ilabel, epsilons advance alone, weights add, result trimmed.
+ * If prov_first / prov_second are non-NULL they receive malloc'ed arrays [num_arcs(result)] with
+ * the arc id each result arc came from (or -1); release them with wfl_free(). */
+wfl_graph* wfl_graph_compose(const wfl_graph* first, const wfl_graph* second, int32_t** prov_first,
+                             int32_t** prov_second);
+/* gtn.remove(g, label) (transducer.py:221,229,269,274); prov as above (arc id in g) */
+wfl_graph* wfl_graph_remove(const wfl_graph* g, int ilabel, int olabel, int32_t** prov);
+/* gtn.project_input / project_output (transducer.py:229,269,273) */
+wfl_graph* wfl_graph_project(const wfl_graph* g, int output);
+/* gtn.viterbi_path on a host graph (transducer.py:228: tiny path (x) token-graph compositions).
+ * Ties: maximum weight, then fewest non-epsilon output labels ("we take the shortest",
+ * transducer.py:226-227), then first found.  Result is a chain graph. */
+wfl_graph* wfl_graph_viterbi_path(const wfl_graph* g);
+/* gtn.equal / gtn.isomorphic (tests/transducer_test.py:47-55,376-418) */
+int wfl_graph_equal(const wfl_graph* a, const wfl_graph* b);
+int wfl_graph_isomorphic(const wfl_graph* a, const wfl_graph* b);
+/* gtn.loadtxt / savetxt text format (utils.py:261, build_transitions.py:221; format pinned by
+ * tests/trans_backoff_test.txt) */
+wfl_graph* wfl_graph_loadtxt(const char* path);
+int wfl_graph_savetxt(const wfl_graph* g, const char* path);
+void wfl_free(void* p);
+
+/* ------------------------------------------------------------------------------------------------
+ * Packed lattice batch: B acceptors A_b ready for the device kernels.
+ *
+ * Per utterance b (all indices local to b): Q_b states renumbered by epsilon level, A_b labelled
+ * arcs sorted by destination, E_b epsilon arcs sorted by destination.  One int32 blob and one
+ * float blob hold everything; `wfl_lattice_desc` says where each array starts (element offsets).
+ * wfl_lattice_pack*() build the blobs on the host; the caller uploads them (one H2D each) and
+ * passes device pointers + the descriptor (by value, host memory) to the kernels.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t B, max_states, max_arcs, max_eps, max_labels, max_levels;
+  int64_t total_states, total_arcs, total_eps, total_labels;
+  int32_t shared; /* 1: one graph shared by every utterance (transition graphs) */
+  /* element offsets into the int32 blob */
+  int64_t state_off; /* [B+1] first state of b in the per-state arrays                         */
+  int64_t arc_off;   /* [B+1] first labelled arc of b                                         */
+  int64_t eps_off;   /* [B+1] first epsilon arc of b                                          */
+  int64_t lab_off;   /* [B+1] first entry of b in `labels`                                    */
+  int64_t lvl_off;   /* [B+1] first entry of b in `lvl_ptr` (n_levels_b + 1 entries each)      */
+  int64_t in_ptr;    /* [total_states + B] CSR by destination over labelled arcs (local ids)   */
+  int64_t out_ptr;   /* [total_states + B] CSR by source                                      */
+  int64_t out_arc;   /* [total_arcs] labelled-arc ids in by-source order                      */
+  int64_t ein_ptr;   /* [total_states + B] CSR by destination over epsilon arcs               */
+  int64_t eout_ptr;  /* [total_states + B]                                                    */
+  int64_t eout_arc;  /* [total_eps]                                                           */
+  int64_t arc_src, arc_dst, arc_slot, arc_lab, arc_wid; /* [total_arcs] each                   */
+  int64_t eps_src, eps_dst, eps_wid;                    /* [total_eps] each                    */
+  int64_t labels;    /* [total_labels] distinct emission columns used by b (slot -> column)    */
+  int64_t lvl_ptr;   /* level boundaries (state ranges) for the epsilon closure                */
+  int64_t arc_orig;  /* [total_arcs] caller's arc id of each labelled arc (for Viterbi paths)  */
+  int64_t eps_orig;  /* [total_eps]                                                           */
+  int64_t int_words; /* size of the int32 blob                                                 */
+  /* element offsets into the float blob */
+  int64_t arc_w;     /* [total_arcs] constant weight (NaN is stored as -inf)    */
+  int64_t eps_w;     /* [total_eps]                                                           */
+  int64_t start_w;   /* [total_states] 0 for start states else -inf                           */
+  int64_t accept_w;  /* [total_states] 0 for accept states else -inf                          */
+  int64_t float_words;
+} wfl_lattice_desc;
+
+typedef struct wfl_lattice_host wfl_lattice_host; /* opaque: descriptor + host blobs */
+
+/* Generic packer: one graph per utterance (or a single shared graph, shared=1, n_graphs=1).
+ * graphs[b] must be an acceptor over emission columns: arc ilabel in [0,C) or WFL_EPSILON.
+ * wid[b] (may be NULL) gives, per arc of graphs[b], the index of the learnable weight it adds
+ * (-1: none).  Replaces what gtn.intersect(emissions, A_b) needs to know about A_b. */
+wfl_lattice_host* wfl_lattice_pack(const wfl_graph* const* graphs, const int32_t* const* wid,
+                                   int n_graphs, int B, int shared, int C);
+/* Bulk builders for the three fixed-topology label graphs (no per-arc host calls):
+ *   CTC  create_ctc_graph          ctc.py:15-29     targets flat + offsets[B+1], blank
+ *   ASG  create_force_align_graph  asg.py:72-81 composed with the transitions graph asg.py:54-69:
+ *        arcs carry wid into W[(C+1),C] row-major
+ *   STC  create_stc_graph          stc.py:23-64     star_idx, log(prob) on star arcs */
+wfl_lattice_host* wfl_lattice_pack_ctc(const int32_t* targets, const int64_t* offsets, int B, int blank, int C);
+wfl_lattice_host* wfl_lattice_pack_asg_fal(const int32_t* targets, const int64_t* offsets, int B, int C);
+wfl_lattice_host* wfl_lattice_pack_stc(const int32_t* targets, const int64_t* offsets, int B, int star_idx,
+                                       float log_prob, int C);
+void wfl_lattice_host_free(wfl_lattice_host* h);
+const wfl_lattice_desc* wfl_lattice_host_desc(const wfl_lattice_host* h);
+const int32_t* wfl_lattice_host_ints(const wfl_lattice_host* h);
+const float* wfl_lattice_host_floats(const wfl_lattice_host* h);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device kernels: generic lattice engine
+ *   loss_b-related quantity logZ_b = forward_score(intersect(emissions_b, A_b))
+ * ------------------------------------------------------------------------------------------------ */
+/* Bytes of scratch the calls below need: xg [B,T,max_labels], alpha/beta [sum_b (T+1) Q_b].
+ * Returned through the out pointers (element counts of float32). */
+int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, int64_t* ab_elems);
+
+/* Stage 1 (all CUs, coalesced): xg[b,t,k] = x[b,t,labels_b[k]].
+ * If row_lse != NULL it also receives logsumexp_c x[b,t,c] and xg is written log-softmaxed
+ * (fused torch.nn.functional.log_softmax of ctc.py:107 / transducer.py:186-187). */
+int wfl_lattice_gather(const wfl_lattice_desc* d, const int32_t* ints, const float* x, int T, int C,
+                       float* xg, float* row_lse, void* stream);
+
+/* Stage 2 (one workgroup per utterance and direction): time-synchronous forward (alpha) and, if
+ * beta != NULL, backward (beta) sweeps of gtn.forward_score (ctc.py:50, asg.py:111, stc.py:86,
+ * transducer.py:283,287) / viterbi_score.  weights = learnable weight vector indexed by arc_wid
+ * (may be NULL).  logz[B] receives the total score.  For WFL_SEMIRING_TROPICAL back-pointers are
+ * written to bptr [sum_b T*Q_b] (int32) instead of beta. */
+int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const float* floats,
+                        const float* xg, int T, const float* weights, int semiring, float* alpha,
+                        float* beta, int32_t* bptr, float* logz, void* stream);
+
+/* Stage 3 (all CUs): arc posteriors -> dense emission gradient rows and learnable-weight grads.
+ *   dx[b,t,c] (+)= coef[b] * gout * sum_{arcs with label c} gamma_t(arc)
+ *   dW[wid]    += coef_w[b] * gout * sum_t gamma_t(arc)           (atomic)
+ * (gtn.backward + emissions.grad(): ctc.py:78-81, asg.py:158-168, stc.py:113-116,
+ * transducer.py:321-325,333-336).  gout: device scalar (grad_output) or NULL for 1.
+ * accumulate != 0 adds into dx instead of overwriting.  If row_lse != NULL the gradient is taken
+ * through the fused log-softmax: dx = coef*(post - softmax(x) * sum_c post). */
+int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float* floats,
+                     const float* xg, int T, int C, const float* weights, const float* alpha,
+                     const float* beta, const float* logz, const float* coef, const float* coef_w,
+                     const float* gout, int accumulate, const float* x, const float* row_lse,
+                     float* dx, float* dW, void* stream);
+
+/* Tropical back-trace (gtn.viterbi_path, transducer.py:221): path[b, 0..len_b) = caller's arc
+ * ids along the best path, in order, including epsilon arcs; path_len[b] its length
+ * (<= T + max_levels*(T+1)); path stride = path_stride. */
+int wfl_lattice_backtrace(const wfl_lattice_desc* d, const int32_t* ints, const float* floats,
+                          const float* alpha, const int32_t* bptr, int T, int32_t* path,
+                          int32_t* path_len, int path_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device kernels: dense (fully connected) transitions -- ASG denominator / ASG Viterbi
+ *   W [(C+1), C] row-major: W[0,i] start->i, W[1+i, j] = score(prev j -> cur i)  (asg.py:54-69)
+ * ------------------------------------------------------------------------------------------------ */
+/* forward_score(intersect(emissions, transitions)) (asg.py:114): alpha, beta [B,T,C], logz [B] */
+int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int semiring,
+                      float* alpha, float* beta, int32_t* bptr, float* logz, void* stream);
+/* dx[b,t,i] (+)= coef[b]*gout*post_t(i);  dW += sum_b coef_w[b]*gout*transition posteriors.
+ * dW_partial: scratch [n_partials, (C+1)*C] (n from wfl_dense_workspace) reduced into dW. */
+int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems);
+int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const float* alpha,
+                   const float* beta, const float* logz, const float* coef, const float* coef_w,
+                   const float* gout, int accumulate, float* dx, float* dW, float* dW_partial,
+                   void* stream);
+/* viterbi_path(intersect(emissions, transitions)).labels_to_list() (asg.py:225-226):
+ * path [B,T] int32 emission labels.  Ties: lowest previous label, then lowest final label. */
+int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float* alpha,
+                      int32_t* bptr, int32_t* path, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device kernels: CTC fast path (create_ctc_graph + intersect + forward_score + backward of
+ * ctc.py:15-94 in one call; banded recursion with register-resident state, no lattice arrays).
+ *   targets: device int32 flat, offsets: device int64 [B+1]; requires max target length <= 127.
+ *   loss_b = -logZ_b is written to nll[B]; dx = coef[b]*gout*posteriors (dense rows).
+ * ------------------------------------------------------------------------------------------------ */
+int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems);
+int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
+                    const int64_t* offsets, int max_len, int blank, float* ws, float* nll,
+                    void* stream);
+int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
+                 int max_len, int blank, const float* ws, const float* nll, const float* coef,
+                 const float* gout, float* dx, void* stream);
+
+/* small device utilities used by the Python layer (kept here so the product never needs a
+ * torch op inside the timed path) */
+/* out[0] = (1/B) * sum_b sign * scale[b] * vals[b]  (+ out[0] if accumulate) */
+int wfl_reduce_loss(const float* vals, const float* scale, int B, float sign, int accumulate,
+                    float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFL_H_ */

@@ -1,0 +1,460 @@
+"""GPU parity tests (-m gpu): the HIP path (through the C ABI of libwfl.so) against the oracle on
+the same inputs, against the committed golden fixtures and the reference's literal vectors, and --
+at BASELINE sizes -- through size-independent properties.
+
+Tolerances: log-semiring losses and gradients 1e-4 relative (BASELINE.json north_star) with an
+absolute floor of 1e-5 on gradients; Viterbi / index outputs bit-exact.
+Nothing here reads /root/reference."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import criteria as OC  # noqa: E402
+from oracle import recurrences as OR  # noqa: E402
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def crit():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gtn_applications_amd.criterions import asg, ctc, stc, transducer
+
+    return dict(ctc=ctc, asg=asg, stc=stc, transducer=transducer)
+
+
+@pytest.fixture(scope="module")
+def lit(golden_dir):
+    with open(os.path.join(golden_dir, "reference_literals.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def cases(golden_dir):
+    with open(os.path.join(golden_dir, "criterion_cases.json")) as f:
+        return json.load(f)
+
+
+def dev(a, grad=False):
+    t = torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+    return t.requires_grad_(True) if grad else t
+
+
+def close(got, want, rtol=RTOL, atol=ATOL, msg=""):
+    got = got.detach().cpu().double().numpy() if hasattr(got, "detach") else np.asarray(got)
+    np.testing.assert_allclose(got, np.asarray(want), rtol=rtol, atol=atol, err_msg=msg)
+
+
+# =================================================================================================
+# CTC
+# =================================================================================================
+def test_native_library_is_the_one_loaded(crit):
+    from gtn_applications_amd import _native
+
+    assert os.path.basename(_native.LIB_PATH) == "libwfl.so" and _native.lib.wfl_version() >= 1
+
+
+def test_ctc_reference_literals(crit, lit):
+    ctc = crit["ctc"]
+    c = lit["ctc_trivial"]
+    lp = torch.log(dev(c["probs"]).view(1, c["T"], c["N"]))
+    assert ctc.CTCLoss(lp, c["labels"], c["blank"]).item() == pytest.approx(0.0, abs=1e-6)
+    c = lit["ctc_uniform"]
+    lp = torch.log_softmax(torch.zeros(1, c["T"], c["N"], device="cuda"), 2)
+    assert ctc.CTCLoss(lp, c["labels"], c["blank"]).item() == pytest.approx(-math.log(0.25 ** 3 * 5), abs=1e-5)
+    for key in ("ctc_5x6", "ctc_5x6_repeat"):
+        c = lit[key]
+        le = torch.log(dev(c["probs"]).view(1, c["T"], c["N"])).requires_grad_(True)
+        loss = ctc.CTCLoss(torch.log_softmax(le, 2), c["labels"], c["blank"])
+        assert loss.item() == pytest.approx(c["loss"], abs=5e-5)
+        loss.backward()
+        close(le.grad.view(-1), c["grad"], rtol=1e-4, atol=1e-6, msg=key)
+
+
+def test_ctc_golden_cases(crit, cases):
+    for name, c in cases.items():
+        if c["kind"] != "ctc":
+            continue
+        x = dev(c["inputs"], grad=True)
+        lp = torch.log_softmax(x, 2) if c["log_softmax"] else x
+        loss = crit["ctc"].CTCLoss(lp, c["targets"], c["blank"], c["reduction"])
+        loss.backward()
+        assert loss.item() == pytest.approx(c["loss"], rel=RTOL, abs=1e-5), name
+        close(x.grad, c["grad"], msg=name)
+
+
+@pytest.mark.parametrize("B,T,C,Lmax,reduction", [(4, 50, 11, 9, "none"), (3, 120, 30, 63, "mean"), (2, 33, 7, 0, "mean"),
+                                                  (5, 64, 20, 20, "mean")])
+def test_ctc_fast_path_vs_oracle(crit, B, T, C, Lmax, reduction):
+    rs = np.random.RandomState(B * 1000 + T)
+    x = rs.randn(B, T, C).astype(np.float32) * 2.0
+    targets = [rs.randint(0, C - 1, size=rs.randint(0, Lmax + 1)).tolist() for _ in range(B)]
+    targets[0] = rs.randint(0, C - 1, size=Lmax).tolist()
+    if Lmax >= 4:
+        targets[-1] = [1, 1, 1, 1][:Lmax]  # forced blanks between repeats
+    want_loss, want_dx = OR.ctc_loss_grad(x, targets, C - 1, reduction)
+    xt = dev(x, grad=True)
+    loss = crit["ctc"].CTCLoss(xt, targets, C - 1, reduction)
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss, rel=RTOL)
+    close(xt.grad, want_dx)
+
+
+def test_ctc_long_targets_use_lattice_engine_and_agree(crit):
+    rs = np.random.RandomState(7)
+    B, T, C = 3, 180, 12
+    x = rs.randn(B, T, C).astype(np.float32)
+    targets = [rs.randint(0, C - 1, size=n).tolist() for n in (70, 64, 5)]
+    want_loss, want_dx = OR.ctc_loss_grad(x, targets, C - 1, "mean")
+    xt = dev(x, grad=True)
+    loss = crit["ctc"].CTCLoss(xt, targets, C - 1, "mean")
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss, rel=RTOL)
+    close(xt.grad, want_dx)
+
+
+def test_ctc_lattice_engine_equals_fast_path(crit):
+    """the same batch through both HIP paths (generic lattice kernels vs CTC kernels)"""
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(11)
+    B, T, C = 6, 90, 17
+    x = dev(rs.randn(B, T, C))
+    targets = [rs.randint(0, C - 1, size=rs.randint(1, 30)).tolist() for _ in range(B)]
+    tg = E.CtcTargets(targets, x.device)
+    ws, nll = E.ctc_forward(x, tg, C - 1)
+    pack = E.PackedLattice.ctc(tg.flat, tg.offsets, C - 1, C, x.device)
+    st = E.lattice_forward(x, pack)
+    close(-st.logz, nll.cpu().double().numpy(), rtol=1e-5, atol=1e-4)
+    coef = torch.full((B,), -1.0 / B, device="cuda")
+    d1, d2 = torch.empty_like(x), torch.empty_like(x)
+    E.ctc_grad(x, tg, C - 1, ws, nll, coef, None, d1)
+    E.lattice_grad(st, coef, dx=d2)
+    close(d1, d2.cpu().double().numpy(), rtol=1e-3, atol=1e-6)
+
+
+def test_ctc_infeasible_and_minus_inf(crit):
+    ctc = crit["ctc"]
+    # T < L: no alignment -> loss +inf, zero gradient (documented policy)
+    x = dev(np.zeros((1, 2, 4)), grad=True)
+    loss = ctc.CTCLoss(x, [[0, 1, 2]], 3)
+    assert math.isinf(loss.item()) and loss.item() > 0
+    loss.backward()
+    assert float(x.grad.abs().max()) == 0.0
+    # -inf emissions on a forced path
+    lp = torch.log(dev([[[1.0, 0.0], [0.0, 1.0], [1.0, 0.0]]]))
+    assert ctc.CTCLoss(lp, [[0, 0]], 1).item() == pytest.approx(0.0, abs=1e-6)
+
+
+def test_ctc_errors_and_cpu_tensors(crit):
+    ctc = crit["ctc"]
+    with pytest.raises(ValueError):
+        ctc.CTCLoss(dev(np.zeros((1, 3, 3))), [[0]], 2, "sum")
+    with pytest.raises(TypeError):
+        ctc.CTCLoss(torch.zeros(1, 3, 3, dtype=torch.float64, device="cuda"), [[0]], 2)
+    x = torch.randn(2, 10, 5, requires_grad=True)  # CPU tensor in -> CPU loss / grad out (ctc.py:69,85)
+    loss = ctc.CTCLoss(x, [[0, 1], [2]], 4, "mean")
+    loss.backward()
+    assert loss.device.type == "cpu" and x.grad.device.type == "cpu"
+    want, dx = OR.ctc_loss_grad(x.detach().numpy(), [[0, 1], [2]], 4, "mean")
+    assert loss.item() == pytest.approx(want, rel=RTOL)
+    close(x.grad, dx)
+
+
+def test_ctc_module_and_greedy_viterbi(crit):
+    ctc = crit["ctc"]
+    rs = np.random.RandomState(3)
+    x = dev(rs.randn(3, 25, 6), grad=True)
+    targets = [torch.tensor([0, 1, 2]), torch.tensor([4, 4]), torch.tensor([3])]
+    loss = ctc.CTC(5, use_pt=False)(x, targets)
+    loss_pt = ctc.CTC(5, use_pt=True)(x.detach(), targets)
+    lp = OC.log_softmax(x.detach().cpu().double().numpy())
+    want, _ = OR.ctc_loss_grad(lp, [t.tolist() for t in targets], 5, "mean")
+    assert loss.item() == pytest.approx(want, rel=RTOL)
+    assert loss_pt.item() == pytest.approx(want, rel=1e-3)  # torch's own CTC: same quantity (ctc.py:109-121)
+    got = [p.tolist() for p in ctc.CTC(5, False).viterbi(x.detach())]
+    assert got == OC.ctc_greedy(x.detach().cpu().numpy(), 5)
+
+
+def test_ctc_baseline_shape_properties(crit):
+    """cfg2 of BASELINE.json (T=1000, C=100, B=128, L=44): oracle on two utterances, and for the
+    whole batch the properties: every gradient row sums to coef_b (posteriors of a frame sum to 1),
+    zero gradient outside the target's label set, loss == torch's independent CTC."""
+    ctc = crit["ctc"]
+    g = torch.Generator().manual_seed(0)
+    B, T, C, L = 128, 1000, 100, 44
+    x = torch.randn(B, T, C, generator=g).cuda().requires_grad_(True)
+    tgt = torch.randint(C - 2, (B, L), generator=g)
+    targets = tgt.tolist()
+    loss = ctc.CTCLoss(x, targets, C - 1)
+    loss.backward()
+    dx = x.grad
+    rows = dx.sum(dim=2)
+    assert torch.allclose(rows, torch.full_like(rows, -1.0 / B), rtol=2e-4, atol=1e-7)
+    mask = torch.ones(B, C, dtype=torch.bool)
+    mask[torch.arange(B).unsqueeze(1), tgt] = False
+    mask[:, C - 1] = False
+    assert float(dx.abs().amax(dim=1).cpu()[mask].max()) == 0.0
+    assert float(dx.max()) <= 0.0
+    per_utt = torch.nn.functional.ctc_loss(
+        x.detach().permute(1, 0, 2), tgt.cuda(), [T] * B, [L] * B, blank=C - 1, reduction="none")
+    assert loss.item() == pytest.approx(per_utt.mean().item(), rel=1e-4)
+    xs = x.detach()[:2].cpu().double().numpy()
+    want_loss, want_dx = OR.ctc_loss_grad(xs, targets[:2], C - 1)
+    sub = ctc.CTCLoss(x.detach()[:2].clone().requires_grad_(True), targets[:2], C - 1)
+    assert sub.item() == pytest.approx(want_loss, rel=RTOL)
+    # gradient of utterances 0,1 inside the B=128 batch differs from the B=2 one only by the 1/B factor
+    close(dx[:2] * (B / 2.0), want_dx, rtol=1e-3, atol=2e-6)
+
+
+# =================================================================================================
+# ASG
+# =================================================================================================
+def test_asg_reference_literals(crit, lit):
+    asg = crit["asg"]
+    c = lit["asg_3x5x6"]
+    x = dev(c["emissions"], grad=True)
+    W = torch.zeros(c["N"] + 1, c["N"], device="cuda", requires_grad=True)
+    loss = asg.ASGLoss(x, W, c["labels"])
+    assert loss.item() == pytest.approx(c["loss"], abs=5e-5)
+    loss.backward()
+    close(x.grad * c["B"], c["grad_times_B"], rtol=1e-3, atol=2e-4)
+    close(W.grad[1:] * c["B"], c["trans_grad_rows1_times_B"], rtol=1e-3, atol=2e-4)
+    c = lit["asg_viterbi"]
+    n = c["N"] + c["num_replabels"]
+    crit_asg = asg.ASG(c["N"], c["num_replabels"], c["use_garbage"]).cuda()
+    with torch.no_grad():
+        crit_asg.transitions.copy_(dev(c["transitions"]).view(n + 1, n))
+    path = crit_asg.viterbi(dev(c["inputs"]).view(1, c["T"], n))[0].tolist()
+    assert path == c["path"]
+
+
+def test_asg_golden_cases(crit, cases):
+    asg = crit["asg"]
+    for name, c in cases.items():
+        if c["kind"] == "asg":
+            x, W = dev(c["inputs"], grad=True), dev(c["transitions"], grad=True)
+            loss = asg.ASGLoss(x, W, c["targets"], c["reduction"])
+            loss.backward()
+            assert loss.item() == pytest.approx(c["loss"], rel=RTOL, abs=1e-5), name
+            close(x.grad, c["grad"], msg=name)
+            close(W.grad, c["trans_grad"], msg=name)
+        elif c["kind"] == "asg_module":
+            m = asg.ASG(c["num_classes"], c["num_replabels"], c["use_garbage"]).cuda()
+            with torch.no_grad():
+                m.transitions.copy_(dev(c["transitions"]))
+            x = dev(c["inputs"], grad=True)
+            loss = m(x, [torch.tensor(t) for t in c["targets"]])
+            loss.backward()
+            assert loss.item() == pytest.approx(c["loss"], rel=RTOL, abs=1e-5)
+            close(x.grad, c["grad"])
+            close(m.transitions.grad, c["trans_grad"])
+            assert [p.tolist() for p in m.viterbi(x.detach())] == c["viterbi"]
+
+
+@pytest.mark.parametrize("B,T,C,reduction", [(3, 40, 9, "none"), (2, 75, 28, "mean"), (4, 30, 100, "mean")])
+def test_asg_vs_oracle(crit, B, T, C, reduction):
+    rs = np.random.RandomState(C)
+    x = rs.randn(B, T, C).astype(np.float32)
+    W = (0.5 * rs.randn(C + 1, C)).astype(np.float32)
+    targets = [rs.randint(0, C, size=rs.randint(1, min(T, 20))).tolist() for _ in range(B)]
+    want = OR.asg_loss_grad(x, W, targets, reduction)
+    xt, Wt = dev(x, grad=True), dev(W, grad=True)
+    loss = crit["asg"].ASGLoss(xt, Wt, targets, reduction)
+    loss.backward()
+    assert loss.item() == pytest.approx(want[0], rel=RTOL)
+    close(xt.grad, want[1])
+    close(Wt.grad, want[2], atol=2e-5)
+    # only one of the two gradients requested (asg.py:151-154)
+    x2, W2 = dev(x, grad=True), dev(W)
+    crit["asg"].ASGLoss(x2, W2, targets, reduction).backward()
+    close(x2.grad, want[1])
+    x3, W3 = dev(x), dev(W, grad=True)
+    crit["asg"].ASGLoss(x3, W3, targets, reduction).backward()
+    close(W3.grad, want[2], atol=2e-5)
+
+
+def test_asg_viterbi_vs_oracle_integer_scores(crit):
+    rs = np.random.RandomState(2)
+    B, T, C = 4, 30, 7
+    x = rs.randint(-6, 7, size=(B, T, C)).astype(np.float32)  # exactly representable: ties are real ties
+    W = rs.randint(-3, 4, size=(C + 1, C)).astype(np.float32)
+    from gtn_applications_amd import engine as E
+
+    got = E.dense_viterbi(dev(x), dev(W)).cpu().tolist()
+    assert got == [OR.dense_viterbi(x[b], W) for b in range(B)]
+
+
+# =================================================================================================
+# STC
+# =================================================================================================
+def test_stc_reference_literals(crit, lit):
+    stc = crit["stc"]
+    c = lit["stc_trivial"]
+    lp = torch.log(dev(c["probs_TBN"]).view(c["T"], 1, c["N"]))
+    assert stc.STC(0, 1, 1, 1)(lp, c["labels"]).item() == pytest.approx(0.0, abs=1e-6)
+    c = lit["stc_uniform"]
+    lp = torch.log_softmax(torch.zeros(c["T"], 1, c["N"], device="cuda"), 2)
+    assert stc.STC(0, 1, 1, 1, "none")(lp, c["labels"]).item() == pytest.approx(c["loss"], abs=1e-5)
+
+
+def test_stc_golden_cases(crit, cases):
+    stc = crit["stc"]
+    for name, c in cases.items():
+        if c["kind"] != "stc":
+            continue
+        x = dev(c["inputs"], grad=True)
+        m = stc.STC(0, c["p0"], c["plast"], c["thalf"], c["reduction"])
+        m.eval()
+        loss = m(torch.log_softmax(x, 2), c["targets"])
+        loss.backward()
+        assert loss.item() == pytest.approx(c["loss"], rel=RTOL, abs=1e-5), name
+        close(x.grad, c["grad"], msg=name)
+
+
+def test_stc_function_vs_oracle(crit):
+    rs = np.random.RandomState(9)
+    B, T, Cp = 3, 40, 6  # Cp selected columns -> Cstar = 2*Cp
+    x = rs.randn(B, T, 2 * Cp).astype(np.float32)
+    targets = [rs.randint(1, Cp, size=n).tolist() for n in (5, 1, 8)]
+    want_loss, want_dx = OC.stc_function(x, targets, 0.3, "mean")
+    xt = dev(x, grad=True)
+    loss = crit["stc"].STCLoss(xt, targets, 0.3, "mean")
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss, rel=RTOL)
+    close(xt.grad, want_dx)
+
+
+# =================================================================================================
+# Transducer
+# =================================================================================================
+def _transducer_from_case(tr, c):
+    toks = [tuple(t) if isinstance(t, list) else t for t in c["tokens"]]
+    g2i = {(int(k) if c["grapheme_keys_are_int"] else k): v for k, v in c["graphemes_to_idx"].items()}
+    return tr.Transducer(toks, g2i, **c["kwargs"]).cuda()
+
+
+def test_transducer_reference_literals(crit, lit):
+    tr = crit["transducer"]
+    c = lit["transducer_trivial"]
+    lp = torch.log(dev(c["probs"]).view(1, c["T"], c["N"]))
+    for k in c["cases"]:
+        m = tr.Transducer(k["tokens"], k["g2i"], blank=k["blank"], allow_repeats=k["allow_repeats"])
+        assert m(lp, k["labels"]).item() == pytest.approx(0.0, abs=1e-6)
+    c = lit["ctc_uniform"]
+    m = tr.Transducer(["a", "b", "c"], {"a": 0, "b": 1, "c": 2}, blank="optional")
+    lp = torch.log_softmax(torch.zeros(1, c["T"], c["N"], device="cuda"), 2)
+    assert m(lp, c["labels"]).item() == pytest.approx(-math.log(0.25 ** 3 * 5), abs=1e-5)
+    for key, rep in (("ctc_5x6", True), ("ctc_5x6_repeat", False)):
+        c = lit[key]
+        le = torch.log(dev(c["probs"]).view(1, c["T"], c["N"])).requires_grad_(True)
+        m = tr.Transducer(["a", "b", "c", "d", "e"], {k: i for i, k in enumerate("abcde")}, blank="optional",
+                          allow_repeats=rep)
+        loss = m(le, c["labels"])
+        assert loss.item() == pytest.approx(c["loss"], abs=5e-5)
+        loss.backward()
+        close(le.grad.view(-1), c["grad"], rtol=1e-4, atol=1e-6, msg=key)
+    v = lit["transducer_viterbi"]
+    em = torch.stack([dev(v["emissions1"]).view(v["T"], v["N"]), dev(v["emissions2"]).view(v["T"], v["N"])])
+    toks = v["no_blank"]["tokens"]
+    m = tr.Transducer(toks, {t: i for i, t in enumerate(toks)}, blank="none")
+    assert [p.tolist() for p in m.viterbi(em)] == v["no_blank"]["labels"]
+    toks = v["blank_norepeat"]["tokens"]
+    m = tr.Transducer(toks, {t: i for i, t in enumerate(toks)}, blank="optional", allow_repeats=False)
+    assert [p.tolist() for p in m.viterbi(em)] == v["blank_norepeat"]["labels"]
+
+
+def test_transducer_equals_ctc(crit, lit):
+    """tests/transducer_test.py:275-316: CTC == Transducer(blank optional, no repeats)."""
+    c = lit["ctc_compare_targets"]
+    T, N, B, tgt = c["T"], c["N"], c["B"], c["targets"]
+    x = torch.randn(B, T, N, generator=torch.Generator().manual_seed(4)).cuda().requires_grad_(True)
+    toks = [(t,) for t in range(N - 1)]
+    for reduction in ("none", "mean"):
+        m = crit["transducer"].Transducer(toks, {t: t for t in range(N - 1)}, blank="optional", allow_repeats=False,
+                                          reduction=reduction)
+        a = crit["ctc"].CTCLoss(torch.log_softmax(x, 2), tgt, N - 1, reduction)
+        a.backward()
+        ga, x.grad = x.grad, None
+        b = m(x, tgt)
+        b.backward()
+        gb, x.grad = x.grad, None
+        assert a.item() == pytest.approx(b.item(), abs=1e-4)
+        assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-5)
+
+
+def test_transducer_golden_cases(crit, cases):
+    for name, c in cases.items():
+        if c["kind"] != "transducer":
+            continue
+        m = _transducer_from_case(crit["transducer"], c)
+        if "transition_params" in c:
+            with torch.no_grad():
+                m.transition_params.copy_(dev(c["transition_params"]))
+        x = dev(c["inputs"], grad=True)
+        loss = m(x, c["targets"])
+        loss.backward()
+        assert loss.item() == pytest.approx(c["loss"], rel=RTOL, abs=1e-5), name
+        close(x.grad, c["grad"], msg=name)
+        if "transition_grad" in c:
+            close(m.transition_params.grad, c["transition_grad"], atol=2e-5, msg=name)
+        assert [p.tolist() for p in m.viterbi(x.detach())] == c["viterbi"], name
+
+
+def test_transducer_asg_transitions(crit, lit):
+    """tests/transducer_test.py:420-532: ASG == Transducer(transitions = ASG graph)."""
+    c = lit["asg_3x5x6"]
+    N = c["N"]
+    trans = crit["asg"].ASGLossFunction.create_transitions_graph(torch.zeros(N + 1, N))
+    m = crit["transducer"].Transducer([(n,) for n in range(N)], {n: n for n in range(N)}, transitions=trans).cuda()
+    x = dev(c["emissions"], grad=True)
+    loss = m(x, c["labels"])
+    assert loss.item() == pytest.approx(c["loss"], abs=5e-5)
+    loss.backward()
+    close(x.grad * c["B"], c["grad_times_B"], rtol=1e-3, atol=2e-4)
+    close(m.transition_params.grad[N:].view(N, N) * c["B"], c["trans_grad_rows1_times_B"], rtol=1e-2, atol=2e-4)
+    v = lit["asg_viterbi_transducer"]
+    trans = crit["asg"].ASGLossFunction.create_transitions_graph(torch.zeros(v["N"] + 1, v["N"]))
+    m = crit["transducer"].Transducer([(n,) for n in range(v["N"])], {n: n for n in range(v["N"])},
+                                      transitions=trans).cuda()
+    with torch.no_grad():
+        m.transition_params.copy_(dev(v["transitions"]))
+    assert m.viterbi(dev(v["inputs"]).view(1, v["T"], v["N"]))[0].tolist() == v["path"]
+
+
+def test_transducer_backoff_transitions(crit, lit, tmp_path):
+    """tests/transducer_test.py:534-566: epsilon (back-off) arcs; analytic vs oracle gradient and
+    vs central differences."""
+    from gtn_applications_amd import graph as G
+    from oracle import minigtn as MG
+
+    c = lit["backoff_transitions"]
+    lines = [" ".join(map(str, c["start"])), " ".join(map(str, c["accept"]))] + [" ".join(map(str, a)) for a in c["arcs"]]
+    path = tmp_path / "backoff.txt"
+    path.write_text("\n".join(lines) + "\n")
+    N = c["N"]
+    toks = [(n,) for n in range(N)]
+    m = crit["transducer"].Transducer(toks, {n: n for n in range(N)}, blank="optional", allow_repeats=False,
+                                      transitions=G.loadtxt(path)).cuda()
+    og = MG.loadtxt(str(path))
+    oracle = OC.TransducerOracle(toks, {n: n for n in range(N)}, blank="optional", allow_repeats=False, transitions=og)
+    rs = np.random.RandomState(0)
+    x = rs.randn(1, c["T"], N + 1).astype(np.float32)
+    params = (0.3 * rs.randn(len(c["arcs"]))).astype(np.float32)
+    oracle.transition_params = params.astype(np.float64)
+    want_loss, want_dx, want_dp = oracle.loss(x, c["labels"])
+    with torch.no_grad():
+        m.transition_params.copy_(dev(params))
+    xt = dev(x, grad=True)
+    loss = m(xt, c["labels"])
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss, rel=RTOL)
+    close(xt.grad, want_dx)
+    close(m.transition_params.grad, want_dp, atol=2e-5)

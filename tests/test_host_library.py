@@ -1,0 +1,245 @@
+"""CPU tests (-m "not gpu") of the native host side: libwfl.so loads and exports every symbol that
+include/wfl.h declares, the graph builders reproduce the reference's builders arc by arc, and the
+C++ graph algebra (compose / remove / project / viterbi_path / pack) agrees with the oracle.
+No device compute is called here."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gtn_applications_amd import _native as N
+from gtn_applications_amd import engine as E
+from gtn_applications_amd import graph as G
+from gtn_applications_amd.criterions import asg, ctc, stc, transducer as TR
+from oracle import criteria as OC
+from oracle import minigtn as MG
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "wfl.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    declared = set(re.findall(r"\b(wfl_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations parsed"
+    assert declared == set(N.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(N.lib, name), name
+    assert N.lib.wfl_version() >= 1
+
+
+def test_desc_struct_matches_header_layout():
+    # one known field pattern: pack a tiny batch and read sizes back through the ctypes mirror
+    flat = np.array([1, 2, 2], np.int32)
+    off = np.array([0, 2, 3], np.int64)
+    p = E.PackedLattice.ctc(flat, off, 0, 4, None)
+    d = p.desc
+    assert (d.B, d.max_states, d.total_states, d.shared) == (2, 5, 8, 0)
+    assert d.total_arcs == (5 + 4 + 1) + (3 + 2 + 0)
+    assert d.float_words >= d.total_arcs + 2 * d.total_states
+    assert list(p.field("state_off", 3)) == [0, 5, 8]
+    assert list(p.field("labels", d.total_labels)) == [0, 1, 2, 0, 2]
+
+
+def as_oracle(g):
+    a = g.arrays()
+    o = MG.Graph(False)
+    for s, c in zip(a["start"], a["accept"]):
+        o.add_node(bool(s), bool(c))
+    for k in range(len(a["src"])):
+        o.add_arc(int(a["src"][k]), int(a["dst"][k]), int(a["ilabel"][k]), int(a["olabel"][k]), float(a["weight"][k]))
+    return o
+
+
+def dump(g):
+    a = g.arrays()
+    return dict(
+        num_nodes=len(a["start"]), start=np.nonzero(a["start"])[0].tolist(), accept=np.nonzero(a["accept"])[0].tolist(),
+        arcs=[[int(a["src"][k]), int(a["dst"][k]), int(a["ilabel"][k]), int(a["olabel"][k]), float(a["weight"][k])]
+              for k in range(len(a["src"]))],
+    )
+
+
+def test_builders_match_reference(golden_dir):
+    import torch
+
+    with open(os.path.join(golden_dir, "builder_graphs.json")) as f:
+        want = json.load(f)
+    wp, g2i = ["a", "b", "ab", "ba", "aba"], {"a": 0, "b": 1}
+    mine = {
+        "ctc_graph_0_1_1": ctc.CTCLossFunction.create_ctc_graph([0, 1, 1], 2),
+        "ctc_graph_empty": ctc.CTCLossFunction.create_ctc_graph([], 2),
+        "asg_fal_2_2_1": asg.ASGLossFunction.create_force_align_graph([2, 2, 1]),
+        "asg_transitions_c3": asg.ASGLossFunction.create_transitions_graph(torch.arange(12.0).view(4, 3)),
+        "stc_graph_1_2": stc.STCLossFunction.create_stc_graph([1, 2], 4, 0.5),
+        "token_none_rep": TR.make_token_graph(["a", "b", "c"], "none", True),
+        "token_opt_rep": TR.make_token_graph(["a", "b", "c"], "optional", True),
+        "token_opt_norep": TR.make_token_graph(["a", "b", "c"], "optional", False),
+        "token_forced_rep": TR.make_token_graph(["a", "b", "c"], "forced", True),
+        "lexicon_wp": TR.make_lexicon_graph(wp, g2i),
+        "chain_3_1_2": TR.make_chain_graph([3, 1, 2]),
+        "ngram1_3": TR.make_transitions_graph(1, 3),
+        "ngram2_3": TR.make_transitions_graph(2, 3),
+        "ngram3_2": TR.make_transitions_graph(3, 2),
+        "kernel_0_0_opt": TR.make_kernel_graph([0, 0], 2, True),
+        "kernel_0_1_opt": TR.make_kernel_graph([0, 1], 2, True),
+        "kernel_0_1_noopt_spike": TR.make_kernel_graph([0, 1], 2, False, spike=True),
+    }
+    assert set(mine) == set(want)
+    for name, g in mine.items():
+        got = dump(g)
+        assert got["num_nodes"] == want[name]["num_nodes"], name
+        assert got["start"] == want[name]["start"] and got["accept"] == want[name]["accept"], name
+        assert [a[:4] for a in got["arcs"]] == [a[:4] for a in want[name]["arcs"]], name
+        np.testing.assert_allclose([a[4] for a in got["arcs"]], [a[4] for a in want[name]["arcs"]], atol=1e-6)
+
+
+def test_token_graph_errors():
+    with pytest.raises(ValueError):
+        TR.make_token_graph(["a"], "none", False)
+    with pytest.raises(ValueError):
+        TR.Transducer(["a"], {"a": 0}, blank="sometimes")
+    with pytest.raises(ValueError):
+        TR.Transducer(["a"], {"a": 0}, ngram=1, transitions=G.Graph())
+
+
+def score(g, x):
+    """oracle forward score of emissions o g for a host graph of either library"""
+    og = g if isinstance(g, MG.Graph) else as_oracle(g)
+    return MG.forward_score(MG.intersect(OC.emissions_graph(x, False), MG.project_input(og))).item()
+
+
+@pytest.mark.parametrize("blank,repeats", [("none", True), ("optional", True), ("optional", False), ("forced", True)])
+def test_alignment_graphs_equivalent_to_oracle(blank, repeats):
+    wp, g2i = ["a", "b", "ab", "ba", "aba"], {"a": 0, "b": 1}
+    tokens = TR.make_token_graph(wp, blank, repeats)
+    lexicon = TR.make_lexicon_graph(wp, g2i)
+    oracle = OC.TransducerOracle(wp, g2i, blank=blank, allow_repeats=repeats)
+    rs = np.random.RandomState(1)
+    C = len(wp) + int(blank != "none")
+    for target in ([0, 1, 0], [1, 1, 0, 0], [0], [1, 0, 1, 0, 1]):
+        mine, _ = TR._alignment_graph(target, tokens, lexicon, None)
+        ref = oracle.alignment_graph(target)
+        assert mine.num_arcs() == ref.num_arcs() and mine.num_nodes() == ref.num_nodes()
+        assert MG.isomorphic(as_oracle(mine), MG.project_input(ref))
+        x = rs.randn(7, C)
+        assert score(mine, x) == pytest.approx(score(ref, x), rel=1e-6, abs=1e-6)
+
+
+def test_compose_with_transitions_and_provenance():
+    toks = [(i,) for i in range(4)]
+    g2i = {i: i for i in range(4)}
+    tokens = TR.make_token_graph(toks, "optional", False)
+    lexicon = TR.make_lexicon_graph(toks, g2i)
+    trans = TR.make_transitions_graph(2, 5)
+    trans.arc_sort()
+    ali, wid = TR._alignment_graph([0, 1, 2], tokens, lexicon, trans)
+    a = ali.arrays()
+    t = trans.arrays()
+    assert wid.shape[0] == ali.num_arcs() and wid.min() >= 0
+    # each composed arc carries the input label of the transition arc it came from
+    np.testing.assert_array_equal(a["ilabel"], t["ilabel"][wid])
+    oracle = OC.TransducerOracle(toks, g2i, ngram=2, blank="optional", allow_repeats=False)
+    ref = MG.intersect(oracle.transitions, oracle.alignment_graph([0, 1, 2]))
+    assert ali.num_arcs() == ref.num_arcs() and ali.num_nodes() == ref.num_nodes()
+
+
+def test_remove_project_viterbi_equal_isomorphic(tmp_path):
+    g = G.Graph()
+    for k in range(4):
+        g.add_node(k == 0, k == 3)
+    g.add_arc(0, 1, 1, G.epsilon, 0.5)
+    g.add_arc(1, 2, G.epsilon, G.epsilon, 0.0)
+    g.add_arc(2, 3, 2, 7, 1.5)
+    g.add_arc(0, 3, 3, 3, 1.0)
+    r = G.remove(G.project_output(g))
+    assert dump(r)["arcs"] == dump_oracle(MG.remove(MG.project_output(as_oracle(g))))["arcs"]
+    best = G.viterbi_path(g)
+    assert best.labels_to_list() == [1, G.epsilon, 2] and best.labels_to_list(False) == [G.epsilon, G.epsilon, 7]
+    assert G.equal(g, g) and G.isomorphic(g, g)
+    h = G.Graph()
+    for k in (3, 2, 1, 0):  # same graph, nodes renumbered n -> 3-n
+        h.add_node(k == 0, k == 3)
+    h.add_arc(3, 2, 1, G.epsilon, 0.5), h.add_arc(2, 1, G.epsilon, G.epsilon, 0.0)
+    h.add_arc(1, 0, 2, 7, 1.5), h.add_arc(3, 0, 3, 3, 1.0)
+    assert G.isomorphic(g, h) and not G.equal(g, h)
+    path = tmp_path / "g.txt"
+    G.savetxt(path, g)
+    assert G.equal(G.loadtxt(path), g)
+
+
+def dump_oracle(g):
+    return dict(arcs=[[g.src[a], g.dst[a], g.ilab[a], g.olab[a], g.w[a]] for a in range(g.num_arcs())])
+
+
+def test_viterbi_path_prefers_shortest_decoding():
+    # tests/transducer_test.py:318-353: [1,1,3,3,0] with repeats allowed decodes to [1,3,0]
+    tokens = TR.make_token_graph(["a", "b", "c", "d"], "none", True)
+    path = G.compose(TR.make_chain_graph([1, 1, 3, 3, 0]), tokens)
+    best = G.remove(G.project_output(G.viterbi_path(path)))
+    assert best.labels_to_list() == [1, 3, 0]
+
+
+def test_backoff_text_fixture_loads(golden_dir, tmp_path):
+    with open(os.path.join(golden_dir, "reference_literals.json")) as f:
+        c = json.load(f)["backoff_transitions"]
+    lines = [" ".join(map(str, c["start"])), " ".join(map(str, c["accept"]))]
+    lines += [" ".join(map(str, a)) for a in c["arcs"]]
+    p = tmp_path / "backoff.txt"
+    p.write_text("\n".join(lines) + "\n")
+    g = G.loadtxt(p)
+    assert (g.num_nodes(), g.num_arcs()) == (8, 37)
+    a = g.arrays()
+    assert a["ilabel"][0] == G.epsilon and a["start"].tolist() == [0] * 7 + [1]
+
+
+def test_pack_epsilon_levels_and_sorting():
+    trans = TR.make_transitions_graph(2, 3)  # 5 nodes: start, 3 histories, </s>; epsilon arcs into </s>
+    wid = np.arange(trans.num_arcs(), dtype=np.int32)
+    p = E.PackedLattice.from_graphs([trans], 3, None, wids=[wid], B=4, shared=True)
+    d = p.desc
+    assert (d.B, d.shared, d.max_levels, d.total_eps, d.total_arcs) == (4, 1, 2, 4, 12)
+    lv = p.field("lvl_ptr", 3)
+    assert list(lv) == [0, 4, 5]  # the </s> node is the only level-1 state
+    dst = p.field("arc_dst", 12)
+    assert (np.diff(dst) >= 0).all()
+    np.testing.assert_array_equal(np.sort(p.field("arc_wid", 12)), np.arange(12))
+    np.testing.assert_array_equal(np.sort(p.field("eps_wid", 4)), np.arange(12, 16))
+    g = G.Graph()
+    g.add_node(True), g.add_node(False, True)
+    g.add_arc(0, 1, G.epsilon), g.add_arc(1, 0, G.epsilon)
+    with pytest.raises(N.WflError):
+        E.PackedLattice.from_graphs([g], 3, None)
+    g2 = G.Graph()
+    g2.add_node(True, True)
+    g2.add_arc(0, 0, 5)
+    with pytest.raises(N.WflError):  # label outside [0, C)
+        E.PackedLattice.from_graphs([g2], 3, None)
+
+
+def test_bulk_packers_match_generic_packer():
+    targets = [[1, 2, 2, 0], [], [3]]
+    flat, off, _ = E.flatten_targets(targets)
+    fast = E.PackedLattice.ctc(flat, off, 4, 5, None)
+    slow = E.PackedLattice.from_graphs([ctc.CTCLossFunction.create_ctc_graph(t, 4) for t in targets], 5, None)
+    for name in ("state_off", "arc_off", "in_ptr", "out_ptr", "out_arc", "arc_src", "arc_dst", "arc_slot", "arc_lab",
+                 "labels", "arc_orig"):
+        n = {"state_off": 4, "arc_off": 4, "in_ptr": fast.desc.total_states + 3, "out_ptr": fast.desc.total_states + 3,
+             "labels": fast.desc.total_labels}.get(name, fast.desc.total_arcs)
+        np.testing.assert_array_equal(fast.field(name, n), slow.field(name, n), err_msg=name)
+    np.testing.assert_array_equal(fast.host_floats, slow.host_floats)
+    fast = E.PackedLattice.stc(flat, off, 5, float(np.log(0.5)), 10, None)
+    slow = E.PackedLattice.from_graphs([stc.STCLossFunction.create_stc_graph(t, 5, 0.5) for t in targets], 10, None)
+    np.testing.assert_array_equal(fast.host_ints, slow.host_ints)
+    np.testing.assert_allclose(fast.host_floats, slow.host_floats, rtol=1e-6)
+
+
+def test_replabels_match_reference_vectors(golden_dir):
+    with open(os.path.join(golden_dir, "reference_literals.json")) as f:
+        c = json.load(f)["replabels"]
+    for n, want in c["pack"].items():
+        assert asg.pack_replabels(c["pack_in"], int(n)) == want
+    for n, want in c["unpack"].items():
+        assert asg.unpack_replabels(c["unpack_in"], int(n)) == want
