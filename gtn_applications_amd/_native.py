@@ -47,6 +47,11 @@ class LatticeDesc(ctypes.Structure):
 
 
 def _load():
+    # torch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so).  Import torch first so
+    # that libwfl.so binds to THAT runtime instance: two HIP runtimes in one process do not share
+    # devices, streams or allocations ("no ROCm-capable device is detected" at the first launch).
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

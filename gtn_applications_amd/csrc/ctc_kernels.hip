@@ -25,8 +25,7 @@ namespace wfl {
 
 constexpr float kNegBig = -1.0e30f;          // stands in for -inf on the chain
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
-constexpr int kCtcPrefetch = 8;
+constexpr int kCtcPrefetch = 16;
 
 __device__ __forceinline__ float wave_shr1(float v, float fill) {
   // lane i receives lane i-1's value; lane 0 receives `fill` (DPP wave_shr:1, bound_ctrl off)
@@ -43,15 +42,23 @@ __device__ __forceinline__ float lse3_b2(float a, float b, float c) {
                                    __builtin_amdgcn_exp2f(c - m));
 }
 
-__device__ __forceinline__ float load_score(const float* p) {
-  const float v = *p * kLog2e;
-  return (v > kNegBig) ? v : kNegBig;  // NaN and -inf both become the sentinel (NaN policy)
-}
+// Workspace layout (float units):
+//   [0, B*2*T*P*2)            float2 ws[b][dir][t][pos], pos < P (= max_len + 1): scores RELATIVE to
+//                             the block offset in force when the frame was produced
+//   then doubles              off[b][dir][blk], blk = step / kCtcRenorm: cumulative offset (base-2 log)
+//   then doubles              z2[b]: log2 Z
+// Every kCtcRenorm frames the running maximum over the wave is subtracted from the state vector and
+// added to a double-precision offset.  Stored scores therefore stay O(10) instead of drifting to
+// O(T): fp32 log-domain rounding is ~1e-6 instead of ~3e-4 at T = 1000 (where plain fp32 log-domain,
+// which is what gtn.forward_score uses, already loses the 4th digit of the posteriors).
+constexpr int kCtcRenorm = 16;
 
-// ws layout: [b][dir][t][pos] float2 with pos < P (= max_len + 1)
+__host__ __device__ inline int64_t ctc_main_floats(int B, int T, int P) { return (int64_t)B * 2 * T * P * 2; }
+__host__ __device__ inline int ctc_blocks(int T) { return (T + kCtcRenorm - 1) / kCtcRenorm; }
+
 __global__ void __launch_bounds__(64)
-    ctc_chain_kernel(const float* __restrict__ x, int T, int C, const int32_t* __restrict__ targets,
-                     const int64_t* __restrict__ offsets, int P, int blank, float2* __restrict__ ws,
+    ctc_chain_kernel(const float* __restrict__ x, int B, int T, int C, const int32_t* __restrict__ targets,
+                     const int64_t* __restrict__ offsets, int P, int blank, float* __restrict__ ws_raw,
                      float* __restrict__ nll) {
   const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x;
   const int64_t o0 = offsets[b];
@@ -64,56 +71,85 @@ __global__ void __launch_bounds__(64)
   const bool skip = has_label && lane >= 1 && y != yprev;
   const float* xb_ptr = x + (int64_t)b * T * C;  // row base; + t*C + column
   const int col = has_label ? y : blank;
-  float2* out = ws + ((int64_t)(b * 2 + dir) * T) * P;
+  float2* out = (float2*)ws_raw + ((int64_t)(b * 2 + dir) * T) * P;
+  const int NB = ctc_blocks(T);
+  double* offs = (double*)(ws_raw + ctc_main_floats(B, T, P)) + (int64_t)(b * 2 + dir) * NB;
+  double* z2out = (double*)(ws_raw + ctc_main_floats(B, T, P)) + (int64_t)B * 2 * NB;
 
   float ab = (lane == 0) ? 0.f : kNegBig;  // virtual slot "before the first frame"
   float al = kNegBig;
-  float xl_r[kCtcPrefetch], xb_r[kCtcPrefetch];
+  double off = 0.0;
+  // Prefetch ring of RAW emissions (scaling/clamping happens at use, kCtcPrefetch frames later, so
+  // that no load is consumed right after it is issued).  Lanes >= L fetch the blank column; the
+  // trailing-blank lane L therefore holds x[t, blank], broadcast with v_readlane (no SMEM load, no
+  // second VMEM load per frame).
+  float ring[kCtcPrefetch];
 #pragma unroll
   for (int j = 0; j < kCtcPrefetch; ++j) {
-    const int t = dir == 0 ? j : T - 1 - j;
-    if (j < T) {
-      xl_r[j] = load_score(xb_ptr + (int64_t)t * C + col);
-      xb_r[j] = load_score(xb_ptr + (int64_t)t * C + blank);
-    }
+    const int step = min(j, T - 1);
+    const int t = dir == 0 ? step : T - 1 - step;
+    ring[j] = xb_ptr[(int64_t)t * C + col];
   }
-  for (int s0 = 0; s0 < T; s0 += kCtcPrefetch) {
-#pragma unroll
-    for (int j = 0; j < kCtcPrefetch; ++j) {
-      const int step = s0 + j;
-      if (step < T) {
-        const int t = dir == 0 ? step : T - 1 - step;
-        const float xl = has_label ? xl_r[j] : kNegBig;
-        const float xb = has_blank ? xb_r[j] : kNegBig;
-        const int sn = step + kCtcPrefetch;
-        if (sn < T) {
-          const int tn = dir == 0 ? sn : T - 1 - sn;
-          xl_r[j] = load_score(xb_ptr + (int64_t)tn * C + col);
-          xb_r[j] = load_score(xb_ptr + (int64_t)tn * C + blank);
-        }
-        const float pal = wave_shr1(al, kNegBig);
-        const float nb = lse2_b2(ab, pal);
-        const float nl = lse3_b2(al, ab, skip ? pal : kNegBig);
-        ab = fmaxf(nb + xb, kNegBig);
-        al = fmaxf(nl + xl, kNegBig);
-        if (lane < P) out[(int64_t)t * P + lane] = dir == 0 ? make_float2(ab, al) : make_float2(nb, nl);
+  auto renorm = [&](int blk) {
+    if (blk > 0) {
+      const float m = wave_max(fmaxf(ab, al));
+      if (m > 0.5f * kNegBig) {
+        ab = fmaxf(ab - m, kNegBig);
+        al = fmaxf(al - m, kNegBig);
+        off += (double)m;
       }
     }
+    if (lane == 0) offs[blk] = off;
+  };
+  auto frame = [&](float raw, int t) {
+    float xs = raw * kLog2e;
+    xs = (xs > kNegBig) ? xs : kNegBig;  // NaN and -inf both become the sentinel (NaN policy)
+    const float xblank = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), L));
+    const float xl = has_label ? xs : kNegBig;
+    const float xb = has_blank ? xblank : kNegBig;
+    const float pal = wave_shr1(al, kNegBig);
+    const float nb = lse2_b2(ab, pal);
+    const float nl = lse3_b2(al, ab, skip ? pal : kNegBig);
+    ab = fmaxf(nb + xb, kNegBig);
+    al = fmaxf(nl + xl, kNegBig);
+    if (lane < P) out[(int64_t)t * P + lane] = dir == 0 ? make_float2(ab, al) : make_float2(nb, nl);
+  };
+  const int nfull = T / kCtcPrefetch;
+  for (int c = 0; c < nfull; ++c) {
+    if ((c * kCtcPrefetch) % kCtcRenorm == 0) renorm(c * kCtcPrefetch / kCtcRenorm);
+#pragma unroll
+    for (int j = 0; j < kCtcPrefetch; ++j) {
+      const int step = c * kCtcPrefetch + j;
+      const float raw = ring[j];
+      const int sn = min(step + kCtcPrefetch, T - 1);  // clamped: a valid address, unused past the end
+      ring[j] = xb_ptr[(int64_t)(dir == 0 ? sn : T - 1 - sn) * C + col];
+      frame(raw, dir == 0 ? step : T - 1 - step);
+    }
+  }
+  {
+    const int s0 = nfull * kCtcPrefetch, rem = T - s0;
+    if (rem > 0 && s0 % kCtcRenorm == 0) renorm(s0 / kCtcRenorm);
+#pragma unroll
+    for (int j = 0; j < kCtcPrefetch; ++j)
+      if (j < rem) frame(ring[j], dir == 0 ? s0 + j : T - 1 - (s0 + j));
   }
   if (dir == 0) {
     // logZ = LSE(alpha_{T-1}[2L], alpha_{T-1}[2L-1]) = LSE(ab[L], al[L-1])   (ctc.py:21 accept states)
     const float a_last = __shfl(ab, L, 64);
     const float l_last = L > 0 ? __shfl(al, L - 1, 64) : kNegBig;
     if (lane == 0) {
-      const float z2 = lse2_b2(a_last, l_last);
-      nll[b] = (z2 > 0.5f * kNegBig) ? -z2 * kLn2 : __builtin_inff();
+      const float zr = lse2_b2(a_last, l_last);
+      const bool alive = zr > 0.5f * kNegBig;
+      const double z2 = alive ? (double)zr + off : -1.0e300;
+      z2out[b] = z2;
+      nll[b] = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
     }
   }
 }
 
 __global__ void __launch_bounds__(256)
-    ctc_grad_kernel(int T, int C, const int32_t* __restrict__ targets, const int64_t* __restrict__ offsets, int P,
-                    int blank, const float2* __restrict__ ws, const float* __restrict__ nll,
+    ctc_grad_kernel(int B, int T, int C, const int32_t* __restrict__ targets, const int64_t* __restrict__ offsets,
+                    int P, int blank, const float* __restrict__ ws_raw, const float* __restrict__ nll,
                     const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -121,12 +157,14 @@ __global__ void __launch_bounds__(256)
   const int64_t o0 = offsets[b];
   const int L = (int)(offsets[b + 1] - o0);
   const int y = lane < L ? targets[o0 + lane] : blank;
-  const float loss = nll[b];
-  const bool dead = !(loss < __builtin_inff());
-  const float z2 = -loss * kLog2e;
+  const bool dead = !(nll[b] < __builtin_inff());
   const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
-  const float2* al = ws + ((int64_t)(b * 2 + 0) * T) * P;
-  const float2* be = ws + ((int64_t)(b * 2 + 1) * T) * P;
+  const int NB = ctc_blocks(T);
+  const float2* al = (const float2*)ws_raw + ((int64_t)(b * 2 + 0) * T) * P;
+  const float2* be = (const float2*)ws_raw + ((int64_t)(b * 2 + 1) * T) * P;
+  const double* offa = (const double*)(ws_raw + ctc_main_floats(B, T, P)) + (int64_t)(b * 2 + 0) * NB;
+  const double* offb = offa + NB;
+  const double z2 = ((const double*)(ws_raw + ctc_main_floats(B, T, P)))[(int64_t)B * 2 * NB + b];
   for (int c = lane; c < C; c += 64) row[c] = 0.f;
   __syncthreads();
   for (int tb = blockIdx.x * 4; tb < T; tb += gridDim.x * 4) {  // uniform trip count: barriers inside
@@ -134,13 +172,15 @@ __global__ void __launch_bounds__(256)
     const bool live = t < T && !dead;
     float gb = 0.f, gl = 0.f;
     if (live && lane <= L) {
+      // block offsets of the two sweeps at this frame, combined with log2 Z in double
+      const float delta = (float)(offa[t / kCtcRenorm] + offb[(T - 1 - t) / kCtcRenorm] - z2);
       const float2 a = al[(int64_t)t * P + lane];
       // mirrored beta: blank state 2i <-> reversed position L-i; label of position i <-> L-1-i
       const float bb = be[(int64_t)t * P + (L - lane)].x;
-      gb = __builtin_amdgcn_exp2f(a.x + bb - z2);
+      gb = __builtin_amdgcn_exp2f(a.x + bb + delta);
       if (lane < L) {
         const float bl = be[(int64_t)t * P + (L - 1 - lane)].y;
-        gl = __builtin_amdgcn_exp2f(a.y + bl - z2);
+        gl = __builtin_amdgcn_exp2f(a.y + bl + delta);
       }
     }
     gb = wave_sum(gb);
@@ -182,7 +222,7 @@ int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems) {
     return WFL_ERR_INVALID;
   }
   (void)C;
-  *ws_elems = (int64_t)B * 2 * T * (max_len + 1) * 2;
+  *ws_elems = ctc_main_floats(B, T, max_len + 1) + 2 * ((int64_t)B * 2 * ctc_blocks(T) + B) + 2;
   return WFL_OK;
 }
 
@@ -193,8 +233,8 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
     set_error("ctc_forward: null buffer");
     return WFL_ERR_INVALID;
   }
-  hipLaunchKernelGGL(ctc_chain_kernel, dim3((unsigned)B, 2u), dim3(64), 0, (hipStream_t)stream, x, T, C, targets,
-                     offsets, max_len + 1, blank, (float2*)ws, nll);
+  hipLaunchKernelGGL(ctc_chain_kernel, dim3((unsigned)B, 2u), dim3(64), 0, (hipStream_t)stream, x, B, T, C, targets,
+                     offsets, max_len + 1, blank, ws, nll);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }
@@ -210,8 +250,7 @@ int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, co
   (void)x;
   const int blocks_t = std::max(1, std::min((T + 3) / 4, (4096 + B - 1) / B));
   hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)blocks_t, (unsigned)B), dim3(256), (size_t)4 * C * 4,
-                     (hipStream_t)stream, T, C, targets, offsets, max_len + 1, blank, (const float2*)ws, nll, coef,
-                     gout, dx);
+                     (hipStream_t)stream, B, T, C, targets, offsets, max_len + 1, blank, ws, nll, coef, gout, dx);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }
