@@ -1,0 +1,37 @@
+"""Aliases for the stale flat-layout spellings the reference's own harnesses still import
+(SURVEY.md 0 and 8(b)): `from utils import CTCLoss` (benchmarks/ctc_benchmark.py:13),
+`from utils import ASGLoss` (benchmarks/asg_benchmark.py:13), `import transducer`
+(benchmarks/transducer_benchmark.py:13, tests/transducer_test.py:17-19),
+`utils.pack_replabels` (tests/utils_test.py:19), `from criterions import ctc, asg, transducer`
+(utils.py:19).  `install()` registers them in `sys.modules`; nothing is copied or patched on disk.
+"""
+import sys
+import types
+
+
+def install(gtn_alias=False):
+    from . import criterions, graph
+    from .criterions import asg, ctc, stc, transducer
+
+    sys.modules["criterions"] = criterions
+    for name, mod in (("ctc", ctc), ("asg", asg), ("stc", stc), ("transducer", transducer)):
+        sys.modules["criterions." + name] = mod
+    sys.modules["transducer"] = transducer
+    utils = sys.modules.get("utils")
+    if utils is None:
+        utils = types.ModuleType("utils")
+        utils.__doc__ = "criterion names of the reference's former flat layout (gtn_applications_amd.compat)"
+        sys.modules["utils"] = utils
+    for name, obj in dict(
+        CTCLoss=ctc.CTCLoss, CTCLossFunction=ctc.CTCLossFunction, ASGLoss=asg.ASGLoss,
+        ASGLossFunction=asg.ASGLossFunction, pack_replabels=asg.pack_replabels,
+        unpack_replabels=asg.unpack_replabels, STCLoss=stc.STCLoss,
+    ).items():
+        if not hasattr(utils, name):
+            setattr(utils, name, obj)
+    if gtn_alias and "gtn" not in sys.modules:
+        # graph construction / text I/O subset of the gtn API (Graph, add_node, add_arc, compose,
+        # remove, project_*, loadtxt, ...).  Scoring functions are NOT graph-level here: they live
+        # in the criteria (device engine).
+        sys.modules["gtn"] = graph
+    return utils

@@ -243,3 +243,26 @@ def test_replabels_match_reference_vectors(golden_dir):
         assert asg.pack_replabels(c["pack_in"], int(n)) == want
     for n, want in c["unpack"].items():
         assert asg.unpack_replabels(c["unpack_in"], int(n)) == want
+
+
+def test_compat_aliases():
+    import sys
+
+    from gtn_applications_amd import compat
+
+    saved = {k: sys.modules.get(k) for k in ("utils", "transducer", "criterions", "criterions.ctc")}
+    try:
+        sys.modules.pop("utils", None)
+        compat.install()
+        from utils import ASGLossFunction, CTCLoss, pack_replabels  # noqa: F401
+        import transducer  # noqa: F401
+        from criterions import ctc as c2
+
+        assert c2.CTCLoss is CTCLoss and transducer.Transducer is TR.Transducer
+        assert pack_replabels([0, 0, 1], 1) == [1, 0, 2]
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
