@@ -2,36 +2,55 @@
 // criterions/ctc.py:15-94 without any graph.
 //
 // Lane mapping (one 64-lane wavefront per utterance and direction): lane i owns target position i,
-// i.e. the blank state 2i ("ab") and the label state 2i+1 ("al") of the CTC label graph
-// (ctc.py:18-27); lane L owns the trailing blank.  One frame of the recursion needs exactly one
-// cross-lane value (al of lane i-1), fetched with a DPP wave shift -- no LDS on the dependent
-// chain:
-//     ab' = xb   + LSE(ab, al[i-1])
-//     al' = xl_i + LSE(al, ab, skip_i ? al[i-1] : -inf)         skip_i = (y_i != y_{i-1})
-// The beta sweep is the same recursion on the reversed target and reversed time (the CTC graph is
-// mirror-symmetric), so one routine serves both directions; it stores the value BEFORE the
-// emission is added, so that posterior(t, s) = alpha_t(s) * beta~_t(s) / Z needs no emission.
-// Scores are kept in base-2 log units (v_exp_f32 / v_log_f32 are base 2): no multiplies on the
-// dependent chain.  -inf is represented by a large finite sentinel so the chain is branch-free.
-// Emissions are gathered straight from the [B,T,C] tensor (one dword per lane per frame, all
-// addresses of a wave inside one C-float row) with an 8-frame register prefetch ring.
+// i.e. the blank state 2i ("b") and the label state 2i+1 ("l") of the CTC label graph
+// (ctc.py:18-27); lane L owns the trailing blank.  One frame of the recursion
+//     b' = xb   + LSE(b, l[i-1])
+//     l' = xl_i + LSE(l, b, skip_i ? l[i-1] : -inf)            skip_i = (y_i != y_{i-1})
+// needs exactly one cross-lane value (the label state of lane i-1), fetched with a DPP wave shift:
+// no LDS on the dependent chain.  The beta sweep is the same recursion on the reversed target and
+// reversed time (the CTC graph is mirror-symmetric), so one routine serves both directions.
 //
-//   stage A  ctc_chain_kernel   grid (B, 2): alpha and beta chains run concurrently
-//   stage B  ctc_grad_kernel    all CUs: one wave per (b, t) row: posteriors, label reduction in
-//                               LDS, dense row store (zeros included, as ctc.py:75 returns)
+// Measured on MI355X (scratch/chain_ubench.hip): a lone wavefront issues ~1 instruction per 4
+// cycles and every VMEM instruction costs it ~50 cycles -- the chain is bound by its instruction
+// count per frame, not by bandwidth.  Therefore:
+//   * the chain stores NOTHING per frame: only the state vector at every 16-frame boundary
+//     (a "checkpoint": 1/16 of the alpha/beta volume) together with its scale offset;
+//   * the gradient kernel recomputes alpha forward and beta backward INSIDE each 16-frame block from
+//     the two checkpoints that bracket it -- 8064 independent wave-sized chains at cfg2, i.e. a
+//     throughput problem spread over all 256 CUs -- forms the posteriors and assembles the dense
+//     gradient rows of the block in LDS, one coalesced 16-B/lane copy per block;
+//   * emissions are gathered straight from the [B,T,C] tensor (one dword per lane per frame, all
+//     addresses of a wave inside one C-float row) through a 16-frame register ring of RAW values (no
+//     load is consumed right after issue); the trailing-blank lane's value is broadcast with
+//     v_readlane, so there is exactly one VMEM load per frame and no SMEM load.
+//
+// Arithmetic: base-2 log domain (v_exp_f32 / v_log_f32 are base 2: no multiplies on the dependent
+// chain), -inf represented by a large finite sentinel so the chain is branch-free.  Every 16 frames
+// the wave maximum is moved into a double-precision offset: stored scores stay O(10) instead of
+// drifting to O(T) (plain fp32 log-domain, which is what gtn.forward_score does, already loses the
+// 4th digit of the posteriors at T = 1000).
+//
+// (A probability-domain chain with a wave-uniform power-of-two scale -- 6 VALU per frame -- was built
+// and measured here too; on unnormalised scores with T >> L the alpha mass piles up at the last
+// states and the beta mass at the first ones, their scale disparity reaches 2^300, and the cells
+// that carry the posterior are flushed.  Its certificate rejected every cfg2 utterance, so it was
+// removed; see DESIGN.md, "CTC numerics".)
 #include "device_common.h"
 
 namespace wfl {
 
-constexpr float kNegBig = -1.0e30f;          // stands in for -inf on the chain
+constexpr float kNegBig = -1.0e30f;  // stands in for -inf on the chain
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr int kCtcPrefetch = 16;
+constexpr int kBlk = 16;  // frames per block: renormalisation, checkpoint and prefetch period
 
 __device__ __forceinline__ float wave_shr1(float v, float fill) {
   // lane i receives lane i-1's value; lane 0 receives `fill` (DPP wave_shr:1, bound_ctrl off)
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
-
+__device__ __forceinline__ float wave_shl1(float v, float fill) {
+  // lane i receives lane i+1's value; lane 63 receives `fill` (DPP wave_shl:1)
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float lse2_b2(float a, float b) {
   const float m = fmaxf(a, b);
   return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m));
@@ -41,70 +60,87 @@ __device__ __forceinline__ float lse3_b2(float a, float b, float c) {
   return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) +
                                    __builtin_amdgcn_exp2f(c - m));
 }
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float to_score(float raw) {
+  const float v = raw * kLog2e;
+  return (v > kNegBig) ? v : kNegBig;  // NaN and -inf both become the sentinel (NaN policy)
+}
 
-// Workspace layout (float units):
-//   [0, B*2*T*P*2)            float2 ws[b][dir][t][pos], pos < P (= max_len + 1): scores RELATIVE to
-//                             the block offset in force when the frame was produced
-//   then doubles              off[b][dir][blk], blk = step / kCtcRenorm: cumulative offset (base-2 log)
-//   then doubles              z2[b]: log2 Z
-// Every kCtcRenorm frames the running maximum over the wave is subtracted from the state vector and
-// added to a double-precision offset.  Stored scores therefore stay O(10) instead of drifting to
-// O(T): fp32 log-domain rounding is ~1e-6 instead of ~3e-4 at T = 1000 (where plain fp32 log-domain,
-// which is what gtn.forward_score uses, already loses the 4th digit of the posteriors).
-constexpr int kCtcRenorm = 16;
+// ------------------------------------------------------------------------------------------------
+// workspace layout (float units).  NB = ceil(T / 16), P = max_len + 1.
+//   float2 ck[b][dir][kk][P]   kk = 0..NB-1 in PROCESSING order: state before the kk-th block the
+//                              sweep processed (alpha: block kk; beta: block NB-1-kk), base-2 log
+//                              scores relative to off[b][dir][kk], emissions of all frames consumed
+//                              so far included
+//   double off[b][dir][kk]     the offset
+//   double z2[b]               log2 Z
+// ------------------------------------------------------------------------------------------------
+struct CtcWs {
+  int64_t ck, off, z2, total;
+};
+__host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
+__host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
+  const int64_t NB = ctc_blocks(T);
+  CtcWs w;
+  int64_t o = 0;
+  w.ck = o, o += (int64_t)B * 2 * NB * P * 2;
+  o = (o + 1) & ~1ll;
+  w.off = o, o += 2 * (int64_t)B * 2 * NB;
+  w.z2 = o, o += 2 * (int64_t)B;
+  w.total = o + 2;
+  return w;
+}
 
-__host__ __device__ inline int64_t ctc_main_floats(int B, int T, int P) { return (int64_t)B * 2 * T * P * 2; }
-__host__ __device__ inline int ctc_blocks(int T) { return (T + kCtcRenorm - 1) / kCtcRenorm; }
+struct CtcArgs {
+  const float* x;
+  int B, T, C, P, blank;
+  const int32_t* targets;
+  const int64_t* offsets;
+  float* ws;
+  float* nll;
+};
 
-__global__ void __launch_bounds__(64)
-    ctc_chain_kernel(const float* __restrict__ x, int B, int T, int C, const int32_t* __restrict__ targets,
-                     const int64_t* __restrict__ offsets, int P, int blank, float* __restrict__ ws_raw,
-                     float* __restrict__ nll) {
+// ------------------------------------------------------------------------------------------------
+// chains: grid (B, 2) x 64
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) ctc_chain_kernel(CtcArgs a) {
   const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x;
-  const int64_t o0 = offsets[b];
-  const int L = (int)(offsets[b + 1] - o0);
+  const int T = a.T, C = a.C, P = a.P;
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
   // this lane's label (reversed target for the beta sweep) and skip flag
   int y = -1, yprev = -1;
-  if (lane < L) y = targets[o0 + (dir == 0 ? lane : L - 1 - lane)];
-  if (lane >= 1 && lane - 1 < L) yprev = targets[o0 + (dir == 0 ? lane - 1 : L - lane)];
+  if (lane < L) y = a.targets[o0 + (dir == 0 ? lane : L - 1 - lane)];
+  if (lane >= 1 && lane - 1 < L) yprev = a.targets[o0 + (dir == 0 ? lane - 1 : L - lane)];
   const bool has_label = lane < L, has_blank = lane <= L;
   const bool skip = has_label && lane >= 1 && y != yprev;
-  const float* xb_ptr = x + (int64_t)b * T * C;  // row base; + t*C + column
-  const int col = has_label ? y : blank;
-  float2* out = (float2*)ws_raw + ((int64_t)(b * 2 + dir) * T) * P;
+  const float* xrow = a.x + (int64_t)b * T * C;
+  const int col = has_label ? y : a.blank;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
   const int NB = ctc_blocks(T);
-  double* offs = (double*)(ws_raw + ctc_main_floats(B, T, P)) + (int64_t)(b * 2 + dir) * NB;
-  double* z2out = (double*)(ws_raw + ctc_main_floats(B, T, P)) + (int64_t)B * 2 * NB;
+  float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
+  double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
 
+  // frame index of processing step s: alpha walks t = 0..T-1; beta walks block by block from the
+  // last block to the first, frames descending inside each block, so that its checkpoints fall on
+  // the same absolute 16-frame boundaries as alpha's
   float ab = (lane == 0) ? 0.f : kNegBig;  // virtual slot "before the first frame"
   float al = kNegBig;
   double off = 0.0;
-  // Prefetch ring of RAW emissions (scaling/clamping happens at use, kCtcPrefetch frames later, so
-  // that no load is consumed right after it is issued).  Lanes >= L fetch the blank column; the
-  // trailing-blank lane L therefore holds x[t, blank], broadcast with v_readlane (no SMEM load, no
-  // second VMEM load per frame).
-  float ring[kCtcPrefetch];
-#pragma unroll
-  for (int j = 0; j < kCtcPrefetch; ++j) {
-    const int step = min(j, T - 1);
-    const int t = dir == 0 ? step : T - 1 - step;
-    ring[j] = xb_ptr[(int64_t)t * C + col];
-  }
-  auto renorm = [&](int blk) {
-    if (blk > 0) {
-      const float m = wave_max(fmaxf(ab, al));
-      if (m > 0.5f * kNegBig) {
-        ab = fmaxf(ab - m, kNegBig);
-        al = fmaxf(al - m, kNegBig);
-        off += (double)m;
-      }
-    }
-    if (lane == 0) offs[blk] = off;
+  float ring[kBlk];
+  auto frame_of = [&](int kk, int j) {  // j-th frame processed in the kk-th processed block
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int t0 = k * kBlk, n = min(kBlk, T - t0);
+    const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
+    return min(max(t, 0), T - 1);  // clamped: a valid address, value unused past the block
   };
-  auto frame = [&](float raw, int t) {
-    float xs = raw * kLog2e;
-    xs = (xs > kNegBig) ? xs : kNegBig;  // NaN and -inf both become the sentinel (NaN policy)
-    const float xblank = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), L));
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) ring[j] = xrow[(int64_t)frame_of(0, j) * C + col];
+  auto frame = [&](float raw) {
+    const float xs = to_score(raw);
+    const float xblank = readlane_f(xs, L);
     const float xl = has_label ? xs : kNegBig;
     const float xb = has_blank ? xblank : kNegBig;
     const float pal = wave_shr1(al, kNegBig);
@@ -112,89 +148,142 @@ __global__ void __launch_bounds__(64)
     const float nl = lse3_b2(al, ab, skip ? pal : kNegBig);
     ab = fmaxf(nb + xb, kNegBig);
     al = fmaxf(nl + xl, kNegBig);
-    if (lane < P) out[(int64_t)t * P + lane] = dir == 0 ? make_float2(ab, al) : make_float2(nb, nl);
   };
-  const int nfull = T / kCtcPrefetch;
-  for (int c = 0; c < nfull; ++c) {
-    if ((c * kCtcPrefetch) % kCtcRenorm == 0) renorm(c * kCtcPrefetch / kCtcRenorm);
+  for (int kk = 0; kk < NB; ++kk) {
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int n = min(kBlk, T - k * kBlk);
+    if (kk > 0) {  // renormalise: wave maximum -> double offset
+      const float m = wave_all_max(fmaxf(ab, al));
+      if (m > 0.5f * kNegBig) {
+        ab = fmaxf(ab - m, kNegBig);
+        al = fmaxf(al - m, kNegBig);
+        off += (double)m;
+      }
+    }
+    if (lane < P) ck[(int64_t)kk * P + lane] = make_float2(ab, al);
+    if (lane == 0) offs[kk] = off;
+    if (n == kBlk) {
 #pragma unroll
-    for (int j = 0; j < kCtcPrefetch; ++j) {
-      const int step = c * kCtcPrefetch + j;
-      const float raw = ring[j];
-      const int sn = min(step + kCtcPrefetch, T - 1);  // clamped: a valid address, unused past the end
-      ring[j] = xb_ptr[(int64_t)(dir == 0 ? sn : T - 1 - sn) * C + col];
-      frame(raw, dir == 0 ? step : T - 1 - step);
+      for (int j = 0; j < kBlk; ++j) {
+        const float raw = ring[j];
+        ring[j] = xrow[(int64_t)frame_of(min(kk + 1, NB - 1), j) * C + col];  // prefetch the next block
+        frame(raw);
+      }
+    } else {  // the one partial block: alpha's last, beta's first
+      float nxt[kBlk];
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) nxt[j] = xrow[(int64_t)frame_of(min(kk + 1, NB - 1), j) * C + col];
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j)
+        if (j < n) frame(ring[j]);
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) ring[j] = nxt[j];
     }
   }
-  {
-    const int s0 = nfull * kCtcPrefetch, rem = T - s0;
-    if (rem > 0 && s0 % kCtcRenorm == 0) renorm(s0 / kCtcRenorm);
-#pragma unroll
-    for (int j = 0; j < kCtcPrefetch; ++j)
-      if (j < rem) frame(ring[j], dir == 0 ? s0 + j : T - 1 - (s0 + j));
-  }
   if (dir == 0) {
-    // logZ = LSE(alpha_{T-1}[2L], alpha_{T-1}[2L-1]) = LSE(ab[L], al[L-1])   (ctc.py:21 accept states)
-    const float a_last = __shfl(ab, L, 64);
-    const float l_last = L > 0 ? __shfl(al, L - 1, 64) : kNegBig;
+    // logZ = LSE(alpha_{T-1}[2L], alpha_{T-1}[2L-1])   (ctc.py:21 accept states)
+    const float a_last = readlane_f(ab, L);
+    const float l_last = L > 0 ? readlane_f(al, L - 1) : kNegBig;
     if (lane == 0) {
       const float zr = lse2_b2(a_last, l_last);
       const bool alive = zr > 0.5f * kNegBig;
       const double z2 = alive ? (double)zr + off : -1.0e300;
-      z2out[b] = z2;
-      nll[b] = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
+      ((double*)(a.ws + w.z2))[b] = z2;
+      a.nll[b] = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
     }
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gradient: one wave per (utterance, 16-frame block), 4 waves per workgroup
+// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-    ctc_grad_kernel(int B, int T, int C, const int32_t* __restrict__ targets, const int64_t* __restrict__ offsets,
-                    int P, int blank, const float* __restrict__ ws_raw, const float* __restrict__ nll,
-                    const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
+    ctc_grad_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* row = (float*)smem + (size_t)wave * C;
-  const int64_t o0 = offsets[b];
-  const int L = (int)(offsets[b + 1] - o0);
-  const int y = lane < L ? targets[o0 + lane] : blank;
-  const bool dead = !(nll[b] < __builtin_inff());
-  const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
   const int NB = ctc_blocks(T);
-  const float2* al = (const float2*)ws_raw + ((int64_t)(b * 2 + 0) * T) * P;
-  const float2* be = (const float2*)ws_raw + ((int64_t)(b * 2 + 1) * T) * P;
-  const double* offa = (const double*)(ws_raw + ctc_main_floats(B, T, P)) + (int64_t)(b * 2 + 0) * NB;
-  const double* offb = offa + NB;
-  const double z2 = ((const double*)(ws_raw + ctc_main_floats(B, T, P)))[(int64_t)B * 2 * NB + b];
-  for (int c = lane; c < C; c += 64) row[c] = 0.f;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;  // (b, k) pairs
+  const bool valid = item < (int64_t)a.B * NB;
+  const int b = valid ? (int)(item / NB) : 0, k = valid ? (int)(item % NB) : 0;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  float* rows = (float*)smem + (size_t)wave * kBlk * C;  // [16][C] per wave
+  const int t0 = k * kBlk, n = min(kBlk, T - t0);
+  const bool live = valid && a.nll[b] < __builtin_inff();  // no accepting path: zero gradient
+  if (valid)
+    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+  if (live) {
+    const int64_t o0 = a.offsets[b];
+    const int L = (int)(a.offsets[b + 1] - o0);
+    const int y = lane < L ? a.targets[o0 + lane] : -1;
+    const int yprev = (lane >= 1 && lane - 1 < L) ? a.targets[o0 + lane - 1] : -1;
+    const int ynext = lane + 1 < L ? a.targets[o0 + lane + 1] : -1;
+    const bool has_label = lane < L, has_blank = lane <= L;
+    const bool skip = has_label && lane >= 1 && y != yprev;  // label i-1 -> label i
+    const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
+    const int col = has_label ? y : a.blank;
+    const float* xrow = a.x + (int64_t)b * T * C;
+    float xl[kBlk], xb[kBlk];
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) xl[j] = xrow[(int64_t)min(t0 + j, T - 1) * C + col];  // all 16 gathers in flight
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const float xs = to_score(xl[j]);
+      xb[j] = has_blank ? readlane_f(xs, L) : kNegBig;
+      xl[j] = has_label ? xs : kNegBig;
+    }
+    const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
+    const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
+    const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
+    const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
+    const double z2 = ((const double*)(a.ws + w.z2))[b];
+    // alpha checkpoint k: state before frame t0.  beta processed blocks NB-1..0, so its checkpoint
+    // before block k has processing index NB-1-k: the full beta of frame t0+n (mirrored lanes:
+    // blank state 2i <-> reversed position L-i; label of position i <-> L-1-i).
+    const float2 ca = lane < P ? cka[(int64_t)k * P + lane] : make_float2(kNegBig, kNegBig);
+    float bb = lane <= L ? ckb[(int64_t)(NB - 1 - k) * P + (L - lane)].x : kNegBig;
+    float bl = lane < L ? ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)].y : kNegBig;
+    // posterior_t(s) = 2^(alpha_t(s) + beta~_t(s) + U), U = off_alpha(k) + off_beta(k) - log2 Z
+    const float U = (float)(offa[k] + offb[NB - 1 - k] - z2);
+    const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+    float pa_b[kBlk], pa_l[kBlk];
+    float ab = ca.x, al = ca.y;
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {  // alpha forward through the block, kept in registers
+      const float pal = wave_shr1(al, kNegBig);
+      const float nb = lse2_b2(ab, pal);
+      const float nl = lse3_b2(al, ab, skip ? pal : kNegBig);
+      ab = fmaxf(nb + xb[j], kNegBig);
+      al = fmaxf(nl + xl[j], kNegBig);
+      pa_b[j] = ab + U, pa_l[j] = al + U;
+    }
+#pragma unroll
+    for (int j = kBlk - 1; j >= 0; --j) {  // beta backwards, in the forward lane mapping
+      if (j < n) {
+        const float bbn = wave_shl1(bb, kNegBig), bln = wave_shl1(bl, kNegBig);
+        const float tb = lse2_b2(bb, bl);                            // blank i -> blank i, label i
+        const float tl = lse3_b2(bl, bbn, skipn ? bln : kNegBig);   // label i -> label i, blank i+1, label i+1
+        const float gb = has_blank ? __builtin_amdgcn_exp2f(pa_b[j] + tb) : 0.f;
+        const float gl = has_label ? __builtin_amdgcn_exp2f(pa_l[j] + tl) : 0.f;
+        const float gsum = wave_reduce_sum_lane63(gb);
+        if (lane == 63 && gsum != 0.f) atomicAdd(&rows[j * C + a.blank], gsum * cf);
+        if (gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
+        bb = fmaxf(tb + xb[j], kNegBig);
+        bl = fmaxf(tl + xl[j], kNegBig);
+      }
+    }
+  }
   __syncthreads();
-  for (int tb = blockIdx.x * 4; tb < T; tb += gridDim.x * 4) {  // uniform trip count: barriers inside
-    const int t = tb + wave;
-    const bool live = t < T && !dead;
-    float gb = 0.f, gl = 0.f;
-    if (live && lane <= L) {
-      // block offsets of the two sweeps at this frame, combined with log2 Z in double
-      const float delta = (float)(offa[t / kCtcRenorm] + offb[(T - 1 - t) / kCtcRenorm] - z2);
-      const float2 a = al[(int64_t)t * P + lane];
-      // mirrored beta: blank state 2i <-> reversed position L-i; label of position i <-> L-1-i
-      const float bb = be[(int64_t)t * P + (L - lane)].x;
-      gb = __builtin_amdgcn_exp2f(a.x + bb + delta);
-      if (lane < L) {
-        const float bl = be[(int64_t)t * P + (L - 1 - lane)].y;
-        gl = __builtin_amdgcn_exp2f(a.y + bl + delta);
-      }
+  if (valid) {  // the dense rows of a block are contiguous in dx: one coalesced copy (zeros included)
+    float* dst = dx + ((int64_t)b * T + t0) * C;
+    const int total = n * C;
+    if ((((uintptr_t)dst) & 15) == 0) {
+      const int n4 = total >> 2;
+      for (int i = lane; i < n4; i += 64) ((float4*)dst)[i] = ((const float4*)rows)[i];
+      for (int i = (n4 << 2) + lane; i < total; i += 64) dst[i] = rows[i];
+    } else {
+      for (int i = lane; i < total; i += 64) dst[i] = rows[i];
     }
-    gb = wave_sum(gb);
-    if (lane == 0 && gb != 0.f) atomicAdd(&row[blank], gb * cf);
-    if (lane < L && gl != 0.f) atomicAdd(&row[y], gl * cf);
-    __syncthreads();
-    if (t < T) {
-      float* dst = dx + ((int64_t)b * T + t) * C;
-      for (int c = lane; c < C; c += 64) {
-        dst[c] = row[c];
-        row[c] = 0.f;
-      }
-    }
-    __syncthreads();
   }
 }
 
@@ -213,6 +302,10 @@ static int ctc_check(int B, int T, int C, int max_len, int blank, const char* wh
     set_error("%s: target length %d needs more than one 64-lane wavefront (use the lattice engine)", who, max_len);
     return WFL_ERR_UNSUPPORTED;
   }
+  if ((size_t)4 * kBlk * C * 4 > (size_t)kLdsBytes) {
+    set_error("%s: C=%d too large for the LDS row tiles of the gradient kernel (use the lattice engine)", who, C);
+    return WFL_ERR_UNSUPPORTED;
+  }
   return WFL_OK;
 }
 
@@ -222,7 +315,7 @@ int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems) {
     return WFL_ERR_INVALID;
   }
   (void)C;
-  *ws_elems = ctc_main_floats(B, T, max_len + 1) + 2 * ((int64_t)B * 2 * ctc_blocks(T) + B) + 2;
+  *ws_elems = ctc_ws_layout(B, T, max_len + 1).total;
   return WFL_OK;
 }
 
@@ -233,8 +326,8 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
     set_error("ctc_forward: null buffer");
     return WFL_ERR_INVALID;
   }
-  hipLaunchKernelGGL(ctc_chain_kernel, dim3((unsigned)B, 2u), dim3(64), 0, (hipStream_t)stream, x, B, T, C, targets,
-                     offsets, max_len + 1, blank, ws, nll);
+  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll};
+  hipLaunchKernelGGL(ctc_chain_kernel, dim3((unsigned)B, 2u), dim3(64), 0, (hipStream_t)stream, a);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }
@@ -243,14 +336,17 @@ int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, co
                  int blank, const float* ws, const float* nll, const float* coef, const float* gout, float* dx,
                  void* stream) {
   if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_grad")) return rc;
-  if (!targets || !offsets || !ws || !nll || !dx) {
+  if (!x || !targets || !offsets || !ws || !nll || !dx) {
     set_error("ctc_grad: null buffer");
     return WFL_ERR_INVALID;
   }
-  (void)x;
-  const int blocks_t = std::max(1, std::min((T + 3) / 4, (4096 + B - 1) / B));
-  hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)blocks_t, (unsigned)B), dim3(256), (size_t)4 * C * 4,
-                     (hipStream_t)stream, B, T, C, targets, offsets, max_len + 1, blank, ws, nll, coef, gout, dx);
+  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, (float*)ws, (float*)nll};
+  const int64_t items = (int64_t)B * ctc_blocks(T);
+  const size_t lds = (size_t)4 * kBlk * C * 4;
+  if (lds > 48 * 1024)
+    WFL_HIP_CHECK(hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream, a, coef,
+                     gout, dx);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

