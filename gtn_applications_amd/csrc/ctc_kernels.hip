@@ -51,14 +51,19 @@ __device__ __forceinline__ float wave_shl1(float v, float fill) {
   // lane i receives lane i+1's value; lane 63 receives `fill` (DPP wave_shl:1)
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float lse2_b2(float a, float b) {
-  const float m = fmaxf(a, b);
-  return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m));
+// log2(2^a + 2^b) with ONE exp and one log: max + log2(1 + 2^-|a-b|).  With the finite -inf sentinel
+// the difference of two sentinels is 0 (-> sentinel + 1, still a sentinel) and sentinel vs finite
+// gives 2^-huge = 0: branch-free.  Cost model on gfx950 (measured): 4 cycles per VALU, 16 per
+// transcendental: 4*4 + 2*16 = 48 cycles.  The bare v_max_f32 avoids the two canonicalising
+// v_max x,x,x that fmaxf() costs under IEEE mode (no NaN can reach this point: NaN policy at load).
+__device__ __forceinline__ float vmax(float a, float b) {
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+  return m;
 }
-__device__ __forceinline__ float lse3_b2(float a, float b, float c) {
-  const float m = fmaxf(fmaxf(a, b), c);
-  return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) +
-                                   __builtin_amdgcn_exp2f(c - m));
+__device__ __forceinline__ float lse2_b2(float a, float b) {
+  const float e = __builtin_amdgcn_exp2f(-fabsf(a - b));
+  return vmax(a, b) + __builtin_amdgcn_logf(1.f + e);
 }
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -103,10 +108,19 @@ struct CtcArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
-// chains: grid (B, 2) x 64
+// chains: grid (B, 2) x 128.  Wave 0 runs the dependent chain and nothing else; wave 1 (on another
+// SIMD of the same CU) feeds it: it gathers the emissions of block kk+2 from HBM, applies the scale /
+// NaN policy / blank broadcast / lane masks and leaves ready (xb, xl) pairs in an LDS ring, two
+// blocks ahead.  One s_barrier per 16-frame block.  This takes the VMEM instruction (~50 cycles for
+// a lone wave), ~6 VALU and ~10 SALU of address arithmetic per frame off the critical wave.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) ctc_chain_kernel(CtcArgs a) {
-  const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x;
+constexpr int kRing = 3;  // LDS ring depth in blocks: consumer at kk, producer at kk+2
+
+__global__ void __launch_bounds__(128) ctc_chain_kernel(CtcArgs a) {
+  __shared__ float2 ring[kRing][kBlk][64];  // 24 KiB
+  __shared__ float2 ckbuf[2][64];           // checkpoint hand-off chain wave -> helper wave
+  __shared__ double offbuf[2];
+  const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = a.T, C = a.C, P = a.P;
   const int64_t o0 = a.offsets[b];
   const int L = (int)(a.offsets[b + 1] - o0);
@@ -120,67 +134,91 @@ __global__ void __launch_bounds__(64) ctc_chain_kernel(CtcArgs a) {
   const int col = has_label ? y : a.blank;
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   const int NB = ctc_blocks(T);
-  float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
-  double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
 
-  // frame index of processing step s: alpha walks t = 0..T-1; beta walks block by block from the
-  // last block to the first, frames descending inside each block, so that its checkpoints fall on
-  // the same absolute 16-frame boundaries as alpha's
+  // alpha walks t = 0..T-1; beta walks block by block from the last block to the first, frames
+  // descending inside each block, so that its checkpoints fall on the same absolute 16-frame
+  // boundaries as alpha's
+  auto produce = [&](int kk) {  // helper wave: stage the kk-th processed block
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int t0 = k * kBlk, n = min(kBlk, T - t0);
+    float raw[kBlk];
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {  // all 16 gathers in flight before the first use
+      const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
+      raw[j] = xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
+    }
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const float xs = to_score(raw[j]);
+      const float xblank = readlane_f(xs, L);
+      ring[kk % kRing][j][lane] = make_float2(has_blank ? xblank : kNegBig, has_label ? xs : kNegBig);
+    }
+  };
+  if (wave == 1) {
+    produce(0);
+    if (NB > 1) produce(1);
+  }
+  __syncthreads();
+
   float ab = (lane == 0) ? 0.f : kNegBig;  // virtual slot "before the first frame"
   float al = kNegBig;
   double off = 0.0;
-  float ring[kBlk];
-  auto frame_of = [&](int kk, int j) {  // j-th frame processed in the kk-th processed block
-    const int k = dir == 0 ? kk : NB - 1 - kk;
-    const int t0 = k * kBlk, n = min(kBlk, T - t0);
-    const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
-    return min(max(t, 0), T - 1);  // clamped: a valid address, value unused past the block
+  float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
+  double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+  auto flush_checkpoint = [&](int kk) {  // helper wave: LDS -> HBM, one block behind the chain
+    if (lane < P) ck[(int64_t)kk * P + lane] = ckbuf[kk & 1][lane];
+    if (lane == 0) offs[kk] = offbuf[kk & 1];
   };
+  float2 e[kBlk], en[kBlk];
+  if (wave == 0) {
 #pragma unroll
-  for (int j = 0; j < kBlk; ++j) ring[j] = xrow[(int64_t)frame_of(0, j) * C + col];
-  auto frame = [&](float raw) {
-    const float xs = to_score(raw);
-    const float xblank = readlane_f(xs, L);
-    const float xl = has_label ? xs : kNegBig;
-    const float xb = has_blank ? xblank : kNegBig;
-    const float pal = wave_shr1(al, kNegBig);
-    const float nb = lse2_b2(ab, pal);
-    const float nl = lse3_b2(al, ab, skip ? pal : kNegBig);
-    ab = fmaxf(nb + xb, kNegBig);
-    al = fmaxf(nl + xl, kNegBig);
-  };
-  for (int kk = 0; kk < NB; ++kk) {
-    const int k = dir == 0 ? kk : NB - 1 - kk;
-    const int n = min(kBlk, T - k * kBlk);
-    if (kk > 0) {  // renormalise: wave maximum -> double offset
-      const float m = wave_all_max(fmaxf(ab, al));
-      if (m > 0.5f * kNegBig) {
-        ab = fmaxf(ab - m, kNegBig);
-        al = fmaxf(al - m, kNegBig);
-        off += (double)m;
-      }
-    }
-    if (lane < P) ck[(int64_t)kk * P + lane] = make_float2(ab, al);
-    if (lane == 0) offs[kk] = off;
-    if (n == kBlk) {
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j) {
-        const float raw = ring[j];
-        ring[j] = xrow[(int64_t)frame_of(min(kk + 1, NB - 1), j) * C + col];  // prefetch the next block
-        frame(raw);
-      }
-    } else {  // the one partial block: alpha's last, beta's first
-      float nxt[kBlk];
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j) nxt[j] = xrow[(int64_t)frame_of(min(kk + 1, NB - 1), j) * C + col];
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j)
-        if (j < n) frame(ring[j]);
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j) ring[j] = nxt[j];
-    }
+    for (int j = 0; j < kBlk; ++j) e[j] = ring[0][j][lane];
   }
-  if (dir == 0) {
+  for (int kk = 0; kk < NB; ++kk) {
+    if (wave == 0) {
+      const int k = dir == 0 ? kk : NB - 1 - kk;
+      const int n = min(kBlk, T - k * kBlk);
+      if (kk + 1 < NB) {  // block kk+1 is already staged (the helper runs two blocks ahead)
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) en[j] = ring[(kk + 1) % kRing][j][lane];
+      }
+      if (kk > 0) {  // renormalise: wave maximum -> double offset
+        const float m = wave_all_max(fmaxf(ab, al));
+        if (m > 0.5f * kNegBig) {
+          ab = fmaxf(ab - m, 4.f * kNegBig);  // keeps dead states at sentinel magnitude over any T
+          al = fmaxf(al - m, 4.f * kNegBig);
+          off += (double)m;
+        }
+      }
+      ckbuf[kk & 1][lane] = make_float2(ab, al);  // checkpoint: state BEFORE this block
+      if (lane == 0) offbuf[kk & 1] = off;
+      auto frame = [&](const float2 em) {
+        const float pal = wave_shr1(al, kNegBig);
+        const float nb = lse2_b2(ab, pal);
+        // LSE(al, ab, pal) = LSE(al, nb) when the skip arc exists, LSE(al, ab) otherwise: two 1-exp
+        // log-adds per frame instead of a 2-exp and a 3-exp one
+        const float nl = lse2_b2(al, skip ? nb : ab);
+        ab = nb + em.x;  // no clamp: sentinels only add up (|sum| <= T * 1e30 << FLT_MAX)
+        al = nl + em.y;
+      };
+      if (n == kBlk) {  // straight-line: a per-frame branch costs the lone wave more than the frame's math
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) frame(e[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j)
+          if (j < n) frame(e[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) e[j] = en[j];
+    } else {
+      if (kk > 0) flush_checkpoint(kk - 1);
+      if (kk + 2 < NB) produce(kk + 2);
+    }
+    __syncthreads();
+  }
+  if (wave == 1) flush_checkpoint(NB - 1);
+  if (dir == 0 && wave == 0) {
     // logZ = LSE(alpha_{T-1}[2L], alpha_{T-1}[2L-1])   (ctc.py:21 accept states)
     const float a_last = readlane_f(ab, L);
     const float l_last = L > 0 ? readlane_f(al, L - 1) : kNegBig;
@@ -207,11 +245,12 @@ __global__ void __launch_bounds__(256)
   const bool valid = item < (int64_t)a.B * NB;
   const int b = valid ? (int)(item / NB) : 0, k = valid ? (int)(item % NB) : 0;
   const CtcWs w = ctc_ws_layout(a.B, T, P);
-  float* rows = (float*)smem + (size_t)wave * kBlk * C;  // [16][C] per wave
+  float* rows = (float*)smem + (size_t)wave * (kBlk + 1) * C;  // [16][C] gradient rows + [C] label counts, per wave
+  int* cnt = (int*)(rows + (size_t)kBlk * C);
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
   const bool live = valid && a.nll[b] < __builtin_inff();  // no accepting path: zero gradient
   if (valid)
-    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+    for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;  // (int 0 == float 0 bit pattern)
   if (live) {
     const int64_t o0 = a.offsets[b];
     const int L = (int)(a.offsets[b + 1] - o0);
@@ -223,6 +262,12 @@ __global__ void __launch_bounds__(256)
     const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
     const int col = has_label ? y : a.blank;
     const float* xrow = a.x + (int64_t)b * T * C;
+    // A label that occurs once in the target (and is not the blank column) owns its gradient column:
+    // plain ds_write instead of ds_add_f32, which costs ~1 LDS cycle per active lane (PMC: 42 cycles
+    // per wave-instruction with 45 lanes).  One counting atomic per block finds the duplicates.
+    if (has_label) atomicAdd(&cnt[y], 1);
+    const bool dup = has_label && (cnt[y] > 1 || y == a.blank);
+    const bool uniq = has_label && !dup;
     float xl[kBlk], xb[kBlk];
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) xl[j] = xrow[(int64_t)min(t0 + j, T - 1) * C + col];  // all 16 gathers in flight
@@ -252,24 +297,31 @@ __global__ void __launch_bounds__(256)
     for (int j = 0; j < kBlk; ++j) {  // alpha forward through the block, kept in registers
       const float pal = wave_shr1(al, kNegBig);
       const float nb = lse2_b2(ab, pal);
-      const float nl = lse3_b2(al, ab, skip ? pal : kNegBig);
-      ab = fmaxf(nb + xb[j], kNegBig);
-      al = fmaxf(nl + xl[j], kNegBig);
+      const float nl = lse2_b2(al, skip ? nb : ab);
+      ab = nb + xb[j];
+      al = nl + xl[j];
       pa_b[j] = ab + U, pa_l[j] = al + U;
     }
 #pragma unroll
     for (int j = kBlk - 1; j >= 0; --j) {  // beta backwards, in the forward lane mapping
       if (j < n) {
-        const float bbn = wave_shl1(bb, kNegBig), bln = wave_shl1(bl, kNegBig);
-        const float tb = lse2_b2(bb, bl);                            // blank i -> blank i, label i
-        const float tl = lse3_b2(bl, bbn, skipn ? bln : kNegBig);   // label i -> label i, blank i+1, label i+1
-        const float gb = has_blank ? __builtin_amdgcn_exp2f(pa_b[j] + tb) : 0.f;
-        const float gl = has_label ? __builtin_amdgcn_exp2f(pa_l[j] + tl) : 0.f;
+        // blank i -> blank i, label i.  label i -> label i, blank i+1 (and label i+1 if allowed):
+        // LSE(bl, bb[i+1], bl[i+1]) = LSE(bl, tb[i+1]) -- the neighbour's freshly computed value
+        const float tb = lse2_b2(bb, bl);
+        // (both shifts are taken unconditionally: a DPP inside a divergent branch would read
+        // neighbours that are masked off)
+        const float tbn = wave_shl1(tb, kNegBig), bbn = wave_shl1(bb, kNegBig);
+        const float tl = lse2_b2(bl, skipn ? tbn : bbn);
+        // dead / non-existent states carry sentinels: exp2 of them is exactly 0, no select needed
+        const float gb = __builtin_amdgcn_exp2f(pa_b[j] + tb);
+        const float gl = __builtin_amdgcn_exp2f(pa_l[j] + tl);
         const float gsum = wave_reduce_sum_lane63(gb);
+        // zero posteriors (most of the lattice away from the alignment band) skip the LDS atomic
         if (lane == 63 && gsum != 0.f) atomicAdd(&rows[j * C + a.blank], gsum * cf);
-        if (gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
-        bb = fmaxf(tb + xb[j], kNegBig);
-        bl = fmaxf(tl + xl[j], kNegBig);
+        if (uniq) rows[j * C + y] = gl * cf;
+        if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
+        bb = tb + xb[j];
+        bl = tl + xl[j];
       }
     }
   }
@@ -302,7 +354,7 @@ static int ctc_check(int B, int T, int C, int max_len, int blank, const char* wh
     set_error("%s: target length %d needs more than one 64-lane wavefront (use the lattice engine)", who, max_len);
     return WFL_ERR_UNSUPPORTED;
   }
-  if ((size_t)4 * kBlk * C * 4 > (size_t)kLdsBytes) {
+  if ((size_t)4 * (kBlk + 1) * C * 4 > (size_t)kLdsBytes) {
     set_error("%s: C=%d too large for the LDS row tiles of the gradient kernel (use the lattice engine)", who, C);
     return WFL_ERR_UNSUPPORTED;
   }
@@ -327,7 +379,7 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
     return WFL_ERR_INVALID;
   }
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll};
-  hipLaunchKernelGGL(ctc_chain_kernel, dim3((unsigned)B, 2u), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ctc_chain_kernel, dim3((unsigned)B, 2u), dim3(128), 0, (hipStream_t)stream, a);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }
@@ -342,7 +394,7 @@ int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, co
   }
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, (float*)ws, (float*)nll};
   const int64_t items = (int64_t)B * ctc_blocks(T);
-  const size_t lds = (size_t)4 * kBlk * C * 4;
+  const size_t lds = (size_t)4 * (kBlk + 1) * C * 4;
   if (lds > 48 * 1024)
     WFL_HIP_CHECK(hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream, a, coef,
