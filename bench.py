@@ -191,6 +191,21 @@ def cpu_baseline(payload, n_utts):
     )
 
 
+def pmc_traffic(kernel, meta):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate `--pmc` runs of this same command; see profiles/README.md).
+    Only valid for the configuration they were measured on; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_ctc_cfg2_pmc_traffic.json")
+    if not os.path.exists(path) or (meta["B"], meta["T"], meta["C"], meta["L"]) != (128, 1000, 100, 44):
+        return None
+    with open(path) as f:
+        rec = json.load(f)["kernels"]
+    for name, v in rec.items():
+        if kernel.startswith(name):
+            return v["hbm_bytes"]
+    return None
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -247,7 +262,7 @@ def main():
         achieved = alg_bytes / (durs[dom] * 1e-3) / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": phases[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(phases[dom], meta),
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": {p: float(d) for p, d in zip(phases, durs)},
             "step_achieved": alg_bytes / (float(durs.sum()) * 1e-3) / 1e9,
