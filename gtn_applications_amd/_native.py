@@ -15,6 +15,7 @@ WFL_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 1, 2, 3
 EPSILON = -1
 SEMIRING_LOG, SEMIRING_TROPICAL = 0, 1
+CTC_FAST_CHAIN = 2
 
 
 class WflError(RuntimeError):
@@ -113,7 +114,7 @@ _SIGS = {
     "wfl_dense_viterbi": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     # device: CTC fast path
     "wfl_ctc_workspace": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int64)]),
-    "wfl_ctc_forward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
+    "wfl_ctc_forward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "wfl_ctc_grad": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "wfl_reduce_loss": (c_int, [_P, _P, c_int, c_float, c_int, _P, _P]),
 }

@@ -81,9 +81,10 @@ __device__ __forceinline__ float to_score(float raw) {
 //                              so far included
 //   double off[b][dir][kk]     the offset
 //   double z2[b]               log2 Z
+//   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
 // ------------------------------------------------------------------------------------------------
 struct CtcWs {
-  int64_t ck, off, z2, total;
+  int64_t ck, off, z2, flag, pbad, total;
 };
 __host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
 __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
@@ -94,6 +95,8 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   o = (o + 1) & ~1ll;
   w.off = o, o += 2 * (int64_t)B * 2 * NB;
   w.z2 = o, o += 2 * (int64_t)B;
+  w.flag = o, o += B;      // int32 flag[b]: 1 = the fast chain's result was rejected, log-domain chain re-ran
+  w.pbad = o, o += 2 * B;  // int32 pbad[b][dir]: the fast chain could not vouch for an interval
   w.total = o + 2;
   return w;
 }
@@ -108,7 +111,7 @@ struct CtcArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
-// chains: grid (B, 2) x 128.  Wave 0 runs the dependent chain and nothing else; wave 1 (on another
+// log-domain chains: grid (B, 2) x 128.  Wave 0 runs the dependent chain and nothing else; wave 1 (on another
 // SIMD of the same CU) feeds it: it gathers the emissions of block kk+2 from HBM, applies the scale /
 // NaN policy / blank broadcast / lane masks and leaves ready (xb, xl) pairs in an LDS ring, two
 // blocks ahead.  One s_barrier per 16-frame block.  This takes the VMEM instruction (~50 cycles for
@@ -116,7 +119,8 @@ struct CtcArgs {
 // ------------------------------------------------------------------------------------------------
 constexpr int kRing = 3;  // LDS ring depth in blocks: consumer at kk, producer at kk+2
 
-__global__ void __launch_bounds__(128) ctc_chain_kernel(CtcArgs a) {
+// only_flagged != 0: repair pass -- run only for utterances whose fast-chain result was rejected
+__global__ void __launch_bounds__(128) ctc_log_chain_kernel(CtcArgs a, int only_flagged) {
   __shared__ float2 ring[kRing][kBlk][64];  // 24 KiB
   __shared__ float2 ckbuf[2][64];           // checkpoint hand-off chain wave -> helper wave
   __shared__ double offbuf[2];
@@ -134,6 +138,7 @@ __global__ void __launch_bounds__(128) ctc_chain_kernel(CtcArgs a) {
   const int col = has_label ? y : a.blank;
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   const int NB = ctc_blocks(T);
+  if (only_flagged && ((const int32_t*)(a.ws + w.flag))[b] == 0) return;  // uniform per workgroup
 
   // alpha walks t = 0..T-1; beta walks block by block from the last block to the first, frames
   // descending inside each block, so that its checkpoints fall on the same absolute 16-frame
@@ -230,6 +235,307 @@ __global__ void __launch_bounds__(128) ctc_chain_kernel(CtcArgs a) {
       a.nll[b] = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST chains ("lane-exponent" arithmetic): grid (B, 2) x 256.  EXPERIMENTAL, opt-in with
+// WFL_CTC_FAST_CHAIN: numerically validated (tests/test_gpu_parity.py) and accepted by its
+// certificate on all cfg2 utterances, but at round 1 its helper waves (71 us alone) and its
+// renormalisation overhead (chain wave alone 48.5 us) leave it at 82.8 us vs 67.6 us for the
+// log-domain chain, and its decay flag still rejects sharply peaked inputs.
+//
+// The log-domain frame is a chain of ~15 DEPENDENT instructions with 4 transcendentals (~155 cycles
+// for a lone wave).  Here a state is a float mantissa with an integer exponent PER LANE (shared by
+// the lane's blank / label pair): value = m * 2^(e_lane + off).  A frame is
+//     q = shr(pl);  tb = fma(q, g, pb);  tl = fma(q, gs, pl + pb);  pb = tb * fb;  pl = tl * fl
+// (6 VALU, no transcendental, dependent depth 3) with g = 2^(e[i-1] - e[i]) fixed for 8 frames and
+// emission factors f = 2^(x*log2e - r_t) relative to a per-frame reference r_t (the frame's largest
+// target-label emission: factors <= 1.42, uniformly unlikely frames cost nothing).  Every 8 frames
+// each lane renormalises ITS OWN exponent (no cross-lane reduction), and a prefix-max scan enforces
+// e[i] >= e[i-1] - kGap so that mass flowing up the lanes can never overflow inside an interval
+// (growth <= 2^(8*(kGap+1.6))); a lane pulled up by the clamp only loses mass that is 2^-126 below
+// what its predecessor is about to hand it (same emission factor applies to both).  A wave-uniform
+// power-of-two scale instead of the per-lane exponents does NOT work on the benchmark's data: with
+// unnormalised scores and T >> L the alpha mass piles up at the last states and the beta mass at
+// the first ones, 2^300 apart, and the cells that carry the posterior are flushed (measured).
+//
+// Wave 0 runs the chain; waves 1..3 stage the factors of every third frame two blocks ahead (gather,
+// scale, NaN policy, per-frame wave maximum, exp2, blank broadcast) into an LDS ring and write the
+// checkpoints out.  Checkpoints have the SAME format as the log-domain chain's (base-2 logs relative
+// to a double offset), so the gradient kernel does not care which chain produced them.
+//
+// What cannot be represented is flushed to zero; ctc_certify_kernel then checks, at every 16-frame
+// boundary, that the two independently computed sweeps reproduce Z (|log2 sum_s alpha*beta~ - log2 Z|
+// < 1.5e-3) -- pruning that matters breaks this identity -- and the chain itself reports intervals
+// in which an established lane decayed into the denormal range (pbad).  Rejected utterances are
+// recomputed by ctc_log_chain_kernel in the same forward call.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSub = 8;       // frames per lane-renormalisation interval
+constexpr int kGap = 10;      // max exponent drop from lane i-1 to lane i
+constexpr int kFRing = 4;     // factor ring depth (blocks)
+constexpr int kEmptyE = -(1 << 28);
+
+__device__ __forceinline__ int wave_shr1_i(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+// inclusive prefix maximum over the 64 lanes (row_shr scan + row broadcasts)
+__device__ __forceinline__ int wave_prefix_max_i(int v) {
+  constexpr int ID = -(1 << 30);
+  v = max(v, dpp_i32<0x111, 0xf>(ID, v));
+  v = max(v, dpp_i32<0x112, 0xf>(ID, v));
+  v = max(v, dpp_i32<0x114, 0xf>(ID, v));
+  v = max(v, dpp_i32<0x118, 0xf>(ID, v));
+  v = max(v, dpp_i32<0x142, 0xa>(ID, v));  // row_bcast:15 -> rows 1,3
+  v = max(v, dpp_i32<0x143, 0xc>(ID, v));  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+__global__ void __launch_bounds__(256) ctc_fast_chain_kernel(CtcArgs a) {
+  __shared__ float2 ring[kFRing][kBlk][64];  // (fb, fl) per frame and lane: 32 KiB
+  __shared__ float fref[kFRing][kBlk];       // per-frame reference r_t (integer valued)
+  __shared__ float2 ckbuf[2][64];            // checkpoint hand-off: chain wave -> wave 1
+  __shared__ int ckexp[2];                   // wave-uniform part of the checkpoint's exponents
+  __shared__ double offtot;                  // sum of all r_t
+  const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  int y = -1, yprev = -1;
+  if (lane < L) y = a.targets[o0 + (dir == 0 ? lane : L - 1 - lane)];
+  if (lane >= 1 && lane - 1 < L) yprev = a.targets[o0 + (dir == 0 ? lane - 1 : L - lane)];
+  const bool has_label = lane < L, has_blank = lane <= L;
+  const bool skip = has_label && lane >= 1 && y != yprev;
+  const float* xrow = a.x + (int64_t)b * T * C;
+  const int col = has_label ? y : a.blank;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  const int NB = ctc_blocks(T);
+  if (dir == 0 && threadIdx.x == 0) ((int32_t*)(a.ws + w.flag))[b] = 0;
+
+  // helper waves h = 0..2 own the frames j with j % 3 == h of every block.  `issue` starts the gathers
+  // of a block, `stage` turns the landed values into factors; between the two lie three loop
+  // iterations (three register buffers, rotated by unrolling the block loop by 3), so the HBM / L2
+  // latency never sits in front of a barrier.
+  auto issue = [&](int kk, int h, float (&raw)[6]) {
+    if (kk >= NB) return;
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int t0 = k * kBlk, n = min(kBlk, T - t0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int j = h + 3 * i;
+      const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
+      raw[i] = xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
+    }
+  };
+  auto stage = [&](int kk, int h, const float (&raw)[6]) {
+    if (kk >= NB) return;
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int n = min(kBlk, T - k * kBlk);
+    float xs[6], r[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float v = raw[i] * kLog2e;
+      xs[i] = (v == v) ? v : WFL_NEG_INF;  // NaN policy: impossible
+      r[i] = xs[i];
+    }
+    // six independent wave maxima, interleaved step by step (each DPP step has a long dependent latency)
+#define WFL_STEP(CTRL, MASK)                                                        \
+  _Pragma("unroll") for (int i = 0; i < 6; ++i) r[i] = fmaxf(r[i], dpp_f32<CTRL, MASK>(WFL_NEG_INF, r[i]));
+    WFL_STEP(0x111, 0xf) WFL_STEP(0x112, 0xf) WFL_STEP(0x114, 0xf) WFL_STEP(0x118, 0xf) WFL_STEP(0x142, 0xa)
+    WFL_STEP(0x143, 0xc)
+#undef WFL_STEP
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int j = h + 3 * i;
+      if (j < kBlk) {
+        float rr = readlane_f(r[i], 63);
+        rr = (rr > -3.0e38f && rr < 3.0e38f) ? rintf(rr) : 0.f;
+        const float f = __builtin_amdgcn_exp2f(xs[i] - rr);
+        const float fb = readlane_f(f, L);
+        ring[kk % kFRing][j][lane] = make_float2(has_blank ? fb : 0.f, has_label ? f : 0.f);
+        if (lane == 0) fref[kk % kFRing][j] = (j < n) ? rr : 0.f;
+      }
+    }
+  };
+  float raw0[6], raw1[6], raw2[6];  // helper waves: gathers in flight for blocks kk+2, kk+3, kk+4
+  if (wave >= 1) {
+    const int h = wave - 1;
+    issue(0, h, raw0);
+    issue(1, h, raw1);
+    stage(0, h, raw0);
+    stage(1, h, raw1);
+    issue(2, h, raw0);
+    issue(3, h, raw1);
+    issue(4, h, raw2);
+  }
+  __syncthreads();
+
+  float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
+  double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+  double offcum = 0.0;  // wave 1: sum of r_t over the blocks already processed
+  float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
+  float pl = 0.f;
+  int e = 0;
+  float g = 0.f, gs = 0.f;
+  bool had = false, bad = false;
+  // per-lane power-of-two renormalisation, neighbour-gap clamp, coupling factors for the interval
+  auto lane_renorm = [&]() {
+    const float mx = vmax(pb, pl);
+    bad = bad || (had && mx < 1.0e-36f) || !(mx < 3.0e38f);
+    const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
+    pb = ldexpf(pb, -k);
+    pl = ldexpf(pl, -k);
+    const int own = mx > 0.f ? e + k : kEmptyE;
+    const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
+    const int sh = mx > 0.f ? pre - own : 0;                            // >= 0: pulled up by the clamp
+    pb = ldexpf(pb, -min(sh, 200));
+    pl = ldexpf(pl, -min(sh, 200));
+    e = pre;
+    const int d = wave_shr1_i(e, e) - e;  // <= kGap by construction
+    g = lane == 0 ? 0.f : ldexpf(1.f, max(d, -200));
+    gs = skip ? g : 0.f;
+    had = vmax(pb, pl) > 0.f;
+  };
+  auto frame = [&](const float2 f) {
+    const float q = wave_shr1(pl, 0.f);
+    const float tb = fmaf(q, g, pb);
+    const float tl = fmaf(q, gs, pl + pb);
+    pb = tb * f.x;
+    pl = tl * f.y;
+  };
+  auto flush_checkpoint = [&](int kk) {  // wave 1, one block behind the chain
+    if (lane < P) ck[(int64_t)kk * P + lane] = ckbuf[kk & 1][lane];
+    if (lane == 0) offs[kk] = offcum + (double)ckexp[kk & 1];
+    // advance the running offset over block kk
+    const float rj = lane < kBlk ? fref[kk % kFRing][lane] : 0.f;
+    offcum += (double)wave_all_sum(rj);
+  };
+  float2 fcur[kBlk], fnxt[kBlk];
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) fcur[j] = ring[0][j][lane];
+  }
+  auto chain_block = [&](int kk) {
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int n = min(kBlk, T - k * kBlk);
+    if (kk + 1 < NB) {
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) fnxt[j] = ring[(kk + 1) % kFRing][j][lane];
+    }
+    lane_renorm();
+    {  // checkpoint = state BEFORE this block, as base-2 logs relative to a wave-uniform exponent
+      const int emax = __builtin_amdgcn_readlane(wave_prefix_max_i(had ? e : kEmptyE), 63);
+      const float de = (float)(e - emax);
+      const float lb = pb > 0.f ? __builtin_amdgcn_logf(pb) + de : kNegBig;
+      const float ll = pl > 0.f ? __builtin_amdgcn_logf(pl) + de : kNegBig;
+      ckbuf[kk & 1][lane] = make_float2(lb, ll);
+      if (lane == 0) ckexp[kk & 1] = emax > kEmptyE ? emax : 0;
+    }
+    if (n == kBlk) {
+#pragma unroll
+      for (int j = 0; j < kSub; ++j) frame(fcur[j]);
+      lane_renorm();
+#pragma unroll
+      for (int j = kSub; j < kBlk; ++j) frame(fcur[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kSub; ++j)
+        if (j < n) frame(fcur[j]);
+      if (n > kSub) {
+        lane_renorm();
+#pragma unroll
+        for (int j = kSub; j < kBlk; ++j)
+          if (j < n) frame(fcur[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) fcur[j] = fnxt[j];
+  };
+  auto helper_block = [&](int kk, float (&buf)[6]) {  // buf holds the gathers of block kk+2
+    if (wave == 1 && kk > 0) flush_checkpoint(kk - 1);
+    stage(kk + 2, wave - 1, buf);
+    issue(kk + 5, wave - 1, buf);  // refill the buffer just consumed: lands three iterations from now
+  };
+  for (int kk0 = 0; kk0 < NB; kk0 += 3) {
+    if (wave == 0) chain_block(kk0); else helper_block(kk0, raw0);
+    __syncthreads();
+    if (kk0 + 1 < NB) {
+      if (wave == 0) chain_block(kk0 + 1); else helper_block(kk0 + 1, raw1);
+      __syncthreads();
+    }
+    if (kk0 + 2 < NB) {
+      if (wave == 0) chain_block(kk0 + 2); else helper_block(kk0 + 2, raw2);
+      __syncthreads();
+    }
+  }
+  if (wave == 1) {
+    flush_checkpoint(NB - 1);
+    if (lane == 0) offtot = offcum;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    lane_renorm();
+    if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = bad ? 1 : 0;
+    if (dir == 0) {
+      // Z = alpha_{T-1}[2L] + alpha_{T-1}[2L-1]   (ctc.py:21 accept states), lanes L and L-1
+      const float zb = readlane_f(pb, L);
+      const float zl = L > 0 ? readlane_f(pl, L - 1) : 0.f;
+      const int eb = __builtin_amdgcn_readlane(e, L);
+      const int el = L > 0 ? __builtin_amdgcn_readlane(e, L - 1) : kEmptyE;
+      if (lane == 0) {
+        const int em = max(zb > 0.f ? eb : kEmptyE, zl > 0.f ? el : kEmptyE);
+        const float s = (zb > 0.f ? ldexpf(zb, max(eb - em, -200)) : 0.f) + (zl > 0.f ? ldexpf(zl, max(el - em, -200)) : 0.f);
+        const bool ok = s > 0.f && s < 3.0e38f;
+        const double z2 = ok ? (double)__builtin_amdgcn_logf(s) + (double)em + offtot : -1.0e300;
+        ((double*)(a.ws + w.z2))[b] = z2;
+        a.nll[b] = ok ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
+      }
+    }
+  }
+}
+
+// certificate: one wave per (utterance, interior 16-frame boundary); 4 waves per workgroup
+__global__ void __launch_bounds__(256) ctc_certify_kernel(CtcArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, P = a.P;
+  const int NB = ctc_blocks(T);
+  const int per = max(NB - 1, 1);
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  if (item >= (int64_t)a.B * per) return;
+  const int b = (int)(item / per), k = (int)(item % per) + 1;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  int32_t* flag = (int32_t*)(a.ws + w.flag) + b;
+  const double z2 = ((const double*)(a.ws + w.z2))[b];
+  if (k == 1) {
+    const int32_t* pbad = (const int32_t*)(a.ws + w.pbad) + b * 2;
+    if (lane == 0 && (!(z2 > -1.0e299) || pbad[0] != 0 || pbad[1] != 0)) atomicOr(flag, 1);
+  }
+  if (k >= NB || !(z2 > -1.0e299)) return;
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  const int y = lane < L ? a.targets[o0 + lane] : -1;
+  const int ynext = lane + 1 < L ? a.targets[o0 + lane + 1] : -1;
+  const bool skipn = lane + 1 < L && ynext != y;
+  const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
+  const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
+  const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
+  const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
+  // boundary k (between frames 16k-1 and 16k): alpha checkpoint k = state after frame 16k-1; the beta
+  // checkpoint taken before beta processed block k-1 (processing index NB-k) = full beta of frame 16k.
+  const float2 al = lane < P ? cka[(int64_t)k * P + lane] : make_float2(kNegBig, kNegBig);
+  const float bb = lane <= L ? ckb[(int64_t)(NB - k) * P + (L - lane)].x : kNegBig;
+  const float bl = lane < L ? ckb[(int64_t)(NB - k) * P + (L - 1 - lane)].y : kNegBig;
+  const float tb = lse2_b2(bb, bl);
+  const float tbn = wave_shl1(tb, kNegBig), bbn = wave_shl1(bb, kNegBig);
+  const float tl = lse2_b2(bl, skipn ? tbn : bbn);
+  const float u = al.x + tb, v = lane < L ? al.y + tl : kNegBig;
+  const float m = wave_all_max(fmaxf(u, v));
+  const float ssum = wave_all_sum(__builtin_amdgcn_exp2f(u - m) + __builtin_amdgcn_exp2f(v - m));
+  const double dev = (double)m + (double)__builtin_amdgcn_logf(ssum) + offa[k] + offb[NB - k] - z2;
+  if (lane == 0 && !(fabs(dev) < 1.5e-3)) atomicOr(flag, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -372,14 +678,23 @@ int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems) {
 }
 
 int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets, int max_len,
-                    int blank, float* ws, float* nll, void* stream) {
+                    int blank, int flags, float* ws, float* nll, void* stream) {
   if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_forward")) return rc;
   if (!x || !targets || !offsets || !ws || !nll) {
     set_error("ctc_forward: null buffer");
     return WFL_ERR_INVALID;
   }
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll};
-  hipLaunchKernelGGL(ctc_chain_kernel, dim3((unsigned)B, 2u), dim3(128), 0, (hipStream_t)stream, a);
+  if (!(flags & WFL_CTC_FAST_CHAIN)) {
+    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(128), 0, (hipStream_t)stream, a, 0);
+  } else {
+    hipLaunchKernelGGL(ctc_fast_chain_kernel, dim3((unsigned)B, 2u), dim3(256), 0, (hipStream_t)stream, a);
+    WFL_LAUNCH_CHECK();
+    const int64_t items = (int64_t)B * std::max(ctc_blocks(T) - 1, 1);
+    hipLaunchKernelGGL(ctc_certify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    WFL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(128), 0, (hipStream_t)stream, a, 1);
+  }
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

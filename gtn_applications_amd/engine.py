@@ -272,15 +272,15 @@ class CtcTargets:
         self.dev_offsets = torch.from_numpy(self.offsets).to(device)
 
 
-def ctc_forward(x, tg, blank):
+def ctc_forward(x, tg, blank, flags=0):
     B, T, C = x.shape
     n = ctypes.c_int64()
     N.check(N.lib.wfl_ctc_workspace(B, T, C, tg.max_len, ctypes.byref(n)))
     ws = torch.empty(n.value, dtype=_F32, device=x.device)
     nll = torch.empty(B, dtype=_F32, device=x.device)
     N.check(
-        N.lib.wfl_ctc_forward(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank, ptr(ws),
-                              ptr(nll), stream_ptr())
+        N.lib.wfl_ctc_forward(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank, flags,
+                              ptr(ws), ptr(nll), stream_ptr())
     )
     return ws, nll
 
@@ -291,6 +291,16 @@ def ctc_grad(x, tg, blank, ws, nll, coef, gout, dx):
         N.lib.wfl_ctc_grad(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank, ptr(ws),
                            ptr(nll), ptr(coef), ptr(gout), ptr(dx), stream_ptr())
     )
+
+
+def ctc_rejected(ws, B, T, max_len):
+    """int32 [B] view of the workspace: 1 where the fast chain's result was rejected by the certificate
+    and the log-domain chain re-ran (tests / diagnostics)."""
+    P, nb = max_len + 1, (T + 15) // 16
+    o = B * 2 * nb * P * 2
+    o = (o + 1) & ~1
+    o += 2 * B * 2 * nb + 2 * B
+    return ws[o:o + B].view(torch.int32)
 
 
 def loss_factors(tg, reduction, norm_lens=None):

@@ -223,10 +223,12 @@ int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float
  *   Base-2 log-domain arithmetic, block-renormalised; the chain stores one checkpoint per 16
  *   frames and the gradient kernel recomputes inside the blocks (csrc/ctc_kernels.hip).
  * ------------------------------------------------------------------------------------------------ */
+#define WFL_CTC_FAST_CHAIN 2 /* flags: experimental lane-exponent chain + certificate + log-domain repair */
 int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems);
-/* alpha and beta chains: writes nll[B] = -log Z_b and the 16-frame checkpoints into ws */
+/* alpha and beta chains: writes nll[B] = -log Z_b and the 16-frame checkpoints into ws.
+ * flags = 0: log-domain chain (default). */
 int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
-                    const int64_t* offsets, int max_len, int blank, float* ws, float* nll,
+                    const int64_t* offsets, int max_len, int blank, int flags, float* ws, float* nll,
                     void* stream);
 /* dense gradient rows, recomputed block by block from the checkpoints of wfl_ctc_forward */
 int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,

@@ -120,26 +120,67 @@ def test_ctc_long_targets_use_lattice_engine_and_agree(crit):
     close(xt.grad, want_dx)
 
 
-def test_ctc_lattice_engine_equals_fast_path(crit):
-    """the same batch through both HIP paths (generic lattice kernels vs CTC kernels), including
-    block-boundary cases of the checkpoint/recompute scheme (T = 16k, 16k+1, 16k+8, 16k+15, < 16)"""
+def test_ctc_three_hip_paths_agree(crit):
+    """the same batch through the generic lattice kernels and through both CTC chains (default
+    log-domain chain; experimental lane-exponent chain with certificate), including block-boundary cases of
+    the checkpoint/recompute scheme (T = 16k, 16k+1, 16k+8, 16k+15, < 16)"""
+    from gtn_applications_amd import _native as N
     from gtn_applications_amd import engine as E
 
     rs = np.random.RandomState(11)
-    for T in (90, 96, 97, 104, 111, 16, 7, 1):
+    for T in (90, 96, 97, 104, 111, 16, 7, 1, 300):
         B, C = 5, 17
         x = dev(rs.randn(B, T, C))
         targets = [rs.randint(0, C - 1, size=rs.randint(0, min(30, T) + 1)).tolist() for _ in range(B)]
         tg = E.CtcTargets(targets, x.device)
-        ws, nll = E.ctc_forward(x, tg, C - 1)
         pack = E.PackedLattice.ctc(tg.flat, tg.offsets, C - 1, C, x.device)
         st = E.lattice_forward(x, pack)
-        close(-st.logz, nll.cpu().double().numpy(), rtol=1e-5, atol=1e-4, msg=f"T={T}")
         coef = torch.full((B,), -1.0 / B, device="cuda")
-        d1, d2 = torch.full_like(x, float("nan")), torch.empty_like(x)
-        E.ctc_grad(x, tg, C - 1, ws, nll, coef, None, d1)
+        d2 = torch.empty_like(x)
         E.lattice_grad(st, coef, dx=d2)
-        close(d1, d2.cpu().double().numpy(), rtol=1e-3, atol=1e-6, msg=f"T={T}")
+        for flags in (0, N.CTC_FAST_CHAIN):
+            ws, nll = E.ctc_forward(x, tg, C - 1, flags)
+            close(-st.logz, nll.cpu().double().numpy(), rtol=1e-5, atol=1e-4, msg=f"T={T} flags={flags}")
+            d1 = torch.full_like(x, float("nan"))
+            E.ctc_grad(x, tg, C - 1, ws, nll, coef, None, d1)
+            close(d1, d2.cpu().double().numpy(), rtol=1e-3, atol=1e-6, msg=f"T={T} flags={flags}")
+            if flags:  # well-conditioned random data: the fast chain must be accepted
+                assert E.ctc_rejected(ws, B, T, tg.max_len).cpu().tolist() == [0] * B, f"T={T}"
+
+
+def test_ctc_certificate_rejects_what_the_fast_chain_cannot_represent(crit):
+    """experimental fast chain: an utterance it cannot represent (one target label 40 nats above all
+    others inside a long unlikely segment) must be rejected by the certificate and repaired by the
+    log-domain chain in the same forward call; the result must match the oracle"""
+    from gtn_applications_amd import _native as N
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(1)
+    T, C, L = 400, 40, 30
+    y = rs.randint(0, C - 1, size=L)
+    logits = rs.randn(2, T, C).astype(np.float32)
+    pos = np.sort(rs.choice(np.arange(5, T - 5), size=L, replace=False))
+    logits[:, :, C - 1] += 12
+    for i, p in enumerate(pos):
+        logits[:, p:p + 2, y[i]] += 25
+    lp = torch.log_softmax(torch.tensor(logits), 2).numpy()
+    other = [c for c in range(C - 1) if c not in y][0]
+    lp[1, 200:215, :] = -40.0
+    lp[1, 200:215, other] = 0.0
+    # uniform shifts of a frame do not matter; a frame where the target labels differ by 40 nats does
+    lp[1, 203, y[0]] = 0.0
+    targets = [y.tolist(), y.tolist()]
+    xt = dev(lp)
+    tg = E.CtcTargets(targets, xt.device)
+    ws, nll = E.ctc_forward(xt, tg, C - 1, N.CTC_FAST_CHAIN)
+    rejected = E.ctc_rejected(ws, 2, T, tg.max_len).cpu().tolist()
+    want_loss, want_dx = OR.ctc_loss_grad(lp, targets, C - 1, "none")
+    dx = torch.full_like(xt, float("nan"))
+    coef = torch.full((2,), -0.5, device="cuda")
+    E.ctc_grad(xt, tg, C - 1, ws, nll, coef, None, dx)
+    assert float(nll.mean()) == pytest.approx(want_loss, rel=RTOL)
+    close(dx, want_dx)
+    assert rejected[1] == 1  # the damaged utterance must not be served by the fast chain
 
 
 def test_ctc_infeasible_and_minus_inf(crit):
