@@ -56,11 +56,6 @@ __device__ __forceinline__ float wave_shl1(float v, float fill) {
 // gives 2^-huge = 0: branch-free.  Cost model on gfx950 (measured): 4 cycles per VALU, 16 per
 // transcendental: 4*4 + 2*16 = 48 cycles.  The bare v_max_f32 avoids the two canonicalising
 // v_max x,x,x that fmaxf() costs under IEEE mode (no NaN can reach this point: NaN policy at load).
-__device__ __forceinline__ float vmax(float a, float b) {
-  float m;
-  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
-  return m;
-}
 __device__ __forceinline__ float lse2_b2(float a, float b) {
   const float e = __builtin_amdgcn_exp2f(-fabsf(a - b));
   return vmax(a, b) + __builtin_amdgcn_logf(1.f + e);

@@ -13,6 +13,14 @@
 // workgroup, W held in registers too) and written as per-workgroup partial sums that a second
 // kernel reduces: deterministic, no atomics.  This path is VALU/transcendental-bound (B*T*C^2
 // exp per sweep), not HBM-bound; see DESIGN.md.
+//
+// The log semiring normally does not run those kernels at all: section "probability-domain sweeps"
+// below turns the per-frame LSE over C*C terms into a C x C matrix-vector product in fp32 FMAs
+// (transition matrix exponentiated once, alpha/beta kept as scaled probabilities with an exact
+// power-of-two renormalisation per frame) and checks, per utterance, that nothing left the fp32
+// range; utterances that fail the check are recomputed by the log-domain kernels above.
+#include <type_traits>
+
 #include "device_common.h"
 
 namespace wfl {
@@ -160,9 +168,10 @@ template <int SR>
 __global__ void __launch_bounds__(256)
     dense_chain_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, int ldw,
                        float* __restrict__ alpha, float* __restrict__ beta, int32_t* __restrict__ bptr,
-                       float* __restrict__ logz) {
+                       float* __restrict__ logz, const int32_t* __restrict__ only_flagged) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
+  if (only_flagged && !(only_flagged[2 * b] | only_flagged[2 * b + 1])) return;  // served by the fast sweep
   const int R = C <= NT ? NT / C : 1;
   DenseLds L;
   float* p = (float*)smem;
@@ -195,11 +204,13 @@ __global__ void __launch_bounds__(256)
     dense_grad_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C,
                       const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
                       const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
-                      int accumulate, float* __restrict__ dx, float* __restrict__ partial, int rows_per_block) {
+                      int accumulate, float* __restrict__ dx, float* __restrict__ partial, int rows_per_block,
+                      const int32_t* __restrict__ only_flagged) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ap = (float*)smem;  // [C] alpha_{t-1}
   float* xb = ap + C;        // [C] x_t + beta_t - logZ
   const int b = blockIdx.y, tid = threadIdx.x, NT = 256;
+  if (only_flagged && !(only_flagged[2 * b] | only_flagged[2 * b + 1])) return;
   const float g0 = gout ? gout[0] : 1.f;
   const float cf = (coef ? coef[b] : 1.f) * g0;
   const float cw = (coef_w ? coef_w[b] : 1.f) * g0;
@@ -260,13 +271,36 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// dW[i] += sum_k partial[k][i]: 32 elements x 8 slices of the partials per workgroup, merged in LDS
+// in a fixed order (deterministic)
 __global__ void __launch_bounds__(256)
     dense_reduce_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ dW) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;
   float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += partial[(int64_t)k * n + i];
-  dW[i] += s;
+  if (i < n) {
+    const int per = (nblk + 7) / 8;
+    const int k0 = g * per, k1 = min(nblk, k0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+      s0 += partial[(int64_t)k * n + i];
+      s1 += partial[(int64_t)(k + 1) * n + i];
+      s2 += partial[(int64_t)(k + 2) * n + i];
+      s3 += partial[(int64_t)(k + 3) * n + i];
+    }
+    for (; k < k1; ++k) s0 += partial[(int64_t)k * n + i];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float t = red[0][e];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += red[q][e];
+    dW[i] += t;
+  }
 }
 
 __global__ void dense_backtrace_kernel(const float* __restrict__ alpha, const int32_t* __restrict__ bptr, int B, int T,
@@ -283,6 +317,398 @@ __global__ void dense_backtrace_kernel(const float* __restrict__ alpha, const in
     out[t] = cur;
     if (t > 0) cur = bptr[((int64_t)b * T + t) * C + cur];
     if (cur < 0) cur = 0;  // unreachable state (all -inf): keep the path well-formed
+  }
+}
+
+// =================================================================================================
+// Probability-domain sweeps (log semiring, C <= 128)
+//
+//   P[i][j]     = 2^((W[1+i][j] - rowmax_i) * log2 e)                     in (0, 1], rows of the thread
+//   e_t[i]      = 2^((x[t,i] + rowmax_i) * log2 e - mx2_t)                mx2_t = max_i of the exponent
+//   a~_t[i]     = e_t[i] * 2^-kk_{t-1} * sum_j P[i][j] a~_{t-1}[j]        (alpha; beta is the transpose)
+//   alpha_t[i]  = a~_t[i] * 2^(E_t + M_t),   E_t = sum kk (int),  M_t = sum mx2 (double)
+//
+// kk_{t-1} is the exponent that brings max_j a~_{t-1}[j] into [2^29, 2^30): an exact scaling.  One
+// workgroup per (utterance, direction): waves 0-1 own one state per lane and keep their row (alpha)
+// or column (beta) of P in registers, the frame vector is broadcast through LDS (ds_read_b128), one
+// barrier per frame; wave 2 runs ahead, turning emission rows into e_t / mx2_t in an LDS ring.
+// Range check: every stored a~ / b~ must stay >= 2^-95 (and finite) and every finite transition
+// within 2^-60 of its row maximum; otherwise the utterance is flagged and the log-domain kernels
+// recompute it (flag[b][dir]).
+// =================================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kNormExp = 30;
+constexpr float kFloor = 0x1p-95f;
+constexpr float kHardGap = 60.f;
+
+struct DenseWs {
+  double* M;      // [B][2][T]  cumulative emission offsets (log2), indexed by frame
+  double* z2;     // [B]        log2 Z
+  int32_t* E;     // [B][2][T]  cumulative renormalisation exponents, indexed by frame
+  float* mx2;     // [B][T]     per-frame emission offset (log2) for t >= 1
+  float* wr2;     // [128]      row maxima of W[1:, :] in log2 units
+  int32_t* flag;  // [B][2]     1: the fast sweep could not represent this utterance
+};
+
+__host__ __device__ inline DenseWs dense_ws_carve(void* ws, int B, int T) {
+  DenseWs w;
+  char* p = (char*)ws;
+  w.M = (double*)p, p += (size_t)8 * B * 2 * T;
+  w.z2 = (double*)p, p += (size_t)8 * B;
+  w.E = (int32_t*)p, p += (size_t)4 * B * 2 * T;
+  w.mx2 = (float*)p, p += (size_t)4 * B * T;
+  w.wr2 = (float*)p, p += (size_t)4 * 128;
+  w.flag = (int32_t*)p;
+  return w;
+}
+static size_t dense_ws_bytes(int B, int T) {
+  return (size_t)8 * B * 2 * T + (size_t)8 * B + (size_t)4 * B * 2 * T + (size_t)4 * B * T + 4 * 128 + (size_t)8 * B + 64;
+}
+
+template <int CP>
+struct FastLds {
+  float vec[2][CP];  // frame vector broadcast to all lanes (ping-pong)
+  float eh[4][CP];   // ring of e_t rows staged by the helper wave
+  float wr2[CP];
+  float st2[CP];     // start weights W[0, :] in log2 units
+  float wmax[2][2];  // per buffer, per chain wave: maximum of the vector
+  float wsum[2];
+  double mtot;
+};
+
+template <int CP, int DIR>
+__device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, const float* __restrict__ W, int T, int C,
+                                                 void* wsp, int B, float* __restrict__ out, float* __restrict__ logz,
+                                                 FastLds<CP>& L) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const DenseWs ws = dense_ws_carve(wsp, B, T);
+  const float* xb = x + (int64_t)b * T * C;
+  float* ob = out + (int64_t)b * T * C;
+  double* Mb = ws.M + ((int64_t)b * 2 + DIR) * T;
+  int32_t* Eb = ws.E + ((int64_t)b * 2 + DIR) * T;
+
+  // ---- row maxima of the transition matrix (one wave per row), start weights
+  for (int i = wave; i < CP; i += 3) {
+    float m = WFL_NEG_INF;
+    if (i < C)
+      for (int j = lane; j < C; j += 64) m = fmaxf(m, W[(1 + i) * C + j]);
+    m = wave_all_max(m);
+    if (lane == 0) L.wr2[i] = i < C ? m * kLog2e : 0.f;
+  }
+  for (int i = tid; i < CP; i += 192) L.st2[i] = i < C ? nan_to_neg(W[i]) * kLog2e : WFL_NEG_INF;
+  __syncthreads();
+  if (b == 0 && DIR == 0)
+    for (int i = tid; i < C; i += 192) ws.wr2[i] = L.wr2[i];
+
+  // ---- chain waves: this state's row (alpha) / column (beta) of P
+  const int q = tid;  // state of a chain lane
+  f32x2 P[CP / 2];    // pairs: the matrix-vector product issues v_pk_fma_f32
+  int hard = 0;
+  if (wave < 2) {
+#pragma unroll
+    for (int j = 0; j < CP; ++j) {
+      float p = 0.f;
+      if (q < C && j < C) {
+        const float w = DIR == 0 ? W[(1 + q) * C + j] : W[(1 + j) * C + q];
+        const float d = w * kLog2e - (DIR == 0 ? L.wr2[q] : L.wr2[j]);
+        hard |= !(d >= -kHardGap);  // -inf, NaN, +inf rows, or a dynamic range the floor check cannot vouch for
+        p = __builtin_amdgcn_exp2f(d);
+      }
+      P[j >> 1][j & 1] = p;
+    }
+  }
+  if (__syncthreads_or(hard)) {
+    if (tid == 0) ws.flag[2 * b + DIR] = 1;
+    return;
+  }
+
+  // ---- helper wave state: lanes cover states lane and lane + 64
+  // item r is the emission row the chain multiplies in at step r: frame r (alpha), frame T - r (beta)
+  const bool has1 = lane + 64 < CP;
+  const float add0 = L.wr2[lane < CP ? lane : 0], add1 = L.wr2[has1 ? lane + 64 : 0];
+  float raw[4][2];
+  double mrun = 0.0;
+  auto item_ok = [&](int r) { return DIR == 0 ? r < T : (r >= 1 && r < T); };
+  auto issue = [&](int r, float (&dst)[2]) {
+    if (!item_ok(r)) return;
+    const float* row = xb + (int64_t)(DIR == 0 ? r : T - r) * C;
+    dst[0] = lane < C ? row[lane] : WFL_NEG_INF;
+    dst[1] = lane + 64 < C ? row[lane + 64] : WFL_NEG_INF;
+  };
+  // CHECKED = false: the caller guarantees 3 <= r and that the item exists (no branches: the main loop
+  // must stay straight-line so that the loads of later items stay in flight across this one's use)
+  auto stage = [&](int r, const float (&src)[2], auto checked) {
+    constexpr bool CHECKED = decltype(checked)::value;
+    if (CHECKED && !item_ok(r)) {
+      if (DIR == 1 && r == 0 && lane == 0) Mb[T - 1] = 0.0;
+      return;
+    }
+    const bool first = CHECKED && DIR == 0 && r == 0;
+    const float s0 = lane < C ? fmaf(nan_to_neg(src[0]), kLog2e, first ? L.st2[lane] : add0) : WFL_NEG_INF;
+    const float s1 = lane + 64 < C ? fmaf(nan_to_neg(src[1]), kLog2e, first ? L.st2[lane + 64] : add1) : WFL_NEG_INF;
+    const float m = wave_all_max(vmax(s0, s1));
+    float* dst = L.eh[r & 3];
+    if (lane < CP) dst[lane] = lane < C ? __builtin_amdgcn_exp2f(s0 - m) : 0.f;
+    if (has1) dst[lane + 64] = lane + 64 < C ? __builtin_amdgcn_exp2f(s1 - m) : 0.f;
+    mrun += (double)m;
+    if (lane == 0) {
+      Mb[DIR == 0 ? r : T - 1 - r] = mrun;
+      if (DIR == 0) ws.mx2[(int64_t)b * T + r] = m;
+    }
+  };
+  auto issue_fast = [&](int r, float (&dst)[2]) {  // the item exists
+    const float* row = xb + (int64_t)(DIR == 0 ? r : T - r) * C;
+    dst[0] = row[lane < C ? lane : 0];
+    dst[1] = row[lane + 64 < C ? lane + 64 : 0];
+  };
+  const std::true_type kChecked;
+  const std::false_type kUnchecked;
+
+  // ---- chain wave state
+  int ecum = 0, bad = 0;
+  float last = 0.f;
+  auto publish = [&](float v, int buf) {  // vector element for the next step + its wave maximum
+    if (q < CP) L.vec[buf][q] = v;
+    const float wm = wave_reduce_max_lane63(v);
+    if (lane == 63) L.wmax[buf][wave] = wm;
+  };
+  auto chain_step = [&](int n) {  // n >= 1
+    const int cur = (n - 1) & 1;
+    const float mx = fmaxf(L.wmax[cur][0], L.wmax[cur][1]);
+    const int kk = __builtin_amdgcn_frexp_expf(mx) - kNormExp;
+    const float inv = __builtin_amdgcn_ldexpf(1.f, -kk);
+    ecum += kk;
+    const float4* v4 = reinterpret_cast<const float4*>(L.vec[cur]);
+    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < CP / 4; ++j) {
+      const float4 v = v4[j];
+      a0 = __builtin_elementwise_fma(P[2 * j], f32x2{v.x, v.y}, a0);
+      a1 = __builtin_elementwise_fma(P[2 * j + 1], f32x2{v.z, v.w}, a1);
+    }
+    const float y = inv * ((a0[0] + a0[1]) + (a1[0] + a1[1]));
+    const int t = DIR == 0 ? n : T - 1 - n;
+    float val, next;
+    if (DIR == 0) {
+      val = L.eh[n & 3][q < CP ? q : 0] * y;
+      next = val;
+    } else {
+      val = y;
+      next = n + 1 < T ? L.eh[(n + 1) & 3][q < CP ? q : 0] * y : 0.f;
+    }
+    if (q < C) {
+      bad |= !(val >= kFloor && val < 3.0e38f);
+      ob[(int64_t)t * C + q] = val;
+    }
+    if (tid == 0) Eb[t] = ecum;
+    last = val;
+    publish(next, cur ^ 1);
+  };
+
+  // ---- prologue: items 0 and 1 staged synchronously, items 2..5 in flight
+  if (wave == 2) {
+    issue(0, raw[0]);
+    issue(1, raw[1]);
+    stage(0, raw[0], kChecked);
+    stage(1, raw[1], kChecked);
+    issue(2, raw[2]);
+    issue(3, raw[3]);
+    issue(4, raw[0]);
+    issue(5, raw[1]);
+  }
+  __syncthreads();
+  // ---- intervals: interval n ends with barrier n; the chain performs step n, the helper stages
+  // item n + 2 and issues the loads of item n + 6.  Role-specialised loops with the same barrier count.
+  const int n_main = T >= 12 ? 1 + ((T - 10) / 4) * 4 : 1;  // main loop covers n in [1, n_main): items n+6 < T
+  if (wave < 2) {
+    {  // interval 0
+      float val, next;
+      if (DIR == 0) {
+        val = L.eh[0][q < CP ? q : 0];
+        next = val;
+      } else {
+        val = q < C ? 1.f : 0.f;
+        next = T > 1 ? L.eh[1][q < CP ? q : 0] * val : 0.f;
+      }
+      if (q < C) {
+        bad |= !(val >= kFloor && val < 3.0e38f);
+        ob[(int64_t)(DIR == 0 ? 0 : T - 1) * C + q] = val;
+      }
+      if (tid == 0) Eb[DIR == 0 ? 0 : T - 1] = 0;
+      last = val;
+      publish(next, 0);
+    }
+    __syncthreads();
+    for (int n = 1; n < T; ++n) {
+      chain_step(n);
+      __syncthreads();
+    }
+  } else {
+    stage(2, raw[2], kChecked);
+    issue(6, raw[2]);
+    __syncthreads();
+    int n = 1;
+    for (; n < n_main; n += 4) {  // items n+2 .. n+9 exist
+      stage(n + 2, raw[3], kUnchecked);
+      issue_fast(n + 6, raw[3]);
+      __syncthreads();
+      stage(n + 3, raw[0], kUnchecked);
+      issue_fast(n + 7, raw[0]);
+      __syncthreads();
+      stage(n + 4, raw[1], kUnchecked);
+      issue_fast(n + 8, raw[1]);
+      __syncthreads();
+      stage(n + 5, raw[2], kUnchecked);
+      issue_fast(n + 9, raw[2]);
+      __syncthreads();
+    }
+    for (; n < T; ++n) {  // tail: synchronous, checked
+      float tmp[2] = {WFL_NEG_INF, WFL_NEG_INF};
+      issue(n + 2, tmp);
+      stage(n + 2, tmp, kChecked);
+      __syncthreads();
+    }
+  }
+  // ---- epilogue: range verdict; log Z from the last alpha vector
+  const int any_bad = __syncthreads_or(bad);
+  if (DIR == 0) {
+    if (wave < 2) {
+      const float s = wave_all_sum(q < C ? last : 0.f);
+      if (lane == 0) L.wsum[wave] = s;
+    } else if (lane == 0) {
+      L.mtot = mrun;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const double z2 = L.mtot + (double)ecum + (double)__builtin_amdgcn_logf(L.wsum[0] + L.wsum[1]);
+      ws.z2[b] = z2;
+      logz[b] = (float)(z2 * 0.6931471805599453);
+    }
+  }
+  if (tid == 0) ws.flag[2 * b + DIR] = any_bad ? 1 : 0;
+}
+
+template <int CP>
+__global__ void __launch_bounds__(192)
+    dense_fast_chain_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, void* wsp, int B,
+                            float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz) {
+  __shared__ __attribute__((aligned(16))) FastLds<CP> L;
+  if (blockIdx.y == 0) {
+    if (!beta && threadIdx.x == 0) dense_ws_carve(wsp, B, T).flag[2 * blockIdx.x + 1] = 0;
+    dense_fast_sweep<CP, 0>(x, W, T, C, wsp, B, alpha, logz, L);
+  } else {
+    dense_fast_sweep<CP, 1>(x, W, T, C, wsp, B, beta, nullptr, L);
+  }
+}
+
+// gradient of the fast sweeps.  Emission gradient: dx[t,i] = cf * a~_t[i] b~_t[i] 2^(La_t + Lb_t - z2).
+// Transition gradient: dW[1+i][j] = P[i][j] * sum_t a~_{t-1}[j] * (e_t[i] b~_t[i]) * 2^(La_{t-1} + mx2_t
+// + Lb_t - z2): an outer-product accumulation over frames, 8x8 register tile per thread, operands
+// staged in LDS eight frames at a time; the power of two is split evenly over both operands so
+// that neither leaves the fp32 range.  Per-workgroup partial sums, reduced by dense_reduce_kernel.
+template <int CP>
+__global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
+    dense_fast_grad_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, int B,
+                           const float* __restrict__ alpha, const float* __restrict__ beta, const void* wsp,
+                           const float* __restrict__ coef, const float* __restrict__ coef_w,
+                           const float* __restrict__ gout, int accumulate, float* __restrict__ dx,
+                           float* __restrict__ partial, int rows_per_block) {
+  constexpr int G = CP / 8, NT = (G * G + 63) / 64 * 64, TS = 8;
+  __shared__ __attribute__((aligned(16))) float A[TS][CP];
+  __shared__ __attribute__((aligned(16))) float U[TS][CP];
+  __shared__ float sc[TS][4];
+  __shared__ float wr2[CP], s0[CP];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const DenseWs ws = dense_ws_carve(const_cast<void*>(wsp), B, T);
+  if (ws.flag[2 * b] | ws.flag[2 * b + 1]) return;  // recomputed by the log-domain kernels
+  const float g0 = gout ? gout[0] : 1.f;
+  const float cf = (coef ? coef[b] : 1.f) * g0;
+  const float cw = (coef_w ? coef_w[b] : 1.f) * g0;
+  const double z2 = ws.z2[b];
+  const double *Ma = ws.M + (int64_t)b * 2 * T, *Mb = Ma + T;
+  const int32_t *Ea = ws.E + (int64_t)b * 2 * T, *Eb = Ea + T;
+  const int t_begin = blockIdx.x * rows_per_block, t_end = min(T, t_begin + rows_per_block);
+  const int64_t base = (int64_t)b * T * C;
+  for (int i = tid; i < CP; i += NT) wr2[i] = i < C ? ws.wr2[i] : 0.f, s0[i] = 0.f;
+  const int ti = tid / G, tj = tid - ti * G;
+  const bool active = tid < G * G && partial;
+  float acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  for (int t0 = t_begin; t0 < t_end; t0 += TS) {
+    const int nr = min(TS, t_end - t0);
+    __syncthreads();
+    if (tid < nr) {
+      const int t = t0 + tid;
+      const double lb = Mb[t] + (double)Eb[t];
+      const float eg = (float)(Ma[t] + (double)Ea[t] + lb - z2);
+      const float m2 = ws.mx2[(int64_t)b * T + t];
+      float ex = WFL_NEG_INF;
+      if (t > 0) ex = (float)(Ma[t - 1] + (double)Ea[t - 1] + (double)m2 + lb - z2);
+      sc[tid][0] = __builtin_amdgcn_exp2f(0.5f * eg);
+      sc[tid][1] = __builtin_amdgcn_exp2f(0.5f * ex);
+      sc[tid][2] = m2;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nr * CP; idx += NT) {
+      const int r = idx / CP, i = idx - r * CP;
+      const int t = t0 + r;
+      float uu = 0.f, aa = 0.f;
+      if (i < C) {
+        const int64_t o = base + (int64_t)t * C + i;
+        const float a = alpha[o], be = beta[o];
+        const float hg = sc[r][0], hx = sc[r][1];
+        const float g = (a * hg) * (be * hg);
+        if (dx) dx[o] = (accumulate ? dx[o] : 0.f) + cf * g;
+        if (partial) {
+          if (t > 0) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(nan_to_neg(x[o]), kLog2e, wr2[i]) - sc[r][2]);
+            uu = e * be * hx * cw;
+            aa = alpha[o - C] * hx;
+          } else {
+            s0[i] = g * cw;
+          }
+        }
+      }
+      U[r][i] = uu, A[r][i] = aa;
+    }
+    __syncthreads();
+    if (active) {
+      for (int r = 0; r < nr; ++r) {
+        const float4 u0 = *reinterpret_cast<const float4*>(&U[r][8 * ti]);
+        const float4 u1 = *reinterpret_cast<const float4*>(&U[r][8 * ti + 4]);
+        const float4 a0 = *reinterpret_cast<const float4*>(&A[r][8 * tj]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&A[r][8 * tj + 4]);
+        const float u[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(u[i], a[j], acc[i][j]);
+      }
+    }
+  }
+  if (partial) {
+    __syncthreads();
+    float* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(C + 1) * C;
+    for (int i = tid; i < C; i += NT) dst[i] = s0[i];
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int si = 8 * ti + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int sj = 8 * tj + j;
+          if (si < C && sj < C) {
+            const float p = __builtin_amdgcn_exp2f(W[(1 + si) * C + sj] * kLog2e - wr2[si]);
+            dst[(1 + si) * C + sj] = acc[i][j] * p;
+          }
+        }
+      }
+    }
   }
 }
 
@@ -307,8 +733,11 @@ static int dense_check(const float* x, const float* W, int B, int T, int C, cons
   return WFL_OK;
 }
 
+// smallest instantiated padded class count >= C (0: no fast path)
+static int dense_fast_cp(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 104 ? 104 : C <= 128 ? 128 : 0; }
+
 int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int semiring, float* alpha, float* beta,
-                      int32_t* bptr, float* logz, void* stream) {
+                      int32_t* bptr, float* logz, void* ws, void* stream) {
   if (int rc = dense_check(x, W, B, T, C, "dense_forward")) return rc;
   if (!alpha) {
     set_error("dense_forward: alpha is required");
@@ -316,12 +745,33 @@ int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int s
   }
   const int ldw = C | 1;
   const size_t lds = dense_chain_lds(C, ldw);
+  hipStream_t st = (hipStream_t)stream;
   if (semiring == WFL_SEMIRING_LOG) {
+    if (!ws || !logz) {
+      set_error("dense_forward: the log semiring needs logz and a workspace (wfl_dense_workspace)");
+      return WFL_ERR_INVALID;
+    }
+    const int cp = dense_fast_cp(C);
+    const DenseWs w = dense_ws_carve(ws, B, T);
+    const dim3 grid((unsigned)B, beta ? 2u : 1u);
+#define WFL_FAST_CHAIN(CP) \
+  hipLaunchKernelGGL(dense_fast_chain_kernel<CP>, grid, dim3(192), 0, st, x, W, T, C, ws, B, alpha, beta, logz)
+    if (cp == 32)
+      WFL_FAST_CHAIN(32);
+    else if (cp == 64)
+      WFL_FAST_CHAIN(64);
+    else if (cp == 104)
+      WFL_FAST_CHAIN(104);
+    else if (cp == 128)
+      WFL_FAST_CHAIN(128);
+#undef WFL_FAST_CHAIN
+    WFL_LAUNCH_CHECK();
+    // log-domain sweep: everything when there is no fast path, otherwise only flagged utterances
     auto k = dense_chain_kernel<WFL_SEMIRING_LOG>;
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)B, beta ? 2u : 1u), dim3(256), lds, (hipStream_t)stream, x, W, T, C, ldw,
-                       alpha, beta, (int32_t*)nullptr, logz);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, W, T, C, ldw, alpha, beta, (int32_t*)nullptr, logz,
+                       cp ? (const int32_t*)w.flag : (const int32_t*)nullptr);
   } else {
     if (!bptr) {
       set_error("dense_forward: tropical semiring needs a back-pointer buffer");
@@ -330,39 +780,57 @@ int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int s
     auto k = dense_chain_kernel<WFL_SEMIRING_TROPICAL>;
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)B, 1u), dim3(256), lds, (hipStream_t)stream, x, W, T, C, ldw, alpha,
-                       (float*)nullptr, bptr, logz);
+    hipLaunchKernelGGL(k, dim3((unsigned)B, 1u), dim3(256), lds, st, x, W, T, C, ldw, alpha, (float*)nullptr, bptr,
+                       logz, (const int32_t*)nullptr);
   }
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }
 
-int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems) {
-  if (B <= 0 || T <= 0 || C <= 0 || !partial_elems) {
+int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws_bytes) {
+  if (B <= 0 || T <= 0 || C <= 0) {
     set_error("dense_workspace: bad arguments");
     return WFL_ERR_INVALID;
   }
-  *partial_elems = (int64_t)B * dense_chunks(B, T) * (int64_t)(C + 1) * C;
+  if (partial_elems) *partial_elems = (int64_t)B * dense_chunks(B, T) * (int64_t)(C + 1) * C;
+  if (ws_bytes) *ws_bytes = (int64_t)dense_ws_bytes(B, T);
   return WFL_OK;
 }
 
 int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const float* alpha, const float* beta,
                    const float* logz, const float* coef, const float* coef_w, const float* gout, int accumulate,
-                   float* dx, float* dW, float* dW_partial, void* stream) {
+                   float* dx, float* dW, float* dW_partial, const void* ws, void* stream) {
   if (int rc = dense_check(x, W, B, T, C, "dense_grad")) return rc;
-  if (!alpha || !beta || !logz || (!dx && !dW) || (dW && !dW_partial)) {
+  if (!alpha || !beta || !logz || !ws || (!dx && !dW) || (dW && !dW_partial)) {
     set_error("dense_grad: missing buffers");
     return WFL_ERR_INVALID;
   }
+  hipStream_t st = (hipStream_t)stream;
   const int chunks = dense_chunks(B, T);
   const int rows = (T + chunks - 1) / chunks;
   const int np = (C * C + 255) / 256;
   const size_t lds = 8 * (size_t)C + 64;
   dim3 grid((unsigned)chunks, (unsigned)B);
   float* part = dW ? dW_partial : nullptr;
-#define WFL_DENSE_GRAD(NP)                                                                                         \
-  hipLaunchKernelGGL(dense_grad_kernel<NP>, grid, dim3(256), lds, (hipStream_t)stream, x, W, T, C, alpha, beta,    \
-                     logz, coef, coef_w, gout, accumulate, dx, part, rows)
+  const int cp = dense_fast_cp(C);
+  const int32_t* flags = cp ? dense_ws_carve(const_cast<void*>(ws), B, T).flag : nullptr;
+#define WFL_FAST_GRAD(CP)                                                                                       \
+  hipLaunchKernelGGL(dense_fast_grad_kernel<CP>, grid, dim3(((CP / 8) * (CP / 8) + 63) / 64 * 64), 0, st, x, W, \
+                     T, C, B, alpha, beta, ws, coef, coef_w, gout, accumulate, dx, part, rows)
+  if (cp == 32)
+    WFL_FAST_GRAD(32);
+  else if (cp == 64)
+    WFL_FAST_GRAD(64);
+  else if (cp == 104)
+    WFL_FAST_GRAD(104);
+  else if (cp == 128)
+    WFL_FAST_GRAD(128);
+#undef WFL_FAST_GRAD
+  WFL_LAUNCH_CHECK();
+  // log-domain gradient for what the fast sweeps did not serve
+#define WFL_DENSE_GRAD(NP)                                                                                 \
+  hipLaunchKernelGGL(dense_grad_kernel<NP>, grid, dim3(256), lds, st, x, W, T, C, alpha, beta, logz, coef, \
+                     coef_w, gout, accumulate, dx, part, rows, flags)
   if (np <= 4)
     WFL_DENSE_GRAD(4);
   else if (np <= 16)
@@ -381,8 +849,8 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
   WFL_LAUNCH_CHECK();
   if (dW) {
     const int n = (C + 1) * C;
-    hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       dW_partial, B * chunks, n, dW);
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, dW_partial, B * chunks,
+                       n, dW);
     WFL_LAUNCH_CHECK();
   }
   return WFL_OK;
@@ -394,7 +862,8 @@ int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float
     set_error("dense_viterbi: path is required");
     return WFL_ERR_INVALID;
   }
-  if (int rc = wfl_dense_forward(x, W, B, T, C, WFL_SEMIRING_TROPICAL, alpha, nullptr, bptr, nullptr, stream)) return rc;
+  if (int rc = wfl_dense_forward(x, W, B, T, C, WFL_SEMIRING_TROPICAL, alpha, nullptr, bptr, nullptr, nullptr, stream))
+    return rc;
   hipLaunchKernelGGL(dense_backtrace_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, alpha,
                      bptr, B, T, C, path);
   WFL_LAUNCH_CHECK();

@@ -33,7 +33,9 @@ constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kLdsBytes = 160 * 1024;  // per CU (and per workgroup) on MI355X
 
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-__device__ __forceinline__ float fast_log(float x) { return __logf(x); }
+// every call site passes a sum of exponentials relative to their maximum (>= 1): no denormal
+// inputs, so the bare v_log_f32 (log2) is enough
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }
 
 // NaN policy: a NaN score is an impossible arc.
 __device__ __forceinline__ float nan_to_neg(float v) { return (v != v) ? WFL_NEG_INF : v; }
@@ -55,13 +57,20 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f32(float identity, float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
+// bare v_max_f32: fmaxf() also emits a canonicalising v_max x,x,x per operand, which matters on
+// latency-bound chains.  NaN operands: returns the other operand (IEEE mode), like fmaxf.
+__device__ __forceinline__ float vmax(float a, float b) {
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+  return m;
+}
 __device__ __forceinline__ float wave_reduce_max_lane63(float v) {
-  v = fmaxf(v, dpp_f32<0x111, 0xf>(WFL_NEG_INF, v));  // row_shr:1
-  v = fmaxf(v, dpp_f32<0x112, 0xf>(WFL_NEG_INF, v));  // row_shr:2
-  v = fmaxf(v, dpp_f32<0x114, 0xf>(WFL_NEG_INF, v));  // row_shr:4
-  v = fmaxf(v, dpp_f32<0x118, 0xf>(WFL_NEG_INF, v));  // row_shr:8
-  v = fmaxf(v, dpp_f32<0x142, 0xa>(WFL_NEG_INF, v));  // row_bcast:15 -> rows 1,3
-  v = fmaxf(v, dpp_f32<0x143, 0xc>(WFL_NEG_INF, v));  // row_bcast:31 -> rows 2,3
+  v = vmax(v, dpp_f32<0x111, 0xf>(WFL_NEG_INF, v));  // row_shr:1
+  v = vmax(v, dpp_f32<0x112, 0xf>(WFL_NEG_INF, v));  // row_shr:2
+  v = vmax(v, dpp_f32<0x114, 0xf>(WFL_NEG_INF, v));  // row_shr:4
+  v = vmax(v, dpp_f32<0x118, 0xf>(WFL_NEG_INF, v));  // row_shr:8
+  v = vmax(v, dpp_f32<0x142, 0xa>(WFL_NEG_INF, v));  // row_bcast:15 -> rows 1,3
+  v = vmax(v, dpp_f32<0x143, 0xc>(WFL_NEG_INF, v));  // row_bcast:31 -> rows 2,3
   return v;
 }
 __device__ __forceinline__ float wave_reduce_sum_lane63(float v) {

@@ -102,8 +102,7 @@ struct ChainLds {
   int* eptr;    // [Q+1]
   float* buf0;  // [Q]
   float* buf1;  // [Q]
-  float* row0;  // [K]
-  float* row1;  // [K]
+  float* rows;  // [2][R][Kmax] emission rows of the current / next chunk of R frames
   float* red;   // [64]
   int* lvl;     // [nlev+1]
 };
@@ -129,26 +128,59 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
   return r;
 }
 
-// one relaxation of state q over its labelled arcs k0..k1 (values read from `from`)
-template <int SR>
-__device__ __forceinline__ void relax_labelled(const ChainLds& L, const float* from, const float* row, int k0, int k1,
-                                               float& val, int& arg) {
-  float m = WFL_NEG_INF;
-  int am = -1;
-  for (int k = k0; k < k1; ++k) {
-    const int2 a = L.arcs[k];
-    const float v = from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
-    if (v > m) m = v, am = k;
+// One relaxation of a state over its labelled in-arcs (values read from `from`).  The first four
+// arcs are independent LDS chains whose terms stay in registers (most states of the criteria's
+// acceptors have in-degree <= 4); longer lists continue with a streaming max / rescale loop over
+// LDS arcs [kt0, kt1).  `k0` is the CSR index of the first arc (for Viterbi back-pointers).
+struct Arc4 {
+  int other[4], slot[4];
+  float w[4];
+};
+
+__device__ __forceinline__ Arc4 load_arc4(const int2* arcs, int k0, int k1) {
+  Arc4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool ok = k0 + i < k1;
+    const int2 a = ok ? arcs[k0 + i] : make_int2(0, __float_as_int(WFL_NEG_INF));
+    r.other[i] = a.x & 0xffff, r.slot[i] = (unsigned)a.x >> 16, r.w[i] = __int_as_float(a.y);
   }
+  return r;
+}
+
+template <int SR>
+__device__ __forceinline__ void relax_labelled(const ChainLds& L, const Arc4& a4, const float* from, const float* row,
+                                               int k0, int kt0, int kt1, float& val, int& arg) {
+  const float v0 = from[a4.other[0]] + row[a4.slot[0]] + a4.w[0];
+  const float v1 = from[a4.other[1]] + row[a4.slot[1]] + a4.w[1];
+  const float v2 = from[a4.other[2]] + row[a4.slot[2]] + a4.w[2];
+  const float v3 = from[a4.other[3]] + row[a4.slot[3]] + a4.w[3];
+  float m = v0;
+  int am = v0 > WFL_NEG_INF ? k0 : -1;
+  if (v1 > m) m = v1, am = k0 + 1;
+  if (v2 > m) m = v2, am = k0 + 2;
+  if (v3 > m) m = v3, am = k0 + 3;
+  auto term = [&](int k) {
+    const int2 a = L.arcs[k];
+    return from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
+  };
   if (SR == WFL_SEMIRING_LOG) {
-    if (m > WFL_NEG_INF && k1 - k0 > 1) {
-      float s = 0.f;
-      for (int k = k0; k < k1; ++k) {
-        const int2 a = L.arcs[k];
-        const float v = from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
+    float s = 0.f;
+    if (m > WFL_NEG_INF) s = fast_exp(v0 - m) + fast_exp(v1 - m) + fast_exp(v2 - m) + fast_exp(v3 - m);
+    for (int k = kt0; k < kt1; ++k) {
+      const float v = term(k);
+      if (v > m) {
+        s = s * fast_exp(m - v) + 1.f;  // m == -inf: s is 0 and exp(-inf) = 0
+        m = v;
+      } else if (v > WFL_NEG_INF) {
         s += fast_exp(v - m);
       }
-      m += fast_log(s);
+    }
+    if (m > WFL_NEG_INF) m += fast_log(s);
+  } else {
+    for (int k = kt0; k < kt1; ++k) {
+      const float v = term(k);
+      if (v > m) m = v, am = k;
     }
   }
   val = m, arg = am;
@@ -178,12 +210,14 @@ __device__ __forceinline__ void relax_eps(const ChainLds& L, float* vals, int q,
   val = m, arg = am;
 }
 
+constexpr int kPre = 8;  // prefetch registers per thread: rows_per_chunk * max_labels <= kPre * blockDim
+
 template <int SR, int DIR>
-__device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const ChainLds& L, int T,
+__device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const ChainLds& L, int T, int rows_per_chunk,
                           const float* __restrict__ xg, const float* __restrict__ weights, float* __restrict__ out,
                           int32_t* __restrict__ bptr, float* __restrict__ logz, int b) {
   const int tid = threadIdx.x, NT = blockDim.x;
-  const int Q = u.Q, A = u.A, E = u.E, K = u.K, nlev = u.nlev, Kmax = d.max_labels;
+  const int Q = u.Q, A = u.A, E = u.E, nlev = u.nlev, Kmax = d.max_labels;
   // ---- stage the acceptor into LDS in this direction's CSR order
   for (int k = tid; k < A; k += NT) {
     const int a = DIR == 0 ? k : u.out_arc[k];
@@ -231,50 +265,85 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
     if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + q] = -1;
   }
   closure(cur, t_first);
-  // first emissions row
-  const int t_row0 = DIR == 0 ? 0 : T - 1;
-  if (T > 0) {
-    float* r = (t_row0 & 1) ? L.row1 : L.row0;
-    for (int k = tid; k < K; k += NT) r[k] = xg[u.xg_base + (int64_t)t_row0 * Kmax + k];
-  }
   __syncthreads();
   for (int q = tid; q < Q; q += NT) out[u.ab_base + (int64_t)t_first * Q + q] = cur[q];
 
-  for (int step = 0; step < T; ++step) {
-    // forward: consume frame t = step, produce slot t+1.  backward: consume frame t = T-1-step, produce slot t.
-    const int t = DIR == 0 ? step : T - 1 - step;
-    const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
-    const float* from = (slot_from & 1) ? L.buf1 : L.buf0;
-    float* to = (slot_to & 1) ? L.buf1 : L.buf0;
-    const float* row = (t & 1) ? L.row1 : L.row0;
-    const int tn = DIR == 0 ? t + 1 : t - 1;  // next frame to be consumed
-    const bool has_next = DIR == 0 ? (tn < T) : (tn >= 0);
-    float pre[4];
-    if (has_next) {
+  // Emission rows travel HBM -> registers -> LDS one chunk of R frames ahead of the chain: the loads
+  // of chunk c+1 are issued before the first frame of chunk c and land in LDS after its last frame,
+  // so their latency is paid once per R frames instead of once per frame.  A chunk is a contiguous
+  // slab of xg (R rows of pitch Kmax) in both directions; the backward sweep walks it downwards.
+  const int R = rows_per_chunk;
+  const int nchunks = (T + R - 1) / R;
+  auto chunk_frames = [&](int c, int& f0, int& n) {  // frames [f0, f0+n) in ascending order
+    const int s0 = c * R;
+    n = min(R, T - s0);
+    f0 = DIR == 0 ? s0 : T - s0 - n;
+  };
+  if (T > 0) {
+    int f0, n;
+    chunk_frames(0, f0, n);
+    const float* src = xg + u.xg_base + (int64_t)f0 * Kmax;
+    for (int e = tid; e < n * Kmax; e += NT) L.rows[e] = src[e];
+  }
+  __syncthreads();
+  // one state per thread in the common case: its first four in-arcs live in registers
+  const int kq0 = tid < Q ? L.ptr[tid] : 0, kq1 = tid < Q ? L.ptr[tid + 1] : 0;
+  const Arc4 mine = load_arc4(L.arcs, kq0, kq1);
+  const bool direct = nlev <= 1;  // no epsilon closure: the relaxed value is final
+  for (int c = 0; c < nchunks; ++c) {
+    int f0, n;
+    chunk_frames(c, f0, n);
+    const float* tile = L.rows + (size_t)(c & 1) * R * Kmax;
+    float pre[kPre];
+    int pf0 = 0, pn = 0;
+    if (c + 1 < nchunks) {
+      chunk_frames(c + 1, pf0, pn);
+      const float* src = xg + u.xg_base + (int64_t)pf0 * Kmax;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = tid + j * NT;
-        if (k < K) pre[j] = xg[u.xg_base + (int64_t)tn * Kmax + k];
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) pre[j] = src[e];
       }
     }
-    for (int q = tid; q < Q; q += NT) {
-      float v;
-      int arg;
-      relax_labelled<SR>(L, from, row, L.ptr[q], L.ptr[q + 1], v, arg);
-      to[q] = v;
-      if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
-    }
-    closure(to, slot_to);
-    if (has_next) {
-      float* rn = (tn & 1) ? L.row1 : L.row0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = tid + j * NT;
-        if (k < K) rn[k] = pre[j];
+    for (int i = 0; i < n; ++i) {
+      // forward: consume frame t, produce slot t+1.  backward: consume frame t, produce slot t.
+      const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+      const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
+      const float* from = (slot_from & 1) ? L.buf1 : L.buf0;
+      float* to = (slot_to & 1) ? L.buf1 : L.buf0;
+      const float* row = tile + (size_t)(t - f0) * Kmax;
+      float* orow = out + u.ab_base + (int64_t)slot_to * Q;
+      if (tid < Q) {
+        float v;
+        int arg;
+        relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
+        to[tid] = v;
+        if (direct) orow[tid] = v;
+        if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
       }
+      for (int q = tid + NT; q < Q; q += NT) {
+        float v;
+        int arg;
+        const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
+        relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
+        to[q] = v;
+        if (direct) orow[q] = v;
+        if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+      }
+      closure(to, slot_to);
+      __syncthreads();
+      if (!direct)
+        for (int q = tid; q < Q; q += NT) orow[q] = to[q];
     }
-    __syncthreads();
-    for (int q = tid; q < Q; q += NT) out[u.ab_base + (int64_t)slot_to * Q + q] = to[q];
+    if (c + 1 < nchunks) {
+      float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) dst[e] = pre[j];
+      }
+      __syncthreads();
+    }
   }
   if (DIR == 0 && logz) {
     const float* fin = (T & 1) ? L.buf1 : L.buf0;
@@ -294,9 +363,9 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
 
 template <int SR>
 __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
-                             const float* __restrict__ xg, int T, const float* __restrict__ weights,
-                             float* __restrict__ alpha, float* __restrict__ beta, int32_t* __restrict__ bptr,
-                             float* __restrict__ logz) {
+                             const float* __restrict__ xg, int T, int rows_per_chunk,
+                             const float* __restrict__ weights, float* __restrict__ alpha, float* __restrict__ beta,
+                             int32_t* __restrict__ bptr, float* __restrict__ logz) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, dir = blockIdx.y;
   const UttView u = make_view(d, ints, floats, b, T);
@@ -308,19 +377,18 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
   L.eptr = (int*)p, p += (size_t)(d.max_states + 1) * 4;
   L.buf0 = (float*)p, p += (size_t)d.max_states * 4;
   L.buf1 = (float*)p, p += (size_t)d.max_states * 4;
-  L.row0 = (float*)p, p += (size_t)d.max_labels * 4;
-  L.row1 = (float*)p, p += (size_t)d.max_labels * 4;
+  L.rows = (float*)p, p += (size_t)2 * rows_per_chunk * d.max_labels * 4;
   L.red = (float*)p, p += 64 * 4;
   L.lvl = (int*)p;
   if (dir == 0)
-    run_chain<SR, 0>(d, u, L, T, xg, weights, alpha, bptr, logz, b);
+    run_chain<SR, 0>(d, u, L, T, rows_per_chunk, xg, weights, alpha, bptr, logz, b);
   else
-    run_chain<SR, 1>(d, u, L, T, xg, weights, beta, nullptr, nullptr, b);
+    run_chain<SR, 1>(d, u, L, T, rows_per_chunk, xg, weights, beta, nullptr, nullptr, b);
 }
 
-static size_t chain_lds_bytes(const wfl_lattice_desc& d) {
+static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
   return (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 8 +
-         (size_t)d.max_labels * 8 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 + 64;
+         (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 + 64;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -511,20 +579,22 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     set_error("lattice_forward: %d distinct labels per utterance (limit 1024)", d->max_labels);
     return WFL_ERR_UNSUPPORTED;
   }
-  const size_t lds = chain_lds_bytes(*d);
+  int nt = d->max_states <= 64 ? 64 : (d->max_states <= 128 ? 128 : 256);
+  while (nt < 256 && nt * kPre < d->max_labels) nt += 64;
+  const int rpc = std::max(1, std::min(16, nt * kPre / std::max(1, d->max_labels)));
+  const size_t lds = chain_lds_bytes(*d, rpc);
   if (lds > (size_t)kLdsBytes) {
     set_error("lattice_forward: acceptor needs %zu B of LDS (limit %d): %d arcs, %d states", lds, kLdsBytes,
               d->max_arcs, d->max_states);
     return WFL_ERR_UNSUPPORTED;
   }
-  const int nt = d->max_states <= 64 ? 64 : (d->max_states <= 128 ? 128 : 256);
   if (semiring == WFL_SEMIRING_LOG) {
     dim3 grid((unsigned)d->B, beta ? 2u : 1u);
     auto k = chain_kernel<WFL_SEMIRING_LOG>;
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, weights, alpha, beta,
-                       (int32_t*)nullptr, logz);
+    hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
+                       beta, (int32_t*)nullptr, logz);
   } else if (semiring == WFL_SEMIRING_TROPICAL) {
     if (!bptr) {
       set_error("lattice_forward: tropical semiring needs a back-pointer buffer");
@@ -534,7 +604,7 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     auto k = chain_kernel<WFL_SEMIRING_TROPICAL>;
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, weights, alpha,
+    hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
                        (float*)nullptr, bptr, logz);
   } else {
     set_error("lattice_forward: unknown semiring %d", semiring);

@@ -217,7 +217,13 @@ def reduce_loss(vals, scale, sign=1.0, out=None):
 # dense transitions
 # -------------------------------------------------------------------------------------------------
 class DenseState:
-    __slots__ = ("alpha", "beta", "logz", "B", "T", "C")
+    __slots__ = ("alpha", "beta", "logz", "ws", "B", "T", "C")
+
+
+def _dense_sizes(B, T, C):
+    n, w = ctypes.c_int64(), ctypes.c_int64()
+    N.check(N.lib.wfl_dense_workspace(B, T, C, ctypes.byref(n), ctypes.byref(w)))
+    return n.value, w.value
 
 
 def dense_forward(x, W, need_beta=True):
@@ -227,22 +233,29 @@ def dense_forward(x, W, need_beta=True):
     st.alpha = torch.empty((B, T, C), dtype=_F32, device=x.device)
     st.beta = torch.empty((B, T, C), dtype=_F32, device=x.device) if need_beta else None
     st.logz = torch.empty(B, dtype=_F32, device=x.device)
+    st.ws = torch.empty(_dense_sizes(B, T, C)[1], dtype=torch.uint8, device=x.device)
     N.check(
         N.lib.wfl_dense_forward(ptr(x), ptr(W), B, T, C, N.SEMIRING_LOG, ptr(st.alpha), ptr(st.beta), None,
-                                ptr(st.logz), stream_ptr())
+                                ptr(st.logz), ptr(st.ws), stream_ptr())
     )
     return st
+
+
+def dense_flagged(st):
+    """[B] bool: utterances the probability-domain sweep handed to the log-domain kernels."""
+    B, T = st.B, st.T
+    off = 8 * B * 2 * T + 8 * B + 4 * B * 2 * T + 4 * B * T + 4 * 128
+    return st.ws[off:off + 8 * B].view(torch.int32).view(B, 2).ne(0).any(dim=1)
 
 
 def dense_grad(x, W, st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None):
     part = None
     if dW is not None:
-        n = ctypes.c_int64()
-        N.check(N.lib.wfl_dense_workspace(st.B, st.T, st.C, ctypes.byref(n)))
-        part = torch.empty(n.value, dtype=_F32, device=x.device)
+        part = torch.empty(_dense_sizes(st.B, st.T, st.C)[0], dtype=_F32, device=x.device)
     N.check(
         N.lib.wfl_dense_grad(ptr(x), ptr(W), st.B, st.T, st.C, ptr(st.alpha), ptr(st.beta), ptr(st.logz), ptr(coef),
-                             ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(dx), ptr(dW), ptr(part), stream_ptr())
+                             ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(dx), ptr(dW), ptr(part), ptr(st.ws),
+                             stream_ptr())
     )
 
 

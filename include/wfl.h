@@ -199,16 +199,21 @@ int wfl_lattice_backtrace(const wfl_lattice_desc* d, const int32_t* ints, const 
  * Device kernels: dense (fully connected) transitions -- ASG denominator / ASG Viterbi
  *   W [(C+1), C] row-major: W[0,i] start->i, W[1+i, j] = score(prev j -> cur i)  (asg.py:54-69)
  * ------------------------------------------------------------------------------------------------ */
-/* forward_score(intersect(emissions, transitions)) (asg.py:114): alpha, beta [B,T,C], logz [B] */
+/* Sizes of the scratch buffers: dW_partial [partial_elems] floats (per-workgroup partial sums of the
+ * transition gradient) and the opaque workspace `ws` [ws_bytes] shared by forward and grad
+ * (per-frame scale bookkeeping of the probability-domain sweeps, per-utterance range flags). */
+int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws_bytes);
+/* forward_score(intersect(emissions, transitions)) (asg.py:114): logz [B]; alpha, beta [B,T,C] are
+ * opaque inputs of wfl_dense_grad in the log semiring (scaled probabilities for utterances served
+ * by the probability-domain sweep, log scores for utterances it had to hand to the log-domain
+ * sweep; ws records which), max-plus scores in the tropical semiring (ws may be NULL there). */
 int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int semiring,
-                      float* alpha, float* beta, int32_t* bptr, float* logz, void* stream);
-/* dx[b,t,i] (+)= coef[b]*gout*post_t(i);  dW += sum_b coef_w[b]*gout*transition posteriors.
- * dW_partial: scratch [n_partials, (C+1)*C] (n from wfl_dense_workspace) reduced into dW. */
-int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems);
+                      float* alpha, float* beta, int32_t* bptr, float* logz, void* ws, void* stream);
+/* dx[b,t,i] (+)= coef[b]*gout*post_t(i);  dW += sum_b coef_w[b]*gout*transition posteriors. */
 int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const float* alpha,
                    const float* beta, const float* logz, const float* coef, const float* coef_w,
                    const float* gout, int accumulate, float* dx, float* dW, float* dW_partial,
-                   void* stream);
+                   const void* ws, void* stream);
 /* viterbi_path(intersect(emissions, transitions)).labels_to_list() (asg.py:225-226):
  * path [B,T] int32 emission labels.  Ties: lowest previous label, then lowest final label. */
 int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float* alpha,
