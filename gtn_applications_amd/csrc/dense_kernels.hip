@@ -328,7 +328,7 @@ __global__ void dense_backtrace_kernel(const float* __restrict__ alpha, const in
 //   a~_t[i]     = e_t[i] * 2^-kk_{t-1} * sum_j P[i][j] a~_{t-1}[j]        (alpha; beta is the transpose)
 //   alpha_t[i]  = a~_t[i] * 2^(E_t + M_t),   E_t = sum kk (int),  M_t = sum mx2 (double)
 //
-// kk_{t-1} is the exponent that brings max_j a~_{t-1}[j] into [2^29, 2^30): an exact scaling.  One
+// kk is an integer exponent read off the vector itself that keeps it near 2^30: an exact scaling.  One
 // workgroup per (utterance, direction): waves 0-1 own one state per lane and keep their row (alpha)
 // or column (beta) of P in registers, the frame vector is broadcast through LDS (ds_read_b128), one
 // barrier per frame; wave 2 runs ahead, turning emission rows into e_t / mx2_t in an LDS ring.
@@ -372,7 +372,6 @@ struct FastLds {
   float eh[4][CP];   // ring of e_t rows staged by the helper wave
   float wr2[CP];
   float st2[CP];     // start weights W[0, :] in log2 units
-  float wmax[2][2];  // per buffer, per chain wave: maximum of the vector
   float wsum[2];
   double mtot;
 };
@@ -466,44 +465,43 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   const std::false_type kUnchecked;
 
   // ---- chain wave state
-  int ecum = 0, bad = 0;
+  // The scale of step n is 2^-kk with kk the exponent of the largest of the first four elements of the
+  // vector being multiplied, minus kNormExp: every lane (and the helper wave, which does the E_t
+  // bookkeeping) derives it from the first ds_read_b128 it issues anyway -- no reduction and no
+  // extra LDS round trip on the per-frame critical path (barrier -> broadcast reads + FMAs ->
+  // ds_write).  Any power of two is exact; how well it centres the vector only matters for the
+  // range check below.
+  int bad = 0;
   float last = 0.f;
-  auto publish = [&](float v, int buf) {  // vector element for the next step + its wave maximum
-    if (q < CP) L.vec[buf][q] = v;
-    const float wm = wave_reduce_max_lane63(v);
-    if (lane == 63) L.wmax[buf][wave] = wm;
+  auto scale_exp = [&](const float4& v) {
+    return __builtin_amdgcn_frexp_expf(vmax(vmax(v.x, v.y), vmax(v.z, v.w))) - kNormExp;
   };
-  auto chain_step = [&](int n) {  // n >= 1
-    const int cur = (n - 1) & 1;
-    const float mx = fmaxf(L.wmax[cur][0], L.wmax[cur][1]);
-    const int kk = __builtin_amdgcn_frexp_expf(mx) - kNormExp;
-    const float inv = __builtin_amdgcn_ldexpf(1.f, -kk);
-    ecum += kk;
+  auto chain_step = [&](int n, int cur) {  // n >= 1, cur = (n - 1) & 1
+    const float e = L.eh[(DIR == 0 ? n : n + 1) & 3][q < CP ? q : 0];  // beta at n = T-1: a stale row, unused
     const float4* v4 = reinterpret_cast<const float4*>(L.vec[cur]);
     f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+    float inv = 1.f;
 #pragma unroll
     for (int j = 0; j < CP / 4; ++j) {
       const float4 v = v4[j];
+      if (j == 0) inv = __builtin_amdgcn_ldexpf(1.f, -scale_exp(v));
       a0 = __builtin_elementwise_fma(P[2 * j], f32x2{v.x, v.y}, a0);
       a1 = __builtin_elementwise_fma(P[2 * j + 1], f32x2{v.z, v.w}, a1);
     }
     const float y = inv * ((a0[0] + a0[1]) + (a1[0] + a1[1]));
-    const int t = DIR == 0 ? n : T - 1 - n;
-    float val, next;
-    if (DIR == 0) {
-      val = L.eh[n & 3][q < CP ? q : 0] * y;
-      next = val;
-    } else {
-      val = y;
-      next = n + 1 < T ? L.eh[(n + 1) & 3][q < CP ? q : 0] * y : 0.f;
-    }
+    const float val = DIR == 0 ? e * y : y;
+    if (q < CP) L.vec[cur ^ 1][q] = DIR == 0 ? val : e * y;
+    last = val;
     if (q < C) {
       bad |= !(val >= kFloor && val < 3.0e38f);
-      ob[(int64_t)t * C + q] = val;
+      ob[(int64_t)(DIR == 0 ? n : T - 1 - n) * C + q] = val;
     }
-    if (tid == 0) Eb[t] = ecum;
-    last = val;
-    publish(next, cur ^ 1);
+  };
+  // helper side of the same bookkeeping: E_t = sum of the exponents applied up to step n
+  int ecum = 0;
+  auto helper_scale = [&](int n) {
+    ecum += scale_exp(*reinterpret_cast<const float4*>(L.vec[(n - 1) & 1]));
+    if (lane == 0) Eb[DIR == 0 ? n : T - 1 - n] = ecum;
   };
 
   // ---- prologue: items 0 and 1 staged synchronously, items 2..5 in flight
@@ -535,35 +533,47 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
         bad |= !(val >= kFloor && val < 3.0e38f);
         ob[(int64_t)(DIR == 0 ? 0 : T - 1) * C + q] = val;
       }
-      if (tid == 0) Eb[DIR == 0 ? 0 : T - 1] = 0;
       last = val;
-      publish(next, 0);
+      if (q < CP) L.vec[0][q] = next;
     }
     __syncthreads();
-    for (int n = 1; n < T; ++n) {
-      chain_step(n);
+    int n = 1;
+    for (; n + 1 < T; n += 2) {
+      chain_step(n, 0);
+      __syncthreads();
+      chain_step(n + 1, 1);
+      __syncthreads();
+    }
+    if (n < T) {
+      chain_step(n, 0);
       __syncthreads();
     }
   } else {
+    if (lane == 0) Eb[DIR == 0 ? 0 : T - 1] = 0;
     stage(2, raw[2], kChecked);
     issue(6, raw[2]);
     __syncthreads();
     int n = 1;
     for (; n < n_main; n += 4) {  // items n+2 .. n+9 exist
+      helper_scale(n);
       stage(n + 2, raw[3], kUnchecked);
       issue_fast(n + 6, raw[3]);
       __syncthreads();
+      helper_scale(n + 1);
       stage(n + 3, raw[0], kUnchecked);
       issue_fast(n + 7, raw[0]);
       __syncthreads();
+      helper_scale(n + 2);
       stage(n + 4, raw[1], kUnchecked);
       issue_fast(n + 8, raw[1]);
       __syncthreads();
+      helper_scale(n + 3);
       stage(n + 5, raw[2], kUnchecked);
       issue_fast(n + 9, raw[2]);
       __syncthreads();
     }
     for (; n < T; ++n) {  // tail: synchronous, checked
+      helper_scale(n);
       float tmp[2] = {WFL_NEG_INF, WFL_NEG_INF};
       issue(n + 2, tmp);
       stage(n + 2, tmp, kChecked);
@@ -577,11 +587,11 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
       const float s = wave_all_sum(q < C ? last : 0.f);
       if (lane == 0) L.wsum[wave] = s;
     } else if (lane == 0) {
-      L.mtot = mrun;
+      L.mtot = mrun + (double)ecum;
     }
     __syncthreads();
     if (tid == 0) {
-      const double z2 = L.mtot + (double)ecum + (double)__builtin_amdgcn_logf(L.wsum[0] + L.wsum[1]);
+      const double z2 = L.mtot + (double)__builtin_amdgcn_logf(L.wsum[0] + L.wsum[1]);
       ws.z2[b] = z2;
       logz[b] = (float)(z2 * 0.6931471805599453);
     }
