@@ -186,6 +186,41 @@ __device__ __forceinline__ void relax_labelled(const ChainLds& L, const Arc4& a4
   val = m, arg = am;
 }
 
+// Lean per-frame update for the common layout (one state per thread, no epsilon levels, log
+// semiring, in-degree <= DEG everywhere): the arcs' LDS addresses are precomputed, absent arcs are
+// padded with weight -inf, and there is no branch -- the chain is one dependent instruction stream
+// per frame, so its length is what bounds the sweep.
+struct LeanArcs {
+  const float* fa[4];  // address of the source state's score in the buffer read by even steps
+  const float* fb[4];  // ... by odd steps
+  int ro[4];           // byte offset of the arc's emission inside a row of the tile
+  float w[4];
+};
+
+template <int DEG>
+__device__ __forceinline__ float lean_relax(const float* const (&fp)[4], const int (&ro)[4], const float (&w)[4],
+                                            const float* row) {
+  float v[DEG];
+#pragma unroll
+  for (int i = 0; i < DEG; ++i)
+    v[i] = *fp[i] + *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + ro[i]) + w[i];
+  if (DEG == 2) {
+    // log(e^a + e^b) = max + log(1 + e^-|a-b|): one exp, one log.  Operands are clamped for the
+    // difference only, so two -inf give max = -inf plus a finite correction = -inf.
+    const float m = vmax(v[0], v[1]);
+    const float d = vmax(v[0], -1.0e30f) - vmax(v[1], -1.0e30f);
+    const float e = __builtin_amdgcn_exp2f(-fabsf(d) * 1.4426950408889634f);
+    return fmaf(__builtin_amdgcn_logf(1.f + e), 0.6931471805599453f, m);
+  } else {
+    const float m = vmax(vmax(v[0], v[1]), vmax(v[2], v[3]));
+    const float mc = vmax(m, -1.0e30f);  // all -inf: every term is 2^-inf = 0, log2(0) = -inf
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) s += __builtin_amdgcn_exp2f((v[i] - mc) * 1.4426950408889634f);
+    return fmaf(__builtin_amdgcn_logf(s), 0.6931471805599453f, mc);
+  }
+}
+
 template <int SR>
 __device__ __forceinline__ void relax_eps(const ChainLds& L, float* vals, int q, int k0, int k1, int A, float& val,
                                           int& arg) {
@@ -290,6 +325,18 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   const int kq0 = tid < Q ? L.ptr[tid] : 0, kq1 = tid < Q ? L.ptr[tid + 1] : 0;
   const Arc4 mine = load_arc4(L.arcs, kq0, kq1);
   const bool direct = nlev <= 1;  // no epsilon closure: the relaxed value is final
+  const int deg = kq1 - kq0;
+  const int any_gt2 = __syncthreads_or(deg > 2), any_gt4 = __syncthreads_or(deg > 4);
+  const bool lean = SR == WFL_SEMIRING_LOG && Q <= NT && direct && !any_gt4;  // block-uniform
+  LeanArcs la;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    la.fa[i] = L.buf0 + mine.other[i], la.fb[i] = L.buf1 + mine.other[i];
+    la.ro[i] = mine.slot[i] * 4, la.w[i] = mine.w[i];
+  }
+  // rows_per_chunk is even, so the first step of every chunk reads the same buffer: forward steps
+  // read slot t (chunks start at even t), backward steps read slot t + 1 = T - c * R - i
+  const bool first_reads_buf1 = DIR == 0 ? false : (T & 1);
   for (int c = 0; c < nchunks; ++c) {
     int f0, n;
     chunk_frames(c, f0, n);
@@ -305,35 +352,64 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
         if (e < pn * Kmax) pre[j] = src[e];
       }
     }
-    for (int i = 0; i < n; ++i) {
-      // forward: consume frame t, produce slot t+1.  backward: consume frame t, produce slot t.
-      const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-      const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
-      const float* from = (slot_from & 1) ? L.buf1 : L.buf0;
-      float* to = (slot_to & 1) ? L.buf1 : L.buf0;
-      const float* row = tile + (size_t)(t - f0) * Kmax;
-      float* orow = out + u.ab_base + (int64_t)slot_to * Q;
-      if (tid < Q) {
-        float v;
-        int arg;
-        relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
-        to[tid] = v;
-        if (direct) orow[tid] = v;
-        if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
+    if (lean) {
+      auto step = [&](int i, const float* const (&fp)[4], float* to) {
+        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+        const float* row = tile + (size_t)(t - f0) * Kmax;
+        const float v = any_gt2 ? lean_relax<4>(fp, la.ro, la.w, row) : lean_relax<2>(fp, la.ro, la.w, row);
+        if (tid < Q) {
+          to[tid] = v;
+          out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = v;
+        }
+        __syncthreads();
+      };
+      float* const to_first = first_reads_buf1 ? L.buf0 : L.buf1;
+      float* const to_second = first_reads_buf1 ? L.buf1 : L.buf0;
+      int i = 0;
+      if (first_reads_buf1) {
+        for (; i + 1 < n; i += 2) {
+          step(i, la.fb, to_first);
+          step(i + 1, la.fa, to_second);
+        }
+        if (i < n) step(i, la.fb, to_first);
+      } else {
+        for (; i + 1 < n; i += 2) {
+          step(i, la.fa, to_first);
+          step(i + 1, la.fb, to_second);
+        }
+        if (i < n) step(i, la.fa, to_first);
       }
-      for (int q = tid + NT; q < Q; q += NT) {
-        float v;
-        int arg;
-        const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
-        relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
-        to[q] = v;
-        if (direct) orow[q] = v;
-        if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+    } else {
+      for (int i = 0; i < n; ++i) {
+        // forward: consume frame t, produce slot t+1.  backward: consume frame t, produce slot t.
+        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+        const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
+        const float* from = (slot_from & 1) ? L.buf1 : L.buf0;
+        float* to = (slot_to & 1) ? L.buf1 : L.buf0;
+        const float* row = tile + (size_t)(t - f0) * Kmax;
+        float* orow = out + u.ab_base + (int64_t)slot_to * Q;
+        if (tid < Q) {
+          float v;
+          int arg;
+          relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
+          to[tid] = v;
+          if (direct) orow[tid] = v;
+          if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
+        }
+        for (int q = tid + NT; q < Q; q += NT) {
+          float v;
+          int arg;
+          const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
+          relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
+          to[q] = v;
+          if (direct) orow[q] = v;
+          if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+        }
+        closure(to, slot_to);
+        __syncthreads();
+        if (!direct)
+          for (int q = tid; q < Q; q += NT) orow[q] = to[q];
       }
-      closure(to, slot_to);
-      __syncthreads();
-      if (!direct)
-        for (int q = tid; q < Q; q += NT) orow[q] = to[q];
     }
     if (c + 1 < nchunks) {
       float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
@@ -580,8 +656,8 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     return WFL_ERR_UNSUPPORTED;
   }
   int nt = d->max_states <= 64 ? 64 : (d->max_states <= 128 ? 128 : 256);
-  while (nt < 256 && nt * kPre < d->max_labels) nt += 64;
-  const int rpc = std::max(1, std::min(16, nt * kPre / std::max(1, d->max_labels)));
+  while (nt < 256 && nt * kPre < 2 * d->max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
+  const int rpc = std::max(2, std::min(16, nt * kPre / std::max(1, d->max_labels)) & ~1);  // even (run_chain)
   const size_t lds = chain_lds_bytes(*d, rpc);
   if (lds > (size_t)kLdsBytes) {
     set_error("lattice_forward: acceptor needs %zu B of LDS (limit %d): %d arcs, %d states", lds, kLdsBytes,
