@@ -43,14 +43,6 @@ constexpr float kNegBig = -1.0e30f;  // stands in for -inf on the chain
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kBlk = 16;  // frames per block: renormalisation, checkpoint and prefetch period
 
-__device__ __forceinline__ float wave_shr1(float v, float fill) {
-  // lane i receives lane i-1's value; lane 0 receives `fill` (DPP wave_shr:1, bound_ctrl off)
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float wave_shl1(float v, float fill) {
-  // lane i receives lane i+1's value; lane 63 receives `fill` (DPP wave_shl:1)
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
-}
 // log2(2^a + 2^b) with ONE exp and one log: max + log2(1 + 2^-|a-b|).  With the finite -inf sentinel
 // the difference of two sentinels is 0 (-> sentinel + 1, still a sentinel) and sentinel vs finite
 // gives 2^-huge = 0: branch-free.  Cost model on gfx950 (measured): 4 cycles per VALU, 16 per

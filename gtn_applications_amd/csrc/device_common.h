@@ -64,6 +64,14 @@ __device__ __forceinline__ float vmax(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
   return m;
 }
+__device__ __forceinline__ float wave_shr1(float v, float fill) {
+  // lane i receives lane i-1's value; lane 0 receives `fill` (DPP wave_shr:1, bound_ctrl off)
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v, float fill) {
+  // lane i receives lane i+1's value; lane 63 receives `fill` (DPP wave_shl:1)
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_reduce_max_lane63(float v) {
   v = vmax(v, dpp_f32<0x111, 0xf>(WFL_NEG_INF, v));  // row_shr:1
   v = vmax(v, dpp_f32<0x112, 0xf>(WFL_NEG_INF, v));  // row_shr:2

@@ -12,6 +12,8 @@
 // This replaces gtn.intersect(emissions, A) + gtn.forward_score / viterbi_path + gtn.backward
 // (criterions/ctc.py:49-51,78-81; asg.py:111-113; stc.py:85-87; transducer.py:283,321-325) without
 // ever materialising the T*|A| composed lattice.  Memory/latency-bound DP: no MFMA by design.
+#include <type_traits>
+
 #include "device_common.h"
 
 namespace wfl {
@@ -190,35 +192,42 @@ __device__ __forceinline__ void relax_labelled(const ChainLds& L, const Arc4& a4
 // semiring, in-degree <= DEG everywhere): the arcs' LDS addresses are precomputed, absent arcs are
 // padded with weight -inf, and there is no branch -- the chain is one dependent instruction stream
 // per frame, so its length is what bounds the sweep.
+constexpr int kLeanDeg = 8;
 struct LeanArcs {
-  const float* fa[4];  // address of the source state's score in the buffer read by even steps
-  const float* fb[4];  // ... by odd steps
-  int ro[4];           // byte offset of the arc's emission inside a row of the tile
-  float w[4];
+  const float* fa[kLeanDeg];  // address of the source state's score in the buffer read by even steps
+  const float* fb[kLeanDeg];  // ... by odd steps
+  int ro[kLeanDeg];           // byte offset of the arc's emission inside a row of the tile
+  int lo[kLeanDeg];           // source state * 4: ds_bpermute address when the whole acceptor is one wave
+  float w[kLeanDeg];
 };
 
+// log-sum of DEG terms (see lean_relax)
 template <int DEG>
-__device__ __forceinline__ float lean_relax(const float* const (&fp)[4], const int (&ro)[4], const float (&w)[4],
-                                            const float* row) {
-  float v[DEG];
-#pragma unroll
-  for (int i = 0; i < DEG; ++i)
-    v[i] = *fp[i] + *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + ro[i]) + w[i];
+__device__ __forceinline__ float lean_lse(const float (&v)[kLeanDeg]) {
   if (DEG == 2) {
-    // log(e^a + e^b) = max + log(1 + e^-|a-b|): one exp, one log.  Operands are clamped for the
-    // difference only, so two -inf give max = -inf plus a finite correction = -inf.
     const float m = vmax(v[0], v[1]);
     const float d = vmax(v[0], -1.0e30f) - vmax(v[1], -1.0e30f);
     const float e = __builtin_amdgcn_exp2f(-fabsf(d) * 1.4426950408889634f);
     return fmaf(__builtin_amdgcn_logf(1.f + e), 0.6931471805599453f, m);
   } else {
-    const float m = vmax(vmax(v[0], v[1]), vmax(v[2], v[3]));
-    const float mc = vmax(m, -1.0e30f);  // all -inf: every term is 2^-inf = 0, log2(0) = -inf
+    float m = vmax(vmax(v[0], v[1]), vmax(v[2], v[3]));
+    if (DEG == 8) m = vmax(m, vmax(vmax(v[4], v[5]), vmax(v[6], v[7])));
+    const float mc = vmax(m, -1.0e30f);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < DEG; ++i) s += __builtin_amdgcn_exp2f((v[i] - mc) * 1.4426950408889634f);
     return fmaf(__builtin_amdgcn_logf(s), 0.6931471805599453f, mc);
   }
+}
+
+template <int DEG>
+__device__ __forceinline__ float lean_relax(const float* const (&fp)[kLeanDeg], const int (&ro)[kLeanDeg],
+                                            const float (&w)[kLeanDeg], const float* row) {
+  float v[kLeanDeg];
+#pragma unroll
+  for (int i = 0; i < DEG; ++i)
+    v[i] = *fp[i] + *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + ro[i]) + w[i];
+  return lean_lse<DEG>(v);
 }
 
 template <int SR>
@@ -327,99 +336,182 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   const bool direct = nlev <= 1;  // no epsilon closure: the relaxed value is final
   const int deg = kq1 - kq0;
   const int any_gt2 = __syncthreads_or(deg > 2), any_gt4 = __syncthreads_or(deg > 4);
-  const bool lean = SR == WFL_SEMIRING_LOG && Q <= NT && direct && !any_gt4;  // block-uniform
+  const int any_gt8 = __syncthreads_or(deg > kLeanDeg);
+  const bool lean = SR == WFL_SEMIRING_LOG && Q <= NT && direct && !any_gt8;  // block-uniform
   LeanArcs la;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    la.fa[i] = L.buf0 + mine.other[i], la.fb[i] = L.buf1 + mine.other[i];
-    la.ro[i] = mine.slot[i] * 4, la.w[i] = mine.w[i];
+  for (int i = 0; i < kLeanDeg; ++i) {
+    const bool ok = kq0 + i < kq1;
+    const int2 a = ok ? L.arcs[kq0 + i] : make_int2(0, __float_as_int(WFL_NEG_INF));
+    la.fa[i] = L.buf0 + (a.x & 0xffff), la.fb[i] = L.buf1 + (a.x & 0xffff);
+    la.ro[i] = (int)((unsigned)a.x >> 16) * 4, la.w[i] = __int_as_float(a.y);
+    la.lo[i] = (a.x & 0xffff) * 4;
   }
+  // single-wave acceptors keep the score vector in registers (one state per lane) and fetch the
+  // source states with ds_bpermute: no LDS write -> barrier -> read round trip on the chain
+  float sc = (NT == 64 && tid < Q) ? cur[tid] : WFL_NEG_INF;
+  // banded acceptors (force alignment, CTC-like chains): every in-arc is a self loop or comes from
+  // the neighbouring state -- the neighbour's score is one DPP wave shift away, no LDS at all
+  const int adj = DIR == 0 ? tid - 1 : tid + 1;
+  float w_self = WFL_NEG_INF, w_adj = WFL_NEG_INF;
+  int ro_self = 0, ro_adj = 0, banded_ok = deg <= 2;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (kq0 + i >= kq1) continue;
+    const int other = la.lo[i] >> 2;
+    if (other == tid && w_self == WFL_NEG_INF)
+      w_self = la.w[i], ro_self = la.ro[i];
+    else if (other == adj && w_adj == WFL_NEG_INF)
+      w_adj = la.w[i], ro_adj = la.ro[i];
+    else if (la.w[i] > WFL_NEG_INF)
+      banded_ok = 0;
+  }
+  const bool banded = lean && NT == 64 && __syncthreads_and(banded_ok);
   // rows_per_chunk is even, so the first step of every chunk reads the same buffer: forward steps
   // read slot t (chunks start at even t), backward steps read slot t + 1 = T - c * R - i
   const bool first_reads_buf1 = DIR == 0 ? false : (T & 1);
-  for (int c = 0; c < nchunks; ++c) {
-    int f0, n;
-    chunk_frames(c, f0, n);
-    const float* tile = L.rows + (size_t)(c & 1) * R * Kmax;
-    float pre[kPre];
-    int pf0 = 0, pn = 0;
-    if (c + 1 < nchunks) {
-      chunk_frames(c + 1, pf0, pn);
-      const float* src = xg + u.xg_base + (int64_t)pf0 * Kmax;
+  auto sweep = [&](auto variant) {
+    constexpr int V = decltype(variant)::value;  // 0: general path, 1: banded, otherwise the lean in-degree bound
+    for (int c = 0; c < nchunks; ++c) {
+      int f0, n;
+      chunk_frames(c, f0, n);
+      const float* tile = L.rows + (size_t)(c & 1) * R * Kmax;
+      float pre[kPre];
+      int pf0 = 0, pn = 0;
+      if (c + 1 < nchunks) {
+        chunk_frames(c + 1, pf0, pn);
+        const float* src = xg + u.xg_base + (int64_t)pf0 * Kmax;
 #pragma unroll
-      for (int j = 0; j < kPre; ++j) {
-        const int e = tid + j * NT;
-        if (e < pn * Kmax) pre[j] = src[e];
-      }
-    }
-    if (lean) {
-      auto step = [&](int i, const float* const (&fp)[4], float* to) {
-        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-        const float* row = tile + (size_t)(t - f0) * Kmax;
-        const float v = any_gt2 ? lean_relax<4>(fp, la.ro, la.w, row) : lean_relax<2>(fp, la.ro, la.w, row);
-        if (tid < Q) {
-          to[tid] = v;
-          out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = v;
+        for (int j = 0; j < kPre; ++j) {
+          const int e = tid + j * NT;
+          if (e < pn * Kmax) pre[j] = src[e];
         }
-        __syncthreads();
+      }
+      // single-wave variants: the emissions of frame i+1 are read from the tile while frame i is
+      // being computed (they do not depend on the chain), so only the score exchange is serial
+      auto row_of = [&](int i) {
+        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+        return reinterpret_cast<const char*>(tile + (size_t)(t - f0) * Kmax);
       };
-      float* const to_first = first_reads_buf1 ? L.buf0 : L.buf1;
-      float* const to_second = first_reads_buf1 ? L.buf1 : L.buf0;
-      int i = 0;
-      if (first_reads_buf1) {
-        for (; i + 1 < n; i += 2) {
-          step(i, la.fb, to_first);
-          step(i + 1, la.fa, to_second);
+      if (V == 1) {
+        float xs = *reinterpret_cast<const float*>(row_of(0) + ro_self);
+        float xa = *reinterpret_cast<const float*>(row_of(0) + ro_adj);
+        for (int i = 0; i < n; ++i) {
+          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+          const char* rn = row_of(i + 1 < n ? i + 1 : i);
+          const float xs_n = *reinterpret_cast<const float*>(rn + ro_self);
+          const float xa_n = *reinterpret_cast<const float*>(rn + ro_adj);
+          const float nb = DIR == 0 ? wave_shr1(sc, WFL_NEG_INF) : wave_shl1(sc, WFL_NEG_INF);
+          float v[kLeanDeg];
+          v[0] = sc + (xs + w_self);
+          v[1] = nb + (xa + w_adj);
+          sc = lean_lse<2>(v);
+          if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
+          xs = xs_n, xa = xa_n;
         }
-        if (i < n) step(i, la.fb, to_first);
-      } else {
-        for (; i + 1 < n; i += 2) {
-          step(i, la.fa, to_first);
-          step(i + 1, la.fb, to_second);
-        }
-        if (i < n) step(i, la.fa, to_first);
-      }
-    } else {
-      for (int i = 0; i < n; ++i) {
-        // forward: consume frame t, produce slot t+1.  backward: consume frame t, produce slot t.
-        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-        const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
-        const float* from = (slot_from & 1) ? L.buf1 : L.buf0;
-        float* to = (slot_to & 1) ? L.buf1 : L.buf0;
-        const float* row = tile + (size_t)(t - f0) * Kmax;
-        float* orow = out + u.ab_base + (int64_t)slot_to * Q;
-        if (tid < Q) {
-          float v;
-          int arg;
-          relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
-          to[tid] = v;
-          if (direct) orow[tid] = v;
-          if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
-        }
-        for (int q = tid + NT; q < Q; q += NT) {
-          float v;
-          int arg;
-          const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
-          relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
-          to[q] = v;
-          if (direct) orow[q] = v;
-          if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
-        }
-        closure(to, slot_to);
-        __syncthreads();
-        if (!direct)
-          for (int q = tid; q < Q; q += NT) orow[q] = to[q];
-      }
-    }
-    if (c + 1 < nchunks) {
-      float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
+      } else if (V != 0 && NT == 64) {
+        constexpr int DEG = V >= 2 ? V : 2;
+        float xr[kLeanDeg];
 #pragma unroll
-      for (int j = 0; j < kPre; ++j) {
-        const int e = tid + j * NT;
-        if (e < pn * Kmax) dst[e] = pre[j];
+        for (int k = 0; k < DEG; ++k) xr[k] = *reinterpret_cast<const float*>(row_of(0) + la.ro[k]) + la.w[k];
+        for (int i = 0; i < n; ++i) {
+          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+          const char* rn = row_of(i + 1 < n ? i + 1 : i);
+          float xn[kLeanDeg], v[kLeanDeg];
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) xn[k] = *reinterpret_cast<const float*>(rn + la.ro[k]) + la.w[k];
+#pragma unroll
+          for (int k = 0; k < DEG; ++k)
+            v[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(la.lo[k], __float_as_int(sc))) + xr[k];
+          sc = lean_lse<DEG>(v);
+          if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) xr[k] = xn[k];
+        }
+      } else if (V != 0) {
+        auto step = [&](int i, const float* const (&fp)[kLeanDeg], float* to) {
+          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+          const float* row = tile + (size_t)(t - f0) * Kmax;
+          const float v = lean_relax<(V >= 2 ? V : 2)>(fp, la.ro, la.w, row);
+          if (tid < Q) {
+            to[tid] = v;
+            out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = v;
+          }
+          __syncthreads();
+        };
+        float* const to_first = first_reads_buf1 ? L.buf0 : L.buf1;
+        float* const to_second = first_reads_buf1 ? L.buf1 : L.buf0;
+        int i = 0;
+        if (first_reads_buf1) {
+          for (; i + 1 < n; i += 2) {
+            step(i, la.fb, to_first);
+            step(i + 1, la.fa, to_second);
+          }
+          if (i < n) step(i, la.fb, to_first);
+        } else {
+          for (; i + 1 < n; i += 2) {
+            step(i, la.fa, to_first);
+            step(i + 1, la.fb, to_second);
+          }
+          if (i < n) step(i, la.fa, to_first);
+        }
+      } else {
+        for (int i = 0; i < n; ++i) {
+          // forward: consume frame t, produce slot t+1.  backward: consume frame t, produce slot t.
+          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+          const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
+          const float* from = (slot_from & 1) ? L.buf1 : L.buf0;
+          float* to = (slot_to & 1) ? L.buf1 : L.buf0;
+          const float* row = tile + (size_t)(t - f0) * Kmax;
+          float* orow = out + u.ab_base + (int64_t)slot_to * Q;
+          if (tid < Q) {
+            float v;
+            int arg;
+            relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
+            to[tid] = v;
+            if (direct) orow[tid] = v;
+            if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
+          }
+          for (int q = tid + NT; q < Q; q += NT) {
+            float v;
+            int arg;
+            const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
+            relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
+            to[q] = v;
+            if (direct) orow[q] = v;
+            if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+          }
+          closure(to, slot_to);
+          __syncthreads();
+          if (!direct)
+            for (int q = tid; q < Q; q += NT) orow[q] = to[q];
+        }
       }
-      __syncthreads();
+      if (c + 1 < nchunks) {
+        float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+          const int e = tid + j * NT;
+          if (e < pn * Kmax) dst[e] = pre[j];
+        }
+        __syncthreads();
+      }
     }
+  };
+  if (!lean)
+    sweep(std::integral_constant<int, 0>{});
+  else if (banded)
+    sweep(std::integral_constant<int, 1>{});
+  else if (any_gt4)
+    sweep(std::integral_constant<int, 8>{});
+  else if (any_gt2)
+    sweep(std::integral_constant<int, 4>{});
+  else
+    sweep(std::integral_constant<int, 2>{});
+  if (lean && NT == 64 && T > 0) {  // the final vector lives in registers: publish it for the log Z reduction
+    float* fin = ((DIR == 0 ? T : 0) & 1) ? L.buf1 : L.buf0;
+    if (tid < Q) fin[tid] = sc;
+    __syncthreads();
   }
   if (DIR == 0 && logz) {
     const float* fin = (T & 1) ? L.buf1 : L.buf0;
@@ -514,18 +606,25 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     if (!dead) {
-      for (int i = tid; i < nr * A; i += NT) {
-        const int r = i / A, a = i - r * A;
-        float w = u.arc_w[a];
+      // one arc per thread (arc data in registers), frames of the tile in the inner loop
+      for (int a = tid; a < A; a += NT) {
         const int wid = u.arc_wid[a];
+        float w = u.arc_w[a] - z;
         if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
-        const float v = al[r * d.max_states + u.arc_src[a]] + xr[r * Kmax + u.arc_slot[a]] + w +
-                        be[(r + 1) * d.max_states + u.arc_dst[a]] - z;
-        if (v > WFL_NEG_INF) {
-          const float g = fast_exp(v);
-          if (dx) atomicAdd(&rows[r * C + u.arc_lab[a]], g * cf);
-          if (dW && wid >= 0) atomicAdd(&dwacc[a], g);
+        const float* pa = al + u.arc_src[a];
+        const float* pb = be + d.max_states + u.arc_dst[a];
+        const float* px = xr + u.arc_slot[a];
+        float* pr = rows + u.arc_lab[a];
+        float wsum = 0.f;
+        for (int r = 0; r < nr; ++r) {
+          const float v = pa[r * d.max_states] + px[r * Kmax] + w + pb[r * d.max_states];
+          if (v > WFL_NEG_INF) {
+            const float g = fast_exp(v);
+            if (dx) atomicAdd(&pr[r * C], g * cf);
+            wsum += g;
+          }
         }
+        if (dW && wid >= 0 && wsum != 0.f) atomicAdd(&dwacc[a], wsum);
       }
       if (dW && E > 0) {
         const int nslots = nr + ((ts0 + nr == T) ? 1 : 0);  // epsilon slots t = ts0 .. (T included once)
@@ -704,10 +803,11 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
     return WFL_ERR_INVALID;
   }
   if (T <= 0) return WFL_OK;
-  // frames per LDS sub-tile: keep the tile under ~56 KiB so that two workgroups fit per CU
+  // frames per LDS sub-tile: keep the tile near 24 KiB so that six workgroups fit per CU -- each one
+  // is a load -> barrier -> compute -> barrier -> store sequence, overlap comes from co-residency
   const size_t row_bytes = 4 * ((size_t)(dx ? C : 0) + 2 * (size_t)d->max_states + (size_t)d->max_labels);
   const size_t fixed = 4 * (2 * (size_t)d->max_states + (dW ? (size_t)d->max_arcs + d->max_eps : 0)) + 64;
-  int TS = fixed + row_bytes < 56 * 1024 ? (int)((56 * 1024 - fixed) / row_bytes) : 1;
+  int TS = fixed + row_bytes < 24 * 1024 ? (int)((24 * 1024 - fixed) / row_bytes) : 1;
   TS = std::max(1, std::min(TS, 32));
   const size_t lds = fixed + row_bytes * TS;
   if (lds > (size_t)kLdsBytes) {
