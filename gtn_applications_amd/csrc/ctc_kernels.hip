@@ -107,7 +107,7 @@ struct CtcArgs {
 constexpr int kRing = 3;  // LDS ring depth in blocks: consumer at kk, producer at kk+2
 
 // only_flagged != 0: repair pass -- run only for utterances whose fast-chain result was rejected
-__global__ void __launch_bounds__(128) ctc_log_chain_kernel(CtcArgs a, int only_flagged) {
+__global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_flagged) {
   __shared__ float2 ring[kRing][kBlk][64];  // 24 KiB
   __shared__ float2 ckbuf[2][64];           // checkpoint hand-off chain wave -> helper wave
   __shared__ double offbuf[2];
@@ -130,15 +130,25 @@ __global__ void __launch_bounds__(128) ctc_log_chain_kernel(CtcArgs a, int only_
   // alpha walks t = 0..T-1; beta walks block by block from the last block to the first, frames
   // descending inside each block, so that its checkpoints fall on the same absolute 16-frame
   // boundaries as alpha's
-  auto produce = [&](int kk) {  // helper wave: stage the kk-th processed block
+  // helper wave: `issue` starts the 16 gathers of the kk-th processed block, `stage` (one loop
+  // iteration = one block of chain work later) turns the landed values into ring entries, so the
+  // HBM / L2 latency never sits in front of a barrier
+  // Two helper waves alternate blocks (helper h owns the processed blocks kk with kk % 2 == h): in a
+  // helper's own instruction stream a block's gathers are issued two chain blocks before they are
+  // consumed and nothing newer is in flight at that point, so the compiler's s_waitcnt vmcnt(0)
+  // in front of the first use costs nothing even when the rows come from HBM (cfg5: x is 524 MB).
+  const int h = wave - 1;
+  float raw[kBlk];
+  auto issue = [&](int kk) {
     const int k = dir == 0 ? kk : NB - 1 - kk;
     const int t0 = k * kBlk, n = min(kBlk, T - t0);
-    float raw[kBlk];
 #pragma unroll
-    for (int j = 0; j < kBlk; ++j) {  // all 16 gathers in flight before the first use
+    for (int j = 0; j < kBlk; ++j) {
       const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
       raw[j] = xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
     }
+  };
+  auto stage = [&](int kk) {
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {
       const float xs = to_score(raw[j]);
@@ -146,9 +156,12 @@ __global__ void __launch_bounds__(128) ctc_log_chain_kernel(CtcArgs a, int only_
       ring[kk % kRing][j][lane] = make_float2(has_blank ? xblank : kNegBig, has_label ? xs : kNegBig);
     }
   };
-  if (wave == 1) {
-    produce(0);
-    if (NB > 1) produce(1);
+  if (wave >= 1) {
+    if (h < NB) {
+      issue(h);
+      stage(h);
+    }
+    if (h + 2 < NB) issue(h + 2);
   }
   __syncthreads();
 
@@ -204,8 +217,11 @@ __global__ void __launch_bounds__(128) ctc_log_chain_kernel(CtcArgs a, int only_
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) e[j] = en[j];
     } else {
-      if (kk > 0) flush_checkpoint(kk - 1);
-      if (kk + 2 < NB) produce(kk + 2);
+      if (kk > 0 && wave == 1) flush_checkpoint(kk - 1);
+      if ((kk & 1) == h) {
+        if (kk + 2 < NB) stage(kk + 2);  // issued two iterations ago
+        if (kk + 4 < NB) issue(kk + 4);
+      }
     }
     __syncthreads();
   }
@@ -673,14 +689,14 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
   }
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll};
   if (!(flags & WFL_CTC_FAST_CHAIN)) {
-    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(128), 0, (hipStream_t)stream, a, 0);
+    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 0);
   } else {
     hipLaunchKernelGGL(ctc_fast_chain_kernel, dim3((unsigned)B, 2u), dim3(256), 0, (hipStream_t)stream, a);
     WFL_LAUNCH_CHECK();
     const int64_t items = (int64_t)B * std::max(ctc_blocks(T) - 1, 1);
     hipLaunchKernelGGL(ctc_certify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     WFL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(128), 0, (hipStream_t)stream, a, 1);
+    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 1);
   }
   WFL_LAUNCH_CHECK();
   return WFL_OK;
