@@ -101,7 +101,7 @@ def make_ctc(args, rank, mode):
             E.reduce_loss(nll, scale, 1.0)
             E.ctc_grad(x, tg, blank, ws, nll, coef, gout, dx)  # posteriors -> dense gradient
             mark(events)
-        phases = ["ctc_chain_kernel", "ctc_grad_kernel(+reduce_loss)"]
+        phases = ["ctc_log_chain_kernel", "ctc_grad_kernel(+reduce_loss)"]
     else:
         xr = x.clone().requires_grad_(True)
 
@@ -109,8 +109,10 @@ def make_ctc(args, rank, mode):
             xr.grad = None
             ctc.CTCLoss(xr, targets, blank).backward()
         phases = []
+    which = {(1000, 100, 128, 44): " (BASELINE configs[1])", (2000, 512, 128, 44): " (BASELINE configs[4], one GPU's shard)",
+             (150, 28, 8, 44): " (BASELINE configs[0])"}.get((T, C, B, L), "")
     meta = dict(
-        workload=f"ctc fwd+bwd T={T} C={C} B={B} L={L} (BASELINE configs[1])", B=B, T=T, C=C, L=L,
+        workload=f"ctc fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L,
         algorithmic_bytes_per_utt=8 * T * C,
     )
     return step, phases, meta, (x, targets, blank)
