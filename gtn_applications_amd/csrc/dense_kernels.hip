@@ -776,6 +776,8 @@ int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int s
       WFL_FAST_CHAIN(128);
 #undef WFL_FAST_CHAIN
     WFL_LAUNCH_CHECK();
+    if (!cp)  // no fast path for this C: every utterance is served by the log-domain kernels
+      WFL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.flag, 1, (size_t)2 * B, st));
     // log-domain sweep: everything when there is no fast path, otherwise only flagged utterances
     auto k = dense_chain_kernel<WFL_SEMIRING_LOG>;
     if (lds > 48 * 1024)

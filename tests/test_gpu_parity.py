@@ -336,6 +336,116 @@ def test_asg_viterbi_vs_oracle_integer_scores(crit):
     assert got == [OR.dense_viterbi(x[b], W) for b in range(B)]
 
 
+
+def _dense_check(x, W, expect_flagged, need_dw=True):
+    """engine-level check of the dense (ASG denominator) kernels against the float64 recurrences"""
+    from gtn_applications_amd import engine as E
+
+    B, T, C = x.shape
+    xt, Wt = dev(x), dev(W)
+    st = E.dense_forward(xt, Wt, need_beta=True)
+    flagged = E.dense_flagged(st).cpu().tolist()
+    coef = torch.full((B,), 0.5, device="cuda")
+    dx = torch.full_like(xt, float("nan"))
+    dW = torch.zeros_like(Wt) if need_dw else None
+    E.dense_grad(xt, Wt, st, coef, coef_w=coef, dx=dx, dW=dW)
+    xo = np.where(np.isnan(x), -np.inf, x)  # NaN policy (DESIGN.md section 4): an impossible emission
+    want = [OR.dense_forward_backward(xo[b], W) for b in range(B)]
+    logz = st.logz.cpu().numpy()
+    for b in range(B):
+        if np.isfinite(want[b][0]):
+            assert logz[b] == pytest.approx(want[b][0], rel=RTOL, abs=1e-4), b
+        else:
+            assert logz[b] == want[b][0], b
+    close(dx, np.stack([0.5 * np.nan_to_num(w[1]) for w in want]))
+    if need_dw:
+        close(dW, 0.5 * sum(np.nan_to_num(w[2]) for w in want), atol=5e-5)
+    assert flagged == expect_flagged
+    # forward only (no beta sweep): same logZ
+    st1 = E.dense_forward(xt, Wt, need_beta=False)
+    np.testing.assert_allclose(st1.logz.cpu().numpy(), logz, rtol=1e-6)
+
+
+@pytest.mark.parametrize("C,T", [(5, 37), (32, 20), (33, 65), (64, 12), (100, 150), (104, 9), (105, 40), (128, 33)])
+def test_dense_probability_domain_sweeps_every_padding_bucket(C, T):
+    """the probability-domain sweeps (C <= 128) on well-conditioned data: served without fallback,
+    loss / emission gradient / transition gradient match the float64 recurrences"""
+    rs = np.random.RandomState(C * 7 + T)
+    B = 3
+    x = (2.0 * rs.randn(B, T, C)).astype(np.float32)
+    W = rs.randn(C + 1, C).astype(np.float32)
+    _dense_check(x, W, [False] * B)
+
+
+def test_dense_more_classes_than_the_fast_path_supports():
+    rs = np.random.RandomState(5)
+    x = rs.randn(2, 25, 150).astype(np.float32)
+    W = (0.3 * rs.randn(151, 150)).astype(np.float32)
+    _dense_check(x, W, [True, True], need_dw=False)  # no fast path: everything is served by the log-domain kernels
+
+
+def test_dense_range_flags_hand_utterances_to_the_log_domain_kernels():
+    """what the probability domain cannot hold must be detected per utterance and recomputed in the
+    log domain with the reference's semantics: -inf emissions, a frame of extreme dynamic range,
+    and (for the whole batch) hard constraints in W"""
+    rs = np.random.RandomState(11)
+    B, T, C = 4, 60, 20
+    x = rs.randn(B, T, C).astype(np.float32)
+    W = (0.5 * rs.randn(C + 1, C)).astype(np.float32)
+    x[1, 10, 3] = -np.inf              # an impossible emission
+    x[2, 20:24, :] -= 90.0 * np.arange(C, dtype=np.float32) / C  # 90 nats of spread inside a frame
+    x[3, 5, :] = np.nan                # NaN policy: an impossible frame -> no path at all
+    _dense_check(x, W, [False, True, True, True])
+    W2 = W.copy()
+    W2[1 + 4, 7] = -np.inf             # a forbidden transition: the whole batch takes the log-domain path
+    x2 = rs.randn(2, 30, C).astype(np.float32)
+    _dense_check(x2, W2, [True, True])
+    W3 = W.copy()
+    W3[0, :] = -np.inf                 # only start weights are impossible except one class
+    W3[0, 2] = 0.0
+    _dense_check(x2, W3, [True, True])
+
+
+def test_dense_baseline_shape_properties():
+    """cfg3 sizes (T=1000, C=100): no oracle at this size in seconds -- size-independent properties:
+    posteriors of every frame sum to the gradient coefficient, transition posteriors sum to T-1,
+    start posteriors to 1, and the fast sweep agrees with the log-domain kernels"""
+    from gtn_applications_amd import engine as E
+    from gtn_applications_amd import _native as N
+
+    g = torch.Generator().manual_seed(3)
+    B, T, C = 8, 1000, 100
+    x = torch.randn(B, T, C, generator=g).cuda()
+    W = torch.randn(C + 1, C, generator=g).cuda()
+    st = E.dense_forward(x, W)
+    assert not E.dense_flagged(st).any()
+    coef = torch.ones(B, device="cuda")
+    dx, dW = torch.empty_like(x), torch.zeros_like(W)
+    E.dense_grad(x, W, st, coef, coef_w=coef, dx=dx, dW=dW)
+    np.testing.assert_allclose(dx.sum(dim=2).cpu().numpy(), 1.0, rtol=2e-4)
+    assert float(dW[0].sum()) == pytest.approx(B, rel=2e-4)
+    assert float(dW[1:].sum()) == pytest.approx(B * (T - 1), rel=2e-4)
+    # same batch through the log-domain kernels: make the fast path unavailable with one -inf in a copy of W that
+    # no path needs (state 0 can still be reached from every other state)
+    Wh = W.clone()
+    Wh[1, 0] = float("-inf")
+    st_h = E.dense_forward(x, Wh)
+    assert E.dense_flagged(st_h).all()
+    W_soft = W.clone()
+    W_soft[1, 0] = -35.0  # numerically the same constraint (e^-35), still inside the fast path's range check
+    st_s = E.dense_forward(x, W_soft)
+    assert not E.dense_flagged(st_s).any()
+    np.testing.assert_allclose(st_s.logz.cpu().numpy(), st_h.logz.cpu().numpy(), rtol=1e-5)
+    dxs, dxh = torch.empty_like(x), torch.empty_like(x)
+    dWs, dWh = torch.zeros_like(W), torch.zeros_like(W)
+    E.dense_grad(x, W_soft, st_s, coef, coef_w=coef, dx=dxs, dW=dWs)
+    E.dense_grad(x, Wh, st_h, coef, coef_w=coef, dx=dxh, dW=dWh)
+    # the log-domain kernels keep plain fp32 log scores like gtn does: at T=1000 they are O(5000), whose ulp
+    # (5e-4) bounds the agreement of the posteriors; the fast sweep keeps its offsets in double
+    np.testing.assert_allclose(dxs.cpu().numpy(), dxh.cpu().numpy(), rtol=1e-2, atol=1e-6)
+    np.testing.assert_allclose(dWs.cpu().numpy(), dWh.cpu().numpy(), rtol=1e-2, atol=1e-3)
+
+
 # =================================================================================================
 # STC
 # =================================================================================================
