@@ -40,7 +40,7 @@ class LatticeDesc(ctypes.Structure):
             for n in (
                 "state_off", "arc_off", "eps_off", "lab_off", "lvl_off", "in_ptr", "out_ptr", "out_arc",
                 "ein_ptr", "eout_ptr", "eout_arc", "arc_src", "arc_dst", "arc_slot", "arc_lab", "arc_wid",
-                "eps_src", "eps_dst", "eps_wid", "labels", "lvl_ptr", "arc_orig", "eps_orig", "int_words",
+                "eps_src", "eps_dst", "eps_wid", "labels", "lvl_ptr", "arc_orig", "eps_orig", "slot_ptr", "slot_arc", "int_words",
                 "arc_w", "eps_w", "start_w", "accept_w", "float_words",
             )
         ]

@@ -188,9 +188,12 @@ class Transducer(torch.nn.Module):
         self.reduction = reduction
 
     def forward(self, inputs, targets):
-        if self.transitions is None:
-            inputs = torch.nn.functional.log_softmax(inputs, dim=2)
         self.tokens.arc_sort(True)
+        if self.transitions is None:
+            # transducer.py:186-187 applies log_softmax here; the engine fuses it into the gather
+            # (forward) and the gradient rows (backward) instead of materialising [B,T,C] twice
+            return _FusedLogSoftmaxTransducerLoss.apply(inputs, targets, self.tokens, self.lexicon, None, None,
+                                                        self.reduction)
         return TransducerLoss(inputs, targets, self.tokens, self.lexicon, self.transition_params,
                               self.transitions, self.reduction)
 
@@ -238,6 +241,11 @@ class TransducerLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inputs, targets, tokens, lexicon, transition_params=None, transitions=None,
                 reduction="none"):
+        return TransducerLossFunction._forward(ctx, False, inputs, targets, tokens, lexicon, transition_params,
+                                               transitions, reduction)
+
+    @staticmethod
+    def _forward(ctx, log_softmax, inputs, targets, tokens, lexicon, transition_params, transitions, reduction):
         B, T, C = inputs.shape
         if transitions is not None and transition_params is None:
             raise ValueError("Specified transitions, but not transition params.")
@@ -264,7 +272,7 @@ class TransducerLossFunction(torch.autograd.Function):
 
         pack, scale, cpos, cneg, _ = _PACK_CACHE.get(key + (reduction == "mean",), build)
         need_grad = inputs.requires_grad or (transition_params is not None and transition_params.requires_grad)
-        num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad)
+        num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax)
         loss = E.reduce_loss(num.logz, scale, -1.0)
         den = None
         if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288
@@ -289,6 +297,17 @@ class TransducerLossFunction(torch.autograd.Function):
         if dW is not None and ctx.devices[1].type != "cuda":
             dW = dW.to(ctx.devices[1])
         return dx, None, None, None, dW, None, None
+
+
+class _FusedLogSoftmaxTransducerLoss(TransducerLossFunction):
+    """TransducerLoss(log_softmax(inputs), ...) without transitions, as one operator: the gather
+    subtracts the rows' log-sum-exp, the gradient kernel differentiates through it."""
+
+    @staticmethod
+    def forward(ctx, inputs, targets, tokens, lexicon, transition_params=None, transitions=None,
+                reduction="none"):
+        return TransducerLossFunction._forward(ctx, True, inputs, targets, tokens, lexicon, transition_params,
+                                               transitions, reduction)
 
 
 TransducerLoss = TransducerLossFunction.apply

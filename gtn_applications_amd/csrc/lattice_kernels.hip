@@ -23,7 +23,7 @@ struct UttView {
   int a0, e0;
   const int32_t *in_ptr, *out_ptr, *out_arc, *ein_ptr, *eout_ptr, *eout_arc;
   const int32_t *arc_src, *arc_dst, *arc_slot, *arc_lab, *arc_wid, *arc_orig;
-  const int32_t *eps_src, *eps_dst, *eps_wid, *eps_orig, *labels, *lvl_ptr;
+  const int32_t *eps_src, *eps_dst, *eps_wid, *eps_orig, *labels, *lvl_ptr, *slot_ptr, *slot_arc;
   const float *arc_w, *eps_w, *start_w, *accept_w;
   int64_t ab_base, xg_base;
 };
@@ -54,6 +54,7 @@ __device__ __forceinline__ UttView make_view(const wfl_lattice_desc& d, const in
   v.eps_src = ints + d.eps_src + v.e0, v.eps_dst = ints + d.eps_dst + v.e0;
   v.eps_wid = ints + d.eps_wid + v.e0, v.eps_orig = ints + d.eps_orig + v.e0;
   v.labels = ints + d.labels + l0;
+  v.slot_ptr = ints + d.slot_ptr + l0 + bb, v.slot_arc = ints + d.slot_arc + v.a0;
   v.lvl_ptr = ints + d.lvl_ptr + lv0;
   v.arc_w = floats + d.arc_w + v.a0, v.eps_w = floats + d.eps_w + v.e0;
   v.start_w = floats + d.start_w + s0, v.accept_w = floats + d.accept_w + s0;
@@ -562,69 +563,113 @@ static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
 // ------------------------------------------------------------------------------------------------
 // stage 3: posteriors -> gradient rows
 // ------------------------------------------------------------------------------------------------
+#ifdef WFL_DBG_TIMELINE
+__device__ unsigned long long g_dbg[3 * 8192];
+#endif
 __global__ void __launch_bounds__(256)
     grad_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
                 const float* __restrict__ xg, int T, int C, const float* __restrict__ weights,
                 const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
                 const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
-                int accumulate, float* __restrict__ dx, float* __restrict__ dW, int rows_per_block, int TS) {
+                int accumulate, const float* __restrict__ x, const float* __restrict__ row_lse,
+                float* __restrict__ dx, float* __restrict__ dW, int rows_per_block, int TS) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
+#ifdef WFL_DBG_TIMELINE
+  const unsigned long long dbg_t0 = wall_clock64();
+#endif
   const UttView u = make_view(d, ints, floats, b, T);
   const int Q = u.Q, A = u.A, E = u.E, K = u.K, Kmax = d.max_labels;
-  float* rows = (float*)smem;                               // [TS][C] (absent when dx == NULL)
-  float* al = rows + (dx ? (size_t)TS * C : 0);             // [TS+1][Qmax]
+  // The dense rows never pass through LDS: posteriors are accumulated per (frame, distinct label)
+  // in a compact tile, and the rows are streamed out as base value (0, the existing gradient, or
+  // the softmax term of the fused log_softmax backward) plus the accumulator of the column's label
+  // slot, looked up in a column -> slot map.
+  float* al = (float*)smem;                                 // [TS+1][Qmax]
   float* be = al + (size_t)(TS + 1) * d.max_states;         // [TS+1][Qmax]
   float* xr = be + (size_t)(TS + 1) * d.max_states;         // [TS][Kmax]
-  float* dwacc = xr + (size_t)TS * Kmax;                    // [A + E] (only if dW)
+  float* acc = xr + (size_t)TS * Kmax;                      // [TS][Kmax] (only if dx)
+  float* dwacc = acc + (dx ? (size_t)TS * Kmax : 0);        // [A + E] (only if dW)
+  int2* sarc = (int2*)(dwacc + (dW ? (size_t)d.max_arcs + d.max_eps : 0));  // [A] by-slot {src | dst << 16, w - z}
+  int* sptr = (int*)(sarc + (dx ? d.max_arcs : 0));         // [K + 1]
+  int16_t* colmap = (int16_t*)(sptr + (dx ? Kmax + 1 : 0));  // [C] (only if dx)
   const float g0 = gout ? gout[0] : 1.f;
   const float cf = coef ? coef[b] * g0 : g0;
   const float z = logz[b];
   const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
   const int t_begin = blockIdx.x * rows_per_block;
   const int t_end = min(T, t_begin + rows_per_block);
+  const float inv_q = 1.f / (float)max(Q, 1), inv_c = 1.f / (float)C;
+  auto fdiv = [](int i, float inv) { return (int)(((float)i + 0.5f) * inv); };
   if (dW)
     for (int a = tid; a < A + E; a += NT) dwacc[a] = 0.f;
+  if (dx) {
+    for (int c = tid; c < C; c += NT) colmap[c] = -1;
+    __syncthreads();
+    for (int k = tid; k < K; k += NT) colmap[u.labels[k]] = (int16_t)k;
+    for (int k = tid; k <= K; k += NT) sptr[k] = u.slot_ptr[k];
+    for (int j = tid; j < A; j += NT) {
+      const int a = u.slot_arc[j];
+      const int wid = u.arc_wid[a];
+      float w = u.arc_w[a] - z;
+      if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+      sarc[j] = make_int2(u.arc_src[a] | (u.arc_dst[a] << 16), __float_as_int(w));
+    }
+  }
   for (int ts0 = t_begin; ts0 < t_end; ts0 += TS) {
     const int nr = min(TS, t_end - ts0);
     __syncthreads();
-    for (int i = tid; i < (nr + 1) * Q; i += NT) {
-      const int r = i / Q, q = i - r * Q;
-      al[r * d.max_states + q] = alpha[u.ab_base + (int64_t)(ts0 + r) * Q + q];
-      be[r * d.max_states + q] = beta[u.ab_base + (int64_t)(ts0 + r) * Q + q];
-    }
-    for (int i = tid; i < nr * K; i += NT) {
-      const int r = i / K, k = i - r * K;
-      xr[r * Kmax + k] = xg[u.xg_base + (int64_t)(ts0 + r) * Kmax + k];
-    }
-    float* gdst = dx ? dx + ((int64_t)b * T + ts0) * C : nullptr;
-    if (dx) {
-      if (accumulate)
-        for (int i = tid; i < nr * C; i += NT) rows[i] = gdst[i];
-      else
-        for (int i = tid; i < nr * C; i += NT) rows[i] = 0.f;
+    // flat, unrolled copy loops: the global loads of several iterations are in flight together
+    // (idx / n by float reciprocal: exact for idx < 2^20, see fdiv)
+    {
+      const float* asrc = alpha + u.ab_base + (int64_t)ts0 * Q;
+      const float* bsrc = beta + u.ab_base + (int64_t)ts0 * Q;
+      const int n = (nr + 1) * Q;
+#pragma unroll 4
+      for (int i = tid; i < n; i += NT) {
+        const int r = fdiv(i, inv_q), q = i - r * Q;
+        const float av = asrc[i], bv = bsrc[i];
+        al[r * d.max_states + q] = av;
+        be[r * d.max_states + q] = bv;
+      }
+      const float* xsrc = xg + u.xg_base + (int64_t)ts0 * Kmax;
+#pragma unroll 4
+      for (int i = tid; i < nr * Kmax; i += NT) {
+        xr[i] = xsrc[i];
+      }
     }
     __syncthreads();
     if (!dead) {
-      // one arc per thread (arc data in registers), frames of the tile in the inner loop
-      for (int a = tid; a < A; a += NT) {
-        const int wid = u.arc_wid[a];
-        float w = u.arc_w[a] - z;
-        if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
-        const float* pa = al + u.arc_src[a];
-        const float* pb = be + d.max_states + u.arc_dst[a];
-        const float* px = xr + u.arc_slot[a];
-        float* pr = rows + u.arc_lab[a];
-        float wsum = 0.f;
-        for (int r = 0; r < nr; ++r) {
-          const float v = pa[r * d.max_states] + px[r * Kmax] + w + pb[r * d.max_states];
-          if (v > WFL_NEG_INF) {
-            const float g = fast_exp(v);
-            if (dx) atomicAdd(&pr[r * C], g * cf);
-            wsum += g;
+      // emission gradient: one thread per (frame, emission slot) sums the posteriors of the slot's
+      // arcs (by-slot CSR staged in LDS) -- no atomics, all 256 lanes busy
+      if (dx) {
+        const float inv_k = 1.f / (float)max(K, 1);
+        for (int i = tid; i < nr * K; i += NT) {
+          const int r = fdiv(i, inv_k), k = i - r * K;
+          const float* pa = al + r * d.max_states;
+          const float* pb = pa + (be - al) + d.max_states;
+          const float xv = xr[r * Kmax + k];
+          float sum = 0.f;
+          for (int j = sptr[k]; j < sptr[k + 1]; ++j) {
+            const int2 a = sarc[j];
+            const float v = pa[a.x & 0xffff] + xv + __int_as_float(a.y) + pb[(unsigned)a.x >> 16];
+            sum += fast_exp(v);  // exp(-inf) = 0
           }
+          acc[r * Kmax + k] = sum;
         }
-        if (dW && wid >= 0 && wsum != 0.f) atomicAdd(&dwacc[a], wsum);
+      }
+      // learnable-weight gradient: one arc per thread, frames of the tile in the inner loop
+      if (dW) {
+        for (int a = tid; a < A; a += NT) {
+          const int wid = u.arc_wid[a];
+          if (wid < 0) continue;
+          const float w = u.arc_w[a] - z + (weights ? nan_to_neg(weights[wid]) : 0.f);
+          const float* pa = al + u.arc_src[a];
+          const float* pb = be + d.max_states + u.arc_dst[a];
+          const float* px = xr + u.arc_slot[a];
+          float wsum = 0.f;
+          for (int r = 0; r < nr; ++r) wsum += fast_exp(pa[r * d.max_states] + px[r * Kmax] + w + pb[r * d.max_states]);
+          if (wsum != 0.f) dwacc[a] += wsum;  // this thread owns dwacc[a]
+        }
       }
       if (dW && E > 0) {
         const int nslots = nr + ((ts0 + nr == T) ? 1 : 0);  // epsilon slots t = ts0 .. (T included once)
@@ -638,9 +683,55 @@ __global__ void __launch_bounds__(256)
         }
       }
     }
-    __syncthreads();
-    if (dx)
-      for (int i = tid; i < nr * C; i += NT) gdst[i] = rows[i];
+    if (dx) {
+      __syncthreads();
+      // fused log_softmax backward (ctc.py:107, transducer.py:186-187): with g = cf * posteriors the
+      // gradient w.r.t. the raw scores is g - softmax * sum_c g, and the posteriors of a frame sum to
+      // one, so the base value of a row is -cf * softmax(x)
+      float* gdst = dx + ((int64_t)b * T + ts0) * C;
+      const float* xsrc = row_lse ? x + ((int64_t)b * T + ts0) * C : nullptr;
+      const float* lse = row_lse ? row_lse + (int64_t)b * T + ts0 : nullptr;
+      const bool soft = row_lse && !dead;
+      auto value = [&](int r, int c, float have, float xv, float l) {
+        float v = have;
+        if (soft && l > WFL_NEG_INF) v -= cf * fast_exp(nan_to_neg(xv) - l);
+        const int k = colmap[c];
+        if (k >= 0 && !dead) v += cf * acc[r * Kmax + k];
+        return v;
+      };
+      if (C >= 512) {
+        // wide rows: one float4 per thread and row (rows are only 4-byte aligned: scalar head / tail)
+        const int64_t e0 = ((int64_t)b * T + ts0) * C;
+        for (int r = 0; r < nr; ++r) {
+          const int head = (int)((4 - ((e0 + (int64_t)r * C) & 3)) & 3);
+          const int nvec = (C - head) >> 2;
+          float* grow = gdst + (int64_t)r * C;
+          const float* xrow = soft ? xsrc + (int64_t)r * C : nullptr;
+          const float l = soft ? lse[r] : 0.f;
+          for (int j = tid; j < nvec; j += NT) {
+            const int c = head + 4 * j;
+            float4 have = make_float4(0.f, 0.f, 0.f, 0.f), xv = have;
+            if (accumulate) have = *reinterpret_cast<const float4*>(grow + c);
+            if (soft) xv = *reinterpret_cast<const float4*>(xrow + c);
+            float4 o;
+            o.x = value(r, c, have.x, xv.x, l), o.y = value(r, c + 1, have.y, xv.y, l);
+            o.z = value(r, c + 2, have.z, xv.z, l), o.w = value(r, c + 3, have.w, xv.w, l);
+            *reinterpret_cast<float4*>(grow + c) = o;
+          }
+          const int ntail = C - head - 4 * nvec;  // < 4
+          if (tid < head + ntail) {
+            const int c = tid < head ? tid : head + 4 * nvec + (tid - head);
+            grow[c] = value(r, c, accumulate ? grow[c] : 0.f, soft ? xrow[c] : 0.f, l);
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int i = tid; i < nr * C; i += NT) {
+          const int r = fdiv(i, inv_c), c = i - r * C;
+          gdst[i] = value(r, c, accumulate ? gdst[i] : 0.f, soft ? xsrc[i] : 0.f, soft ? lse[r] : 0.f);
+        }
+      }
+    }
   }
   if (dW) {
     __syncthreads();
@@ -651,6 +742,18 @@ __global__ void __launch_bounds__(256)
       if (wid >= 0 && g != 0.f) atomicAdd(&dW[wid], g * cw);
     }
   }
+#ifdef WFL_DBG_TIMELINE
+  if (tid == 0) {
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 8192) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_dbg[3 * wg] = dbg_t0, g_dbg[3 * wg + 1] = wall_clock64(), g_dbg[3 * wg + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -794,19 +897,25 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
                      const float* coef_w, const float* gout, int accumulate, const float* x, const float* row_lse,
                      float* dx, float* dW, void* stream) {
   if (int rc = check_desc(d, "lattice_grad")) return rc;
-  if (row_lse || x) {
-    set_error("lattice_grad: fused log-softmax backward is not built yet");
-    return WFL_ERR_UNSUPPORTED;
+  if ((row_lse != nullptr) != (x != nullptr)) {
+    set_error("lattice_grad: the fused log-softmax backward needs both x and row_lse");
+    return WFL_ERR_INVALID;
   }
   if (!alpha || !beta || !logz || (!dx && !dW)) {
     set_error("lattice_grad: alpha, beta, logz and at least one output are required");
     return WFL_ERR_INVALID;
   }
   if (T <= 0) return WFL_OK;
-  // frames per LDS sub-tile: keep the tile near 24 KiB so that six workgroups fit per CU -- each one
-  // is a load -> barrier -> compute -> barrier -> store sequence, overlap comes from co-residency
-  const size_t row_bytes = 4 * ((size_t)(dx ? C : 0) + 2 * (size_t)d->max_states + (size_t)d->max_labels);
-  const size_t fixed = 4 * (2 * (size_t)d->max_states + (dW ? (size_t)d->max_arcs + d->max_eps : 0)) + 64;
+  // frames per LDS sub-tile: alpha, beta, gathered emissions and the per-label accumulators of TS
+  // frames; ~24 KiB at most so that several workgroups are co-resident (each one is a load ->
+  // barrier -> compute -> barrier -> stream-out sequence, overlap comes from co-residency)
+  const size_t row_bytes = 4 * (2 * (size_t)d->max_states + (size_t)d->max_labels * (dx ? 2 : 1));
+  const size_t fixed = 4 * (2 * (size_t)d->max_states + (dW ? (size_t)d->max_arcs + d->max_eps : 0)) +
+                       (dx ? 8 * (size_t)d->max_arcs + 4 * ((size_t)d->max_labels + 1) + 2 * (size_t)C : 0) + 64;
+  if (dx && d->max_labels > 32767) {
+    set_error("lattice_grad: %d distinct labels per utterance (limit 32767)", d->max_labels);
+    return WFL_ERR_UNSUPPORTED;
+  }
   int TS = fixed + row_bytes < 24 * 1024 ? (int)((24 * 1024 - fixed) / row_bytes) : 1;
   TS = std::max(1, std::min(TS, 32));
   const size_t lds = fixed + row_bytes * TS;
@@ -814,17 +923,20 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
     set_error("lattice_grad: needs %zu B of LDS (limit %d)", lds, kLdsBytes);
     return WFL_ERR_UNSUPPORTED;
   }
-  // enough workgroups to fill 256 CUs several times over, but few enough that the per-block
-  // learnable-weight atomics stay cheap
-  int blocks_t = std::max(1, std::min((T + TS - 1) / TS, (2048 + d->B - 1) / d->B));
+  // Every workgroup takes about the same time and they all fit the chip at once only up to
+  // (resident workgroups per CU) x 256: a grid slightly above that costs a whole second round
+  // (measured: 1856 workgroups on 1536 slots = 2 x 250 us).  Size the grid to ONE round.
+  int per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, grad_kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  const int slots = per_cu * 256;
+  int blocks_t = std::max(1, std::min((T + TS - 1) / TS, slots / std::max(1, d->B)));
   int rows_per_block = (T + blocks_t - 1) / blocks_t;
-  rows_per_block = ((rows_per_block + TS - 1) / TS) * TS;
   blocks_t = (T + rows_per_block - 1) / rows_per_block;
   if (lds > 48 * 1024)
     WFL_HIP_CHECK(hipFuncSetAttribute((const void*)grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(grad_kernel, dim3((unsigned)blocks_t, (unsigned)d->B), dim3(256), lds, (hipStream_t)stream, *d,
-                     ints, floats, xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, dx, dW,
-                     rows_per_block, TS);
+                     ints, floats, xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, x, row_lse,
+                     dx, dW, rows_per_block, TS);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }
@@ -836,6 +948,18 @@ int wfl_lattice_backtrace(const wfl_lattice_desc* d, const int32_t* ints, const 
                      floats, alpha, bptr, T, path, path_len, path_stride);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
+}
+
+#ifdef WFL_DBG_TIMELINE
+int wfl_debug_timeline(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
+}
+#endif
+// diagnostic: resident workgroups per CU of the gradient kernel for a given dynamic LDS size
+int wfl_debug_grad_occupancy(int lds_bytes) {
+  int n = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, grad_kernel, 256, (size_t)lds_bytes) != hipSuccess) return -1;
+  return n;
 }
 
 int wfl_reduce_loss(const float* vals, const float* scale, int B, float sign, int accumulate, float* out, void* stream) {

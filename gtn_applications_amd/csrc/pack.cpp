@@ -29,7 +29,7 @@ struct Builder {
   std::vector<int32_t> in_ptr, out_ptr, out_arc, ein_ptr, eout_ptr, eout_arc;
   std::vector<int32_t> arc_src, arc_dst, arc_slot, arc_lab, arc_wid, arc_orig;
   std::vector<int32_t> eps_src, eps_dst, eps_wid, eps_orig;
-  std::vector<int32_t> labels, lvl_ptr;
+  std::vector<int32_t> labels, lvl_ptr, slot_ptr, slot_arc;
   std::vector<float> arc_w, eps_w, start_w, accept_w;
   int max_states = 0, max_arcs = 0, max_eps = 0, max_labels = 0, max_levels = 0;
   // scratch reused across utterances
@@ -126,6 +126,15 @@ struct Builder {
       for (const Arc& a : v) op[ob + a.src + 1]++;
       for (int q = 0; q < Q; ++q) op[ob + q + 1] += op[ob + q];
       oa.insert(oa.end(), order.begin(), order.end());
+      if (labelled) {  // by-slot order: the gradient kernel sums the arcs of one emission column without atomics
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return slot_of[v[a].lab] < slot_of[v[b].lab]; });
+        const size_t sb = slot_ptr.size();
+        slot_ptr.resize(sb + K + 1, 0);
+        for (const Arc& a : v) slot_ptr[sb + slot_of[a.lab] + 1]++;
+        for (int k = 0; k < K; ++k) slot_ptr[sb + k + 1] += slot_ptr[sb + k];
+        slot_arc.insert(slot_arc.end(), order.begin(), order.end());
+      }
       for (const Arc& a : v) {
         const float w = (a.w != a.w) ? NEG : a.w;  // NaN weight == impossible arc
         if (labelled) {
@@ -171,6 +180,7 @@ struct Builder {
     put(d.arc_src, arc_src), put(d.arc_dst, arc_dst), put(d.arc_slot, arc_slot), put(d.arc_lab, arc_lab);
     put(d.arc_wid, arc_wid), put(d.eps_src, eps_src), put(d.eps_dst, eps_dst), put(d.eps_wid, eps_wid);
     put(d.labels, labels), put(d.lvl_ptr, lvl_ptr), put(d.arc_orig, arc_orig), put(d.eps_orig, eps_orig);
+    put(d.slot_ptr, slot_ptr), put(d.slot_arc, slot_arc);
     d.int_words = (int64_t)h->ints.size();
     auto putf = [&](int64_t& off, const std::vector<float>& v) {
       off = (int64_t)h->floats.size();

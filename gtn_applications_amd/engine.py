@@ -140,10 +140,10 @@ class PackedLattice:
 class LatticeState:
     """Everything the backward pass needs from a forward pass of the lattice engine."""
 
-    __slots__ = ("pack", "T", "C", "xg", "alpha", "beta", "logz", "weights", "bptr")
+    __slots__ = ("pack", "T", "C", "xg", "alpha", "beta", "logz", "weights", "bptr", "x", "row_lse")
 
 
-def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_LOG):
+def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_LOG, log_softmax=False):
     """forward_score(intersect(emissions, A_b)) for every b: returns a LatticeState whose `logz`
     holds the per-utterance score (gtn call sites: ctc.py:50, asg.py:111, stc.py:86,
     transducer.py:283,287)."""
@@ -162,8 +162,12 @@ def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_L
     st.beta = torch.empty(max(n_ab.value, 1), dtype=_F32, device=dev) if (need_beta and not tropical) else None
     st.bptr = torch.empty(max(n_ab.value, 1), dtype=torch.int32, device=dev) if tropical else None
     st.logz = torch.empty(B, dtype=_F32, device=dev)
+    # log_softmax=True: x holds raw scores; the gather subtracts each row's log-sum-exp and the
+    # gradient kernel differentiates through it (ctc.py:107, transducer.py:186-187 fused into the path)
+    st.x = x if log_softmax else None
+    st.row_lse = torch.empty((B, T), dtype=_F32, device=dev) if log_softmax else None
     s = stream_ptr()
-    N.check(N.lib.wfl_lattice_gather(pack._desc_ref, ptr(pack.ints), ptr(x), T, C, ptr(st.xg), None, s))
+    N.check(N.lib.wfl_lattice_gather(pack._desc_ref, ptr(pack.ints), ptr(x), T, C, ptr(st.xg), ptr(st.row_lse), s))
     N.check(
         N.lib.wfl_lattice_forward(
             pack._desc_ref, ptr(pack.ints), ptr(pack.floats), ptr(st.xg), T, ptr(weights), semiring,
@@ -179,8 +183,8 @@ def lattice_grad(st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW
     N.check(
         N.lib.wfl_lattice_grad(
             p._desc_ref, ptr(p.ints), ptr(p.floats), ptr(st.xg), st.T, st.C, ptr(st.weights), ptr(st.alpha),
-            ptr(st.beta), ptr(st.logz), ptr(coef), ptr(coef_w), ptr(gout), int(bool(accumulate)), None, None,
-            ptr(dx), ptr(dW), stream_ptr(),
+            ptr(st.beta), ptr(st.logz), ptr(coef), ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(st.x),
+            ptr(st.row_lse), ptr(dx), ptr(dW), stream_ptr(),
         )
     )
 

@@ -121,6 +121,8 @@ typedef struct {
   int64_t lvl_ptr;   /* level boundaries (state ranges) for the epsilon closure                */
   int64_t arc_orig;  /* [total_arcs] caller's arc id of each labelled arc (for Viterbi paths)  */
   int64_t eps_orig;  /* [total_eps]                                                           */
+  int64_t slot_ptr;  /* [total_labels + B] CSR by emission slot over labelled arcs (gradient rows) */
+  int64_t slot_arc;  /* [total_arcs] labelled-arc ids in by-slot order                         */
   int64_t int_words; /* size of the int32 blob                                                 */
   /* element offsets into the float blob */
   int64_t arc_w;     /* [total_arcs] constant weight (NaN is stored as -inf)    */
