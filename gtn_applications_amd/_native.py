@@ -16,6 +16,7 @@ ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 1, 2, 3
 EPSILON = -1
 SEMIRING_LOG, SEMIRING_TROPICAL = 0, 1
 CTC_FAST_CHAIN = 2
+CONV_SPIKE, CONV_BLANK_OPTIONAL = 1, 2
 
 
 class WflError(RuntimeError):
@@ -107,6 +108,10 @@ _SIGS = {
         [POINTER(LatticeDesc), _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P],
     ),
     "wfl_lattice_backtrace": (c_int, [POINTER(LatticeDesc), _P, _P, _P, _P, c_int, _P, _P, c_int, _P]),
+    # device: ConvTransduce1D
+    "wfl_conv_forward": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "wfl_conv_grad": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P,
+                              _P]),
     # device: dense transitions
     "wfl_dense_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "wfl_dense_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),

@@ -9,9 +9,12 @@ transducer.py:265-281) runs in the C++ host library; everything that touches the
 """
 import itertools
 
+import math
+
 import numpy as np
 import torch
 
+from .. import _native as N
 from .. import engine as E
 from .. import graph as G
 
@@ -311,3 +314,138 @@ class _FusedLogSoftmaxTransducerLoss(TransducerLossFunction):
 
 
 TransducerLoss = TransducerLossFunction.apply
+
+
+# -------------------------------------------------------------------------------------------------
+# ConvTransduce1D (transducer.py:370-556)
+# -------------------------------------------------------------------------------------------------
+class _KernelTable:
+    """Device description of a lexicon for csrc/conv_kernels.hip (layout: include/wfl.h).  Arc ids
+    follow the insertion order of make_kernel_graph, which is also the layout of `kernel_params`
+    (transducer.py:474-483 hands consecutive slices of it to the kernels' arc weights)."""
+
+    def __init__(self, lexicon, blank_optional, spike):
+        self.lexicon = [tuple(int(c) for c in tok) for tok in lexicon]
+        self.blank_optional, self.spike = bool(blank_optional), bool(spike)
+        tab = np.zeros((len(self.lexicon), 36), dtype=np.int32)
+        ns = 0 if spike else 1
+        n = 0
+        for k, tok in enumerate(self.lexicon):
+            if len(tok) > 15:
+                raise ValueError(f"ConvTransduce1D: lexicon entry {k} has {len(tok)} sub-tokens (limit 15)")
+            tab[k, 0] = len(tok)
+            tab[k, 34] = n  # arc 0 -> 0
+            n += 1
+            for i, c in enumerate(tok):
+                tab[k, 2 + i] = c
+                tab[k, 18 + i] = n
+                skip = i > 0 and blank_optional and tok[i - 1] != c
+                if skip:
+                    tab[k, 1] |= 1 << i
+                n += 3 + ns + int(skip)
+        self.table, self.num_arcs = tab, n
+        self.flags = (N.CONV_SPIKE if spike else 0) | (N.CONV_BLANK_OPTIONAL if blank_optional else 0)
+        self._dev = {}
+
+    def on(self, device):
+        t = self._dev.get(device)
+        if t is None:
+            t = self._dev[device] = torch.from_numpy(self.table).to(device)
+        return t
+
+
+class ConvTransduce1DFunction(torch.autograd.Function):
+    """transducer.py:461-552.  `kernels` is the lexicon table built by ConvTransduce1D (a list of
+    kernel graphs made by make_kernel_graph is accepted too and converted).  Unlike the reference
+    there is no process-global CTX_GRAPHS: everything backward needs lives on `ctx` (re-entrant)."""
+
+    @staticmethod
+    def forward(ctx, inputs, kernels, kernel_size, stride, kernel_params=None, viterbi=False):
+        B, T, C = inputs.shape
+        if T < kernel_size:  # padding should be done outside of this function (transducer.py:468-470)
+            raise ValueError(f"Input ({T}) too short for kernel ({kernel_size})")
+        if not isinstance(kernels, _KernelTable):
+            raise TypeError("ConvTransduce1DFunction: pass the ConvTransduce1D module's kernel table")
+        dev = E.require_gpu()
+        x = E.as_device_f32(inputs.detach(), dev)
+        params = E.as_device_f32(kernel_params.detach(), dev) if kernel_params is not None else None
+        if params is not None and params.numel() != kernels.num_arcs:
+            raise ValueError(f"kernel_params has {params.numel()} entries, the kernels have {kernels.num_arcs} arcs")
+        tab = kernels.on(dev)
+        K = tab.shape[0]
+        blank = kernels.blank_idx
+        Tout = (T - kernel_size) // stride + 1
+        out = torch.empty((B, Tout, K), dtype=torch.float32, device=dev)
+        sr = N.SEMIRING_TROPICAL if viterbi else N.SEMIRING_LOG
+        N.check(N.lib.wfl_conv_forward(E.ptr(x), B, T, C, E.ptr(tab), K, kernel_size, stride, blank, kernels.flags,
+                                       E.ptr(params), sr, E.ptr(out), E.stream_ptr()))
+        ctx.aux = (x, params, tab, kernels, kernel_size, stride, sr)
+        ctx.devices = (inputs.device, None if kernel_params is None else kernel_params.device)
+        return out if inputs.is_cuda else out.to(inputs.device)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, params, tab, kernels, kernel_size, stride, sr = ctx.aux
+        B, T, C = x.shape
+        delta = E.as_device_f32(grad_output.detach(), x.device)
+        dx = torch.empty_like(x)
+        dparams = torch.zeros_like(params) if (params is not None and ctx.needs_input_grad[4]) else None
+        N.check(N.lib.wfl_conv_grad(E.ptr(x), B, T, C, E.ptr(tab), tab.shape[0], kernel_size, stride,
+                                    kernels.blank_idx, kernels.flags, E.ptr(params), sr, E.ptr(delta), E.ptr(dx),
+                                    E.ptr(dparams), E.stream_ptr()))
+        if ctx.devices[0].type != "cuda":
+            dx = dx.to(ctx.devices[0])
+        if dparams is not None and ctx.devices[1].type != "cuda":
+            dparams = dparams.to(ctx.devices[1])
+        return dx, None, None, None, dparams, None
+
+
+class ConvTransduce1D(torch.nn.Module):
+    """A 1D convolutional transducer layer (transducer.py:370-457): every lexicon entry is a small
+    alignment graph over the previous layer's tokens, slid over the input like a convolution."""
+
+    def __init__(self, lexicon, kernel_size, stride, blank_idx, blank_optional=True, learn_params=False,
+                 scale="none", normalize="none", viterbi=False, spike=False):
+        super().__init__()
+        self.normalize = normalize
+        self.viterbi = viterbi
+        if scale == "none":
+            self.scale = 1.0
+        elif scale == "sqrt":
+            self.scale = math.sqrt(kernel_size)
+        elif scale == "linear":
+            self.scale = kernel_size
+        else:
+            raise ValueError(f"Unknown scale {scale}")
+        if normalize not in ["none", "pre", "post"]:
+            raise ValueError(f"Unknown normalization {normalize}")
+        self.kernel_size = kernel_size
+        assert self.kernel_size % 2 != 0, "Use an odd kernel size for easy padding."
+        self.stride = stride
+
+        def size_with_rep(token):
+            return len(token) + sum(t1 == t2 for t1, t2 in zip(token[:-1], token[1:]))
+
+        min_kernel_size = max(size_with_rep(l) for l in lexicon)
+        if kernel_size < min_kernel_size:
+            raise ValueError(f"Kernel size needed of at least {min_kernel_size}.")
+        self.kernels = _KernelTable(lexicon, blank_optional, spike)
+        self.kernels.blank_idx = int(blank_idx)
+        self.kernel_params = None
+        if learn_params:
+            self.kernel_params = torch.nn.Parameter(torch.zeros(self.kernels.num_arcs))
+
+    def forward(self, inputs):
+        # inputs are of shape [B, T, C]
+        pad = self.kernel_size // 2
+        inputs = torch.nn.functional.pad(inputs, (0, 0, pad, pad))
+        if self.normalize == "pre":
+            inputs = torch.nn.functional.log_softmax(inputs, dim=2)
+        outputs = ConvTransduce1DFunction.apply(inputs, self.kernels, self.kernel_size, self.stride,
+                                                self.kernel_params, self.viterbi)
+        outputs = outputs / self.scale
+        if self.normalize == "post":
+            outputs = torch.nn.functional.softmax(outputs, dim=2)
+        if self.normalize == "pre":
+            outputs = outputs.exp()
+        return outputs

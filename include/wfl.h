@@ -222,6 +222,27 @@ int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float
                       int32_t* bptr, int32_t* path, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Device kernels: ConvTransduce1D (transducer.py:351-556)
+ *   out[b, w, k] = forward_score | viterbi_score (intersect(x[b, w*stride : w*stride+ks, :],
+ *                  make_kernel_graph(lexicon[k])))                       transducer.py:485-500
+ *   x [B,T,C] already padded by the caller (T >= ks, transducer.py:468-470), Tout = (T-ks)/stride+1.
+ *   ktab [K][36] int32 describes the lexicon: {L, skip mask (bit i: arc 2i-1 -> 2i+1 exists),
+ *   tok[16], base[16] (index in kernel_params of entry k's arc 2i -> 2i+1), index of its arc 0->0,
+ *   pad}; arc ids follow the insertion order of make_kernel_graph (transducer.py:351-364).
+ *   params: kernel_params (NULL: all arc weights 0).  L <= 15, ks <= 16.
+ * ------------------------------------------------------------------------------------------------ */
+#define WFL_CONV_SPIKE 1          /* flags: no self loops on sub-token states */
+#define WFL_CONV_BLANK_OPTIONAL 2 /* flags: state 2L-1 accepts, skip arcs between different sub-tokens */
+int wfl_conv_forward(const float* x, int B, int T, int C, const int32_t* ktab, int K, int ks,
+                     int stride, int blank, int flags, const float* params, int semiring, float* out,
+                     void* stream);
+/* dx [B,T,C] = sum_{w,k} delta[b,w,k] * d out[b,w,k] / d x (overwritten); dparams [num_arcs]
+ * (accumulated, may be NULL) likewise for kernel_params (transducer.py:514-552). */
+int wfl_conv_grad(const float* x, int B, int T, int C, const int32_t* ktab, int K, int ks, int stride,
+                  int blank, int flags, const float* params, int semiring, const float* delta,
+                  float* dx, float* dparams, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Device kernels: CTC fast path (create_ctc_graph + intersect + forward_score + backward of
  * ctc.py:15-94; banded recursion with register-resident state, no lattice arrays).
  *   targets: device int32 flat, offsets: device int64 [B+1]; requires max target length <= 63

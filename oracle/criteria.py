@@ -459,6 +459,74 @@ class TransducerOracle:
         return res
 
 
+def conv_transduce_1d_grad(x, lexicon, blank_idx, kernel_size, stride, deltas, blank_optional=True, spike=False,
+                           kernel_params=None, viterbi=False):
+    """transducer.py:461-552 forward + backward for x [B,T,C] (already padded) and upstream
+    gradients deltas [B,Tout,K]: returns (out [B,Tout,K], dx [B,T,C], dparams [num_arcs] or None)."""
+    x = np.asarray(x, dtype=np.float64)
+    B, T, C = x.shape
+    if T < kernel_size:
+        raise ValueError(f"Input ({T}) too short for kernel ({kernel_size})")
+    kernels = [make_kernel_graph(l, blank_idx, blank_optional, spike) for l in lexicon]
+    if kernel_params is not None:  # transducer.py:474-483: consecutive slices of kernel_params
+        kp = np.asarray(kernel_params, dtype=np.float64)
+        s = 0
+        for k in kernels:
+            na = k.num_arcs()
+            k.set_weights(kp[s:s + na])
+            k.calc_grad = True
+            k.zero_grad()
+            s += na
+    score = G.viterbi_score if viterbi else G.forward_score
+    starts = list(range(0, T - kernel_size + 1, stride))
+    out = np.zeros((B, len(starts), len(kernels)))
+    dx = np.zeros_like(x)
+    for b in range(B):
+        for w, t in enumerate(starts):
+            em = emissions_graph(x[b, t:t + kernel_size], True)
+            for c, k in enumerate(kernels):
+                o = score(G.intersect(em, k))
+                out[b, w, c] = o.item()
+                G.backward(o, G.scalar_graph(float(deltas[b][w][c])))
+            dx[b, t:t + kernel_size] += em.grad64().reshape(kernel_size, C)
+    dparams = None
+    if kernel_params is not None:
+        dparams = np.concatenate([k.grad64() for k in kernels])
+    return out, dx, dparams
+
+
+def conv_layer(x, lexicon, kernel_size, stride, blank_idx, out_weights, blank_optional=True, learn_params=False,
+               scale="none", normalize="none", viterbi=False, spike=False, kernel_params=None):
+    """The ConvTransduce1D module (transducer.py:438-457) around conv_transduce_1d_grad, with the
+    scalar objective sum(out * out_weights): returns (out, d objective / d x, d / d kernel_params)."""
+    x = np.asarray(x, dtype=np.float64)
+    W = np.asarray(out_weights, dtype=np.float64)
+    pad = kernel_size // 2
+    xp = np.pad(x, ((0, 0), (pad, pad), (0, 0)))
+    xin = log_softmax(xp, 2) if normalize == "pre" else xp
+    sc = {"none": 1.0, "sqrt": math.sqrt(kernel_size), "linear": float(kernel_size)}[scale]
+    ones = np.ones((x.shape[0], (xp.shape[1] - kernel_size) // stride + 1, len(lexicon)))
+    raw, _, _ = conv_transduce_1d_grad(xin, lexicon, blank_idx, kernel_size, stride, 0.0 * ones, blank_optional, spike,
+                                       kernel_params if learn_params else None, viterbi)
+    y = raw / sc
+    if normalize == "post":
+        e = np.exp(y - y.max(axis=2, keepdims=True))
+        out = e / e.sum(axis=2, keepdims=True)
+        dy = out * (W - (W * out).sum(axis=2, keepdims=True))
+    elif normalize == "pre":
+        out = np.exp(y)
+        dy = W * out
+    else:
+        out, dy = y, W
+    _, dxin, dparams = conv_transduce_1d_grad(xin, lexicon, blank_idx, kernel_size, stride, dy / sc, blank_optional,
+                                              spike, kernel_params if learn_params else None, viterbi)
+    if normalize == "pre":
+        dxp = dxin - np.exp(xin) * dxin.sum(axis=2, keepdims=True)
+    else:
+        dxp = dxin
+    return out, dxp[:, pad:xp.shape[1] - pad], dparams
+
+
 def conv_transduce_1d(x, kernels, kernel_size, stride, viterbi=False):
     """transducer.py:461-524 forward only: [B,T,C] -> [B,Tout,len(kernels)] window scores."""
     x = np.asarray(x, dtype=np.float64)

@@ -202,6 +202,35 @@ def write_golden(ctc, asg, stc, transducer):
                    ngram=2, blank="optional", allow_repeats=False, reduction="mean")
     run_transducer("tr_ngram2_noblank", toks, gi, [[2, 1], [0, 3, 3]], 6, 23, trans_scale=0.5, ngram=2)
 
+    # ---- ConvTransduce1D (criterions/transducer.py:370-556), the reference module itself ------------
+    def run_conv(name, lexicon, ks, stride, blank_idx, B, T, C, seed, param_scale=0.0, **kw):
+        g = torch.Generator().manual_seed(seed)
+        layer = transducer.ConvTransduce1D(lexicon, ks, stride, blank_idx, **kw)
+        if layer.kernel_params is not None and param_scale:
+            with torch.no_grad():
+                layer.kernel_params.copy_(param_scale * torch.randn(layer.kernel_params.numel(), generator=g))
+        x = torch.randn(B, T, C, generator=g).requires_grad_(True)
+        out = layer(x)
+        w = torch.randn(out.shape, generator=g)
+        (out * w).sum().backward()
+        rec = dict(kind="conv", lexicon=[list(l) for l in lexicon], kernel_size=ks, stride=stride,
+                   blank_idx=blank_idx, kwargs=kw, inputs=_tolist(x), out_weights=_tolist(w),
+                   outputs=_tolist(out), grad=_tolist(x.grad))
+        if layer.kernel_params is not None:
+            rec["kernel_params"] = _tolist(layer.kernel_params)
+            rec["kernel_grad"] = _tolist(layer.kernel_params.grad)
+        cases[name] = rec
+
+    lex4 = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    run_conv("conv_basic", lex4, 5, 3, 2, 2, 8, 3, 31)
+    run_conv("conv_no_optional_blank", lex4, 5, 2, 2, 2, 7, 3, 32, blank_optional=False)
+    run_conv("conv_spike_sqrt", [(0,), (1, 2), (2, 1, 0)], 5, 1, 3, 1, 6, 4, 33, spike=True, scale="sqrt")
+    run_conv("conv_learned_post", [(0, 1, 2), (2,), (1, 1)], 7, 4, 3, 2, 9, 4, 34, param_scale=0.5,
+             learn_params=True, normalize="post", scale="linear")
+    run_conv("conv_viterbi_pre", lex4, 5, 3, 2, 2, 8, 3, 35, viterbi=True, normalize="pre")
+    run_conv("conv_viterbi_learned", [(0, 1), (1,), (0, 0)], 5, 2, 2, 1, 7, 3, 36, param_scale=0.7,
+             viterbi=True, learn_params=True)
+
     # ---- structural goldens of the graph builders ----------------------------------------------
     def dump(gr):
         return dict(

@@ -612,3 +612,93 @@ def test_transducer_backoff_transitions(crit, lit, tmp_path):
     assert loss.item() == pytest.approx(want_loss, rel=RTOL)
     close(xt.grad, want_dx)
     close(m.transition_params.grad, want_dp, atol=2e-5)
+
+
+# =================================================================================================
+# ConvTransduce1D
+# =================================================================================================
+def test_conv_transduce_golden_cases(crit, cases):
+    """the reference module (run on the oracle primitives) vs the HIP layer: outputs, input gradient
+    and kernel-parameter gradient for the objective sum(out * w), forward and Viterbi scores"""
+    tr = crit["transducer"]
+    n = 0
+    for name, c in cases.items():
+        if c["kind"] != "conv":
+            continue
+        n += 1
+        layer = tr.ConvTransduce1D([tuple(l) for l in c["lexicon"]], c["kernel_size"], c["stride"], c["blank_idx"],
+                                   **c["kwargs"])
+        if "kernel_params" in c:
+            with torch.no_grad():
+                layer.kernel_params.copy_(torch.tensor(c["kernel_params"]))
+            layer.cuda()
+        x = dev(np.array(c["inputs"], dtype=np.float32), grad=True)
+        out = layer(x)
+        close(out, c["outputs"], msg=name)
+        (out * dev(np.array(c["out_weights"], dtype=np.float32))).sum().backward()
+        close(x.grad, c["grad"], msg=name)
+        if "kernel_grad" in c:
+            close(layer.kernel_params.grad, c["kernel_grad"], msg=name)
+    assert n >= 6
+
+
+@pytest.mark.parametrize("viterbi,learn,spike,bo", [(False, False, False, True), (False, True, True, False),
+                                                    (True, True, False, True), (False, True, False, True)])
+def test_conv_transduce_vs_oracle(crit, viterbi, learn, spike, bo):
+    """random lexicon with repeats, overlapping windows (stride < kernel), more entries than one
+    workgroup pass (K > 16), CPU-resident input"""
+    tr = crit["transducer"]
+    rs = np.random.RandomState(17 + 2 * viterbi + learn)
+    C, blank, ks, stride, B, T = 6, 5, 7, 2, 2, 11
+    lexicon = [tuple(rs.randint(0, 5, size=rs.randint(1, 4)).tolist()) for _ in range(21)] + [(1, 1, 1), (2, 2, 3)]
+    layer = tr.ConvTransduce1D(lexicon, ks, stride, blank, blank_optional=bo, learn_params=learn, viterbi=viterbi,
+                               spike=spike)
+    params = None
+    if learn:
+        params = (0.5 * rs.randn(layer.kernel_params.numel())).astype(np.float32)
+        with torch.no_grad():
+            layer.kernel_params.copy_(torch.from_numpy(params))
+    x = rs.randn(B, T, C).astype(np.float32)
+    w = rs.randn(B, (T + 2 * (ks // 2) - ks) // stride + 1, len(lexicon)).astype(np.float32)
+    want_out, want_dx, want_dp = OC.conv_layer(x, lexicon, ks, stride, blank, w, blank_optional=bo, learn_params=learn,
+                                               viterbi=viterbi, spike=spike, kernel_params=params)
+    xt = torch.from_numpy(x).requires_grad_(True)  # CPU tensor in, CPU tensors out
+    out = layer(xt)
+    assert out.device.type == "cpu" and tuple(out.shape) == want_out.shape
+    close(out, want_out)
+    (out * torch.from_numpy(w)).sum().backward()
+    close(xt.grad, want_dx)
+    if learn:
+        close(layer.kernel_params.grad, want_dp, atol=5e-5)
+
+
+def test_conv_transduce_shapes_and_errors(crit):
+    """tests/transducer_test.py:57-96: output shapes for every input length, ValueError on T = 0"""
+    tr = crit["transducer"]
+    lexicon = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    conv = tr.ConvTransduce1D(lexicon, 5, 3, 2)
+    with pytest.raises(ValueError):
+        conv(torch.randn(2, 0, 3))
+    for Tin in (1, 2, 3, 4):
+        conv(torch.randn(2, Tin, 3))
+    for Ti, To in zip((1, 3, 4, 6, 7, 8), (1, 1, 2, 2, 3, 3)):
+        x = torch.randn(2, Ti, 3, requires_grad=True)
+        out = conv(x)
+        assert tuple(out.shape) == (2, To, len(lexicon))
+        out.backward(torch.ones_like(out))
+        assert torch.isfinite(x.grad).all()
+    # an entry that cannot be aligned inside the window (three repeats need tok,blank,tok,blank,tok and, without
+    # the optional blank, a final blank: 6 frames > 5): score -inf like forward_score of an empty intersection,
+    # and no NaN in the gradient of the other entries
+    conv2 = tr.ConvTransduce1D([(0, 0, 0), (1,)], 5, 5, 2, blank_optional=False)
+    x = torch.randn(1, 5, 3, requires_grad=True)
+    out = conv2(x)
+    assert out[0, 0, 0] == float("-inf") and torch.isfinite(out[0, 0, 1])
+    out[0, 0, 1].backward()
+    assert torch.isfinite(x.grad).all()
+    with pytest.raises(ValueError):
+        tr.ConvTransduce1D([(0, 0, 0)], 3, 1, 2)  # kernel too small for the entry (transducer.py:425-426)
+    with pytest.raises(ValueError):
+        tr.ConvTransduce1D(lexicon, 5, 1, 2, scale="cubic")
+    with pytest.raises(ValueError):
+        tr.ConvTransduce1D(lexicon, 5, 1, 2, normalize="both")

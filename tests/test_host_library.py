@@ -266,3 +266,33 @@ def test_compat_aliases():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_conv_kernel_table_matches_kernel_graphs():
+    """the device table of ConvTransduce1D numbers arcs exactly like make_kernel_graph inserts them
+    (transducer.py:351-364), for every blank_optional / spike combination"""
+    from gtn_applications_amd.criterions import transducer as TR
+
+    lexicon = [(0, 0), (0, 1), (1,), (2, 1, 1, 0), ()]
+    for bo in (True, False):
+        for spike in (True, False):
+            tab = TR._KernelTable(lexicon, bo, spike)
+            n = 0
+            for k, tok in enumerate(lexicon):
+                g = TR.make_kernel_graph(tok, 3, bo, spike)
+                a = g.arrays()
+                src, dst, lab = a["src"].tolist(), a["dst"].tolist(), a["ilabel"].tolist()
+                assert tab.table[k, 0] == len(tok) and tab.table[k, 34] == n
+                assert (src[0], dst[0], lab[0]) == (0, 0, 3)
+                ns = 0 if spike else 1
+                for i, c in enumerate(tok):
+                    base = tab.table[k, 18 + i] - n
+                    assert (src[base], dst[base], lab[base]) == (2 * i, 2 * i + 1, c)
+                    if ns:
+                        assert (src[base + 1], dst[base + 1], lab[base + 1]) == (2 * i + 1, 2 * i + 1, c)
+                    assert (src[base + 1 + ns], dst[base + 1 + ns], lab[base + 1 + ns]) == (2 * i + 1, 2 * i + 2, 3)
+                    assert (src[base + 2 + ns], dst[base + 2 + ns], lab[base + 2 + ns]) == (2 * i + 2, 2 * i + 2, 3)
+                    if (tab.table[k, 1] >> i) & 1:
+                        assert (src[base + 3 + ns], dst[base + 3 + ns], lab[base + 3 + ns]) == (2 * i - 1, 2 * i + 1, c)
+                n += g.num_arcs()
+            assert tab.num_arcs == n
