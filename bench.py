@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--C", type=int, default=None)
     ap.add_argument("--L", type=int, default=44)
+    ap.add_argument("--ctc-chain", default="default", choices=["default", "log", "fast"],
+                    help="CTC chain kernel: library default, log-domain, or fp64 probability-domain + certificate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-utts", type=int, default=128)
     return ap.parse_args()
@@ -93,10 +95,12 @@ def make_ctc(args, rank, mode):
             e.record()
             events.append(e)
 
+    from gtn_applications_amd import _native as N
+    chain_flags = {"default": E.CTC_DEFAULT_FLAGS, "log": 0, "fast": N.CTC_FAST_CHAIN}[args.ctc_chain]
     if mode == "abi":
         def step(events=None):
             mark(events)
-            ws, nll = E.ctc_forward(x, tg, blank)          # alpha || beta chains
+            ws, nll = E.ctc_forward(x, tg, blank, chain_flags)  # alpha || beta chains
             mark(events)
             E.reduce_loss(nll, scale, 1.0)
             E.ctc_grad(x, tg, blank, ws, nll, coef, gout, dx)  # posteriors -> dense gradient

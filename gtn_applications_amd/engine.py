@@ -289,12 +289,17 @@ class CtcTargets:
         self.dev_offsets = torch.from_numpy(self.offsets).to(device)
 
 
-def ctc_forward(x, tg, blank, flags=0):
+CTC_DEFAULT_FLAGS = 0  # chain kernel used by the criteria (see include/wfl.h, WFL_CTC_FAST_CHAIN)
+
+
+def ctc_forward(x, tg, blank, flags=None):
     B, T, C = x.shape
     n = ctypes.c_int64()
     N.check(N.lib.wfl_ctc_workspace(B, T, C, tg.max_len, ctypes.byref(n)))
     ws = torch.empty(n.value, dtype=_F32, device=x.device)
     nll = torch.empty(B, dtype=_F32, device=x.device)
+    if flags is None:
+        flags = CTC_DEFAULT_FLAGS
     N.check(
         N.lib.wfl_ctc_forward(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank, flags,
                               ptr(ws), ptr(nll), stream_ptr())
