@@ -280,6 +280,30 @@ def main():
         ach = alg_bytes / (ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "whole step (host-timed)", "achieved": ach,
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None}
+    if rank == 0 and world == 1 and args.workload == "ctc" and args.mode == "abi":
+        # the same three launches captured once in a hipGraph and replayed (no host launch gaps, no event records)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(graph):
+                step()
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            n_rep = max(args.steps, 20)
+            t0 = time.perf_counter()
+            for _ in range(n_rep):
+                graph.replay()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            out["hip_graph"] = {"value": B * n_rep / el, "unit": "utt/s", "ms_per_step": el * 1e3 / n_rep,
+                                "what": "the step's kernels captured in one hipGraph and replayed"}
+        except Exception as exc:  # capture is an extra, never fail the bench on it
+            out["hip_graph"] = {"error": str(exc)[:200]}
     if rank == 0 and world == 1 and args.workload == "ctc":
         if args.mode == "abi":  # the same step through the Python drop-in operator, for the record
             step_api, _, _, _ = make_ctc(args, rank, "api")

@@ -14,17 +14,30 @@ from . import _native as N
 _F32 = torch.float32
 
 
+_HAVE_GPU = None
+_DEVICES = {}
+
+
 def require_gpu():
-    if not torch.cuda.is_available():
+    global _HAVE_GPU
+    if _HAVE_GPU is None:  # (a visible GPU does not go away within a process)
+        _HAVE_GPU = bool(torch.cuda.is_available())
+    if not _HAVE_GPU:
         raise RuntimeError(
             "gtn_applications_amd: no ROCm GPU visible. The criteria run on HIP kernels only; "
             "there is deliberately no CPU fallback."
         )
-    return torch.device("cuda", torch.cuda.current_device())
+    idx = torch.cuda.current_device()
+    dev = _DEVICES.get(idx)
+    if dev is None:
+        dev = _DEVICES[idx] = torch.device("cuda", idx)
+    return dev
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of torch's current stream on the current device (what current_stream().cuda_stream
+    # returns, without building the Stream object: this sits on every launch)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def ptr(t):
@@ -289,14 +302,19 @@ class CtcTargets:
         self.dev_offsets = torch.from_numpy(self.offsets).to(device)
 
 
+_CTC_WS_SIZES = {}
 CTC_DEFAULT_FLAGS = 0  # chain kernel used by the criteria (see include/wfl.h, WFL_CTC_FAST_CHAIN)
 
 
 def ctc_forward(x, tg, blank, flags=None):
     B, T, C = x.shape
-    n = ctypes.c_int64()
-    N.check(N.lib.wfl_ctc_workspace(B, T, C, tg.max_len, ctypes.byref(n)))
-    ws = torch.empty(n.value, dtype=_F32, device=x.device)
+    key = (B, T, C, tg.max_len)
+    n_ws = _CTC_WS_SIZES.get(key)
+    if n_ws is None:
+        n = ctypes.c_int64()
+        N.check(N.lib.wfl_ctc_workspace(B, T, C, tg.max_len, ctypes.byref(n)))
+        n_ws = _CTC_WS_SIZES[key] = n.value
+    ws = torch.empty(n_ws, dtype=_F32, device=x.device)
     nll = torch.empty(B, dtype=_F32, device=x.device)
     if flags is None:
         flags = CTC_DEFAULT_FLAGS
@@ -351,6 +369,6 @@ _TARGET_CACHE = LRU(64)
 
 def targets_on_device(targets, device):
     """Upload (once per distinct content) the targets of a batch; content-keyed LRU."""
-    rows = [t.tolist() if hasattr(t, "tolist") else list(t) for t in targets]
+    rows = [t.tolist() if hasattr(t, "tolist") else (t if type(t) is list else list(t)) for t in targets]
     key = (tuple(map(tuple, rows)), device.index)
     return _TARGET_CACHE.get(key, lambda: CtcTargets(rows, device))
