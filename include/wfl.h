@@ -197,6 +197,9 @@ int wfl_lattice_backtrace(const wfl_lattice_desc* d, const int32_t* ints, const 
                           const float* alpha, const int32_t* bptr, int T, int32_t* path,
                           int32_t* path_len, int path_stride, void* stream);
 
+/* diagnostic: resident workgroups per CU of the lattice gradient kernel for a dynamic LDS size */
+int wfl_debug_grad_occupancy(int lds_bytes);
+
 /* ------------------------------------------------------------------------------------------------
  * Device kernels: dense (fully connected) transitions -- ASG denominator / ASG Viterbi
  *   W [(C+1), C] row-major: W[0,i] start->i, W[1+i, j] = score(prev j -> cur i)  (asg.py:54-69)
