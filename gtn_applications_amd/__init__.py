@@ -4,4 +4,37 @@ gfx950 HIP kernels behind the C ABI of include/wfl.h (libwfl.so).  See DESIGN.md
 from . import _native  # noqa: F401  (fails loudly if libwfl.so is missing)
 from . import graph  # noqa: F401
 
-__all__ = ["graph", "criterions", "engine"]
+__all__ = ["graph", "criterions", "engine", "load_criterion"]
+
+
+def load_criterion(criterion_type, preprocessor, config):
+    """The reference's criterion factory (utils.py:245-273): returns (criterion, output_size).
+    `preprocessor` needs `num_tokens`, and for the transducer `tokens` and `graphemes_to_index`."""
+    from . import graph as G
+    from .criterions import asg, ctc, transducer
+
+    num_tokens = preprocessor.num_tokens
+    if criterion_type == "asg":
+        num_replabels = config.get("num_replabels", 0)
+        use_garbage = config.get("use_garbage", True)
+        return (asg.ASG(num_tokens, num_replabels, use_garbage), num_tokens + num_replabels + int(use_garbage))
+    elif criterion_type == "ctc":
+        use_pt = config.get("use_pt", True)  # use pytorch implementation
+        return ctc.CTC(num_tokens, use_pt), num_tokens + 1  # account for blank
+    elif criterion_type == "transducer":
+        blank = config.get("blank", "none")
+        transitions = config.get("transitions", None)
+        if transitions is not None:
+            transitions = G.load(transitions)  # text format (gtn's binary format is unpinned, DESIGN.md section 7)
+        criterion = transducer.Transducer(
+            preprocessor.tokens,
+            preprocessor.graphemes_to_index,
+            ngram=config.get("ngram", 0),
+            transitions=transitions,
+            blank=blank,
+            allow_repeats=config.get("allow_repeats", True),
+            reduction="mean",
+        )
+        return criterion, num_tokens + int(blank != "none")
+    else:
+        raise ValueError(f"Unknown model type {criterion_type}")

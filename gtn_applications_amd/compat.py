@@ -3,7 +3,7 @@
 `from utils import ASGLoss` (benchmarks/asg_benchmark.py:13), `import transducer`
 (benchmarks/transducer_benchmark.py:13, tests/transducer_test.py:17-19),
 `utils.pack_replabels` (tests/utils_test.py:19), `from criterions import ctc, asg, transducer`
-(utils.py:19).  `install()` registers them in `sys.modules`; nothing is copied or patched on disk.
+(utils.py:19), `utils.load_criterion` (utils.py:245-273; callers train.py:201, test.py:75).  `install()` registers them in `sys.modules`; nothing is copied or patched on disk.
 """
 import sys
 import types
@@ -22,8 +22,10 @@ def install(gtn_alias=False):
         utils = types.ModuleType("utils")
         utils.__doc__ = "criterion names of the reference's former flat layout (gtn_applications_amd.compat)"
         sys.modules["utils"] = utils
+    from . import load_criterion
+
     for name, obj in dict(
-        CTCLoss=ctc.CTCLoss, CTCLossFunction=ctc.CTCLossFunction, ASGLoss=asg.ASGLoss,
+        load_criterion=load_criterion, CTCLoss=ctc.CTCLoss, CTCLossFunction=ctc.CTCLossFunction, ASGLoss=asg.ASGLoss,
         ASGLossFunction=asg.ASGLossFunction, pack_replabels=asg.pack_replabels,
         unpack_replabels=asg.unpack_replabels, STCLoss=stc.STCLoss,
     ).items():

@@ -296,3 +296,25 @@ def test_conv_kernel_table_matches_kernel_graphs():
                         assert (src[base + 3 + ns], dst[base + 3 + ns], lab[base + 3 + ns]) == (2 * i - 1, 2 * i + 1, c)
                 n += g.num_arcs()
             assert tab.num_arcs == n
+
+
+def test_load_criterion_factory(golden_dir):
+    """utils.load_criterion (utils.py:245-273): criterion types, output sizes, unknown type"""
+    import types
+
+    import gtn_applications_amd as pkg
+
+    pre = types.SimpleNamespace(num_tokens=5, tokens=["a", "b", "ab", "ba", "aba"], graphemes_to_index={"a": 0, "b": 1})
+    crit, n = pkg.load_criterion("ctc", pre, {})
+    assert n == 6 and crit.blank == 5
+    crit, n = pkg.load_criterion("asg", pre, {"num_replabels": 1, "use_garbage": True})
+    assert n == 7 and tuple(crit.transitions.shape) == (8, 7)
+    crit, n = pkg.load_criterion("transducer", pre, {"blank": "optional", "allow_repeats": False, "ngram": 2})
+    assert n == 6 and crit.transition_params is not None and crit.reduction == "mean"
+    crit, n = pkg.load_criterion("transducer", pre, {})
+    assert n == 5 and crit.transition_params is None
+    with pytest.raises(ValueError):
+        pkg.load_criterion("seq2seq", pre, {})
+    from gtn_applications_amd import compat
+
+    assert compat.install().load_criterion is pkg.load_criterion
