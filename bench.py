@@ -189,12 +189,38 @@ def cpu_baseline(payload, n_utts):
         cpu_ref.ctc_cpu(xs, tg, blank, "none", cores)
         reps += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 20:
+        if el > 10.0:  # a bounded sample: about 10 s of wall clock on all host cores
             break
     return dict(
         value=n * reps / el, unit="utt/s", cores=cores, kind="port",
         sample=f"{reps} x fwd+bwd of {n} utterances (same T,C,L) with oracle/cpu_ref.c on {cores} threads, {el:.1f} s",
     )
+
+
+def cpu_torch_ctc(payload):
+    """torch.nn.functional.ctc_loss on the host cores -- the reference's own alternative CTC path
+    (criterions/ctc.py:109-121) -- on the same batch, forward + backward, for context."""
+    x, targets, blank = payload
+    xc = x.detach().cpu().requires_grad_(True)
+    B, T, _ = xc.shape
+    tg = torch.tensor(targets, dtype=torch.long)
+    lens = torch.full((B,), tg.shape[1], dtype=torch.long)
+
+    def run():
+        xc.grad = None
+        torch.nn.functional.ctc_loss(xc.permute(1, 0, 2), tg, torch.full((B,), T, dtype=torch.long), lens,
+                                     blank=blank, reduction="sum").backward()
+
+    run()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 3.0:
+            break
+    return dict(value=B * reps / el, unit="utt/s", threads=torch.get_num_threads(),
+                what=f"torch.nn.functional.ctc_loss fwd+bwd on CPU, {reps} x {B} utterances in {el:.1f} s")
 
 
 def pmc_traffic(kernel, meta):
@@ -321,6 +347,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(payload, args.cpu_sample_utts)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            out["cpu_torch_ctc_loss"] = cpu_torch_ctc(payload)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
