@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--L", type=int, default=44)
     ap.add_argument("--ctc-chain", default="default", choices=["default", "log", "fast"],
                     help="CTC chain kernel: library default, log-domain, or fp64 probability-domain + certificate")
+    ap.add_argument("--ctc-step", default="split", choices=["split", "pipelined"],
+                    help="CTC step: forward and gradient kernels back to back, or one pipelined launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-utts", type=int, default=128)
     return ap.parse_args()
@@ -97,7 +99,14 @@ def make_ctc(args, rank, mode):
 
     from gtn_applications_amd import _native as N
     chain_flags = {"default": E.CTC_DEFAULT_FLAGS, "log": 0, "fast": N.CTC_FAST_CHAIN}[args.ctc_chain]
-    if mode == "abi":
+    if mode == "abi" and args.ctc_step == "pipelined":
+        def step(events=None):
+            mark(events)
+            ws, nll = E.ctc_forward_backward(x, tg, blank, coef, gout, dx)  # chains + gradient waves, one launch
+            E.reduce_loss(nll, scale, 1.0)
+            mark(events)
+        phases = ["ctc_pipelined_kernel(+reduce_loss)"]
+    elif mode == "abi":
         def step(events=None):
             mark(events)
             ws, nll = E.ctc_forward(x, tg, blank, chain_flags)  # alpha || beta chains

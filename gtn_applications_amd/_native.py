@@ -122,6 +122,7 @@ _SIGS = {
     "wfl_ctc_workspace": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int64)]),
     "wfl_ctc_forward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "wfl_ctc_grad": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "wfl_ctc_forward_backward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "wfl_reduce_loss": (c_int, [_P, _P, c_int, c_float, c_int, _P, _P]),
 }
 

@@ -35,6 +35,8 @@
 // states and the beta mass at the first ones, their scale disparity reaches 2^300, and the cells
 // that carry the posterior are flushed.  Its certificate rejected every cfg2 utterance, so it was
 // removed; see DESIGN.md, "CTC numerics".)
+#include <atomic>
+
 #include "device_common.h"
 
 namespace wfl {
@@ -71,7 +73,7 @@ __device__ __forceinline__ float to_score(float raw) {
 //   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
 // ------------------------------------------------------------------------------------------------
 struct CtcWs {
-  int64_t ck, off, z2, flag, pbad, total;
+  int64_t ck, off, z2, flag, pbad, ready, perr, total;
 };
 __host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
 __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
@@ -84,6 +86,9 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   w.z2 = o, o += 2 * (int64_t)B;
   w.flag = o, o += B;      // int32 flag[b]: 1 = the fast chain's result was rejected, log-domain chain re-ran
   w.pbad = o, o += 2 * B;  // int32 pbad[b][dir]: the fast chain could not vouch for an interval
+  o = (o + 1) & ~1ll;
+  w.ready = o, o += 2 * (int64_t)B * 2 * NB;  // uint64 ready[b][dir][block]: == the launch token once published
+  w.perr = o, o += 2;                         // int32: a gradient wave of the pipelined step gave up waiting
   w.total = o + 2;
   return w;
 }
@@ -95,6 +100,7 @@ struct CtcArgs {
   const int64_t* offsets;
   float* ws;
   float* nll;
+  unsigned long long token;  // pipelined step: value a ready flag takes when its checkpoint is published
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -106,12 +112,21 @@ struct CtcArgs {
 // ------------------------------------------------------------------------------------------------
 constexpr int kRing = 3;  // LDS ring depth in blocks: consumer at kk, producer at kk+2
 
-// only_flagged != 0: repair pass -- run only for utterances whose fast-chain result was rejected
-__global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_flagged) {
-  __shared__ float2 ring[kRing][kBlk][64];  // 24 KiB
-  __shared__ float2 ckbuf[2][64];           // checkpoint hand-off chain wave -> helper wave
-  __shared__ double offbuf[2];
-  const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+struct ChainLdsT {
+  float2 ring[kRing][kBlk][64];  // 24 KiB
+  float2 ckbuf[2][64];           // checkpoint hand-off chain wave -> helper wave
+  double offbuf[2];
+};
+
+// only_flagged != 0: repair pass -- run only for utterances whose fast-chain result was rejected.
+// SIGNAL: publish ready[b][dir][block] (agent-scope release) after each checkpoint reached HBM, for the
+// gradient waves of the pipelined step that are waiting for it.
+template <bool SIGNAL>
+__device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int dir, int only_flagged, ChainLdsT& S) {
+  auto& ring = S.ring;
+  auto& ckbuf = S.ckbuf;
+  auto& offbuf = S.offbuf;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = a.T, C = a.C, P = a.P;
   const int64_t o0 = a.offsets[b];
   const int L = (int)(a.offsets[b + 1] - o0);
@@ -170,9 +185,34 @@ __global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_
   double off = 0.0;
   float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
   double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+  unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
   auto flush_checkpoint = [&](int kk) {  // helper wave: LDS -> HBM, one block behind the chain
-    if (lane < P) ck[(int64_t)kk * P + lane] = ckbuf[kk & 1][lane];
-    if (lane == 0) offs[kk] = offbuf[kk & 1];
+    if (!SIGNAL) {
+      if (lane < P) ck[(int64_t)kk * P + lane] = ckbuf[kk & 1][lane];
+      if (lane == 0) offs[kk] = offbuf[kk & 1];
+    } else {
+      // The consumers run on other CUs / XCDs of the same launch.  A release fence at agent scope
+      // would write back this XCD's whole L2 -- including the gradient rows streaming through it --
+      // once per block (measured: 10x slower).  Instead the few checkpoint words themselves are
+      // stored device-coherently (agent-scope relaxed atomics bypass the non-coherent L2 state),
+      // the wave waits for their acknowledgement, and only then raises the flag the same way.
+      if (lane < P) {
+        const float2 v = ckbuf[kk & 1][lane];
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &v, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&ck[(int64_t)kk * P + lane]), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        unsigned long long bits;
+        const double o = offbuf[kk & 1];
+        __builtin_memcpy(&bits, &o, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&offs[kk]), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): the stores are acknowledged
+      if (lane == 0) __hip_atomic_store(&ready[kk], a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   };
   float2 e[kBlk], en[kBlk];
   if (wave == 0) {
@@ -238,6 +278,11 @@ __global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_
       a.nll[b] = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
     }
   }
+}
+
+__global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_flagged) {
+  __shared__ ChainLdsT S;
+  ctc_log_chain_body<false>(a, blockIdx.x, blockIdx.y, only_flagged, S);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -522,22 +567,42 @@ __global__ void __launch_bounds__(256) ctc_certify_kernel(CtcArgs a) {
 // ------------------------------------------------------------------------------------------------
 // gradient: one wave per (utterance, 16-frame block), 4 waves per workgroup
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-    ctc_grad_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// PIPE: the pipelined step -- wait for the two checkpoints of block k to be published by the chain
+// workgroups of the same launch, and normalise the posteriors by the Z the block itself reproduces
+// (sum_s alpha(s) beta(s) at its last frame; the certificate's identity) instead of the log Z that the
+// alpha chain only knows when it has finished.
+template <bool PIPE>
+__device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
+                                              const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = a.T, C = a.C, P = a.P;
   const int NB = ctc_blocks(T);
-  const int64_t item = (int64_t)blockIdx.x * 4 + wave;  // (b, k) pairs
-  const bool valid = item < (int64_t)a.B * NB;
-  const int b = valid ? (int)(item / NB) : 0, k = valid ? (int)(item % NB) : 0;
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   float* rows = (float*)smem + (size_t)wave * (kBlk + 1) * C;  // [16][C] gradient rows + [C] label counts, per wave
   int* cnt = (int*)(rows + (size_t)kBlk * C);
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
-  const bool live = valid && a.nll[b] < __builtin_inff();  // no accepting path: zero gradient
+  bool live = valid && (PIPE || a.nll[b] < __builtin_inff());  // no accepting path: zero gradient
   if (valid)
     for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;  // (int 0 == float 0 bit pattern)
+  if (PIPE && valid) {
+    // alpha checkpoint k and beta checkpoint NB-1-k: published by wave 1 of the two chain workgroups
+    // (flags are compared with a 64-bit token that is unique to this launch: the workspace needs no clearing)
+    const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
+    const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
+    // poll with relaxed device-scope loads (an acquire per poll would invalidate this XCD's L2 every
+    // time: measured 35x slower); the checkpoints are then read device-coherently as well
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 20); ++spin) {  // (bounded: a lost signal must not hang the GPU)
+      ok = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
+           __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(64);
+    }
+    if (!ok) {
+      live = false;
+      if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+    }
+  }
   if (live) {
     const int64_t o0 = a.offsets[b];
     const int L = (int)(a.offsets[b + 1] - o0);
@@ -568,15 +633,28 @@ __global__ void __launch_bounds__(256)
     const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
     const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
     const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
-    const double z2 = ((const double*)(a.ws + w.z2))[b];
+    const double z2 = PIPE ? 0.0 : ((const double*)(a.ws + w.z2))[b];
     // alpha checkpoint k: state before frame t0.  beta processed blocks NB-1..0, so its checkpoint
     // before block k has processing index NB-1-k: the full beta of frame t0+n (mirrored lanes:
     // blank state 2i <-> reversed position L-i; label of position i <-> L-1-i).
-    const float2 ca = lane < P ? cka[(int64_t)k * P + lane] : make_float2(kNegBig, kNegBig);
-    float bb = lane <= L ? ckb[(int64_t)(NB - 1 - k) * P + (L - lane)].x : kNegBig;
-    float bl = lane < L ? ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)].y : kNegBig;
+    auto load_ck = [&](const float2* p) {  // PIPE: written by another CU during this launch
+      if (!PIPE) return *p;
+      const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float2 v;
+      __builtin_memcpy(&v, &bits, 8);
+      return v;
+    };
+    const float2 ca = lane < P ? load_ck(&cka[(int64_t)k * P + lane]) : make_float2(kNegBig, kNegBig);
+    float bb = lane <= L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - lane)]).x : kNegBig;
+    float bl = lane < L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)]).y : kNegBig;
+    if (PIPE && lane == 0) {  // this wave was the only consumer of the two flags: leave them cleared
+      unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
+      __hip_atomic_store(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rdy + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // posterior_t(s) = 2^(alpha_t(s) + beta~_t(s) + U), U = off_alpha(k) + off_beta(k) - log2 Z
-    const float U = (float)(offa[k] + offb[NB - 1 - k] - z2);
+    float U = PIPE ? 0.f : (float)(offa[k] + offb[NB - 1 - k] - z2);
     const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
     float pa_b[kBlk], pa_l[kBlk];
     float ab = ca.x, al = ca.y;
@@ -587,7 +665,23 @@ __global__ void __launch_bounds__(256)
       const float nl = lse2_b2(al, skip ? nb : ab);
       ab = nb + xb[j];
       al = nl + xl[j];
-      pa_b[j] = ab + U, pa_l[j] = al + U;
+      pa_b[j] = ab, pa_l[j] = al;
+    }
+    if (PIPE) {
+      // local log2 Z at the block's last frame: sum_s 2^(alpha_{n-1}(s) + [transition-propagated beta](s))
+      const float tb0 = lse2_b2(bb, bl);
+      const float tbn0 = wave_shl1(tb0, kNegBig), bbn0 = wave_shl1(bb, kNegBig);
+      const float tl0 = lse2_b2(bl, skipn ? tbn0 : bbn0);
+      float ub = kNegBig, ul = kNegBig;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j)
+        if (j == n - 1) ub = pa_b[j] + tb0, ul = pa_l[j] + tl0;
+      const float m = wave_all_max(vmax(ub, ul));
+      const float ssum = wave_all_sum(__builtin_amdgcn_exp2f(ub - m) + __builtin_amdgcn_exp2f(ul - m));
+      if (m > 0.5f * kNegBig && ssum > 0.f)
+        U = -(m + __builtin_amdgcn_logf(ssum));
+      else
+        U = kNegBig;  // no accepting path through this block: every posterior is 2^-huge = 0
     }
 #pragma unroll
     for (int j = kBlk - 1; j >= 0; --j) {  // beta backwards, in the forward lane mapping
@@ -600,8 +694,8 @@ __global__ void __launch_bounds__(256)
         const float tbn = wave_shl1(tb, kNegBig), bbn = wave_shl1(bb, kNegBig);
         const float tl = lse2_b2(bl, skipn ? tbn : bbn);
         // dead / non-existent states carry sentinels: exp2 of them is exactly 0, no select needed
-        const float gb = __builtin_amdgcn_exp2f(pa_b[j] + tb);
-        const float gl = __builtin_amdgcn_exp2f(pa_l[j] + tl);
+        const float gb = __builtin_amdgcn_exp2f(pa_b[j] + tb + U);
+        const float gl = __builtin_amdgcn_exp2f(pa_l[j] + tl + U);
         // blank column: one DPP wave reduction + a single LDS add (per-lane ds_add_f32 instead was
         // measured at 49 us for the kernel vs 28 us: LDS float atomics serialise per active lane)
         const float gsum = wave_reduce_sum_lane63(gb);
@@ -613,7 +707,7 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
-  __syncthreads();
+  // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
   if (valid) {  // the dense rows of a block are contiguous in dx: one coalesced copy (zeros included)
     float* dst = dx + ((int64_t)b * T + t0) * C;
     const int total = n * C;
@@ -625,6 +719,50 @@ __global__ void __launch_bounds__(256)
       for (int i = lane; i < total; i += 64) dst[i] = rows[i];
     }
   }
+}
+
+__global__ void __launch_bounds__(256)
+    ctc_grad_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, k) pairs
+  const bool valid = item < (int64_t)a.B * NB;
+  ctc_grad_body<false>(a, valid, valid ? (int)(item / NB) : 0, valid ? (int)(item % NB) : 0, coef, gout, dx, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined forward + backward: ONE launch.  Workgroups 0 .. 2B-1 are the alpha / beta chains (they
+// are dispatched first and there is one per CU at B = 128); the remaining workgroups are gradient
+// waves that wait for "their" two checkpoints and then recompute / emit their 16 frames while the
+// chains are still running.  Block k needs alpha checkpoint k (ready after k blocks of the alpha
+// sweep) and beta checkpoint NB-1-k (ready after NB-k blocks of the beta sweep): the middle of the
+// utterance is ready after half the chain time, the ends when the chains finish -- so gradient
+// items are numbered from the middle outwards and almost all of the gradient kernel's work
+// disappears behind the latency-bound chains, which leave most of every CU idle.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    ctc_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
+                         float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nchain = 2 * a.B;
+  if ((int)blockIdx.x < nchain) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)  // (a gradient wave gives up only after ~1 s of polling)
+      *(int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr) = 0;
+    if (threadIdx.x >= 192) return;  // the chain role uses three waves
+    if (threadIdx.x < 64)  // the dependent chain (and its feeders) go first on their SIMDs
+      __builtin_amdgcn_s_setprio(3);
+    else
+      __builtin_amdgcn_s_setprio(2);
+    ctc_log_chain_body<true>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, 0, *reinterpret_cast<ChainLdsT*>(smem));
+    return;
+  }
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)(blockIdx.x - nchain) * 4 + (threadIdx.x >> 6);
+  const bool valid = item < (int64_t)a.B * NB;
+  const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;  // r: rank in readiness order
+  const int mid = (NB - 1) / 2;
+  const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+  ctc_grad_body<true>(a, valid, b, k, coef, gout, dx, smem);
 }
 
 }  // namespace wfl
@@ -677,6 +815,32 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
     WFL_LAUNCH_CHECK();
     hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 1);
   }
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
+                             int max_len, int blank, float* ws, float* nll, const float* coef, const float* gout,
+                             float* dx, void* stream) {
+  if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_forward_backward")) return rc;
+  if (!x || !targets || !offsets || !ws || !nll || !dx) {
+    set_error("ctc_forward_backward: null buffer");
+    return WFL_ERR_INVALID;
+  }
+  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll, 0ull};
+  // launch token: process-wide counter mixed with the workspace address -- uninitialised memory or flags
+  // left by a launch that used the block earlier cannot equal it; consumers clear the flags they used,
+  // so replaying the SAME launch from a hipGraph (same token, same workspace) starts from cleared flags
+  static std::atomic<unsigned long long> counter{0x9e3779b97f4a7c15ull};
+  a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
+  if (a.token == 0) a.token = 1;
+  const int64_t items = (int64_t)B * ctc_blocks(T);
+  const size_t lds = std::max((size_t)4 * (kBlk + 1) * C * 4, sizeof(ChainLdsT));
+  if (lds > 48 * 1024)
+    WFL_HIP_CHECK(
+        hipFuncSetAttribute((const void*)ctc_pipelined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ctc_pipelined_kernel, dim3((unsigned)(2 * B + (items + 3) / 4)), dim3(256), lds,
+                     (hipStream_t)stream, a, coef, gout, dx);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

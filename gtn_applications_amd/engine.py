@@ -325,6 +325,35 @@ def ctc_forward(x, tg, blank, flags=None):
     return ws, nll
 
 
+def ctc_forward_backward(x, tg, blank, coef, gout, dx):
+    """Loss and gradient in one pipelined launch (wfl_ctc_forward_backward): returns (ws, nll)."""
+    B, T, C = x.shape
+    key = (B, T, C, tg.max_len)
+    n_ws = _CTC_WS_SIZES.get(key)
+    if n_ws is None:
+        n = ctypes.c_int64()
+        N.check(N.lib.wfl_ctc_workspace(B, T, C, tg.max_len, ctypes.byref(n)))
+        n_ws = _CTC_WS_SIZES[key] = n.value
+    ws = torch.empty(n_ws, dtype=_F32, device=x.device)
+    nll = torch.empty(B, dtype=_F32, device=x.device)
+    N.check(
+        N.lib.wfl_ctc_forward_backward(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank,
+                                       ptr(ws), ptr(nll), ptr(coef), ptr(gout), ptr(dx), stream_ptr())
+    )
+    return ws, nll
+
+
+def ctc_pipeline_gave_up(ws, B, T, max_len):
+    """True if a gradient wave of the pipelined step stopped waiting for a checkpoint (diagnostics)."""
+    P, nb = max_len + 1, (T + 15) // 16
+    o = B * 2 * nb * P * 2
+    o = (o + 1) & ~1
+    o += 2 * B * 2 * nb + 2 * B + B + 2 * B
+    o = (o + 1) & ~1
+    o += 2 * B * 2 * nb
+    return bool(ws[o:o + 1].view(torch.int32).item())
+
+
 def ctc_grad(x, tg, blank, ws, nll, coef, gout, dx):
     B, T, C = x.shape
     N.check(

@@ -261,6 +261,12 @@ int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems);
 int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
                     const int64_t* offsets, int max_len, int blank, int flags, float* ws, float* nll,
                     void* stream);
+/* wfl_ctc_forward (log-domain chain) and wfl_ctc_grad as ONE pipelined launch: gradient waves wait
+ * for the checkpoints they need and run while the chains are still sweeping.  Same outputs (nll,
+ * dx); posteriors are normalised per 16-frame block by the Z the block reproduces. */
+int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t* targets,
+                             const int64_t* offsets, int max_len, int blank, float* ws, float* nll,
+                             const float* coef, const float* gout, float* dx, void* stream);
 /* dense gradient rows, recomputed block by block from the checkpoints of wfl_ctc_forward */
 int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
                  int max_len, int blank, const float* ws, const float* nll, const float* coef,

@@ -183,6 +183,78 @@ def test_ctc_certificate_rejects_what_the_fast_chain_cannot_represent(crit):
     assert rejected[1] == 1  # the damaged utterance must not be served by the fast chain
 
 
+def test_ctc_pipelined_step_matches_split_step_and_oracle():
+    """wfl_ctc_forward_backward: chains and gradient waves in one launch (gradient waves wait on
+    device-side flags); same loss, gradient within tolerance of the oracle and of the two-kernel
+    step; ragged targets, T not a multiple of 16, an infeasible utterance, one 16-frame block only"""
+    from gtn_applications_amd import engine as E
+
+    for (B, T, C, Lmax, seed) in [(5, 83, 13, 11, 1), (3, 16, 7, 3, 2), (4, 250, 40, 30, 3), (2, 7, 5, 2, 4)]:
+        rs = np.random.RandomState(seed)
+        x = rs.randn(B, T, C).astype(np.float32)
+        targets = [rs.randint(0, C - 1, size=rs.randint(0, Lmax + 1)).tolist() for _ in range(B)]
+        targets[0] = rs.randint(0, C - 1, size=Lmax).tolist()
+        if T < 20:
+            targets[-1] = [1] * (T + 1)  # cannot be aligned: loss inf, zero gradient
+        want_loss, want_dx = OR.ctc_loss_grad(x, targets, C - 1, "none")
+        xt = dev(x)
+        tg = E.targets_on_device(targets, xt.device)
+        scale, _, coef = E.loss_factors(tg, "none")
+        gout = torch.full((1,), 0.75, device="cuda")
+        dx = torch.full_like(xt, float("nan"))
+        ws, nll = E.ctc_forward_backward(xt, tg, C - 1, coef, gout, dx)
+        torch.cuda.synchronize()
+        assert not E.ctc_pipeline_gave_up(ws, B, T, tg.max_len)
+        dx2 = torch.full_like(xt, float("nan"))
+        ws2, nll2 = E.ctc_forward(xt, tg, C - 1)
+        E.ctc_grad(xt, tg, C - 1, ws2, nll2, coef, gout, dx2)
+        assert torch.equal(nll, nll2)
+        fin = np.isfinite(nll.cpu().numpy())
+        wl, _ = OR.ctc_loss_grad(x[fin], [t for t, f in zip(targets, fin) if f], C - 1, "none")
+        assert float(nll[torch.from_numpy(fin).cuda()].mean()) == pytest.approx(wl, rel=RTOL)
+        close(dx2, 0.75 * np.nan_to_num(want_dx))
+        close(dx, 0.75 * np.nan_to_num(want_dx))
+
+
+def test_ctc_pipelined_step_at_baseline_size_and_under_graph_replay():
+    """cfg2 sizes: the pipelined launch agrees with the two-kernel step; captured in a hipGraph and
+    replayed (same workspace, same launch token every time) it keeps producing the same gradient --
+    the consumers must have cleared the ready flags of the previous replay"""
+    from gtn_applications_amd import engine as E
+
+    g = torch.Generator().manual_seed(5)
+    B, T, C, L = 128, 1000, 100, 44
+    x = torch.randn(B, T, C, generator=g).cuda()
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    tg = E.targets_on_device(targets, x.device)
+    scale, _, coef = E.loss_factors(tg, "none")
+    gout = torch.ones(1, device="cuda")
+    dx_split, dx_pipe = torch.empty_like(x), torch.empty_like(x)
+    ws, nll = E.ctc_forward(x, tg, C - 1)
+    E.ctc_grad(x, tg, C - 1, ws, nll, coef, gout, dx_split)
+    ws2, nll2 = E.ctc_forward_backward(x, tg, C - 1, coef, gout, dx_pipe)
+    torch.cuda.synchronize()
+    assert not E.ctc_pipeline_gave_up(ws2, B, T, tg.max_len)
+    assert torch.equal(nll, nll2)
+    np.testing.assert_allclose(dx_pipe.cpu().numpy(), dx_split.cpu().numpy(), rtol=2e-3, atol=2e-8)
+    np.testing.assert_allclose(dx_pipe.sum(dim=2).cpu().numpy(), coef.cpu().numpy()[:, None] * np.ones((1, T)), rtol=1e-4)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    dx_g = torch.empty_like(x)
+    with torch.cuda.stream(side):
+        E.ctc_forward_backward(x, tg, C - 1, coef, gout, dx_g)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        ws_g, nll_g = E.ctc_forward_backward(x, tg, C - 1, coef, gout, dx_g)
+    for _ in range(3):
+        dx_g.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert not E.ctc_pipeline_gave_up(ws_g, B, T, tg.max_len)
+        assert torch.equal(dx_g, dx_pipe) and torch.equal(nll_g, nll)
+
+
 def test_ctc_infeasible_and_minus_inf(crit):
     ctc = crit["ctc"]
     # T < L: no alignment -> loss +inf, zero gradient (documented policy)
