@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--L", type=int, default=44)
     ap.add_argument("--ctc-chain", default="default", choices=["default", "log", "fast"],
                     help="CTC chain kernel: library default, log-domain, or fp64 probability-domain + certificate")
-    ap.add_argument("--ctc-step", default="split", choices=["split", "pipelined"],
+    ap.add_argument("--ctc-step", default="pipelined", choices=["split", "pipelined"],
                     help="CTC step: forward and gradient kernels back to back, or one pipelined launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-utts", type=int, default=128)
@@ -102,10 +102,10 @@ def make_ctc(args, rank, mode):
     if mode == "abi" and args.ctc_step == "pipelined":
         def step(events=None):
             mark(events)
-            ws, nll = E.ctc_forward_backward(x, tg, blank, coef, gout, dx)  # chains + gradient waves, one launch
-            E.reduce_loss(nll, scale, 1.0)
+            # chains + gradient waves + loss reduction, one launch
+            E.ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=scale, want_loss=True)
             mark(events)
-        phases = ["ctc_pipelined_kernel(+reduce_loss)"]
+        phases = ["ctc_pipelined_kernel"]
     elif mode == "abi":
         def step(events=None):
             mark(events)

@@ -44,10 +44,16 @@ class CTCLossFunction(torch.autograd.Function):
             raise ValueError(f"got {tg.B} targets for a batch of {B}")
         scale, _, coef = E.loss_factors(tg, reduction)  # loss scale; gradient coefficient -scale/B
         need_grad = log_probs.requires_grad
-        if tg.max_len <= 63:
+        if tg.max_len <= 63 and need_grad:
+            # loss and gradient in ONE pipelined launch (gradient waves run behind the chains); backward
+            # only applies the upstream scalar.  Like torch's own CTC, the gradient is produced eagerly.
+            dx = torch.empty_like(x)
+            _, _, loss = E.ctc_forward_backward(x, tg, int(blank_idx), coef, None, dx, loss_scale=scale, want_loss=True)
+            ctx.aux = ("pipelined", x, tg, int(blank_idx), dx, coef)
+        elif tg.max_len <= 63:
             ws, nll = E.ctc_forward(x, tg, int(blank_idx))
             loss = E.reduce_loss(nll, scale, 1.0)
-            ctx.aux = ("fast", x, tg, int(blank_idx), ws if need_grad else None, nll, coef)
+            ctx.aux = ("fast", x, tg, int(blank_idx), None, nll, coef)
         else:
             pack = tg.cache.get(("ctc_lattice", int(blank_idx), C))
             if pack is None:
@@ -63,11 +69,19 @@ class CTCLossFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         kind, x = ctx.aux[0], ctx.aux[1]
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
-        dx = torch.empty_like(x)
-        if kind == "fast":
-            _, _, tg, blank, ws, nll, coef = ctx.aux
-            E.ctc_grad(x, tg, blank, ws, nll, coef, gout, dx)
+        if kind == "pipelined":
+            _, _, tg, blank, dx, coef = ctx.aux
+            if dx is None:  # a second backward through a retained graph: recompute with the two-kernel step
+                dx = torch.empty_like(x)
+                ws, nll = E.ctc_forward(x, tg, blank)
+                E.ctc_grad(x, tg, blank, ws, nll, coef, gout, dx)
+            else:
+                E.scale_inplace(dx, gout)
+                ctx.aux = ("pipelined", x, tg, blank, None, coef)
+        elif kind == "fast":
+            raise RuntimeError("CTCLoss: backward through an input that did not require grad in forward")
         else:
+            dx = torch.empty_like(x)
             _, _, st, coef = ctx.aux
             E.lattice_grad(st, coef, gout=gout, dx=dx)
         if ctx.in_device.type != "cuda":

@@ -73,7 +73,7 @@ __device__ __forceinline__ float to_score(float raw) {
 //   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
 // ------------------------------------------------------------------------------------------------
 struct CtcWs {
-  int64_t ck, off, z2, flag, pbad, ready, perr, total;
+  int64_t ck, off, z2, flag, pbad, ready, done, perr, total;
 };
 __host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
 __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
@@ -88,6 +88,7 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   w.pbad = o, o += 2 * B;  // int32 pbad[b][dir]: the fast chain could not vouch for an interval
   o = (o + 1) & ~1ll;
   w.ready = o, o += 2 * (int64_t)B * 2 * NB;  // uint64 ready[b][dir][block]: == the launch token once published
+  w.done = o, o += 2 * (int64_t)B;            // uint64 done[b]: == the launch token once nll[b] is published
   w.perr = o, o += 2;                         // int32: a gradient wave of the pipelined step gave up waiting
   w.total = o + 2;
   return w;
@@ -101,6 +102,8 @@ struct CtcArgs {
   float* ws;
   float* nll;
   unsigned long long token;  // pipelined step: value a ready flag takes when its checkpoint is published
+  const float* loss_scale;   // pipelined step, optional: loss_out[0] = mean_b(loss_scale[b] * nll[b])  (ctc.py:68-69)
+  float* loss_out;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -275,7 +278,38 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       const bool alive = zr > 0.5f * kNegBig;
       const double z2 = alive ? (double)zr + off : -1.0e300;
       ((double*)(a.ws + w.z2))[b] = z2;
-      a.nll[b] = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
+      const float nllb = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
+      a.nll[b] = nllb;
+      if (SIGNAL && a.loss_out) {  // publish nll[b] device-coherently for the workgroup that reduces the loss
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(a.nll + b), __float_as_uint(nllb), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store((unsigned long long*)(a.ws + w.done) + b, a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (SIGNAL && a.loss_out && b == 0) {
+      // the alpha chain of utterance 0 waits for all the others (they finish within microseconds of each
+      // other) and reduces the loss in a fixed order: mean_b(scale_b * nll_b), no extra launch, deterministic
+      unsigned long long* done = (unsigned long long*)(a.ws + w.done);
+      float part = 0.f;
+      bool ok = true;
+      for (int u = lane; u < a.B; u += 64) {
+        bool seen = false;
+        for (int spin = 0; spin < (1 << 20) && !seen; ++spin) {
+          seen = __hip_atomic_load(done + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+          if (!seen) __builtin_amdgcn_s_sleep(16);
+        }
+        ok = ok && seen;
+        __hip_atomic_store(done + u, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sole consumer: clear
+        const float v = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(a.nll + u),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        part += (a.loss_scale ? a.loss_scale[u] : 1.f) * v;
+      }
+      const float total = wave_all_sum(part);  // fixed lane order
+      if (lane == 0) {
+        a.loss_out[0] = total / (float)a.B;
+      }
+      if (!ok && lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
     }
   }
 }
@@ -821,13 +855,13 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
 
 int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
                              int max_len, int blank, float* ws, float* nll, const float* coef, const float* gout,
-                             float* dx, void* stream) {
+                             float* dx, const float* loss_scale, float* loss_out, void* stream) {
   if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_forward_backward")) return rc;
   if (!x || !targets || !offsets || !ws || !nll || !dx) {
     set_error("ctc_forward_backward: null buffer");
     return WFL_ERR_INVALID;
   }
-  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll, 0ull};
+  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll, 0ull, loss_scale, loss_out};
   // launch token: process-wide counter mixed with the workspace address -- uninitialised memory or flags
   // left by a launch that used the block earlier cannot equal it; consumers clear the flags they used,
   // so replaying the SAME launch from a hipGraph (same token, same workspace) starts from cleared flags

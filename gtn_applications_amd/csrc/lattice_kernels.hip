@@ -807,6 +807,20 @@ __global__ void reduce_loss_kernel(const float* __restrict__ vals, const float* 
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s / (float)B;
 }
 
+// v *= s[0], skipped when s[0] == 1 (the usual upstream gradient of a scalar loss)
+__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ v, int64_t n4, int64_t n, const float* __restrict__ s) {
+  const float f = s[0];
+  if (f == 1.f) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 t = v4[i];
+    t.x *= f, t.y *= f, t.z *= f, t.w *= f;
+    v4[i] = t;
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] *= f;
+}
+
 }  // namespace wfl
 
 using namespace wfl;
@@ -960,6 +974,17 @@ int wfl_debug_grad_occupancy(int lds_bytes) {
   int n = -1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, grad_kernel, 256, (size_t)lds_bytes) != hipSuccess) return -1;
   return n;
+}
+
+int wfl_scale(float* v, int64_t n, const float* s, void* stream) {
+  if (!v || !s || n < 0 || (((uintptr_t)v) & 15)) {
+    set_error("scale: bad arguments (v must be 16-byte aligned)");
+    return WFL_ERR_INVALID;
+  }
+  if (n == 0) return WFL_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, v, n / 4, n, s);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
 }
 
 int wfl_reduce_loss(const float* vals, const float* scale, int B, float sign, int accumulate, float* out, void* stream) {

@@ -220,6 +220,12 @@ def lattice_viterbi(x, pack, weights=None):
     return [None if plen[b] < 0 else path[b, :plen[b]].copy() for b in range(B)], st.logz
 
 
+def scale_inplace(v, s):
+    """v *= s[0] on the device without a host sync (skipped by the kernel when s[0] == 1)."""
+    N.check(N.lib.wfl_scale(ptr(v), v.numel(), ptr(s), stream_ptr()))
+    return v
+
+
 def reduce_loss(vals, scale, sign=1.0, out=None):
     """out = (1/B) sum_b sign * scale[b] * vals[b]   (ctc.py:68-69 and twins), on the device."""
     B = vals.numel()
@@ -325,8 +331,9 @@ def ctc_forward(x, tg, blank, flags=None):
     return ws, nll
 
 
-def ctc_forward_backward(x, tg, blank, coef, gout, dx):
-    """Loss and gradient in one pipelined launch (wfl_ctc_forward_backward): returns (ws, nll)."""
+def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_loss=False):
+    """Loss and gradient in one pipelined launch (wfl_ctc_forward_backward): returns (ws, nll) or,
+    with want_loss, (ws, nll, mean_b(loss_scale[b] * nll[b]) as a 0-dim device tensor)."""
     B, T, C = x.shape
     key = (B, T, C, tg.max_len)
     n_ws = _CTC_WS_SIZES.get(key)
@@ -336,11 +343,13 @@ def ctc_forward_backward(x, tg, blank, coef, gout, dx):
         n_ws = _CTC_WS_SIZES[key] = n.value
     ws = torch.empty(n_ws, dtype=_F32, device=x.device)
     nll = torch.empty(B, dtype=_F32, device=x.device)
+    loss = torch.empty((), dtype=_F32, device=x.device) if want_loss else None
     N.check(
         N.lib.wfl_ctc_forward_backward(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank,
-                                       ptr(ws), ptr(nll), ptr(coef), ptr(gout), ptr(dx), stream_ptr())
+                                       ptr(ws), ptr(nll), ptr(coef), ptr(gout), ptr(dx), ptr(loss_scale), ptr(loss),
+                                       stream_ptr())
     )
-    return ws, nll
+    return (ws, nll, loss) if want_loss else (ws, nll)
 
 
 def ctc_pipeline_gave_up(ws, B, T, max_len):
@@ -350,7 +359,7 @@ def ctc_pipeline_gave_up(ws, B, T, max_len):
     o = (o + 1) & ~1
     o += 2 * B * 2 * nb + 2 * B + B + 2 * B
     o = (o + 1) & ~1
-    o += 2 * B * 2 * nb
+    o += 2 * B * 2 * nb + 2 * B
     return bool(ws[o:o + 1].view(torch.int32).item())
 
 

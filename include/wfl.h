@@ -263,10 +263,13 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
                     void* stream);
 /* wfl_ctc_forward (log-domain chain) and wfl_ctc_grad as ONE pipelined launch: gradient waves wait
  * for the checkpoints they need and run while the chains are still sweeping.  Same outputs (nll,
- * dx); posteriors are normalised per 16-frame block by the Z the block reproduces. */
+ * dx); posteriors are normalised per 16-frame block by the Z the block reproduces.  If loss_out is
+ * not NULL it also receives mean_b(loss_scale[b] * nll[b]) (ctc.py:68-69; loss_scale NULL = 1),
+ * reduced in a fixed order by the last chain to finish -- no separate wfl_reduce_loss launch. */
 int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t* targets,
                              const int64_t* offsets, int max_len, int blank, float* ws, float* nll,
-                             const float* coef, const float* gout, float* dx, void* stream);
+                             const float* coef, const float* gout, float* dx, const float* loss_scale,
+                             float* loss_out, void* stream);
 /* dense gradient rows, recomputed block by block from the checkpoints of wfl_ctc_forward */
 int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
                  int max_len, int blank, const float* ws, const float* nll, const float* coef,
@@ -275,6 +278,8 @@ int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, co
 /* small device utilities used by the Python layer (kept here so the product never needs a
  * torch op inside the timed path) */
 /* out[0] = (1/B) * sum_b sign * scale[b] * vals[b]  (+ out[0] if accumulate) */
+/* v[0..n) *= s[0] on the device; a no-op pass when s[0] == 1 (upstream gradient of a scalar loss) */
+int wfl_scale(float* v, int64_t n, const float* s, void* stream);
 int wfl_reduce_loss(const float* vals, const float* scale, int B, float sign, int accumulate,
                     float* out, void* stream);
 

@@ -202,9 +202,11 @@ def test_ctc_pipelined_step_matches_split_step_and_oracle():
         scale, _, coef = E.loss_factors(tg, "none")
         gout = torch.full((1,), 0.75, device="cuda")
         dx = torch.full_like(xt, float("nan"))
-        ws, nll = E.ctc_forward_backward(xt, tg, C - 1, coef, gout, dx)
+        ws, nll, loss = E.ctc_forward_backward(xt, tg, C - 1, coef, gout, dx, loss_scale=scale, want_loss=True)
         torch.cuda.synchronize()
         assert not E.ctc_pipeline_gave_up(ws, B, T, tg.max_len)
+        ref = E.reduce_loss(nll, scale, 1.0)
+        assert torch.equal(loss, ref) or torch.allclose(loss, ref, rtol=1e-6)  # (inf == inf for the infeasible case)
         dx2 = torch.full_like(xt, float("nan"))
         ws2, nll2 = E.ctc_forward(xt, tg, C - 1)
         E.ctc_grad(xt, tg, C - 1, ws2, nll2, coef, gout, dx2)
