@@ -156,6 +156,9 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
   // consumed and nothing newer is in flight at that point, so the compiler's s_waitcnt vmcnt(0)
   // in front of the first use costs nothing even when the rows come from HBM (cfg5: x is 524 MB).
   const int h = wave - 1;
+  // pipelined step: a fourth wave does nothing but publish checkpoints -- its wait for the stores'
+  // acknowledgement must not also wait for a helper's emission gathers
+  constexpr int kFlusher = SIGNAL ? 3 : 1;
   float raw[kBlk];
   auto issue = [&](int kk) {
     const int k = dir == 0 ? kk : NB - 1 - kk;
@@ -174,7 +177,7 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       ring[kk % kRing][j][lane] = make_float2(has_blank ? xblank : kNegBig, has_label ? xs : kNegBig);
     }
   };
-  if (wave >= 1) {
+  if (wave == 1 || wave == 2) {
     if (h < NB) {
       issue(h);
       stage(h);
@@ -260,15 +263,15 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) e[j] = en[j];
     } else {
-      if (kk > 0 && wave == 1) flush_checkpoint(kk - 1);
-      if ((kk & 1) == h) {
+      if (kk > 0 && wave == kFlusher) flush_checkpoint(kk - 1);
+      if ((kk & 1) == h && wave <= 2) {
         if (kk + 2 < NB) stage(kk + 2);  // issued two iterations ago
         if (kk + 4 < NB) issue(kk + 4);
       }
     }
     __syncthreads();
   }
-  if (wave == 1) flush_checkpoint(NB - 1);
+  if (wave == kFlusher) flush_checkpoint(NB - 1);
   if (dir == 0 && wave == 0) {
     // logZ = LSE(alpha_{T-1}[2L], alpha_{T-1}[2L-1])   (ctc.py:21 accept states)
     const float a_last = readlane_f(ab, L);
@@ -782,7 +785,6 @@ __global__ void __launch_bounds__(256)
   if ((int)blockIdx.x < nchain) {
     if (blockIdx.x == 0 && threadIdx.x == 0)  // (a gradient wave gives up only after ~1 s of polling)
       *(int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr) = 0;
-    if (threadIdx.x >= 192) return;  // the chain role uses three waves
     if (threadIdx.x < 64)  // the dependent chain (and its feeders) go first on their SIMDs
       __builtin_amdgcn_s_setprio(3);
     else
