@@ -282,12 +282,16 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       const double z2 = alive ? (double)zr + off : -1.0e300;
       ((double*)(a.ws + w.z2))[b] = z2;
       const float nllb = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
-      a.nll[b] = nllb;
       if (SIGNAL && a.loss_out) {  // publish nll[b] device-coherently for the workgroup that reduces the loss
+        // (ONLY this store: a plain store to the same word first would leave a dirty non-coherent line in
+        // this XCD's L2 that the coherent store merges into instead of writing through -- measured: the
+        // reducer then read stale values)
         __hip_atomic_store(reinterpret_cast<unsigned int*>(a.nll + b), __float_as_uint(nllb), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_store((unsigned long long*)(a.ws + w.done) + b, a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        a.nll[b] = nllb;
       }
     }
     if (SIGNAL && a.loss_out && b == 0) {

@@ -257,6 +257,58 @@ def test_ctc_pipelined_step_at_baseline_size_and_under_graph_replay():
         assert torch.equal(dx_g, dx_pipe) and torch.equal(nll_g, nll)
 
 
+def test_ctc_pipelined_step_more_chains_than_workgroup_slots():
+    """B = 900 utterances = 1800 chain workgroups, more than the chip holds at once: the chains are
+    dispatched (in order) before any gradient workgroup, so waiting gradient waves can never starve
+    them; long utterances make the waits real"""
+    from gtn_applications_amd import engine as E
+
+    g = torch.Generator().manual_seed(9)
+    B, T, C, L = 900, 400, 30, 20
+    x = torch.randn(B, T, C, generator=g).cuda()
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    tg = E.targets_on_device(targets, x.device)
+    scale, _, coef = E.loss_factors(tg, "mean")
+    gout = torch.ones(1, device="cuda")
+    dx_split, dx_pipe = torch.empty_like(x), torch.empty_like(x)
+    ws, nll = E.ctc_forward(x, tg, C - 1)
+    E.ctc_grad(x, tg, C - 1, ws, nll, coef, gout, dx_split)
+    ws2, nll2, loss = E.ctc_forward_backward(x, tg, C - 1, coef, gout, dx_pipe, loss_scale=scale, want_loss=True)
+    torch.cuda.synchronize()
+    assert not E.ctc_pipeline_gave_up(ws2, B, T, tg.max_len)
+    assert torch.equal(nll, nll2)
+    assert float(loss) == pytest.approx(float((scale * nll).mean()), rel=1e-6)
+    np.testing.assert_allclose(dx_pipe.cpu().numpy(), dx_split.cpu().numpy(), rtol=2e-3, atol=1e-9)
+
+
+def test_ctc_pipelined_step_stress_fresh_data_same_buffers():
+    """the checkpoints travel between CUs of different XCDs inside one launch: thirty steps with new
+    emissions each time in the SAME buffers (the allocator hands the blocks out again), every element
+    of loss and gradient compared with the two-kernel step -- a stale cross-XCD read would show here"""
+    from gtn_applications_amd import engine as E
+
+    g = torch.Generator().manual_seed(21)
+    B, T, C, L = 128, 640, 64, 30
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    gout = torch.ones(1, device="cuda")
+    for it in range(30):
+        x = torch.randn(B, T, C, generator=g).cuda() * (1.0 + 0.1 * it)
+        tg = E.targets_on_device(targets, x.device)
+        scale, _, coef = E.loss_factors(tg, "mean")
+        dx_pipe = torch.empty_like(x)
+        ws2, nll2, loss = E.ctc_forward_backward(x, tg, C - 1, coef, gout, dx_pipe, loss_scale=scale, want_loss=True)
+        dx_split = torch.empty_like(x)
+        ws, nll = E.ctc_forward(x, tg, C - 1)
+        E.ctc_grad(x, tg, C - 1, ws, nll, coef, gout, dx_split)
+        ref = E.reduce_loss(nll, scale, 1.0)
+        torch.cuda.synchronize()
+        assert not E.ctc_pipeline_gave_up(ws2, B, T, tg.max_len), it
+        assert torch.equal(nll, nll2), it
+        assert torch.allclose(loss, ref, rtol=1e-6), (it, float(loss), float(ref))
+        np.testing.assert_allclose(dx_pipe.cpu().numpy(), dx_split.cpu().numpy(), rtol=2e-3, atol=1e-9, err_msg=str(it))
+        del x, dx_pipe, dx_split, ws, ws2, nll, nll2, loss
+
+
 def test_ctc_infeasible_and_minus_inf(crit):
     ctc = crit["ctc"]
     # T < L: no alignment -> loss +inf, zero gradient (documented policy)
