@@ -316,7 +316,10 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       if (lane == 0) {
         a.loss_out[0] = total / (float)a.B;
       }
-      if (!ok && lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+      if (!ok) {
+        if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+        __builtin_trap();
+      }
     }
   }
 }
@@ -639,9 +642,10 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
       if (ok) break;
       __builtin_amdgcn_s_sleep(64);
     }
-    if (!ok) {
-      live = false;
+    if (!ok) {  // ~2 s without the signal: never expected (in-order dispatch puts every chain ahead of the
+                // waiting waves).  Fail loudly rather than return a silently wrong gradient.
       if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+      __builtin_trap();
     }
   }
   if (live) {
