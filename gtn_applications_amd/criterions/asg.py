@@ -103,8 +103,12 @@ class ASGLossFunction(torch.autograd.Function):
         if pack is None:
             pack = tg.cache[("asg_fal", C)] = E.PackedLattice.asg_force_align(tg.flat, tg.offsets, C, dev)
         need_grad = inputs.requires_grad or transitions.requires_grad
+        # numerator (force-aligned lattice) and denominator (fully connected) sweeps are independent and
+        # both latency-bound: fork the numerator onto a second stream so that they overlap
+        with E.side_stream(dev) as fork:
+            fal = E.lattice_forward(x, pack, weights=W, need_beta=need_grad)
         fcc = E.dense_forward(x, W, need_beta=need_grad)
-        fal = E.lattice_forward(x, pack, weights=W, need_beta=need_grad)
+        fork.join(fal.xg, fal.alpha, fal.beta, fal.logz)
         loss = E.reduce_loss(fcc.logz, scale, 1.0)
         loss = E.reduce_loss(fal.logz, scale, -1.0, out=loss)
         ctx.aux = (x, W, fcc, fal, cpos, cneg)

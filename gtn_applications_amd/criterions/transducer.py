@@ -275,11 +275,16 @@ class TransducerLossFunction(torch.autograd.Function):
 
         pack, scale, cpos, cneg, _ = _PACK_CACHE.get(key + (reduction == "mean",), build)
         need_grad = inputs.requires_grad or (transition_params is not None and transition_params.requires_grad)
-        num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax)
-        loss = E.reduce_loss(num.logz, scale, -1.0)
         den = None
         if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288
-            den = E.lattice_forward(x, _transitions_pack(transitions, B, C, dev), weights=params, need_beta=need_grad)
+            # independent of the numerator sweep: forked onto a second stream so that the two overlap
+            with E.side_stream(dev) as fork:
+                den = E.lattice_forward(x, _transitions_pack(transitions, B, C, dev), weights=params,
+                                        need_beta=need_grad)
+        num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax)
+        loss = E.reduce_loss(num.logz, scale, -1.0)
+        if den is not None:
+            fork.join(den.xg, den.alpha, den.beta, den.logz)
             loss = E.reduce_loss(den.logz, scale, 1.0, out=loss)
         ctx.aux = (x, params, num, den, cpos, cneg)
         ctx.devices = (inputs.device, None if transition_params is None else transition_params.device)

@@ -220,6 +220,40 @@ def lattice_viterbi(x, pack, weights=None):
     return [None if plen[b] < 0 else path[b, :plen[b]].copy() for b in range(B)], st.logz
 
 
+_SIDE_STREAMS = {}
+
+
+class side_stream:
+    """Run a block of launches on a second HIP stream that forks from / joins the current one: two
+    independent latency-bound sweeps (ASG numerator and denominator) then share the GPU instead of
+    queueing behind each other.  Tensors allocated inside must be passed to `keep()` so that the
+    caching allocator knows the current stream uses them later."""
+
+    def __init__(self, device):
+        self.cur = torch.cuda.current_stream(device)
+        key = device.index
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+        self.side = _SIDE_STREAMS[key]
+        self.ctx = None
+
+    def __enter__(self):
+        self.side.wait_stream(self.cur)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        self.cur.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.cur)
+
+
 def scale_inplace(v, s):
     """v *= s[0] on the device without a host sync (skipped by the kernel when s[0] == 1)."""
     N.check(N.lib.wfl_scale(ptr(v), v.numel(), ptr(s), stream_ptr()))
