@@ -108,6 +108,7 @@ struct ChainLds {
   float* rows;  // [2][R][Kmax] emission rows of the current / next chunk of R frames
   float* red;   // [64]
   int* lvl;     // [nlev+1]
+  int* heavy;   // [Q] states with more than kHeavyDeg in-arcs (cooperative relaxation), heavy[Q] = their count
 };
 
 __device__ __forceinline__ float block_reduce_max(float v, float* red) {
@@ -231,6 +232,110 @@ __device__ __forceinline__ float lean_relax(const float* const (&fp)[kLeanDeg], 
   return lean_lse<DEG>(v);
 }
 
+// High in-degree states (dense n-gram transition graphs: 81 in-arcs per state in the reference's
+// transducer benchmark) are relaxed cooperatively: a row of 16 lanes strides over the state's
+// labelled in-arcs and merges with DPP row operations, four states per wavefront at a time.
+// Tropical ties keep the lowest arc index, like the serial walk.
+constexpr int kHeavyDeg = 24;
+
+__device__ __forceinline__ float row16_max(float v) {  // every lane of the 16-lane row receives the row's maximum
+  v = fmaxf(v, dpp_f32<0x111, 0xf>(WFL_NEG_INF, v));
+  v = fmaxf(v, dpp_f32<0x112, 0xf>(WFL_NEG_INF, v));
+  v = fmaxf(v, dpp_f32<0x114, 0xf>(WFL_NEG_INF, v));
+  v = fmaxf(v, dpp_f32<0x118, 0xf>(WFL_NEG_INF, v));
+  return __shfl(v, 15, 16);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0x111, 0xf>(0.f, v);
+  v += dpp_f32<0x112, 0xf>(0.f, v);
+  v += dpp_f32<0x114, 0xf>(0.f, v);
+  v += dpp_f32<0x118, 0xf>(0.f, v);
+  return __shfl(v, 15, 16);
+}
+__device__ __forceinline__ int row16_min(int v) {
+  v = min(v, __shfl_xor(v, 1, 16));
+  v = min(v, __shfl_xor(v, 2, 16));
+  v = min(v, __shfl_xor(v, 4, 16));
+  v = min(v, __shfl_xor(v, 8, 16));
+  return v;
+}
+
+// epsilon closure of a state with many epsilon in-arcs (the back-off state of an n-gram graph collects
+// one from every history): same 16-lane cooperation; `val` / `arg` enter with the labelled result
+template <int SR>
+__device__ __forceinline__ void relax_eps_row16(const ChainLds& L, const float* vals, int k0, int k1, int A, float& val,
+                                                int& arg) {
+  const int r = threadIdx.x & 15;
+  float m = r == 0 ? val : WFL_NEG_INF, s = (r == 0 && val > WFL_NEG_INF) ? 1.f : 0.f;
+  int am = 0x7fffffff;  // (the labelled result wins ties: it is "earlier" than every epsilon arc)
+  for (int k = k0 + r; k < k1; k += 16) {
+    const int2 a = L.eps[k];
+    const float v = vals[a.x] + __int_as_float(a.y);
+    if (SR == WFL_SEMIRING_LOG) {
+      if (v > m) {
+        s = s * fast_exp(m - v) + 1.f;
+        m = v;
+      } else if (v > WFL_NEG_INF) {
+        s += fast_exp(v - m);
+      }
+    } else if (v > m) {
+      m = v, am = A + k;
+    }
+  }
+  const float mt = row16_max(m);
+  if (SR == WFL_SEMIRING_LOG) {
+    const float st = row16_sum(m > WFL_NEG_INF ? s * fast_exp(m - mt) : 0.f);
+    val = mt > WFL_NEG_INF ? mt + fast_log(st) : WFL_NEG_INF;
+  } else {
+    // an epsilon arc replaces the labelled back-pointer only if it is strictly better than it
+    const int cand = row16_min((m == mt && mt > val) ? am : 0x7fffffff);
+    if (cand != 0x7fffffff) arg = cand;
+    val = mt;
+  }
+}
+
+// all 64 lanes of the wave must call this (rows without a state pass k0 == k1)
+template <int SR>
+__device__ __forceinline__ void relax_labelled_row16(const ChainLds& L, const float* from, const float* row, int k0,
+                                                     int k1, float& val, int& arg) {
+  const int r = threadIdx.x & 15;
+  float m = WFL_NEG_INF, s = 0.f;
+  int am = 0x7fffffff;
+  auto term = [&](int k) {  // -inf past the end of the list
+    if (k >= k1) return WFL_NEG_INF;
+    const int2 a = L.arcs[k];
+    return from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
+  };
+  // four independent arcs per step: their LDS round trips overlap instead of queueing behind each other
+  for (int k = k0 + r; k < k1; k += 64) {
+    const float v0 = term(k), v1 = term(k + 16), v2 = term(k + 32), v3 = term(k + 48);
+    const float m4 = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+    if (SR == WFL_SEMIRING_LOG) {
+      if (m4 > WFL_NEG_INF) {
+        const float mn = fmaxf(m, m4);
+        s = s * fast_exp(m - mn) + fast_exp(v0 - mn) + fast_exp(v1 - mn) + fast_exp(v2 - mn) + fast_exp(v3 - mn);
+        m = mn;
+      }
+    } else {
+      // ascending arc index: strict '>' keeps the first maximum
+      if (v0 > m) m = v0, am = k;
+      if (v1 > m) m = v1, am = k + 16;
+      if (v2 > m) m = v2, am = k + 32;
+      if (v3 > m) m = v3, am = k + 48;
+    }
+  }
+  const float mt = row16_max(m);
+  if (SR == WFL_SEMIRING_LOG) {
+    const float st = row16_sum(m > WFL_NEG_INF ? s * fast_exp(m - mt) : 0.f);
+    val = mt > WFL_NEG_INF ? mt + fast_log(st) : WFL_NEG_INF;
+    arg = -1;
+  } else {
+    const int cand = row16_min((m == mt && mt > WFL_NEG_INF) ? am : 0x7fffffff);
+    val = mt;
+    arg = cand == 0x7fffffff ? -1 : cand;
+  }
+}
+
 template <int SR>
 __device__ __forceinline__ void relax_eps(const ChainLds& L, float* vals, int q, int k0, int k1, int A, float& val,
                                           int& arg) {
@@ -287,17 +392,32 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   for (int l = tid; l <= nlev; l += NT) L.lvl[l] = u.lvl_ptr[l];
 
   // epsilon closure of `vals` for this direction; `tslot` is the time slot for back-pointers
+  bool eps_heavy = false;  // set once the acceptor is staged (below)
   auto closure = [&](float* vals, int tslot) {
     if (nlev <= 1) return;
     for (int step = 1; step < nlev; ++step) {
       const int lev = DIR == 0 ? step : nlev - 1 - step;
       __syncthreads();
       for (int q = L.lvl[lev] + tid; q < L.lvl[lev + 1]; q += NT) {
+        if (L.eptr[q + 1] - L.eptr[q] > kHeavyDeg) continue;  // cooperative pass below
         float v = vals[q];
         int arg = -2;
         relax_eps<SR>(L, vals, q, L.eptr[q], L.eptr[q + 1], A, v, arg);
         vals[q] = v;
         if (SR == WFL_SEMIRING_TROPICAL && DIR == 0 && arg != -2) bptr[u.ab_base + (int64_t)tslot * Q + q] = arg;
+      }
+      if (eps_heavy) {  // states of this level with many epsilon in-arcs: one 16-lane row each
+        for (int q = L.lvl[lev] + (tid >> 4); q < L.lvl[lev + 1]; q += NT >> 4) {
+          const int k0 = L.eptr[q], k1 = L.eptr[q + 1];
+          if (k1 - k0 <= kHeavyDeg) continue;  // uniform within the row
+          float v = vals[q];
+          int arg = -2;
+          relax_eps_row16<SR>(L, vals, k0, k1, A, v, arg);
+          if ((tid & 15) == 0) {
+            vals[q] = v;
+            if (SR == WFL_SEMIRING_TROPICAL && DIR == 0 && arg != -2) bptr[u.ab_base + (int64_t)tslot * Q + q] = arg;
+          }
+        }
       }
     }
   };
@@ -305,6 +425,11 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   const int t_first = DIR == 0 ? 0 : T;  // time slot of the boundary vector
   float* cur = (t_first & 1) ? L.buf1 : L.buf0;
   __syncthreads();
+  {
+    int eh = 0;
+    for (int q = tid; q < Q; q += NT) eh |= (L.eptr[q + 1] - L.eptr[q]) > kHeavyDeg;
+    eps_heavy = __syncthreads_or(eh) != 0;
+  }
   for (int q = tid; q < Q; q += NT) {
     cur[q] = DIR == 0 ? u.start_w[q] : u.accept_w[q];
     if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + q] = -1;
@@ -338,6 +463,12 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   const int deg = kq1 - kq0;
   const int any_gt2 = __syncthreads_or(deg > 2), any_gt4 = __syncthreads_or(deg > 4);
   const int any_gt8 = __syncthreads_or(deg > kLeanDeg);
+  if (tid == 0) L.heavy[Q] = 0;
+  __syncthreads();
+  for (int q = tid; q < Q; q += NT)
+    if (L.ptr[q + 1] - L.ptr[q] > kHeavyDeg) L.heavy[atomicAdd(&L.heavy[Q], 1)] = q;
+  __syncthreads();
+  const int n_heavy = L.heavy[Q];
   const bool lean = SR == WFL_SEMIRING_LOG && Q <= NT && direct && !any_gt8;  // block-uniform
   LeanArcs la;
 #pragma unroll
@@ -465,7 +596,7 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           float* to = (slot_to & 1) ? L.buf1 : L.buf0;
           const float* row = tile + (size_t)(t - f0) * Kmax;
           float* orow = out + u.ab_base + (int64_t)slot_to * Q;
-          if (tid < Q) {
+          if (tid < Q && kq1 - kq0 <= kHeavyDeg) {
             float v;
             int arg;
             relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
@@ -477,10 +608,27 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
             float v;
             int arg;
             const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
+            if (k1 - k0 > kHeavyDeg) continue;
             relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
             to[q] = v;
             if (direct) orow[q] = v;
             if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+          }
+          if (n_heavy) {  // one 16-lane row per high in-degree state, NT / 16 states at a time
+            const int grow = tid >> 4, nrows = NT >> 4;
+            for (int h0 = 0; h0 < n_heavy; h0 += nrows) {  // (uniform trip count: DPP rows need the whole wave)
+              const int hq = h0 + grow;
+              const int q = hq < n_heavy ? L.heavy[hq] : -1;
+              const int k0 = q >= 0 ? L.ptr[q] : 0, k1 = q >= 0 ? L.ptr[q + 1] : 0;
+              float v;
+              int arg;
+              relax_labelled_row16<SR>(L, from, row, k0, k1, v, arg);
+              if (q >= 0 && (tid & 15) == 0) {
+                to[q] = v;
+                if (direct) orow[q] = v;
+                if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+              }
+            }
           }
           closure(to, slot_to);
           __syncthreads();
@@ -548,7 +696,8 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
   L.buf1 = (float*)p, p += (size_t)d.max_states * 4;
   L.rows = (float*)p, p += (size_t)2 * rows_per_chunk * d.max_labels * 4;
   L.red = (float*)p, p += 64 * 4;
-  L.lvl = (int*)p;
+  L.lvl = (int*)p, p += (size_t)(d.max_levels + 1) * 4;
+  L.heavy = (int*)p;
   if (dir == 0)
     run_chain<SR, 0>(d, u, L, T, rows_per_chunk, xg, weights, alpha, bptr, logz, b);
   else
@@ -557,7 +706,8 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
 
 static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
   return (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 8 +
-         (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 + 64;
+         (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 +
+         (size_t)(d.max_states + 1) * 4 + 64;
 }
 
 // ------------------------------------------------------------------------------------------------

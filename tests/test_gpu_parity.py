@@ -740,6 +740,38 @@ def test_transducer_backoff_transitions(crit, lit, tmp_path):
     close(m.transition_params.grad, want_dp, atol=2e-5)
 
 
+
+@pytest.mark.parametrize("ngram,blank", [(1, "optional"), (2, "none"), (2, "optional")])
+def test_transducer_dense_ngram_transitions_use_the_cooperative_relaxation(crit, ngram, blank):
+    """30 tokens: the n-gram transition graph has 30-way in-degree, above the threshold at which a
+    whole wavefront relaxes a state (lattice engine, general path); loss, emission gradient,
+    transition-parameter gradient and Viterbi against the graph oracle"""
+    tr = crit["transducer"]
+    ntok = 30
+    tokens = [(i,) for i in range(ntok)]
+    g2i = {i: i for i in range(ntok)}
+    kw = dict(ngram=ngram, blank=blank, allow_repeats=(blank == "none"), reduction="mean")
+    rs = np.random.RandomState(40 + ngram)
+    B, T = 2, 14
+    C = ntok + int(blank != "none")
+    x = rs.randn(B, T, C).astype(np.float32)
+    targets = [rs.randint(0, ntok, size=5).tolist(), rs.randint(0, ntok, size=3).tolist()]
+    m = tr.Transducer(tokens, g2i, **kw)
+    params = (0.3 * rs.randn(m.transition_params.numel())).astype(np.float32)
+    with torch.no_grad():
+        m.transition_params.copy_(torch.from_numpy(params))
+    m.cuda()
+    orc = OC.TransducerOracle(tokens, g2i, **kw)
+    orc.transition_params = params.astype(np.float64)
+    want_loss, want_dx, want_dp = orc.loss(x, targets)
+    xt = dev(x, grad=True)
+    loss = m(xt, [torch.tensor(t) for t in targets])
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss, rel=RTOL)
+    close(xt.grad, want_dx)
+    close(m.transition_params.grad, want_dp, atol=2e-5)
+    assert [p.tolist() for p in m.viterbi(xt.detach())] == orc.viterbi(x)
+
 # =================================================================================================
 # ConvTransduce1D
 # =================================================================================================
