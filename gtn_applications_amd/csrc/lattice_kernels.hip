@@ -713,6 +713,7 @@ static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
 // ------------------------------------------------------------------------------------------------
 // stage 3: posteriors -> gradient rows
 // ------------------------------------------------------------------------------------------------
+constexpr int kChunk = 16;
 #ifdef WFL_DBG_TIMELINE
 __device__ unsigned long long g_dbg[3 * 8192];
 #endif
@@ -741,7 +742,11 @@ __global__ void __launch_bounds__(256)
   float* dwacc = acc + (dx ? (size_t)TS * Kmax : 0);        // [A + E] (only if dW)
   int2* sarc = (int2*)(dwacc + (dW ? (size_t)d.max_arcs + d.max_eps : 0));  // [A] by-slot {src | dst << 16, w - z}
   int* sptr = (int*)(sarc + (dx ? d.max_arcs : 0));         // [K + 1]
-  int16_t* colmap = (int16_t*)(sptr + (dx ? Kmax + 1 : 0));  // [C] (only if dx)
+  // work items of the emission gradient: a slot's arc list in chunks of at most kChunk arcs, so that
+  // the blank column of a CTC-like acceptor (two in-arcs per blank state: hundreds of arcs in ONE
+  // slot) is spread over many threads instead of serialising the tile
+  int2* chunk = (int2*)(sptr + (dx ? ((Kmax + 3) & ~1) : 0));  // [NC] {slot, first arc}; NC <= K + A / kChunk (8-byte aligned)
+  int16_t* colmap = (int16_t*)(chunk + (dx ? Kmax + d.max_arcs / kChunk + 1 : 0));  // [C] (only if dx)
   const float g0 = gout ? gout[0] : 1.f;
   const float cf = coef ? coef[b] * g0 : g0;
   const float z = logz[b];
@@ -757,6 +762,12 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     for (int k = tid; k < K; k += NT) colmap[u.labels[k]] = (int16_t)k;
     for (int k = tid; k <= K; k += NT) sptr[k] = u.slot_ptr[k];
+    if (tid == 0) {  // chunk table (a few hundred entries at most, once per workgroup)
+      int nc = 0;
+      for (int k = 0; k < K; ++k)
+        for (int a0 = u.slot_ptr[k]; a0 < u.slot_ptr[k + 1]; a0 += kChunk) chunk[nc++] = make_int2(k, a0);
+      sptr[Kmax + 1] = nc;
+    }
     for (int j = tid; j < A; j += NT) {
       const int a = u.slot_arc[j];
       const int wid = u.arc_wid[a];
@@ -785,6 +796,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll 4
       for (int i = tid; i < nr * Kmax; i += NT) {
         xr[i] = xsrc[i];
+        if (dx) acc[i] = 0.f;
       }
     }
     __syncthreads();
@@ -792,19 +804,25 @@ __global__ void __launch_bounds__(256)
       // emission gradient: one thread per (frame, emission slot) sums the posteriors of the slot's
       // arcs (by-slot CSR staged in LDS) -- no atomics, all 256 lanes busy
       if (dx) {
-        const float inv_k = 1.f / (float)max(K, 1);
-        for (int i = tid; i < nr * K; i += NT) {
-          const int r = fdiv(i, inv_k), k = i - r * K;
+        const int NC = sptr[Kmax + 1];
+        const float inv_nc = 1.f / (float)max(NC, 1);
+        for (int i = tid; i < nr * NC; i += NT) {
+          const int r = fdiv(i, inv_nc);
+          const int2 ch = chunk[i - r * NC];
+          const int k = ch.x, j1 = min(ch.y + kChunk, sptr[k + 1]);
           const float* pa = al + r * d.max_states;
           const float* pb = pa + (be - al) + d.max_states;
           const float xv = xr[r * Kmax + k];
           float sum = 0.f;
-          for (int j = sptr[k]; j < sptr[k + 1]; ++j) {
+          for (int j = ch.y; j < j1; ++j) {
             const int2 a = sarc[j];
             const float v = pa[a.x & 0xffff] + xv + __int_as_float(a.y) + pb[(unsigned)a.x >> 16];
             sum += fast_exp(v);  // exp(-inf) = 0
           }
-          acc[r * Kmax + k] = sum;
+          if (sptr[k + 1] - sptr[k] <= kChunk)
+            acc[r * Kmax + k] = sum;  // the slot's only chunk
+          else if (sum != 0.f)
+            atomicAdd(&acc[r * Kmax + k], sum);
         }
       }
       // learnable-weight gradient: one arc per thread, frames of the tile in the inner loop
@@ -1021,7 +1039,8 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     set_error("lattice_forward: %d distinct labels per utterance (limit 1024)", d->max_labels);
     return WFL_ERR_UNSUPPORTED;
   }
-  int nt = d->max_states <= 64 ? 64 : (d->max_states <= 128 ? 128 : 256);
+  // one state per thread up to 1024 states (the lean frame paths need it); beyond that threads loop
+  int nt = d->max_states <= 64 ? 64 : d->max_states <= 128 ? 128 : d->max_states <= 256 ? 256 : d->max_states <= 512 ? 512 : 1024;
   while (nt < 256 && nt * kPre < 2 * d->max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
   const int rpc = std::max(2, std::min(16, nt * kPre / std::max(1, d->max_labels)) & ~1);  // even (run_chain)
   const size_t lds = chain_lds_bytes(*d, rpc);
@@ -1075,7 +1094,10 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
   // barrier -> compute -> barrier -> stream-out sequence, overlap comes from co-residency)
   const size_t row_bytes = 4 * (2 * (size_t)d->max_states + (size_t)d->max_labels * (dx ? 2 : 1));
   const size_t fixed = 4 * (2 * (size_t)d->max_states + (dW ? (size_t)d->max_arcs + d->max_eps : 0)) +
-                       (dx ? 8 * (size_t)d->max_arcs + 4 * ((size_t)d->max_labels + 1) + 2 * (size_t)C : 0) + 64;
+                       (dx ? 8 * (size_t)d->max_arcs + 4 * (((size_t)d->max_labels + 3) & ~(size_t)1) +
+                                8 * ((size_t)d->max_labels + d->max_arcs / kChunk + 1) + 2 * (size_t)C
+                          : 0) +
+                       64;
   if (dx && d->max_labels > 32767) {
     set_error("lattice_grad: %d distinct labels per utterance (limit 32767)", d->max_labels);
     return WFL_ERR_UNSUPPORTED;
