@@ -1113,7 +1113,18 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
   // (resident workgroups per CU) x 256: a grid slightly above that costs a whole second round
   // (measured: 1856 workgroups on 1536 slots = 2 x 250 us).  Size the grid to ONE round.
   int per_cu = 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, grad_kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  {  // (the occupancy query costs a few microseconds of host time: remember the last answer)
+    static std::mutex mu;
+    static size_t last_lds = ~(size_t)0;
+    static int last_per_cu = 1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (lds != last_lds) {
+      int n = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, grad_kernel, 256, lds) != hipSuccess || n < 1) n = 1;
+      last_lds = lds, last_per_cu = n;
+    }
+    per_cu = last_per_cu;
+  }
   const int slots = per_cu * 256;
   int blocks_t = std::max(1, std::min((T + TS - 1) / TS, slots / std::max(1, d->B)));
   int rows_per_block = (T + blocks_t - 1) / blocks_t;
