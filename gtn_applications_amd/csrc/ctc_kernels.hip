@@ -30,11 +30,11 @@
 // drifting to O(T) (plain fp32 log-domain, which is what gtn.forward_score does, already loses the
 // 4th digit of the posteriors at T = 1000).
 //
-// (A probability-domain chain with a wave-uniform power-of-two scale -- 6 VALU per frame -- was built
-// and measured here too; on unnormalised scores with T >> L the alpha mass piles up at the last
-// states and the beta mass at the first ones, their scale disparity reaches 2^300, and the cells
-// that carry the posterior are flushed.  Its certificate rejected every cfg2 utterance, so it was
-// removed; see DESIGN.md, "CTC numerics".)
+// Kernels: ctc_log_chain_kernel + ctc_grad_kernel (+ wfl_reduce_loss) are the three-launch step;
+// ctc_pipelined_kernel runs the same chain and gradient bodies in ONE launch, the gradient waves
+// waiting on device-coherent per-block flags while the chains sweep (the default training step).
+// ctc_fast_chain_kernel + ctc_certify_kernel are an experimental, opt-in replacement of the chain
+// (lane-exponent probability-domain arithmetic with a certificate and log-domain repair).
 #include <atomic>
 
 #include "device_common.h"

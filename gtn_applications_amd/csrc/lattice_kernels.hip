@@ -2,12 +2,16 @@
 // an arbitrary per-utterance acceptor A_b composed with the implicit emissions chain.
 //
 //   stage 1  wfl_lattice_gather   all CUs, one wave per (b,t) row: xg[b,t,k] = x[b,t,labels_b[k]]
+//                                 (optionally minus the row's log-sum-exp: fused log_softmax)
 //   stage 2  wfl_lattice_forward  one workgroup per (utterance, direction); arcs of A_b staged in
-//                                 LDS as CSR lists, alpha/beta ping-pong in LDS, one barrier per
-//                                 frame (+1 per epsilon level), next xg row prefetched in registers
-//   stage 3  wfl_lattice_grad     all CUs, tiles of frames: arc posteriors -> LDS row buffer
-//                                 (ds_add_f32) -> dense coalesced gradient rows incl. zeros;
-//                                 learnable-weight grads reduced in LDS, one atomic per arc/block
+//                                 LDS as CSR lists; emission rows prefetched a chunk of frames
+//                                 ahead; per frame one of: banded (DPP) / single-wave (ds_bpermute) /
+//                                 multi-wave lean / general path with epsilon levels, cooperative
+//                                 16-lane relaxation of high in-degree states
+//   stage 3  wfl_lattice_grad     all CUs, tiles of frames: posteriors accumulated per (frame,
+//                                 distinct label) by threads owning <= 16 arcs of one label, dense
+//                                 rows streamed out through a column -> slot map (fused log_softmax
+//                                 backward optional); learnable-weight grads reduced per workgroup
 //
 // This replaces gtn.intersect(emissions, A) + gtn.forward_score / viterbi_path + gtn.backward
 // (criterions/ctc.py:49-51,78-81; asg.py:111-113; stc.py:85-87; transducer.py:283,321-325) without
