@@ -440,7 +440,10 @@ _TARGET_CACHE = LRU(64)
 
 
 def targets_on_device(targets, device):
-    """Upload (once per distinct content) the targets of a batch; content-keyed LRU."""
+    """Upload (once per distinct content) the targets of a batch; content-keyed LRU.  A CtcTargets
+    built earlier is passed through (callers that reuse a batch skip the ~50 us content hash)."""
+    if isinstance(targets, CtcTargets):
+        return targets
     rows = [t.tolist() if hasattr(t, "tolist") else (t if type(t) is list else list(t)) for t in targets]
     key = (tuple(map(tuple, rows)), device.index)
     return _TARGET_CACHE.get(key, lambda: CtcTargets(rows, device))
