@@ -3,8 +3,8 @@
 `CTCLossFunction.forward/backward`, `CTCLoss` and `CTC` keep the reference's signatures
 (ctc.py:13-135).  Where the reference builds `gtn.intersect(g_emissions, g_criterion)` per sample
 on host threads (ctc.py:38-65), this sends the whole batch through the CTC fast-path kernels
-(csrc/ctc_kernels.hip) -- or, for targets longer than 63 labels, through the generic lattice
-engine (csrc/lattice_kernels.hip).  Both are HIP paths; there is no CPU path.
+(csrc/ctc_kernels.hip; up to four target positions per lane) -- or, for targets longer than 255
+labels, through the generic lattice engine (csrc/lattice_kernels.hip).  Both are HIP paths; there is no CPU path.
 """
 import torch
 
@@ -44,13 +44,13 @@ class CTCLossFunction(torch.autograd.Function):
             raise ValueError(f"got {tg.B} targets for a batch of {B}")
         scale, _, coef = E.loss_factors(tg, reduction)  # loss scale; gradient coefficient -scale/B
         need_grad = log_probs.requires_grad
-        if tg.max_len <= 63 and need_grad:
+        if tg.max_len <= E.CTC_FAST_MAX_LEN and need_grad:
             # loss and gradient in ONE pipelined launch (gradient waves run behind the chains); backward
             # only applies the upstream scalar.  Like torch's own CTC, the gradient is produced eagerly.
             dx = torch.empty_like(x)
             _, _, loss = E.ctc_forward_backward(x, tg, int(blank_idx), coef, None, dx, loss_scale=scale, want_loss=True)
             ctx.aux = ("pipelined", x, tg, int(blank_idx), dx, coef)
-        elif tg.max_len <= 63:
+        elif tg.max_len <= E.CTC_FAST_MAX_LEN:
             ws, nll = E.ctc_forward(x, tg, int(blank_idx))
             loss = E.reduce_loss(nll, scale, 1.0)
             ctx.aux = ("fast", x, tg, int(blank_idx), None, nll, coef)

@@ -809,6 +809,446 @@ __global__ void __launch_bounds__(256)
   ctc_grad_body<true>(a, valid, b, k, coef, gout, dx, smem);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long targets (64 <= L + 1 <= 256): PPL = 2, 3 or 4 target positions per lane, lane i owning the
+// contiguous positions PPL*i .. PPL*i + PPL-1.  Within a frame all positions read the PREVIOUS
+// frame's values, so a lane's PPL updates are independent (instruction-level parallelism that
+// the single-position chain does not have) and still only ONE value crosses lanes per frame (the
+// label state of the lane's first position needs the last position of lane i-1: a DPP shift).
+// Same checkpoint format (indexed by position), same pipelining, same numerics as above; the
+// emission ring holds the label emissions per position and the frame's blank emission once
+// (states that do not exist stay at the sentinel by themselves: everything that feeds them is one).
+// ------------------------------------------------------------------------------------------------
+template <int PPL>
+struct LongLds {
+  float ring_xl[kRing][kBlk][64][PPL];
+  float ring_xb[kRing][kBlk];
+  float2 ckbuf[2][64 * PPL];
+  double offbuf[2];
+};
+
+template <int PPL>
+struct LongLane {  // what a lane knows about its PPL positions (alpha: forward target, beta: reversed)
+  int col[PPL];
+  bool has_label[PPL], skip[PPL];
+};
+
+template <int PPL>
+__device__ __forceinline__ LongLane<PPL> long_lane(const CtcArgs& a, int64_t o0, int L, int lane, int dir) {
+  LongLane<PPL> c;
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    const int pos = PPL * lane + p;
+    int y = -1, yprev = -1;
+    if (pos < L) y = a.targets[o0 + (dir == 0 ? pos : L - 1 - pos)];
+    if (pos >= 1 && pos - 1 < L) yprev = a.targets[o0 + (dir == 0 ? pos - 1 : L - pos)];
+    c.has_label[p] = pos < L;
+    c.skip[p] = c.has_label[p] && pos >= 1 && y != yprev;
+    c.col[p] = c.has_label[p] ? y : a.blank;
+  }
+  return c;
+}
+
+// value held for position `pos` (lane pos / PPL, slot pos % PPL) broadcast to the wave
+template <int PPL>
+__device__ __forceinline__ float long_read(const float (&v)[PPL], int pos) {
+  const int slot = pos % PPL;
+  float s = v[0];
+#pragma unroll
+  for (int p = 1; p < PPL; ++p) s = slot == p ? v[p] : s;  // wave-uniform select
+  return readlane_f(s, pos / PPL);
+}
+
+template <int PPL, bool SIGNAL>
+__device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int dir, LongLds<PPL>& S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  const LongLane<PPL> c = long_lane<PPL>(a, o0, L, lane, dir);
+  const float* xrow = a.x + (int64_t)b * T * C;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  const int NB = ctc_blocks(T);
+  const int h = wave - 1;
+  constexpr int kFlusher = SIGNAL ? 3 : 1;
+  float raw[kBlk][PPL];
+  auto issue = [&](int kk) {
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int t0 = k * kBlk, n = min(kBlk, T - t0);
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
+      const float* row = xrow + (int64_t)min(max(t, 0), T - 1) * C;
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) raw[j][p] = row[c.col[p]];
+    }
+  };
+  auto stage = [&](int kk) {
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      float xs[PPL];
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) xs[p] = to_score(raw[j][p]);
+      const float xblank = long_read<PPL>(xs, L);  // position L has no label: its column is the blank
+      if (lane == 0) S.ring_xb[kk % kRing][j] = xblank;
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) S.ring_xl[kk % kRing][j][lane][p] = c.has_label[p] ? xs[p] : kNegBig;
+    }
+  };
+  if (wave == 1 || wave == 2) {
+    if (h < NB) {
+      issue(h);
+      stage(h);
+    }
+    if (h + 2 < NB) issue(h + 2);
+  }
+  __syncthreads();
+
+  float ab[PPL], al[PPL];
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) ab[p] = kNegBig, al[p] = kNegBig;
+  if (lane == 0) ab[0] = 0.f;  // virtual slot "before the first frame"
+  double off = 0.0;
+  float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
+  double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+  unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
+  auto flush_checkpoint = [&](int kk) {
+    for (int i = lane; i < P; i += 64) {
+      const float2 v = S.ckbuf[kk & 1][i];
+      if (!SIGNAL) {
+        ck[(int64_t)kk * P + i] = v;
+      } else {
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &v, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&ck[(int64_t)kk * P + i]), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (lane == 0) {
+      const double o = S.offbuf[kk & 1];
+      if (!SIGNAL) {
+        offs[kk] = o;
+      } else {
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &o, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&offs[kk]), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (SIGNAL) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the stores are acknowledged
+      if (lane == 0) __hip_atomic_store(&ready[kk], a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  float e[kBlk][PPL], en[kBlk][PPL], eb[kBlk], ebn[kBlk];
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      eb[j] = S.ring_xb[0][j];
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) e[j][p] = S.ring_xl[0][j][lane][p];
+    }
+  }
+  for (int kk = 0; kk < NB; ++kk) {
+    if (wave == 0) {
+      const int k = dir == 0 ? kk : NB - 1 - kk;
+      const int n = min(kBlk, T - k * kBlk);
+      if (kk + 1 < NB) {
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+          ebn[j] = S.ring_xb[(kk + 1) % kRing][j];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) en[j][p] = S.ring_xl[(kk + 1) % kRing][j][lane][p];
+        }
+      }
+      if (kk > 0) {
+        float mx = kNegBig;
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) mx = vmax(mx, vmax(ab[p], al[p]));
+        const float m = wave_all_max(mx);
+        if (m > 0.5f * kNegBig) {
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            ab[p] = fmaxf(ab[p] - m, 4.f * kNegBig);
+            al[p] = fmaxf(al[p] - m, 4.f * kNegBig);
+          }
+          off += (double)m;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) S.ckbuf[kk & 1][PPL * lane + p] = make_float2(ab[p], al[p]);
+      if (lane == 0) S.offbuf[kk & 1] = off;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        if (j < n) {  // (n is uniform; only the last block is short)
+          float pal[PPL], nb[PPL], nl[PPL];
+          pal[0] = wave_shr1(al[PPL - 1], kNegBig);
+#pragma unroll
+          for (int p = 1; p < PPL; ++p) pal[p] = al[p - 1];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            nb[p] = lse2_b2(ab[p], pal[p]);
+            nl[p] = lse2_b2(al[p], c.skip[p] ? nb[p] : ab[p]);
+          }
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) ab[p] = nb[p] + eb[j], al[p] = nl[p] + e[j][p];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        eb[j] = ebn[j];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) e[j][p] = en[j][p];
+      }
+    } else {
+      if (kk > 0 && wave == kFlusher) flush_checkpoint(kk - 1);
+      if ((kk & 1) == h && wave <= 2) {
+        if (kk + 2 < NB) stage(kk + 2);
+        if (kk + 4 < NB) issue(kk + 4);
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == kFlusher) flush_checkpoint(NB - 1);
+  if (dir == 0 && wave == 0) {
+    const float a_last = long_read<PPL>(ab, L);
+    const float l_last = L > 0 ? long_read<PPL>(al, L - 1) : kNegBig;
+    if (lane == 0) {
+      const float zr = lse2_b2(a_last, l_last);
+      const bool alive = zr > 0.5f * kNegBig;
+      const double z2 = alive ? (double)zr + off : -1.0e300;
+      ((double*)(a.ws + w.z2))[b] = z2;
+      a.nll[b] = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
+    }
+  }
+}
+
+template <int PPL, bool PIPE>
+__device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid, int b, int k,
+                                                   const float* __restrict__ coef, const float* __restrict__ gout,
+                                                   float* __restrict__ dx, char* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
+  const int NB = ctc_blocks(T);
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  float* rows = (float*)smem + (size_t)wave * (kBlk + 1) * C;
+  int* cnt = (int*)(rows + (size_t)kBlk * C);
+  const int t0 = k * kBlk, n = min(kBlk, T - t0);
+  bool live = valid && (PIPE || a.nll[b] < __builtin_inff());
+  if (valid)
+    for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;
+  if (PIPE && valid) {
+    const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
+    const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+      ok = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
+           __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(64);
+    }
+    if (!ok) {
+      if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+      __builtin_trap();
+    }
+  }
+  if (!live) {
+    if (valid) {  // zero rows for a dead utterance
+      float* dst = dx + ((int64_t)b * T + t0) * C;
+      for (int i = lane; i < n * C; i += 64) dst[i] = 0.f;
+    }
+    return;
+  }
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  int y[PPL];
+  bool has_label[PPL], skip[PPL], skipn[PPL], uniq[PPL], dup[PPL];
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    const int pos = PPL * lane + p;
+    has_label[p] = pos < L;
+    y[p] = has_label[p] ? a.targets[o0 + pos] : a.blank;
+    const int yprev = (pos >= 1 && pos - 1 < L) ? a.targets[o0 + pos - 1] : -1;
+    const int ynext = pos + 1 < L ? a.targets[o0 + pos + 1] : -1;
+    skip[p] = has_label[p] && pos >= 1 && y[p] != yprev;
+    skipn[p] = pos + 1 < L && ynext != y[p];
+    if (has_label[p]) atomicAdd(&cnt[y[p]], 1);
+  }
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    dup[p] = has_label[p] && (cnt[y[p]] > 1 || y[p] == a.blank);
+    uniq[p] = has_label[p] && !dup[p];
+  }
+  const float* xrow = a.x + (int64_t)b * T * C;
+  float xl[kBlk][PPL], xb[kBlk];
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    const float* row = xrow + (int64_t)min(t0 + j, T - 1) * C;
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) xl[j][p] = row[y[p]];
+  }
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    float xs[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) xs[p] = to_score(xl[j][p]);
+    xb[j] = long_read<PPL>(xs, L);
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) xl[j][p] = has_label[p] ? xs[p] : kNegBig;
+  }
+  const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
+  const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
+  const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
+  const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
+  auto load_ck = [&](const float2* p) {
+    if (!PIPE) return *p;
+    const unsigned long long bits =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float2 v;
+    __builtin_memcpy(&v, &bits, 8);
+    return v;
+  };
+  float ab[PPL], al[PPL], bb[PPL], bl[PPL];
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    const int pos = PPL * lane + p;
+    const float2 ca = pos < P ? load_ck(&cka[(int64_t)k * P + pos]) : make_float2(kNegBig, kNegBig);
+    ab[p] = ca.x, al[p] = ca.y;
+    bb[p] = pos <= L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - pos)]).x : kNegBig;
+    bl[p] = pos < L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - pos)]).y : kNegBig;
+  }
+  if (PIPE && lane == 0) {
+    unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
+    __hip_atomic_store(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rdy + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  float U = PIPE ? 0.f : (float)(offa[k] + offb[NB - 1 - k] - ((const double*)(a.ws + w.z2))[b]);
+  const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+  float pa_b[kBlk][PPL], pa_l[kBlk][PPL];
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {  // alpha forward through the block, kept in registers
+    float pal[PPL], nb[PPL], nl[PPL];
+    pal[0] = wave_shr1(al[PPL - 1], kNegBig);
+#pragma unroll
+    for (int p = 1; p < PPL; ++p) pal[p] = al[p - 1];
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      nb[p] = lse2_b2(ab[p], pal[p]);
+      nl[p] = lse2_b2(al[p], skip[p] ? nb[p] : ab[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      ab[p] = nb[p] + xb[j], al[p] = nl[p] + xl[j][p];
+      pa_b[j][p] = ab[p], pa_l[j][p] = al[p];
+    }
+  }
+  // transition-propagated beta of one frame: tb (blank states), tl (label states)
+  auto propagate = [&](float (&tb)[PPL], float (&tl)[PPL]) {
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) tb[p] = lse2_b2(bb[p], bl[p]);
+    const float tb_next_lane = wave_shl1(tb[0], kNegBig), bb_next_lane = wave_shl1(bb[0], kNegBig);
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      const float tbn = p + 1 < PPL ? tb[p + 1 < PPL ? p + 1 : 0] : tb_next_lane;
+      const float bbn = p + 1 < PPL ? bb[p + 1 < PPL ? p + 1 : 0] : bb_next_lane;
+      tl[p] = lse2_b2(bl[p], skipn[p] ? tbn : bbn);
+    }
+  };
+  if (PIPE) {
+    float tb[PPL], tl[PPL];
+    propagate(tb, tl);
+    float u = kNegBig;
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j)
+      if (j == n - 1) {
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) u = vmax(u, vmax(pa_b[j][p] + tb[p], pa_l[j][p] + tl[p]));
+      }
+    const float m = wave_all_max(u);
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j)
+      if (j == n - 1) {
+#pragma unroll
+        for (int p = 0; p < PPL; ++p)
+          part += __builtin_amdgcn_exp2f(pa_b[j][p] + tb[p] - m) + __builtin_amdgcn_exp2f(pa_l[j][p] + tl[p] - m);
+      }
+    const float ssum = wave_all_sum(part);
+    U = (m > 0.5f * kNegBig && ssum > 0.f) ? -(m + __builtin_amdgcn_logf(ssum)) : kNegBig;
+  }
+#pragma unroll
+  for (int j = kBlk - 1; j >= 0; --j) {
+    if (j < n) {
+      float tb[PPL], tl[PPL];
+      propagate(tb, tl);
+      float gbs = 0.f;
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) {
+        gbs += __builtin_amdgcn_exp2f(pa_b[j][p] + tb[p] + U);
+        const float gl = __builtin_amdgcn_exp2f(pa_l[j][p] + tl[p] + U);
+        if (uniq[p]) rows[j * C + y[p]] = gl * cf;
+        if (dup[p] && gl != 0.f) atomicAdd(&rows[j * C + y[p]], gl * cf);
+      }
+      const float gsum = wave_reduce_sum_lane63(gbs);
+      if (lane == 63 && gsum != 0.f) atomicAdd(&rows[j * C + a.blank], gsum * cf);
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) bb[p] = tb[p] + xb[j], bl[p] = tl[p] + xl[j][p];
+    }
+  }
+  {
+    float* dst = dx + ((int64_t)b * T + t0) * C;
+    const int total = n * C;
+    if ((((uintptr_t)dst) & 15) == 0) {
+      const int n4 = total >> 2;
+      for (int i = lane; i < n4; i += 64) ((float4*)dst)[i] = ((const float4*)rows)[i];
+      for (int i = (n4 << 2) + lane; i < total; i += 64) dst[i] = rows[i];
+    } else {
+      for (int i = lane; i < total; i += 64) dst[i] = rows[i];
+    }
+  }
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(256)
+    ctc_long_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
+                              float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nchain = 2 * a.B;
+  if ((int)blockIdx.x < nchain) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *(int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr) = 0;
+    if (threadIdx.x < 64)
+      __builtin_amdgcn_s_setprio(3);
+    else
+      __builtin_amdgcn_s_setprio(2);
+    ctc_long_chain_body<PPL, true>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<LongLds<PPL>*>(smem));
+    return;
+  }
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)(blockIdx.x - nchain) * 4 + (threadIdx.x >> 6);
+  const bool valid = item < (int64_t)a.B * NB;
+  const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;
+  const int mid = (NB - 1) / 2;
+  const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+  ctc_long_grad_body<PPL, true>(a, valid, b, k, coef, gout, dx, smem);
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(192) ctc_long_chain_kernel(CtcArgs a) {
+  __shared__ LongLds<PPL> S;
+  ctc_long_chain_body<PPL, false>(a, blockIdx.x, blockIdx.y, S);
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(256)
+    ctc_long_grad_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool valid = item < (int64_t)a.B * NB;
+  ctc_long_grad_body<PPL, false>(a, valid, valid ? (int)(item / NB) : 0, valid ? (int)(item % NB) : 0, coef, gout, dx,
+                                 smem);
+}
+
 }  // namespace wfl
 
 using namespace wfl;
@@ -820,8 +1260,8 @@ static int ctc_check(int B, int T, int C, int max_len, int blank, const char* wh
     set_error("%s: bad arguments (B=%d T=%d C=%d blank=%d max_len=%d)", who, B, T, C, blank, max_len);
     return WFL_ERR_INVALID;
   }
-  if (max_len + 1 > 64) {
-    set_error("%s: target length %d needs more than one 64-lane wavefront (use the lattice engine)", who, max_len);
+  if (max_len + 1 > 256) {
+    set_error("%s: target length %d exceeds four positions per lane (use the lattice engine)", who, max_len);
     return WFL_ERR_UNSUPPORTED;
   }
   if ((size_t)4 * (kBlk + 1) * C * 4 > (size_t)kLdsBytes) {
@@ -849,7 +1289,16 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
     return WFL_ERR_INVALID;
   }
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll};
-  if (!(flags & WFL_CTC_FAST_CHAIN)) {
+  const int ppl = (max_len + 1 + 63) / 64;  // target positions per lane
+  if (ppl > 1) {  // long targets: multi-position lanes, log-domain chain only
+    const dim3 grid((unsigned)B, 2u);
+    if (ppl == 2)
+      hipLaunchKernelGGL(ctc_long_chain_kernel<2>, grid, dim3(192), 0, (hipStream_t)stream, a);
+    else if (ppl == 3)
+      hipLaunchKernelGGL(ctc_long_chain_kernel<3>, grid, dim3(192), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(ctc_long_chain_kernel<4>, grid, dim3(192), 0, (hipStream_t)stream, a);
+  } else if (!(flags & WFL_CTC_FAST_CHAIN)) {
     hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 0);
   } else {
     hipLaunchKernelGGL(ctc_fast_chain_kernel, dim3((unsigned)B, 2u), dim3(512), 0, (hipStream_t)stream, a);
@@ -879,13 +1328,32 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
   if (a.token == 0) a.token = 1;
   const int64_t items = (int64_t)B * ctc_blocks(T);
-  const size_t lds = std::max((size_t)4 * (kBlk + 1) * C * 4, sizeof(ChainLdsT));
-  if (lds > 48 * 1024)
-    WFL_HIP_CHECK(
-        hipFuncSetAttribute((const void*)ctc_pipelined_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(ctc_pipelined_kernel, dim3((unsigned)(2 * B + (items + 3) / 4)), dim3(256), lds,
-                     (hipStream_t)stream, a, coef, gout, dx);
+  const int ppl = (max_len + 1 + 63) / 64;  // target positions per lane
+  const dim3 grid((unsigned)(2 * B + (items + 3) / 4));
+  const size_t rows_lds = (size_t)4 * (kBlk + 1) * C * 4;
+  auto launch = [&](auto kern, size_t chain_lds) -> int {
+    const size_t lds = std::max(rows_lds, chain_lds);
+    if (lds > (size_t)kLdsBytes) {
+      set_error("ctc_forward_backward: needs %zu B of LDS (limit %d)", lds, kLdsBytes);
+      return WFL_ERR_UNSUPPORTED;
+    }
+    if (lds > 48 * 1024)
+      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
+    return WFL_OK;
+  };
+  int rc = WFL_OK;
+  if (ppl == 1) {
+    rc = launch(ctc_pipelined_kernel, sizeof(ChainLdsT));
+  } else {
+    a.loss_out = nullptr;  // the long-target chains do not reduce the loss in-kernel
+    rc = ppl == 2   ? launch(ctc_long_pipelined_kernel<2>, sizeof(LongLds<2>))
+         : ppl == 3 ? launch(ctc_long_pipelined_kernel<3>, sizeof(LongLds<3>))
+                    : launch(ctc_long_pipelined_kernel<4>, sizeof(LongLds<4>));
+  }
+  if (rc) return rc;
   WFL_LAUNCH_CHECK();
+  if (ppl > 1 && loss_out) return wfl_reduce_loss(nll, loss_scale, B, 1.f, 0, loss_out, stream);
   return WFL_OK;
 }
 
@@ -900,10 +1368,18 @@ int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, co
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, (float*)ws, (float*)nll};
   const int64_t items = (int64_t)B * ctc_blocks(T);
   const size_t lds = (size_t)4 * (kBlk + 1) * C * 4;
-  if (lds > 48 * 1024)
-    WFL_HIP_CHECK(hipFuncSetAttribute((const void*)ctc_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream, a, coef,
-                     gout, dx);
+  const int ppl = (max_len + 1 + 63) / 64;
+  auto launch = [&](auto kern) -> int {
+    if (lds > 48 * 1024)
+      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
+    return WFL_OK;
+  };
+  if (int rc = ppl == 1   ? launch(ctc_grad_kernel)
+               : ppl == 2 ? launch(ctc_long_grad_kernel<2>)
+               : ppl == 3 ? launch(ctc_long_grad_kernel<3>)
+                          : launch(ctc_long_grad_kernel<4>))
+    return rc;
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

@@ -343,6 +343,7 @@ class CtcTargets:
 
 
 _CTC_WS_SIZES = {}
+CTC_FAST_MAX_LEN = 255  # longest target of the CTC fast path (four positions per lane); beyond: lattice engine
 CTC_DEFAULT_FLAGS = 0  # chain kernel used by the criteria (see include/wfl.h, WFL_CTC_FAST_CHAIN)
 
 

@@ -248,7 +248,8 @@ int wfl_conv_grad(const float* x, int B, int T, int C, const int32_t* ktab, int 
 /* ------------------------------------------------------------------------------------------------
  * Device kernels: CTC fast path (create_ctc_graph + intersect + forward_score + backward of
  * ctc.py:15-94; banded recursion with register-resident state, no lattice arrays).
- *   targets: device int32 flat, offsets: device int64 [B+1]; requires max target length <= 63
+ *   targets: device int32 flat, offsets: device int64 [B+1]; requires max target length <= 255
+ *   (up to 63: one position per lane; longer: two to four positions per lane)
  *   (longer targets: WFL_ERR_UNSUPPORTED -> use wfl_lattice_pack_ctc + the lattice engine).
  *   loss_b = -logZ_b is written to nll[B]; dx = coef[b]*gout*posteriors (dense rows).
  *   Base-2 log-domain arithmetic, block-renormalised; the chain stores one checkpoint per 16

@@ -107,17 +107,32 @@ def test_ctc_fast_path_vs_oracle(crit, B, T, C, Lmax, reduction):
     close(xt.grad, want_dx)
 
 
-def test_ctc_long_targets_use_lattice_engine_and_agree(crit):
-    rs = np.random.RandomState(7)
-    B, T, C = 3, 180, 12
+@pytest.mark.parametrize("lens,T", [((70, 64, 5), 180), ((127, 128, 0), 300), ((129, 191, 192), 420),
+                                    ((255, 193, 17), 530), ((256, 300, 12), 640)])
+def test_ctc_long_targets(crit, lens, T):
+    """targets longer than a wavefront: two to four positions per lane on the CTC fast path (pipelined
+    step through CTCLoss, two-kernel step through the engine calls), the generic lattice engine
+    beyond 255 labels -- all against the oracle, with repeated labels and ragged lengths"""
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(sum(lens))
+    B, C = len(lens), 12
     x = rs.randn(B, T, C).astype(np.float32)
-    targets = [rs.randint(0, C - 1, size=n).tolist() for n in (70, 64, 5)]
+    targets = [rs.randint(0, C - 1, size=n).tolist() for n in lens]
     want_loss, want_dx = OR.ctc_loss_grad(x, targets, C - 1, "mean")
     xt = dev(x, grad=True)
     loss = crit["ctc"].CTCLoss(xt, targets, C - 1, "mean")
     loss.backward()
     assert loss.item() == pytest.approx(want_loss, rel=RTOL)
     close(xt.grad, want_dx)
+    if max(lens) <= E.CTC_FAST_MAX_LEN:
+        tg = E.targets_on_device(targets, xt.device)
+        scale, _, coef = E.loss_factors(tg, "mean")
+        dx = torch.full_like(xt, float("nan"))
+        ws, nll = E.ctc_forward(xt.detach(), tg, C - 1)
+        E.ctc_grad(xt.detach(), tg, C - 1, ws, nll, coef, None, dx)
+        assert float(E.reduce_loss(nll, scale, 1.0)) == pytest.approx(want_loss, rel=RTOL)
+        close(dx, want_dx)
 
 
 def test_ctc_three_hip_paths_agree(crit):
