@@ -5,12 +5,14 @@ Metric (BASELINE.json): utterances/sec, forward+backward, on the CTC benchmark o
 (benchmarks/ctc_benchmark.py:17-31 protocol: randn "log_probs", targets randint(C-2), blank C-1,
 reduction "none", fwd + bwd per step) at configs[1]: T=1000, C=100, B=128, L=44, one MI355X.
 
-A "step" = one pass of the hot path over one batch resident in HBM: the calls the criterion makes
-through the C ABI of libwfl.so (wfl_ctc_forward -> wfl_reduce_loss -> wfl_ctc_grad), i.e. alpha and
-beta chains, loss reduction, dense [B,T,C] gradient.  `value` is measured at that boundary
+A "step" = one pass of the hot path over one batch resident in HBM: the call the criterion makes
+through the C ABI of libwfl.so -- wfl_ctc_forward_backward, ONE pipelined launch that runs the alpha
+and beta chains, the loss reduction and the dense [B,T,C] gradient (--ctc-step split times the same
+work as wfl_ctc_forward -> wfl_reduce_loss -> wfl_ctc_grad).  `value` is measured at that boundary
 (--mode abi, default); the same step through the Python drop-in operator
 (`CTCLoss(x, targets, blank).backward()`, what the reference's benchmark script times) is reported
-next to it as `python_api`.
+next to it as `python_api`, a hipGraph replay of it as `hip_graph`, the CPU baselines as
+`cpu_baseline` (oracle C port, all host cores) and `cpu_torch_ctc_loss`.
 
   python bench.py                      # 1 GPU, defaults finish in well under a minute
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
