@@ -611,6 +611,40 @@ __global__ void __launch_bounds__(256) ctc_certify_kernel(CtcArgs a) {
 // ------------------------------------------------------------------------------------------------
 // gradient: one wave per (utterance, 16-frame block), 4 waves per workgroup
 // ------------------------------------------------------------------------------------------------
+// Sum 16 per-lane values over the 64 lanes at once: instead of 16 wave reductions (16 x 18 instructions)
+// the lanes fold the 16 values pairwise -- after the exchange with lane^1 a lane only keeps the 8
+// values whose index has its bit 0, after lane^2 four, ... -- so that lane l (l < 16, every row)
+// ends up with the 64-lane total of value l.  ~55 instructions.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {  // quad_perm / row_ror moves, all lanes valid
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) {
+  float a[8], b[4], c[2];
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {  // partner lane^1: quad_perm [1,0,3,2]
+    const float keep = b0 ? v[2 * m + 1] : v[2 * m], send = b0 ? v[2 * m] : v[2 * m + 1];
+    a[m] = keep + dpp_quad<0xb1>(send);
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {  // partner lane^2: quad_perm [2,3,0,1]
+    const float keep = b1 ? a[2 * m + 1] : a[2 * m], send = b1 ? a[2 * m] : a[2 * m + 1];
+    b[m] = keep + dpp_quad<0x4e>(send);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {  // partner lane^4 inside the row of 16: rotate by 4 or by 12
+    const float keep = b2 ? b[2 * m + 1] : b[2 * m], send = b2 ? b[2 * m] : b[2 * m + 1];
+    const float up = dpp_quad<0x124>(send), down = dpp_quad<0x12c>(send);  // row_ror:4 (from lane+12 = lane-4), row_ror:12 (from lane+4)
+    c[m] = keep + (b2 ? up : down);
+  }
+  const float keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
+  float t = keep + dpp_quad<0x128>(send);  // partner lane^8: row_ror:8
+  t += __shfl_xor(t, 16, 64);
+  t += __shfl_xor(t, 32, 64);
+  return t;
+}
+
 // PIPE: the pipelined step -- wait for the two checkpoints of block k to be published by the chain
 // workgroups of the same launch, and normalise the posteriors by the Z the block itself reproduces
 // (sum_s alpha(s) beta(s) at its last frame; the certificate's identity) instead of the log Z that the
@@ -728,6 +762,9 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
       else
         U = kNegBig;  // no accepting path through this block: every posterior is 2^-huge = 0
     }
+    float gbv[kBlk];
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) gbv[j] = 0.f;
 #pragma unroll
     for (int j = kBlk - 1; j >= 0; --j) {  // beta backwards, in the forward lane mapping
       if (j < n) {
@@ -741,16 +778,18 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
         // dead / non-existent states carry sentinels: exp2 of them is exactly 0, no select needed
         const float gb = __builtin_amdgcn_exp2f(pa_b[j] + tb + U);
         const float gl = __builtin_amdgcn_exp2f(pa_l[j] + tl + U);
-        // blank column: one DPP wave reduction + a single LDS add (per-lane ds_add_f32 instead was
-        // measured at 49 us for the kernel vs 28 us: LDS float atomics serialise per active lane)
-        const float gsum = wave_reduce_sum_lane63(gb);
-        if (lane == 63 && gsum != 0.f) atomicAdd(&rows[j * C + a.blank], gsum * cf);
+        // blank column: the 16 frames' lane values are summed over the wave together after the loop
+        // (per-lane ds_add_f32 instead was measured at 49 us for the kernel vs 28 us: LDS float atomics
+        // serialise per active lane; one wave reduction per frame costs 18 instructions x 16)
+        gbv[j] = gb;
         if (uniq) rows[j * C + y] = gl * cf;
         if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
         bb = tb + xb[j];
         bl = tl + xl[j];
       }
     }
+    const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
+    if (lane < n && gtot != 0.f) atomicAdd(&rows[lane * C + a.blank], gtot * cf);
   }
   // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
   if (valid) {  // the dense rows of a block are contiguous in dx: one coalesced copy (zeros included)
