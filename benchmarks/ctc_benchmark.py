@@ -30,3 +30,24 @@ def func():
 
 ms = time_func(func, name="ctc fwd + bwd")
 print("utterances/s: %.0f" % (B / (ms * 1e-3)))
+
+# the criterion module of the training loop (criterions/ctc.py:41-63 in the reference): raw scores in,
+# log_softmax + loss + gradient -- fused into the pipelined launch here vs torch's log_softmax in front
+from criterions.ctc import CTC  # noqa: E402
+
+module = CTC(N - 1, False)
+targets = [torch.tensor(t) for t in tgt]
+
+
+def fused():
+    inputs.grad = None
+    module(inputs, targets).backward()
+
+
+def unfused():
+    inputs.grad = None
+    CTCLoss(torch.nn.functional.log_softmax(inputs, dim=2), tgt, N - 1).backward()
+
+
+time_func(fused, name="CTC module (log_softmax fused) fwd + bwd")
+time_func(unfused, name="torch log_softmax + CTCLoss fwd + bwd")

@@ -123,7 +123,8 @@ _SIGS = {
     "wfl_ctc_forward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "wfl_ctc_grad": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "wfl_ctc_forward_backward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
-                                         _P]),
+                                         _P, _P]),
+    "wfl_row_lse": (c_int, [_P, c_int64, c_int, _P, _P]),
     "wfl_reduce_loss": (c_int, [_P, _P, c_int, c_float, c_int, _P, _P]),
     "wfl_scale": (c_int, [_P, c_int64, _P, _P]),
 }

@@ -48,8 +48,12 @@ class CTCLossFunction(torch.autograd.Function):
             # loss and gradient in ONE pipelined launch (gradient waves run behind the chains); backward
             # only applies the upstream scalar.  Like torch's own CTC, the gradient is produced eagerly.
             dx = torch.empty_like(x)
-            _, _, loss = E.ctc_forward_backward(x, tg, int(blank_idx), coef, None, dx, loss_scale=scale, want_loss=True)
+            lse = E.row_lse(x) if ctx_log_softmax(ctx) else None
+            _, _, loss = E.ctc_forward_backward(x, tg, int(blank_idx), coef, None, dx, loss_scale=scale, want_loss=True,
+                                                lse=lse)
             ctx.aux = ("pipelined", x, tg, int(blank_idx), dx, coef)
+        elif ctx_log_softmax(ctx):
+            raise RuntimeError("fused log_softmax CTC is only used on the pipelined path")
         elif tg.max_len <= E.CTC_FAST_MAX_LEN:
             ws, nll = E.ctc_forward(x, tg, int(blank_idx))
             loss = E.reduce_loss(nll, scale, 1.0)
@@ -89,6 +93,22 @@ class CTCLossFunction(torch.autograd.Function):
         return dx, None, None, None
 
 
+def ctx_log_softmax(ctx):
+    return getattr(ctx, "fused_log_softmax", False)
+
+
+class _FusedLogSoftmaxCTCLoss(CTCLossFunction):
+    """CTCLoss(log_softmax(inputs), ...) as one operator (ctc.py:107 + ctc.py:122): the row log-sum-exps
+    are computed once, subtracted where the chains gather their emissions, and the gradient rows
+    start at -cf * softmax(inputs); only for the pipelined path (targets up to 255 labels, input
+    requires grad) -- the module falls back to torch's log_softmax otherwise."""
+
+    @staticmethod
+    def forward(ctx, inputs, targets, blank_idx=0, reduction="none"):
+        ctx.fused_log_softmax = True
+        return CTCLossFunction.forward(ctx, inputs, targets, blank_idx, reduction)
+
+
 CTCLoss = CTCLossFunction.apply
 
 
@@ -99,6 +119,9 @@ class CTC(torch.nn.Module):
         self.use_pt = use_pt  # use torch.nn.functional.ctc_loss instead of the WFST engine
 
     def forward(self, inputs, targets):
+        if not self.use_pt and inputs.requires_grad and inputs.dtype == torch.float32 and \
+                max((t.numel() for t in targets), default=0) <= E.CTC_FAST_MAX_LEN:
+            return _FusedLogSoftmaxCTCLoss.apply(inputs, targets, self.blank, "mean")
         log_probs = torch.nn.functional.log_softmax(inputs, dim=2)
         if self.use_pt:  # ctc.py:109-121
             return torch.nn.functional.ctc_loss(

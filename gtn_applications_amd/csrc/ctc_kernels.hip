@@ -104,6 +104,10 @@ struct CtcArgs {
   unsigned long long token;  // pipelined step: value a ready flag takes when its checkpoint is published
   const float* loss_scale;   // pipelined step, optional: loss_out[0] = mean_b(loss_scale[b] * nll[b])  (ctc.py:68-69)
   float* loss_out;
+  // pipelined step, optional: x holds raw scores and row_lse[b*T + t] their log-sum-exp -- the fused
+  // torch.nn.functional.log_softmax of ctc.py:107 (forward: subtracted at the gather; backward: the rows
+  // start at -cf * softmax(x) because the posteriors of a frame sum to one)
+  const float* row_lse;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -124,7 +128,7 @@ struct ChainLdsT {
 // only_flagged != 0: repair pass -- run only for utterances whose fast-chain result was rejected.
 // SIGNAL: publish ready[b][dir][block] (agent-scope release) after each checkpoint reached HBM, for the
 // gradient waves of the pipelined step that are waiting for it.
-template <bool SIGNAL>
+template <bool SIGNAL, bool LSM = false>
 __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int dir, int only_flagged, ChainLdsT& S) {
   auto& ring = S.ring;
   auto& ckbuf = S.ckbuf;
@@ -160,6 +164,7 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
   // acknowledgement must not also wait for a helper's emission gathers
   constexpr int kFlusher = SIGNAL ? 3 : 1;
   float raw[kBlk];
+  float lse_raw = 0.f;  // lane j < 16: log-sum-exp of the block's j-th processed frame (fused log_softmax)
   auto issue = [&](int kk) {
     const int k = dir == 0 ? kk : NB - 1 - kk;
     const int t0 = k * kBlk, n = min(kBlk, T - t0);
@@ -168,11 +173,15 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
       raw[j] = xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
     }
+    if (LSM) {
+      const int t = dir == 0 ? t0 + (lane & 15) : t0 + n - 1 - (lane & 15);
+      lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
+    }
   };
   auto stage = [&](int kk) {
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {
-      const float xs = to_score(raw[j]);
+      const float xs = to_score(LSM ? raw[j] - readlane_f(lse_raw, j) : raw[j]);
       const float xblank = readlane_f(xs, L);
       ring[kk % kRing][j][lane] = make_float2(has_blank ? xblank : kNegBig, has_label ? xs : kNegBig);
     }
@@ -645,11 +654,58 @@ __device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) {
   return t;
 }
 
+// Fused log_softmax backward, first half: rows[j*C + c] = -cf * softmax(x)[t0 + j, c] for the block's n
+// frames (contiguous in x).  Flat and vectorised, eight loads in flight per lane: the wave has
+// nothing else to hide the latency behind.  lse_blk: lane j < 16 holds the log-sum-exp of frame t0 + j.
+__device__ __forceinline__ void lsm_seed_rows(float* rows, const float* __restrict__ xsrc, int n, int C, float lse_blk,
+                                              float cf_row, int lane) {
+  const int total = n * C;
+  const unsigned magic = (unsigned)((0x100000000ull + (unsigned)C - 1) / (unsigned)C);  // i / C for i * C < 2^32
+  auto seed = [&](float xv, float l) {
+    const float e = __expf((xv == xv ? xv : WFL_NEG_INF) - l);
+    return l > WFL_NEG_INF ? -cf_row * e : 0.f;  // a frame without finite scores: no softmax term
+  };
+  constexpr int U = 8;
+  if ((C & 3) == 0 && (((uintptr_t)xsrc) & 15) == 0) {
+    const int n4 = total >> 2;
+    for (int i0 = lane; i0 < n4; i0 += 64 * U) {
+      float4 v[U];
+      float l[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + 64 * u, n4 - 1);
+        v[u] = ((const float4*)xsrc)[i];
+        l[u] = __shfl(lse_blk, (int)__umulhi((unsigned)i * 4u, magic), 64);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 64 * u;
+        if (i < n4) ((float4*)rows)[i] = float4{seed(v[u].x, l[u]), seed(v[u].y, l[u]), seed(v[u].z, l[u]), seed(v[u].w, l[u])};
+      }
+    }
+  } else {
+    for (int i0 = lane; i0 < total; i0 += 64 * U) {
+      float v[U], l[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + 64 * u, total - 1);
+        v[u] = xsrc[i];
+        l[u] = __shfl(lse_blk, (int)__umulhi((unsigned)i, magic), 64);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 64 * u;
+        if (i < total) rows[i] = seed(v[u], l[u]);
+      }
+    }
+  }
+}
+
 // PIPE: the pipelined step -- wait for the two checkpoints of block k to be published by the chain
 // workgroups of the same launch, and normalise the posteriors by the Z the block itself reproduces
 // (sum_s alpha(s) beta(s) at its last frame; the certificate's identity) instead of the log Z that the
 // alpha chain only knows when it has finished.
-template <bool PIPE>
+template <bool PIPE, bool LSM = false>
 __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
                                               const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -660,8 +716,18 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
   int* cnt = (int*)(rows + (size_t)kBlk * C);
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
   bool live = valid && (PIPE || a.nll[b] < __builtin_inff());  // no accepting path: zero gradient
-  if (valid)
+  constexpr bool lsm = PIPE && LSM;  // fused log_softmax (raw scores in x)
+  const float cf_row = (coef ? coef[valid ? b : 0] : 1.f) * (gout ? gout[0] : 1.f);
+  float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
+  if (valid) {
     for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;  // (int 0 == float 0 bit pattern)
+    if (lsm) {
+      // d loss / d raw score = g - softmax(x) * sum_c g, and the posteriors of a frame sum to one:
+      // the rows start at -cf * softmax(x) (done before waiting: it does not depend on the chains)
+      lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
+      lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf_row, lane);
+    }
+  }
   if (PIPE && valid) {
     // alpha checkpoint k and beta checkpoint NB-1-k: published by wave 1 of the two chain workgroups
     // (flags are compared with a 64-bit token that is unique to this launch: the workspace needs no clearing)
@@ -704,7 +770,7 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
     for (int j = 0; j < kBlk; ++j) xl[j] = xrow[(int64_t)min(t0 + j, T - 1) * C + col];  // all 16 gathers in flight
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {
-      const float xs = to_score(xl[j]);
+      const float xs = to_score(lsm ? xl[j] - readlane_f(lse_blk, j) : xl[j]);
       xb[j] = has_blank ? readlane_f(xs, L) : kNegBig;
       xl[j] = has_label ? xs : kNegBig;
     }
@@ -782,7 +848,7 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
         // (per-lane ds_add_f32 instead was measured at 49 us for the kernel vs 28 us: LDS float atomics
         // serialise per active lane; one wave reduction per frame costs 18 instructions x 16)
         gbv[j] = gb;
-        if (uniq) rows[j * C + y] = gl * cf;
+        if (uniq) rows[j * C + y] = (lsm ? rows[j * C + y] : 0.f) + gl * cf;  // sole writer of this column
         if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
         bb = tb + xb[j];
         bl = tl + xl[j];
@@ -790,6 +856,8 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
     }
     const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
     if (lane < n && gtot != 0.f) atomicAdd(&rows[lane * C + a.blank], gtot * cf);
+    if (lsm && !(U > 0.5f * kNegBig))  // no accepting path: zero gradient, softmax term included
+      for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
   }
   // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
   if (valid) {  // the dense rows of a block are contiguous in dx: one coalesced copy (zeros included)
@@ -824,6 +892,7 @@ __global__ void __launch_bounds__(256)
 // items are numbered from the middle outwards and almost all of the gradient kernel's work
 // disappears behind the latency-bound chains, which leave most of every CU idle.
 // ------------------------------------------------------------------------------------------------
+template <bool LSM>
 __global__ void __launch_bounds__(256)
     ctc_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
                          float* __restrict__ dx) {
@@ -836,7 +905,7 @@ __global__ void __launch_bounds__(256)
       __builtin_amdgcn_s_setprio(3);
     else
       __builtin_amdgcn_s_setprio(2);
-    ctc_log_chain_body<true>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, 0, *reinterpret_cast<ChainLdsT*>(smem));
+    ctc_log_chain_body<true, LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, 0, *reinterpret_cast<ChainLdsT*>(smem));
     return;
   }
   const int NB = ctc_blocks(a.T);
@@ -845,7 +914,7 @@ __global__ void __launch_bounds__(256)
   const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;  // r: rank in readiness order
   const int mid = (NB - 1) / 2;
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-  ctc_grad_body<true>(a, valid, b, k, coef, gout, dx, smem);
+  ctc_grad_body<true, LSM>(a, valid, b, k, coef, gout, dx, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -898,7 +967,7 @@ __device__ __forceinline__ float long_read(const float (&v)[PPL], int pos) {
   return readlane_f(s, pos / PPL);
 }
 
-template <int PPL, bool SIGNAL>
+template <int PPL, bool SIGNAL, bool LSM = false>
 __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int dir, LongLds<PPL>& S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = a.T, C = a.C, P = a.P;
@@ -911,6 +980,7 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
   const int h = wave - 1;
   constexpr int kFlusher = SIGNAL ? 3 : 1;
   float raw[kBlk][PPL];
+  float lse_raw = 0.f;
   auto issue = [&](int kk) {
     const int k = dir == 0 ? kk : NB - 1 - kk;
     const int t0 = k * kBlk, n = min(kBlk, T - t0);
@@ -921,13 +991,18 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
 #pragma unroll
       for (int p = 0; p < PPL; ++p) raw[j][p] = row[c.col[p]];
     }
+    if (LSM) {
+      const int t = dir == 0 ? t0 + (lane & 15) : t0 + n - 1 - (lane & 15);
+      lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
+    }
   };
   auto stage = [&](int kk) {
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {
       float xs[PPL];
+      const float lj = LSM ? readlane_f(lse_raw, j) : 0.f;
 #pragma unroll
-      for (int p = 0; p < PPL; ++p) xs[p] = to_score(raw[j][p]);
+      for (int p = 0; p < PPL; ++p) xs[p] = to_score(raw[j][p] - lj);
       const float xblank = long_read<PPL>(xs, L);  // position L has no label: its column is the blank
       if (lane == 0) S.ring_xb[kk % kRing][j] = xblank;
 #pragma unroll
@@ -1062,7 +1137,7 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
   }
 }
 
-template <int PPL, bool PIPE>
+template <int PPL, bool PIPE, bool LSM = false>
 __device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid, int b, int k,
                                                    const float* __restrict__ coef, const float* __restrict__ gout,
                                                    float* __restrict__ dx, char* smem) {
@@ -1074,8 +1149,16 @@ __device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid,
   int* cnt = (int*)(rows + (size_t)kBlk * C);
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
   bool live = valid && (PIPE || a.nll[b] < __builtin_inff());
-  if (valid)
+  constexpr bool lsm = PIPE && LSM;
+  const float cf_row = (coef ? coef[valid ? b : 0] : 1.f) * (gout ? gout[0] : 1.f);
+  float lse_blk = 0.f;
+  if (valid) {
     for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;
+    if (lsm) {
+      lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
+      lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf_row, lane);
+    }
+  }
   if (PIPE && valid) {
     const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
     const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
@@ -1129,8 +1212,9 @@ __device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid,
 #pragma unroll
   for (int j = 0; j < kBlk; ++j) {
     float xs[PPL];
+    const float lj = lsm ? readlane_f(lse_blk, j) : 0.f;
 #pragma unroll
-    for (int p = 0; p < PPL; ++p) xs[p] = to_score(xl[j][p]);
+    for (int p = 0; p < PPL; ++p) xs[p] = to_score(xl[j][p] - lj);
     xb[j] = long_read<PPL>(xs, L);
 #pragma unroll
     for (int p = 0; p < PPL; ++p) xl[j][p] = has_label[p] ? xs[p] : kNegBig;
@@ -1225,7 +1309,7 @@ __device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid,
       for (int p = 0; p < PPL; ++p) {
         gbs += __builtin_amdgcn_exp2f(pa_b[j][p] + tb[p] + U);
         const float gl = __builtin_amdgcn_exp2f(pa_l[j][p] + tl[p] + U);
-        if (uniq[p]) rows[j * C + y[p]] = gl * cf;
+        if (uniq[p]) rows[j * C + y[p]] = (lsm ? rows[j * C + y[p]] : 0.f) + gl * cf;
         if (dup[p] && gl != 0.f) atomicAdd(&rows[j * C + y[p]], gl * cf);
       }
       const float gsum = wave_reduce_sum_lane63(gbs);
@@ -1234,6 +1318,8 @@ __device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid,
       for (int p = 0; p < PPL; ++p) bb[p] = tb[p] + xb[j], bl[p] = tl[p] + xl[j][p];
     }
   }
+  if (lsm && !(U > 0.5f * kNegBig))  // no accepting path: zero gradient, softmax term included
+    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
   {
     float* dst = dx + ((int64_t)b * T + t0) * C;
     const int total = n * C;
@@ -1247,7 +1333,7 @@ __device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid,
   }
 }
 
-template <int PPL>
+template <int PPL, bool LSM>
 __global__ void __launch_bounds__(256)
     ctc_long_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
                               float* __restrict__ dx) {
@@ -1259,7 +1345,7 @@ __global__ void __launch_bounds__(256)
       __builtin_amdgcn_s_setprio(3);
     else
       __builtin_amdgcn_s_setprio(2);
-    ctc_long_chain_body<PPL, true>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<LongLds<PPL>*>(smem));
+    ctc_long_chain_body<PPL, true, LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<LongLds<PPL>*>(smem));
     return;
   }
   const int NB = ctc_blocks(a.T);
@@ -1268,7 +1354,7 @@ __global__ void __launch_bounds__(256)
   const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;
   const int mid = (NB - 1) / 2;
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-  ctc_long_grad_body<PPL, true>(a, valid, b, k, coef, gout, dx, smem);
+  ctc_long_grad_body<PPL, true, LSM>(a, valid, b, k, coef, gout, dx, smem);
 }
 
 template <int PPL>
@@ -1353,13 +1439,13 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
 
 int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
                              int max_len, int blank, float* ws, float* nll, const float* coef, const float* gout,
-                             float* dx, const float* loss_scale, float* loss_out, void* stream) {
+                             float* dx, const float* loss_scale, float* loss_out, const float* row_lse, void* stream) {
   if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_forward_backward")) return rc;
   if (!x || !targets || !offsets || !ws || !nll || !dx) {
     set_error("ctc_forward_backward: null buffer");
     return WFL_ERR_INVALID;
   }
-  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll, 0ull, loss_scale, loss_out};
+  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll, 0ull, loss_scale, loss_out, row_lse};
   // launch token: process-wide counter mixed with the workspace address -- uninitialised memory or flags
   // left by a launch that used the block earlier cannot equal it; consumers clear the flags they used,
   // so replaying the SAME launch from a hipGraph (same token, same workspace) starts from cleared flags
@@ -1383,12 +1469,18 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   };
   int rc = WFL_OK;
   if (ppl == 1) {
-    rc = launch(ctc_pipelined_kernel, sizeof(ChainLdsT));
+    rc = row_lse ? launch(ctc_pipelined_kernel<true>, sizeof(ChainLdsT))
+                 : launch(ctc_pipelined_kernel<false>, sizeof(ChainLdsT));
   } else {
     a.loss_out = nullptr;  // the long-target chains do not reduce the loss in-kernel
-    rc = ppl == 2   ? launch(ctc_long_pipelined_kernel<2>, sizeof(LongLds<2>))
-         : ppl == 3 ? launch(ctc_long_pipelined_kernel<3>, sizeof(LongLds<3>))
-                    : launch(ctc_long_pipelined_kernel<4>, sizeof(LongLds<4>));
+    if (row_lse)
+      rc = ppl == 2   ? launch(ctc_long_pipelined_kernel<2, true>, sizeof(LongLds<2>))
+           : ppl == 3 ? launch(ctc_long_pipelined_kernel<3, true>, sizeof(LongLds<3>))
+                      : launch(ctc_long_pipelined_kernel<4, true>, sizeof(LongLds<4>));
+    else
+      rc = ppl == 2   ? launch(ctc_long_pipelined_kernel<2, false>, sizeof(LongLds<2>))
+           : ppl == 3 ? launch(ctc_long_pipelined_kernel<3, false>, sizeof(LongLds<3>))
+                      : launch(ctc_long_pipelined_kernel<4, false>, sizeof(LongLds<4>));
   }
   if (rc) return rc;
   WFL_LAUNCH_CHECK();

@@ -979,6 +979,67 @@ __global__ void reduce_loss_kernel(const float* __restrict__ vals, const float* 
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s / (float)B;
 }
 
+// out[r] = logsumexp_c x[r, c] (NaN = -inf): the forward half of a fused log_softmax.  One wave per row,
+// RU rows per iteration with all NV * RU loads of a lane issued before the first use (16 in flight per
+// lane: the kernel is one streaming read of x and needs the bytes in flight to reach HBM speed).
+template <int NV, int RU>
+__global__ void __launch_bounds__(256) row_lse_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RU; r0 < rows; r0 += nw * RU) {
+    float v[RU][NV];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const float* row = x + min(r0 + u, rows - 1) * C;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[u][i] = c < C ? row[c] : WFL_NEG_INF;
+      }
+    }
+    float m[RU], sum[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      m[u] = WFL_NEG_INF;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[u][i] = nan_to_neg(v[u][i]), m[u] = fmaxf(m[u], v[u][i]);
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) m[u] = wave_all_max(m[u]);  // (DPP; the __shfl reductions go through LDS)
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      sum[u] = 0.f;
+      if (m[u] > WFL_NEG_INF) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum[u] += fast_exp(v[u][i] - m[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) sum[u] = wave_all_sum(sum[u]);
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (lane == 0 && r0 + u < rows) out[r0 + u] = m[u] > WFL_NEG_INF ? m[u] + fast_log(sum[u]) : WFL_NEG_INF;
+  }
+}
+
+// any C: two passes over the row (the second one hits L2)
+__global__ void __launch_bounds__(256) row_lse_wide_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                            float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const float* row = x + r * C;
+    float m = WFL_NEG_INF;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, nan_to_neg(row[c]));
+    m = wave_max(m);
+    float s = 0.f;
+    if (m > WFL_NEG_INF)
+      for (int c = lane; c < C; c += 64) s += fast_exp(nan_to_neg(row[c]) - m);
+    s = wave_sum(s);
+    if (lane == 0) out[r] = m > WFL_NEG_INF ? m + fast_log(s) : WFL_NEG_INF;
+  }
+}
+
 // v *= s[0], skipped when s[0] == 1 (the usual upstream gradient of a scalar loss)
 __global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ v, int64_t n4, int64_t n, const float* __restrict__ s) {
   const float f = s[0];
@@ -1161,6 +1222,32 @@ int wfl_debug_grad_occupancy(int lds_bytes) {
   int n = -1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, grad_kernel, 256, (size_t)lds_bytes) != hipSuccess) return -1;
   return n;
+}
+
+int wfl_row_lse(const float* x, int64_t rows, int C, float* out, void* stream) {
+  if (!x || !out || rows < 0 || C <= 0) {
+    set_error("row_lse: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  if (rows == 0) return WFL_OK;
+  auto launch = [&](auto kern, int ru) {
+    const unsigned grid = (unsigned)std::min<int64_t>((rows + 4 * ru - 1) / (4 * ru), 1 << 16);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, rows, C, out);
+  };
+  if (C <= 64)
+    launch(row_lse_kernel<1, 16>, 16);
+  else if (C <= 128)
+    launch(row_lse_kernel<2, 8>, 8);
+  else if (C <= 256)
+    launch(row_lse_kernel<4, 4>, 4);
+  else if (C <= 512)
+    launch(row_lse_kernel<8, 2>, 2);
+  else if (C <= 1024)
+    launch(row_lse_kernel<16, 1>, 1);
+  else
+    launch(row_lse_wide_kernel, 1);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
 }
 
 int wfl_scale(float* v, int64_t n, const float* s, void* stream) {

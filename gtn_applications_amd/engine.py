@@ -333,9 +333,14 @@ class CtcTargets:
 
     __slots__ = ("flat", "offsets", "lens", "max_len", "B", "dev_flat", "dev_offsets", "cache")
 
-    def __init__(self, targets, device):
+    def __init__(self, targets, device, flat=None, lens=None):
         self.cache = {}  # derived device objects (scale factors, packed lattices), keyed by the caller
-        self.flat, self.offsets, self.lens = flatten_targets(targets)
+        if flat is None:
+            self.flat, self.offsets, self.lens = flatten_targets(targets)
+        else:  # already flattened (list of 1-D tensors: one torch.cat instead of B tolist() calls)
+            self.flat, self.lens = flat, lens
+            self.offsets = np.zeros(len(lens) + 1, dtype=np.int64)
+            np.cumsum(lens, out=self.offsets[1:])
         self.B = len(self.lens)
         self.max_len = max(self.lens) if self.lens else 0
         self.dev_flat = torch.from_numpy(self.flat if self.flat.size else np.zeros(1, np.int32)).to(device)
@@ -366,7 +371,15 @@ def ctc_forward(x, tg, blank, flags=None):
     return ws, nll
 
 
-def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_loss=False):
+def row_lse(x):
+    """[B,T] log-sum-exp over the classes of x [B,T,C] (the forward half of a fused log_softmax)."""
+    B, T, C = x.shape
+    out = torch.empty((B, T), dtype=_F32, device=x.device)
+    N.check(N.lib.wfl_row_lse(ptr(x), B * T, C, ptr(out), stream_ptr()))
+    return out
+
+
+def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_loss=False, lse=None):
     """Loss and gradient in one pipelined launch (wfl_ctc_forward_backward): returns (ws, nll) or,
     with want_loss, (ws, nll, mean_b(loss_scale[b] * nll[b]) as a 0-dim device tensor)."""
     B, T, C = x.shape
@@ -382,7 +395,7 @@ def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_los
     N.check(
         N.lib.wfl_ctc_forward_backward(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank,
                                        ptr(ws), ptr(nll), ptr(coef), ptr(gout), ptr(dx), ptr(loss_scale), ptr(loss),
-                                       stream_ptr())
+                                       ptr(lse), stream_ptr())
     )
     return (ws, nll, loss) if want_loss else (ws, nll)
 
@@ -445,6 +458,11 @@ def targets_on_device(targets, device):
     built earlier is passed through (callers that reuse a batch skip the ~50 us content hash)."""
     if isinstance(targets, CtcTargets):
         return targets
+    if len(targets) and all(type(t) is torch.Tensor and t.dim() == 1 and not t.is_cuda for t in targets):
+        lens = [t.numel() for t in targets]
+        flat = torch.cat(targets).to(torch.int32).numpy()
+        key = (flat.tobytes(), tuple(lens), device.index)
+        return _TARGET_CACHE.get(key, lambda: CtcTargets(None, device, flat, lens))
     rows = [t.tolist() if hasattr(t, "tolist") else (t if type(t) is list else list(t)) for t in targets]
     key = (tuple(map(tuple, rows)), device.index)
     return _TARGET_CACHE.get(key, lambda: CtcTargets(rows, device))

@@ -266,11 +266,16 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
  * for the checkpoints they need and run while the chains are still sweeping.  Same outputs (nll,
  * dx); posteriors are normalised per 16-frame block by the Z the block reproduces.  If loss_out is
  * not NULL it also receives mean_b(loss_scale[b] * nll[b]) (ctc.py:68-69; loss_scale NULL = 1),
- * reduced in a fixed order by the last chain to finish -- no separate wfl_reduce_loss launch. */
+ * reduced in a fixed order by the last chain to finish -- no separate wfl_reduce_loss launch.
+ * If row_lse is not NULL, x holds RAW scores and row_lse[b*T + t] their log-sum-exp over the classes
+ * (wfl_row_lse): the log_softmax of the CTC module (ctc.py:107) is fused into the launch, forward
+ * and backward (dx is then the gradient w.r.t. the raw scores). */
 int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t* targets,
                              const int64_t* offsets, int max_len, int blank, float* ws, float* nll,
                              const float* coef, const float* gout, float* dx, const float* loss_scale,
-                             float* loss_out, void* stream);
+                             float* loss_out, const float* row_lse, void* stream);
+/* out[r] = logsumexp_c x[r*C + c] for r < rows (NaN counts as -inf) */
+int wfl_row_lse(const float* x, int64_t rows, int C, float* out, void* stream);
 /* dense gradient rows, recomputed block by block from the checkpoints of wfl_ctc_forward */
 int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
                  int max_len, int blank, const float* ws, const float* nll, const float* coef,

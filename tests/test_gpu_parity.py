@@ -324,6 +324,33 @@ def test_ctc_pipelined_step_stress_fresh_data_same_buffers():
         del x, dx_pipe, dx_split, ws, ws2, nll, nll2, loss
 
 
+@pytest.mark.parametrize("lens,T,C", [((7, 0, 12, 3), 60, 12), ((100, 64, 5), 230, 9), ((200, 30), 400, 15)])
+def test_ctc_module_fused_log_softmax(crit, lens, T, C):
+    """CTC(blank, use_pt=False): log_softmax is fused into the pipelined launch (forward at the gather,
+    backward as the softmax term of the rows) -- against the oracle's log_softmax + CTC + chain rule,
+    and against the same module with the fusion bypassed; raw scores with a -inf and a NaN entry"""
+    rs = np.random.RandomState(sum(lens) + T)
+    B = len(lens)
+    x = (2.0 * rs.randn(B, T, C)).astype(np.float32)
+    x[0, 3, 1] = -np.inf
+    x[-1, 5, 2] = np.nan
+    targets = [rs.randint(0, C - 1, size=n).tolist() for n in lens]
+    xo = np.where(np.isnan(x), -np.inf, x).astype(np.float64)
+    lp = OC.log_softmax(xo)
+    want_loss, dlp = OR.ctc_loss_grad(lp, targets, C - 1, "mean")
+    want_dx = dlp - np.exp(lp) * dlp.sum(axis=2, keepdims=True)
+    m = crit["ctc"].CTC(C - 1, False)
+    xt = dev(x, grad=True)
+    loss = m(xt, [torch.tensor(t, dtype=torch.long) for t in targets])
+    (1.5 * loss).backward()
+    assert loss.item() == pytest.approx(want_loss, rel=RTOL)
+    close(xt.grad, 1.5 * want_dx)
+    # the unfused route through the same kernels: torch log_softmax + CTCLoss
+    x2 = dev(np.where(np.isnan(x), -np.inf, x).astype(np.float32), grad=True)
+    loss2 = crit["ctc"].CTCLoss(torch.nn.functional.log_softmax(x2, dim=2), targets, C - 1, "mean")
+    assert loss.item() == pytest.approx(loss2.item(), rel=1e-5)
+
+
 def test_ctc_infeasible_and_minus_inf(crit):
     ctc = crit["ctc"]
     # T < L: no alignment -> loss +inf, zero gradient (documented policy)
