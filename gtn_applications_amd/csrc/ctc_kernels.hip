@@ -373,7 +373,6 @@ __global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_
 // ctc_log_chain_kernel in the same forward call.
 // ------------------------------------------------------------------------------------------------
 constexpr int kGap = 5;       // max exponent drop from lane i-1 to lane i
-constexpr int kFRing = 4;     // factor ring depth (blocks)
 constexpr int kEmptyE = -(1 << 28);
 
 __device__ __forceinline__ int wave_shr1_i(int v, int fill) {
@@ -383,25 +382,105 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i32(int identity, int v) {
   return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
 }
-// inclusive prefix maximum over the 64 lanes (row_shr scan + row broadcasts)
+// inclusive prefix maximum over the 64 lanes (row_shr scan + row broadcasts).  v_max_i32 with a DPP source:
+// a lane whose source lane does not exist (or whose row is masked) is simply not written, which is the
+// identity of a running maximum -- one instruction per step instead of mov / mov_dpp / max.  The s_nops
+// are the two wait states a DPP read needs after a VALU write of the same register.
 __device__ __forceinline__ int wave_prefix_max_i(int v) {
-  constexpr int ID = -(1 << 30);
-  v = max(v, dpp_i32<0x111, 0xf>(ID, v));
-  v = max(v, dpp_i32<0x112, 0xf>(ID, v));
-  v = max(v, dpp_i32<0x114, 0xf>(ID, v));
-  v = max(v, dpp_i32<0x118, 0xf>(ID, v));
-  v = max(v, dpp_i32<0x142, 0xa>(ID, v));  // row_bcast:15 -> rows 1,3
-  v = max(v, dpp_i32<0x143, 0xc>(ID, v));  // row_bcast:31 -> rows 2,3
+  asm volatile(
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(v));
   return v;
 }
+// acc0 += lane[i-1].src * c0, acc1 += lane[i-1].src * c1 (lane 0: unchanged)
+__device__ __forceinline__ void fmac2_shr1(float& acc0, float& acc1, float src, float c0, float c1) {
+  asm volatile(
+      "s_nop 1\n\tv_fmac_f32_dpp %0, %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc0), "+v"(acc1)
+      : "v"(src), "v"(c0), "v"(c1));
+}
 
-__global__ void __launch_bounds__(512) ctc_fast_chain_kernel(CtcArgs a) {
-  __shared__ float2 ring[kFRing][kBlk][64];  // (fb, fl) per frame and lane: 32 KiB
-  __shared__ float fref[kFRing][kBlk];       // per-frame reference r_t (integer valued)
-  __shared__ float2 ckbuf[2][64];            // checkpoint hand-off: chain wave -> wave 1
-  __shared__ int ckexp[2];                   // wave-uniform part of the checkpoint's exponents
-  __shared__ double offtot;                  // sum of all r_t
-  const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Reduce 16 per-lane values over the 64 lanes at once: instead of 16 wave reductions (16 x 18 instructions)
+// the lanes fold the 16 values pairwise -- after the exchange with lane^1 a lane only keeps the 8
+// values whose index has its bit 0, after lane^2 four, ... -- so that lane l (l < 16, every row)
+// ends up with the 64-lane total (MAX: maximum) of value l.  ~55 instructions.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {  // quad_perm / row_ror moves, all lanes valid
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float fold16(const float (&v)[16], int lane) {
+  auto op = [](float x, float y) { return MAX ? vmax(x, y) : x + y; };
+  float a[8], b[4], c[2];
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {  // partner lane^1: quad_perm [1,0,3,2]
+    const float keep = b0 ? v[2 * m + 1] : v[2 * m], send = b0 ? v[2 * m] : v[2 * m + 1];
+    a[m] = op(keep, dpp_quad<0xb1>(send));
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {  // partner lane^2: quad_perm [2,3,0,1]
+    const float keep = b1 ? a[2 * m + 1] : a[2 * m], send = b1 ? a[2 * m] : a[2 * m + 1];
+    b[m] = op(keep, dpp_quad<0x4e>(send));
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {  // partner lane^4 inside the row of 16: rotate by 4 or by 12
+    const float keep = b2 ? b[2 * m + 1] : b[2 * m], send = b2 ? b[2 * m] : b[2 * m + 1];
+    const float up = dpp_quad<0x124>(send), down = dpp_quad<0x12c>(send);  // row_ror:4 (from lane+12 = lane-4), row_ror:12 (from lane+4)
+    c[m] = op(keep, b2 ? up : down);
+  }
+  const float keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
+  float t = op(keep, dpp_quad<0x128>(send));  // partner lane^8: row_ror:8
+  t = op(t, __shfl_xor(t, 16, 64));
+  t = op(t, __shfl_xor(t, 32, 64));
+  return t;
+}
+__device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) { return fold16<false>(v, lane); }
+
+#ifndef WFL_DBG_FAST
+#define WFL_DBG_FAST 0  // scratch/chain_harness.cpp: bit 0 no frames, 1 no staging math, 2 no gathers, 3 idle flusher, 4 chain launch only
+#endif
+constexpr int kFHelpers = 6;  // waves 1..6 stage emission factors (whole blocks, round robin); wave 7 flushes checkpoints
+constexpr int kFSlots = 8;    // LDS ring depth in blocks (factors and checkpoint hand-off)
+
+struct FastLdsT {
+  float2 ring[kFSlots][kBlk][64];  // (fb, fl) per frame and lane: 64 KiB
+  float fref[kFSlots][kBlk];       // per-frame reference r_t (integer valued)
+  float2 ckm[kFSlots][64];         // checkpoint hand-off chain wave -> flusher: mantissas ...
+  int cke[kFSlots][64];            // ... and per-lane exponents
+  int staged[kFSlots];             // == n + 1 once block n sits in slot n % kFSlots
+  int consumed;                    // blocks the chain wave has loaded into registers
+  int ckready;                     // checkpoints handed over
+  int ckdone;                      // checkpoints the flusher has picked up
+  double offtot;                   // sum of all r_t
+};
+
+// LDS mailboxes between the waves of a workgroup.  DS instructions of a wave execute in issue order and
+// the LDS serves one instruction at a time, so "data, then flag" from the producer and "flag, then data"
+// from the consumer need no wait in between -- only the compiler has to keep the order.
+// (The casts to the LDS address space matter: a volatile access through a generic pointer is compiled to
+// a system-coherent FLAT instruction with an immediate s_waitcnt -- measured: 4 of them per block cost the
+// chain wave more than its 16 frames.)
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ __forceinline__ int lds_peek(const int* p) { return *(const volatile lds_int_t*)(const lds_int_t*)p; }
+__device__ __forceinline__ void lds_post(int* p, int v) {
+  asm volatile("" ::: "memory");
+  *(volatile lds_int_t*)(lds_int_t*)p = v;
+}
+
+// No barrier inside the sweep: every wave runs at its own pace.  Helper h owns blocks h, h+6, h+12, ...
+// entirely (16 gathers issued six chain blocks ahead of their use, one reference per FRAME), the chain
+// wave only multiplies and adds, and the flusher turns the raw (mantissa, exponent) checkpoints into
+// the log2 format of the gradient kernel.
+template <bool SIGNAL, bool LSM = false>
+__device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int dir, FastLdsT& S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = a.T, C = a.C, P = a.P;
   const int64_t o0 = a.offsets[b];
   const int L = (int)(a.offsets[b + 1] - o0);
@@ -414,149 +493,197 @@ __global__ void __launch_bounds__(512) ctc_fast_chain_kernel(CtcArgs a) {
   const int col = has_label ? y : a.blank;
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   const int NB = ctc_blocks(T);
-  if (dir == 0 && threadIdx.x == 0) ((int32_t*)(a.ws + w.flag))[b] = 0;
+  if (!SIGNAL && dir == 0 && threadIdx.x == 0) ((int32_t*)(a.ws + w.flag))[b] = 0;
+  if (threadIdx.x < kFSlots) S.staged[threadIdx.x] = 0;
+  if (threadIdx.x == 0) S.consumed = 0, S.ckready = 0, S.ckdone = 0;
+  __syncthreads();
 
-  // helper wave (set, h): set = processed-block parity it serves, h = which frames (j % 3 == h)
-  auto issue = [&](int kk, int h, float (&raw)[6]) {
-    const int k = dir == 0 ? kk : NB - 1 - kk;
-    const int t0 = k * kBlk, n = min(kBlk, T - t0);
+  if (wave >= 1 && wave <= kFHelpers) {
+    // ---------------------------------------------------------------- helpers
+    float lse_raw = 0.f;
+    auto issue = [&](int n, float (&raw)[kBlk]) {
+      const int k = dir == 0 ? n : NB - 1 - n;
+      const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int j = h + 3 * i;
-      const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
-      raw[i] = xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
-    }
-  };
-  auto stage = [&](int kk, int h, const float (&raw)[6]) {
-    const int k = dir == 0 ? kk : NB - 1 - kk;
-    const int n = min(kBlk, T - k * kBlk);
-    float xs[6];
-    float m = WFL_NEG_INF;
+      for (int j = 0; j < kBlk; ++j) {
+        const int t = dir == 0 ? t0 + j : t0 + cnt - 1 - j;
+        raw[j] = (WFL_DBG_FAST & 4) ? 0.01f * t : xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
+      }
+      if (LSM) {
+        const int t = dir == 0 ? t0 + (lane & 15) : t0 + cnt - 1 - (lane & 15);
+        lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
+      }
+    };
+    auto stage = [&](int n, const float (&raw)[kBlk]) {
+      const int k = dir == 0 ? n : NB - 1 - n;
+      const int cnt = min(kBlk, T - k * kBlk);
+      const int slot = n % kFSlots;
+      if (WFL_DBG_FAST & 2) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const float v = raw[i] * kLog2e;
-      xs[i] = (v == v) ? v : WFL_NEG_INF;  // NaN policy: impossible
-      if (h + 3 * i < n) m = vmax(m, xs[i]);
-    }
-    // ONE reference for the helper's frames of this block: its largest target-label emission
-    float rr = wave_all_max(m);
-    rr = (rr > -3.0e38f && rr < 3.0e38f) ? rintf(rr) : 0.f;
+        for (int j = 0; j < kBlk; ++j) S.ring[slot][j][lane] = make_float2(has_blank ? 0.4f : 0.f, has_label ? 0.4f + 0.001f * raw[j] : 0.f);
+        if (lane < kBlk) S.fref[slot][lane] = 0.f;
+        return;
+      }
+      float xs[kBlk];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int j = h + 3 * i;
-      if (j < kBlk) {
-        const float f = __builtin_amdgcn_exp2f(xs[i] - rr);
+      for (int j = 0; j < kBlk; ++j) {
+        const float v = (LSM ? raw[j] - readlane_f(lse_raw, j) : raw[j]) * kLog2e;
+        xs[j] = (v == v) ? v : WFL_NEG_INF;  // NaN policy: impossible
+      }
+      // reference of frame j: its largest target-label emission, rounded (all 16 wave maxima in one fold;
+      // lane j < 16 of every row ends up with frame j's)
+      const float m = fold16<true>(xs, lane);
+      const float rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        const float f = __builtin_amdgcn_exp2f(xs[j] - readlane_f(rr, j));
         const float fb = readlane_f(f, L);
-        ring[kk % kFRing][j][lane] = make_float2(has_blank ? fb : 0.f, has_label ? f : 0.f);
+        S.ring[slot][j][lane] = make_float2(has_blank ? fb : 0.f, has_label ? f : 0.f);
       }
+      if (lane < kBlk) S.fref[slot][lane] = lane < cnt ? rr : 0.f;
+    };
+    const int h = wave - 1;
+    float raw[kBlk];
+    if (h < NB) issue(h, raw);
+    for (int n = h; n < NB; n += kFHelpers) {
+      // slot n % kFSlots held block n - kFSlots: free once the chain has it in registers and the flusher
+      // has taken its references
+      while (n >= kFSlots && min(lds_peek(&S.consumed), lds_peek(&S.ckdone)) < n - kFSlots + 1) __builtin_amdgcn_s_sleep(2);
+      stage(n, raw);
+      lds_post(&S.staged[n % kFSlots], n + 1);
+      if (n + kFHelpers < NB) issue(n + kFHelpers, raw);
     }
-    if (lane < 6 && h + 3 * lane < kBlk) fref[kk % kFRing][h + 3 * lane] = (h + 3 * lane < n) ? rr : 0.f;
-  };
-  // wave 4 only takes part in the barriers (an attempt to keep the chain wave alone on its SIMD;
-  // measured: no effect)
-  const bool helper = wave >= 1 && wave != 4;
-  const int hset = wave >= 5 ? 1 : 0, hh = wave >= 5 ? wave - 5 : wave - 1;
-  float raw[6];
-  if (helper) {
-    if (hset < NB) {
-      issue(hset, hh, raw);
-      stage(hset, hh, raw);
-    }
-    if (hset + 2 < NB) issue(hset + 2, hh, raw);
-  }
-  __syncthreads();
-
-  float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
-  double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
-  double offcum = 0.0;  // wave 1: sum of r_t over the blocks already processed
-  float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
-  float pl = 0.f;
-  int e = 0;
-  float g = 0.f, gs = 0.f;
-  bool had = false, bad = false;
-  // per-lane power-of-two renormalisation, neighbour-gap clamp, coupling factors for the interval
-  auto lane_renorm = [&]() {
-    const float mx = vmax(pb, pl);
-    bad = bad || !(mx < 3.0e38f);
-    const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
-    pb = ldexpf(pb, -k);
-    pl = ldexpf(pl, -k);
-    const int own = mx > 0.f ? e + k : kEmptyE;
-    const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
-    const int sh = mx > 0.f ? pre - own : 0;                            // >= 0: pulled up by the clamp
-    pb = ldexpf(pb, -min(sh, 200));
-    pl = ldexpf(pl, -min(sh, 200));
-    e = pre;
-    const int d = wave_shr1_i(e, e) - e;  // <= kGap by construction
-    g = lane == 0 ? 0.f : ldexpf(1.f, max(d, -200));
-    gs = skip ? g : 0.f;
-    had = vmax(pb, pl) > 0.f;
-  };
-  auto frame = [&](const float2 f) {
-    const float q = wave_shr1(pl, 0.f);
-    const float tb = fmaf(q, g, pb);
-    const float tl = fmaf(q, gs, pl + pb);
-    pb = tb * f.x;
-    pl = tl * f.y;
-  };
-  auto flush_checkpoint = [&](int kk) {  // wave 1, one block behind the chain
-    if (lane < P) ck[(int64_t)kk * P + lane] = ckbuf[kk & 1][lane];
-    if (lane == 0) offs[kk] = offcum + (double)ckexp[kk & 1];
-    // advance the running offset over block kk
-    const float rj = lane < kBlk ? fref[kk % kFRing][lane] : 0.f;
-    offcum += (double)wave_all_sum(rj);
-  };
-  float2 fcur[kBlk], fnxt[kBlk];
-  if (wave == 0) {
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j) fcur[j] = ring[0][j][lane];
-  }
-  auto chain_block = [&](int kk) {
-    const int k = dir == 0 ? kk : NB - 1 - kk;
-    const int n = min(kBlk, T - k * kBlk);
-    if (kk + 1 < NB) {
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j) fnxt[j] = ring[(kk + 1) % kFRing][j][lane];
-    }
-    lane_renorm();
-    {  // checkpoint = state BEFORE this block, as base-2 logs relative to a wave-uniform exponent
-      const int emax = __builtin_amdgcn_readlane(wave_prefix_max_i(had ? e : kEmptyE), 63);
+  } else if (wave == kFHelpers + 1) {
+    // ---------------------------------------------------------------- flusher
+    float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
+    double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+    double offcum = 0.0;  // sum of r_t over the blocks before the checkpoint
+    for (int kk = 0; kk < NB; ++kk) {
+      while (lds_peek(&S.ckready) < kk + 1) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      const float2 m = S.ckm[kk % kFSlots][lane];
+      const int e = S.cke[kk % kFSlots][lane];
+      const float rj = lane < kBlk ? S.fref[kk % kFSlots][lane] : 0.f;
+      lds_post(&S.ckdone, kk + 1);
+      if (WFL_DBG_FAST & 8) continue;
+      // checkpoint = state BEFORE block kk, as base-2 logs relative to a wave-uniform exponent
+      const int emax = __builtin_amdgcn_readlane(wave_prefix_max_i(e), 63);
       const float de = (float)(e - emax);
-      const float lb = pb > 0.f ? __builtin_amdgcn_logf(pb) + de : kNegBig;
-      const float ll = pl > 0.f ? __builtin_amdgcn_logf(pl) + de : kNegBig;
-      ckbuf[kk & 1][lane] = make_float2(lb, ll);
-      if (lane == 0) ckexp[kk & 1] = emax > kEmptyE ? emax : 0;
+      const float lb = m.x > 0.f ? __builtin_amdgcn_logf(m.x) + de : kNegBig;
+      const float ll = m.y > 0.f ? __builtin_amdgcn_logf(m.y) + de : kNegBig;
+      if (lane < P) ck[(int64_t)kk * P + lane] = make_float2(lb, ll);
+      if (lane == 0) offs[kk] = offcum + (double)(emax > kEmptyE ? emax : 0);
+      offcum += (double)wave_all_sum(rj);
     }
-    if (n == kBlk) {
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j) frame(fcur[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j)
-        if (j < n) frame(fcur[j]);
+    if (lane == 0) S.offtot = offcum;
+  } else if (wave == 0) {
+    // ---------------------------------------------------------------- the chain
+    float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
+    float pl = 0.f;
+    int e = 0;
+    float g = 0.f, gs = 0.f;
+    bool had = false, bad = false;
+    // per-lane power-of-two renormalisation, neighbour-gap clamp, coupling factors for the interval
+    auto lane_renorm = [&]() {
+      const float mx = vmax(pb, pl);
+      bad = bad || !(mx < 3.0e38f);
+      const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
+      pb = ldexpf(pb, -k);
+      pl = ldexpf(pl, -k);
+      const int own = mx > 0.f ? e + k : kEmptyE;
+      const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
+      const int sh = mx > 0.f ? pre - own : 0;                            // >= 0: pulled up by the clamp
+      pb = ldexpf(pb, -min(sh, 200));
+      pl = ldexpf(pl, -min(sh, 200));
+      e = pre;
+      const int d = wave_shr1_i(e, e) - e;  // <= kGap by construction
+      g = lane == 0 ? 0.f : ldexpf(1.f, max(d, -200));
+      gs = skip ? g : 0.f;
+      had = vmax(pb, pl) > 0.f;
+    };
+    // pb' = fb (pb + g q), pl' = fl (pl + pb + gs q) with q = pl of lane i-1, arranged so that only TWO
+    // dependent instructions separate pl' from pl (the DPP multiply-add and the final fma): the products
+    // with pb and the coefficient products do not depend on the newest pl
+    auto frame = [&](const float2 f) {
+      const float c0 = f.x * g, c1 = f.y * gs;
+      float t0 = f.x * pb, t1 = f.y * pb;
+      fmac2_shr1(t0, t1, pl, c0, c1);
+      pl = fmaf(f.y, pl, t1);
+      pb = t0;
+    };
+    // Four frames in FIVE instructions each (the wave is issue-bound: ~4.5 cycles per VALU instruction whether
+    // dependent or not): packed multiplies for the two coefficient products and the two pb products, the two
+    // DPP multiply-adds, and the fma that adds fl * pl.  State pair P = (pb, pl) and the running pair t swap
+    // roles every frame; they are pinned to v[2:3] / v[4:5] because the template has to name their halves.
+    // The two packed multiplies between the write of pl and its DPP read are the required wait states.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+#define WFL_FRAME(P, PH, TT, TL, TH, F, FY)                                   \
+  "v_pk_mul_f32 v[6:7], " F ", %[G]\n\t"                                      \
+  "v_pk_mul_f32 " TT ", " F ", " P " op_sel_hi:[1,0]\n\t"                     \
+  "v_fmac_f32_dpp " TL ", " PH ", v6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp " TH ", " PH ", v7 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32 " TH ", " FY ", " PH "\n\t"
+    auto frames4 = [&](const float2& f0, const float2& f1, const float2& f2, const float2& f3) {
+      v2f P = {pb, pl};
+      const v2f G = {g, gs};
+      const v2f F0 = {f0.x, f0.y}, F1 = {f1.x, f1.y}, F2 = {f2.x, f2.y}, F3 = {f3.x, f3.y};
+      asm volatile(WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F0]", "%[Y0]")
+                   WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F1]", "%[Y1]")
+                   WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F2]", "%[Y2]")
+                   WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F3]", "%[Y3]")
+                   : "+{v[2:3]}"(P)
+                   : [G] "v"(G), [F0] "v"(F0), [F1] "v"(F1), [F2] "v"(F2), [F3] "v"(F3), [Y0] "v"(f0.y), [Y1] "v"(f1.y),
+                     [Y2] "v"(f2.y), [Y3] "v"(f3.y)
+                   : "v4", "v5", "v6", "v7");
+      pb = P.x;
+      pl = P.y;
+    };
+    float2 fa[kBlk], fb2[kBlk];  // two register sets, alternating: no copies between blocks
+    while (lds_peek(&S.staged[0]) != 1) {
     }
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < kBlk; ++j) fcur[j] = fnxt[j];
-  };
-  for (int kk = 0; kk < NB; ++kk) {
-    if (wave == 0) {
-      chain_block(kk);
-    } else if (helper) {
-      if (wave == 1 && kk > 0) flush_checkpoint(kk - 1);
-      if (hset == (kk & 1)) {  // block kk + 2 belongs to this set: gathers issued two iterations ago
-        if (kk + 2 < NB) stage(kk + 2, hh, raw);
-        if (kk + 4 < NB) issue(kk + 4, hh, raw);
+    for (int j = 0; j < kBlk; ++j) fa[j] = S.ring[0][j][lane];
+    int nflag = NB > 1 ? lds_peek(&S.staged[1]) : 0;  // looked at one block ahead of its use: off the dependent path
+    int done_seen = 0;
+    auto block = [&](int kk, const float2 (&fcur)[kBlk], float2 (&fnxt)[kBlk]) {
+      const int k = dir == 0 ? kk : NB - 1 - kk;
+      const int n = min(kBlk, T - k * kBlk);
+      lds_post(&S.consumed, kk + 1);
+      if (kk + 1 < NB) {
+        if (nflag != kk + 2)
+          while (lds_peek(&S.staged[(kk + 1) % kFSlots]) != kk + 2) {
+          }
+        asm volatile("" ::: "memory");
+        if (kk + 2 < NB) nflag = lds_peek(&S.staged[(kk + 2) % kFSlots]);
+        done_seen = lds_peek(&S.ckdone);
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) fnxt[j] = (WFL_DBG_FAST & 128) ? make_float2(0.4f + 0.01f * j, 0.5f) : S.ring[(kk + 1) % kFSlots][j][lane];
       }
+      if (!(WFL_DBG_FAST & 64)) lane_renorm();
+      if (kk >= kFSlots && done_seen < kk - kFSlots + 1)
+        while (lds_peek(&S.ckdone) < kk - kFSlots + 1) {
+        }
+      S.ckm[kk % kFSlots][lane] = make_float2(pb, pl);
+      S.cke[kk % kFSlots][lane] = had ? e : kEmptyE;
+      lds_post(&S.ckready, kk + 1);
+      if (WFL_DBG_FAST & 1) {
+        pb += fcur[0].x + fcur[15].y;
+      } else if (n == kBlk) {
+#pragma unroll
+        for (int j = 0; j < kBlk; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j)
+          if (j < n) frame(fcur[j]);
+      }
+    };
+    for (int kk = 0; kk < NB; kk += 2) {
+      block(kk, fa, fb2);
+      if (kk + 1 < NB) block(kk + 1, fb2, fa);
     }
-    __syncthreads();
-  }
-  if (wave == 1) {
-    flush_checkpoint(NB - 1);
-    if (lane == 0) offtot = offcum;
-  }
-  __syncthreads();
-  if (wave == 0) {
     lane_renorm();
+    __syncthreads();  // the flusher has summed all references
     if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = bad ? 1 : 0;
     if (dir == 0) {
       // Z = alpha_{T-1}[2L] + alpha_{T-1}[2L-1]   (ctc.py:21 accept states), lanes L and L-1
@@ -568,12 +695,19 @@ __global__ void __launch_bounds__(512) ctc_fast_chain_kernel(CtcArgs a) {
         const int em = max(zb > 0.f ? eb : kEmptyE, zl > 0.f ? el : kEmptyE);
         const float s = (zb > 0.f ? ldexpf(zb, max(eb - em, -200)) : 0.f) + (zl > 0.f ? ldexpf(zl, max(el - em, -200)) : 0.f);
         const bool ok = s > 0.f && s < 3.0e38f;
-        const double z2 = ok ? (double)__builtin_amdgcn_logf(s) + (double)em + offtot : -1.0e300;
+        const double z2 = ok ? (double)__builtin_amdgcn_logf(s) + (double)em + S.offtot : -1.0e300;
         ((double*)(a.ws + w.z2))[b] = z2;
         a.nll[b] = ok ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
       }
     }
+    return;
   }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(512) ctc_fast_chain_kernel(CtcArgs a) {
+  __shared__ FastLdsT S;
+  ctc_fast_chain_body<false>(a, blockIdx.x, blockIdx.y, S);
 }
 
 // certificate: one wave per (utterance, interior 16-frame boundary); 4 waves per workgroup
@@ -620,40 +754,6 @@ __global__ void __launch_bounds__(256) ctc_certify_kernel(CtcArgs a) {
 // ------------------------------------------------------------------------------------------------
 // gradient: one wave per (utterance, 16-frame block), 4 waves per workgroup
 // ------------------------------------------------------------------------------------------------
-// Sum 16 per-lane values over the 64 lanes at once: instead of 16 wave reductions (16 x 18 instructions)
-// the lanes fold the 16 values pairwise -- after the exchange with lane^1 a lane only keeps the 8
-// values whose index has its bit 0, after lane^2 four, ... -- so that lane l (l < 16, every row)
-// ends up with the 64-lane total of value l.  ~55 instructions.
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {  // quad_perm / row_ror moves, all lanes valid
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) {
-  float a[8], b[4], c[2];
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {  // partner lane^1: quad_perm [1,0,3,2]
-    const float keep = b0 ? v[2 * m + 1] : v[2 * m], send = b0 ? v[2 * m] : v[2 * m + 1];
-    a[m] = keep + dpp_quad<0xb1>(send);
-  }
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {  // partner lane^2: quad_perm [2,3,0,1]
-    const float keep = b1 ? a[2 * m + 1] : a[2 * m], send = b1 ? a[2 * m] : a[2 * m + 1];
-    b[m] = keep + dpp_quad<0x4e>(send);
-  }
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {  // partner lane^4 inside the row of 16: rotate by 4 or by 12
-    const float keep = b2 ? b[2 * m + 1] : b[2 * m], send = b2 ? b[2 * m] : b[2 * m + 1];
-    const float up = dpp_quad<0x124>(send), down = dpp_quad<0x12c>(send);  // row_ror:4 (from lane+12 = lane-4), row_ror:12 (from lane+4)
-    c[m] = keep + (b2 ? up : down);
-  }
-  const float keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
-  float t = keep + dpp_quad<0x128>(send);  // partner lane^8: row_ror:8
-  t += __shfl_xor(t, 16, 64);
-  t += __shfl_xor(t, 32, 64);
-  return t;
-}
-
 // Fused log_softmax backward, first half: rows[j*C + c] = -cf * softmax(x)[t0 + j, c] for the block's n
 // frames (contiguous in x).  Flat and vectorised, eight loads in flight per lane: the wave has
 // nothing else to hide the latency behind.  lse_blk: lane j < 16 holds the log-sum-exp of frame t0 + j.
@@ -1428,6 +1528,7 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
   } else {
     hipLaunchKernelGGL(ctc_fast_chain_kernel, dim3((unsigned)B, 2u), dim3(512), 0, (hipStream_t)stream, a);
     WFL_LAUNCH_CHECK();
+    if (WFL_DBG_FAST & 16) return WFL_OK;
     const int64_t items = (int64_t)B * std::max(ctc_blocks(T) - 1, 1);
     hipLaunchKernelGGL(ctc_certify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     WFL_LAUNCH_CHECK();
