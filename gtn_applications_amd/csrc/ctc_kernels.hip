@@ -36,6 +36,7 @@
 // ctc_fast_chain_kernel + ctc_certify_kernel are an experimental, opt-in replacement of the chain
 // (lane-exponent probability-domain arithmetic with a certificate and log-domain repair).
 #include <atomic>
+#include <string>
 
 #include "device_common.h"
 
@@ -73,7 +74,7 @@ __device__ __forceinline__ float to_score(float raw) {
 //   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
 // ------------------------------------------------------------------------------------------------
 struct CtcWs {
-  int64_t ck, off, z2, flag, pbad, ready, done, perr, total;
+  int64_t ck, off, z2, flag, pbad, ready, done, perr, zloc, total;
 };
 __host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
 __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
@@ -90,6 +91,7 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   w.ready = o, o += 2 * (int64_t)B * 2 * NB;  // uint64 ready[b][dir][block]: == the launch token once published
   w.done = o, o += 2 * (int64_t)B;            // uint64 done[b]: == the launch token once nll[b] is published
   w.perr = o, o += 2;                         // int32: a gradient wave of the pipelined step gave up waiting
+  w.zloc = o, o += 4 * (int64_t)B;            // int64 zloc[b][2]: min / max over the blocks of log2 Z (x 2^16) as their gradient waves reproduced it
   w.total = o + 2;
   return w;
 }
@@ -110,6 +112,91 @@ struct CtcArgs {
   const float* row_lse;
 };
 
+// ---- pieces shared by the chains of the pipelined launches -------------------------------------------
+__device__ __forceinline__ void coherent_store64(void* p, unsigned long long v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long coherent_load64(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double coherent_load_f64(const double* p) {
+  const unsigned long long bits = coherent_load64(p);
+  double v;
+  __builtin_memcpy(&v, &bits, 8);
+  return v;
+}
+
+// one lane: publish nll[b] (and, when a workgroup of this launch reduces the loss, the done flag)
+template <bool SIGNAL, bool REPAIR>
+__device__ __forceinline__ void publish_nll(const CtcArgs& a, const CtcWs& w, int b, bool alive, double z2) {
+  const float nllb = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
+  if (SIGNAL && (a.loss_out || REPAIR)) {  // device-coherently for the workgroup that reduces the loss
+    // (ONLY this store: a plain store to the same word first would leave a dirty non-coherent line in
+    // this XCD's L2 that the coherent store merges into instead of writing through -- measured: the
+    // reducer then read stale values)
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(a.nll + b), __float_as_uint(nllb), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store((unsigned long long*)(a.ws + w.done) + b, a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    a.nll[b] = nllb;
+  }
+}
+
+// The certificate of the fast pipelined launch, evaluated by the launch that follows it: every block's
+// gradient wave reproduced log2 Z from the two sweeps (sum_s alpha beta at its last frame) and folded it
+// into a per-utterance minimum / maximum (16.16 fixed point, device-scope atomics; initialised by the
+// utterance's alpha chain before it publishes its first checkpoint).  Pruning or overflow in the
+// lane-exponent chains breaks the agreement with the chain's own Z.
+constexpr long long kZDead = -(1ll << 62);
+__device__ __forceinline__ long long z_fixed(double z2) { return z2 > -1.0e299 ? (long long)llrint(z2 * 65536.0) : kZDead; }
+__device__ __forceinline__ bool utterance_rejected(const CtcArgs& a, const CtcWs& w, int u) {
+  const int32_t* pbad = (const int32_t*)(a.ws + w.pbad) + u * 2;
+  const double z2 = ((const double*)(a.ws + w.z2))[u];
+  const long long* zmm = (const long long*)(a.ws + w.zloc) + (int64_t)u * 2;
+  const long long zq = z_fixed(z2);
+  // 5e-4 in log2 units: a lost mass fraction of 3.5e-4.  The comparison itself is noisy at the 1e-4 level (fp32
+  // log-domain recompute at magnitudes of several hundred: measured 5e-5 median, 2e-4 maximum on well-represented data)
+  constexpr long long tol = 33;
+  return pbad[0] != 0 || pbad[1] != 0 || zq == kZDead || zmm[0] < zq - tol || zmm[1] > zq + tol;
+}
+__device__ __forceinline__ bool utterance_rejected_wave(const CtcArgs& a, const CtcWs& w, int u, int lane) {
+  (void)lane;
+  return utterance_rejected(a, w, u);  // (same words for every lane: wave-uniform)
+}
+
+// one wave: wait for the alpha chains that publish in this launch (all of them, or -- in the repair
+// launch -- the rejected utterances only; nothing to do if there are none), then reduce the loss in a
+// fixed order: mean_b(scale_b * nll_b), no extra launch, deterministic
+__device__ __forceinline__ void reduce_loss_when_done(const CtcArgs& a, const CtcWs& w, int lane, bool rejected_only) {
+  unsigned long long* done = (unsigned long long*)(a.ws + w.done);
+  bool any = false;
+  for (int u = lane; u < a.B; u += 64) any = any || !rejected_only || utterance_rejected(a, w, u);
+  if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+  float part = 0.f;
+  bool ok = true;
+  for (int u = lane; u < a.B; u += 64) {
+    if (!rejected_only || utterance_rejected(a, w, u)) {
+      bool seen = false;
+      for (int spin = 0; spin < (1 << 20) && !seen; ++spin) {
+        seen = __hip_atomic_load(done + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+        if (!seen) __builtin_amdgcn_s_sleep(16);
+      }
+      ok = ok && seen;
+      __hip_atomic_store(done + u, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sole consumer: clear
+    }
+    const float v = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(a.nll + u), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT));
+    part += (a.loss_scale ? a.loss_scale[u] : 1.f) * v;
+  }
+  const float total = wave_all_sum(part);  // fixed lane order
+  if (lane == 0 && a.loss_out) a.loss_out[0] = total / (float)a.B;
+  if (!ok) {
+    if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+    __builtin_trap();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // log-domain chains: grid (B, 2) x 128.  Wave 0 runs the dependent chain and nothing else; wave 1 (on another
 // SIMD of the same CU) feeds it: it gathers the emissions of block kk+2 from HBM, applies the scale /
@@ -128,7 +215,7 @@ struct ChainLdsT {
 // only_flagged != 0: repair pass -- run only for utterances whose fast-chain result was rejected.
 // SIGNAL: publish ready[b][dir][block] (agent-scope release) after each checkpoint reached HBM, for the
 // gradient waves of the pipelined step that are waiting for it.
-template <bool SIGNAL, bool LSM = false>
+template <bool SIGNAL, bool LSM = false, bool REPAIR = false>
 __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int dir, int only_flagged, ChainLdsT& S) {
   auto& ring = S.ring;
   auto& ckbuf = S.ckbuf;
@@ -290,46 +377,9 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       const bool alive = zr > 0.5f * kNegBig;
       const double z2 = alive ? (double)zr + off : -1.0e300;
       ((double*)(a.ws + w.z2))[b] = z2;
-      const float nllb = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
-      if (SIGNAL && a.loss_out) {  // publish nll[b] device-coherently for the workgroup that reduces the loss
-        // (ONLY this store: a plain store to the same word first would leave a dirty non-coherent line in
-        // this XCD's L2 that the coherent store merges into instead of writing through -- measured: the
-        // reducer then read stale values)
-        __hip_atomic_store(reinterpret_cast<unsigned int*>(a.nll + b), __float_as_uint(nllb), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __hip_atomic_store((unsigned long long*)(a.ws + w.done) + b, a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        a.nll[b] = nllb;
-      }
+      publish_nll<SIGNAL, REPAIR>(a, w, b, alive, z2);
     }
-    if (SIGNAL && a.loss_out && b == 0) {
-      // the alpha chain of utterance 0 waits for all the others (they finish within microseconds of each
-      // other) and reduces the loss in a fixed order: mean_b(scale_b * nll_b), no extra launch, deterministic
-      unsigned long long* done = (unsigned long long*)(a.ws + w.done);
-      float part = 0.f;
-      bool ok = true;
-      for (int u = lane; u < a.B; u += 64) {
-        bool seen = false;
-        for (int spin = 0; spin < (1 << 20) && !seen; ++spin) {
-          seen = __hip_atomic_load(done + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
-          if (!seen) __builtin_amdgcn_s_sleep(16);
-        }
-        ok = ok && seen;
-        __hip_atomic_store(done + u, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sole consumer: clear
-        const float v = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(a.nll + u),
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        part += (a.loss_scale ? a.loss_scale[u] : 1.f) * v;
-      }
-      const float total = wave_all_sum(part);  // fixed lane order
-      if (lane == 0) {
-        a.loss_out[0] = total / (float)a.B;
-      }
-      if (!ok) {
-        if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
-        __builtin_trap();
-      }
-    }
+    if (SIGNAL && !REPAIR && a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
   }
 }
 
@@ -480,7 +530,8 @@ __device__ __forceinline__ void lds_post(int* p, int v) {
 // the log2 format of the gradient kernel.
 template <bool SIGNAL, bool LSM = false>
 __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int dir, FastLdsT& S) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave index as a scalar: block numbers, frame numbers and row addresses of the helpers then live in SGPRs)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int T = a.T, C = a.C, P = a.P;
   const int64_t o0 = a.offsets[b];
   const int L = (int)(a.offsets[b + 1] - o0);
@@ -494,6 +545,12 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   const int NB = ctc_blocks(T);
   if (!SIGNAL && dir == 0 && threadIdx.x == 0) ((int32_t*)(a.ws + w.flag))[b] = 0;
+  if (SIGNAL && dir == 0 && threadIdx.x == 0) {  // certificate accumulators (before the first checkpoint is published)
+    long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+    coherent_store64(zmm, (unsigned long long)(1ll << 62));
+    coherent_store64(zmm + 1, (unsigned long long)(-(1ll << 62) - 1));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  }
   if (threadIdx.x < kFSlots) S.staged[threadIdx.x] = 0;
   if (threadIdx.x == 0) S.consumed = 0, S.ckready = 0, S.ckdone = 0;
   __syncthreads();
@@ -557,6 +614,8 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
     // ---------------------------------------------------------------- flusher
     float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
     double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+    unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
+    constexpr int kLag = 8;  // checkpoints between a store and the flag that vouches for it (3 * kLag <= 63: vmcnt is 6 bits)
     double offcum = 0.0;  // sum of r_t over the blocks before the checkpoint
     for (int kk = 0; kk < NB; ++kk) {
       while (lds_peek(&S.ckready) < kk + 1) __builtin_amdgcn_s_sleep(1);
@@ -571,13 +630,41 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       const float de = (float)(e - emax);
       const float lb = m.x > 0.f ? __builtin_amdgcn_logf(m.x) + de : kNegBig;
       const float ll = m.y > 0.f ? __builtin_amdgcn_logf(m.y) + de : kNegBig;
-      if (lane < P) ck[(int64_t)kk * P + lane] = make_float2(lb, ll);
-      if (lane == 0) offs[kk] = offcum + (double)(emax > kEmptyE ? emax : 0);
+      const double offk = offcum + (double)(emax > kEmptyE ? emax : 0);
+      if (!SIGNAL) {
+        if (lane < P) ck[(int64_t)kk * P + lane] = make_float2(lb, ll);
+        if (lane == 0) offs[kk] = offk;
+      } else {
+        // Device-coherent stores (see ctc_log_chain_body), but this wave cannot afford to wait for the
+        // acknowledgement of every checkpoint: a block of the fast chain is shorter than a store round
+        // trip.  The flag of checkpoint kk - kLag is raised once everything older than the last
+        // 3 * kLag vector-memory instructions has been acknowledged (stores are acknowledged in issue
+        // order; EXACTLY three are issued per iteration -- before the first kLag iterations the third one
+        // writes "not ready" to the block's own flag).
+        const float2 v = make_float2(lb, ll);
+        unsigned long long bits, obits;
+        __builtin_memcpy(&bits, &v, 8);
+        __builtin_memcpy(&obits, &offk, 8);
+        float2* dst = &ck[(int64_t)kk * P + lane];
+        if (lane < P) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(bits) : "memory");
+        if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(&offs[kk]), "v"(obits) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kLag) : "memory");
+        const int pub = kk - kLag;
+        unsigned long long* fl = &ready[pub >= 0 ? pub : kk];
+        const unsigned long long val = pub >= 0 ? a.token : 0ull;
+        if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(fl), "v"(val) : "memory");
+      }
       offcum += (double)wave_all_sum(rj);
+    }
+    if (SIGNAL) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        for (int kk = max(NB - kLag, 0); kk < NB; ++kk) coherent_store64(&ready[kk], a.token);
     }
     if (lane == 0) S.offtot = offcum;
   } else if (wave == 0) {
     // ---------------------------------------------------------------- the chain
+    __builtin_amdgcn_s_setprio(3);  // issue-bound: wins the arbitration against the helper wave on its SIMD
     float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
     float pl = 0.f;
     int e = 0;
@@ -697,8 +784,9 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
         const bool ok = s > 0.f && s < 3.0e38f;
         const double z2 = ok ? (double)__builtin_amdgcn_logf(s) + (double)em + S.offtot : -1.0e300;
         ((double*)(a.ws + w.z2))[b] = z2;
-        a.nll[b] = ok ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
+        publish_nll<SIGNAL, false>(a, w, b, ok, z2);
       }
+      if (SIGNAL && a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
     }
     return;
   }
@@ -805,7 +893,7 @@ __device__ __forceinline__ void lsm_seed_rows(float* rows, const float* __restri
 // workgroups of the same launch, and normalise the posteriors by the Z the block itself reproduces
 // (sum_s alpha(s) beta(s) at its last frame; the certificate's identity) instead of the log Z that the
 // alpha chain only knows when it has finished.
-template <bool PIPE, bool LSM = false>
+template <bool PIPE, bool LSM = false, bool CERT = false>
 __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
                                               const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -927,6 +1015,15 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
         U = -(m + __builtin_amdgcn_logf(ssum));
       else
         U = kNegBig;  // no accepting path through this block: every posterior is 2^-huge = 0
+      if (CERT && lane == 0) {  // log2 Z as this block reproduced it, for the certificate of the fast chains
+        const double zk = U > 0.5f * kNegBig
+                              ? coherent_load_f64(&offa[k]) + coherent_load_f64(&offb[NB - 1 - k]) - (double)U
+                              : -1.0e300;
+        long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+        const long long zq = z_fixed(zk);
+        __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     float gbv[kBlk];
 #pragma unroll
@@ -999,8 +1096,10 @@ __global__ void __launch_bounds__(256)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nchain = 2 * a.B;
   if ((int)blockIdx.x < nchain) {
-    if (blockIdx.x == 0 && threadIdx.x == 0)  // (a gradient wave gives up only after ~1 s of polling)
-      *(int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr) = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (a gradient wave gives up only after ~1 s of polling)
+      int32_t* perr = (int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr);
+      perr[0] = 0, perr[1] = 0;
+    }
     if (threadIdx.x < 64)  // the dependent chain (and its feeders) go first on their SIMDs
       __builtin_amdgcn_s_setprio(3);
     else
@@ -1014,6 +1113,69 @@ __global__ void __launch_bounds__(256)
   const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;  // r: rank in readiness order
   const int mid = (NB - 1) / 2;
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+  ctc_grad_body<true, LSM>(a, valid, b, k, coef, gout, dx, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST pipelined step: the same single launch with the lane-exponent chains (8 waves per workgroup:
+// gradient workgroups carry 8 blocks), followed by ctc_repair_kernel.  The gradient waves reproduce
+// log2 Z per block (zloc); the repair launch evaluates that certificate and re-runs rejected
+// utterances -- chains and gradient -- in the log domain.  On data the fast chains can represent the
+// repair launch exits at once.
+// ------------------------------------------------------------------------------------------------
+template <bool LSM>
+__global__ void __launch_bounds__(512)
+    ctc_fast_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
+                              float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nchain = 2 * a.B;
+  if ((int)blockIdx.x < nchain) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      int32_t* perr = (int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr);
+      perr[0] = 0;  // a gradient wave gave up waiting
+      perr[1] = 0;  // utterances the repair launch recomputed
+    }
+    if (threadIdx.x >= 64) __builtin_amdgcn_s_setprio(2);  // (the chain wave raises itself to 3)
+    ctc_fast_chain_body<true, LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<FastLdsT*>(smem));
+    return;
+  }
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)(blockIdx.x - nchain) * 8 + (threadIdx.x >> 6);
+  const bool valid = item < (int64_t)a.B * NB;
+  const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;  // r: rank in readiness order
+  const int mid = (NB - 1) / 2;
+  const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+  ctc_grad_body<true, LSM, true>(a, valid, b, k, coef, gout, dx, smem);
+}
+
+template <bool LSM>
+__global__ void __launch_bounds__(256)
+    ctc_repair_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const CtcWs w = ctc_ws_layout(a.B, a.T, a.P);
+  const int nchain = 2 * a.B;
+  if ((int)blockIdx.x < nchain) {
+    const int b = (int)blockIdx.x >> 1, dir = (int)blockIdx.x & 1;
+    if (utterance_rejected_wave(a, w, b, lane)) {  // (uniform over the workgroup: every wave evaluates it)
+      if (dir == 0 && threadIdx.x == 0) atomicAdd((int32_t*)(a.ws + w.perr) + 1, 1);
+      if (threadIdx.x < 64)
+        __builtin_amdgcn_s_setprio(3);
+      else
+        __builtin_amdgcn_s_setprio(2);
+      ctc_log_chain_body<true, LSM, true>(a, b, dir, 0, *reinterpret_cast<ChainLdsT*>(smem));
+    }
+    // the loss of the fast launch stands unless an utterance was repaired
+    if (blockIdx.x == 0 && threadIdx.x < 64 && a.loss_out) reduce_loss_when_done(a, w, lane, true);
+    return;
+  }
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)(blockIdx.x - nchain) * 4 + (threadIdx.x >> 6);
+  bool valid = item < (int64_t)a.B * NB;
+  const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;
+  const int mid = (NB - 1) / 2;
+  const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+  valid = valid && utterance_rejected_wave(a, w, b, lane);
   ctc_grad_body<true, LSM>(a, valid, b, k, coef, gout, dx, smem);
 }
 
@@ -1440,7 +1602,10 @@ __global__ void __launch_bounds__(256)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nchain = 2 * a.B;
   if ((int)blockIdx.x < nchain) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *(int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr) = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      int32_t* perr = (int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr);
+      perr[0] = 0, perr[1] = 0;
+    }
     if (threadIdx.x < 64)
       __builtin_amdgcn_s_setprio(3);
     else
@@ -1569,7 +1734,28 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     return WFL_OK;
   };
   int rc = WFL_OK;
-  if (ppl == 1) {
+  // lane-exponent chains + certificate + repair launch: when the 8-wave gradient workgroups fit the LDS
+  // (WFL_CTC_PIPELINE=log selects the log-domain chains)
+  static const bool force_log = [] {
+    const char* e = getenv("WFL_CTC_PIPELINE");
+    return e && std::string(e) == "log";
+  }();
+  const size_t rows8_lds = (size_t)8 * (kBlk + 1) * C * 4;
+  if (ppl == 1 && !force_log && rows8_lds <= (size_t)kLdsBytes) {
+    const size_t lds = std::max(rows8_lds, sizeof(FastLdsT));
+    const dim3 grid8((unsigned)(2 * B + (items + 7) / 8));
+    auto launch_fast = [&](auto kern) -> int {
+      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid8, dim3(512), lds, (hipStream_t)stream, a, coef, gout, dx);
+      return WFL_OK;
+    };
+    rc = row_lse ? launch_fast(ctc_fast_pipelined_kernel<true>) : launch_fast(ctc_fast_pipelined_kernel<false>);
+    if (rc) return rc;
+    WFL_LAUNCH_CHECK();
+    a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
+    if (a.token == 0) a.token = 1;
+    rc = row_lse ? launch(ctc_repair_kernel<true>, sizeof(ChainLdsT)) : launch(ctc_repair_kernel<false>, sizeof(ChainLdsT));
+  } else if (ppl == 1) {
     rc = row_lse ? launch(ctc_pipelined_kernel<true>, sizeof(ChainLdsT))
                  : launch(ctc_pipelined_kernel<false>, sizeof(ChainLdsT));
   } else {

@@ -411,6 +411,18 @@ def ctc_pipeline_gave_up(ws, B, T, max_len):
     return bool(ws[o:o + 1].view(torch.int32).item())
 
 
+def ctc_pipeline_repaired(ws, B, T, max_len):
+    """Number of utterances of the last pipelined step whose lane-exponent chains failed the certificate
+    and were recomputed in the log domain by the repair launch (diagnostics; 0 on the log-domain step)."""
+    P, nb = max_len + 1, (T + 15) // 16
+    o = B * 2 * nb * P * 2
+    o = (o + 1) & ~1
+    o += 2 * B * 2 * nb + 2 * B + B + 2 * B
+    o = (o + 1) & ~1
+    o += 2 * B * 2 * nb + 2 * B
+    return int(ws[o + 1:o + 2].view(torch.int32).item())
+
+
 def ctc_grad(x, tg, blank, ws, nll, coef, gout, dx):
     B, T, C = x.shape
     N.check(

@@ -225,7 +225,9 @@ def test_ctc_pipelined_step_matches_split_step_and_oracle():
         dx2 = torch.full_like(xt, float("nan"))
         ws2, nll2 = E.ctc_forward(xt, tg, C - 1)
         E.ctc_grad(xt, tg, C - 1, ws2, nll2, coef, gout, dx2)
-        assert torch.equal(nll, nll2)
+        # (the pipelined step runs the lane-exponent chains, the split step the log-domain ones)
+        assert torch.equal(torch.isfinite(nll), torch.isfinite(nll2))
+        assert torch.allclose(torch.nan_to_num(nll, posinf=0.0), torch.nan_to_num(nll2, posinf=0.0), rtol=1e-5, atol=1e-4)
         fin = np.isfinite(nll.cpu().numpy())
         wl, _ = OR.ctc_loss_grad(x[fin], [t for t, f in zip(targets, fin) if f], C - 1, "none")
         assert float(nll[torch.from_numpy(fin).cuda()].mean()) == pytest.approx(wl, rel=RTOL)
@@ -252,7 +254,8 @@ def test_ctc_pipelined_step_at_baseline_size_and_under_graph_replay():
     ws2, nll2 = E.ctc_forward_backward(x, tg, C - 1, coef, gout, dx_pipe)
     torch.cuda.synchronize()
     assert not E.ctc_pipeline_gave_up(ws2, B, T, tg.max_len)
-    assert torch.equal(nll, nll2)
+    assert E.ctc_pipeline_repaired(ws2, B, T, tg.max_len) == 0  # benchmark data: served by the lane-exponent chains
+    assert torch.allclose(nll, nll2, rtol=1e-5, atol=1e-4)  # (log-domain chains vs lane-exponent chains)
     np.testing.assert_allclose(dx_pipe.cpu().numpy(), dx_split.cpu().numpy(), rtol=2e-3, atol=2e-8)
     np.testing.assert_allclose(dx_pipe.sum(dim=2).cpu().numpy(), coef.cpu().numpy()[:, None] * np.ones((1, T)), rtol=1e-4)
     graph = torch.cuda.CUDAGraph()
@@ -269,7 +272,7 @@ def test_ctc_pipelined_step_at_baseline_size_and_under_graph_replay():
         graph.replay()
         torch.cuda.synchronize()
         assert not E.ctc_pipeline_gave_up(ws_g, B, T, tg.max_len)
-        assert torch.equal(dx_g, dx_pipe) and torch.equal(nll_g, nll)
+        assert torch.equal(dx_g, dx_pipe) and torch.equal(nll_g, nll2)
 
 
 def test_ctc_pipelined_step_more_chains_than_workgroup_slots():
@@ -291,8 +294,9 @@ def test_ctc_pipelined_step_more_chains_than_workgroup_slots():
     ws2, nll2, loss = E.ctc_forward_backward(x, tg, C - 1, coef, gout, dx_pipe, loss_scale=scale, want_loss=True)
     torch.cuda.synchronize()
     assert not E.ctc_pipeline_gave_up(ws2, B, T, tg.max_len)
-    assert torch.equal(nll, nll2)
-    assert float(loss) == pytest.approx(float((scale * nll).mean()), rel=1e-6)
+    assert E.ctc_pipeline_repaired(ws2, B, T, tg.max_len) == 0
+    assert torch.allclose(nll, nll2, rtol=1e-5, atol=1e-4)
+    assert float(loss) == pytest.approx(float((scale * nll2).mean()), rel=1e-6)
     np.testing.assert_allclose(dx_pipe.cpu().numpy(), dx_split.cpu().numpy(), rtol=2e-3, atol=1e-9)
 
 
@@ -318,9 +322,10 @@ def test_ctc_pipelined_step_stress_fresh_data_same_buffers():
         ref = E.reduce_loss(nll, scale, 1.0)
         torch.cuda.synchronize()
         assert not E.ctc_pipeline_gave_up(ws2, B, T, tg.max_len), it
-        assert torch.equal(nll, nll2), it
-        assert torch.allclose(loss, ref, rtol=1e-6), (it, float(loss), float(ref))
-        np.testing.assert_allclose(dx_pipe.cpu().numpy(), dx_split.cpu().numpy(), rtol=2e-3, atol=1e-9, err_msg=str(it))
+        assert torch.allclose(nll, nll2, rtol=1e-5, atol=1e-4), it
+        assert torch.allclose(loss, ref, rtol=1e-5), (it, float(loss), float(ref))
+        # (1e-4 of the gradient's scale |coef| = 1/B: the parity bar; the lane-exponent chains prune mass below that)
+        np.testing.assert_allclose(dx_pipe.cpu().numpy(), dx_split.cpu().numpy(), rtol=2e-3, atol=1e-4 / B, err_msg=str(it))
         del x, dx_pipe, dx_split, ws, ws2, nll, nll2, loss
 
 
