@@ -452,7 +452,7 @@ __device__ __forceinline__ void fmac2_shr1(float& acc0, float& acc1, float src, 
   asm volatile(
       "s_nop 1\n\tv_fmac_f32_dpp %0, %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
       "v_fmac_f32_dpp %1, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf"
-      : "+v"(acc0), "+v"(acc1)
+      : "+&v"(acc0), "+&v"(acc1)
       : "v"(src), "v"(c0), "v"(c1));
 }
 
@@ -1070,6 +1070,228 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
   }
 }
 
+// acc += lane[i+1].s0 * c0 + lane[i+1].s1 * c1 (lane 63: unchanged)
+__device__ __forceinline__ void fmac2_shl1(float& acc, float s0, float s1, float c0, float c1) {
+  asm volatile(
+      "s_nop 1\n\tv_fmac_f32_dpp %0, %1, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %2, %4 wave_shl:1 row_mask:0xf bank_mask:0xf"
+      : "+&v"(acc)  // (early clobber: acc starts as a copy of s1 and must not share its register)
+      : "v"(s0), "v"(s1), "v"(c0), "v"(c1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradient of one 16-frame block in lane-exponent arithmetic (the fast pipelined launch).  The
+// log-domain block (ctc_grad_body) costs ~2500 instructions, 160 of them transcendentals, and the
+// gradient part of the launch is bound by VALU issue; here the two sweeps are multiply-adds like the
+// chain's (the block is exactly what the chain runs between two of its renormalisations: same
+// per-lane exponents with the same neighbour clamp, same per-frame references, same growth bound).
+// Everything that does not depend on the checkpoints -- gathers, references, the 16 exp2 per lane --
+// is done BEFORE the wave starts waiting for them.
+//   alpha_j(s) = ma_j(s) 2^ea(s), beta~_j(s) = mb_j(s) 2^eb(s), exponents fixed over the block;
+//   Z_local = sum_s alpha_{n-1}(s) [A beta~_n](s)  (relative to the checkpoints' offsets and the
+//   block's references); posterior = ma mb' K(s) with K(s) = 2^(ea + eb - E) / Zm folded into ma.
+// ------------------------------------------------------------------------------------------------
+template <bool LSM, bool CERT>
+__device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
+                                                   const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
+  const int NB = ctc_blocks(T);
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  if (!valid) return;  // (uniform over the wave)
+  float* rows = (float*)smem + (size_t)wave * (kBlk + 1) * C;  // [16][C] gradient rows + [C] label counts, per wave
+  int* cnt = (int*)(rows + (size_t)kBlk * C);
+  const int t0 = k * kBlk, n = min(kBlk, T - t0);
+  const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+  float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
+  for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;  // (int 0 == float 0 bit pattern)
+  if (LSM) {
+    lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
+    lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf, lane);
+  }
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  const int y = lane < L ? a.targets[o0 + lane] : -1;
+  const int yprev = (lane >= 1 && lane - 1 < L) ? a.targets[o0 + lane - 1] : -1;
+  const int ynext = lane + 1 < L ? a.targets[o0 + lane + 1] : -1;
+  const bool has_label = lane < L;
+  const bool skip = has_label && lane >= 1 && y != yprev;  // label i-1 -> label i
+  const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
+  const int col = has_label ? y : a.blank;
+  const float* xrow = a.x + (int64_t)b * T * C;
+  if (has_label) atomicAdd(&cnt[y], 1);  // (see ctc_grad_body: labels that occur once own their gradient column)
+  const bool dup = has_label && (cnt[y] > 1 || y == a.blank);
+  const bool uniq = has_label && !dup;
+
+  // ---- emission factors of the block's frames: f = 2^(x log2e - r_j), r_j = round(largest target-label score)
+  float fl[kBlk], fb[kBlk];
+  float rsum;
+  {
+    float xs[kBlk];
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) xs[j] = xrow[(int64_t)min(t0 + j, T - 1) * C + col];  // all 16 gathers in flight
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const float v = (LSM ? xs[j] - readlane_f(lse_blk, j) : xs[j]) * kLog2e;
+      xs[j] = (v == v && j < n) ? v : WFL_NEG_INF;  // NaN policy: impossible
+    }
+    const float m = fold16<true>(xs, lane);  // lane j < 16 (every row): the maximum of frame j
+    const float rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const float f = __builtin_amdgcn_exp2f(xs[j] - readlane_f(rr, j));
+      fb[j] = readlane_f(f, L);
+      fl[j] = has_label ? f : 0.f;
+    }
+    rsum = wave_all_sum(lane < n ? rr : 0.f);
+  }
+
+  // ---- wait for alpha checkpoint k and beta checkpoint NB-1-k (see ctc_grad_body)
+  {
+    const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
+    const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 20); ++spin) {  // (bounded: a lost signal must not hang the GPU)
+      ok = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
+           __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(64);
+    }
+    if (!ok) {
+      if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+      __builtin_trap();
+    }
+  }
+  const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
+  const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
+  const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
+  const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
+  auto load_ck = [&](const float2* p) {
+    const unsigned long long bits = coherent_load64(p);
+    float2 v;
+    __builtin_memcpy(&v, &bits, 8);
+    return v;
+  };
+  // (mirrored lanes of the beta sweep: blank state 2i <-> reversed position L-i; label of position i <-> L-1-i)
+  const float2 ca = lane < P ? load_ck(&cka[(int64_t)k * P + lane]) : make_float2(kNegBig, kNegBig);
+  const float cbb = lane <= L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - lane)]).x : kNegBig;
+  const float cbl = lane < L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)]).y : kNegBig;
+  double off_sum = 0.0;
+  if (CERT && lane == 0) off_sum = coherent_load_f64(&offa[k]) + coherent_load_f64(&offb[NB - 1 - k]);
+  if (lane == 0) {  // this wave was the only consumer of the two flags: leave them cleared
+    unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
+    coherent_store64(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull);
+    coherent_store64(rdy + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k), 0ull);
+  }
+
+  // ---- per-lane exponents (neighbour-gap clamp as in the chain), mantissas, coupling factors
+  const float ma = vmax(ca.x, ca.y), mbt = vmax(cbb, cbl);
+  int ea = ma > 0.5f * kNegBig ? (int)floorf(ma) + 1 : kEmptyE;
+  ea = wave_prefix_max_i(ea + kGap * lane) - kGap * lane;  // ea[i] >= ea[i-1] - kGap
+  int eb = mbt > 0.5f * kNegBig ? (int)floorf(mbt) + 1 : kEmptyE;
+  {  // eb[i] >= eb[i+1] - kGap: the same scan on the reversed lanes
+    int er = __shfl(eb, 63 - lane, 64);
+    er = wave_prefix_max_i(er + kGap * lane) - kGap * lane;
+    eb = __shfl(er, 63 - lane, 64);
+  }
+  float pb = __builtin_amdgcn_exp2f(ca.x - (float)ea), pl = __builtin_amdgcn_exp2f(ca.y - (float)ea);
+  float bb = __builtin_amdgcn_exp2f(cbb - (float)eb), bl = __builtin_amdgcn_exp2f(cbl - (float)eb);
+  const int ea_prev = wave_shr1_i(ea, ea);  // (taken unconditionally: inside the ?: the DPP would run with lane 0 masked off)
+  const float g = lane == 0 ? 0.f : ldexpf(1.f, max(ea_prev - ea, -200));
+  const float gs = skip ? g : 0.f;
+  const int eb_next = __builtin_amdgcn_update_dpp(eb, eb, 0x130, 0xf, 0xf, false);  // wave_shl:1 (lane 63: own)
+  const float h = lane == 63 ? 0.f : ldexpf(1.f, max(eb_next - eb, -200));
+  const float hs = skipn ? h : 0.f;
+
+  // ---- alpha forward through the block, kept in registers
+  float pa_b[kBlk], pa_l[kBlk];
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    if (j < n) {
+      const float c0 = fb[j] * g, c1 = fl[j] * gs;
+      float u0 = fb[j] * pb, u1 = fl[j] * pb;
+      fmac2_shr1(u0, u1, pl, c0, c1);
+      pl = fmaf(fl[j], pl, u1);
+      pb = u0;
+    }
+    pa_b[j] = pb, pa_l[j] = pl;
+  }
+  // ---- local Z at the block's last frame
+  float K = 0.f;
+  bool alive;
+  double zk;  // (lane 0) log2 Z as this block reproduces it
+  {
+    const float tb0 = bb + bl;
+    float tl0 = bl;
+    fmac2_shl1(tl0, bb, bl, h, hs);
+    const float v = pb * tb0 + pl * tl0;  // (pb, pl): alpha of frame n-1
+    const int sx = ea + eb;
+    const int own = v > 0.f ? sx + __builtin_amdgcn_frexp_expf(v) : kEmptyE;
+    const int E = __builtin_amdgcn_readlane(wave_prefix_max_i(own), 63);
+    const float term = v > 0.f ? ldexpf(v, max(sx - E, -200)) : 0.f;
+    const float Zm = wave_all_sum(term);
+    alive = Zm > 0.f && Zm < 3.0e38f && E > kEmptyE;
+#if WFL_DBG_FAST & 256
+    if (b == 0 && k == 0 && lane < 4)
+      printf("lane %d ca %g %g cb %g %g ea %d eb %d pb %g pl %g bb %g bl %g g %g h %g tb0 %g tl0 %g v %g sx %d own %d E %d term %g Zm %g rsum %g off %g\n",
+             lane, ca.x, ca.y, cbb, cbl, ea, eb, pb, pl, bb, bl, g, h, tb0, tl0, v, sx, own, E, term, Zm, rsum, off_sum);
+#endif
+    // (exponent clamped from above too: a lane whose alpha beta is ~0 at the last frame may sit far above E;
+    // if that distorts a posterior that matters, the per-frame sum check below rejects the block)
+    if (alive) K = cf * ldexpf(1.f / Zm, min(max(sx - E, -200), 100));
+    zk = alive ? off_sum + (double)E + (double)__builtin_amdgcn_logf(Zm) + (double)rsum : -1.0e300;
+  }
+  // ---- beta backwards (forward lane mapping), posteriors, gradient rows
+  float gbv[kBlk], gsv[kBlk];
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) gbv[j] = 0.f, gsv[j] = 0.f;
+#pragma unroll
+  for (int j = kBlk - 1; j >= 0; --j) {
+    if (j < n) {
+      // blank i -> blank i, label i.  label i -> label i, blank i+1 (and label i+1 if allowed)
+      const float tb = bb + bl;
+      float tl = bl;
+      fmac2_shl1(tl, bb, bl, h, hs);
+      const float gb = pa_b[j] * K * tb;
+      const float gl = pa_l[j] * K * tl;
+      gbv[j] = gb;
+      gsv[j] = gb + gl;
+      if (uniq) rows[j * C + y] = (LSM ? rows[j * C + y] : 0.f) + gl;  // sole writer of this column
+      if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl);
+      bb = tb * fb[j];
+      bl = tl * fl[j];
+    }
+  }
+  const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
+  if (lane < n && gtot != 0.f) atomicAdd(&rows[lane * C + a.blank], gtot);
+  if (CERT) {
+    // certificate, part two: the posteriors of EVERY frame of the block must sum to one (the exponents are fixed
+    // over the block; an occupancy that moves by more than the float range within 16 frames shows here), part
+    // one: the block's log2 Z for the comparison with the chain's
+    const float stot = fold16_sum(gsv, lane);
+    const bool off = alive && lane < n && !(fabsf(stot - cf) <= 1e-3f * fabsf(cf));
+    const bool bad_block = __builtin_amdgcn_ballot_w64(off) != 0;
+    if (lane == 0) {
+      long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+      const long long zq = bad_block ? kZDead : z_fixed(zk);
+      __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (LSM && !alive)  // no accepting path: zero gradient, softmax term included
+    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+  // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
+  float* dst = dx + ((int64_t)b * T + t0) * C;
+  const int total = n * C;
+  if ((((uintptr_t)dst) & 15) == 0) {
+    const int n4 = total >> 2;
+    for (int i = lane; i < n4; i += 64) ((float4*)dst)[i] = ((const float4*)rows)[i];
+    for (int i = (n4 << 2) + lane; i < total; i += 64) dst[i] = rows[i];
+  } else {
+    for (int i = lane; i < total; i += 64) dst[i] = rows[i];
+  }
+}
+
 __global__ void __launch_bounds__(256)
     ctc_grad_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1145,7 +1367,7 @@ __global__ void __launch_bounds__(512)
   const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;  // r: rank in readiness order
   const int mid = (NB - 1) / 2;
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-  ctc_grad_body<true, LSM, true>(a, valid, b, k, coef, gout, dx, smem);
+  ctc_fast_grad_body<LSM, true>(a, valid, b, k, coef, gout, dx, smem);
 }
 
 template <bool LSM>
@@ -1743,7 +1965,8 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   const size_t rows8_lds = (size_t)8 * (kBlk + 1) * C * 4;
   if (ppl == 1 && !force_log && rows8_lds <= (size_t)kLdsBytes) {
     const size_t lds = std::max(rows8_lds, sizeof(FastLdsT));
-    const dim3 grid8((unsigned)(2 * B + (items + 7) / 8));
+    static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)
+    const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : (items + 7) / 8)));
     auto launch_fast = [&](auto kern) -> int {
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid8, dim3(512), lds, (hipStream_t)stream, a, coef, gout, dx);
