@@ -74,7 +74,7 @@ __device__ __forceinline__ float to_score(float raw) {
 //   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
 // ------------------------------------------------------------------------------------------------
 struct CtcWs {
-  int64_t ck, off, z2, flag, pbad, ready, done, perr, zloc, total;
+  int64_t ck, off, z2, flag, pbad, ready, done, perr, zloc, total, dbg;
 };
 __host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
 __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
@@ -92,6 +92,10 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   w.done = o, o += 2 * (int64_t)B;            // uint64 done[b]: == the launch token once nll[b] is published
   w.perr = o, o += 2;                         // int32: a gradient wave of the pipelined step gave up waiting
   w.zloc = o, o += 4 * (int64_t)B;            // int64 zloc[b][2]: min / max over the blocks of log2 Z (x 2^16) as their gradient waves reproduced it
+#if WFL_DBG_FAST & 512
+  o = (o + 1) & ~1ll;
+  w.dbg = o, o += 2 * 4 * ((int64_t)B * NB + 2 * B);  // int64 [item][4] timestamps (scratch/timeline_fast.py)
+#endif
   w.total = o + 2;
   return w;
 }
@@ -497,13 +501,17 @@ __device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) { re
 #define WFL_DBG_FAST 0  // scratch/chain_harness.cpp: bit 0 no frames, 1 no staging math, 2 no gathers, 3 idle flusher, 4 chain launch only
 #endif
 constexpr int kFHelpers = 6;  // waves 1..6 stage emission factors (whole blocks, round robin); wave 7 flushes checkpoints
-constexpr int kFSlots = 8;    // LDS ring depth in blocks (factors and checkpoint hand-off)
+constexpr int kFWaves = kFHelpers + 2;  // workgroup of the fast kernels.  (Measured: 3 helpers / 5 waves keep up as well, but
+                                        // 5-wave workgroups do not spread evenly over the 4 SIMDs and no more of them become
+                                        // resident: same 61 us for the pipelined launch.)
+constexpr int kFSlots = kFHelpers + 2;  // LDS ring depth in blocks (factors): the chain reads block kk+1 while the helpers stage the next ones
+constexpr int kCkSlots = 8;   // depth of the checkpoint hand-off (and of the per-frame references the flusher sums)
 
 struct FastLdsT {
   float2 ring[kFSlots][kBlk][64];  // (fb, fl) per frame and lane: 64 KiB
-  float fref[kFSlots][kBlk];       // per-frame reference r_t (integer valued)
-  float2 ckm[kFSlots][64];         // checkpoint hand-off chain wave -> flusher: mantissas ...
-  int cke[kFSlots][64];            // ... and per-lane exponents
+  float fref[kCkSlots][kBlk];      // per-frame reference r_t (integer valued)
+  float2 ckm[kCkSlots][64];        // checkpoint hand-off chain wave -> flusher: mantissas ...
+  int cke[kCkSlots][64];           // ... and per-lane exponents
   int staged[kFSlots];             // == n + 1 once block n sits in slot n % kFSlots
   int consumed;                    // blocks the chain wave has loaded into registers
   int ckready;                     // checkpoints handed over
@@ -578,7 +586,7 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       if (WFL_DBG_FAST & 2) {
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) S.ring[slot][j][lane] = make_float2(has_blank ? 0.4f : 0.f, has_label ? 0.4f + 0.001f * raw[j] : 0.f);
-        if (lane < kBlk) S.fref[slot][lane] = 0.f;
+        if (lane < kBlk) S.fref[n % kCkSlots][lane] = 0.f;
         return;
       }
       float xs[kBlk];
@@ -597,7 +605,7 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
         const float fb = readlane_f(f, L);
         S.ring[slot][j][lane] = make_float2(has_blank ? fb : 0.f, has_label ? f : 0.f);
       }
-      if (lane < kBlk) S.fref[slot][lane] = lane < cnt ? rr : 0.f;
+      if (lane < kBlk) S.fref[n % kCkSlots][lane] = lane < cnt ? rr : 0.f;
     };
     const int h = wave - 1;
     float raw[kBlk];
@@ -605,7 +613,8 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
     for (int n = h; n < NB; n += kFHelpers) {
       // slot n % kFSlots held block n - kFSlots: free once the chain has it in registers and the flusher
       // has taken its references
-      while (n >= kFSlots && min(lds_peek(&S.consumed), lds_peek(&S.ckdone)) < n - kFSlots + 1) __builtin_amdgcn_s_sleep(2);
+      while ((n >= kFSlots && lds_peek(&S.consumed) < n - kFSlots + 1) || (n >= kCkSlots && lds_peek(&S.ckdone) < n - kCkSlots + 1))
+        __builtin_amdgcn_s_sleep(1);
       stage(n, raw);
       lds_post(&S.staged[n % kFSlots], n + 1);
       if (n + kFHelpers < NB) issue(n + kFHelpers, raw);
@@ -615,14 +624,14 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
     float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
     double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
     unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
-    constexpr int kLag = 8;  // checkpoints between a store and the flag that vouches for it (3 * kLag <= 63: vmcnt is 6 bits)
+    constexpr int kLag = 4;  // checkpoints between a store and the flag that vouches for it (3 * kLag <= 63: vmcnt is 6 bits)
     double offcum = 0.0;  // sum of r_t over the blocks before the checkpoint
     for (int kk = 0; kk < NB; ++kk) {
       while (lds_peek(&S.ckready) < kk + 1) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
-      const float2 m = S.ckm[kk % kFSlots][lane];
-      const int e = S.cke[kk % kFSlots][lane];
-      const float rj = lane < kBlk ? S.fref[kk % kFSlots][lane] : 0.f;
+      const float2 m = S.ckm[kk % kCkSlots][lane];
+      const int e = S.cke[kk % kCkSlots][lane];
+      const float rj = lane < kBlk ? S.fref[kk % kCkSlots][lane] : 0.f;
       lds_post(&S.ckdone, kk + 1);
       if (WFL_DBG_FAST & 8) continue;
       // checkpoint = state BEFORE block kk, as base-2 logs relative to a wave-uniform exponent
@@ -665,6 +674,10 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
   } else if (wave == 0) {
     // ---------------------------------------------------------------- the chain
     __builtin_amdgcn_s_setprio(3);  // issue-bound: wins the arbitration against the helper wave on its SIMD
+#if WFL_DBG_FAST & 512
+    long long* dbgc = (long long*)(a.ws + w.dbg) + ((int64_t)a.B * NB + b * 2 + dir) * 4;
+    if (SIGNAL && lane == 0) dbgc[0] = wall_clock64();
+#endif
     float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
     float pl = 0.f;
     int e = 0;
@@ -748,11 +761,11 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
         for (int j = 0; j < kBlk; ++j) fnxt[j] = (WFL_DBG_FAST & 128) ? make_float2(0.4f + 0.01f * j, 0.5f) : S.ring[(kk + 1) % kFSlots][j][lane];
       }
       if (!(WFL_DBG_FAST & 64)) lane_renorm();
-      if (kk >= kFSlots && done_seen < kk - kFSlots + 1)
-        while (lds_peek(&S.ckdone) < kk - kFSlots + 1) {
+      if (kk >= kCkSlots && done_seen < kk - kCkSlots + 1)
+        while (lds_peek(&S.ckdone) < kk - kCkSlots + 1) {
         }
-      S.ckm[kk % kFSlots][lane] = make_float2(pb, pl);
-      S.cke[kk % kFSlots][lane] = had ? e : kEmptyE;
+      S.ckm[kk % kCkSlots][lane] = make_float2(pb, pl);
+      S.cke[kk % kCkSlots][lane] = had ? e : kEmptyE;
       lds_post(&S.ckready, kk + 1);
       if (WFL_DBG_FAST & 1) {
         pb += fcur[0].x + fcur[15].y;
@@ -770,6 +783,9 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       if (kk + 1 < NB) block(kk + 1, fb2, fa);
     }
     lane_renorm();
+#if WFL_DBG_FAST & 512
+    if (SIGNAL && lane == 0) dbgc[1] = wall_clock64();
+#endif
     __syncthreads();  // the flusher has summed all references
     if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = bad ? 1 : 0;
     if (dir == 0) {
@@ -793,7 +809,7 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(512) ctc_fast_chain_kernel(CtcArgs a) {
+__global__ void __launch_bounds__(kFWaves * 64) ctc_fast_chain_kernel(CtcArgs a) {
   __shared__ FastLdsT S;
   ctc_fast_chain_body<false>(a, blockIdx.x, blockIdx.y, S);
 }
@@ -1099,6 +1115,10 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   const int NB = ctc_blocks(T);
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   if (!valid) return;  // (uniform over the wave)
+#if WFL_DBG_FAST & 512
+  long long* dbg = (long long*)(a.ws + w.dbg) + ((int64_t)b * NB + k) * 4;
+  if (lane == 0) dbg[0] = wall_clock64();
+#endif
   float* rows = (float*)smem + (size_t)wave * (kBlk + 1) * C;  // [16][C] gradient rows + [C] label counts, per wave
   int* cnt = (int*)(rows + (size_t)kBlk * C);
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
@@ -1155,13 +1175,16 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
       ok = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
            __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
       if (ok) break;
-      __builtin_amdgcn_s_sleep(64);
+      __builtin_amdgcn_s_sleep(16);
     }
     if (!ok) {
       if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
       __builtin_trap();
     }
   }
+#if WFL_DBG_FAST & 512
+  if (lane == 0) dbg[1] = wall_clock64();
+#endif
   const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
   const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
   const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
@@ -1290,6 +1313,9 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   } else {
     for (int i = lane; i < total; i += 64) dst[i] = rows[i];
   }
+#if WFL_DBG_FAST & 512
+  if (lane == 0) dbg[2] = wall_clock64();
+#endif
 }
 
 __global__ void __launch_bounds__(256)
@@ -1346,7 +1372,7 @@ __global__ void __launch_bounds__(256)
 // repair launch exits at once.
 // ------------------------------------------------------------------------------------------------
 template <bool LSM>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(kFWaves * 64)
     ctc_fast_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
                               float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1362,13 +1388,24 @@ __global__ void __launch_bounds__(512)
     return;
   }
   const int NB = ctc_blocks(a.T);
-  const int64_t item = (int64_t)(blockIdx.x - nchain) * 8 + (threadIdx.x >> 6);
+  const int64_t item = (int64_t)(blockIdx.x - nchain) * kFWaves + (threadIdx.x >> 6);
   const bool valid = item < (int64_t)a.B * NB;
   const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;  // r: rank in readiness order
   const int mid = (NB - 1) / 2;
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
   ctc_fast_grad_body<LSM, true>(a, valid, b, k, coef, gout, dx, smem);
 }
+
+#ifdef WFL_DBG_GRADONLY  // (register counts of the two halves alone: hipcc -S -DWFL_DBG_GRADONLY)
+__global__ void __launch_bounds__(kFWaves * 64) dbg_fast_chain_only(CtcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ctc_fast_chain_body<true, false>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<FastLdsT*>(smem));
+}
+__global__ void __launch_bounds__(kFWaves * 64) dbg_fast_grad_only(CtcArgs a, const float* coef, const float* gout, float* dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ctc_fast_grad_body<false, true>(a, true, (int)blockIdx.x, (int)blockIdx.y, coef, gout, dx, smem);
+}
+#endif
 
 template <bool LSM>
 __global__ void __launch_bounds__(256)
@@ -1913,7 +1950,7 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
   } else if (!(flags & WFL_CTC_FAST_CHAIN)) {
     hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 0);
   } else {
-    hipLaunchKernelGGL(ctc_fast_chain_kernel, dim3((unsigned)B, 2u), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ctc_fast_chain_kernel, dim3((unsigned)B, 2u), dim3(kFWaves * 64), 0, (hipStream_t)stream, a);
     WFL_LAUNCH_CHECK();
     if (WFL_DBG_FAST & 16) return WFL_OK;
     const int64_t items = (int64_t)B * std::max(ctc_blocks(T) - 1, 1);
@@ -1962,14 +1999,14 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     const char* e = getenv("WFL_CTC_PIPELINE");
     return e && std::string(e) == "log";
   }();
-  const size_t rows8_lds = (size_t)8 * (kBlk + 1) * C * 4;
+  const size_t rows8_lds = (size_t)kFWaves * (kBlk + 1) * C * 4;
   if (ppl == 1 && !force_log && rows8_lds <= (size_t)kLdsBytes) {
     const size_t lds = std::max(rows8_lds, sizeof(FastLdsT));
     static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)
-    const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : (items + 7) / 8)));
+    const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : (items + kFWaves - 1) / kFWaves)));
     auto launch_fast = [&](auto kern) -> int {
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, grid8, dim3(512), lds, (hipStream_t)stream, a, coef, gout, dx);
+      hipLaunchKernelGGL(kern, grid8, dim3(kFWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
       return WFL_OK;
     };
     rc = row_lse ? launch_fast(ctc_fast_pipelined_kernel<true>) : launch_fast(ctc_fast_pipelined_kernel<false>);
