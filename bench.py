@@ -101,13 +101,16 @@ def make_ctc(args, rank, mode):
 
     from gtn_applications_amd import _native as N
     chain_flags = {"default": E.CTC_DEFAULT_FLAGS, "log": 0, "fast": N.CTC_FAST_CHAIN}[args.ctc_chain]
+    last = [None]
     if mode == "abi" and args.ctc_step == "pipelined":
         def step(events=None):
             mark(events)
             # chains + gradient waves + loss reduction, one launch
-            E.ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=scale, want_loss=True)
+            last[0] = E.ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=scale, want_loss=True)
             mark(events)
-        phases = ["ctc_pipelined_kernel"]
+        # (the event bracket holds both launches of the step: lane-exponent pipelined launch + certificate / repair launch)
+        phases = ["ctc_fast_pipelined_kernel (+ctc_repair_kernel)" if os.environ.get("WFL_CTC_PIPELINE") != "log" and C <= 300
+                  else "ctc_pipelined_kernel"]
     elif mode == "abi":
         def step(events=None):
             mark(events)
@@ -126,8 +129,11 @@ def make_ctc(args, rank, mode):
         phases = []
     which = {(1000, 100, 128, 44): " (BASELINE configs[1])", (2000, 512, 128, 44): " (BASELINE configs[4], one GPU's shard)",
              (150, 28, 8, 44): " (BASELINE configs[0])"}.get((T, C, B, L), "")
+    def repaired():  # utterances of the last step that the certificate sent to the log-domain repair launch
+        return E.ctc_pipeline_repaired(last[0][0], B, T, tg.max_len) if last[0] is not None else None
+
     meta = dict(
-        workload=f"ctc fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L,
+        workload=f"ctc fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L, repaired=repaired,
         algorithmic_bytes_per_utt=8 * T * C,
     )
     return step, phases, meta, (x, targets, blank)
@@ -292,6 +298,8 @@ def main():
                    "global_batch": B * world, "parallelism": f"dp{world} (utterance shards, no data-path collective)"
                    if args.workload == "ctc" else f"dp{world} (all-reduce of transition grads)"},
     }
+    if callable(meta.get("repaired")):
+        out["config"]["utterances_repaired_in_log_domain"] = meta["repaired"]()
     alg_bytes = meta["algorithmic_bytes_per_utt"] * B  # per launch: every launch processes the whole batch
     if events:
         per = len(phases) + 1
