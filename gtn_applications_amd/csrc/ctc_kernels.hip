@@ -74,7 +74,7 @@ __device__ __forceinline__ float to_score(float raw) {
 //   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
 // ------------------------------------------------------------------------------------------------
 struct CtcWs {
-  int64_t ck, off, z2, flag, pbad, ready, done, perr, zloc, total, dbg;
+  int64_t ck, off, z2, flag, pbad, ready, done, perr, dup, zloc, total, dbg;
 };
 __host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
 __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
@@ -91,6 +91,7 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   w.ready = o, o += 2 * (int64_t)B * 2 * NB;  // uint64 ready[b][dir][block]: == the launch token once published
   w.done = o, o += 2 * (int64_t)B;            // uint64 done[b]: == the launch token once nll[b] is published
   w.perr = o, o += 2;                         // int32: a gradient wave of the pipelined step gave up waiting
+  w.dup = o, o += 2 * (int64_t)B;             // uint64 dup[b]: bit i = target label i also occurs elsewhere in the target (or is the blank)
   w.zloc = o, o += 4 * (int64_t)B;            // int64 zloc[b][2]: min / max over the blocks of log2 Z (x 2^16) as their gradient waves reproduced it
 #if WFL_DBG_FAST & 512
   o = (o + 1) & ~1ll;
@@ -500,15 +501,16 @@ __device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) { re
 #ifndef WFL_DBG_FAST
 #define WFL_DBG_FAST 0  // scratch/chain_harness.cpp: bit 0 no frames, 1 no staging math, 2 no gathers, 3 idle flusher, 4 chain launch only
 #endif
-constexpr int kFHelpers = 6;  // waves 1..6 stage emission factors (whole blocks, round robin); wave 7 flushes checkpoints
-constexpr int kFWaves = kFHelpers + 2;  // workgroup of the fast kernels.  (Measured: 3 helpers / 5 waves keep up as well, but
-                                        // 5-wave workgroups do not spread evenly over the 4 SIMDs and no more of them become
-                                        // resident: same 61 us for the pipelined launch.)
-constexpr int kFSlots = kFHelpers + 2;  // LDS ring depth in blocks (factors): the chain reads block kk+1 while the helpers stage the next ones
+constexpr int kFHelpers = 4;  // waves 1..4 stage emission factors (whole blocks, round robin); wave 5 flushes checkpoints
+constexpr int kFWaves = 8;    // workgroup of the fast kernels (waves 6, 7 of a chain workgroup leave at once).  Workgroup
+                              // shapes that are not a multiple of 4 waves do not spread evenly over the SIMDs (measured with
+                              // 5 waves: no additional workgroup became resident).
+constexpr int kFSlots = kFHelpers + 1;  // LDS ring depth in blocks (factors): the chain reads block kk+1 while the helpers stage
+                                        // kk+2 .. ; 40 KiB -- with the 51 KB of gradient rows at C = 100 three workgroups share a CU
 constexpr int kCkSlots = 8;   // depth of the checkpoint hand-off (and of the per-frame references the flusher sums)
 
 struct FastLdsT {
-  float2 ring[kFSlots][kBlk][64];  // (fb, fl) per frame and lane: 64 KiB
+  float2 ring[kFSlots][kBlk][64];  // (fb, fl) per frame and lane: 40 KiB
   float fref[kCkSlots][kBlk];      // per-frame reference r_t (integer valued)
   float2 ckm[kCkSlots][64];        // checkpoint hand-off chain wave -> flusher: mantissas ...
   int cke[kCkSlots][64];           // ... and per-lane exponents
@@ -562,6 +564,7 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
   if (threadIdx.x < kFSlots) S.staged[threadIdx.x] = 0;
   if (threadIdx.x == 0) S.consumed = 0, S.ckready = 0, S.ckdone = 0;
   __syncthreads();
+  if (wave > kFHelpers + 1) return;  // (a wave that has ended no longer counts for the workgroup's barriers)
 
   if (wave >= 1 && wave <= kFHelpers) {
     // ---------------------------------------------------------------- helpers
@@ -626,6 +629,15 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
     unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
     constexpr int kLag = 4;  // checkpoints between a store and the flag that vouches for it (3 * kLag <= 63: vmcnt is 6 bits)
     double offcum = 0.0;  // sum of r_t over the blocks before the checkpoint
+    if (SIGNAL && dir == 0) {
+      // which target labels own their gradient column (occur once, are not the blank): one mask per utterance for
+      // all its gradient waves, stored before the first checkpoint (acknowledged before any flag is raised)
+      bool dupl = false;
+      for (int j = 0; j < L; ++j) dupl = dupl || (__builtin_amdgcn_readlane(y, j) == y && j != lane);
+      dupl = has_label && (dupl || y == a.blank);
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(dupl);
+      if (lane == 0) coherent_store64((unsigned long long*)(a.ws + w.dup) + b, mask);
+    }
     for (int kk = 0; kk < NB; ++kk) {
       while (lds_peek(&S.ckready) < kk + 1) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
@@ -738,49 +750,62 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       pb = P.x;
       pl = P.y;
     };
-    float2 fa[kBlk], fb2[kBlk];  // two register sets, alternating: no copies between blocks
+    // The factors travel ring -> registers in HALF blocks (two sets of 8 float2, alternating: no copies and half the
+    // registers of whole blocks -- the kernel's register count decides how many gradient workgroups share the CU).
+    constexpr int kHalf = kBlk / 2;
+    float2 ha[kHalf], hb[kHalf];
     while (lds_peek(&S.staged[0]) != 1) {
     }
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < kBlk; ++j) fa[j] = S.ring[0][j][lane];
+    for (int j = 0; j < kHalf; ++j) ha[j] = S.ring[0][j][lane];
     int nflag = NB > 1 ? lds_peek(&S.staged[1]) : 0;  // looked at one block ahead of its use: off the dependent path
     int done_seen = 0;
-    auto block = [&](int kk, const float2 (&fcur)[kBlk], float2 (&fnxt)[kBlk]) {
+    // q: half-block index (block q / 2, frames (q & 1) * 8 ...)
+    auto half = [&](int q, const float2 (&fcur)[kHalf], float2 (&fnxt)[kHalf]) {
+      const int kk = q >> 1, second = q & 1;
       const int k = dir == 0 ? kk : NB - 1 - kk;
-      const int n = min(kBlk, T - k * kBlk);
-      lds_post(&S.consumed, kk + 1);
-      if (kk + 1 < NB) {
-        if (nflag != kk + 2)
-          while (lds_peek(&S.staged[(kk + 1) % kFSlots]) != kk + 2) {
-          }
-        asm volatile("" ::: "memory");
-        if (kk + 2 < NB) nflag = lds_peek(&S.staged[(kk + 2) % kFSlots]);
-        done_seen = lds_peek(&S.ckdone);
+      const int n = min(kBlk, T - k * kBlk) - second * kHalf;  // frames of this half that exist (may be <= 0)
+      if (second) {
+        // the next half opens block kk + 1: it has to be staged
+        if (kk + 1 < NB) {
+          if (nflag != kk + 2)
+            while (lds_peek(&S.staged[(kk + 1) % kFSlots]) != kk + 2) {
+            }
+          asm volatile("" ::: "memory");
+          if (kk + 2 < NB) nflag = lds_peek(&S.staged[(kk + 2) % kFSlots]);
+          done_seen = lds_peek(&S.ckdone);
 #pragma unroll
-        for (int j = 0; j < kBlk; ++j) fnxt[j] = (WFL_DBG_FAST & 128) ? make_float2(0.4f + 0.01f * j, 0.5f) : S.ring[(kk + 1) % kFSlots][j][lane];
-      }
-      if (!(WFL_DBG_FAST & 64)) lane_renorm();
-      if (kk >= kCkSlots && done_seen < kk - kCkSlots + 1)
-        while (lds_peek(&S.ckdone) < kk - kCkSlots + 1) {
+          for (int j = 0; j < kHalf; ++j)
+            fnxt[j] = (WFL_DBG_FAST & 128) ? make_float2(0.4f + 0.01f * j, 0.5f) : S.ring[(kk + 1) % kFSlots][j][lane];
         }
-      S.ckm[kk % kCkSlots][lane] = make_float2(pb, pl);
-      S.cke[kk % kCkSlots][lane] = had ? e : kEmptyE;
-      lds_post(&S.ckready, kk + 1);
-      if (WFL_DBG_FAST & 1) {
-        pb += fcur[0].x + fcur[15].y;
-      } else if (n == kBlk) {
-#pragma unroll
-        for (int j = 0; j < kBlk; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
       } else {
 #pragma unroll
-        for (int j = 0; j < kBlk; ++j)
+        for (int j = 0; j < kHalf; ++j)
+          fnxt[j] = (WFL_DBG_FAST & 128) ? make_float2(0.4f + 0.01f * j, 0.5f) : S.ring[kk % kFSlots][kHalf + j][lane];
+        lds_post(&S.consumed, kk + 1);  // (after the reads were issued: LDS executes a wave's instructions in order)
+        if (!(WFL_DBG_FAST & 64)) lane_renorm();
+        if (kk >= kCkSlots && done_seen < kk - kCkSlots + 1)
+          while (lds_peek(&S.ckdone) < kk - kCkSlots + 1) {
+          }
+        S.ckm[kk % kCkSlots][lane] = make_float2(pb, pl);
+        S.cke[kk % kCkSlots][lane] = had ? e : kEmptyE;
+        lds_post(&S.ckready, kk + 1);
+      }
+      if (WFL_DBG_FAST & 1) {
+        pb += fcur[0].x + fcur[kHalf - 1].y;
+      } else if (n >= kHalf) {
+#pragma unroll
+        for (int j = 0; j < kHalf; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kHalf; ++j)
           if (j < n) frame(fcur[j]);
       }
     };
-    for (int kk = 0; kk < NB; kk += 2) {
-      block(kk, fa, fb2);
-      if (kk + 1 < NB) block(kk + 1, fb2, fa);
+    for (int kk = 0; kk < NB; ++kk) {
+      half(2 * kk, ha, hb);
+      half(2 * kk + 1, hb, ha);
     }
     lane_renorm();
 #if WFL_DBG_FAST & 512
@@ -1119,12 +1144,11 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   long long* dbg = (long long*)(a.ws + w.dbg) + ((int64_t)b * NB + k) * 4;
   if (lane == 0) dbg[0] = wall_clock64();
 #endif
-  float* rows = (float*)smem + (size_t)wave * (kBlk + 1) * C;  // [16][C] gradient rows + [C] label counts, per wave
-  int* cnt = (int*)(rows + (size_t)kBlk * C);
+  float* rows = (float*)smem + (size_t)wave * kBlk * C;  // [16][C] gradient rows, per wave
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
   const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
   float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
-  for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;  // (int 0 == float 0 bit pattern)
+  for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
   if (LSM) {
     lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
     lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf, lane);
@@ -1139,9 +1163,6 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
   const int col = has_label ? y : a.blank;
   const float* xrow = a.x + (int64_t)b * T * C;
-  if (has_label) atomicAdd(&cnt[y], 1);  // (see ctc_grad_body: labels that occur once own their gradient column)
-  const bool dup = has_label && (cnt[y] > 1 || y == a.blank);
-  const bool uniq = has_label && !dup;
 
   // ---- emission factors of the block's frames: f = 2^(x log2e - r_j), r_j = round(largest target-label score)
   float fl[kBlk], fb[kBlk];
@@ -1201,6 +1222,10 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   const float cbl = lane < L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)]).y : kNegBig;
   double off_sum = 0.0;
   if (CERT && lane == 0) off_sum = coherent_load_f64(&offa[k]) + coherent_load_f64(&offb[NB - 1 - k]);
+  // labels that occur once in the target (and are not the blank) own their gradient column: plain ds_write instead
+  // of ds_add_f32 (see ctc_grad_body); the mask was computed once per utterance by its alpha chain workgroup
+  const bool dup = has_label && ((coherent_load64((const unsigned long long*)(a.ws + w.dup) + b) >> lane) & 1ull) != 0;
+  const bool uniq = has_label && !dup;
   if (lane == 0) {  // this wave was the only consumer of the two flags: leave them cleared
     unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
     coherent_store64(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull);
@@ -1265,9 +1290,10 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
     zk = alive ? off_sum + (double)E + (double)__builtin_amdgcn_logf(Zm) + (double)rsum : -1.0e300;
   }
   // ---- beta backwards (forward lane mapping), posteriors, gradient rows
-  float gbv[kBlk], gsv[kBlk];
+  float gbv[kBlk];
+  float wsum = 0.f;  // sum_j w_j (gb + gl)[j], w_j = 1 + j / 32: the frames' posterior mass, weighted so that errors cannot cancel
 #pragma unroll
-  for (int j = 0; j < kBlk; ++j) gbv[j] = 0.f, gsv[j] = 0.f;
+  for (int j = 0; j < kBlk; ++j) gbv[j] = 0.f;
 #pragma unroll
   for (int j = kBlk - 1; j >= 0; --j) {
     if (j < n) {
@@ -1278,7 +1304,7 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
       const float gb = pa_b[j] * K * tb;
       const float gl = pa_l[j] * K * tl;
       gbv[j] = gb;
-      gsv[j] = gb + gl;
+      wsum = fmaf(gb + gl, 1.f + (float)j * (1.f / 32.f), wsum);
       if (uniq) rows[j * C + y] = (LSM ? rows[j * C + y] : 0.f) + gl;  // sole writer of this column
       if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl);
       bb = tb * fb[j];
@@ -1288,12 +1314,13 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
   if (lane < n && gtot != 0.f) atomicAdd(&rows[lane * C + a.blank], gtot);
   if (CERT) {
-    // certificate, part two: the posteriors of EVERY frame of the block must sum to one (the exponents are fixed
-    // over the block; an occupancy that moves by more than the float range within 16 frames shows here), part
-    // one: the block's log2 Z for the comparison with the chain's
-    const float stot = fold16_sum(gsv, lane);
-    const bool off = alive && lane < n && !(fabsf(stot - cf) <= 1e-3f * fabsf(cf));
-    const bool bad_block = __builtin_amdgcn_ballot_w64(off) != 0;
+    // certificate, part two: the posteriors of every frame of the block must sum to one (the exponents are fixed
+    // over the block; an occupancy that moves by more than the float range within 16 frames shows here; the
+    // frames are summed with distinct weights, one register instead of sixteen), part one: the block's log2 Z
+    // for the comparison with the chain's
+    const float stot = wave_all_sum(wsum);
+    const float want = cf * ((float)n + (float)(n * (n - 1)) * (1.f / 64.f));  // cf * sum_{j<n} w_j
+    const bool bad_block = alive && !(fabsf(stot - want) <= 1e-3f * fabsf(cf));
     if (lane == 0) {
       long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
       const long long zq = bad_block ? kZDead : z_fixed(zk);
@@ -1372,7 +1399,7 @@ __global__ void __launch_bounds__(256)
 // repair launch exits at once.
 // ------------------------------------------------------------------------------------------------
 template <bool LSM>
-__global__ void __launch_bounds__(kFWaves * 64)
+__global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_eu(6, 6)))  // <= 80 VGPRs: three workgroups per CU
     ctc_fast_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
                               float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1388,12 +1415,12 @@ __global__ void __launch_bounds__(kFWaves * 64)
     return;
   }
   const int NB = ctc_blocks(a.T);
-  const int64_t item = (int64_t)(blockIdx.x - nchain) * kFWaves + (threadIdx.x >> 6);
-  const bool valid = item < (int64_t)a.B * NB;
-  const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;  // r: rank in readiness order
+  const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - nchain) * kFWaves + (int)(threadIdx.x >> 6));
+  if (item >= a.B * NB) return;
+  const int r = item / a.B, b = item % a.B;  // r: rank in readiness order
   const int mid = (NB - 1) / 2;
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-  ctc_fast_grad_body<LSM, true>(a, valid, b, k, coef, gout, dx, smem);
+  ctc_fast_grad_body<LSM, true>(a, true, b, k, coef, gout, dx, smem);
 }
 
 #ifdef WFL_DBG_GRADONLY  // (register counts of the two halves alone: hipcc -S -DWFL_DBG_GRADONLY)
@@ -1999,7 +2026,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     const char* e = getenv("WFL_CTC_PIPELINE");
     return e && std::string(e) == "log";
   }();
-  const size_t rows8_lds = (size_t)kFWaves * (kBlk + 1) * C * 4;
+  const size_t rows8_lds = (size_t)kFWaves * kBlk * C * 4;
   if (ppl == 1 && !force_log && rows8_lds <= (size_t)kLdsBytes) {
     const size_t lds = std::max(rows8_lds, sizeof(FastLdsT));
     static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)

@@ -16,7 +16,7 @@ torch.cuda.synchronize()
 P, nb = tg.max_len + 1, (T + 15) // 16
 o = B * 2 * nb * P * 2; o = (o + 1) & ~1
 o += 2 * B * 2 * nb + 2 * B + B + 2 * B; o = (o + 1) & ~1
-o += 2 * B * 2 * nb + 2 * B + 2 + 4 * B; o = (o + 1) & ~1
+o += 2 * B * 2 * nb + 2 * B + 2 + 2 * B + 4 * B; o = (o + 1) & ~1
 d = ws[o:o + 2 * 4 * (B * nb + 2 * B)].view(torch.int64).cpu().numpy().reshape(-1, 4).astype(np.float64) / 100.0  # us (100 MHz)
 items, chains = d[:B * nb], d[B * nb:]
 t0 = min(items[:, 0].min(), chains[:, 0].min())
