@@ -30,11 +30,13 @@
 // drifting to O(T) (plain fp32 log-domain, which is what gtn.forward_score does, already loses the
 // 4th digit of the posteriors at T = 1000).
 //
-// Kernels: ctc_log_chain_kernel + ctc_grad_kernel (+ wfl_reduce_loss) are the three-launch step;
-// ctc_pipelined_kernel runs the same chain and gradient bodies in ONE launch, the gradient waves
-// waiting on device-coherent per-block flags while the chains sweep (the default training step).
-// ctc_fast_chain_kernel + ctc_certify_kernel are an experimental, opt-in replacement of the chain
-// (lane-exponent probability-domain arithmetic with a certificate and log-domain repair).
+// Kernels.  The training step (wfl_ctc_forward_backward) is ctc_fast_pipelined_kernel: chains and gradient in
+// ONE launch, the gradient waves waiting on device-coherent per-block flags while the chains sweep; its chains
+// and gradient blocks run in lane-exponent (probability-domain) arithmetic, every block certifies what it
+// computed, and ctc_repair_kernel re-runs rejected utterances with the log-domain bodies.  ctc_pipelined_kernel
+// is the same single launch with the log-domain bodies throughout (C > 300, WFL_CTC_PIPELINE=log, long targets).
+// ctc_log_chain_kernel + ctc_grad_kernel (+ wfl_reduce_loss) are the three-launch step behind
+// wfl_ctc_forward / wfl_ctc_grad; WFL_CTC_FAST_CHAIN selects ctc_fast_chain_kernel + ctc_certify_kernel there.
 #include <atomic>
 #include <string>
 
@@ -394,15 +396,16 @@ __global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST chains ("lane-exponent" arithmetic): grid (B, 2) x 512, opt-in with WFL_CTC_FAST_CHAIN.
+// FAST chains ("lane-exponent" arithmetic): the chains of ctc_fast_pipelined_kernel, and (grid (B, 2) x 512,
+// WFL_CTC_FAST_CHAIN) of the three-launch step.
 //
 // The log-domain frame is a chain of ~15 DEPENDENT instructions with 4 transcendentals (~155 cycles
 // for a lone wave).  Here a state is a float mantissa with an integer exponent PER LANE (shared by
 // the lane's blank / label pair): value = m * 2^(e_lane + off).  A frame is
-//     q = shr(pl);  tb = fma(q, g, pb);  tl = fma(q, gs, pl + pb);  pb = tb * fb;  pl = tl * fl
-// (6 VALU, no transcendental, dependent depth 3) with g = 2^(e[i-1] - e[i]) fixed for a 16-frame
-// block and emission factors f = 2^(x*log2e - r) <= 1 relative to a reference r (the largest
-// target-label emission among the frames a helper wave stages).  Once per block each lane
+//     pb' = fb (pb + g q),   pl' = fl (pl + pb + gs q),   q = pl of lane i-1
+// -- five instructions, no transcendental (see frames4) -- with g = 2^(e[i-1] - e[i]) fixed for a
+// 16-frame block and emission factors f = 2^(x*log2e - r_t) <= 2^0.5 relative to a per-FRAME reference
+// r_t (the rounded largest target-label score of the frame).  Once per block each lane
 // renormalises ITS OWN exponent, and a prefix-max scan enforces e[i] >= e[i-1] - kGap so that mass
 // flowing up the lanes cannot overflow inside a block (growth <= 2^(16*(kGap+1.6)) < 2^127); a lane
 // pulled up by the clamp only loses mass that is 2^-126 below what its predecessor is about to hand
@@ -412,20 +415,22 @@ __global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_
 // are flushed (measured); fp64 with a wave-uniform scale works but its dependent latency leaves the
 // chain at 47 us (measured; scratch/ctc_kernels_fp64_chain.hip.txt).
 //
-// Wave 0 runs the chain.  Waves 1-3 and 5-7 are helpers in two sets that alternate blocks; inside a set
-// each wave stages every third frame (gather, scale, NaN policy, wave maximum, exp2, blank
-// broadcast) into an LDS ring.  A helper issues the gathers of its next block right after staging
-// the current one, two chain blocks before they are consumed and with nothing newer in flight.
-// Wave 1 also writes the checkpoints out.  Round-1 status (measured at cfg2): chain wave alone 44 us,
-// helpers alone 42 us, together 59-62 us (+ 4.9 us certificate + the repair launch) against 68 us for
-// the log-domain chain: not yet a win, so it stays opt-in.  Checkpoints have the SAME format as the log-domain
-// chain's (base-2 logs relative to a double offset), so the gradient kernel does not care which
-// chain produced them.
+// A lone wave is ISSUE-bound, not latency-bound (measured: ~4.5 cycles per VALU instruction whether
+// dependent or not), so the design minimises the chain wave's instruction count: wave 0 runs the
+// chain and nothing else; waves 1..kFHelpers stage whole blocks of factors (gather, NaN policy, the 16
+// per-frame maxima in one fold, exp2, blank broadcast) into an LDS ring; wave kFHelpers+1 turns the raw
+// (mantissa, exponent) checkpoints into the log2 format of the gradient kernels and writes them out.
+// No barrier inside the sweep: the waves meet in LDS mailboxes (ds_write / ds_read of a wave execute in
+// order, so "data, then flag" needs no wait).  Measured at cfg2: 33.5 us for the sweep (grid (B, 2))
+// against 68 us for the log-domain chain; inside the pipelined launch 36-39 us.
 //
-// What cannot be represented is flushed to zero; ctc_certify_kernel then checks, at every 16-frame
-// boundary, that the two independently computed sweeps reproduce Z (|log2 sum_s alpha*beta~ - log2 Z|
-// < 1.5e-3) -- pruning that matters breaks this identity.  Rejected utterances are recomputed by
-// ctc_log_chain_kernel in the same forward call.
+// What cannot be represented is flushed to zero or overflows; the results are certified.  Three-launch
+// step: ctc_certify_kernel checks, at every 16-frame boundary, that the two independently computed sweeps
+// reproduce Z (|log2 sum_s alpha*beta~ - log2 Z| < 1.5e-3), rejected utterances are recomputed by
+// ctc_log_chain_kernel in the same forward call.  Pipelined step: every gradient block reproduces log2 Z and
+// checks that the posteriors of its frames sum to one (ctc_fast_grad_body); ctc_repair_kernel evaluates.
+// Checkpoints have the SAME format as the log-domain chain's (base-2 logs relative to a double offset), so
+// the gradient kernels do not care which chain produced them.
 // ------------------------------------------------------------------------------------------------
 constexpr int kGap = 5;       // max exponent drop from lane i-1 to lane i
 constexpr int kEmptyE = -(1 << 28);

@@ -255,16 +255,21 @@ int wfl_conv_grad(const float* x, int B, int T, int C, const int32_t* ktab, int 
  *   Base-2 log-domain arithmetic, block-renormalised; the chain stores one checkpoint per 16
  *   frames and the gradient kernel recomputes inside the blocks (csrc/ctc_kernels.hip).
  * ------------------------------------------------------------------------------------------------ */
-#define WFL_CTC_FAST_CHAIN 2 /* flags: experimental lane-exponent chain + certificate + log-domain repair */
+#define WFL_CTC_FAST_CHAIN 2 /* flags of wfl_ctc_forward: lane-exponent chains + certificate + log-domain repair */
 int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems);
 /* alpha and beta chains: writes nll[B] = -log Z_b and the 16-frame checkpoints into ws.
  * flags = 0: log-domain chain (default). */
 int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
                     const int64_t* offsets, int max_len, int blank, int flags, float* ws, float* nll,
                     void* stream);
-/* wfl_ctc_forward (log-domain chain) and wfl_ctc_grad as ONE pipelined launch: gradient waves wait
- * for the checkpoints they need and run while the chains are still sweeping.  Same outputs (nll,
- * dx); posteriors are normalised per 16-frame block by the Z the block reproduces.  If loss_out is
+/* wfl_ctc_forward and wfl_ctc_grad as ONE pipelined launch: gradient waves wait for the checkpoints
+ * they need and run while the chains are still sweeping.  Same outputs (nll, dx); posteriors are
+ * normalised per 16-frame block by the Z the block reproduces.
+ * Targets of up to 63 labels with C <= 300: chains and gradient blocks run in lane-exponent
+ * (probability-domain) arithmetic; every block certifies its result (log2 Z reproduced to 5e-4, the
+ * posteriors of its frames sum to one to 1e-3) and a second, normally empty launch recomputes rejected
+ * utterances in the log domain -- the caller always receives certified or log-domain results.
+ * WFL_CTC_PIPELINE=log in the environment selects the log-domain launch throughout.  If loss_out is
  * not NULL it also receives mean_b(loss_scale[b] * nll[b]) (ctc.py:68-69; loss_scale NULL = 1),
  * reduced in a fixed order by the last chain to finish -- no separate wfl_reduce_loss launch.
  * If row_lse is not NULL, x holds RAW scores and row_lse[b*T + t] their log-sum-exp over the classes
