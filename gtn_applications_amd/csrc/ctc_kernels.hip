@@ -39,6 +39,7 @@
 // wfl_ctc_forward / wfl_ctc_grad; WFL_CTC_FAST_CHAIN selects ctc_fast_chain_kernel + ctc_certify_kernel there.
 #include <atomic>
 #include <string>
+#include <type_traits>
 
 #include "device_common.h"
 
@@ -705,13 +706,11 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       const float mx = vmax(pb, pl);
       bad = bad || !(mx < 3.0e38f);
       const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
-      pb = ldexpf(pb, -k);
-      pl = ldexpf(pl, -k);
       const int own = mx > 0.f ? e + k : kEmptyE;
       const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
       const int sh = mx > 0.f ? pre - own : 0;                            // >= 0: pulled up by the clamp
-      pb = ldexpf(pb, -min(sh, 200));
-      pl = ldexpf(pl, -min(sh, 200));
+      pb = ldexpf(pb, -(k + min(sh, 200)));  // (mantissa to [0.5, 1), then down by the clamp: one scaling)
+      pl = ldexpf(pl, -(k + min(sh, 200)));
       e = pre;
       const int d = wave_shr1_i(e, e) - e;  // <= kGap by construction
       g = lane == 0 ? 0.f : ldexpf(1.f, max(d, -200));
@@ -767,18 +766,21 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
     int nflag = NB > 1 ? lds_peek(&S.staged[1]) : 0;  // looked at one block ahead of its use: off the dependent path
     int done_seen = 0;
     // q: half-block index (block q / 2, frames (q & 1) * 8 ...)
-    auto half = [&](int q, const float2 (&fcur)[kHalf], float2 (&fnxt)[kHalf]) {
+    // STEADY: an interior block (complete, followed by another one) -- the bulk of the sweep runs without the
+    // boundary tests (a uniform branch costs the lone wave more than an arithmetic instruction)
+    auto half = [&](int q, const float2 (&fcur)[kHalf], float2 (&fnxt)[kHalf], auto steady) {
+      constexpr bool STEADY = decltype(steady)::value;
       const int kk = q >> 1, second = q & 1;
       const int k = dir == 0 ? kk : NB - 1 - kk;
-      const int n = min(kBlk, T - k * kBlk) - second * kHalf;  // frames of this half that exist (may be <= 0)
+      const int n = STEADY ? kHalf : min(kBlk, T - k * kBlk) - second * kHalf;  // frames of this half that exist (may be <= 0)
       if (second) {
         // the next half opens block kk + 1: it has to be staged
-        if (kk + 1 < NB) {
+        if (STEADY || kk + 1 < NB) {
           if (nflag != kk + 2)
             while (lds_peek(&S.staged[(kk + 1) % kFSlots]) != kk + 2) {
             }
           asm volatile("" ::: "memory");
-          if (kk + 2 < NB) nflag = lds_peek(&S.staged[(kk + 2) % kFSlots]);
+          if (STEADY || kk + 2 < NB) nflag = lds_peek(&S.staged[(kk + 2) % kFSlots]);
           done_seen = lds_peek(&S.ckdone);
 #pragma unroll
           for (int j = 0; j < kHalf; ++j)
@@ -808,9 +810,18 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
           if (j < n) frame(fcur[j]);
       }
     };
-    for (int kk = 0; kk < NB; ++kk) {
-      half(2 * kk, ha, hb);
-      half(2 * kk + 1, hb, ha);
+    {
+      half(0, ha, hb, std::false_type{});
+      half(1, hb, ha, std::false_type{});
+      int kk = 1;
+      for (; kk + 2 < NB; ++kk) {  // blocks 1 .. NB-3: complete for both directions, two more blocks follow
+        half(2 * kk, ha, hb, std::true_type{});
+        half(2 * kk + 1, hb, ha, std::true_type{});
+      }
+      for (; kk < NB; ++kk) {
+        half(2 * kk, ha, hb, std::false_type{});
+        half(2 * kk + 1, hb, ha, std::false_type{});
+      }
     }
     lane_renorm();
 #if WFL_DBG_FAST & 512
