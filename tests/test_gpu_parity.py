@@ -329,6 +329,52 @@ def test_ctc_pipelined_step_stress_fresh_data_same_buffers():
         del x, dx_pipe, dx_split, ws, ws2, nll, nll2, loss
 
 
+def test_ctc_fast_pipelined_step_random_shapes():
+    """lane-exponent pipelined step (with and without the fused log_softmax) against the three-launch log-domain
+    step over random shapes: T around the 16-frame block boundaries, 2 <= C <= 300 (the fast step's limit), targets
+    of 0..63 labels, infeasible utterances, -inf / NaN entries, score spreads that make the certificate reject
+    some utterances (repaired in the log domain within the same call)"""
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(7)
+    repaired_total = 0
+    for it in range(40):
+        B = int(rs.choice([1, 2, 5, 17, 64, 130]))
+        T = int(rs.choice([1, 5, 16, 17, 31, 32, 33, 100, 257, 640]))
+        C = int(rs.choice([2, 3, 8, 29, 100, 255, 300]))
+        Lmax = int(rs.choice([0, 1, 3, 20, 44, 63]))
+        sc = float(rs.choice([0.3, 1.0, 1.0, 1.7]))
+        lsm = bool(rs.randint(2))
+        x = torch.tensor(rs.randn(B, T, C).astype(np.float32) * sc).cuda()
+        if rs.rand() < 0.3:
+            x[rs.randint(B), rs.randint(T), rs.randint(C)] = float("-inf")
+        if rs.rand() < 0.2:
+            x[rs.randint(B), rs.randint(T), rs.randint(C)] = float("nan")
+        targets = [rs.randint(0, max(C - 1, 1), size=rs.randint(0, Lmax + 1)).tolist() for _ in range(B)]
+        tg = E.CtcTargets(targets, x.device)
+        scale, _, coef = E.loss_factors(tg, "mean")
+        dx = torch.full_like(x, float("nan"))
+        ws, nll, loss = E.ctc_forward_backward(x, tg, C - 1, coef, None, dx, loss_scale=scale, want_loss=True,
+                                               lse=E.row_lse(x) if lsm else None)
+        xl = torch.log_softmax(torch.nan_to_num(x, nan=float("-inf")), 2) if lsm else x
+        ws2, nll2 = E.ctc_forward(xl, tg, C - 1)
+        dx2 = torch.empty_like(x)
+        E.ctc_grad(xl, tg, C - 1, ws2, nll2, coef, None, dx2)
+        if lsm:  # chain rule of log_softmax by hand
+            dx2 = torch.nan_to_num(dx2 - torch.exp(xl) * dx2.sum(2, keepdim=True), nan=0.0)
+        torch.cuda.synchronize()
+        msg = f"it={it} B={B} T={T} C={C} Lmax={Lmax} scale={sc} lsm={lsm}"
+        assert not E.ctc_pipeline_gave_up(ws, B, T, tg.max_len), msg
+        repaired_total += E.ctc_pipeline_repaired(ws, B, T, tg.max_len)
+        fin = torch.isfinite(nll2)
+        assert torch.equal(torch.isfinite(nll), fin), msg
+        assert torch.allclose(nll[fin], nll2[fin], rtol=2e-5, atol=2e-4), msg
+        assert bool(torch.isfinite(dx).all()), msg
+        err = float((dx - dx2).abs().max()) / float(coef.abs().max())
+        assert err < 2e-4, (msg, err)  # 1e-4 of the gradient's scale is the parity bar; both sides are fp32
+    assert repaired_total > 0  # (the sweep must exercise the repair launch as well)
+
+
 @pytest.mark.parametrize("lens,T,C", [((7, 0, 12, 3), 60, 12), ((100, 64, 5), 230, 9), ((200, 30), 400, 15)])
 def test_ctc_module_fused_log_softmax(crit, lens, T, C):
     """CTC(blank, use_pt=False): log_softmax is fused into the pipelined launch (forward at the gather,
