@@ -43,6 +43,11 @@
 
 #include "device_common.h"
 
+#ifndef WFL_DBG_FAST
+#define WFL_DBG_FAST 0  // scratch/chain_harness.cpp, timeline_fast.py: bit 0 no frames, 1 no staging math, 2 no gathers, 3 idle flusher,
+                        // 4 chain launch only, 9 (512) per-item timestamps in the workspace
+#endif
+
 namespace wfl {
 
 constexpr float kNegBig = -1.0e30f;  // stands in for -inf on the chain
@@ -504,9 +509,6 @@ __device__ __forceinline__ float fold16(const float (&v)[16], int lane) {
 }
 __device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) { return fold16<false>(v, lane); }
 
-#ifndef WFL_DBG_FAST
-#define WFL_DBG_FAST 0  // scratch/chain_harness.cpp: bit 0 no frames, 1 no staging math, 2 no gathers, 3 idle flusher, 4 chain launch only
-#endif
 constexpr int kFHelpers = 4;  // waves 1..4 stage emission factors (whole blocks, round robin); wave 5 flushes checkpoints
 constexpr int kFWaves = 8;    // workgroup of the fast kernels (waves 6, 7 of a chain workgroup leave at once).  Workgroup
                               // shapes that are not a multiple of 4 waves do not spread evenly over the SIMDs (measured with
@@ -784,14 +786,14 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
           done_seen = lds_peek(&S.ckdone);
 #pragma unroll
           for (int j = 0; j < kHalf; ++j)
-            fnxt[j] = (WFL_DBG_FAST & 128) ? make_float2(0.4f + 0.01f * j, 0.5f) : S.ring[(kk + 1) % kFSlots][j][lane];
+            fnxt[j] = S.ring[(kk + 1) % kFSlots][j][lane];
         }
       } else {
 #pragma unroll
         for (int j = 0; j < kHalf; ++j)
-          fnxt[j] = (WFL_DBG_FAST & 128) ? make_float2(0.4f + 0.01f * j, 0.5f) : S.ring[kk % kFSlots][kHalf + j][lane];
+          fnxt[j] = S.ring[kk % kFSlots][kHalf + j][lane];
         lds_post(&S.consumed, kk + 1);  // (after the reads were issued: LDS executes a wave's instructions in order)
-        if (!(WFL_DBG_FAST & 64)) lane_renorm();
+        lane_renorm();
         if (kk >= kCkSlots && done_seen < kk - kCkSlots + 1)
           while (lds_peek(&S.ckdone) < kk - kCkSlots + 1) {
           }
@@ -950,7 +952,7 @@ __device__ __forceinline__ void lsm_seed_rows(float* rows, const float* __restri
 // workgroups of the same launch, and normalise the posteriors by the Z the block itself reproduces
 // (sum_s alpha(s) beta(s) at its last frame; the certificate's identity) instead of the log Z that the
 // alpha chain only knows when it has finished.
-template <bool PIPE, bool LSM = false, bool CERT = false>
+template <bool PIPE, bool LSM = false>
 __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
                                               const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1072,15 +1074,6 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
         U = -(m + __builtin_amdgcn_logf(ssum));
       else
         U = kNegBig;  // no accepting path through this block: every posterior is 2^-huge = 0
-      if (CERT && lane == 0) {  // log2 Z as this block reproduced it, for the certificate of the fast chains
-        const double zk = U > 0.5f * kNegBig
-                              ? coherent_load_f64(&offa[k]) + coherent_load_f64(&offb[NB - 1 - k]) - (double)U
-                              : -1.0e300;
-        long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
-        const long long zq = z_fixed(zk);
-        __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
     float gbv[kBlk];
 #pragma unroll
@@ -1295,11 +1288,6 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
     const float term = v > 0.f ? ldexpf(v, max(sx - E, -200)) : 0.f;
     const float Zm = wave_all_sum(term);
     alive = Zm > 0.f && Zm < 3.0e38f && E > kEmptyE;
-#if WFL_DBG_FAST & 256
-    if (b == 0 && k == 0 && lane < 4)
-      printf("lane %d ca %g %g cb %g %g ea %d eb %d pb %g pl %g bb %g bl %g g %g h %g tb0 %g tl0 %g v %g sx %d own %d E %d term %g Zm %g rsum %g off %g\n",
-             lane, ca.x, ca.y, cbb, cbl, ea, eb, pb, pl, bb, bl, g, h, tb0, tl0, v, sx, own, E, term, Zm, rsum, off_sum);
-#endif
     // (exponent clamped from above too: a lane whose alpha beta is ~0 at the last frame may sit far above E;
     // if that distorts a posterior that matters, the per-frame sum check below rejects the block)
     if (alive) K = cf * ldexpf(1.f / Zm, min(max(sx - E, -200), 100));
