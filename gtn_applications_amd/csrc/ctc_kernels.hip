@@ -1459,14 +1459,20 @@ __global__ void __launch_bounds__(256)
     if (blockIdx.x == 0 && threadIdx.x < 64 && a.loss_out) reduce_loss_when_done(a, w, lane, true);
     return;
   }
+  // gradient workgroups: a small persistent grid (the launch is empty on data the fast chains can represent,
+  // and what it costs then is its dispatch).  Nothing to repair anywhere: leave after one look at the certificates.
+  bool any = false;
+  for (int u = threadIdx.x; u < a.B; u += blockDim.x) any = any || utterance_rejected(a, w, u);
+  if (!__syncthreads_or(any)) return;
   const int NB = ctc_blocks(a.T);
-  const int64_t item = (int64_t)(blockIdx.x - nchain) * 4 + (threadIdx.x >> 6);
-  bool valid = item < (int64_t)a.B * NB;
-  const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;
+  const int64_t stride = (int64_t)(gridDim.x - nchain) * 4;
   const int mid = (NB - 1) / 2;
-  const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-  valid = valid && utterance_rejected_wave(a, w, b, lane);
-  ctc_grad_body<true, LSM>(a, valid, b, k, coef, gout, dx, smem);
+#pragma unroll 1
+  for (int64_t item = (int64_t)(blockIdx.x - nchain) * 4 + (threadIdx.x >> 6); item < (int64_t)a.B * NB; item += stride) {
+    const int r = (int)(item / a.B), b = (int)(item % a.B);  // r: rank in readiness order
+    const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+    ctc_grad_body<true, LSM>(a, utterance_rejected_wave(a, w, b, lane), b, k, coef, gout, dx, smem);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2045,7 +2051,15 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     WFL_LAUNCH_CHECK();
     a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
     if (a.token == 0) a.token = 1;
-    rc = row_lse ? launch(ctc_repair_kernel<true>, sizeof(ChainLdsT)) : launch(ctc_repair_kernel<false>, sizeof(ChainLdsT));
+    auto launch_repair = [&](auto kern) -> int {
+      const size_t lds = std::max(rows_lds, sizeof(ChainLdsT));
+      if (lds > 48 * 1024)
+        WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const dim3 rgrid((unsigned)(2 * B + std::min<int64_t>((items + 3) / 4, 512)));
+      hipLaunchKernelGGL(kern, rgrid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
+      return WFL_OK;
+    };
+    rc = row_lse ? launch_repair(ctc_repair_kernel<true>) : launch_repair(ctc_repair_kernel<false>);
   } else if (ppl == 1) {
     rc = row_lse ? launch(ctc_pipelined_kernel<true>, sizeof(ChainLdsT))
                  : launch(ctc_pipelined_kernel<false>, sizeof(ChainLdsT));
