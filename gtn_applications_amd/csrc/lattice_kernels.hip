@@ -99,6 +99,53 @@ __global__ void __launch_bounds__(256) gather_kernel(wfl_lattice_desc d, const i
   }
 }
 
+// The fused-log_softmax gather for C <= 64 * NV classes: the row is read ONCE into registers (NV loads in flight per
+// lane; the generic kernel above walks it three times with one load in flight), reduced with DPP, and the label columns
+// are picked out of L1/L2.  One wave per row, RU rows per iteration for the narrow cases.
+template <int NV, int RU>
+__global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints,
+                                                          const float* __restrict__ x, int T, int C,
+                                                          float* __restrict__ xg, float* __restrict__ row_lse) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bb = d.shared ? 0 : b;
+  const int l0 = ints[d.lab_off + bb];
+  const int K = ints[d.lab_off + bb + 1] - l0;
+  const int32_t* labels = ints + d.labels + l0;
+  const int Kmax = d.max_labels;
+  for (int t0 = (blockIdx.x * 4 + wave) * RU; t0 < T; t0 += gridDim.x * 4 * RU) {
+    float v[RU][NV];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const float* row = x + ((int64_t)b * T + min(t0 + u, T - 1)) * C;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[u][i] = c < C ? row[c] : WFL_NEG_INF;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (t0 + u >= T) break;
+      float m = WFL_NEG_INF;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[u][i] = nan_to_neg(v[u][i]), m = fmaxf(m, v[u][i]);
+      m = wave_all_max(m);
+      float sum = 0.f;
+      if (m > WFL_NEG_INF) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum += fast_exp(v[u][i] - m);
+      }
+      sum = wave_all_sum(sum);
+      const float lse = (m > WFL_NEG_INF) ? m + fast_log(sum) : WFL_NEG_INF;
+      const float* row = x + ((int64_t)b * T + t0 + u) * C;
+      if (lane == 0) row_lse[(int64_t)b * T + t0 + u] = lse;
+      float* dst = xg + ((int64_t)b * T + t0 + u) * Kmax;
+      for (int k = lane; k < K; k += 64) dst[k] = nan_to_neg(row[labels[k]]) - lse;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // stage 2: chains
 // ------------------------------------------------------------------------------------------------
@@ -1086,8 +1133,20 @@ int wfl_lattice_gather(const wfl_lattice_desc* d, const int32_t* ints, const flo
                        float* row_lse, void* stream) {
   if (int rc = check_desc(d, "lattice_gather")) return rc;
   if (T <= 0) return WFL_OK;
-  dim3 grid((unsigned)std::min(1024, (T + 3) / 4), (unsigned)d->B);
-  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d, ints, x, T, C, xg, row_lse);
+  auto launch = [&](auto kern, int ru) {
+    dim3 grid((unsigned)std::min(1024, (T + 4 * ru - 1) / (4 * ru)), (unsigned)d->B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, *d, ints, x, T, C, xg, row_lse);
+  };
+  if (!row_lse || C > 1024)
+    launch(gather_kernel, 1);
+  else if (C <= 128)
+    launch(gather_lse_kernel<2, 4>, 4);
+  else if (C <= 256)
+    launch(gather_lse_kernel<4, 2>, 2);
+  else if (C <= 512)
+    launch(gather_lse_kernel<8, 1>, 1);
+  else
+    launch(gather_lse_kernel<16, 1>, 1);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }
