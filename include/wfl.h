@@ -266,8 +266,8 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
  * they need and run while the chains are still sweeping.  Same outputs (nll, dx); posteriors are
  * normalised per 16-frame block by the Z the block reproduces.
  * Targets of up to 63 labels with C <= 300: chains and gradient blocks run in lane-exponent
- * (probability-domain) arithmetic; every block certifies its result (log2 Z reproduced to 5e-4, the
- * posteriors of its frames sum to one to 1e-3) and a second, normally empty launch recomputes rejected
+ * (probability-domain) arithmetic; every block certifies its result (log2 Z reproduced to 1.5e-4, the
+ * posteriors of its frames sum to one to 2e-4) and a second, normally empty launch recomputes rejected
  * utterances in the log domain -- the caller always receives certified or log-domain results.
  * WFL_CTC_PIPELINE=log in the environment selects the log-domain launch throughout.  If loss_out is
  * not NULL it also receives mean_b(loss_scale[b] * nll[b]) (ctc.py:68-69; loss_scale NULL = 1),

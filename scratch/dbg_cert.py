@@ -10,7 +10,7 @@ def cert(ws2, B, T, max_len):
     off_z2 = o + 2 * B * 2 * nb
     o2 = off_z2 + 2 * B + B + 2 * B
     o2 = (o2 + 1) & ~1
-    o2 += 2 * B * 2 * nb + 2 * B + 2
+    o2 += 2 * B * 2 * nb + 2 * B + 2 + 2 * B  # ... ready, done, perr, dup
     z2 = ws2[off_z2:off_z2 + 2 * B].view(torch.float64).cpu().numpy()
     zmm = ws2[o2:o2 + 4 * B].view(torch.int64).cpu().numpy().reshape(B, 2) / 65536.0
     return z2, zmm
