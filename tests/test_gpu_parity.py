@@ -329,6 +329,40 @@ def test_ctc_pipelined_step_stress_fresh_data_same_buffers():
         del x, dx_pipe, dx_split, ws, ws2, nll, nll2, loss
 
 
+def test_ctc_pipeline_env_selects_log_domain_launch():
+    """WFL_CTC_PIPELINE=log (read once per process): the log-domain pipelined launch serves the step, nothing is
+    ever 'repaired', and the result agrees with the default (lane-exponent) step of this process"""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from gtn_applications_amd import engine as E\n"
+        "g = torch.Generator().manual_seed(4)\n"
+        "x = torch.randn(6, 200, 40, generator=g).cuda()\n"
+        "targets = torch.randint(38, (6, 17), generator=g).tolist()\n"
+        "tg = E.targets_on_device(targets, x.device)\n"
+        "scale, _, coef = E.loss_factors(tg, 'mean')\n"
+        "dx = torch.empty_like(x)\n"
+        "ws, nll, loss = E.ctc_forward_backward(x, tg, 39, coef, None, dx, loss_scale=scale, want_loss=True)\n"
+        "torch.cuda.synchronize()\n"
+        "print(repr(float(loss)), repr(float(dx.double().abs().sum())), E.ctc_pipeline_repaired(ws, 6, 200, tg.max_len))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_val in ("log", None):
+        env = dict(os.environ)
+        env.pop("WFL_CTC_PIPELINE", None)
+        if env_val:
+            env["WFL_CTC_PIPELINE"] = env_val
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1].split())
+    (l0, g0, r0), (l1, g1, r1) = outs
+    assert int(r0) == 0 and int(r1) == 0
+    assert float(l0) == pytest.approx(float(l1), rel=1e-5)
+    assert float(g0) == pytest.approx(float(g1), rel=1e-4)
+
+
 def test_ctc_fast_pipelined_step_random_shapes():
     """lane-exponent pipelined step (with and without the fused log_softmax) against the three-launch log-domain
     step over random shapes: T around the 16-frame block boundaries, 2 <= C <= 300 (the fast step's limit), targets
