@@ -27,5 +27,5 @@ print("items: start min %.1f max %.1f; end min %.1f max %.1f" % (it[:, :, 0].min
 pre = it[:, :, 1] - it[:, :, 0]; post = it[:, :, 2] - it[:, :, 1]
 print("start->flags seen: median %.1f p10 %.1f p90 %.1f us;  flags seen->end: median %.1f p10 %.1f p90 %.1f max %.1f us" % (np.median(pre), np.percentile(pre, 10), np.percentile(pre, 90), np.median(post), np.percentile(post, 10), np.percentile(post, 90), post.max()))
 mid = (nb - 1) // 2
-for k in (mid, mid + 8, mid + 16, mid + 24, nb - 1, 0):
+for k in (mid, mid + 8, mid + 16, mid + 20, mid + 24, mid + 25, mid + 26, nb - 2, nb - 1, 0):
     print("block %2d: start %.1f flags %.1f end %.1f (medians over utterances)" % (k, np.median(it[:, k, 0]), np.median(it[:, k, 1]), np.median(it[:, k, 2])))
