@@ -1173,6 +1173,39 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   const int col = has_label ? y : a.blank;
   const float* xrow = a.x + (int64_t)b * T * C;
 
+  // ---- the two checkpoints: a block of a later round finds them published when it starts -- their loads then
+  // travel together with the gathers instead of after them
+  const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
+  const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
+  auto flags_up = [&]() {
+    return __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
+           __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+  };
+  float2 ca = make_float2(kNegBig, kNegBig);
+  float cbb = kNegBig, cbl = kNegBig;
+  double off_sum = 0.0;
+  unsigned long long dupmask = 0;
+  auto load_checkpoints = [&]() {
+    const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
+    const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
+    const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
+    const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
+    auto load_ck = [&](const float2* p) {
+      const unsigned long long bits = coherent_load64(p);
+      float2 v;
+      __builtin_memcpy(&v, &bits, 8);
+      return v;
+    };
+    // (mirrored lanes of the beta sweep: blank state 2i <-> reversed position L-i; label of position i <-> L-1-i)
+    if (lane < P) ca = load_ck(&cka[(int64_t)k * P + lane]);
+    if (lane <= L) cbb = load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - lane)]).x;
+    if (lane < L) cbl = load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)]).y;
+    if (CERT && lane == 0) off_sum = coherent_load_f64(&offa[k]) + coherent_load_f64(&offb[NB - 1 - k]);
+    dupmask = coherent_load64((const unsigned long long*)(a.ws + w.dup) + b);
+  };
+  const bool early = flags_up();  // (uniform)
+  if (early) load_checkpoints();
+
   // ---- emission factors of the block's frames: f = 2^(x log2e - r_j), r_j = round(largest target-label score)
   float fl[kBlk], fb[kBlk];
   float rsum;
@@ -1196,14 +1229,11 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
     rsum = wave_all_sum(lane < n ? rr : 0.f);
   }
 
-  // ---- wait for alpha checkpoint k and beta checkpoint NB-1-k (see ctc_grad_body)
-  {
-    const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
-    const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
+  // ---- wait for alpha checkpoint k and beta checkpoint NB-1-k (see ctc_grad_body), unless they were there already
+  if (!early) {
     int ok = 0;
     for (int spin = 0; spin < (1 << 20); ++spin) {  // (bounded: a lost signal must not hang the GPU)
-      ok = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
-           __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+      ok = flags_up();
       if (ok) break;
       __builtin_amdgcn_s_sleep(16);
     }
@@ -1211,29 +1241,14 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
       if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
       __builtin_trap();
     }
+    load_checkpoints();
   }
 #if WFL_DBG_FAST & 512
   if (lane == 0) dbg[1] = wall_clock64();
 #endif
-  const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
-  const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
-  const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
-  const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
-  auto load_ck = [&](const float2* p) {
-    const unsigned long long bits = coherent_load64(p);
-    float2 v;
-    __builtin_memcpy(&v, &bits, 8);
-    return v;
-  };
-  // (mirrored lanes of the beta sweep: blank state 2i <-> reversed position L-i; label of position i <-> L-1-i)
-  const float2 ca = lane < P ? load_ck(&cka[(int64_t)k * P + lane]) : make_float2(kNegBig, kNegBig);
-  const float cbb = lane <= L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - lane)]).x : kNegBig;
-  const float cbl = lane < L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)]).y : kNegBig;
-  double off_sum = 0.0;
-  if (CERT && lane == 0) off_sum = coherent_load_f64(&offa[k]) + coherent_load_f64(&offb[NB - 1 - k]);
   // labels that occur once in the target (and are not the blank) own their gradient column: plain ds_write instead
   // of ds_add_f32 (see ctc_grad_body); the mask was computed once per utterance by its alpha chain workgroup
-  const bool dup = has_label && ((coherent_load64((const unsigned long long*)(a.ws + w.dup) + b) >> lane) & 1ull) != 0;
+  const bool dup = has_label && ((dupmask >> lane) & 1ull) != 0;
   const bool uniq = has_label && !dup;
   if (lane == 0) {  // this wave was the only consumer of the two flags: leave them cleared
     unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
