@@ -16,6 +16,7 @@ ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 1, 2, 3
 EPSILON = -1
 SEMIRING_LOG, SEMIRING_TROPICAL = 0, 1
 CTC_FAST_CHAIN = 2
+CTC_WS_REJECTED, CTC_WS_STATUS, CTC_WS_LOG2Z, CTC_WS_ZRANGE = 0, 1, 2, 3
 CONV_SPIKE, CONV_BLANK_OPTIONAL = 1, 2
 
 
@@ -120,6 +121,7 @@ _SIGS = {
     "wfl_dense_viterbi": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     # device: CTC fast path
     "wfl_ctc_workspace": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int64)]),
+    "wfl_ctc_workspace_field": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "wfl_ctc_forward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "wfl_ctc_grad": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "wfl_ctc_forward_backward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,

@@ -1982,6 +1982,22 @@ int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems) {
   return WFL_OK;
 }
 
+int wfl_ctc_workspace_field(int B, int T, int max_len, int field, int64_t* offset_elems, int64_t* length_elems) {
+  if (!offset_elems || !length_elems || B <= 0 || T <= 0 || max_len < 0) {
+    set_error("ctc_workspace_field: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  const CtcWs w = ctc_ws_layout(B, T, max_len + 1);
+  switch (field) {
+    case WFL_CTC_WS_REJECTED: *offset_elems = w.flag, *length_elems = B; break;
+    case WFL_CTC_WS_STATUS: *offset_elems = w.perr, *length_elems = 2; break;
+    case WFL_CTC_WS_LOG2Z: *offset_elems = w.z2, *length_elems = 2 * (int64_t)B; break;
+    case WFL_CTC_WS_ZRANGE: *offset_elems = w.zloc, *length_elems = 4 * (int64_t)B; break;
+    default: set_error("ctc_workspace_field: unknown field %d", field); return WFL_ERR_INVALID;
+  }
+  return WFL_OK;
+}
+
 int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets, int max_len,
                     int blank, int flags, float* ws, float* nll, void* stream) {
   if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_forward")) return rc;

@@ -400,27 +400,29 @@ def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_los
     return (ws, nll, loss) if want_loss else (ws, nll)
 
 
+_CTC_WS_FIELDS = {}
+
+
+def ctc_workspace_field(ws, B, T, max_len, field):
+    """Slice of the CTC workspace that holds a bookkeeping field (include/wfl.h, WFL_CTC_WS_*)."""
+    key = (B, T, max_len, field)
+    span = _CTC_WS_FIELDS.get(key)
+    if span is None:
+        off, n = ctypes.c_int64(), ctypes.c_int64()
+        N.check(N.lib.wfl_ctc_workspace_field(B, T, max_len, field, ctypes.byref(off), ctypes.byref(n)))
+        span = _CTC_WS_FIELDS[key] = (off.value, n.value)
+    return ws[span[0]:span[0] + span[1]]
+
+
 def ctc_pipeline_gave_up(ws, B, T, max_len):
     """True if a gradient wave of the pipelined step stopped waiting for a checkpoint (diagnostics)."""
-    P, nb = max_len + 1, (T + 15) // 16
-    o = B * 2 * nb * P * 2
-    o = (o + 1) & ~1
-    o += 2 * B * 2 * nb + 2 * B + B + 2 * B
-    o = (o + 1) & ~1
-    o += 2 * B * 2 * nb + 2 * B
-    return bool(ws[o:o + 1].view(torch.int32).item())
+    return bool(ctc_workspace_field(ws, B, T, max_len, N.CTC_WS_STATUS).view(torch.int32)[0].item())
 
 
 def ctc_pipeline_repaired(ws, B, T, max_len):
     """Number of utterances of the last pipelined step whose lane-exponent chains failed the certificate
     and were recomputed in the log domain by the repair launch (diagnostics; 0 on the log-domain step)."""
-    P, nb = max_len + 1, (T + 15) // 16
-    o = B * 2 * nb * P * 2
-    o = (o + 1) & ~1
-    o += 2 * B * 2 * nb + 2 * B + B + 2 * B
-    o = (o + 1) & ~1
-    o += 2 * B * 2 * nb + 2 * B
-    return int(ws[o + 1:o + 2].view(torch.int32).item())
+    return int(ctc_workspace_field(ws, B, T, max_len, N.CTC_WS_STATUS).view(torch.int32)[1].item())
 
 
 def ctc_grad(x, tg, blank, ws, nll, coef, gout, dx):
@@ -433,12 +435,8 @@ def ctc_grad(x, tg, blank, ws, nll, coef, gout, dx):
 
 def ctc_rejected(ws, B, T, max_len):
     """int32 [B] view of the workspace: 1 where the fast chain's result was rejected by the certificate
-    and the log-domain chain re-ran (tests / diagnostics)."""
-    P, nb = max_len + 1, (T + 15) // 16
-    o = B * 2 * nb * P * 2
-    o = (o + 1) & ~1
-    o += 2 * B * 2 * nb + 2 * B
-    return ws[o:o + B].view(torch.int32)
+    and the log-domain chain re-ran (three-launch step; tests / diagnostics)."""
+    return ctc_workspace_field(ws, B, T, max_len, N.CTC_WS_REJECTED).view(torch.int32)
 
 
 def loss_factors(tg, reduction, norm_lens=None):

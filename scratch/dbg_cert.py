@@ -4,15 +4,9 @@ import numpy as np, torch
 from gtn_applications_amd import engine as E
 
 def cert(ws2, B, T, max_len):
-    P, nb = max_len + 1, (T + 15) // 16
-    o = B * 2 * nb * P * 2
-    o = (o + 1) & ~1
-    off_z2 = o + 2 * B * 2 * nb
-    o2 = off_z2 + 2 * B + B + 2 * B
-    o2 = (o2 + 1) & ~1
-    o2 += 2 * B * 2 * nb + 2 * B + 2 + 2 * B  # ... ready, done, perr, dup
-    z2 = ws2[off_z2:off_z2 + 2 * B].view(torch.float64).cpu().numpy()
-    zmm = ws2[o2:o2 + 4 * B].view(torch.int64).cpu().numpy().reshape(B, 2) / 65536.0
+    from gtn_applications_amd import _native as N
+    z2 = E.ctc_workspace_field(ws2, B, T, max_len, N.CTC_WS_LOG2Z).view(torch.float64).cpu().numpy()
+    zmm = E.ctc_workspace_field(ws2, B, T, max_len, N.CTC_WS_ZRANGE).view(torch.int64).cpu().numpy().reshape(B, 2) / 65536.0
     return z2, zmm
 
 if __name__ == "__main__":

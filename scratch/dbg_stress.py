@@ -19,16 +19,10 @@ ws, nll = E.ctc_forward(x, tg, C - 1)
 E.ctc_grad(x, tg, C - 1, ws, nll, coef, gout, dx_split)
 torch.cuda.synchronize()
 print("repaired", E.ctc_pipeline_repaired(ws2, B, T, tg.max_len))
-P, nb = tg.max_len + 1, (T + 15) // 16
-o = B * 2 * nb * P * 2
-o = (o + 1) & ~1
-off_z2 = o + 2 * B * 2 * nb
-o2 = off_z2 + 2 * B + B + 2 * B
-o2 = (o2 + 1) & ~1
-o2 += 2 * B * 2 * nb + 2 * B + 2
-z2 = ws2[off_z2:off_z2 + 2 * B].view(torch.float64).cpu().numpy()
-zmm = ws2[o2:o2 + 4 * B].view(torch.int64).cpu().numpy().reshape(B, 2) / 65536.0
-pb = ws2[off_z2 + 2 * B + B: off_z2 + 2 * B + 3 * B].view(torch.int32).cpu().numpy().reshape(B, 2)
+from gtn_applications_amd import _native as N
+z2 = E.ctc_workspace_field(ws2, B, T, tg.max_len, N.CTC_WS_LOG2Z).view(torch.float64).cpu().numpy()
+zmm = E.ctc_workspace_field(ws2, B, T, tg.max_len, N.CTC_WS_ZRANGE).view(torch.int64).cpu().numpy().reshape(B, 2) / 65536.0
+pb = np.zeros((B, 2), int)
 for u in range(B):
     if abs(zmm[u, 0] - z2[u]) > 1.4e-3 or abs(zmm[u, 1] - z2[u]) > 1.4e-3 or pb[u].any():
         print("cert", u, z2[u], zmm[u] - z2[u], pb[u])

@@ -318,3 +318,41 @@ def test_load_criterion_factory(golden_dir):
     from gtn_applications_amd import compat
 
     assert compat.install().load_criterion is pkg.load_criterion
+
+
+def test_ctc_workspace_fields_lie_inside_the_workspace():
+    """wfl_ctc_workspace_field (diagnostics): every field is inside the workspace wfl_ctc_workspace sizes, and
+    the fields do not overlap"""
+    import ctypes
+
+    from gtn_applications_amd import _native as N
+
+    for (B, T, L) in [(1, 1, 0), (5, 83, 11), (128, 1000, 44), (3, 2000, 255)]:
+        total = ctypes.c_int64()
+        N.check(N.lib.wfl_ctc_workspace(B, T, 10, L, ctypes.byref(total)))
+        spans = []
+        for field in (N.CTC_WS_REJECTED, N.CTC_WS_STATUS, N.CTC_WS_LOG2Z, N.CTC_WS_ZRANGE):
+            off, n = ctypes.c_int64(), ctypes.c_int64()
+            N.check(N.lib.wfl_ctc_workspace_field(B, T, L, field, ctypes.byref(off), ctypes.byref(n)))
+            assert 0 <= off.value and off.value + n.value <= total.value
+            spans.append((off.value, off.value + n.value))
+        spans.sort()
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    off, n = ctypes.c_int64(), ctypes.c_int64()
+    assert N.lib.wfl_ctc_workspace_field(4, 100, 10, 99, ctypes.byref(off), ctypes.byref(n)) != 0  # unknown field
+
+
+def test_targets_on_device_accepts_tensors_and_lists_alike():
+    """the criterion modules pass lists of 1-D tensors (one torch.cat), the functions lists of lists: same flat
+    labels, offsets and lengths either way; empty targets included"""
+    import torch
+
+    from gtn_applications_amd import engine as E
+
+    rows = [[3, 1, 2], [], [7], [5, 5, 0, 1]]
+    cpu = torch.device("cpu")
+    a = E.targets_on_device([torch.tensor(r, dtype=torch.long) for r in rows], cpu)
+    b = E.CtcTargets(rows, cpu)
+    assert a.flat.tolist() == b.flat.tolist() and a.offsets.tolist() == b.offsets.tolist()
+    assert list(a.lens) == list(b.lens) and a.max_len == b.max_len == 4 and a.B == b.B == 4
+    assert E.targets_on_device(a, cpu) is a  # prebuilt targets pass through
