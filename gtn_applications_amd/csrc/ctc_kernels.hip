@@ -168,6 +168,7 @@ __device__ __forceinline__ bool utterance_rejected(const CtcArgs& a, const CtcWs
   const double z2 = ((const double*)(a.ws + w.z2))[u];
   const long long* zmm = (const long long*)(a.ws + w.zloc) + (int64_t)u * 2;
   const long long zq = z_fixed(z2);
+  if (zq == kZDead && (((const unsigned long long*)(a.ws + w.dup))[u] >> 63)) return false;  // cannot be aligned: exact
   // 1.5e-4 in log2 units: a lost mass fraction of 1e-4 (the parity bar).  The lane-exponent blocks reproduce the
   // chain's log2 Z to 1-3e-5 on well-represented data (measured; fixed-point resolution 1.5e-5)
   constexpr long long tol = 10;
@@ -643,7 +644,11 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       bool dupl = false;
       for (int j = 0; j < L; ++j) dupl = dupl || (__builtin_amdgcn_readlane(y, j) == y && j != lane);
       dupl = has_label && (dupl || y == a.blank);
-      const unsigned long long mask = __builtin_amdgcn_ballot_w64(dupl);
+      unsigned long long mask = __builtin_amdgcn_ballot_w64(dupl);
+      // bit 63 (no label lives in lane 63): the target cannot be aligned at all -- T < L + adjacent repeats.  Such an
+      // utterance has Z = 0 exactly, in any arithmetic: loss inf, zero gradient, nothing for the certificate to doubt
+      const int repeats = __builtin_popcountll(__builtin_amdgcn_ballot_w64(has_label && lane >= 1 && y == yprev));
+      if (T < L + repeats) mask |= 1ull << 63;
       if (lane == 0) coherent_store64((unsigned long long*)(a.ws + w.dup) + b, mask);
     }
     for (int kk = 0; kk < NB; ++kk) {

@@ -329,6 +329,27 @@ def test_ctc_pipelined_step_stress_fresh_data_same_buffers():
         del x, dx_pipe, dx_split, ws, ws2, nll, nll2, loss
 
 
+def test_ctc_fast_step_accepts_targets_that_cannot_be_aligned_without_repair():
+    """T < L + adjacent repeats: Z = 0 exactly in any arithmetic, so the lane-exponent step's inf loss / zero gradient
+    needs no repair launch work (one such utterance in a batch must not double the step time)"""
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(0)
+    B, T, C = 6, 20, 9
+    x = rs.randn(B, T, C).astype(np.float32)
+    targets = [[1, 2, 3], [1] * 25, [1] * 11, [2, 3] * 10, [], [4, 4, 5]]  # [1]*11 needs 21 frames, [2,3]*10 exactly 20
+    xt = dev(x)
+    tg = E.CtcTargets(targets, xt.device)
+    scale, _, coef = E.loss_factors(tg, "none")
+    dx = torch.full_like(xt, float("nan"))
+    ws, nll, loss = E.ctc_forward_backward(xt, tg, C - 1, coef, None, dx, loss_scale=scale, want_loss=True)
+    torch.cuda.synchronize()
+    assert E.ctc_pipeline_repaired(ws, B, T, tg.max_len) == 0
+    assert [math.isinf(v) for v in nll.tolist()] == [False, True, True, False, False, False]
+    want_loss, want_dx = OR.ctc_loss_grad(x, targets, C - 1, "none")
+    close(dx, np.nan_to_num(want_dx))
+
+
 def test_ctc_pipeline_env_selects_log_domain_launch():
     """WFL_CTC_PIPELINE=log (read once per process): the log-domain pipelined launch serves the step, nothing is
     ever 'repaired', and the result agrees with the default (lane-exponent) step of this process"""
