@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--C", type=int, default=None)
     ap.add_argument("--L", type=int, default=44)
     ap.add_argument("--ctc-chain", default="default", choices=["default", "log", "fast"],
-                    help="CTC chain kernel of the split step: library default, log-domain, or the experimental lane-exponent chain + certificate")
+                    help="CTC chain kernel of the split step: library default, log-domain, or the lane-exponent chain + certificate")
     ap.add_argument("--ctc-step", default="pipelined", choices=["split", "pipelined"],
                     help="CTC step: forward and gradient kernels back to back, or one pipelined launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")

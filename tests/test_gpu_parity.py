@@ -137,7 +137,7 @@ def test_ctc_long_targets(crit, lens, T):
 
 def test_ctc_three_hip_paths_agree(crit):
     """the same batch through the generic lattice kernels and through both CTC chains (default
-    log-domain chain; experimental lane-exponent chain with certificate), including block-boundary cases of
+    log-domain chain; lane-exponent chain with certificate), including block-boundary cases of
     the checkpoint/recompute scheme (T = 16k, 16k+1, 16k+8, 16k+15, < 16)"""
     from gtn_applications_amd import _native as N
     from gtn_applications_amd import engine as E
@@ -164,7 +164,7 @@ def test_ctc_three_hip_paths_agree(crit):
 
 
 def test_ctc_certificate_rejects_what_the_fast_chain_cannot_represent(crit):
-    """experimental fast chain: an utterance it cannot represent (one target label 40 nats above all
+    """fast chain (three-launch step): an utterance it cannot represent (one target label 40 nats above all
     others inside a long unlikely segment) must be rejected by the certificate and repaired by the
     log-domain chain in the same forward call; the result must match the oracle"""
     from gtn_applications_amd import _native as N
