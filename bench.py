@@ -109,7 +109,7 @@ def make_ctc(args, rank, mode):
             last[0] = E.ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=scale, want_loss=True)
             mark(events)
         # (the event bracket holds both launches of the step: lane-exponent pipelined launch + certificate / repair launch)
-        phases = ["ctc_fast_pipelined_kernel (+ctc_repair_kernel)" if os.environ.get("WFL_CTC_PIPELINE") != "log" and C <= 300
+        phases = ["ctc_fast_pipelined_kernel (+ctc_repair_kernel)" if os.environ.get("WFL_CTC_PIPELINE") != "log" and L <= 63
                   else "ctc_pipelined_kernel"]
     elif mode == "abi":
         def step(events=None):

@@ -44,7 +44,7 @@ class CTCLossFunction(torch.autograd.Function):
             raise ValueError(f"got {tg.B} targets for a batch of {B}")
         scale, _, coef = E.loss_factors(tg, reduction)  # loss scale; gradient coefficient -scale/B
         need_grad = log_probs.requires_grad
-        if tg.max_len <= E.CTC_FAST_MAX_LEN and need_grad:
+        if E.ctc_fast_path_ok(tg.max_len, C) and need_grad:
             # loss and gradient in ONE pipelined launch (gradient waves run behind the chains); backward
             # only applies the upstream scalar.  Like torch's own CTC, the gradient is produced eagerly.
             dx = torch.empty_like(x)
@@ -54,7 +54,7 @@ class CTCLossFunction(torch.autograd.Function):
             ctx.aux = ("pipelined", x, tg, int(blank_idx), dx, coef)
         elif ctx_log_softmax(ctx):
             raise RuntimeError("fused log_softmax CTC is only used on the pipelined path")
-        elif tg.max_len <= E.CTC_FAST_MAX_LEN:
+        elif E.ctc_fast_path_ok(tg.max_len, C):
             ws, nll = E.ctc_forward(x, tg, int(blank_idx))
             loss = E.reduce_loss(nll, scale, 1.0)
             ctx.aux = ("fast", x, tg, int(blank_idx), None, nll, coef)
@@ -120,7 +120,7 @@ class CTC(torch.nn.Module):
 
     def forward(self, inputs, targets):
         if not self.use_pt and inputs.requires_grad and inputs.dtype == torch.float32 and \
-                max((t.numel() for t in targets), default=0) <= E.CTC_FAST_MAX_LEN:
+                E.ctc_fast_path_ok(max((t.numel() for t in targets), default=0), inputs.shape[2]):
             return _FusedLogSoftmaxCTCLoss.apply(inputs, targets, self.blank, "mean")
         log_probs = torch.nn.functional.log_softmax(inputs, dim=2)
         if self.use_pt:  # ctc.py:109-121

@@ -82,7 +82,7 @@ __device__ __forceinline__ float to_score(float raw) {
 //   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
 // ------------------------------------------------------------------------------------------------
 struct CtcWs {
-  int64_t ck, off, z2, flag, pbad, ready, done, perr, dup, zloc, total, dbg;
+  int64_t ck, off, z2, flag, pbad, ready, done, perr, dup, own, zloc, total, dbg;
 };
 __host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
 __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
@@ -100,6 +100,7 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   w.done = o, o += 2 * (int64_t)B;            // uint64 done[b]: == the launch token once nll[b] is published
   w.perr = o, o += 2;                         // int32: a gradient wave of the pipelined step gave up waiting
   w.dup = o, o += 2 * (int64_t)B;             // uint64 dup[b]: bit i = target label i also occurs elsewhere in the target (or is the blank)
+  w.own = o, o += 64 * (int64_t)B;            // int32 own[b][64]: lane of the first occurrence of the lane's label (63: the blank's slot)
   w.zloc = o, o += 4 * (int64_t)B;            // int64 zloc[b][2]: min / max over the blocks of log2 Z (x 2^16) as their gradient waves reproduced it
 #if WFL_DBG_FAST & 512
   o = (o + 1) & ~1ll;
@@ -642,8 +643,15 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       // which target labels own their gradient column (occur once, are not the blank): one mask per utterance for
       // all its gradient waves, stored before the first checkpoint (acknowledged before any flag is raised)
       bool dupl = false;
-      for (int j = 0; j < L; ++j) dupl = dupl || (__builtin_amdgcn_readlane(y, j) == y && j != lane);
+      int own = lane;  // lane of the label's first occurrence: the slot of its column in the compact gradient tile
+      for (int j = 0; j < L; ++j) {
+        const bool same = __builtin_amdgcn_readlane(y, j) == y;
+        dupl = dupl || (same && j != lane);
+        if (same && j < own) own = j;
+      }
       dupl = has_label && (dupl || y == a.blank);
+      if (y == a.blank) own = 63;  // (a target label equal to the blank index shares the blank's slot)
+      __hip_atomic_store((int32_t*)(a.ws + w.own) + (int64_t)b * 64 + lane, own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       unsigned long long mask = __builtin_amdgcn_ballot_w64(dupl);
       // bit 63 (no label lives in lane 63): the target cannot be aligned at all -- T < L + adjacent repeats.  Such an
       // utterance has Z = 0 exactly, in any arithmetic: loss inf, zero gradient, nothing for the certificate to doubt
@@ -953,31 +961,81 @@ __device__ __forceinline__ void lsm_seed_rows(float* rows, const float* __restri
   }
 }
 
+// COMPACT gradient tile (wide rows): the wave accumulates a block's posteriors in [16][64] floats -- one slot per
+// target position (the slot of a repeated label is the lane of its first occurrence), slot 63 the blank -- next to
+// a column -> slot byte map (255: no slot), and the dense rows are expanded while they are written:
+//   dx[t0 + j, c] = tile[j][slot(c)] (0 without a slot)  - cf * softmax(x)[c] (fused log_softmax).
+// The dense LDS tile [16][C] of the narrow case would leave a single gradient workgroup per CU from C = 160 on and
+// does not fit at all beyond C = 602.
+__device__ __forceinline__ size_t compact_wave_bytes(int C) { return (size_t)kBlk * 64 * 4 + ((C + 15) & ~15); }
+__device__ __forceinline__ void compact_init(float* tile, unsigned char* cmap, int C, int lane) {
+  for (int i = lane; i < kBlk * 64; i += 64) tile[i] = 0.f;
+  for (int i = lane; i < ((C + 15) & ~15) / 4; i += 64) ((unsigned int*)cmap)[i] = 0xffffffffu;
+}
+__device__ __forceinline__ void compact_expand(const float* tile, const unsigned char* cmap, float* __restrict__ dst,
+                                               const float* __restrict__ xsrc, float lse_blk, int n, int C, float cf,
+                                               bool alive, bool soft, int lane) {
+  auto value = [&](int j, unsigned sl, float xv, float l) {
+    float v = (sl != 255u && alive) ? tile[j * 64 + (int)sl] : 0.f;
+    if (soft && l > WFL_NEG_INF) v -= cf * __expf((xv == xv ? xv : WFL_NEG_INF) - l);
+    return v;
+  };
+  if ((C & 3) == 0 && (((uintptr_t)dst) & 15) == 0 && (!soft || (((uintptr_t)xsrc) & 15) == 0)) {
+    const int c4n = C >> 2;
+#pragma unroll 2
+    for (int j = 0; j < n; ++j) {
+      const float l = soft ? readlane_f(lse_blk, j) : 0.f;
+      for (int c4 = lane; c4 < c4n; c4 += 64) {
+        const unsigned m4 = ((const unsigned int*)cmap)[c4];
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (soft) xv = ((const float4*)(xsrc + (int64_t)j * C))[c4];
+        float4 o;
+        o.x = value(j, m4 & 255u, xv.x, l), o.y = value(j, (m4 >> 8) & 255u, xv.y, l);
+        o.z = value(j, (m4 >> 16) & 255u, xv.z, l), o.w = value(j, m4 >> 24, xv.w, l);
+        ((float4*)(dst + (int64_t)j * C))[c4] = o;
+      }
+    }
+  } else {
+    for (int j = 0; j < n; ++j) {
+      const float l = soft ? readlane_f(lse_blk, j) : 0.f;
+      for (int c = lane; c < C; c += 64)
+        dst[(int64_t)j * C + c] = value(j, cmap[c], soft ? xsrc[(int64_t)j * C + c] : 0.f, l);
+    }
+  }
+}
+
 // PIPE: the pipelined step -- wait for the two checkpoints of block k to be published by the chain
 // workgroups of the same launch, and normalise the posteriors by the Z the block itself reproduces
 // (sum_s alpha(s) beta(s) at its last frame; the certificate's identity) instead of the log Z that the
 // alpha chain only knows when it has finished.
-template <bool PIPE, bool LSM = false>
+template <bool PIPE, bool LSM = false, bool COMPACT = false>
 __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
                                               const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = a.T, C = a.C, P = a.P;
   const int NB = ctc_blocks(T);
   const CtcWs w = ctc_ws_layout(a.B, T, P);
-  float* rows = (float*)smem + (size_t)wave * (kBlk + 1) * C;  // [16][C] gradient rows + [C] label counts, per wave
-  int* cnt = (int*)(rows + (size_t)kBlk * C);
+  // [16][C] gradient rows + [C] label counts per wave, or (COMPACT, wide rows) the compact tile + column map
+  char* wbase = smem + (size_t)wave * (COMPACT ? compact_wave_bytes(C) : (size_t)(kBlk + 1) * C * 4);
+  float* rows = (float*)wbase;
+  int* cnt = (int*)(rows + (size_t)kBlk * C);                             // (dense tile only)
+  unsigned char* cmap = (unsigned char*)(wbase + (size_t)kBlk * 64 * 4);  // (COMPACT only)
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
   bool live = valid && (PIPE || a.nll[b] < __builtin_inff());  // no accepting path: zero gradient
   constexpr bool lsm = PIPE && LSM;  // fused log_softmax (raw scores in x)
   const float cf_row = (coef ? coef[valid ? b : 0] : 1.f) * (gout ? gout[0] : 1.f);
   float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
+  bool alive_blk = true;  // (COMPACT) the block carries posterior mass
   if (valid) {
-    for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;  // (int 0 == float 0 bit pattern)
+    if (COMPACT)
+      compact_init(rows, cmap, C, lane);
+    else
+      for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;  // (int 0 == float 0 bit pattern)
     if (lsm) {
       // d loss / d raw score = g - softmax(x) * sum_c g, and the posteriors of a frame sum to one:
       // the rows start at -cf * softmax(x) (done before waiting: it does not depend on the chains)
       lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
-      lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf_row, lane);
+      if (!COMPACT) lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf_row, lane);
     }
   }
   if (PIPE && valid) {
@@ -1014,8 +1072,23 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
     // A label that occurs once in the target (and is not the blank column) owns its gradient column:
     // plain ds_write instead of ds_add_f32, which costs ~1 LDS cycle per active lane (PMC: 42 cycles
     // per wave-instruction with 45 lanes).  One counting atomic per block finds the duplicates.
-    if (has_label) atomicAdd(&cnt[y], 1);
-    const bool dup = has_label && (cnt[y] > 1 || y == a.blank);
+    bool dup;
+    int slot = lane;  // COMPACT: lane of the label's first occurrence
+    if (COMPACT) {
+      bool dupl = false;
+      for (int j = 0; j < L; ++j) {
+        const bool same = __builtin_amdgcn_readlane(y, j) == y;
+        dupl = dupl || (same && j != lane);
+        if (same && j < slot) slot = j;
+      }
+      dup = has_label && (dupl || y == a.blank);
+      if (y == a.blank) slot = 63;
+      if (has_label && slot == lane) cmap[y] = (unsigned char)lane;
+      if (lane == 0) cmap[a.blank] = 63;
+    } else {
+      if (has_label) atomicAdd(&cnt[y], 1);
+      dup = has_label && (cnt[y] > 1 || y == a.blank);
+    }
     const bool uniq = has_label && !dup;
     float xl[kBlk], xb[kBlk];
 #pragma unroll
@@ -1100,19 +1173,29 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
         // (per-lane ds_add_f32 instead was measured at 49 us for the kernel vs 28 us: LDS float atomics
         // serialise per active lane; one wave reduction per frame costs 18 instructions x 16)
         gbv[j] = gb;
-        if (uniq) rows[j * C + y] = (lsm ? rows[j * C + y] : 0.f) + gl * cf;  // sole writer of this column
-        if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
+        if (COMPACT) {
+          if (uniq) rows[j * 64 + lane] = gl * cf;
+          if (dup && gl != 0.f) atomicAdd(&rows[j * 64 + slot], gl * cf);
+        } else {
+          if (uniq) rows[j * C + y] = (lsm ? rows[j * C + y] : 0.f) + gl * cf;  // sole writer of this column
+          if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
+        }
         bb = tb + xb[j];
         bl = tl + xl[j];
       }
     }
     const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
-    if (lane < n && gtot != 0.f) atomicAdd(&rows[lane * C + a.blank], gtot * cf);
-    if (lsm && !(U > 0.5f * kNegBig))  // no accepting path: zero gradient, softmax term included
+    if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * 64 + 63 : lane * C + a.blank], gtot * cf);
+    if (PIPE) alive_blk = U > 0.5f * kNegBig;
+    if (lsm && !alive_blk && !COMPACT)  // no accepting path: zero gradient, softmax term included
       for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
   }
   // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
-  if (valid) {  // the dense rows of a block are contiguous in dx: one coalesced copy (zeros included)
+  if (valid && COMPACT) {
+    const bool alive = live && alive_blk;
+    compact_expand(rows, cmap, dx + ((int64_t)b * T + t0) * C, a.x + ((int64_t)b * T + t0) * C, lse_blk, n, C, cf_row, alive,
+                   lsm && alive, lane);
+  } else if (valid) {  // the dense rows of a block are contiguous in dx: one coalesced copy (zeros included)
     float* dst = dx + ((int64_t)b * T + t0) * C;
     const int total = n * C;
     if ((((uintptr_t)dst) & 15) == 0) {
@@ -1146,7 +1229,7 @@ __device__ __forceinline__ void fmac2_shl1(float& acc, float s0, float s1, float
 //   Z_local = sum_s alpha_{n-1}(s) [A beta~_n](s)  (relative to the checkpoints' offsets and the
 //   block's references); posterior = ma mb' K(s) with K(s) = 2^(ea + eb - E) / Zm folded into ma.
 // ------------------------------------------------------------------------------------------------
-template <bool LSM, bool CERT>
+template <bool LSM, bool CERT, bool COMPACT = false>
 __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
                                                    const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1158,14 +1241,21 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   long long* dbg = (long long*)(a.ws + w.dbg) + ((int64_t)b * NB + k) * 4;
   if (lane == 0) dbg[0] = wall_clock64();
 #endif
-  float* rows = (float*)smem + (size_t)wave * kBlk * C;  // [16][C] gradient rows, per wave
+  // Gradient rows of the wave: the dense LDS tile [16][C] (scattered into, copied out in one piece) for narrow rows,
+  // the COMPACT tile + column map (see compact_expand) for wide ones.
+  char* wbase = smem + (size_t)wave * (COMPACT ? compact_wave_bytes(C) : (size_t)kBlk * C * 4);
+  float* rows = (float*)wbase;
+  unsigned char* cmap = (unsigned char*)(wbase + (size_t)kBlk * 64 * 4);  // (COMPACT only)
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
   const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
   float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
-  for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+  if (COMPACT)
+    compact_init(rows, cmap, C, lane);
+  else
+    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
   if (LSM) {
     lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
-    lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf, lane);
+    if (!COMPACT) lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf, lane);
   }
   const int64_t o0 = a.offsets[b];
   const int L = (int)(a.offsets[b + 1] - o0);
@@ -1255,6 +1345,12 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   // of ds_add_f32 (see ctc_grad_body); the mask was computed once per utterance by its alpha chain workgroup
   const bool dup = has_label && ((dupmask >> lane) & 1ull) != 0;
   const bool uniq = has_label && !dup;
+  int slot = lane;  // COMPACT: where this lane's label accumulates
+  if (COMPACT) {
+    slot = __hip_atomic_load((const int32_t*)(a.ws + w.own) + (int64_t)b * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (has_label && slot == lane) cmap[y] = (unsigned char)lane;  // (first occurrences only: one writer per column)
+    if (lane == 0) cmap[a.blank] = 63;
+  }
   if (lane == 0) {  // this wave was the only consumer of the two flags: leave them cleared
     unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
     coherent_store64(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull);
@@ -1329,14 +1425,19 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
       const float gl = pa_l[j] * K * tl;
       gbv[j] = gb;
       wsum = fmaf(gb + gl, 1.f + (float)j * (1.f / 32.f), wsum);
-      if (uniq) rows[j * C + y] = (LSM ? rows[j * C + y] : 0.f) + gl;  // sole writer of this column
-      if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl);
+      if (COMPACT) {
+        if (uniq) rows[j * 64 + lane] = gl;
+        if (dup && gl != 0.f) atomicAdd(&rows[j * 64 + slot], gl);
+      } else {
+        if (uniq) rows[j * C + y] = (LSM ? rows[j * C + y] : 0.f) + gl;  // sole writer of this column
+        if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl);
+      }
       bb = tb * fb[j];
       bl = tl * fl[j];
     }
   }
   const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
-  if (lane < n && gtot != 0.f) atomicAdd(&rows[lane * C + a.blank], gtot);
+  if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * 64 + 63 : lane * C + a.blank], gtot);
   if (CERT) {
     // certificate, part two: the posteriors of every frame of the block must sum to one (the exponents are fixed
     // over the block; an occupancy that moves by more than the float range within 16 frames shows here; the
@@ -1352,11 +1453,13 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
       __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (LSM && !alive)  // no accepting path: zero gradient, softmax term included
+  if (LSM && !alive && !COMPACT)  // no accepting path: zero gradient, softmax term included
     for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
   // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
   float* dst = dx + ((int64_t)b * T + t0) * C;
-  const int total = n * C;
+  if (COMPACT)
+    compact_expand(rows, cmap, dst, a.x + ((int64_t)b * T + t0) * C, lse_blk, n, C, cf, alive, LSM && alive, lane);
+  const int total = COMPACT ? 0 : n * C;
   if ((((uintptr_t)dst) & 15) == 0) {
     const int n4 = total >> 2;
     for (int i = lane; i < n4; i += 64) ((float4*)dst)[i] = ((const float4*)rows)[i];
@@ -1369,13 +1472,14 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
 #endif
 }
 
+template <bool COMPACT>
 __global__ void __launch_bounds__(256)
     ctc_grad_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NB = ctc_blocks(a.T);
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, k) pairs
   const bool valid = item < (int64_t)a.B * NB;
-  ctc_grad_body<false>(a, valid, valid ? (int)(item / NB) : 0, valid ? (int)(item % NB) : 0, coef, gout, dx, smem);
+  ctc_grad_body<false, false, COMPACT>(a, valid, valid ? (int)(item / NB) : 0, valid ? (int)(item % NB) : 0, coef, gout, dx, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1388,7 +1492,7 @@ __global__ void __launch_bounds__(256)
 // items are numbered from the middle outwards and almost all of the gradient kernel's work
 // disappears behind the latency-bound chains, which leave most of every CU idle.
 // ------------------------------------------------------------------------------------------------
-template <bool LSM>
+template <bool LSM, bool COMPACT>
 __global__ void __launch_bounds__(256)
     ctc_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
                          float* __restrict__ dx) {
@@ -1412,7 +1516,7 @@ __global__ void __launch_bounds__(256)
   const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;  // r: rank in readiness order
   const int mid = (NB - 1) / 2;
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-  ctc_grad_body<true, LSM>(a, valid, b, k, coef, gout, dx, smem);
+  ctc_grad_body<true, LSM, COMPACT>(a, valid, b, k, coef, gout, dx, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1422,7 +1526,7 @@ __global__ void __launch_bounds__(256)
 // utterances -- chains and gradient -- in the log domain.  On data the fast chains can represent the
 // repair launch exits at once.
 // ------------------------------------------------------------------------------------------------
-template <bool LSM>
+template <bool LSM, bool COMPACT>
 __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_eu(6, 6)))  // <= 80 VGPRs: three workgroups per CU
     ctc_fast_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
                               float* __restrict__ dx) {
@@ -1444,7 +1548,7 @@ __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_
   const int r = item / a.B, b = item % a.B;  // r: rank in readiness order
   const int mid = (NB - 1) / 2;
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-  ctc_fast_grad_body<LSM, true>(a, true, b, k, coef, gout, dx, smem);
+  ctc_fast_grad_body<LSM, true, COMPACT>(a, true, b, k, coef, gout, dx, smem);
 }
 
 #ifdef WFL_DBG_GRADONLY  // (register counts of the two halves alone: hipcc -S -DWFL_DBG_GRADONLY)
@@ -1454,11 +1558,11 @@ __global__ void __launch_bounds__(kFWaves * 64) dbg_fast_chain_only(CtcArgs a) {
 }
 __global__ void __launch_bounds__(kFWaves * 64) dbg_fast_grad_only(CtcArgs a, const float* coef, const float* gout, float* dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  ctc_fast_grad_body<false, true>(a, true, (int)blockIdx.x, (int)blockIdx.y, coef, gout, dx, smem);
+  ctc_fast_grad_body<false, true, false>(a, true, (int)blockIdx.x, (int)blockIdx.y, coef, gout, dx, smem);
 }
 #endif
 
-template <bool LSM>
+template <bool LSM, bool COMPACT>
 __global__ void __launch_bounds__(256)
     ctc_repair_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1491,7 +1595,7 @@ __global__ void __launch_bounds__(256)
   for (int64_t item = (int64_t)(blockIdx.x - nchain) * 4 + (threadIdx.x >> 6); item < (int64_t)a.B * NB; item += stride) {
     const int r = (int)(item / a.B), b = (int)(item % a.B);  // r: rank in readiness order
     const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-    ctc_grad_body<true, LSM>(a, utterance_rejected_wave(a, w, b, lane), b, k, coef, gout, dx, smem);
+    ctc_grad_body<true, LSM, COMPACT>(a, utterance_rejected_wave(a, w, b, lane), b, k, coef, gout, dx, smem);
   }
 }
 
@@ -1970,8 +2074,11 @@ static int ctc_check(int B, int T, int C, int max_len, int blank, const char* wh
     set_error("%s: target length %d exceeds four positions per lane (use the lattice engine)", who, max_len);
     return WFL_ERR_UNSUPPORTED;
   }
-  if ((size_t)4 * (kBlk + 1) * C * 4 > (size_t)kLdsBytes) {
-    set_error("%s: C=%d too large for the LDS row tiles of the gradient kernel (use the lattice engine)", who, C);
+  // gradient tiles in LDS: dense [17][C] per wave for long targets, compact [16][64] + C bytes otherwise
+  const bool wide = max_len + 1 > 64 ? (size_t)4 * (kBlk + 1) * C * 4 > (size_t)kLdsBytes
+                                     : (size_t)8 * ((size_t)kBlk * 64 * 4 + ((C + 15) & ~15)) > (size_t)kLdsBytes;
+  if (wide) {
+    set_error("%s: C=%d too large for the LDS tiles of the gradient kernel (use the lattice engine)", who, C);
     return WFL_ERR_UNSUPPORTED;
   }
   return WFL_OK;
@@ -2053,7 +2160,9 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   const int64_t items = (int64_t)B * ctc_blocks(T);
   const int ppl = (max_len + 1 + 63) / 64;  // target positions per lane
   const dim3 grid((unsigned)(2 * B + (items + 3) / 4));
-  const size_t rows_lds = (size_t)4 * (kBlk + 1) * C * 4;
+  // log-domain kernels (4-wave workgroups): dense row tiles while five workgroups share a CU with them, compact beyond
+  const bool lcompact = ppl == 1 && C > 120;
+  const size_t rows_lds = lcompact ? (size_t)4 * ((size_t)kBlk * 64 * 4 + ((C + 15) & ~15)) : (size_t)4 * (kBlk + 1) * C * 4;
   auto launch = [&](auto kern, size_t chain_lds) -> int {
     const size_t lds = std::max(rows_lds, chain_lds);
     if (lds > (size_t)kLdsBytes) {
@@ -2073,8 +2182,15 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     return e && std::string(e) == "log";
   }();
   const size_t rows8_lds = (size_t)kFWaves * kBlk * C * 4;
-  if (ppl == 1 && !force_log && rows8_lds <= (size_t)kLdsBytes) {
-    const size_t lds = std::max(rows8_lds, sizeof(FastLdsT));
+  // gradient rows as a dense LDS tile while three workgroups still fit a CU with it (C <= 100), compact beyond
+  static const int force_tile = [] {
+    const char* e = getenv("WFL_CTC_ROWS");  // "dense" / "compact": measurements
+    return !e ? -1 : std::string(e) == "compact" ? 1 : 0;
+  }();
+  const size_t compact_lds = (size_t)kFWaves * ((size_t)kBlk * 64 * 4 + ((C + 15) & ~15));
+  const bool compact = force_tile >= 0 ? force_tile == 1 : 3 * std::max(rows8_lds, sizeof(FastLdsT)) > (size_t)kLdsBytes;
+  if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
+    const size_t lds = std::max(compact ? compact_lds : rows8_lds, sizeof(FastLdsT));
     static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)
     const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : (items + kFWaves - 1) / kFWaves)));
     auto launch_fast = [&](auto kern) -> int {
@@ -2082,7 +2198,8 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       hipLaunchKernelGGL(kern, grid8, dim3(kFWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
       return WFL_OK;
     };
-    rc = row_lse ? launch_fast(ctc_fast_pipelined_kernel<true>) : launch_fast(ctc_fast_pipelined_kernel<false>);
+    rc = compact ? (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, true>) : launch_fast(ctc_fast_pipelined_kernel<false, true>))
+                 : (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, false>) : launch_fast(ctc_fast_pipelined_kernel<false, false>));
     if (rc) return rc;
     WFL_LAUNCH_CHECK();
     a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
@@ -2095,10 +2212,13 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       hipLaunchKernelGGL(kern, rgrid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
       return WFL_OK;
     };
-    rc = row_lse ? launch_repair(ctc_repair_kernel<true>) : launch_repair(ctc_repair_kernel<false>);
+    rc = lcompact ? (row_lse ? launch_repair(ctc_repair_kernel<true, true>) : launch_repair(ctc_repair_kernel<false, true>))
+                  : (row_lse ? launch_repair(ctc_repair_kernel<true, false>) : launch_repair(ctc_repair_kernel<false, false>));
   } else if (ppl == 1) {
-    rc = row_lse ? launch(ctc_pipelined_kernel<true>, sizeof(ChainLdsT))
-                 : launch(ctc_pipelined_kernel<false>, sizeof(ChainLdsT));
+    rc = lcompact ? (row_lse ? launch(ctc_pipelined_kernel<true, true>, sizeof(ChainLdsT))
+                             : launch(ctc_pipelined_kernel<false, true>, sizeof(ChainLdsT)))
+                  : (row_lse ? launch(ctc_pipelined_kernel<true, false>, sizeof(ChainLdsT))
+                             : launch(ctc_pipelined_kernel<false, false>, sizeof(ChainLdsT)));
   } else {
     a.loss_out = nullptr;  // the long-target chains do not reduce the loss in-kernel
     if (row_lse)
@@ -2126,15 +2246,16 @@ int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, co
   }
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, (float*)ws, (float*)nll};
   const int64_t items = (int64_t)B * ctc_blocks(T);
-  const size_t lds = (size_t)4 * (kBlk + 1) * C * 4;
   const int ppl = (max_len + 1 + 63) / 64;
+  const bool lcompact = ppl == 1 && C > 120;  // (see wfl_ctc_forward_backward)
+  const size_t lds = lcompact ? (size_t)4 * ((size_t)kBlk * 64 * 4 + ((C + 15) & ~15)) : (size_t)4 * (kBlk + 1) * C * 4;
   auto launch = [&](auto kern) -> int {
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
     return WFL_OK;
   };
-  if (int rc = ppl == 1   ? launch(ctc_grad_kernel)
+  if (int rc = ppl == 1   ? (lcompact ? launch(ctc_grad_kernel<true>) : launch(ctc_grad_kernel<false>))
                : ppl == 2 ? launch(ctc_long_grad_kernel<2>)
                : ppl == 3 ? launch(ctc_long_grad_kernel<3>)
                           : launch(ctc_long_grad_kernel<4>))

@@ -349,6 +349,13 @@ class CtcTargets:
 
 _CTC_WS_SIZES = {}
 CTC_FAST_MAX_LEN = 255  # longest target of the CTC fast path (four positions per lane); beyond: lattice engine
+CTC_FAST_MAX_CLASSES = 16000  # widest emission row of the CTC fast path (compact gradient tiles: 8 x (4 KB + C bytes) of LDS) ...
+CTC_FAST_MAX_CLASSES_LONG = 602  # ... and for targets of more than 63 labels (dense row tiles [17][C] per wave)
+
+
+def ctc_fast_path_ok(max_len, C):
+    """Does the CTC fast path (csrc/ctc_kernels.hip) take this shape?  Otherwise: the generic lattice engine."""
+    return max_len <= CTC_FAST_MAX_LEN and C <= (CTC_FAST_MAX_CLASSES if max_len <= 63 else CTC_FAST_MAX_CLASSES_LONG)
 CTC_DEFAULT_FLAGS = 0  # chain kernel used by the criteria (see include/wfl.h, WFL_CTC_FAST_CHAIN)
 
 

@@ -248,7 +248,8 @@ int wfl_conv_grad(const float* x, int B, int T, int C, const int32_t* ktab, int 
 /* ------------------------------------------------------------------------------------------------
  * Device kernels: CTC fast path (create_ctc_graph + intersect + forward_score + backward of
  * ctc.py:15-94; banded recursion with register-resident state, no lattice arrays).
- *   targets: device int32 flat, offsets: device int64 [B+1]; requires max target length <= 255
+ *   targets: device int32 flat, offsets: device int64 [B+1]; requires max target length <= 255 and
+ *   C <= 16384 (targets of more than 63 labels: C <= 602) -- the gradient tiles live in LDS
  *   (up to 63: one position per lane; longer: two to four positions per lane)
  *   (longer targets: WFL_ERR_UNSUPPORTED -> use wfl_lattice_pack_ctc + the lattice engine).
  *   loss_b = -logZ_b is written to nll[B]; dx = coef[b]*gout*posteriors (dense rows).
@@ -275,7 +276,7 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
 /* wfl_ctc_forward and wfl_ctc_grad as ONE pipelined launch: gradient waves wait for the checkpoints
  * they need and run while the chains are still sweeping.  Same outputs (nll, dx); posteriors are
  * normalised per 16-frame block by the Z the block reproduces.
- * Targets of up to 63 labels with C <= 300: chains and gradient blocks run in lane-exponent
+ * Targets of up to 63 labels: chains and gradient blocks run in lane-exponent
  * (probability-domain) arithmetic; every block certifies its result (log2 Z reproduced to 1.5e-4, the
  * posteriors of its frames sum to one to 2e-4) and a second, normally empty launch recomputes rejected
  * utterances in the log domain -- the caller always receives certified or log-domain results.

@@ -8,7 +8,7 @@ nbad = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     B = int(rs.choice([1, 2, 5, 17, 64, 130]))
     T = int(rs.choice([1, 5, 16, 17, 31, 32, 33, 100, 257, 640]))
-    C = int(rs.choice([2, 3, 8, 29, 100, 255, 300]))
+    C = int(rs.choice([2, 3, 8, 29, 100, 130, 255, 300, 513, 1001]))
     Lmax = int(min(63, rs.choice([0, 1, 3, 20, 44, 63])))
     sc = float(rs.choice([0.3, 1.0, 1.0, 1.7]))
     lsm = bool(rs.randint(2))

@@ -396,7 +396,7 @@ def test_ctc_fast_pipelined_step_random_shapes():
     for it in range(40):
         B = int(rs.choice([1, 2, 5, 17, 64, 130]))
         T = int(rs.choice([1, 5, 16, 17, 31, 32, 33, 100, 257, 640]))
-        C = int(rs.choice([2, 3, 8, 29, 100, 255, 300]))
+        C = int(rs.choice([2, 3, 8, 29, 100, 130, 255, 300, 513, 1001]))
         Lmax = int(rs.choice([0, 1, 3, 20, 44, 63]))
         sc = float(rs.choice([0.3, 1.0, 1.0, 1.7]))
         lsm = bool(rs.randint(2))
