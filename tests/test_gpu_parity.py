@@ -350,6 +350,31 @@ def test_ctc_fast_step_accepts_targets_that_cannot_be_aligned_without_repair():
     close(dx, np.nan_to_num(want_dx))
 
 
+@pytest.mark.parametrize("C", [513, 1001, 2500, 17001])
+def test_ctc_wide_rows_through_the_criterion(crit, C):
+    """word-piece sized vocabularies: compact gradient tiles on the CTC fast path (C <= 16384), the generic lattice
+    engine beyond -- CTCLoss and the CTC module (fused log_softmax) against the oracle"""
+    rs = np.random.RandomState(C)
+    B, T = 3, 50
+    x = rs.randn(B, T, C).astype(np.float32)
+    targets = [rs.randint(0, C - 1, size=n).tolist() for n in (7, 0, 12)]
+    targets[2][3] = targets[2][4] = targets[2][9]  # a repeated label: adjacent and apart
+    xt = dev(x, grad=True)
+    loss = crit["ctc"].CTCLoss(xt, targets, C - 1, "mean")
+    loss.backward()
+    want_loss, want_dx = OR.ctc_loss_grad(x, targets, C - 1, "mean")
+    assert loss.item() == pytest.approx(want_loss, rel=RTOL)
+    close(xt.grad, want_dx)
+    lp = OC.log_softmax(x.astype(np.float64))
+    want_loss, dlp = OR.ctc_loss_grad(lp, targets, C - 1, "mean")
+    want_dx = dlp - np.exp(lp) * dlp.sum(axis=2, keepdims=True)
+    xt = dev(x, grad=True)
+    loss = crit["ctc"].CTC(C - 1, False)(xt, [torch.tensor(t, dtype=torch.long) for t in targets])
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss, rel=RTOL)
+    close(xt.grad, want_dx)
+
+
 def test_ctc_pipeline_env_selects_log_domain_launch():
     """WFL_CTC_PIPELINE=log (read once per process): the log-domain pipelined launch serves the step, nothing is
     ever 'repaired', and the result agrees with the default (lane-exponent) step of this process"""
