@@ -218,21 +218,25 @@ __global__ void __launch_bounds__(256)
   const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());
   const int t_begin = blockIdx.x * rows_per_block, t_end = min(T, t_begin + rows_per_block);
   const int npairs = C * C;
+  const int64_t base = (int64_t)b * T * C;
+  // NP * 256 transition pairs per pass over the block's frames (one pass up to C = 128; wider matrices stream the
+  // frames again for the next slice of pairs -- a fallback, not a fast path)
+  for (int pass0 = 0; pass0 < (partial ? npairs : 1); pass0 += NP * NT) {
+  const bool first_pass = pass0 == 0;
   float acc[NP], wreg[NP];
   int pij[NP];  // (i << 16) | j
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    const int p = tid + k * NT;
+    const int p = pass0 + tid + k * NT;
     acc[k] = 0.f;
     pij[k] = p < npairs ? ((p / C) << 16) | (p % C) : 0;
     wreg[k] = p < npairs ? nan_to_neg(W[C + p]) : WFL_NEG_INF;  // W[1+i, j]
   }
-  const int64_t base = (int64_t)b * T * C;
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
     for (int i = tid; i < C; i += NT) {
       const float a = alpha[base + (int64_t)t * C + i], be = beta[base + (int64_t)t * C + i];
-      if (dx) {
+      if (dx && first_pass) {
         const float post = dead ? 0.f : fast_exp(a + be - z);
         const int64_t o = base + (int64_t)t * C + i;
         dx[o] = (accumulate ? dx[o] : 0.f) + cf * (post == post ? post : 0.f);
@@ -255,20 +259,22 @@ __global__ void __launch_bounds__(256)
   if (partial) {
     float* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(C + 1) * C;
     // start arcs: posterior of frame 0 (only the block that owns t = 0)
-    for (int i = tid; i < C; i += NT) {
-      float v = 0.f;
-      if (t_begin == 0 && !dead) {
-        const float p = fast_exp(alpha[base + i] + beta[base + i] - z);
-        v = (p == p) ? p * cw : 0.f;
+    if (first_pass)
+      for (int i = tid; i < C; i += NT) {
+        float v = 0.f;
+        if (t_begin == 0 && !dead) {
+          const float p = fast_exp(alpha[base + i] + beta[base + i] - z);
+          v = (p == p) ? p * cw : 0.f;
+        }
+        dst[i] = v;
       }
-      dst[i] = v;
-    }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const int p = tid + k * NT;
+      const int p = pass0 + tid + k * NT;
       if (p < npairs) dst[C + p] = acc[k] * cw;
     }
   }
+  }  // pass
 }
 
 // dW[i] += sum_k partial[k][i]: 32 elements x 8 slices of the partials per workgroup, merged in LDS
@@ -849,14 +855,10 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
     WFL_DENSE_GRAD(16);
   else if (np <= 40)
     WFL_DENSE_GRAD(40);
-  else if (np <= 64)
-    WFL_DENSE_GRAD(64);
   else if (!dW)
     WFL_DENSE_GRAD(4);  // emission gradient only: the pair accumulators are unused
-  else {
-    set_error("dense_grad: C=%d too large for the register-resident transition-gradient kernel", C);
-    return WFL_ERR_UNSUPPORTED;
-  }
+  else
+    WFL_DENSE_GRAD(64);  // (C > 128: several passes over the frames, 16384 transition pairs each)
 #undef WFL_DENSE_GRAD
   WFL_LAUNCH_CHECK();
   if (dW) {

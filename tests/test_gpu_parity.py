@@ -676,6 +676,26 @@ def test_dense_probability_domain_sweeps_every_padding_bucket(C, T):
     _dense_check(x, W, [False] * B)
 
 
+@pytest.mark.parametrize("C", [130, 188])
+def test_asg_beyond_128_classes(crit, C):
+    """ASG up to the limit of the LDS-resident transition matrix (about 190 classes): the log-domain kernels serve
+    everything above 128, the transition gradient in several passes over the frames"""
+    rs = np.random.RandomState(C)
+    B, T = 2, 40
+    x = rs.randn(B, T, C).astype(np.float32)
+    W = (0.3 * rs.randn(C + 1, C)).astype(np.float32)
+    targets = [rs.randint(0, C, size=n).tolist() for n in (5, 9)]
+    xt, Wt = dev(x, grad=True), dev(W, grad=True)
+    loss = crit["asg"].ASGLoss(xt, Wt, targets, "mean")
+    loss.backward()
+    want = OR.asg_loss_grad(x, W, targets, "mean")
+    assert loss.item() == pytest.approx(want[0], rel=RTOL)
+    close(xt.grad, want[1])
+    close(Wt.grad, want[2], atol=2e-4)
+    with pytest.raises(Exception, match="does not fit the LDS-resident transition matrix"):
+        crit["asg"].ASGLoss(dev(rs.randn(1, 10, 300).astype(np.float32)), dev(np.zeros((301, 300), np.float32)), [[1, 2]], "mean")
+
+
 def test_dense_more_classes_than_the_fast_path_supports():
     rs = np.random.RandomState(5)
     x = rs.randn(2, 25, 150).astype(np.float32)
