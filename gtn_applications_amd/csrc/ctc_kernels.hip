@@ -34,7 +34,7 @@
 // ONE launch, the gradient waves waiting on device-coherent per-block flags while the chains sweep; its chains
 // and gradient blocks run in lane-exponent (probability-domain) arithmetic, every block certifies what it
 // computed, and ctc_repair_kernel re-runs rejected utterances with the log-domain bodies.  ctc_pipelined_kernel
-// is the same single launch with the log-domain bodies throughout (C > 300, WFL_CTC_PIPELINE=log, long targets).
+// is the same single launch with the log-domain bodies throughout (WFL_CTC_PIPELINE=log, long targets).
 // ctc_log_chain_kernel + ctc_grad_kernel (+ wfl_reduce_loss) are the three-launch step behind
 // wfl_ctc_forward / wfl_ctc_grad; WFL_CTC_FAST_CHAIN selects ctc_fast_chain_kernel + ctc_certify_kernel there.
 #include <atomic>
