@@ -961,45 +961,49 @@ __device__ __forceinline__ void lsm_seed_rows(float* rows, const float* __restri
   }
 }
 
-// COMPACT gradient tile (wide rows): the wave accumulates a block's posteriors in [16][64] floats -- one slot per
-// target position (the slot of a repeated label is the lane of its first occurrence), slot 63 the blank -- next to
-// a column -> slot byte map (255: no slot), and the dense rows are expanded while they are written:
-//   dx[t0 + j, c] = tile[j][slot(c)] (0 without a slot)  - cf * softmax(x)[c] (fused log_softmax).
+// COMPACT gradient tile (wide rows): the wave accumulates a block's posteriors in [16][65] floats -- one slot per
+// target position (the slot of a repeated label is the lane of its first occurrence), slot 63 the blank, slot 64
+// zero -- next to a column -> slot byte map, and the dense rows are expanded while they are written:
+//   dx[t0 + j, c] = tile[j][slot(c)]  - cf * softmax(x)[c] (fused log_softmax).
 // The dense LDS tile [16][C] of the narrow case would leave a single gradient workgroup per CU from C = 160 on and
 // does not fit at all beyond C = 602.
-__device__ __forceinline__ size_t compact_wave_bytes(int C) { return (size_t)kBlk * 64 * 4 + ((C + 15) & ~15); }
+// Tile rows are kCS = 65 floats: slots 0..62 target positions, 63 the blank, 64 a constant zero that every column
+// without a slot maps to -- the expansion reads the tile unconditionally (four ds_read_b32 + one global store per
+// float4; with a "no slot" test per element it was five times as many instructions).
+constexpr int kCS = 65;
+constexpr int kCTileBytes = kBlk * kCS * 4;  // 4160
+__host__ __device__ __forceinline__ size_t compact_wave_bytes(int C) { return (size_t)kCTileBytes + ((C + 15) & ~15); }
 __device__ __forceinline__ void compact_init(float* tile, unsigned char* cmap, int C, int lane) {
-  for (int i = lane; i < kBlk * 64; i += 64) tile[i] = 0.f;
-  for (int i = lane; i < ((C + 15) & ~15) / 4; i += 64) ((unsigned int*)cmap)[i] = 0xffffffffu;
+  for (int i = lane; i < kBlk * kCS; i += 64) tile[i] = 0.f;
+  for (int i = lane; i < ((C + 15) & ~15) / 4; i += 64) ((unsigned int*)cmap)[i] = 0x40404040u;  // 64: the zero slot
 }
 __device__ __forceinline__ void compact_expand(const float* tile, const unsigned char* cmap, float* __restrict__ dst,
                                                const float* __restrict__ xsrc, float lse_blk, int n, int C, float cf,
                                                bool alive, bool soft, int lane) {
-  auto value = [&](int j, unsigned sl, float xv, float l) {
-    float v = (sl != 255u && alive) ? tile[j * 64 + (int)sl] : 0.f;
-    if (soft && l > WFL_NEG_INF) v -= cf * __expf((xv == xv ? xv : WFL_NEG_INF) - l);
-    return v;
-  };
-  if ((C & 3) == 0 && (((uintptr_t)dst) & 15) == 0 && (!soft || (((uintptr_t)xsrc) & 15) == 0)) {
-    const int c4n = C >> 2;
+  auto softterm = [&](float xv, float l) { return l > WFL_NEG_INF ? cf * __expf((xv == xv ? xv : WFL_NEG_INF) - l) : 0.f; };
+  // (rows of dx start at any 4-byte boundary: global dwordx4 accesses only need dword alignment, the type says so)
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int c4n = C >> 2;
 #pragma unroll 2
-    for (int j = 0; j < n; ++j) {
-      const float l = soft ? readlane_f(lse_blk, j) : 0.f;
-      for (int c4 = lane; c4 < c4n; c4 += 64) {
-        const unsigned m4 = ((const unsigned int*)cmap)[c4];
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (soft) xv = ((const float4*)(xsrc + (int64_t)j * C))[c4];
-        float4 o;
-        o.x = value(j, m4 & 255u, xv.x, l), o.y = value(j, (m4 >> 8) & 255u, xv.y, l);
-        o.z = value(j, (m4 >> 16) & 255u, xv.z, l), o.w = value(j, m4 >> 24, xv.w, l);
-        ((float4*)(dst + (int64_t)j * C))[c4] = o;
+  for (int j = 0; j < n; ++j) {  // row after row: whole rows leave in address order
+    const float l = soft ? readlane_f(lse_blk, j) : 0.f;
+    const float* tr = tile + j * kCS;
+    float* drow = dst + (int64_t)j * C;
+    const float* xr = xsrc + (int64_t)j * C;
+    for (int c4 = lane; c4 < c4n; c4 += 64) {
+      const unsigned m4 = alive ? ((const unsigned int*)cmap)[c4] : 0x40404040u;
+      f4u o = {tr[m4 & 255u], tr[(m4 >> 8) & 255u], tr[(m4 >> 16) & 255u], tr[m4 >> 24]};
+      if (soft) {
+        const f4u xv = *reinterpret_cast<const f4u*>(xr + 4 * c4);
+        o.x -= softterm(xv.x, l), o.y -= softterm(xv.y, l), o.z -= softterm(xv.z, l), o.w -= softterm(xv.w, l);
       }
+      *reinterpret_cast<f4u*>(drow + 4 * c4) = o;
     }
-  } else {
-    for (int j = 0; j < n; ++j) {
-      const float l = soft ? readlane_f(lse_blk, j) : 0.f;
-      for (int c = lane; c < C; c += 64)
-        dst[(int64_t)j * C + c] = value(j, cmap[c], soft ? xsrc[(int64_t)j * C + c] : 0.f, l);
+    const int c = 4 * c4n + lane;  // the last C % 4 columns
+    if (c < C) {
+      float v = tr[alive ? (int)cmap[c] : 64];
+      if (soft) v -= softterm(xr[c], l);
+      drow[c] = v;
     }
   }
 }
@@ -1019,7 +1023,7 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
   char* wbase = smem + (size_t)wave * (COMPACT ? compact_wave_bytes(C) : (size_t)(kBlk + 1) * C * 4);
   float* rows = (float*)wbase;
   int* cnt = (int*)(rows + (size_t)kBlk * C);                             // (dense tile only)
-  unsigned char* cmap = (unsigned char*)(wbase + (size_t)kBlk * 64 * 4);  // (COMPACT only)
+  unsigned char* cmap = (unsigned char*)(wbase + (size_t)kCTileBytes);  // (COMPACT only)
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
   bool live = valid && (PIPE || a.nll[b] < __builtin_inff());  // no accepting path: zero gradient
   constexpr bool lsm = PIPE && LSM;  // fused log_softmax (raw scores in x)
@@ -1174,8 +1178,8 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
         // serialise per active lane; one wave reduction per frame costs 18 instructions x 16)
         gbv[j] = gb;
         if (COMPACT) {
-          if (uniq) rows[j * 64 + lane] = gl * cf;
-          if (dup && gl != 0.f) atomicAdd(&rows[j * 64 + slot], gl * cf);
+          if (uniq) rows[j * kCS + lane] = gl * cf;
+          if (dup && gl != 0.f) atomicAdd(&rows[j * kCS + slot], gl * cf);
         } else {
           if (uniq) rows[j * C + y] = (lsm ? rows[j * C + y] : 0.f) + gl * cf;  // sole writer of this column
           if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
@@ -1185,7 +1189,7 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
       }
     }
     const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
-    if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * 64 + 63 : lane * C + a.blank], gtot * cf);
+    if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * kCS + 63 : lane * C + a.blank], gtot * cf);
     if (PIPE) alive_blk = U > 0.5f * kNegBig;
     if (lsm && !alive_blk && !COMPACT)  // no accepting path: zero gradient, softmax term included
       for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
@@ -1245,7 +1249,7 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   // the COMPACT tile + column map (see compact_expand) for wide ones.
   char* wbase = smem + (size_t)wave * (COMPACT ? compact_wave_bytes(C) : (size_t)kBlk * C * 4);
   float* rows = (float*)wbase;
-  unsigned char* cmap = (unsigned char*)(wbase + (size_t)kBlk * 64 * 4);  // (COMPACT only)
+  unsigned char* cmap = (unsigned char*)(wbase + (size_t)kCTileBytes);  // (COMPACT only)
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
   const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
   float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
@@ -1426,8 +1430,8 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
       gbv[j] = gb;
       wsum = fmaf(gb + gl, 1.f + (float)j * (1.f / 32.f), wsum);
       if (COMPACT) {
-        if (uniq) rows[j * 64 + lane] = gl;
-        if (dup && gl != 0.f) atomicAdd(&rows[j * 64 + slot], gl);
+        if (uniq) rows[j * kCS + lane] = gl;
+        if (dup && gl != 0.f) atomicAdd(&rows[j * kCS + slot], gl);
       } else {
         if (uniq) rows[j * C + y] = (LSM ? rows[j * C + y] : 0.f) + gl;  // sole writer of this column
         if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl);
@@ -1437,7 +1441,7 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
     }
   }
   const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
-  if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * 64 + 63 : lane * C + a.blank], gtot);
+  if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * kCS + 63 : lane * C + a.blank], gtot);
   if (CERT) {
     // certificate, part two: the posteriors of every frame of the block must sum to one (the exponents are fixed
     // over the block; an occupancy that moves by more than the float range within 16 frames shows here; the
@@ -2076,7 +2080,7 @@ static int ctc_check(int B, int T, int C, int max_len, int blank, const char* wh
   }
   // gradient tiles in LDS: dense [17][C] per wave for long targets, compact [16][64] + C bytes otherwise
   const bool wide = max_len + 1 > 64 ? (size_t)4 * (kBlk + 1) * C * 4 > (size_t)kLdsBytes
-                                     : (size_t)8 * ((size_t)kBlk * 64 * 4 + ((C + 15) & ~15)) > (size_t)kLdsBytes;
+                                     : (size_t)8 * compact_wave_bytes(C) > (size_t)kLdsBytes;
   if (wide) {
     set_error("%s: C=%d too large for the LDS tiles of the gradient kernel (use the lattice engine)", who, C);
     return WFL_ERR_UNSUPPORTED;
@@ -2162,7 +2166,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   const dim3 grid((unsigned)(2 * B + (items + 3) / 4));
   // log-domain kernels (4-wave workgroups): dense row tiles while five workgroups share a CU with them, compact beyond
   const bool lcompact = ppl == 1 && C > 120;
-  const size_t rows_lds = lcompact ? (size_t)4 * ((size_t)kBlk * 64 * 4 + ((C + 15) & ~15)) : (size_t)4 * (kBlk + 1) * C * 4;
+  const size_t rows_lds = lcompact ? (size_t)4 * compact_wave_bytes(C) : (size_t)4 * (kBlk + 1) * C * 4;
   auto launch = [&](auto kern, size_t chain_lds) -> int {
     const size_t lds = std::max(rows_lds, chain_lds);
     if (lds > (size_t)kLdsBytes) {
@@ -2187,7 +2191,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     const char* e = getenv("WFL_CTC_ROWS");  // "dense" / "compact": measurements
     return !e ? -1 : std::string(e) == "compact" ? 1 : 0;
   }();
-  const size_t compact_lds = (size_t)kFWaves * ((size_t)kBlk * 64 * 4 + ((C + 15) & ~15));
+  const size_t compact_lds = (size_t)kFWaves * compact_wave_bytes(C);
   const bool compact = force_tile >= 0 ? force_tile == 1 : 3 * std::max(rows8_lds, sizeof(FastLdsT)) > (size_t)kLdsBytes;
   if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
     const size_t lds = std::max(compact ? compact_lds : rows8_lds, sizeof(FastLdsT));
@@ -2248,7 +2252,7 @@ int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, co
   const int64_t items = (int64_t)B * ctc_blocks(T);
   const int ppl = (max_len + 1 + 63) / 64;
   const bool lcompact = ppl == 1 && C > 120;  // (see wfl_ctc_forward_backward)
-  const size_t lds = lcompact ? (size_t)4 * ((size_t)kBlk * 64 * 4 + ((C + 15) & ~15)) : (size_t)4 * (kBlk + 1) * C * 4;
+  const size_t lds = lcompact ? (size_t)4 * compact_wave_bytes(C) : (size_t)4 * (kBlk + 1) * C * 4;
   auto launch = [&](auto kern) -> int {
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
