@@ -1,7 +1,7 @@
 """Counterpart of the reference's benchmarks/transducer_benchmark.py: the same three scenarios
 (word-piece decompositions; CTC-like and ASG-like token graphs with n-gram transitions, n = 0, 1, 2),
-same shapes, same 20-iteration protocol.  The reference reads benchmarks/word_pieces_tokens_1000.txt,
-which is not shipped here: 1000 synthetic pieces with the same length statistics stand in.
+same shapes, same 20-iteration protocol, the reference's own token list
+(benchmarks/word_pieces_tokens_1000.txt: 1000 word pieces over 78 graphemes -- a data file, shipped as a fixture).
 Usage: python benchmarks/transducer_benchmark.py [B]"""
 import os
 import random
@@ -23,12 +23,10 @@ torch.manual_seed(0)
 
 
 def word_decompositions():
-    letters = "abcdefghijklmnopqrstuvwxyz"
-    pieces = set(letters)
-    while len(pieces) < 1000:
-        pieces.add("".join(random.choice(letters) for _ in range(random.choice([2, 3, 4, 5, 6, 7]))))
-    tokens = sorted(pieces)
-    graphemes_to_index = {t: i for i, t in enumerate(letters)}
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "word_pieces_tokens_1000.txt"), "r") as fid:
+        tokens = sorted([l.strip() for l in fid])
+    graphemes = sorted(set(c for t in tokens for c in t))
+    graphemes_to_index = {t: i for i, t in enumerate(graphemes)}
     N, T, L = len(tokens) + 1, 100, 15
     inputs = torch.randn(B, T, N, dtype=torch.float).cuda().requires_grad_(True)
     targets = [torch.tensor([graphemes_to_index[c] for _ in range(L) for c in random.choice(tokens)]) for _ in range(B)]

@@ -4,7 +4,7 @@ gfx950 HIP kernels behind the C ABI of include/wfl.h (libwfl.so).  See DESIGN.md
 from . import _native  # noqa: F401  (fails loudly if libwfl.so is missing)
 from . import graph  # noqa: F401
 
-__all__ = ["graph", "criterions", "engine", "load_criterion"]
+__all__ = ["graph", "criterions", "engine", "load_criterion", "load_from_checkpoint"]
 
 
 def load_criterion(criterion_type, preprocessor, config):
@@ -25,7 +25,10 @@ def load_criterion(criterion_type, preprocessor, config):
         blank = config.get("blank", "none")
         transitions = config.get("transitions", None)
         if transitions is not None:
-            transitions = G.load(transitions)  # text format (gtn's binary format is unpinned)
+            # utils.py:261 reads this file with gtn.load.  G.load accepts gtn's text format (pinned by the
+            # reference's tests/trans_backoff_test.txt) and gtn's binary layout as restated in include/wfl.h
+            # (UNPINNED: gtn is not vendored); a file that is consistently neither raises instead of being mis-read.
+            transitions = G.load(transitions)
         criterion = transducer.Transducer(
             preprocessor.tokens,
             preprocessor.graphemes_to_index,
@@ -38,3 +41,15 @@ def load_criterion(criterion_type, preprocessor, config):
         return criterion, num_tokens + int(blank != "none")
     else:
         raise ValueError(f"Unknown model type {criterion_type}")
+
+
+def load_from_checkpoint(model, criterion, checkpoint_path, load_last=False):
+    """utils.py:276-283: restores `model.checkpoint[.best]` / `criterion.checkpoint[.best]`; the criteria's
+    parameter names (`transitions`, `transition_params`) are the reference's, so its checkpoints load."""
+    import os
+
+    import torch
+
+    suffix = "" if load_last else ".best"
+    model.load_state_dict(torch.load(os.path.join(checkpoint_path, "model.checkpoint" + suffix)))
+    criterion.load_state_dict(torch.load(os.path.join(checkpoint_path, "criterion.checkpoint" + suffix)))

@@ -91,6 +91,8 @@ _SIGS = {
     "wfl_graph_isomorphic": (c_int, [_P, _P]),
     "wfl_graph_loadtxt": (_P, [c_char_p]),
     "wfl_graph_savetxt": (c_int, [_P, c_char_p]),
+    "wfl_graph_load": (_P, [c_char_p]),
+    "wfl_graph_save": (c_int, [_P, c_char_p]),
     # lattice packing
     "wfl_lattice_pack": (_P, [_P, _P, c_int, c_int, c_int, c_int]),
     "wfl_lattice_pack_ctc": (_P, [_P, _P, c_int, c_int, c_int]),

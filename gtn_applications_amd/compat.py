@@ -3,7 +3,8 @@
 `from utils import ASGLoss` (benchmarks/asg_benchmark.py:13), `import transducer`
 (benchmarks/transducer_benchmark.py:13, tests/transducer_test.py:17-19),
 `utils.pack_replabels` (tests/utils_test.py:19), `from criterions import ctc, asg, transducer`
-(utils.py:19), `utils.load_criterion` (utils.py:245-273; callers train.py:201, test.py:75).  `install()` registers them in `sys.modules`; nothing is copied or patched on disk.
+(utils.py:19), `utils.load_criterion` (utils.py:245-273; callers train.py:201, test.py:75), and `models.load_criterion` /
+`models.load_from_checkpoint` (test.py:77-86; `models.load_model` builds acoustic models and is the caller's).  `install()` registers them in `sys.modules`; nothing is copied or patched on disk.
 """
 import sys
 import types
@@ -22,10 +23,18 @@ def install(gtn_alias=False):
         utils = types.ModuleType("utils")
         utils.__doc__ = "criterion names of the reference's former flat layout (gtn_applications_amd.compat)"
         sys.modules["utils"] = utils
-    from . import load_criterion
+    from . import load_criterion, load_from_checkpoint
 
+    models = sys.modules.get("models")
+    if models is None:
+        models = types.ModuleType("models")
+        models.__doc__ = "criterion-side names test.py expects under `models` (gtn_applications_amd.compat)"
+        sys.modules["models"] = models
+    for name, obj in dict(load_criterion=load_criterion, load_from_checkpoint=load_from_checkpoint).items():
+        if not hasattr(models, name):
+            setattr(models, name, obj)
     for name, obj in dict(
-        load_criterion=load_criterion, CTCLoss=ctc.CTCLoss, CTCLossFunction=ctc.CTCLossFunction, ASGLoss=asg.ASGLoss,
+        load_criterion=load_criterion, load_from_checkpoint=load_from_checkpoint, CTCLoss=ctc.CTCLoss, CTCLossFunction=ctc.CTCLossFunction, ASGLoss=asg.ASGLoss,
         ASGLossFunction=asg.ASGLossFunction, pack_replabels=asg.pack_replabels,
         unpack_replabels=asg.unpack_replabels, STCLoss=stc.STCLoss,
     ).items():

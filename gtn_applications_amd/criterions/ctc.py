@@ -42,6 +42,9 @@ class CTCLossFunction(torch.autograd.Function):
         tg = E.targets_on_device(targets, dev)
         if tg.B != B:
             raise ValueError(f"got {tg.B} targets for a batch of {B}")
+        E.check_labels(tg, C, "CTCLoss")
+        if not 0 <= int(blank_idx) < C:
+            raise ValueError(f"CTCLoss: blank index {blank_idx} is outside [0, {C})")
         scale, _, coef = E.loss_factors(tg, reduction)  # loss scale; gradient coefficient -scale/B
         need_grad = log_probs.requires_grad
         if E.ctc_fast_path_ok(tg.max_len, C) and need_grad:
@@ -51,7 +54,7 @@ class CTCLossFunction(torch.autograd.Function):
             lse = E.row_lse(x) if ctx_log_softmax(ctx) else None
             _, _, loss = E.ctc_forward_backward(x, tg, int(blank_idx), coef, None, dx, loss_scale=scale, want_loss=True,
                                                 lse=lse)
-            ctx.aux = ("pipelined", x, tg, int(blank_idx), dx, coef)
+            ctx.aux = ("pipelined", x, tg, int(blank_idx), dx, coef, lse)
         elif ctx_log_softmax(ctx):
             raise RuntimeError("fused log_softmax CTC is only used on the pipelined path")
         elif E.ctc_fast_path_ok(tg.max_len, C):
@@ -74,14 +77,16 @@ class CTCLossFunction(torch.autograd.Function):
         kind, x = ctx.aux[0], ctx.aux[1]
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
         if kind == "pipelined":
-            _, _, tg, blank, dx, coef = ctx.aux
-            if dx is None:  # a second backward through a retained graph: recompute with the two-kernel step
+            _, _, tg, blank, dx, coef, lse = ctx.aux
+            if dx is None:
+                # a second backward through a retained graph: the eager gradient was handed out (and scaled in
+                # place) by the first one, so run the same launch again -- with the same row log-sum-exps when
+                # the log_softmax is fused -- into a fresh buffer, the upstream scalar applied by the kernel
                 dx = torch.empty_like(x)
-                ws, nll = E.ctc_forward(x, tg, blank)
-                E.ctc_grad(x, tg, blank, ws, nll, coef, gout, dx)
+                E.ctc_forward_backward(x, tg, blank, coef, gout, dx, lse=lse)
             else:
                 E.scale_inplace(dx, gout)
-                ctx.aux = ("pipelined", x, tg, blank, None, coef)
+                ctx.aux = ("pipelined", x, tg, blank, None, coef, lse)
         elif kind == "fast":
             raise RuntimeError("CTCLoss: backward through an input that did not require grad in forward")
         else:

@@ -3,10 +3,12 @@
 // Replaces the corresponding entry points of the external `gtn` library; the
 // call sites are cited in include/wfl.h.  Pure host code, never touches the GPU.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <iterator>
 #include <functional>
 #include <limits>
 #include <numeric>
@@ -535,7 +537,8 @@ wfl_graph* wfl_graph_loadtxt(const char* path) {
     A a{0, 0, 0, 0, 0.f};
     if (!(ss >> a.s >> a.d >> a.il)) continue;
     if (!(ss >> a.ol)) a.ol = a.il;
-    if (!(ss >> a.w)) a.w = 0.f;
+    std::string wtok;  // strtof, not operator>>: "-inf" / "nan" are legal weights (hard constraints)
+    a.w = (ss >> wtok) ? std::strtof(wtok.c_str(), nullptr) : 0.f;
     arcs.push_back(a);
     maxn = std::max(maxn, std::max(a.s, a.d));
   }
@@ -565,6 +568,97 @@ int wfl_graph_savetxt(const wfl_graph* g, const char* path) {
   for (int64_t k = 0; k < g->num_arcs(); ++k)
     out << g->src[k] << " " << g->dst[k] << " " << g->il[k] << " " << g->ol[k] << " " << g->w[k] << "\n";
   return WFL_OK;
+}
+
+// ---- gtn.save / gtn.load (utils.py:261 reads config["transitions"] with gtn.load; build_transitions.py:221
+// writes it with gtn.save).  gtn is not vendored, so the layout is restated from gtn's published utils.cpp and is
+// UNPINNED: four int32 counts (num_nodes + the numbers of start nodes, accept nodes and arcs), the start ids, the
+// accept ids, then per arc {src, dst, ilabel, olabel : int32, weight : float32}, little endian.  The order of the
+// three trailing counts is not something this tree can check against gtn, so the reader accepts the two
+// plausible orders and picks the one that is consistent with the file size and with every id being in range;
+// a file that fits neither is rejected loudly instead of being mis-parsed.
+static wfl_graph* parse_binary(const std::vector<char>& buf, const char* path) {
+  const int64_t size = (int64_t)buf.size();
+  if (size < 16) {
+    wfl::set_error("load: %s is too short for a binary graph header", path);
+    return nullptr;
+  }
+  int32_t h[4];
+  std::memcpy(h, buf.data(), 16);
+  const int64_t n = h[0];
+  // (num_start, num_accept, num_arcs) candidates: {nodes, start, accept, arcs} and {nodes, arcs, start, accept}
+  const int64_t cand[2][3] = {{h[1], h[2], h[3]}, {h[2], h[3], h[1]}};
+  for (int c = 0; c < 2; ++c) {
+    const int64_t ns = cand[c][0], na = cand[c][1], m = cand[c][2];
+    if (n < 0 || ns < 0 || na < 0 || m < 0 || ns > n || na > n) continue;
+    if (16 + 4 * (ns + na) + 20 * m != size) continue;
+    const char* p = buf.data() + 16;
+    std::vector<int32_t> st(ns), ac(na);
+    std::memcpy(st.data(), p, 4 * ns), p += 4 * ns;
+    std::memcpy(ac.data(), p, 4 * na), p += 4 * na;
+    bool ok = true;
+    for (int32_t v : st) ok &= v >= 0 && v < n;
+    for (int32_t v : ac) ok &= v >= 0 && v < n;
+    if (!ok) continue;
+    auto* g = new wfl_graph();
+    g->start.assign(n, 0), g->accept.assign(n, 0);
+    for (int32_t v : st) g->start[v] = 1;
+    for (int32_t v : ac) g->accept[v] = 1;
+    g->src.resize(m), g->dst.resize(m), g->il.resize(m), g->ol.resize(m), g->w.resize(m);
+    for (int64_t k = 0; k < m && ok; ++k, p += 20) {
+      int32_t a[4];
+      std::memcpy(a, p, 16);
+      std::memcpy(&g->w[k], p + 16, 4);
+      g->src[k] = a[0], g->dst[k] = a[1], g->il[k] = a[2], g->ol[k] = a[3];
+      ok &= a[0] >= 0 && a[0] < n && a[1] >= 0 && a[1] < n && a[2] >= -1 && a[3] >= -1;
+    }
+    if (ok) return g;
+    delete g;
+  }
+  wfl::set_error("load: %s is neither gtn text nor a consistent gtn binary graph (size %lld, header %d %d %d %d); "
+                 "re-export it with gtn.savetxt", path, (long long)size, h[0], h[1], h[2], h[3]);
+  return nullptr;
+}
+
+wfl_graph* wfl_graph_load(const char* path) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) {
+    wfl::set_error("load: cannot open %s", path);
+    return nullptr;
+  }
+  std::vector<char> buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  // text files hold digits, signs, dots, exponents and white space only
+  bool text = !buf.empty();
+  for (char ch : buf)
+    if (!(std::isdigit((unsigned char)ch) || std::isspace((unsigned char)ch) || (ch != 0 && std::strchr("+-.eEinfa", ch)))) {
+      text = false;
+      break;
+    }
+  if (text) return wfl_graph_loadtxt(path);
+  return parse_binary(buf, path);
+}
+
+int wfl_graph_save(const wfl_graph* g, const char* path) {
+  std::ofstream out(path, std::ios::binary);
+  if (!out) {
+    wfl::set_error("save: cannot open %s", path);
+    return WFL_ERR_INVALID;
+  }
+  std::vector<int32_t> st, ac;
+  for (int i = 0; i < g->num_nodes(); ++i) {
+    if (g->start[i]) st.push_back(i);
+    if (g->accept[i]) ac.push_back(i);
+  }
+  const int32_t h[4] = {(int32_t)g->num_nodes(), (int32_t)st.size(), (int32_t)ac.size(), (int32_t)g->num_arcs()};
+  out.write((const char*)h, 16);
+  out.write((const char*)st.data(), 4 * st.size());
+  out.write((const char*)ac.data(), 4 * ac.size());
+  for (int64_t k = 0; k < g->num_arcs(); ++k) {
+    const int32_t a[4] = {g->src[k], g->dst[k], g->il[k], g->ol[k]};
+    out.write((const char*)a, 16);
+    out.write((const char*)&g->w[k], 4);
+  }
+  return out ? WFL_OK : WFL_ERR_RUNTIME;
 }
 
 }  // extern "C"

@@ -331,7 +331,7 @@ def dense_viterbi(x, W):
 class CtcTargets:
     """Device-resident targets of a batch (flat labels + offsets) and the per-utterance factors."""
 
-    __slots__ = ("flat", "offsets", "lens", "max_len", "B", "dev_flat", "dev_offsets", "cache")
+    __slots__ = ("flat", "offsets", "lens", "max_len", "B", "dev_flat", "dev_offsets", "cache", "label_min", "label_max")
 
     def __init__(self, targets, device, flat=None, lens=None):
         self.cache = {}  # derived device objects (scale factors, packed lattices), keyed by the caller
@@ -343,6 +343,9 @@ class CtcTargets:
             np.cumsum(lens, out=self.offsets[1:])
         self.B = len(self.lens)
         self.max_len = max(self.lens) if self.lens else 0
+        # label range, checked against C by the criteria (the kernels index x[b,t,label] unchecked)
+        self.label_min = int(self.flat.min()) if self.flat.size else 0
+        self.label_max = int(self.flat.max()) if self.flat.size else -1
         self.dev_flat = torch.from_numpy(self.flat if self.flat.size else np.zeros(1, np.int32)).to(device)
         self.dev_offsets = torch.from_numpy(self.offsets).to(device)
 
@@ -351,6 +354,14 @@ _CTC_WS_SIZES = {}
 CTC_FAST_MAX_LEN = 255  # longest target of the CTC fast path (four positions per lane); beyond: lattice engine
 CTC_FAST_MAX_CLASSES = 16000  # widest emission row of the CTC fast path (compact gradient tiles: 8 x (4 KB + C bytes) of LDS) ...
 CTC_FAST_MAX_CLASSES_LONG = 602  # ... and for targets of more than 63 labels (dense row tiles [17][C] per wave)
+
+
+def check_labels(tg, C, what):
+    """Labels must index the emission row: the reference's intersect would find no path (loss +inf);
+    here an out-of-range label is a caller error and is rejected before any kernel indexes with it."""
+    if tg.label_min < 0 or tg.label_max >= C:
+        bad = tg.label_min if tg.label_min < 0 else tg.label_max
+        raise ValueError(f"{what}: target label {bad} is outside [0, {C}) (emissions have {C} classes)")
 
 
 def ctc_fast_path_ok(max_len, C):

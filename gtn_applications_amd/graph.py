@@ -188,11 +188,15 @@ def savetxt(path, g):
     N.check(N.lib.wfl_graph_savetxt(g._h, str(path).encode()))
 
 
-load = loadtxt  # the binary gtn format is unpinned; text is the supported one
+def load(path):
+    """gtn.load (utils.py:261): sniffs gtn text vs gtn's binary layout; the binary layout is restated from gtn's
+    published source and unpinned (include/wfl.h) -- anything inconsistent raises instead of being mis-read."""
+    return Graph(True, _handle=N.check_handle(N.lib.wfl_graph_load(str(path).encode())))
 
 
 def save(path, g):
-    savetxt(path, g)
+    """gtn.save (scripts/build_transitions.py:221): binary layout, see load()."""
+    N.check(N.lib.wfl_graph_save(g._h, str(path).encode()))
 
 
 def linear_graph(M, N_, device=None, calc_grad=True):

@@ -88,6 +88,13 @@ int wfl_graph_isomorphic(const wfl_graph* a, const wfl_graph* b);
  * tests/trans_backoff_test.txt) */
 wfl_graph* wfl_graph_loadtxt(const char* path);
 int wfl_graph_savetxt(const wfl_graph* g, const char* path);
+/* gtn.load / gtn.save (utils.py:261 reads config["transitions"] with gtn.load; scripts/build_transitions.py:221
+ * writes it with gtn.save).  load sniffs the file: gtn text (as above) or gtn's binary layout -- int32 counts
+ * {nodes, start, accept, arcs}, start ids, accept ids, then {src, dst, ilabel, olabel, float weight} per arc --
+ * restated from gtn's published utils.cpp and UNPINNED (gtn is not vendored): the reader cross-checks the counts
+ * against the file size and id ranges (both plausible count orders) and fails loudly on anything else. */
+wfl_graph* wfl_graph_load(const char* path);
+int wfl_graph_save(const wfl_graph* g, const char* path);
 void wfl_free(void* p);
 
 /* ------------------------------------------------------------------------------------------------

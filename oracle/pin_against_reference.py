@@ -269,9 +269,77 @@ def write_golden(ctc, asg, stc, transducer):
     print(f"wrote {len(cases)} criterion cases and {len(builders)} builder graphs to {out_dir}")
 
 
+def write_round2_golden(transducer):
+    """Round-2 fixtures, kept apart from criterion_cases.json so that the round-1 vectors stay byte-identical:
+      * transition_builder.json -- the reference's scripts/build_transitions.py functions (count / prune /
+        blank grams / self loops / build_graph) run on a small seeded corpus, on the oracle's Graph: corpus,
+        options and the resulting node / arc lists (arc order included);
+      * transducer_wordpieces_1000.npz -- the reference's Transducer module with the 1000 word pieces of
+        benchmarks/word_pieces_tokens_1000.txt (BASELINE configs[3]: blank optional, no repeats, mean) on a short
+        seeded input: loss and dense gradient (inputs are regenerated from the seed by the test)."""
+    import numpy as np
+    import torch
+
+    out_dir = os.path.join(REPO, "tests", "golden")
+    spec = importlib.util.spec_from_file_location("ref_build_transitions", os.path.join(REF, "scripts", "build_transitions.py"))
+    bt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bt)
+
+    def dump(gr):
+        return dict(num_nodes=gr.num_nodes(), start=gr.start_nodes(), accept=gr.accept_nodes(),
+                    arcs=[[gr.src[a], gr.dst[a], gr.ilab[a], gr.olab[a]] for a in range(gr.num_arcs())])
+
+    rnd = random.Random(5)
+    tokens = list("abcde")
+    # a corpus with a skewed distribution, so that pruning thresholds bite differently per order
+    lines = ["".join(rnd.choice("aaabbcde"[: rnd.randint(3, 8)]) for _ in range(rnd.randint(1, 9))) for _ in range(60)]
+    t2i = {t: e for e, t in enumerate(tokens)}
+    cases = {}
+    for name, (prune, blank, loops, nobackoff) in {
+        "unigram": ([0], "none", False, False),
+        "bigram": ([0, 1], "none", False, False),
+        "trigram_pruned": ([0, 2, 4], "none", False, False),
+        "bigram_blank_optional": ([0, 1], "optional", False, False),
+        "bigram_blank_forced": ([0, 1], "forced", False, False),
+        "trigram_self_loops": ([0, 1, 3], "none", True, False),
+        "bigram_no_backoff": ([0, 0], "none", False, True),
+        "trigram_blank_optional_loops": ([0, 1, 2], "optional", True, False),
+    }.items():
+        counts = bt.count_ngrams(lines, len(prune), t2i)
+        kept = bt.prune_ngrams(counts, prune)
+        if blank != "none":
+            kept = bt.add_blank_grams(kept, len(t2i), blank)
+        if loops:
+            kept = bt.add_self_loops(kept)
+        gr = bt.build_graph(kept, nobackoff)
+        cases[name] = dict(prune=prune, blank=blank, add_self_loops=loops, disable_backoff=nobackoff, graph=dump(gr),
+                           kept=[[list(g) for g in grams] for grams in kept])
+    with open(os.path.join(out_dir, "transition_builder.json"), "w") as fid:
+        json.dump(dict(tokens=tokens, lines=lines, cases=cases), fid)
+    print(f"wrote {len(cases)} transition-builder graphs")
+
+    with open(os.path.join(out_dir, "word_pieces_tokens_1000.txt"), "r") as fid:
+        wp = sorted(l.strip() for l in fid)
+    graphemes = sorted(set(c for t in wp for c in t))
+    g2i = {t: i for i, t in enumerate(graphemes)}
+    rnd = random.Random(11)
+    B, T, L, seed = 2, 24, 3, 2024
+    targets = [[g2i[c] for _ in range(L) for c in rnd.choice(wp)] for _ in range(B)]
+    crit = transducer.Transducer(wp, g2i, blank="optional", allow_repeats=False, reduction="mean")
+    x = torch.randn(B, T, len(wp) + 1, generator=torch.Generator().manual_seed(seed)).requires_grad_(True)
+    loss = crit(x, [torch.tensor(t) for t in targets])
+    loss.backward()
+    np.savez_compressed(os.path.join(out_dir, "transducer_wordpieces_1000.npz"), seed=seed, B=B, T=T,
+                        targets=np.array([len(t) for t in targets] + [v for t in targets for v in t]),
+                        loss=loss.item(), grad=x.grad.numpy().astype(np.float32),
+                        x_checksum=float(x.detach().double().sum()))
+    print("wrote transducer_wordpieces_1000.npz: loss", loss.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write-golden", action="store_true")
+    ap.add_argument("--write-round2-golden", action="store_true")
     args = ap.parse_args()
     random.seed(0)
     _, ctc, asg, stc, transducer = install_reference_on_oracle()
@@ -283,6 +351,10 @@ def main():
         if not ok:
             raise SystemExit("refusing to write golden vectors from an unpinned oracle")
         write_golden(ctc, asg, stc, transducer)
+    if args.write_round2_golden:
+        if not ok:
+            raise SystemExit("refusing to write golden vectors from an unpinned oracle")
+        write_round2_golden(transducer)
     sys.exit(0 if ok else 1)
 
 

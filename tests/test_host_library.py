@@ -356,3 +356,134 @@ def test_targets_on_device_accepts_tensors_and_lists_alike():
     assert a.flat.tolist() == b.flat.tolist() and a.offsets.tolist() == b.offsets.tolist()
     assert list(a.lens) == list(b.lens) and a.max_len == b.max_len == 4 and a.B == b.B == 4
     assert E.targets_on_device(a, cpu) is a  # prebuilt targets pass through
+
+
+# =================================================================================================
+# round 2: graph file formats, the offline transition builder, compat names, label validation
+# =================================================================================================
+def _sample_graph():
+    g = G.Graph()
+    for k in range(5):
+        g.add_node(k in (0, 4), k in (2, 3))
+    g.add_arc(0, 1, 1, G.epsilon, 0.5), g.add_arc(1, 2, G.epsilon, G.epsilon, -2.25)
+    g.add_arc(4, 3, 2, 7, 1.5), g.add_arc(0, 3, 3, 3, 1e-3), g.add_arc(3, 3, 0, 0, float("-inf"))
+    return g
+
+
+def test_binary_graph_format_round_trip_and_sniffing(tmp_path):
+    import struct
+
+    g = _sample_graph()
+    pb, pt = str(tmp_path / "g.bin"), str(tmp_path / "g.txt")
+    G.save(pb, g)
+    G.savetxt(pt, g)
+    assert G.equal(G.load(pb), g) and G.equal(G.load(pt), g)  # load sniffs binary vs text
+    raw = open(pb, "rb").read()
+    assert len(raw) == 16 + 4 * (2 + 2) + 20 * 5
+    assert struct.unpack("<4i", raw[:16]) == (5, 2, 2, 5)
+    # the other plausible order of the counts (nodes, arcs, start, accept) is recognised by file size + id ranges
+    n, ns, na, m = struct.unpack("<4i", raw[:16])
+    alt = str(tmp_path / "alt.bin")
+    open(alt, "wb").write(struct.pack("<4i", n, m, ns, na) + raw[16:])
+    assert G.equal(G.load(alt), g)
+    # anything inconsistent is rejected loudly, never mis-parsed
+    for bad in (raw[:-3], raw + b"\0\0\0\0", struct.pack("<4i", 5, 2, 2, 6) + raw[16:], b"\x01\x02"):
+        p = str(tmp_path / "bad.bin")
+        open(p, "wb").write(bad)
+        with pytest.raises(N.WflError):
+            G.load(p)
+    with pytest.raises(N.WflError):
+        G.load(str(tmp_path / "missing.bin"))
+
+
+def test_load_criterion_reads_transitions_file(tmp_path):
+    import gtn_applications_amd as pkg
+
+    trans = TR.make_transitions_graph(2, 4, True)  # 3 tokens + blank
+    for name, writer in (("t.bin", G.save), ("t.txt", G.savetxt)):
+        path = str(tmp_path / name)
+        writer(path, trans)
+
+        class Pre:
+            num_tokens = 3
+            tokens = ["a", "b", "c"]
+            graphemes_to_index = {"a": 0, "b": 1, "c": 2}
+
+        crit, out = pkg.load_criterion("transducer", Pre, {"blank": "optional", "transitions": path})
+        assert out == 4 and crit.transition_params.numel() == trans.num_arcs()
+        assert G.isomorphic(crit.transitions, TR._zero_weight_view(trans))
+
+
+def test_transition_builder_matches_reference_script_goldens(golden_dir, tmp_path):
+    from gtn_applications_amd import transitions_builder as TB
+
+    with open(os.path.join(golden_dir, "transition_builder.json")) as f:
+        gold = json.load(f)
+    t2i = {t: e for e, t in enumerate(gold["tokens"])}
+    for name, c in gold["cases"].items():
+        counts = TB.count_ngrams(gold["lines"], len(c["prune"]), t2i)
+        kept = TB.prune_ngrams(counts, c["prune"])
+        if c["blank"] != "none":
+            kept = TB.add_blank_grams(kept, len(t2i), c["blank"])
+        if c["add_self_loops"]:
+            kept = TB.add_self_loops(kept)
+        assert [[list(g) for g in grams] for grams in kept] == c["kept"], name
+        got = dump(TB.build_graph(kept, c["disable_backoff"]))
+        want = c["graph"]
+        assert (got["num_nodes"], got["start"], got["accept"]) == (want["num_nodes"], want["start"], want["accept"]), name
+        assert [a[:4] for a in got["arcs"]] == want["arcs"], name
+        whole = TB.build_transitions(gold["lines"], gold["tokens"], c["prune"], c["blank"], c["add_self_loops"],
+                                     c["disable_backoff"])
+        assert [a[:4] for a in dump(whole)["arcs"]] == want["arcs"], name
+    # the CLI writes a file that load_criterion's reader takes back (binary by default, text with --text)
+    data, toks = tmp_path / "text", tmp_path / "tokens"
+    data.write_text("\n".join(gold["lines"]) + "\n")
+    toks.write_text("\n".join(gold["tokens"]) + "\n")
+    for extra in ([], ["--text"]):
+        out = str(tmp_path / ("trans" + "".join(extra)))
+        g = TB.main(["--data_path", str(data), "--tokens", str(toks), "--prune", "0", "1", "--blank", "optional",
+                     "--save_path", out] + extra)
+        assert G.equal(G.load(out), g)
+        assert [a[:4] for a in dump(g)["arcs"]] == gold["cases"]["bigram_blank_optional"]["graph"]["arcs"]
+    with pytest.raises(ValueError):
+        TB.build_transitions(gold["lines"], gold["tokens"], [3, 1])
+    with pytest.raises(ValueError):  # a kept bigram whose suffix unigram was pruned
+        TB.build_graph([[(0,)], [(TB.START_IDX, 0), (0, 1)]])
+
+
+def test_compat_registers_models_and_utils_names():
+    import sys
+
+    from gtn_applications_amd import compat
+
+    saved = {k: sys.modules.get(k) for k in ("utils", "models", "criterions", "transducer")}
+    try:
+        for k in saved:
+            sys.modules.pop(k, None)
+        compat.install()
+        import models
+        import utils
+
+        assert models.load_criterion is utils.load_criterion and callable(models.load_from_checkpoint)
+        assert utils.CTCLoss is ctc.CTCLoss and sys.modules["transducer"] is TR
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+
+
+def test_target_labels_are_range_checked_before_any_kernel_sees_them():
+    class FakeTargets:
+        pass
+
+    for flat, ok in (([0, 3, 2], True), ([0, 4], False), ([-1, 2], False), ([], True)):
+        tg = FakeTargets()
+        arr = np.asarray(flat, np.int32)
+        tg.label_min = int(arr.min()) if arr.size else 0
+        tg.label_max = int(arr.max()) if arr.size else -1
+        if ok:
+            E.check_labels(tg, 4, "t")
+        else:
+            with pytest.raises(ValueError):
+                E.check_labels(tg, 4, "t")
