@@ -164,3 +164,156 @@ def dense_viterbi(x, W):
         cur = int(back[t, cur])
         path.append(cur)
     return path[::-1]
+
+
+# --------------------------------------------------------------------------------------------------
+# Batched variants for BASELINE-size parity checks (tests only).  Same recurrences as above, vectorised
+# over the batch so that B=128, T=1000..2000 finishes in seconds; tests/test_oracle.py checks them against
+# the per-utterance functions above, so they inherit their pinning.
+# --------------------------------------------------------------------------------------------------
+def ctc_loss_grad_batched(x, targets, blank, reduction="none", out_dtype=np.float64, batch_size=None):
+    """criterions/ctc.py:32-94, all utterances at once (ragged targets are padded; padded states are
+    unreachable).  Returns (per-utterance scaled losses [B], dx [B,T,C]).  `batch_size`: the B of the 1/B factor
+    when x is a slice of a larger batch (ctc.py:87)."""
+    x = np.asarray(x, dtype=np.float64)
+    x = np.where(np.isnan(x), NEG, x)
+    B, T, C = x.shape
+    lens = np.array([len(t) for t in targets], dtype=np.int64)
+    Lm = int(lens.max()) if B else 0
+    S = 2 * Lm + 1
+    lab = np.full((B, S), blank, dtype=np.int64)
+    for b, t in enumerate(targets):
+        if len(t):
+            lab[b, 1:2 * len(t):2] = np.asarray(t, dtype=np.int64)
+    s_idx = np.arange(S)[None, :]
+    valid = s_idx < (2 * lens[:, None] + 1)
+    skip = np.zeros((B, S), dtype=bool)  # arc s-2 -> s exists: s odd, s > 1, label differs from the previous label
+    skip[:, 3::2] = lab[:, 3::2] != lab[:, 1:-2:2]
+    skip &= valid
+    bi = np.arange(B)[:, None]
+    e = np.transpose(x[bi, :, lab], (0, 2, 1))  # [B,T,S] emission of each state's label per frame
+    e = np.where(valid[:, None, :], e, NEG)
+
+    def shift(a, k):
+        out = np.full_like(a, NEG)
+        out[:, k:] = a[:, :-k]
+        return out
+
+    with np.errstate(all="ignore"):
+        alpha = np.full((B, T, S), NEG)
+        alpha[:, 0, 0] = e[:, 0, 0]
+        if S > 1:
+            alpha[:, 0, 1] = e[:, 0, 1]
+        for t in range(1, T):
+            p = alpha[:, t - 1]
+            acc = np.logaddexp(p, shift(p, 1))
+            if S > 2:
+                acc = np.logaddexp(acc, np.where(skip, shift(p, 2), NEG))
+            alpha[:, t] = acc + e[:, t]
+        last = 2 * lens  # final blank state; the last label state (last-1) also accepts when L > 0
+        fin = np.full((B, S), NEG)
+        fin[np.arange(B), last] = 0.0
+        has = lens > 0
+        fin[np.arange(B)[has], last[has] - 1] = 0.0
+        logz = _lse(alpha[:, T - 1] + fin, axis=1)
+        # beta[t][s] = score of finishing from state s after frame t (emission of frame t excluded)
+        beta = np.full((B, T, S), NEG)
+        beta[:, T - 1] = fin
+        skip_from = np.zeros((B, S), dtype=bool)  # arc s -> s+2 exists
+        skip_from[:, :-2] = skip[:, 2:]
+
+        def shl(a, k):
+            out = np.full_like(a, NEG)
+            out[:, :-k] = a[:, k:]
+            return out
+
+        for t in range(T - 2, -1, -1):
+            q = beta[:, t + 1] + e[:, t + 1]
+            acc = np.logaddexp(q, shl(q, 1))
+            if S > 2:
+                acc = np.logaddexp(acc, np.where(skip_from, shl(q, 2), NEG))
+            beta[:, t] = acc
+        post = np.exp(alpha + beta - logz[:, None, None])
+        post = np.where(np.isfinite(post), post, 0.0)
+    post[~np.isfinite(logz)] = 0.0
+    sc = np.ones(B)
+    if reduction == "mean":
+        sc = np.where(lens > 0, 1.0 / np.maximum(lens, 1), 1.0)
+    dx = np.zeros((B, T, C), dtype=out_dtype)
+    coef = -(sc / (batch_size or B))
+    for b in range(B):  # scatter-add the state posteriors into their label columns
+        g = np.zeros((T, C))
+        np.add.at(g, (np.arange(T)[:, None], lab[b][None, :]), post[b])
+        dx[b] = g * coef[b]
+    return -logz * sc, dx
+
+
+def asg_loss_grad_batched(x, W, targets, reduction="none"):
+    """criterions/asg.py:84-185 for a whole batch: the fully connected sweeps run as float64 scaled
+    matrix products over the batch (finite scores only), the force-aligned numerator through
+    lattice_forward_backward.  Returns (scaled per-utterance losses [B], dx [B,T,C], dW)."""
+    x = np.asarray(x, dtype=np.float64)
+    W = np.asarray(W, dtype=np.float64)
+    if not (np.isfinite(x).all() and np.isfinite(W).all()):
+        raise ValueError("asg_loss_grad_batched: finite scores only (use asg_loss_grad)")
+    B, T, C = x.shape
+    M = W[1:]  # [cur, prev]
+    mrow = M.max()
+    P = np.exp(M - mrow)  # [cur, prev], entries in (0, 1]
+    xm = x.max(axis=2, keepdims=True)
+    ex = np.exp(x - xm)  # [B,T,C]
+    # alpha~_t = ex_t * (alpha~_{t-1} @ P^T), normalised; log scale in la[b,t]
+    a = np.empty((B, T, C))
+    la = np.empty((B, T))
+    v = ex[:, 0] * np.exp(W[0] - W[0].max())
+    s = v.sum(axis=1)
+    a[:, 0] = v / s[:, None]
+    la[:, 0] = np.log(s) + xm[:, 0, 0] + W[0].max()
+    for t in range(1, T):
+        v = ex[:, t] * (a[:, t - 1] @ P.T)
+        s = v.sum(axis=1)
+        a[:, t] = v / s[:, None]
+        la[:, t] = la[:, t - 1] + np.log(s) + xm[:, t, 0] + mrow
+    logz = la[:, T - 1]  # sum of alpha~_{T-1} is 1
+    bt = np.empty((B, T, C))
+    lb = np.empty((B, T))
+    bt[:, T - 1] = 1.0 / C
+    lb[:, T - 1] = np.log(C)
+    for t in range(T - 2, -1, -1):
+        v = (bt[:, t + 1] * ex[:, t + 1]) @ P
+        s = v.sum(axis=1)
+        bt[:, t] = v / s[:, None]
+        lb[:, t] = lb[:, t + 1] + np.log(s) + xm[:, t + 1, 0] + mrow
+    post = a * bt * np.exp(la + lb - logz[:, None])[:, :, None]  # state posteriors [B,T,C]
+    lens = np.array([len(t) for t in targets])
+    sc = np.ones(B)
+    if reduction == "mean":
+        sc = np.where(lens > 0, 1.0 / np.maximum(lens, 1), 1.0)
+    cf = sc / B
+    # transition posteriors: xi_t[i,j] = a_{t-1}[j] P[i,j] ex_t[i] bt_t[i] * exp(la_{t-1} + lb_t + xm_t + mrow - logz)
+    wgt = np.exp(la[:, :-1] + lb[:, 1:] + xm[:, 1:, 0] + mrow - logz[:, None]) * cf[:, None]  # [B,T-1]
+    left = (ex[:, 1:] * bt[:, 1:] * wgt[:, :, None]).reshape(-1, C)  # rows (b,t): cur side
+    right = a[:, :-1].reshape(-1, C)  # prev side
+    dW = np.zeros_like(W)
+    dW[1:] = P * (left.T @ right)
+    dW[0] = (post[:, 0] * cf[:, None]).sum(axis=0)
+    dx = post * cf[:, None, None]
+    losses = np.empty(B)
+    wflat = W.reshape(-1)
+    for b in range(B):
+        y = list(targets[b])
+        L = len(y)
+        src, dst, lab, wid = [], [], [], []
+        for l in range(1, L + 1):
+            c = y[l - 1]
+            src.append(l - 1), dst.append(l), lab.append(c)
+            wid.append(c if l == 1 else (1 + c) * C + y[l - 2])
+            src.append(l), dst.append(l), lab.append(c)
+            wid.append((1 + c) * C + c)
+        fal, gx, garc = lattice_forward_backward(x[b], src, dst, lab, wflat[wid] if wid else np.zeros(0), [0], [L], L + 1)
+        losses[b] = (logz[b] - fal) * sc[b]
+        dx[b] -= gx * cf[b]
+        gW = np.zeros(W.size)
+        np.add.at(gW, np.asarray(wid, dtype=np.int64), garc)
+        dW -= gW.reshape(W.shape) * cf[b]
+    return losses, dx, dW

@@ -1,0 +1,216 @@
+"""GPU parity at the sizes BASELINE.json names (-m gpu): every utterance of each single-GPU configuration
+against the float64 oracle, at the north-star tolerance.
+
+  cfg2  CTC        T=1000 C=100  B=128 L=44     (benchmarks/ctc_benchmark.py)
+  cfg3  ASG        T=1000 C=100  B=128 L=44     (benchmarks/asg_benchmark.py), learned (C+1)xC transitions
+  cfg4  Transducer T=800  C=1001 B=64, the 1000 word pieces of benchmarks/word_pieces_tokens_1000.txt
+        (benchmarks/transducer_benchmark.py:18-53: blank optional, no repeats, reduction mean)
+  cfg5  CTC        T=2000 C=512  B=128 -- one GPU's shard of the 8-GPU configuration
+
+Tolerance (north_star: 1e-4 relative on log-semiring loss / grad): every gradient element within
+1e-4 * |expected| + 1e-4 * |coef_b|, where coef_b = scale_b / B is the factor the reference multiplies a
+posterior (a number in [0,1]) with (ctc.py:87, asg.py:171-179, transducer.py:329-336) -- i.e. posteriors are
+right to 1e-4 of their scale; per-utterance losses to 1e-4 relative.  The measured worst cases are written to
+gpurun_out/parity_r02.json.  Nothing here reads /root/reference."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import criteria as OC  # noqa: E402
+from oracle import recurrences as OR  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL = 1e-4
+STATS = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu_and_stats():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    yield
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_r02.json"), "w") as f:
+            json.dump(STATS, f, indent=1)
+    except OSError:
+        pass
+
+
+def check(name, got, want, scale):
+    """|got - want| <= RTOL * |want| + RTOL * scale elementwise; records the worst case."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape and np.isfinite(got).all(), name
+    err = np.abs(got - want)
+    tol = RTOL * np.abs(want) + RTOL * scale
+    k = int(np.argmax(err / tol))
+    rec = STATS.setdefault(name, dict(max_err_over_tol=0.0, max_abs_err=0.0, max_abs_err_over_scale=0.0, elements=0))
+    rec["max_err_over_tol"] = max(rec["max_err_over_tol"], float((err / tol).flat[k]))
+    rec["max_abs_err"] = max(rec["max_abs_err"], float(err.max()))
+    rec["max_abs_err_over_scale"] = max(rec["max_abs_err_over_scale"], float(err.max() / scale))
+    rec["elements"] += int(err.size)
+    assert err.flat[k] <= tol.flat[k], (f"{name}: |{got.flat[k]:.9g} - {want.flat[k]:.9g}| = {err.flat[k]:.3g} "
+                                        f"> {tol.flat[k]:.3g} at flat index {k}")
+
+
+def test_cfg2_ctc_every_utterance():
+    """BASELINE configs[1] through the default step (lane-exponent pipelined launch + certificate / repair)."""
+    from gtn_applications_amd import engine as E
+    from gtn_applications_amd.criterions import ctc
+
+    B, T, C, L = 128, 1000, 100, 44
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, C, generator=g)
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    want_loss, want_dx = OR.ctc_loss_grad_batched(x.numpy(), targets, C - 1)
+    xg = x.cuda().requires_grad_(True)
+    loss = ctc.CTCLoss(xg, targets, C - 1)
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss.mean(), rel=RTOL)
+    check("cfg2_ctc_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / B)
+    # per-utterance losses and the repair count of the same launch, through the engine call the criterion makes
+    dev = xg.device
+    tg = E.targets_on_device(targets, dev)
+    scale, _, coef = E.loss_factors(tg, "none")
+    dx = torch.full_like(xg.detach(), float("nan"))
+    ws, nll = E.ctc_forward_backward(xg.detach(), tg, C - 1, coef, None, dx)
+    check("cfg2_ctc_nll", nll.cpu().numpy(), want_loss, 0.0)
+    check("cfg2_ctc_dx_engine", dx.cpu().numpy(), want_dx, 1.0 / B)
+    STATS["cfg2_ctc_repaired_utterances"] = E.ctc_pipeline_repaired(ws, B, T, tg.max_len)
+    # mean reduction (gradient scaled by 1/L) and the upstream scalar
+    xg2 = x.cuda().requires_grad_(True)
+    (3.0 * ctc.CTCLoss(xg2, targets, C - 1, "mean")).backward()
+    check("cfg2_ctc_dx_mean_x3", xg2.grad.cpu().numpy(), want_dx * (3.0 / L), 3.0 / (L * B))
+
+
+def test_cfg3_asg_every_utterance():
+    """BASELINE configs[2]: ASGLoss at B=128 with random learned transitions, dx and dW of the whole batch."""
+    from gtn_applications_amd.criterions import asg
+
+    B, T, C, L = 128, 1000, 100, 44
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, C, generator=g)
+    W = torch.randn(C + 1, C, generator=g)
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    want_loss, want_dx, want_dW = OR.asg_loss_grad_batched(x.numpy(), W.numpy(), targets)
+    xg, Wg = x.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
+    loss = asg.ASGLoss(xg, Wg, targets)
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss.mean(), rel=RTOL)
+    check("cfg3_asg_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / B)
+    # a transition gradient is a sum of B*(T-1) posteriors of scale 1/B each: tolerance relative to the
+    # expected value plus 1e-4 of ONE posterior's scale
+    check("cfg3_asg_dW", Wg.grad.cpu().numpy(), want_dW, 1.0 / B)
+    # mean reduction, gradient of each input alone (asg.py:142-185 honours needs_input_grad)
+    xg2 = x.cuda().requires_grad_(True)
+    asg.ASGLoss(xg2, W.cuda(), targets, "mean").backward()
+    check("cfg3_asg_dx_mean", xg2.grad.cpu().numpy(), want_dx / L, 1.0 / (L * B))
+
+
+def _word_piece_setup():
+    with open(os.path.join(ROOT, "tests", "golden", "word_pieces_tokens_1000.txt")) as fid:
+        tokens = sorted(l.strip() for l in fid)
+    graphemes = sorted(set(c for t in tokens for c in t))
+    return tokens, {t: i for i, t in enumerate(graphemes)}
+
+
+def _lattice_oracle(x_b, arcs, sc, B):
+    """loss and gradient w.r.t. RAW scores of -sc * forward_score(log_softmax(x) o A) (transducer.py:186-187,
+    283,302-305,329-336) for an epsilon-free acceptor given as arrays."""
+    lp = OC.log_softmax(np.asarray(x_b, dtype=np.float64), 1)
+    src, dst, lab, start, accept, n = arcs
+    logz, g, _ = OR.lattice_forward_backward(lp, src, dst, lab, np.zeros(len(src)), start, accept, n)
+    din = -g * sc / B
+    return -logz * sc, din - np.exp(lp) * din.sum(axis=1, keepdims=True)
+
+
+def test_cfg4_transducer_word_pieces():
+    """BASELINE configs[3] with the reference's own 1000 word pieces: 10^6-arc token graph, C=1001, T=800,
+    B=64.  Every utterance against the float64 recurrence over the alignment acceptor the host library built;
+    two utterances against the acceptor built by the ORACLE's graph algebra (compose / remove / project);
+    plus the batch properties (rows sum to zero through the fused log_softmax, loss finite)."""
+    from gtn_applications_amd.criterions import transducer as TR
+
+    tokens, g2i = _word_piece_setup()
+    B, T, Lp = 64, 800, 15
+    C = len(tokens) + 1
+    random.seed(0)
+    targets = [[g2i[c] for wp in (random.choice(tokens) for _ in range(Lp)) for c in wp] for _ in range(B)]
+    x = torch.randn(B, T, C, generator=torch.Generator().manual_seed(0))
+    crit = TR.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+    assert crit.tokens.num_arcs() == 1002002 and crit.lexicon.num_arcs() == 4644
+    xg = x.cuda().requires_grad_(True)
+    loss = crit(xg, [torch.tensor(t) for t in targets])
+    loss.backward()
+    dx = xg.grad.cpu().numpy()
+    assert np.isfinite(loss.item())
+    assert np.abs(dx.sum(axis=2)).max() <= 1e-4 * (1.0 / (B * 60))  # log_softmax backward: rows sum to zero
+    crit.tokens.arc_sort(True)
+    losses = []
+    for b in range(B):
+        a = TR._alignment_graph(targets[b], crit.tokens, crit.lexicon, None)[0].arrays()
+        assert (a["ilabel"] >= 0).all()
+        arcs = (a["src"], a["dst"], a["ilabel"], np.nonzero(a["start"])[0], np.nonzero(a["accept"])[0], len(a["start"]))
+        sc = 1.0 / len(targets[b])
+        want_loss, want_dx = _lattice_oracle(x[b].numpy(), arcs, sc, B)
+        losses.append(want_loss)
+        check("cfg4_transducer_dx", dx[b], want_dx, sc / B)
+    assert loss.item() == pytest.approx(float(np.mean(losses)), rel=RTOL)
+    oracle = OC.TransducerOracle(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+    for b in (0, B - 1):
+        ali = oracle.alignment_graph(targets[b])
+        arcs = (ali.src, ali.dst, ali.ilab, ali.start_nodes(), ali.accept_nodes(), ali.num_nodes())
+        sc = 1.0 / len(targets[b])
+        want_loss, want_dx = _lattice_oracle(x[b].numpy(), arcs, sc, B)
+        assert want_loss == pytest.approx(losses[b], rel=1e-9)  # host library and oracle built the same acceptor
+        check("cfg4_transducer_dx_oracle_graph", dx[b], want_dx, sc / B)
+
+
+def test_transducer_word_pieces_reference_golden(golden_dir):
+    """the reference's Transducer module itself (run on the oracle's WFST primitives by
+    oracle/pin_against_reference.py --write-round2-golden) with the 1000 word pieces, short input"""
+    from gtn_applications_amd.criterions import transducer as TR
+
+    gold = np.load(os.path.join(golden_dir, "transducer_wordpieces_1000.npz"))
+    tokens, g2i = _word_piece_setup()
+    B, T = int(gold["B"]), int(gold["T"])
+    flat = gold["targets"].tolist()
+    lens, flat = flat[:B], flat[B:]
+    targets = [flat[sum(lens[:b]):sum(lens[:b + 1])] for b in range(B)]
+    x = torch.randn(B, T, len(tokens) + 1, generator=torch.Generator().manual_seed(int(gold["seed"])))
+    assert float(x.double().sum()) == pytest.approx(float(gold["x_checksum"]), abs=1e-6)  # same inputs as the generator
+    crit = TR.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+    xg = x.cuda().requires_grad_(True)
+    loss = crit(xg, [torch.tensor(t) for t in targets])
+    loss.backward()
+    assert loss.item() == pytest.approx(float(gold["loss"]), rel=RTOL)
+    check("transducer_wordpieces_reference_golden_dx", xg.grad.cpu().numpy(), gold["grad"], 1.0 / (B * min(lens)))
+
+
+def test_cfg5_ctc_shard_every_utterance():
+    """One GPU's shard of BASELINE configs[4] (T=2000, C=512, B=128, seed = rank 0): wide rows, compact
+    gradient tiles; oracle in chunks of 32 utterances."""
+    from gtn_applications_amd.criterions import ctc
+
+    B, T, C, L = 128, 2000, 512, 44
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, C, generator=g)
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    xg = x.cuda().requires_grad_(True)
+    loss = ctc.CTCLoss(xg, targets, C - 1)
+    loss.backward()
+    dx = xg.grad.cpu().numpy()
+    losses = []
+    for lo in range(0, B, 32):
+        want_loss, want_dx = OR.ctc_loss_grad_batched(x[lo:lo + 32].numpy(), targets[lo:lo + 32], C - 1, batch_size=B)
+        losses.append(want_loss)
+        check("cfg5_ctc_shard_dx", dx[lo:lo + 32], want_dx, 1.0 / B)
+    assert loss.item() == pytest.approx(float(np.concatenate(losses).mean()), rel=RTOL)
