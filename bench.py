@@ -1,30 +1,41 @@
 #!/usr/bin/env python
-"""Headline benchmark of the MI355X WFST loss engine.
+"""Benchmarks of the MI355X WFST loss engine on the BASELINE.json configurations.
 
-Metric (BASELINE.json): utterances/sec, forward+backward, on the CTC benchmark of the reference
-(benchmarks/ctc_benchmark.py:17-31 protocol: randn "log_probs", targets randint(C-2), blank C-1,
-reduction "none", fwd + bwd per step) at configs[1]: T=1000, C=100, B=128, L=44, one MI355X.
+Headline (default, what the driver runs): BASELINE.json's metric -- utterances/sec, forward+backward -- on
+configs[1], the reference's CTC benchmark (benchmarks/ctc_benchmark.py:17-31: randn "log_probs", targets
+randint(C-2), blank C-1, reduction "none") at T=1000, C=100, B=128, L=44 on one MI355X.
 
-A "step" = one pass of the hot path over one batch resident in HBM: the call the criterion makes
-through the C ABI of libwfl.so -- wfl_ctc_forward_backward, ONE pipelined launch that runs the alpha
-and beta chains, the loss reduction and the dense [B,T,C] gradient (--ctc-step split times the same
-work as wfl_ctc_forward -> wfl_reduce_loss -> wfl_ctc_grad).  `value` is measured at that boundary
-(--mode abi, default); the same step through the Python drop-in operator
-(`CTCLoss(x, targets, blank).backward()`, what the reference's benchmark script times) is reported
-next to it as `python_api`, a hipGraph replay of it as `hip_graph`, the CPU baselines as
-`cpu_baseline` (oracle C port, all host cores) and `cpu_torch_ctc_loss`.
+A "step" = one pass of the hot path over one batch whose emissions are resident in HBM:
+  --mode api (default)  the drop-in operator exactly as the reference's benchmark scripts call it --
+                        `CTCLoss(x, targets, blank).backward()` (`ASGLoss(...)`, `Transducer(...)(x, targets)`),
+                        autograd, host-side target handling / graph algebra and upload included;
+  --mode abi            (ctc only) the C-ABI call underneath with targets pre-staged: the kernels alone.
+  --targets fresh (default)  every step (warm-up included) gets targets never seen before, so no content-keyed
+                        cache of the engine can hit: per-batch host work is inside the timed region;
+  --targets same        the reference benchmarks' own protocol (one target list reused by every iteration).
+`value` is the default (api, fresh); the other combinations are reported next to it as labelled extras
+(`same_targets`, `abi_kernels_only`, `hip_graph`).
 
-  python bench.py                      # 1 GPU, defaults finish in well under a minute
+Per-kernel times come from HIP events recorded on the stream each launch goes to, inside the timed region
+(engine.PHASE_EVENTS); `roofline` is computed for the dominant one, `traffic` from the committed PMC passes
+(profiles/r02_pmc_traffic.json, collected with scripts/collect_round.sh on the same commands).
+
+  python bench.py                                   # cfg2 CTC, 1 GPU, finishes in about a minute
+  python bench.py --workload asg                    # cfg3
+  python bench.py --workload transducer             # cfg4 (the reference's 1000 word pieces)
+  python bench.py --T 2000 --C 512                  # one GPU's shard of cfg5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: utterances shard over ranks (same per-GPU batch: weak scaling); CTC has no learnable
-transition weights, so there is no data-path collective (ASG's transition-gradient all-reduce is
-exercised with --workload asg).  Timing: barrier + synchronize on both sides, MAX over ranks.
+Multi-GPU: utterances shard over ranks (same per-GPU batch: weak scaling), no emissions cross GPUs.  CTC has no
+learnable transition weights, hence no data-path collective; --workload asg averages the transition-weight
+gradient over ranks each step (parallel.sync_transition_grads, RCCL all-reduce).  Timing: barrier + synchronize
+on both sides, MAX over ranks.
 """
 import argparse
 import json
 import os
+import random
 import sys
 import time
 
@@ -37,6 +48,22 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
+# which kernels run inside each timed phase of engine.PHASE_EVENTS (short names as rocprofv3 reports them)
+PHASE_KERNEL_NAMES = {
+    "ctc_step": ["ctc_fast_pipelined_kernel", "ctc_repair_kernel"],
+    "ctc_chains": ["ctc_log_chain_kernel"],
+    "ctc_grad": ["reduce_loss_kernel", "ctc_grad_kernel"],
+    "lattice_gather": ["gather_lse_kernel", "gather_kernel"],
+    "lattice_chain": ["chain_kernel"],
+    "lattice_grad": ["grad_kernel"],
+    "lattice_gather/shared": ["gather_kernel"],
+    "lattice_chain/shared": ["chain_kernel"],
+    "lattice_grad/shared": ["grad_kernel"],
+    "dense_chain": ["dense_fast_chain_kernel", "dense_chain_kernel"],
+    "dense_grad": ["dense_fast_grad_kernel", "dense_reduce_kernel"],
+}
+PHASE_KERNELS = {k: " + ".join(v) + (" (transitions graph)" if k.endswith("/shared") else "") for k, v in PHASE_KERNEL_NAMES.items()}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -44,17 +71,19 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ctc", choices=["ctc", "asg", "transducer"])
-    ap.add_argument("--mode", default="abi", choices=["abi", "api"])
+    ap.add_argument("--mode", default="api", choices=["abi", "api"])
+    ap.add_argument("--targets", default="fresh", choices=["fresh", "same"])
     ap.add_argument("--B", type=int, default=None)
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--C", type=int, default=None)
     ap.add_argument("--L", type=int, default=44)
     ap.add_argument("--ctc-chain", default="default", choices=["default", "log", "fast"],
-                    help="CTC chain kernel of the split step: library default, log-domain, or the lane-exponent chain + certificate")
+                    help="CTC chain kernel of the split abi step: library default, log-domain, or lane-exponent + certificate")
     ap.add_argument("--ctc-step", default="pipelined", choices=["split", "pipelined"],
-                    help="CTC step: forward and gradient kernels back to back, or one pipelined launch")
+                    help="abi CTC step: forward and gradient kernels back to back, or one pipelined launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-utts", type=int, default=128)
+    ap.add_argument("--no-extras", action="store_true", help="skip the labelled extra measurements (profiling runs)")
+    ap.add_argument("--cpu-sample-utts", type=int, default=None)
     return ap.parse_args()
 
 
@@ -75,149 +104,185 @@ def dist_setup(n):
 
 
 # --------------------------------------------------------------------------------------------------
-# workloads: each returns (step_fn, phase_names, meta).  step_fn(events) runs one fwd+bwd and, if
-# `events` is a list, appends torch.cuda.Event markers between the kernels on the launch stream.
+# workloads: each returns dict(step=fn(i), meta=..., payload=for the CPU baseline, [abi_step]).
+# step(i) runs forward+backward of batch i; with fresh targets batch i has targets no earlier step saw.
 # --------------------------------------------------------------------------------------------------
-def make_ctc(args, rank, mode):
+def make_ctc(args, rank, n_batches):
+    from gtn_applications_amd import _native as N
     from gtn_applications_amd import engine as E
     from gtn_applications_amd.criterions import ctc
 
     B, T, C, L = args.B or 128, args.T or 1000, args.C or 100, args.L
     g = torch.Generator().manual_seed(rank)
     x = torch.randn(B, T, C, generator=g).cuda()
-    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
     blank = C - 1
+    # benchmarks/ctc_benchmark.py:23-24: randint(N - 2, (B, L)) as a list of int lists
+    batches = [torch.randint(C - 2, (B, L), generator=g).tolist() for _ in range(n_batches)]
+    xr = x.clone().requires_grad_(True)
+
+    def step(i):
+        xr.grad = None
+        ctc.CTCLoss(xr, batches[i % n_batches], blank).backward()
+
+    # the C-ABI call underneath, targets pre-staged (kernels only)
     dev = x.device
-    tg = E.targets_on_device(targets, dev)
+    tg = E.targets_on_device(batches[0], dev)
     scale, _, coef = E.loss_factors(tg, "none")
     gout = torch.ones(1, device=dev)
     dx = torch.empty_like(x)
-
-    def mark(events):
-        if events is not None:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            events.append(e)
-
-    from gtn_applications_amd import _native as N
     chain_flags = {"default": E.CTC_DEFAULT_FLAGS, "log": 0, "fast": N.CTC_FAST_CHAIN}[args.ctc_chain]
     last = [None]
-    if mode == "abi" and args.ctc_step == "pipelined":
-        def step(events=None):
-            mark(events)
-            # chains + gradient waves + loss reduction, one launch
+    if args.ctc_step == "pipelined":
+        def abi_step(i):
             last[0] = E.ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=scale, want_loss=True)
-            mark(events)
-        # (the event bracket holds both launches of the step: lane-exponent pipelined launch + certificate / repair launch)
-        phases = ["ctc_fast_pipelined_kernel (+ctc_repair_kernel)" if os.environ.get("WFL_CTC_PIPELINE") != "log" and L <= 63
-                  else "ctc_pipelined_kernel"]
-    elif mode == "abi":
-        def step(events=None):
-            mark(events)
-            ws, nll = E.ctc_forward(x, tg, blank, chain_flags)  # alpha || beta chains
-            mark(events)
-            E.reduce_loss(nll, scale, 1.0)
-            E.ctc_grad(x, tg, blank, ws, nll, coef, gout, dx)  # posteriors -> dense gradient
-            mark(events)
-        phases = ["ctc_log_chain_kernel", "ctc_grad_kernel(+reduce_loss)"]
     else:
-        xr = x.clone().requires_grad_(True)
+        def abi_step(i):
+            tok = E._mark("ctc_chains")
+            ws, nll = E.ctc_forward(x, tg, blank, chain_flags)
+            E._done(tok)
+            tok = E._mark("ctc_grad")
+            E.reduce_loss(nll, scale, 1.0)
+            E.ctc_grad(x, tg, blank, ws, nll, coef, gout, dx)
+            E._done(tok)
 
-        def step(events=None):
-            xr.grad = None
-            ctc.CTCLoss(xr, targets, blank).backward()
-        phases = []
-    which = {(1000, 100, 128, 44): " (BASELINE configs[1])", (2000, 512, 128, 44): " (BASELINE configs[4], one GPU's shard)",
-             (150, 28, 8, 44): " (BASELINE configs[0])"}.get((T, C, B, L), "")
-    def repaired():  # utterances of the last step that the certificate sent to the log-domain repair launch
+    def repaired():  # utterances of the last abi step that the certificate sent to the log-domain repair launch
         return E.ctc_pipeline_repaired(last[0][0], B, T, tg.max_len) if last[0] is not None else None
 
-    meta = dict(
-        workload=f"ctc fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L, repaired=repaired,
-        algorithmic_bytes_per_utt=8 * T * C,
-    )
-    return step, phases, meta, (x, targets, blank)
+    which = {(1000, 100, 128, 44): " (BASELINE configs[1])", (2000, 512, 128, 44): " (BASELINE configs[4], one GPU's shard)",
+             (150, 28, 8, 44): " (BASELINE configs[0])"}.get((T, C, B, L), "")
+    key = {(1000, 100, 128, 44): "cfg2", (2000, 512, 128, 44): "cfg5_shard"}.get((T, C, B, L))
+    meta = dict(workload=f"ctc fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L, key=key, repaired=repaired,
+                metric=f"utterances/sec fwd+bwd (ctc_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
+                call="CTCLoss(x, targets, blank).backward()", algorithmic_bytes_per_utt=8 * T * C)
+    return dict(step=step, abi_step=abi_step, meta=meta, payload=("ctc", x, batches[0], blank))
 
 
-def make_asg(args, rank, mode, dist):
+def make_asg(args, rank, n_batches, dist):
+    from gtn_applications_amd import parallel
     from gtn_applications_amd.criterions import asg
 
     B, T, C, L = args.B or 128, args.T or 1000, args.C or 100, args.L
     g = torch.Generator().manual_seed(rank)
     x = torch.randn(B, T, C, generator=g).cuda().requires_grad_(True)
-    W = torch.randn(C + 1, C, generator=g).cuda().requires_grad_(True)
-    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
 
-    def step(events=None):
+    class Crit(torch.nn.Module):  # asg_benchmark.py:21-22: a free (C+1) x C transitions tensor with requires_grad
+        def __init__(self):
+            super().__init__()
+            self.transitions = torch.nn.Parameter(torch.randn(C + 1, C, generator=torch.Generator().manual_seed(7)))
+
+        def forward(self, inputs, targets):
+            return asg.ASGLoss(inputs, self.transitions, targets)
+
+    crit = Crit().cuda()
+    batches = [torch.randint(C - 2, (B, L), generator=g).tolist() for _ in range(n_batches)]
+
+    def step(i):
         x.grad = None
-        W.grad = None
-        asg.ASGLoss(x, W, targets).backward()
-        if dist is not None:  # the one exchange step of the path: transition-weight gradient
-            dist.all_reduce(W.grad)
+        crit.transitions.grad = None
+        crit(x, batches[i % n_batches]).backward()
+        if dist is not None:  # the one exchange step of the path (train.py:205-208: DDP averages criterion grads)
+            parallel.sync_transition_grads(crit)
 
-    meta = dict(workload=f"asg fwd+bwd T={T} C={C} B={B} L={L} (BASELINE configs[2])", B=B, T=T, C=C, L=L,
-                algorithmic_bytes_per_utt=8 * T * C)
-    return step, [], meta, None
+    which = " (BASELINE configs[2])" if (T, C, B, L) == (1000, 100, 128, 44) else ""
+    meta = dict(workload=f"asg fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L,
+                key="cfg3" if which else None,
+                metric=f"utterances/sec fwd+bwd (asg_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
+                call="ASGLoss(x, transitions, targets).backward()",
+                algorithmic_bytes_per_utt=8 * T * C, algorithmic_bytes_per_batch=8 * (C + 1) * C)
+    return dict(step=step, meta=meta, payload=("asg", x.detach(), crit.transitions.detach(), batches[0]))
 
 
-def make_transducer(args, rank, mode):
-    import random
+def word_pieces():
+    """benchmarks/word_pieces_tokens_1000.txt (the reference's data file, shipped as a fixture): 1000 pieces,
+    78 graphemes (transducer_benchmark.py:19-23)."""
+    with open(os.path.join(ROOT, "benchmarks", "word_pieces_tokens_1000.txt"), "r") as fid:
+        tokens = sorted(l.strip() for l in fid)
+    graphemes = sorted(set(c for t in tokens for c in t))
+    return tokens, {t: i for i, t in enumerate(graphemes)}
 
+
+def make_transducer(args, rank, n_batches):
     from gtn_applications_amd.criterions import transducer
 
-    B, T = args.B or 64, args.T or 800
-    rnd = random.Random(rank)
-    # 1000 synthetic word pieces over 26 graphemes (the reference's token file is not shipped):
-    # same size and length statistics as benchmarks/word_pieces_tokens_1000.txt (mean ~4.6 letters)
-    letters = "abcdefghijklmnopqrstuvwxyz"
-    pieces = set(letters)
-    while len(pieces) < 1000:
-        pieces.add("".join(rnd.choice(letters) for _ in range(rnd.choice([2, 3, 4, 5, 6, 7]))))
-    tokens = sorted(pieces)
-    g2i = {c: i for i, c in enumerate(letters)}
+    B, T, Lp = args.B or 64, args.T or 800, 15
+    tokens, g2i = word_pieces()
     C = len(tokens) + 1
-    g = torch.Generator().manual_seed(rank)
-    x = torch.randn(B, T, C, generator=g).cuda().requires_grad_(True)
-    targets = [torch.tensor([g2i[ch] for _ in range(15) for ch in rnd.choice(tokens)]) for _ in range(B)]
+    rnd = random.Random(rank)
+    x = torch.randn(B, T, C, generator=torch.Generator().manual_seed(rank)).cuda().requires_grad_(True)
+    # transducer_benchmark.py:36-40: 15 random pieces per sample, spelled out in graphemes, as tensors
+    batches = [[torch.tensor([g2i[ch] for _ in range(Lp) for ch in rnd.choice(tokens)]) for _ in range(B)]
+               for _ in range(n_batches)]
     crit = transducer.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
 
-    def step(events=None):
+    def step(i):
         x.grad = None
-        crit(x, targets).backward()
+        crit(x, batches[i % n_batches]).backward()
 
-    meta = dict(workload=f"transducer 1000 word pieces fwd+bwd T={T} C={C} B={B} (BASELINE configs[3])", B=B, T=T, C=C,
-                L=15, algorithmic_bytes_per_utt=8 * T * C)
-    return step, [], meta, None
+    which = " (BASELINE configs[3])" if (T, B) == (800, 64) else ""
+    meta = dict(workload=f"transducer fwd+bwd, 1000 word pieces (word_pieces_tokens_1000.txt) T={T} C={C} B={B}{which}",
+                B=B, T=T, C=C, L=Lp, key="cfg4" if which else None,
+                metric=f"utterances/sec fwd+bwd (transducer_benchmark word decompositions T={T},C={C},B={B}); HBM GB/s vs peak",
+                call="Transducer(tokens, ..., blank='optional', allow_repeats=False, reduction='mean')(x, targets).backward()",
+                algorithmic_bytes_per_utt=8 * T * C)
+    return dict(step=step, meta=meta, payload=("transducer", x.detach(), crit, batches[0]))
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baselines (oracle/cpu_ref.c, "port"), bounded samples, rank 0 at N=1 only
+# --------------------------------------------------------------------------------------------------
+def _timed_reps(fn, budget_s):
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            return reps, el
 
 
 def cpu_baseline(payload, n_utts):
-    """The oracle's graph-faithful C restatement (oracle/cpu_ref.c, "port") on this box's host
-    cores, on a bounded sample of the same workload."""
     from oracle import cpu_ref
 
-    x, targets, blank = payload
-    n = min(n_utts, x.shape[0])
-    xs = x[:n].cpu().numpy()
-    tg = targets[:n]
     cores = os.cpu_count() or 1
-    cpu_ref.ctc_cpu(xs[:max(1, n // 8)], tg[:max(1, n // 8)], blank, "none", cores)  # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        cpu_ref.ctc_cpu(xs, tg, blank, "none", cores)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 10.0:  # a bounded sample: about 10 s of wall clock on all host cores
-            break
-    return dict(
-        value=n * reps / el, unit="utt/s", cores=cores, kind="port",
-        sample=f"{reps} x fwd+bwd of {n} utterances (same T,C,L) with oracle/cpu_ref.c on {cores} threads, {el:.1f} s",
-    )
+    kind = payload[0]
+    if kind == "ctc":
+        _, x, targets, blank = payload
+        n = min(n_utts or 128, x.shape[0])
+        xs, tg = x[:n].cpu().numpy(), targets[:n]
+        run = lambda: cpu_ref.ctc_cpu(xs, tg, blank, "none", cores)  # noqa: E731
+        what = "graph-faithful CTC (materialised emissions x label-graph lattice)"
+    elif kind == "asg":
+        _, x, W, targets = payload
+        n = min(n_utts or 128, x.shape[0])
+        xs, Ws, tg = x[:n].cpu().numpy(), W.cpu().numpy(), targets[:n]
+        run = lambda: cpu_ref.asg_cpu(xs, Ws, tg, "none", cores)  # noqa: E731
+        what = "graph-faithful ASG (per-sample transitions graph, T*C^2-arc denominator lattice)"
+    else:
+        from gtn_applications_amd.criterions import transducer as TR
+
+        _, x, crit, targets = payload
+        n = min(n_utts or 64, x.shape[0])
+        xs = x[:n].cpu().numpy()
+        crit.tokens.arc_sort(True)
+        accs, scales = [], []
+        for t in targets[:n]:  # alignment acceptors: built ONCE outside the timed region (not part of the port)
+            a = TR._alignment_graph(t.tolist(), crit.tokens, crit.lexicon, None)[0].arrays()
+            accs.append(dict(src=a["src"], dst=a["dst"], lab=a["ilabel"], start=a["start"], accept=a["accept"]))
+            scales.append(1.0 / max(1, t.numel()))
+        run = lambda: cpu_ref.lattice_cpu(xs, accs, scales, True, cores)  # noqa: E731
+        what = ("log_softmax + forward_score/backward over emissions x alignment acceptor; the per-sample graph algebra "
+                "(compose/remove/project, transducer.py:265-276) is EXCLUDED from the port, i.e. it is faster than the real path")
+    run()  # warm-up (page in, thread start)
+    reps, el = _timed_reps(run, 10.0)
+    return dict(value=n * reps / el, unit="utt/s", cores=cores, kind="port",
+                sample=f"{reps} x fwd+bwd of {n} utterances of the same workload with oracle/cpu_ref.c on {cores} threads, "
+                       f"{el:.1f} s: {what}")
 
 
 def cpu_torch_ctc(payload):
     """torch.nn.functional.ctc_loss on the host cores -- the reference's own alternative CTC path
     (criterions/ctc.py:109-121) -- on the same batch, forward + backward, for context."""
-    x, targets, blank = payload
+    _, x, targets, blank = payload
     xc = x.detach().cpu().requires_grad_(True)
     B, T, _ = xc.shape
     tg = torch.tensor(targets, dtype=torch.long)
@@ -229,30 +294,43 @@ def cpu_torch_ctc(payload):
                                      blank=blank, reduction="sum").backward()
 
     run()
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        run()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 3.0:
-            break
+    reps, el = _timed_reps(run, 3.0)
     return dict(value=B * reps / el, unit="utt/s", threads=torch.get_num_threads(),
                 what=f"torch.nn.functional.ctc_loss fwd+bwd on CPU, {reps} x {B} utterances in {el:.1f} s")
 
 
-def pmc_traffic(kernel, meta):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE are collected in separate `--pmc` runs of this same command; see profiles/README.md).
-    Only valid for the configuration they were measured on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_ctc_cfg2_pmc_traffic.json")
-    if not os.path.exists(path) or (meta["B"], meta["T"], meta["C"], meta["L"]) != (128, 1000, 100, 44):
+def pmc_traffic(key, phase):
+    """HBM bytes per launch of the phase's kernels from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate `--pmc` runs of this same command, corrected with the factors measured by
+    scripts/pmc_calib.hip; see profiles/README.md).  Only for the configurations they were measured on."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if key is None or not os.path.exists(path):
         return None
     with open(path) as f:
-        rec = json.load(f)["kernels"]
-    for name, v in rec.items():
-        if kernel.startswith(name):
-            return v["hbm_bytes"]
-    return None
+        rec = json.load(f).get(key, {}).get("kernels", {})
+    tot = [rec[n]["hbm_bytes"] for n in PHASE_KERNEL_NAMES.get(phase, []) if n in rec]
+    return float(sum(tot)) if tot else None
+
+
+# --------------------------------------------------------------------------------------------------
+def timed_loop(step, steps, warmup, fence, collect_events):
+    from gtn_applications_amd import engine as E
+
+    for i in range(warmup):
+        step(i)
+    fence()
+    E.PHASE_EVENTS = [] if collect_events else None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    events, E.PHASE_EVENTS = E.PHASE_EVENTS, None
+    phases = {}
+    for name, a, b in events or []:
+        phases.setdefault(name, []).append(a.elapsed_time(b))
+    # ms per step: a phase may launch more than once per step (numerator + denominator)
+    return elapsed, {k: float(np.sum(v)) / steps for k, v in phases.items()}
 
 
 def main():
@@ -260,27 +338,24 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     rank, world, local, dist = dist_setup(args.gpus)
+    n_batches = (args.steps + args.warmup) if args.targets == "fresh" else 1
     if args.workload == "ctc":
-        step, phases, meta, payload = make_ctc(args, rank, args.mode)
+        wl = make_ctc(args, rank, n_batches)
     elif args.workload == "asg":
-        step, phases, meta, payload = make_asg(args, rank, args.mode, dist)
+        wl = make_asg(args, rank, n_batches, dist)
     else:
-        step, phases, meta, payload = make_transducer(args, rank, args.mode)
+        wl = make_transducer(args, rank, n_batches)
+    meta = wl["meta"]
+    if args.mode == "abi" and "abi_step" not in wl:
+        raise SystemExit("--mode abi exists for --workload ctc only")
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    events = [] if phases else None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(events)
-    fence()
-    elapsed = time.perf_counter() - t0
+    step = wl["abi_step"] if args.mode == "abi" else wl["step"]
+    elapsed, phase_ms = timed_loop(step, args.steps, args.warmup, fence, True)
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,84 +364,73 @@ def main():
     B = meta["B"]
     ms = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
+    par = (f"dp{world} (utterance shards, no data-path collective)" if args.workload != "asg"
+           else f"dp{world} (utterance shards; all-reduce(mean) of the transition-weight gradient per step)")
     out = {
-        "metric": "utterances/sec fwd+bwd (ctc_benchmark T=1000,C=100,B=128); HBM GB/s vs peak",
-        "value": value, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": meta["metric"], "value": value, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": meta["workload"], "mode": args.mode, "per_gpu_batch": B,
-                   "global_batch": B * world, "parallelism": f"dp{world} (utterance shards, no data-path collective)"
-                   if args.workload == "ctc" else f"dp{world} (all-reduce of transition grads)"},
+        "config": {"workload": meta["workload"], "mode": args.mode, "targets": args.targets if args.mode == "api" else "pre-staged",
+                   "timed_call": meta["call"] if args.mode == "api" else "wfl_ctc_forward_backward (C ABI, targets pre-staged)",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": par},
     }
-    if callable(meta.get("repaired")):
-        out["config"]["utterances_repaired_in_log_domain"] = meta["repaired"]()
-    alg_bytes = meta["algorithmic_bytes_per_utt"] * B  # per launch: every launch processes the whole batch
-    if events:
-        per = len(phases) + 1
-        durs = np.zeros(len(phases))
-        for s in range(args.steps):
-            ev = events[s * per:(s + 1) * per]
-            for k in range(len(phases)):
-                durs[k] += ev[k].elapsed_time(ev[k + 1])
-        durs /= args.steps  # ms, average per launch
-        dom = int(np.argmax(durs))
-        achieved = alg_bytes / (durs[dom] * 1e-3) / 1e9
+    alg_bytes = meta["algorithmic_bytes_per_utt"] * B + meta.get("algorithmic_bytes_per_batch", 0)
+    if phase_ms:
+        dom = max(phase_ms, key=phase_ms.get)
+        gpu_ms = float(sum(phase_ms.values()))
+        achieved = alg_bytes / (phase_ms[dom] * 1e-3) / 1e9
         out["roofline"] = {
-            "bound": "hbm", "kernel": phases[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(phases[dom], meta),
+            "bound": "hbm", "kernel": PHASE_KERNELS.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(meta["key"], dom),
             "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel_ms": {p: float(d) for p, d in zip(phases, durs)},
-            "step_achieved": alg_bytes / (float(durs.sum()) * 1e-3) / 1e9,
-            "step_frac": alg_bytes / (float(durs.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "note": "achieved = 8*T*C*B algorithmic bytes / average duration of the dominant kernel (HIP events on "
-                    "the launch stream, over the timed region); step_* divides by the sum of all kernels of a step",
+            "kernel_ms": {PHASE_KERNELS.get(k, k): v for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])},
+            "step_kernels_ms": gpu_ms, "step_frac": alg_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "note": "achieved = algorithmic bytes of the batch (8*T*C per utterance, + 8*(C+1)*C for ASG's W and dW) / "
+                    "average duration of the dominant kernel group, HIP events on the launch stream inside the timed "
+                    "region; step_* divides by the sum over all kernel groups of a step (groups on forked streams overlap)",
         }
-    else:
-        ach = alg_bytes / (ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "whole step (host-timed)", "achieved": ach,
-                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None}
-    if rank == 0 and world == 1 and args.workload == "ctc" and args.mode == "abi":
-        # the same three launches captured once in a hipGraph and replayed (no host launch gaps, no event records)
-        try:
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(graph):
-                step()
-            for _ in range(3):
-                graph.replay()
-            torch.cuda.synchronize()
-            n_rep = max(args.steps, 20)
-            t0 = time.perf_counter()
-            for _ in range(n_rep):
-                graph.replay()
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            out["hip_graph"] = {"value": B * n_rep / el, "unit": "utt/s", "ms_per_step": el * 1e3 / n_rep,
-                                "what": "the step's kernels captured in one hipGraph and replayed"}
-        except Exception as exc:  # capture is an extra, never fail the bench on it
-            out["hip_graph"] = {"error": str(exc)[:200]}
-    if rank == 0 and world == 1 and args.workload == "ctc":
-        if args.mode == "abi":  # the same step through the Python drop-in operator, for the record
-            step_api, _, _, _ = make_ctc(args, rank, "api")
-            for _ in range(3):
-                step_api()
-            torch.cuda.synchronize()
-            n_api = max(10, args.steps // 4)
-            t0 = time.perf_counter()
-            for _ in range(n_api):
-                step_api()
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            out["python_api"] = {"value": B * n_api / el, "unit": "utt/s", "ms_per_step": el * 1e3 / n_api,
-                                 "what": "CTCLoss(x, targets, blank).backward() eager, incl. host overhead"}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(payload, args.cpu_sample_utts)
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-            out["cpu_torch_ctc_loss"] = cpu_torch_ctc(payload)
+    single = rank == 0 and world == 1
+    if single and not args.no_extras:
+        extras_steps = max(10, args.steps // 2)
+        if args.mode == "api" and args.targets == "fresh":
+            # the reference benchmarks' own protocol: the same target list every iteration
+            el, _ = timed_loop(lambda i: wl["step"](0), extras_steps, 3, fence, False)
+            out["same_targets"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
+                                   "what": "operator path, one target list reused by every iteration (the reference "
+                                           "benchmark scripts' protocol; content-keyed host caches hit)"}
+        if args.workload == "ctc" and args.mode == "api":
+            el, ph = timed_loop(wl["abi_step"], extras_steps, 3, fence, True)
+            out["abi_kernels_only"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
+                                       "kernel_ms": ph, "utterances_repaired_in_log_domain": meta["repaired"](),
+                                       "what": "wfl_ctc_forward_backward through the C ABI, targets pre-staged: kernels only"}
+        if args.workload == "ctc":
+            try:  # the ABI step captured once in a hipGraph and replayed (no host launch gaps)
+                abi = wl["abi_step"]
+                graph = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    abi(0)
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.cuda.graph(graph):
+                    abi(0)
+                for _ in range(3):
+                    graph.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(extras_steps):
+                    graph.replay()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                out["hip_graph"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
+                                    "what": "the ABI step's kernels captured in one hipGraph and replayed"}
+            except Exception as exc:  # capture is an extra, never fail the bench on it
+                out["hip_graph"] = {"error": str(exc)[:200]}
+    if single and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl["payload"], args.cpu_sample_utts)
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if args.workload == "ctc":
+            out["cpu_torch_ctc_loss"] = cpu_torch_ctc(wl["payload"])
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

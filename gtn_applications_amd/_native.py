@@ -95,6 +95,7 @@ _SIGS = {
     "wfl_graph_save": (c_int, [_P, c_char_p]),
     # lattice packing
     "wfl_lattice_pack": (_P, [_P, _P, c_int, c_int, c_int, c_int]),
+    "wfl_transducer_pack_batch": (_P, [_P, _P, _P, _P, _P, c_int, c_int, c_int]),
     "wfl_lattice_pack_ctc": (_P, [_P, _P, c_int, c_int, c_int]),
     "wfl_lattice_pack_asg_fal": (_P, [_P, _P, c_int, c_int]),
     "wfl_lattice_pack_stc": (_P, [_P, _P, c_int, c_int, c_float, c_int]),

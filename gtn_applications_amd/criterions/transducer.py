@@ -256,18 +256,19 @@ class TransducerLossFunction(torch.autograd.Function):
             raise ValueError("TransducerLoss: empty emissions (T == 0)")
         dev = E.require_gpu()
         x = E.as_device_f32(inputs.detach(), dev)
-        rows = [t.tolist() if hasattr(t, "tolist") else [int(v) for v in t] for t in targets]
-        if len(rows) != B:
-            raise ValueError(f"got {len(rows)} targets for a batch of {B}")
+        flat, offsets, lens = E.flatten_any(targets)
+        if len(lens) != B:
+            raise ValueError(f"got {len(lens)} targets for a batch of {B}")
         params = E.as_device_f32(transition_params.detach(), dev) if transitions is not None else None
 
-        key = ("num", tuple(map(tuple, rows)), id(tokens), id(lexicon), id(transitions), C, dev.index)
+        key = ("num", flat.tobytes(), tuple(lens), id(tokens), id(lexicon), id(transitions), C, dev.index)
 
         def build():
-            graphs, wids = zip(*[_alignment_graph(r, tokens, lexicon, transitions) for r in rows])
-            pack = E.PackedLattice.from_graphs(list(graphs), C, dev, wids=list(wids) if transitions is not None else None)
+            # per-sample graph algebra of transducer.py:262-281 for the whole batch: one native call, threaded
+            # over the utterances like the reference's gtn.parallel_for (transducer.py:296)
+            pack = E.PackedLattice.transducer_batch(tokens, lexicon, transitions, flat, offsets, C, dev)
             if reduction == "mean":  # transducer.py:302-305: normalise by the (grapheme) target length
-                sc = [1.0 / len(r) if len(r) > 0 else 1.0 for r in rows]
+                sc = [1.0 / n if n > 0 else 1.0 for n in lens]
             else:
                 sc = [1.0] * B
             scale = torch.tensor(sc, dtype=torch.float32, device=dev)

@@ -174,31 +174,100 @@ wfl_graph* wfl_graph_compose(const wfl_graph* g1, const wfl_graph* g2, int32_t**
   const wfl::Adjacency& A1 = g1->out_sorted(true);   // by olabel
   const wfl::Adjacency& A2 = g2->out_sorted(false);  // by ilabel
   const int64_t n2 = g2->num_nodes();
-  std::unordered_map<int64_t, int32_t> node_of;
+  // (n1, n2) -> composed node: open-addressing table (linear probing, power-of-two capacity); the per-utterance
+  // compositions of the Transducer visit a few thousand pairs each and std::unordered_map's node allocations
+  // were most of their cost
+  std::vector<int64_t> tab_key(1024, -1);
+  std::vector<int32_t> tab_val(1024, 0);
+  size_t tab_mask = 1023, tab_used = 0;
   std::vector<std::pair<int32_t, int32_t>> pairs;  // node -> (n1, n2)
+  pairs.reserve(512);
   struct TArc {
     int32_t s, d, il, ol, a1, a2;
     float w;
   };
   std::vector<TArc> arcs;
-  std::deque<int32_t> queue;
-  auto get_node = [&](int32_t a, int32_t b) -> int32_t {
+  arcs.reserve(1024);
+  std::vector<int32_t> queue;  // FIFO: consumed through `qhead`
+  queue.reserve(512);
+  size_t qhead = 0;
+  auto slot_of_key = [&](int64_t key) {
+    uint64_t h = (uint64_t)key * 0x9E3779B97F4A7C15ull;
+    size_t i = (size_t)(h >> 20) & tab_mask;
+    while (tab_key[i] != -1 && tab_key[i] != key) i = (i + 1) & tab_mask;
+    return i;
+  };
+  // Dead-end pruning: a pair that is not accepting and has no way forward would only be trimmed again at the end,
+  // together with every arc into it.  Most pairs of the per-utterance compositions are of this kind (the reference's
+  // lexicon graph is an unshared trie: ~100 word pieces start with the same letter and all but a few die on their
+  // second letter), so they are recognised BEFORE a node, a queue entry and an arc are spent on them.  The
+  // surviving nodes and arcs keep their relative order: the result is identical to composing first and trimming after.
+  auto can_move = [&](int32_t a, int32_t b) -> bool {
+    if (g1->accept[a] && g2->accept[b]) return true;
+    const int32_t* x = A1.idx.data() + A1.ptr[a];
+    const int32_t* xe = A1.idx.data() + A1.ptr[a + 1];
+    const int32_t* y = A2.idx.data() + A2.ptr[b];
+    const int32_t* ye = A2.idx.data() + A2.ptr[b + 1];
+    if (x == xe && y == ye) return false;
+    if (x != xe && g1->ol[*x] == WFL_EPSILON) return true;  // (sorted: epsilon = -1 comes first)
+    if (y != ye && g2->il[*y] == WFL_EPSILON) return true;
+    if (x == xe || y == ye) return false;
+    if ((xe - x) * 8 < (ye - y) || (ye - y) * 8 < (xe - x)) {
+      const bool small_first = (xe - x) < (ye - y);
+      const int32_t *sm = small_first ? x : y, *sme = small_first ? xe : ye;
+      const int32_t *lg = small_first ? y : x, *lge = small_first ? ye : xe;
+      const std::vector<int32_t>& skey = small_first ? g1->ol : g2->il;
+      const std::vector<int32_t>& lkey = small_first ? g2->il : g1->ol;
+      for (; sm != sme; ++sm) {
+        const int32_t lab = skey[*sm];
+        const int32_t* lo = std::lower_bound(lg, lge, lab, [&](int32_t arc, int32_t v) { return lkey[arc] < v; });
+        if (lo != lge && lkey[*lo] == lab) return true;
+      }
+      return false;
+    }
+    while (x != xe && y != ye) {
+      const int32_t lx = g1->ol[*x], ly = g2->il[*y];
+      if (lx == ly) return true;
+      if (lx < ly)
+        ++x;
+      else
+        ++y;
+    }
+    return false;
+  };
+  // returns the node of pair (a, b), creating it on first sight; -1 for a dead end (remembered in the table)
+  auto get_node = [&](int32_t a, int32_t b, bool force) -> int32_t {
     const int64_t key = (int64_t)a * n2 + b;
-    auto it = node_of.find(key);
-    if (it != node_of.end()) return it->second;
-    const int32_t id = (int32_t)pairs.size();
-    node_of.emplace(key, id);
-    pairs.emplace_back(a, b);
-    queue.push_back(id);
+    size_t i = slot_of_key(key);
+    if (tab_key[i] == key) return tab_val[i];
+    const bool alive = force || can_move(a, b);
+    const int32_t id = alive ? (int32_t)pairs.size() : -1;
+    tab_key[i] = key, tab_val[i] = id;
+    ++tab_used;
+    if (alive) {
+      pairs.emplace_back(a, b);
+      queue.push_back(id);
+    }
+    if (tab_used * 2 > tab_mask) {  // keep the load factor below 1/2
+      std::vector<int64_t> ok;
+      std::vector<int32_t> ov;
+      ok.swap(tab_key), ov.swap(tab_val);
+      tab_mask = tab_mask * 4 + 3;
+      tab_key.assign(tab_mask + 1, -1), tab_val.assign(tab_mask + 1, 0);
+      for (size_t k = 0; k < ok.size(); ++k)
+        if (ok[k] != -1) {
+          const size_t j = slot_of_key(ok[k]);
+          tab_key[j] = ok[k], tab_val[j] = ov[k];
+        }
+    }
     return id;
   };
   for (int a = 0; a < g1->num_nodes(); ++a)
     if (g1->start[a])
       for (int b = 0; b < g2->num_nodes(); ++b)
-        if (g2->start[b]) get_node(a, b);
-  while (!queue.empty()) {
-    const int32_t cur = queue.front();
-    queue.pop_front();
+        if (g2->start[b]) get_node(a, b, true);
+  while (qhead < queue.size()) {
+    const int32_t cur = queue[qhead++];
     const int32_t a = pairs[cur].first, b = pairs[cur].second;
     const int32_t* x = A1.idx.data() + A1.ptr[a];
     const int32_t* xe = A1.idx.data() + A1.ptr[a + 1];
@@ -206,21 +275,21 @@ wfl_graph* wfl_graph_compose(const wfl_graph* g1, const wfl_graph* g2, int32_t**
     const int32_t* ye = A2.idx.data() + A2.ptr[b + 1];
     // epsilon on the first graph's output: advance first alone
     for (; x != xe && g1->ol[*x] == WFL_EPSILON; ++x) {
-      const int32_t d = get_node(g1->dst[*x], b);
-      arcs.push_back({cur, d, g1->il[*x], WFL_EPSILON, *x, -1, g1->w[*x]});
+      const int32_t d = get_node(g1->dst[*x], b, false);
+      if (d >= 0) arcs.push_back({cur, d, g1->il[*x], WFL_EPSILON, *x, -1, g1->w[*x]});
     }
     // epsilon on the second graph's input: advance second alone
     const int32_t* y0 = y;
     for (; y != ye && g2->il[*y] == WFL_EPSILON; ++y) {
-      const int32_t d = get_node(a, g2->dst[*y]);
-      arcs.push_back({cur, d, WFL_EPSILON, g2->ol[*y], -1, *y, g2->w[*y]});
+      const int32_t d = get_node(a, g2->dst[*y], false);
+      if (d >= 0) arcs.push_back({cur, d, WFL_EPSILON, g2->ol[*y], -1, *y, g2->w[*y]});
     }
     (void)y0;
     // label matches: both ranges are sorted by the matching label
     const int64_t nx = xe - x, ny = ye - y;
     auto emit = [&](const int32_t* xa, const int32_t* ya) {
-      const int32_t d = get_node(g1->dst[*xa], g2->dst[*ya]);
-      arcs.push_back({cur, d, g1->il[*xa], g2->ol[*ya], *xa, *ya, g1->w[*xa] + g2->w[*ya]});
+      const int32_t d = get_node(g1->dst[*xa], g2->dst[*ya], false);
+      if (d >= 0) arcs.push_back({cur, d, g1->il[*xa], g2->ol[*ya], *xa, *ya, g1->w[*xa] + g2->w[*ya]});
     };
     if (nx == 0 || ny == 0) continue;
     if (nx * 8 < ny || ny * 8 < nx) {

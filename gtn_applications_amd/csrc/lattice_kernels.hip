@@ -416,8 +416,17 @@ constexpr int kPre = 8;  // prefetch registers per thread: rows_per_chunk * max_
 template <int SR, int DIR>
 __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const ChainLds& L, int T, int rows_per_chunk,
                           const float* __restrict__ xg, const float* __restrict__ weights, float* __restrict__ out,
-                          int32_t* __restrict__ bptr, float* __restrict__ logz, int b) {
+                          int32_t* __restrict__ bptr, float* __restrict__ logz, int b, double* __restrict__ offs,
+                          double* __restrict__ z64) {
   const int tid = threadIdx.x, NT = blockDim.x;
+  // Block renormalisation (log semiring): plain fp32 log scores drift to O(T) -- thousands at T = 800..1000, where
+  // one ulp is 2.4e-4 .. 4.9e-4 and the posteriors lose their third digit (measured against the float64 oracle at
+  // BASELINE configs 3 and 4).  So at the start of every chunk of R frames the maximum of the state vector moves
+  // into a double offset: stored scores stay O(R * |x|), offs[1 + c] is what the slots produced in chunk c are
+  // relative to (offs[0] = 0: the boundary slot), and the gradient kernel adds offs_alpha + offs_beta - log Z in
+  // double before it exponentiates.
+  double cum = 0.0;
+  if (SR == WFL_SEMIRING_LOG && tid == 0) offs[0] = 0.0;
   const int Q = u.Q, A = u.A, E = u.E, nlev = u.nlev, Kmax = d.max_labels;
   // ---- stage the acceptor into LDS in this direction's CSR order
   for (int k = tid; k < A; k += NT) {
@@ -569,6 +578,32 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           const int e = tid + j * NT;
           if (e < pn * Kmax) pre[j] = src[e];
         }
+      }
+      if (SR == WFL_SEMIRING_LOG) {
+        if (c > 0) {
+          float m;
+          if (V != 0 && NT == 64) {  // the vector lives in registers
+            m = wave_all_max(sc);
+            if (m > WFL_NEG_INF && m < __builtin_inff())
+              sc -= m;
+            else
+              m = 0.f;
+          } else {
+            const int tf = DIR == 0 ? f0 : f0 + n;  // slot the first frame of the chunk reads
+            float* fromb = V != 0 ? (first_reads_buf1 ? L.buf1 : L.buf0) : ((tf & 1) ? L.buf1 : L.buf0);
+            float v = WFL_NEG_INF;
+            for (int q = tid; q < Q; q += NT) v = fmaxf(v, fromb[q]);
+            m = block_reduce_max(v, L.red);
+            if (m > WFL_NEG_INF && m < __builtin_inff()) {
+              for (int q = tid; q < Q; q += NT) fromb[q] -= m;
+            } else {
+              m = 0.f;
+            }
+            __syncthreads();
+          }
+          cum += (double)m;
+        }
+        if (tid == 0) offs[1 + c] = cum;
       }
       // single-wave variants: the emissions of frame i+1 are read from the tile while frame i is
       // being computed (they do not depend on the chain), so only the score exchange is serial
@@ -725,7 +760,11 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
       s = block_reduce_sum(s, L.red);
       z = m + fast_log(s);
     }
-    if (tid == 0) logz[b] = z;
+    if (tid == 0) {
+      const double zd = (double)z + cum;  // (-inf + cum = -inf: no accepting path)
+      logz[b] = (float)zd;
+      if (SR == WFL_SEMIRING_LOG) z64[b] = zd;
+    }
   }
 }
 
@@ -733,9 +772,13 @@ template <int SR>
 __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
                              const float* __restrict__ xg, int T, int rows_per_chunk,
                              const float* __restrict__ weights, float* __restrict__ alpha, float* __restrict__ beta,
-                             int32_t* __restrict__ bptr, float* __restrict__ logz) {
+                             int32_t* __restrict__ bptr, float* __restrict__ logz, int64_t tail, int nch1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, dir = blockIdx.y;
+  // renormalisation offsets live behind the score arrays (wfl_lattice_workspace reserves the room):
+  // alpha + tail: double offs[B][nch1], double logZ[B];  beta + tail: double offs[B][nch1]
+  double* offs_a = reinterpret_cast<double*>(alpha + tail);
+  double* offs_b = beta ? reinterpret_cast<double*>(beta + tail) : nullptr;
   const UttView u = make_view(d, ints, floats, b, T);
   ChainLds L;
   char* p = smem;
@@ -750,9 +793,11 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
   L.lvl = (int*)p, p += (size_t)(d.max_levels + 1) * 4;
   L.heavy = (int*)p;
   if (dir == 0)
-    run_chain<SR, 0>(d, u, L, T, rows_per_chunk, xg, weights, alpha, bptr, logz, b);
+    run_chain<SR, 0>(d, u, L, T, rows_per_chunk, xg, weights, alpha, bptr, logz, b, offs_a + (int64_t)b * nch1,
+                     offs_a + (int64_t)d.B * nch1);
   else
-    run_chain<SR, 1>(d, u, L, T, rows_per_chunk, xg, weights, beta, nullptr, nullptr, b);
+    run_chain<SR, 1>(d, u, L, T, rows_per_chunk, xg, weights, beta, nullptr, nullptr, b, offs_b + (int64_t)b * nch1,
+                     nullptr);
 }
 
 static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
@@ -774,7 +819,8 @@ __global__ void __launch_bounds__(256)
                 const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
                 const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
                 int accumulate, const float* __restrict__ x, const float* __restrict__ row_lse,
-                float* __restrict__ dx, float* __restrict__ dW, int rows_per_block, int TS) {
+                float* __restrict__ dx, float* __restrict__ dW, int rows_per_block, int TS, int64_t tail, int nch1,
+                int R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
 #ifdef WFL_DBG_TIMELINE
@@ -797,7 +843,14 @@ __global__ void __launch_bounds__(256)
   // the blank column of a CTC-like acceptor (two in-arcs per blank state: hundreds of arcs in ONE
   // slot) is spread over many threads instead of serialising the tile
   int2* chunk = (int2*)(sptr + (dx ? ((Kmax + 3) & ~1) : 0));  // [NC] {slot, first arc}; NC <= K + A / kChunk (8-byte aligned)
-  int16_t* colmap = (int16_t*)(chunk + (dx ? Kmax + d.max_arcs / kChunk + 1 : 0));  // [C] (only if dx)
+  float* corr = (float*)(chunk + (dx ? Kmax + d.max_arcs / kChunk + 1 : 0));  // [TS]: offs_alpha(t) + offs_beta(t+1) - log Z
+  float* corr_eps = corr + TS;                                                 // [TS+1]: both at slot t (epsilon arcs)
+  int16_t* colmap = (int16_t*)(corr_eps + TS + 1);  // [C] (only if dx)
+  // scores are stored relative to per-chunk double offsets (run_chain): slot s of alpha belongs to chunk (s-1)/R of
+  // the forward sweep, slot s of beta to chunk (T-1-s)/R of the backward sweep, the boundary slots to offset 0
+  const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
+  const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
+  const double zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];
   const float g0 = gout ? gout[0] : 1.f;
   const float cf = coef ? coef[b] * g0 : g0;
   const float z = logz[b];
@@ -822,7 +875,7 @@ __global__ void __launch_bounds__(256)
     for (int j = tid; j < A; j += NT) {
       const int a = u.slot_arc[j];
       const int wid = u.arc_wid[a];
-      float w = u.arc_w[a] - z;
+      float w = u.arc_w[a];
       if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
       sarc[j] = make_int2(u.arc_src[a] | (u.arc_dst[a] << 16), __float_as_int(w));
     }
@@ -849,6 +902,12 @@ __global__ void __launch_bounds__(256)
         xr[i] = xsrc[i];
         if (dx) acc[i] = 0.f;
       }
+      if (tid <= nr) {
+        const int sl = ts0 + tid;
+        const double oa = offs_a[sl == 0 ? 0 : 1 + (sl - 1) / R];
+        corr_eps[tid] = (float)(oa + offs_b[sl == T ? 0 : 1 + (T - 1 - sl) / R] - zd);
+        if (tid < nr) corr[tid] = (float)(oa + offs_b[sl + 1 == T ? 0 : 1 + (T - 2 - sl) / R] - zd);
+      }
     }
     __syncthreads();
     if (!dead) {
@@ -863,7 +922,7 @@ __global__ void __launch_bounds__(256)
           const int k = ch.x, j1 = min(ch.y + kChunk, sptr[k + 1]);
           const float* pa = al + r * d.max_states;
           const float* pb = pa + (be - al) + d.max_states;
-          const float xv = xr[r * Kmax + k];
+          const float xv = xr[r * Kmax + k] + corr[r];
           float sum = 0.f;
           for (int j = ch.y; j < j1; ++j) {
             const int2 a = sarc[j];
@@ -881,12 +940,13 @@ __global__ void __launch_bounds__(256)
         for (int a = tid; a < A; a += NT) {
           const int wid = u.arc_wid[a];
           if (wid < 0) continue;
-          const float w = u.arc_w[a] - z + (weights ? nan_to_neg(weights[wid]) : 0.f);
+          const float w = u.arc_w[a] + (weights ? nan_to_neg(weights[wid]) : 0.f);
           const float* pa = al + u.arc_src[a];
           const float* pb = be + d.max_states + u.arc_dst[a];
           const float* px = xr + u.arc_slot[a];
           float wsum = 0.f;
-          for (int r = 0; r < nr; ++r) wsum += fast_exp(pa[r * d.max_states] + px[r * Kmax] + w + pb[r * d.max_states]);
+          for (int r = 0; r < nr; ++r)
+            wsum += fast_exp(pa[r * d.max_states] + (px[r * Kmax] + corr[r]) + w + pb[r * d.max_states]);
           if (wsum != 0.f) dwacc[a] += wsum;  // this thread owns dwacc[a]
         }
       }
@@ -897,7 +957,7 @@ __global__ void __launch_bounds__(256)
           const int wid = u.eps_wid[e];
           if (wid < 0) continue;
           const float w = u.eps_w[e] + (weights ? nan_to_neg(weights[wid]) : 0.f);
-          const float v = al[r * d.max_states + u.eps_src[e]] + w + be[r * d.max_states + u.eps_dst[e]] - z;
+          const float v = al[r * d.max_states + u.eps_src[e]] + w + be[r * d.max_states + u.eps_dst[e]] + corr_eps[r];
           if (v > WFL_NEG_INF) atomicAdd(&dwacc[A + e], fast_exp(v));
         }
       }
@@ -1107,13 +1167,37 @@ using namespace wfl;
 
 extern "C" {
 
+// Launch shape of the chain kernel: threads per workgroup and emission rows per chunk (also the renormalisation
+// interval, so the gradient kernel needs the same number).
+static void chain_config(const wfl_lattice_desc& d, int& nt, int& rpc) {
+  // one state per thread up to 1024 states (the lean frame paths need it); beyond that threads loop
+  nt = d.max_states <= 64 ? 64 : d.max_states <= 128 ? 128 : d.max_states <= 256 ? 256 : d.max_states <= 512 ? 512 : 1024;
+  while (nt < 256 && nt * kPre < 2 * d.max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
+  rpc = std::max(2, std::min(16, nt * kPre / std::max(1, d.max_labels)) & ~1);  // even (run_chain)
+}
+// scores [..] | pad to 8 B | double offs[B][nch1] | double logZ[B]   (nch1 = chunks + 1; see run_chain)
+static int64_t ab_main_elems(const wfl_lattice_desc& d, int T) {
+  return d.shared ? (int64_t)d.B * (T + 1) * d.max_states : (int64_t)(T + 1) * d.total_states;
+}
+static void ab_tail(const wfl_lattice_desc& d, int T, int64_t& tail, int& nch1) {
+  int nt, rpc;
+  chain_config(d, nt, rpc);
+  nch1 = (T + rpc - 1) / rpc + 1;
+  tail = (ab_main_elems(d, T) + 1) & ~(int64_t)1;
+}
+
 int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, int64_t* ab_elems) {
   if (!d || T < 0) {
     set_error("lattice_workspace: bad arguments");
     return WFL_ERR_INVALID;
   }
   if (xg_elems) *xg_elems = (int64_t)d->B * T * d->max_labels;
-  if (ab_elems) *ab_elems = d->shared ? (int64_t)d->B * (T + 1) * d->max_states : (int64_t)(T + 1) * d->total_states;
+  if (ab_elems) {
+    int64_t tail;
+    int nch1;
+    ab_tail(*d, T, tail, nch1);
+    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B);
+  }
   return WFL_OK;
 }
 
@@ -1163,10 +1247,10 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     set_error("lattice_forward: %d distinct labels per utterance (limit 1024)", d->max_labels);
     return WFL_ERR_UNSUPPORTED;
   }
-  // one state per thread up to 1024 states (the lean frame paths need it); beyond that threads loop
-  int nt = d->max_states <= 64 ? 64 : d->max_states <= 128 ? 128 : d->max_states <= 256 ? 256 : d->max_states <= 512 ? 512 : 1024;
-  while (nt < 256 && nt * kPre < 2 * d->max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
-  const int rpc = std::max(2, std::min(16, nt * kPre / std::max(1, d->max_labels)) & ~1);  // even (run_chain)
+  int nt, rpc, nch1;
+  int64_t tail;
+  chain_config(*d, nt, rpc);
+  ab_tail(*d, T, tail, nch1);
   const size_t lds = chain_lds_bytes(*d, rpc);
   if (lds > (size_t)kLdsBytes) {
     set_error("lattice_forward: acceptor needs %zu B of LDS (limit %d): %d arcs, %d states", lds, kLdsBytes,
@@ -1179,7 +1263,7 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
-                       beta, (int32_t*)nullptr, logz);
+                       beta, (int32_t*)nullptr, logz, tail, nch1);
   } else if (semiring == WFL_SEMIRING_TROPICAL) {
     if (!bptr) {
       set_error("lattice_forward: tropical semiring needs a back-pointer buffer");
@@ -1190,7 +1274,7 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
-                       (float*)nullptr, bptr, logz);
+                       (float*)nullptr, bptr, logz, tail, nch1);
   } else {
     set_error("lattice_forward: unknown semiring %d", semiring);
     return WFL_ERR_INVALID;
@@ -1221,11 +1305,15 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
                        (dx ? 8 * (size_t)d->max_arcs + 4 * (((size_t)d->max_labels + 3) & ~(size_t)1) +
                                 8 * ((size_t)d->max_labels + d->max_arcs / kChunk + 1) + 2 * (size_t)C
                           : 0) +
-                       64;
+                       4 * (2 * 32 + 2) + 64;  // (+ the per-row offset corrections of at most 32 + 1 rows)
   if (dx && d->max_labels > 32767) {
     set_error("lattice_grad: %d distinct labels per utterance (limit 32767)", d->max_labels);
     return WFL_ERR_UNSUPPORTED;
   }
+  int nt_chain, rpc, nch1;
+  int64_t tail;
+  chain_config(*d, nt_chain, rpc);
+  ab_tail(*d, T, tail, nch1);
   int TS = fixed + row_bytes < 24 * 1024 ? (int)((24 * 1024 - fixed) / row_bytes) : 1;
   TS = std::max(1, std::min(TS, 32));
   const size_t lds = fixed + row_bytes * TS;
@@ -1257,7 +1345,7 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
     WFL_HIP_CHECK(hipFuncSetAttribute((const void*)grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(grad_kernel, dim3((unsigned)blocks_t, (unsigned)d->B), dim3(256), lds, (hipStream_t)stream, *d,
                      ints, floats, xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, x, row_lse,
-                     dx, dW, rows_per_block, TS);
+                     dx, dW, rows_per_block, TS, tail, nch1, rpc);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

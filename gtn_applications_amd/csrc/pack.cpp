@@ -3,11 +3,17 @@
 // label-graph constructors without per-arc host calls:
 //   CTC  criterions/ctc.py:15-29, ASG force-align asg.py:72-81 composed with the dense transitions
 //   graph asg.py:54-69, STC stc.py:23-64.
+#include <pthread.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 #include "common.h"
 
@@ -158,6 +164,28 @@ struct Builder {
     max_labels = std::max(max_labels, K);
     max_levels = std::max(max_levels, n_levels);
     return true;
+  }
+
+  // Appends the utterances of `o` (built independently, e.g. on another host thread) behind this builder's.
+  void append(const Builder& o) {
+    auto cat = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+    for (size_t k = 1; k < o.state_off.size(); ++k) {
+      state_off.push_back(state_off.back() + (o.state_off[k] - o.state_off[k - 1]));
+      arc_off.push_back(arc_off.back() + (o.arc_off[k] - o.arc_off[k - 1]));
+      eps_off.push_back(eps_off.back() + (o.eps_off[k] - o.eps_off[k - 1]));
+      lab_off.push_back((int32_t)labels.size() + o.lab_off[k]);
+      lvl_off.push_back((int32_t)lvl_ptr.size() + o.lvl_off[k]);
+    }
+    cat(in_ptr, o.in_ptr), cat(out_ptr, o.out_ptr), cat(out_arc, o.out_arc);
+    cat(ein_ptr, o.ein_ptr), cat(eout_ptr, o.eout_ptr), cat(eout_arc, o.eout_arc);
+    cat(arc_src, o.arc_src), cat(arc_dst, o.arc_dst), cat(arc_slot, o.arc_slot), cat(arc_lab, o.arc_lab);
+    cat(arc_wid, o.arc_wid), cat(arc_orig, o.arc_orig), cat(eps_src, o.eps_src), cat(eps_dst, o.eps_dst);
+    cat(eps_wid, o.eps_wid), cat(eps_orig, o.eps_orig), cat(labels, o.labels), cat(lvl_ptr, o.lvl_ptr);
+    cat(slot_ptr, o.slot_ptr), cat(slot_arc, o.slot_arc);
+    cat(arc_w, o.arc_w), cat(eps_w, o.eps_w), cat(start_w, o.start_w), cat(accept_w, o.accept_w);
+    max_states = std::max(max_states, o.max_states), max_arcs = std::max(max_arcs, o.max_arcs);
+    max_eps = std::max(max_eps, o.max_eps), max_labels = std::max(max_labels, o.max_labels);
+    max_levels = std::max(max_levels, o.max_levels);
   }
 
   wfl_lattice_host* finish(int B, int shared) {
@@ -314,6 +342,199 @@ wfl_lattice_host* wfl_lattice_pack_stc(const int32_t* targets, const int64_t* of
     if (!bld.add(Q, st.data(), ac.data(), arcs)) return nullptr;
   }
   return bld.finish(B, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batch-parallel host side of the Transducer (gtn.parallel_for over process(b), transducer.py:296,327)
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// A persistent pool of host threads: parallel_for(n, fn) runs fn(0..n-1) on the pool plus the calling thread
+// and returns when all are done.  Created on first use, never destroyed (threads die with the process); a
+// forked child starts with a fresh pool.  Concurrent callers are serialised.
+class HostPool {
+ public:
+  explicit HostPool(int nthreads) {
+    for (int i = 0; i < nthreads; ++i) std::thread([this] { worker(); }).detach();
+  }
+  void parallel_for(int n, const std::function<void(int)>& fn) {
+    std::lock_guard<std::mutex> run(run_mu_);
+    {
+      // stragglers of the previous job may still be leaving drain(): they must not see the new counters
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_done_.wait(lk, [this] { return inside_ == 0; });
+      fn_ = &fn, n_ = n, next_.store(0), pending_ = n, ++epoch_;
+    }
+    cv_work_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void drain() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_) break;
+      (*fn_)(i);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) cv_done_.notify_all();
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_work_.wait(lk, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (!fn_) continue;
+        ++inside_;
+      }
+      drain();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--inside_ == 0) cv_done_.notify_all();
+    }
+  }
+  std::mutex run_mu_, mu_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, pending_ = 0, inside_ = 0;
+  uint64_t epoch_ = 0;
+};
+
+std::mutex g_pool_mu;
+HostPool* g_pool = nullptr;
+int g_pool_threads = 0;
+
+void pool_after_fork_child() {  // the parent's threads do not exist in the child: start over (leaks one object)
+  new (&g_pool_mu) std::mutex();
+  g_pool = nullptr, g_pool_threads = 0;
+}
+
+HostPool& host_pool() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (!g_pool) {
+    static bool hooked = false;
+    if (!hooked) pthread_atfork(nullptr, nullptr, pool_after_fork_child), hooked = true;
+    const unsigned hw = std::thread::hardware_concurrency();
+    g_pool_threads = (int)std::max(1u, std::min(hw ? hw - 1 : 7u, 63u));  // + the calling thread
+    g_pool = new HostPool(g_pool_threads);
+  }
+  return *g_pool;
+}
+
+struct GraphOwner {  // frees an intermediate graph at scope exit
+  wfl_graph* g;
+  explicit GraphOwner(wfl_graph* p) : g(p) {}
+  ~GraphOwner() { wfl_graph_free(g); }
+  GraphOwner(const GraphOwner&) = delete;
+  GraphOwner& operator=(const GraphOwner&) = delete;
+};
+
+// transducer.py:265-281 for one target: all frame-level alignments of all decompositions of the target into
+// tokens, optionally intersected with the transition model (then `wid` = arc of the transition model behind each
+// arc, the index of its learnable weight).  Returns false with the thread's error set.
+#ifdef WFL_PROFILE_HOST
+#include <chrono>
+static std::atomic<long long> g_prof[8];
+struct ProfDump { ~ProfDump() { for (int i = 0; i < 8; ++i) fprintf(stderr, "prof[%d] = %.3f ms\n", i, g_prof[i].load() / 1e6); } } g_prof_dump;
+#define PROF_T0 auto _t = std::chrono::steady_clock::now();
+#define PROF(i) { auto _n = std::chrono::steady_clock::now(); g_prof[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(_n - _t).count(); _t = _n; }
+#else
+#define PROF_T0
+#define PROF(i)
+#endif
+bool alignment_acceptor(const wfl_graph* tokens, const wfl_graph* lexicon, const wfl_graph* transitions,
+                        const int32_t* target, int len, int C, Builder& out) {
+  wfl_graph chain;  // make_chain_graph (transducer.py:23-29)
+  chain.start.assign(len + 1, 0), chain.accept.assign(len + 1, 0);
+  chain.start[0] = 1, chain.accept[len] = 1;
+  for (int i = 0; i < len; ++i)
+    chain.src.push_back(i), chain.dst.push_back(i + 1), chain.il.push_back(target[i]), chain.ol.push_back(target[i]),
+        chain.w.push_back(0.f);
+  PROF_T0
+  GraphOwner c1(wfl_graph_compose(&chain, lexicon, nullptr, nullptr));
+  if (!c1.g) return false;
+  PROF(0)
+  c1.g->il = c1.g->ol;  // project_output in place (c1 is ours)
+  GraphOwner tokens_target(wfl_graph_remove(c1.g, WFL_EPSILON, WFL_EPSILON, nullptr));
+  if (!tokens_target.g) return false;
+  PROF(1)
+  GraphOwner c2(wfl_graph_compose(tokens, tokens_target.g, nullptr, nullptr));
+  if (!c2.g) return false;
+  PROF(2)
+  GraphOwner ali(wfl_graph_remove(c2.g, WFL_EPSILON, WFL_EPSILON, nullptr));
+  if (!ali.g) return false;
+  PROF(3)
+  ali.g->ol = ali.g->il;  // project_input
+  const wfl_graph* fin = ali.g;
+  int32_t* prov = nullptr;
+  wfl_graph* with_trans = nullptr;
+  if (transitions) {
+    with_trans = wfl_graph_compose(transitions, ali.g, &prov, nullptr);
+    if (!with_trans) return false;
+    fin = with_trans;
+  }
+  std::vector<Arc> arcs;
+  const int64_t m = fin->num_arcs();
+  arcs.reserve(m);
+  for (int64_t a = 0; a < m; ++a)
+    arcs.push_back({fin->src[a], fin->dst[a], fin->il[a], prov ? prov[a] : -1, (int32_t)a, transitions ? 0.f : fin->w[a]});
+  out.C = C;
+  PROF(4)
+  const bool ok = out.add(fin->num_nodes(), fin->start.data(), fin->accept.data(), arcs);
+  PROF(5)
+  if (prov) free(prov);
+  if (with_trans) wfl_graph_free(with_trans);
+  return ok;
+}
+
+}  // namespace
+
+extern "C" {
+
+wfl_lattice_host* wfl_transducer_pack_batch(const wfl_graph* tokens, const wfl_graph* lexicon,
+                                            const wfl_graph* transitions, const int32_t* targets,
+                                            const int64_t* offsets, int B, int C, int nthreads) {
+  if (!tokens || !lexicon || !targets || !offsets || B <= 0) {
+    set_error("transducer_pack_batch: bad arguments");
+    return nullptr;
+  }
+  // build the shared operands' label-sorted adjacency once, before the threads ask for it
+  tokens->out_sorted(true), lexicon->out_sorted(false);
+  if (transitions) transitions->out_sorted(true);
+  std::vector<Builder> parts(B);
+  std::vector<std::string> errors(B);
+  std::atomic<int> failed{0};
+  auto one = [&](int b) {
+    if (!alignment_acceptor(tokens, lexicon, transitions, targets + offsets[b], (int)(offsets[b + 1] - offsets[b]), C,
+                            parts[b])) {
+      errors[b] = wfl_last_error();
+      failed.store(1);
+    }
+  };
+  if (nthreads == 1 || B == 1) {
+    for (int b = 0; b < B; ++b) one(b);
+  } else {
+    host_pool().parallel_for(B, one);
+  }
+  if (failed.load()) {
+    for (int b = 0; b < B; ++b)
+      if (!errors[b].empty()) {
+        set_error("transducer_pack_batch: utterance %d: %s", b, errors[b].c_str());
+        break;
+      }
+    return nullptr;
+  }
+  Builder all;
+  all.C = C;
+  for (int b = 0; b < B; ++b) all.append(parts[b]);
+  return all.finish(B, 0);
 }
 
 void wfl_lattice_host_free(wfl_lattice_host* h) { delete h; }

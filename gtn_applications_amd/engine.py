@@ -63,6 +63,39 @@ def flatten_targets(targets):
     return flat, offsets, lens
 
 
+# bench.py sets this to a list to time the native launches of a step with HIP events recorded on the stream
+# each launch goes to: entries are (phase name, start event, end event).  None (the default) costs one test.
+PHASE_EVENTS = None
+
+
+def _mark(name):
+    if PHASE_EVENTS is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return name, ev
+
+
+def _done(tok):
+    if tok is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        PHASE_EVENTS.append((tok[0], tok[1], ev))
+
+
+def flatten_any(targets):
+    """Targets as the criteria receive them -- a list of int sequences or of 1-D LongTensors (train.py hands over
+    tensors, the benchmarks lists) -> (flat int32 array, offsets int64 [B+1], lengths).  Tensors are flattened
+    with one torch.cat instead of B tolist() calls."""
+    if len(targets) and all(type(t) is torch.Tensor and t.dim() == 1 and not t.is_cuda for t in targets):
+        lens = [t.numel() for t in targets]
+        flat = torch.cat(targets).to(torch.int32).numpy() if sum(lens) else np.zeros(0, np.int32)
+        offsets = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        return flat, offsets, lens
+    return flatten_targets(targets)
+
+
 class LRU:
     def __init__(self, capacity=32):
         self.capacity = capacity
@@ -129,6 +162,17 @@ class PackedLattice:
         return cls(h, device)
 
     @classmethod
+    def transducer_batch(cls, tokens, lexicon, transitions, flat, offsets, C, device, nthreads=0):
+        """Alignment acceptors of a whole batch, built and packed on the library's host thread pool
+        (wfl_transducer_pack_batch: transducer.py:262-281 under gtn.parallel_for)."""
+        flat = np.ascontiguousarray(flat, dtype=np.int32)
+        if flat.size == 0:
+            flat = np.zeros(1, np.int32)
+        h = N.lib.wfl_transducer_pack_batch(tokens._h, lexicon._h, None if transitions is None else transitions._h,
+                                            flat.ctypes.data, offsets.ctypes.data, len(offsets) - 1, int(C), int(nthreads))
+        return cls(h, device)
+
+    @classmethod
     def ctc(cls, flat, offsets, blank, C, device):
         return cls(N.lib.wfl_lattice_pack_ctc(flat.ctypes.data, offsets.ctypes.data, len(offsets) - 1, blank, C), device)
 
@@ -180,19 +224,25 @@ def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_L
     st.x = x if log_softmax else None
     st.row_lse = torch.empty((B, T), dtype=_F32, device=dev) if log_softmax else None
     s = stream_ptr()
+    tag = "/shared" if d.shared else ""
+    tok = _mark("lattice_gather" + tag)
     N.check(N.lib.wfl_lattice_gather(pack._desc_ref, ptr(pack.ints), ptr(x), T, C, ptr(st.xg), ptr(st.row_lse), s))
+    _done(tok)
+    tok = _mark("lattice_chain" + tag)
     N.check(
         N.lib.wfl_lattice_forward(
             pack._desc_ref, ptr(pack.ints), ptr(pack.floats), ptr(st.xg), T, ptr(weights), semiring,
             ptr(st.alpha), ptr(st.beta), ptr(st.bptr), ptr(st.logz), s,
         )
     )
+    _done(tok)
     return st
 
 
 def lattice_grad(st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None):
     """Posteriors of the lattice -> dense emission gradient rows (and learnable-weight grads)."""
     p = st.pack
+    tok = _mark("lattice_grad" + ("/shared" if p.desc.shared else ""))
     N.check(
         N.lib.wfl_lattice_grad(
             p._desc_ref, ptr(p.ints), ptr(p.floats), ptr(st.xg), st.T, st.C, ptr(st.weights), ptr(st.alpha),
@@ -200,6 +250,7 @@ def lattice_grad(st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW
             ptr(st.row_lse), ptr(dx), ptr(dW), stream_ptr(),
         )
     )
+    _done(tok)
 
 
 def lattice_viterbi(x, pack, weights=None):
@@ -291,10 +342,12 @@ def dense_forward(x, W, need_beta=True):
     st.beta = torch.empty((B, T, C), dtype=_F32, device=x.device) if need_beta else None
     st.logz = torch.empty(B, dtype=_F32, device=x.device)
     st.ws = torch.empty(_dense_sizes(B, T, C)[1], dtype=torch.uint8, device=x.device)
+    tok = _mark("dense_chain")
     N.check(
         N.lib.wfl_dense_forward(ptr(x), ptr(W), B, T, C, N.SEMIRING_LOG, ptr(st.alpha), ptr(st.beta), None,
                                 ptr(st.logz), ptr(st.ws), stream_ptr())
     )
+    _done(tok)
     return st
 
 
@@ -309,11 +362,13 @@ def dense_grad(x, W, st, coef, coef_w=None, gout=None, dx=None, accumulate=False
     part = None
     if dW is not None:
         part = torch.empty(_dense_sizes(st.B, st.T, st.C)[0], dtype=_F32, device=x.device)
+    tok = _mark("dense_grad")
     N.check(
         N.lib.wfl_dense_grad(ptr(x), ptr(W), st.B, st.T, st.C, ptr(st.alpha), ptr(st.beta), ptr(st.logz), ptr(coef),
                              ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(dx), ptr(dW), ptr(part), ptr(st.ws),
                              stream_ptr())
     )
+    _done(tok)
 
 
 def dense_viterbi(x, W):
@@ -410,11 +465,13 @@ def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_los
     ws = torch.empty(n_ws, dtype=_F32, device=x.device)
     nll = torch.empty(B, dtype=_F32, device=x.device)
     loss = torch.empty((), dtype=_F32, device=x.device) if want_loss else None
+    tok = _mark("ctc_step")
     N.check(
         N.lib.wfl_ctc_forward_backward(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank,
                                        ptr(ws), ptr(nll), ptr(coef), ptr(gout), ptr(dx), ptr(loss_scale), ptr(loss),
                                        ptr(lse), stream_ptr())
     )
+    _done(tok)
     return (ws, nll, loss) if want_loss else (ws, nll)
 
 

@@ -147,6 +147,17 @@ typedef struct wfl_lattice_host wfl_lattice_host; /* opaque: descriptor + host b
  * (-1: none).  Replaces what gtn.intersect(emissions, A_b) needs to know about A_b. */
 wfl_lattice_host* wfl_lattice_pack(const wfl_graph* const* graphs, const int32_t* const* wid,
                                    int n_graphs, int B, int shared, int C);
+/* TransducerLossFunction.forward's per-sample host work for a whole batch (transducer.py:262-281 under
+ * gtn.parallel_for, :296): for every target b (flat int32 graphemes + offsets[B+1])
+ *     tokens_target = remove(project_output(compose(chain(target_b), lexicon)))
+ *     alignments_b  = project_input(remove(compose(tokens, tokens_target)))
+ *     [alignments_b = compose(transitions, alignments_b); wid = arc of `transitions` behind each arc]
+ * on a persistent pool of host threads (nthreads: 1 = serial in the caller, otherwise the pool: one thread per
+ * host core up to 64), packed like wfl_lattice_pack.  With `transitions` the arcs' constant weights are 0 (the
+ * learnable weights are added on the device through wid), as the reference overwrites them (transducer.py:255). */
+wfl_lattice_host* wfl_transducer_pack_batch(const wfl_graph* tokens, const wfl_graph* lexicon,
+                                            const wfl_graph* transitions, const int32_t* targets,
+                                            const int64_t* offsets, int B, int C, int nthreads);
 /* Bulk builders for the three fixed-topology label graphs (no per-arc host calls):
  *   CTC  create_ctc_graph          ctc.py:15-29     targets flat + offsets[B+1], blank
  *   ASG  create_force_align_graph  asg.py:72-81 composed with the transitions graph asg.py:54-69:

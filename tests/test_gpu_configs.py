@@ -152,7 +152,8 @@ def test_cfg4_transducer_word_pieces():
     loss.backward()
     dx = xg.grad.cpu().numpy()
     assert np.isfinite(loss.item())
-    assert np.abs(dx.sum(axis=2)).max() <= 1e-4 * (1.0 / (B * 60))  # log_softmax backward: rows sum to zero
+    # log_softmax backward: rows sum to zero, i.e. the posteriors of a frame sum to one to 1e-4 of their scale
+    assert np.abs(dx.sum(axis=2)).max() <= 1e-4 * (1.0 / (B * min(len(t) for t in targets)))
     crit.tokens.arc_sort(True)
     losses = []
     for b in range(B):

@@ -487,3 +487,40 @@ def test_target_labels_are_range_checked_before_any_kernel_sees_them():
         else:
             with pytest.raises(ValueError):
                 E.check_labels(tg, 4, "t")
+
+
+@pytest.mark.parametrize("with_transitions", [False, True])
+def test_native_batch_builder_equals_per_utterance_graph_algebra(with_transitions):
+    """wfl_transducer_pack_batch (thread pool over the batch, transducer.py:262-281,296) produces exactly the
+    packed batch that composing / removing / projecting utterance by utterance and then packing does --
+    serial and threaded, several times over (the pool is persistent)."""
+    rs = np.random.RandomState(4)
+    pieces = ["a", "b", "ab", "ba", "aba", "bab", "c", "ca"]
+    g2i = {"a": 0, "b": 1, "c": 2}
+    tokens = TR.make_token_graph(pieces, "optional", False)
+    lexicon = TR.make_lexicon_graph(pieces, g2i)
+    C = len(pieces) + 1
+    trans = None
+    if with_transitions:
+        trans = TR._zero_weight_view(TR.make_transitions_graph(2, C, True))
+        trans.arc_sort()
+    tokens.arc_sort(True)
+    for B in (1, 3, 37):
+        rows = [[g2i[ch] for _ in range(rs.randint(1, 6)) for ch in pieces[rs.randint(len(pieces))]] for _ in range(B)]
+        graphs, wids = zip(*[TR._alignment_graph(r, tokens, lexicon, trans) for r in rows])
+        want = E.PackedLattice.from_graphs(list(graphs), C, None, wids=list(wids) if with_transitions else None)
+        flat, off, _ = E.flatten_targets(rows)
+        for nthreads in (1, 0, 0):
+            got = E.PackedLattice.transducer_batch(tokens, lexicon, trans, flat, off, C, None, nthreads)
+            assert bytes(got.desc) == bytes(want.desc)
+            np.testing.assert_array_equal(got.host_ints, want.host_ints)
+            np.testing.assert_array_equal(got.host_floats, want.host_floats)
+    # a target that cannot be spelled with the pieces: an empty acceptor, not an error (loss +inf downstream)
+    flat, off, _ = E.flatten_targets([[3, 0], [0]])  # grapheme 3 is in no piece
+    got = E.PackedLattice.transducer_batch(tokens, lexicon, trans, flat, off, C, None)
+    assert got.desc.B == 2 and list(got.field("state_off", 3))[1] == 0
+    # tensors are flattened without tolist()
+    import torch
+
+    f2, o2, l2 = E.flatten_any([torch.tensor([2, 2, 1]), torch.tensor([0])])
+    assert f2.tolist() == [2, 2, 1, 0] and o2.tolist() == [0, 3, 4] and l2 == [3, 1]
