@@ -45,19 +45,21 @@ class CTCLossFunction(torch.autograd.Function):
         E.check_labels(tg, C, "CTCLoss")
         if not 0 <= int(blank_idx) < C:
             raise ValueError(f"CTCLoss: blank index {blank_idx} is outside [0, {C})")
-        scale, _, coef = E.loss_factors(tg, reduction)  # loss scale; gradient coefficient -scale/B
         need_grad = log_probs.requires_grad
         if E.ctc_fast_path_ok(tg.max_len, C) and need_grad:
             # loss and gradient in ONE pipelined launch (gradient waves run behind the chains); backward
             # only applies the upstream scalar.  Like torch's own CTC, the gradient is produced eagerly.
+            # The per-utterance factors (loss scale; gradient coefficient -scale/B) were uploaded with the targets.
+            scale, coef = tg.addr("scale_" + reduction), tg.addr("cneg_" + reduction)
             dx = torch.empty_like(x)
             lse = E.row_lse(x) if ctx_log_softmax(ctx) else None
             _, _, loss = E.ctc_forward_backward(x, tg, int(blank_idx), coef, None, dx, loss_scale=scale, want_loss=True,
-                                                lse=lse)
+                                                lse=lse, shared_ws=True)
             ctx.aux = ("pipelined", x, tg, int(blank_idx), dx, coef, lse)
         elif ctx_log_softmax(ctx):
             raise RuntimeError("fused log_softmax CTC is only used on the pipelined path")
         elif E.ctc_fast_path_ok(tg.max_len, C):
+            scale, _, coef = E.loss_factors(tg, reduction)
             ws, nll = E.ctc_forward(x, tg, int(blank_idx))
             loss = E.reduce_loss(nll, scale, 1.0)
             ctx.aux = ("fast", x, tg, int(blank_idx), None, nll, coef)
@@ -66,6 +68,7 @@ class CTCLossFunction(torch.autograd.Function):
             if pack is None:
                 pack = tg.cache[("ctc_lattice", int(blank_idx), C)] = E.PackedLattice.ctc(
                     tg.flat, tg.offsets, int(blank_idx), C, dev)
+            scale, _, coef = E.loss_factors(tg, reduction)
             st = E.lattice_forward(x, pack, need_beta=need_grad)
             loss = E.reduce_loss(st.logz, scale, -1.0)
             ctx.aux = ("lattice", x, st, coef)
@@ -83,7 +86,7 @@ class CTCLossFunction(torch.autograd.Function):
                 # place) by the first one, so run the same launch again -- with the same row log-sum-exps when
                 # the log_softmax is fused -- into a fresh buffer, the upstream scalar applied by the kernel
                 dx = torch.empty_like(x)
-                E.ctc_forward_backward(x, tg, blank, coef, gout, dx, lse=lse)
+                E.ctc_forward_backward(x, tg, blank, coef, gout, dx, lse=lse, shared_ws=True)
             else:
                 E.scale_inplace(dx, gout)
                 ctx.aux = ("pipelined", x, tg, blank, None, coef, lse)

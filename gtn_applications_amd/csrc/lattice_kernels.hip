@@ -419,14 +419,18 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
                           int32_t* __restrict__ bptr, float* __restrict__ logz, int b, double* __restrict__ offs,
                           double* __restrict__ z64) {
   const int tid = threadIdx.x, NT = blockDim.x;
-  // Block renormalisation (log semiring): plain fp32 log scores drift to O(T) -- thousands at T = 800..1000, where
-  // one ulp is 2.4e-4 .. 4.9e-4 and the posteriors lose their third digit (measured against the float64 oracle at
-  // BASELINE configs 3 and 4).  So at the start of every chunk of R frames the maximum of the state vector moves
-  // into a double offset: stored scores stay O(R * |x|), offs[1 + c] is what the slots produced in chunk c are
-  // relative to (offs[0] = 0: the boundary slot), and the gradient kernel adds offs_alpha + offs_beta - log Z in
-  // double before it exponentiates.
+  // Per-frame renormalisation (log semiring).  Plain fp32 log scores drift to O(T) -- thousands at T = 800..1000,
+  // where one ulp is 2.4e-4 .. 4.9e-4: the posteriors lost their third digit (measured against the float64 oracle at
+  // BASELINE configs 3 and 4), and even a renormalisation every 16 frames left 2.5e-4 on log-probabilities of a
+  // 1000-class softmax (7 per frame).  So every frame subtracts the maximum of the vector it reads (the single-wave
+  // paths: of the vector before, computed off the dependent chain) and the running sum of what was subtracted lives in
+  // a double: stored scores stay within a few frames' worth of emissions of zero, offs[slot] is what slot's scores
+  // are relative to (offs[boundary slot] = 0), and the gradient kernel adds offs_alpha + offs_beta - log Z in double
+  // before it exponentiates.
   double cum = 0.0;
-  if (SR == WFL_SEMIRING_LOG && tid == 0) offs[0] = 0.0;
+  float m_cur = 0.f;  // what this frame subtracts
+  auto finite_or_zero = [](float m) { return (m > WFL_NEG_INF && m < __builtin_inff()) ? m : 0.f; };
+  if (SR == WFL_SEMIRING_LOG && tid == 0) offs[DIR == 0 ? 0 : T] = 0.0;
   const int Q = u.Q, A = u.A, E = u.E, nlev = u.nlev, Kmax = d.max_labels;
   // ---- stage the acceptor into LDS in this direction's CSR order
   for (int k = tid; k < A; k += NT) {
@@ -562,6 +566,9 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   // rows_per_chunk is even, so the first step of every chunk reads the same buffer: forward steps
   // read slot t (chunks start at even t), backward steps read slot t + 1 = T - c * R - i
   const bool first_reads_buf1 = DIR == 0 ? false : (T & 1);
+  int lean_par = 0;  // parity of the wave-maximum mailboxes of the multi-wave lean path
+  if (SR == WFL_SEMIRING_LOG && tid < 32) L.red[tid] = 0.f;  // first frame: subtract nothing
+  __syncthreads();
   auto sweep = [&](auto variant) {
     constexpr int V = decltype(variant)::value;  // 0: general path, 1: banded, otherwise the lean in-degree bound
     for (int c = 0; c < nchunks; ++c) {
@@ -579,32 +586,6 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           if (e < pn * Kmax) pre[j] = src[e];
         }
       }
-      if (SR == WFL_SEMIRING_LOG) {
-        if (c > 0) {
-          float m;
-          if (V != 0 && NT == 64) {  // the vector lives in registers
-            m = wave_all_max(sc);
-            if (m > WFL_NEG_INF && m < __builtin_inff())
-              sc -= m;
-            else
-              m = 0.f;
-          } else {
-            const int tf = DIR == 0 ? f0 : f0 + n;  // slot the first frame of the chunk reads
-            float* fromb = V != 0 ? (first_reads_buf1 ? L.buf1 : L.buf0) : ((tf & 1) ? L.buf1 : L.buf0);
-            float v = WFL_NEG_INF;
-            for (int q = tid; q < Q; q += NT) v = fmaxf(v, fromb[q]);
-            m = block_reduce_max(v, L.red);
-            if (m > WFL_NEG_INF && m < __builtin_inff()) {
-              for (int q = tid; q < Q; q += NT) fromb[q] -= m;
-            } else {
-              m = 0.f;
-            }
-            __syncthreads();
-          }
-          cum += (double)m;
-        }
-        if (tid == 0) offs[1 + c] = cum;
-      }
       // single-wave variants: the emissions of frame i+1 are read from the tile while frame i is
       // being computed (they do not depend on the chain), so only the score exchange is serial
       auto row_of = [&](int i) {
@@ -620,11 +601,15 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           const float xs_n = *reinterpret_cast<const float*>(rn + ro_self);
           const float xa_n = *reinterpret_cast<const float*>(rn + ro_adj);
           const float nb = DIR == 0 ? wave_shr1(sc, WFL_NEG_INF) : wave_shl1(sc, WFL_NEG_INF);
+          const float mn = wave_all_max(sc);  // (not on the chain: used by the NEXT frame)
           float v[kLeanDeg];
-          v[0] = sc + (xs + w_self);
-          v[1] = nb + (xa + w_adj);
+          v[0] = sc + ((xs + w_self) - m_cur);
+          v[1] = nb + ((xa + w_adj) - m_cur);
           sc = lean_lse<2>(v);
+          cum += (double)m_cur;
+          m_cur = finite_or_zero(mn);
           if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
+          if (tid == 0) offs[DIR == 0 ? t + 1 : t] = cum;
           xs = xs_n, xa = xa_n;
         }
       } else if (V != 0 && NT == 64) {
@@ -638,11 +623,15 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           float xn[kLeanDeg], v[kLeanDeg];
 #pragma unroll
           for (int k = 0; k < DEG; ++k) xn[k] = *reinterpret_cast<const float*>(rn + la.ro[k]) + la.w[k];
+          const float mn = wave_all_max(sc);  // (not on the chain: used by the NEXT frame)
 #pragma unroll
           for (int k = 0; k < DEG; ++k)
-            v[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(la.lo[k], __float_as_int(sc))) + xr[k];
+            v[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(la.lo[k], __float_as_int(sc))) + (xr[k] - m_cur);
           sc = lean_lse<DEG>(v);
+          cum += (double)m_cur;
+          m_cur = finite_or_zero(mn);
           if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
+          if (tid == 0) offs[DIR == 0 ? t + 1 : t] = cum;
 #pragma unroll
           for (int k = 0; k < DEG; ++k) xr[k] = xn[k];
         }
@@ -650,11 +639,22 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
         auto step = [&](int i, const float* const (&fp)[kLeanDeg], float* to) {
           const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
           const float* row = tile + (size_t)(t - f0) * Kmax;
-          const float v = lean_relax<(V >= 2 ? V : 2)>(fp, la.ro, la.w, row);
+          // maximum of the vector this frame reads: the waves left theirs in `red` before the last barrier
+          float* red_prev = L.red + 16 * (lean_par & 1);
+          float* red_next = L.red + 16 * ((lean_par + 1) & 1);
+          ++lean_par;
+          float m = red_prev[0];
+          for (int wv = 1; wv < (NT >> 6); ++wv) m = fmaxf(m, red_prev[wv]);
+          m = finite_or_zero(m);
+          const float v = lean_relax<(V >= 2 ? V : 2)>(fp, la.ro, la.w, row) - m;
+          cum += (double)m;
+          const float wm = wave_all_max(tid < Q ? v : WFL_NEG_INF);
+          if ((tid & 63) == 0) red_next[tid >> 6] = wm;
           if (tid < Q) {
             to[tid] = v;
             out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = v;
           }
+          if (tid == 0) offs[DIR == 0 ? t + 1 : t] = cum;
           __syncthreads();
         };
         float* const to_first = first_reads_buf1 ? L.buf0 : L.buf1;
@@ -682,10 +682,19 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           float* to = (slot_to & 1) ? L.buf1 : L.buf0;
           const float* row = tile + (size_t)(t - f0) * Kmax;
           float* orow = out + u.ab_base + (int64_t)slot_to * Q;
+          float msub = 0.f;  // log semiring: the maximum of the vector read moves into the double offset
+          if (SR == WFL_SEMIRING_LOG) {
+            float mx = WFL_NEG_INF;
+            for (int q = tid; q < Q; q += NT) mx = fmaxf(mx, from[q]);
+            msub = finite_or_zero(block_reduce_max(mx, L.red));
+            cum += (double)msub;
+            if (tid == 0) offs[slot_to] = cum;
+          }
           if (tid < Q && kq1 - kq0 <= kHeavyDeg) {
             float v;
             int arg;
             relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
+            v -= msub;
             to[tid] = v;
             if (direct) orow[tid] = v;
             if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
@@ -696,6 +705,7 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
             const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
             if (k1 - k0 > kHeavyDeg) continue;
             relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
+            v -= msub;
             to[q] = v;
             if (direct) orow[q] = v;
             if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
@@ -709,6 +719,7 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
               float v;
               int arg;
               relax_labelled_row16<SR>(L, from, row, k0, k1, v, arg);
+              v -= msub;
               if (q >= 0 && (tid & 15) == 0) {
                 to[q] = v;
                 if (direct) orow[q] = v;
@@ -846,8 +857,7 @@ __global__ void __launch_bounds__(256)
   float* corr = (float*)(chunk + (dx ? Kmax + d.max_arcs / kChunk + 1 : 0));  // [TS]: offs_alpha(t) + offs_beta(t+1) - log Z
   float* corr_eps = corr + TS;                                                 // [TS+1]: both at slot t (epsilon arcs)
   int16_t* colmap = (int16_t*)(corr_eps + TS + 1);  // [C] (only if dx)
-  // scores are stored relative to per-chunk double offsets (run_chain): slot s of alpha belongs to chunk (s-1)/R of
-  // the forward sweep, slot s of beta to chunk (T-1-s)/R of the backward sweep, the boundary slots to offset 0
+  // scores are stored relative to per-slot double offsets (run_chain)
   const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
   const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
   const double zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];
@@ -904,9 +914,9 @@ __global__ void __launch_bounds__(256)
       }
       if (tid <= nr) {
         const int sl = ts0 + tid;
-        const double oa = offs_a[sl == 0 ? 0 : 1 + (sl - 1) / R];
-        corr_eps[tid] = (float)(oa + offs_b[sl == T ? 0 : 1 + (T - 1 - sl) / R] - zd);
-        if (tid < nr) corr[tid] = (float)(oa + offs_b[sl + 1 == T ? 0 : 1 + (T - 2 - sl) / R] - zd);
+        const double oa = offs_a[sl];
+        corr_eps[tid] = (float)(oa + offs_b[sl] - zd);
+        if (tid < nr) corr[tid] = (float)(oa + offs_b[sl + 1] - zd);
       }
     }
     __syncthreads();
@@ -1175,14 +1185,12 @@ static void chain_config(const wfl_lattice_desc& d, int& nt, int& rpc) {
   while (nt < 256 && nt * kPre < 2 * d.max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
   rpc = std::max(2, std::min(16, nt * kPre / std::max(1, d.max_labels)) & ~1);  // even (run_chain)
 }
-// scores [..] | pad to 8 B | double offs[B][nch1] | double logZ[B]   (nch1 = chunks + 1; see run_chain)
+// scores [..] | pad to 8 B | double offs[B][nch1] | double logZ[B]   (nch1 = T + 1 time slots; see run_chain)
 static int64_t ab_main_elems(const wfl_lattice_desc& d, int T) {
   return d.shared ? (int64_t)d.B * (T + 1) * d.max_states : (int64_t)(T + 1) * d.total_states;
 }
 static void ab_tail(const wfl_lattice_desc& d, int T, int64_t& tail, int& nch1) {
-  int nt, rpc;
-  chain_config(d, nt, rpc);
-  nch1 = (T + rpc - 1) / rpc + 1;
+  nch1 = T + 1;
   tail = (ab_main_elems(d, T) + 1) & ~(int64_t)1;
 }
 

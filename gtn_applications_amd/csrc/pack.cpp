@@ -197,6 +197,15 @@ struct Builder {
     d.max_labels = std::max(1, max_labels), d.max_levels = max_levels;
     d.total_states = state_off.back(), d.total_arcs = arc_off.back(), d.total_eps = eps_off.back();
     d.total_labels = (int64_t)labels.size();
+    {  // one allocation for each blob (every array is padded to a multiple of 4 elements)
+      size_t ni = 0, nf = 0;
+      for (const auto* v : {&state_off, &arc_off, &eps_off, &lab_off, &lvl_off, &in_ptr, &out_ptr, &out_arc, &ein_ptr,
+                            &eout_ptr, &eout_arc, &arc_src, &arc_dst, &arc_slot, &arc_lab, &arc_wid, &eps_src, &eps_dst,
+                            &eps_wid, &labels, &lvl_ptr, &arc_orig, &eps_orig, &slot_ptr, &slot_arc})
+        ni += (v->size() + 3) & ~(size_t)3;
+      for (const auto* v : {&arc_w, &eps_w, &start_w, &accept_w}) nf += (v->size() + 3) & ~(size_t)3;
+      h->ints.reserve(ni), h->floats.reserve(nf);
+    }
     auto put = [&](int64_t& off, const std::vector<int32_t>& v) {
       off = (int64_t)h->ints.size();
       h->ints.insert(h->ints.end(), v.begin(), v.end());
@@ -220,6 +229,14 @@ struct Builder {
     return h;
   }
 };
+
+// Runs per_utt(b, builder, scratch arcs, start mask, accept mask) for b = 0..B-1 on the host thread pool in
+// contiguous ranges (one Builder per range, merged in order): the packed batch is identical to a serial build.
+struct PackScratch {
+  std::vector<Arc> arcs;
+  std::vector<uint8_t> st, ac;
+};
+wfl_lattice_host* build_batch(int B, int C, const std::function<bool(int, Builder&, PackScratch&)>& per_utt);
 
 }  // namespace
 
@@ -255,11 +272,9 @@ wfl_lattice_host* wfl_lattice_pack_ctc(const int32_t* targets, const int64_t* of
     set_error("pack_ctc: blank %d outside [0,%d)", blank, C);
     return nullptr;
   }
-  Builder bld;
-  bld.C = C;
-  std::vector<Arc> arcs;
-  std::vector<uint8_t> st, ac;
-  for (int b = 0; b < B; ++b) {
+  return build_batch(B, C, [&](int b, Builder& bld, PackScratch& sc) {
+    auto& arcs = sc.arcs;
+    auto &st = sc.st, &ac = sc.ac;
     const int32_t* y = targets + offsets[b];
     const int L = (int)(offsets[b + 1] - offsets[b]);
     const int S = 2 * L + 1;
@@ -274,17 +289,14 @@ wfl_lattice_host* wfl_lattice_pack_ctc(const int32_t* targets, const int64_t* of
       if (s > 0) arcs.push_back({s - 1, s, lab, -1, id++, 0.f});
       if ((s & 1) && s > 1 && lab != y[(s - 1) / 2 - 1]) arcs.push_back({s - 2, s, lab, -1, id++, 0.f});
     }
-    if (!bld.add(S, st.data(), ac.data(), arcs)) return nullptr;
-  }
-  return bld.finish(B, 0);
+    return bld.add(S, st.data(), ac.data(), arcs);
+  });
 }
 
 wfl_lattice_host* wfl_lattice_pack_asg_fal(const int32_t* targets, const int64_t* offsets, int B, int C) {
-  Builder bld;
-  bld.C = C;
-  std::vector<Arc> arcs;
-  std::vector<uint8_t> st, ac;
-  for (int b = 0; b < B; ++b) {
+  return build_batch(B, C, [&](int b, Builder& bld, PackScratch& sc) {
+    auto& arcs = sc.arcs;
+    auto &st = sc.st, &ac = sc.ac;
     const int32_t* y = targets + offsets[b];
     const int L = (int)(offsets[b + 1] - offsets[b]);
     arcs.clear();
@@ -296,25 +308,22 @@ wfl_lattice_host* wfl_lattice_pack_asg_fal(const int32_t* targets, const int64_t
       const int32_t c = y[l - 1];
       if (c < 0 || c >= C) {
         set_error("pack_asg_fal: label %d outside [0,%d)", c, C);
-        return nullptr;
+        return false;
       }
       const int32_t enter = (l == 1) ? c : (1 + c) * C + y[l - 2];  // W[0,c] or W[1+c, prev]
       arcs.push_back({l - 1, l, c, enter, id++, 0.f});
       arcs.push_back({l, l, c, (1 + c) * C + c, id++, 0.f});
     }
-    if (!bld.add(L + 1, st.data(), ac.data(), arcs)) return nullptr;
-  }
-  return bld.finish(B, 0);
+    return bld.add(L + 1, st.data(), ac.data(), arcs);
+  });
 }
 
 wfl_lattice_host* wfl_lattice_pack_stc(const int32_t* targets, const int64_t* offsets, int B, int star_idx,
                                        float log_prob, int C) {
-  Builder bld;
-  bld.C = C;
-  std::vector<Arc> arcs;
-  std::vector<uint8_t> st, ac;
   const int32_t BLANK = 0;  // stc.py:13
-  for (int b = 0; b < B; ++b) {
+  return build_batch(B, C, [&](int b, Builder& bld, PackScratch& sc) {
+    auto& arcs = sc.arcs;
+    auto &st = sc.st, &ac = sc.ac;
     const int32_t* y = targets + offsets[b];
     const int L = (int)(offsets[b + 1] - offsets[b]);
     const int S = 2 * L + 1, Q = S + L + 1;
@@ -339,9 +348,8 @@ wfl_lattice_host* wfl_lattice_pack_stc(const int32_t* targets, const int64_t* of
       if (l < L) arcs.push_back({c, 2 * l + 1, y[l], -1, id++, 0.f});
       arcs.push_back({c, p2, BLANK, -1, id++, 0.f});
     }
-    if (!bld.add(Q, st.data(), ac.data(), arcs)) return nullptr;
-  }
-  return bld.finish(B, 0);
+    return bld.add(Q, st.data(), ac.data(), arcs);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -426,6 +434,47 @@ HostPool& host_pool() {
     g_pool = new HostPool(g_pool_threads);
   }
   return *g_pool;
+}
+
+wfl_lattice_host* build_batch(int B, int C, const std::function<bool(int, Builder&, PackScratch&)>& per_utt) {
+  if (B <= 0) {
+    set_error("lattice_pack: empty batch");
+    return nullptr;
+  }
+  // ranges of at least 8 utterances: below that a Builder's fixed cost outweighs the parallelism
+  HostPool& pool = host_pool();
+  const int ranges = std::max(1, std::min(g_pool_threads + 1, B / 8));
+  std::vector<Builder> parts(ranges);
+  std::vector<std::string> errors(ranges);
+  std::atomic<int> failed{0};
+  auto run = [&](int r) {
+    PackScratch sc;
+    parts[r].C = C;
+    const int lo = (int)((int64_t)B * r / ranges), hi = (int)((int64_t)B * (r + 1) / ranges);
+    for (int b = lo; b < hi; ++b)
+      if (!per_utt(b, parts[r], sc)) {
+        errors[r] = wfl_last_error();
+        failed.store(1);
+        return;
+      }
+  };
+  if (ranges == 1)
+    run(0);
+  else
+    pool.parallel_for(ranges, run);
+  if (failed.load()) {
+    for (auto& e : errors)
+      if (!e.empty()) {
+        set_error("%s", e.c_str());
+        break;
+      }
+    return nullptr;
+  }
+  if (ranges == 1) return parts[0].finish(B, 0);
+  Builder all;
+  all.C = C;
+  for (auto& p : parts) all.append(p);
+  return all.finish(B, 0);
 }
 
 struct GraphOwner {  // frees an intermediate graph at scope exit

@@ -1,0 +1,69 @@
+/* _wflpy: CPython helper of the operator layer (gtn_applications_amd/engine.py).  One job: turn the targets the
+ * reference's criteria receive -- a list of int lists (benchmarks/ctc_benchmark.py:23-24, train.py's
+ * `[t.tolist() for t in targets]`) -- into the flat int32 + int64 offsets layout of the C ABI without a
+ * Python-level loop or a numpy nested-sequence conversion (5632 labels: ~150 us in numpy, ~25 us here).
+ * Not part of libwfl.so: the C ABI stays free of Python; this is glue on the Python side of it. */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+
+/* flatten_into(targets, flat_addr, flat_capacity, offsets_addr) -> (total, max_len, min_label, max_label)
+ * targets: list/tuple of list/tuple of ints.  Writes int32 labels to flat_addr (capacity in elements) and
+ * int64 offsets [B+1] to offsets_addr.  Returns None if the capacity is too small (nothing useful written)
+ * and raises TypeError for anything that is not a sequence of int sequences (the caller falls back). */
+static PyObject* flatten_into(PyObject* self, PyObject* args) {
+  PyObject* targets;
+  unsigned long long flat_addr, off_addr;
+  Py_ssize_t capacity;
+  if (!PyArg_ParseTuple(args, "OKnK", &targets, &flat_addr, &capacity, &off_addr)) return NULL;
+  if (!PyList_Check(targets) && !PyTuple_Check(targets)) {
+    PyErr_SetString(PyExc_TypeError, "targets must be a list or tuple");
+    return NULL;
+  }
+  int32_t* flat = (int32_t*)(uintptr_t)flat_addr;
+  int64_t* off = (int64_t*)(uintptr_t)off_addr;
+  const Py_ssize_t B = PySequence_Fast_GET_SIZE(targets);
+  PyObject** rows = PySequence_Fast_ITEMS(targets);
+  Py_ssize_t total = 0, max_len = 0;
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    PyObject* r = rows[b];
+    if (!PyList_Check(r) && !PyTuple_Check(r)) {
+      PyErr_SetString(PyExc_TypeError, "every target must be a list or tuple of ints");
+      return NULL;
+    }
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(r);
+    off[b] = (int64_t)total;
+    total += n;
+    if (n > max_len) max_len = n;
+  }
+  off[B] = (int64_t)total;
+  if (total > capacity) Py_RETURN_NONE;
+  long lo = 0, hi = -1;
+  int first = 1;
+  Py_ssize_t k = 0;
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    PyObject* r = rows[b];
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(r);
+    PyObject** it = PySequence_Fast_ITEMS(r);
+    for (Py_ssize_t i = 0; i < n; ++i) {
+      const long v = PyLong_AsLong(it[i]);
+      if (v == -1 && PyErr_Occurred()) return NULL; /* not an int (or overflow) */
+      if (v > INT32_MAX || v < INT32_MIN) {
+        PyErr_SetString(PyExc_OverflowError, "target label does not fit int32");
+        return NULL;
+      }
+      if (first || v < lo) lo = v;
+      if (first || v > hi) hi = v;
+      first = 0;
+      flat[k++] = (int32_t)v;
+    }
+  }
+  return Py_BuildValue("nnll", total, max_len, lo, hi);
+}
+
+static PyMethodDef methods[] = {
+    {"flatten_into", flatten_into, METH_VARARGS, "flatten list-of-int-lists targets into int32 flat + int64 offsets"},
+    {NULL, NULL, 0, NULL}};
+static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_wflpy", "operator-layer helpers of gtn_applications_amd", -1,
+                                    methods};
+PyMODINIT_FUNC PyInit__wflpy(void) { return PyModule_Create(&moddef); }

@@ -41,7 +41,10 @@ def stream_ptr():
 
 
 def ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """device pointer argument: a tensor, a raw address (int) or None"""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t if type(t) is int else t.data_ptr())
 
 
 def as_device_f32(t, device):
@@ -383,26 +386,149 @@ def dense_viterbi(x, W):
 # -------------------------------------------------------------------------------------------------
 # CTC fast path
 # -------------------------------------------------------------------------------------------------
+class _StagingRing:
+    """Pinned host buffers through which a batch's targets reach the device in ONE asynchronous copy.  A slot is
+    reused only after the copy that last read it has completed (event per slot)."""
+
+    def __init__(self, slots=8, nbytes=1 << 18):
+        self.bufs, self.views, self.events = [None] * slots, [None] * slots, [None] * slots
+        self.i, self.nbytes = 0, nbytes
+
+    def next(self, need, pinned):
+        i = self.i = (self.i + 1) % len(self.bufs)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        buf = self.bufs[i]
+        if buf is None or buf.numel() < need:
+            n = max(self.nbytes, 1 << (int(need) - 1).bit_length())
+            buf = self.bufs[i] = torch.empty(n, dtype=torch.uint8, pin_memory=pinned)
+            self.views[i] = buf.numpy()
+        return i, buf, self.views[i]
+
+
+_STAGING = {}
+_FACTORS = ("scale_none", "scale_mean", "cpos_none", "cpos_mean", "cneg_none", "cneg_mean")
+
+
 class CtcTargets:
-    """Device-resident targets of a batch (flat labels + offsets) and the per-utterance factors."""
+    """Targets of a batch as the kernels want them, resident on the device: int64 offsets [B+1], int32 flat labels
+    and the per-utterance loss / gradient factors of both reductions (scale_b = 1/len_b for "mean", 1 for "none";
+    +-scale_b/B: ctc.py:53-58,87, asg.py:116-121,171-179) in ONE buffer filled on the host and uploaded with one
+    asynchronous copy from pinned memory.  Lists of int lists are flattened by the CPython helper (_wflpy), lists
+    of 1-D tensors by one torch.cat."""
 
-    __slots__ = ("flat", "offsets", "lens", "max_len", "B", "dev_flat", "dev_offsets", "cache", "label_min", "label_max")
+    __slots__ = ("max_len", "B", "dev_buf", "cache", "label_min", "label_max", "n", "_off_flat", "_off_fac", "_key",
+                 "_lens")
 
-    def __init__(self, targets, device, flat=None, lens=None):
-        self.cache = {}  # derived device objects (scale factors, packed lattices), keyed by the caller
-        if flat is None:
-            self.flat, self.offsets, self.lens = flatten_targets(targets)
-        else:  # already flattened (list of 1-D tensors: one torch.cat instead of B tolist() calls)
-            self.flat, self.lens = flat, lens
-            self.offsets = np.zeros(len(lens) + 1, dtype=np.int64)
-            np.cumsum(lens, out=self.offsets[1:])
-        self.B = len(self.lens)
-        self.max_len = max(self.lens) if self.lens else 0
-        # label range, checked against C by the criteria (the kernels index x[b,t,label] unchecked)
-        self.label_min = int(self.flat.min()) if self.flat.size else 0
-        self.label_max = int(self.flat.max()) if self.flat.size else -1
-        self.dev_flat = torch.from_numpy(self.flat if self.flat.size else np.zeros(1, np.int32)).to(device)
-        self.dev_offsets = torch.from_numpy(self.offsets).to(device)
+    def __init__(self, targets, device, flat=None, lens=None, _staged=None):
+        self.cache = {}  # derived device objects (factor views, packed lattices), keyed by the caller
+        st = _staged if _staged is not None else _stage_targets(targets, device, flat, lens)
+        slot, host, nbytes, B, n, self.max_len, self.label_min, self.label_max, self._off_flat, self._off_fac, self._key = st
+        self.B, self.n, self._lens = B, n, None
+        view = host[1]
+        if device.type == "cuda":
+            ring = _STAGING[device.index]
+            self.dev_buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.dev_buf.copy_(host[0][:nbytes], non_blocking=True)
+            ev = ring.events[slot]
+            if ev is None:
+                ev = ring.events[slot] = torch.cuda.Event()
+            ev.record()
+        else:  # host-only uses (tests of the packers): same layout, no device
+            self.dev_buf = torch.from_numpy(view[:nbytes].copy())
+
+    # host copies of the staged content (the key bytes hold offsets and labels back to back)
+    @property
+    def offsets(self):
+        return np.frombuffer(self._key[0], dtype=np.int64, count=self.B + 1)
+
+    @property
+    def flat(self):
+        return np.frombuffer(self._key[0], dtype=np.int32, count=self.n, offset=self._off_flat)
+
+    @property
+    def lens(self):
+        if self._lens is None:
+            self._lens = np.diff(self.offsets).tolist()
+        return self._lens
+
+    # raw device addresses (what the C ABI takes) and tensor views of the same memory
+    def addr(self, what):
+        base = self.dev_buf.data_ptr()
+        if what == "offsets":
+            return base
+        if what == "flat":
+            return base + self._off_flat
+        return base + self._off_fac + 4 * self.B * _FACTORS.index(what)
+
+    def factor(self, what):
+        k = _FACTORS.index(what)
+        lo = self._off_fac + 4 * self.B * k
+        return self.dev_buf[lo:lo + 4 * self.B].view(_F32)
+
+    @property
+    def dev_offsets(self):
+        return self.dev_buf[:8 * (self.B + 1)].view(torch.int64)
+
+    @property
+    def dev_flat(self):
+        return self.dev_buf[self._off_flat:self._off_flat + 4 * max(self.n, 1)].view(torch.int32)
+
+
+def _stage_targets(targets, device, flat=None, lens=None):
+    """Fill a staging slot with [offsets | flat | factors]; returns what CtcTargets needs plus a content key."""
+    from . import _wflpy
+
+    key = device.index if device.type == "cuda" else -1
+    ring = _STAGING.get(key)
+    if ring is None:
+        ring = _STAGING[key] = _StagingRing()
+    pinned = device.type == "cuda"
+    B = len(lens) if flat is not None else len(targets)
+    off_flat = 8 * (B + 1)
+    tail = 4 * B * len(_FACTORS) + 16
+    slot, buf, view = ring.next(off_flat + tail + 4096, pinned)
+    if flat is None and len(targets) and all(type(t) is torch.Tensor and t.dim() == 1 and not t.is_cuda for t in targets):
+        lens = [t.numel() for t in targets]
+        flat = torch.cat(targets).to(torch.int32).numpy() if sum(lens) else np.zeros(0, np.int32)
+    if flat is not None:
+        n = int(flat.size)
+        if off_flat + 4 * n + tail > buf.numel():
+            ring.i -= 1
+            slot, buf, view = ring.next(off_flat + 4 * n + tail, pinned)
+        offs = view[:off_flat].view(np.int64)
+        offs[0] = 0
+        np.cumsum(lens, out=offs[1:])
+        view[off_flat:off_flat + 4 * n].view(np.int32)[:] = flat
+        max_len = max(lens) if lens else 0
+        lo, hi = (int(flat.min()), int(flat.max())) if n else (0, -1)
+    else:
+        rows = targets
+        while True:
+            cap = (buf.numel() - off_flat - tail) // 4
+            try:
+                res = _wflpy.flatten_into(rows, buf.data_ptr() + off_flat, cap, buf.data_ptr())
+            except TypeError:  # rows of tensors / ranges / numpy ints: normalise once and retry
+                rows = [t.tolist() if hasattr(t, "tolist") else [int(v) for v in t] for t in rows]
+                continue
+            if res is not None:
+                break
+            need = off_flat + 4 * int(view[:off_flat].view(np.int64)[B]) + tail
+            ring.i -= 1
+            slot, buf, view = ring.next(need, pinned)
+        n, max_len, lo, hi = res
+    off_fac = (off_flat + 4 * max(n, 1) + 7) & ~7
+    nbytes = off_fac + 4 * B * len(_FACTORS)
+    ln = np.diff(view[:off_flat].view(np.int64)).astype(np.float32)
+    fac = view[off_fac:nbytes].view(np.float32).reshape(len(_FACTORS), B)
+    fac[0] = 1.0
+    np.divide(1.0, ln, out=fac[1], where=ln > 0)
+    fac[1][ln <= 0] = 1.0
+    inv_b = 1.0 / max(B, 1)
+    np.multiply(fac[0:2], inv_b, out=fac[2:4])
+    np.multiply(fac[0:2], -inv_b, out=fac[4:6])
+    content = (view[:off_flat + 4 * n].tobytes(), key)
+    return slot, (buf, view), nbytes, B, n, max_len, lo, hi, off_flat, off_fac, content
 
 
 _CTC_WS_SIZES = {}
@@ -452,22 +578,50 @@ def row_lse(x):
     return out
 
 
-def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_loss=False, lse=None):
-    """Loss and gradient in one pipelined launch (wfl_ctc_forward_backward): returns (ws, nll) or,
-    with want_loss, (ws, nll, mean_b(loss_scale[b] * nll[b]) as a 0-dim device tensor)."""
+_CTC_WS_CACHE = {}
+
+
+def ctc_workspace(x, max_len):
+    """Scratch of the pipelined step (checkpoints, flags, certificate words) and the per-utterance nll, one per
+    (device, stream, shape): consecutive steps on a stream are ordered, so they can share it -- no allocation per
+    call.  (The returned nll is overwritten by the next step of the same shape on the same stream.)"""
     B, T, C = x.shape
-    key = (B, T, C, tg.max_len)
-    n_ws = _CTC_WS_SIZES.get(key)
-    if n_ws is None:
-        n = ctypes.c_int64()
-        N.check(N.lib.wfl_ctc_workspace(B, T, C, tg.max_len, ctypes.byref(n)))
-        n_ws = _CTC_WS_SIZES[key] = n.value
-    ws = torch.empty(n_ws, dtype=_F32, device=x.device)
-    nll = torch.empty(B, dtype=_F32, device=x.device)
+    idx = x.device.index
+    key = (idx, torch._C._cuda_getCurrentRawStream(idx), B, T, C, max_len)
+    hit = _CTC_WS_CACHE.get(key)
+    if hit is None:
+        n_ws = _CTC_WS_SIZES.get(key[2:])
+        if n_ws is None:
+            n = ctypes.c_int64()
+            N.check(N.lib.wfl_ctc_workspace(B, T, C, max_len, ctypes.byref(n)))
+            n_ws = _CTC_WS_SIZES[key[2:]] = n.value
+        if len(_CTC_WS_CACHE) >= 16:
+            _CTC_WS_CACHE.clear()
+        hit = _CTC_WS_CACHE[key] = (torch.empty(n_ws, dtype=_F32, device=x.device),
+                                    torch.empty(B, dtype=_F32, device=x.device))
+    return hit
+
+
+def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_loss=False, lse=None, shared_ws=False):
+    """Loss and gradient in one pipelined launch (wfl_ctc_forward_backward): returns (ws, nll) or,
+    with want_loss, (ws, nll, mean_b(loss_scale[b] * nll[b]) as a 0-dim device tensor).  `coef` / `loss_scale`
+    may be tensors or raw device addresses (CtcTargets.addr).  shared_ws: use the per-stream cached workspace."""
+    B, T, C = x.shape
+    if shared_ws:
+        ws, nll = ctc_workspace(x, tg.max_len)
+    else:
+        key = (B, T, C, tg.max_len)
+        n_ws = _CTC_WS_SIZES.get(key)
+        if n_ws is None:
+            n = ctypes.c_int64()
+            N.check(N.lib.wfl_ctc_workspace(B, T, C, tg.max_len, ctypes.byref(n)))
+            n_ws = _CTC_WS_SIZES[key] = n.value
+        ws = torch.empty(n_ws, dtype=_F32, device=x.device)
+        nll = torch.empty(B, dtype=_F32, device=x.device)
     loss = torch.empty((), dtype=_F32, device=x.device) if want_loss else None
     tok = _mark("ctc_step")
     N.check(
-        N.lib.wfl_ctc_forward_backward(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank,
+        N.lib.wfl_ctc_forward_backward(ptr(x), B, T, C, ptr(tg.addr("flat")), ptr(tg.addr("offsets")), tg.max_len, blank,
                                        ptr(ws), ptr(nll), ptr(coef), ptr(gout), ptr(dx), ptr(loss_scale), ptr(loss),
                                        ptr(lse), stream_ptr())
     )
@@ -515,22 +669,22 @@ def ctc_rejected(ws, B, T, max_len):
 
 
 def loss_factors(tg, reduction, norm_lens=None):
-    """Per-utterance loss scale and gradient coefficients, cached on the target object.
+    """Per-utterance loss scale and gradient coefficients as device tensors (scale, +scale/B, -scale/B).
 
     scale_b = 1/len_b for "mean" (1 if len_b == 0), 1 for "none" (ctc.py:53-58, asg.py:116-121,
-    transducer.py:302-305); returns (scale, +scale/B, -scale/B) as device tensors."""
+    transducer.py:302-305).  Normalised by the target lengths they are views of the buffer uploaded with the
+    targets (no kernel, no copy); `norm_lens` (STC normalises by T) builds them separately, cached on `tg`."""
+    if reduction not in ("mean", "none"):
+        raise ValueError("invalid value for reduction '" + str(reduction) + "'")
     key = ("factors", reduction, None if norm_lens is None else tuple(norm_lens))
     hit = tg.cache.get(key)
     if hit is None:
-        lens = tg.lens if norm_lens is None else norm_lens
-        if reduction == "mean":
-            sc = [1.0 / n if n > 0 else 1.0 for n in lens]
-        elif reduction == "none":
-            sc = [1.0] * len(lens)
+        if norm_lens is None:
+            hit = (tg.factor("scale_" + reduction), tg.factor("cpos_" + reduction), tg.factor("cneg_" + reduction))
         else:
-            raise ValueError("invalid value for reduction '" + str(reduction) + "'")
-        scale = torch.tensor(sc, dtype=_F32, device=tg.dev_offsets.device)
-        hit = (scale, scale / len(lens), -scale / len(lens))
+            sc = [1.0 / n if n > 0 else 1.0 for n in norm_lens] if reduction == "mean" else [1.0] * len(norm_lens)
+            scale = torch.tensor(sc, dtype=_F32, device=tg.dev_buf.device)
+            hit = (scale, scale / len(sc), -scale / len(sc))
         tg.cache[key] = hit
     return hit
 
@@ -539,15 +693,14 @@ _TARGET_CACHE = LRU(64)
 
 
 def targets_on_device(targets, device):
-    """Upload (once per distinct content) the targets of a batch; content-keyed LRU.  A CtcTargets
-    built earlier is passed through (callers that reuse a batch skip the ~50 us content hash)."""
+    """Stage and upload the targets of a batch (once per distinct content: the staged bytes are the key of a small
+    LRU, so a repeated batch -- the reference benchmarks reuse one target list -- skips the upload and keeps its
+    derived objects).  A CtcTargets built earlier is passed through."""
     if isinstance(targets, CtcTargets):
         return targets
-    if len(targets) and all(type(t) is torch.Tensor and t.dim() == 1 and not t.is_cuda for t in targets):
-        lens = [t.numel() for t in targets]
-        flat = torch.cat(targets).to(torch.int32).numpy()
-        key = (flat.tobytes(), tuple(lens), device.index)
-        return _TARGET_CACHE.get(key, lambda: CtcTargets(None, device, flat, lens))
-    rows = [t.tolist() if hasattr(t, "tolist") else (t if type(t) is list else list(t)) for t in targets]
-    key = (tuple(map(tuple, rows)), device.index)
-    return _TARGET_CACHE.get(key, lambda: CtcTargets(rows, device))
+    st = _stage_targets(targets, device)
+    hit = _TARGET_CACHE.data.get(st[-1])
+    if hit is not None:
+        _TARGET_CACHE.data.move_to_end(st[-1])
+        return hit
+    return _TARGET_CACHE.get(st[-1], lambda: CtcTargets(None, device, _staged=st))

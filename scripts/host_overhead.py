@@ -1,0 +1,66 @@
+"""Where the host time of the operator path goes (run on the GPU box): per-call wall times of the pieces of
+`CTCLoss(x, targets, blank).backward()` with fresh targets, GPU work left asynchronous."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gtn_applications_amd import engine as E
+from gtn_applications_amd.criterions import ctc
+
+B, T, C, L, N = 128, 1000, 100, 44, 200
+g = torch.Generator().manual_seed(0)
+x = torch.randn(B, T, C, generator=g).cuda().requires_grad_(True)
+batches = [torch.randint(C - 2, (B, L), generator=g).tolist() for _ in range(N + 20)]
+dev = x.device
+
+
+def timed(fn, n=N, skip=20):
+    for i in range(skip):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(skip, skip + n):
+        fn(i)
+    host = (time.perf_counter() - t0) / n * 1e6
+    torch.cuda.synchronize()
+    return host, (time.perf_counter() - t0) / n * 1e6
+
+
+E._TARGET_CACHE.data.clear()
+print("targets_on_device (fresh)      host %.1f us  (with sync %.1f)" % timed(lambda i: E.targets_on_device(batches[i], dev)))
+print("targets_on_device (cached)     host %.1f us  (with sync %.1f)" % timed(lambda i: E.targets_on_device(batches[5], dev)))
+tg = E.targets_on_device(batches[0], dev)
+xd = x.detach()
+dx = torch.empty_like(xd)
+coef, scale = tg.addr("cneg_none"), tg.addr("scale_none")
+print("engine call (shared ws)        host %.1f us  (with sync %.1f)" % timed(
+    lambda i: E.ctc_forward_backward(xd, tg, C - 1, coef, None, dx, loss_scale=scale, want_loss=True, shared_ws=True)))
+print("torch.empty_like(x)            host %.1f us  (with sync %.1f)" % timed(lambda i: torch.empty_like(xd)))
+E._TARGET_CACHE.data.clear()
+losses = [None]
+
+
+def fwd(i):
+    losses[0] = ctc.CTCLoss(x, batches[i], C - 1)
+
+
+print("CTCLoss forward (fresh)        host %.1f us  (with sync %.1f)" % timed(fwd))
+
+
+def fwd_bwd(i):
+    x.grad = None
+    ctc.CTCLoss(x, batches[i], C - 1).backward()
+
+
+E._TARGET_CACHE.data.clear()
+print("CTCLoss fwd+bwd (fresh)        host %.1f us  (with sync %.1f)" % timed(fwd_bwd))
+print("CTCLoss fwd+bwd (same targets) host %.1f us  (with sync %.1f)" % timed(lambda i: fwd_bwd(3)))
+tens = [[torch.tensor(r) for r in b] for b in batches]
+E._TARGET_CACHE.data.clear()
+
+
+def fwd_bwd_t(i):
+    x.grad = None
+    ctc.CTCLoss(x, tens[i], C - 1).backward()
+
+
+print("CTCLoss fwd+bwd (fresh, tensor targets) host %.1f us  (with sync %.1f)" % timed(fwd_bwd_t))
