@@ -542,48 +542,48 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
       last = val;
       if (q < CP) L.vec[0][q] = next;
     }
-    __syncthreads();
+    lds_barrier();
     int n = 1;
     for (; n + 1 < T; n += 2) {
       chain_step(n, 0);
-      __syncthreads();
+      lds_barrier();
       chain_step(n + 1, 1);
-      __syncthreads();
+      lds_barrier();
     }
     if (n < T) {
       chain_step(n, 0);
-      __syncthreads();
+      lds_barrier();
     }
   } else {
     if (lane == 0) Eb[DIR == 0 ? 0 : T - 1] = 0;
     stage(2, raw[2], kChecked);
     issue(6, raw[2]);
-    __syncthreads();
+    lds_barrier();
     int n = 1;
     for (; n < n_main; n += 4) {  // items n+2 .. n+9 exist
       helper_scale(n);
       stage(n + 2, raw[3], kUnchecked);
       issue_fast(n + 6, raw[3]);
-      __syncthreads();
+      lds_barrier();
       helper_scale(n + 1);
       stage(n + 3, raw[0], kUnchecked);
       issue_fast(n + 7, raw[0]);
-      __syncthreads();
+      lds_barrier();
       helper_scale(n + 2);
       stage(n + 4, raw[1], kUnchecked);
       issue_fast(n + 8, raw[1]);
-      __syncthreads();
+      lds_barrier();
       helper_scale(n + 3);
       stage(n + 5, raw[2], kUnchecked);
       issue_fast(n + 9, raw[2]);
-      __syncthreads();
+      lds_barrier();
     }
     for (; n < T; ++n) {  // tail: synchronous, checked
       helper_scale(n);
       float tmp[2] = {WFL_NEG_INF, WFL_NEG_INF};
       issue(n + 2, tmp);
       stage(n + 2, tmp, kChecked);
-      __syncthreads();
+      lds_barrier();
     }
   }
   // ---- epilogue: range verdict; log Z from the last alpha vector

@@ -37,6 +37,13 @@ __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 // inputs, so the bare v_log_f32 (log2) is enough
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL
+// stores (s_waitcnt vmcnt(0)): in a per-frame loop that streams its results to HBM that is one store round trip
+// (~1 us) per frame on the dependent path.  Use where the waves only exchange data through LDS.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // NaN policy: a NaN score is an impossible arc.
 __device__ __forceinline__ float nan_to_neg(float v) { return (v != v) ? WFL_NEG_INF : v; }
 

@@ -16,6 +16,8 @@
 // This replaces gtn.intersect(emissions, A) + gtn.forward_score / viterbi_path + gtn.backward
 // (criterions/ctc.py:49-51,78-81; asg.py:111-113; stc.py:85-87; transducer.py:283,321-325) without
 // ever materialising the T*|A| composed lattice.  Memory/latency-bound DP: no MFMA by design.
+#include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "device_common.h"
@@ -70,9 +72,21 @@ __device__ __forceinline__ UttView make_view(const wfl_lattice_desc& d, const in
 // ------------------------------------------------------------------------------------------------
 // stage 1: gather
 // ------------------------------------------------------------------------------------------------
+// Probability-domain copy of a gathered row for the fp64 chains (run_chain_prob): factors
+// fg[k] = 2^((xg[k] - r) * log2 e) <= 1 relative to the row's reference r = max_k xg[k] (0 if the row is all -inf).
+// One wave per row; `vmx` is the lane's running maximum of the values it wrote to `dst` (re-read from L1 here).
+__device__ __forceinline__ void emit_factors(const float* dst, float* fdst, float* rdst, int K, int lane, float vmx) {
+  if (!fdst) return;
+  float r = wave_all_max(vmx);
+  if (!(r > WFL_NEG_INF)) r = 0.f;
+  for (int k = lane; k < K; k += 64) fdst[k] = __builtin_amdgcn_exp2f((dst[k] - r) * 1.4426950408889634f);
+  if (lane == 0) *rdst = r;
+}
+
 __global__ void __launch_bounds__(256) gather_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints,
                                                       const float* __restrict__ x, int T, int C,
-                                                      float* __restrict__ xg, float* __restrict__ row_lse) {
+                                                      float* __restrict__ xg, float* __restrict__ row_lse,
+                                                      float* __restrict__ fg, float* __restrict__ rmax) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bb = d.shared ? 0 : b;
@@ -95,7 +109,14 @@ __global__ void __launch_bounds__(256) gather_kernel(wfl_lattice_desc d, const i
       if (lane == 0) row_lse[(int64_t)b * T + t] = lse;
     }
     float* dst = xg + ((int64_t)b * T + t) * Kmax;
-    for (int k = lane; k < K; k += 64) dst[k] = nan_to_neg(row[labels[k]]) - lse;
+    float vmx = WFL_NEG_INF;
+    for (int k = lane; k < K; k += 64) {
+      const float v = nan_to_neg(row[labels[k]]) - lse;
+      dst[k] = v;
+      vmx = fmaxf(vmx, v);
+    }
+    emit_factors(dst, fg ? fg + ((int64_t)b * T + t) * Kmax : nullptr, rmax ? rmax + (int64_t)b * T + t : nullptr, K, lane,
+                 vmx);
   }
 }
 
@@ -105,7 +126,8 @@ __global__ void __launch_bounds__(256) gather_kernel(wfl_lattice_desc d, const i
 template <int NV, int RU>
 __global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints,
                                                           const float* __restrict__ x, int T, int C,
-                                                          float* __restrict__ xg, float* __restrict__ row_lse) {
+                                                          float* __restrict__ xg, float* __restrict__ row_lse,
+                                                          float* __restrict__ fg, float* __restrict__ rmax) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bb = d.shared ? 0 : b;
@@ -141,7 +163,14 @@ __global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, con
       const float* row = x + ((int64_t)b * T + t0 + u) * C;
       if (lane == 0) row_lse[(int64_t)b * T + t0 + u] = lse;
       float* dst = xg + ((int64_t)b * T + t0 + u) * Kmax;
-      for (int k = lane; k < K; k += 64) dst[k] = nan_to_neg(row[labels[k]]) - lse;
+      float vmx = WFL_NEG_INF;
+      for (int k = lane; k < K; k += 64) {
+        const float v = nan_to_neg(row[labels[k]]) - lse;
+        dst[k] = v;
+        vmx = fmaxf(vmx, v);
+      }
+      emit_factors(dst, fg ? fg + ((int64_t)b * T + t0 + u) * Kmax : nullptr,
+                   rmax ? rmax + (int64_t)b * T + t0 + u : nullptr, K, lane, vmx);
     }
   }
 }
@@ -419,18 +448,14 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
                           int32_t* __restrict__ bptr, float* __restrict__ logz, int b, double* __restrict__ offs,
                           double* __restrict__ z64) {
   const int tid = threadIdx.x, NT = blockDim.x;
-  // Per-frame renormalisation (log semiring).  Plain fp32 log scores drift to O(T) -- thousands at T = 800..1000,
-  // where one ulp is 2.4e-4 .. 4.9e-4: the posteriors lost their third digit (measured against the float64 oracle at
-  // BASELINE configs 3 and 4), and even a renormalisation every 16 frames left 2.5e-4 on log-probabilities of a
-  // 1000-class softmax (7 per frame).  So every frame subtracts the maximum of the vector it reads (the single-wave
-  // paths: of the vector before, computed off the dependent chain) and the running sum of what was subtracted lives in
-  // a double: stored scores stay within a few frames' worth of emissions of zero, offs[slot] is what slot's scores
-  // are relative to (offs[boundary slot] = 0), and the gradient kernel adds offs_alpha + offs_beta - log Z in double
-  // before it exponentiates.
+  // Block renormalisation (log semiring): plain fp32 log scores drift to O(T) -- thousands at T = 800..1000, where
+  // one ulp is 2.4e-4 .. 4.9e-4 and the posteriors lose their third digit (measured against the float64 oracle at
+  // BASELINE configs 3 and 4).  So at the start of every chunk of R frames the maximum of the state vector moves
+  // into a double offset: stored scores stay O(R * |x|), offs[1 + c] is what the slots produced in chunk c are
+  // relative to (offs[0] = 0: the boundary slot), and the gradient kernel adds offs_alpha + offs_beta - log Z in
+  // double before it exponentiates.
   double cum = 0.0;
-  float m_cur = 0.f;  // what this frame subtracts
-  auto finite_or_zero = [](float m) { return (m > WFL_NEG_INF && m < __builtin_inff()) ? m : 0.f; };
-  if (SR == WFL_SEMIRING_LOG && tid == 0) offs[DIR == 0 ? 0 : T] = 0.0;
+  if (SR == WFL_SEMIRING_LOG && tid == 0) offs[0] = 0.0;
   const int Q = u.Q, A = u.A, E = u.E, nlev = u.nlev, Kmax = d.max_labels;
   // ---- stage the acceptor into LDS in this direction's CSR order
   for (int k = tid; k < A; k += NT) {
@@ -566,9 +591,6 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   // rows_per_chunk is even, so the first step of every chunk reads the same buffer: forward steps
   // read slot t (chunks start at even t), backward steps read slot t + 1 = T - c * R - i
   const bool first_reads_buf1 = DIR == 0 ? false : (T & 1);
-  int lean_par = 0;  // parity of the wave-maximum mailboxes of the multi-wave lean path
-  if (SR == WFL_SEMIRING_LOG && tid < 32) L.red[tid] = 0.f;  // first frame: subtract nothing
-  __syncthreads();
   auto sweep = [&](auto variant) {
     constexpr int V = decltype(variant)::value;  // 0: general path, 1: banded, otherwise the lean in-degree bound
     for (int c = 0; c < nchunks; ++c) {
@@ -586,6 +608,32 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           if (e < pn * Kmax) pre[j] = src[e];
         }
       }
+      if (SR == WFL_SEMIRING_LOG) {
+        if (c > 0) {
+          float m;
+          if (V != 0 && NT == 64) {  // the vector lives in registers
+            m = wave_all_max(sc);
+            if (m > WFL_NEG_INF && m < __builtin_inff())
+              sc -= m;
+            else
+              m = 0.f;
+          } else {
+            const int tf = DIR == 0 ? f0 : f0 + n;  // slot the first frame of the chunk reads
+            float* fromb = V != 0 ? (first_reads_buf1 ? L.buf1 : L.buf0) : ((tf & 1) ? L.buf1 : L.buf0);
+            float v = WFL_NEG_INF;
+            for (int q = tid; q < Q; q += NT) v = fmaxf(v, fromb[q]);
+            m = block_reduce_max(v, L.red);
+            if (m > WFL_NEG_INF && m < __builtin_inff()) {
+              for (int q = tid; q < Q; q += NT) fromb[q] -= m;
+            } else {
+              m = 0.f;
+            }
+            __syncthreads();
+          }
+          cum += (double)m;
+        }
+        if (tid == 0) offs[1 + c] = cum;
+      }
       // single-wave variants: the emissions of frame i+1 are read from the tile while frame i is
       // being computed (they do not depend on the chain), so only the score exchange is serial
       auto row_of = [&](int i) {
@@ -601,15 +649,11 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           const float xs_n = *reinterpret_cast<const float*>(rn + ro_self);
           const float xa_n = *reinterpret_cast<const float*>(rn + ro_adj);
           const float nb = DIR == 0 ? wave_shr1(sc, WFL_NEG_INF) : wave_shl1(sc, WFL_NEG_INF);
-          const float mn = wave_all_max(sc);  // (not on the chain: used by the NEXT frame)
           float v[kLeanDeg];
-          v[0] = sc + ((xs + w_self) - m_cur);
-          v[1] = nb + ((xa + w_adj) - m_cur);
+          v[0] = sc + (xs + w_self);
+          v[1] = nb + (xa + w_adj);
           sc = lean_lse<2>(v);
-          cum += (double)m_cur;
-          m_cur = finite_or_zero(mn);
           if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
-          if (tid == 0) offs[DIR == 0 ? t + 1 : t] = cum;
           xs = xs_n, xa = xa_n;
         }
       } else if (V != 0 && NT == 64) {
@@ -623,15 +667,11 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           float xn[kLeanDeg], v[kLeanDeg];
 #pragma unroll
           for (int k = 0; k < DEG; ++k) xn[k] = *reinterpret_cast<const float*>(rn + la.ro[k]) + la.w[k];
-          const float mn = wave_all_max(sc);  // (not on the chain: used by the NEXT frame)
 #pragma unroll
           for (int k = 0; k < DEG; ++k)
-            v[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(la.lo[k], __float_as_int(sc))) + (xr[k] - m_cur);
+            v[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(la.lo[k], __float_as_int(sc))) + xr[k];
           sc = lean_lse<DEG>(v);
-          cum += (double)m_cur;
-          m_cur = finite_or_zero(mn);
           if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
-          if (tid == 0) offs[DIR == 0 ? t + 1 : t] = cum;
 #pragma unroll
           for (int k = 0; k < DEG; ++k) xr[k] = xn[k];
         }
@@ -639,23 +679,12 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
         auto step = [&](int i, const float* const (&fp)[kLeanDeg], float* to) {
           const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
           const float* row = tile + (size_t)(t - f0) * Kmax;
-          // maximum of the vector this frame reads: the waves left theirs in `red` before the last barrier
-          float* red_prev = L.red + 16 * (lean_par & 1);
-          float* red_next = L.red + 16 * ((lean_par + 1) & 1);
-          ++lean_par;
-          float m = red_prev[0];
-          for (int wv = 1; wv < (NT >> 6); ++wv) m = fmaxf(m, red_prev[wv]);
-          m = finite_or_zero(m);
-          const float v = lean_relax<(V >= 2 ? V : 2)>(fp, la.ro, la.w, row) - m;
-          cum += (double)m;
-          const float wm = wave_all_max(tid < Q ? v : WFL_NEG_INF);
-          if ((tid & 63) == 0) red_next[tid >> 6] = wm;
+          const float v = lean_relax<(V >= 2 ? V : 2)>(fp, la.ro, la.w, row);
           if (tid < Q) {
             to[tid] = v;
             out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = v;
           }
-          if (tid == 0) offs[DIR == 0 ? t + 1 : t] = cum;
-          __syncthreads();
+          lds_barrier();
         };
         float* const to_first = first_reads_buf1 ? L.buf0 : L.buf1;
         float* const to_second = first_reads_buf1 ? L.buf1 : L.buf0;
@@ -682,19 +711,10 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
           float* to = (slot_to & 1) ? L.buf1 : L.buf0;
           const float* row = tile + (size_t)(t - f0) * Kmax;
           float* orow = out + u.ab_base + (int64_t)slot_to * Q;
-          float msub = 0.f;  // log semiring: the maximum of the vector read moves into the double offset
-          if (SR == WFL_SEMIRING_LOG) {
-            float mx = WFL_NEG_INF;
-            for (int q = tid; q < Q; q += NT) mx = fmaxf(mx, from[q]);
-            msub = finite_or_zero(block_reduce_max(mx, L.red));
-            cum += (double)msub;
-            if (tid == 0) offs[slot_to] = cum;
-          }
           if (tid < Q && kq1 - kq0 <= kHeavyDeg) {
             float v;
             int arg;
             relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
-            v -= msub;
             to[tid] = v;
             if (direct) orow[tid] = v;
             if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
@@ -705,7 +725,6 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
             const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
             if (k1 - k0 > kHeavyDeg) continue;
             relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
-            v -= msub;
             to[q] = v;
             if (direct) orow[q] = v;
             if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
@@ -719,7 +738,6 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
               float v;
               int arg;
               relax_labelled_row16<SR>(L, from, row, k0, k1, v, arg);
-              v -= msub;
               if (q >= 0 && (tid & 15) == 0) {
                 to[q] = v;
                 if (direct) orow[q] = v;
@@ -779,18 +797,305 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// stage 2, probability domain (the default for the log semiring on "lean" acceptors: one state per thread, no
+// epsilon arcs, at most kLeanDeg arcs into AND out of every state -- CTC-like chains, ASG force alignment, STC, the
+// Transducer's alignment graphs).
+//
+// fp32 log-domain sweeps pay a v_exp_f32 per arc and a v_log_f32 per state and frame, and their results carry the
+// transcendentals' (biased) rounding: measured 1.5e-4 .. 2.5e-4 on posteriors / log Z after T = 800..1000 frames
+// against the float64 oracle, whatever the renormalisation.  Here a state is a DOUBLE probability relative to a
+// workgroup-uniform power-of-two scale (renormalised every chunk: exact) and the per-frame references of the gathered
+// emission factors; a frame is one multiply-add per arc:
+//     p'[q] = sum_{arcs s->q} p[s] * wf[arc] * f_t[slot(arc)]        wf = e^(w - wref), f_t = e^(x_t - r_t) <= 1
+// The 11-bit exponent of a double holds what a float cannot: alpha mass piles up at the last states and beta mass
+// at the first ones (2^328 apart at T = 1000), far from the diagonal that carries the posteriors.  What even a
+// double cannot hold shows up as disagreement between the two sweeps' log Z (alpha from the accept states at T,
+// beta from the start states at 0) or as a non-finite / vanished state vector: such an utterance is re-run in the
+// log domain by the repair launch that follows (a no-op otherwise) and marked in fmt[b].
+//   out[slot][q] (double) relative to offs[slot] in LOG2 units:  log2 value = log2 out + offs[slot]
+// ------------------------------------------------------------------------------------------------
+constexpr int kFmtLog = 0, kFmtProb = 1;
+__device__ __forceinline__ int64_t xg_main_dev(const wfl_lattice_desc& d, int T) {
+  return (((int64_t)d.B * T * d.max_labels) + 3) & ~(int64_t)3;
+}
+constexpr double kLog2e_d = 1.4426950408889634074;
+
+struct ProbLds {
+  double* buf0;  // [Q]
+  double* buf1;  // [Q]
+  float* rows;   // [2][R][Kmax] emission factors of the current / next chunk
+  float* refs;   // [2][R]       their references
+  float* red;    // [64] (reductions; reused as int)
+};
+
+__device__ __forceinline__ int block_reduce_max_int(int v, int* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  int r = red[0];
+  for (int i = 1; i < nw; ++i) r = max(r, red[i]);
+  return r;
+}
+__device__ __forceinline__ double block_reduce_sum_f64(double v, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
+  return r;
+}
+
+// Is utterance `u` one for the probability-domain chains?  (block-uniform; both directions must agree, so both
+// degrees are checked by both workgroups)
+__device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {
+  int bad = (u.Q > NT) | (u.E > 0) | (u.nlev > 1);
+  if (!bad)
+    for (int q = threadIdx.x; q < u.Q; q += NT)
+      bad |= (u.in_ptr[q + 1] - u.in_ptr[q] > kLeanDeg) | (u.out_ptr[q + 1] - u.out_ptr[q] > kLeanDeg);
+  return !__syncthreads_or(bad);
+}
+
+template <int DIR>
+__device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, const ProbLds& L, int T, int R,
+                               const float* __restrict__ fg, const float* __restrict__ rmax,
+                               const float* __restrict__ weights, double* __restrict__ out, float* __restrict__ logz,
+                               int b, double* __restrict__ offs, double* __restrict__ z64, float* __restrict__ wref_out,
+                               double* __restrict__ z_copy) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int Q = u.Q, Kmax = d.max_labels;
+  // ---- this thread's state: its in-arcs (forward) / out-arcs (backward) in registers
+  const int32_t* ptr = DIR == 0 ? u.in_ptr : u.out_ptr;
+  const int k0 = tid < Q ? ptr[tid] : 0, k1 = tid < Q ? ptr[tid + 1] : 0;
+  int asrc[kLeanDeg], aslot[kLeanDeg];
+  float aw[kLeanDeg];
+  float wmx = WFL_NEG_INF;
+#pragma unroll
+  for (int i = 0; i < kLeanDeg; ++i) {
+    asrc[i] = 0, aslot[i] = 0, aw[i] = WFL_NEG_INF;
+    if (k0 + i < k1) {
+      const int a = DIR == 0 ? k0 + i : u.out_arc[k0 + i];
+      asrc[i] = DIR == 0 ? u.arc_src[a] : u.arc_dst[a];
+      aslot[i] = u.arc_slot[a];
+      float w = u.arc_w[a];
+      const int wid = u.arc_wid[a];
+      if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+      aw[i] = nan_to_neg(w);
+      wmx = fmaxf(wmx, aw[i]);
+    }
+  }
+  const int deg_class = __syncthreads_or(k1 - k0 > 4) ? 2 : (__syncthreads_or(k1 - k0 > 2) ? 1 : 0);
+  float wref = block_reduce_max(wmx, L.red);  // every frame multiplies by e^wref once more: part of the offset
+  if (!(wref > WFL_NEG_INF)) wref = 0.f;
+  if (wref_out && tid == 0) wref_out[b] = wref;
+  double wf[kLeanDeg];  // (float exponential: the gradient kernel recomputes the same factor)
+#pragma unroll
+  for (int i = 0; i < kLeanDeg; ++i) wf[i] = (double)fast_exp(aw[i] - wref);
+
+  const int t_first = DIR == 0 ? 0 : T;
+  double p = 0.0;
+  if (tid < Q) p = (DIR == 0 ? u.start_w[tid] : u.accept_w[tid]) > WFL_NEG_INF ? 1.0 : 0.0;  // (boundary weights are 0 / -inf)
+  double cum = 0.0;  // log2 of everything factored out of the stored probabilities so far
+  double* cur = (t_first & 1) ? L.buf1 : L.buf0;
+  if (tid < Q) {
+    cur[tid] = p;
+    out[u.ab_base + (int64_t)t_first * Q + tid] = p;
+  }
+  if (tid == 0) offs[t_first] = 0.0;
+
+  const int nchunks = (T + R - 1) / R;
+  auto chunk_frames = [&](int c, int& f0, int& n) {
+    const int s0 = c * R;
+    n = min(R, T - s0);
+    f0 = DIR == 0 ? s0 : T - s0 - n;
+  };
+  if (T > 0) {
+    int f0, n;
+    chunk_frames(0, f0, n);
+    const float* src = fg + u.xg_base + (int64_t)f0 * Kmax;
+    for (int e = tid; e < n * Kmax; e += NT) L.rows[e] = src[e];
+    if (tid < n) L.refs[tid] = rmax[(int64_t)b * T + f0 + tid];
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    int f0, n;
+    chunk_frames(c, f0, n);
+    const float* tile = L.rows + (size_t)(c & 1) * R * Kmax;
+    const float* rtile = L.refs + (size_t)(c & 1) * R;
+    float pre[kPre], rpre = 0.f;
+    int pf0 = 0, pn = 0;
+    if (c + 1 < nchunks) {
+      chunk_frames(c + 1, pf0, pn);
+      const float* src = fg + u.xg_base + (int64_t)pf0 * Kmax;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) pre[j] = src[e];
+      }
+      if (tid < pn) rpre = rmax[(int64_t)b * T + pf0 + tid];
+    }
+    if (c > 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
+      const int ex = (tid < Q && p > 0.0) ? ilogb(p) : -(1 << 30);
+      const int emax = block_reduce_max_int(ex, (int*)L.red);
+      if (emax > -(1 << 30) && emax < 2000) {
+        p = scalbn(p, -emax);
+        cum += (double)emax;
+        double* fromb = ((DIR == 0 ? f0 : f0 + n) & 1) ? L.buf1 : L.buf0;
+        if (tid < Q) fromb[tid] = p;
+      }
+      __syncthreads();
+    }
+    // Software pipeline: the arc coefficients c[k] = wf[k] * f_t[slot_k] of a frame do not depend on the chain, so
+    // they are formed while the previous frame's sources are still on their way from LDS; after the barrier only the
+    // DEG source reads (issued back to back) and DEG multiply-adds (two independent accumulators) remain.
+    auto coeffs = [&](int i, double (&c)[kLeanDeg], auto deg) {
+      constexpr int DEG = decltype(deg)::value;
+      const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+      const float* row = tile + (size_t)(t - f0) * Kmax;
+      float f[DEG];
+#pragma unroll
+      for (int k = 0; k < DEG; ++k) f[k] = row[aslot[k]];
+#pragma unroll
+      for (int k = 0; k < DEG; ++k) c[k] = wf[k] * (double)f[k];
+    };
+    auto frames = [&](auto deg) {
+      constexpr int DEG = decltype(deg)::value;
+      double c[kLeanDeg], cn[kLeanDeg];
+      coeffs(0, c, deg);
+      for (int i = 0; i < n; ++i) {
+        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+        const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
+        const double* from = (slot_from & 1) ? L.buf1 : L.buf0;
+        double* to = (slot_to & 1) ? L.buf1 : L.buf0;
+        double ps[DEG];
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+        if (i + 1 < n) coeffs(i + 1, cn, deg);
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DEG; k += 2) {
+          acc0 = fma(ps[k], c[k], acc0);
+          acc1 = fma(ps[k + 1], c[k + 1], acc1);
+        }
+        p = acc0 + acc1;
+        cum += ((double)rtile[t - f0] + (double)wref) * kLog2e_d;
+        if (tid < Q) {
+          to[tid] = p;
+          out[u.ab_base + (int64_t)slot_to * Q + tid] = p;
+        }
+        if (tid == 0) offs[slot_to] = cum;
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) c[k] = cn[k];
+        lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
+      }
+    };
+    // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
+    if (deg_class == 0)
+      frames(std::integral_constant<int, 2>{});
+    else if (deg_class == 1)
+      frames(std::integral_constant<int, 4>{});
+    else
+      frames(std::integral_constant<int, kLeanDeg>{});
+    if (c + 1 < nchunks) {
+      float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) dst[e] = pre[j];
+      }
+      if (tid < pn) L.refs[(size_t)((c + 1) & 1) * R + tid] = rpre;
+      __syncthreads();
+    }
+  }
+  // log2 of the total: alpha over the accept states at slot T, beta over the start states at slot 0
+  {
+    const float bw = tid < Q ? (DIR == 0 ? u.accept_w[tid] : u.start_w[tid]) : WFL_NEG_INF;
+    const double tot = block_reduce_sum_f64(bw > WFL_NEG_INF ? p : 0.0, (double*)L.red);
+    if (tid == 0) {
+      const bool ok = tot > 0.0 && tot < 1.0e300;
+      const double z2 = ok ? log2(tot) + cum : (tot == 0.0 ? -__builtin_inf() : __builtin_nan(""));
+      z64[b] = z2;  // log2 Z as this sweep sees it (the certificate compares the two)
+      if (z_copy) z_copy[b] = z2;
+      if (DIR == 0 && logz) logz[b] = (float)(z2 * 0.6931471805599453094);
+    }
+  }
+}
+
+// The probability-domain sweeps as their own kernel (their register budget is not the general path's): utterances it
+// does not take are left to the log-domain launch that follows (chain_kernel, mode 2).
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT)
+    prob_chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                      const float* __restrict__ xg, int T, int rows_per_chunk, const float* __restrict__ weights,
+                      float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz, int64_t tail,
+                      int nch1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const UttView u = make_view(d, ints, floats, b, T);
+  double* offs_a = reinterpret_cast<double*>(alpha + tail);  // (tail layout: see chain_kernel)
+  double* offs_b = beta ? reinterpret_cast<double*>(beta + tail) : nullptr;
+  double* za = offs_a + (int64_t)d.B * nch1;
+  double* zb = offs_b ? offs_b + (int64_t)d.B * nch1 : nullptr;
+  int32_t* fmt = reinterpret_cast<int32_t*>(za + d.B);
+  float* wrefs = reinterpret_cast<float*>(fmt + d.B);
+  if (!prob_eligible(u, blockDim.x)) return;
+  ProbLds P;
+  char* p = smem;
+  P.buf0 = (double*)p, p += (size_t)d.max_states * 8;
+  P.buf1 = (double*)p, p += (size_t)d.max_states * 8;
+  P.red = (float*)p, p += 64 * 4;
+  P.rows = (float*)p, p += (size_t)2 * rows_per_chunk * d.max_labels * 4;
+  P.refs = (float*)p;
+  const float* fg = xg + xg_main_dev(d, T);
+  const float* rmax = fg + xg_main_dev(d, T);
+  if (dir == 0) {
+    if (threadIdx.x == 0) fmt[b] = kFmtProb;
+    run_chain_prob<0>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
+                      offs_a + (int64_t)b * nch1, za, wrefs, zb ? zb + d.B : nullptr);
+  } else {
+    run_chain_prob<1>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
+                      offs_b + (int64_t)b * nch1, zb, nullptr, nullptr);
+  }
+}
+
 template <int SR>
 __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
                              const float* __restrict__ xg, int T, int rows_per_chunk,
                              const float* __restrict__ weights, float* __restrict__ alpha, float* __restrict__ beta,
-                             int32_t* __restrict__ bptr, float* __restrict__ logz, int64_t tail, int nch1) {
+                             int32_t* __restrict__ bptr, float* __restrict__ logz, int64_t tail, int nch1, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, dir = blockIdx.y;
-  // renormalisation offsets live behind the score arrays (wfl_lattice_workspace reserves the room):
-  // alpha + tail: double offs[B][nch1], double logZ[B];  beta + tail: double offs[B][nch1]
+  const UttView u = make_view(d, ints, floats, b, T);
+  // behind the score arrays (wfl_lattice_workspace reserves the room):
+  //   alpha + tail: double offs[B][nch1], double Z[B] (ln Z; log2 Z for probability-domain utterances),
+  //                 int32 fmt[B], float wref[B]
+  //   beta + tail:  double offs[B][nch1], double Z[B] as the backward sweep sees it (probability domain), double
+  //                 Z[B] of the forward sweep once more (the repair launch decides on this pair: nothing it writes)
   double* offs_a = reinterpret_cast<double*>(alpha + tail);
   double* offs_b = beta ? reinterpret_cast<double*>(beta + tail) : nullptr;
-  const UttView u = make_view(d, ints, floats, b, T);
+  double* za = offs_a + (int64_t)d.B * nch1;
+  double* zb = offs_b ? offs_b + (int64_t)d.B * nch1 : nullptr;
+  int32_t* fmt = reinterpret_cast<int32_t*>(za + d.B);
+  float* wrefs = reinterpret_cast<float*>(fmt + d.B);
+  // mode: 1 = every utterance in the log domain (WFL_LATTICE_DOMAIN=log, tropical semiring);
+  //       2 = the launch after prob_chain_kernel: the log-domain sweeps of what that launch left -- utterances whose
+  //           acceptor it does not take, and those whose two probability-domain sweeps disagree about Z
+  if (SR == WFL_SEMIRING_LOG && mode == 2) {
+    if (prob_eligible(u, blockDim.x)) {
+      if (!zb) return;  // (forward only: nothing to compare)
+      const double a2 = zb[d.B + b], b2 = zb[b];
+      const bool both_dead = a2 == -__builtin_inf() && b2 == -__builtin_inf();
+      if (both_dead || fabs(a2 - b2) <= 1.0e-4) return;  // log2 units; NaN compares false
+    }
+  }
+  if (SR == WFL_SEMIRING_LOG && dir == 0 && threadIdx.x == 0) fmt[b] = kFmtLog;
   ChainLds L;
   char* p = smem;
   L.arcs = (int2*)p, p += (size_t)d.max_arcs * 8;
@@ -804,17 +1109,18 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
   L.lvl = (int*)p, p += (size_t)(d.max_levels + 1) * 4;
   L.heavy = (int*)p;
   if (dir == 0)
-    run_chain<SR, 0>(d, u, L, T, rows_per_chunk, xg, weights, alpha, bptr, logz, b, offs_a + (int64_t)b * nch1,
-                     offs_a + (int64_t)d.B * nch1);
+    run_chain<SR, 0>(d, u, L, T, rows_per_chunk, xg, weights, alpha, bptr, logz, b, offs_a + (int64_t)b * nch1, za);
   else
     run_chain<SR, 1>(d, u, L, T, rows_per_chunk, xg, weights, beta, nullptr, nullptr, b, offs_b + (int64_t)b * nch1,
                      nullptr);
 }
 
 static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
-  return (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 8 +
+  const size_t prob = (size_t)d.max_states * 16 + 64 * 4 + (size_t)2 * rows_per_chunk * d.max_labels * 4 +
+                      (size_t)2 * rows_per_chunk * 4 + 64;
+  return std::max(prob, (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 8 +
          (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 +
-         (size_t)(d.max_states + 1) * 4 + 64;
+         (size_t)(d.max_states + 1) * 4 + 64);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -843,9 +1149,13 @@ __global__ void __launch_bounds__(256)
   // in a compact tile, and the rows are streamed out as base value (0, the existing gradient, or
   // the softmax term of the fused log_softmax backward) plus the accumulator of the column's label
   // slot, looked up in a column -> slot map.
-  float* al = (float*)smem;                                 // [TS+1][Qmax]
-  float* be = al + (size_t)(TS + 1) * d.max_states;         // [TS+1][Qmax]
-  float* xr = be + (size_t)(TS + 1) * d.max_states;         // [TS][Kmax]
+  // alpha / beta rows of the tile: doubles for utterances swept in the probability domain (fmt[b] == kFmtProb), floats
+  // (in the first half of the same room) for the log domain
+  double* ald = (double*)smem;                              // [TS+1][Qmax]
+  double* bed = ald + (size_t)(TS + 1) * d.max_states;      // [TS+1][Qmax]
+  float* al = (float*)ald;
+  float* be = (float*)bed;
+  float* xr = (float*)(bed + (size_t)(TS + 1) * d.max_states);  // [TS][Kmax]: log scores | factors
   float* acc = xr + (size_t)TS * Kmax;                      // [TS][Kmax] (only if dx)
   float* dwacc = acc + (dx ? (size_t)TS * Kmax : 0);        // [A + E] (only if dW)
   int2* sarc = (int2*)(dwacc + (dW ? (size_t)d.max_arcs + d.max_eps : 0));  // [A] by-slot {src | dst << 16, w - z}
@@ -854,13 +1164,23 @@ __global__ void __launch_bounds__(256)
   // the blank column of a CTC-like acceptor (two in-arcs per blank state: hundreds of arcs in ONE
   // slot) is spread over many threads instead of serialising the tile
   int2* chunk = (int2*)(sptr + (dx ? ((Kmax + 3) & ~1) : 0));  // [NC] {slot, first arc}; NC <= K + A / kChunk (8-byte aligned)
-  float* corr = (float*)(chunk + (dx ? Kmax + d.max_arcs / kChunk + 1 : 0));  // [TS]: offs_alpha(t) + offs_beta(t+1) - log Z
-  float* corr_eps = corr + TS;                                                 // [TS+1]: both at slot t (epsilon arcs)
-  int16_t* colmap = (int16_t*)(corr_eps + TS + 1);  // [C] (only if dx)
-  // scores are stored relative to per-slot double offsets (run_chain)
+  double* corr_d = (double*)(chunk + (dx ? Kmax + d.max_arcs / kChunk + 1 : 0));  // [TS] probability domain: 2^(offsets - log2 Z)
+  float* corr = (float*)(corr_d + 33);  // [TS]: offs_alpha(t) + offs_beta(t+1) - log Z
+  float* corr_eps = corr + 33;          // [TS+1]: both at slot t (epsilon arcs)
+  int16_t* colmap = (int16_t*)(corr_eps + 34);  // [C] (only if dx)
+  // scores are stored relative to per-chunk double offsets (run_chain): slot s of alpha belongs to chunk (s-1)/R of
+  // the forward sweep, slot s of beta to chunk (T-1-s)/R of the backward sweep, the boundary slots to offset 0
   const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
   const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
-  const double zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];
+  const double zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];  // ln Z | log2 Z (prob)
+  const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
+  const float* wrefs = reinterpret_cast<const float*>(fmt + d.B);
+  const bool prob = fmt[b] == kFmtProb;
+  const float wref = prob ? wrefs[b] : 0.f;
+  const float* fgp = xg + xg_main_dev(d, T);                    // probability-domain factors of the gathered rows
+  const float* rmaxp = fgp + xg_main_dev(d, T) + (int64_t)b * T;  // their references
+  const double* alpha_d = reinterpret_cast<const double*>(alpha);
+  const double* beta_d = reinterpret_cast<const double*>(beta);
   const float g0 = gout ? gout[0] : 1.f;
   const float cf = coef ? coef[b] * g0 : g0;
   const float z = logz[b];
@@ -887,6 +1207,7 @@ __global__ void __launch_bounds__(256)
       const int wid = u.arc_wid[a];
       float w = u.arc_w[a];
       if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+      if (prob) w = fast_exp(nan_to_neg(w) - wref);  // the arc's factor (run_chain_prob)
       sarc[j] = make_int2(u.arc_src[a] | (u.arc_dst[a] << 16), __float_as_int(w));
     }
   }
@@ -896,17 +1217,29 @@ __global__ void __launch_bounds__(256)
     // flat, unrolled copy loops: the global loads of several iterations are in flight together
     // (idx / n by float reciprocal: exact for idx < 2^20, see fdiv)
     {
-      const float* asrc = alpha + u.ab_base + (int64_t)ts0 * Q;
-      const float* bsrc = beta + u.ab_base + (int64_t)ts0 * Q;
       const int n = (nr + 1) * Q;
+      if (prob) {
+        const double* asrc = alpha_d + u.ab_base + (int64_t)ts0 * Q;
+        const double* bsrc = beta_d + u.ab_base + (int64_t)ts0 * Q;
 #pragma unroll 4
-      for (int i = tid; i < n; i += NT) {
-        const int r = fdiv(i, inv_q), q = i - r * Q;
-        const float av = asrc[i], bv = bsrc[i];
-        al[r * d.max_states + q] = av;
-        be[r * d.max_states + q] = bv;
+        for (int i = tid; i < n; i += NT) {
+          const int r = fdiv(i, inv_q), q = i - r * Q;
+          const double av = asrc[i], bv = bsrc[i];
+          ald[r * d.max_states + q] = av;
+          bed[r * d.max_states + q] = bv;
+        }
+      } else {
+        const float* asrc = alpha + u.ab_base + (int64_t)ts0 * Q;
+        const float* bsrc = beta + u.ab_base + (int64_t)ts0 * Q;
+#pragma unroll 4
+        for (int i = tid; i < n; i += NT) {
+          const int r = fdiv(i, inv_q), q = i - r * Q;
+          const float av = asrc[i], bv = bsrc[i];
+          al[r * d.max_states + q] = av;
+          be[r * d.max_states + q] = bv;
+        }
       }
-      const float* xsrc = xg + u.xg_base + (int64_t)ts0 * Kmax;
+      const float* xsrc = (prob ? fgp : xg) + u.xg_base + (int64_t)ts0 * Kmax;
 #pragma unroll 4
       for (int i = tid; i < nr * Kmax; i += NT) {
         xr[i] = xsrc[i];
@@ -914,9 +1247,15 @@ __global__ void __launch_bounds__(256)
       }
       if (tid <= nr) {
         const int sl = ts0 + tid;
-        const double oa = offs_a[sl];
-        corr_eps[tid] = (float)(oa + offs_b[sl] - zd);
-        if (tid < nr) corr[tid] = (float)(oa + offs_b[sl + 1] - zd);
+        if (prob) {
+          // gamma_t(arc) = p_alpha[t][src] wf f_t[slot] p_beta[t+1][dst] * 2^(offs_a[t] + offs_b[t+1] + (r_t + wref) log2e - log2 Z)
+          if (tid < nr)
+            corr_d[tid] = exp2(offs_a[sl] + offs_b[sl + 1] + ((double)rmaxp[sl] + (double)wref) * kLog2e_d - zd);
+        } else {
+          const double oa = offs_a[sl == 0 ? 0 : 1 + (sl - 1) / R];
+          corr_eps[tid] = (float)(oa + offs_b[sl == T ? 0 : 1 + (T - 1 - sl) / R] - zd);
+          if (tid < nr) corr[tid] = (float)(oa + offs_b[sl + 1 == T ? 0 : 1 + (T - 2 - sl) / R] - zd);
+        }
       }
     }
     __syncthreads();
@@ -930,14 +1269,25 @@ __global__ void __launch_bounds__(256)
           const int r = fdiv(i, inv_nc);
           const int2 ch = chunk[i - r * NC];
           const int k = ch.x, j1 = min(ch.y + kChunk, sptr[k + 1]);
-          const float* pa = al + r * d.max_states;
-          const float* pb = pa + (be - al) + d.max_states;
-          const float xv = xr[r * Kmax + k] + corr[r];
           float sum = 0.f;
-          for (int j = ch.y; j < j1; ++j) {
-            const int2 a = sarc[j];
-            const float v = pa[a.x & 0xffff] + xv + __int_as_float(a.y) + pb[(unsigned)a.x >> 16];
-            sum += fast_exp(v);  // exp(-inf) = 0
+          if (prob) {
+            const double* pa = ald + r * d.max_states;
+            const double* pb = bed + (r + 1) * d.max_states;
+            double dsum = 0.0;
+            for (int j = ch.y; j < j1; ++j) {
+              const int2 a = sarc[j];
+              dsum = fma(pa[a.x & 0xffff] * pb[(unsigned)a.x >> 16], (double)__int_as_float(a.y), dsum);
+            }
+            sum = (float)(dsum * (corr_d[r] * (double)xr[r * Kmax + k]));
+          } else {
+            const float* pa = al + r * d.max_states;
+            const float* pb = pa + (be - al) + d.max_states;
+            const float xv = xr[r * Kmax + k] + corr[r];
+            for (int j = ch.y; j < j1; ++j) {
+              const int2 a = sarc[j];
+              const float v = pa[a.x & 0xffff] + xv + __int_as_float(a.y) + pb[(unsigned)a.x >> 16];
+              sum += fast_exp(v);  // exp(-inf) = 0
+            }
           }
           if (sptr[k + 1] - sptr[k] <= kChunk)
             acc[r * Kmax + k] = sum;  // the slot's only chunk
@@ -951,16 +1301,25 @@ __global__ void __launch_bounds__(256)
           const int wid = u.arc_wid[a];
           if (wid < 0) continue;
           const float w = u.arc_w[a] + (weights ? nan_to_neg(weights[wid]) : 0.f);
-          const float* pa = al + u.arc_src[a];
-          const float* pb = be + d.max_states + u.arc_dst[a];
           const float* px = xr + u.arc_slot[a];
           float wsum = 0.f;
-          for (int r = 0; r < nr; ++r)
-            wsum += fast_exp(pa[r * d.max_states] + (px[r * Kmax] + corr[r]) + w + pb[r * d.max_states]);
+          if (prob) {
+            const double* pa = ald + u.arc_src[a];
+            const double* pb = bed + d.max_states + u.arc_dst[a];
+            double ds = 0.0;
+            for (int r = 0; r < nr; ++r)
+              ds = fma(pa[r * d.max_states] * pb[r * d.max_states], corr_d[r] * (double)px[r * Kmax], ds);
+            wsum = (float)(ds * (double)fast_exp(nan_to_neg(w) - wref));
+          } else {
+            const float* pa = al + u.arc_src[a];
+            const float* pb = be + d.max_states + u.arc_dst[a];
+            for (int r = 0; r < nr; ++r)
+              wsum += fast_exp(pa[r * d.max_states] + (px[r * Kmax] + corr[r]) + w + pb[r * d.max_states]);
+          }
           if (wsum != 0.f) dwacc[a] += wsum;  // this thread owns dwacc[a]
         }
       }
-      if (dW && E > 0) {
+      if (dW && E > 0 && !prob) {  // (probability-domain utterances have no epsilon arcs)
         const int nslots = nr + ((ts0 + nr == T) ? 1 : 0);  // epsilon slots t = ts0 .. (T included once)
         for (int i = tid; i < nslots * E; i += NT) {
           const int r = i / E, e = i - r * E;
@@ -1177,6 +1536,8 @@ using namespace wfl;
 
 extern "C" {
 
+static int64_t xg_main(const wfl_lattice_desc& d, int T) { return (((int64_t)d.B * T * d.max_labels) + 3) & ~(int64_t)3; }
+
 // Launch shape of the chain kernel: threads per workgroup and emission rows per chunk (also the renormalisation
 // interval, so the gradient kernel needs the same number).
 static void chain_config(const wfl_lattice_desc& d, int& nt, int& rpc) {
@@ -1185,13 +1546,13 @@ static void chain_config(const wfl_lattice_desc& d, int& nt, int& rpc) {
   while (nt < 256 && nt * kPre < 2 * d.max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
   rpc = std::max(2, std::min(16, nt * kPre / std::max(1, d.max_labels)) & ~1);  // even (run_chain)
 }
-// scores [..] | pad to 8 B | double offs[B][nch1] | double logZ[B]   (nch1 = T + 1 time slots; see run_chain)
-static int64_t ab_main_elems(const wfl_lattice_desc& d, int T) {
-  return d.shared ? (int64_t)d.B * (T + 1) * d.max_states : (int64_t)(T + 1) * d.total_states;
+// scores (float | double) [..] | double offs[B][nch1] | double Z[B] | int32 fmt[B] | float wref[B]   (see chain_kernel)
+static int64_t ab_main_elems(const wfl_lattice_desc& d, int T) {  // (float units; room for doubles)
+  return 2 * (d.shared ? (int64_t)d.B * (T + 1) * d.max_states : (int64_t)(T + 1) * d.total_states);
 }
 static void ab_tail(const wfl_lattice_desc& d, int T, int64_t& tail, int& nch1) {
-  nch1 = T + 1;
-  tail = (ab_main_elems(d, T) + 1) & ~(int64_t)1;
+  nch1 = T + 1;  // one offset per time slot (probability domain); the log domain uses one per chunk
+  tail = ab_main_elems(d, T);
 }
 
 int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, int64_t* ab_elems) {
@@ -1199,12 +1560,13 @@ int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, i
     set_error("lattice_workspace: bad arguments");
     return WFL_ERR_INVALID;
   }
-  if (xg_elems) *xg_elems = (int64_t)d->B * T * d->max_labels;
+  // xg: log-domain rows | probability-domain factors of the same rows | one reference per row
+  if (xg_elems) *xg_elems = 2 * xg_main(*d, T) + (int64_t)d->B * T;
   if (ab_elems) {
     int64_t tail;
     int nch1;
     ab_tail(*d, T, tail, nch1);
-    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B);
+    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2;
   }
   return WFL_OK;
 }
@@ -1227,7 +1589,8 @@ int wfl_lattice_gather(const wfl_lattice_desc* d, const int32_t* ints, const flo
   if (T <= 0) return WFL_OK;
   auto launch = [&](auto kern, int ru) {
     dim3 grid((unsigned)std::min(1024, (T + 4 * ru - 1) / (4 * ru)), (unsigned)d->B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, *d, ints, x, T, C, xg, row_lse);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, *d, ints, x, T, C, xg, row_lse, xg + xg_main(*d, T),
+                       xg + 2 * xg_main(*d, T));
   };
   if (!row_lse || C > 1024)
     launch(gather_kernel, 1);
@@ -1270,8 +1633,26 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     auto k = chain_kernel<WFL_SEMIRING_LOG>;
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const int log_only = [] {  // WFL_LATTICE_DOMAIN=log: the fp32 log-domain sweeps throughout (A/B tests)
+      const char* e = getenv("WFL_LATTICE_DOMAIN");
+      return (e && std::string(e) == "log") ? 1 : 0;
+    }();
+    if (!log_only) {
+      // probability-domain sweeps of every utterance whose acceptor allows it ...
+      auto launch_prob = [&](auto kern) {
+        if (lds > 48 * 1024)
+          hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
+                           beta, logz, tail, nch1);
+      };
+      if (nt <= 256)
+        launch_prob(prob_chain_kernel<256>);
+      else
+        launch_prob(prob_chain_kernel<1024>);
+    }
+    // ... then the log-domain sweeps of the rest (and of utterances whose two sweeps disagree: the certificate)
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
-                       beta, (int32_t*)nullptr, logz, tail, nch1);
+                       beta, (int32_t*)nullptr, logz, tail, nch1, log_only ? 1 : 2);
   } else if (semiring == WFL_SEMIRING_TROPICAL) {
     if (!bptr) {
       set_error("lattice_forward: tropical semiring needs a back-pointer buffer");
@@ -1282,7 +1663,7 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
-                       (float*)nullptr, bptr, logz, tail, nch1);
+                       (float*)nullptr, bptr, logz, tail, nch1, 1);
   } else {
     set_error("lattice_forward: unknown semiring %d", semiring);
     return WFL_ERR_INVALID;
@@ -1308,12 +1689,12 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
   // frames per LDS sub-tile: alpha, beta, gathered emissions and the per-label accumulators of TS
   // frames; ~24 KiB at most so that several workgroups are co-resident (each one is a load ->
   // barrier -> compute -> barrier -> stream-out sequence, overlap comes from co-residency)
-  const size_t row_bytes = 4 * (2 * (size_t)d->max_states + (size_t)d->max_labels * (dx ? 2 : 1));
-  const size_t fixed = 4 * (2 * (size_t)d->max_states + (dW ? (size_t)d->max_arcs + d->max_eps : 0)) +
+  const size_t row_bytes = 16 * (size_t)d->max_states + 4 * (size_t)d->max_labels * (dx ? 2 : 1);  // (alpha, beta: doubles)
+  const size_t fixed = 16 * (size_t)d->max_states + 4 * (dW ? (size_t)d->max_arcs + d->max_eps : 0) +
                        (dx ? 8 * (size_t)d->max_arcs + 4 * (((size_t)d->max_labels + 3) & ~(size_t)1) +
                                 8 * ((size_t)d->max_labels + d->max_arcs / kChunk + 1) + 2 * (size_t)C
                           : 0) +
-                       4 * (2 * 32 + 2) + 64;  // (+ the per-row offset corrections of at most 32 + 1 rows)
+                       8 * 33 + 4 * (33 + 34) + 64;  // (+ the per-row offset corrections of at most 32 + 1 rows)
   if (dx && d->max_labels > 32767) {
     set_error("lattice_grad: %d distinct labels per utterance (limit 32767)", d->max_labels);
     return WFL_ERR_UNSUPPORTED;
