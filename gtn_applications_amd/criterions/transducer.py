@@ -266,13 +266,15 @@ class TransducerLossFunction(torch.autograd.Function):
         def build():
             # per-sample graph algebra of transducer.py:262-281 for the whole batch: one native call, threaded
             # over the utterances like the reference's gtn.parallel_for (transducer.py:296)
-            pack = E.PackedLattice.transducer_batch(tokens, lexicon, transitions, flat, offsets, C, dev)
             if reduction == "mean":  # transducer.py:302-305: normalise by the (grapheme) target length
-                sc = [1.0 / n if n > 0 else 1.0 for n in lens]
+                sc = np.array([1.0 / n if n > 0 else 1.0 for n in lens], dtype=np.float32)
             else:
-                sc = [1.0] * B
-            scale = torch.tensor(sc, dtype=torch.float32, device=dev)
-            return pack, scale, scale / B, -scale / B, (tokens, lexicon, transitions)
+                sc = np.ones(B, dtype=np.float32)
+            # (loss scale, +scale/B, -scale/B) travel with the packed batch: one asynchronous upload, no kernels
+            pack = E.PackedLattice.transducer_batch(tokens, lexicon, transitions, flat, offsets, C, dev,
+                                                    extra=np.concatenate([sc, sc / B, -sc / B]))
+            fac = pack.extra
+            return pack, fac[:B], fac[B:2 * B], fac[2 * B:], (tokens, lexicon, transitions)
 
         pack, scale, cpos, cneg, _ = _PACK_CACHE.get(key + (reduction == "mean",), build)
         need_grad = inputs.requires_grad or (transition_params is not None and transition_params.requires_grad)

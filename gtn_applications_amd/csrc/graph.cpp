@@ -45,6 +45,122 @@ static void build_sorted(const wfl_graph& g, bool by_ol, Adjacency& adj) {
                      [&](int32_t a, int32_t b) { return key[a] < key[b]; });
 }
 
+// A graph is lexicon-shaped (what make_lexicon_graph builds, transducer.py:61-75) if node 0 is its only start and
+// only accept node and every arc lies on a simple path 0 -> n1 -> ... -> 0 whose inner nodes have exactly one in- and
+// one out-arc, whose input labels are not epsilon and whose output labels are epsilon except on the last arc.
+static std::shared_ptr<LexTrie> build_lex_trie(const wfl_graph& g) {
+  const int n = g.num_nodes();
+  const int64_t m = g.num_arcs();
+  if (n < 1 || !g.start[0] || !g.accept[0]) return nullptr;
+  for (int i = 1; i < n; ++i)
+    if (g.start[i] || g.accept[i]) return nullptr;
+  std::vector<int32_t> out_arc(n, -1), out_deg(n, 0), in_deg(n, 0);
+  for (int64_t a = 0; a < m; ++a) {
+    if (g.il[a] == WFL_EPSILON) return nullptr;
+    out_deg[g.src[a]]++, in_deg[g.dst[a]]++;
+    if (g.src[a] != 0) out_arc[g.src[a]] = (int32_t)a;
+  }
+  for (int i = 1; i < n; ++i)
+    if (out_deg[i] != 1 || in_deg[i] != 1) return nullptr;
+  // spellings in arc order of their first arc (keeps the relative order of the entries)
+  struct Node {
+    std::vector<std::pair<int32_t, int32_t>> kids;  // (label, node)
+    std::vector<LexTrie::Term> terms;
+  };
+  std::vector<Node> nodes(1);
+  int64_t used = 0;
+  for (int64_t a0 = 0; a0 < m; ++a0) {
+    if (g.src[a0] != 0) continue;
+    int cur = 0;
+    float w = 0.f;
+    int64_t a = a0;
+    for (int steps = 0;; ++steps) {
+      if (steps > n) return nullptr;
+      ++used;
+      w += g.w[a];
+      int next = -1;
+      for (auto& kv : nodes[cur].kids)
+        if (kv.first == g.il[a]) next = kv.second;
+      if (next < 0) {
+        next = (int)nodes.size();
+        nodes[cur].kids.emplace_back(g.il[a], next);
+        nodes.emplace_back();
+      }
+      cur = next;
+      if (g.dst[a] == 0) {
+        nodes[cur].terms.push_back({g.ol[a], w});
+        break;
+      }
+      if (g.ol[a] != WFL_EPSILON) return nullptr;
+      a = out_arc[g.dst[a]];
+      if (a < 0) return nullptr;
+    }
+  }
+  if (used != m) return nullptr;
+  auto t = std::make_shared<LexTrie>();
+  t->child_ptr.push_back(0), t->term_ptr.push_back(0);
+  for (auto& nd : nodes) {
+    std::sort(nd.kids.begin(), nd.kids.end());
+    for (auto& kv : nd.kids) t->child_label.push_back(kv.first), t->child_node.push_back(kv.second);
+    t->child_ptr.push_back((int32_t)t->child_label.size());
+    for (auto& tm : nd.terms) t->terms.push_back(tm);
+    t->term_ptr.push_back((int32_t)t->terms.size());
+  }
+  return t;
+}
+
+wfl_graph* lexicon_decompose(const wfl_graph* lexicon, const int32_t* target, int len) {
+  std::shared_ptr<LexTrie> trie;
+  {
+    std::lock_guard<std::mutex> lock(lexicon->mu);
+    if (lexicon->lex_state == 0) {
+      lexicon->lex_trie = build_lex_trie(*lexicon);
+      lexicon->lex_state = lexicon->lex_trie ? 1 : -1;
+    }
+    if (lexicon->lex_state < 0) return nullptr;
+    trie = lexicon->lex_trie;
+  }
+  const LexTrie& t = *trie;
+  struct A {
+    int32_t s, d, lab;
+    float w;
+  };
+  std::vector<A> arcs;
+  std::vector<uint8_t> reach(len + 1, 0), co(len + 1, 0);
+  reach[0] = 1;
+  for (int i = 0; i < len; ++i) {
+    if (!reach[i]) continue;
+    int node = 0;
+    for (int j = i; j < len; ++j) {
+      const int32_t* lo = t.child_label.data() + t.child_ptr[node];
+      const int32_t* hi = t.child_label.data() + t.child_ptr[node + 1];
+      const int32_t* it = std::lower_bound(lo, hi, target[j]);
+      if (it == hi || *it != target[j]) break;
+      node = t.child_node[it - t.child_label.data()];
+      for (int k = t.term_ptr[node]; k < t.term_ptr[node + 1]; ++k) {
+        arcs.push_back({i, j + 1, t.terms[k].olabel, t.terms[k].w});
+        reach[j + 1] = 1;
+      }
+    }
+  }
+  co[len] = 1;
+  for (size_t k = arcs.size(); k-- > 0;)  // arcs are ordered by source position: one reverse pass settles it
+    if (co[arcs[k].d]) co[arcs[k].s] = 1;
+  auto* out = new wfl_graph();
+  std::vector<int32_t> id(len + 1, -1);
+  for (int i = 0; i <= len; ++i)
+    if (reach[i] && co[i]) {
+      id[i] = out->num_nodes();
+      out->start.push_back(i == 0), out->accept.push_back(i == len);
+    }
+  for (const A& a : arcs)
+    if (id[a.s] >= 0 && id[a.d] >= 0) {
+      out->src.push_back(id[a.s]), out->dst.push_back(id[a.d]);
+      out->il.push_back(a.lab), out->ol.push_back(a.lab), out->w.push_back(a.w);
+    }
+  return out;
+}
+
 }  // namespace wfl
 
 const wfl::Adjacency& wfl_graph::out_sorted(bool by_olabel) const {

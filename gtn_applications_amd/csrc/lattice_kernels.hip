@@ -855,10 +855,10 @@ __device__ __forceinline__ double block_reduce_sum_f64(double v, double* red) {
 
 // Is utterance `u` one for the probability-domain chains?  (block-uniform; both directions must agree, so both
 // degrees are checked by both workgroups)
-__device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {
+__device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {  // NT: threads of the CHAIN workgroups
   int bad = (u.Q > NT) | (u.E > 0) | (u.nlev > 1);
   if (!bad)
-    for (int q = threadIdx.x; q < u.Q; q += NT)
+    for (int q = threadIdx.x; q < u.Q; q += blockDim.x)
       bad |= (u.in_ptr[q + 1] - u.in_ptr[q] > kLeanDeg) | (u.out_ptr[q + 1] - u.out_ptr[q] > kLeanDeg);
   return !__syncthreads_or(bad);
 }
@@ -1058,11 +1058,59 @@ __global__ void __launch_bounds__(MAXT)
   if (dir == 0) {
     if (threadIdx.x == 0) fmt[b] = kFmtProb;
     run_chain_prob<0>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
-                      offs_a + (int64_t)b * nch1, za, wrefs, zb ? zb + d.B : nullptr);
+                      offs_a + (int64_t)b * nch1, za, wrefs, nullptr);
   } else {
     run_chain_prob<1>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
                       offs_b + (int64_t)b * nch1, zb, nullptr, nullptr);
   }
+}
+
+// Certificate of the probability-domain sweeps.  A double holds a spread of 2^1000 between the largest state and
+// the ones that carry the posteriors; beyond that the latter are flushed, in BOTH sweeps (comparing the two totals is
+// not enough: each sweep can lose a different half of the paths and the halves can weigh the same).  What cannot
+// fail silently is sum_s alpha_t[s] beta_t[s] = Z at every time slot: checked at every 8th slot (a flushed region
+// spans many frames) plus both ends, against the forward sweep's log2 Z, to 1e-4 (the parity bar).  One workgroup per
+// utterance; verdict[b] = 1 sends the utterance to the log-domain launch that follows.
+__global__ void __launch_bounds__(256)
+    prob_certify_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T,
+                        const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt) {
+  __shared__ double red[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const UttView u = make_view(d, ints, floats, b, T);
+  const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
+  double* tail_b = reinterpret_cast<double*>(beta + tail);
+  const double* offs_b = tail_b + (int64_t)b * nch1;
+  const double za = (reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * nch1)[b];
+  const double zbv = (tail_b + (int64_t)d.B * nch1)[b];
+  double* verdict = tail_b + (int64_t)d.B * (nch1 + 1) + b;
+  if (!prob_eligible(u, chain_nt)) {
+    if (tid == 0) *verdict = 1.0;  // (not swept in the probability domain at all: the log-domain launch takes it)
+    return;
+  }
+  const double* pa = reinterpret_cast<const double*>(alpha) + u.ab_base;
+  const double* pb = reinterpret_cast<const double*>(beta) + u.ab_base;
+  const int Q = u.Q;
+  double worst = 0.0;
+  const bool dead = za == -__builtin_inf() && zbv == -__builtin_inf();  // no accepting path: exact in any arithmetic
+  if (!dead) {
+    worst = fabs(za - zbv);
+    if (!(worst <= 1.0)) worst = 1.0e9;  // NaN / one-sided -inf
+    for (int t = 0; t <= T; t += (t + 8 <= T || t == T) ? 8 : T - t) {
+      double s = 0.0;
+      for (int q = tid; q < Q; q += 256) s = fma(pa[(int64_t)t * Q + q], pb[(int64_t)t * Q + q], s);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      __syncthreads();
+      if ((tid & 63) == 0) red[tid >> 6] = s;
+      __syncthreads();
+      if (tid == 0) {
+        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        const double dev = (tot > 0.0 && tot < 1.0e300) ? fabs(log2(tot) + offs_a[t] + offs_b[t] - za) : 1.0e9;
+        worst = fmax(worst, dev);
+      }
+    }
+  }
+  if (tid == 0) *verdict = (worst <= 1.0e-4) ? 0.0 : 1.0;
 }
 
 template <int SR>
@@ -1077,7 +1125,7 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
   //   alpha + tail: double offs[B][nch1], double Z[B] (ln Z; log2 Z for probability-domain utterances),
   //                 int32 fmt[B], float wref[B]
   //   beta + tail:  double offs[B][nch1], double Z[B] as the backward sweep sees it (probability domain), double
-  //                 Z[B] of the forward sweep once more (the repair launch decides on this pair: nothing it writes)
+  //                 verdict[B] of prob_certify_kernel (0: certified, 1: re-run in the log domain)
   double* offs_a = reinterpret_cast<double*>(alpha + tail);
   double* offs_b = beta ? reinterpret_cast<double*>(beta + tail) : nullptr;
   double* za = offs_a + (int64_t)d.B * nch1;
@@ -1089,10 +1137,8 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
   //           acceptor it does not take, and those whose two probability-domain sweeps disagree about Z
   if (SR == WFL_SEMIRING_LOG && mode == 2) {
     if (prob_eligible(u, blockDim.x)) {
-      if (!zb) return;  // (forward only: nothing to compare)
-      const double a2 = zb[d.B + b], b2 = zb[b];
-      const bool both_dead = a2 == -__builtin_inf() && b2 == -__builtin_inf();
-      if (both_dead || fabs(a2 - b2) <= 1.0e-4) return;  // log2 units; NaN compares false
+      if (!zb) return;                 // (forward only: nothing to compare)
+      if (zb[d.B + b] == 0.0) return;  // certified by prob_certify_kernel
     }
   }
   if (SR == WFL_SEMIRING_LOG && dir == 0 && threadIdx.x == 0) fmt[b] = kFmtLog;
@@ -1649,6 +1695,9 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
         launch_prob(prob_chain_kernel<256>);
       else
         launch_prob(prob_chain_kernel<1024>);
+      if (beta)
+        hipLaunchKernelGGL(prob_certify_kernel, dim3((unsigned)d->B), dim3(256), 0, (hipStream_t)stream, *d, ints, floats, T,
+                           alpha, beta, tail, nch1, nt);
     }
     // ... then the log-domain sweeps of the rest (and of utterances whose two sweeps disagree: the certificate)
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,

@@ -39,8 +39,8 @@ struct Builder {
   std::vector<float> arc_w, eps_w, start_w, accept_w;
   int max_states = 0, max_arcs = 0, max_eps = 0, max_labels = 0, max_levels = 0;
   // scratch reused across utterances
-  std::vector<int32_t> level, perm, inv, order, tmp, slot_of;
-  std::vector<Arc> lab_arcs, eps_arcs;
+  std::vector<int32_t> level, perm, inv, order, tmp, slot_of, cnt;
+  std::vector<Arc> lab_arcs, eps_arcs, sorted;
 
   // Adds one utterance.  `arcs` may be reordered.  Returns false (error set) on invalid input.
   bool add(int Q, const uint8_t* start, const uint8_t* accept, std::vector<Arc>& arcs) {
@@ -111,9 +111,24 @@ struct Builder {
     for (int k = 0; k < K; ++k) slot_of[tmp[k]] = k, labels.push_back(tmp[k]);
     lab_off.push_back((int32_t)labels.size());
 
+    // stable counting sort of the indices 0..n-1 by key(i) in [0, nkeys): the keys are state / slot numbers, so
+    // this is O(n + nkeys) without the temporary buffer std::stable_sort allocates (the packer runs per utterance
+    // and per step on the host path of the criteria)
+    auto counting_order = [&](int n, int nkeys, auto key, std::vector<int32_t>& out) {
+      cnt.assign(nkeys + 1, 0);
+      for (int i = 0; i < n; ++i) cnt[key(i) + 1]++;
+      for (int k = 0; k < nkeys; ++k) cnt[k + 1] += cnt[k];
+      out.resize(n);
+      for (int i = 0; i < n; ++i) out[cnt[key(i)]++] = i;
+    };
     auto emit_csr = [&](std::vector<Arc>& v, bool labelled) {
       for (Arc& a : v) a.src = inv[a.src], a.dst = inv[a.dst];
-      std::stable_sort(v.begin(), v.end(), [](const Arc& a, const Arc& b) { return a.dst < b.dst; });
+      {
+        counting_order((int)v.size(), Q, [&](int i) { return v[i].dst; }, order);
+        sorted.resize(v.size());
+        for (size_t i = 0; i < v.size(); ++i) sorted[i] = v[order[i]];
+        v.swap(sorted);
+      }
       const int n = (int)v.size();
       std::vector<int32_t>& ip = labelled ? in_ptr : ein_ptr;
       std::vector<int32_t>& op = labelled ? out_ptr : eout_ptr;
@@ -124,17 +139,14 @@ struct Builder {
       for (const Arc& a : v) ip[ib + a.dst + 1]++;
       for (int q = 0; q < Q; ++q) ip[ib + q + 1] += ip[ib + q];
       // out order
-      order.resize(n);
-      std::iota(order.begin(), order.end(), 0);
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return v[a].src < v[b].src; });
+      counting_order(n, Q, [&](int i) { return v[i].src; }, order);
       const size_t ob = op.size();
       op.resize(ob + Q + 1, 0);
       for (const Arc& a : v) op[ob + a.src + 1]++;
       for (int q = 0; q < Q; ++q) op[ob + q + 1] += op[ob + q];
       oa.insert(oa.end(), order.begin(), order.end());
       if (labelled) {  // by-slot order: the gradient kernel sums the arcs of one emission column without atomics
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return slot_of[v[a].lab] < slot_of[v[b].lab]; });
+        counting_order(n, std::max(K, 1), [&](int i) { return slot_of[v[i].lab]; }, order);
         const size_t sb = slot_ptr.size();
         slot_ptr.resize(sb + K + 1, 0);
         for (const Arc& a : v) slot_ptr[sb + slot_of[a.lab] + 1]++;
@@ -500,19 +512,23 @@ struct ProfDump { ~ProfDump() { for (int i = 0; i < 8; ++i) fprintf(stderr, "pro
 #endif
 bool alignment_acceptor(const wfl_graph* tokens, const wfl_graph* lexicon, const wfl_graph* transitions,
                         const int32_t* target, int len, int C, Builder& out) {
-  wfl_graph chain;  // make_chain_graph (transducer.py:23-29)
-  chain.start.assign(len + 1, 0), chain.accept.assign(len + 1, 0);
-  chain.start[0] = 1, chain.accept[len] = 1;
-  for (int i = 0; i < len; ++i)
-    chain.src.push_back(i), chain.dst.push_back(i + 1), chain.il.push_back(target[i]), chain.ol.push_back(target[i]),
-        chain.w.push_back(0.f);
   PROF_T0
-  GraphOwner c1(wfl_graph_compose(&chain, lexicon, nullptr, nullptr));
-  if (!c1.g) return false;
-  PROF(0)
-  c1.g->il = c1.g->ol;  // project_output in place (c1 is ours)
-  GraphOwner tokens_target(wfl_graph_remove(c1.g, WFL_EPSILON, WFL_EPSILON, nullptr));
-  if (!tokens_target.g) return false;
+  // tokens_target = remove(project_output(compose(chain(target), lexicon))): all decompositions into tokens
+  wfl_graph* tt = wfl::lexicon_decompose(lexicon, target, len);
+  if (!tt) {  // not a make_lexicon_graph-shaped lexicon: the generic graph algebra
+    wfl_graph chain;  // make_chain_graph (transducer.py:23-29)
+    chain.start.assign(len + 1, 0), chain.accept.assign(len + 1, 0);
+    chain.start[0] = 1, chain.accept[len] = 1;
+    for (int i = 0; i < len; ++i)
+      chain.src.push_back(i), chain.dst.push_back(i + 1), chain.il.push_back(target[i]), chain.ol.push_back(target[i]),
+          chain.w.push_back(0.f);
+    GraphOwner c1(wfl_graph_compose(&chain, lexicon, nullptr, nullptr));
+    if (!c1.g) return false;
+    c1.g->il = c1.g->ol;  // project_output in place (c1 is ours)
+    tt = wfl_graph_remove(c1.g, WFL_EPSILON, WFL_EPSILON, nullptr);
+    if (!tt) return false;
+  }
+  GraphOwner tokens_target(tt);
   PROF(1)
   GraphOwner c2(wfl_graph_compose(tokens, tokens_target.g, nullptr, nullptr));
   if (!c2.g) return false;

@@ -119,26 +119,35 @@ class LRU:
 class PackedLattice:
     """B acceptors in the flat device format of `wfl_lattice_desc`, resident in HBM."""
 
-    def __init__(self, host_handle, device):
+    def __init__(self, host_handle, device, extra=None):
+        """`extra`: optional float32 host array uploaded behind the float blob in the same copy (per-utterance loss
+        factors); `self.extra` is its device view."""
         N.check_handle(host_handle)
+        cuda = device is not None and device.type == "cuda"
         try:
             d = N.lib.wfl_lattice_host_desc(host_handle).contents
             self.desc = N.LatticeDesc.from_buffer_copy(d)
             ni, nf = int(d.int_words), int(d.float_words)
-            ints = np.ctypeslib.as_array(
-                ctypes.cast(N.lib.wfl_lattice_host_ints(host_handle), ctypes.POINTER(ctypes.c_int32)), shape=(max(ni, 1),)
-            )
-            floats = np.ctypeslib.as_array(
-                ctypes.cast(N.lib.wfl_lattice_host_floats(host_handle), ctypes.POINTER(ctypes.c_float)),
-                shape=(max(nf, 1),),
-            )
-            self.host_ints = ints[:ni].copy()
-            self.host_floats = floats[:nf].copy()
+            ne = 0 if extra is None else int(extra.size)
+            # the blobs go through PINNED host tensors and asynchronous copies: a pageable copy is synchronous, i.e. it
+            # would wait for everything queued on the stream before it -- the previous step's kernels
+            hi = torch.empty(max(ni, 1), dtype=torch.int32, pin_memory=cuda)
+            hf = torch.empty(max(nf + ne, 1), dtype=_F32, pin_memory=cuda)
+            if ni:
+                ctypes.memmove(hi.data_ptr(), N.lib.wfl_lattice_host_ints(host_handle), 4 * ni)
+            if nf:
+                ctypes.memmove(hf.data_ptr(), N.lib.wfl_lattice_host_floats(host_handle), 4 * nf)
+            self.host_ints = hi.numpy()[:ni]
+            self.host_floats = hf.numpy()[:nf]
+            if ne:
+                hf.numpy()[nf:nf + ne] = np.asarray(extra, dtype=np.float32).reshape(-1)
         finally:
             N.lib.wfl_lattice_host_free(host_handle)
         self.device = device
-        self.ints = torch.from_numpy(self.host_ints).to(device) if device is not None else None
-        self.floats = torch.from_numpy(self.host_floats).to(device) if device is not None else None
+        self._host = (hi, hf)  # (keeps the pinned memory alive while the copies are in flight)
+        self.ints = hi.to(device, non_blocking=True) if device is not None else None
+        self.floats = hf.to(device, non_blocking=True) if device is not None else None
+        self.extra = self.floats[nf:nf + ne] if (ne and device is not None) else None
         self._desc_ref = ctypes.byref(self.desc)
 
     # -- constructors ---------------------------------------------------------------------------
@@ -165,7 +174,7 @@ class PackedLattice:
         return cls(h, device)
 
     @classmethod
-    def transducer_batch(cls, tokens, lexicon, transitions, flat, offsets, C, device, nthreads=0):
+    def transducer_batch(cls, tokens, lexicon, transitions, flat, offsets, C, device, nthreads=0, extra=None):
         """Alignment acceptors of a whole batch, built and packed on the library's host thread pool
         (wfl_transducer_pack_batch: transducer.py:262-281 under gtn.parallel_for)."""
         flat = np.ascontiguousarray(flat, dtype=np.int32)
@@ -173,7 +182,7 @@ class PackedLattice:
             flat = np.zeros(1, np.int32)
         h = N.lib.wfl_transducer_pack_batch(tokens._h, lexicon._h, None if transitions is None else transitions._h,
                                             flat.ctypes.data, offsets.ctypes.data, len(offsets) - 1, int(C), int(nthreads))
-        return cls(h, device)
+        return cls(h, device, extra)
 
     @classmethod
     def ctc(cls, flat, offsets, blank, C, device):
@@ -240,6 +249,17 @@ def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_L
     )
     _done(tok)
     return st
+
+
+def lattice_formats(st):
+    """int32 [B] (device): how each utterance of a log-semiring forward pass was swept -- 1: fp64 probability domain,
+    0: fp32 log domain (acceptor with epsilon arcs / in- or out-degree above 8 / more than 1024 states, or the
+    certificate's repair: the two probability-domain sweeps disagreed about Z).  Diagnostics and tests; the layout is
+    the tail of the alpha buffer described in csrc/lattice_kernels.hip (chain_kernel)."""
+    B, T = st.pack.desc.B, st.T
+    tail = st.alpha.numel() - (2 * (B * (T + 1) + B) + 2 * B + 2)
+    off = tail + 2 * (B * (T + 1) + B)
+    return st.alpha[off:off + B].view(torch.int32)
 
 
 def lattice_grad(st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None):

@@ -64,3 +64,61 @@ def fwd_bwd_t(i):
 
 
 print("CTCLoss fwd+bwd (fresh, tensor targets) host %.1f us  (with sync %.1f)" % timed(fwd_bwd_t))
+
+# ---- Transducer (cfg4): where the cold (fresh targets) host time goes
+import ctypes
+import random
+import numpy as np
+from gtn_applications_amd import _native as N
+from gtn_applications_amd.criterions import transducer as TR
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tokens = sorted(l.strip() for l in open(os.path.join(ROOT, "benchmarks", "word_pieces_tokens_1000.txt")))
+graphemes = sorted(set(c for t in tokens for c in t))
+g2i = {t: i for i, t in enumerate(graphemes)}
+crit = TR.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+crit.tokens.arc_sort(True)
+rnd = random.Random(0)
+NB = 40
+tb = [[torch.tensor([g2i[ch] for _ in range(15) for ch in rnd.choice(tokens)]) for _ in range(64)] for _ in range(NB)]
+flats = [E.flatten_any(t) for t in tb]
+Cc = len(tokens) + 1
+
+
+def tt(fn, n=NB - 5, skip=5):
+    for i in range(skip):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(skip, skip + n):
+        fn(i)
+    h = (time.perf_counter() - t0) / n * 1e6
+    torch.cuda.synchronize()
+    return h, (time.perf_counter() - t0) / n * 1e6
+
+
+print("flatten_any (64 tensors)            host %.1f us (sync %.1f)" % tt(lambda i: E.flatten_any(tb[i])))
+
+
+def native_only(i, nthreads=0):
+    flat, off, _ = flats[i]
+    h = N.lib.wfl_transducer_pack_batch(crit.tokens._h, crit.lexicon._h, None, flat.ctypes.data, off.ctypes.data, 64, Cc, nthreads)
+    N.lib.wfl_lattice_host_free(h)
+
+
+print("wfl_transducer_pack_batch (pool)    host %.1f us (sync %.1f)" % tt(native_only))
+print("wfl_transducer_pack_batch (serial)  host %.1f us (sync %.1f)" % tt(lambda i: native_only(i, 1), n=5, skip=1))
+print("PackedLattice.transducer_batch      host %.1f us (sync %.1f)" % tt(
+    lambda i: E.PackedLattice.transducer_batch(crit.tokens, crit.lexicon, None, flats[i][0], flats[i][1], Cc, dev)))
+xt = torch.randn(64, 800, Cc, device="cuda", requires_grad=True)
+TR._PACK_CACHE.data.clear()
+
+
+def tfwd(i):
+    xt.grad = None
+    crit(xt, tb[i]).backward()
+
+
+print("Transducer fwd+bwd (fresh)          host %.1f us (sync %.1f)" % tt(tfwd))
+print("Transducer fwd+bwd (same)           host %.1f us (sync %.1f)" % tt(lambda i: tfwd(7)))
+print("host cores", os.cpu_count())

@@ -1053,3 +1053,84 @@ def test_conv_transduce_shapes_and_errors(crit):
         tr.ConvTransduce1D(lexicon, 5, 1, 2, scale="cubic")
     with pytest.raises(ValueError):
         tr.ConvTransduce1D(lexicon, 5, 1, 2, normalize="both")
+
+
+# =================================================================================================
+# lattice engine, probability domain (round 2)
+# =================================================================================================
+def test_lattice_probability_domain_is_the_default_and_matches_log_domain(crit):
+    """lean acceptors (CTC-like, force alignment, STC, Transducer alignments) are swept in the fp64 probability
+    domain; WFL_LATTICE_DOMAIN=log (read at the first launch of a process) is covered by the subprocess below"""
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(7)
+    B, T, C = 3, 300, 9
+    x = dev(rs.randn(B, T, C) * 1.5)
+    targets = [rs.randint(0, C - 1, size=n).tolist() for n in (300, 0, 17)]  # 300 labels: lattice engine (L > 255), Q = 601
+    tg = E.targets_on_device(targets, x.device)
+    pack = E.PackedLattice.ctc(tg.flat, tg.offsets, C - 1, C, x.device)
+    st = E.lattice_forward(x, pack)
+    assert E.lattice_formats(st).tolist() == [1, 1, 1]
+    coef = torch.ones(B, device="cuda")
+    dx = torch.full_like(x, float("nan"))
+    E.lattice_grad(st, coef, dx=dx)
+    want_loss, want_dx = OR.ctc_loss_grad_batched(x.cpu().numpy(), targets, C - 1)
+    got = st.logz.cpu().numpy()
+    assert np.isinf(want_loss[0]) and got[0] == -np.inf and float(dx[0].abs().max()) == 0.0  # 300 labels need > 300 frames
+    np.testing.assert_allclose(-got[1:], want_loss[1:], rtol=1e-6)
+    close(dx[1:], -want_dx[1:] * B, rtol=1e-5, atol=1e-6)
+    import subprocess
+    import sys
+
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "os.environ['WFL_LATTICE_DOMAIN'] = 'log'\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from gtn_applications_amd import engine as E\n"
+        "rs = np.random.RandomState(7)\n"
+        "x = torch.tensor(rs.randn(3, 300, 9) * 1.5, dtype=torch.float32, device='cuda')\n"
+        "targets = [rs.randint(0, 8, size=n).tolist() for n in (300, 0, 17)]\n"
+        "tg = E.targets_on_device(targets, x.device)\n"
+        "st = E.lattice_forward(x, E.PackedLattice.ctc(tg.flat, tg.offsets, 8, 9, x.device))\n"
+        "assert E.lattice_formats(st).tolist() == [0, 0, 0]\n"
+        "print(' '.join('%.6f' % v for v in st.logz.cpu().tolist()))\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    logd = [float(v) for v in out.stdout.split()[-3:]]
+    assert logd[0] == -np.inf
+    np.testing.assert_allclose(logd[1:], got[1:], rtol=2e-6)
+
+
+def test_lattice_certificate_sends_what_a_double_cannot_hold_to_the_log_domain(crit):
+    """Monotone chains whose alpha mass sits 2^2900 above the states that carry the posteriors (scores that reward the
+    late states early and the early states late): the forward sweep's double underflows there, the two sweeps disagree
+    about Z, the repair launch re-runs the utterance in the log domain -- next to a harmless utterance that stays in
+    the probability domain.  Both against the float64 oracle."""
+    from gtn_applications_amd import engine as E
+
+    T, L, C, c = 400, 20, 24, 10.0
+    x = np.zeros((2, T, C), dtype=np.float32)
+    y = list(range(L))
+    x[0, : T // 2, L // 2:L] = c  # early frames reward the late labels ...
+    x[0, T // 2:, : L // 2] = c   # ... late frames the early labels: no monotone path collects either
+    rs = np.random.RandomState(0)
+    x[1] = rs.randn(T, C)
+    targets = [y, y]
+    xt = dev(x)
+    tg = E.targets_on_device(targets, xt.device)
+    W = torch.zeros(C + 1, C, device="cuda")
+    pack = E.PackedLattice.asg_force_align(tg.flat, tg.offsets, C, xt.device)
+    st = E.lattice_forward(xt, pack, weights=W)
+    assert E.lattice_formats(st).tolist() == [0, 1]  # utterance 0 was repaired in the log domain
+    dx = torch.zeros_like(xt)
+    E.lattice_grad(st, torch.ones(2, device="cuda"), dx=dx)
+    for b in range(2):
+        src, dst, lab = [], [], []
+        for l in range(1, L + 1):
+            src += [l - 1, l]
+            dst += [l, l]
+            lab += [y[l - 1], y[l - 1]]
+        lz, gx, _ = OR.lattice_forward_backward(x[b], src, dst, lab, np.zeros(2 * L), [0], [L], L + 1)
+        assert float(st.logz[b]) == pytest.approx(lz, rel=1e-5)
+        close(dx[b], gx, rtol=2e-3 if b == 0 else 1e-4, atol=2e-3 if b == 0 else 1e-5, msg=f"utterance {b}")
