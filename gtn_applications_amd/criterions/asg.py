@@ -50,6 +50,13 @@ def unpack_replabels(tokens, num_replabels):
     return out
 
 
+def max_classes():
+    """Largest class count the ASG kernels accept (wfl_dense_max_classes: the transition matrix is LDS-resident)."""
+    from .. import _native as N
+
+    return int(N.lib.wfl_dense_max_classes())
+
+
 class ASGLossFunction(torch.autograd.Function):
     @staticmethod
     def create_transitions_graph(transitions, calc_grad=False):
@@ -143,6 +150,13 @@ class ASG(torch.nn.Module):
         assert self.num_replabels > 0
         self.garbage_idx = (num_classes + num_replabels) if use_garbage else None
         self.N = num_classes + num_replabels + int(use_garbage)
+        limit = max_classes()
+        if self.N > limit:
+            # documented deviation from the reference (asg.py:191-209 has no limit): the fully connected
+            # (N+1) x N transition sweeps keep the matrix on chip; say so here, not at the first training step
+            raise NotImplementedError(
+                f"ASG with {self.N} classes (tokens + replabels + garbage): the MI355X dense-transition kernels take at most "
+                f"{limit} (DESIGN.md section 3.3).  Use the Transducer criterion with ngram=1/2 transitions for larger token sets.")
         self.transitions = torch.nn.Parameter(torch.zeros(self.N + 1, self.N))
 
     def forward(self, inputs, targets):

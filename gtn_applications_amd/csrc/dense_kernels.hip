@@ -335,9 +335,14 @@ __global__ void dense_backtrace_kernel(const float* __restrict__ alpha, const in
 //   alpha_t[i]  = a~_t[i] * 2^(E_t + M_t),   E_t = sum kk (int),  M_t = sum mx2 (double)
 //
 // kk is an integer exponent read off the vector itself that keeps it near 2^30: an exact scaling.  One
-// workgroup per (utterance, direction): waves 0-1 own one state per lane and keep their row (alpha)
-// or column (beta) of P in registers, the frame vector is broadcast through LDS (ds_read_b128), one
-// barrier per frame; wave 2 runs ahead, turning emission rows into e_t / mx2_t in an LDS ring.
+// workgroup per (utterance, direction), five waves.  Waves 0-3 (one per SIMD) run the matrix-vector product: a
+// wave covers 32 states, and each state's dot product is split over TWO lanes (lane l and l ^ 16 take the two
+// halves of the vector), so a lane keeps HALF a row (alpha) / column (beta) of P in registers, issues CP/4
+// v_pk_fma_f32 per frame and the halves meet in one cross-lane add -- all four SIMDs issue FMAs and the dependent
+// work per frame is a quarter of the two-wave layout this replaces (measured there: ~1050 cycles per frame, 370 of
+// them broadcast LDS reads, the FMAs on two SIMDs only).  The frame vector is broadcast through LDS (ds_read_b128,
+// the two halves 16 bytes apart in bank space), one barrier per frame; wave 4 runs ahead, turning emission rows
+// into e_t / mx2_t in an LDS ring.
 // Range check: every stored a~ / b~ must stay >= 2^-95 (and finite) and every finite transition
 // within 2^-60 of its row maximum; otherwise the utterance is flagged and the log-domain kernels
 // recompute it (flag[b][dir]).
@@ -372,13 +377,15 @@ static size_t dense_ws_bytes(int B, int T) {
   return (size_t)8 * B * 2 * T + (size_t)8 * B + (size_t)4 * B * 2 * T + (size_t)4 * B * T + 4 * 128 + (size_t)8 * B + 64;
 }
 
+constexpr int kDenseChainWaves = 4, kDenseThreads = (kDenseChainWaves + 1) * 64;
 template <int CP>
 struct FastLds {
-  float vec[2][CP];  // frame vector broadcast to all lanes (ping-pong)
-  float eh[4][CP];   // ring of e_t rows staged by the helper wave
+  static constexpr int H = (CP / 2 + 3) / 4 * 4;  // states per half of the vector (a multiple of 4: float4 reads)
+  float vec[2][2][H + 4];  // frame vector (ping-pong) in two halves, the second one 16 B off in bank space
+  float eh[4][CP];         // ring of e_t rows staged by the helper wave
   float wr2[CP];
-  float st2[CP];     // start weights W[0, :] in log2 units
-  float wsum[2];
+  float st2[CP];           // start weights W[0, :] in log2 units
+  float wsum[kDenseChainWaves];
   double mtot;
 };
 
@@ -394,25 +401,30 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   int32_t* Eb = ws.E + ((int64_t)b * 2 + DIR) * T;
 
   // ---- row maxima of the transition matrix (one wave per row), start weights
-  for (int i = wave; i < CP; i += 3) {
+  for (int i = wave; i < CP; i += kDenseChainWaves + 1) {
     float m = WFL_NEG_INF;
     if (i < C)
       for (int j = lane; j < C; j += 64) m = fmaxf(m, W[(1 + i) * C + j]);
     m = wave_all_max(m);
     if (lane == 0) L.wr2[i] = i < C ? m * kLog2e : 0.f;
   }
-  for (int i = tid; i < CP; i += 192) L.st2[i] = i < C ? nan_to_neg(W[i]) * kLog2e : WFL_NEG_INF;
+  for (int i = tid; i < CP; i += kDenseThreads) L.st2[i] = i < C ? nan_to_neg(W[i]) * kLog2e : WFL_NEG_INF;
   __syncthreads();
   if (b == 0 && DIR == 0)
-    for (int i = tid; i < C; i += 192) ws.wr2[i] = L.wr2[i];
+    for (int i = tid; i < C; i += kDenseThreads) ws.wr2[i] = L.wr2[i];
 
-  // ---- chain waves: this state's row (alpha) / column (beta) of P
-  const int q = tid;  // state of a chain lane
-  f32x2 P[CP / 2];    // pairs: the matrix-vector product issues v_pk_fma_f32
+  // ---- chain waves: lane (wave, hh, qq, il) works on state q = 32 wave + 16 hh + il and on the half qq of the
+  // vector: its half of the state's row (alpha) / column (beta) of P
+  constexpr int H = FastLds<CP>::H;
+  const int qq = (lane >> 4) & 1;                         // which half of the vector this lane multiplies
+  const int q = 32 * wave + 16 * (lane >> 5) + (lane & 15);  // state of a chain lane
+  const bool owner = qq == 0;                              // the lane that finishes the state
+  f32x2 P[H / 2];  // pairs: the matrix-vector product issues v_pk_fma_f32
   int hard = 0;
-  if (wave < 2) {
+  if (wave < kDenseChainWaves) {
 #pragma unroll
-    for (int j = 0; j < CP; ++j) {
+    for (int k = 0; k < H; ++k) {
+      const int j = qq * H + k;
       float p = 0.f;
       if (q < C && j < C) {
         const float w = DIR == 0 ? W[(1 + q) * C + j] : W[(1 + j) * C + q];
@@ -420,7 +432,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
         hard |= !(d >= -kHardGap);  // -inf, NaN, +inf rows, or a dynamic range the floor check cannot vouch for
         p = __builtin_amdgcn_exp2f(d);
       }
-      P[j >> 1][j & 1] = p;
+      P[k >> 1][k & 1] = p;
     }
   }
   if (__syncthreads_or(hard)) {
@@ -482,23 +494,26 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   auto scale_exp = [&](const float4& v) {
     return __builtin_amdgcn_frexp_expf(vmax(vmax(v.x, v.y), vmax(v.z, v.w))) - kNormExp;
   };
+  // where state i sits in the two-halves layout of the frame vector
+  auto vslot = [&](int cur, int i) -> float& { return L.vec[cur][i >= H ? 1 : 0][i >= H ? i - H : i]; };
   auto chain_step = [&](int n, int cur) {  // n >= 1, cur = (n - 1) & 1
     const float e = L.eh[(DIR == 0 ? n : n + 1) & 3][q < CP ? q : 0];  // beta at n = T-1: a stale row, unused
-    const float4* v4 = reinterpret_cast<const float4*>(L.vec[cur]);
+    const float4* v4 = reinterpret_cast<const float4*>(L.vec[cur][qq]);
+    const float inv = __builtin_amdgcn_ldexpf(1.f, -scale_exp(*reinterpret_cast<const float4*>(L.vec[cur][0])));
     f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-    float inv = 1.f;
 #pragma unroll
-    for (int j = 0; j < CP / 4; ++j) {
+    for (int j = 0; j < H / 4; ++j) {
       const float4 v = v4[j];
-      if (j == 0) inv = __builtin_amdgcn_ldexpf(1.f, -scale_exp(v));
       a0 = __builtin_elementwise_fma(P[2 * j], f32x2{v.x, v.y}, a0);
       a1 = __builtin_elementwise_fma(P[2 * j + 1], f32x2{v.z, v.w}, a1);
     }
-    const float y = inv * ((a0[0] + a0[1]) + (a1[0] + a1[1]));
+    float part = (a0[0] + a0[1]) + (a1[0] + a1[1]);
+    part += __shfl_xor(part, 16, 64);  // the other half of the dot product (lane ^ 16: same state)
+    const float y = inv * part;
     const float val = DIR == 0 ? e * y : y;
-    if (q < CP) L.vec[cur ^ 1][q] = DIR == 0 ? val : e * y;
+    if (owner && q < CP) vslot(cur ^ 1, q) = DIR == 0 ? val : e * y;
     last = val;
-    if (q < C) {
+    if (owner && q < C) {
       bad |= !(val >= kFloor && val < 3.0e38f);
       ob[(int64_t)(DIR == 0 ? n : T - 1 - n) * C + q] = val;
     }
@@ -506,12 +521,12 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   // helper side of the same bookkeeping: E_t = sum of the exponents applied up to step n
   int ecum = 0;
   auto helper_scale = [&](int n) {
-    ecum += scale_exp(*reinterpret_cast<const float4*>(L.vec[(n - 1) & 1]));
+    ecum += scale_exp(*reinterpret_cast<const float4*>(L.vec[(n - 1) & 1][0]));
     if (lane == 0) Eb[DIR == 0 ? n : T - 1 - n] = ecum;
   };
 
   // ---- prologue: items 0 and 1 staged synchronously, items 2..5 in flight
-  if (wave == 2) {
+  if (wave == kDenseChainWaves) {
     issue(0, raw[0]);
     issue(1, raw[1]);
     stage(0, raw[0], kChecked);
@@ -525,7 +540,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   // ---- intervals: interval n ends with barrier n; the chain performs step n, the helper stages
   // item n + 2 and issues the loads of item n + 6.  Role-specialised loops with the same barrier count.
   const int n_main = T >= 12 ? 1 + ((T - 10) / 4) * 4 : 1;  // main loop covers n in [1, n_main): items n+6 < T
-  if (wave < 2) {
+  if (wave < kDenseChainWaves) {
     {  // interval 0
       float val, next;
       if (DIR == 0) {
@@ -535,12 +550,12 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
         val = q < C ? 1.f : 0.f;
         next = T > 1 ? L.eh[1][q < CP ? q : 0] * val : 0.f;
       }
-      if (q < C) {
+      if (owner && q < C) {
         bad |= !(val >= kFloor && val < 3.0e38f);
         ob[(int64_t)(DIR == 0 ? 0 : T - 1) * C + q] = val;
       }
       last = val;
-      if (q < CP) L.vec[0][q] = next;
+      if (owner && q < CP) vslot(0, q) = next;
     }
     lds_barrier();
     int n = 1;
@@ -589,15 +604,15 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   // ---- epilogue: range verdict; log Z from the last alpha vector
   const int any_bad = __syncthreads_or(bad);
   if (DIR == 0) {
-    if (wave < 2) {
-      const float s = wave_all_sum(q < C ? last : 0.f);
+    if (wave < kDenseChainWaves) {
+      const float s = wave_all_sum((owner && q < C) ? last : 0.f);
       if (lane == 0) L.wsum[wave] = s;
     } else if (lane == 0) {
       L.mtot = mrun + (double)ecum;
     }
     __syncthreads();
     if (tid == 0) {
-      const double z2 = L.mtot + (double)__builtin_amdgcn_logf(L.wsum[0] + L.wsum[1]);
+      const double z2 = L.mtot + (double)__builtin_amdgcn_logf((L.wsum[0] + L.wsum[1]) + (L.wsum[2] + L.wsum[3]));
       ws.z2[b] = z2;
       logz[b] = (float)(z2 * 0.6931471805599453);
     }
@@ -606,7 +621,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
 }
 
 template <int CP>
-__global__ void __launch_bounds__(192)
+__global__ void __launch_bounds__(kDenseThreads)
     dense_fast_chain_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, void* wsp, int B,
                             float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz) {
   __shared__ __attribute__((aligned(16))) FastLds<CP> L;
@@ -749,6 +764,15 @@ static int dense_check(const float* x, const float* W, int B, int T, int C, cons
   return WFL_OK;
 }
 
+// Largest number of classes the dense-transition kernels take: the (C+1) x C matrix of the log-domain / Viterbi
+// kernels lives in LDS.  (ASG is a letter-level criterion -- the reference's recipes use 28..80 classes; a
+// word-piece sized ASG needs a streamed-W kernel that does not exist yet: callers are told at construction time.)
+extern "C" int wfl_dense_max_classes(void) {
+  int c = 1;
+  while (dense_chain_lds(c + 1, (c + 1) | 1) <= (size_t)kLdsBytes) ++c;
+  return c;
+}
+
 // smallest instantiated padded class count >= C (0: no fast path)
 static int dense_fast_cp(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 104 ? 104 : C <= 128 ? 128 : 0; }
 
@@ -771,7 +795,7 @@ int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int s
     const DenseWs w = dense_ws_carve(ws, B, T);
     const dim3 grid((unsigned)B, beta ? 2u : 1u);
 #define WFL_FAST_CHAIN(CP) \
-  hipLaunchKernelGGL(dense_fast_chain_kernel<CP>, grid, dim3(192), 0, st, x, W, T, C, ws, B, alpha, beta, logz)
+  hipLaunchKernelGGL(dense_fast_chain_kernel<CP>, grid, dim3(kDenseThreads), 0, st, x, W, T, C, ws, B, alpha, beta, logz)
     if (cp == 32)
       WFL_FAST_CHAIN(32);
     else if (cp == 64)

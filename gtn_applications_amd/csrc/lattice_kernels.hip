@@ -899,6 +899,23 @@ __device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, cons
 #pragma unroll
   for (int i = 0; i < kLeanDeg; ++i) wf[i] = (double)fast_exp(aw[i] - wref);
 
+  // single-wave banded acceptors (ASG force alignment, CTC-like chains without skips): every arc comes from the state
+  // itself or from its neighbour -- the state vector stays in registers, the neighbour is one DPP wave shift away
+  const int adj = DIR == 0 ? tid - 1 : tid + 1;
+  double wf_self = 0.0, wf_adj = 0.0;
+  int slot_self = 0, slot_adj = 0, band_ok = 1;
+#pragma unroll
+  for (int i = 0; i < kLeanDeg; ++i) {
+    if (!(aw[i] > WFL_NEG_INF)) continue;
+    if (asrc[i] == tid && wf_self == 0.0)
+      wf_self = wf[i], slot_self = aslot[i];
+    else if (asrc[i] == adj && wf_adj == 0.0)
+      wf_adj = wf[i], slot_adj = aslot[i];
+    else
+      band_ok = 0;
+  }
+  const bool banded = NT == 64 && __syncthreads_and(band_ok);
+
   const int t_first = DIR == 0 ? 0 : T;
   double p = 0.0;
   if (tid < Q) p = (DIR == 0 ? u.start_w[tid] : u.accept_w[tid]) > WFL_NEG_INF ? 1.0 : 0.0;  // (boundary weights are 0 / -inf)
@@ -996,8 +1013,48 @@ __device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, cons
         lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
       }
     };
+    auto frames_banded = [&]() {
+      // all coefficients of the chunk first (R <= 16 frames: 2 x 16 doubles + 16 references in registers, the LDS
+      // reads issued back to back), then the frames are register arithmetic only: two DPP moves, a multiply, an fma
+      constexpr int kMaxR = 16;
+      double cs[kMaxR], ca[kMaxR];
+      float rr[kMaxR];
+#pragma unroll
+      for (int i = 0; i < kMaxR; ++i) {
+        const int ii = i < n ? i : 0;
+        const int t = DIR == 0 ? f0 + ii : f0 + n - 1 - ii;
+        const float* row = tile + (size_t)(t - f0) * Kmax;
+        cs[i] = wf_self * (double)row[slot_self];
+        ca[i] = wf_adj * (double)row[slot_adj];
+        rr[i] = rtile[t - f0];
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxR; ++i) {
+        if (i < n) {
+          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+          const int slot_to = DIR == 0 ? t + 1 : t;
+          // the neighbour's value: both halves of the double through a DPP wave shift (lanes without a neighbour: 0)
+          const int lo = __double2loint(p), hi = __double2hiint(p);
+          const int nlo = DIR == 0 ? __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false)
+                                   : __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+          const int nhi = DIR == 0 ? __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false)
+                                   : __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+          const double pn = __hiloint2double(nhi, nlo);
+          p = fma(p, cs[i], pn * ca[i]);
+          cum += ((double)rr[i] + (double)wref) * kLog2e_d;
+          if (tid < Q) out[u.ab_base + (int64_t)slot_to * Q + tid] = p;
+          if (tid == 0) offs[slot_to] = cum;
+        }
+      }
+      // the next chunk (and the renormalisation) reads the vector from LDS
+      double* to = ((DIR == 0 ? f0 + n : f0) & 1) ? L.buf1 : L.buf0;
+      if (tid < Q) to[tid] = p;
+      __syncthreads();
+    };
     // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
-    if (deg_class == 0)
+    if (banded)
+      frames_banded();
+    else if (deg_class == 0)
       frames(std::integral_constant<int, 2>{});
     else if (deg_class == 1)
       frames(std::integral_constant<int, 4>{});
@@ -1060,6 +1117,7 @@ __global__ void __launch_bounds__(MAXT)
     run_chain_prob<0>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
                       offs_a + (int64_t)b * nch1, za, wrefs, nullptr);
   } else {
+    if (threadIdx.x == 0) zb[d.B + b] = 0.0;  // the certificate's verdict: raised by prob_certify_kernel
     run_chain_prob<1>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
                       offs_b + (int64_t)b * nch1, zb, nullptr, nullptr);
   }
@@ -1074,8 +1132,10 @@ __global__ void __launch_bounds__(MAXT)
 __global__ void __launch_bounds__(256)
     prob_certify_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T,
                         const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt) {
-  __shared__ double red[8];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  // grid (B, kCertSplit): every wave takes the checked slots s = wave index, + number of waves, ... on its own
+  // (wave-level reductions only); a wave that finds a violation raises the utterance's verdict (cleared by the beta
+  // sweep of prob_chain_kernel before it started)
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const UttView u = make_view(d, ints, floats, b, T);
   const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
   double* tail_b = reinterpret_cast<double*>(beta + tail);
@@ -1087,30 +1147,23 @@ __global__ void __launch_bounds__(256)
     if (tid == 0) *verdict = 1.0;  // (not swept in the probability domain at all: the log-domain launch takes it)
     return;
   }
+  if (za == -__builtin_inf() && zbv == -__builtin_inf()) return;  // no accepting path: exact in any arithmetic
   const double* pa = reinterpret_cast<const double*>(alpha) + u.ab_base;
   const double* pb = reinterpret_cast<const double*>(beta) + u.ab_base;
   const int Q = u.Q;
-  double worst = 0.0;
-  const bool dead = za == -__builtin_inf() && zbv == -__builtin_inf();  // no accepting path: exact in any arithmetic
-  if (!dead) {
-    worst = fabs(za - zbv);
-    if (!(worst <= 1.0)) worst = 1.0e9;  // NaN / one-sided -inf
-    for (int t = 0; t <= T; t += (t + 8 <= T || t == T) ? 8 : T - t) {
-      double s = 0.0;
-      for (int q = tid; q < Q; q += 256) s = fma(pa[(int64_t)t * Q + q], pb[(int64_t)t * Q + q], s);
+  const int nchk = (T + 7) / 8 + 1;  // slots 0, 8, 16, ... and T
+  const int w0 = blockIdx.y * 4 + (tid >> 6), nw = gridDim.y * 4;
+  bool bad = false;
+  for (int c = w0; c < nchk; c += nw) {
+    const int t = min(c * 8, T);
+    double s = 0.0;
+    for (int q = lane; q < Q; q += 64) s = fma(pa[(int64_t)t * Q + q], pb[(int64_t)t * Q + q], s);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      __syncthreads();
-      if ((tid & 63) == 0) red[tid >> 6] = s;
-      __syncthreads();
-      if (tid == 0) {
-        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
-        const double dev = (tot > 0.0 && tot < 1.0e300) ? fabs(log2(tot) + offs_a[t] + offs_b[t] - za) : 1.0e9;
-        worst = fmax(worst, dev);
-      }
-    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const double dev = (s > 0.0 && s < 1.0e300) ? fabs(log2(s) + offs_a[t] + offs_b[t] - za) : 1.0e9;
+    bad = bad || !(dev <= 1.0e-4);
   }
-  if (tid == 0) *verdict = (worst <= 1.0e-4) ? 0.0 : 1.0;
+  if (bad && lane == 0) *verdict = 1.0;
 }
 
 template <int SR>
@@ -1693,11 +1746,13 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
       };
       if (nt <= 256)
         launch_prob(prob_chain_kernel<256>);
+      else if (nt <= 512)
+        launch_prob(prob_chain_kernel<512>);
       else
         launch_prob(prob_chain_kernel<1024>);
       if (beta)
-        hipLaunchKernelGGL(prob_certify_kernel, dim3((unsigned)d->B), dim3(256), 0, (hipStream_t)stream, *d, ints, floats, T,
-                           alpha, beta, tail, nch1, nt);
+        hipLaunchKernelGGL(prob_certify_kernel, dim3((unsigned)d->B, 8u), dim3(256), 0, (hipStream_t)stream, *d, ints,
+                           floats, T, alpha, beta, tail, nch1, nt);
     }
     // ... then the log-domain sweeps of the rest (and of utterances whose two sweeps disagree: the certificate)
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,

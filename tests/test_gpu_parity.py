@@ -1134,3 +1134,43 @@ def test_lattice_certificate_sends_what_a_double_cannot_hold_to_the_log_domain(c
         lz, gx, _ = OR.lattice_forward_backward(x[b], src, dst, lab, np.zeros(2 * L), [0], [L], L + 1)
         assert float(st.logz[b]) == pytest.approx(lz, rel=1e-5)
         close(dx[b], gx, rtol=2e-3 if b == 0 else 1e-4, atol=2e-3 if b == 0 else 1e-5, msg=f"utterance {b}")
+
+
+def test_ctc_pipelined_step_keeps_its_forward_progress_under_cu_contention():
+    """The gradient workgroups of the pipelined launch wait on flags raised by the chain workgroups of the SAME launch:
+    safe only while the chains get CUs.  In data-parallel training another stream (RCCL all-reduce, the model's
+    backward GEMMs) competes for them -- exactly the 8-GPU situation this box cannot show.  Here a second stream keeps
+    every CU busy with large GEMMs and device-wide copies while 30 steps run: no wave may give up waiting (status
+    word), and every step must reproduce the uncontended result bit for bit (same kernels, same order of operations)."""
+    from gtn_applications_amd import engine as E
+
+    B, T, C, L = 128, 1000, 100, 44
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, C, generator=g).cuda()
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    tg = E.targets_on_device(targets, x.device)
+    scale, _, coef = E.loss_factors(tg, "none")
+    ref_dx = torch.empty_like(x)
+    ws, ref_nll, ref_loss = E.ctc_forward_backward(x, tg, C - 1, coef, None, ref_dx, loss_scale=scale, want_loss=True)
+    torch.cuda.synchronize()
+    assert not E.ctc_pipeline_gave_up(ws, B, T, tg.max_len)
+    ref_nll, ref_loss = ref_nll.clone(), ref_loss.clone()
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda")
+    big = torch.empty(256 * 1024 * 1024 // 4, device="cuda")
+    stop = torch.zeros((), device="cuda")
+    with torch.cuda.stream(side):  # ~1 s of all-CU work queued ahead: GEMMs (compute) and fills / copies (bandwidth)
+        for _ in range(60):
+            c = a @ a
+            big.copy_(big.roll(1)[: big.numel()])
+            stop += c[0, 0] * 0
+    for step in range(30):
+        dx = torch.full_like(x, float("nan"))
+        ws, nll, loss = E.ctc_forward_backward(x, tg, C - 1, coef, None, dx, loss_scale=scale, want_loss=True)
+        assert side.query() is False or step > 0, "the competing stream finished before the first step was queued"
+        torch.cuda.current_stream().synchronize()
+        assert not E.ctc_pipeline_gave_up(ws, B, T, tg.max_len), f"step {step}: a gradient wave gave up waiting"
+        assert torch.equal(nll, ref_nll) and torch.equal(loss, ref_loss) and torch.equal(dx, ref_dx), f"step {step}"
+    busy_during = not side.query()
+    torch.cuda.synchronize()
+    assert busy_during, "the competing stream did not outlast the steps: the test did not exercise contention"

@@ -524,3 +524,12 @@ def test_native_batch_builder_equals_per_utterance_graph_algebra(with_transition
 
     f2, o2, l2 = E.flatten_any([torch.tensor([2, 2, 1]), torch.tensor([0])])
     assert f2.tolist() == [2, 2, 1, 0] and o2.tolist() == [0, 3, 4] and l2 == [3, 1]
+
+
+def test_asg_class_limit_is_reported_at_construction():
+    """documented deviation: the dense-transition kernels keep the (N+1) x N matrix on chip"""
+    limit = asg.max_classes()
+    assert 128 <= limit <= 256 and N.lib.wfl_dense_max_classes() == limit
+    assert asg.ASG(limit - 2, 1, True).N == limit
+    with pytest.raises(NotImplementedError, match="dense-transition kernels take at most"):
+        asg.ASG(limit - 1, 1, True)
