@@ -307,7 +307,7 @@ def pmc_traffic(key, phase):
     if key is None or not os.path.exists(path):
         return None
     with open(path) as f:
-        rec = json.load(f).get(key, {}).get("kernels", {})
+        rec = json.load(f).get("configs", {}).get(key, {}).get("kernels", {})
     tot = [rec[n]["hbm_bytes"] for n in PHASE_KERNEL_NAMES.get(phase, []) if n in rec]
     return float(sum(tot)) if tot else None
 
