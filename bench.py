@@ -319,6 +319,8 @@ def timed_loop(step, steps, warmup, fence, collect_events):
     for i in range(warmup):
         step(i)
     fence()
+    if collect_events:
+        E.prealloc_events(16 * steps)
     E.PHASE_EVENTS = [] if collect_events else None
     t0 = time.perf_counter()
     for i in range(steps):

@@ -337,12 +337,14 @@ __global__ void dense_backtrace_kernel(const float* __restrict__ alpha, const in
 // kk is an integer exponent read off the vector itself that keeps it near 2^30: an exact scaling.  One
 // workgroup per (utterance, direction), five waves.  Waves 0-3 (one per SIMD) run the matrix-vector product: a
 // wave covers 32 states, and each state's dot product is split over TWO lanes (lane l and l ^ 16 take the two
-// halves of the vector), so a lane keeps HALF a row (alpha) / column (beta) of P in registers, issues CP/4
-// v_pk_fma_f32 per frame and the halves meet in one cross-lane add -- all four SIMDs issue FMAs and the dependent
-// work per frame is a quarter of the two-wave layout this replaces (measured there: ~1050 cycles per frame, 370 of
-// them broadcast LDS reads, the FMAs on two SIMDs only).  The frame vector is broadcast through LDS (ds_read_b128,
-// the two halves 16 bytes apart in bank space), one barrier per frame; wave 4 runs ahead, turning emission rows
-// into e_t / mx2_t in an LDS ring.
+// halves of the vector), so a lane keeps HALF a row (alpha) / column (beta) of P in registers and the halves meet
+// in one cross-lane add.  The frame vector reaches the multipliers through DPP, not through LDS: every row of 16
+// lanes holds 16 consecutive elements of its half of the vector per register (NCH <= 4 registers, filled by ONE
+// ds_read_b128 per lane and frame from a transposed copy), and element k is broadcast inside the row by the
+// multiply-add itself (v_fmac_f32_dpp row_newbcast:k).  Delivering every v[j] to every lane through LDS costs
+// 128 x 128 x 4 B = 64 KiB of LDS return traffic per frame, ~512 cycles at 128 B/clk whatever the lane layout
+// (measured: ~1050 cycles per frame for both the two-wave and the four-wave ds_read_b128 variants); the DPP form
+// moves 4 KiB.  One barrier per frame; wave 4 runs ahead, turning emission rows into e_t / mx2_t in an LDS ring.
 // Range check: every stored a~ / b~ must stay >= 2^-95 (and finite) and every finite transition
 // within 2^-60 of its row maximum; otherwise the utterance is flagged and the log-domain kernels
 // recompute it (flag[b][dir]).
@@ -380,8 +382,9 @@ static size_t dense_ws_bytes(int B, int T) {
 constexpr int kDenseChainWaves = 4, kDenseThreads = (kDenseChainWaves + 1) * 64;
 template <int CP>
 struct FastLds {
-  static constexpr int H = (CP / 2 + 3) / 4 * 4;  // states per half of the vector (a multiple of 4: float4 reads)
-  float vec[2][2][H + 4];  // frame vector (ping-pong) in two halves, the second one 16 B off in bank space
+  static constexpr int NCH = (CP / 2 + 15) / 16;  // 16-element chunks per half of the vector
+  static constexpr int H = 16 * NCH;               // states per half (padded)
+  float vecT[2][2][16][4];  // frame vector (ping-pong): [half][position in chunk][chunk]: a lane's NCH elements contiguous
   float eh[4][CP];         // ring of e_t rows staged by the helper wave
   float wr2[CP];
   float st2[CP];           // start weights W[0, :] in log2 units
@@ -415,12 +418,14 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
 
   // ---- chain waves: lane (wave, hh, qq, il) works on state q = 32 wave + 16 hh + il and on the half qq of the
   // vector: its half of the state's row (alpha) / column (beta) of P
-  constexpr int H = FastLds<CP>::H;
+  constexpr int H = FastLds<CP>::H, NCH = FastLds<CP>::NCH;
   const int qq = (lane >> 4) & 1;                         // which half of the vector this lane multiplies
-  const int q = 32 * wave + 16 * (lane >> 5) + (lane & 15);  // state of a chain lane
+  const int il = lane & 15;
+  const int q = 32 * wave + 16 * (lane >> 5) + il;        // state of a chain lane
   const bool owner = qq == 0;                              // the lane that finishes the state
-  f32x2 P[H / 2];  // pairs: the matrix-vector product issues v_pk_fma_f32
+  float P[H];
   int hard = 0;
+  for (int i = tid; i < 2 * 2 * 16 * 4; i += kDenseThreads) (&L.vecT[0][0][0][0])[i] = 0.f;  // (padding stays 0)
   if (wave < kDenseChainWaves) {
 #pragma unroll
     for (int k = 0; k < H; ++k) {
@@ -432,7 +437,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
         hard |= !(d >= -kHardGap);  // -inf, NaN, +inf rows, or a dynamic range the floor check cannot vouch for
         p = __builtin_amdgcn_exp2f(d);
       }
-      P[k >> 1][k & 1] = p;
+      P[k] = p;
     }
   }
   if (__syncthreads_or(hard)) {
@@ -444,7 +449,11 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   // item r is the emission row the chain multiplies in at step r: frame r (alpha), frame T - r (beta)
   const bool has1 = lane + 64 < CP;
   const float add0 = L.wr2[lane < CP ? lane : 0], add1 = L.wr2[has1 ? lane + 64 : 0];
-  float raw[4][2];
+  // Emission rows travel HBM -> registers kDepth items ahead of their use.  (The first version kept 4 in flight: with
+  // ~1.7 us of load latency under load that alone pinned the sweep at latency / 4 = ~1000 cycles per frame, whatever
+  // the matrix-vector product cost -- measured with three different product layouts.)
+  constexpr int kDepth = 16;
+  float raw[kDepth][2];
   double mrun = 0.0;
   auto item_ok = [&](int r) { return DIR == 0 ? r < T : (r >= 1 && r < T); };
   auto issue = [&](int r, float (&dst)[2]) {
@@ -474,13 +483,29 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
       if (DIR == 0) ws.mx2[(int64_t)b * T + r] = m;
     }
   };
-  auto issue_fast = [&](int r, float (&dst)[2]) {  // the item exists
-    const float* row = xb + (int64_t)(DIR == 0 ? r : T - r) * C;
+  auto issue_fast = [&](int r, float (&dst)[2]) {  // straight-line: the row index is clamped, items past the end are unused
+    const int rr = DIR == 0 ? min(r, T - 1) : max(T - r, 0);
+    const float* row = xb + (int64_t)rr * C;
     dst[0] = row[lane < C ? lane : 0];
     dst[1] = row[lane + 64 < C ? lane + 64 : 0];
   };
+  // straight-line staging of item r >= 2 (no early return: later items' loads stay in flight across this one's
+  // use); items past the end only skip their bookkeeping
+  auto stage_fast = [&](int r, const float (&src)[2]) {
+    const bool ok = r < T;
+    const float s0 = lane < C ? fmaf(nan_to_neg(src[0]), kLog2e, add0) : WFL_NEG_INF;
+    const float s1 = lane + 64 < C ? fmaf(nan_to_neg(src[1]), kLog2e, add1) : WFL_NEG_INF;
+    const float m = wave_all_max(vmax(s0, s1));
+    float* dst = L.eh[r & 3];
+    if (lane < CP) dst[lane] = lane < C ? __builtin_amdgcn_exp2f(s0 - m) : 0.f;
+    if (has1) dst[lane + 64] = lane + 64 < C ? __builtin_amdgcn_exp2f(s1 - m) : 0.f;
+    mrun += ok ? (double)m : 0.0;
+    if (lane == 0 && ok) {
+      Mb[DIR == 0 ? r : T - 1 - r] = mrun;
+      if (DIR == 0) ws.mx2[(int64_t)b * T + r] = m;
+    }
+  };
   const std::true_type kChecked;
-  const std::false_type kUnchecked;
 
   // ---- chain wave state
   // The scale of step n is 2^-kk with kk the exponent of the largest of the first four elements of the
@@ -494,20 +519,37 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   auto scale_exp = [&](const float4& v) {
     return __builtin_amdgcn_frexp_expf(vmax(vmax(v.x, v.y), vmax(v.z, v.w))) - kNormExp;
   };
-  // where state i sits in the two-halves layout of the frame vector
-  auto vslot = [&](int cur, int i) -> float& { return L.vec[cur][i >= H ? 1 : 0][i >= H ? i - H : i]; };
+  // where state i sits in the transposed two-halves layout of the frame vector
+  auto vslot = [&](int cur, int i) -> float& {
+    const int half = i >= H ? 1 : 0, pos = i - half * H;
+    return L.vecT[cur][half][pos & 15][pos >> 4];
+  };
+  // the scale reference: four fixed elements of the vector (v[0], v[16], v[32], v[48]: one aligned 16-B read)
+  auto scale_ref = [&](int cur) { return *reinterpret_cast<const float4*>(L.vecT[cur][0][0]); };
   auto chain_step = [&](int n, int cur) {  // n >= 1, cur = (n - 1) & 1
     const float e = L.eh[(DIR == 0 ? n : n + 1) & 3][q < CP ? q : 0];  // beta at n = T-1: a stale row, unused
-    const float4* v4 = reinterpret_cast<const float4*>(L.vec[cur][qq]);
-    const float inv = __builtin_amdgcn_ldexpf(1.f, -scale_exp(*reinterpret_cast<const float4*>(L.vec[cur][0])));
-    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < H / 4; ++j) {
-      const float4 v = v4[j];
-      a0 = __builtin_elementwise_fma(P[2 * j], f32x2{v.x, v.y}, a0);
-      a1 = __builtin_elementwise_fma(P[2 * j + 1], f32x2{v.z, v.w}, a1);
-    }
-    float part = (a0[0] + a0[1]) + (a1[0] + a1[1]);
+    const float4 vc4 = *reinterpret_cast<const float4*>(L.vecT[cur][qq][il]);  // this row's chunks of its half
+    const float inv = __builtin_amdgcn_ldexpf(1.f, -scale_exp(scale_ref(cur)));
+    const float vc[4] = {vc4.x, vc4.y, vc4.z, vc4.w};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // element k of the row's chunk, broadcast to the row's 16 lanes by the multiply-add's DPP source
+#define WFL_BC(c, k)                                                                             \
+  asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf"          \
+               : "+v"(acc[(k) & 3])                                                                  \
+               : "v"(vc[c]), "v"(P[16 * (c) + (k)]));
+#define WFL_BC16(c)                                                                                           \
+  WFL_BC(c, 0) WFL_BC(c, 1) WFL_BC(c, 2) WFL_BC(c, 3) WFL_BC(c, 4) WFL_BC(c, 5) WFL_BC(c, 6) WFL_BC(c, 7)     \
+  WFL_BC(c, 8) WFL_BC(c, 9) WFL_BC(c, 10) WFL_BC(c, 11) WFL_BC(c, 12) WFL_BC(c, 13) WFL_BC(c, 14) WFL_BC(c, 15)
+    // (the chunk registers may have been moved by a VALU instruction just before: a DPP read of a VGPR needs two wait
+    // states after a VALU write of it, and the hazard recogniser does not look into inline assembly)
+    asm volatile("s_nop 1" ::: "memory");
+    WFL_BC16(0)
+    if (NCH > 1) { WFL_BC16(1) }
+    if (NCH > 2) { WFL_BC16(2) }
+    if (NCH > 3) { WFL_BC16(3) }
+#undef WFL_BC16
+#undef WFL_BC
+    float part = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     part += __shfl_xor(part, 16, 64);  // the other half of the dot product (lane ^ 16: same state)
     const float y = inv * part;
     const float val = DIR == 0 ? e * y : y;
@@ -521,25 +563,24 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   // helper side of the same bookkeeping: E_t = sum of the exponents applied up to step n
   int ecum = 0;
   auto helper_scale = [&](int n) {
-    ecum += scale_exp(*reinterpret_cast<const float4*>(L.vec[(n - 1) & 1][0]));
+    ecum += scale_exp(scale_ref((n - 1) & 1));
     if (lane == 0) Eb[DIR == 0 ? n : T - 1 - n] = ecum;
   };
 
-  // ---- prologue: items 0 and 1 staged synchronously, items 2..5 in flight
+  // ---- prologue: items 0, 1 and 2 staged synchronously, items 3 .. kDepth+2 in flight (item r lives in raw[r % kDepth])
   if (wave == kDenseChainWaves) {
     issue(0, raw[0]);
     issue(1, raw[1]);
+    issue(2, raw[2]);
     stage(0, raw[0], kChecked);
     stage(1, raw[1], kChecked);
-    issue(2, raw[2]);
-    issue(3, raw[3]);
-    issue(4, raw[0]);
-    issue(5, raw[1]);
+    stage(2, raw[2], kChecked);
+#pragma unroll
+    for (int r = 3; r < kDepth + 3; ++r) issue_fast(r, raw[r % kDepth]);
   }
   __syncthreads();
   // ---- intervals: interval n ends with barrier n; the chain performs step n, the helper stages
   // item n + 2 and issues the loads of item n + 6.  Role-specialised loops with the same barrier count.
-  const int n_main = T >= 12 ? 1 + ((T - 10) / 4) * 4 : 1;  // main loop covers n in [1, n_main): items n+6 < T
   if (wave < kDenseChainWaves) {
     {  // interval 0
       float val, next;
@@ -571,34 +612,20 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     }
   } else {
     if (lane == 0) Eb[DIR == 0 ? 0 : T - 1] = 0;
-    stage(2, raw[2], kChecked);
-    issue(6, raw[2]);
-    lds_barrier();
-    int n = 1;
-    for (; n < n_main; n += 4) {  // items n+2 .. n+9 exist
-      helper_scale(n);
-      stage(n + 2, raw[3], kUnchecked);
-      issue_fast(n + 6, raw[3]);
-      lds_barrier();
-      helper_scale(n + 1);
-      stage(n + 3, raw[0], kUnchecked);
-      issue_fast(n + 7, raw[0]);
-      lds_barrier();
-      helper_scale(n + 2);
-      stage(n + 4, raw[1], kUnchecked);
-      issue_fast(n + 8, raw[1]);
-      lds_barrier();
-      helper_scale(n + 3);
-      stage(n + 5, raw[2], kUnchecked);
-      issue_fast(n + 9, raw[2]);
-      lds_barrier();
-    }
-    for (; n < T; ++n) {  // tail: synchronous, checked
-      helper_scale(n);
-      float tmp[2] = {WFL_NEG_INF, WFL_NEG_INF};
-      issue(n + 2, tmp);
-      stage(n + 2, tmp, kChecked);
-      lds_barrier();
+    lds_barrier();  // interval 0
+    // interval n: the helper stages item n + 2 (loaded kDepth intervals ago) and issues the loads of item
+    // n + 2 + kDepth into the registers it just freed.  Unrolled by kDepth so that the register ring is indexed by
+    // constants; the only branch is the loop exit.
+    for (int n = 1; n < T; n += kDepth) {
+#pragma unroll
+      for (int k = 0; k < kDepth; ++k) {
+        if (n + k < T) {
+          helper_scale(n + k);
+          stage_fast(n + k + 2, raw[(k + 3) % kDepth]);
+          issue_fast(n + k + 2 + kDepth, raw[(k + 3) % kDepth]);
+          lds_barrier();
+        }
+      }
     }
   }
   // ---- epilogue: range verdict; log Z from the last alpha vector

@@ -36,15 +36,16 @@ def require_gpu():
 
 def stream_ptr():
     # raw handle of torch's current stream on the current device (what current_stream().cuda_stream
-    # returns, without building the Stream object: this sits on every launch)
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    # returns, without building the Stream object: this sits on every launch).  Plain ints: ctypes converts them
+    # for c_void_p parameters without a Python-level c_void_p object per argument.
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()) or None
 
 
 def ptr(t):
     """device pointer argument: a tensor, a raw address (int) or None"""
     if t is None:
         return None
-    return ctypes.c_void_p(t if type(t) is int else t.data_ptr())
+    return t if type(t) is int else t.data_ptr()
 
 
 def as_device_f32(t, device):
@@ -71,19 +72,30 @@ def flatten_targets(targets):
 PHASE_EVENTS = None
 
 
+_EVENT_POOL = []
+
+
+def prealloc_events(n):
+    """bench.py: create the timing events of a timed region up front (hipEventCreate costs more than the record)"""
+    while len(_EVENT_POOL) < n:
+        _EVENT_POOL.append(torch.cuda.Event(enable_timing=True))
+
+
+def _event():
+    ev = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
 def _mark(name):
     if PHASE_EVENTS is None:
         return None
-    ev = torch.cuda.Event(enable_timing=True)
-    ev.record()
-    return name, ev
+    return name, _event()
 
 
 def _done(tok):
     if tok is not None:
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        PHASE_EVENTS.append((tok[0], tok[1], ev))
+        PHASE_EVENTS.append((tok[0], tok[1], _event()))
 
 
 def flatten_any(targets):
