@@ -581,6 +581,11 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   __syncthreads();
   // ---- intervals: interval n ends with barrier n; the chain performs step n, the helper stages
   // item n + 2 and issues the loads of item n + 6.  Role-specialised loops with the same barrier count.
+  // five waves on four SIMDs: the helper shares one with a chain wave and must not take its issue slots
+  if (wave < kDenseChainWaves)
+    __builtin_amdgcn_s_setprio(3);
+  else
+    __builtin_amdgcn_s_setprio(0);
   if (wave < kDenseChainWaves) {
     {  // interval 0
       float val, next;

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -442,7 +443,14 @@ HostPool& host_pool() {
     static bool hooked = false;
     if (!hooked) pthread_atfork(nullptr, nullptr, pool_after_fork_child), hooked = true;
     const unsigned hw = std::thread::hardware_concurrency();
-    g_pool_threads = (int)std::max(1u, std::min(hw ? hw - 1 : 7u, 63u));  // + the calling thread
+    // + the calling thread.  Not one per core: waking a sleeping thread costs microseconds and the jobs are ~0.1 ms
+    // each -- measured on the 256-core host (scratch/pool_sweep.py): 24..48 threads are the sweet spot for a batch
+    // of 64 utterances (0.6 ms against 4.7 ms serial), 64 and 128 are slower
+    g_pool_threads = (int)std::max(1u, std::min(hw ? hw - 1 : 7u, 31u));
+    if (const char* e = getenv("WFL_HOST_THREADS")) {  // total threads incl. the caller (tuning / tests)
+      const int n = atoi(e);
+      if (n >= 1) g_pool_threads = std::min(n - 1, 255);
+    }
     g_pool = new HostPool(g_pool_threads);
   }
   return *g_pool;
@@ -596,6 +604,8 @@ wfl_lattice_host* wfl_transducer_pack_batch(const wfl_graph* tokens, const wfl_g
       }
     return nullptr;
   }
+  // (serial merge: a second pass over the pool costs more in wake-ups than the ~1.8 MB of copies it would spread --
+  // measured on the 256-core host of the MI355X box)
   Builder all;
   all.C = C;
   for (int b = 0; b < B; ++b) all.append(parts[b]);
