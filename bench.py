@@ -54,10 +54,10 @@ PHASE_KERNEL_NAMES = {
     "ctc_chains": ["ctc_log_chain_kernel"],
     "ctc_grad": ["reduce_loss_kernel", "ctc_grad_kernel"],
     "lattice_gather": ["gather_lse_kernel", "gather_kernel"],
-    "lattice_chain": ["chain_kernel"],
+    "lattice_chain": ["prob_chain_kernel", "prob_certify_kernel", "chain_kernel"],
     "lattice_grad": ["grad_kernel"],
     "lattice_gather/shared": ["gather_kernel"],
-    "lattice_chain/shared": ["chain_kernel"],
+    "lattice_chain/shared": ["prob_chain_kernel", "prob_certify_kernel", "chain_kernel"],
     "lattice_grad/shared": ["grad_kernel"],
     "dense_chain": ["dense_fast_chain_kernel", "dense_chain_kernel"],
     "dense_grad": ["dense_fast_grad_kernel", "dense_reduce_kernel"],
