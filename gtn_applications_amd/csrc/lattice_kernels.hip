@@ -915,6 +915,19 @@ __device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, cons
       band_ok = 0;
   }
   const bool banded = NT == 64 && __syncthreads_and(band_ok);
+  // "uniform-label" acceptors: every arc INTO a state carries the same emission column (CTC-like chains, force
+  // alignment, token-level alignment graphs: the label belongs to the destination state).  Then the frame's factor is
+  // applied once per state by its owner -- after the sum (alpha), or before publishing (beta: the owner publishes
+  // f_t[label(d)] * beta_{t+1}[d]) -- instead of once per arc: one LDS read, one conversion and one multiply per
+  // thread and frame where the general form needs kLeanDeg of each.
+  int my_slot = 0, uni_ok = 1;
+  if (tid < Q) {
+    const int i0 = u.in_ptr[tid], i1 = u.in_ptr[tid + 1];
+    if (i0 < i1) my_slot = u.arc_slot[i0];
+    for (int k = i0 + 1; k < i1; ++k) uni_ok &= u.arc_slot[k] == my_slot;
+  }
+  const bool uniform = __syncthreads_and(uni_ok);
+  const bool wave_live = (tid & ~63) < Q;  // (waves without a state only take part in the barriers)
 
   const int t_first = DIR == 0 ? 0 : T;
   double p = 0.0;
@@ -991,27 +1004,75 @@ __device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, cons
         const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
         const double* from = (slot_from & 1) ? L.buf1 : L.buf0;
         double* to = (slot_to & 1) ? L.buf1 : L.buf0;
-        double ps[DEG];
+        if (wave_live) {
+          double ps[DEG];
 #pragma unroll
-        for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
-        if (i + 1 < n) coeffs(i + 1, cn, deg);
-        double acc0 = 0.0, acc1 = 0.0;
+          for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+          if (i + 1 < n) coeffs(i + 1, cn, deg);
+          double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < DEG; k += 2) {
-          acc0 = fma(ps[k], c[k], acc0);
-          acc1 = fma(ps[k + 1], c[k + 1], acc1);
+          for (int k = 0; k < DEG; k += 2) {
+            acc0 = fma(ps[k], c[k], acc0);
+            acc1 = fma(ps[k + 1], c[k + 1], acc1);
+          }
+          p = acc0 + acc1;
+          if (tid < Q) {
+            to[tid] = p;
+            out[u.ab_base + (int64_t)slot_to * Q + tid] = p;
+          }
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) c[k] = cn[k];
         }
-        p = acc0 + acc1;
         cum += ((double)rtile[t - f0] + (double)wref) * kLog2e_d;
-        if (tid < Q) {
-          to[tid] = p;
-          out[u.ab_base + (int64_t)slot_to * Q + tid] = p;
-        }
         if (tid == 0) offs[slot_to] = cum;
-#pragma unroll
-        for (int k = 0; k < DEG; ++k) c[k] = cn[k];
         lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
       }
+    };
+    auto frames_uniform = [&](auto deg) {
+      constexpr int DEG = decltype(deg)::value;
+      if (DIR == 1) {
+        // beta: the LDS vector holds G = f[label(d)] * beta[d] for the frame about to be consumed; at the chunk's
+        // first frame it still holds plain beta (the tile of this chunk was not there when it was written)
+        const int t0 = f0 + n - 1;
+        const double* fromb = ((t0 + 1) & 1) ? L.buf1 : L.buf0;
+        if (tid < Q) {  // (own entry only: no hazard before the write)
+          double* fb = const_cast<double*>(fromb);
+          fb[tid] = fb[tid] * (double)tile[(size_t)(t0 - f0) * Kmax + my_slot];
+        }
+        lds_barrier();
+      }
+      for (int i = 0; i < n; ++i) {
+        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+        const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
+        const double* from = (slot_from & 1) ? L.buf1 : L.buf0;
+        double* to = (slot_to & 1) ? L.buf1 : L.buf0;
+        if (wave_live) {
+          double ps[DEG];
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+          // alpha: this frame's factor of the state; beta: the factor of the NEXT frame to be consumed (t - 1), with
+          // which the owner publishes; past the chunk (the tile is not there yet) plain beta is published
+          const int tf = DIR == 0 ? t : t - 1;
+          const float f = (DIR == 0 || tf >= f0) ? tile[(size_t)(tf - f0) * Kmax + my_slot] : 1.f;
+          double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < DEG; k += 2) {
+            acc0 = fma(ps[k], wf[k], acc0);
+            acc1 = fma(ps[k + 1], wf[k + 1], acc1);
+          }
+          const double sum = acc0 + acc1;
+          p = DIR == 0 ? sum * (double)f : sum;
+          if (tid < Q) {
+            to[tid] = DIR == 0 ? p : p * (double)f;
+            out[u.ab_base + (int64_t)slot_to * Q + tid] = p;
+          }
+        }
+        cum += ((double)rtile[t - f0] + (double)wref) * kLog2e_d;
+        if (tid == 0) offs[slot_to] = cum;
+        lds_barrier();
+      }
+      // (beta: the chunk's last step published plain beta -- no factor past the chunk -- which is what the
+      // renormalisation and the next chunk's first step expect)
     };
     auto frames_banded = [&]() {
       // all coefficients of the chunk first (R <= 16 frames: 2 x 16 doubles + 16 references in registers, the LDS
@@ -1054,6 +1115,12 @@ __device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, cons
     // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
     if (banded)
       frames_banded();
+    else if (uniform && deg_class == 0)
+      frames_uniform(std::integral_constant<int, 2>{});
+    else if (uniform && deg_class == 1)
+      frames_uniform(std::integral_constant<int, 4>{});
+    else if (uniform)
+      frames_uniform(std::integral_constant<int, kLeanDeg>{});
     else if (deg_class == 0)
       frames(std::integral_constant<int, 2>{});
     else if (deg_class == 1)
