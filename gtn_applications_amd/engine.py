@@ -141,26 +141,56 @@ class PackedLattice:
             self.desc = N.LatticeDesc.from_buffer_copy(d)
             ni, nf = int(d.int_words), int(d.float_words)
             ne = 0 if extra is None else int(extra.size)
-            # the blobs go through PINNED host tensors and asynchronous copies: a pageable copy is synchronous, i.e. it
-            # would wait for everything queued on the stream before it -- the previous step's kernels
-            hi = torch.empty(max(ni, 1), dtype=torch.int32, pin_memory=cuda)
-            hf = torch.empty(max(nf + ne, 1), dtype=_F32, pin_memory=cuda)
-            if ni:
-                ctypes.memmove(hi.data_ptr(), N.lib.wfl_lattice_host_ints(host_handle), 4 * ni)
+            off_i = (4 * (nf + ne) + 15) & ~15  # [floats | extra | pad to 16 B | ints]: ONE buffer, one upload
+            nbytes = off_i + 4 * max(ni, 1)
+            if cuda:
+                # through a ring of reusable PINNED buffers and one asynchronous copy: a pageable copy is synchronous
+                # (it would wait for everything queued on the stream before it -- the previous step's kernels), and
+                # a fresh pinned allocation per batch costs a hipHostMalloc
+                ring = _LATTICE_STAGING.get(device.index)
+                if ring is None:
+                    ring = _LATTICE_STAGING[device.index] = _StagingRing(slots=4, nbytes=1 << 22)
+                slot, buf, view = ring.next(nbytes, True)
+            else:
+                buf = torch.empty(nbytes, dtype=torch.uint8)
+                view = buf.numpy()
             if nf:
-                ctypes.memmove(hf.data_ptr(), N.lib.wfl_lattice_host_floats(host_handle), 4 * nf)
-            self.host_ints = hi.numpy()[:ni]
-            self.host_floats = hf.numpy()[:nf]
+                ctypes.memmove(buf.data_ptr(), N.lib.wfl_lattice_host_floats(host_handle), 4 * nf)
             if ne:
-                hf.numpy()[nf:nf + ne] = np.asarray(extra, dtype=np.float32).reshape(-1)
+                view[4 * nf:4 * (nf + ne)].view(np.float32)[:] = np.asarray(extra, dtype=np.float32).reshape(-1)
+            if ni:
+                ctypes.memmove(buf.data_ptr() + off_i, N.lib.wfl_lattice_host_ints(host_handle), 4 * ni)
         finally:
             N.lib.wfl_lattice_host_free(host_handle)
         self.device = device
-        self._host = (hi, hf)  # (keeps the pinned memory alive while the copies are in flight)
-        self.ints = hi.to(device, non_blocking=True) if device is not None else None
-        self.floats = hf.to(device, non_blocking=True) if device is not None else None
-        self.extra = self.floats[nf:nf + ne] if (ne and device is not None) else None
+        self._host = None
+        if cuda:
+            blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            blob.copy_(buf[:nbytes], non_blocking=True)
+            ev = ring.events[slot]
+            if ev is None:
+                ev = ring.events[slot] = torch.cuda.Event()
+            ev.record()
+        elif device is not None:
+            blob = buf.to(device)
+        else:
+            blob = None
+            self._host = (view[:4 * nf].view(np.float32).copy(), view[off_i:off_i + 4 * ni].view(np.int32).copy())
+        self._blob = blob
+        self.floats = blob[:4 * (nf + ne)].view(_F32) if blob is not None else None
+        self.ints = blob[off_i:off_i + 4 * max(ni, 1)].view(torch.int32) if blob is not None else None
+        self.extra = self.floats[nf:nf + ne] if (ne and blob is not None) else None
+        self._n = (ni, nf)
         self._desc_ref = ctypes.byref(self.desc)
+
+    # host copies of the blobs (tests, diagnostics): kept when there is no device, fetched back otherwise
+    @property
+    def host_ints(self):
+        return self._host[1] if self._host is not None else self.ints[:self._n[0]].cpu().numpy()
+
+    @property
+    def host_floats(self):
+        return self._host[0] if self._host is not None else self.floats[:self._n[1]].cpu().numpy()
 
     # -- constructors ---------------------------------------------------------------------------
     @classmethod
@@ -439,6 +469,7 @@ class _StagingRing:
 
 
 _STAGING = {}
+_LATTICE_STAGING = {}
 _FACTORS = ("scale_none", "scale_mean", "cpos_none", "cpos_mean", "cneg_none", "cneg_mean")
 
 
