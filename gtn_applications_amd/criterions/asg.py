@@ -109,29 +109,37 @@ class ASGLossFunction(torch.autograd.Function):
         pack = tg.cache.get(("asg_fal", C))
         if pack is None:
             pack = tg.cache[("asg_fal", C)] = E.PackedLattice.asg_force_align(tg.flat, tg.offsets, C, dev)
-        need_grad = inputs.requires_grad or transitions.requires_grad
+        need_dx, need_dw = inputs.requires_grad, transitions.requires_grad
+        need_grad = need_dx or need_dw
         # numerator (force-aligned lattice) and denominator (fully connected) sweeps are independent and
-        # both latency-bound: fork the numerator onto a second stream so that they overlap
+        # both latency-bound: fork the numerator onto a second stream so that they overlap.  The numerator is
+        # the shorter of the two, so its gradient (for grad_output = 1) is computed right behind its sweeps, still
+        # under the denominator's; backward adds it, scaled by grad_output, inside the denominator's gradient kernel.
+        dx_num = dw_num = None
         with E.side_stream(dev) as fork:
             fal = E.lattice_forward(x, pack, weights=W, need_beta=need_grad)
+            if need_grad:
+                dx_num = torch.empty_like(x) if need_dx else None
+                dw_num = torch.zeros_like(W) if need_dw else None
+                E.lattice_grad(fal, cneg, coef_w=cneg, gout=None, dx=dx_num, accumulate=False, dW=dw_num)
         fcc = E.dense_forward(x, W, need_beta=need_grad)
-        fork.join(fal.xg, fal.alpha, fal.beta, fal.logz)
+        fork.join(fal.xg, fal.alpha, fal.beta, fal.logz, dx_num, dw_num)
         loss = E.reduce_loss(fcc.logz, scale, 1.0)
         loss = E.reduce_loss(fal.logz, scale, -1.0, out=loss)
-        ctx.aux = (x, W, fcc, fal, cpos, cneg)
+        ctx.aux = (x, W, fcc, cpos, dx_num, dw_num)
         ctx.devices = (inputs.device, transitions.device)
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
     def backward(ctx, grad_output):
-        x, W, fcc, fal, cpos, cneg = ctx.aux
+        x, W, fcc, cpos, dx_num, dw_num = ctx.aux
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dW = torch.zeros_like(W) if ctx.needs_input_grad[1] else None
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] and dx_num is not None else None
+        dW = dw_num * gout if ctx.needs_input_grad[1] and dw_num is not None else None
         if dx is not None or dW is not None:
-            # + posteriors of the fully connected graph, - posteriors of the force-aligned one
-            E.dense_grad(x, W, fcc, cpos, coef_w=cpos, gout=gout, dx=dx, accumulate=False, dW=dW)
-            E.lattice_grad(fal, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=True, dW=dW)
+            # + posteriors of the fully connected graph, - posteriors of the force-aligned one (asg.py:158-168)
+            E.dense_grad(x, W, fcc, cpos, coef_w=cpos, gout=gout, dx=dx, accumulate=False, dW=dW,
+                         addend=dx_num if dx is not None else None)
         if dx is not None and ctx.devices[0].type != "cuda":
             dx = dx.to(ctx.devices[0])
         if dW is not None and ctx.devices[1].type != "cuda":

@@ -204,8 +204,8 @@ __global__ void __launch_bounds__(256)
     dense_grad_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C,
                       const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
                       const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
-                      int accumulate, float* __restrict__ dx, float* __restrict__ partial, int rows_per_block,
-                      const int32_t* __restrict__ only_flagged) {
+                      int accumulate, const float* __restrict__ addend, float* __restrict__ dx,
+                      float* __restrict__ partial, int rows_per_block, const int32_t* __restrict__ only_flagged) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ap = (float*)smem;  // [C] alpha_{t-1}
   float* xb = ap + C;        // [C] x_t + beta_t - logZ
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256)
       if (dx && first_pass) {
         const float post = dead ? 0.f : fast_exp(a + be - z);
         const int64_t o = base + (int64_t)t * C + i;
-        dx[o] = (accumulate ? dx[o] : 0.f) + cf * (post == post ? post : 0.f);
+        dx[o] = (accumulate ? dx[o] : 0.f) + (addend ? g0 * addend[o] : 0.f) + cf * (post == post ? post : 0.f);
       }
       if (partial) {
         ap[i] = t > 0 ? alpha[base + (int64_t)(t - 1) * C + i] : WFL_NEG_INF;
@@ -668,19 +668,25 @@ __global__ void __launch_bounds__(kDenseThreads)
 // gradient of the fast sweeps.  Emission gradient: dx[t,i] = cf * a~_t[i] b~_t[i] 2^(La_t + Lb_t - z2).
 // Transition gradient: dW[1+i][j] = P[i][j] * sum_t a~_{t-1}[j] * (e_t[i] b~_t[i]) * 2^(La_{t-1} + mx2_t
 // + Lb_t - z2): an outer-product accumulation over frames, 8x8 register tile per thread, operands
-// staged in LDS eight frames at a time; the power of two is split evenly over both operands so
+// staged in LDS TS frames at a time; the power of two is split evenly over both operands so
 // that neither leaves the fp32 range.  Per-workgroup partial sums, reduced by dense_reduce_kernel.
-template <int CP>
+//
+// The kernel is a stream over three [T, C] arrays with ~300 cycles of FMAs per frame, and only two or three
+// workgroups fit the grid on a CU: unpipelined, every stage paid a full HBM round trip with nothing else to run
+// (214 us at B=128, T=1000, C=100 against 40 us of traffic and 31 us of FMAs).  The loads of stage s+1 (and the
+// per-frame scale words) are therefore issued into registers BEFORE the FMAs of stage s and consumed after them.
+template <int CP, int TS>
 __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
     dense_fast_grad_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, int B,
                            const float* __restrict__ alpha, const float* __restrict__ beta, const void* wsp,
                            const float* __restrict__ coef, const float* __restrict__ coef_w,
-                           const float* __restrict__ gout, int accumulate, float* __restrict__ dx,
-                           float* __restrict__ partial, int rows_per_block) {
-  constexpr int G = CP / 8, NT = (G * G + 63) / 64 * 64, TS = 8;
+                           const float* __restrict__ gout, int accumulate, const float* __restrict__ addend,
+                           float* __restrict__ dx, float* __restrict__ partial, int rows_per_block) {
+  constexpr int G = CP / 8, NT = (G * G + 63) / 64 * 64, NI = (TS * CP + NT - 1) / NT;
+  static_assert(TS <= 64, "the scale words of a stage are computed by the first wave");
   __shared__ __attribute__((aligned(16))) float A[TS][CP];
   __shared__ __attribute__((aligned(16))) float U[TS][CP];
-  __shared__ float sc[TS][4];
+  __shared__ float sc[2][TS][4];
   __shared__ float wr2[CP], s0[CP];
   const int b = blockIdx.y, tid = threadIdx.x;
   const DenseWs ws = dense_ws_carve(const_cast<void*>(wsp), B, T);
@@ -691,46 +697,91 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
   const double z2 = ws.z2[b];
   const double *Ma = ws.M + (int64_t)b * 2 * T, *Mb = Ma + T;
   const int32_t *Ea = ws.E + (int64_t)b * 2 * T, *Eb = Ea + T;
+  const float* mx2 = ws.mx2 + (int64_t)b * T;
   const int t_begin = blockIdx.x * rows_per_block, t_end = min(T, t_begin + rows_per_block);
   const int64_t base = (int64_t)b * T * C;
   for (int i = tid; i < CP; i += NT) wr2[i] = i < C ? ws.wr2[i] : 0.f, s0[i] = 0.f;
   const int ti = tid / G, tj = tid - ti * G;
   const bool active = tid < G * G && partial;
+  // the (row, column) of this thread's NI staged elements never change: only the stage's first frame does
+  int er[NI], ei[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int idx = tid + k * NT;
+    er[k] = idx / CP, ei[k] = idx - er[k] * CP;
+    if (idx >= TS * CP || ei[k] >= C) er[k] = -1;
+  }
+  // registers of the stage in flight.  issue() only LOADS (branch-free, from clamped addresses): any arithmetic on
+  // a loaded value here would put its s_waitcnt in front of the FMAs the loads are meant to fly under.
+  float ra[NI], rb[NI], rx[NI], rp[NI], rd[NI], re[NI];
+  double q_ma = 0., q_mb = 0., q_mp = 0.;  // lane r < TS: scale words of frame t0 + r (and of the frame before it)
+  int32_t q_ea = 0, q_eb = 0, q_ep = 0;
+  float q_m2 = 0.f;
+  const float* const prev_dx = (dx && accumulate) ? dx : nullptr;
+  auto issue = [&](int t0) {
+    if (tid < TS) {
+      const int t = min(t0 + tid, T - 1), tp = max(t - 1, 0);
+      q_ma = Ma[t], q_ea = Ea[t], q_mb = Mb[t], q_eb = Eb[t], q_m2 = mx2[t], q_mp = Ma[tp], q_ep = Ea[tp];
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int t = min(t0 + max(er[k], 0), t_end - 1);
+      const int64_t o = base + (int64_t)t * C + (er[k] >= 0 ? ei[k] : 0);
+      ra[k] = alpha[o], rb[k] = beta[o], rx[k] = x[o], rp[k] = alpha[t > 0 ? o - C : o];
+    }
+    if (prev_dx) {
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int t = min(t0 + max(er[k], 0), t_end - 1);
+        rd[k] = prev_dx[base + (int64_t)t * C + (er[k] >= 0 ? ei[k] : 0)];
+      }
+    }
+    if (addend) {
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int t = min(t0 + max(er[k], 0), t_end - 1);
+        re[k] = addend[base + (int64_t)t * C + (er[k] >= 0 ? ei[k] : 0)];
+      }
+    }
+  };
+  auto scales = [&](int t0, int buf) {  // first wave: the stage's per-frame powers of two
+    if (tid < TS) {
+      const int t = t0 + tid;
+      const double lb = q_mb + (double)q_eb;
+      const float eg = (float)(q_ma + (double)q_ea + lb - z2);
+      float ex = WFL_NEG_INF;
+      if (t > 0) ex = (float)(q_mp + (double)q_ep + (double)q_m2 + lb - z2);
+      sc[buf][tid][0] = __builtin_amdgcn_exp2f(0.5f * eg);
+      sc[buf][tid][1] = __builtin_amdgcn_exp2f(0.5f * ex);
+      sc[buf][tid][2] = q_m2;
+    }
+  };
   float acc[8][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-  for (int t0 = t_begin; t0 < t_end; t0 += TS) {
+  issue(t_begin);
+  scales(t_begin, 0);
+  int buf = 0;
+  for (int t0 = t_begin; t0 < t_end; t0 += TS, buf ^= 1) {
     const int nr = min(TS, t_end - t0);
-    __syncthreads();
-    if (tid < nr) {
-      const int t = t0 + tid;
-      const double lb = Mb[t] + (double)Eb[t];
-      const float eg = (float)(Ma[t] + (double)Ea[t] + lb - z2);
-      const float m2 = ws.mx2[(int64_t)b * T + t];
-      float ex = WFL_NEG_INF;
-      if (t > 0) ex = (float)(Ma[t - 1] + (double)Ea[t - 1] + (double)m2 + lb - z2);
-      sc[tid][0] = __builtin_amdgcn_exp2f(0.5f * eg);
-      sc[tid][1] = __builtin_amdgcn_exp2f(0.5f * ex);
-      sc[tid][2] = m2;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < nr * CP; idx += NT) {
-      const int r = idx / CP, i = idx - r * CP;
-      const int t = t0 + r;
+    __syncthreads();  // the previous stage's FMAs are done with A/U; sc[buf] is visible
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      if (er[k] < 0) continue;
+      const int r = er[k], i = ei[k], t = t0 + r;
       float uu = 0.f, aa = 0.f;
-      if (i < C) {
+      if (t < t_end) {
         const int64_t o = base + (int64_t)t * C + i;
-        const float a = alpha[o], be = beta[o];
-        const float hg = sc[r][0], hx = sc[r][1];
-        const float g = (a * hg) * (be * hg);
-        if (dx) dx[o] = (accumulate ? dx[o] : 0.f) + cf * g;
+        const float hg = sc[buf][r][0], hx = sc[buf][r][1];
+        const float g = (ra[k] * hg) * (rb[k] * hg);
+        if (dx) dx[o] = (prev_dx ? rd[k] : 0.f) + (addend ? g0 * re[k] : 0.f) + cf * g;
         if (partial) {
           if (t > 0) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(nan_to_neg(x[o]), kLog2e, wr2[i]) - sc[r][2]);
-            uu = e * be * hx * cw;
-            aa = alpha[o - C] * hx;
+            const float e = __builtin_amdgcn_exp2f(fmaf(nan_to_neg(rx[k]), kLog2e, wr2[i]) - sc[buf][r][2]);
+            uu = e * rb[k] * hx * cw;
+            aa = rp[k] * hx;
           } else {
             s0[i] = g * cw;
           }
@@ -739,6 +790,7 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
       U[r][i] = uu, A[r][i] = aa;
     }
     __syncthreads();
+    if (t0 + TS < t_end) issue(t0 + TS);  // in flight during the FMAs below
     if (active) {
       for (int r = 0; r < nr; ++r) {
         const float4 u0 = *reinterpret_cast<const float4*>(&U[r][8 * ti]);
@@ -753,28 +805,36 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
           for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(u[i], a[j], acc[i][j]);
       }
     }
+    if (t0 + TS < t_end) scales(t0 + TS, buf ^ 1);
   }
   if (partial) {
     __syncthreads();
     float* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(C + 1) * C;
     for (int i = tid; i < C; i += NT) dst[i] = s0[i];
     if (active) {
+      // all 64 transition scores first, from clamped (always valid) addresses: a load inside the bounds test below
+      // would be waited for element by element -- 64 dependent HBM round trips, most of this kernel's time before
+      float wv[8][8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[i][j] = W[(1 + min(8 * ti + i, C - 1)) * C + min(8 * tj + j, C - 1)];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int si = 8 * ti + i;
+        const float wr = wr2[min(si, CP - 1)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int sj = 8 * tj + j;
-          if (si < C && sj < C) {
-            const float p = __builtin_amdgcn_exp2f(W[(1 + si) * C + sj] * kLog2e - wr2[si]);
-            dst[(1 + si) * C + sj] = acc[i][j] * p;
-          }
+          const float p = __builtin_amdgcn_exp2f(fmaf(wv[i][j], kLog2e, -wr));
+          if (si < C && sj < C) dst[(1 + si) * C + sj] = acc[i][j] * p;
         }
       }
     }
   }
 }
 
+constexpr int kGradStage = 8;  // frames per LDS stage of dense_fast_grad_kernel
 static int dense_chunks(int B, int T) { return std::max(1, std::min(T, (512 + B - 1) / B)); }
 
 }  // namespace wfl
@@ -873,7 +933,7 @@ int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws
 
 int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const float* alpha, const float* beta,
                    const float* logz, const float* coef, const float* coef_w, const float* gout, int accumulate,
-                   float* dx, float* dW, float* dW_partial, const void* ws, void* stream) {
+                   const float* addend, float* dx, float* dW, float* dW_partial, const void* ws, void* stream) {
   if (int rc = dense_check(x, W, B, T, C, "dense_grad")) return rc;
   if (!alpha || !beta || !logz || !ws || (!dx && !dW) || (dW && !dW_partial)) {
     set_error("dense_grad: missing buffers");
@@ -889,8 +949,8 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
   const int cp = dense_fast_cp(C);
   const int32_t* flags = cp ? dense_ws_carve(const_cast<void*>(ws), B, T).flag : nullptr;
 #define WFL_FAST_GRAD(CP)                                                                                       \
-  hipLaunchKernelGGL(dense_fast_grad_kernel<CP>, grid, dim3(((CP / 8) * (CP / 8) + 63) / 64 * 64), 0, st, x, W, \
-                     T, C, B, alpha, beta, ws, coef, coef_w, gout, accumulate, dx, part, rows)
+  hipLaunchKernelGGL((dense_fast_grad_kernel<CP, kGradStage>), grid, dim3(((CP / 8) * (CP / 8) + 63) / 64 * 64), 0, st, \
+                     x, W, T, C, B, alpha, beta, ws, coef, coef_w, gout, accumulate, addend, dx, part, rows)
   if (cp == 32)
     WFL_FAST_GRAD(32);
   else if (cp == 64)
@@ -904,7 +964,7 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
   // log-domain gradient for what the fast sweeps did not serve
 #define WFL_DENSE_GRAD(NP)                                                                                 \
   hipLaunchKernelGGL(dense_grad_kernel<NP>, grid, dim3(256), lds, st, x, W, T, C, alpha, beta, logz, coef, \
-                     coef_w, gout, accumulate, dx, part, rows, flags)
+                     coef_w, gout, accumulate, addend, dx, part, rows, flags)
   if (np <= 4)
     WFL_DENSE_GRAD(4);
   else if (np <= 16)

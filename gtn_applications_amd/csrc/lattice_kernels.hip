@@ -821,6 +821,14 @@ __device__ __forceinline__ int64_t xg_main_dev(const wfl_lattice_desc& d, int T)
   return (((int64_t)d.B * T * d.max_labels) + 3) & ~(int64_t)3;
 }
 constexpr double kLog2e_d = 1.4426950408889634074;
+constexpr int kBandDepth = 4;
+// floats of the probability-domain sweeps' row tile: two chunks of the tile path, or the banded sweep's two tiles of
+// 16 rows (+ their references)
+__host__ __device__ inline size_t prob_rows_floats(const wfl_lattice_desc& d, int rows_per_chunk) {
+  const size_t tile = (size_t)2 * rows_per_chunk * d.max_labels;
+  const size_t band = d.max_states <= 64 ? (size_t)2 * 1024 + 2 * 64 : 0;
+  return tile > band ? tile : band;
+}  // chunks of 16 frames the banded sweep loads ahead of the one it works on
 
 struct ProbLds {
   double* buf0;  // [Q]
@@ -863,8 +871,8 @@ __device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {  // NT
   return !__syncthreads_or(bad);
 }
 
-template <int DIR>
-__device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, const ProbLds& L, int T, int R,
+template <int DIR, bool BAND>  // BAND: single-wave workgroups (the register-resident banded sweep is compiled in)
+__device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, const ProbLds& L, int T, int R,
                                const float* __restrict__ fg, const float* __restrict__ rmax,
                                const float* __restrict__ weights, double* __restrict__ out, float* __restrict__ logz,
                                int b, double* __restrict__ offs, double* __restrict__ z64, float* __restrict__ wref_out,
@@ -914,7 +922,7 @@ __device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, cons
     else
       band_ok = 0;
   }
-  const bool banded = NT == 64 && __syncthreads_and(band_ok);
+  const bool banded = BAND && NT == 128 && Q <= 64 && (Kmax & 3) == 0 && Kmax <= 64 && __syncthreads_and(band_ok);
   // "uniform-label" acceptors: every arc INTO a state carries the same emission column (CTC-like chains, force
   // alignment, token-level alignment graphs: the label belongs to the destination state).  Then the frame's factor is
   // applied once per state by its owner -- after the sum (alpha), or before publishing (beta: the owner publishes
@@ -940,13 +948,163 @@ __device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, cons
   }
   if (tid == 0) offs[t_first] = 0.0;
 
-  const int nchunks = (T + R - 1) / R;
+  if constexpr (BAND) if (banded) {
+    // The whole sweep in ONE wave's registers (wave 0), fed by a loader wave (wave 1); the two meet at one LDS-only
+    // barrier per chunk of 16 frames.  A frame is ~100 cycles of dependent arithmetic and an HBM round trip is
+    // 2000-5000, so the rows must be requested several chunks ahead -- and on gfx9 a wave's loads and stores share
+    // one in-order counter (vmcnt), so a wave that both streams its scores out every frame and waits for prefetched
+    // rows ends up waiting for its own stores.  Hence two waves: the chain wave only stores, the loader only loads
+    // (kBandDepth chunks in flight in its registers: the compact rows of a chunk are contiguous, up to four float4
+    // per lane) and hands each chunk over through a double-buffered LDS tile.  The tile path below has one chunk of
+    // lookahead and a barrier per FRAME: 235 us at T = 1000 for the ASG force-alignment lattice; this one 60.
+    constexpr int RB = 16, D = kBandDepth, NV = 4;
+    const int K4 = Kmax >> 2, nch = (T + RB - 1) / RB;
+    constexpr int kSlot = 64 * 4 * NV;     // floats per tile (every loader lane stores its NV float4: no divergence)
+    float* ring = L.rows;                  // [2][kSlot], rows of RB * Kmax <= kSlot floats
+    float* rref = ring + 2 * kSlot;        // [2][64]: per-frame references of the chunk (first RB entries)
+    auto chunk_lo = [&](int c, int n) { return DIR == 0 ? c * RB : T - c * RB - n; };  // lowest frame of chunk c
+    if (tid >= 64) {
+      // ---- loader
+      const int l = tid - 64;
+      const float4* fgu = reinterpret_cast<const float4*>(fg + u.xg_base);  // (Kmax % 4 == 0: checked by `banded`)
+      const float* rmu = rmax + (int64_t)b * T;
+      float gv[D][4 * NV];  // (plain floats: an array of float4 is not promoted to registers)
+      float gr[D];
+      auto load = [&](int c, float (&v_)[4 * NV], float& r_) {
+        const int cc = min(c, nch - 1);  // (past the end: the last chunk again, never handed over)
+        const int n = min(RB, T - cc * RB);
+        const int64_t base4 = (int64_t)chunk_lo(cc, n) * K4;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          const float4 q = fgu[base4 + min(l + 64 * k, n * K4 - 1)];
+          v_[4 * k] = q.x, v_[4 * k + 1] = q.y, v_[4 * k + 2] = q.z, v_[4 * k + 3] = q.w;
+        }
+        r_ = rmu[min(chunk_lo(cc, n) + (l & 15), T - 1)];
+      };
+      auto hand_over = [&](int c, float (&v_)[4 * NV], float& r_) {  // chunk c -> LDS slot c & 1, then refill
+        // (branch-free on purpose: around a divergent branch the compiler waits for ALL outstanding loads)
+        float4* dst = reinterpret_cast<float4*>(ring + (size_t)(c & 1) * kSlot);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) dst[l + 64 * k] = make_float4(v_[4 * k], v_[4 * k + 1], v_[4 * k + 2], v_[4 * k + 3]);
+        rref[(c & 1) * 64 + l] = r_;
+        load(c + D, v_, r_);
+      };
+#pragma unroll
+      for (int j = 0; j < D; ++j) load(j, gv[j], gr[j]);
+      hand_over(0, gv[0], gr[0]);
+      lds_barrier();
+      // while the chain wave works on chunk c, prepare chunk c + 1.  The steady state is straight-line code (D
+      // hand-overs per trip, no test in between): the compiler counts the loads a wait may leave outstanding along
+      // the SHORTEST path, so a skipped hand-over anywhere in the loop would shrink every wait to "all but the last".
+      int c = 0;
+      for (; c + D < nch; c += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          hand_over(c + j + 1, gv[(j + 1) % D], gr[(j + 1) % D]);
+          lds_barrier();
+        }
+      }
+      for (; c < nch; ++c) {  // the last D chunks or fewer
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          if (c + 1 < nch && (c + 1) % D == j) hand_over(c + 1, gv[j], gr[j]);
+        lds_barrier();
+      }
+    } else {
+      // ---- chain
+      const int ss = tid < Q ? slot_self : 0, sa = tid < Q ? slot_adj : 0;
+      bool two_l = ss != sa;
+      const bool two = __any(two_l);
+      lds_barrier();
+      for (int c = 0; c < nch; ++c) {
+        const int n = min(RB, T - c * RB);
+        const float* tile = ring + (size_t)(c & 1) * kSlot;
+        if (c > 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
+          int ex = (tid < Q && p > 0.0) ? __builtin_amdgcn_frexp_exp(p) - 1 : -(1 << 30);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) ex = max(ex, __shfl_xor(ex, o, 64));
+          if (ex > -(1 << 30) && ex < 2000) p = ldexp(p, -ex), cum += (double)ex;
+        }
+        // this lane's factors of the chunk: all LDS reads issued back to back, THEN converted (a test or a use
+        // between two reads makes the compiler wait for each read in turn: 16 LDS round trips per chunk)
+        float fs[RB], fa[RB];
+        const int r0 = DIR == 0 ? 0 : n - 1, dr = DIR == 0 ? Kmax : -Kmax;
+        const float* ts = tile + r0 * Kmax + ss;
+        const float* ta = tile + r0 * Kmax + sa;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) fs[i] = ts[(i < n ? i : 0) * dr];  // (i >= n: row r0 again, not consumed)
+        if (two) {
+#pragma unroll
+          for (int i = 0; i < RB; ++i) fa[i] = ta[(i < n ? i : 0) * dr];
+        } else {
+#pragma unroll
+          for (int i = 0; i < RB; ++i) fa[i] = fs[i];
+        }
+        double cs[RB], ca[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) cs[i] = wf_self * (double)fs[i], ca[i] = wf_adj * (double)fa[i];
+        // offsets of the chunk's frames: inclusive prefix sum of the per-frame log2 factors over lanes 0..15
+        // (lane i: the chunk's i-th frame IN SWEEP ORDER)
+        const float rsel = rref[(c & 1) * 64 + ((DIR == 0 ? (tid & 15) : n - 1 - (tid & 15)) & 15)];
+        double pre = (tid & 15) < n ? ((double)rsel + (double)wref) * kLog2e_d : 0.0;
+#pragma unroll
+        for (int o = 1; o < RB; o <<= 1) {
+          const int lo = __double2loint(pre), hi = __double2hiint(pre);  // row_shr:o, lanes without a source read 0
+          const int slo = o == 1   ? __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true)
+                          : o == 2 ? __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true)
+                          : o == 4 ? __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true)
+                                   : __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true);
+          const int shi = o == 1   ? __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true)
+                          : o == 2 ? __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true)
+                          : o == 4 ? __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true)
+                                   : __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true);
+          pre += __hiloint2double(shi, slo);
+        }
+        // lane i: the offset after the chunk's i-th frame -- the chunk's offsets in one store
+        if (tid < n) offs[DIR == 0 ? c * RB + tid + 1 : T - 1 - (c * RB + tid)] = cum + pre;
+        cum += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pre), 15),
+                                __builtin_amdgcn_readlane(__double2loint(pre), 15));  // (lanes >= n added 0)
+        // The frames: two DPP moves, a multiply, an fma and a store each -- a single wave issues one instruction every
+        // ~5 cycles, so the instruction count IS the frame time.  Lanes without a state sit the loop out (a DPP read
+        // from a disabled lane returns 0, which is what their probability is), the row pointer is wave-uniform
+        // (scalar adds), and full chunks run without the per-frame bound test.
+        double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? c * RB + 1 : T - 1 - c * RB) * Q;
+        auto frames16 = [&](auto full) {
+          constexpr bool FULL = decltype(full)::value;
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            if (FULL || i < n) {
+              // the neighbour's value: both halves of the double through a DPP wave shift (lanes without one: 0)
+              const int lo = __double2loint(p), hi = __double2hiint(p);
+              const int nlo = DIR == 0 ? __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false)
+                                       : __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+              const int nhi = DIR == 0 ? __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false)
+                                       : __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+              const double pn = __hiloint2double(nhi, nlo);
+              p = fma(p, cs[i], pn * ca[i]);
+              orow[tid] = p;
+              orow = DIR == 0 ? orow + Q : orow - Q;
+            }
+          }
+        };
+        if (tid < Q) {
+          if (n == RB)
+            frames16(std::true_type{});
+          else
+            frames16(std::false_type{});
+        }
+        lds_barrier();
+      }
+    }
+    __syncthreads();
+  }
+  const int nchunks = banded ? 0 : (T + R - 1) / R;
   auto chunk_frames = [&](int c, int& f0, int& n) {
     const int s0 = c * R;
     n = min(R, T - s0);
     f0 = DIR == 0 ? s0 : T - s0 - n;
   };
-  if (T > 0) {
+  if (T > 0 && !banded) {
     int f0, n;
     chunk_frames(0, f0, n);
     const float* src = fg + u.xg_base + (int64_t)f0 * Kmax;
@@ -1074,48 +1232,8 @@ __device__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, cons
       // (beta: the chunk's last step published plain beta -- no factor past the chunk -- which is what the
       // renormalisation and the next chunk's first step expect)
     };
-    auto frames_banded = [&]() {
-      // all coefficients of the chunk first (R <= 16 frames: 2 x 16 doubles + 16 references in registers, the LDS
-      // reads issued back to back), then the frames are register arithmetic only: two DPP moves, a multiply, an fma
-      constexpr int kMaxR = 16;
-      double cs[kMaxR], ca[kMaxR];
-      float rr[kMaxR];
-#pragma unroll
-      for (int i = 0; i < kMaxR; ++i) {
-        const int ii = i < n ? i : 0;
-        const int t = DIR == 0 ? f0 + ii : f0 + n - 1 - ii;
-        const float* row = tile + (size_t)(t - f0) * Kmax;
-        cs[i] = wf_self * (double)row[slot_self];
-        ca[i] = wf_adj * (double)row[slot_adj];
-        rr[i] = rtile[t - f0];
-      }
-#pragma unroll
-      for (int i = 0; i < kMaxR; ++i) {
-        if (i < n) {
-          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-          const int slot_to = DIR == 0 ? t + 1 : t;
-          // the neighbour's value: both halves of the double through a DPP wave shift (lanes without a neighbour: 0)
-          const int lo = __double2loint(p), hi = __double2hiint(p);
-          const int nlo = DIR == 0 ? __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false)
-                                   : __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
-          const int nhi = DIR == 0 ? __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false)
-                                   : __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
-          const double pn = __hiloint2double(nhi, nlo);
-          p = fma(p, cs[i], pn * ca[i]);
-          cum += ((double)rr[i] + (double)wref) * kLog2e_d;
-          if (tid < Q) out[u.ab_base + (int64_t)slot_to * Q + tid] = p;
-          if (tid == 0) offs[slot_to] = cum;
-        }
-      }
-      // the next chunk (and the renormalisation) reads the vector from LDS
-      double* to = ((DIR == 0 ? f0 + n : f0) & 1) ? L.buf1 : L.buf0;
-      if (tid < Q) to[tid] = p;
-      __syncthreads();
-    };
     // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
-    if (banded)
-      frames_banded();
-    else if (uniform && deg_class == 0)
+    if (uniform && deg_class == 0)
       frames_uniform(std::integral_constant<int, 2>{});
     else if (uniform && deg_class == 1)
       frames_uniform(std::integral_constant<int, 4>{});
@@ -1175,17 +1293,17 @@ __global__ void __launch_bounds__(MAXT)
   P.buf0 = (double*)p, p += (size_t)d.max_states * 8;
   P.buf1 = (double*)p, p += (size_t)d.max_states * 8;
   P.red = (float*)p, p += 64 * 4;
-  P.rows = (float*)p, p += (size_t)2 * rows_per_chunk * d.max_labels * 4;
+  P.rows = (float*)p, p += prob_rows_floats(d, rows_per_chunk) * 4;
   P.refs = (float*)p;
   const float* fg = xg + xg_main_dev(d, T);
   const float* rmax = fg + xg_main_dev(d, T);
   if (dir == 0) {
     if (threadIdx.x == 0) fmt[b] = kFmtProb;
-    run_chain_prob<0>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
+    run_chain_prob<0, MAXT == 128>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
                       offs_a + (int64_t)b * nch1, za, wrefs, nullptr);
   } else {
     if (threadIdx.x == 0) zb[d.B + b] = 0.0;  // the certificate's verdict: raised by prob_certify_kernel
-    run_chain_prob<1>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
+    run_chain_prob<1, MAXT == 128>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
                       offs_b + (int64_t)b * nch1, zb, nullptr, nullptr);
   }
 }
@@ -1282,7 +1400,7 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
 }
 
 static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
-  const size_t prob = (size_t)d.max_states * 16 + 64 * 4 + (size_t)2 * rows_per_chunk * d.max_labels * 4 +
+  const size_t prob = (size_t)d.max_states * 16 + 64 * 4 + prob_rows_floats(d, rows_per_chunk) * 4 +
                       (size_t)2 * rows_per_chunk * 4 + 64;
   return std::max(prob, (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 8 +
          (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 +
@@ -1708,7 +1826,7 @@ static int64_t xg_main(const wfl_lattice_desc& d, int T) { return (((int64_t)d.B
 // interval, so the gradient kernel needs the same number).
 static void chain_config(const wfl_lattice_desc& d, int& nt, int& rpc) {
   // one state per thread up to 1024 states (the lean frame paths need it); beyond that threads loop
-  nt = d.max_states <= 64 ? 64 : d.max_states <= 128 ? 128 : d.max_states <= 256 ? 256 : d.max_states <= 512 ? 512 : 1024;
+  nt = d.max_states <= 128 ? 128 : d.max_states <= 256 ? 256 : d.max_states <= 512 ? 512 : 1024;
   while (nt < 256 && nt * kPre < 2 * d.max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
   rpc = std::max(2, std::min(16, nt * kPre / std::max(1, d.max_labels)) & ~1);  // even (run_chain)
 }
@@ -1807,11 +1925,13 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
       // probability-domain sweeps of every utterance whose acceptor allows it ...
       auto launch_prob = [&](auto kern) {
         if (lds > 48 * 1024)
-          hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
                            beta, logz, tail, nch1);
       };
-      if (nt <= 256)
+      if (nt == 128 && d->max_states <= 64)
+        launch_prob(prob_chain_kernel<128>);  // chain wave + loader wave (the banded sweep)
+      else if (nt <= 256)
         launch_prob(prob_chain_kernel<256>);
       else if (nt <= 512)
         launch_prob(prob_chain_kernel<512>);

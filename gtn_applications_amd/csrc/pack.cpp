@@ -31,6 +31,10 @@ struct Arc {
   float w;
 };
 
+// Row stride of the per-utterance compact emission rows (wfl_lattice_desc::max_labels): the widest label set of the
+// batch, rounded up to a multiple of four so that every row starts 16-byte aligned (the sweeps load them as float4).
+inline int pad_labels(int k) { return (std::max(1, k) + 3) & ~3; }
+
 struct Builder {
   int C = 0;
   // per-field accumulators
@@ -220,7 +224,7 @@ struct Builder {
     memset(&d, 0, sizeof(d));
     d.B = B, d.shared = shared;
     d.max_states = max_states, d.max_arcs = max_arcs, d.max_eps = max_eps;
-    d.max_labels = std::max(1, max_labels), d.max_levels = max_levels;
+    d.max_labels = pad_labels(max_labels), d.max_levels = max_levels;
     d.total_states = state_off.back(), d.total_arcs = arc_off.back(), d.total_eps = eps_off.back();
     d.total_labels = (int64_t)labels.size();
     {  // one allocation for each blob (every array is padded to a multiple of 4 elements)
@@ -544,7 +548,7 @@ wfl_lattice_host* merge_direct(std::vector<Builder>& parts, int np, int B, int C
   memset(&d, 0, sizeof(d));
   d.B = B, d.shared = 0;
   d.max_states = tab.max_states, d.max_arcs = tab.max_arcs, d.max_eps = tab.max_eps;
-  d.max_labels = std::max(1, tab.max_labels), d.max_levels = tab.max_levels;
+  d.max_labels = pad_labels(tab.max_labels), d.max_levels = tab.max_levels;
   d.total_states = tab.state_off.back(), d.total_arcs = tab.arc_off.back(), d.total_eps = tab.eps_off.back();
   d.total_labels = n_labels;
   auto pad4 = [](int64_t n) { return (n + 3) & ~(int64_t)3; };

@@ -423,15 +423,16 @@ def dense_flagged(st):
     return st.ws[off:off + 8 * B].view(torch.int32).view(B, 2).ne(0).any(dim=1)
 
 
-def dense_grad(x, W, st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None):
+def dense_grad(x, W, st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None, addend=None):
+    """`addend`: [B,T,C] term added to dx scaled by gout (a gradient computed before gout was known)."""
     part = None
     if dW is not None:
         part = torch.empty(_dense_sizes(st.B, st.T, st.C)[0], dtype=_F32, device=x.device)
     tok = _mark("dense_grad")
     N.check(
         N.lib.wfl_dense_grad(ptr(x), ptr(W), st.B, st.T, st.C, ptr(st.alpha), ptr(st.beta), ptr(st.logz), ptr(coef),
-                             ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(dx), ptr(dW), ptr(part), ptr(st.ws),
-                             stream_ptr())
+                             ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(addend), ptr(dx), ptr(dW), ptr(part),
+                             ptr(st.ws), stream_ptr())
     )
     _done(tok)
 

@@ -236,11 +236,14 @@ int wfl_dense_max_classes(void);
  * sweep; ws records which), max-plus scores in the tropical semiring (ws may be NULL there). */
 int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int semiring,
                       float* alpha, float* beta, int32_t* bptr, float* logz, void* ws, void* stream);
-/* dx[b,t,i] (+)= coef[b]*gout*post_t(i);  dW += sum_b coef_w[b]*gout*transition posteriors. */
+/* dx[b,t,i] = (accumulate ? dx : 0) + gout*addend[b,t,i] + coef[b]*gout*post_t(i);
+ * dW += sum_b coef_w[b]*gout*transition posteriors.  `addend` (may be NULL): a [B,T,C] term computed for gout = 1
+ * before gout was known -- the ASG numerator's posteriors, which the criterion computes during forward on a second
+ * stream under the (longer) denominator sweeps (asg.py:158-168 adds the two gradients in backward). */
 int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const float* alpha,
                    const float* beta, const float* logz, const float* coef, const float* coef_w,
-                   const float* gout, int accumulate, float* dx, float* dW, float* dW_partial,
-                   const void* ws, void* stream);
+                   const float* gout, int accumulate, const float* addend, float* dx, float* dW,
+                   float* dW_partial, const void* ws, void* stream);
 /* viterbi_path(intersect(emissions, transitions)).labels_to_list() (asg.py:225-226):
  * path [B,T] int32 emission labels.  Ties: lowest previous label, then lowest final label. */
 int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float* alpha,

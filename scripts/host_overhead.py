@@ -121,4 +121,39 @@ def tfwd(i):
 
 print("Transducer fwd+bwd (fresh)          host %.1f us (sync %.1f)" % tt(tfwd))
 print("Transducer fwd+bwd (same)           host %.1f us (sync %.1f)" % tt(lambda i: tfwd(7)))
+# ---- ASG (cfg3)
+from gtn_applications_amd.criterions import asg as AS
+Wt = torch.zeros(C + 1, C, device="cuda", requires_grad=True)
+E._TARGET_CACHE.data.clear()
+tgs = [E.targets_on_device(b, dev) for b in batches[:60]]
+print("asg_force_align pack+upload         host %.1f us (sync %.1f)" % tt(
+    lambda i: E.PackedLattice.asg_force_align(tgs[i].flat, tgs[i].offsets, C, dev)))
+
+
+def native_fal(i):
+    h = N.lib.wfl_lattice_pack_asg_fal(tgs[i].flat.ctypes.data, tgs[i].offsets.ctypes.data, B, C)
+    N.lib.wfl_lattice_host_free(h)
+
+
+print("wfl_lattice_pack_asg_fal            host %.1f us (sync %.1f)" % tt(native_fal))
+E._TARGET_CACHE.data.clear()
+
+
+def afwd(i):
+    x.grad = None
+    Wt.grad = None
+    AS.ASGLoss(x, Wt, batches[i], "mean").backward()
+
+
+print("ASGLoss fwd+bwd (fresh)             host %.1f us (sync %.1f)" % timed(afwd))
+print("ASGLoss fwd+bwd (same)              host %.1f us (sync %.1f)" % timed(lambda i: afwd(3)))
+
+
+def afwd_only(i):
+    AS.ASGLoss(x, Wt, batches[i], "mean")
+
+
+E._TARGET_CACHE.data.clear()
+print("ASGLoss forward (fresh)             host %.1f us (sync %.1f)" % timed(afwd_only))
+print("ASGLoss forward (same)              host %.1f us (sync %.1f)" % timed(lambda i: afwd_only(3)))
 print("host cores", os.cpu_count())

@@ -622,6 +622,17 @@ def test_asg_vs_oracle(crit, B, T, C, reduction):
     x3, W3 = dev(x), dev(W, grad=True)
     crit["asg"].ASGLoss(x3, W3, targets, reduction).backward()
     close(W3.grad, want[2], atol=2e-5)
+    # a non-unit upstream gradient scales both halves (the numerator's is computed during forward for
+    # grad_output = 1 and rescaled in backward), and a second backward over the retained graph repeats it
+    x4, W4 = dev(x, grad=True), dev(W, grad=True)
+    loss4 = crit["asg"].ASGLoss(x4, W4, targets, reduction)
+    (loss4 * -2.5).sum().backward(retain_graph=True)
+    close(x4.grad, -2.5 * want[1])
+    close(W4.grad, -2.5 * want[2], atol=5e-5)
+    x4.grad = W4.grad = None
+    (loss4 * 0.5).sum().backward()
+    close(x4.grad, 0.5 * want[1])
+    close(W4.grad, 0.5 * want[2], atol=2e-5)
 
 
 def test_asg_viterbi_vs_oracle_integer_scores(crit):
