@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwfl.so")
+LIB_PATH = os.environ.get("WFL_LIB_PATH") or os.path.join(_HERE, "libwfl.so")  # (override: A/B builds of the kernels)
 
 WFL_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 1, 2, 3

@@ -1471,7 +1471,7 @@ __global__ void __launch_bounds__(256)
   const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
   const int t_begin = blockIdx.x * rows_per_block;
   const int t_end = min(T, t_begin + rows_per_block);
-  const float inv_q = 1.f / (float)max(Q, 1), inv_c = 1.f / (float)C;
+  const float inv_q = 1.f / (float)max(Q, 1);
   auto fdiv = [](int i, float inv) { return (int)(((float)i + 0.5f) * inv); };
   if (dW)
     for (int a = tid; a < A + E; a += NT) dwacc[a] = 0.f;
@@ -1657,10 +1657,21 @@ __global__ void __launch_bounds__(256)
           }
         }
       } else {
+        // narrow rows: a lane owns a column (its label slot looked up once), a wave owns every fourth row
+        const int lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
+        for (int c = lane; c < C; c += 64) {
+          const int k = dead ? -1 : colmap[c];
 #pragma unroll 4
-        for (int i = tid; i < nr * C; i += NT) {
-          const int r = fdiv(i, inv_c), c = i - r * C;
-          gdst[i] = value(r, c, accumulate ? gdst[i] : 0.f, soft ? xsrc[i] : 0.f, soft ? lse[r] : 0.f);
+          for (int r = wv; r < nr; r += nw) {
+            const int i = r * C + c;
+            float v = accumulate ? gdst[i] : 0.f;
+            if (soft) {
+              const float l = lse[r];
+              if (l > WFL_NEG_INF) v -= cf * fast_exp(nan_to_neg(xsrc[i]) - l);
+            }
+            if (k >= 0) v += cf * acc[r * Kmax + k];
+            gdst[i] = v;
+          }
         }
       }
     }
@@ -1978,8 +1989,10 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
   }
   if (T <= 0) return WFL_OK;
   // frames per LDS sub-tile: alpha, beta, gathered emissions and the per-label accumulators of TS
-  // frames; ~24 KiB at most so that several workgroups are co-resident (each one is a load ->
-  // barrier -> compute -> barrier -> stream-out sequence, overlap comes from co-residency)
+  // frames; ~40 KiB at most so that several workgroups are co-resident (each one is a load ->
+  // barrier -> compute -> barrier -> stream-out sequence, overlap comes from co-residency).  Measured on MI355X
+  // (kernel us at 24 / 32 / 40 / 48 KiB): Transducer cfg4 (263 states, 917 arcs: ONE frame per tile at 24 KiB)
+  // 301 / 230 / 239 / 283; ASG force alignment alone 81 / 112 / 78 / 78, under the denominator sweeps 220 / 198 / 174.
   const size_t row_bytes = 16 * (size_t)d->max_states + 4 * (size_t)d->max_labels * (dx ? 2 : 1);  // (alpha, beta: doubles)
   const size_t fixed = 16 * (size_t)d->max_states + 4 * (dW ? (size_t)d->max_arcs + d->max_eps : 0) +
                        (dx ? 8 * (size_t)d->max_arcs + 4 * (((size_t)d->max_labels + 3) & ~(size_t)1) +
@@ -1994,7 +2007,11 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
   int64_t tail;
   chain_config(*d, nt_chain, rpc);
   ab_tail(*d, T, tail, nch1);
-  int TS = fixed + row_bytes < 24 * 1024 ? (int)((24 * 1024 - fixed) / row_bytes) : 1;
+  static const size_t budget = [] {  // (WFL_GRAD_LDS_KB: tuning knob)
+    const char* e = getenv("WFL_GRAD_LDS_KB");
+    return (size_t)(e ? atoi(e) : 40) * 1024;
+  }();
+  int TS = fixed + row_bytes < budget ? (int)((budget - fixed) / row_bytes) : 1;
   TS = std::max(1, std::min(TS, 32));
   const size_t lds = fixed + row_bytes * TS;
   if (lds > (size_t)kLdsBytes) {
