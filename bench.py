@@ -314,25 +314,44 @@ def pmc_traffic(key, phase):
 
 # --------------------------------------------------------------------------------------------------
 def timed_loop(step, steps, warmup, fence, collect_events):
+    """-> (seconds of the timed region, ms per step of the dominant kernel group measured INSIDE it, ms per step of every
+    group measured during warm-up).  HIP events around every launch perturb the step (each record is a packet on the
+    stream, ~5 us on the critical path), so the timed region brackets only the dominant group -- found during the
+    warm-up steps, which bracket them all."""
     from gtn_applications_amd import engine as E
 
-    for i in range(warmup):
+    def collect(events, n):
+        phases = {}
+        for name, a, b in events or []:
+            phases.setdefault(name, []).append(a.elapsed_time(b))
+        # ms per step: a phase may launch more than once per step (numerator + denominator)
+        return {k: float(np.sum(v)) / n for k, v in phases.items()}
+
+    cal = min(warmup, 3) if collect_events else 0
+    for i in range(warmup - cal):
         step(i)
     fence()
-    if collect_events:
-        E.prealloc_events(16 * steps)
+    warm = {}
+    if cal:
+        E.prealloc_events(16 * (steps + cal))
+        E.PHASE_EVENTS, E.PHASE_ONLY = [], None
+        for i in range(warmup - cal, warmup):
+            step(i)
+        fence()
+        warm = collect(E.PHASE_EVENTS, cal)
+    # (--warmup 0: nothing to calibrate on, every group is bracketed inside the timed region)
     E.PHASE_EVENTS = [] if collect_events else None
+    E.PHASE_ONLY = {max(warm, key=warm.get)} if warm else None
+    if collect_events and not warm:
+        E.prealloc_events(16 * steps)
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    events, E.PHASE_EVENTS = E.PHASE_EVENTS, None
-    phases = {}
-    for name, a, b in events or []:
-        phases.setdefault(name, []).append(a.elapsed_time(b))
-    # ms per step: a phase may launch more than once per step (numerator + denominator)
-    return elapsed, {k: float(np.sum(v)) / steps for k, v in phases.items()}
+    events, E.PHASE_EVENTS, E.PHASE_ONLY = E.PHASE_EVENTS, None, None
+    timed = collect(events, steps)
+    return elapsed, {**warm, **timed}
 
 
 def main():
@@ -389,7 +408,9 @@ def main():
             "step_kernels_ms": gpu_ms, "step_frac": alg_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "note": "achieved = algorithmic bytes of the batch (8*T*C per utterance, + 8*(C+1)*C for ASG's W and dW) / "
                     "average duration of the dominant kernel group, HIP events on the launch stream inside the timed "
-                    "region; step_* divides by the sum over all kernel groups of a step (groups on forked streams overlap)",
+                    "region (the other groups of kernel_ms are bracketed during the last warm-up steps only: an event "
+                    "pair per launch costs the step ~10 us each); step_* divides by the sum over all kernel groups of a "
+                    "step (groups on forked streams overlap)",
         }
     single = rank == 0 and world == 1
     if single and not args.no_extras:

@@ -121,7 +121,7 @@ _SIGS = {
     "wfl_dense_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "wfl_dense_max_classes": (c_int, []),
     "wfl_dense_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
-    "wfl_dense_grad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "wfl_dense_grad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "wfl_dense_viterbi": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     # device: CTC fast path
     "wfl_ctc_workspace": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int64)]),
@@ -131,7 +131,7 @@ _SIGS = {
     "wfl_ctc_forward_backward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
                                          _P, _P]),
     "wfl_row_lse": (c_int, [_P, c_int64, c_int, _P, _P]),
-    "wfl_reduce_loss": (c_int, [_P, _P, c_int, c_float, c_int, _P, _P]),
+    "wfl_reduce_loss": (c_int, [_P, _P, _P, c_int, c_float, c_int, _P, _P]),
     "wfl_scale": (c_int, [_P, c_int64, _P, _P]),
 }
 

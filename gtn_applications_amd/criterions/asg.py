@@ -118,28 +118,30 @@ class ASGLossFunction(torch.autograd.Function):
         dx_num = dw_num = None
         with E.side_stream(dev) as fork:
             fal = E.lattice_forward(x, pack, weights=W, need_beta=need_grad)
+            swept = fork.mark()
             if need_grad:
                 dx_num = torch.empty_like(x) if need_dx else None
                 dw_num = torch.zeros_like(W) if need_dw else None
                 E.lattice_grad(fal, cneg, coef_w=cneg, gout=None, dx=dx_num, accumulate=False, dW=dw_num)
         fcc = E.dense_forward(x, W, need_beta=need_grad)
-        fork.join(fal.xg, fal.alpha, fal.beta, fal.logz, dx_num, dw_num)
-        loss = E.reduce_loss(fcc.logz, scale, 1.0)
-        loss = E.reduce_loss(fal.logz, scale, -1.0, out=loss)
-        ctx.aux = (x, W, fcc, cpos, dx_num, dw_num)
+        # the loss only needs the numerator's sweeps; its gradient keeps running and is joined in backward
+        fork.join_at(swept, fal.xg, fal.alpha, fal.beta, fal.logz)
+        loss = E.reduce_loss(fcc.logz, scale, 1.0, minus=fal.logz)
+        ctx.aux = (x, W, fcc, cpos, dx_num, dw_num, fork if need_grad else None)
         ctx.devices = (inputs.device, transitions.device)
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
     def backward(ctx, grad_output):
-        x, W, fcc, cpos, dx_num, dw_num = ctx.aux
+        x, W, fcc, cpos, dx_num, dw_num, fork = ctx.aux
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] and dx_num is not None else None
-        dW = dw_num * gout if ctx.needs_input_grad[1] and dw_num is not None else None
+        dW = torch.empty_like(W) if ctx.needs_input_grad[1] and dw_num is not None else None
         if dx is not None or dW is not None:
+            fork.join(dx_num, dw_num)
             # + posteriors of the fully connected graph, - posteriors of the force-aligned one (asg.py:158-168)
             E.dense_grad(x, W, fcc, cpos, coef_w=cpos, gout=gout, dx=dx, accumulate=False, dW=dW,
-                         addend=dx_num if dx is not None else None)
+                         addend=dx_num if dx is not None else None, dW_addend=dw_num if dW is not None else None)
         if dx is not None and ctx.devices[0].type != "cuda":
             dx = dx.to(ctx.devices[0])
         if dW is not None and ctx.devices[1].type != "cuda":

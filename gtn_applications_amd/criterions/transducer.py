@@ -285,10 +285,11 @@ class TransducerLossFunction(torch.autograd.Function):
                 den = E.lattice_forward(x, _transitions_pack(transitions, B, C, dev), weights=params,
                                         need_beta=need_grad)
         num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax)
-        loss = E.reduce_loss(num.logz, scale, -1.0)
         if den is not None:
             fork.join(den.xg, den.alpha, den.beta, den.logz)
-            loss = E.reduce_loss(den.logz, scale, 1.0, out=loss)
+            loss = E.reduce_loss(den.logz, scale, 1.0, minus=num.logz)
+        else:
+            loss = E.reduce_loss(num.logz, scale, -1.0)
         ctx.aux = (x, params, num, den, cpos, cneg)
         ctx.devices = (inputs.device, None if transition_params is None else transition_params.device)
         return loss if inputs.is_cuda else loss.cpu()

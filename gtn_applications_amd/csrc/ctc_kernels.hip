@@ -2236,7 +2236,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   }
   if (rc) return rc;
   WFL_LAUNCH_CHECK();
-  if (ppl > 1 && loss_out) return wfl_reduce_loss(nll, loss_scale, B, 1.f, 0, loss_out, stream);
+  if (ppl > 1 && loss_out) return wfl_reduce_loss(nll, nullptr, loss_scale, B, 1.f, 0, loss_out, stream);
   return WFL_OK;
 }
 

@@ -277,10 +277,11 @@ __global__ void __launch_bounds__(256)
   }  // pass
 }
 
-// dW[i] += sum_k partial[k][i]: 32 elements x 8 slices of the partials per workgroup, merged in LDS
-// in a fixed order (deterministic)
+// dW[i] = (accumulate ? dW[i] : 0) + gout * addend[i] + sum_k partial[k][i]: 32 elements x 8 slices of the partials
+// per workgroup, merged in LDS in a fixed order (deterministic)
 __global__ void __launch_bounds__(256)
-    dense_reduce_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ dW) {
+    dense_reduce_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ dW, int accumulate,
+                        const float* __restrict__ addend, const float* __restrict__ gout) {
   __shared__ float red[8][32];
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + e;
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(256)
     float t = red[0][e];
 #pragma unroll
     for (int q = 1; q < 8; ++q) t += red[q][e];
-    dW[i] += t;
+    dW[i] = (accumulate ? dW[i] : 0.f) + (addend ? (gout ? gout[0] : 1.f) * addend[i] : 0.f) + t;
   }
 }
 
@@ -933,7 +934,8 @@ int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws
 
 int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const float* alpha, const float* beta,
                    const float* logz, const float* coef, const float* coef_w, const float* gout, int accumulate,
-                   const float* addend, float* dx, float* dW, float* dW_partial, const void* ws, void* stream) {
+                   const float* addend, const float* dW_addend, float* dx, float* dW, float* dW_partial, const void* ws,
+                   void* stream) {
   if (int rc = dense_check(x, W, B, T, C, "dense_grad")) return rc;
   if (!alpha || !beta || !logz || !ws || (!dx && !dW) || (dW && !dW_partial)) {
     set_error("dense_grad: missing buffers");
@@ -980,7 +982,7 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
   if (dW) {
     const int n = (C + 1) * C;
     hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, dW_partial, B * chunks,
-                       n, dW);
+                       n, dW, accumulate, dW_addend, gout);
     WFL_LAUNCH_CHECK();
   }
   return WFL_OK;

@@ -1741,11 +1741,13 @@ __global__ void backtrace_kernel(wfl_lattice_desc d, const int32_t* __restrict__
   path_len[b] = n;
 }
 
-__global__ void reduce_loss_kernel(const float* __restrict__ vals, const float* __restrict__ scale, int B, float sign,
-                                   int accumulate, float* __restrict__ out) {
+__global__ void reduce_loss_kernel(const float* __restrict__ vals, const float* __restrict__ minus,
+                                   const float* __restrict__ scale, int B, float sign, int accumulate,
+                                   float* __restrict__ out) {
   __shared__ float red[64];
   float s = 0.f;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) s += sign * (scale ? scale[b] : 1.f) * vals[b];
+  for (int b = threadIdx.x; b < B; b += blockDim.x)
+    s += sign * (scale ? scale[b] : 1.f) * (minus ? vals[b] - minus[b] : vals[b]);
   s = block_reduce_sum(s, red);
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s / (float)B;
 }
@@ -2105,12 +2107,14 @@ int wfl_scale(float* v, int64_t n, const float* s, void* stream) {
   return WFL_OK;
 }
 
-int wfl_reduce_loss(const float* vals, const float* scale, int B, float sign, int accumulate, float* out, void* stream) {
+int wfl_reduce_loss(const float* vals, const float* minus, const float* scale, int B, float sign, int accumulate,
+                    float* out, void* stream) {
   if (B <= 0 || !vals || !out) {
     set_error("reduce_loss: bad arguments");
     return WFL_ERR_INVALID;
   }
-  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, vals, scale, B, sign, accumulate, out);
+  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, vals, minus, scale, B, sign,
+                     accumulate, out);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

@@ -70,6 +70,7 @@ def flatten_targets(targets):
 # bench.py sets this to a list to time the native launches of a step with HIP events recorded on the stream
 # each launch goes to: entries are (phase name, start event, end event).  None (the default) costs one test.
 PHASE_EVENTS = None
+PHASE_ONLY = None  # optional set of phase names: the only ones recorded (bench.py's timed region records one)
 
 
 _EVENT_POOL = []
@@ -88,7 +89,7 @@ def _event():
 
 
 def _mark(name):
-    if PHASE_EVENTS is None:
+    if PHASE_EVENTS is None or (PHASE_ONLY is not None and name not in PHASE_ONLY):
         return None
     return name, _event()
 
@@ -364,7 +365,22 @@ class side_stream:
         return False
 
     def join(self, *tensors):
-        self.cur.wait_stream(self.side)
+        """The current stream waits for everything launched on the side stream so far."""
+        cur = torch.cuda.current_stream(self.side.device)
+        cur.wait_stream(self.side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(cur)
+
+    def mark(self):
+        """Event after what has been launched on the side stream so far (call inside the block)."""
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return ev
+
+    def join_at(self, ev, *tensors):
+        """The current stream waits for the side stream only up to `ev` (work launched after it keeps overlapping)."""
+        self.cur.wait_event(ev)
         for t in tensors:
             if t is not None:
                 t.record_stream(self.cur)
@@ -376,13 +392,14 @@ def scale_inplace(v, s):
     return v
 
 
-def reduce_loss(vals, scale, sign=1.0, out=None):
-    """out = (1/B) sum_b sign * scale[b] * vals[b]   (ctc.py:68-69 and twins), on the device."""
+def reduce_loss(vals, scale, sign=1.0, out=None, minus=None):
+    """out = (1/B) sum_b sign * scale[b] * (vals[b] - minus[b])   (ctc.py:68-69 and twins), on the device."""
     B = vals.numel()
     accumulate = out is not None
     if out is None:
         out = torch.empty((), dtype=_F32, device=vals.device)
-    N.check(N.lib.wfl_reduce_loss(ptr(vals), ptr(scale), B, float(sign), int(accumulate), ptr(out), stream_ptr()))
+    N.check(N.lib.wfl_reduce_loss(ptr(vals), ptr(minus), ptr(scale), B, float(sign), int(accumulate), ptr(out),
+                                  stream_ptr()))
     return out
 
 
@@ -423,16 +440,17 @@ def dense_flagged(st):
     return st.ws[off:off + 8 * B].view(torch.int32).view(B, 2).ne(0).any(dim=1)
 
 
-def dense_grad(x, W, st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None, addend=None):
-    """`addend`: [B,T,C] term added to dx scaled by gout (a gradient computed before gout was known)."""
+def dense_grad(x, W, st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None, addend=None, dW_addend=None):
+    """dx / dW are OVERWRITTEN unless `accumulate`.  `addend` [B,T,C], `dW_addend` [(C+1),C]: terms added to dx / dW
+    scaled by gout (gradients computed before gout was known)."""
     part = None
     if dW is not None:
         part = torch.empty(_dense_sizes(st.B, st.T, st.C)[0], dtype=_F32, device=x.device)
     tok = _mark("dense_grad")
     N.check(
         N.lib.wfl_dense_grad(ptr(x), ptr(W), st.B, st.T, st.C, ptr(st.alpha), ptr(st.beta), ptr(st.logz), ptr(coef),
-                             ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(addend), ptr(dx), ptr(dW), ptr(part),
-                             ptr(st.ws), stream_ptr())
+                             ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(addend), ptr(dW_addend), ptr(dx),
+                             ptr(dW), ptr(part), ptr(st.ws), stream_ptr())
     )
     _done(tok)
 

@@ -237,13 +237,14 @@ int wfl_dense_max_classes(void);
 int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int semiring,
                       float* alpha, float* beta, int32_t* bptr, float* logz, void* ws, void* stream);
 /* dx[b,t,i] = (accumulate ? dx : 0) + gout*addend[b,t,i] + coef[b]*gout*post_t(i);
- * dW += sum_b coef_w[b]*gout*transition posteriors.  `addend` (may be NULL): a [B,T,C] term computed for gout = 1
- * before gout was known -- the ASG numerator's posteriors, which the criterion computes during forward on a second
- * stream under the (longer) denominator sweeps (asg.py:158-168 adds the two gradients in backward). */
+ * dW       = (accumulate ? dW : 0) + gout*dW_addend    + sum_b coef_w[b]*gout*transition posteriors.
+ * `addend` [B,T,C] and `dW_addend` [(C+1),C] (either may be NULL): terms computed for gout = 1 before gout was
+ * known -- the ASG numerator's posteriors, which the criterion computes during forward on a second stream under the
+ * (longer) denominator sweeps (asg.py:158-168 adds the two gradients in backward). */
 int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const float* alpha,
                    const float* beta, const float* logz, const float* coef, const float* coef_w,
-                   const float* gout, int accumulate, const float* addend, float* dx, float* dW,
-                   float* dW_partial, const void* ws, void* stream);
+                   const float* gout, int accumulate, const float* addend, const float* dW_addend,
+                   float* dx, float* dW, float* dW_partial, const void* ws, void* stream);
 /* viterbi_path(intersect(emissions, transitions)).labels_to_list() (asg.py:225-226):
  * path [B,T] int32 emission labels.  Ties: lowest previous label, then lowest final label. */
 int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float* alpha,
@@ -324,11 +325,12 @@ int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, co
 
 /* small device utilities used by the Python layer (kept here so the product never needs a
  * torch op inside the timed path) */
-/* out[0] = (1/B) * sum_b sign * scale[b] * vals[b]  (+ out[0] if accumulate) */
 /* v[0..n) *= s[0] on the device; a no-op pass when s[0] == 1 (upstream gradient of a scalar loss) */
 int wfl_scale(float* v, int64_t n, const float* s, void* stream);
-int wfl_reduce_loss(const float* vals, const float* scale, int B, float sign, int accumulate,
-                    float* out, void* stream);
+/* out[0] = (1/B) * sum_b sign * scale[b] * (vals[b] - minus[b])  (+ out[0] if accumulate); minus may be NULL (0).
+ * With `minus` the two-term criteria (ASG: denominator - numerator, asg.py:116-121; Transducer) reduce in one launch. */
+int wfl_reduce_loss(const float* vals, const float* minus, const float* scale, int B, float sign,
+                    int accumulate, float* out, void* stream);
 
 #ifdef __cplusplus
 }
