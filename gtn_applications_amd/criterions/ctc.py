@@ -117,7 +117,54 @@ class _FusedLogSoftmaxCTCLoss(CTCLossFunction):
         return CTCLossFunction.forward(ctx, inputs, targets, blank_idx, reduction)
 
 
-CTCLoss = CTCLossFunction.apply
+def _native_node():
+    """The C++ autograd node of the pipelined step (csrc/torch_ops.cpp), or None if the extension was not built."""
+    global _NODE
+    if _NODE is False:
+        try:
+            from .. import _wfl_torch as _NODE
+        except ImportError:
+            _NODE = None
+    return _NODE
+
+
+_NODE = False
+
+
+def _ctc_loss(log_probs, targets, blank_idx, reduction, fused_log_softmax):
+    """CTCLossFunction.apply, with the hot case -- float32 device emissions that require grad, targets the fast
+    kernels take -- routed through the C++ autograd node: same checks, same staging, same launch, but neither the
+    forward nor the backward passes through Python's autograd.Function machinery (which costs more host time than
+    the step's kernels take on the GPU at the benchmark shape)."""
+    node = _native_node()
+    if (node is not None and type(log_probs) is torch.Tensor and log_probs.is_cuda and log_probs.requires_grad
+            and log_probs.dtype == torch.float32 and log_probs.dim() == 3 and log_probs.is_contiguous()
+            and torch.is_grad_enabled() and log_probs.shape[1] > 0 and reduction in ("none", "mean")
+            and log_probs.device.index == torch.cuda.current_device()):
+        B, T, C = log_probs.shape
+        dev = log_probs.device
+        tg = E.targets_on_device(targets, dev)
+        if E.ctc_fast_path_ok(tg.max_len, C):
+            if tg.B != B:
+                raise ValueError(f"got {tg.B} targets for a batch of {B}")
+            E.check_labels(tg, C, "CTCLoss")
+            if not 0 <= int(blank_idx) < C:
+                raise ValueError(f"CTCLoss: blank index {blank_idx} is outside [0, {C})")
+            ws, nll = E.ctc_workspace(log_probs, tg.max_len)
+            lse = E.row_lse(log_probs.detach()) if fused_log_softmax else None
+            fac = tg._off_fac + 4 * B * (0 if reduction == "none" else 1)  # byte offset of scale_<reduction>
+            tok = E._mark("ctc_step")
+            loss = node.ctc_step(log_probs, tg.dev_buf, 0, tg._off_flat, fac, fac + 16 * B, tg.max_len, int(blank_idx),
+                                 ws, nll, lse)
+            E._done(tok)
+            return loss
+    fn = _FusedLogSoftmaxCTCLoss if fused_log_softmax else CTCLossFunction
+    return fn.apply(log_probs, targets, blank_idx, reduction)
+
+
+def CTCLoss(log_probs, targets, blank_idx=0, reduction="none"):
+    """ctc.py:96 (`CTCLoss = CTCLossFunction.apply`): same call, same result."""
+    return _ctc_loss(log_probs, targets, blank_idx, reduction, False)
 
 
 class CTC(torch.nn.Module):
@@ -129,7 +176,7 @@ class CTC(torch.nn.Module):
     def forward(self, inputs, targets):
         if not self.use_pt and inputs.requires_grad and inputs.dtype == torch.float32 and \
                 E.ctc_fast_path_ok(max((t.numel() for t in targets), default=0), inputs.shape[2]):
-            return _FusedLogSoftmaxCTCLoss.apply(inputs, targets, self.blank, "mean")
+            return _ctc_loss(inputs, targets, self.blank, "mean", True)
         log_probs = torch.nn.functional.log_softmax(inputs, dim=2)
         if self.use_pt:  # ctc.py:109-121
             return torch.nn.functional.ctc_loss(

@@ -55,6 +55,42 @@ def close(got, want, rtol=RTOL, atol=ATOL, msg=""):
 # =================================================================================================
 # CTC
 # =================================================================================================
+@pytest.mark.parametrize("reduction", ["none", "mean"])
+def test_ctc_cpp_autograd_node_is_the_python_operator(crit, reduction):
+    """The hot case goes through the C++ autograd node (csrc/torch_ops.cpp): same loss and gradient, bit for bit,
+    as the Python autograd.Function it stands in for; a non-unit upstream gradient, a second backward over a
+    retained graph and the fused log_softmax of the module behave the same."""
+    ctc = crit["ctc"]
+    assert ctc._native_node() is not None, "_wfl_torch.so is not built"
+    rs = np.random.RandomState(7)
+    B, T, C = 5, 60, 12
+    xs = np.log(rs.dirichlet(np.ones(C), size=(B, T))).astype(np.float32)
+    targets = [rs.randint(0, C - 1, size=rs.randint(0, 14)).tolist() for _ in range(B)]
+    x1, x2 = dev(xs, grad=True), dev(xs, grad=True)
+    l1 = ctc.CTCLoss(x1, targets, C - 1, reduction)
+    assert "CtcStep" in l1.grad_fn.name(), l1.grad_fn.name()
+    l2 = ctc.CTCLossFunction.apply(x2, targets, C - 1, reduction)
+    assert torch.equal(l1, l2)
+    w = dev(rs.randn(*l1.shape))
+    (l1 * w).sum().backward(retain_graph=True)
+    (l2 * w).sum().backward(retain_graph=True)
+    assert torch.equal(x1.grad, x2.grad)
+    want = OR.ctc_loss_grad(xs, targets, C - 1, reduction)
+    close(l1, want[0])
+    g1 = x1.grad.clone()
+    x1.grad = None
+    (l1 * w).sum().backward()  # second backward: the launch runs again
+    close(x1.grad, g1.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # module with the fused log_softmax
+    raw = rs.randn(B, T, C).astype(np.float32)
+    r1, r2 = dev(raw, grad=True), dev(raw, grad=True)
+    tt = [torch.tensor(t, dtype=torch.long) for t in targets]
+    m = ctc.CTC(C - 1, False)
+    m(r1, tt).backward()
+    ctc._FusedLogSoftmaxCTCLoss.apply(r2, tt, C - 1, "mean").backward()
+    assert torch.equal(r1.grad, r2.grad)
+
+
 def test_native_library_is_the_one_loaded(crit):
     from gtn_applications_amd import _native
 
