@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -196,6 +197,70 @@ struct Builder {
     return true;
   }
 
+  // The ASG force-alignment acceptor of target y[0..L) in closed form -- exactly what add() produces for its arcs
+  // (l-1 -> l and l -> l labelled y[l-1], in that order, weights W[0,c] / W[1+c,prev] / W[1+c,c]; asg.py:72-81), without
+  // the generic sorts: a chain's arcs are already grouped by destination, each state has its self loop and the arc to
+  // its successor as out-arcs.  (The generic path costs 2.6 us per utterance, this one a few hundred ns; the ASG
+  // criterion packs one such acceptor per utterance and step.)
+  bool add_force_align(const int32_t* y, int L) {
+    const int Q = L + 1, A = 2 * L;
+    for (int l = 0; l < L; ++l)
+      if (y[l] < 0 || y[l] >= C) {
+        set_error("pack_asg_fal: label %d outside [0,%d)", y[l], C);
+        return false;
+      }
+    lvl_ptr.push_back(0), lvl_ptr.push_back(Q);
+    lvl_off.push_back((int32_t)lvl_ptr.size());
+    for (int q = 0; q < Q; ++q) {
+      start_w.push_back(q == 0 ? 0.f : NEG);
+      accept_w.push_back(q == L && L > 0 ? 0.f : NEG);  // (asg.py:75-77: no accepting node for an empty target)
+    }
+    tmp.assign(y, y + L);
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    const int K = (int)tmp.size();
+    if ((int)slot_of.size() < C) slot_of.assign(C, -1);
+    for (int k = 0; k < K; ++k) slot_of[tmp[k]] = k, labels.push_back(tmp[k]);
+    lab_off.push_back((int32_t)labels.size());
+    // in-arcs of state q >= 1: arcs 2(q-1), 2(q-1)+1;  out-arcs: its self loop 2q-1 (q >= 1), then 2q (q < L)
+    in_ptr.push_back(0), out_ptr.push_back(0);
+    for (int q = 0; q < Q; ++q) {
+      in_ptr.push_back(2 * q);
+      out_ptr.push_back(q < L ? 2 * q + 1 : A);
+      if (q >= 1) out_arc.push_back(2 * q - 1);
+      if (q < L) out_arc.push_back(2 * q);
+    }
+    ein_ptr.insert(ein_ptr.end(), (size_t)Q + 1, 0), eout_ptr.insert(eout_ptr.end(), (size_t)Q + 1, 0);
+    // by-slot order (stable): the arcs of every position whose label has the slot, positions ascending
+    const size_t sb = slot_ptr.size();
+    slot_ptr.resize(sb + K + 1, 0);
+    for (int l = 0; l < L; ++l) slot_ptr[sb + slot_of[y[l]] + 1] += 2;
+    for (int k = 0; k < K; ++k) slot_ptr[sb + k + 1] += slot_ptr[sb + k];
+    cnt.assign(slot_ptr.begin() + sb, slot_ptr.begin() + sb + K);
+    const size_t ab = slot_arc.size();
+    slot_arc.resize(ab + A);
+    for (int l = 0; l < L; ++l) {
+      int32_t& at = cnt[slot_of[y[l]]];
+      slot_arc[ab + at] = 2 * l, slot_arc[ab + at + 1] = 2 * l + 1;
+      at += 2;
+    }
+    for (int l = 1; l <= L; ++l) {
+      const int32_t c = y[l - 1], slot = slot_of[c];
+      const int32_t enter = l == 1 ? c : (1 + c) * C + y[l - 2];  // W[0,c] or W[1+c, prev]
+      arc_src.push_back(l - 1), arc_dst.push_back(l), arc_slot.push_back(slot), arc_lab.push_back(c);
+      arc_wid.push_back(enter), arc_orig.push_back(2 * (l - 1)), arc_w.push_back(0.f);
+      arc_src.push_back(l), arc_dst.push_back(l), arc_slot.push_back(slot), arc_lab.push_back(c);
+      arc_wid.push_back((1 + c) * C + c), arc_orig.push_back(2 * (l - 1) + 1), arc_w.push_back(0.f);
+    }
+    for (int k = 0; k < K; ++k) slot_of[tmp[k]] = -1;
+    state_off.push_back(state_off.back() + Q);
+    arc_off.push_back(arc_off.back() + A);
+    eps_off.push_back(eps_off.back());
+    max_states = std::max(max_states, Q), max_arcs = std::max(max_arcs, A);
+    max_labels = std::max(max_labels, K), max_levels = std::max(max_levels, 1);
+    return true;
+  }
+
   // Appends the utterances of `o` (built independently, e.g. on another host thread) behind this builder's.
   void append(const Builder& o) {
     auto cat = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
@@ -324,29 +389,126 @@ wfl_lattice_host* wfl_lattice_pack_ctc(const int32_t* targets, const int64_t* of
   });
 }
 
+// The ASG force-alignment batch written straight into its final blobs: every array's size follows from the target
+// lengths (Q = L + 1 states, 2L arcs, no epsilon arcs) and the number of distinct labels of each target, so one
+// sizing pass and one filling pass replace per-utterance builders, their merge and the copy into the blobs.  The
+// content is Builder::add_force_align's (== the generic add()'s for the same arcs: tests/test_host_library.py).
 wfl_lattice_host* wfl_lattice_pack_asg_fal(const int32_t* targets, const int64_t* offsets, int B, int C) {
-  return build_batch(B, C, [&](int b, Builder& bld, PackScratch& sc) {
-    auto& arcs = sc.arcs;
-    auto &st = sc.st, &ac = sc.ac;
+  if (B <= 0) {
+    set_error("lattice_pack: empty batch");
+    return nullptr;
+  }
+  const int64_t n = offsets[B] - offsets[0];
+  if (n >= (1 << 18))  // long batches: the threaded builders
+    return build_batch(B, C, [&](int b, Builder& bld, PackScratch&) {
+      return bld.add_force_align(targets + offsets[b], (int)(offsets[b + 1] - offsets[b]));
+    });
+  static const bool trace = getenv("WFL_PACK_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  // pass 1: distinct labels of each target (sorted) and the slot of every position
+  // (scratch kept per thread; bound to plain references once -- every access to a thread_local of a shared library
+  // is a call into the TLS resolver)
+  static thread_local std::vector<int32_t> t_labs, t_lab_cum, t_pos_slot, t_slot_of, t_cnt;
+  std::vector<int32_t>&labs = t_labs, &lab_cum = t_lab_cum, &pos_slot = t_pos_slot, &slot_of = t_slot_of, &cnt = t_cnt;
+  labs.clear(), lab_cum.assign(1, 0), pos_slot.resize((size_t)n);
+  if ((int)slot_of.size() < C) slot_of.assign(C, -1);
+  int max_L = 0, max_K = 0;
+  for (int b = 0; b < B; ++b) {
     const int32_t* y = targets + offsets[b];
     const int L = (int)(offsets[b + 1] - offsets[b]);
-    arcs.clear();
-    st.assign(L + 1, 0), ac.assign(L + 1, 0);
-    st[0] = 1, ac[L] = 1;
-    if (L == 0) ac[0] = 0;  // asg.py:75-77: no accepting node for an empty target
-    int32_t id = 0;
-    for (int l = 1; l <= L; ++l) {
-      const int32_t c = y[l - 1];
-      if (c < 0 || c >= C) {
-        set_error("pack_asg_fal: label %d outside [0,%d)", c, C);
-        return false;
+    const size_t l0 = labs.size();
+    for (int l = 0; l < L; ++l) {
+      if (y[l] < 0 || y[l] >= C) {
+        for (size_t k = l0; k < labs.size(); ++k) slot_of[labs[k]] = -1;
+        set_error("pack_asg_fal: label %d outside [0,%d)", y[l], C);
+        return nullptr;
       }
-      const int32_t enter = (l == 1) ? c : (1 + c) * C + y[l - 2];  // W[0,c] or W[1+c, prev]
-      arcs.push_back({l - 1, l, c, enter, id++, 0.f});
-      arcs.push_back({l, l, c, (1 + c) * C + c, id++, 0.f});
+      if (slot_of[y[l]] < 0) slot_of[y[l]] = 0, labs.push_back(y[l]);
     }
-    return bld.add(L + 1, st.data(), ac.data(), arcs);
-  });
+    if (C <= 8 * L) {  // few classes: the marks, scanned in class order, ARE the sorted list
+      size_t k = l0;
+      for (int c = 0; c < C && k < labs.size(); ++c)
+        if (slot_of[c] == 0) labs[k++] = c;
+    } else {
+      std::sort(labs.begin() + l0, labs.end());
+    }
+    const int K = (int)(labs.size() - l0);
+    for (int k = 0; k < K; ++k) slot_of[labs[l0 + k]] = k;
+    int32_t* ps = pos_slot.data() + (offsets[b] - offsets[0]);
+    for (int l = 0; l < L; ++l) ps[l] = slot_of[y[l]];
+    for (int k = 0; k < K; ++k) slot_of[labs[l0 + k]] = -1;
+    lab_cum.push_back((int32_t)labs.size());
+    max_L = std::max(max_L, L), max_K = std::max(max_K, K);
+  }
+  const int64_t S = n + B, A = 2 * n, NL = (int64_t)labs.size();
+  auto* h = new wfl_lattice_host();
+  wfl_lattice_desc& d = h->desc;
+  memset(&d, 0, sizeof(d));
+  d.B = B, d.shared = 0;
+  d.max_states = max_L + 1, d.max_arcs = 2 * max_L, d.max_eps = 0, d.max_labels = pad_labels(max_K), d.max_levels = 1;
+  d.total_states = S, d.total_arcs = A, d.total_eps = 0, d.total_labels = NL;
+  int64_t ni = 0, nf = 0;
+  auto lay = [](int64_t& cursor, int64_t& field, int64_t count) { field = cursor, cursor += (count + 3) & ~(int64_t)3; };
+  lay(ni, d.state_off, B + 1), lay(ni, d.arc_off, B + 1), lay(ni, d.eps_off, B + 1), lay(ni, d.lab_off, B + 1);
+  lay(ni, d.lvl_off, B + 1), lay(ni, d.in_ptr, S + B), lay(ni, d.out_ptr, S + B), lay(ni, d.out_arc, A);
+  lay(ni, d.ein_ptr, S + B), lay(ni, d.eout_ptr, S + B), lay(ni, d.eout_arc, 0);
+  lay(ni, d.arc_src, A), lay(ni, d.arc_dst, A), lay(ni, d.arc_slot, A), lay(ni, d.arc_lab, A), lay(ni, d.arc_wid, A);
+  lay(ni, d.eps_src, 0), lay(ni, d.eps_dst, 0), lay(ni, d.eps_wid, 0);
+  lay(ni, d.labels, NL), lay(ni, d.lvl_ptr, 2 * (int64_t)B), lay(ni, d.arc_orig, A), lay(ni, d.eps_orig, 0);
+  lay(ni, d.slot_ptr, NL + B), lay(ni, d.slot_arc, A);
+  lay(nf, d.arc_w, A), lay(nf, d.eps_w, 0), lay(nf, d.start_w, S), lay(nf, d.accept_w, S);
+  d.int_words = ni, d.float_words = nf;
+  const auto t1 = std::chrono::steady_clock::now();
+  h->ints.assign((size_t)ni, 0), h->floats.assign((size_t)nf, 0.f);  // (arc_w, the epsilon CSRs and the padding stay 0)
+  const auto t2 = std::chrono::steady_clock::now();
+  int32_t* I = h->ints.data();
+  float* F = h->floats.data();
+  memcpy(I + d.labels, labs.data(), (size_t)NL * sizeof(int32_t));
+  // pass 2
+  int64_t s0 = 0, a0 = 0;
+  for (int b = 0; b < B; ++b) {
+    const int32_t* y = targets + offsets[b];
+    const int L = (int)(offsets[b + 1] - offsets[b]), Q = L + 1, K = lab_cum[b + 1] - lab_cum[b];
+    const int32_t* ps = pos_slot.data() + (offsets[b] - offsets[0]);
+    I[d.state_off + b + 1] = (int32_t)(s0 + Q), I[d.arc_off + b + 1] = (int32_t)(a0 + 2 * L);
+    I[d.lab_off + b + 1] = lab_cum[b + 1], I[d.lvl_off + b + 1] = 2 * (b + 1);
+    I[d.lvl_ptr + 2 * b + 1] = Q;
+    int32_t* ip = I + d.in_ptr + s0 + b;
+    int32_t* op = I + d.out_ptr + s0 + b;
+    int32_t* oa = I + d.out_arc + a0;
+    float* sw = F + d.start_w + s0;
+    float* aw = F + d.accept_w + s0;
+    for (int q = 0; q < Q; ++q) {
+      ip[q + 1] = 2 * q, op[q + 1] = q < L ? 2 * q + 1 : 2 * L;
+      sw[q] = q == 0 ? 0.f : NEG, aw[q] = (q == L && L > 0) ? 0.f : NEG;
+      if (q >= 1) *oa++ = 2 * q - 1;
+      if (q < L) *oa++ = 2 * q;
+    }
+    int32_t* sp = I + d.slot_ptr + lab_cum[b] + b;
+    for (int l = 0; l < L; ++l) sp[ps[l] + 1] += 2;
+    for (int k = 0; k < K; ++k) sp[k + 1] += sp[k];
+    cnt.assign(sp, sp + K);
+    int32_t* sa = I + d.slot_arc + a0;
+    int32_t *src = I + d.arc_src + a0, *dst = I + d.arc_dst + a0, *slt = I + d.arc_slot + a0, *lab = I + d.arc_lab + a0;
+    int32_t *wid = I + d.arc_wid + a0, *org = I + d.arc_orig + a0;
+    for (int l = 0; l < L; ++l) {
+      const int32_t c = y[l], k = ps[l];
+      int32_t& at = cnt[k];
+      sa[at] = 2 * l, sa[at + 1] = 2 * l + 1, at += 2;
+      src[2 * l] = l, dst[2 * l] = l + 1, src[2 * l + 1] = l + 1, dst[2 * l + 1] = l + 1;
+      slt[2 * l] = slt[2 * l + 1] = k, lab[2 * l] = lab[2 * l + 1] = c;
+      wid[2 * l] = l == 0 ? c : (1 + c) * C + y[l - 1];  // W[0,c] or W[1+c, prev]
+      wid[2 * l + 1] = (1 + c) * C + c;
+      org[2 * l] = 2 * l, org[2 * l + 1] = 2 * l + 1;
+    }
+    s0 += Q, a0 += 2 * L;
+  }
+  if (trace) {
+    auto us = [](auto a, auto b) { return std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1000.0; };
+    fprintf(stderr, "[wfl pack_asg_fal] slots %.0f us, alloc %.0f us, fill %.0f us\n", us(t0, t1), us(t1, t2),
+            us(t2, std::chrono::steady_clock::now()));
+  }
+  return h;
 }
 
 wfl_lattice_host* wfl_lattice_pack_stc(const int32_t* targets, const int64_t* offsets, int B, int star_idx,
@@ -595,7 +757,6 @@ struct GraphOwner {  // frees an intermediate graph at scope exit
 // tokens, optionally intersected with the transition model (then `wid` = arc of the transition model behind each
 // arc, the index of its learnable weight).  Returns false with the thread's error set.
 #ifdef WFL_PROFILE_HOST
-#include <chrono>
 static std::atomic<long long> g_prof[8];
 struct ProfDump { ~ProfDump() { for (int i = 0; i < 8; ++i) fprintf(stderr, "prof[%d] = %.3f ms\n", i, g_prof[i].load() / 1e6); } } g_prof_dump;
 #define PROF_T0 auto _t = std::chrono::steady_clock::now();

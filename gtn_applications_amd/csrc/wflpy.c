@@ -61,8 +61,29 @@ static PyObject* flatten_into(PyObject* self, PyObject* args) {
   return Py_BuildValue("nnll", total, max_len, lo, hi);
 }
 
+/* factors_into(offsets_addr, B, fac_addr): the per-utterance loss / gradient factors of both reductions, six float
+ * arrays of B back to back at fac_addr -- scale_none = 1, scale_mean = 1/len (1 for an empty target), then both
+ * times +1/B and times -1/B (ctc.py:53-58,87; asg.py:116-121,171-179) -- from the int64 offsets [B+1]. */
+static PyObject* factors_into(PyObject* self, PyObject* args) {
+  unsigned long long off_addr, fac_addr;
+  Py_ssize_t B;
+  if (!PyArg_ParseTuple(args, "KnK", &off_addr, &B, &fac_addr)) return NULL;
+  const int64_t* off = (const int64_t*)(uintptr_t)off_addr;
+  float* fac = (float*)(uintptr_t)fac_addr;
+  const float inv_b = 1.0f / (float)(B > 0 ? B : 1);
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    const float ln = (float)(off[b + 1] - off[b]);
+    const float mean = ln > 0.f ? 1.0f / ln : 1.0f;
+    fac[b] = 1.0f, fac[B + b] = mean;
+    fac[2 * B + b] = 1.0f * inv_b, fac[3 * B + b] = mean * inv_b;
+    fac[4 * B + b] = 1.0f * -inv_b, fac[5 * B + b] = mean * -inv_b;
+  }
+  Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
     {"flatten_into", flatten_into, METH_VARARGS, "flatten list-of-int-lists targets into int32 flat + int64 offsets"},
+    {"factors_into", factors_into, METH_VARARGS, "per-utterance loss / gradient factors from the offsets"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_wflpy", "operator-layer helpers of gtn_applications_amd", -1,
                                     methods};

@@ -601,14 +601,7 @@ def _stage_targets(targets, device, flat=None, lens=None):
         n, max_len, lo, hi = res
     off_fac = (off_flat + 4 * max(n, 1) + 7) & ~7
     nbytes = off_fac + 4 * B * len(_FACTORS)
-    ln = np.diff(view[:off_flat].view(np.int64)).astype(np.float32)
-    fac = view[off_fac:nbytes].view(np.float32).reshape(len(_FACTORS), B)
-    fac[0] = 1.0
-    np.divide(1.0, ln, out=fac[1], where=ln > 0)
-    fac[1][ln <= 0] = 1.0
-    inv_b = 1.0 / max(B, 1)
-    np.multiply(fac[0:2], inv_b, out=fac[2:4])
-    np.multiply(fac[0:2], -inv_b, out=fac[4:6])
+    _wflpy.factors_into(buf.data_ptr(), B, buf.data_ptr() + off_fac)  # (the six _FACTORS arrays, in that order)
     content = (view[:off_flat + 4 * n].tobytes(), key)
     return slot, (buf, view), nbytes, B, n, max_len, lo, hi, off_flat, off_fac, content
 

@@ -234,6 +234,30 @@ def test_bulk_packers_match_generic_packer():
     slow = E.PackedLattice.from_graphs([stc.STCLossFunction.create_stc_graph(t, 5, 0.5) for t in targets], 10, None)
     np.testing.assert_array_equal(fast.host_ints, slow.host_ints)
     np.testing.assert_allclose(fast.host_floats, slow.host_floats, rtol=1e-6)
+    # ASG force alignment: the closed-form packer against the generic one on the same arcs and weight indices
+    rs = np.random.RandomState(3)
+    C = 7
+    targets = [[1, 2, 2, 0], [], [3], [6] * 9] + [rs.randint(0, C, size=rs.randint(1, 30)).tolist() for _ in range(20)]
+    flat, off, _ = E.flatten_targets(targets)
+    graphs, wids = [], []
+    for t in targets:
+        g = G.Graph(False)
+        g.add_node(True, False)
+        wid = []
+        for l in range(1, len(t) + 1):
+            g.add_node(False, l == len(t))
+            c = t[l - 1]
+            g.add_arc(l - 1, l, c)
+            g.add_arc(l, l, c)
+            wid += [c if l == 1 else (1 + c) * C + t[l - 2], (1 + c) * C + c]
+        graphs.append(g)
+        wids.append(np.asarray(wid, dtype=np.int32))
+    fast = E.PackedLattice.asg_force_align(flat, off, C, None)
+    slow = E.PackedLattice.from_graphs(graphs, C, None, wids=wids)
+    np.testing.assert_array_equal(fast.host_ints, slow.host_ints)
+    np.testing.assert_array_equal(fast.host_floats, slow.host_floats)
+    for f in ("max_states", "max_arcs", "max_labels", "max_levels", "total_states", "total_arcs", "total_labels"):
+        assert getattr(fast.desc, f) == getattr(slow.desc, f), f
 
 
 def test_replabels_match_reference_vectors(golden_dir):
