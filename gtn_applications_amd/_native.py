@@ -131,6 +131,7 @@ _SIGS = {
     "wfl_ctc_forward_backward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
                                          _P, _P]),
     "wfl_row_lse": (c_int, [_P, c_int64, c_int, _P, _P]),
+    "wfl_upload": (c_int, [_P, _P, c_int64, _P]),
     "wfl_reduce_loss": (c_int, [_P, _P, _P, c_int, c_float, c_int, _P, _P]),
     "wfl_scale": (c_int, [_P, c_int64, _P, _P]),
 }

@@ -1813,6 +1813,19 @@ __global__ void __launch_bounds__(256) row_lse_wide_kernel(const float* __restri
   }
 }
 
+// dst[0..nbytes) = src[0..nbytes): `src` is pinned host memory read through its device-visible address (a kernel
+// launch never waits for the stream to drain; hipMemcpyAsync from pinned memory sometimes does, see wfl_upload)
+__global__ void __launch_bounds__(256) upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
+                                                      int64_t nbytes) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0) {
+    const int64_t done = n16 * 16;
+    if ((int64_t)threadIdx.x < nbytes - done)
+      reinterpret_cast<uint8_t*>(dst)[done + threadIdx.x] = reinterpret_cast<const uint8_t*>(src)[done + threadIdx.x];
+  }
+}
+
 // v *= s[0], skipped when s[0] == 1 (the usual upstream gradient of a scalar loss)
 __global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ v, int64_t n4, int64_t n, const float* __restrict__ s) {
   const float f = s[0];
@@ -2092,6 +2105,20 @@ int wfl_row_lse(const float* x, int64_t rows, int C, float* out, void* stream) {
     launch(row_lse_kernel<16, 1>, 1);
   else
     launch(row_lse_wide_kernel, 1);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_upload(void* dst, const void* src_pinned, int64_t nbytes, void* stream) {
+  if (!dst || !src_pinned || nbytes < 0 || (((uintptr_t)dst | (uintptr_t)src_pinned) & 15)) {
+    set_error("upload: bad arguments (both buffers must be 16-byte aligned)");
+    return WFL_ERR_INVALID;
+  }
+  if (nbytes == 0) return WFL_OK;
+  const int64_t n16 = nbytes / 16;
+  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (n16 + 255) / 256));
+  hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(src_pinned),
+                     reinterpret_cast<uint4*>(dst), n16, nbytes);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

@@ -3,6 +3,7 @@ lattices and the calls into libwfl.so.  torch is plumbing here (device memory + 
 all arithmetic happens in the HIP kernels behind the C ABI (include/wfl.h).
 """
 import ctypes
+import os
 import itertools
 from collections import OrderedDict
 
@@ -167,7 +168,7 @@ class PackedLattice:
         self._host = None
         if cuda:
             blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            blob.copy_(buf[:nbytes], non_blocking=True)
+            upload(blob, buf, nbytes)
             ev = ring.events[slot]
             if ev is None:
                 ev = ring.events[slot] = torch.cuda.Event()
@@ -368,6 +369,8 @@ class side_stream:
         """The current stream waits for everything launched on the side stream so far."""
         cur = torch.cuda.current_stream(self.side.device)
         cur.wait_stream(self.side)
+        if os.environ.get("WFL_NO_RECORD_STREAM"):
+            return
         for t in tensors:
             if t is not None:
                 t.record_stream(cur)
@@ -381,6 +384,8 @@ class side_stream:
     def join_at(self, ev, *tensors):
         """The current stream waits for the side stream only up to `ev` (work launched after it keeps overlapping)."""
         self.cur.wait_event(ev)
+        if os.environ.get("WFL_NO_RECORD_STREAM"):
+            return
         for t in tensors:
             if t is not None:
                 t.record_stream(self.cur)
@@ -467,6 +472,13 @@ def dense_viterbi(x, W):
 # -------------------------------------------------------------------------------------------------
 # CTC fast path
 # -------------------------------------------------------------------------------------------------
+def upload(dst, pinned, nbytes):
+    """dst[:nbytes] (device uint8 tensor) = pinned[:nbytes] (pinned host uint8 tensor) on the current stream, by a
+    kernel that reads the pinned buffer directly (wfl_upload): `copy_(non_blocking=True)` -- hipMemcpyAsync -- from
+    pinned memory intermittently blocks the host until the stream has drained, which serialises host and GPU."""
+    N.check(N.lib.wfl_upload(dst.data_ptr(), pinned.data_ptr(), int(nbytes), stream_ptr()))
+
+
 class _StagingRing:
     """Pinned host buffers through which a batch's targets reach the device in ONE asynchronous copy.  A slot is
     reused only after the copy that last read it has completed (event per slot)."""
@@ -511,7 +523,7 @@ class CtcTargets:
         if device.type == "cuda":
             ring = _STAGING[device.index]
             self.dev_buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self.dev_buf.copy_(host[0][:nbytes], non_blocking=True)
+            upload(self.dev_buf, host[0], nbytes)
             ev = ring.events[slot]
             if ev is None:
                 ev = ring.events[slot] = torch.cuda.Event()
