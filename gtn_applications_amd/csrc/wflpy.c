@@ -6,6 +6,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <string.h>
 
 /* flatten_into(targets, flat_addr, flat_capacity, offsets_addr) -> (total, max_len, min_label, max_label)
  * targets: list/tuple of list/tuple of ints.  Writes int32 labels to flat_addr (capacity in elements) and
@@ -81,9 +82,57 @@ static PyObject* factors_into(PyObject* self, PyObject* args) {
   Py_RETURN_NONE;
 }
 
+/* content_key(addr, nbytes) -> (h1, h2): a 128-bit hash of the staged target bytes (the MurmurHash3 x64_128 mixing
+ * steps), the key of the operator layer's small content cache.  Python's own hash of a 23 KB bytes object costs more
+ * than staging the targets does; a hit is still confirmed byte for byte (same_bytes) before it is used. */
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33, k *= 0xff51afd7ed558ccdULL, k ^= k >> 33, k *= 0xc4ceb9fe1a85ec53ULL, k ^= k >> 33;
+  return k;
+}
+static PyObject* content_key(PyObject* self, PyObject* args) {
+  unsigned long long addr;
+  Py_ssize_t n;
+  if (!PyArg_ParseTuple(args, "Kn", &addr, &n)) return NULL;
+  const uint8_t* p = (const uint8_t*)(uintptr_t)addr;
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  uint64_t h1 = 0x9e3779b97f4a7c15ULL, h2 = 0xd1b54a32d192ed03ULL;
+  const Py_ssize_t nb = n / 16;
+  for (Py_ssize_t i = 0; i < nb; ++i) {
+    uint64_t k1, k2;
+    memcpy(&k1, p + 16 * i, 8), memcpy(&k2, p + 16 * i + 8, 8);
+    k1 *= c1, k1 = rotl64(k1, 31), k1 *= c2, h1 ^= k1;
+    h1 = rotl64(h1, 27), h1 += h2, h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2, k2 = rotl64(k2, 33), k2 *= c1, h2 ^= k2;
+    h2 = rotl64(h2, 31), h2 += h1, h2 = h2 * 5 + 0x38495ab5;
+  }
+  uint64_t t1 = 0, t2 = 0;
+  const Py_ssize_t rem = n - 16 * nb;
+  if (rem > 8) memcpy(&t2, p + 16 * nb + 8, (size_t)(rem - 8));
+  if (rem > 0) memcpy(&t1, p + 16 * nb, (size_t)(rem > 8 ? 8 : rem));
+  t2 *= c2, t2 = rotl64(t2, 33), t2 *= c1, h2 ^= t2;
+  t1 *= c1, t1 = rotl64(t1, 31), t1 *= c2, h1 ^= t1;
+  h1 ^= (uint64_t)n, h2 ^= (uint64_t)n;
+  h1 += h2, h2 += h1;
+  h1 = fmix64(h1), h2 = fmix64(h2);
+  h1 += h2, h2 += h1;
+  return Py_BuildValue("KK", (unsigned long long)h1, (unsigned long long)h2);
+}
+
+/* same_bytes(addr, bytes) -> bool: memcmp of a staged buffer against the bytes a cache entry was made from */
+static PyObject* same_bytes(PyObject* self, PyObject* args) {
+  unsigned long long addr;
+  PyObject* b;
+  if (!PyArg_ParseTuple(args, "KS", &addr, &b)) return NULL;
+  if (memcmp((const void*)(uintptr_t)addr, PyBytes_AS_STRING(b), (size_t)PyBytes_GET_SIZE(b)) == 0) Py_RETURN_TRUE;
+  Py_RETURN_FALSE;
+}
+
 static PyMethodDef methods[] = {
     {"flatten_into", flatten_into, METH_VARARGS, "flatten list-of-int-lists targets into int32 flat + int64 offsets"},
     {"factors_into", factors_into, METH_VARARGS, "per-utterance loss / gradient factors from the offsets"},
+    {"content_key", content_key, METH_VARARGS, "128-bit hash of a staged buffer"},
+    {"same_bytes", same_bytes, METH_VARARGS, "memcmp of a staged buffer against a bytes object"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_wflpy", "operator-layer helpers of gtn_applications_amd", -1,
                                     methods};
