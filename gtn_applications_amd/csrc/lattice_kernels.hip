@@ -1181,8 +1181,6 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
 #pragma unroll
           for (int k = 0; k < DEG; ++k) c[k] = cn[k];
         }
-        cum += ((double)rtile[t - f0] + (double)wref) * kLog2e_d;
-        if (tid == 0) offs[slot_to] = cum;
         lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
       }
     };
@@ -1225,13 +1223,37 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
             out[u.ab_base + (int64_t)slot_to * Q + tid] = p;
           }
         }
-        cum += ((double)rtile[t - f0] + (double)wref) * kLog2e_d;
-        if (tid == 0) offs[slot_to] = cum;
         lds_barrier();
       }
       // (beta: the chunk's last step published plain beta -- no factor past the chunk -- which is what the
       // renormalisation and the next chunk's first step expect)
     };
+    // The chunk's per-slot offsets at once, outside the frame loop (n <= 16 frames): lane i of every row of 16 takes
+    // the chunk's i-th frame in sweep order, an inclusive prefix sum over the row (DPP) gives the offset after each
+    // frame, wave 0 stores them in one instruction.  Inside the loop the same bookkeeping was an LDS read whose wait
+    // sat in front of every frame's barrier.
+    double chunk_log2;
+    {
+      const int li = tid & 15;
+      const float rsel = rtile[(DIR == 0 ? li : n - 1 - li) & 15];
+      double pre = li < n ? ((double)rsel + (double)wref) * kLog2e_d : 0.0;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const int lo = __double2loint(pre), hi = __double2hiint(pre);  // row_shr:o, lanes without a source read 0
+        const int slo = o == 1   ? __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true)
+                        : o == 2 ? __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true)
+                        : o == 4 ? __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true)
+                                 : __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true);
+        const int shi = o == 1   ? __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true)
+                        : o == 2 ? __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true)
+                        : o == 4 ? __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true)
+                                 : __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true);
+        pre += __hiloint2double(shi, slo);
+      }
+      if (tid < n) offs[DIR == 0 ? f0 + tid + 1 : f0 + n - 1 - tid] = cum + pre;
+      chunk_log2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pre), 15),
+                                    __builtin_amdgcn_readlane(__double2loint(pre), 15));  // (lanes >= n added 0)
+    }
     // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
     if (uniform && deg_class == 0)
       frames_uniform(std::integral_constant<int, 2>{});
@@ -1245,6 +1267,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       frames(std::integral_constant<int, 4>{});
     else
       frames(std::integral_constant<int, kLeanDeg>{});
+    cum += chunk_log2;
     if (c + 1 < nchunks) {
       float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
 #pragma unroll
