@@ -143,6 +143,21 @@ def _ctc_loss(log_probs, targets, blank_idx, reduction, fused_log_softmax):
             and log_probs.device.index == torch.cuda.current_device()):
         B, T, C = log_probs.shape
         dev = log_probs.device
+        if type(targets) in (list, tuple):
+            # staging, upload, checks and launch in one native call (csrc/torch_ops.cpp); None: not its case after all
+            lim = (int(blank_idx), reduction == "mean", fused_log_softmax, E.CTC_FAST_MAX_LEN, E.CTC_FAST_MAX_CLASSES,
+                   E.CTC_FAST_MAX_CLASSES_LONG)
+            tok = None if E.PHASE_EVENTS is None else E._mark("ctc_step")
+            if tok is None:
+                loss = node.ctc_loss_lists(log_probs, targets, *lim)
+            else:  # (profiling: the event pair brackets the launch, not the staging)
+                E._EVENT_POOL.append(tok[1])  # (recorded too early: take the start event again after the staging)
+                st = node.stage_lists(targets, log_probs)
+                tok = (tok[0], E._event())
+                loss = node.ctc_loss_staged(log_probs, st, *lim)
+                E._done(tok)
+            if loss is not None:
+                return loss
         tg = E.targets_on_device(targets, dev)
         if E.ctc_fast_path_ok(tg.max_len, C):
             if tg.B != B:

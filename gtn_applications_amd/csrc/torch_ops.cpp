@@ -6,7 +6,13 @@
 // CTCLossFunction.forward / backward, /root/reference/criterions/ctc.py:31-93 -- as a torch::autograd::Function that
 // calls the C ABI of libwfl.so (include/wfl.h) directly.  Host-side plumbing only: no arithmetic happens here.
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 #include <torch/extension.h>
+
+#include <list>
+#include <map>
+#include <string>
+#include <unordered_map>
 
 #include "../../include/wfl.h"
 
@@ -86,6 +92,206 @@ struct CtcStep : public torch::autograd::Function<CtcStep> {
   }
 };
 
+// ------------------------------------------------------------------------------------------------------------
+// Targets of a batch, staged and uploaded without passing through Python objects: what engine.CtcTargets does
+// (flatten list-of-int-lists -> [int64 offsets | int32 labels | six per-utterance factor arrays] in a pinned ring ->
+// one wfl_upload -> small content-keyed cache), for the one operator whose kernels are shorter than that Python code.
+// ------------------------------------------------------------------------------------------------------------
+struct StagedTargets {
+  at::Tensor dev_buf;  // uint8, device
+  std::string key_bytes;  // [offsets | labels] as staged (confirms a cache hit byte for byte)
+  int64_t B = 0, n = 0, max_len = 0, off_flat = 0, off_fac = 0;
+  long label_min = 0, label_max = -1;
+};
+
+struct PinnedRing {  // reusable pinned staging buffers; a slot is reused after the upload that read it has completed
+  static constexpr int kSlots = 8;
+  at::Tensor buf[kSlots];
+  hipEvent_t ev[kSlots] = {};
+  int i = 0;
+  uint8_t* next(int64_t need, int& slot) {
+    slot = i = (i + 1) % kSlots;
+    if (ev[slot]) (void)hipEventSynchronize(ev[slot]);
+    if (!buf[slot].defined() || buf[slot].numel() < need) {
+      int64_t cap = 1 << 18;
+      while (cap < need) cap <<= 1;
+      buf[slot] = at::empty({cap}, at::TensorOptions().dtype(at::kByte).pinned_memory(true));
+    }
+    return buf[slot].data_ptr<uint8_t>();
+  }
+  void uploaded(int slot, hipStream_t stream) {
+    if (!ev[slot]) (void)hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming);
+    (void)hipEventRecord(ev[slot], stream);
+  }
+};
+
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+inline uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33, k *= 0xff51afd7ed558ccdULL, k ^= k >> 33, k *= 0xc4ceb9fe1a85ec53ULL, k ^= k >> 33;
+  return k;
+}
+std::pair<uint64_t, uint64_t> hash128(const uint8_t* p, int64_t n) {  // MurmurHash3 x64_128 mixing steps
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  uint64_t h1 = 0x9e3779b97f4a7c15ULL, h2 = 0xd1b54a32d192ed03ULL;
+  const int64_t nb = n / 16;
+  for (int64_t i = 0; i < nb; ++i) {
+    uint64_t k1, k2;
+    memcpy(&k1, p + 16 * i, 8), memcpy(&k2, p + 16 * i + 8, 8);
+    k1 *= c1, k1 = rotl64(k1, 31), k1 *= c2, h1 ^= k1, h1 = rotl64(h1, 27), h1 += h2, h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2, k2 = rotl64(k2, 33), k2 *= c1, h2 ^= k2, h2 = rotl64(h2, 31), h2 += h1, h2 = h2 * 5 + 0x38495ab5;
+  }
+  uint64_t t1 = 0, t2 = 0;
+  const int64_t rem = n - 16 * nb;
+  if (rem > 8) memcpy(&t2, p + 16 * nb + 8, (size_t)(rem - 8));
+  if (rem > 0) memcpy(&t1, p + 16 * nb, (size_t)(rem > 8 ? 8 : rem));
+  t2 *= c2, t2 = rotl64(t2, 33), t2 *= c1, h2 ^= t2;
+  t1 *= c1, t1 = rotl64(t1, 31), t1 *= c2, h1 ^= t1;
+  h1 ^= (uint64_t)n, h2 ^= (uint64_t)n, h1 += h2, h2 += h1, h1 = fmix64(h1), h2 = fmix64(h2), h1 += h2, h2 += h1;
+  return {h1, h2};
+}
+
+struct TargetCache {  // per device: ring + LRU of the last 64 distinct batches
+  PinnedRing ring;
+  using Key = std::tuple<uint64_t, uint64_t, int64_t>;
+  std::list<std::pair<Key, std::shared_ptr<StagedTargets>>> lru;
+  std::map<Key, decltype(lru)::iterator> index;
+};
+std::unordered_map<int, TargetCache> g_targets;
+
+// -> staged targets, or nullptr if `targets` is not a list / tuple of lists / tuples of ints (the caller falls back)
+std::shared_ptr<StagedTargets> stage_targets(const py::handle& targets, const at::Device& dev) {
+  PyObject* t = targets.ptr();
+  if (!PyList_Check(t) && !PyTuple_Check(t)) return nullptr;
+  const Py_ssize_t B = PySequence_Fast_GET_SIZE(t);
+  PyObject** rows = PySequence_Fast_ITEMS(t);
+  int64_t total = 0, max_len = 0;
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    if (!PyList_Check(rows[b]) && !PyTuple_Check(rows[b])) return nullptr;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(rows[b]);
+    total += n, max_len = std::max<int64_t>(max_len, n);
+  }
+  TargetCache& tc = g_targets[dev.index()];
+  const int64_t off_flat = 8 * (B + 1), off_fac = (off_flat + 4 * std::max<int64_t>(total, 1) + 7) & ~(int64_t)7;
+  const int64_t nbytes = off_fac + 4 * B * 6;
+  int slot;
+  uint8_t* base = tc.ring.next(nbytes + 16, slot);
+  int64_t* off = reinterpret_cast<int64_t*>(base);
+  int32_t* flat = reinterpret_cast<int32_t*>(base + off_flat);
+  long lo = 0, hi = -1;
+  bool first = true;
+  int64_t k = 0;
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(rows[b]);
+    PyObject** it = PySequence_Fast_ITEMS(rows[b]);
+    off[b] = k;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+      const long v = PyLong_AsLong(it[i]);
+      if (v == -1 && PyErr_Occurred()) {
+        PyErr_Clear();
+        tc.ring.i = (tc.ring.i + PinnedRing::kSlots - 1) % PinnedRing::kSlots;  // slot not used
+        return nullptr;  // not ints: the Python path normalises (tensors, numpy ints, ranges)
+      }
+      if (v > INT32_MAX || v < INT32_MIN) throw py::value_error("target label does not fit int32");
+      if (first || v < lo) lo = v;
+      if (first || v > hi) hi = v;
+      first = false;
+      flat[k++] = (int32_t)v;
+    }
+  }
+  off[B] = k;
+  const int64_t nkey = off_flat + 4 * total;
+  const auto h = hash128(base, nkey);
+  const TargetCache::Key key{h.first, h.second, nkey};
+  auto hit = tc.index.find(key);
+  if (hit != tc.index.end() && (int64_t)hit->second->second->key_bytes.size() == nkey &&
+      memcmp(hit->second->second->key_bytes.data(), base, (size_t)nkey) == 0) {
+    tc.lru.splice(tc.lru.begin(), tc.lru, hit->second);
+    tc.ring.i = (tc.ring.i + PinnedRing::kSlots - 1) % PinnedRing::kSlots;  // nothing was uploaded from the slot
+    return hit->second->second;
+  }
+  // per-utterance factors (engine._FACTORS order): scale_none, scale_mean, then both times +1/B and -1/B
+  float* fac = reinterpret_cast<float*>(base + off_fac);
+  const float inv_b = 1.0f / (float)(B > 0 ? B : 1);
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    const float ln = (float)(off[b + 1] - off[b]);
+    const float mean = ln > 0.f ? 1.0f / ln : 1.0f;
+    fac[b] = 1.0f, fac[B + b] = mean, fac[2 * B + b] = inv_b, fac[3 * B + b] = mean * inv_b;
+    fac[4 * B + b] = -inv_b, fac[5 * B + b] = mean * -inv_b;
+  }
+  auto st = std::make_shared<StagedTargets>();
+  st->B = B, st->n = total, st->max_len = max_len, st->off_flat = off_flat, st->off_fac = off_fac;
+  st->label_min = lo, st->label_max = hi;
+  st->key_bytes.assign(reinterpret_cast<const char*>(base), (size_t)nkey);
+  st->dev_buf = at::empty({nbytes}, at::TensorOptions().dtype(at::kByte).device(dev));
+  const hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+  check(wfl_upload(st->dev_buf.data_ptr(), base, nbytes, (void*)stream), "stage_targets");
+  tc.ring.uploaded(slot, stream);
+  if (hit != tc.index.end()) {  // (same hash, different bytes: replace)
+    tc.lru.erase(hit->second);
+    tc.index.erase(hit);
+  }
+  tc.lru.emplace_front(key, st);
+  tc.index[key] = tc.lru.begin();
+  if (tc.lru.size() > 64) {
+    tc.index.erase(tc.lru.back().first);
+    tc.lru.pop_back();
+  }
+  return st;
+}
+
+struct WsKey {
+  int dev;
+  void* stream;
+  int64_t B, T, C, L;
+  bool operator<(const WsKey& o) const { return std::tie(dev, stream, B, T, C, L) < std::tie(o.dev, o.stream, o.B, o.T, o.C, o.L); }
+};
+std::map<WsKey, std::pair<at::Tensor, at::Tensor>> g_ws;  // (engine.ctc_workspace: scratch + nll per stream and shape)
+
+// CTCLoss(log_probs, targets, blank, reduction) for the hot case, everything between the Python call and the launch
+// in this one function.  Returns None when the case is not the hot one (the caller takes the Python path).
+py::object ctc_loss_staged(const at::Tensor& x, const std::shared_ptr<StagedTargets>& st, int64_t blank, bool mean,
+                           bool fused_lse, int64_t lim_len, int64_t lim_c, int64_t lim_c_long) {
+  const auto B = x.size(0), T = x.size(1), C = x.size(2);
+  if (!st) return py::none();
+  if (!(st->max_len <= lim_len && C <= (st->max_len <= 63 ? lim_c : lim_c_long))) return py::none();
+  if (st->B != B) throw py::value_error("got " + std::to_string(st->B) + " targets for a batch of " + std::to_string(B));
+  if (st->label_min < 0 || st->label_max >= C) {
+    const long bad = st->label_min < 0 ? st->label_min : st->label_max;
+    throw py::value_error("CTCLoss: target label " + std::to_string(bad) + " is outside [0, " + std::to_string(C) +
+                          ") (emissions have " + std::to_string(C) + " classes)");
+  }
+  if (blank < 0 || blank >= C)
+    throw py::value_error("CTCLoss: blank index " + std::to_string(blank) + " is outside [0, " + std::to_string(C) + ")");
+  void* stream = current_stream(x);
+  const WsKey wk{x.device().index(), stream, B, T, C, st->max_len};
+  auto w = g_ws.find(wk);
+  if (w == g_ws.end()) {
+    int64_t n = 0;
+    check(wfl_ctc_workspace((int)B, (int)T, (int)C, (int)st->max_len, &n), "ctc_workspace");
+    if (g_ws.size() >= 16) g_ws.clear();
+    w = g_ws.emplace(wk, std::make_pair(at::empty({n}, x.options()), at::empty({B}, x.options()))).first;
+  }
+  c10::optional<at::Tensor> lse;
+  if (fused_lse) {
+    lse = at::empty({B, T}, x.options());
+    check(wfl_row_lse(x.data_ptr<float>(), B * T, (int)C, lse->data_ptr<float>(), stream), "row_lse");
+  }
+  const int64_t fac = st->off_fac + 4 * B * (mean ? 1 : 0);  // scale_<reduction>; cneg_<reduction> is 4 arrays on
+  return py::cast(CtcStep::apply(x, st->dev_buf, 0, st->off_flat, fac, fac + 16 * B, st->max_len, blank, w->second.first,
+                                 w->second.second, lse));
+}
+
+// CTCLoss(log_probs, targets, blank, reduction) for the hot case, everything between the Python call and the launch
+// in this one function.  Returns None when the case is not the hot one (the caller takes the Python path).
+py::object ctc_loss_lists(const at::Tensor& x, const py::handle& targets, int64_t blank, bool mean, bool fused_lse,
+                          int64_t lim_len, int64_t lim_c, int64_t lim_c_long) {
+  return ctc_loss_staged(x, stage_targets(targets, x.device()), blank, mean, fused_lse, lim_len, lim_c, lim_c_long);
+}
+
+std::shared_ptr<StagedTargets> stage_lists(const py::handle& targets, const at::Tensor& like) {
+  return stage_targets(targets, like.device());
+}
+
 at::Tensor ctc_step(const at::Tensor& x, const at::Tensor& staged, int64_t off_offsets, int64_t off_flat,
                     int64_t off_scale, int64_t off_coef, int64_t max_len, int64_t blank, const at::Tensor& ws,
                     const at::Tensor& nll, const c10::optional<at::Tensor>& lse) {
@@ -96,4 +302,12 @@ at::Tensor ctc_step(const at::Tensor& x, const at::Tensor& staged, int64_t off_o
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ctc_step", &ctc_step, "CTC loss + eager gradient in one pipelined launch (C++ autograd node)");
+  py::class_<StagedTargets, std::shared_ptr<StagedTargets>>(m, "StagedTargets")
+      .def_readonly("B", &StagedTargets::B)
+      .def_readonly("n", &StagedTargets::n)
+      .def_readonly("max_len", &StagedTargets::max_len);
+  m.def("stage_lists", &stage_lists, "stage + upload list-of-int-list targets (None if they are something else)");
+  m.def("ctc_loss_staged", &ctc_loss_staged, "the second half of ctc_loss_lists (profiling: bracket the launch alone)");
+  m.def("ctc_loss_lists", &ctc_loss_lists,
+        "CTCLoss for list-of-int-list targets: staging, upload, checks and the pipelined launch in one native call");
 }

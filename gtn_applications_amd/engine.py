@@ -72,6 +72,8 @@ def flatten_targets(targets):
 # each launch goes to: entries are (phase name, start event, end event).  None (the default) costs one test.
 PHASE_EVENTS = None
 PHASE_ONLY = None  # optional set of phase names: the only ones recorded (bench.py's timed region records one)
+PHASE_STRIDE = 1   # record every PHASE_STRIDE-th launch of a phase (an event pair costs the step ~10 us)
+_PHASE_COUNT = {}
 
 
 _EVENT_POOL = []
@@ -92,6 +94,10 @@ def _event():
 def _mark(name):
     if PHASE_EVENTS is None or (PHASE_ONLY is not None and name not in PHASE_ONLY):
         return None
+    if PHASE_STRIDE > 1:
+        k = _PHASE_COUNT[name] = _PHASE_COUNT.get(name, 0) + 1
+        if k % PHASE_STRIDE:
+            return None
     return name, _event()
 
 
