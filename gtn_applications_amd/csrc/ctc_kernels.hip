@@ -1546,13 +1546,19 @@ __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_
     ctc_fast_chain_body<true, LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<FastLdsT*>(smem));
     return;
   }
+  // Gradient waves are persistent: a wave takes item after item (stride: all gradient waves of the launch), in
+  // readiness order -- the middle blocks of every utterance first, their checkpoints exist at half time.  With one
+  // item per wave and more items than resident waves, the second half of the items waited for workgroup slots and
+  // then paid their start-up (dispatch, three dependent loads) after the chains had finished.
   const int NB = ctc_blocks(a.T);
-  const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - nchain) * kFWaves + (int)(threadIdx.x >> 6));
-  if (item >= a.B * NB) return;
-  const int r = item / a.B, b = item % a.B;  // r: rank in readiness order
   const int mid = (NB - 1) / 2;
-  const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-  ctc_fast_grad_body<LSM, true, COMPACT>(a, true, b, k, coef, gout, dx, smem);
+  const int nwaves = (int)(gridDim.x - nchain) * kFWaves;
+  for (int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - nchain) * kFWaves + (int)(threadIdx.x >> 6));
+       item < a.B * NB; item += nwaves) {
+    const int r = item / a.B, b = item % a.B;  // r: rank in readiness order
+    const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+    ctc_fast_grad_body<LSM, true, COMPACT>(a, true, b, k, coef, gout, dx, smem);
+  }
 }
 
 #ifdef WFL_DBG_GRADONLY  // (register counts of the two halves alone: hipcc -S -DWFL_DBG_GRADONLY)
@@ -2196,7 +2202,26 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
     const size_t lds = std::max(compact ? compact_lds : rows8_lds, sizeof(FastLdsT));
     static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)
-    const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : (items + kFWaves - 1) / kFWaves)));
+    // gradient workgroups: one item per wave, or -- small batches, where the launch is latency-bound and all chains
+    // plus a full complement of gradient workgroups are resident at once (three workgroups per CU) -- as many
+    // workgroups as there are free slots, their waves looping over the items (WFL_CTC_GRAD_WGS: 0 = one item per
+    // wave, n = that many workgroups)
+    static const int n_cus = [] {
+      int dev = 0, n = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return n > 0 ? n : 256;
+    }();
+    static const int grad_wgs_env = [] {
+      const char* e = getenv("WFL_CTC_GRAD_WGS");
+      return e ? atoi(e) : -1;
+    }();
+    const int64_t all_wgs = (items + kFWaves - 1) / kFWaves;
+    int64_t grad_wgs = all_wgs;
+    if (grad_wgs_env > 0)
+      grad_wgs = std::min<int64_t>(all_wgs, grad_wgs_env);
+    else if (grad_wgs_env < 0 && 2 * (int64_t)B <= 3 * n_cus / 2)
+      grad_wgs = std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
+    const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : grad_wgs)));
     auto launch_fast = [&](auto kern) -> int {
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid8, dim3(kFWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
