@@ -518,7 +518,7 @@ class CtcTargets:
     of 1-D tensors by one torch.cat."""
 
     __slots__ = ("max_len", "B", "dev_buf", "cache", "label_min", "label_max", "n", "_off_flat", "_off_fac", "_key",
-                 "_lens")
+                 "_lens", "_uploaded")
 
     def __init__(self, targets, device, flat=None, lens=None, _staged=None):
         self.cache = {}  # derived device objects (factor views, packed lattices), keyed by the caller
@@ -535,8 +535,12 @@ class CtcTargets:
             if ev is None:
                 ev = ring.events[slot] = torch.cuda.Event()
             ev.record()
+            # (a later user on ANOTHER stream orders itself behind the upload: targets_on_device; the slot's event
+            # may be re-recorded by then -- later on this same stream, which is still behind the upload)
+            self._uploaded = (stream_ptr(), ev)
         else:  # host-only uses (tests of the packers): same layout, no device
             self.dev_buf = torch.from_numpy(view[:nbytes].copy())
+            self._uploaded = None
 
     # host copies of the staged content (the key bytes hold offsets and labels back to back)
     @property
@@ -802,6 +806,8 @@ def targets_on_device(targets, device):
     hit = data.get(st[-1])
     if hit is not None and _wflpy.same_bytes(st[1][0].data_ptr(), hit._key[0]):
         data.move_to_end(st[-1])
+        if hit._uploaded is not None and hit._uploaded[0] != stream_ptr():
+            torch.cuda.current_stream().wait_event(hit._uploaded[1])
         return hit
     val = data[st[-1]] = CtcTargets(None, device, _staged=st)
     data.move_to_end(st[-1])
