@@ -2152,7 +2152,11 @@ int wfl_scale(float* v, int64_t n, const float* s, void* stream) {
     return WFL_ERR_INVALID;
   }
   if (n == 0) return WFL_OK;
-  hipLaunchKernelGGL(scale_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, v, n / 4, n, s);
+  // (grid-stride; 512 workgroups keep 2 MB in flight -- enough for HBM speed when there is something to scale -- and
+  // cost half of what 2048 did when s[0] == 1 and every workgroup returns at once: that launch sits on the critical
+  // path of every backward of a scalar loss)
+  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512, (n / 4 + 255) / 256));
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, n / 4, n, s);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }
