@@ -317,7 +317,8 @@ def timed_loop(step, steps, warmup, fence, collect_events):
     """-> (seconds of the timed region, ms per step of the dominant kernel group measured INSIDE it, ms per step of every
     group measured during warm-up).  HIP events around every launch perturb the step (each record is a packet on the
     stream, ~5 us on the critical path), so the timed region brackets only the dominant group -- found during the
-    warm-up steps, which bracket them all -- and, from 64 steps on, only every 8th of its launches."""
+    warm-up steps, which bracket them all -- and only every 8th of its launches (every 4th below 32 steps, all of them
+    below 8)."""
     from gtn_applications_amd import engine as E
 
     def collect(events, n):
@@ -342,7 +343,8 @@ def timed_loop(step, steps, warmup, fence, collect_events):
     # (--warmup 0: nothing to calibrate on, every group is bracketed inside the timed region)
     E.PHASE_EVENTS = [] if collect_events else None
     E.PHASE_ONLY = {max(warm, key=warm.get)} if warm else None
-    E.PHASE_STRIDE = 8 if (warm and steps >= 64) else 1  # bracket every 8th launch of the dominant group
+    # bracket every 8th (short runs: 4th) launch of the dominant group
+    E.PHASE_STRIDE = (8 if steps >= 32 else 4 if steps >= 8 else 1) if warm else 1
     E._PHASE_COUNT.clear()
     if collect_events and not warm:
         E.prealloc_events(16 * steps)
