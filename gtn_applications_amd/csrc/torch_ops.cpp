@@ -7,6 +7,7 @@
 // calls the C ABI of libwfl.so (include/wfl.h) directly.  Host-side plumbing only: no arithmetic happens here.
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
+#include <torch/csrc/autograd/python_variable.h>
 #include <torch/extension.h>
 
 #include <list>
@@ -166,10 +167,22 @@ std::shared_ptr<StagedTargets> stage_targets(const py::handle& targets, const at
   if (!PyList_Check(t) && !PyTuple_Check(t)) return nullptr;
   const Py_ssize_t B = PySequence_Fast_GET_SIZE(t);
   PyObject** rows = PySequence_Fast_ITEMS(t);
+  // rows: lists / tuples of ints (the benchmarks, `[t.tolist() for t in targets]`) or 1-D CPU int tensors (train.py)
+  auto tensor_row = [](PyObject* r) -> const at::Tensor* {
+    if (!THPVariable_Check(r)) return nullptr;
+    const at::Tensor& v = THPVariable_Unpack(r);
+    const bool ok = v.dim() == 1 && v.device().is_cpu() && (v.scalar_type() == at::kLong || v.scalar_type() == at::kInt);
+    return ok ? &v : nullptr;
+  };
   int64_t total = 0, max_len = 0;
   for (Py_ssize_t b = 0; b < B; ++b) {
-    if (!PyList_Check(rows[b]) && !PyTuple_Check(rows[b])) return nullptr;
-    const Py_ssize_t n = PySequence_Fast_GET_SIZE(rows[b]);
+    int64_t n;
+    if (PyList_Check(rows[b]) || PyTuple_Check(rows[b]))
+      n = PySequence_Fast_GET_SIZE(rows[b]);
+    else if (const at::Tensor* v = tensor_row(rows[b]))
+      n = v->numel();
+    else
+      return nullptr;
     total += n, max_len = std::max<int64_t>(max_len, n);
   }
   TargetCache& tc = g_targets[dev.index()];
@@ -182,22 +195,36 @@ std::shared_ptr<StagedTargets> stage_targets(const py::handle& targets, const at
   long lo = 0, hi = -1;
   bool first = true;
   int64_t k = 0;
+  auto put = [&](long v) {
+    if (v > INT32_MAX || v < INT32_MIN) throw py::value_error("target label does not fit int32");
+    if (first || v < lo) lo = v;
+    if (first || v > hi) hi = v;
+    first = false;
+    flat[k++] = (int32_t)v;
+  };
   for (Py_ssize_t b = 0; b < B; ++b) {
+    off[b] = k;
+    if (const at::Tensor* v = tensor_row(rows[b])) {
+      const int64_t n = v->numel(), st = n ? v->stride(0) : 1;
+      if (v->scalar_type() == at::kLong) {
+        const int64_t* p = v->data_ptr<int64_t>();
+        for (int64_t i = 0; i < n; ++i) put((long)p[i * st]);
+      } else {
+        const int32_t* p = v->data_ptr<int32_t>();
+        for (int64_t i = 0; i < n; ++i) put((long)p[i * st]);
+      }
+      continue;
+    }
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(rows[b]);
     PyObject** it = PySequence_Fast_ITEMS(rows[b]);
-    off[b] = k;
     for (Py_ssize_t i = 0; i < n; ++i) {
       const long v = PyLong_AsLong(it[i]);
       if (v == -1 && PyErr_Occurred()) {
         PyErr_Clear();
         tc.ring.i = (tc.ring.i + PinnedRing::kSlots - 1) % PinnedRing::kSlots;  // slot not used
-        return nullptr;  // not ints: the Python path normalises (tensors, numpy ints, ranges)
+        return nullptr;  // not ints: the Python path normalises (numpy ints, ranges, ...)
       }
-      if (v > INT32_MAX || v < INT32_MIN) throw py::value_error("target label does not fit int32");
-      if (first || v < lo) lo = v;
-      if (first || v > hi) hi = v;
-      first = false;
-      flat[k++] = (int32_t)v;
+      put(v);
     }
   }
   off[B] = k;

@@ -81,6 +81,13 @@ def test_ctc_cpp_autograd_node_is_the_python_operator(crit, reduction):
     x1.grad = None
     (l1 * w).sum().backward()  # second backward: the launch runs again
     close(x1.grad, g1.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # targets as 1-D CPU tensors (what train.py hands over): int64, and a strided int32 view
+    x3 = dev(xs, grad=True)
+    l3 = ctc.CTCLoss(x3, [torch.tensor(t, dtype=torch.long) for t in targets], C - 1, reduction)
+    assert "CtcStep" in l3.grad_fn.name() and torch.equal(l3, l1)
+    x4 = dev(xs, grad=True)
+    wide = [torch.tensor([v for u in t for v in (u, -7)], dtype=torch.int32)[::2] for t in targets]
+    assert torch.equal(ctc.CTCLoss(x4, wide, C - 1, reduction), l1)
     # module with the fused log_softmax
     raw = rs.randn(B, T, C).astype(np.float32)
     r1, r2 = dev(raw, grad=True), dev(raw, grad=True)
