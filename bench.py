@@ -50,7 +50,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s ac
 
 # which kernels run inside each timed phase of engine.PHASE_EVENTS (short names as rocprofv3 reports them)
 PHASE_KERNEL_NAMES = {
-    "ctc_step": ["ctc_fast_pipelined_kernel", "ctc_repair_kernel"],
+    "ctc_step": ["ctc_compact_x_kernel", "ctc_fast_pipelined_kernel", "ctc_repair_kernel"],
     "ctc_chains": ["ctc_log_chain_kernel"],
     "ctc_grad": ["reduce_loss_kernel", "ctc_grad_kernel"],
     "lattice_gather": ["gather_lse_kernel", "gather_kernel"],
@@ -62,7 +62,8 @@ PHASE_KERNEL_NAMES = {
     "dense_chain": ["dense_fast_chain_kernel", "dense_chain_kernel"],
     "dense_grad": ["dense_fast_grad_kernel", "dense_reduce_kernel"],
 }
-PHASE_KERNELS = {k: " + ".join(v) + (" (transitions graph)" if k.endswith("/shared") else "") for k, v in PHASE_KERNEL_NAMES.items()}
+PHASE_KERNELS = {k: " + ".join(n for n in v if n != "ctc_compact_x_kernel") + (" (transitions graph)" if k.endswith("/shared") else "")
+                 for k, v in PHASE_KERNEL_NAMES.items()}  # (the compact pre-pass only runs for wide rows beyond the cache)
 
 
 def parse():

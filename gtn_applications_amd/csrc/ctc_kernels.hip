@@ -124,7 +124,11 @@ struct CtcArgs {
   // torch.nn.functional.log_softmax of ctc.py:107 (forward: subtracted at the gather; backward: the rows
   // start at -cf * softmax(x) because the posteriors of a frame sum to one)
   const float* row_lse;
+  // fast pipelined step, optional: xc[b][t][kXcStride] = the emissions the sweeps gather -- slot i = x[b][t][y_i]
+  // (target position i), slot L = x[b][t][blank] -- written by ctc_compact_x_kernel (see wfl_ctc_forward_backward)
+  const float* xc;
 };
+constexpr int kXcStride = 64;
 
 // ---- pieces shared by the chains of the pipelined launches -------------------------------------------
 __device__ __forceinline__ void coherent_store64(void* p, unsigned long long v) {
@@ -562,6 +566,11 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
   const bool skip = has_label && lane >= 1 && y != yprev;
   const float* xrow = a.x + (int64_t)b * T * C;
   const int col = has_label ? y : a.blank;
+  // where this lane's emission of a frame comes from: its column of x, or its slot of the compact copy (the beta
+  // sweep's lanes hold the target mirrored).  Selected without a branch: a load inside one is waited for on its own.
+  const float* esrc = a.xc ? a.xc + (int64_t)b * T * kXcStride : xrow;
+  const int estride = a.xc ? kXcStride : C;
+  const int eidx = a.xc ? (has_label ? (dir == 0 ? lane : L - 1 - lane) : L) : col;
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   const int NB = ctc_blocks(T);
   if (!SIGNAL && dir == 0 && threadIdx.x == 0) ((int32_t*)(a.ws + w.flag))[b] = 0;
@@ -585,7 +594,7 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) {
         const int t = dir == 0 ? t0 + j : t0 + cnt - 1 - j;
-        raw[j] = (WFL_DBG_FAST & 4) ? 0.01f * t : xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
+        raw[j] = (WFL_DBG_FAST & 4) ? 0.01f * t : esrc[(int64_t)min(max(t, 0), T - 1) * estride + eidx];  // clamped: valid address, unused past the block
       }
       if (LSM) {
         const int t = dir == 0 ? t0 + (lane & 15) : t0 + cnt - 1 - (lane & 15);
@@ -1271,6 +1280,9 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
   const int col = has_label ? y : a.blank;
   const float* xrow = a.x + (int64_t)b * T * C;
+  const float* esrc = a.xc ? a.xc + (int64_t)b * T * kXcStride : xrow;  // (see ctc_fast_chain_body)
+  const int estride = a.xc ? kXcStride : C;
+  const int eidx = a.xc ? (has_label ? lane : L) : col;
 
   // ---- the two checkpoints: a block of a later round finds them published when it starts -- their loads then
   // travel together with the gathers instead of after them
@@ -1311,7 +1323,7 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   {
     float xs[kBlk];
 #pragma unroll
-    for (int j = 0; j < kBlk; ++j) xs[j] = xrow[(int64_t)min(t0 + j, T - 1) * C + col];  // all 16 gathers in flight
+    for (int j = 0; j < kBlk; ++j) xs[j] = esrc[(int64_t)min(t0 + j, T - 1) * estride + eidx];  // all 16 gathers in flight
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {
       const float v = (LSM ? xs[j] - readlane_f(lse_blk, j) : xs[j]) * kLog2e;
@@ -1521,6 +1533,33 @@ __global__ void __launch_bounds__(256)
   const int mid = (NB - 1) / 2;
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
   ctc_grad_body<true, LSM, COMPACT>(a, valid, b, k, coef, gout, dx, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compact copy of the emissions the sweeps gather (wide rows, inputs beyond the Infinity Cache): one pass over x
+// leaves, per frame, the <= 64 scores the alpha chains, the beta chains and the gradient blocks each gather --
+// three passes over x (a 45-label gather touches three quarters of the lines of a 2-KB row) become one, the other
+// two read 256 contiguous bytes per frame.  One wave per row, kXcRows rows per iteration with their loads in flight.
+// ------------------------------------------------------------------------------------------------
+constexpr int kXcRows = 8;
+__global__ void __launch_bounds__(256)
+    ctc_compact_x_kernel(const float* __restrict__ x, const int32_t* __restrict__ targets,
+                         const int64_t* __restrict__ offsets, int T, int C, int blank, float* __restrict__ xc) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int64_t o0 = offsets[b];
+  const int L = (int)(offsets[b + 1] - o0);
+  const int col = lane < L ? targets[o0 + lane] : blank;
+  const float* xrow = x + (int64_t)b * T * C;
+  float* dst = xc + (int64_t)b * T * kXcStride;
+  const int nw = gridDim.x * 4;
+  for (int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kXcRows; t0 < T; t0 += nw * kXcRows) {
+    float v[kXcRows];
+#pragma unroll
+    for (int u = 0; u < kXcRows; ++u) v[u] = xrow[(int64_t)min(t0 + u, T - 1) * C + col];
+#pragma unroll
+    for (int u = 0; u < kXcRows; ++u)
+      if (t0 + u < T) dst[(int64_t)(t0 + u) * kXcStride + lane] = v[u];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2094,13 +2133,24 @@ static int ctc_check(int B, int T, int C, int max_len, int blank, const char* wh
   return WFL_OK;
 }
 
+// The compact emission copy pays when x does not stay in the Infinity Cache between the three sweeps (256 MiB) and
+// its rows are wide enough for a 45-label gather to waste most of what it touches.  WFL_CTC_COMPACT_X=0|1 overrides.
+static bool ctc_use_xc(int B, int T, int C, int max_len) {
+  static const int force = [] {
+    const char* e = getenv("WFL_CTC_COMPACT_X");
+    return e ? atoi(e) : -1;
+  }();
+  if (max_len + 1 > 64) return false;  // (the lane-exponent step: one target position per lane)
+  if (force >= 0) return force != 0;
+  return (int64_t)B * T * C * 4 >= (192ll << 20) && C >= 192;
+}
+
 int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems) {
   if (!ws_elems || B <= 0 || T <= 0 || max_len < 0) {
     set_error("ctc_workspace: bad arguments");
     return WFL_ERR_INVALID;
   }
-  (void)C;
-  *ws_elems = ctc_ws_layout(B, T, max_len + 1).total;
+  *ws_elems = ctc_ws_layout(B, T, max_len + 1).total + (ctc_use_xc(B, T, C, max_len) ? 4 + (int64_t)B * T * kXcStride : 0);
   return WFL_OK;
 }
 
@@ -2222,6 +2272,16 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     else if (grad_wgs_env < 0 && 2 * (int64_t)B <= 3 * n_cus / 2)
       grad_wgs = std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
     const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : grad_wgs)));
+    if (ctc_use_xc(B, T, C, max_len)) {
+      float* xc = ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3);
+      // (a streaming variant -- coalesced float4 rows through an LDS tile -- is no faster: 141 vs 143 us at cfg5.  The
+      // pass also absorbs the write-back of the previous step's gradient, still dirty in the Infinity Cache.)
+      const unsigned gx = (unsigned)std::max(1, std::min((T + 4 * kXcRows - 1) / (4 * kXcRows), 64));
+      hipLaunchKernelGGL(ctc_compact_x_kernel, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, targets, offsets,
+                         T, C, blank, xc);
+      WFL_LAUNCH_CHECK();
+      a.xc = xc;
+    }
     auto launch_fast = [&](auto kern) -> int {
       WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid8, dim3(kFWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
