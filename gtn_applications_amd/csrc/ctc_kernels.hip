@@ -552,7 +552,7 @@ __device__ __forceinline__ void lds_post(int* p, int v) {
 // entirely (16 gathers issued six chain blocks ahead of their use, one reference per FRAME), the chain
 // wave only multiplies and adds, and the flusher turns the raw (mantissa, exponent) checkpoints into
 // the log2 format of the gradient kernel.
-template <bool SIGNAL, bool LSM = false>
+template <bool SIGNAL, bool LSM = false, bool XC = false>  // XC: emissions from the compact copy (CtcArgs::xc)
 __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int dir, FastLdsT& S) {
   // (wave index as a scalar: block numbers, frame numbers and row addresses of the helpers then live in SGPRs)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -567,10 +567,10 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
   const float* xrow = a.x + (int64_t)b * T * C;
   const int col = has_label ? y : a.blank;
   // where this lane's emission of a frame comes from: its column of x, or its slot of the compact copy (the beta
-  // sweep's lanes hold the target mirrored).  Selected without a branch: a load inside one is waited for on its own.
-  const float* esrc = a.xc ? a.xc + (int64_t)b * T * kXcStride : xrow;
-  const int estride = a.xc ? kXcStride : C;
-  const int eidx = a.xc ? (has_label ? (dir == 0 ? lane : L - 1 - lane) : L) : col;
+  // sweep's lanes hold the target mirrored).  A template parameter: the step's hot kernel is at its 80-register cap.
+  const float* esrc = XC ? a.xc + (int64_t)b * T * kXcStride : xrow;
+  const int estride = XC ? kXcStride : C;
+  const int eidx = XC ? (has_label ? (dir == 0 ? lane : L - 1 - lane) : L) : col;
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   const int NB = ctc_blocks(T);
   if (!SIGNAL && dir == 0 && threadIdx.x == 0) ((int32_t*)(a.ws + w.flag))[b] = 0;
@@ -1242,7 +1242,7 @@ __device__ __forceinline__ void fmac2_shl1(float& acc, float s0, float s1, float
 //   Z_local = sum_s alpha_{n-1}(s) [A beta~_n](s)  (relative to the checkpoints' offsets and the
 //   block's references); posterior = ma mb' K(s) with K(s) = 2^(ea + eb - E) / Zm folded into ma.
 // ------------------------------------------------------------------------------------------------
-template <bool LSM, bool CERT, bool COMPACT = false>
+template <bool LSM, bool CERT, bool COMPACT = false, bool XC = false>
 __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
                                                    const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1280,9 +1280,9 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
   const int col = has_label ? y : a.blank;
   const float* xrow = a.x + (int64_t)b * T * C;
-  const float* esrc = a.xc ? a.xc + (int64_t)b * T * kXcStride : xrow;  // (see ctc_fast_chain_body)
-  const int estride = a.xc ? kXcStride : C;
-  const int eidx = a.xc ? (has_label ? lane : L) : col;
+  const float* esrc = XC ? a.xc + (int64_t)b * T * kXcStride : xrow;  // (see ctc_fast_chain_body)
+  const int estride = XC ? kXcStride : C;
+  const int eidx = XC ? (has_label ? lane : L) : col;
 
   // ---- the two checkpoints: a block of a later round finds them published when it starts -- their loads then
   // travel together with the gathers instead of after them
@@ -1569,7 +1569,7 @@ __global__ void __launch_bounds__(256)
 // utterances -- chains and gradient -- in the log domain.  On data the fast chains can represent the
 // repair launch exits at once.
 // ------------------------------------------------------------------------------------------------
-template <bool LSM, bool COMPACT>
+template <bool LSM, bool COMPACT, bool XC = false>
 __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_eu(6, 6)))  // <= 80 VGPRs: three workgroups per CU
     ctc_fast_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
                               float* __restrict__ dx) {
@@ -1582,7 +1582,7 @@ __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_
       perr[1] = 0;  // utterances the repair launch recomputed
     }
     if (threadIdx.x >= 64) __builtin_amdgcn_s_setprio(2);  // (the chain wave raises itself to 3)
-    ctc_fast_chain_body<true, LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<FastLdsT*>(smem));
+    ctc_fast_chain_body<true, LSM, XC>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<FastLdsT*>(smem));
     return;
   }
   // Gradient waves are persistent: a wave takes item after item (stride: all gradient waves of the launch), in
@@ -1596,7 +1596,7 @@ __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_
        item < a.B * NB; item += nwaves) {
     const int r = item / a.B, b = item % a.B;  // r: rank in readiness order
     const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-    ctc_fast_grad_body<LSM, true, COMPACT>(a, true, b, k, coef, gout, dx, smem);
+    ctc_fast_grad_body<LSM, true, COMPACT, XC>(a, true, b, k, coef, gout, dx, smem);
   }
 }
 
@@ -2272,7 +2272,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     else if (grad_wgs_env < 0 && 2 * (int64_t)B <= 3 * n_cus / 2)
       grad_wgs = std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
     const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : grad_wgs)));
-    if (ctc_use_xc(B, T, C, max_len)) {
+    if (compact && ctc_use_xc(B, T, C, max_len)) {  // (wide rows: they use the compact gradient tile)
       float* xc = ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3);
       // (a streaming variant -- coalesced float4 rows through an LDS tile -- is no faster: 141 vs 143 us at cfg5.  The
       // pass also absorbs the write-back of the previous step's gradient, still dirty in the Infinity Cache.)
@@ -2287,8 +2287,9 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       hipLaunchKernelGGL(kern, grid8, dim3(kFWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
       return WFL_OK;
     };
-    rc = compact ? (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, true>) : launch_fast(ctc_fast_pipelined_kernel<false, true>))
-                 : (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, false>) : launch_fast(ctc_fast_pipelined_kernel<false, false>));
+    rc = a.xc ? (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, true, true>) : launch_fast(ctc_fast_pipelined_kernel<false, true, true>))
+         : compact ? (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, true>) : launch_fast(ctc_fast_pipelined_kernel<false, true>))
+                   : (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, false>) : launch_fast(ctc_fast_pipelined_kernel<false, false>));
     if (rc) return rc;
     WFL_LAUNCH_CHECK();
     a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
