@@ -127,6 +127,7 @@ struct CtcArgs {
   // fast pipelined step, optional: xc[b][t][kXcStride] = the emissions the sweeps gather -- slot i = x[b][t][y_i]
   // (target position i), slot L = x[b][t][blank] -- written by ctc_compact_x_kernel (see wfl_ctc_forward_backward)
   const float* xc;
+  int place;  // fast pipelined step: 1 = keep an utterance's chains and gradient items on one XCD (speed only)
 };
 constexpr int kXcStride = 64;
 
@@ -1582,7 +1583,15 @@ __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_
       perr[1] = 0;  // utterances the repair launch recomputed
     }
     if (threadIdx.x >= 64) __builtin_amdgcn_s_setprio(2);  // (the chain wave raises itself to 3)
-    ctc_fast_chain_body<true, LSM, XC>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<FastLdsT*>(smem));
+    // XCD placement (speed only): workgroup i is observed to run on XCD i % 8, and every XCD has its own L2.  The two
+    // chains and all gradient items of an utterance are kept on ONE XCD (utterance b on XCD b % 8), so that x[b], the
+    // checkpoints and the flags of b are fetched into one L2 instead of up to eight.
+    int b = (int)blockIdx.x >> 1, dir = (int)blockIdx.x & 1;
+    if (a.place) {
+      const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+      b = (slot >> 1) * 8 + xcd, dir = slot & 1;
+    }
+    ctc_fast_chain_body<true, LSM, XC>(a, b, dir, *reinterpret_cast<FastLdsT*>(smem));
     return;
   }
   // Gradient waves are persistent: a wave takes item after item (stride: all gradient waves of the launch), in
@@ -1591,10 +1600,14 @@ __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_
   // then paid their start-up (dispatch, three dependent loads) after the chains had finished.
   const int NB = ctc_blocks(a.T);
   const int mid = (NB - 1) / 2;
-  const int nwaves = (int)(gridDim.x - nchain) * kFWaves;
-  for (int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - nchain) * kFWaves + (int)(threadIdx.x >> 6));
-       item < a.B * NB; item += nwaves) {
-    const int r = item / a.B, b = item % a.B;  // r: rank in readiness order
+  const int gwgs = (int)(gridDim.x - nchain), g = (int)(blockIdx.x - nchain);
+  // (same placement as the chains where the counts allow it: utterance b's items on XCD b % 8)
+  const bool placed = a.place && (gwgs & 7) == 0;
+  const int xcd = placed ? g & 7 : 0, mult = placed ? 8 : 1, nb = placed ? a.B >> 3 : a.B;  // utterances of this XCD
+  const int stride = (placed ? gwgs >> 3 : gwgs) * kFWaves;
+  for (int li = __builtin_amdgcn_readfirstlane((placed ? g >> 3 : g) * kFWaves + (int)(threadIdx.x >> 6)); li < nb * NB;
+       li += stride) {
+    const int r = li / nb, b = (li % nb) * mult + xcd;  // r: rank in readiness order
     const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
     ctc_fast_grad_body<LSM, true, COMPACT, XC>(a, true, b, k, coef, gout, dx, smem);
   }
@@ -2272,6 +2285,14 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     else if (grad_wgs_env < 0 && 2 * (int64_t)B <= 3 * n_cus / 2)
       grad_wgs = std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
     const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : grad_wgs)));
+    static const int place_env = [] {
+      // Measured on one box, cfg2: placement cuts the memory-side traffic of the launch 278 -> 223 MB (x[b] lands in
+      // one L2 instead of several) and COSTS 2 us (59.8 -> 62.0; +2 % at cfg5): eight utterance groups with their own
+      // chains finish less evenly than 128 utterances spread over everything.  Off by default; WFL_CTC_XCD=1 enables.
+      const char* e = getenv("WFL_CTC_XCD");
+      return e ? atoi(e) : 0;
+    }();
+    a.place = place_env && (B & 7) == 0;
     if (compact && ctc_use_xc(B, T, C, max_len)) {  // (wide rows: they use the compact gradient tile)
       float* xc = ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3);
       // (a streaming variant -- coalesced float4 rows through an LDS tile -- is no faster: 141 vs 143 us at cfg5.  The
