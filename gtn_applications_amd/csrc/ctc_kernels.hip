@@ -451,10 +451,7 @@ constexpr int kEmptyE = -(1 << 28);
 __device__ __forceinline__ int wave_shr1_i(int v, int fill) {
   return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
 }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i32(int identity, int v) {
-  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
-}
+// (dpp_i32: device_common.h)
 // inclusive prefix maximum over the 64 lanes (row_shr scan + row broadcasts).  v_max_i32 with a DPP source:
 // a lane whose source lane does not exist (or whose row is masked) is simply not written, which is the
 // identity of a running maximum -- one instruction per step instead of mov / mov_dpp / max.  The s_nops

@@ -551,7 +551,14 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
 #undef WFL_BC16
 #undef WFL_BC
     float part = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    part += __shfl_xor(part, 16, 64);  // the other half of the dot product (lane ^ 16: same state)
+    {  // + the other half of the dot product (lane ^ 16: same state).  v_permlane16_swap exchanges the odd rows of
+       // 16 lanes of its first operand with the even rows of its second: given the same value twice, the two results
+       // hold, for every lane, its own value and that of lane ^ 16 (in one order or the other) -- one VALU
+       // instruction where __shfl_xor is a ds_bpermute round trip (~65 cycles on the per-frame critical path)
+      typedef unsigned v2u __attribute__((ext_vector_type(2)));
+      const v2u sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+      part = __uint_as_float(sw.x) + __uint_as_float(sw.y);
+    }
     const float y = inv * part;
     const float val = DIR == 0 ? e * y : y;
     if (owner && q < CP) vslot(cur ^ 1, q) = DIR == 0 ? val : e * y;

@@ -97,6 +97,21 @@ __device__ __forceinline__ float wave_reduce_sum_lane63(float v) {
   v += dpp_f32<0x143, 0xc>(0.f, v);
   return v;
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+// the same reduction for ints (exponents of the probability-domain renormalisations): every lane gets the maximum
+__device__ __forceinline__ int wave_all_max_int(int v) {
+  constexpr int kMin = -2147483647 - 1;
+  v = max(v, dpp_i32<0x111, 0xf>(kMin, v));
+  v = max(v, dpp_i32<0x112, 0xf>(kMin, v));
+  v = max(v, dpp_i32<0x114, 0xf>(kMin, v));
+  v = max(v, dpp_i32<0x118, 0xf>(kMin, v));
+  v = max(v, dpp_i32<0x142, 0xa>(kMin, v));
+  v = max(v, dpp_i32<0x143, 0xc>(kMin, v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ float wave_all_max(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_reduce_max_lane63(v)), 63));
 }

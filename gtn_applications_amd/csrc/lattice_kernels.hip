@@ -840,8 +840,7 @@ struct ProbLds {
 
 __device__ __forceinline__ int block_reduce_max_int(int v, int* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  v = wave_all_max_int(v);
   __syncthreads();
   if (lane == 0) red[wave] = v;
   __syncthreads();
@@ -1021,8 +1020,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         const float* tile = ring + (size_t)(c & 1) * kSlot;
         if (c > 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
           int ex = (tid < Q && p > 0.0) ? __builtin_amdgcn_frexp_exp(p) - 1 : -(1 << 30);
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) ex = max(ex, __shfl_xor(ex, o, 64));
+          ex = wave_all_max_int(ex);  // (DPP: six VALU instructions; the __shfl_xor form is six ds_bpermute round trips)
           if (ex > -(1 << 30) && ex < 2000) p = ldexp(p, -ex), cum += (double)ex;
         }
         // this lane's factors of the chunk: all LDS reads issued back to back, THEN converted (a test or a use
