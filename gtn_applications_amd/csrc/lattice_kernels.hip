@@ -1151,34 +1151,42 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
 #pragma unroll
       for (int k = 0; k < DEG; ++k) c[k] = wf[k] * (double)f[k];
     };
+    // Frame loops.  The workgroup's waves meet at ONE LDS-only barrier per frame and a wave issues an instruction every
+    // ~5 cycles, so the instruction count of a frame is its time (SQ counters at cfg4: 27 VALU + 19 SALU + 5 LDS
+    // instructions per live wave and frame, waves waiting 63 % of their cycles): waves without a state only run the
+    // barriers, the row pointer and the tile pointer advance by scalar adds, the ping-pong buffers swap by parity.
     auto frames = [&](auto deg) {
       constexpr int DEG = decltype(deg)::value;
+      if (!wave_live) {
+        for (int i = 0; i < n; ++i) lds_barrier();
+        return;
+      }
       double c[kLeanDeg], cn[kLeanDeg];
       coeffs(0, c, deg);
+      double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
+      int par = (DIR == 0 ? f0 : f0 + n) & 1;  // parity of the slot the frame reads from
       for (int i = 0; i < n; ++i) {
-        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-        const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
-        const double* from = (slot_from & 1) ? L.buf1 : L.buf0;
-        double* to = (slot_to & 1) ? L.buf1 : L.buf0;
-        if (wave_live) {
-          double ps[DEG];
+        const double* from = par ? L.buf1 : L.buf0;
+        double* to = par ? L.buf0 : L.buf1;
+        double ps[DEG];
 #pragma unroll
-          for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
-          if (i + 1 < n) coeffs(i + 1, cn, deg);
-          double acc0 = 0.0, acc1 = 0.0;
+        for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+        if (i + 1 < n) coeffs(i + 1, cn, deg);
+        double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-          for (int k = 0; k < DEG; k += 2) {
-            acc0 = fma(ps[k], c[k], acc0);
-            acc1 = fma(ps[k + 1], c[k + 1], acc1);
-          }
-          p = acc0 + acc1;
-          if (tid < Q) {
-            to[tid] = p;
-            out[u.ab_base + (int64_t)slot_to * Q + tid] = p;
-          }
-#pragma unroll
-          for (int k = 0; k < DEG; ++k) c[k] = cn[k];
+        for (int k = 0; k < DEG; k += 2) {
+          acc0 = fma(ps[k], c[k], acc0);
+          acc1 = fma(ps[k + 1], c[k + 1], acc1);
         }
+        p = acc0 + acc1;
+        if (tid < Q) {
+          to[tid] = p;
+          orow[tid] = p;
+        }
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) c[k] = cn[k];
+        orow = DIR == 0 ? orow + Q : orow - Q;
+        par ^= 1;
         lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
       }
     };
@@ -1195,32 +1203,38 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         }
         lds_barrier();
       }
+      if (!wave_live) {
+        for (int i = 0; i < n; ++i) lds_barrier();
+        return;
+      }
+      double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
+      int par = (DIR == 0 ? f0 : f0 + n) & 1;
+      // alpha: this frame's factor of the state; beta: the factor of the NEXT frame to be consumed (t - 1), with
+      // which the owner publishes; past the chunk (the tile is not there yet) plain beta is published
+      const float* fptr = tile + (size_t)(DIR == 0 ? 0 : max(n - 2, 0)) * Kmax + my_slot;
       for (int i = 0; i < n; ++i) {
-        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-        const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
-        const double* from = (slot_from & 1) ? L.buf1 : L.buf0;
-        double* to = (slot_to & 1) ? L.buf1 : L.buf0;
-        if (wave_live) {
-          double ps[DEG];
+        const double* from = par ? L.buf1 : L.buf0;
+        double* to = par ? L.buf0 : L.buf1;
+        double ps[DEG];
 #pragma unroll
-          for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
-          // alpha: this frame's factor of the state; beta: the factor of the NEXT frame to be consumed (t - 1), with
-          // which the owner publishes; past the chunk (the tile is not there yet) plain beta is published
-          const int tf = DIR == 0 ? t : t - 1;
-          const float f = (DIR == 0 || tf >= f0) ? tile[(size_t)(tf - f0) * Kmax + my_slot] : 1.f;
-          double acc0 = 0.0, acc1 = 0.0;
+        for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+        const float fr = *fptr;
+        const float f = (DIR == 0 || i + 1 < n) ? fr : 1.f;
+        double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-          for (int k = 0; k < DEG; k += 2) {
-            acc0 = fma(ps[k], wf[k], acc0);
-            acc1 = fma(ps[k + 1], wf[k + 1], acc1);
-          }
-          const double sum = acc0 + acc1;
-          p = DIR == 0 ? sum * (double)f : sum;
-          if (tid < Q) {
-            to[tid] = DIR == 0 ? p : p * (double)f;
-            out[u.ab_base + (int64_t)slot_to * Q + tid] = p;
-          }
+        for (int k = 0; k < DEG; k += 2) {
+          acc0 = fma(ps[k], wf[k], acc0);
+          acc1 = fma(ps[k + 1], wf[k + 1], acc1);
         }
+        const double sum = acc0 + acc1;
+        p = DIR == 0 ? sum * (double)f : sum;
+        if (tid < Q) {
+          to[tid] = DIR == 0 ? p : p * (double)f;
+          orow[tid] = p;
+        }
+        orow = DIR == 0 ? orow + Q : orow - Q;
+        if (DIR == 0 || i + 2 < n) fptr = DIR == 0 ? fptr + Kmax : fptr - Kmax;
+        par ^= 1;
         lds_barrier();
       }
       // (beta: the chunk's last step published plain beta -- no factor past the chunk -- which is what the
