@@ -375,8 +375,6 @@ class side_stream:
         """The current stream waits for everything launched on the side stream so far."""
         cur = torch.cuda.current_stream(self.side.device)
         cur.wait_stream(self.side)
-        if os.environ.get("WFL_NO_RECORD_STREAM"):
-            return
         for t in tensors:
             if t is not None:
                 t.record_stream(cur)
@@ -390,8 +388,6 @@ class side_stream:
     def join_at(self, ev, *tensors):
         """The current stream waits for the side stream only up to `ev` (work launched after it keeps overlapping)."""
         self.cur.wait_event(ev)
-        if os.environ.get("WFL_NO_RECORD_STREAM"):
-            return
         for t in tensors:
             if t is not None:
                 t.record_stream(self.cur)
