@@ -118,7 +118,13 @@ struct PinnedRing {  // reusable pinned staging buffers; a slot is reused after 
     if (!buf[slot].defined() || buf[slot].numel() < need) {
       int64_t cap = 1 << 18;
       while (cap < need) cap <<= 1;
-      buf[slot] = at::empty({cap}, at::TensorOptions().dtype(at::kByte).pinned_memory(true));
+      // every slot at once: a pinned allocation costs hundreds of microseconds, and allocating slot by slot would
+      // spread eight of them over the first eight steps of a run instead of paying them in the first one
+      for (int k = 0; k < kSlots; ++k)
+        if (!buf[k].defined() || buf[k].numel() < cap) {
+          if (ev[k]) (void)hipEventSynchronize(ev[k]);
+          buf[k] = at::empty({cap}, at::TensorOptions().dtype(at::kByte).pinned_memory(true));
+        }
     }
     return buf[slot].data_ptr<uint8_t>();
   }

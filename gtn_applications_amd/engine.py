@@ -496,8 +496,15 @@ class _StagingRing:
         buf = self.bufs[i]
         if buf is None or buf.numel() < need:
             n = max(self.nbytes, 1 << (int(need) - 1).bit_length())
-            buf = self.bufs[i] = torch.empty(n, dtype=torch.uint8, pin_memory=pinned)
-            self.views[i] = buf.numpy()
+            # every slot at once: a pinned allocation costs hundreds of microseconds -- slot by slot they would be
+            # spread over the first steps of a run instead of being paid in the first one
+            for k in range(len(self.bufs)):
+                if self.bufs[k] is None or self.bufs[k].numel() < n:
+                    if self.events[k] is not None:
+                        self.events[k].synchronize()
+                    self.bufs[k] = torch.empty(n, dtype=torch.uint8, pin_memory=pinned)
+                    self.views[k] = self.bufs[k].numpy()
+            buf = self.bufs[i]
         return i, buf, self.views[i]
 
 
