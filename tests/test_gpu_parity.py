@@ -1156,6 +1156,54 @@ def test_lattice_probability_domain_is_the_default_and_matches_log_domain(crit):
     np.testing.assert_allclose(logd[1:], got[1:], rtol=2e-6)
 
 
+@pytest.mark.parametrize("T", [1, 2, 15, 16, 17, 33, 130])
+def test_banded_sweep_awkward_sizes(crit, T):
+    """The ASG force-alignment lattices run the register-resident banded sweep (chain wave + loader wave, chunks of
+    16 frames, four chunks of lookahead): frame counts around the chunk size, targets from empty to 63 labels (64
+    states: the whole wave), label sets that are not a multiple of four (the compact rows are padded), repeated
+    labels (two arcs of one slot) -- numerator scores and gradients against the oracle, every utterance."""
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(T)
+    C = 11
+    lens = [0, 1, 2, 3, 5, 9, 16, 31, 63]
+    B = len(lens)
+    targets = [rs.randint(0, C, size=n).tolist() for n in lens]
+    x = rs.randn(B, T, C).astype(np.float32)
+    W = (0.3 * rs.randn(C + 1, C)).astype(np.float32)
+    xd, Wd = dev(x), dev(W)
+    tg = E.targets_on_device(targets, xd.device)
+    pack = E.PackedLattice.asg_force_align(tg.flat, tg.offsets, C, xd.device)
+    assert pack.desc.max_labels % 4 == 0 and pack.desc.max_states == 64
+    st = E.lattice_forward(xd, pack, weights=Wd)
+    fmt = E.lattice_formats(st).tolist()  # 1: probability domain (the banded path); utterances without any accepting
+    assert all(f == 1 for f, n in zip(fmt, lens) if 1 <= n <= T), fmt  # path may be handed to the log-domain repair
+    coef = torch.ones(B, device="cuda")
+    dx, dW = torch.full_like(xd, float("nan")), torch.zeros_like(Wd)
+    E.lattice_grad(st, coef, coef_w=coef, dx=dx, dW=dW)
+    got = st.logz.cpu().numpy()
+    wflat = W.astype(np.float64).reshape(-1)
+    dW_want = np.zeros(W.size)
+    for b, y in enumerate(targets):
+        L = len(y)
+        src, dst, lab, wid = [], [], [], []  # asg.py:72-81 with the weight indices of asg.py:54-69
+        for l in range(1, L + 1):
+            c = y[l - 1]
+            src += [l - 1, l]
+            dst += [l, l]
+            lab += [c, c]
+            wid += [c if l == 1 else (1 + c) * C + y[l - 2], (1 + c) * C + c]
+        score, gx, garc = OR.lattice_forward_backward(x[b].astype(np.float64), src, dst, lab,
+                                                      wflat[wid] if wid else np.zeros(0), [0], [L], L + 1)
+        if L == 0 or L > T or not np.isfinite(score):  # (asg.py:75-77: no accepting node for an empty target)
+            assert got[b] == -np.inf and float(dx[b].abs().max()) == 0.0, (b, L, got[b])
+            continue
+        assert got[b] == pytest.approx(score, rel=RTOL, abs=1e-5)
+        close(dx[b], gx, msg=f"utterance {b} (L={L})")
+        np.add.at(dW_want, np.asarray(wid, dtype=np.int64), garc)
+    close(dW, dW_want.reshape(W.shape), atol=5e-5)
+
+
 def test_lattice_certificate_sends_what_a_double_cannot_hold_to_the_log_domain(crit):
     """Monotone chains whose alpha mass sits 2^2900 above the states that carry the posteriors (scores that reward the
     late states early and the early states late): the forward sweep's double underflows there, the two sweeps disagree
