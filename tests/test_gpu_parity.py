@@ -98,6 +98,20 @@ def test_ctc_cpp_autograd_node_is_the_python_operator(crit, reduction):
     assert torch.equal(r1.grad, r2.grad)
 
 
+@pytest.mark.parametrize("nbytes", [1, 15, 16, 17, 4095, 23 * 1024 + 3, 1 << 20])
+def test_upload_kernel_copies_pinned_memory_exactly(crit, nbytes):
+    """wfl_upload: the staged targets / packed lattices reach the device through a kernel that reads the pinned buffer."""
+    from gtn_applications_amd import engine as E
+
+    g = torch.Generator().manual_seed(nbytes)
+    src = torch.empty(nbytes + 64, dtype=torch.uint8, pin_memory=True)
+    src.copy_(torch.randint(0, 256, (nbytes + 64,), generator=g, dtype=torch.uint8))
+    dst = torch.full((nbytes + 64,), 7, dtype=torch.uint8, device="cuda")
+    E.upload(dst, src, nbytes)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:nbytes].cpu(), src[:nbytes]) and bool((dst[nbytes:] == 7).all())
+
+
 def test_native_library_is_the_one_loaded(crit):
     from gtn_applications_amd import _native
 

@@ -565,3 +565,34 @@ def test_cpp_autograd_extension_is_built_and_exports_the_ctc_node():
     from gtn_applications_amd import _wfl_torch
 
     assert callable(_wfl_torch.ctc_step)
+
+
+def test_cpython_helper_factors_and_content_key():
+    """_wflpy: per-utterance loss / gradient factors (ctc.py:53-58,87) and the 128-bit content key of the target cache."""
+    from gtn_applications_amd import _wflpy
+
+    lens = [4, 0, 1, 7, 3]
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    B = len(lens)
+    fac = np.full((6, B), np.nan, dtype=np.float32)
+    _wflpy.factors_into(off.ctypes.data, B, fac.ctypes.data)
+    mean = np.array([1.0 / n if n else 1.0 for n in lens], dtype=np.float32)
+    np.testing.assert_array_equal(fac[0], np.ones(B, np.float32))
+    np.testing.assert_array_equal(fac[1], mean)
+    np.testing.assert_allclose(fac[2], np.float32(1.0 / B), rtol=1e-7)
+    np.testing.assert_allclose(fac[3], mean / B, rtol=1e-6)
+    np.testing.assert_allclose(fac[4], -fac[2], rtol=0)
+    np.testing.assert_allclose(fac[5], -fac[3], rtol=0)
+    rs = np.random.RandomState(0)
+    buf = rs.randint(0, 256, size=1000).astype(np.uint8)
+    keys = set()
+    for n in (0, 1, 8, 15, 16, 17, 31, 32, 999, 1000):
+        k = _wflpy.content_key(buf.ctypes.data, n)
+        assert k == _wflpy.content_key(buf.copy().ctypes.data, n)  # content, not address
+        keys.add(k)
+    assert len(keys) == 10  # (prefixes of different length hash differently)
+    other = buf.copy()
+    other[500] ^= 1
+    assert _wflpy.content_key(other.ctypes.data, 1000) != _wflpy.content_key(buf.ctypes.data, 1000)
+    assert _wflpy.same_bytes(buf.ctypes.data, buf.tobytes()) and not _wflpy.same_bytes(other.ctypes.data, buf.tobytes())
