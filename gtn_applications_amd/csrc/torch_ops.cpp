@@ -62,6 +62,9 @@ struct CtcStep : public torch::autograd::Function<CtcStep> {
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     at::Tensor x = ctx->saved_data["x"].toTensor();
+    if (!grads[0].defined())  // (the loss did not take part in what is being differentiated)
+      return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+              at::Tensor(), at::Tensor(), at::Tensor()};
     at::Tensor g = grads[0].detach().reshape({1});
     if (!g.is_cuda() || g.scalar_type() != at::kFloat) g = g.to(x.device(), at::kFloat);
     auto it = ctx->saved_data.find("dx");
