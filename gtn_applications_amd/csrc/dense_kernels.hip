@@ -383,8 +383,9 @@ static size_t dense_ws_bytes(int B, int T) {
 constexpr int kDenseChainWaves = 4, kDenseThreads = (kDenseChainWaves + 1) * 64;
 template <int CP>
 struct FastLds {
-  static constexpr int NCH = (CP / 2 + 15) / 16;  // 16-element chunks per half of the vector
-  static constexpr int H = 16 * NCH;               // states per half (padded)
+  static constexpr int H = CP / 2;                 // states per half of the vector (both halves equally full)
+  static constexpr int NCH = (H + 15) / 16;        // 16-element chunks per half
+  static constexpr int LASTN = H - 16 * (NCH - 1); // elements of the last chunk (the others are full)
   float vecT[2][2][16][4];  // frame vector (ping-pong): [half][position in chunk][chunk]: a lane's NCH elements contiguous
   float eh[4][CP];         // ring of e_t rows staged by the helper wave
   float wr2[CP];
@@ -419,20 +420,20 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
 
   // ---- chain waves: lane (wave, hh, qq, il) works on state q = 32 wave + 16 hh + il and on the half qq of the
   // vector: its half of the state's row (alpha) / column (beta) of P
-  constexpr int H = FastLds<CP>::H, NCH = FastLds<CP>::NCH;
+  constexpr int H = FastLds<CP>::H, NCH = FastLds<CP>::NCH, LASTN = FastLds<CP>::LASTN;
   const int qq = (lane >> 4) & 1;                         // which half of the vector this lane multiplies
   const int il = lane & 15;
   const int q = 32 * wave + 16 * (lane >> 5) + il;        // state of a chain lane
   const bool owner = qq == 0;                              // the lane that finishes the state
-  float P[H];
+  float P[16 * NCH];
   int hard = 0;
   for (int i = tid; i < 2 * 2 * 16 * 4; i += kDenseThreads) (&L.vecT[0][0][0][0])[i] = 0.f;  // (padding stays 0)
   if (wave < kDenseChainWaves) {
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
+    for (int k = 0; k < 16 * NCH; ++k) {
       const int j = qq * H + k;
       float p = 0.f;
-      if (q < C && j < C) {
+      if (k < H && q < C && j < C) {
         const float w = DIR == 0 ? W[(1 + q) * C + j] : W[(1 + j) * C + q];
         const float d = w * kLog2e - (DIR == 0 ? L.wr2[q] : L.wr2[j]);
         hard |= !(d >= -kHardGap);  // -inf, NaN, +inf rows, or a dynamic range the floor check cannot vouch for
@@ -534,20 +535,24 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     const float vc[4] = {vc4.x, vc4.y, vc4.z, vc4.w};
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // element k of the row's chunk, broadcast to the row's 16 lanes by the multiply-add's DPP source
-#define WFL_BC(c, k)                                                                             \
-  asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf"          \
-               : "+v"(acc[(k) & 3])                                                                  \
-               : "v"(vc[c]), "v"(P[16 * (c) + (k)]));
-#define WFL_BC16(c)                                                                                           \
-  WFL_BC(c, 0) WFL_BC(c, 1) WFL_BC(c, 2) WFL_BC(c, 3) WFL_BC(c, 4) WFL_BC(c, 5) WFL_BC(c, 6) WFL_BC(c, 7)     \
-  WFL_BC(c, 8) WFL_BC(c, 9) WFL_BC(c, 10) WFL_BC(c, 11) WFL_BC(c, 12) WFL_BC(c, 13) WFL_BC(c, 14) WFL_BC(c, 15)
+    // (chunk c holds N valid elements: 16, or LASTN in the last one -- at C = 100 the halves are 52 long, so the
+    // last chunk issues 4 multiply-adds instead of 16: 52 per frame, not 64, at 6.4 cycles each)
+#define WFL_BC(c, k, N)                                                                            \
+  if constexpr ((k) < (N))                                                                         \
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf"          \
+                 : "+v"(acc[(k) & 3])                                                                  \
+                 : "v"(vc[c]), "v"(P[16 * (c) + (k)]));
+#define WFL_BC16(c, N)                                                                                                   \
+  WFL_BC(c, 0, N) WFL_BC(c, 1, N) WFL_BC(c, 2, N) WFL_BC(c, 3, N) WFL_BC(c, 4, N) WFL_BC(c, 5, N) WFL_BC(c, 6, N)       \
+  WFL_BC(c, 7, N) WFL_BC(c, 8, N) WFL_BC(c, 9, N) WFL_BC(c, 10, N) WFL_BC(c, 11, N) WFL_BC(c, 12, N) WFL_BC(c, 13, N)  \
+  WFL_BC(c, 14, N) WFL_BC(c, 15, N)
     // (the chunk registers may have been moved by a VALU instruction just before: a DPP read of a VGPR needs two wait
     // states after a VALU write of it, and the hazard recogniser does not look into inline assembly)
     asm volatile("s_nop 1" ::: "memory");
-    WFL_BC16(0)
-    if (NCH > 1) { WFL_BC16(1) }
-    if (NCH > 2) { WFL_BC16(2) }
-    if (NCH > 3) { WFL_BC16(3) }
+    WFL_BC16(0, NCH == 1 ? LASTN : 16)
+    if constexpr (NCH > 1) { WFL_BC16(1, NCH == 2 ? LASTN : 16) }
+    if constexpr (NCH > 2) { WFL_BC16(2, NCH == 3 ? LASTN : 16) }
+    if constexpr (NCH > 3) { WFL_BC16(3, NCH == 4 ? LASTN : 16) }
 #undef WFL_BC16
 #undef WFL_BC
     float part = (acc[0] + acc[1]) + (acc[2] + acc[3]);
