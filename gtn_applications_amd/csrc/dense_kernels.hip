@@ -493,7 +493,16 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   };
   // straight-line staging of item r >= 2 (no early return: later items' loads stay in flight across this one's
   // use); items past the end only skip their bookkeeping
-  auto stage_fast = [&](int r, const float (&src)[2]) {
+  // The bookkeeping words of a frame (running offset M, the frame's offset mx2, the exponent sum E) are NOT stored
+  // frame by frame: lane k of the helper keeps those of the k-th frame of a group of kDepth and the group is written
+  // with one store per array.  A store per frame from the wave that also waits for the prefetched rows shrinks the
+  // prefetch: loads and stores share the in-order vmcnt counter, the conditional stores are not counted by the
+  // compiler along the shortest path, and its `s_waitcnt vmcnt(16)` then means "all but the last three frames'
+  // operations" -- the rows were effectively requested three frames ahead, not sixteen (371 -> 337 us at cfg3).
+  double gM = 0.0;
+  float gm2 = 0.f;
+  int gE = 0;
+  auto stage_fast = [&](int r, const float (&src)[2], int k) {
     const bool ok = r < T;
     const float s0 = lane < C ? fmaf(nan_to_neg(src[0]), kLog2e, add0) : WFL_NEG_INF;
     const float s1 = lane + 64 < C ? fmaf(nan_to_neg(src[1]), kLog2e, add1) : WFL_NEG_INF;
@@ -502,10 +511,8 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     if (lane < CP) dst[lane] = lane < C ? __builtin_amdgcn_exp2f(s0 - m) : 0.f;
     if (has1) dst[lane + 64] = lane + 64 < C ? __builtin_amdgcn_exp2f(s1 - m) : 0.f;
     mrun += ok ? (double)m : 0.0;
-    if (lane == 0 && ok) {
-      Mb[DIR == 0 ? r : T - 1 - r] = mrun;
-      if (DIR == 0) ws.mx2[(int64_t)b * T + r] = m;
-    }
+    gM = lane == k ? mrun : gM;
+    gm2 = lane == k ? m : gm2;
   };
   const std::true_type kChecked;
 
@@ -575,9 +582,9 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   };
   // helper side of the same bookkeeping: E_t = sum of the exponents applied up to step n
   int ecum = 0;
-  auto helper_scale = [&](int n) {
+  auto helper_scale = [&](int n, int k) {
     ecum += scale_exp(scale_ref((n - 1) & 1));
-    if (lane == 0) Eb[DIR == 0 ? n : T - 1 - n] = ecum;
+    gE = lane == k ? ecum : gE;
   };
 
   // ---- prologue: items 0, 1 and 2 staged synchronously, items 3 .. kDepth+2 in flight (item r lives in raw[r % kDepth])
@@ -638,10 +645,19 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
 #pragma unroll
       for (int k = 0; k < kDepth; ++k) {
         if (n + k < T) {
-          helper_scale(n + k);
-          stage_fast(n + k + 2, raw[(k + 3) % kDepth]);
+          helper_scale(n + k, k);
+          stage_fast(n + k + 2, raw[(k + 3) % kDepth], k);
           issue_fast(n + k + 2 + kDepth, raw[(k + 3) % kDepth]);
           lds_barrier();
+        }
+      }
+      // the group's words: lane k holds those of step n + k (E) and of item n + k + 2 (M, mx2)
+      if (lane < kDepth && n + lane < T) {
+        Eb[DIR == 0 ? n + lane : T - 1 - (n + lane)] = gE;
+        const int r = n + lane + 2;
+        if (r < T) {
+          Mb[DIR == 0 ? r : T - 1 - r] = gM;
+          if (DIR == 0) ws.mx2[(int64_t)b * T + r] = gm2;
         }
       }
     }
