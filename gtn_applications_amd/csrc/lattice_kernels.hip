@@ -821,6 +821,7 @@ __device__ __forceinline__ int64_t xg_main_dev(const wfl_lattice_desc& d, int T)
   return (((int64_t)d.B * T * d.max_labels) + 3) & ~(int64_t)3;
 }
 constexpr double kLog2e_d = 1.4426950408889634074;
+constexpr int kDumpDoubles = 1024;  // scratch behind the alpha / beta tails (see run_chain_prob)
 constexpr int kBandDepth = 4;
 // floats of the probability-domain sweeps' row tile: two chunks of the tile path, or the banded sweep's two tiles of
 // 16 rows (+ their references)
@@ -875,7 +876,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
                                const float* __restrict__ fg, const float* __restrict__ rmax,
                                const float* __restrict__ weights, double* __restrict__ out, float* __restrict__ logz,
                                int b, double* __restrict__ offs, double* __restrict__ z64, float* __restrict__ wref_out,
-                               double* __restrict__ z_copy) {
+                               double* __restrict__ dump) {  // dump: kDumpDoubles doubles nobody reads
   const int tid = threadIdx.x, NT = blockDim.x;
   const int Q = u.Q, Kmax = d.max_labels;
   // ---- this thread's state: its in-arcs (forward) / out-arcs (backward) in registers
@@ -1212,6 +1213,43 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       // alpha: this frame's factor of the state; beta: the factor of the NEXT frame to be consumed (t - 1), with
       // which the owner publishes; past the chunk (the tile is not there yet) plain beta is published
       const float* fptr = tile + (size_t)(DIR == 0 ? 0 : max(n - 2, 0)) * Kmax + my_slot;
+      if (n == 16) {
+        // A full chunk as straight-line code whose stores EVERY lane executes (lanes without a state store to a dump
+        // and to their own, never read, LDS entry).  The threads of this workgroup also prefetch the next chunk's rows:
+        // loads and stores share the in-order vmcnt counter and the compiler counts, for the wait in front of the
+        // prefetched rows, only the operations that are issued on EVERY path -- with the stores inside `if (tid < Q)`
+        // or inside a loop of unknown trip count that wait became "everything", i.e. the last frame's store round trip
+        // (~1.5 us) at the end of every chunk.
+        const bool mine = tid < Q;
+        double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
+        const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
+        const double* bA = par ? L.buf1 : L.buf0;  // read by the even frames of the chunk, written by the odd ones
+        const double* bB = par ? L.buf0 : L.buf1;
+        const int fstep = DIR == 0 ? Kmax : -Kmax;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const double* from = (i & 1) ? bB : bA;
+          double* to = const_cast<double*>((i & 1) ? bA : bB);
+          double ps[DEG];
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+          const float fr = fptr[(DIR == 0 || i < 15) ? i * fstep : 14 * fstep];
+          const float f = (DIR == 0 || i < 15) ? fr : 1.f;
+          double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < DEG; k += 2) {
+            acc0 = fma(ps[k], wf[k], acc0);
+            acc1 = fma(ps[k + 1], wf[k + 1], acc1);
+          }
+          const double sum = acc0 + acc1;
+          p = DIR == 0 ? sum * (double)f : sum;
+          to[tid] = DIR == 0 ? p : p * (double)f;
+          *po = p;
+          po += pstep;
+          lds_barrier();
+        }
+        return;
+      }
       for (int i = 0; i < n; ++i) {
         const double* from = par ? L.buf1 : L.buf0;
         double* to = par ? L.buf0 : L.buf1;
@@ -1299,7 +1337,6 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       const bool ok = tot > 0.0 && tot < 1.0e300;
       const double z2 = ok ? log2(tot) + cum : (tot == 0.0 ? -__builtin_inf() : __builtin_nan(""));
       z64[b] = z2;  // log2 Z as this sweep sees it (the certificate compares the two)
-      if (z_copy) z_copy[b] = z2;
       if (DIR == 0 && logz) logz[b] = (float)(z2 * 0.6931471805599453094);
     }
   }
@@ -1325,8 +1362,9 @@ __global__ void __launch_bounds__(MAXT)
   if (!prob_eligible(u, blockDim.x)) return;
   ProbLds P;
   char* p = smem;
-  P.buf0 = (double*)p, p += (size_t)d.max_states * 8;
-  P.buf1 = (double*)p, p += (size_t)d.max_states * 8;
+  const size_t nvec = max((size_t)d.max_states, (size_t)blockDim.x);  // (one entry per THREAD: every lane may write)
+  P.buf0 = (double*)p, p += nvec * 8;
+  P.buf1 = (double*)p, p += nvec * 8;
   P.red = (float*)p, p += 64 * 4;
   P.rows = (float*)p, p += prob_rows_floats(d, rows_per_chunk) * 4;
   P.refs = (float*)p;
@@ -1335,11 +1373,11 @@ __global__ void __launch_bounds__(MAXT)
   if (dir == 0) {
     if (threadIdx.x == 0) fmt[b] = kFmtProb;
     run_chain_prob<0, MAXT == 128>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
-                      offs_a + (int64_t)b * nch1, za, wrefs, nullptr);
+                      offs_a + (int64_t)b * nch1, za, wrefs, offs_a + (int64_t)d.B * nch1 + 2 * (int64_t)d.B);
   } else {
     if (threadIdx.x == 0) zb[d.B + b] = 0.0;  // the certificate's verdict: raised by prob_certify_kernel
     run_chain_prob<1, MAXT == 128>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
-                      offs_b + (int64_t)b * nch1, zb, nullptr, nullptr);
+                      offs_b + (int64_t)b * nch1, zb, nullptr, offs_b + (int64_t)d.B * nch1 + 2 * (int64_t)d.B);
   }
 }
 
@@ -1434,8 +1472,16 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
                      nullptr);
 }
 
+// threads of the sweep workgroups: one state per thread up to 1024 states (the lean frame paths need it); beyond
+// that threads loop
+static int chain_threads(const wfl_lattice_desc& d) {
+  int nt = d.max_states <= 128 ? 128 : d.max_states <= 256 ? 256 : d.max_states <= 512 ? 512 : 1024;
+  while (nt < 256 && nt * kPre < 2 * d.max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
+  return nt;
+}
 static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
-  const size_t prob = (size_t)d.max_states * 16 + 64 * 4 + prob_rows_floats(d, rows_per_chunk) * 4 +
+  const int nt = chain_threads(d);
+  const size_t prob = (size_t)std::max(d.max_states, nt) * 16 + 64 * 4 + prob_rows_floats(d, rows_per_chunk) * 4 +
                       (size_t)2 * rows_per_chunk * 4 + 64;
   return std::max(prob, (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 8 +
          (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 +
@@ -1886,9 +1932,7 @@ static int64_t xg_main(const wfl_lattice_desc& d, int T) { return (((int64_t)d.B
 // Launch shape of the chain kernel: threads per workgroup and emission rows per chunk (also the renormalisation
 // interval, so the gradient kernel needs the same number).
 static void chain_config(const wfl_lattice_desc& d, int& nt, int& rpc) {
-  // one state per thread up to 1024 states (the lean frame paths need it); beyond that threads loop
-  nt = d.max_states <= 128 ? 128 : d.max_states <= 256 ? 256 : d.max_states <= 512 ? 512 : 1024;
-  while (nt < 256 && nt * kPre < 2 * d.max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
+  nt = chain_threads(d);
   rpc = std::max(2, std::min(16, nt * kPre / std::max(1, d.max_labels)) & ~1);  // even (run_chain)
 }
 // scores (float | double) [..] | double offs[B][nch1] | double Z[B] | int32 fmt[B] | float wref[B]   (see chain_kernel)
@@ -1911,7 +1955,8 @@ int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, i
     int64_t tail;
     int nch1;
     ab_tail(*d, T, tail, nch1);
-    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2;
+    // (+ kDumpDoubles doubles behind the tail: where the lanes without a state of the unrolled sweeps "store")
+    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2 + 2 * kDumpDoubles;
   }
   return WFL_OK;
 }

@@ -307,7 +307,7 @@ def lattice_formats(st):
     certificate's repair: the two probability-domain sweeps disagreed about Z).  Diagnostics and tests; the layout is
     the tail of the alpha buffer described in csrc/lattice_kernels.hip (chain_kernel)."""
     B, T = st.pack.desc.B, st.T
-    tail = st.alpha.numel() - (2 * (B * (T + 1) + B) + 2 * B + 2)
+    tail = st.alpha.numel() - (2 * (B * (T + 1) + B) + 2 * B + 2 + 2 * 1024)  # (kDumpDoubles behind the tail)
     off = tail + 2 * (B * (T + 1) + B)
     return st.alpha[off:off + B].view(torch.int32)
 
