@@ -871,7 +871,9 @@ __device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {  // NT
   return !__syncthreads_or(bad);
 }
 
-template <int DIR, bool BAND>  // BAND: single-wave workgroups (the register-resident banded sweep is compiled in)
+// BAND: the register-resident banded sweep is compiled in (chain wave + loader wave workgroups); UNR: full chunks as
+// straight-line code (not for the 1024-thread instantiation: its 128-register budget would spill)
+template <int DIR, bool BAND, bool UNR = true>
 __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, const ProbLds& L, int T, int R,
                                const float* __restrict__ fg, const float* __restrict__ rmax,
                                const float* __restrict__ weights, double* __restrict__ out, float* __restrict__ logz,
@@ -1166,6 +1168,36 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       coeffs(0, c, deg);
       double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
       int par = (DIR == 0 ? f0 : f0 + n) & 1;  // parity of the slot the frame reads from
+      if (UNR && n == 16) {  // (a full chunk as straight-line code with unconditional stores: see frames_uniform)
+        const bool mine = tid < Q;
+        double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
+        const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
+        const double* bA = par ? L.buf1 : L.buf0;
+        const double* bB = par ? L.buf0 : L.buf1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const double* from = (i & 1) ? bB : bA;
+          double* to = const_cast<double*>((i & 1) ? bA : bB);
+          double ps[DEG];
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+          if (i + 1 < 16) coeffs(i + 1, cn, deg);
+          double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < DEG; k += 2) {
+            acc0 = fma(ps[k], c[k], acc0);
+            acc1 = fma(ps[k + 1], c[k + 1], acc1);
+          }
+          p = acc0 + acc1;
+          to[tid] = p;
+          *po = p;
+          po += pstep;
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) c[k] = cn[k];
+          lds_barrier();
+        }
+        return;
+      }
       for (int i = 0; i < n; ++i) {
         const double* from = par ? L.buf1 : L.buf0;
         double* to = par ? L.buf0 : L.buf1;
@@ -1213,7 +1245,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       // alpha: this frame's factor of the state; beta: the factor of the NEXT frame to be consumed (t - 1), with
       // which the owner publishes; past the chunk (the tile is not there yet) plain beta is published
       const float* fptr = tile + (size_t)(DIR == 0 ? 0 : max(n - 2, 0)) * Kmax + my_slot;
-      if (n == 16) {
+      if (UNR && n == 16) {
         // A full chunk as straight-line code whose stores EVERY lane executes (lanes without a state store to a dump
         // and to their own, never read, LDS entry).  The threads of this workgroup also prefetch the next chunk's rows:
         // loads and stores share the in-order vmcnt counter and the compiler counts, for the wait in front of the
@@ -1372,11 +1404,11 @@ __global__ void __launch_bounds__(MAXT)
   const float* rmax = fg + xg_main_dev(d, T);
   if (dir == 0) {
     if (threadIdx.x == 0) fmt[b] = kFmtProb;
-    run_chain_prob<0, MAXT == 128>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
+    run_chain_prob<0, MAXT == 128, MAXT <= 512>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
                       offs_a + (int64_t)b * nch1, za, wrefs, offs_a + (int64_t)d.B * nch1 + 2 * (int64_t)d.B);
   } else {
     if (threadIdx.x == 0) zb[d.B + b] = 0.0;  // the certificate's verdict: raised by prob_certify_kernel
-    run_chain_prob<1, MAXT == 128>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
+    run_chain_prob<1, MAXT == 128, MAXT <= 512>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
                       offs_b + (int64_t)b * nch1, zb, nullptr, offs_b + (int64_t)d.B * nch1 + 2 * (int64_t)d.B);
   }
 }
