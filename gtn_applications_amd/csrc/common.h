@@ -20,6 +20,33 @@ struct Adjacency {
   // CSR over nodes; `idx` holds arc ids ordered by (node, key) where key is the matching label
   std::vector<int64_t> ptr;
   std::vector<int32_t> idx;
+  // Label table of the nodes with many out-arcs over a dense label range (the token graph of the Transducer has a
+  // thousand arcs per node, one per label): tab[tab_base[n] + (label - lab_lo[n])] = position in the node's range of
+  // the first arc with that label, -1 if none.  lab_w[n] == 0: no table, binary search.  One probe instead of ten
+  // through an index array into a 4 MB label array (each one a cache miss: 88 ns per composed arc -> 30).
+  std::vector<int32_t> lab_lo, lab_w, tab;
+  std::vector<int64_t> tab_base;
+  // first arc (pointer into idx) of node n whose key equals `lab`, or nullptr; `end` receives the end of n's range
+  const int32_t* find(int n, int32_t lab, const std::vector<int32_t>& key, const int32_t*& end) const {
+    const int32_t* lo = idx.data() + ptr[n];
+    end = idx.data() + ptr[n + 1];
+    if (!lab_w.empty() && lab_w[n] > 0) {
+      const int64_t off = (int64_t)lab - lab_lo[n];
+      if (off < 0 || off >= lab_w[n]) return nullptr;
+      const int32_t pos = tab[tab_base[n] + off];
+      return pos < 0 ? nullptr : lo + pos;
+    }
+    // (binary search by hand: <algorithm> is not included here)
+    const int32_t* hi = end;
+    while (lo < hi) {
+      const int32_t* mid = lo + (hi - lo) / 2;
+      if (key[*mid] < lab)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    return (lo != end && key[*lo] == lab) ? lo : nullptr;
+  }
 };
 
 // Prefix trie over the input-label spellings of a lexicon-shaped transducer (see lexicon_decompose in graph.cpp)

@@ -43,6 +43,19 @@ static void build_sorted(const wfl_graph& g, bool by_ol, Adjacency& adj) {
   for (int i = 0; i < n; ++i)
     std::stable_sort(adj.idx.begin() + adj.ptr[i], adj.idx.begin() + adj.ptr[i + 1],
                      [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  // label tables (see Adjacency): nodes with at least 32 out-arcs whose labels span at most 4 x their number
+  adj.lab_lo.assign(n, 0), adj.lab_w.assign(n, 0), adj.tab_base.assign(n, 0), adj.tab.clear();
+  for (int i = 0; i < n; ++i) {
+    const int64_t b = adj.ptr[i], e = adj.ptr[i + 1];
+    if (e - b < 32) continue;
+    const int32_t lo = key[adj.idx[b]], hi = key[adj.idx[e - 1]];  // (sorted; epsilon = -1 simply widens the range by one)
+    const int64_t width = (int64_t)hi - lo + 1;
+    if (width > 4 * (e - b)) continue;
+    adj.lab_lo[i] = lo, adj.lab_w[i] = (int32_t)width, adj.tab_base[i] = (int64_t)adj.tab.size();
+    adj.tab.resize(adj.tab.size() + (size_t)width, -1);
+    int32_t* t = adj.tab.data() + adj.tab_base[i];
+    for (int64_t k = e - 1; k >= b; --k) t[key[adj.idx[k]] - lo] = (int32_t)(k - b);  // (downwards: the FIRST arc wins)
+  }
 }
 
 // A graph is lexicon-shaped (what make_lexicon_graph builds, transducer.py:61-75) if node 0 is its only start and
@@ -331,13 +344,13 @@ wfl_graph* wfl_graph_compose(const wfl_graph* g1, const wfl_graph* g2, int32_t**
     if ((xe - x) * 8 < (ye - y) || (ye - y) * 8 < (xe - x)) {
       const bool small_first = (xe - x) < (ye - y);
       const int32_t *sm = small_first ? x : y, *sme = small_first ? xe : ye;
-      const int32_t *lg = small_first ? y : x, *lge = small_first ? ye : xe;
       const std::vector<int32_t>& skey = small_first ? g1->ol : g2->il;
       const std::vector<int32_t>& lkey = small_first ? g2->il : g1->ol;
+      const wfl::Adjacency& LA = small_first ? A2 : A1;
+      const int ln = small_first ? b : a;
       for (; sm != sme; ++sm) {
-        const int32_t lab = skey[*sm];
-        const int32_t* lo = std::lower_bound(lg, lge, lab, [&](int32_t arc, int32_t v) { return lkey[arc] < v; });
-        if (lo != lge && lkey[*lo] == lab) return true;
+        const int32_t* end;
+        if (LA.find(ln, skey[*sm], lkey, end)) return true;
       }
       return false;
     }
@@ -415,10 +428,15 @@ wfl_graph* wfl_graph_compose(const wfl_graph* g1, const wfl_graph* g2, int32_t**
       const int32_t *l = small_first ? y : x, *le = small_first ? ye : xe;
       const std::vector<int32_t>& skey = small_first ? g1->ol : g2->il;
       const std::vector<int32_t>& lkey = small_first ? g2->il : g1->ol;
+      const wfl::Adjacency& LA = small_first ? A2 : A1;
+      const int ln = small_first ? b : a;
+      (void)l;
       for (; s != se; ++s) {
         const int32_t lab = skey[*s];
-        const int32_t* lo = std::lower_bound(l, le, lab, [&](int32_t arc, int32_t v) { return lkey[arc] < v; });
-        for (; lo != le && lkey[*lo] == lab; ++lo) small_first ? emit(s, lo) : emit(lo, s);
+        const int32_t* end;
+        const int32_t* lo = LA.find(ln, lab, lkey, end);
+        if (!lo) continue;
+        for (; lo != le && lo != end && lkey[*lo] == lab; ++lo) small_first ? emit(s, lo) : emit(lo, s);
       }
     } else {
       while (x != xe && y != ye) {
