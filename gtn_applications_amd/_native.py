@@ -96,6 +96,8 @@ _SIGS = {
     # lattice packing
     "wfl_lattice_pack": (_P, [_P, _P, c_int, c_int, c_int, c_int]),
     "wfl_transducer_pack_batch": (_P, [_P, _P, _P, _P, _P, c_int, c_int, c_int]),
+    "wfl_transducer_pack_batch_into": (_P, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_int64]),
+    "wfl_lattice_host_external": (c_int64, [_P]),
     "wfl_lattice_pack_ctc": (_P, [_P, _P, c_int, c_int, c_int]),
     "wfl_lattice_pack_asg_fal": (_P, [_P, _P, c_int, c_int]),
     "wfl_lattice_pack_stc": (_P, [_P, _P, c_int, c_int, c_float, c_int]),

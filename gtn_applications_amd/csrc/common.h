@@ -98,4 +98,7 @@ struct wfl_lattice_host {
   wfl_lattice_desc desc;
   std::vector<int32_t> ints;
   std::vector<float> floats;
+  // >= 0: the blobs were written to the caller's buffer ([floats | reserved | pad to 16 B | ints]) and this is the
+  // byte offset of the int blob in it; `ints` / `floats` are then empty (wfl_transducer_pack_batch_into)
+  int64_t external_ints_offset = -1;
 };

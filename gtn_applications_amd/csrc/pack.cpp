@@ -336,7 +336,8 @@ struct PackScratch {
   std::vector<uint8_t> st, ac;
 };
 wfl_lattice_host* build_batch(int B, int C, const std::function<bool(int, Builder&, PackScratch&)>& per_utt);
-wfl_lattice_host* merge_direct(std::vector<Builder>& parts, int np, int B, int C);
+wfl_lattice_host* merge_direct(std::vector<Builder>& parts, int np, int B, int C, void* dst = nullptr, int64_t dst_bytes = 0,
+                               int64_t reserve_floats = 0);
 
 }  // namespace
 
@@ -683,7 +684,10 @@ wfl_lattice_host* build_batch(int B, int C, const std::function<bool(int, Builde
 // Builders of consecutive utterance ranges -> the final blobs, every bulk array copied ONCE, straight to its place
 // (the cumulative offset tables are a few hundred integers).
 // The layout is finish()'s: the same arrays in the same order, each padded to a multiple of four elements.
-wfl_lattice_host* merge_direct(std::vector<Builder>& parts, int np, int B, int C) {
+// `dst` (optional, 16-byte aligned, dst_bytes large): the blobs go there instead of into the handle, laid out as the
+// operator layer uploads them -- [floats | reserve_floats floats for the caller | pad to 16 B | ints] -- if they fit.
+wfl_lattice_host* merge_direct(std::vector<Builder>& parts, int np, int B, int C, void* dst, int64_t dst_bytes,
+                               int64_t reserve_floats) {
   using IV = std::vector<int32_t> Builder::*;
   using FV = std::vector<float> Builder::*;
   static const IV bulk_i[] = {&Builder::in_ptr,  &Builder::out_ptr,  &Builder::out_arc,  &Builder::ein_ptr, &Builder::eout_ptr,
@@ -734,17 +738,34 @@ wfl_lattice_host* merge_direct(std::vector<Builder>& parts, int np, int B, int C
   int64_t nf = 0;
   for (int f = 0; f < NF; ++f) *bulk_foff[f] = nf, nf += pad4(fpos[f][np]);
   d.int_words = ni, d.float_words = nf;
-  h->ints.assign((size_t)ni, 0), h->floats.assign((size_t)nf, 0.f);
-  for (int t = 0; t < 5; ++t) memcpy(h->ints.data() + *tab_off[t], tabs[t]->data(), tabs[t]->size() * sizeof(int32_t));
+  int32_t* I;
+  float* F;
+  const int64_t off_i = (4 * (nf + reserve_floats) + 15) & ~(int64_t)15;
+  if (dst && off_i + 4 * std::max<int64_t>(ni, 1) <= dst_bytes) {
+    F = static_cast<float*>(dst), I = reinterpret_cast<int32_t*>(static_cast<char*>(dst) + off_i);
+    h->external_ints_offset = off_i;
+    // (the gaps that pad every array to four elements: zero, like the blobs the handle would own)
+    for (int t = 0; t < 5; ++t)
+      for (int64_t k = (int64_t)tabs[t]->size(); k < pad4((int64_t)tabs[t]->size()); ++k) I[*tab_off[t] + k] = 0;
+    for (int f = 0; f < NI; ++f)
+      for (int64_t k = ipos[f][np]; k < pad4(ipos[f][np]); ++k) I[*bulk_off[f] + k] = 0;
+    for (int f = 0; f < NF; ++f)
+      for (int64_t k = fpos[f][np]; k < pad4(fpos[f][np]); ++k) F[*bulk_foff[f] + k] = 0.f;
+    memset(static_cast<char*>(dst) + 4 * (nf + reserve_floats), 0, (size_t)(off_i - 4 * (nf + reserve_floats)));
+  } else {
+    h->ints.assign((size_t)ni, 0), h->floats.assign((size_t)nf, 0.f);
+    I = h->ints.data(), F = h->floats.data();
+  }
+  for (int t = 0; t < 5; ++t) memcpy(I + *tab_off[t], tabs[t]->data(), tabs[t]->size() * sizeof(int32_t));
   auto copy_part = [&](int p) {
     const Builder& o = parts[p];
     for (int f = 0; f < NI; ++f) {
       const auto& src = o.*bulk_i[f];
-      if (!src.empty()) memcpy(h->ints.data() + *bulk_off[f] + ipos[f][p], src.data(), src.size() * sizeof(int32_t));
+      if (!src.empty()) memcpy(I + *bulk_off[f] + ipos[f][p], src.data(), src.size() * sizeof(int32_t));
     }
     for (int f = 0; f < NF; ++f) {
       const auto& src = o.*bulk_f[f];
-      if (!src.empty()) memcpy(h->floats.data() + *bulk_foff[f] + fpos[f][p], src.data(), src.size() * sizeof(float));
+      if (!src.empty()) memcpy(F + *bulk_foff[f] + fpos[f][p], src.data(), src.size() * sizeof(float));
     }
   };
   // (serial: ~2 MB of memcpy takes 50 us here, a second pass over the pool 140 us in wake-ups alone)
@@ -828,6 +849,13 @@ extern "C" {
 wfl_lattice_host* wfl_transducer_pack_batch(const wfl_graph* tokens, const wfl_graph* lexicon,
                                             const wfl_graph* transitions, const int32_t* targets,
                                             const int64_t* offsets, int B, int C, int nthreads) {
+  return wfl_transducer_pack_batch_into(tokens, lexicon, transitions, targets, offsets, B, C, nthreads, nullptr, 0, 0);
+}
+
+wfl_lattice_host* wfl_transducer_pack_batch_into(const wfl_graph* tokens, const wfl_graph* lexicon,
+                                                 const wfl_graph* transitions, const int32_t* targets,
+                                                 const int64_t* offsets, int B, int C, int nthreads, void* dst,
+                                                 int64_t dst_bytes, int64_t reserve_floats) {
   if (!tokens || !lexicon || !targets || !offsets || B <= 0) {
     set_error("transducer_pack_batch: bad arguments");
     return nullptr;
@@ -872,7 +900,7 @@ wfl_lattice_host* wfl_transducer_pack_batch(const wfl_graph* tokens, const wfl_g
     return nullptr;
   }
   auto t1 = now();
-  wfl_lattice_host* h = merge_direct(parts, B, B, C);
+  wfl_lattice_host* h = merge_direct(parts, B, B, C, dst, dst_bytes, reserve_floats);
   if (trace) {
     auto t2 = now();
     auto t3 = now();
@@ -883,6 +911,7 @@ wfl_lattice_host* wfl_transducer_pack_batch(const wfl_graph* tokens, const wfl_g
 }
 
 void wfl_lattice_host_free(wfl_lattice_host* h) { delete h; }
+int64_t wfl_lattice_host_external(const wfl_lattice_host* h) { return h ? h->external_ints_offset : -1; }
 const wfl_lattice_desc* wfl_lattice_host_desc(const wfl_lattice_host* h) { return &h->desc; }
 const int32_t* wfl_lattice_host_ints(const wfl_lattice_host* h) { return h->ints.data(); }
 const float* wfl_lattice_host_floats(const wfl_lattice_host* h) { return h->floats.data(); }

@@ -139,9 +139,10 @@ class LRU:
 class PackedLattice:
     """B acceptors in the flat device format of `wfl_lattice_desc`, resident in HBM."""
 
-    def __init__(self, host_handle, device, extra=None):
+    def __init__(self, host_handle, device, extra=None, staged=None):
         """`extra`: optional float32 host array uploaded behind the float blob in the same copy (per-utterance loss
-        factors); `self.extra` is its device view."""
+        factors); `self.extra` is its device view.  `staged` = (slot, buf, view): the packer already wrote the blobs
+        into that staging slot (wfl_transducer_pack_batch_into)."""
         N.check_handle(host_handle)
         cuda = device is not None and device.type == "cuda"
         try:
@@ -151,22 +152,28 @@ class PackedLattice:
             ne = 0 if extra is None else int(extra.size)
             off_i = (4 * (nf + ne) + 15) & ~15  # [floats | extra | pad to 16 B | ints]: ONE buffer, one upload
             nbytes = off_i + 4 * max(ni, 1)
-            if cuda:
+            external = staged is not None and N.lib.wfl_lattice_host_external(host_handle) == off_i
+            if external:
+                slot, buf, view = staged
+                ring = _LATTICE_STAGING[device.index]
+            elif cuda:
                 # through a ring of reusable PINNED buffers and one asynchronous copy: a pageable copy is synchronous
                 # (it would wait for everything queued on the stream before it -- the previous step's kernels), and
                 # a fresh pinned allocation per batch costs a hipHostMalloc
                 ring = _LATTICE_STAGING.get(device.index)
                 if ring is None:
                     ring = _LATTICE_STAGING[device.index] = _StagingRing(slots=4, nbytes=1 << 22)
+                if staged is not None:
+                    ring.i -= 1  # (the slot offered to the packer was too small: take it again, grown)
                 slot, buf, view = ring.next(nbytes, True)
             else:
                 buf = torch.empty(nbytes, dtype=torch.uint8)
                 view = buf.numpy()
-            if nf:
+            if nf and not external:
                 ctypes.memmove(buf.data_ptr(), N.lib.wfl_lattice_host_floats(host_handle), 4 * nf)
             if ne:
                 view[4 * nf:4 * (nf + ne)].view(np.float32)[:] = np.asarray(extra, dtype=np.float32).reshape(-1)
-            if ni:
+            if ni and not external:
                 ctypes.memmove(buf.data_ptr() + off_i, N.lib.wfl_lattice_host_ints(host_handle), 4 * ni)
         finally:
             N.lib.wfl_lattice_host_free(host_handle)
@@ -230,9 +237,21 @@ class PackedLattice:
         flat = np.ascontiguousarray(flat, dtype=np.int32)
         if flat.size == 0:
             flat = np.zeros(1, np.int32)
-        h = N.lib.wfl_transducer_pack_batch(tokens._h, lexicon._h, None if transitions is None else transitions._h,
-                                            flat.ctypes.data, offsets.ctypes.data, len(offsets) - 1, int(C), int(nthreads))
-        return cls(h, device, extra)
+        tr = None if transitions is None else transitions._h
+        staged = None
+        if device is not None and device.type == "cuda":
+            # the packer writes the blobs straight into the pinned staging slot they are uploaded from
+            ring = _LATTICE_STAGING.get(device.index)
+            if ring is None:
+                ring = _LATTICE_STAGING[device.index] = _StagingRing(slots=4, nbytes=1 << 22)
+            staged = ring.next(ring.nbytes, True)
+            h = N.lib.wfl_transducer_pack_batch_into(tokens._h, lexicon._h, tr, flat.ctypes.data, offsets.ctypes.data,
+                                                     len(offsets) - 1, int(C), int(nthreads), staged[1].data_ptr(),
+                                                     staged[1].numel(), 0 if extra is None else int(extra.size))
+        else:
+            h = N.lib.wfl_transducer_pack_batch(tokens._h, lexicon._h, tr, flat.ctypes.data, offsets.ctypes.data,
+                                                len(offsets) - 1, int(C), int(nthreads))
+        return cls(h, device, extra, staged)
 
     @classmethod
     def ctc(cls, flat, offsets, blank, C, device):

@@ -158,6 +158,16 @@ wfl_lattice_host* wfl_lattice_pack(const wfl_graph* const* graphs, const int32_t
 wfl_lattice_host* wfl_transducer_pack_batch(const wfl_graph* tokens, const wfl_graph* lexicon,
                                             const wfl_graph* transitions, const int32_t* targets,
                                             const int64_t* offsets, int B, int C, int nthreads);
+/* The same, with the blobs written to the CALLER's buffer (typically pinned staging memory that is then uploaded:
+ * saves the copy out of the handle) if they fit: `dst` (16-byte aligned, dst_bytes) receives
+ * [float blob | reserve_floats floats left for the caller | pad to 16 bytes | int32 blob].
+ * wfl_lattice_host_external(h) then returns the byte offset of the int blob in dst (and the handle holds only the
+ * descriptor); -1 means the blobs did not fit (or dst was NULL) and are in the handle as usual. */
+wfl_lattice_host* wfl_transducer_pack_batch_into(const wfl_graph* tokens, const wfl_graph* lexicon,
+                                                 const wfl_graph* transitions, const int32_t* targets,
+                                                 const int64_t* offsets, int B, int C, int nthreads, void* dst,
+                                                 int64_t dst_bytes, int64_t reserve_floats);
+int64_t wfl_lattice_host_external(const wfl_lattice_host* h);
 /* Bulk builders for the three fixed-topology label graphs (no per-arc host calls):
  *   CTC  create_ctc_graph          ctc.py:15-29     targets flat + offsets[B+1], blank
  *   ASG  create_force_align_graph  asg.py:72-81 composed with the transitions graph asg.py:54-69:

@@ -550,6 +550,47 @@ def test_native_batch_builder_equals_per_utterance_graph_algebra(with_transition
     assert f2.tolist() == [2, 2, 1, 0] and o2.tolist() == [0, 3, 4] and l2 == [3, 1]
 
 
+def test_batch_builder_writes_into_the_callers_buffer():
+    """wfl_transducer_pack_batch_into: [floats | reserved | pad to 16 B | ints] laid out in the caller's (staging)
+    buffer, byte-equal to the library-owned blobs; a buffer that is too small falls back to library storage."""
+    import ctypes
+
+    rs = np.random.RandomState(9)
+    pieces = ["a", "b", "ab", "ba", "aba", "c", "ca"]
+    g2i = {"a": 0, "b": 1, "c": 2}
+    tokens = TR.make_token_graph(pieces, "optional", False)
+    lexicon = TR.make_lexicon_graph(pieces, g2i)
+    tokens.arc_sort(True)
+    C = len(pieces) + 1
+    rows = [[g2i[ch] for _ in range(rs.randint(1, 6)) for ch in pieces[rs.randint(len(pieces))]] for _ in range(11)]
+    flat, off, _ = E.flatten_targets(rows)
+    want = E.PackedLattice.transducer_batch(tokens, lexicon, None, flat, off, C, None, 1)
+    nf, ni = want.host_floats.size, want.host_ints.size
+    for reserve in (0, 5):
+        off_i = (4 * (nf + reserve) + 15) & ~15
+        for nbytes, fits in ((off_i + 4 * ni + 64, True), (off_i + 4 * ni, True), (off_i + 4 * ni - 4, False)):
+            buf = np.full(nbytes, 0xAB, dtype=np.uint8)
+            h = N.lib.wfl_transducer_pack_batch_into(tokens._h, lexicon._h, None, flat.ctypes.data, off.ctypes.data,
+                                                     len(off) - 1, C, 0, buf.ctypes.data, nbytes, reserve)
+            N.check_handle(h)
+            try:
+                ext = N.lib.wfl_lattice_host_external(h)
+                assert ext == (off_i if fits else -1)
+                d = N.lib.wfl_lattice_host_desc(h).contents
+                assert (int(d.float_words), int(d.int_words)) == (nf, ni)
+                if fits:
+                    np.testing.assert_array_equal(buf[:4 * nf].view(np.float32), want.host_floats)
+                    np.testing.assert_array_equal(buf[off_i:off_i + 4 * ni].view(np.int32), want.host_ints)
+                    assert not buf[4 * (nf + reserve):off_i].any()  # the pad is zeroed, the reserve is the caller's
+                else:
+                    got = np.ctypeslib.as_array(ctypes.cast(N.lib.wfl_lattice_host_ints(h),
+                                                            ctypes.POINTER(ctypes.c_int32)), (ni,))
+                    np.testing.assert_array_equal(got, want.host_ints)
+                    assert (buf == 0xAB).all()
+            finally:
+                N.lib.wfl_lattice_host_free(h)
+
+
 def test_asg_class_limit_is_reported_at_construction():
     """documented deviation: the dense-transition kernels keep the (N+1) x N matrix on chip"""
     limit = asg.max_classes()
