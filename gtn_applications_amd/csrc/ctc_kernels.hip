@@ -128,8 +128,12 @@ struct CtcArgs {
   // (target position i), slot L = x[b][t][blank] -- written by ctc_compact_x_kernel (see wfl_ctc_forward_backward)
   const float* xc;
   int place;  // fast pipelined step: 1 = keep an utterance's chains and gradient items on one XCD (speed only)
+  // fast pipelined step with persistent gradient waves, optional: kParkStride floats per gradient wave, where a wave
+  // leaves the emission factors of its SECOND item before it starts waiting for the checkpoints of its first
+  float* park;
 };
 constexpr int kXcStride = 64;
+constexpr int kParkStride = 17 * 64;  // 16 frames x 64 lanes of factors + the per-lane reference word
 
 // ---- pieces shared by the chains of the pipelined launches -------------------------------------------
 __device__ __forceinline__ void coherent_store64(void* p, unsigned long long v) {
@@ -1240,9 +1244,55 @@ __device__ __forceinline__ void fmac2_shl1(float& acc, float s0, float s1, float
 //   Z_local = sum_s alpha_{n-1}(s) [A beta~_n](s)  (relative to the checkpoints' offsets and the
 //   block's references); posterior = ma mb' K(s) with K(s) = 2^(ea + eb - E) / Zm folded into ma.
 // ------------------------------------------------------------------------------------------------
+// Emission factors of one block's frames for the lane's column: f_j = 2^(x log2e - r_j), r_j = round(largest
+// target-label score of frame j) -- rr holds r_j in the lanes with (lane & 15) == j.
+template <bool LSM>
+__device__ __forceinline__ void fast_block_factors(const float* __restrict__ esrc, int estride, int eidx, int t0, int n, int T,
+                                                   float lse_blk, int lane, float (&f)[kBlk], float& rr) {
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) f[j] = esrc[(int64_t)min(t0 + j, T - 1) * estride + eidx];  // all 16 gathers in flight
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    const float v = (LSM ? f[j] - readlane_f(lse_blk, j) : f[j]) * kLog2e;
+    f[j] = (v == v && j < n) ? v : WFL_NEG_INF;  // NaN policy: impossible
+  }
+  const float m = fold16<true>(f, lane);  // lane j < 16 (every row): the maximum of frame j
+  rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) f[j] = __builtin_amdgcn_exp2f(f[j] - readlane_f(rr, j));
+}
+
+// A persistent gradient wave has nothing to do until the checkpoints of its first item exist (half the chain time
+// at the earliest) and is then busy to the end of the launch: it computes the factors of its SECOND item -- gathers,
+// references, exp2: a third of an item -- in that idle time and leaves them in its slot of a.park.
+template <bool LSM, bool XC>
+__device__ __forceinline__ void ctc_fast_park_factors(const CtcArgs& a, int b, int k, float* __restrict__ park) {
+  const int lane = threadIdx.x & 63;
+  const int T = a.T, t0 = k * kBlk, n = min(kBlk, T - t0);
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  const int col = lane < L ? a.targets[o0 + lane] : a.blank;
+  const float* esrc = XC ? a.xc + (int64_t)b * T * kXcStride : a.x + (int64_t)b * T * a.C;
+  float lse_blk = 0.f;
+  if (LSM) lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
+  float f[kBlk], rr;
+  fast_block_factors<LSM>(esrc, XC ? kXcStride : a.C, XC ? (lane < L ? lane : L) : col, t0, n, T, lse_blk, lane, f, rr);
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) park[j * 64 + lane] = f[j];
+  park[kBlk * 64 + lane] = rr;
+}
+
+// what a gradient wave keeps of its utterance from one item to the next (a persistent wave's items belong to one
+// utterance whenever the stride is a multiple of the batch)
+struct FastUtt {
+  int b = -1, L = 0, y = -1, yprev = -1, ynext = -1;
+  float cf = 0.f;
+};
+
 template <bool LSM, bool CERT, bool COMPACT = false, bool XC = false>
 __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
-                                                   const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
+                                                   const float* __restrict__ gout, float* __restrict__ dx, char* smem,
+                                                   FastUtt& u, const float* __restrict__ parked = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = a.T, C = a.C, P = a.P;
   const int NB = ctc_blocks(T);
@@ -1252,13 +1302,33 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   long long* dbg = (long long*)(a.ws + w.dbg) + ((int64_t)b * NB + k) * 4;
   if (lane == 0) dbg[0] = wall_clock64();
 #endif
+  // ---- first, what needs a round trip and depends on nothing: the two flags, the parked factors, the utterance
+  const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
+  const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
+  const unsigned long long seen_a = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long seen_b = __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float xs[kBlk], rr = 0.f;  // emission factors of the block's frames (this lane's column), per-frame references
+  if (parked) {  // (uniform) this wave computed them while it waited for its first item: ctc_fast_park_factors
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) xs[j] = parked[j * 64 + lane];
+    rr = parked[kBlk * 64 + lane];
+  }
+  if (u.b != b) {  // (uniform)
+    const int64_t o0 = a.offsets[b];
+    u.L = (int)(a.offsets[b + 1] - o0);
+    u.y = lane < u.L ? a.targets[o0 + lane] : -1;
+    u.yprev = (lane >= 1 && lane - 1 < u.L) ? a.targets[o0 + lane - 1] : -1;
+    u.ynext = lane + 1 < u.L ? a.targets[o0 + lane + 1] : -1;
+    u.cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+    u.b = b;
+  }
   // Gradient rows of the wave: the dense LDS tile [16][C] (scattered into, copied out in one piece) for narrow rows,
   // the COMPACT tile + column map (see compact_expand) for wide ones.
   char* wbase = smem + (size_t)wave * (COMPACT ? compact_wave_bytes(C) : (size_t)kBlk * C * 4);
   float* rows = (float*)wbase;
   unsigned char* cmap = (unsigned char*)(wbase + (size_t)kCTileBytes);  // (COMPACT only)
   const int t0 = k * kBlk, n = min(kBlk, T - t0);
-  const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+  const float cf = u.cf;
   float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
   if (COMPACT)
     compact_init(rows, cmap, C, lane);
@@ -1268,11 +1338,7 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
     lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
     if (!COMPACT) lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf, lane);
   }
-  const int64_t o0 = a.offsets[b];
-  const int L = (int)(a.offsets[b + 1] - o0);
-  const int y = lane < L ? a.targets[o0 + lane] : -1;
-  const int yprev = (lane >= 1 && lane - 1 < L) ? a.targets[o0 + lane - 1] : -1;
-  const int ynext = lane + 1 < L ? a.targets[o0 + lane + 1] : -1;
+  const int L = u.L, y = u.y, yprev = u.yprev, ynext = u.ynext;
   const bool has_label = lane < L;
   const bool skip = has_label && lane >= 1 && y != yprev;  // label i-1 -> label i
   const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
@@ -1284,8 +1350,6 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
 
   // ---- the two checkpoints: a block of a later round finds them published when it starts -- their loads then
   // travel together with the gathers instead of after them
-  const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
-  const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
   auto flags_up = [&]() {
     return __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
            __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
@@ -1312,28 +1376,18 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
     if (CERT && lane == 0) off_sum = coherent_load_f64(&offa[k]) + coherent_load_f64(&offb[NB - 1 - k]);
     dupmask = coherent_load64((const unsigned long long*)(a.ws + w.dup) + b);
   };
-  const bool early = flags_up();  // (uniform)
+  const bool early = seen_a == a.token && seen_b == a.token;  // (uniform)
   if (early) load_checkpoints();
 
   // ---- emission factors of the block's frames: f = 2^(x log2e - r_j), r_j = round(largest target-label score)
   float fl[kBlk], fb[kBlk];
   float rsum;
   {
-    float xs[kBlk];
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j) xs[j] = esrc[(int64_t)min(t0 + j, T - 1) * estride + eidx];  // all 16 gathers in flight
+    if (!parked) fast_block_factors<LSM>(esrc, estride, eidx, t0, n, T, lse_blk, lane, xs, rr);
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {
-      const float v = (LSM ? xs[j] - readlane_f(lse_blk, j) : xs[j]) * kLog2e;
-      xs[j] = (v == v && j < n) ? v : WFL_NEG_INF;  // NaN policy: impossible
-    }
-    const float m = fold16<true>(xs, lane);  // lane j < 16 (every row): the maximum of frame j
-    const float rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j) {
-      const float f = __builtin_amdgcn_exp2f(xs[j] - readlane_f(rr, j));
-      fb[j] = readlane_f(f, L);
-      fl[j] = has_label ? f : 0.f;
+      fb[j] = readlane_f(xs[j], L);
+      fl[j] = has_label ? xs[j] : 0.f;
     }
     rsum = wave_all_sum(lane < n ? rr : 0.f);
   }
@@ -1602,11 +1656,24 @@ __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_
   const bool placed = a.place && (gwgs & 7) == 0;
   const int xcd = placed ? g & 7 : 0, mult = placed ? 8 : 1, nb = placed ? a.B >> 3 : a.B;  // utterances of this XCD
   const int stride = (placed ? gwgs >> 3 : gwgs) * kFWaves;
-  for (int li = __builtin_amdgcn_readfirstlane((placed ? g >> 3 : g) * kFWaves + (int)(threadIdx.x >> 6)); li < nb * NB;
-       li += stride) {
-    const int r = li / nb, b = (li % nb) * mult + xcd;  // r: rank in readiness order
-    const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-    ctc_fast_grad_body<LSM, true, COMPACT, XC>(a, true, b, k, coef, gout, dx, smem);
+  const int first = __builtin_amdgcn_readfirstlane((placed ? g >> 3 : g) * kFWaves + (int)(threadIdx.x >> 6));
+  auto item = [&](int li, int& b, int& k) {
+    const int r = li / nb;  // rank in readiness order
+    b = (li % nb) * mult + xcd;
+    k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+  };
+  float* park = nullptr;
+  if (a.park && first + stride < nb * NB) {
+    park = a.park + (int64_t)__builtin_amdgcn_readfirstlane(g * kFWaves + (int)(threadIdx.x >> 6)) * kParkStride;
+    int b2, k2;
+    item(first + stride, b2, k2);
+    ctc_fast_park_factors<LSM, XC>(a, b2, k2, park);
+  }
+  FastUtt utt;
+  for (int li = first; li < nb * NB; li += stride) {
+    int b, k;
+    item(li, b, k);
+    ctc_fast_grad_body<LSM, true, COMPACT, XC>(a, true, b, k, coef, gout, dx, smem, utt, li == first + stride ? park : nullptr);
   }
 }
 
@@ -1617,7 +1684,8 @@ __global__ void __launch_bounds__(kFWaves * 64) dbg_fast_chain_only(CtcArgs a) {
 }
 __global__ void __launch_bounds__(kFWaves * 64) dbg_fast_grad_only(CtcArgs a, const float* coef, const float* gout, float* dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  ctc_fast_grad_body<false, true, false>(a, true, (int)blockIdx.x, (int)blockIdx.y, coef, gout, dx, smem);
+  FastUtt utt;
+  ctc_fast_grad_body<false, true, false>(a, true, (int)blockIdx.x, (int)blockIdx.y, coef, gout, dx, smem, utt);
 }
 #endif
 
@@ -2155,12 +2223,42 @@ static bool ctc_use_xc(int B, int T, int C, int max_len) {
   return (int64_t)B * T * C * 4 >= (192ll << 20) && C >= 192;
 }
 
+// Gradient workgroups of the fast pipelined launch: one item per wave, or -- small batches, where the launch is
+// latency-bound and all chains plus a full complement of gradient workgroups are resident at once (three workgroups
+// per CU) -- as many workgroups as there are free slots, their waves looping over the items (WFL_CTC_GRAD_WGS: 0 = one
+// item per wave, n = that many workgroups).
+static int64_t ctc_fast_grad_wgs(int B, int T) {
+  static const int n_cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static const int grad_wgs_env = [] {
+    const char* e = getenv("WFL_CTC_GRAD_WGS");
+    return e ? atoi(e) : -1;
+  }();
+  const int64_t all_wgs = ((int64_t)B * ctc_blocks(T) + kFWaves - 1) / kFWaves;
+  if (grad_wgs_env > 0) return std::min<int64_t>(all_wgs, grad_wgs_env);
+  if (grad_wgs_env < 0 && 2 * (int64_t)B <= 3 * n_cus / 2) return std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
+  return all_wgs;
+}
+// parking area of the persistent gradient waves (CtcArgs::park), behind the compact emission copy.  WFL_CTC_PARK=0: none
+static int64_t ctc_park_floats(int B, int T) {
+  static const bool off = [] {
+    const char* e = getenv("WFL_CTC_PARK");
+    return e && atoi(e) == 0;
+  }();
+  const int64_t wgs = ctc_fast_grad_wgs(B, T), all_wgs = ((int64_t)B * ctc_blocks(T) + kFWaves - 1) / kFWaves;
+  return (off || wgs >= all_wgs) ? 0 : wgs * kFWaves * kParkStride;
+}
+
 int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems) {
   if (!ws_elems || B <= 0 || T <= 0 || max_len < 0) {
     set_error("ctc_workspace: bad arguments");
     return WFL_ERR_INVALID;
   }
-  *ws_elems = ctc_ws_layout(B, T, max_len + 1).total + (ctc_use_xc(B, T, C, max_len) ? 4 + (int64_t)B * T * kXcStride : 0);
+  *ws_elems = ctc_ws_layout(B, T, max_len + 1).total + 4 + (ctc_use_xc(B, T, C, max_len) ? (int64_t)B * T * kXcStride : 0) +
+              ctc_park_floats(B, T);
   return WFL_OK;
 }
 
@@ -2262,25 +2360,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
     const size_t lds = std::max(compact ? compact_lds : rows8_lds, sizeof(FastLdsT));
     static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)
-    // gradient workgroups: one item per wave, or -- small batches, where the launch is latency-bound and all chains
-    // plus a full complement of gradient workgroups are resident at once (three workgroups per CU) -- as many
-    // workgroups as there are free slots, their waves looping over the items (WFL_CTC_GRAD_WGS: 0 = one item per
-    // wave, n = that many workgroups)
-    static const int n_cus = [] {
-      int dev = 0, n = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      return n > 0 ? n : 256;
-    }();
-    static const int grad_wgs_env = [] {
-      const char* e = getenv("WFL_CTC_GRAD_WGS");
-      return e ? atoi(e) : -1;
-    }();
-    const int64_t all_wgs = (items + kFWaves - 1) / kFWaves;
-    int64_t grad_wgs = all_wgs;
-    if (grad_wgs_env > 0)
-      grad_wgs = std::min<int64_t>(all_wgs, grad_wgs_env);
-    else if (grad_wgs_env < 0 && 2 * (int64_t)B <= 3 * n_cus / 2)
-      grad_wgs = std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
+    const int64_t grad_wgs = ctc_fast_grad_wgs(B, T);
     const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : grad_wgs)));
     static const int place_env = [] {
       // Measured on one box, cfg2: placement cuts the memory-side traffic of the launch 278 -> 223 MB (x[b] lands in
@@ -2290,8 +2370,10 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       return e ? atoi(e) : 0;
     }();
     a.place = place_env && (B & 7) == 0;
+    float* behind = ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3);
+    a.park = ctc_park_floats(B, T) ? behind + (ctc_use_xc(B, T, C, max_len) ? (int64_t)B * T * kXcStride : 0) : nullptr;
     if (compact && ctc_use_xc(B, T, C, max_len)) {  // (wide rows: they use the compact gradient tile)
-      float* xc = ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3);
+      float* xc = behind;
       // (a streaming variant -- coalesced float4 rows through an LDS tile -- is no faster: 141 vs 143 us at cfg5.  The
       // pass also absorbs the write-back of the previous step's gradient, still dirty in the Infinity Cache.)
       const unsigned gx = (unsigned)std::max(1, std::min((T + 4 * kXcRows - 1) / (4 * kXcRows), 64));
