@@ -285,7 +285,7 @@ int wfl_conv_forward(const float* x, int B, int T, int C, const int32_t* ktab, i
   const int spike = flags & WFL_CONV_SPIKE ? 1 : 0, bo = flags & WFL_CONV_BLANK_OPTIONAL ? 1 : 0;
   auto launch = [&](auto kern) -> int {
     if (lds > 48 * 1024)
-      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x, T, C, ktab, K, ks, stride, blank, spike, bo,
                        params, out);
     return WFL_OK;
@@ -312,7 +312,7 @@ int wfl_conv_grad(const float* x, int B, int T, int C, const int32_t* ktab, int 
   const int spike = flags & WFL_CONV_SPIKE ? 1 : 0, bo = flags & WFL_CONV_BLANK_OPTIONAL ? 1 : 0;
   auto launch = [&](auto kern) -> int {
     if (lds > 48 * 1024)
-      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x, T, C, ktab, K, ks, stride, blank, spike, bo,
                        params, delta, dx, dparams);
     return WFL_OK;

@@ -2338,7 +2338,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       return WFL_ERR_UNSUPPORTED;
     }
     if (lds > 48 * 1024)
-      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
     return WFL_OK;
   };
@@ -2383,7 +2383,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       a.xc = xc;
     }
     auto launch_fast = [&](auto kern) -> int {
-      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
       hipLaunchKernelGGL(kern, grid8, dim3(kFWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
       return WFL_OK;
     };
@@ -2397,7 +2397,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     auto launch_repair = [&](auto kern) -> int {
       const size_t lds = std::max(rows_lds, sizeof(ChainLdsT));
       if (lds > 48 * 1024)
-        WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
       const dim3 rgrid((unsigned)(2 * B + std::min<int64_t>((items + 3) / 4, 512)));
       hipLaunchKernelGGL(kern, rgrid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
       return WFL_OK;
@@ -2441,7 +2441,7 @@ int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, co
   const size_t lds = lcompact ? (size_t)4 * compact_wave_bytes(C) : (size_t)4 * (kBlk + 1) * C * 4;
   auto launch = [&](auto kern) -> int {
     if (lds > 48 * 1024)
-      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
     return WFL_OK;
   };

@@ -454,7 +454,10 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   // Emission rows travel HBM -> registers kDepth items ahead of their use.  (The first version kept 4 in flight: with
   // ~1.7 us of load latency under load that alone pinned the sweep at latency / 4 = ~1000 cycles per frame, whatever
   // the matrix-vector product cost -- measured with three different product layouts.)
-  constexpr int kDepth = 16;
+  // 31 rows = 62 loads: as deep as the 6-bit vmcnt counter allows.  With 16, the sweep ran at 343 us alone but at 375 us
+  // next to the numerator's gradient kernel streaming 170 MB on the other stream (the round trip grows past the 5.4 us
+  // that 16 frames cover); with 31: 358 us.
+  constexpr int kDepth = 31;
   float raw[kDepth][2];
   double mrun = 0.0;
   auto item_ok = [&](int r) { return DIR == 0 ? r < T : (r >= 1 && r < T); };
@@ -602,8 +605,11 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   // ---- intervals: interval n ends with barrier n; the chain performs step n, the helper stages
   // item n + 2 and issues the loads of item n + 6.  Role-specialised loops with the same barrier count.
   // five waves on four SIMDs: the helper shares one with a chain wave and must not take its issue slots
+#ifndef WFL_DENSE_CHAIN_PRIO
+#define WFL_DENSE_CHAIN_PRIO 3
+#endif
   if (wave < kDenseChainWaves)
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(WFL_DENSE_CHAIN_PRIO);
   else
     __builtin_amdgcn_s_setprio(0);
   if (wave < kDenseChainWaves) {
@@ -704,6 +710,10 @@ __global__ void __launch_bounds__(kDenseThreads)
 // workgroups fit the grid on a CU: unpipelined, every stage paid a full HBM round trip with nothing else to run
 // (214 us at B=128, T=1000, C=100 against 40 us of traffic and 31 us of FMAs).  The loads of stage s+1 (and the
 // per-frame scale words) are therefore issued into registers BEFORE the FMAs of stage s and consumed after them.
+__device__ __forceinline__ float at_byte(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 template <int CP, int TS>
 __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
     dense_fast_grad_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, int B,
@@ -738,15 +748,25 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
   for (int k = 0; k < NI; ++k) {
     const int idx = tid + k * NT;
     er[k] = idx / CP, ei[k] = idx - er[k] * CP;
-    if (idx >= TS * CP || ei[k] >= C) er[k] = -1;
+    if (idx >= TS * CP || ei[k] >= C) er[k] = -1, ei[k] = 0;
   }
   // registers of the stage in flight.  issue() only LOADS (branch-free, from clamped addresses): any arithmetic on
-  // a loaded value here would put its s_waitcnt in front of the FMAs the loads are meant to fly under.
+  // a loaded value here would put its s_waitcnt in front of the FMAs the loads are meant to fly under.  Addresses are
+  // the utterance's (uniform) base pointers plus 32-bit BYTE offsets (scalar base + vector offset addressing), built
+  // with 24-bit multiplies.  With 64-bit per-element addresses the kernel sat at 242 registers and the allocator
+  // recycled the destinations of loads still in flight as address temporaries (even the dead upper half of a
+  // v_mad_u64_u32 result shares a register with a load in flight): a wait for a full round trip after every few
+  // loads of the "prefetch" -- measured 163 -> 127 us for this kernel + the reduction at cfg3.
   float ra[NI], rb[NI], rx[NI], rp[NI], rd[NI], re[NI];
   double q_ma = 0., q_mb = 0., q_mp = 0.;  // lane r < TS: scale words of frame t0 + r (and of the frame before it)
   int32_t q_ea = 0, q_eb = 0, q_ep = 0;
   float q_m2 = 0.f;
-  const float* const prev_dx = (dx && accumulate) ? dx : nullptr;
+  const float* const ab = alpha + base;
+  const float* const bb = beta + base;
+  const float* const xb = x + base;
+  float* const dxb = dx ? dx + base : nullptr;
+  const float* const prev_dx = (dx && accumulate) ? dx + base : nullptr;
+  const float* const addb = addend ? addend + base : nullptr;
   auto issue = [&](int t0) {
     if (tid < TS) {
       const int t = min(t0 + tid, T - 1), tp = max(t - 1, 0);
@@ -755,22 +775,11 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       const int t = min(t0 + max(er[k], 0), t_end - 1);
-      const int64_t o = base + (int64_t)t * C + (er[k] >= 0 ? ei[k] : 0);
-      ra[k] = alpha[o], rb[k] = beta[o], rx[k] = x[o], rp[k] = alpha[t > 0 ? o - C : o];
-    }
-    if (prev_dx) {
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        const int t = min(t0 + max(er[k], 0), t_end - 1);
-        rd[k] = prev_dx[base + (int64_t)t * C + (er[k] >= 0 ? ei[k] : 0)];
-      }
-    }
-    if (addend) {
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        const int t = min(t0 + max(er[k], 0), t_end - 1);
-        re[k] = addend[base + (int64_t)t * C + (er[k] >= 0 ? ei[k] : 0)];
-      }
+      const unsigned o = 4u * (__umul24((unsigned)t, (unsigned)C) + (unsigned)ei[k]);
+      ra[k] = at_byte(ab, o), rb[k] = at_byte(bb, o), rx[k] = at_byte(xb, o);
+      rp[k] = at_byte(ab, t > 0 ? o - 4u * (unsigned)C : o);
+      if (prev_dx) rd[k] = at_byte(prev_dx, o);
+      if (addb) re[k] = at_byte(addb, o);
     }
   };
   auto scales = [&](int t0, int buf) {  // first wave: the stage's per-frame powers of two
@@ -802,10 +811,11 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
       const int r = er[k], i = ei[k], t = t0 + r;
       float uu = 0.f, aa = 0.f;
       if (t < t_end) {
-        const int64_t o = base + (int64_t)t * C + i;
         const float hg = sc[buf][r][0], hx = sc[buf][r][1];
         const float g = (ra[k] * hg) * (rb[k] * hg);
-        if (dx) dx[o] = (prev_dx ? rd[k] : 0.f) + (addend ? g0 * re[k] : 0.f) + cf * g;
+        if (dxb)
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(dxb) + 4u * (__umul24((unsigned)t, (unsigned)C) + (unsigned)i)) =
+              (prev_dx ? rd[k] : 0.f) + (addb ? g0 * re[k] : 0.f) + cf * g;
         if (partial) {
           if (t > 0) {
             const float e = __builtin_amdgcn_exp2f(fmaf(nan_to_neg(rx[k]), kLog2e, wr2[i]) - sc[buf][r][2]);
@@ -843,27 +853,34 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
     if (active) {
       // all 64 transition scores first, from clamped (always valid) addresses: a load inside the bounds test below
       // would be waited for element by element -- 64 dependent HBM round trips, most of this kernel's time before
-      float wv[8][8];
+      // (in two halves of four rows: 64 more live registers would set the kernel's register count)
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int ih = 0; ih < 8; ih += 4) {
+        float wv[4][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wv[i][j] = W[(1 + min(8 * ti + i, C - 1)) * C + min(8 * tj + j, C - 1)];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int si = 8 * ti + i;
-        const float wr = wr2[min(si, CP - 1)];
+          for (int j = 0; j < 8; ++j) wv[i][j] = W[(1 + min(8 * ti + ih + i, C - 1)) * C + min(8 * tj + j, C - 1)];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int sj = 8 * tj + j;
-          const float p = __builtin_amdgcn_exp2f(fmaf(wv[i][j], kLog2e, -wr));
-          if (si < C && sj < C) dst[(1 + si) * C + sj] = acc[i][j] * p;
+        for (int i = 0; i < 4; ++i) {
+          const int si = 8 * ti + ih + i;
+          const float wr = wr2[min(si, CP - 1)];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int sj = 8 * tj + j;
+            const float p = __builtin_amdgcn_exp2f(fmaf(wv[i][j], kLog2e, -wr));
+            if (si < C && sj < C) dst[(1 + si) * C + sj] = acc[ih + i][j] * p;
+          }
         }
       }
     }
   }
 }
 
-constexpr int kGradStage = 8;  // frames per LDS stage of dense_fast_grad_kernel
+#ifndef WFL_DENSE_GRAD_STAGE
+#define WFL_DENSE_GRAD_STAGE 8
+#endif
+constexpr int kGradStage = WFL_DENSE_GRAD_STAGE;  // frames per LDS stage of dense_fast_grad_kernel
 static int dense_chunks(int B, int T) { return std::max(1, std::min(T, (512 + B - 1) / B)); }
 
 }  // namespace wfl
@@ -932,7 +949,7 @@ int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int s
     // log-domain sweep: everything when there is no fast path, otherwise only flagged utterances
     auto k = dense_chain_kernel<WFL_SEMIRING_LOG>;
     if (lds > 48 * 1024)
-      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)k, (int)lds));
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, W, T, C, ldw, alpha, beta, (int32_t*)nullptr, logz,
                        cp ? (const int32_t*)w.flag : (const int32_t*)nullptr);
   } else {
@@ -942,7 +959,7 @@ int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int s
     }
     auto k = dense_chain_kernel<WFL_SEMIRING_TROPICAL>;
     if (lds > 48 * 1024)
-      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)k, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)B, 1u), dim3(256), lds, st, x, W, T, C, ldw, alpha, (float*)nullptr, bptr,
                        logz, (const int32_t*)nullptr);
   }

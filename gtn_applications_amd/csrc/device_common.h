@@ -7,6 +7,10 @@
 
 #include "common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #define WFL_NEG_INF (-__builtin_inff())
 
 #define WFL_HIP_CHECK(expr)                                                              \
@@ -17,6 +21,23 @@
       return WFL_ERR_RUNTIME;                                                            \
     }                                                                                    \
   } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of once per launch: the
+// call costs the host a microsecond or two, and the CTC operator is host-bound at B = 128
+namespace wfl {
+inline hipError_t set_max_dynamic_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  int& have = done[{dev, kern}];
+  if (have >= bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+}  // namespace wfl
 
 #define WFL_LAUNCH_CHECK()                                                         \
   do {                                                                             \

@@ -1383,6 +1383,10 @@ __global__ void __launch_bounds__(MAXT)
                       float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz, int64_t tail,
                       int nch1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef WFL_BAND_PRIO
+#define WFL_BAND_PRIO 0
+#endif
+  if (MAXT == 128 && WFL_BAND_PRIO) __builtin_amdgcn_s_setprio(WFL_BAND_PRIO);
   const int b = blockIdx.x, dir = blockIdx.y;
   const UttView u = make_view(d, ints, floats, b, T);
   double* offs_a = reinterpret_cast<double*>(alpha + tail);  // (tail layout: see chain_kernel)
@@ -1523,6 +1527,36 @@ static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
 // ------------------------------------------------------------------------------------------------
 // stage 3: posteriors -> gradient rows
 // ------------------------------------------------------------------------------------------------
+// (banded acceptors: see band_grad_kernel)
+struct BandArcs {
+  int ok, has_self, has_adj, slot_self, slot_adj, wid_self, wid_adj;
+  float w_self, w_adj;
+};
+// lane = state: its in-arcs if they fit the band (ok = 0 otherwise); -inf arcs do not exist (run_chain_prob)
+__device__ __forceinline__ BandArcs band_in_arcs(const UttView& u, const float* __restrict__ weights, int lane) {
+  BandArcs r{1, 0, 0, 0, 0, -1, -1, WFL_NEG_INF, WFL_NEG_INF};
+  if (lane >= u.Q) return r;
+  const int k0 = u.in_ptr[lane], k1 = u.in_ptr[lane + 1];
+  for (int a = k0; a < k1; ++a) {
+    const int wid = u.arc_wid[a];
+    float w = u.arc_w[a];
+    if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+    w = nan_to_neg(w);
+    if (!(w > WFL_NEG_INF)) continue;
+    const int src = u.arc_src[a];
+    if (src == lane && !r.has_self)
+      r.has_self = 1, r.slot_self = u.arc_slot[a], r.wid_self = wid, r.w_self = w;
+    else if (src == lane - 1 && !r.has_adj)
+      r.has_adj = 1, r.slot_adj = u.arc_slot[a], r.wid_adj = wid, r.w_adj = w;
+    else
+      r.ok = 0;
+  }
+  return r;
+}
+__device__ __forceinline__ bool band_shape(const wfl_lattice_desc& d, const UttView& u) {
+  return u.Q >= 1 && u.Q <= 64 && u.E == 0 && d.max_labels <= 64;
+}
+
 constexpr int kChunk = 16;
 #ifdef WFL_DBG_TIMELINE
 __device__ unsigned long long g_dbg[3 * 8192];
@@ -1534,7 +1568,7 @@ __global__ void __launch_bounds__(256)
                 const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
                 int accumulate, const float* __restrict__ x, const float* __restrict__ row_lse,
                 float* __restrict__ dx, float* __restrict__ dW, int rows_per_block, int TS, int64_t tail, int nch1,
-                int R) {
+                int R, int skip_band) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
 #ifdef WFL_DBG_TIMELINE
@@ -1573,6 +1607,10 @@ __global__ void __launch_bounds__(256)
   const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
   const float* wrefs = reinterpret_cast<const float*>(fmt + d.B);
   const bool prob = fmt[b] == kFmtProb;
+  if (skip_band) {  // band_grad_kernel served this utterance (the same test decides there)
+    const int band_ok = band_in_arcs(u, weights, tid).ok;
+    if (__syncthreads_and(band_ok) && prob && band_shape(d, u)) return;
+  }
   const float wref = prob ? wrefs[b] : 0.f;
   const float* fgp = xg + xg_main_dev(d, T);                    // probability-domain factors of the gathered rows
   const float* rmaxp = fgp + xg_main_dev(d, T) + (int64_t)b * T;  // their references
@@ -1810,6 +1848,146 @@ __global__ void __launch_bounds__(256)
     }
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 3 for banded acceptors swept in the probability domain (ASG force alignment, chains without skips: every arc
+// comes from the state itself or from its neighbour, at most 64 states): one WAVE per block of 16 frames, lane = state,
+// no barrier.  The general kernel below stages double-precision tiles of alpha and beta in LDS and walks arc lists
+// behind three barriers per tile -- 170-250 us for the force-alignment lattice of the ASG benchmark, next to which
+// the sweeps take 120; here a lane reads its own alpha (the neighbour's through a DPP wave shift) and beta doubles,
+// forms the two posteriors of its in-arcs, adds them into a compact [16][labels] tile (repeated labels share a
+// slot: LDS float atomics) and the wave expands the tile into the dense rows.  Transition gradients accumulate in
+// two registers per lane over all blocks of the wave: one global atomic per arc and wave.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    band_grad_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                     const float* __restrict__ xg, int T, int C, const float* __restrict__ weights,
+                     const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
+                     const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
+                     int accumulate, float* __restrict__ dx, float* __restrict__ dW, int64_t tail, int nch1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RB = 16;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const UttView u = make_view(d, ints, floats, b, T);
+  const int Q = u.Q, Kmax = d.max_labels;
+  const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
+  const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
+  const double zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];  // log2 Z
+  const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
+  const float wref = reinterpret_cast<const float*>(fmt + d.B)[b];
+  const BandArcs arcs = band_in_arcs(u, weights, lane);
+  const bool shape = fmt[b] == kFmtProb && band_shape(d, u);
+  if (!__syncthreads_and(arcs.ok) || !shape) return;  // the general kernel takes this utterance (same test there)
+  float* acc = reinterpret_cast<float*>(smem) + (size_t)wave * RB * Kmax;  // [RB][Kmax], this wave's
+  int16_t* colmap = reinterpret_cast<int16_t*>(reinterpret_cast<float*>(smem) + (size_t)4 * RB * Kmax);  // [C]
+  if (dx) {
+    for (int c = tid; c < C; c += 256) colmap[c] = -1;
+    __syncthreads();
+    for (int k = tid; k < u.K; k += 256) colmap[u.labels[k]] = (int16_t)k;
+    __syncthreads();
+  }
+  const float g0 = gout ? gout[0] : 1.f;
+  const float cf = coef ? coef[b] * g0 : g0;
+  const float cw = (coef_w ? coef_w[b] : 1.f) * g0;
+  const float z = logz[b];
+  const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
+  const double wfs = arcs.has_self ? (double)fast_exp(arcs.w_self - wref) : 0.0;  // (the sweeps' factors)
+  const double wfa = arcs.has_adj ? (double)fast_exp(arcs.w_adj - wref) : 0.0;
+  // (lanes without a state read the last state's column and multiply it by arc factors of zero: every lane stays
+  // active, so that the per-frame words can be read from ANY lane below -- under `lane < Q` the compiler computes them
+  // for those lanes only)
+  const double* A_ = reinterpret_cast<const double*>(alpha) + u.ab_base + min(lane, Q - 1);
+  const double* B_ = reinterpret_cast<const double*>(beta) + u.ab_base + min(lane, Q - 1);
+  const float* fgu = xg + xg_main_dev(d, T) + u.xg_base;                         // factors of the gathered rows
+  const float* rmu = xg + 2 * xg_main_dev(d, T) + (int64_t)b * T;                // their references
+  const bool one_slot = arcs.slot_self == arcs.slot_adj;
+  double sum_s = 0.0, sum_a = 0.0;
+  const int nblk = (T + RB - 1) / RB, nw = gridDim.x * 4;
+  for (int kb = blockIdx.x * 4 + wave; kb < nblk; kb += nw) {
+    const int t0 = kb * RB, n = min(RB, T - t0);
+    if (dx)
+      for (int i = lane; i < RB * Kmax; i += 64) acc[i] = 0.f;
+    if (!dead) {
+      // gamma_t(arc) = p_alpha[t][src] wf f_t[slot] p_beta[t+1][dst] 2^e_t,
+      // e_t = offs_a[t] + offs_b[t+1] + (r_t + wref) log2e - log2 Z: lane j holds frame t0 + j's as mantissa x 2^exponent
+      double e = 0.0;
+      if (lane < n) e = offs_a[t0 + lane] + offs_b[t0 + lane + 1] + ((double)rmu[t0 + lane] + (double)wref) * kLog2e_d - zd;
+      e = fmin(fmax(e, -2000.0), 2000.0);
+      const double ef = floor(e);
+      const float cm = __builtin_amdgcn_exp2f((float)(e - ef));
+      const int ce = (int)ef;
+      // (eight frames at a time: sixteen frames of operands in flight cost the fourth wave per SIMD)
+      constexpr int HB = RB / 2;
+#pragma unroll 1
+      for (int h = 0; h < RB; h += HB) {
+        if (h >= n) break;
+        double pa[HB], pb[HB];
+        float fs[HB], fa[HB];
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {  // (rows past the end: the last one again, not consumed)
+          const int t = t0 + min(h + j, n - 1);
+          pa[j] = A_[(int64_t)t * Q], pb[j] = B_[(int64_t)(t + 1) * Q];
+          fs[j] = fgu[(int64_t)t * Kmax + arcs.slot_self], fa[j] = fgu[(int64_t)t * Kmax + arcs.slot_adj];
+        }
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          if (h + j < n) {
+            const int lo = __double2loint(pa[j]), hi = __double2hiint(pa[j]);  // the neighbour's alpha (lane 0: none)
+            const double pn = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false),
+                                               __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false));
+            const double cj = ldexp((double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cm), h + j)),
+                                    __builtin_amdgcn_readlane(ce, h + j));
+            const double right = pb[j] * cj;
+            const double ps = pa[j] * wfs * (double)fs[j] * right;
+            const double pd = pn * wfa * (double)fa[j] * right;
+            sum_s += ps, sum_a += pd;
+            if (dx) {
+              float* row = acc + (h + j) * Kmax;
+              if (one_slot) {
+                const float g = (float)(ps + pd);
+                if (g != 0.f) atomicAdd(&row[arcs.slot_self], g);
+              } else {
+                if (ps != 0.0) atomicAdd(&row[arcs.slot_self], (float)ps);
+                if (pd != 0.0) atomicAdd(&row[arcs.slot_adj], (float)pd);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (dx) {
+      // the block's rows are contiguous: dense row value = cf * (the tile entry of the column's label slot)
+      float* g = dx + ((int64_t)b * T + t0) * C;
+      const int total = n * C;
+      const float inv_c = 1.f / (float)C;
+      if ((C & 3) == 0) {
+        for (int i4 = lane; i4 < (total >> 2); i4 += 64) {
+          const int i = i4 << 2;
+          const int r = (int)(((float)i + 0.5f) * inv_c), c = i - r * C;  // (exact for i < 2^20)
+          float4 v = accumulate ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const int k0 = colmap[c], k1 = colmap[c + 1], k2 = colmap[c + 2], k3 = colmap[c + 3];
+          if (k0 >= 0) v.x += cf * acc[r * Kmax + k0];
+          if (k1 >= 0) v.y += cf * acc[r * Kmax + k1];
+          if (k2 >= 0) v.z += cf * acc[r * Kmax + k2];
+          if (k3 >= 0) v.w += cf * acc[r * Kmax + k3];
+          *reinterpret_cast<float4*>(g + i) = v;
+        }
+      } else {
+        for (int i = lane; i < total; i += 64) {
+          const int r = (int)(((float)i + 0.5f) * inv_c), c = i - r * C;
+          const int k = colmap[c];
+          float v = accumulate ? g[i] : 0.f;
+          if (k >= 0) v += cf * acc[r * Kmax + k];
+          g[i] = v;
+        }
+      }
+    }
+  }
+  if (dW && !dead && lane < Q) {
+    if (arcs.wid_self >= 0 && sum_s != 0.0) atomicAdd(&dW[arcs.wid_self], (float)sum_s * cw);
+    if (arcs.wid_adj >= 0 && sum_a != 0.0) atomicAdd(&dW[arcs.wid_adj], (float)sum_a * cw);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2054,7 +2232,7 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     dim3 grid((unsigned)d->B, beta ? 2u : 1u);
     auto k = chain_kernel<WFL_SEMIRING_LOG>;
     if (lds > 48 * 1024)
-      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)k, (int)lds));
     static const int log_only = [] {  // WFL_LATTICE_DOMAIN=log: the fp32 log-domain sweeps throughout (A/B tests)
       const char* e = getenv("WFL_LATTICE_DOMAIN");
       return (e && std::string(e) == "log") ? 1 : 0;
@@ -2063,7 +2241,7 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
       // probability-domain sweeps of every utterance whose acceptor allows it ...
       auto launch_prob = [&](auto kern) {
         if (lds > 48 * 1024)
-          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          (void)wfl::set_max_dynamic_lds((const void*)kern, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
                            beta, logz, tail, nch1);
       };
@@ -2090,7 +2268,7 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
     dim3 grid((unsigned)d->B, 1u);
     auto k = chain_kernel<WFL_SEMIRING_TROPICAL>;
     if (lds > 48 * 1024)
-      WFL_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)k, (int)lds));
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
                        (float*)nullptr, bptr, logz, tail, nch1, 1);
   } else {
@@ -2165,11 +2343,25 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
   int blocks_t = std::max(1, std::min((T + TS - 1) / TS, slots / std::max(1, d->B)));
   int rows_per_block = (T + blocks_t - 1) / blocks_t;
   blocks_t = (T + rows_per_block - 1) / rows_per_block;
+  // banded acceptors swept in the probability domain go to band_grad_kernel; the general launch skips them
+  static const bool band_off = [] {
+    const char* e = getenv("WFL_LATTICE_BAND_GRAD");  // (0: measurements)
+    return e && atoi(e) == 0;
+  }();
+  const int band = !band_off && d->max_states <= 64 && d->max_labels <= 64 && d->max_eps == 0 && !row_lse;
+  if (band) {
+    const int nblk = (T + 15) / 16;
+    const unsigned bx = (unsigned)std::max(1, std::min((nblk + 3) / 4, (1024 + d->B - 1) / d->B));
+    const size_t blds = (size_t)4 * 16 * d->max_labels * 4 + (size_t)2 * C + 16;
+    hipLaunchKernelGGL(band_grad_kernel, dim3(bx, (unsigned)d->B), dim3(256), blds, (hipStream_t)stream, *d, ints, floats,
+                       xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, dx, dW, tail, nch1);
+    WFL_LAUNCH_CHECK();
+  }
   if (lds > 48 * 1024)
-    WFL_HIP_CHECK(hipFuncSetAttribute((const void*)grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)grad_kernel, (int)lds));
   hipLaunchKernelGGL(grad_kernel, dim3((unsigned)blocks_t, (unsigned)d->B), dim3(256), lds, (hipStream_t)stream, *d,
                      ints, floats, xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, x, row_lse,
-                     dx, dW, rows_per_block, TS, tail, nch1, rpc);
+                     dx, dW, rows_per_block, TS, tail, nch1, rpc, band);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }
