@@ -115,13 +115,17 @@ class ASGLossFunction(torch.autograd.Function):
         # both latency-bound: fork the numerator onto a second stream so that they overlap.  The numerator is
         # the shorter of the two, so its gradient (for grad_output = 1) is computed right behind its sweeps, still
         # under the denominator's; backward adds it, scaled by grad_output, inside the denominator's gradient kernel.
-        dx_num = dw_num = None
+        # (its buffers first, on this stream: the numerator's stream is the longer one, a fill there is a fill on the
+        # step's critical path)
+        dx_num = torch.empty_like(x) if need_dx else None
+        dw_num = torch.zeros_like(W) if need_dw else None
         with E.side_stream(dev) as fork:
+            for t in (dx_num, dw_num):
+                if t is not None:
+                    t.record_stream(fork.side)
             fal = E.lattice_forward(x, pack, weights=W, need_beta=need_grad)
             swept = fork.mark()
             if need_grad:
-                dx_num = torch.empty_like(x) if need_dx else None
-                dw_num = torch.zeros_like(W) if need_dw else None
                 E.lattice_grad(fal, cneg, coef_w=cneg, gout=None, dx=dx_num, accumulate=False, dW=dw_num)
         fcc = E.dense_forward(x, W, need_beta=need_grad)
         # the loss only needs the numerator's sweeps; its gradient keeps running and is joined in backward

@@ -87,6 +87,10 @@ __global__ void __launch_bounds__(256) gather_kernel(wfl_lattice_desc d, const i
                                                       const float* __restrict__ x, int T, int C,
                                                       float* __restrict__ xg, float* __restrict__ row_lse,
                                                       float* __restrict__ fg, float* __restrict__ rmax) {
+#ifndef WFL_GATHER_PRIO
+#define WFL_GATHER_PRIO 0
+#endif
+  if (WFL_GATHER_PRIO) __builtin_amdgcn_s_setprio(WFL_GATHER_PRIO);
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bb = d.shared ? 0 : b;
@@ -1867,6 +1871,10 @@ __global__ void __launch_bounds__(256)
                      const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
                      int accumulate, float* __restrict__ dx, float* __restrict__ dW, int64_t tail, int nch1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef WFL_BANDGRAD_PRIO
+#define WFL_BANDGRAD_PRIO 0
+#endif
+  if (WFL_BANDGRAD_PRIO) __builtin_amdgcn_s_setprio(WFL_BANDGRAD_PRIO);
   constexpr int RB = 16;
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const UttView u = make_view(d, ints, floats, b, T);
