@@ -2352,10 +2352,8 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
   int rows_per_block = (T + blocks_t - 1) / blocks_t;
   blocks_t = (T + rows_per_block - 1) / rows_per_block;
   // banded acceptors swept in the probability domain go to band_grad_kernel; the general launch skips them
-  static const bool band_off = [] {
-    const char* e = getenv("WFL_LATTICE_BAND_GRAD");  // (0: measurements)
-    return e && atoi(e) == 0;
-  }();
+  const char* band_env = getenv("WFL_LATTICE_BAND_GRAD");  // (0: the general kernel for everything -- tests, measurements)
+  const bool band_off = band_env && atoi(band_env) == 0;
   const int band = !band_off && d->max_states <= 64 && d->max_labels <= 64 && d->max_eps == 0 && !row_lse;
   if (band) {
     const int nblk = (T + 15) / 16;

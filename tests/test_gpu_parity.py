@@ -1218,6 +1218,41 @@ def test_banded_sweep_awkward_sizes(crit, T):
     close(dW, dW_want.reshape(W.shape), atol=5e-5)
 
 
+@pytest.mark.parametrize("T,accumulate", [(5, False), (47, True), (200, False)])
+def test_banded_gradient_kernel_matches_the_general_kernel(crit, T, accumulate, monkeypatch):
+    """band_grad_kernel (one wave per 16 frames, lane = state) against grad_kernel (LDS tiles, arc lists) on the same
+    sweeps: per-utterance factors, an upstream scalar, accumulation into an existing gradient, repeated labels,
+    targets from one label to the whole wave, utterances without an accepting path.  WFL_LATTICE_BAND_GRAD=0 sends
+    every utterance to the general kernel."""
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(100 + T)
+    C = 13
+    lens = [1, 2, 4, 4, 7, 20, 40, 63, T + 1]
+    targets = [rs.randint(0, C, size=n).tolist() for n in lens]
+    targets[3] = [5, 5, 5, 5]
+    B = len(lens)
+    xd, Wd = dev(rs.randn(B, T, C).astype(np.float32)), dev((0.5 * rs.randn(C + 1, C)).astype(np.float32))
+    tg = E.targets_on_device(targets, xd.device)
+    pack = E.PackedLattice.asg_force_align(tg.flat, tg.offsets, C, xd.device)
+    st = E.lattice_forward(xd, pack, weights=Wd)
+    coef = dev((rs.rand(B) + 0.5).astype(np.float32))
+    gout = dev(np.array([0.37], dtype=np.float32))
+    seed = dev(rs.randn(B, T, C).astype(np.float32))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WFL_LATTICE_BAND_GRAD", mode)
+        dx, dW = seed.clone(), torch.zeros_like(Wd)
+        E.lattice_grad(st, coef, coef_w=coef, gout=gout, dx=dx, accumulate=accumulate, dW=dW)
+        out[mode] = (dx.cpu().numpy(), dW.cpu().numpy())
+    monkeypatch.delenv("WFL_LATTICE_BAND_GRAD")
+    base = seed.cpu().numpy() if accumulate else 0.0
+    assert np.abs(out["0"][0] - base).max() > 0.05  # (the gradient is not trivially zero)
+    close(out["1"][0], out["0"][0], atol=2e-6)
+    close(out["1"][1], out["0"][1], atol=2e-5)
+    assert float(np.abs(out["1"][0][-1] - (base[-1] if accumulate else 0.0)).max()) == 0.0  # T + 1 labels: no path
+
+
 def test_lattice_certificate_sends_what_a_double_cannot_hold_to_the_log_domain(crit):
     """Monotone chains whose alpha mass sits 2^2900 above the states that carry the posteriors (scores that reward the
     late states early and the early states late): the forward sweep's double underflows there, the two sweeps disagree
