@@ -877,11 +877,18 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
   }
 }
 
-#ifndef WFL_DENSE_GRAD_STAGE
-#define WFL_DENSE_GRAD_STAGE 8
-#endif
-constexpr int kGradStage = WFL_DENSE_GRAD_STAGE;  // frames per LDS stage of dense_fast_grad_kernel
-static int dense_chunks(int B, int T) { return std::max(1, std::min(T, (512 + B - 1) / B)); }
+// frames per LDS stage of dense_fast_grad_kernel: 16 where a thread stages few elements per frame (wide matrices:
+// 192 / 256 threads), 8 for the one-wave workgroups of the small ones (16 frames would double their operand registers).
+// cfg3 (C = 100): 128 -> 122 us with 16; more workgroups per utterance than 512 / B lose (768: 160 us, 1024: 155 us).
+template <int CP>
+constexpr int grad_stage() { return CP >= 104 ? 16 : 8; }
+static int dense_chunks(int B, int T) {
+  static const int target = [] {
+    const char* e = getenv("WFL_DENSE_GRAD_WGS");  // (measurements) workgroups the gradient launch aims at
+    return e && atoi(e) > 0 ? atoi(e) : 512;
+  }();
+  return std::max(1, std::min(T, (target + B - 1) / B));
+}
 
 }  // namespace wfl
 
@@ -996,7 +1003,7 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
   const int cp = dense_fast_cp(C);
   const int32_t* flags = cp ? dense_ws_carve(const_cast<void*>(ws), B, T).flag : nullptr;
 #define WFL_FAST_GRAD(CP)                                                                                       \
-  hipLaunchKernelGGL((dense_fast_grad_kernel<CP, kGradStage>), grid, dim3(((CP / 8) * (CP / 8) + 63) / 64 * 64), 0, st, \
+  hipLaunchKernelGGL((dense_fast_grad_kernel<CP, grad_stage<CP>()>), grid, dim3(((CP / 8) * (CP / 8) + 63) / 64 * 64), 0, st, \
                      x, W, T, C, B, alpha, beta, ws, coef, coef_w, gout, accumulate, addend, dx, part, rows)
   if (cp == 32)
     WFL_FAST_GRAD(32);

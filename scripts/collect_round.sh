@@ -3,7 +3,7 @@
 # Everything profiles/ quotes for a round, under gpurun_out/<tag>/:
 #   <cfg>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py <cfg args> --targets same`
 #   pmc_<cfg>_{FETCH,WRITE}_SIZE.csv -> pmc_traffic.json (scripts/pmc_traffic.py; separate --pmc passes)
-#   bench_lines.jsonl        the default bench.py line of every configuration (operator path, fresh targets)
+#   bench_lines.jsonl        the default bench.py line of every configuration (operator path; `fresh_targets` beside it)
 tag=${1:-r}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
