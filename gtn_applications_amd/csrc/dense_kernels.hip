@@ -394,7 +394,7 @@ struct FastLds {
   double mtot;
 };
 
-template <int CP, int DIR>
+template <int CP, int DIR, bool PAIR>
 __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, const float* __restrict__ W, int T, int C,
                                                  void* wsp, int B, float* __restrict__ out, float* __restrict__ logz,
                                                  FastLds<CP>& L) {
@@ -447,25 +447,27 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     return;
   }
 
-  // ---- helper wave state: lanes cover states lane and lane + 64
+  // ---- helper wave state: a lane covers two states -- lane and lane + 64, or (PAIR: an even number of classes and
+  // an 8-byte aligned tensor) 2 lane and 2 lane + 1, whose scores then arrive in ONE 8-byte load per row
   // item r is the emission row the chain multiplies in at step r: frame r (alpha), frame T - r (beta)
-  const bool has1 = lane + 64 < CP;
-  const float add0 = L.wr2[lane < CP ? lane : 0], add1 = L.wr2[has1 ? lane + 64 : 0];
+  const int i0 = PAIR ? 2 * lane : lane, i1 = PAIR ? 2 * lane + 1 : lane + 64;
+  const bool has0 = i0 < CP, has1 = i1 < CP;
+  const float add0 = L.wr2[has0 ? i0 : 0], add1 = L.wr2[has1 ? i1 : 0];
   // Emission rows travel HBM -> registers kDepth items ahead of their use.  (The first version kept 4 in flight: with
   // ~1.7 us of load latency under load that alone pinned the sweep at latency / 4 = ~1000 cycles per frame, whatever
   // the matrix-vector product cost -- measured with three different product layouts.)
-  // 31 rows = 62 loads: as deep as the 6-bit vmcnt counter allows.  With 16, the sweep ran at 343 us alone but at 375 us
-  // next to the numerator's gradient kernel streaming 170 MB on the other stream (the round trip grows past the 5.4 us
-  // that 16 frames cover); with 31: 358 us.
-  constexpr int kDepth = 31;
+  // As deep as the 6-bit vmcnt counter allows: 31 rows of two loads, 48 rows of one.  With 16, the sweep ran at 343 us
+  // alone but at 375 us next to the numerator's gradient kernel streaming 170 MB on the other stream (the round trip
+  // grows past the 5.4 us that 16 frames cover); with 31: 358 us.
+  constexpr int kDepth = PAIR ? 48 : 31;
   float raw[kDepth][2];
   double mrun = 0.0;
   auto item_ok = [&](int r) { return DIR == 0 ? r < T : (r >= 1 && r < T); };
   auto issue = [&](int r, float (&dst)[2]) {
     if (!item_ok(r)) return;
     const float* row = xb + (int64_t)(DIR == 0 ? r : T - r) * C;
-    dst[0] = lane < C ? row[lane] : WFL_NEG_INF;
-    dst[1] = lane + 64 < C ? row[lane + 64] : WFL_NEG_INF;
+    dst[0] = i0 < C ? row[i0] : WFL_NEG_INF;
+    dst[1] = i1 < C ? row[i1] : WFL_NEG_INF;
   };
   // CHECKED = false: the caller guarantees 3 <= r and that the item exists (no branches: the main loop
   // must stay straight-line so that the loads of later items stay in flight across this one's use)
@@ -476,12 +478,12 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
       return;
     }
     const bool first = CHECKED && DIR == 0 && r == 0;
-    const float s0 = lane < C ? fmaf(nan_to_neg(src[0]), kLog2e, first ? L.st2[lane] : add0) : WFL_NEG_INF;
-    const float s1 = lane + 64 < C ? fmaf(nan_to_neg(src[1]), kLog2e, first ? L.st2[lane + 64] : add1) : WFL_NEG_INF;
+    const float s0 = i0 < C ? fmaf(nan_to_neg(src[0]), kLog2e, first ? L.st2[i0] : add0) : WFL_NEG_INF;
+    const float s1 = i1 < C ? fmaf(nan_to_neg(src[1]), kLog2e, first ? L.st2[i1] : add1) : WFL_NEG_INF;
     const float m = wave_all_max(vmax(s0, s1));
     float* dst = L.eh[r & 3];
-    if (lane < CP) dst[lane] = lane < C ? __builtin_amdgcn_exp2f(s0 - m) : 0.f;
-    if (has1) dst[lane + 64] = lane + 64 < C ? __builtin_amdgcn_exp2f(s1 - m) : 0.f;
+    if (has0) dst[i0] = i0 < C ? __builtin_amdgcn_exp2f(s0 - m) : 0.f;
+    if (has1) dst[i1] = i1 < C ? __builtin_amdgcn_exp2f(s1 - m) : 0.f;
     mrun += (double)m;
     if (lane == 0) {
       Mb[DIR == 0 ? r : T - 1 - r] = mrun;
@@ -491,8 +493,13 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   auto issue_fast = [&](int r, float (&dst)[2]) {  // straight-line: the row index is clamped, items past the end are unused
     const int rr = DIR == 0 ? min(r, T - 1) : max(T - r, 0);
     const float* row = xb + (int64_t)rr * C;
-    dst[0] = row[lane < C ? lane : 0];
-    dst[1] = row[lane + 64 < C ? lane + 64 : 0];
+    if (PAIR) {  // (C is even: the last pair starts at C - 2)
+      const float2 v = *reinterpret_cast<const float2*>(row + min(i0, C - 2));
+      dst[0] = v.x, dst[1] = v.y;
+    } else {
+      dst[0] = row[i0 < C ? i0 : 0];
+      dst[1] = row[i1 < C ? i1 : 0];
+    }
   };
   // straight-line staging of item r >= 2 (no early return: later items' loads stay in flight across this one's
   // use); items past the end only skip their bookkeeping
@@ -507,12 +514,12 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   int gE = 0;
   auto stage_fast = [&](int r, const float (&src)[2], int k) {
     const bool ok = r < T;
-    const float s0 = lane < C ? fmaf(nan_to_neg(src[0]), kLog2e, add0) : WFL_NEG_INF;
-    const float s1 = lane + 64 < C ? fmaf(nan_to_neg(src[1]), kLog2e, add1) : WFL_NEG_INF;
+    const float s0 = i0 < C ? fmaf(nan_to_neg(src[0]), kLog2e, add0) : WFL_NEG_INF;
+    const float s1 = i1 < C ? fmaf(nan_to_neg(src[1]), kLog2e, add1) : WFL_NEG_INF;
     const float m = wave_all_max(vmax(s0, s1));
     float* dst = L.eh[r & 3];
-    if (lane < CP) dst[lane] = lane < C ? __builtin_amdgcn_exp2f(s0 - m) : 0.f;
-    if (has1) dst[lane + 64] = lane + 64 < C ? __builtin_amdgcn_exp2f(s1 - m) : 0.f;
+    if (has0) dst[i0] = i0 < C ? __builtin_amdgcn_exp2f(s0 - m) : 0.f;
+    if (has1) dst[i1] = i1 < C ? __builtin_amdgcn_exp2f(s1 - m) : 0.f;
     mrun += ok ? (double)m : 0.0;
     gM = lane == k ? mrun : gM;
     gm2 = lane == k ? m : gm2;
@@ -687,16 +694,16 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   if (tid == 0) ws.flag[2 * b + DIR] = any_bad ? 1 : 0;
 }
 
-template <int CP>
+template <int CP, bool PAIR>
 __global__ void __launch_bounds__(kDenseThreads)
     dense_fast_chain_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, void* wsp, int B,
                             float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz) {
   __shared__ __attribute__((aligned(16))) FastLds<CP> L;
   if (blockIdx.y == 0) {
     if (!beta && threadIdx.x == 0) dense_ws_carve(wsp, B, T).flag[2 * blockIdx.x + 1] = 0;
-    dense_fast_sweep<CP, 0>(x, W, T, C, wsp, B, alpha, logz, L);
+    dense_fast_sweep<CP, 0, PAIR>(x, W, T, C, wsp, B, alpha, logz, L);
   } else {
-    dense_fast_sweep<CP, 1>(x, W, T, C, wsp, B, beta, nullptr, L);
+    dense_fast_sweep<CP, 1, PAIR>(x, W, T, C, wsp, B, beta, nullptr, L);
   }
 }
 
@@ -939,8 +946,21 @@ int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int s
     const int cp = dense_fast_cp(C);
     const DenseWs w = dense_ws_carve(ws, B, T);
     const dim3 grid((unsigned)B, beta ? 2u : 1u);
-#define WFL_FAST_CHAIN(CP) \
-  hipLaunchKernelGGL(dense_fast_chain_kernel<CP>, grid, dim3(kDenseThreads), 0, st, x, W, T, C, ws, B, alpha, beta, logz)
+    // (one 8-byte load per emission row where the rows are 8-byte aligned: see the helper wave)
+    static const bool pair_off = [] {
+      const char* e = getenv("WFL_DENSE_PAIR");  // (0: measurements)
+      return e && atoi(e) == 0;
+    }();
+    const bool pair = !pair_off && (C & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
+#define WFL_FAST_CHAIN(CP)                                                                                              \
+  do {                                                                                                                  \
+    if (pair)                                                                                                           \
+      hipLaunchKernelGGL((dense_fast_chain_kernel<CP, true>), grid, dim3(kDenseThreads), 0, st, x, W, T, C, ws, B, alpha, \
+                         beta, logz);                                                                                   \
+    else                                                                                                                \
+      hipLaunchKernelGGL((dense_fast_chain_kernel<CP, false>), grid, dim3(kDenseThreads), 0, st, x, W, T, C, ws, B,     \
+                         alpha, beta, logz);                                                                            \
+  } while (0)
     if (cp == 32)
       WFL_FAST_CHAIN(32);
     else if (cp == 64)
