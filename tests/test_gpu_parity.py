@@ -744,6 +744,30 @@ def test_dense_probability_domain_sweeps_every_padding_bucket(C, T):
     _dense_check(x, W, [False] * B)
 
 
+def test_dense_sweep_emissions_that_are_only_four_byte_aligned():
+    """With an even class count the sweep's helper wave loads a row's scores as 8-byte pairs; a tensor that starts on an
+    odd float (a view into a larger buffer) takes the two-load form instead: same results either way."""
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(5)
+    B, T, C = 2, 70, 100
+    x = (2.0 * rs.randn(B, T, C)).astype(np.float32)
+    W = rs.randn(C + 1, C).astype(np.float32)
+    Wt = dev(W)
+    buf = torch.zeros(B * T * C + 1, device="cuda")
+    odd = buf[1:].view(B, T, C)
+    odd.copy_(dev(x))
+    assert odd.data_ptr() % 8 == 4 and odd.is_contiguous()
+    a, b = E.dense_forward(dev(x), Wt, need_beta=True), E.dense_forward(odd, Wt, need_beta=True)
+    np.testing.assert_allclose(b.logz.cpu().numpy(), a.logz.cpu().numpy(), rtol=1e-6)
+    want = [OR.dense_forward_backward(x[i], W) for i in range(B)]
+    coef = torch.ones(B, device="cuda")
+    dx = torch.empty_like(odd)
+    E.dense_grad(odd, Wt, b, coef, coef_w=coef, dx=dx, dW=None)
+    close(dx, np.stack([w[1] for w in want]))
+    assert E.dense_flagged(b).cpu().tolist() == [False] * B
+
+
 @pytest.mark.parametrize("C", [130, 188])
 def test_asg_beyond_128_classes(crit, C):
     """ASG up to the limit of the LDS-resident transition matrix (about 190 classes): the log-domain kernels serve
