@@ -391,6 +391,7 @@ struct FastLds {
   float wr2[CP];
   float st2[CP];           // start weights W[0, :] in log2 units
   float wsum[kDenseChainWaves];
+  float sinv[2];           // 2^-kk of step n at [n & 1], written by the helper wave one interval ahead
   double mtot;
 };
 
@@ -548,7 +549,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   auto chain_step = [&](int n, int cur) {  // n >= 1, cur = (n - 1) & 1
     const float e = L.eh[(DIR == 0 ? n : n + 1) & 3][q < CP ? q : 0];  // beta at n = T-1: a stale row, unused
     const float4 vc4 = *reinterpret_cast<const float4*>(L.vecT[cur][qq][il]);  // this row's chunks of its half
-    const float inv = __builtin_amdgcn_ldexpf(1.f, -scale_exp(scale_ref(cur)));
+    const float inv = L.sinv[n & 1];
     const float vc[4] = {vc4.x, vc4.y, vc4.z, vc4.w};
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // element k of the row's chunk, broadcast to the row's 16 lanes by the multiply-add's DPP source
@@ -591,14 +592,27 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     }
   };
   // helper side of the same bookkeeping: E_t = sum of the exponents applied up to step n
-  int ecum = 0;
+  // The scale of step n is PREDICTED an interval ahead by the helper wave and left in LDS as 2^-kk: the chain waves read
+  // one word instead of a second ds_read_b128, three max, frexp and ldexp per frame.  With s_n the exponent (minus
+  // kNormExp) of the vector step n multiplies -- what the helper can see during interval n -- the vector of step n+1
+  // sits at s_n + g_n - kk_n, g_n the growth of the step in flight; the growth of the step before,
+  // g_{n-1} = s_n - s_{n-1} + kk_{n-1}, stands in for it: kk_{n+1} = 2 s_n - s_{n-1} + kk_{n-1} - kk_n, which leaves
+  // the vector off centre by g_n - g_{n-1} only (no accumulation; any power of two is exact).  Using s_n itself, one
+  // frame stale, is a feedback loop with a delay of one step and gain one -- it does not damp and the vector wanders
+  // out of the fp32 range (measured: every utterance flagged).  Step 1 is not scaled (kk_1 = 0).
+  int ecum = 0, kcur = 0, kprev = 0, sprev = 0;
   auto helper_scale = [&](int n, int k) {
-    ecum += scale_exp(scale_ref((n - 1) & 1));
+    ecum += kcur;  // kk_n, applied by the chain waves in this interval
     gE = lane == k ? ecum : gE;
+    const int sn = scale_exp(scale_ref((n - 1) & 1));
+    const int knext = 2 * sn - (n == 1 ? sn : sprev) + kprev - kcur;
+    if (lane == 0) L.sinv[(n + 1) & 1] = __builtin_amdgcn_ldexpf(1.f, -knext);
+    kprev = kcur, kcur = knext, sprev = sn;
   };
 
   // ---- prologue: items 0, 1 and 2 staged synchronously, items 3 .. kDepth+2 in flight (item r lives in raw[r % kDepth])
   if (wave == kDenseChainWaves) {
+    if (lane == 0) L.sinv[1] = 1.f;  // (step 1)
     issue(0, raw[0]);
     issue(1, raw[1]);
     issue(2, raw[2]);

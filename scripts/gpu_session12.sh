@@ -4,7 +4,6 @@ run() { # label, env...
   lbl=$1; shift
   env "$@" python bench.py --workload asg --steps 40 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$lbl', round(d['ms_per_step'],4), {k: round(v,4) for k,v in d['roofline']['kernel_ms'].items()})" >> gpurun_out/s12.txt
+d=json.loads(sys.stdin.read()); print('$lbl', round(d['ms_per_step'],4), {k: round(v,4) for k,v in d['roofline']['kernel_ms'].items() if 'dense' in k})" >> gpurun_out/s12.txt
 }
-for i in 1 2 3; do run split A=1; done
-bash scratch/timeline.sh asg > gpurun_out/tl_asg.txt 2>&1
+for i in 1 2 3; do run new A=1; done
