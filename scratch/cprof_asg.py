@@ -8,7 +8,9 @@ g = torch.Generator().manual_seed(0)
 x = torch.randn(B, T, C, generator=g).cuda().requires_grad_(True)
 Wt = torch.zeros(C + 1, C, device="cuda", requires_grad=True)
 batches = [torch.randint(C - 2, (B, L), generator=g).tolist() for _ in range(N + 20)]
+SAME = len(sys.argv) > 2
 def afwd(i):
+    i = 0 if SAME else i
     x.grad = None; Wt.grad = None
     AS.ASGLoss(x, Wt, batches[i], "mean").backward()
 def cfwd(i):
