@@ -1,0 +1,2460 @@
+// CTC fast path for gfx950: create_ctc_graph + intersect + forward_score + backward of
+// criterions/ctc.py:15-94 without any graph.
+//
+// Lane mapping (one 64-lane wavefront per utterance and direction): lane i owns target position i,
+// i.e. the blank state 2i ("b") and the label state 2i+1 ("l") of the CTC label graph
+// (ctc.py:18-27); lane L owns the trailing blank.  One frame of the recursion
+//     b' = xb   + LSE(b, l[i-1])
+//     l' = xl_i + LSE(l, b, skip_i ? l[i-1] : -inf)            skip_i = (y_i != y_{i-1})
+// needs exactly one cross-lane value (the label state of lane i-1), fetched with a DPP wave shift:
+// no LDS on the dependent chain.  The beta sweep is the same recursion on the reversed target and
+// reversed time (the CTC graph is mirror-symmetric), so one routine serves both directions.
+//
+// Measured on MI355X (scratch/chain_ubench.hip): a lone wavefront issues ~1 instruction per 4
+// cycles and every VMEM instruction costs it ~50 cycles -- the chain is bound by its instruction
+// count per frame, not by bandwidth.  Therefore:
+//   * the chain stores NOTHING per frame: only the state vector at every 16-frame boundary
+//     (a "checkpoint": 1/16 of the alpha/beta volume) together with its scale offset;
+//   * the gradient kernel recomputes alpha forward and beta backward INSIDE each 16-frame block from
+//     the two checkpoints that bracket it -- 8064 independent wave-sized chains at cfg2, i.e. a
+//     throughput problem spread over all 256 CUs -- forms the posteriors and assembles the dense
+//     gradient rows of the block in LDS, one coalesced 16-B/lane copy per block;
+//   * emissions are gathered straight from the [B,T,C] tensor (one dword per lane per frame, all
+//     addresses of a wave inside one C-float row) through a 16-frame register ring of RAW values (no
+//     load is consumed right after issue); the trailing-blank lane's value is broadcast with
+//     v_readlane, so there is exactly one VMEM load per frame and no SMEM load.
+//
+// Arithmetic: base-2 log domain (v_exp_f32 / v_log_f32 are base 2: no multiplies on the dependent
+// chain), -inf represented by a large finite sentinel so the chain is branch-free.  Every 16 frames
+// the wave maximum is moved into a double-precision offset: stored scores stay O(10) instead of
+// drifting to O(T) (plain fp32 log-domain, which is what gtn.forward_score does, already loses the
+// 4th digit of the posteriors at T = 1000).
+//
+// Kernels.  The training step (wfl_ctc_forward_backward) is ctc_fast_pipelined_kernel: chains and gradient in
+// ONE launch, the gradient waves waiting on device-coherent per-block flags while the chains sweep; its chains
+// and gradient blocks run in lane-exponent (probability-domain) arithmetic, every block certifies what it
+// computed, and ctc_repair_kernel re-runs rejected utterances with the log-domain bodies.  ctc_pipelined_kernel
+// is the same single launch with the log-domain bodies throughout (WFL_CTC_PIPELINE=log, long targets).
+// ctc_log_chain_kernel + ctc_grad_kernel (+ wfl_reduce_loss) are the three-launch step behind
+// wfl_ctc_forward / wfl_ctc_grad; WFL_CTC_FAST_CHAIN selects ctc_fast_chain_kernel + ctc_certify_kernel there.
+#include <atomic>
+#include <string>
+#include <type_traits>
+
+#include "device_common.h"
+
+#ifndef WFL_DBG_FAST
+#define WFL_DBG_FAST 0  // scratch/chain_harness.cpp, timeline_fast.py: bit 0 no frames, 1 no staging math, 2 no gathers, 3 idle flusher,
+                        // 4 chain launch only, 9 (512) per-item timestamps in the workspace
+#endif
+
+namespace wfl {
+
+constexpr float kNegBig = -1.0e30f;  // stands in for -inf on the chain
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kBlk = 16;  // frames per block: renormalisation, checkpoint and prefetch period
+
+// log2(2^a + 2^b) with ONE exp and one log: max + log2(1 + 2^-|a-b|).  With the finite -inf sentinel
+// the difference of two sentinels is 0 (-> sentinel + 1, still a sentinel) and sentinel vs finite
+// gives 2^-huge = 0: branch-free.  Cost model on gfx950 (measured): 4 cycles per VALU, 16 per
+// transcendental: 4*4 + 2*16 = 48 cycles.  The bare v_max_f32 avoids the two canonicalising
+// v_max x,x,x that fmaxf() costs under IEEE mode (no NaN can reach this point: NaN policy at load).
+__device__ __forceinline__ float lse2_b2(float a, float b) {
+  const float e = __builtin_amdgcn_exp2f(-fabsf(a - b));
+  return vmax(a, b) + __builtin_amdgcn_logf(1.f + e);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float to_score(float raw) {
+  const float v = raw * kLog2e;
+  return (v > kNegBig) ? v : kNegBig;  // NaN and -inf both become the sentinel (NaN policy)
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout (float units).  NB = ceil(T / 16), P = max_len + 1.
+//   float2 ck[b][dir][kk][P]   kk = 0..NB-1 in PROCESSING order: state before the kk-th block the
+//                              sweep processed (alpha: block kk; beta: block NB-1-kk), base-2 log
+//                              scores relative to off[b][dir][kk], emissions of all frames consumed
+//                              so far included
+//   double off[b][dir][kk]     the offset
+//   double z2[b]               log2 Z
+//   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
+// ------------------------------------------------------------------------------------------------
+struct CtcWs {
+  int64_t ck, off, z2, flag, pbad, ready, done, perr, dup, own, zloc, total, dbg;
+};
+__host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
+__host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
+  const int64_t NB = ctc_blocks(T);
+  CtcWs w;
+  int64_t o = 0;
+  w.ck = o, o += (int64_t)B * 2 * NB * P * 2;
+  o = (o + 1) & ~1ll;
+  w.off = o, o += 2 * (int64_t)B * 2 * NB;
+  w.z2 = o, o += 2 * (int64_t)B;
+  w.flag = o, o += B;      // int32 flag[b]: 1 = the fast chain's result was rejected, log-domain chain re-ran
+  w.pbad = o, o += 2 * B;  // int32 pbad[b][dir]: the fast chain could not vouch for an interval
+  o = (o + 1) & ~1ll;
+  w.ready = o, o += 2 * (int64_t)B * 2 * NB;  // uint64 ready[b][dir][block]: == the launch token once published
+  w.done = o, o += 2 * (int64_t)B;            // uint64 done[b]: == the launch token once nll[b] is published
+  w.perr = o, o += 2;                         // int32: a gradient wave of the pipelined step gave up waiting
+  w.dup = o, o += 2 * (int64_t)B;             // uint64 dup[b]: bit i = target label i also occurs elsewhere in the target (or is the blank)
+  w.own = o, o += 64 * (int64_t)B;            // int32 own[b][64]: lane of the first occurrence of the lane's label (63: the blank's slot)
+  w.zloc = o, o += 4 * (int64_t)B;            // int64 zloc[b][2]: min / max over the blocks of log2 Z (x 2^16) as their gradient waves reproduced it
+#if WFL_DBG_FAST & 512
+  o = (o + 1) & ~1ll;
+  w.dbg = o, o += 2 * 4 * ((int64_t)B * NB + 2 * B);  // int64 [item][4] timestamps (scratch/timeline_fast.py)
+#endif
+  w.total = o + 2;
+  return w;
+}
+
+struct CtcArgs {
+  const float* x;
+  int B, T, C, P, blank;
+  const int32_t* targets;
+  const int64_t* offsets;
+  float* ws;
+  float* nll;
+  unsigned long long token;  // pipelined step: value a ready flag takes when its checkpoint is published
+  const float* loss_scale;   // pipelined step, optional: loss_out[0] = mean_b(loss_scale[b] * nll[b])  (ctc.py:68-69)
+  float* loss_out;
+  // pipelined step, optional: x holds raw scores and row_lse[b*T + t] their log-sum-exp -- the fused
+  // torch.nn.functional.log_softmax of ctc.py:107 (forward: subtracted at the gather; backward: the rows
+  // start at -cf * softmax(x) because the posteriors of a frame sum to one)
+  const float* row_lse;
+  // fast pipelined step, optional: xc[b][t][kXcStride] = the emissions the sweeps gather -- slot i = x[b][t][y_i]
+  // (target position i), slot L = x[b][t][blank] -- written by ctc_compact_x_kernel (see wfl_ctc_forward_backward)
+  const float* xc;
+  int place;  // fast pipelined step: 1 = keep an utterance's chains and gradient items on one XCD (speed only)
+  // fast pipelined step with persistent gradient waves, optional: kParkStride floats per gradient wave, where a wave
+  // leaves the emission factors of its SECOND item before it starts waiting for the checkpoints of its first
+  float* park;
+};
+constexpr int kXcStride = 64;
+constexpr int kParkStride = 17 * 64;  // 16 frames x 64 lanes of factors + the per-lane reference word
+
+// ---- pieces shared by the chains of the pipelined launches -------------------------------------------
+__device__ __forceinline__ void coherent_store64(void* p, unsigned long long v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long coherent_load64(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double coherent_load_f64(const double* p) {
+  const unsigned long long bits = coherent_load64(p);
+  double v;
+  __builtin_memcpy(&v, &bits, 8);
+  return v;
+}
+
+// one lane: publish nll[b] (and, when a workgroup of this launch reduces the loss, the done flag)
+template <bool SIGNAL, bool REPAIR>
+__device__ __forceinline__ void publish_nll(const CtcArgs& a, const CtcWs& w, int b, bool alive, double z2) {
+  const float nllb = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
+  if (SIGNAL && (a.loss_out || REPAIR)) {  // device-coherently for the workgroup that reduces the loss
+    // (ONLY this store: a plain store to the same word first would leave a dirty non-coherent line in
+    // this XCD's L2 that the coherent store merges into instead of writing through -- measured: the
+    // reducer then read stale values)
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(a.nll + b), __float_as_uint(nllb), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store((unsigned long long*)(a.ws + w.done) + b, a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    a.nll[b] = nllb;
+  }
+}
+
+// The certificate of the fast pipelined launch, evaluated by the launch that follows it: every block's
+// gradient wave reproduced log2 Z from the two sweeps (sum_s alpha beta at its last frame) and folded it
+// into a per-utterance minimum / maximum (16.16 fixed point, device-scope atomics; initialised by the
+// utterance's alpha chain before it publishes its first checkpoint).  Pruning or overflow in the
+// lane-exponent chains breaks the agreement with the chain's own Z.
+constexpr long long kZDead = -(1ll << 62);
+__device__ __forceinline__ long long z_fixed(double z2) { return z2 > -1.0e299 ? (long long)llrint(z2 * 65536.0) : kZDead; }
+__device__ __forceinline__ bool utterance_rejected(const CtcArgs& a, const CtcWs& w, int u) {
+  const int32_t* pbad = (const int32_t*)(a.ws + w.pbad) + u * 2;
+  const double z2 = ((const double*)(a.ws + w.z2))[u];
+  const long long* zmm = (const long long*)(a.ws + w.zloc) + (int64_t)u * 2;
+  const long long zq = z_fixed(z2);
+  if (zq == kZDead && (((const unsigned long long*)(a.ws + w.dup))[u] >> 63)) return false;  // cannot be aligned: exact
+  // 1.5e-4 in log2 units: a lost mass fraction of 1e-4 (the parity bar).  The lane-exponent blocks reproduce the
+  // chain's log2 Z to 1-3e-5 on well-represented data (measured; fixed-point resolution 1.5e-5)
+  constexpr long long tol = 10;
+  return pbad[0] != 0 || pbad[1] != 0 || zq == kZDead || zmm[0] < zq - tol || zmm[1] > zq + tol;
+}
+__device__ __forceinline__ bool utterance_rejected_wave(const CtcArgs& a, const CtcWs& w, int u, int lane) {
+  (void)lane;
+  return utterance_rejected(a, w, u);  // (same words for every lane: wave-uniform)
+}
+
+// one wave: wait for the alpha chains that publish in this launch (all of them, or -- in the repair
+// launch -- the rejected utterances only; nothing to do if there are none), then reduce the loss in a
+// fixed order: mean_b(scale_b * nll_b), no extra launch, deterministic
+__device__ __forceinline__ void reduce_loss_when_done(const CtcArgs& a, const CtcWs& w, int lane, bool rejected_only) {
+  unsigned long long* done = (unsigned long long*)(a.ws + w.done);
+  bool any = false;
+  for (int u = lane; u < a.B; u += 64) any = any || !rejected_only || utterance_rejected(a, w, u);
+  if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+  float part = 0.f;
+  bool ok = true;
+  for (int u = lane; u < a.B; u += 64) {
+    if (!rejected_only || utterance_rejected(a, w, u)) {
+      bool seen = false;
+      for (int spin = 0; spin < (1 << 20) && !seen; ++spin) {
+        seen = __hip_atomic_load(done + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+        if (!seen) __builtin_amdgcn_s_sleep(16);
+      }
+      ok = ok && seen;
+      __hip_atomic_store(done + u, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sole consumer: clear
+    }
+    const float v = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(a.nll + u), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT));
+    part += (a.loss_scale ? a.loss_scale[u] : 1.f) * v;
+  }
+  const float total = wave_all_sum(part);  // fixed lane order
+  if (lane == 0 && a.loss_out) a.loss_out[0] = total / (float)a.B;
+  if (!ok) {
+    if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+    __builtin_trap();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-domain chains: grid (B, 2) x 128.  Wave 0 runs the dependent chain and nothing else; wave 1 (on another
+// SIMD of the same CU) feeds it: it gathers the emissions of block kk+2 from HBM, applies the scale /
+// NaN policy / blank broadcast / lane masks and leaves ready (xb, xl) pairs in an LDS ring, two
+// blocks ahead.  One s_barrier per 16-frame block.  This takes the VMEM instruction (~50 cycles for
+// a lone wave), ~6 VALU and ~10 SALU of address arithmetic per frame off the critical wave.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRing = 3;  // LDS ring depth in blocks: consumer at kk, producer at kk+2
+
+struct ChainLdsT {
+  float2 ring[kRing][kBlk][64];  // 24 KiB
+  float2 ckbuf[2][64];           // checkpoint hand-off chain wave -> helper wave
+  double offbuf[2];
+};
+
+// only_flagged != 0: repair pass -- run only for utterances whose fast-chain result was rejected.
+// SIGNAL: publish ready[b][dir][block] (agent-scope release) after each checkpoint reached HBM, for the
+// gradient waves of the pipelined step that are waiting for it.
+template <bool SIGNAL, bool LSM = false, bool REPAIR = false>
+__device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int dir, int only_flagged, ChainLdsT& S) {
+  auto& ring = S.ring;
+  auto& ckbuf = S.ckbuf;
+  auto& offbuf = S.offbuf;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  // this lane's label (reversed target for the beta sweep) and skip flag
+  int y = -1, yprev = -1;
+  if (lane < L) y = a.targets[o0 + (dir == 0 ? lane : L - 1 - lane)];
+  if (lane >= 1 && lane - 1 < L) yprev = a.targets[o0 + (dir == 0 ? lane - 1 : L - lane)];
+  const bool has_label = lane < L, has_blank = lane <= L;
+  const bool skip = has_label && lane >= 1 && y != yprev;
+  const float* xrow = a.x + (int64_t)b * T * C;
+  const int col = has_label ? y : a.blank;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  const int NB = ctc_blocks(T);
+  if (only_flagged && ((const int32_t*)(a.ws + w.flag))[b] == 0) return;  // uniform per workgroup
+
+  // alpha walks t = 0..T-1; beta walks block by block from the last block to the first, frames
+  // descending inside each block, so that its checkpoints fall on the same absolute 16-frame
+  // boundaries as alpha's
+  // helper wave: `issue` starts the 16 gathers of the kk-th processed block, `stage` (one loop
+  // iteration = one block of chain work later) turns the landed values into ring entries, so the
+  // HBM / L2 latency never sits in front of a barrier
+  // Two helper waves alternate blocks (helper h owns the processed blocks kk with kk % 2 == h): in a
+  // helper's own instruction stream a block's gathers are issued two chain blocks before they are
+  // consumed and nothing newer is in flight at that point, so the compiler's s_waitcnt vmcnt(0)
+  // in front of the first use costs nothing even when the rows come from HBM (cfg5: x is 524 MB).
+  const int h = wave - 1;
+  // pipelined step: a fourth wave does nothing but publish checkpoints -- its wait for the stores'
+  // acknowledgement must not also wait for a helper's emission gathers
+  constexpr int kFlusher = SIGNAL ? 3 : 1;
+  float raw[kBlk];
+  float lse_raw = 0.f;  // lane j < 16: log-sum-exp of the block's j-th processed frame (fused log_softmax)
+  auto issue = [&](int kk) {
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int t0 = k * kBlk, n = min(kBlk, T - t0);
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
+      raw[j] = xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
+    }
+    if (LSM) {
+      const int t = dir == 0 ? t0 + (lane & 15) : t0 + n - 1 - (lane & 15);
+      lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
+    }
+  };
+  auto stage = [&](int kk) {
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const float xs = to_score(LSM ? raw[j] - readlane_f(lse_raw, j) : raw[j]);
+      const float xblank = readlane_f(xs, L);
+      ring[kk % kRing][j][lane] = make_float2(has_blank ? xblank : kNegBig, has_label ? xs : kNegBig);
+    }
+  };
+  if (wave == 1 || wave == 2) {
+    if (h < NB) {
+      issue(h);
+      stage(h);
+    }
+    if (h + 2 < NB) issue(h + 2);
+  }
+  __syncthreads();
+
+  float ab = (lane == 0) ? 0.f : kNegBig;  // virtual slot "before the first frame"
+  float al = kNegBig;
+  double off = 0.0;
+  float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
+  double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+  unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
+  auto flush_checkpoint = [&](int kk) {  // helper wave: LDS -> HBM, one block behind the chain
+    if (!SIGNAL) {
+      if (lane < P) ck[(int64_t)kk * P + lane] = ckbuf[kk & 1][lane];
+      if (lane == 0) offs[kk] = offbuf[kk & 1];
+    } else {
+      // The consumers run on other CUs / XCDs of the same launch.  A release fence at agent scope
+      // would write back this XCD's whole L2 -- including the gradient rows streaming through it --
+      // once per block (measured: 10x slower).  Instead the few checkpoint words themselves are
+      // stored device-coherently (agent-scope relaxed atomics bypass the non-coherent L2 state),
+      // the wave waits for their acknowledgement, and only then raises the flag the same way.
+      if (lane < P) {
+        const float2 v = ckbuf[kk & 1][lane];
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &v, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&ck[(int64_t)kk * P + lane]), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        unsigned long long bits;
+        const double o = offbuf[kk & 1];
+        __builtin_memcpy(&bits, &o, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&offs[kk]), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): the stores are acknowledged
+      if (lane == 0) __hip_atomic_store(&ready[kk], a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  float2 e[kBlk], en[kBlk];
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) e[j] = ring[0][j][lane];
+  }
+  for (int kk = 0; kk < NB; ++kk) {
+    if (wave == 0) {
+      const int k = dir == 0 ? kk : NB - 1 - kk;
+      const int n = min(kBlk, T - k * kBlk);
+      if (kk + 1 < NB) {  // block kk+1 is already staged (the helper runs two blocks ahead)
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) en[j] = ring[(kk + 1) % kRing][j][lane];
+      }
+      if (kk > 0) {  // renormalise: wave maximum -> double offset
+        const float m = wave_all_max(fmaxf(ab, al));
+        if (m > 0.5f * kNegBig) {
+          ab = fmaxf(ab - m, 4.f * kNegBig);  // keeps dead states at sentinel magnitude over any T
+          al = fmaxf(al - m, 4.f * kNegBig);
+          off += (double)m;
+        }
+      }
+      ckbuf[kk & 1][lane] = make_float2(ab, al);  // checkpoint: state BEFORE this block
+      if (lane == 0) offbuf[kk & 1] = off;
+      auto frame = [&](const float2 em) {
+        const float pal = wave_shr1(al, kNegBig);
+        const float nb = lse2_b2(ab, pal);
+        // LSE(al, ab, pal) = LSE(al, nb) when the skip arc exists, LSE(al, ab) otherwise: two 1-exp
+        // log-adds per frame instead of a 2-exp and a 3-exp one
+        const float nl = lse2_b2(al, skip ? nb : ab);
+        ab = nb + em.x;  // no clamp: sentinels only add up (|sum| <= T * 1e30 << FLT_MAX)
+        al = nl + em.y;
+      };
+      if (n == kBlk) {  // straight-line: a per-frame branch costs the lone wave more than the frame's math
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) frame(e[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j)
+          if (j < n) frame(e[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) e[j] = en[j];
+    } else {
+      if (kk > 0 && wave == kFlusher) flush_checkpoint(kk - 1);
+      if ((kk & 1) == h && wave <= 2) {
+        if (kk + 2 < NB) stage(kk + 2);  // issued two iterations ago
+        if (kk + 4 < NB) issue(kk + 4);
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == kFlusher) flush_checkpoint(NB - 1);
+  if (dir == 0 && wave == 0) {
+    // logZ = LSE(alpha_{T-1}[2L], alpha_{T-1}[2L-1])   (ctc.py:21 accept states)
+    const float a_last = readlane_f(ab, L);
+    const float l_last = L > 0 ? readlane_f(al, L - 1) : kNegBig;
+    if (lane == 0) {
+      const float zr = lse2_b2(a_last, l_last);
+      const bool alive = zr > 0.5f * kNegBig;
+      const double z2 = alive ? (double)zr + off : -1.0e300;
+      ((double*)(a.ws + w.z2))[b] = z2;
+      publish_nll<SIGNAL, REPAIR>(a, w, b, alive, z2);
+    }
+    if (SIGNAL && !REPAIR && a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
+  }
+}
+
+__global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_flagged) {
+  __shared__ ChainLdsT S;
+  ctc_log_chain_body<false>(a, blockIdx.x, blockIdx.y, only_flagged, S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST chains ("lane-exponent" arithmetic): the chains of ctc_fast_pipelined_kernel, and (grid (B, 2) x 512,
+// WFL_CTC_FAST_CHAIN) of the three-launch step.
+//
+// The log-domain frame is a chain of ~15 DEPENDENT instructions with 4 transcendentals (~155 cycles
+// for a lone wave).  Here a state is a float mantissa with an integer exponent PER LANE (shared by
+// the lane's blank / label pair): value = m * 2^(e_lane + off).  A frame is
+//     pb' = fb (pb + g q),   pl' = fl (pl + pb + gs q),   q = pl of lane i-1
+// -- five instructions, no transcendental (see frames4) -- with g = 2^(e[i-1] - e[i]) fixed for a
+// 16-frame block and emission factors f = 2^(x*log2e - r_t) <= 2^0.5 relative to a per-FRAME reference
+// r_t (the rounded largest target-label score of the frame).  Once per block each lane
+// renormalises ITS OWN exponent, and a prefix-max scan enforces e[i] >= e[i-1] - kGap so that mass
+// flowing up the lanes cannot overflow inside a block (growth <= 2^(16*(kGap+1.6)) < 2^127); a lane
+// pulled up by the clamp only loses mass that is 2^-126 below what its predecessor is about to hand
+// it.  A wave-uniform power-of-two scale instead of the per-lane exponents does NOT work on the
+// benchmark's data: with unnormalised scores and T >> L the alpha mass piles up at the last states
+// and the beta mass at the first ones, 2^328 apart at cfg2, and the cells that carry the posterior
+// are flushed (measured); fp64 with a wave-uniform scale works but its dependent latency leaves the
+// chain at 47 us (measured; scratch/ctc_kernels_fp64_chain.hip.txt).
+//
+// A lone wave is ISSUE-bound, not latency-bound (measured: ~4.5 cycles per VALU instruction whether
+// dependent or not), so the design minimises the chain wave's instruction count: wave 0 runs the
+// chain and nothing else; waves 1..kFHelpers stage whole blocks of factors (gather, NaN policy, the 16
+// per-frame maxima in one fold, exp2, blank broadcast) into an LDS ring; wave kFHelpers+1 turns the raw
+// (mantissa, exponent) checkpoints into the log2 format of the gradient kernels and writes them out.
+// No barrier inside the sweep: the waves meet in LDS mailboxes (ds_write / ds_read of a wave execute in
+// order, so "data, then flag" needs no wait).  Measured at cfg2: 33.5 us for the sweep (grid (B, 2))
+// against 68 us for the log-domain chain; inside the pipelined launch 36-39 us.
+//
+// What cannot be represented is flushed to zero or overflows; the results are certified.  Three-launch
+// step: ctc_certify_kernel checks, at every 16-frame boundary, that the two independently computed sweeps
+// reproduce Z (|log2 sum_s alpha*beta~ - log2 Z| < 1.5e-3), rejected utterances are recomputed by
+// ctc_log_chain_kernel in the same forward call.  Pipelined step: every gradient block reproduces log2 Z and
+// checks that the posteriors of its frames sum to one (ctc_fast_grad_body); ctc_repair_kernel evaluates.
+// Checkpoints have the SAME format as the log-domain chain's (base-2 logs relative to a double offset), so
+// the gradient kernels do not care which chain produced them.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGap = 5;       // max exponent drop from lane i-1 to lane i
+constexpr int kEmptyE = -(1 << 28);
+
+__device__ __forceinline__ int wave_shr1_i(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+// (dpp_i32: device_common.h)
+// inclusive prefix maximum over the 64 lanes (row_shr scan + row broadcasts).  v_max_i32 with a DPP source:
+// a lane whose source lane does not exist (or whose row is masked) is simply not written, which is the
+// identity of a running maximum -- one instruction per step instead of mov / mov_dpp / max.  The s_nops
+// are the two wait states a DPP read needs after a VALU write of the same register.
+__device__ __forceinline__ int wave_prefix_max_i(int v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(v));
+  return v;
+}
+// acc0 += lane[i-1].src * c0, acc1 += lane[i-1].src * c1 (lane 0: unchanged)
+__device__ __forceinline__ void fmac2_shr1(float& acc0, float& acc1, float src, float c0, float c1) {
+  asm volatile(
+      "s_nop 1\n\tv_fmac_f32_dpp %0, %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf"
+      : "+&v"(acc0), "+&v"(acc1)
+      : "v"(src), "v"(c0), "v"(c1));
+}
+
+// Reduce 16 per-lane values over the 64 lanes at once: instead of 16 wave reductions (16 x 18 instructions)
+// the lanes fold the 16 values pairwise -- after the exchange with lane^1 a lane only keeps the 8
+// values whose index has its bit 0, after lane^2 four, ... -- so that lane l (l < 16, every row)
+// ends up with the 64-lane total (MAX: maximum) of value l.  ~55 instructions.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {  // quad_perm / row_ror moves, all lanes valid
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float fold16(const float (&v)[16], int lane) {
+  auto op = [](float x, float y) { return MAX ? vmax(x, y) : x + y; };
+  float a[8], b[4], c[2];
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {  // partner lane^1: quad_perm [1,0,3,2]
+    const float keep = b0 ? v[2 * m + 1] : v[2 * m], send = b0 ? v[2 * m] : v[2 * m + 1];
+    a[m] = op(keep, dpp_quad<0xb1>(send));
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {  // partner lane^2: quad_perm [2,3,0,1]
+    const float keep = b1 ? a[2 * m + 1] : a[2 * m], send = b1 ? a[2 * m] : a[2 * m + 1];
+    b[m] = op(keep, dpp_quad<0x4e>(send));
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {  // partner lane^4 inside the row of 16: rotate by 4 or by 12
+    const float keep = b2 ? b[2 * m + 1] : b[2 * m], send = b2 ? b[2 * m] : b[2 * m + 1];
+    const float up = dpp_quad<0x124>(send), down = dpp_quad<0x12c>(send);  // row_ror:4 (from lane+12 = lane-4), row_ror:12 (from lane+4)
+    c[m] = op(keep, b2 ? up : down);
+  }
+  const float keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
+  float t = op(keep, dpp_quad<0x128>(send));  // partner lane^8: row_ror:8
+  t = op(t, __shfl_xor(t, 16, 64));
+  t = op(t, __shfl_xor(t, 32, 64));
+  return t;
+}
+__device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) { return fold16<false>(v, lane); }
+
+constexpr int kFHelpers = 4;  // waves 1..4 stage emission factors (whole blocks, round robin); wave 5 flushes checkpoints
+constexpr int kFWaves = 8;    // workgroup of the fast kernels (waves 6, 7 of a chain workgroup leave at once).  Workgroup
+                              // shapes that are not a multiple of 4 waves do not spread evenly over the SIMDs (measured with
+                              // 5 waves: no additional workgroup became resident).
+constexpr int kFSlots = kFHelpers + 1;  // LDS ring depth in blocks (factors): the chain reads block kk+1 while the helpers stage
+                                        // kk+2 .. ; 40 KiB -- with the 51 KB of gradient rows at C = 100 three workgroups share a CU
+constexpr int kCkSlots = 8;   // depth of the checkpoint hand-off (and of the per-frame references the flusher sums)
+
+struct FastLdsT {
+  float2 ring[kFSlots][kBlk][64];  // (fb, fl) per frame and lane: 40 KiB
+  float fref[kCkSlots][kBlk];      // per-frame reference r_t (integer valued)
+  float2 ckm[kCkSlots][64];        // checkpoint hand-off chain wave -> flusher: mantissas ...
+  int cke[kCkSlots][64];           // ... and per-lane exponents
+  int staged[kFSlots];             // == n + 1 once block n sits in slot n % kFSlots
+  int consumed;                    // blocks the chain wave has loaded into registers
+  int ckready;                     // checkpoints handed over
+  int ckdone;                      // checkpoints the flusher has picked up
+  double offtot;                   // sum of all r_t
+};
+
+// LDS mailboxes between the waves of a workgroup.  DS instructions of a wave execute in issue order and
+// the LDS serves one instruction at a time, so "data, then flag" from the producer and "flag, then data"
+// from the consumer need no wait in between -- only the compiler has to keep the order.
+// (The casts to the LDS address space matter: a volatile access through a generic pointer is compiled to
+// a system-coherent FLAT instruction with an immediate s_waitcnt -- measured: 4 of them per block cost the
+// chain wave more than its 16 frames.)
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ __forceinline__ int lds_peek(const int* p) { return *(const volatile lds_int_t*)(const lds_int_t*)p; }
+__device__ __forceinline__ void lds_post(int* p, int v) {
+  asm volatile("" ::: "memory");
+  *(volatile lds_int_t*)(lds_int_t*)p = v;
+}
+
+// No barrier inside the sweep: every wave runs at its own pace.  Helper h owns blocks h, h+6, h+12, ...
+// entirely (16 gathers issued six chain blocks ahead of their use, one reference per FRAME), the chain
+// wave only multiplies and adds, and the flusher turns the raw (mantissa, exponent) checkpoints into
+// the log2 format of the gradient kernel.
+template <bool SIGNAL, bool LSM = false, bool XC = false>  // XC: emissions from the compact copy (CtcArgs::xc)
+__device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int dir, FastLdsT& S) {
+  // (wave index as a scalar: block numbers, frame numbers and row addresses of the helpers then live in SGPRs)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int T = a.T, C = a.C, P = a.P;
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  int y = -1, yprev = -1;
+  if (lane < L) y = a.targets[o0 + (dir == 0 ? lane : L - 1 - lane)];
+  if (lane >= 1 && lane - 1 < L) yprev = a.targets[o0 + (dir == 0 ? lane - 1 : L - lane)];
+  const bool has_label = lane < L, has_blank = lane <= L;
+  const bool skip = has_label && lane >= 1 && y != yprev;
+  const float* xrow = a.x + (int64_t)b * T * C;
+  const int col = has_label ? y : a.blank;
+  // where this lane's emission of a frame comes from: its column of x, or its slot of the compact copy (the beta
+  // sweep's lanes hold the target mirrored).  A template parameter: the step's hot kernel is at its 80-register cap.
+  const float* esrc = XC ? a.xc + (int64_t)b * T * kXcStride : xrow;
+  const int estride = XC ? kXcStride : C;
+  const int eidx = XC ? (has_label ? (dir == 0 ? lane : L - 1 - lane) : L) : col;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  const int NB = ctc_blocks(T);
+  if (!SIGNAL && dir == 0 && threadIdx.x == 0) ((int32_t*)(a.ws + w.flag))[b] = 0;
+  if (SIGNAL && dir == 0 && threadIdx.x == 0) {  // certificate accumulators (before the first checkpoint is published)
+    long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+    coherent_store64(zmm, (unsigned long long)(1ll << 62));
+    coherent_store64(zmm + 1, (unsigned long long)(-(1ll << 62) - 1));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  }
+  if (threadIdx.x < kFSlots) S.staged[threadIdx.x] = 0;
+  if (threadIdx.x == 0) S.consumed = 0, S.ckready = 0, S.ckdone = 0;
+  __syncthreads();
+  if (wave > kFHelpers + 1) return;  // (a wave that has ended no longer counts for the workgroup's barriers)
+
+  if (wave >= 1 && wave <= kFHelpers) {
+    // ---------------------------------------------------------------- helpers
+    float lse_raw = 0.f;
+    auto issue = [&](int n, float (&raw)[kBlk]) {
+      const int k = dir == 0 ? n : NB - 1 - n;
+      const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        const int t = dir == 0 ? t0 + j : t0 + cnt - 1 - j;
+        raw[j] = (WFL_DBG_FAST & 4) ? 0.01f * t : esrc[(int64_t)min(max(t, 0), T - 1) * estride + eidx];  // clamped: valid address, unused past the block
+      }
+      if (LSM) {
+        const int t = dir == 0 ? t0 + (lane & 15) : t0 + cnt - 1 - (lane & 15);
+        lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
+      }
+    };
+    auto stage = [&](int n, const float (&raw)[kBlk]) {
+      const int k = dir == 0 ? n : NB - 1 - n;
+      const int cnt = min(kBlk, T - k * kBlk);
+      const int slot = n % kFSlots;
+      if (WFL_DBG_FAST & 2) {
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) S.ring[slot][j][lane] = make_float2(has_blank ? 0.4f : 0.f, has_label ? 0.4f + 0.001f * raw[j] : 0.f);
+        if (lane < kBlk) S.fref[n % kCkSlots][lane] = 0.f;
+        return;
+      }
+      float xs[kBlk];
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        const float v = (LSM ? raw[j] - readlane_f(lse_raw, j) : raw[j]) * kLog2e;
+        xs[j] = (v == v) ? v : WFL_NEG_INF;  // NaN policy: impossible
+      }
+      // reference of frame j: its largest target-label emission, rounded (all 16 wave maxima in one fold;
+      // lane j < 16 of every row ends up with frame j's)
+      const float m = fold16<true>(xs, lane);
+      const float rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        const float f = __builtin_amdgcn_exp2f(xs[j] - readlane_f(rr, j));
+        const float fb = readlane_f(f, L);
+        S.ring[slot][j][lane] = make_float2(has_blank ? fb : 0.f, has_label ? f : 0.f);
+      }
+      if (lane < kBlk) S.fref[n % kCkSlots][lane] = lane < cnt ? rr : 0.f;
+    };
+    const int h = wave - 1;
+    float raw[kBlk];
+    if (h < NB) issue(h, raw);
+    for (int n = h; n < NB; n += kFHelpers) {
+      // slot n % kFSlots held block n - kFSlots: free once the chain has it in registers and the flusher
+      // has taken its references
+      while ((n >= kFSlots && lds_peek(&S.consumed) < n - kFSlots + 1) || (n >= kCkSlots && lds_peek(&S.ckdone) < n - kCkSlots + 1))
+        __builtin_amdgcn_s_sleep(1);
+      stage(n, raw);
+      lds_post(&S.staged[n % kFSlots], n + 1);
+      if (n + kFHelpers < NB) issue(n + kFHelpers, raw);
+    }
+  } else if (wave == kFHelpers + 1) {
+    // ---------------------------------------------------------------- flusher
+    float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
+    double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+    unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
+    constexpr int kLag = 4;  // checkpoints between a store and the flag that vouches for it (3 * kLag <= 63: vmcnt is 6 bits)
+    double offcum = 0.0;  // sum of r_t over the blocks before the checkpoint
+    if (SIGNAL && dir == 0) {
+      // which target labels own their gradient column (occur once, are not the blank): one mask per utterance for
+      // all its gradient waves, stored before the first checkpoint (acknowledged before any flag is raised)
+      bool dupl = false;
+      int own = lane;  // lane of the label's first occurrence: the slot of its column in the compact gradient tile
+      for (int j = 0; j < L; ++j) {
+        const bool same = __builtin_amdgcn_readlane(y, j) == y;
+        dupl = dupl || (same && j != lane);
+        if (same && j < own) own = j;
+      }
+      dupl = has_label && (dupl || y == a.blank);
+      if (y == a.blank) own = 63;  // (a target label equal to the blank index shares the blank's slot)
+      __hip_atomic_store((int32_t*)(a.ws + w.own) + (int64_t)b * 64 + lane, own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long mask = __builtin_amdgcn_ballot_w64(dupl);
+      // bit 63 (no label lives in lane 63): the target cannot be aligned at all -- T < L + adjacent repeats.  Such an
+      // utterance has Z = 0 exactly, in any arithmetic: loss inf, zero gradient, nothing for the certificate to doubt
+      const int repeats = __builtin_popcountll(__builtin_amdgcn_ballot_w64(has_label && lane >= 1 && y == yprev));
+      if (T < L + repeats) mask |= 1ull << 63;
+      if (lane == 0) coherent_store64((unsigned long long*)(a.ws + w.dup) + b, mask);
+    }
+    for (int kk = 0; kk < NB; ++kk) {
+      while (lds_peek(&S.ckready) < kk + 1) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      const float2 m = S.ckm[kk % kCkSlots][lane];
+      const int e = S.cke[kk % kCkSlots][lane];
+      const float rj = lane < kBlk ? S.fref[kk % kCkSlots][lane] : 0.f;
+      lds_post(&S.ckdone, kk + 1);
+      if (WFL_DBG_FAST & 8) continue;
+      // checkpoint = state BEFORE block kk, as base-2 logs relative to a wave-uniform exponent
+      const int emax = __builtin_amdgcn_readlane(wave_prefix_max_i(e), 63);
+      const float de = (float)(e - emax);
+      const float lb = m.x > 0.f ? __builtin_amdgcn_logf(m.x) + de : kNegBig;
+      const float ll = m.y > 0.f ? __builtin_amdgcn_logf(m.y) + de : kNegBig;
+      const double offk = offcum + (double)(emax > kEmptyE ? emax : 0);
+      if (!SIGNAL) {
+        if (lane < P) ck[(int64_t)kk * P + lane] = make_float2(lb, ll);
+        if (lane == 0) offs[kk] = offk;
+      } else {
+        // Device-coherent stores (see ctc_log_chain_body), but this wave cannot afford to wait for the
+        // acknowledgement of every checkpoint: a block of the fast chain is shorter than a store round
+        // trip.  The flag of checkpoint kk - kLag is raised once everything older than the last
+        // 3 * kLag vector-memory instructions has been acknowledged (stores are acknowledged in issue
+        // order; EXACTLY three are issued per iteration -- before the first kLag iterations the third one
+        // writes "not ready" to the block's own flag).
+        const float2 v = make_float2(lb, ll);
+        unsigned long long bits, obits;
+        __builtin_memcpy(&bits, &v, 8);
+        __builtin_memcpy(&obits, &offk, 8);
+        float2* dst = &ck[(int64_t)kk * P + lane];
+        if (lane < P) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(bits) : "memory");
+        if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(&offs[kk]), "v"(obits) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kLag) : "memory");
+        const int pub = kk - kLag;
+        unsigned long long* fl = &ready[pub >= 0 ? pub : kk];
+        const unsigned long long val = pub >= 0 ? a.token : 0ull;
+        if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(fl), "v"(val) : "memory");
+      }
+      offcum += (double)wave_all_sum(rj);
+    }
+    if (SIGNAL) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        for (int kk = max(NB - kLag, 0); kk < NB; ++kk) coherent_store64(&ready[kk], a.token);
+    }
+    if (lane == 0) S.offtot = offcum;
+  } else if (wave == 0) {
+    // ---------------------------------------------------------------- the chain
+    __builtin_amdgcn_s_setprio(3);  // issue-bound: wins the arbitration against the helper wave on its SIMD
+#if WFL_DBG_FAST & 512
+    long long* dbgc = (long long*)(a.ws + w.dbg) + ((int64_t)a.B * NB + b * 2 + dir) * 4;
+    if (SIGNAL && lane == 0) dbgc[0] = wall_clock64();
+#endif
+    float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
+    float pl = 0.f;
+    int e = 0;
+    float g = 0.f, gs = 0.f;
+    bool had = false, bad = false;
+    // per-lane power-of-two renormalisation, neighbour-gap clamp, coupling factors for the interval
+    auto lane_renorm = [&]() {
+      const float mx = vmax(pb, pl);
+      bad = bad || !(mx < 3.0e38f);
+      const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
+      const int own = mx > 0.f ? e + k : kEmptyE;
+      const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
+      const int sh = mx > 0.f ? pre - own : 0;                            // >= 0: pulled up by the clamp
+      pb = ldexpf(pb, -(k + min(sh, 200)));  // (mantissa to [0.5, 1), then down by the clamp: one scaling)
+      pl = ldexpf(pl, -(k + min(sh, 200)));
+      e = pre;
+      const int d = wave_shr1_i(e, e) - e;  // <= kGap by construction
+      g = lane == 0 ? 0.f : ldexpf(1.f, max(d, -200));
+      gs = skip ? g : 0.f;
+      had = vmax(pb, pl) > 0.f;
+    };
+    // pb' = fb (pb + g q), pl' = fl (pl + pb + gs q) with q = pl of lane i-1, arranged so that only TWO
+    // dependent instructions separate pl' from pl (the DPP multiply-add and the final fma): the products
+    // with pb and the coefficient products do not depend on the newest pl
+    auto frame = [&](const float2 f) {
+      const float c0 = f.x * g, c1 = f.y * gs;
+      float t0 = f.x * pb, t1 = f.y * pb;
+      fmac2_shr1(t0, t1, pl, c0, c1);
+      pl = fmaf(f.y, pl, t1);
+      pb = t0;
+    };
+    // Four frames in FIVE instructions each (the wave is issue-bound: ~4.5 cycles per VALU instruction whether
+    // dependent or not): packed multiplies for the two coefficient products and the two pb products, the two
+    // DPP multiply-adds, and the fma that adds fl * pl.  State pair P = (pb, pl) and the running pair t swap
+    // roles every frame; they are pinned to v[2:3] / v[4:5] because the template has to name their halves.
+    // The two packed multiplies between the write of pl and its DPP read are the required wait states.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+#define WFL_FRAME(P, PH, TT, TL, TH, F, FY)                                   \
+  "v_pk_mul_f32 v[6:7], " F ", %[G]\n\t"                                      \
+  "v_pk_mul_f32 " TT ", " F ", " P " op_sel_hi:[1,0]\n\t"                     \
+  "v_fmac_f32_dpp " TL ", " PH ", v6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp " TH ", " PH ", v7 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32 " TH ", " FY ", " PH "\n\t"
+    auto frames4 = [&](const float2& f0, const float2& f1, const float2& f2, const float2& f3) {
+      v2f P = {pb, pl};
+      const v2f G = {g, gs};
+      const v2f F0 = {f0.x, f0.y}, F1 = {f1.x, f1.y}, F2 = {f2.x, f2.y}, F3 = {f3.x, f3.y};
+      asm volatile(WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F0]", "%[Y0]")
+                   WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F1]", "%[Y1]")
+                   WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F2]", "%[Y2]")
+                   WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F3]", "%[Y3]")
+                   : "+{v[2:3]}"(P)
+                   : [G] "v"(G), [F0] "v"(F0), [F1] "v"(F1), [F2] "v"(F2), [F3] "v"(F3), [Y0] "v"(f0.y), [Y1] "v"(f1.y),
+                     [Y2] "v"(f2.y), [Y3] "v"(f3.y)
+                   : "v4", "v5", "v6", "v7");
+      pb = P.x;
+      pl = P.y;
+    };
+    // The factors travel ring -> registers in HALF blocks (two sets of 8 float2, alternating: no copies and half the
+    // registers of whole blocks -- the kernel's register count decides how many gradient workgroups share the CU).
+    constexpr int kHalf = kBlk / 2;
+    float2 ha[kHalf], hb[kHalf];
+    while (lds_peek(&S.staged[0]) != 1) {
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < kHalf; ++j) ha[j] = S.ring[0][j][lane];
+    int nflag = NB > 1 ? lds_peek(&S.staged[1]) : 0;  // looked at one block ahead of its use: off the dependent path
+    int done_seen = 0;
+    // q: half-block index (block q / 2, frames (q & 1) * 8 ...)
+    // STEADY: an interior block (complete, followed by another one) -- the bulk of the sweep runs without the
+    // boundary tests (a uniform branch costs the lone wave more than an arithmetic instruction)
+    auto half = [&](int q, const float2 (&fcur)[kHalf], float2 (&fnxt)[kHalf], auto steady) {
+      constexpr bool STEADY = decltype(steady)::value;
+      const int kk = q >> 1, second = q & 1;
+      const int k = dir == 0 ? kk : NB - 1 - kk;
+      const int n = STEADY ? kHalf : min(kBlk, T - k * kBlk) - second * kHalf;  // frames of this half that exist (may be <= 0)
+      if (second) {
+        // the next half opens block kk + 1: it has to be staged
+        if (STEADY || kk + 1 < NB) {
+          if (nflag != kk + 2)
+            while (lds_peek(&S.staged[(kk + 1) % kFSlots]) != kk + 2) {
+            }
+          asm volatile("" ::: "memory");
+          if (STEADY || kk + 2 < NB) nflag = lds_peek(&S.staged[(kk + 2) % kFSlots]);
+          done_seen = lds_peek(&S.ckdone);
+#pragma unroll
+          for (int j = 0; j < kHalf; ++j)
+            fnxt[j] = S.ring[(kk + 1) % kFSlots][j][lane];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kHalf; ++j)
+          fnxt[j] = S.ring[kk % kFSlots][kHalf + j][lane];
+        lds_post(&S.consumed, kk + 1);  // (after the reads were issued: LDS executes a wave's instructions in order)
+        lane_renorm();
+        if (kk >= kCkSlots && done_seen < kk - kCkSlots + 1)
+          while (lds_peek(&S.ckdone) < kk - kCkSlots + 1) {
+          }
+        S.ckm[kk % kCkSlots][lane] = make_float2(pb, pl);
+        S.cke[kk % kCkSlots][lane] = had ? e : kEmptyE;
+        lds_post(&S.ckready, kk + 1);
+      }
+      if (WFL_DBG_FAST & 1) {
+        pb += fcur[0].x + fcur[kHalf - 1].y;
+      } else if (n >= kHalf) {
+#pragma unroll
+        for (int j = 0; j < kHalf; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kHalf; ++j)
+          if (j < n) frame(fcur[j]);
+      }
+    };
+    {
+      half(0, ha, hb, std::false_type{});
+      half(1, hb, ha, std::false_type{});
+      int kk = 1;
+      for (; kk + 2 < NB; ++kk) {  // blocks 1 .. NB-3: complete for both directions, two more blocks follow
+        half(2 * kk, ha, hb, std::true_type{});
+        half(2 * kk + 1, hb, ha, std::true_type{});
+      }
+      for (; kk < NB; ++kk) {
+        half(2 * kk, ha, hb, std::false_type{});
+        half(2 * kk + 1, hb, ha, std::false_type{});
+      }
+    }
+    lane_renorm();
+#if WFL_DBG_FAST & 512
+    if (SIGNAL && lane == 0) dbgc[1] = wall_clock64();
+#endif
+    __syncthreads();  // the flusher has summed all references
+    if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = bad ? 1 : 0;
+    if (dir == 0) {
+      // Z = alpha_{T-1}[2L] + alpha_{T-1}[2L-1]   (ctc.py:21 accept states), lanes L and L-1
+      const float zb = readlane_f(pb, L);
+      const float zl = L > 0 ? readlane_f(pl, L - 1) : 0.f;
+      const int eb = __builtin_amdgcn_readlane(e, L);
+      const int el = L > 0 ? __builtin_amdgcn_readlane(e, L - 1) : kEmptyE;
+      if (lane == 0) {
+        const int em = max(zb > 0.f ? eb : kEmptyE, zl > 0.f ? el : kEmptyE);
+        const float s = (zb > 0.f ? ldexpf(zb, max(eb - em, -200)) : 0.f) + (zl > 0.f ? ldexpf(zl, max(el - em, -200)) : 0.f);
+        const bool ok = s > 0.f && s < 3.0e38f;
+        const double z2 = ok ? (double)__builtin_amdgcn_logf(s) + (double)em + S.offtot : -1.0e300;
+        ((double*)(a.ws + w.z2))[b] = z2;
+        publish_nll<SIGNAL, false>(a, w, b, ok, z2);
+      }
+      if (SIGNAL && a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
+    }
+    return;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kFWaves * 64) ctc_fast_chain_kernel(CtcArgs a) {
+  __shared__ FastLdsT S;
+  ctc_fast_chain_body<false>(a, blockIdx.x, blockIdx.y, S);
+}
+
+// certificate: one wave per (utterance, interior 16-frame boundary); 4 waves per workgroup
+__global__ void __launch_bounds__(256) ctc_certify_kernel(CtcArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, P = a.P;
+  const int NB = ctc_blocks(T);
+  const int per = max(NB - 1, 1);
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  if (item >= (int64_t)a.B * per) return;
+  const int b = (int)(item / per), k = (int)(item % per) + 1;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  int32_t* flag = (int32_t*)(a.ws + w.flag) + b;
+  const double z2 = ((const double*)(a.ws + w.z2))[b];
+  if (k == 1) {
+    const int32_t* pbad = (const int32_t*)(a.ws + w.pbad) + b * 2;
+    if (lane == 0 && (!(z2 > -1.0e299) || pbad[0] != 0 || pbad[1] != 0)) atomicOr(flag, 1);
+  }
+  if (k >= NB || !(z2 > -1.0e299)) return;
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  const int y = lane < L ? a.targets[o0 + lane] : -1;
+  const int ynext = lane + 1 < L ? a.targets[o0 + lane + 1] : -1;
+  const bool skipn = lane + 1 < L && ynext != y;
+  const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
+  const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
+  const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
+  const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
+  // boundary k (between frames 16k-1 and 16k): alpha checkpoint k = state after frame 16k-1; the beta
+  // checkpoint taken before beta processed block k-1 (processing index NB-k) = full beta of frame 16k.
+  const float2 al = lane < P ? cka[(int64_t)k * P + lane] : make_float2(kNegBig, kNegBig);
+  const float bb = lane <= L ? ckb[(int64_t)(NB - k) * P + (L - lane)].x : kNegBig;
+  const float bl = lane < L ? ckb[(int64_t)(NB - k) * P + (L - 1 - lane)].y : kNegBig;
+  const float tb = lse2_b2(bb, bl);
+  const float tbn = wave_shl1(tb, kNegBig), bbn = wave_shl1(bb, kNegBig);
+  const float tl = lse2_b2(bl, skipn ? tbn : bbn);
+  const float u = al.x + tb, v = lane < L ? al.y + tl : kNegBig;
+  const float m = wave_all_max(fmaxf(u, v));
+  const float ssum = wave_all_sum(__builtin_amdgcn_exp2f(u - m) + __builtin_amdgcn_exp2f(v - m));
+  const double dev = (double)m + (double)__builtin_amdgcn_logf(ssum) + offa[k] + offb[NB - k] - z2;
+  if (lane == 0 && !(fabs(dev) < 1.5e-3)) atomicOr(flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient: one wave per (utterance, 16-frame block), 4 waves per workgroup
+// ------------------------------------------------------------------------------------------------
+// Fused log_softmax backward, first half: rows[j*C + c] = -cf * softmax(x)[t0 + j, c] for the block's n
+// frames (contiguous in x).  Flat and vectorised, eight loads in flight per lane: the wave has
+// nothing else to hide the latency behind.  lse_blk: lane j < 16 holds the log-sum-exp of frame t0 + j.
+__device__ __forceinline__ void lsm_seed_rows(float* rows, const float* __restrict__ xsrc, int n, int C, float lse_blk,
+                                              float cf_row, int lane) {
+  const int total = n * C;
+  const unsigned magic = (unsigned)((0x100000000ull + (unsigned)C - 1) / (unsigned)C);  // i / C for i * C < 2^32
+  auto seed = [&](float xv, float l) {
+    const float e = __expf((xv == xv ? xv : WFL_NEG_INF) - l);
+    return l > WFL_NEG_INF ? -cf_row * e : 0.f;  // a frame without finite scores: no softmax term
+  };
+  constexpr int U = 8;
+  if ((C & 3) == 0 && (((uintptr_t)xsrc) & 15) == 0) {
+    const int n4 = total >> 2;
+    for (int i0 = lane; i0 < n4; i0 += 64 * U) {
+      float4 v[U];
+      float l[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + 64 * u, n4 - 1);
+        v[u] = ((const float4*)xsrc)[i];
+        l[u] = __shfl(lse_blk, (int)__umulhi((unsigned)i * 4u, magic), 64);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 64 * u;
+        if (i < n4) ((float4*)rows)[i] = float4{seed(v[u].x, l[u]), seed(v[u].y, l[u]), seed(v[u].z, l[u]), seed(v[u].w, l[u])};
+      }
+    }
+  } else {
+    for (int i0 = lane; i0 < total; i0 += 64 * U) {
+      float v[U], l[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + 64 * u, total - 1);
+        v[u] = xsrc[i];
+        l[u] = __shfl(lse_blk, (int)__umulhi((unsigned)i, magic), 64);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 64 * u;
+        if (i < total) rows[i] = seed(v[u], l[u]);
+      }
+    }
+  }
+}
+
+// COMPACT gradient tile (wide rows): the wave accumulates a block's posteriors in [16][65] floats -- one slot per
+// target position (the slot of a repeated label is the lane of its first occurrence), slot 63 the blank, slot 64
+// zero -- next to a column -> slot byte map, and the dense rows are expanded while they are written:
+//   dx[t0 + j, c] = tile[j][slot(c)]  - cf * softmax(x)[c] (fused log_softmax).
+// The dense LDS tile [16][C] of the narrow case would leave a single gradient workgroup per CU from C = 160 on and
+// does not fit at all beyond C = 602.
+// Tile rows are kCS = 65 floats: slots 0..62 target positions, 63 the blank, 64 a constant zero that every column
+// without a slot maps to -- the expansion reads the tile unconditionally (four ds_read_b32 + one global store per
+// float4; with a "no slot" test per element it was five times as many instructions).
+constexpr int kCS = 65;
+constexpr int kCTileBytes = kBlk * kCS * 4;  // 4160
+__host__ __device__ __forceinline__ size_t compact_wave_bytes(int C) { return (size_t)kCTileBytes + ((C + 15) & ~15); }
+__device__ __forceinline__ void compact_init(float* tile, unsigned char* cmap, int C, int lane) {
+  for (int i = lane; i < kBlk * kCS; i += 64) tile[i] = 0.f;
+  for (int i = lane; i < ((C + 15) & ~15) / 4; i += 64) ((unsigned int*)cmap)[i] = 0x40404040u;  // 64: the zero slot
+}
+__device__ __forceinline__ void compact_expand(const float* tile, const unsigned char* cmap, float* __restrict__ dst,
+                                               const float* __restrict__ xsrc, float lse_blk, int n, int C, float cf,
+                                               bool alive, bool soft, int lane) {
+  auto softterm = [&](float xv, float l) { return l > WFL_NEG_INF ? cf * __expf((xv == xv ? xv : WFL_NEG_INF) - l) : 0.f; };
+  // (rows of dx start at any 4-byte boundary: global dwordx4 accesses only need dword alignment, the type says so)
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int c4n = C >> 2;
+#pragma unroll 2
+  for (int j = 0; j < n; ++j) {  // row after row: whole rows leave in address order
+    const float l = soft ? readlane_f(lse_blk, j) : 0.f;
+    const float* tr = tile + j * kCS;
+    float* drow = dst + (int64_t)j * C;
+    const float* xr = xsrc + (int64_t)j * C;
+    for (int c4 = lane; c4 < c4n; c4 += 64) {
+      const unsigned m4 = alive ? ((const unsigned int*)cmap)[c4] : 0x40404040u;
+      f4u o = {tr[m4 & 255u], tr[(m4 >> 8) & 255u], tr[(m4 >> 16) & 255u], tr[m4 >> 24]};
+      if (soft) {
+        const f4u xv = *reinterpret_cast<const f4u*>(xr + 4 * c4);
+        o.x -= softterm(xv.x, l), o.y -= softterm(xv.y, l), o.z -= softterm(xv.z, l), o.w -= softterm(xv.w, l);
+      }
+      *reinterpret_cast<f4u*>(drow + 4 * c4) = o;
+    }
+    const int c = 4 * c4n + lane;  // the last C % 4 columns
+    if (c < C) {
+      float v = tr[alive ? (int)cmap[c] : 64];
+      if (soft) v -= softterm(xr[c], l);
+      drow[c] = v;
+    }
+  }
+}
+
+// PIPE: the pipelined step -- wait for the two checkpoints of block k to be published by the chain
+// workgroups of the same launch, and normalise the posteriors by the Z the block itself reproduces
+// (sum_s alpha(s) beta(s) at its last frame; the certificate's identity) instead of the log Z that the
+// alpha chain only knows when it has finished.
+template <bool PIPE, bool LSM = false, bool COMPACT = false>
+__device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
+                                              const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
+  const int NB = ctc_blocks(T);
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  // [16][C] gradient rows + [C] label counts per wave, or (COMPACT, wide rows) the compact tile + column map
+  char* wbase = smem + (size_t)wave * (COMPACT ? compact_wave_bytes(C) : (size_t)(kBlk + 1) * C * 4);
+  float* rows = (float*)wbase;
+  int* cnt = (int*)(rows + (size_t)kBlk * C);                             // (dense tile only)
+  unsigned char* cmap = (unsigned char*)(wbase + (size_t)kCTileBytes);  // (COMPACT only)
+  const int t0 = k * kBlk, n = min(kBlk, T - t0);
+  bool live = valid && (PIPE || a.nll[b] < __builtin_inff());  // no accepting path: zero gradient
+  constexpr bool lsm = PIPE && LSM;  // fused log_softmax (raw scores in x)
+  const float cf_row = (coef ? coef[valid ? b : 0] : 1.f) * (gout ? gout[0] : 1.f);
+  float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
+  bool alive_blk = true;  // (COMPACT) the block carries posterior mass
+  if (valid) {
+    if (COMPACT)
+      compact_init(rows, cmap, C, lane);
+    else
+      for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;  // (int 0 == float 0 bit pattern)
+    if (lsm) {
+      // d loss / d raw score = g - softmax(x) * sum_c g, and the posteriors of a frame sum to one:
+      // the rows start at -cf * softmax(x) (done before waiting: it does not depend on the chains)
+      lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
+      if (!COMPACT) lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf_row, lane);
+    }
+  }
+  if (PIPE && valid) {
+    // alpha checkpoint k and beta checkpoint NB-1-k: published by wave 1 of the two chain workgroups
+    // (flags are compared with a 64-bit token that is unique to this launch: the workspace needs no clearing)
+    const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
+    const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
+    // poll with relaxed device-scope loads (an acquire per poll would invalidate this XCD's L2 every
+    // time: measured 35x slower); the checkpoints are then read device-coherently as well
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 20); ++spin) {  // (bounded: a lost signal must not hang the GPU)
+      ok = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
+           __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(64);
+    }
+    if (!ok) {  // ~2 s without the signal: never expected (in-order dispatch puts every chain ahead of the
+                // waiting waves).  Fail loudly rather than return a silently wrong gradient.
+      if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+      __builtin_trap();
+    }
+  }
+  if (live) {
+    const int64_t o0 = a.offsets[b];
+    const int L = (int)(a.offsets[b + 1] - o0);
+    const int y = lane < L ? a.targets[o0 + lane] : -1;
+    const int yprev = (lane >= 1 && lane - 1 < L) ? a.targets[o0 + lane - 1] : -1;
+    const int ynext = lane + 1 < L ? a.targets[o0 + lane + 1] : -1;
+    const bool has_label = lane < L, has_blank = lane <= L;
+    const bool skip = has_label && lane >= 1 && y != yprev;  // label i-1 -> label i
+    const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
+    const int col = has_label ? y : a.blank;
+    const float* xrow = a.x + (int64_t)b * T * C;
+    // A label that occurs once in the target (and is not the blank column) owns its gradient column:
+    // plain ds_write instead of ds_add_f32, which costs ~1 LDS cycle per active lane (PMC: 42 cycles
+    // per wave-instruction with 45 lanes).  One counting atomic per block finds the duplicates.
+    bool dup;
+    int slot = lane;  // COMPACT: lane of the label's first occurrence
+    if (COMPACT) {
+      bool dupl = false;
+      for (int j = 0; j < L; ++j) {
+        const bool same = __builtin_amdgcn_readlane(y, j) == y;
+        dupl = dupl || (same && j != lane);
+        if (same && j < slot) slot = j;
+      }
+      dup = has_label && (dupl || y == a.blank);
+      if (y == a.blank) slot = 63;
+      if (has_label && slot == lane) cmap[y] = (unsigned char)lane;
+      if (lane == 0) cmap[a.blank] = 63;
+    } else {
+      if (has_label) atomicAdd(&cnt[y], 1);
+      dup = has_label && (cnt[y] > 1 || y == a.blank);
+    }
+    const bool uniq = has_label && !dup;
+    float xl[kBlk], xb[kBlk];
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) xl[j] = xrow[(int64_t)min(t0 + j, T - 1) * C + col];  // all 16 gathers in flight
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const float xs = to_score(lsm ? xl[j] - readlane_f(lse_blk, j) : xl[j]);
+      xb[j] = has_blank ? readlane_f(xs, L) : kNegBig;
+      xl[j] = has_label ? xs : kNegBig;
+    }
+    const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
+    const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
+    const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
+    const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
+    const double z2 = PIPE ? 0.0 : ((const double*)(a.ws + w.z2))[b];
+    // alpha checkpoint k: state before frame t0.  beta processed blocks NB-1..0, so its checkpoint
+    // before block k has processing index NB-1-k: the full beta of frame t0+n (mirrored lanes:
+    // blank state 2i <-> reversed position L-i; label of position i <-> L-1-i).
+    auto load_ck = [&](const float2* p) {  // PIPE: written by another CU during this launch
+      if (!PIPE) return *p;
+      const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float2 v;
+      __builtin_memcpy(&v, &bits, 8);
+      return v;
+    };
+    const float2 ca = lane < P ? load_ck(&cka[(int64_t)k * P + lane]) : make_float2(kNegBig, kNegBig);
+    float bb = lane <= L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - lane)]).x : kNegBig;
+    float bl = lane < L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)]).y : kNegBig;
+    if (PIPE && lane == 0) {  // this wave was the only consumer of the two flags: leave them cleared
+      unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
+      __hip_atomic_store(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rdy + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // posterior_t(s) = 2^(alpha_t(s) + beta~_t(s) + U), U = off_alpha(k) + off_beta(k) - log2 Z
+    float U = PIPE ? 0.f : (float)(offa[k] + offb[NB - 1 - k] - z2);
+    const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+    float pa_b[kBlk], pa_l[kBlk];
+    float ab = ca.x, al = ca.y;
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {  // alpha forward through the block, kept in registers
+      const float pal = wave_shr1(al, kNegBig);
+      const float nb = lse2_b2(ab, pal);
+      const float nl = lse2_b2(al, skip ? nb : ab);
+      ab = nb + xb[j];
+      al = nl + xl[j];
+      pa_b[j] = ab, pa_l[j] = al;
+    }
+    if (PIPE) {
+      // local log2 Z at the block's last frame: sum_s 2^(alpha_{n-1}(s) + [transition-propagated beta](s))
+      const float tb0 = lse2_b2(bb, bl);
+      const float tbn0 = wave_shl1(tb0, kNegBig), bbn0 = wave_shl1(bb, kNegBig);
+      const float tl0 = lse2_b2(bl, skipn ? tbn0 : bbn0);
+      float ub = kNegBig, ul = kNegBig;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j)
+        if (j == n - 1) ub = pa_b[j] + tb0, ul = pa_l[j] + tl0;
+      const float m = wave_all_max(vmax(ub, ul));
+      const float ssum = wave_all_sum(__builtin_amdgcn_exp2f(ub - m) + __builtin_amdgcn_exp2f(ul - m));
+      if (m > 0.5f * kNegBig && ssum > 0.f)
+        U = -(m + __builtin_amdgcn_logf(ssum));
+      else
+        U = kNegBig;  // no accepting path through this block: every posterior is 2^-huge = 0
+    }
+    float gbv[kBlk];
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) gbv[j] = 0.f;
+#pragma unroll
+    for (int j = kBlk - 1; j >= 0; --j) {  // beta backwards, in the forward lane mapping
+      if (j < n) {
+        // blank i -> blank i, label i.  label i -> label i, blank i+1 (and label i+1 if allowed):
+        // LSE(bl, bb[i+1], bl[i+1]) = LSE(bl, tb[i+1]) -- the neighbour's freshly computed value
+        const float tb = lse2_b2(bb, bl);
+        // (both shifts are taken unconditionally: a DPP inside a divergent branch would read
+        // neighbours that are masked off)
+        const float tbn = wave_shl1(tb, kNegBig), bbn = wave_shl1(bb, kNegBig);
+        const float tl = lse2_b2(bl, skipn ? tbn : bbn);
+        // dead / non-existent states carry sentinels: exp2 of them is exactly 0, no select needed
+        const float gb = __builtin_amdgcn_exp2f(pa_b[j] + tb + U);
+        const float gl = __builtin_amdgcn_exp2f(pa_l[j] + tl + U);
+        // blank column: the 16 frames' lane values are summed over the wave together after the loop
+        // (per-lane ds_add_f32 instead was measured at 49 us for the kernel vs 28 us: LDS float atomics
+        // serialise per active lane; one wave reduction per frame costs 18 instructions x 16)
+        gbv[j] = gb;
+        if (COMPACT) {
+          if (uniq) rows[j * kCS + lane] = gl * cf;
+          if (dup && gl != 0.f) atomicAdd(&rows[j * kCS + slot], gl * cf);
+        } else {
+          if (uniq) rows[j * C + y] = (lsm ? rows[j * C + y] : 0.f) + gl * cf;  // sole writer of this column
+          if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
+        }
+        bb = tb + xb[j];
+        bl = tl + xl[j];
+      }
+    }
+    const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
+    if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * kCS + 63 : lane * C + a.blank], gtot * cf);
+    if (PIPE) alive_blk = U > 0.5f * kNegBig;
+    if (lsm && !alive_blk && !COMPACT)  // no accepting path: zero gradient, softmax term included
+      for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+  }
+  // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
+  if (valid && COMPACT) {
+    const bool alive = live && alive_blk;
+    compact_expand(rows, cmap, dx + ((int64_t)b * T + t0) * C, a.x + ((int64_t)b * T + t0) * C, lse_blk, n, C, cf_row, alive,
+                   lsm && alive, lane);
+  } else if (valid) {  // the dense rows of a block are contiguous in dx: one coalesced copy (zeros included)
+    float* dst = dx + ((int64_t)b * T + t0) * C;
+    const int total = n * C;
+    if ((((uintptr_t)dst) & 15) == 0) {
+      const int n4 = total >> 2;
+      for (int i = lane; i < n4; i += 64) ((float4*)dst)[i] = ((const float4*)rows)[i];
+      for (int i = (n4 << 2) + lane; i < total; i += 64) dst[i] = rows[i];
+    } else {
+      for (int i = lane; i < total; i += 64) dst[i] = rows[i];
+    }
+  }
+}
+
+// acc += lane[i+1].s0 * c0 + lane[i+1].s1 * c1 (lane 63: unchanged)
+__device__ __forceinline__ void fmac2_shl1(float& acc, float s0, float s1, float c0, float c1) {
+  asm volatile(
+      "s_nop 1\n\tv_fmac_f32_dpp %0, %1, %3 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %0, %2, %4 wave_shl:1 row_mask:0xf bank_mask:0xf"
+      : "+&v"(acc)  // (early clobber: acc starts as a copy of s1 and must not share its register)
+      : "v"(s0), "v"(s1), "v"(c0), "v"(c1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradient of one 16-frame block in lane-exponent arithmetic (the fast pipelined launch).  The
+// log-domain block (ctc_grad_body) costs ~2500 instructions, 160 of them transcendentals, and the
+// gradient part of the launch is bound by VALU issue; here the two sweeps are multiply-adds like the
+// chain's (the block is exactly what the chain runs between two of its renormalisations: same
+// per-lane exponents with the same neighbour clamp, same per-frame references, same growth bound).
+// Everything that does not depend on the checkpoints -- gathers, references, the 16 exp2 per lane --
+// is done BEFORE the wave starts waiting for them.
+//   alpha_j(s) = ma_j(s) 2^ea(s), beta~_j(s) = mb_j(s) 2^eb(s), exponents fixed over the block;
+//   Z_local = sum_s alpha_{n-1}(s) [A beta~_n](s)  (relative to the checkpoints' offsets and the
+//   block's references); posterior = ma mb' K(s) with K(s) = 2^(ea + eb - E) / Zm folded into ma.
+// ------------------------------------------------------------------------------------------------
+// Emission factors of one block's frames for the lane's column: f_j = 2^(x log2e - r_j), r_j = round(largest
+// target-label score of frame j) -- rr holds r_j in the lanes with (lane & 15) == j.
+template <bool LSM>
+__device__ __forceinline__ void fast_block_factors(const float* __restrict__ esrc, int estride, int eidx, int t0, int n, int T,
+                                                   float lse_blk, int lane, float (&f)[kBlk], float& rr) {
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) f[j] = esrc[(int64_t)min(t0 + j, T - 1) * estride + eidx];  // all 16 gathers in flight
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    const float v = (LSM ? f[j] - readlane_f(lse_blk, j) : f[j]) * kLog2e;
+    f[j] = (v == v && j < n) ? v : WFL_NEG_INF;  // NaN policy: impossible
+  }
+  const float m = fold16<true>(f, lane);  // lane j < 16 (every row): the maximum of frame j
+  rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) f[j] = __builtin_amdgcn_exp2f(f[j] - readlane_f(rr, j));
+}
+
+// A persistent gradient wave has nothing to do until the checkpoints of its first item exist (half the chain time
+// at the earliest) and is then busy to the end of the launch: it computes the factors of its SECOND item -- gathers,
+// references, exp2: a third of an item -- in that idle time and leaves them in its slot of a.park.
+template <bool LSM, bool XC>
+__device__ __forceinline__ void ctc_fast_park_factors(const CtcArgs& a, int b, int k, float* __restrict__ park) {
+  const int lane = threadIdx.x & 63;
+  const int T = a.T, t0 = k * kBlk, n = min(kBlk, T - t0);
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  const int col = lane < L ? a.targets[o0 + lane] : a.blank;
+  const float* esrc = XC ? a.xc + (int64_t)b * T * kXcStride : a.x + (int64_t)b * T * a.C;
+  float lse_blk = 0.f;
+  if (LSM) lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
+  float f[kBlk], rr;
+  fast_block_factors<LSM>(esrc, XC ? kXcStride : a.C, XC ? (lane < L ? lane : L) : col, t0, n, T, lse_blk, lane, f, rr);
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) park[j * 64 + lane] = f[j];
+  park[kBlk * 64 + lane] = rr;
+}
+
+// what a gradient wave keeps of its utterance from one item to the next (a persistent wave's items belong to one
+// utterance whenever the stride is a multiple of the batch)
+struct FastUtt {
+  int b = -1, L = 0, y = -1, yprev = -1, ynext = -1;
+  float cf = 0.f;
+};
+
+template <bool LSM, bool CERT, bool COMPACT = false, bool XC = false>
+__device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
+                                                   const float* __restrict__ gout, float* __restrict__ dx, char* smem,
+                                                   FastUtt& u, const float* __restrict__ parked = nullptr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
+  const int NB = ctc_blocks(T);
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  if (!valid) return;  // (uniform over the wave)
+#if WFL_DBG_FAST & 512
+  long long* dbg = (long long*)(a.ws + w.dbg) + ((int64_t)b * NB + k) * 4;
+  if (lane == 0) dbg[0] = wall_clock64();
+#endif
+  // ---- first, what needs a round trip and depends on nothing: the two flags, the parked factors, the utterance
+  const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
+  const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
+  const unsigned long long seen_a = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long seen_b = __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float xs[kBlk], rr = 0.f;  // emission factors of the block's frames (this lane's column), per-frame references
+  if (parked) {  // (uniform) this wave computed them while it waited for its first item: ctc_fast_park_factors
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) xs[j] = parked[j * 64 + lane];
+    rr = parked[kBlk * 64 + lane];
+  }
+  if (u.b != b) {  // (uniform)
+    const int64_t o0 = a.offsets[b];
+    u.L = (int)(a.offsets[b + 1] - o0);
+    u.y = lane < u.L ? a.targets[o0 + lane] : -1;
+    u.yprev = (lane >= 1 && lane - 1 < u.L) ? a.targets[o0 + lane - 1] : -1;
+    u.ynext = lane + 1 < u.L ? a.targets[o0 + lane + 1] : -1;
+    u.cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+    u.b = b;
+  }
+  // Gradient rows of the wave: the dense LDS tile [16][C] (scattered into, copied out in one piece) for narrow rows,
+  // the COMPACT tile + column map (see compact_expand) for wide ones.
+  char* wbase = smem + (size_t)wave * (COMPACT ? compact_wave_bytes(C) : (size_t)kBlk * C * 4);
+  float* rows = (float*)wbase;
+  unsigned char* cmap = (unsigned char*)(wbase + (size_t)kCTileBytes);  // (COMPACT only)
+  const int t0 = k * kBlk, n = min(kBlk, T - t0);
+  const float cf = u.cf;
+  float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
+  if (COMPACT)
+    compact_init(rows, cmap, C, lane);
+  else
+    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+  if (LSM) {
+    lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
+    if (!COMPACT) lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf, lane);
+  }
+  const int L = u.L, y = u.y, yprev = u.yprev, ynext = u.ynext;
+  const bool has_label = lane < L;
+  const bool skip = has_label && lane >= 1 && y != yprev;  // label i-1 -> label i
+  const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
+  const int col = has_label ? y : a.blank;
+  const float* xrow = a.x + (int64_t)b * T * C;
+  const float* esrc = XC ? a.xc + (int64_t)b * T * kXcStride : xrow;  // (see ctc_fast_chain_body)
+  const int estride = XC ? kXcStride : C;
+  const int eidx = XC ? (has_label ? lane : L) : col;
+
+  // ---- the two checkpoints: a block of a later round finds them published when it starts -- their loads then
+  // travel together with the gathers instead of after them
+  auto flags_up = [&]() {
+    return __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
+           __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+  };
+  float2 ca = make_float2(kNegBig, kNegBig);
+  float cbb = kNegBig, cbl = kNegBig;
+  double off_sum = 0.0;
+  unsigned long long dupmask = 0;
+  auto load_checkpoints = [&]() {
+    const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
+    const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
+    const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
+    const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
+    auto load_ck = [&](const float2* p) {
+      const unsigned long long bits = coherent_load64(p);
+      float2 v;
+      __builtin_memcpy(&v, &bits, 8);
+      return v;
+    };
+    // (mirrored lanes of the beta sweep: blank state 2i <-> reversed position L-i; label of position i <-> L-1-i)
+    if (lane < P) ca = load_ck(&cka[(int64_t)k * P + lane]);
+    if (lane <= L) cbb = load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - lane)]).x;
+    if (lane < L) cbl = load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)]).y;
+    if (CERT && lane == 0) off_sum = coherent_load_f64(&offa[k]) + coherent_load_f64(&offb[NB - 1 - k]);
+    dupmask = coherent_load64((const unsigned long long*)(a.ws + w.dup) + b);
+  };
+  const bool early = seen_a == a.token && seen_b == a.token;  // (uniform)
+  if (early) load_checkpoints();
+
+  // ---- emission factors of the block's frames: f = 2^(x log2e - r_j), r_j = round(largest target-label score)
+  float fl[kBlk], fb[kBlk];
+  float rsum;
+  {
+    if (!parked) fast_block_factors<LSM>(esrc, estride, eidx, t0, n, T, lse_blk, lane, xs, rr);
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      fb[j] = readlane_f(xs[j], L);
+      fl[j] = has_label ? xs[j] : 0.f;
+    }
+    rsum = wave_all_sum(lane < n ? rr : 0.f);
+  }
+
+  // ---- wait for alpha checkpoint k and beta checkpoint NB-1-k (see ctc_grad_body), unless they were there already
+  if (!early) {
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 20); ++spin) {  // (bounded: a lost signal must not hang the GPU)
+      ok = flags_up();
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (!ok) {
+      if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+      __builtin_trap();
+    }
+    load_checkpoints();
+  }
+#if WFL_DBG_FAST & 512
+  if (lane == 0) dbg[1] = wall_clock64();
+#endif
+  // labels that occur once in the target (and are not the blank) own their gradient column: plain ds_write instead
+  // of ds_add_f32 (see ctc_grad_body); the mask was computed once per utterance by its alpha chain workgroup
+  const bool dup = has_label && ((dupmask >> lane) & 1ull) != 0;
+  const bool uniq = has_label && !dup;
+  int slot = lane;  // COMPACT: where this lane's label accumulates
+  if (COMPACT) {
+    slot = __hip_atomic_load((const int32_t*)(a.ws + w.own) + (int64_t)b * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (has_label && slot == lane) cmap[y] = (unsigned char)lane;  // (first occurrences only: one writer per column)
+    if (lane == 0) cmap[a.blank] = 63;
+  }
+  if (lane == 0) {  // this wave was the only consumer of the two flags: leave them cleared
+    unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
+    coherent_store64(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull);
+    coherent_store64(rdy + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k), 0ull);
+  }
+
+  // ---- per-lane exponents (neighbour-gap clamp as in the chain), mantissas, coupling factors
+  const float ma = vmax(ca.x, ca.y), mbt = vmax(cbb, cbl);
+  int ea = ma > 0.5f * kNegBig ? (int)floorf(ma) + 1 : kEmptyE;
+  ea = wave_prefix_max_i(ea + kGap * lane) - kGap * lane;  // ea[i] >= ea[i-1] - kGap
+  int eb = mbt > 0.5f * kNegBig ? (int)floorf(mbt) + 1 : kEmptyE;
+  {  // eb[i] >= eb[i+1] - kGap: the same scan on the reversed lanes
+    int er = __shfl(eb, 63 - lane, 64);
+    er = wave_prefix_max_i(er + kGap * lane) - kGap * lane;
+    eb = __shfl(er, 63 - lane, 64);
+  }
+  float pb = __builtin_amdgcn_exp2f(ca.x - (float)ea), pl = __builtin_amdgcn_exp2f(ca.y - (float)ea);
+  float bb = __builtin_amdgcn_exp2f(cbb - (float)eb), bl = __builtin_amdgcn_exp2f(cbl - (float)eb);
+  const int ea_prev = wave_shr1_i(ea, ea);  // (taken unconditionally: inside the ?: the DPP would run with lane 0 masked off)
+  const float g = lane == 0 ? 0.f : ldexpf(1.f, max(ea_prev - ea, -200));
+  const float gs = skip ? g : 0.f;
+  const int eb_next = __builtin_amdgcn_update_dpp(eb, eb, 0x130, 0xf, 0xf, false);  // wave_shl:1 (lane 63: own)
+  const float h = lane == 63 ? 0.f : ldexpf(1.f, max(eb_next - eb, -200));
+  const float hs = skipn ? h : 0.f;
+
+  // ---- alpha forward through the block, kept in registers
+  float pa_b[kBlk], pa_l[kBlk];
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    if (j < n) {
+      const float c0 = fb[j] * g, c1 = fl[j] * gs;
+      float u0 = fb[j] * pb, u1 = fl[j] * pb;
+      fmac2_shr1(u0, u1, pl, c0, c1);
+      pl = fmaf(fl[j], pl, u1);
+      pb = u0;
+    }
+    pa_b[j] = pb, pa_l[j] = pl;
+  }
+  // ---- local Z at the block's last frame
+  float K = 0.f;
+  bool alive;
+  double zk;  // (lane 0) log2 Z as this block reproduces it
+  {
+    const float tb0 = bb + bl;
+    float tl0 = bl;
+    fmac2_shl1(tl0, bb, bl, h, hs);
+    const float v = pb * tb0 + pl * tl0;  // (pb, pl): alpha of frame n-1
+    const int sx = ea + eb;
+    const int own = v > 0.f ? sx + __builtin_amdgcn_frexp_expf(v) : kEmptyE;
+    const int E = __builtin_amdgcn_readlane(wave_prefix_max_i(own), 63);
+    const float term = v > 0.f ? ldexpf(v, max(sx - E, -200)) : 0.f;
+    const float Zm = wave_all_sum(term);
+    alive = Zm > 0.f && Zm < 3.0e38f && E > kEmptyE;
+    // (exponent clamped from above too: a lane whose alpha beta is ~0 at the last frame may sit far above E;
+    // if that distorts a posterior that matters, the per-frame sum check below rejects the block)
+    if (alive) K = cf * ldexpf(1.f / Zm, min(max(sx - E, -200), 100));
+    zk = alive ? off_sum + (double)E + (double)__builtin_amdgcn_logf(Zm) + (double)rsum : -1.0e300;
+  }
+  // ---- beta backwards (forward lane mapping), posteriors, gradient rows
+  float gbv[kBlk];
+  float wsum = 0.f;  // sum_j w_j (gb + gl)[j], w_j = 1 + j / 32: the frames' posterior mass, weighted so that errors cannot cancel
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) gbv[j] = 0.f;
+#pragma unroll
+  for (int j = kBlk - 1; j >= 0; --j) {
+    if (j < n) {
+      // blank i -> blank i, label i.  label i -> label i, blank i+1 (and label i+1 if allowed)
+      const float tb = bb + bl;
+      float tl = bl;
+      fmac2_shl1(tl, bb, bl, h, hs);
+      const float gb = pa_b[j] * K * tb;
+      const float gl = pa_l[j] * K * tl;
+      gbv[j] = gb;
+      wsum = fmaf(gb + gl, 1.f + (float)j * (1.f / 32.f), wsum);
+      if (COMPACT) {
+        if (uniq) rows[j * kCS + lane] = gl;
+        if (dup && gl != 0.f) atomicAdd(&rows[j * kCS + slot], gl);
+      } else {
+        if (uniq) rows[j * C + y] = (LSM ? rows[j * C + y] : 0.f) + gl;  // sole writer of this column
+        if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl);
+      }
+      bb = tb * fb[j];
+      bl = tl * fl[j];
+    }
+  }
+  const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
+  if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * kCS + 63 : lane * C + a.blank], gtot);
+  if (CERT) {
+    // certificate, part two: the posteriors of every frame of the block must sum to one (the exponents are fixed
+    // over the block; an occupancy that moves by more than the float range within 16 frames shows here; the
+    // frames are summed with distinct weights, one register instead of sixteen), part one: the block's log2 Z
+    // for the comparison with the chain's
+    const float stot = wave_all_sum(wsum);
+    const float want = cf * ((float)n + (float)(n * (n - 1)) * (1.f / 64.f));  // cf * sum_{j<n} w_j
+    const bool bad_block = alive && !(fabsf(stot - want) <= 2e-4f * fabsf(cf));
+    if (lane == 0) {
+      long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+      const long long zq = bad_block ? kZDead : z_fixed(zk);
+      __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (LSM && !alive && !COMPACT)  // no accepting path: zero gradient, softmax term included
+    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+  // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
+  float* dst = dx + ((int64_t)b * T + t0) * C;
+  if (COMPACT)
+    compact_expand(rows, cmap, dst, a.x + ((int64_t)b * T + t0) * C, lse_blk, n, C, cf, alive, LSM && alive, lane);
+  const int total = COMPACT ? 0 : n * C;
+  if ((((uintptr_t)dst) & 15) == 0) {
+    const int n4 = total >> 2;
+    for (int i = lane; i < n4; i += 64) ((float4*)dst)[i] = ((const float4*)rows)[i];
+    for (int i = (n4 << 2) + lane; i < total; i += 64) dst[i] = rows[i];
+  } else {
+    for (int i = lane; i < total; i += 64) dst[i] = rows[i];
+  }
+#if WFL_DBG_FAST & 512
+  if (lane == 0) dbg[2] = wall_clock64();
+#endif
+}
+
+template <bool COMPACT>
+__global__ void __launch_bounds__(256)
+    ctc_grad_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, k) pairs
+  const bool valid = item < (int64_t)a.B * NB;
+  ctc_grad_body<false, false, COMPACT>(a, valid, valid ? (int)(item / NB) : 0, valid ? (int)(item % NB) : 0, coef, gout, dx, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined forward + backward: ONE launch.  Workgroups 0 .. 2B-1 are the alpha / beta chains (they
+// are dispatched first and there is one per CU at B = 128); the remaining workgroups are gradient
+// waves that wait for "their" two checkpoints and then recompute / emit their 16 frames while the
+// chains are still running.  Block k needs alpha checkpoint k (ready after k blocks of the alpha
+// sweep) and beta checkpoint NB-1-k (ready after NB-k blocks of the beta sweep): the middle of the
+// utterance is ready after half the chain time, the ends when the chains finish -- so gradient
+// items are numbered from the middle outwards and almost all of the gradient kernel's work
+// disappears behind the latency-bound chains, which leave most of every CU idle.
+// ------------------------------------------------------------------------------------------------
+template <bool LSM, bool COMPACT>
+__global__ void __launch_bounds__(256)
+    ctc_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
+                         float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nchain = 2 * a.B;
+  if ((int)blockIdx.x < nchain) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (a gradient wave gives up only after ~1 s of polling)
+      int32_t* perr = (int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr);
+      perr[0] = 0, perr[1] = 0;
+    }
+    if (threadIdx.x < 64)  // the dependent chain (and its feeders) go first on their SIMDs
+      __builtin_amdgcn_s_setprio(3);
+    else
+      __builtin_amdgcn_s_setprio(2);
+    ctc_log_chain_body<true, LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, 0, *reinterpret_cast<ChainLdsT*>(smem));
+    return;
+  }
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)(blockIdx.x - nchain) * 4 + (threadIdx.x >> 6);
+  const bool valid = item < (int64_t)a.B * NB;
+  const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;  // r: rank in readiness order
+  const int mid = (NB - 1) / 2;
+  const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+  ctc_grad_body<true, LSM, COMPACT>(a, valid, b, k, coef, gout, dx, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compact copy of the emissions the sweeps gather (wide rows, inputs beyond the Infinity Cache): one pass over x
+// leaves, per frame, the <= 64 scores the alpha chains, the beta chains and the gradient blocks each gather --
+// three passes over x (a 45-label gather touches three quarters of the lines of a 2-KB row) become one, the other
+// two read 256 contiguous bytes per frame.  One wave per row, kXcRows rows per iteration with their loads in flight.
+// ------------------------------------------------------------------------------------------------
+constexpr int kXcRows = 8;
+__global__ void __launch_bounds__(256)
+    ctc_compact_x_kernel(const float* __restrict__ x, const int32_t* __restrict__ targets,
+                         const int64_t* __restrict__ offsets, int T, int C, int blank, float* __restrict__ xc) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int64_t o0 = offsets[b];
+  const int L = (int)(offsets[b + 1] - o0);
+  const int col = lane < L ? targets[o0 + lane] : blank;
+  const float* xrow = x + (int64_t)b * T * C;
+  float* dst = xc + (int64_t)b * T * kXcStride;
+  const int nw = gridDim.x * 4;
+  for (int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kXcRows; t0 < T; t0 += nw * kXcRows) {
+    float v[kXcRows];
+#pragma unroll
+    for (int u = 0; u < kXcRows; ++u) v[u] = xrow[(int64_t)min(t0 + u, T - 1) * C + col];
+#pragma unroll
+    for (int u = 0; u < kXcRows; ++u)
+      if (t0 + u < T) dst[(int64_t)(t0 + u) * kXcStride + lane] = v[u];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST pipelined step: the same single launch with the lane-exponent chains (8 waves per workgroup:
+// gradient workgroups carry 8 blocks), followed by ctc_repair_kernel.  The gradient waves reproduce
+// log2 Z per block (zloc); the repair launch evaluates that certificate and re-runs rejected
+// utterances -- chains and gradient -- in the log domain.  On data the fast chains can represent the
+// repair launch exits at once.
+// ------------------------------------------------------------------------------------------------
+template <bool LSM, bool COMPACT, bool XC = false>
+__global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_eu(6, 6)))  // <= 80 VGPRs: three workgroups per CU
+    ctc_fast_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
+                              float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nchain = 2 * a.B;
+  if ((int)blockIdx.x < nchain) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      int32_t* perr = (int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr);
+      perr[0] = 0;  // a gradient wave gave up waiting
+      perr[1] = 0;  // utterances the repair launch recomputed
+    }
+    if (threadIdx.x >= 64) __builtin_amdgcn_s_setprio(2);  // (the chain wave raises itself to 3)
+    // XCD placement (speed only): workgroup i is observed to run on XCD i % 8, and every XCD has its own L2.  The two
+    // chains and all gradient items of an utterance are kept on ONE XCD (utterance b on XCD b % 8), so that x[b], the
+    // checkpoints and the flags of b are fetched into one L2 instead of up to eight.
+    int b = (int)blockIdx.x >> 1, dir = (int)blockIdx.x & 1;
+    if (a.place) {
+      const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+      b = (slot >> 1) * 8 + xcd, dir = slot & 1;
+    }
+    ctc_fast_chain_body<true, LSM, XC>(a, b, dir, *reinterpret_cast<FastLdsT*>(smem));
+    return;
+  }
+  // Gradient waves are persistent: a wave takes item after item (stride: all gradient waves of the launch), in
+  // readiness order -- the middle blocks of every utterance first, their checkpoints exist at half time.  With one
+  // item per wave and more items than resident waves, the second half of the items waited for workgroup slots and
+  // then paid their start-up (dispatch, three dependent loads) after the chains had finished.
+  const int NB = ctc_blocks(a.T);
+  const int mid = (NB - 1) / 2;
+  const int gwgs = (int)(gridDim.x - nchain), g = (int)(blockIdx.x - nchain);
+  // (same placement as the chains where the counts allow it: utterance b's items on XCD b % 8)
+  const bool placed = a.place && (gwgs & 7) == 0;
+  const int xcd = placed ? g & 7 : 0, mult = placed ? 8 : 1, nb = placed ? a.B >> 3 : a.B;  // utterances of this XCD
+  const int stride = (placed ? gwgs >> 3 : gwgs) * kFWaves;
+  const int first = __builtin_amdgcn_readfirstlane((placed ? g >> 3 : g) * kFWaves + (int)(threadIdx.x >> 6));
+  auto item = [&](int li, int& b, int& k) {
+    const int r = li / nb;  // rank in readiness order
+    b = (li % nb) * mult + xcd;
+    k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+  };
+  float* park = nullptr;
+  if (a.park && first + stride < nb * NB) {
+    park = a.park + (int64_t)__builtin_amdgcn_readfirstlane(g * kFWaves + (int)(threadIdx.x >> 6)) * kParkStride;
+    int b2, k2;
+    item(first + stride, b2, k2);
+    ctc_fast_park_factors<LSM, XC>(a, b2, k2, park);
+  }
+  FastUtt utt;
+  for (int li = first; li < nb * NB; li += stride) {
+    int b, k;
+    item(li, b, k);
+    ctc_fast_grad_body<LSM, true, COMPACT, XC>(a, true, b, k, coef, gout, dx, smem, utt, li == first + stride ? park : nullptr);
+  }
+}
+
+#ifdef WFL_DBG_GRADONLY  // (register counts of the two halves alone: hipcc -S -DWFL_DBG_GRADONLY)
+__global__ void __launch_bounds__(kFWaves * 64) dbg_fast_chain_only(CtcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ctc_fast_chain_body<true, false>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<FastLdsT*>(smem));
+}
+__global__ void __launch_bounds__(kFWaves * 64) dbg_fast_grad_only(CtcArgs a, const float* coef, const float* gout, float* dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  FastUtt utt;
+  ctc_fast_grad_body<false, true, false>(a, true, (int)blockIdx.x, (int)blockIdx.y, coef, gout, dx, smem, utt);
+}
+#endif
+
+template <bool LSM, bool COMPACT>
+__global__ void __launch_bounds__(256)
+    ctc_repair_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const CtcWs w = ctc_ws_layout(a.B, a.T, a.P);
+  const int nchain = 2 * a.B;
+  if ((int)blockIdx.x < nchain) {
+    const int b = (int)blockIdx.x >> 1, dir = (int)blockIdx.x & 1;
+    if (utterance_rejected_wave(a, w, b, lane)) {  // (uniform over the workgroup: every wave evaluates it)
+      if (dir == 0 && threadIdx.x == 0) atomicAdd((int32_t*)(a.ws + w.perr) + 1, 1);
+      if (threadIdx.x < 64)
+        __builtin_amdgcn_s_setprio(3);
+      else
+        __builtin_amdgcn_s_setprio(2);
+      ctc_log_chain_body<true, LSM, true>(a, b, dir, 0, *reinterpret_cast<ChainLdsT*>(smem));
+    }
+    // the loss of the fast launch stands unless an utterance was repaired
+    if (blockIdx.x == 0 && threadIdx.x < 64 && a.loss_out) reduce_loss_when_done(a, w, lane, true);
+    return;
+  }
+  // gradient workgroups: a small persistent grid (the launch is empty on data the fast chains can represent,
+  // and what it costs then is its dispatch).  Nothing to repair anywhere: leave after one look at the certificates.
+  bool any = false;
+  for (int u = threadIdx.x; u < a.B; u += blockDim.x) any = any || utterance_rejected(a, w, u);
+  if (!__syncthreads_or(any)) return;
+  const int NB = ctc_blocks(a.T);
+  const int64_t stride = (int64_t)(gridDim.x - nchain) * 4;
+  const int mid = (NB - 1) / 2;
+#pragma unroll 1
+  for (int64_t item = (int64_t)(blockIdx.x - nchain) * 4 + (threadIdx.x >> 6); item < (int64_t)a.B * NB; item += stride) {
+    const int r = (int)(item / a.B), b = (int)(item % a.B);  // r: rank in readiness order
+    const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+    ctc_grad_body<true, LSM, COMPACT>(a, utterance_rejected_wave(a, w, b, lane), b, k, coef, gout, dx, smem);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Long targets (64 <= L + 1 <= 256): PPL = 2, 3 or 4 target positions per lane, lane i owning the
+// contiguous positions PPL*i .. PPL*i + PPL-1.  Within a frame all positions read the PREVIOUS
+// frame's values, so a lane's PPL updates are independent (instruction-level parallelism that
+// the single-position chain does not have) and still only ONE value crosses lanes per frame (the
+// label state of the lane's first position needs the last position of lane i-1: a DPP shift).
+// Same checkpoint format (indexed by position), same pipelining, same numerics as above; the
+// emission ring holds the label emissions per position and the frame's blank emission once
+// (states that do not exist stay at the sentinel by themselves: everything that feeds them is one).
+// ------------------------------------------------------------------------------------------------
+template <int PPL>
+struct LongLds {
+  float ring_xl[kRing][kBlk][64][PPL];
+  float ring_xb[kRing][kBlk];
+  float2 ckbuf[2][64 * PPL];
+  double offbuf[2];
+};
+
+template <int PPL>
+struct LongLane {  // what a lane knows about its PPL positions (alpha: forward target, beta: reversed)
+  int col[PPL];
+  bool has_label[PPL], skip[PPL];
+};
+
+template <int PPL>
+__device__ __forceinline__ LongLane<PPL> long_lane(const CtcArgs& a, int64_t o0, int L, int lane, int dir) {
+  LongLane<PPL> c;
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    const int pos = PPL * lane + p;
+    int y = -1, yprev = -1;
+    if (pos < L) y = a.targets[o0 + (dir == 0 ? pos : L - 1 - pos)];
+    if (pos >= 1 && pos - 1 < L) yprev = a.targets[o0 + (dir == 0 ? pos - 1 : L - pos)];
+    c.has_label[p] = pos < L;
+    c.skip[p] = c.has_label[p] && pos >= 1 && y != yprev;
+    c.col[p] = c.has_label[p] ? y : a.blank;
+  }
+  return c;
+}
+
+// value held for position `pos` (lane pos / PPL, slot pos % PPL) broadcast to the wave
+template <int PPL>
+__device__ __forceinline__ float long_read(const float (&v)[PPL], int pos) {
+  const int slot = pos % PPL;
+  float s = v[0];
+#pragma unroll
+  for (int p = 1; p < PPL; ++p) s = slot == p ? v[p] : s;  // wave-uniform select
+  return readlane_f(s, pos / PPL);
+}
+
+template <int PPL, bool SIGNAL, bool LSM = false>
+__device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int dir, LongLds<PPL>& S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  const LongLane<PPL> c = long_lane<PPL>(a, o0, L, lane, dir);
+  const float* xrow = a.x + (int64_t)b * T * C;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  const int NB = ctc_blocks(T);
+  const int h = wave - 1;
+  constexpr int kFlusher = SIGNAL ? 3 : 1;
+  float raw[kBlk][PPL];
+  float lse_raw = 0.f;
+  auto issue = [&](int kk) {
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int t0 = k * kBlk, n = min(kBlk, T - t0);
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const int t = dir == 0 ? t0 + j : t0 + n - 1 - j;
+      const float* row = xrow + (int64_t)min(max(t, 0), T - 1) * C;
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) raw[j][p] = row[c.col[p]];
+    }
+    if (LSM) {
+      const int t = dir == 0 ? t0 + (lane & 15) : t0 + n - 1 - (lane & 15);
+      lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
+    }
+  };
+  auto stage = [&](int kk) {
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      float xs[PPL];
+      const float lj = LSM ? readlane_f(lse_raw, j) : 0.f;
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) xs[p] = to_score(raw[j][p] - lj);
+      const float xblank = long_read<PPL>(xs, L);  // position L has no label: its column is the blank
+      if (lane == 0) S.ring_xb[kk % kRing][j] = xblank;
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) S.ring_xl[kk % kRing][j][lane][p] = c.has_label[p] ? xs[p] : kNegBig;
+    }
+  };
+  if (wave == 1 || wave == 2) {
+    if (h < NB) {
+      issue(h);
+      stage(h);
+    }
+    if (h + 2 < NB) issue(h + 2);
+  }
+  __syncthreads();
+
+  float ab[PPL], al[PPL];
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) ab[p] = kNegBig, al[p] = kNegBig;
+  if (lane == 0) ab[0] = 0.f;  // virtual slot "before the first frame"
+  double off = 0.0;
+  float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
+  double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+  unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
+  auto flush_checkpoint = [&](int kk) {
+    for (int i = lane; i < P; i += 64) {
+      const float2 v = S.ckbuf[kk & 1][i];
+      if (!SIGNAL) {
+        ck[(int64_t)kk * P + i] = v;
+      } else {
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &v, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&ck[(int64_t)kk * P + i]), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (lane == 0) {
+      const double o = S.offbuf[kk & 1];
+      if (!SIGNAL) {
+        offs[kk] = o;
+      } else {
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &o, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&offs[kk]), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (SIGNAL) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the stores are acknowledged
+      if (lane == 0) __hip_atomic_store(&ready[kk], a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  float e[kBlk][PPL], en[kBlk][PPL], eb[kBlk], ebn[kBlk];
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      eb[j] = S.ring_xb[0][j];
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) e[j][p] = S.ring_xl[0][j][lane][p];
+    }
+  }
+  for (int kk = 0; kk < NB; ++kk) {
+    if (wave == 0) {
+      const int k = dir == 0 ? kk : NB - 1 - kk;
+      const int n = min(kBlk, T - k * kBlk);
+      if (kk + 1 < NB) {
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+          ebn[j] = S.ring_xb[(kk + 1) % kRing][j];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) en[j][p] = S.ring_xl[(kk + 1) % kRing][j][lane][p];
+        }
+      }
+      if (kk > 0) {
+        float mx = kNegBig;
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) mx = vmax(mx, vmax(ab[p], al[p]));
+        const float m = wave_all_max(mx);
+        if (m > 0.5f * kNegBig) {
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            ab[p] = fmaxf(ab[p] - m, 4.f * kNegBig);
+            al[p] = fmaxf(al[p] - m, 4.f * kNegBig);
+          }
+          off += (double)m;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) S.ckbuf[kk & 1][PPL * lane + p] = make_float2(ab[p], al[p]);
+      if (lane == 0) S.offbuf[kk & 1] = off;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        if (j < n) {  // (n is uniform; only the last block is short)
+          float pal[PPL], nb[PPL], nl[PPL];
+          pal[0] = wave_shr1(al[PPL - 1], kNegBig);
+#pragma unroll
+          for (int p = 1; p < PPL; ++p) pal[p] = al[p - 1];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            nb[p] = lse2_b2(ab[p], pal[p]);
+            nl[p] = lse2_b2(al[p], c.skip[p] ? nb[p] : ab[p]);
+          }
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) ab[p] = nb[p] + eb[j], al[p] = nl[p] + e[j][p];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        eb[j] = ebn[j];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) e[j][p] = en[j][p];
+      }
+    } else {
+      if (kk > 0 && wave == kFlusher) flush_checkpoint(kk - 1);
+      if ((kk & 1) == h && wave <= 2) {
+        if (kk + 2 < NB) stage(kk + 2);
+        if (kk + 4 < NB) issue(kk + 4);
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == kFlusher) flush_checkpoint(NB - 1);
+  if (dir == 0 && wave == 0) {
+    const float a_last = long_read<PPL>(ab, L);
+    const float l_last = L > 0 ? long_read<PPL>(al, L - 1) : kNegBig;
+    if (lane == 0) {
+      const float zr = lse2_b2(a_last, l_last);
+      const bool alive = zr > 0.5f * kNegBig;
+      const double z2 = alive ? (double)zr + off : -1.0e300;
+      ((double*)(a.ws + w.z2))[b] = z2;
+      a.nll[b] = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
+    }
+  }
+}
+
+template <int PPL, bool PIPE, bool LSM = false>
+__device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid, int b, int k,
+                                                   const float* __restrict__ coef, const float* __restrict__ gout,
+                                                   float* __restrict__ dx, char* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = a.T, C = a.C, P = a.P;
+  const int NB = ctc_blocks(T);
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  float* rows = (float*)smem + (size_t)wave * (kBlk + 1) * C;
+  int* cnt = (int*)(rows + (size_t)kBlk * C);
+  const int t0 = k * kBlk, n = min(kBlk, T - t0);
+  bool live = valid && (PIPE || a.nll[b] < __builtin_inff());
+  constexpr bool lsm = PIPE && LSM;
+  const float cf_row = (coef ? coef[valid ? b : 0] : 1.f) * (gout ? gout[0] : 1.f);
+  float lse_blk = 0.f;
+  if (valid) {
+    for (int i = lane; i < (kBlk + 1) * C; i += 64) rows[i] = 0.f;
+    if (lsm) {
+      lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
+      lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf_row, lane);
+    }
+  }
+  if (PIPE && valid) {
+    const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
+    const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+      ok = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
+           __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(64);
+    }
+    if (!ok) {
+      if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+      __builtin_trap();
+    }
+  }
+  if (!live) {
+    if (valid) {  // zero rows for a dead utterance
+      float* dst = dx + ((int64_t)b * T + t0) * C;
+      for (int i = lane; i < n * C; i += 64) dst[i] = 0.f;
+    }
+    return;
+  }
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  int y[PPL];
+  bool has_label[PPL], skip[PPL], skipn[PPL], uniq[PPL], dup[PPL];
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    const int pos = PPL * lane + p;
+    has_label[p] = pos < L;
+    y[p] = has_label[p] ? a.targets[o0 + pos] : a.blank;
+    const int yprev = (pos >= 1 && pos - 1 < L) ? a.targets[o0 + pos - 1] : -1;
+    const int ynext = pos + 1 < L ? a.targets[o0 + pos + 1] : -1;
+    skip[p] = has_label[p] && pos >= 1 && y[p] != yprev;
+    skipn[p] = pos + 1 < L && ynext != y[p];
+    if (has_label[p]) atomicAdd(&cnt[y[p]], 1);
+  }
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    dup[p] = has_label[p] && (cnt[y[p]] > 1 || y[p] == a.blank);
+    uniq[p] = has_label[p] && !dup[p];
+  }
+  const float* xrow = a.x + (int64_t)b * T * C;
+  float xl[kBlk][PPL], xb[kBlk];
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    const float* row = xrow + (int64_t)min(t0 + j, T - 1) * C;
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) xl[j][p] = row[y[p]];
+  }
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    float xs[PPL];
+    const float lj = lsm ? readlane_f(lse_blk, j) : 0.f;
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) xs[p] = to_score(xl[j][p] - lj);
+    xb[j] = long_read<PPL>(xs, L);
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) xl[j][p] = has_label[p] ? xs[p] : kNegBig;
+  }
+  const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
+  const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
+  const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
+  const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
+  auto load_ck = [&](const float2* p) {
+    if (!PIPE) return *p;
+    const unsigned long long bits =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float2 v;
+    __builtin_memcpy(&v, &bits, 8);
+    return v;
+  };
+  float ab[PPL], al[PPL], bb[PPL], bl[PPL];
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    const int pos = PPL * lane + p;
+    const float2 ca = pos < P ? load_ck(&cka[(int64_t)k * P + pos]) : make_float2(kNegBig, kNegBig);
+    ab[p] = ca.x, al[p] = ca.y;
+    bb[p] = pos <= L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - pos)]).x : kNegBig;
+    bl[p] = pos < L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - pos)]).y : kNegBig;
+  }
+  if (PIPE && lane == 0) {
+    unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
+    __hip_atomic_store(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rdy + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  float U = PIPE ? 0.f : (float)(offa[k] + offb[NB - 1 - k] - ((const double*)(a.ws + w.z2))[b]);
+  const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+  float pa_b[kBlk][PPL], pa_l[kBlk][PPL];
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {  // alpha forward through the block, kept in registers
+    float pal[PPL], nb[PPL], nl[PPL];
+    pal[0] = wave_shr1(al[PPL - 1], kNegBig);
+#pragma unroll
+    for (int p = 1; p < PPL; ++p) pal[p] = al[p - 1];
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      nb[p] = lse2_b2(ab[p], pal[p]);
+      nl[p] = lse2_b2(al[p], skip[p] ? nb[p] : ab[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      ab[p] = nb[p] + xb[j], al[p] = nl[p] + xl[j][p];
+      pa_b[j][p] = ab[p], pa_l[j][p] = al[p];
+    }
+  }
+  // transition-propagated beta of one frame: tb (blank states), tl (label states)
+  auto propagate = [&](float (&tb)[PPL], float (&tl)[PPL]) {
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) tb[p] = lse2_b2(bb[p], bl[p]);
+    const float tb_next_lane = wave_shl1(tb[0], kNegBig), bb_next_lane = wave_shl1(bb[0], kNegBig);
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      const float tbn = p + 1 < PPL ? tb[p + 1 < PPL ? p + 1 : 0] : tb_next_lane;
+      const float bbn = p + 1 < PPL ? bb[p + 1 < PPL ? p + 1 : 0] : bb_next_lane;
+      tl[p] = lse2_b2(bl[p], skipn[p] ? tbn : bbn);
+    }
+  };
+  if (PIPE) {
+    float tb[PPL], tl[PPL];
+    propagate(tb, tl);
+    float u = kNegBig;
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j)
+      if (j == n - 1) {
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) u = vmax(u, vmax(pa_b[j][p] + tb[p], pa_l[j][p] + tl[p]));
+      }
+    const float m = wave_all_max(u);
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j)
+      if (j == n - 1) {
+#pragma unroll
+        for (int p = 0; p < PPL; ++p)
+          part += __builtin_amdgcn_exp2f(pa_b[j][p] + tb[p] - m) + __builtin_amdgcn_exp2f(pa_l[j][p] + tl[p] - m);
+      }
+    const float ssum = wave_all_sum(part);
+    U = (m > 0.5f * kNegBig && ssum > 0.f) ? -(m + __builtin_amdgcn_logf(ssum)) : kNegBig;
+  }
+#pragma unroll
+  for (int j = kBlk - 1; j >= 0; --j) {
+    if (j < n) {
+      float tb[PPL], tl[PPL];
+      propagate(tb, tl);
+      float gbs = 0.f;
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) {
+        gbs += __builtin_amdgcn_exp2f(pa_b[j][p] + tb[p] + U);
+        const float gl = __builtin_amdgcn_exp2f(pa_l[j][p] + tl[p] + U);
+        if (uniq[p]) rows[j * C + y[p]] = (lsm ? rows[j * C + y[p]] : 0.f) + gl * cf;
+        if (dup[p] && gl != 0.f) atomicAdd(&rows[j * C + y[p]], gl * cf);
+      }
+      const float gsum = wave_reduce_sum_lane63(gbs);
+      if (lane == 63 && gsum != 0.f) atomicAdd(&rows[j * C + a.blank], gsum * cf);
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) bb[p] = tb[p] + xb[j], bl[p] = tl[p] + xl[j][p];
+    }
+  }
+  if (lsm && !(U > 0.5f * kNegBig))  // no accepting path: zero gradient, softmax term included
+    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+  {
+    float* dst = dx + ((int64_t)b * T + t0) * C;
+    const int total = n * C;
+    if ((((uintptr_t)dst) & 15) == 0) {
+      const int n4 = total >> 2;
+      for (int i = lane; i < n4; i += 64) ((float4*)dst)[i] = ((const float4*)rows)[i];
+      for (int i = (n4 << 2) + lane; i < total; i += 64) dst[i] = rows[i];
+    } else {
+      for (int i = lane; i < total; i += 64) dst[i] = rows[i];
+    }
+  }
+}
+
+template <int PPL, bool LSM>
+__global__ void __launch_bounds__(256)
+    ctc_long_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
+                              float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nchain = 2 * a.B;
+  if ((int)blockIdx.x < nchain) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      int32_t* perr = (int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr);
+      perr[0] = 0, perr[1] = 0;
+    }
+    if (threadIdx.x < 64)
+      __builtin_amdgcn_s_setprio(3);
+    else
+      __builtin_amdgcn_s_setprio(2);
+    ctc_long_chain_body<PPL, true, LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<LongLds<PPL>*>(smem));
+    return;
+  }
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)(blockIdx.x - nchain) * 4 + (threadIdx.x >> 6);
+  const bool valid = item < (int64_t)a.B * NB;
+  const int r = valid ? (int)(item / a.B) : 0, b = valid ? (int)(item % a.B) : 0;
+  const int mid = (NB - 1) / 2;
+  const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
+  ctc_long_grad_body<PPL, true, LSM>(a, valid, b, k, coef, gout, dx, smem);
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(192) ctc_long_chain_kernel(CtcArgs a) {
+  __shared__ LongLds<PPL> S;
+  ctc_long_chain_body<PPL, false>(a, blockIdx.x, blockIdx.y, S);
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(256)
+    ctc_long_grad_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NB = ctc_blocks(a.T);
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool valid = item < (int64_t)a.B * NB;
+  ctc_long_grad_body<PPL, false>(a, valid, valid ? (int)(item / NB) : 0, valid ? (int)(item % NB) : 0, coef, gout, dx,
+                                 smem);
+}
+
+}  // namespace wfl
+
+using namespace wfl;
+
+extern "C" {
+
+static int ctc_check(int B, int T, int C, int max_len, int blank, const char* who) {
+  if (B <= 0 || T <= 0 || C <= 0 || blank < 0 || blank >= C || max_len < 0) {
+    set_error("%s: bad arguments (B=%d T=%d C=%d blank=%d max_len=%d)", who, B, T, C, blank, max_len);
+    return WFL_ERR_INVALID;
+  }
+  if (max_len + 1 > 256) {
+    set_error("%s: target length %d exceeds four positions per lane (use the lattice engine)", who, max_len);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  // gradient tiles in LDS: dense [17][C] per wave for long targets, compact [16][64] + C bytes otherwise
+  const bool wide = max_len + 1 > 64 ? (size_t)4 * (kBlk + 1) * C * 4 > (size_t)kLdsBytes
+                                     : (size_t)8 * compact_wave_bytes(C) > (size_t)kLdsBytes;
+  if (wide) {
+    set_error("%s: C=%d too large for the LDS tiles of the gradient kernel (use the lattice engine)", who, C);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  return WFL_OK;
+}
+
+// The compact emission copy pays when x does not stay in the Infinity Cache between the three sweeps (256 MiB) and
+// its rows are wide enough for a 45-label gather to waste most of what it touches.  WFL_CTC_COMPACT_X=0|1 overrides.
+static bool ctc_use_xc(int B, int T, int C, int max_len) {
+  static const int force = [] {
+    const char* e = getenv("WFL_CTC_COMPACT_X");
+    return e ? atoi(e) : -1;
+  }();
+  if (max_len + 1 > 64) return false;  // (the lane-exponent step: one target position per lane)
+  if (force >= 0) return force != 0;
+  return (int64_t)B * T * C * 4 >= (192ll << 20) && C >= 192;
+}
+
+// Gradient workgroups of the fast pipelined launch: one item per wave, or -- small batches, where the launch is
+// latency-bound and all chains plus a full complement of gradient workgroups are resident at once (three workgroups
+// per CU) -- as many workgroups as there are free slots, their waves looping over the items (WFL_CTC_GRAD_WGS: 0 = one
+// item per wave, n = that many workgroups).
+static int64_t ctc_fast_grad_wgs(int B, int T) {
+  static const int n_cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static const int grad_wgs_env = [] {
+    const char* e = getenv("WFL_CTC_GRAD_WGS");
+    return e ? atoi(e) : -1;
+  }();
+  const int64_t all_wgs = ((int64_t)B * ctc_blocks(T) + kFWaves - 1) / kFWaves;
+  if (grad_wgs_env > 0) return std::min<int64_t>(all_wgs, grad_wgs_env);
+  if (grad_wgs_env < 0 && 2 * (int64_t)B <= 3 * n_cus / 2) return std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
+  return all_wgs;
+}
+// parking area of the persistent gradient waves (CtcArgs::park), behind the compact emission copy.  OFF unless
+// WFL_CTC_PARK=1 -- measured at cfg2: the factors of a wave's second item, computed while it waits for its first,
+// shorten that item's start-up (3.1 instead of 5.3 us from start to checkpoints on the launch's own timeline), but the
+// 35 MB they add to the launch's traffic (302 instead of 267 MB) cost more in back-to-back steps: 61.5 against 60.4 us.
+static int64_t ctc_park_floats(int B, int T) {
+  static const bool off = [] {
+    const char* e = getenv("WFL_CTC_PARK");
+    return !(e && atoi(e) == 1);
+  }();
+  const int64_t wgs = ctc_fast_grad_wgs(B, T), all_wgs = ((int64_t)B * ctc_blocks(T) + kFWaves - 1) / kFWaves;
+  return (off || wgs >= all_wgs) ? 0 : wgs * kFWaves * kParkStride;
+}
+
+int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems) {
+  if (!ws_elems || B <= 0 || T <= 0 || max_len < 0) {
+    set_error("ctc_workspace: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  *ws_elems = ctc_ws_layout(B, T, max_len + 1).total + 4 + (ctc_use_xc(B, T, C, max_len) ? (int64_t)B * T * kXcStride : 0) +
+              ctc_park_floats(B, T);
+  return WFL_OK;
+}
+
+int wfl_ctc_workspace_field(int B, int T, int max_len, int field, int64_t* offset_elems, int64_t* length_elems) {
+  if (!offset_elems || !length_elems || B <= 0 || T <= 0 || max_len < 0) {
+    set_error("ctc_workspace_field: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  const CtcWs w = ctc_ws_layout(B, T, max_len + 1);
+  switch (field) {
+    case WFL_CTC_WS_REJECTED: *offset_elems = w.flag, *length_elems = B; break;
+    case WFL_CTC_WS_STATUS: *offset_elems = w.perr, *length_elems = 2; break;
+    case WFL_CTC_WS_LOG2Z: *offset_elems = w.z2, *length_elems = 2 * (int64_t)B; break;
+    case WFL_CTC_WS_ZRANGE: *offset_elems = w.zloc, *length_elems = 4 * (int64_t)B; break;
+    default: set_error("ctc_workspace_field: unknown field %d", field); return WFL_ERR_INVALID;
+  }
+  return WFL_OK;
+}
+
+int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets, int max_len,
+                    int blank, int flags, float* ws, float* nll, void* stream) {
+  if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_forward")) return rc;
+  if (!x || !targets || !offsets || !ws || !nll) {
+    set_error("ctc_forward: null buffer");
+    return WFL_ERR_INVALID;
+  }
+  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll};
+  const int ppl = (max_len + 1 + 63) / 64;  // target positions per lane
+  if (ppl > 1) {  // long targets: multi-position lanes, log-domain chain only
+    const dim3 grid((unsigned)B, 2u);
+    if (ppl == 2)
+      hipLaunchKernelGGL(ctc_long_chain_kernel<2>, grid, dim3(192), 0, (hipStream_t)stream, a);
+    else if (ppl == 3)
+      hipLaunchKernelGGL(ctc_long_chain_kernel<3>, grid, dim3(192), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(ctc_long_chain_kernel<4>, grid, dim3(192), 0, (hipStream_t)stream, a);
+  } else if (!(flags & WFL_CTC_FAST_CHAIN)) {
+    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 0);
+  } else {
+    hipLaunchKernelGGL(ctc_fast_chain_kernel, dim3((unsigned)B, 2u), dim3(kFWaves * 64), 0, (hipStream_t)stream, a);
+    WFL_LAUNCH_CHECK();
+    if (WFL_DBG_FAST & 16) return WFL_OK;
+    const int64_t items = (int64_t)B * std::max(ctc_blocks(T) - 1, 1);
+    hipLaunchKernelGGL(ctc_certify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    WFL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 1);
+  }
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
+                             int max_len, int blank, float* ws, float* nll, const float* coef, const float* gout,
+                             float* dx, const float* loss_scale, float* loss_out, const float* row_lse, void* stream) {
+  if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_forward_backward")) return rc;
+  if (!x || !targets || !offsets || !ws || !nll || !dx) {
+    set_error("ctc_forward_backward: null buffer");
+    return WFL_ERR_INVALID;
+  }
+  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll, 0ull, loss_scale, loss_out, row_lse};
+  // launch token: process-wide counter mixed with the workspace address -- uninitialised memory or flags
+  // left by a launch that used the block earlier cannot equal it; consumers clear the flags they used,
+  // so replaying the SAME launch from a hipGraph (same token, same workspace) starts from cleared flags
+  static std::atomic<unsigned long long> counter{0x9e3779b97f4a7c15ull};
+  a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
+  if (a.token == 0) a.token = 1;
+  const int64_t items = (int64_t)B * ctc_blocks(T);
+  const int ppl = (max_len + 1 + 63) / 64;  // target positions per lane
+  const dim3 grid((unsigned)(2 * B + (items + 3) / 4));
+  // log-domain kernels (4-wave workgroups): dense row tiles while five workgroups share a CU with them, compact beyond
+  const bool lcompact = ppl == 1 && C > 120;
+  const size_t rows_lds = lcompact ? (size_t)4 * compact_wave_bytes(C) : (size_t)4 * (kBlk + 1) * C * 4;
+  auto launch = [&](auto kern, size_t chain_lds) -> int {
+    const size_t lds = std::max(rows_lds, chain_lds);
+    if (lds > (size_t)kLdsBytes) {
+      set_error("ctc_forward_backward: needs %zu B of LDS (limit %d)", lds, kLdsBytes);
+      return WFL_ERR_UNSUPPORTED;
+    }
+    if (lds > 48 * 1024)
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
+    return WFL_OK;
+  };
+  int rc = WFL_OK;
+  // lane-exponent chains + certificate + repair launch: when the 8-wave gradient workgroups fit the LDS
+  // (WFL_CTC_PIPELINE=log selects the log-domain chains)
+  static const bool force_log = [] {
+    const char* e = getenv("WFL_CTC_PIPELINE");
+    return e && std::string(e) == "log";
+  }();
+  const size_t rows8_lds = (size_t)kFWaves * kBlk * C * 4;
+  // gradient rows as a dense LDS tile while three workgroups still fit a CU with it (C <= 100), compact beyond
+  static const int force_tile = [] {
+    const char* e = getenv("WFL_CTC_ROWS");  // "dense" / "compact": measurements
+    return !e ? -1 : std::string(e) == "compact" ? 1 : 0;
+  }();
+  const size_t compact_lds = (size_t)kFWaves * compact_wave_bytes(C);
+  const bool compact = force_tile >= 0 ? force_tile == 1 : 3 * std::max(rows8_lds, sizeof(FastLdsT)) > (size_t)kLdsBytes;
+  if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
+    const size_t lds = std::max(compact ? compact_lds : rows8_lds, sizeof(FastLdsT));
+    static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)
+    const int64_t grad_wgs = ctc_fast_grad_wgs(B, T);
+    const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : grad_wgs)));
+    static const int place_env = [] {
+      // Measured on one box, cfg2: placement cuts the memory-side traffic of the launch 278 -> 223 MB (x[b] lands in
+      // one L2 instead of several) and COSTS 2 us (59.8 -> 62.0; +2 % at cfg5): eight utterance groups with their own
+      // chains finish less evenly than 128 utterances spread over everything.  Off by default; WFL_CTC_XCD=1 enables.
+      const char* e = getenv("WFL_CTC_XCD");
+      return e ? atoi(e) : 0;
+    }();
+    a.place = place_env && (B & 7) == 0;
+    float* behind = ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3);
+    a.park = ctc_park_floats(B, T) ? behind + (ctc_use_xc(B, T, C, max_len) ? (int64_t)B * T * kXcStride : 0) : nullptr;
+    if (compact && ctc_use_xc(B, T, C, max_len)) {  // (wide rows: they use the compact gradient tile)
+      float* xc = behind;
+      // (a streaming variant -- coalesced float4 rows through an LDS tile -- is no faster: 141 vs 143 us at cfg5.  The
+      // pass also absorbs the write-back of the previous step's gradient, still dirty in the Infinity Cache.)
+      const unsigned gx = (unsigned)std::max(1, std::min((T + 4 * kXcRows - 1) / (4 * kXcRows), 64));
+      hipLaunchKernelGGL(ctc_compact_x_kernel, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, targets, offsets,
+                         T, C, blank, xc);
+      WFL_LAUNCH_CHECK();
+      a.xc = xc;
+    }
+    auto launch_fast = [&](auto kern) -> int {
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
+      hipLaunchKernelGGL(kern, grid8, dim3(kFWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
+      return WFL_OK;
+    };
+    rc = a.xc ? (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, true, true>) : launch_fast(ctc_fast_pipelined_kernel<false, true, true>))
+         : compact ? (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, true>) : launch_fast(ctc_fast_pipelined_kernel<false, true>))
+                   : (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, false>) : launch_fast(ctc_fast_pipelined_kernel<false, false>));
+    if (rc) return rc;
+    WFL_LAUNCH_CHECK();
+    a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
+    if (a.token == 0) a.token = 1;
+    auto launch_repair = [&](auto kern) -> int {
+      const size_t lds = std::max(rows_lds, sizeof(ChainLdsT));
+      if (lds > 48 * 1024)
+        WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
+      const dim3 rgrid((unsigned)(2 * B + std::min<int64_t>((items + 3) / 4, 512)));
+      hipLaunchKernelGGL(kern, rgrid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
+      return WFL_OK;
+    };
+    rc = lcompact ? (row_lse ? launch_repair(ctc_repair_kernel<true, true>) : launch_repair(ctc_repair_kernel<false, true>))
+                  : (row_lse ? launch_repair(ctc_repair_kernel<true, false>) : launch_repair(ctc_repair_kernel<false, false>));
+  } else if (ppl == 1) {
+    rc = lcompact ? (row_lse ? launch(ctc_pipelined_kernel<true, true>, sizeof(ChainLdsT))
+                             : launch(ctc_pipelined_kernel<false, true>, sizeof(ChainLdsT)))
+                  : (row_lse ? launch(ctc_pipelined_kernel<true, false>, sizeof(ChainLdsT))
+                             : launch(ctc_pipelined_kernel<false, false>, sizeof(ChainLdsT)));
+  } else {
+    a.loss_out = nullptr;  // the long-target chains do not reduce the loss in-kernel
+    if (row_lse)
+      rc = ppl == 2   ? launch(ctc_long_pipelined_kernel<2, true>, sizeof(LongLds<2>))
+           : ppl == 3 ? launch(ctc_long_pipelined_kernel<3, true>, sizeof(LongLds<3>))
+                      : launch(ctc_long_pipelined_kernel<4, true>, sizeof(LongLds<4>));
+    else
+      rc = ppl == 2   ? launch(ctc_long_pipelined_kernel<2, false>, sizeof(LongLds<2>))
+           : ppl == 3 ? launch(ctc_long_pipelined_kernel<3, false>, sizeof(LongLds<3>))
+                      : launch(ctc_long_pipelined_kernel<4, false>, sizeof(LongLds<4>));
+  }
+  if (rc) return rc;
+  WFL_LAUNCH_CHECK();
+  if (ppl > 1 && loss_out) return wfl_reduce_loss(nll, nullptr, loss_scale, B, 1.f, 0, loss_out, stream);
+  return WFL_OK;
+}
+
+int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets, int max_len,
+                 int blank, const float* ws, const float* nll, const float* coef, const float* gout, float* dx,
+                 void* stream) {
+  if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_grad")) return rc;
+  if (!x || !targets || !offsets || !ws || !nll || !dx) {
+    set_error("ctc_grad: null buffer");
+    return WFL_ERR_INVALID;
+  }
+  CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, (float*)ws, (float*)nll};
+  const int64_t items = (int64_t)B * ctc_blocks(T);
+  const int ppl = (max_len + 1 + 63) / 64;
+  const bool lcompact = ppl == 1 && C > 120;  // (see wfl_ctc_forward_backward)
+  const size_t lds = lcompact ? (size_t)4 * compact_wave_bytes(C) : (size_t)4 * (kBlk + 1) * C * 4;
+  auto launch = [&](auto kern) -> int {
+    if (lds > 48 * 1024)
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
+    return WFL_OK;
+  };
+  if (int rc = ppl == 1   ? (lcompact ? launch(ctc_grad_kernel<true>) : launch(ctc_grad_kernel<false>))
+               : ppl == 2 ? launch(ctc_long_grad_kernel<2>)
+               : ppl == 3 ? launch(ctc_long_grad_kernel<3>)
+                          : launch(ctc_long_grad_kernel<4>))
+    return rc;
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,2463 @@
+// Generic lattice engine for gfx950 (MI355X): time-synchronous log-/max-plus forward-backward over
+// an arbitrary per-utterance acceptor A_b composed with the implicit emissions chain.
+//
+//   stage 1  wfl_lattice_gather   all CUs, one wave per (b,t) row: xg[b,t,k] = x[b,t,labels_b[k]]
+//                                 (optionally minus the row's log-sum-exp: fused log_softmax)
+//   stage 2  wfl_lattice_forward  one workgroup per (utterance, direction); arcs of A_b staged in
+//                                 LDS as CSR lists; emission rows prefetched a chunk of frames
+//                                 ahead; per frame one of: banded (DPP) / single-wave (ds_bpermute) /
+//                                 multi-wave lean / general path with epsilon levels, cooperative
+//                                 16-lane relaxation of high in-degree states
+//   stage 3  wfl_lattice_grad     all CUs, tiles of frames: posteriors accumulated per (frame,
+//                                 distinct label) by threads owning <= 16 arcs of one label, dense
+//                                 rows streamed out through a column -> slot map (fused log_softmax
+//                                 backward optional); learnable-weight grads reduced per workgroup
+//
+// This replaces gtn.intersect(emissions, A) + gtn.forward_score / viterbi_path + gtn.backward
+// (criterions/ctc.py:49-51,78-81; asg.py:111-113; stc.py:85-87; transducer.py:283,321-325) without
+// ever materialising the T*|A| composed lattice.  Memory/latency-bound DP: no MFMA by design.
+#include <cstdlib>
+#include <string>
+#include <type_traits>
+
+#include "device_common.h"
+
+namespace wfl {
+
+struct UttView {
+  int Q, A, E, K, nlev;
+  int a0, e0;
+  const int32_t *in_ptr, *out_ptr, *out_arc, *ein_ptr, *eout_ptr, *eout_arc;
+  const int32_t *arc_src, *arc_dst, *arc_slot, *arc_lab, *arc_wid, *arc_orig;
+  const int32_t *eps_src, *eps_dst, *eps_wid, *eps_orig, *labels, *lvl_ptr, *slot_ptr, *slot_arc;
+  const float *arc_w, *eps_w, *start_w, *accept_w;
+  int64_t ab_base, xg_base;
+};
+
+__device__ __forceinline__ UttView make_view(const wfl_lattice_desc& d, const int32_t* ints, const float* floats,
+                                             int b, int T) {
+  UttView v;
+  const int bb = d.shared ? 0 : b;
+  const int s0 = ints[d.state_off + bb];
+  v.Q = ints[d.state_off + bb + 1] - s0;
+  v.a0 = ints[d.arc_off + bb];
+  v.A = ints[d.arc_off + bb + 1] - v.a0;
+  v.e0 = ints[d.eps_off + bb];
+  v.E = ints[d.eps_off + bb + 1] - v.e0;
+  const int l0 = ints[d.lab_off + bb];
+  v.K = ints[d.lab_off + bb + 1] - l0;
+  const int lv0 = ints[d.lvl_off + bb];
+  v.nlev = ints[d.lvl_off + bb + 1] - lv0 - 1;
+  v.in_ptr = ints + d.in_ptr + s0 + bb;
+  v.out_ptr = ints + d.out_ptr + s0 + bb;
+  v.ein_ptr = ints + d.ein_ptr + s0 + bb;
+  v.eout_ptr = ints + d.eout_ptr + s0 + bb;
+  v.out_arc = ints + d.out_arc + v.a0;
+  v.eout_arc = ints + d.eout_arc + v.e0;
+  v.arc_src = ints + d.arc_src + v.a0, v.arc_dst = ints + d.arc_dst + v.a0;
+  v.arc_slot = ints + d.arc_slot + v.a0, v.arc_lab = ints + d.arc_lab + v.a0;
+  v.arc_wid = ints + d.arc_wid + v.a0, v.arc_orig = ints + d.arc_orig + v.a0;
+  v.eps_src = ints + d.eps_src + v.e0, v.eps_dst = ints + d.eps_dst + v.e0;
+  v.eps_wid = ints + d.eps_wid + v.e0, v.eps_orig = ints + d.eps_orig + v.e0;
+  v.labels = ints + d.labels + l0;
+  v.slot_ptr = ints + d.slot_ptr + l0 + bb, v.slot_arc = ints + d.slot_arc + v.a0;
+  v.lvl_ptr = ints + d.lvl_ptr + lv0;
+  v.arc_w = floats + d.arc_w + v.a0, v.eps_w = floats + d.eps_w + v.e0;
+  v.start_w = floats + d.start_w + s0, v.accept_w = floats + d.accept_w + s0;
+  v.ab_base = d.shared ? (int64_t)b * (T + 1) * v.Q : (int64_t)(T + 1) * s0;
+  v.xg_base = (int64_t)b * T * d.max_labels;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1: gather
+// ------------------------------------------------------------------------------------------------
+// Probability-domain copy of a gathered row for the fp64 chains (run_chain_prob): factors
+// fg[k] = 2^((xg[k] - r) * log2 e) <= 1 relative to the row's reference r = max_k xg[k] (0 if the row is all -inf).
+// One wave per row; `vmx` is the lane's running maximum of the values it wrote to `dst` (re-read from L1 here).
+__device__ __forceinline__ void emit_factors(const float* dst, float* fdst, float* rdst, int K, int lane, float vmx) {
+  if (!fdst) return;
+  float r = wave_all_max(vmx);
+  if (!(r > WFL_NEG_INF)) r = 0.f;
+  for (int k = lane; k < K; k += 64) fdst[k] = __builtin_amdgcn_exp2f((dst[k] - r) * 1.4426950408889634f);
+  if (lane == 0) *rdst = r;
+}
+
+__global__ void __launch_bounds__(256) gather_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints,
+                                                      const float* __restrict__ x, int T, int C,
+                                                      float* __restrict__ xg, float* __restrict__ row_lse,
+                                                      float* __restrict__ fg, float* __restrict__ rmax) {
+#ifndef WFL_GATHER_PRIO
+#define WFL_GATHER_PRIO 0
+#endif
+  if (WFL_GATHER_PRIO) __builtin_amdgcn_s_setprio(WFL_GATHER_PRIO);
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bb = d.shared ? 0 : b;
+  const int l0 = ints[d.lab_off + bb];
+  const int K = ints[d.lab_off + bb + 1] - l0;
+  const int32_t* labels = ints + d.labels + l0;
+  const int Kmax = d.max_labels;
+  for (int t = blockIdx.x * 4 + wave; t < T; t += gridDim.x * 4) {
+    const float* row = x + ((int64_t)b * T + t) * C;
+    float lse = 0.f;
+    if (row_lse) {  // fused log_softmax (ctc.py:107, transducer.py:186-187)
+      float m = WFL_NEG_INF;
+      for (int c = lane; c < C; c += 64) m = fmaxf(m, nan_to_neg(row[c]));
+      m = wave_max(m);
+      float s = 0.f;
+      if (m > WFL_NEG_INF)
+        for (int c = lane; c < C; c += 64) s += fast_exp(nan_to_neg(row[c]) - m);
+      s = wave_sum(s);
+      lse = (m > WFL_NEG_INF) ? m + fast_log(s) : WFL_NEG_INF;
+      if (lane == 0) row_lse[(int64_t)b * T + t] = lse;
+    }
+    float* dst = xg + ((int64_t)b * T + t) * Kmax;
+    float vmx = WFL_NEG_INF;
+    for (int k = lane; k < K; k += 64) {
+      const float v = nan_to_neg(row[labels[k]]) - lse;
+      dst[k] = v;
+      vmx = fmaxf(vmx, v);
+    }
+    emit_factors(dst, fg ? fg + ((int64_t)b * T + t) * Kmax : nullptr, rmax ? rmax + (int64_t)b * T + t : nullptr, K, lane,
+                 vmx);
+  }
+}
+
+// The fused-log_softmax gather for C <= 64 * NV classes: the row is read ONCE into registers (NV loads in flight per
+// lane; the generic kernel above walks it three times with one load in flight), reduced with DPP, and the label columns
+// are picked out of L1/L2.  One wave per row, RU rows per iteration for the narrow cases.
+template <int NV, int RU>
+__global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints,
+                                                          const float* __restrict__ x, int T, int C,
+                                                          float* __restrict__ xg, float* __restrict__ row_lse,
+                                                          float* __restrict__ fg, float* __restrict__ rmax) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bb = d.shared ? 0 : b;
+  const int l0 = ints[d.lab_off + bb];
+  const int K = ints[d.lab_off + bb + 1] - l0;
+  const int32_t* labels = ints + d.labels + l0;
+  const int Kmax = d.max_labels;
+  for (int t0 = (blockIdx.x * 4 + wave) * RU; t0 < T; t0 += gridDim.x * 4 * RU) {
+    float v[RU][NV];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const float* row = x + ((int64_t)b * T + min(t0 + u, T - 1)) * C;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[u][i] = c < C ? row[c] : WFL_NEG_INF;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (t0 + u >= T) break;
+      float m = WFL_NEG_INF;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[u][i] = nan_to_neg(v[u][i]), m = fmaxf(m, v[u][i]);
+      m = wave_all_max(m);
+      float sum = 0.f;
+      if (m > WFL_NEG_INF) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum += fast_exp(v[u][i] - m);
+      }
+      sum = wave_all_sum(sum);
+      const float lse = (m > WFL_NEG_INF) ? m + fast_log(sum) : WFL_NEG_INF;
+      const float* row = x + ((int64_t)b * T + t0 + u) * C;
+      if (lane == 0) row_lse[(int64_t)b * T + t0 + u] = lse;
+      float* dst = xg + ((int64_t)b * T + t0 + u) * Kmax;
+      float vmx = WFL_NEG_INF;
+      for (int k = lane; k < K; k += 64) {
+        const float v = nan_to_neg(row[labels[k]]) - lse;
+        dst[k] = v;
+        vmx = fmaxf(vmx, v);
+      }
+      emit_factors(dst, fg ? fg + ((int64_t)b * T + t0 + u) * Kmax : nullptr,
+                   rmax ? rmax + (int64_t)b * T + t0 + u : nullptr, K, lane, vmx);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 2: chains
+// ------------------------------------------------------------------------------------------------
+struct ChainLds {
+  int2* arcs;   // [A] {other_state | slot << 16, weight bits}
+  int2* eps;    // [E] {other_state, weight bits}
+  int* ptr;     // [Q+1]
+  int* eptr;    // [Q+1]
+  float* buf0;  // [Q]
+  float* buf1;  // [Q]
+  float* rows;  // [2][R][Kmax] emission rows of the current / next chunk of R frames
+  float* red;   // [64]
+  int* lvl;     // [nlev+1]
+  int* heavy;   // [Q] states with more than kHeavyDeg in-arcs (cooperative relaxation), heavy[Q] = their count
+};
+
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
+  return r;
+}
+
+// One relaxation of a state over its labelled in-arcs (values read from `from`).  The first four
+// arcs are independent LDS chains whose terms stay in registers (most states of the criteria's
+// acceptors have in-degree <= 4); longer lists continue with a streaming max / rescale loop over
+// LDS arcs [kt0, kt1).  `k0` is the CSR index of the first arc (for Viterbi back-pointers).
+struct Arc4 {
+  int other[4], slot[4];
+  float w[4];
+};
+
+__device__ __forceinline__ Arc4 load_arc4(const int2* arcs, int k0, int k1) {
+  Arc4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool ok = k0 + i < k1;
+    const int2 a = ok ? arcs[k0 + i] : make_int2(0, __float_as_int(WFL_NEG_INF));
+    r.other[i] = a.x & 0xffff, r.slot[i] = (unsigned)a.x >> 16, r.w[i] = __int_as_float(a.y);
+  }
+  return r;
+}
+
+template <int SR>
+__device__ __forceinline__ void relax_labelled(const ChainLds& L, const Arc4& a4, const float* from, const float* row,
+                                               int k0, int kt0, int kt1, float& val, int& arg) {
+  const float v0 = from[a4.other[0]] + row[a4.slot[0]] + a4.w[0];
+  const float v1 = from[a4.other[1]] + row[a4.slot[1]] + a4.w[1];
+  const float v2 = from[a4.other[2]] + row[a4.slot[2]] + a4.w[2];
+  const float v3 = from[a4.other[3]] + row[a4.slot[3]] + a4.w[3];
+  float m = v0;
+  int am = v0 > WFL_NEG_INF ? k0 : -1;
+  if (v1 > m) m = v1, am = k0 + 1;
+  if (v2 > m) m = v2, am = k0 + 2;
+  if (v3 > m) m = v3, am = k0 + 3;
+  auto term = [&](int k) {
+    const int2 a = L.arcs[k];
+    return from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
+  };
+  if (SR == WFL_SEMIRING_LOG) {
+    float s = 0.f;
+    if (m > WFL_NEG_INF) s = fast_exp(v0 - m) + fast_exp(v1 - m) + fast_exp(v2 - m) + fast_exp(v3 - m);
+    for (int k = kt0; k < kt1; ++k) {
+      const float v = term(k);
+      if (v > m) {
+        s = s * fast_exp(m - v) + 1.f;  // m == -inf: s is 0 and exp(-inf) = 0
+        m = v;
+      } else if (v > WFL_NEG_INF) {
+        s += fast_exp(v - m);
+      }
+    }
+    if (m > WFL_NEG_INF) m += fast_log(s);
+  } else {
+    for (int k = kt0; k < kt1; ++k) {
+      const float v = term(k);
+      if (v > m) m = v, am = k;
+    }
+  }
+  val = m, arg = am;
+}
+
+// Lean per-frame update for the common layout (one state per thread, no epsilon levels, log
+// semiring, in-degree <= DEG everywhere): the arcs' LDS addresses are precomputed, absent arcs are
+// padded with weight -inf, and there is no branch -- the chain is one dependent instruction stream
+// per frame, so its length is what bounds the sweep.
+constexpr int kLeanDeg = 8;
+struct LeanArcs {
+  const float* fa[kLeanDeg];  // address of the source state's score in the buffer read by even steps
+  const float* fb[kLeanDeg];  // ... by odd steps
+  int ro[kLeanDeg];           // byte offset of the arc's emission inside a row of the tile
+  int lo[kLeanDeg];           // source state * 4: ds_bpermute address when the whole acceptor is one wave
+  float w[kLeanDeg];
+};
+
+// log-sum of DEG terms (see lean_relax)
+template <int DEG>
+__device__ __forceinline__ float lean_lse(const float (&v)[kLeanDeg]) {
+  if (DEG == 2) {
+    const float m = vmax(v[0], v[1]);
+    const float d = vmax(v[0], -1.0e30f) - vmax(v[1], -1.0e30f);
+    const float e = __builtin_amdgcn_exp2f(-fabsf(d) * 1.4426950408889634f);
+    return fmaf(__builtin_amdgcn_logf(1.f + e), 0.6931471805599453f, m);
+  } else {
+    float m = vmax(vmax(v[0], v[1]), vmax(v[2], v[3]));
+    if (DEG == 8) m = vmax(m, vmax(vmax(v[4], v[5]), vmax(v[6], v[7])));
+    const float mc = vmax(m, -1.0e30f);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) s += __builtin_amdgcn_exp2f((v[i] - mc) * 1.4426950408889634f);
+    return fmaf(__builtin_amdgcn_logf(s), 0.6931471805599453f, mc);
+  }
+}
+
+template <int DEG>
+__device__ __forceinline__ float lean_relax(const float* const (&fp)[kLeanDeg], const int (&ro)[kLeanDeg],
+                                            const float (&w)[kLeanDeg], const float* row) {
+  float v[kLeanDeg];
+#pragma unroll
+  for (int i = 0; i < DEG; ++i)
+    v[i] = *fp[i] + *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + ro[i]) + w[i];
+  return lean_lse<DEG>(v);
+}
+
+// High in-degree states (dense n-gram transition graphs: 81 in-arcs per state in the reference's
+// transducer benchmark) are relaxed cooperatively: a row of 16 lanes strides over the state's
+// labelled in-arcs and merges with DPP row operations, four states per wavefront at a time.
+// Tropical ties keep the lowest arc index, like the serial walk.
+constexpr int kHeavyDeg = 24;
+
+__device__ __forceinline__ float row16_max(float v) {  // every lane of the 16-lane row receives the row's maximum
+  v = fmaxf(v, dpp_f32<0x111, 0xf>(WFL_NEG_INF, v));
+  v = fmaxf(v, dpp_f32<0x112, 0xf>(WFL_NEG_INF, v));
+  v = fmaxf(v, dpp_f32<0x114, 0xf>(WFL_NEG_INF, v));
+  v = fmaxf(v, dpp_f32<0x118, 0xf>(WFL_NEG_INF, v));
+  return __shfl(v, 15, 16);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0x111, 0xf>(0.f, v);
+  v += dpp_f32<0x112, 0xf>(0.f, v);
+  v += dpp_f32<0x114, 0xf>(0.f, v);
+  v += dpp_f32<0x118, 0xf>(0.f, v);
+  return __shfl(v, 15, 16);
+}
+__device__ __forceinline__ int row16_min(int v) {
+  v = min(v, __shfl_xor(v, 1, 16));
+  v = min(v, __shfl_xor(v, 2, 16));
+  v = min(v, __shfl_xor(v, 4, 16));
+  v = min(v, __shfl_xor(v, 8, 16));
+  return v;
+}
+
+// epsilon closure of a state with many epsilon in-arcs (the back-off state of an n-gram graph collects
+// one from every history): same 16-lane cooperation; `val` / `arg` enter with the labelled result
+template <int SR>
+__device__ __forceinline__ void relax_eps_row16(const ChainLds& L, const float* vals, int k0, int k1, int A, float& val,
+                                                int& arg) {
+  const int r = threadIdx.x & 15;
+  float m = r == 0 ? val : WFL_NEG_INF, s = (r == 0 && val > WFL_NEG_INF) ? 1.f : 0.f;
+  int am = 0x7fffffff;  // (the labelled result wins ties: it is "earlier" than every epsilon arc)
+  for (int k = k0 + r; k < k1; k += 16) {
+    const int2 a = L.eps[k];
+    const float v = vals[a.x] + __int_as_float(a.y);
+    if (SR == WFL_SEMIRING_LOG) {
+      if (v > m) {
+        s = s * fast_exp(m - v) + 1.f;
+        m = v;
+      } else if (v > WFL_NEG_INF) {
+        s += fast_exp(v - m);
+      }
+    } else if (v > m) {
+      m = v, am = A + k;
+    }
+  }
+  const float mt = row16_max(m);
+  if (SR == WFL_SEMIRING_LOG) {
+    const float st = row16_sum(m > WFL_NEG_INF ? s * fast_exp(m - mt) : 0.f);
+    val = mt > WFL_NEG_INF ? mt + fast_log(st) : WFL_NEG_INF;
+  } else {
+    // an epsilon arc replaces the labelled back-pointer only if it is strictly better than it
+    const int cand = row16_min((m == mt && mt > val) ? am : 0x7fffffff);
+    if (cand != 0x7fffffff) arg = cand;
+    val = mt;
+  }
+}
+
+// all 64 lanes of the wave must call this (rows without a state pass k0 == k1)
+template <int SR>
+__device__ __forceinline__ void relax_labelled_row16(const ChainLds& L, const float* from, const float* row, int k0,
+                                                     int k1, float& val, int& arg) {
+  const int r = threadIdx.x & 15;
+  float m = WFL_NEG_INF, s = 0.f;
+  int am = 0x7fffffff;
+  auto term = [&](int k) {  // -inf past the end of the list
+    if (k >= k1) return WFL_NEG_INF;
+    const int2 a = L.arcs[k];
+    return from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
+  };
+  // four independent arcs per step: their LDS round trips overlap instead of queueing behind each other
+  for (int k = k0 + r; k < k1; k += 64) {
+    const float v0 = term(k), v1 = term(k + 16), v2 = term(k + 32), v3 = term(k + 48);
+    const float m4 = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+    if (SR == WFL_SEMIRING_LOG) {
+      if (m4 > WFL_NEG_INF) {
+        const float mn = fmaxf(m, m4);
+        s = s * fast_exp(m - mn) + fast_exp(v0 - mn) + fast_exp(v1 - mn) + fast_exp(v2 - mn) + fast_exp(v3 - mn);
+        m = mn;
+      }
+    } else {
+      // ascending arc index: strict '>' keeps the first maximum
+      if (v0 > m) m = v0, am = k;
+      if (v1 > m) m = v1, am = k + 16;
+      if (v2 > m) m = v2, am = k + 32;
+      if (v3 > m) m = v3, am = k + 48;
+    }
+  }
+  const float mt = row16_max(m);
+  if (SR == WFL_SEMIRING_LOG) {
+    const float st = row16_sum(m > WFL_NEG_INF ? s * fast_exp(m - mt) : 0.f);
+    val = mt > WFL_NEG_INF ? mt + fast_log(st) : WFL_NEG_INF;
+    arg = -1;
+  } else {
+    const int cand = row16_min((m == mt && mt > WFL_NEG_INF) ? am : 0x7fffffff);
+    val = mt;
+    arg = cand == 0x7fffffff ? -1 : cand;
+  }
+}
+
+template <int SR>
+__device__ __forceinline__ void relax_eps(const ChainLds& L, float* vals, int q, int k0, int k1, int A, float& val,
+                                          int& arg) {
+  // combine the current value of q with its epsilon arcs (other endpoints are already final)
+  float m = val;
+  int am = arg;
+  for (int k = k0; k < k1; ++k) {
+    const int2 a = L.eps[k];
+    const float v = vals[a.x] + __int_as_float(a.y);
+    if (v > m) m = v, am = A + k;
+  }
+  if (SR == WFL_SEMIRING_LOG) {
+    if (m > WFL_NEG_INF) {
+      float s = fast_exp(val - m);
+      for (int k = k0; k < k1; ++k) {
+        const int2 a = L.eps[k];
+        s += fast_exp(vals[a.x] + __int_as_float(a.y) - m);
+      }
+      m += fast_log(s);
+    }
+  }
+  val = m, arg = am;
+}
+
+constexpr int kPre = 8;  // prefetch registers per thread: rows_per_chunk * max_labels <= kPre * blockDim
+
+template <int SR, int DIR>
+__device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const ChainLds& L, int T, int rows_per_chunk,
+                          const float* __restrict__ xg, const float* __restrict__ weights, float* __restrict__ out,
+                          int32_t* __restrict__ bptr, float* __restrict__ logz, int b, double* __restrict__ offs,
+                          double* __restrict__ z64) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  // Block renormalisation (log semiring): plain fp32 log scores drift to O(T) -- thousands at T = 800..1000, where
+  // one ulp is 2.4e-4 .. 4.9e-4 and the posteriors lose their third digit (measured against the float64 oracle at
+  // BASELINE configs 3 and 4).  So at the start of every chunk of R frames the maximum of the state vector moves
+  // into a double offset: stored scores stay O(R * |x|), offs[1 + c] is what the slots produced in chunk c are
+  // relative to (offs[0] = 0: the boundary slot), and the gradient kernel adds offs_alpha + offs_beta - log Z in
+  // double before it exponentiates.
+  double cum = 0.0;
+  if (SR == WFL_SEMIRING_LOG && tid == 0) offs[0] = 0.0;
+  const int Q = u.Q, A = u.A, E = u.E, nlev = u.nlev, Kmax = d.max_labels;
+  // ---- stage the acceptor into LDS in this direction's CSR order
+  for (int k = tid; k < A; k += NT) {
+    const int a = DIR == 0 ? k : u.out_arc[k];
+    const int other = DIR == 0 ? u.arc_src[a] : u.arc_dst[a];
+    float w = u.arc_w[a];
+    const int wid = u.arc_wid[a];
+    if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+    L.arcs[k] = make_int2(other | (u.arc_slot[a] << 16), __float_as_int(w));
+  }
+  for (int k = tid; k < E; k += NT) {
+    const int e = DIR == 0 ? k : u.eout_arc[k];
+    const int other = DIR == 0 ? u.eps_src[e] : u.eps_dst[e];
+    float w = u.eps_w[e];
+    const int wid = u.eps_wid[e];
+    if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+    L.eps[k] = make_int2(other, __float_as_int(w));
+  }
+  for (int q = tid; q <= Q; q += NT) {
+    L.ptr[q] = DIR == 0 ? u.in_ptr[q] : u.out_ptr[q];
+    L.eptr[q] = DIR == 0 ? u.ein_ptr[q] : u.eout_ptr[q];
+  }
+  for (int l = tid; l <= nlev; l += NT) L.lvl[l] = u.lvl_ptr[l];
+
+  // epsilon closure of `vals` for this direction; `tslot` is the time slot for back-pointers
+  bool eps_heavy = false;  // set once the acceptor is staged (below)
+  auto closure = [&](float* vals, int tslot) {
+    if (nlev <= 1) return;
+    for (int step = 1; step < nlev; ++step) {
+      const int lev = DIR == 0 ? step : nlev - 1 - step;
+      __syncthreads();
+      for (int q = L.lvl[lev] + tid; q < L.lvl[lev + 1]; q += NT) {
+        if (L.eptr[q + 1] - L.eptr[q] > kHeavyDeg) continue;  // cooperative pass below
+        float v = vals[q];
+        int arg = -2;
+        relax_eps<SR>(L, vals, q, L.eptr[q], L.eptr[q + 1], A, v, arg);
+        vals[q] = v;
+        if (SR == WFL_SEMIRING_TROPICAL && DIR == 0 && arg != -2) bptr[u.ab_base + (int64_t)tslot * Q + q] = arg;
+      }
+      if (eps_heavy) {  // states of this level with many epsilon in-arcs: one 16-lane row each
+        for (int q = L.lvl[lev] + (tid >> 4); q < L.lvl[lev + 1]; q += NT >> 4) {
+          const int k0 = L.eptr[q], k1 = L.eptr[q + 1];
+          if (k1 - k0 <= kHeavyDeg) continue;  // uniform within the row
+          float v = vals[q];
+          int arg = -2;
+          relax_eps_row16<SR>(L, vals, k0, k1, A, v, arg);
+          if ((tid & 15) == 0) {
+            vals[q] = v;
+            if (SR == WFL_SEMIRING_TROPICAL && DIR == 0 && arg != -2) bptr[u.ab_base + (int64_t)tslot * Q + q] = arg;
+          }
+        }
+      }
+    }
+  };
+
+  const int t_first = DIR == 0 ? 0 : T;  // time slot of the boundary vector
+  float* cur = (t_first & 1) ? L.buf1 : L.buf0;
+  __syncthreads();
+  {
+    int eh = 0;
+    for (int q = tid; q < Q; q += NT) eh |= (L.eptr[q + 1] - L.eptr[q]) > kHeavyDeg;
+    eps_heavy = __syncthreads_or(eh) != 0;
+  }
+  for (int q = tid; q < Q; q += NT) {
+    cur[q] = DIR == 0 ? u.start_w[q] : u.accept_w[q];
+    if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + q] = -1;
+  }
+  closure(cur, t_first);
+  __syncthreads();
+  for (int q = tid; q < Q; q += NT) out[u.ab_base + (int64_t)t_first * Q + q] = cur[q];
+
+  // Emission rows travel HBM -> registers -> LDS one chunk of R frames ahead of the chain: the loads
+  // of chunk c+1 are issued before the first frame of chunk c and land in LDS after its last frame,
+  // so their latency is paid once per R frames instead of once per frame.  A chunk is a contiguous
+  // slab of xg (R rows of pitch Kmax) in both directions; the backward sweep walks it downwards.
+  const int R = rows_per_chunk;
+  const int nchunks = (T + R - 1) / R;
+  auto chunk_frames = [&](int c, int& f0, int& n) {  // frames [f0, f0+n) in ascending order
+    const int s0 = c * R;
+    n = min(R, T - s0);
+    f0 = DIR == 0 ? s0 : T - s0 - n;
+  };
+  if (T > 0) {
+    int f0, n;
+    chunk_frames(0, f0, n);
+    const float* src = xg + u.xg_base + (int64_t)f0 * Kmax;
+    for (int e = tid; e < n * Kmax; e += NT) L.rows[e] = src[e];
+  }
+  __syncthreads();
+  // one state per thread in the common case: its first four in-arcs live in registers
+  const int kq0 = tid < Q ? L.ptr[tid] : 0, kq1 = tid < Q ? L.ptr[tid + 1] : 0;
+  const Arc4 mine = load_arc4(L.arcs, kq0, kq1);
+  const bool direct = nlev <= 1;  // no epsilon closure: the relaxed value is final
+  const int deg = kq1 - kq0;
+  const int any_gt2 = __syncthreads_or(deg > 2), any_gt4 = __syncthreads_or(deg > 4);
+  const int any_gt8 = __syncthreads_or(deg > kLeanDeg);
+  if (tid == 0) L.heavy[Q] = 0;
+  __syncthreads();
+  for (int q = tid; q < Q; q += NT)
+    if (L.ptr[q + 1] - L.ptr[q] > kHeavyDeg) L.heavy[atomicAdd(&L.heavy[Q], 1)] = q;
+  __syncthreads();
+  const int n_heavy = L.heavy[Q];
+  const bool lean = SR == WFL_SEMIRING_LOG && Q <= NT && direct && !any_gt8;  // block-uniform
+  LeanArcs la;
+#pragma unroll
+  for (int i = 0; i < kLeanDeg; ++i) {
+    const bool ok = kq0 + i < kq1;
+    const int2 a = ok ? L.arcs[kq0 + i] : make_int2(0, __float_as_int(WFL_NEG_INF));
+    la.fa[i] = L.buf0 + (a.x & 0xffff), la.fb[i] = L.buf1 + (a.x & 0xffff);
+    la.ro[i] = (int)((unsigned)a.x >> 16) * 4, la.w[i] = __int_as_float(a.y);
+    la.lo[i] = (a.x & 0xffff) * 4;
+  }
+  // single-wave acceptors keep the score vector in registers (one state per lane) and fetch the
+  // source states with ds_bpermute: no LDS write -> barrier -> read round trip on the chain
+  float sc = (NT == 64 && tid < Q) ? cur[tid] : WFL_NEG_INF;
+  // banded acceptors (force alignment, CTC-like chains): every in-arc is a self loop or comes from
+  // the neighbouring state -- the neighbour's score is one DPP wave shift away, no LDS at all
+  const int adj = DIR == 0 ? tid - 1 : tid + 1;
+  float w_self = WFL_NEG_INF, w_adj = WFL_NEG_INF;
+  int ro_self = 0, ro_adj = 0, banded_ok = deg <= 2;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (kq0 + i >= kq1) continue;
+    const int other = la.lo[i] >> 2;
+    if (other == tid && w_self == WFL_NEG_INF)
+      w_self = la.w[i], ro_self = la.ro[i];
+    else if (other == adj && w_adj == WFL_NEG_INF)
+      w_adj = la.w[i], ro_adj = la.ro[i];
+    else if (la.w[i] > WFL_NEG_INF)
+      banded_ok = 0;
+  }
+  const bool banded = lean && NT == 64 && __syncthreads_and(banded_ok);
+  // rows_per_chunk is even, so the first step of every chunk reads the same buffer: forward steps
+  // read slot t (chunks start at even t), backward steps read slot t + 1 = T - c * R - i
+  const bool first_reads_buf1 = DIR == 0 ? false : (T & 1);
+  auto sweep = [&](auto variant) {
+    constexpr int V = decltype(variant)::value;  // 0: general path, 1: banded, otherwise the lean in-degree bound
+    for (int c = 0; c < nchunks; ++c) {
+      int f0, n;
+      chunk_frames(c, f0, n);
+      const float* tile = L.rows + (size_t)(c & 1) * R * Kmax;
+      float pre[kPre];
+      int pf0 = 0, pn = 0;
+      if (c + 1 < nchunks) {
+        chunk_frames(c + 1, pf0, pn);
+        const float* src = xg + u.xg_base + (int64_t)pf0 * Kmax;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+          const int e = tid + j * NT;
+          if (e < pn * Kmax) pre[j] = src[e];
+        }
+      }
+      if (SR == WFL_SEMIRING_LOG) {
+        if (c > 0) {
+          float m;
+          if (V != 0 && NT == 64) {  // the vector lives in registers
+            m = wave_all_max(sc);
+            if (m > WFL_NEG_INF && m < __builtin_inff())
+              sc -= m;
+            else
+              m = 0.f;
+          } else {
+            const int tf = DIR == 0 ? f0 : f0 + n;  // slot the first frame of the chunk reads
+            float* fromb = V != 0 ? (first_reads_buf1 ? L.buf1 : L.buf0) : ((tf & 1) ? L.buf1 : L.buf0);
+            float v = WFL_NEG_INF;
+            for (int q = tid; q < Q; q += NT) v = fmaxf(v, fromb[q]);
+            m = block_reduce_max(v, L.red);
+            if (m > WFL_NEG_INF && m < __builtin_inff()) {
+              for (int q = tid; q < Q; q += NT) fromb[q] -= m;
+            } else {
+              m = 0.f;
+            }
+            __syncthreads();
+          }
+          cum += (double)m;
+        }
+        if (tid == 0) offs[1 + c] = cum;
+      }
+      // single-wave variants: the emissions of frame i+1 are read from the tile while frame i is
+      // being computed (they do not depend on the chain), so only the score exchange is serial
+      auto row_of = [&](int i) {
+        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+        return reinterpret_cast<const char*>(tile + (size_t)(t - f0) * Kmax);
+      };
+      if (V == 1) {
+        float xs = *reinterpret_cast<const float*>(row_of(0) + ro_self);
+        float xa = *reinterpret_cast<const float*>(row_of(0) + ro_adj);
+        for (int i = 0; i < n; ++i) {
+          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+          const char* rn = row_of(i + 1 < n ? i + 1 : i);
+          const float xs_n = *reinterpret_cast<const float*>(rn + ro_self);
+          const float xa_n = *reinterpret_cast<const float*>(rn + ro_adj);
+          const float nb = DIR == 0 ? wave_shr1(sc, WFL_NEG_INF) : wave_shl1(sc, WFL_NEG_INF);
+          float v[kLeanDeg];
+          v[0] = sc + (xs + w_self);
+          v[1] = nb + (xa + w_adj);
+          sc = lean_lse<2>(v);
+          if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
+          xs = xs_n, xa = xa_n;
+        }
+      } else if (V != 0 && NT == 64) {
+        constexpr int DEG = V >= 2 ? V : 2;
+        float xr[kLeanDeg];
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) xr[k] = *reinterpret_cast<const float*>(row_of(0) + la.ro[k]) + la.w[k];
+        for (int i = 0; i < n; ++i) {
+          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+          const char* rn = row_of(i + 1 < n ? i + 1 : i);
+          float xn[kLeanDeg], v[kLeanDeg];
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) xn[k] = *reinterpret_cast<const float*>(rn + la.ro[k]) + la.w[k];
+#pragma unroll
+          for (int k = 0; k < DEG; ++k)
+            v[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(la.lo[k], __float_as_int(sc))) + xr[k];
+          sc = lean_lse<DEG>(v);
+          if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) xr[k] = xn[k];
+        }
+      } else if (V != 0) {
+        auto step = [&](int i, const float* const (&fp)[kLeanDeg], float* to) {
+          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+          const float* row = tile + (size_t)(t - f0) * Kmax;
+          const float v = lean_relax<(V >= 2 ? V : 2)>(fp, la.ro, la.w, row);
+          if (tid < Q) {
+            to[tid] = v;
+            out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = v;
+          }
+          lds_barrier();
+        };
+        float* const to_first = first_reads_buf1 ? L.buf0 : L.buf1;
+        float* const to_second = first_reads_buf1 ? L.buf1 : L.buf0;
+        int i = 0;
+        if (first_reads_buf1) {
+          for (; i + 1 < n; i += 2) {
+            step(i, la.fb, to_first);
+            step(i + 1, la.fa, to_second);
+          }
+          if (i < n) step(i, la.fb, to_first);
+        } else {
+          for (; i + 1 < n; i += 2) {
+            step(i, la.fa, to_first);
+            step(i + 1, la.fb, to_second);
+          }
+          if (i < n) step(i, la.fa, to_first);
+        }
+      } else {
+        for (int i = 0; i < n; ++i) {
+          // forward: consume frame t, produce slot t+1.  backward: consume frame t, produce slot t.
+          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+          const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
+          const float* from = (slot_from & 1) ? L.buf1 : L.buf0;
+          float* to = (slot_to & 1) ? L.buf1 : L.buf0;
+          const float* row = tile + (size_t)(t - f0) * Kmax;
+          float* orow = out + u.ab_base + (int64_t)slot_to * Q;
+          if (tid < Q && kq1 - kq0 <= kHeavyDeg) {
+            float v;
+            int arg;
+            relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
+            to[tid] = v;
+            if (direct) orow[tid] = v;
+            if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
+          }
+          for (int q = tid + NT; q < Q; q += NT) {
+            float v;
+            int arg;
+            const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
+            if (k1 - k0 > kHeavyDeg) continue;
+            relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
+            to[q] = v;
+            if (direct) orow[q] = v;
+            if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+          }
+          if (n_heavy) {  // one 16-lane row per high in-degree state, NT / 16 states at a time
+            const int grow = tid >> 4, nrows = NT >> 4;
+            for (int h0 = 0; h0 < n_heavy; h0 += nrows) {  // (uniform trip count: DPP rows need the whole wave)
+              const int hq = h0 + grow;
+              const int q = hq < n_heavy ? L.heavy[hq] : -1;
+              const int k0 = q >= 0 ? L.ptr[q] : 0, k1 = q >= 0 ? L.ptr[q + 1] : 0;
+              float v;
+              int arg;
+              relax_labelled_row16<SR>(L, from, row, k0, k1, v, arg);
+              if (q >= 0 && (tid & 15) == 0) {
+                to[q] = v;
+                if (direct) orow[q] = v;
+                if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+              }
+            }
+          }
+          closure(to, slot_to);
+          __syncthreads();
+          if (!direct)
+            for (int q = tid; q < Q; q += NT) orow[q] = to[q];
+        }
+      }
+      if (c + 1 < nchunks) {
+        float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+          const int e = tid + j * NT;
+          if (e < pn * Kmax) dst[e] = pre[j];
+        }
+        __syncthreads();
+      }
+    }
+  };
+  if (!lean)
+    sweep(std::integral_constant<int, 0>{});
+  else if (banded)
+    sweep(std::integral_constant<int, 1>{});
+  else if (any_gt4)
+    sweep(std::integral_constant<int, 8>{});
+  else if (any_gt2)
+    sweep(std::integral_constant<int, 4>{});
+  else
+    sweep(std::integral_constant<int, 2>{});
+  if (lean && NT == 64 && T > 0) {  // the final vector lives in registers: publish it for the log Z reduction
+    float* fin = ((DIR == 0 ? T : 0) & 1) ? L.buf1 : L.buf0;
+    if (tid < Q) fin[tid] = sc;
+    __syncthreads();
+  }
+  if (DIR == 0 && logz) {
+    const float* fin = (T & 1) ? L.buf1 : L.buf0;
+    float m = WFL_NEG_INF;
+    for (int q = tid; q < Q; q += NT) m = fmaxf(m, fin[q] + u.accept_w[q]);
+    m = block_reduce_max(m, L.red);
+    float z = m;
+    if (SR == WFL_SEMIRING_LOG && m > WFL_NEG_INF) {
+      float s = 0.f;
+      for (int q = tid; q < Q; q += NT) s += fast_exp(fin[q] + u.accept_w[q] - m);
+      s = block_reduce_sum(s, L.red);
+      z = m + fast_log(s);
+    }
+    if (tid == 0) {
+      const double zd = (double)z + cum;  // (-inf + cum = -inf: no accepting path)
+      logz[b] = (float)zd;
+      if (SR == WFL_SEMIRING_LOG) z64[b] = zd;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// stage 2, probability domain (the default for the log semiring on "lean" acceptors: one state per thread, no
+// epsilon arcs, at most kLeanDeg arcs into AND out of every state -- CTC-like chains, ASG force alignment, STC, the
+// Transducer's alignment graphs).
+//
+// fp32 log-domain sweeps pay a v_exp_f32 per arc and a v_log_f32 per state and frame, and their results carry the
+// transcendentals' (biased) rounding: measured 1.5e-4 .. 2.5e-4 on posteriors / log Z after T = 800..1000 frames
+// against the float64 oracle, whatever the renormalisation.  Here a state is a DOUBLE probability relative to a
+// workgroup-uniform power-of-two scale (renormalised every chunk: exact) and the per-frame references of the gathered
+// emission factors; a frame is one multiply-add per arc:
+//     p'[q] = sum_{arcs s->q} p[s] * wf[arc] * f_t[slot(arc)]        wf = e^(w - wref), f_t = e^(x_t - r_t) <= 1
+// The 11-bit exponent of a double holds what a float cannot: alpha mass piles up at the last states and beta mass
+// at the first ones (2^328 apart at T = 1000), far from the diagonal that carries the posteriors.  What even a
+// double cannot hold shows up as disagreement between the two sweeps' log Z (alpha from the accept states at T,
+// beta from the start states at 0) or as a non-finite / vanished state vector: such an utterance is re-run in the
+// log domain by the repair launch that follows (a no-op otherwise) and marked in fmt[b].
+//   out[slot][q] (double) relative to offs[slot] in LOG2 units:  log2 value = log2 out + offs[slot]
+// ------------------------------------------------------------------------------------------------
+constexpr int kFmtLog = 0, kFmtProb = 1;
+__device__ __forceinline__ int64_t xg_main_dev(const wfl_lattice_desc& d, int T) {
+  return (((int64_t)d.B * T * d.max_labels) + 3) & ~(int64_t)3;
+}
+constexpr double kLog2e_d = 1.4426950408889634074;
+constexpr int kDumpDoubles = 1024;  // scratch behind the alpha / beta tails (see run_chain_prob)
+constexpr int kBandDepth = 4;
+// floats of the probability-domain sweeps' row tile: two chunks of the tile path, or the banded sweep's two tiles of
+// 16 rows (+ their references)
+__host__ __device__ inline size_t prob_rows_floats(const wfl_lattice_desc& d, int rows_per_chunk) {
+  const size_t tile = (size_t)2 * rows_per_chunk * d.max_labels;
+  const size_t band = d.max_states <= 64 ? (size_t)2 * 1024 + 2 * 64 : 0;
+  return tile > band ? tile : band;
+}  // chunks of 16 frames the banded sweep loads ahead of the one it works on
+
+struct ProbLds {
+  double* buf0;  // [Q]
+  double* buf1;  // [Q]
+  float* rows;   // [2][R][Kmax] emission factors of the current / next chunk
+  float* refs;   // [2][R]       their references
+  float* red;    // [64] (reductions; reused as int)
+};
+
+__device__ __forceinline__ int block_reduce_max_int(int v, int* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_all_max_int(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  int r = red[0];
+  for (int i = 1; i < nw; ++i) r = max(r, red[i]);
+  return r;
+}
+__device__ __forceinline__ double block_reduce_sum_f64(double v, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
+  return r;
+}
+
+// Is utterance `u` one for the probability-domain chains?  (block-uniform; both directions must agree, so both
+// degrees are checked by both workgroups)
+__device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {  // NT: threads of the CHAIN workgroups
+  int bad = (u.Q > NT) | (u.E > 0) | (u.nlev > 1);
+  if (!bad)
+    for (int q = threadIdx.x; q < u.Q; q += blockDim.x)
+      bad |= (u.in_ptr[q + 1] - u.in_ptr[q] > kLeanDeg) | (u.out_ptr[q + 1] - u.out_ptr[q] > kLeanDeg);
+  return !__syncthreads_or(bad);
+}
+
+// BAND: the register-resident banded sweep is compiled in (chain wave + loader wave workgroups); UNR: full chunks as
+// straight-line code (not for the 1024-thread instantiation: its 128-register budget would spill)
+template <int DIR, bool BAND, bool UNR = true>
+__device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, const ProbLds& L, int T, int R,
+                               const float* __restrict__ fg, const float* __restrict__ rmax,
+                               const float* __restrict__ weights, double* __restrict__ out, float* __restrict__ logz,
+                               int b, double* __restrict__ offs, double* __restrict__ z64, float* __restrict__ wref_out,
+                               double* __restrict__ dump) {  // dump: kDumpDoubles doubles nobody reads
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int Q = u.Q, Kmax = d.max_labels;
+  // ---- this thread's state: its in-arcs (forward) / out-arcs (backward) in registers
+  const int32_t* ptr = DIR == 0 ? u.in_ptr : u.out_ptr;
+  const int k0 = tid < Q ? ptr[tid] : 0, k1 = tid < Q ? ptr[tid + 1] : 0;
+  int asrc[kLeanDeg], aslot[kLeanDeg];
+  float aw[kLeanDeg];
+  float wmx = WFL_NEG_INF;
+#pragma unroll
+  for (int i = 0; i < kLeanDeg; ++i) {
+    asrc[i] = 0, aslot[i] = 0, aw[i] = WFL_NEG_INF;
+    if (k0 + i < k1) {
+      const int a = DIR == 0 ? k0 + i : u.out_arc[k0 + i];
+      asrc[i] = DIR == 0 ? u.arc_src[a] : u.arc_dst[a];
+      aslot[i] = u.arc_slot[a];
+      float w = u.arc_w[a];
+      const int wid = u.arc_wid[a];
+      if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+      aw[i] = nan_to_neg(w);
+      wmx = fmaxf(wmx, aw[i]);
+    }
+  }
+  const int deg_class = __syncthreads_or(k1 - k0 > 4) ? 2 : (__syncthreads_or(k1 - k0 > 2) ? 1 : 0);
+  float wref = block_reduce_max(wmx, L.red);  // every frame multiplies by e^wref once more: part of the offset
+  if (!(wref > WFL_NEG_INF)) wref = 0.f;
+  if (wref_out && tid == 0) wref_out[b] = wref;
+  double wf[kLeanDeg];  // (float exponential: the gradient kernel recomputes the same factor)
+#pragma unroll
+  for (int i = 0; i < kLeanDeg; ++i) wf[i] = (double)fast_exp(aw[i] - wref);
+
+  // single-wave banded acceptors (ASG force alignment, CTC-like chains without skips): every arc comes from the state
+  // itself or from its neighbour -- the state vector stays in registers, the neighbour is one DPP wave shift away
+  const int adj = DIR == 0 ? tid - 1 : tid + 1;
+  double wf_self = 0.0, wf_adj = 0.0;
+  int slot_self = 0, slot_adj = 0, band_ok = 1;
+#pragma unroll
+  for (int i = 0; i < kLeanDeg; ++i) {
+    if (!(aw[i] > WFL_NEG_INF)) continue;
+    if (asrc[i] == tid && wf_self == 0.0)
+      wf_self = wf[i], slot_self = aslot[i];
+    else if (asrc[i] == adj && wf_adj == 0.0)
+      wf_adj = wf[i], slot_adj = aslot[i];
+    else
+      band_ok = 0;
+  }
+  const bool banded = BAND && NT == 128 && Q <= 64 && (Kmax & 3) == 0 && Kmax <= 64 && __syncthreads_and(band_ok);
+  // "uniform-label" acceptors: every arc INTO a state carries the same emission column (CTC-like chains, force
+  // alignment, token-level alignment graphs: the label belongs to the destination state).  Then the frame's factor is
+  // applied once per state by its owner -- after the sum (alpha), or before publishing (beta: the owner publishes
+  // f_t[label(d)] * beta_{t+1}[d]) -- instead of once per arc: one LDS read, one conversion and one multiply per
+  // thread and frame where the general form needs kLeanDeg of each.
+  int my_slot = 0, uni_ok = 1;
+  if (tid < Q) {
+    const int i0 = u.in_ptr[tid], i1 = u.in_ptr[tid + 1];
+    if (i0 < i1) my_slot = u.arc_slot[i0];
+    for (int k = i0 + 1; k < i1; ++k) uni_ok &= u.arc_slot[k] == my_slot;
+  }
+  const bool uniform = __syncthreads_and(uni_ok);
+  const bool wave_live = (tid & ~63) < Q;  // (waves without a state only take part in the barriers)
+
+  const int t_first = DIR == 0 ? 0 : T;
+  double p = 0.0;
+  if (tid < Q) p = (DIR == 0 ? u.start_w[tid] : u.accept_w[tid]) > WFL_NEG_INF ? 1.0 : 0.0;  // (boundary weights are 0 / -inf)
+  double cum = 0.0;  // log2 of everything factored out of the stored probabilities so far
+  double* cur = (t_first & 1) ? L.buf1 : L.buf0;
+  if (tid < Q) {
+    cur[tid] = p;
+    out[u.ab_base + (int64_t)t_first * Q + tid] = p;
+  }
+  if (tid == 0) offs[t_first] = 0.0;
+
+  if constexpr (BAND) if (banded) {
+    // The whole sweep in ONE wave's registers (wave 0), fed by a loader wave (wave 1); the two meet at one LDS-only
+    // barrier per chunk of 16 frames.  A frame is ~100 cycles of dependent arithmetic and an HBM round trip is
+    // 2000-5000, so the rows must be requested several chunks ahead -- and on gfx9 a wave's loads and stores share
+    // one in-order counter (vmcnt), so a wave that both streams its scores out every frame and waits for prefetched
+    // rows ends up waiting for its own stores.  Hence two waves: the chain wave only stores, the loader only loads
+    // (kBandDepth chunks in flight in its registers: the compact rows of a chunk are contiguous, up to four float4
+    // per lane) and hands each chunk over through a double-buffered LDS tile.  The tile path below has one chunk of
+    // lookahead and a barrier per FRAME: 235 us at T = 1000 for the ASG force-alignment lattice; this one 60.
+    constexpr int RB = 16, D = kBandDepth, NV = 4;
+    const int K4 = Kmax >> 2, nch = (T + RB - 1) / RB;
+    constexpr int kSlot = 64 * 4 * NV;     // floats per tile (every loader lane stores its NV float4: no divergence)
+    float* ring = L.rows;                  // [2][kSlot], rows of RB * Kmax <= kSlot floats
+    float* rref = ring + 2 * kSlot;        // [2][64]: per-frame references of the chunk (first RB entries)
+    auto chunk_lo = [&](int c, int n) { return DIR == 0 ? c * RB : T - c * RB - n; };  // lowest frame of chunk c
+    if (tid >= 64) {
+      // ---- loader
+      const int l = tid - 64;
+      const float4* fgu = reinterpret_cast<const float4*>(fg + u.xg_base);  // (Kmax % 4 == 0: checked by `banded`)
+      const float* rmu = rmax + (int64_t)b * T;
+      float gv[D][4 * NV];  // (plain floats: an array of float4 is not promoted to registers)
+      float gr[D];
+      auto load = [&](int c, float (&v_)[4 * NV], float& r_) {
+        const int cc = min(c, nch - 1);  // (past the end: the last chunk again, never handed over)
+        const int n = min(RB, T - cc * RB);
+        const int64_t base4 = (int64_t)chunk_lo(cc, n) * K4;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          const float4 q = fgu[base4 + min(l + 64 * k, n * K4 - 1)];
+          v_[4 * k] = q.x, v_[4 * k + 1] = q.y, v_[4 * k + 2] = q.z, v_[4 * k + 3] = q.w;
+        }
+        r_ = rmu[min(chunk_lo(cc, n) + (l & 15), T - 1)];
+      };
+      auto hand_over = [&](int c, float (&v_)[4 * NV], float& r_) {  // chunk c -> LDS slot c & 1, then refill
+        // (branch-free on purpose: around a divergent branch the compiler waits for ALL outstanding loads)
+        float4* dst = reinterpret_cast<float4*>(ring + (size_t)(c & 1) * kSlot);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) dst[l + 64 * k] = make_float4(v_[4 * k], v_[4 * k + 1], v_[4 * k + 2], v_[4 * k + 3]);
+        rref[(c & 1) * 64 + l] = r_;
+        load(c + D, v_, r_);
+      };
+#pragma unroll
+      for (int j = 0; j < D; ++j) load(j, gv[j], gr[j]);
+      hand_over(0, gv[0], gr[0]);
+      lds_barrier();
+      // while the chain wave works on chunk c, prepare chunk c + 1.  The steady state is straight-line code (D
+      // hand-overs per trip, no test in between): the compiler counts the loads a wait may leave outstanding along
+      // the SHORTEST path, so a skipped hand-over anywhere in the loop would shrink every wait to "all but the last".
+      int c = 0;
+      for (; c + D < nch; c += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          hand_over(c + j + 1, gv[(j + 1) % D], gr[(j + 1) % D]);
+          lds_barrier();
+        }
+      }
+      for (; c < nch; ++c) {  // the last D chunks or fewer
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          if (c + 1 < nch && (c + 1) % D == j) hand_over(c + 1, gv[j], gr[j]);
+        lds_barrier();
+      }
+    } else {
+      // ---- chain
+      const int ss = tid < Q ? slot_self : 0, sa = tid < Q ? slot_adj : 0;
+      bool two_l = ss != sa;
+      const bool two = __any(two_l);
+      lds_barrier();
+      for (int c = 0; c < nch; ++c) {
+        const int n = min(RB, T - c * RB);
+        const float* tile = ring + (size_t)(c & 1) * kSlot;
+        if (c > 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
+          int ex = (tid < Q && p > 0.0) ? __builtin_amdgcn_frexp_exp(p) - 1 : -(1 << 30);
+          ex = wave_all_max_int(ex);  // (DPP: six VALU instructions; the __shfl_xor form is six ds_bpermute round trips)
+          if (ex > -(1 << 30) && ex < 2000) p = ldexp(p, -ex), cum += (double)ex;
+        }
+        // this lane's factors of the chunk: all LDS reads issued back to back, THEN converted (a test or a use
+        // between two reads makes the compiler wait for each read in turn: 16 LDS round trips per chunk)
+        float fs[RB], fa[RB];
+        const int r0 = DIR == 0 ? 0 : n - 1, dr = DIR == 0 ? Kmax : -Kmax;
+        const float* ts = tile + r0 * Kmax + ss;
+        const float* ta = tile + r0 * Kmax + sa;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) fs[i] = ts[(i < n ? i : 0) * dr];  // (i >= n: row r0 again, not consumed)
+        if (two) {
+#pragma unroll
+          for (int i = 0; i < RB; ++i) fa[i] = ta[(i < n ? i : 0) * dr];
+        } else {
+#pragma unroll
+          for (int i = 0; i < RB; ++i) fa[i] = fs[i];
+        }
+        double cs[RB], ca[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) cs[i] = wf_self * (double)fs[i], ca[i] = wf_adj * (double)fa[i];
+        // offsets of the chunk's frames: inclusive prefix sum of the per-frame log2 factors over lanes 0..15
+        // (lane i: the chunk's i-th frame IN SWEEP ORDER)
+        const float rsel = rref[(c & 1) * 64 + ((DIR == 0 ? (tid & 15) : n - 1 - (tid & 15)) & 15)];
+        double pre = (tid & 15) < n ? ((double)rsel + (double)wref) * kLog2e_d : 0.0;
+#pragma unroll
+        for (int o = 1; o < RB; o <<= 1) {
+          const int lo = __double2loint(pre), hi = __double2hiint(pre);  // row_shr:o, lanes without a source read 0
+          const int slo = o == 1   ? __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true)
+                          : o == 2 ? __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true)
+                          : o == 4 ? __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true)
+                                   : __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true);
+          const int shi = o == 1   ? __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true)
+                          : o == 2 ? __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true)
+                          : o == 4 ? __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true)
+                                   : __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true);
+          pre += __hiloint2double(shi, slo);
+        }
+        // lane i: the offset after the chunk's i-th frame -- the chunk's offsets in one store
+        if (tid < n) offs[DIR == 0 ? c * RB + tid + 1 : T - 1 - (c * RB + tid)] = cum + pre;
+        cum += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pre), 15),
+                                __builtin_amdgcn_readlane(__double2loint(pre), 15));  // (lanes >= n added 0)
+        // The frames: two DPP moves, a multiply, an fma and a store each -- a single wave issues one instruction every
+        // ~5 cycles, so the instruction count IS the frame time.  Lanes without a state sit the loop out (a DPP read
+        // from a disabled lane returns 0, which is what their probability is), the row pointer is wave-uniform
+        // (scalar adds), and full chunks run without the per-frame bound test.
+        double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? c * RB + 1 : T - 1 - c * RB) * Q;
+        auto frames16 = [&](auto full) {
+          constexpr bool FULL = decltype(full)::value;
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            if (FULL || i < n) {
+              // the neighbour's value: both halves of the double through a DPP wave shift (lanes without one: 0)
+              const int lo = __double2loint(p), hi = __double2hiint(p);
+              const int nlo = DIR == 0 ? __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false)
+                                       : __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+              const int nhi = DIR == 0 ? __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false)
+                                       : __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+              const double pn = __hiloint2double(nhi, nlo);
+              p = fma(p, cs[i], pn * ca[i]);
+              orow[tid] = p;
+              orow = DIR == 0 ? orow + Q : orow - Q;
+            }
+          }
+        };
+        if (tid < Q) {
+          if (n == RB)
+            frames16(std::true_type{});
+          else
+            frames16(std::false_type{});
+        }
+        lds_barrier();
+      }
+    }
+    __syncthreads();
+  }
+  const int nchunks = banded ? 0 : (T + R - 1) / R;
+  auto chunk_frames = [&](int c, int& f0, int& n) {
+    const int s0 = c * R;
+    n = min(R, T - s0);
+    f0 = DIR == 0 ? s0 : T - s0 - n;
+  };
+  if (T > 0 && !banded) {
+    int f0, n;
+    chunk_frames(0, f0, n);
+    const float* src = fg + u.xg_base + (int64_t)f0 * Kmax;
+    for (int e = tid; e < n * Kmax; e += NT) L.rows[e] = src[e];
+    if (tid < n) L.refs[tid] = rmax[(int64_t)b * T + f0 + tid];
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    int f0, n;
+    chunk_frames(c, f0, n);
+    const float* tile = L.rows + (size_t)(c & 1) * R * Kmax;
+    const float* rtile = L.refs + (size_t)(c & 1) * R;
+    float pre[kPre], rpre = 0.f;
+    int pf0 = 0, pn = 0;
+    if (c + 1 < nchunks) {
+      chunk_frames(c + 1, pf0, pn);
+      const float* src = fg + u.xg_base + (int64_t)pf0 * Kmax;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) pre[j] = src[e];
+      }
+      if (tid < pn) rpre = rmax[(int64_t)b * T + pf0 + tid];
+    }
+    if (c > 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
+      const int ex = (tid < Q && p > 0.0) ? ilogb(p) : -(1 << 30);
+      const int emax = block_reduce_max_int(ex, (int*)L.red);
+      if (emax > -(1 << 30) && emax < 2000) {
+        p = scalbn(p, -emax);
+        cum += (double)emax;
+        double* fromb = ((DIR == 0 ? f0 : f0 + n) & 1) ? L.buf1 : L.buf0;
+        if (tid < Q) fromb[tid] = p;
+      }
+      __syncthreads();
+    }
+    // Software pipeline: the arc coefficients c[k] = wf[k] * f_t[slot_k] of a frame do not depend on the chain, so
+    // they are formed while the previous frame's sources are still on their way from LDS; after the barrier only the
+    // DEG source reads (issued back to back) and DEG multiply-adds (two independent accumulators) remain.
+    auto coeffs = [&](int i, double (&c)[kLeanDeg], auto deg) {
+      constexpr int DEG = decltype(deg)::value;
+      const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+      const float* row = tile + (size_t)(t - f0) * Kmax;
+      float f[DEG];
+#pragma unroll
+      for (int k = 0; k < DEG; ++k) f[k] = row[aslot[k]];
+#pragma unroll
+      for (int k = 0; k < DEG; ++k) c[k] = wf[k] * (double)f[k];
+    };
+    // Frame loops.  The workgroup's waves meet at ONE LDS-only barrier per frame and a wave issues an instruction every
+    // ~5 cycles, so the instruction count of a frame is its time (SQ counters at cfg4: 27 VALU + 19 SALU + 5 LDS
+    // instructions per live wave and frame, waves waiting 63 % of their cycles): waves without a state only run the
+    // barriers, the row pointer and the tile pointer advance by scalar adds, the ping-pong buffers swap by parity.
+    auto frames = [&](auto deg) {
+      constexpr int DEG = decltype(deg)::value;
+      if (!wave_live) {
+        for (int i = 0; i < n; ++i) lds_barrier();
+        return;
+      }
+      double c[kLeanDeg], cn[kLeanDeg];
+      coeffs(0, c, deg);
+      double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
+      int par = (DIR == 0 ? f0 : f0 + n) & 1;  // parity of the slot the frame reads from
+      if (UNR && n == 16) {  // (a full chunk as straight-line code with unconditional stores: see frames_uniform)
+        const bool mine = tid < Q;
+        double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
+        const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
+        const double* bA = par ? L.buf1 : L.buf0;
+        const double* bB = par ? L.buf0 : L.buf1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const double* from = (i & 1) ? bB : bA;
+          double* to = const_cast<double*>((i & 1) ? bA : bB);
+          double ps[DEG];
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+          if (i + 1 < 16) coeffs(i + 1, cn, deg);
+          double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < DEG; k += 2) {
+            acc0 = fma(ps[k], c[k], acc0);
+            acc1 = fma(ps[k + 1], c[k + 1], acc1);
+          }
+          p = acc0 + acc1;
+          to[tid] = p;
+          *po = p;
+          po += pstep;
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) c[k] = cn[k];
+          lds_barrier();
+        }
+        return;
+      }
+      for (int i = 0; i < n; ++i) {
+        const double* from = par ? L.buf1 : L.buf0;
+        double* to = par ? L.buf0 : L.buf1;
+        double ps[DEG];
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+        if (i + 1 < n) coeffs(i + 1, cn, deg);
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DEG; k += 2) {
+          acc0 = fma(ps[k], c[k], acc0);
+          acc1 = fma(ps[k + 1], c[k + 1], acc1);
+        }
+        p = acc0 + acc1;
+        if (tid < Q) {
+          to[tid] = p;
+          orow[tid] = p;
+        }
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) c[k] = cn[k];
+        orow = DIR == 0 ? orow + Q : orow - Q;
+        par ^= 1;
+        lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
+      }
+    };
+    auto frames_uniform = [&](auto deg) {
+      constexpr int DEG = decltype(deg)::value;
+      if (DIR == 1) {
+        // beta: the LDS vector holds G = f[label(d)] * beta[d] for the frame about to be consumed; at the chunk's
+        // first frame it still holds plain beta (the tile of this chunk was not there when it was written)
+        const int t0 = f0 + n - 1;
+        const double* fromb = ((t0 + 1) & 1) ? L.buf1 : L.buf0;
+        if (tid < Q) {  // (own entry only: no hazard before the write)
+          double* fb = const_cast<double*>(fromb);
+          fb[tid] = fb[tid] * (double)tile[(size_t)(t0 - f0) * Kmax + my_slot];
+        }
+        lds_barrier();
+      }
+      if (!wave_live) {
+        for (int i = 0; i < n; ++i) lds_barrier();
+        return;
+      }
+      double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
+      int par = (DIR == 0 ? f0 : f0 + n) & 1;
+      // alpha: this frame's factor of the state; beta: the factor of the NEXT frame to be consumed (t - 1), with
+      // which the owner publishes; past the chunk (the tile is not there yet) plain beta is published
+      const float* fptr = tile + (size_t)(DIR == 0 ? 0 : max(n - 2, 0)) * Kmax + my_slot;
+      if (UNR && n == 16) {
+        // A full chunk as straight-line code whose stores EVERY lane executes (lanes without a state store to a dump
+        // and to their own, never read, LDS entry).  The threads of this workgroup also prefetch the next chunk's rows:
+        // loads and stores share the in-order vmcnt counter and the compiler counts, for the wait in front of the
+        // prefetched rows, only the operations that are issued on EVERY path -- with the stores inside `if (tid < Q)`
+        // or inside a loop of unknown trip count that wait became "everything", i.e. the last frame's store round trip
+        // (~1.5 us) at the end of every chunk.
+        const bool mine = tid < Q;
+        double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
+        const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
+        const double* bA = par ? L.buf1 : L.buf0;  // read by the even frames of the chunk, written by the odd ones
+        const double* bB = par ? L.buf0 : L.buf1;
+        const int fstep = DIR == 0 ? Kmax : -Kmax;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const double* from = (i & 1) ? bB : bA;
+          double* to = const_cast<double*>((i & 1) ? bA : bB);
+          double ps[DEG];
+#pragma unroll
+          for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+          const float fr = fptr[(DIR == 0 || i < 15) ? i * fstep : 14 * fstep];
+          const float f = (DIR == 0 || i < 15) ? fr : 1.f;
+          double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < DEG; k += 2) {
+            acc0 = fma(ps[k], wf[k], acc0);
+            acc1 = fma(ps[k + 1], wf[k + 1], acc1);
+          }
+          const double sum = acc0 + acc1;
+          p = DIR == 0 ? sum * (double)f : sum;
+          to[tid] = DIR == 0 ? p : p * (double)f;
+          *po = p;
+          po += pstep;
+          lds_barrier();
+        }
+        return;
+      }
+      for (int i = 0; i < n; ++i) {
+        const double* from = par ? L.buf1 : L.buf0;
+        double* to = par ? L.buf0 : L.buf1;
+        double ps[DEG];
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+        const float fr = *fptr;
+        const float f = (DIR == 0 || i + 1 < n) ? fr : 1.f;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DEG; k += 2) {
+          acc0 = fma(ps[k], wf[k], acc0);
+          acc1 = fma(ps[k + 1], wf[k + 1], acc1);
+        }
+        const double sum = acc0 + acc1;
+        p = DIR == 0 ? sum * (double)f : sum;
+        if (tid < Q) {
+          to[tid] = DIR == 0 ? p : p * (double)f;
+          orow[tid] = p;
+        }
+        orow = DIR == 0 ? orow + Q : orow - Q;
+        if (DIR == 0 || i + 2 < n) fptr = DIR == 0 ? fptr + Kmax : fptr - Kmax;
+        par ^= 1;
+        lds_barrier();
+      }
+      // (beta: the chunk's last step published plain beta -- no factor past the chunk -- which is what the
+      // renormalisation and the next chunk's first step expect)
+    };
+    // The chunk's per-slot offsets at once, outside the frame loop (n <= 16 frames): lane i of every row of 16 takes
+    // the chunk's i-th frame in sweep order, an inclusive prefix sum over the row (DPP) gives the offset after each
+    // frame, wave 0 stores them in one instruction.  Inside the loop the same bookkeeping was an LDS read whose wait
+    // sat in front of every frame's barrier.
+    double chunk_log2;
+    {
+      const int li = tid & 15;
+      const float rsel = rtile[(DIR == 0 ? li : n - 1 - li) & 15];
+      double pre = li < n ? ((double)rsel + (double)wref) * kLog2e_d : 0.0;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const int lo = __double2loint(pre), hi = __double2hiint(pre);  // row_shr:o, lanes without a source read 0
+        const int slo = o == 1   ? __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true)
+                        : o == 2 ? __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true)
+                        : o == 4 ? __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true)
+                                 : __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true);
+        const int shi = o == 1   ? __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true)
+                        : o == 2 ? __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true)
+                        : o == 4 ? __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true)
+                                 : __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true);
+        pre += __hiloint2double(shi, slo);
+      }
+      if (tid < n) offs[DIR == 0 ? f0 + tid + 1 : f0 + n - 1 - tid] = cum + pre;
+      chunk_log2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pre), 15),
+                                    __builtin_amdgcn_readlane(__double2loint(pre), 15));  // (lanes >= n added 0)
+    }
+    // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
+    if (uniform && deg_class == 0)
+      frames_uniform(std::integral_constant<int, 2>{});
+    else if (uniform && deg_class == 1)
+      frames_uniform(std::integral_constant<int, 4>{});
+    else if (uniform)
+      frames_uniform(std::integral_constant<int, kLeanDeg>{});
+    else if (deg_class == 0)
+      frames(std::integral_constant<int, 2>{});
+    else if (deg_class == 1)
+      frames(std::integral_constant<int, 4>{});
+    else
+      frames(std::integral_constant<int, kLeanDeg>{});
+    cum += chunk_log2;
+    if (c + 1 < nchunks) {
+      float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) dst[e] = pre[j];
+      }
+      if (tid < pn) L.refs[(size_t)((c + 1) & 1) * R + tid] = rpre;
+      __syncthreads();
+    }
+  }
+  // log2 of the total: alpha over the accept states at slot T, beta over the start states at slot 0
+  {
+    const float bw = tid < Q ? (DIR == 0 ? u.accept_w[tid] : u.start_w[tid]) : WFL_NEG_INF;
+    const double tot = block_reduce_sum_f64(bw > WFL_NEG_INF ? p : 0.0, (double*)L.red);
+    if (tid == 0) {
+      const bool ok = tot > 0.0 && tot < 1.0e300;
+      const double z2 = ok ? log2(tot) + cum : (tot == 0.0 ? -__builtin_inf() : __builtin_nan(""));
+      z64[b] = z2;  // log2 Z as this sweep sees it (the certificate compares the two)
+      if (DIR == 0 && logz) logz[b] = (float)(z2 * 0.6931471805599453094);
+    }
+  }
+}
+
+// The probability-domain sweeps as their own kernel (their register budget is not the general path's): utterances it
+// does not take are left to the log-domain launch that follows (chain_kernel, mode 2).
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT)
+    prob_chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                      const float* __restrict__ xg, int T, int rows_per_chunk, const float* __restrict__ weights,
+                      float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz, int64_t tail,
+                      int nch1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef WFL_BAND_PRIO
+#define WFL_BAND_PRIO 0
+#endif
+  if (MAXT == 128 && WFL_BAND_PRIO) __builtin_amdgcn_s_setprio(WFL_BAND_PRIO);
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const UttView u = make_view(d, ints, floats, b, T);
+  double* offs_a = reinterpret_cast<double*>(alpha + tail);  // (tail layout: see chain_kernel)
+  double* offs_b = beta ? reinterpret_cast<double*>(beta + tail) : nullptr;
+  double* za = offs_a + (int64_t)d.B * nch1;
+  double* zb = offs_b ? offs_b + (int64_t)d.B * nch1 : nullptr;
+  int32_t* fmt = reinterpret_cast<int32_t*>(za + d.B);
+  float* wrefs = reinterpret_cast<float*>(fmt + d.B);
+  if (!prob_eligible(u, blockDim.x)) return;
+  ProbLds P;
+  char* p = smem;
+  const size_t nvec = max((size_t)d.max_states, (size_t)blockDim.x);  // (one entry per THREAD: every lane may write)
+  P.buf0 = (double*)p, p += nvec * 8;
+  P.buf1 = (double*)p, p += nvec * 8;
+  P.red = (float*)p, p += 64 * 4;
+  P.rows = (float*)p, p += prob_rows_floats(d, rows_per_chunk) * 4;
+  P.refs = (float*)p;
+  const float* fg = xg + xg_main_dev(d, T);
+  const float* rmax = fg + xg_main_dev(d, T);
+  if (dir == 0) {
+    if (threadIdx.x == 0) fmt[b] = kFmtProb;
+    run_chain_prob<0, MAXT == 128, MAXT <= 512>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
+                      offs_a + (int64_t)b * nch1, za, wrefs, offs_a + (int64_t)d.B * nch1 + 2 * (int64_t)d.B);
+  } else {
+    if (threadIdx.x == 0) zb[d.B + b] = 0.0;  // the certificate's verdict: raised by prob_certify_kernel
+    run_chain_prob<1, MAXT == 128, MAXT <= 512>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
+                      offs_b + (int64_t)b * nch1, zb, nullptr, offs_b + (int64_t)d.B * nch1 + 2 * (int64_t)d.B);
+  }
+}
+
+// Certificate of the probability-domain sweeps.  A double holds a spread of 2^1000 between the largest state and
+// the ones that carry the posteriors; beyond that the latter are flushed, in BOTH sweeps (comparing the two totals is
+// not enough: each sweep can lose a different half of the paths and the halves can weigh the same).  What cannot
+// fail silently is sum_s alpha_t[s] beta_t[s] = Z at every time slot: checked at every 8th slot (a flushed region
+// spans many frames) plus both ends, against the forward sweep's log2 Z, to 1e-4 (the parity bar).  One workgroup per
+// utterance; verdict[b] = 1 sends the utterance to the log-domain launch that follows.
+__global__ void __launch_bounds__(256)
+    prob_certify_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T,
+                        const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt) {
+  // grid (B, kCertSplit): every wave takes the checked slots s = wave index, + number of waves, ... on its own
+  // (wave-level reductions only); a wave that finds a violation raises the utterance's verdict (cleared by the beta
+  // sweep of prob_chain_kernel before it started)
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const UttView u = make_view(d, ints, floats, b, T);
+  const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
+  double* tail_b = reinterpret_cast<double*>(beta + tail);
+  const double* offs_b = tail_b + (int64_t)b * nch1;
+  const double za = (reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * nch1)[b];
+  const double zbv = (tail_b + (int64_t)d.B * nch1)[b];
+  double* verdict = tail_b + (int64_t)d.B * (nch1 + 1) + b;
+  if (!prob_eligible(u, chain_nt)) {
+    if (tid == 0) *verdict = 1.0;  // (not swept in the probability domain at all: the log-domain launch takes it)
+    return;
+  }
+  if (za == -__builtin_inf() && zbv == -__builtin_inf()) return;  // no accepting path: exact in any arithmetic
+  const double* pa = reinterpret_cast<const double*>(alpha) + u.ab_base;
+  const double* pb = reinterpret_cast<const double*>(beta) + u.ab_base;
+  const int Q = u.Q;
+  const int nchk = (T + 7) / 8 + 1;  // slots 0, 8, 16, ... and T
+  const int w0 = blockIdx.y * 4 + (tid >> 6), nw = gridDim.y * 4;
+  bool bad = false;
+  for (int c = w0; c < nchk; c += nw) {
+    const int t = min(c * 8, T);
+    double s = 0.0;
+    for (int q = lane; q < Q; q += 64) s = fma(pa[(int64_t)t * Q + q], pb[(int64_t)t * Q + q], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const double dev = (s > 0.0 && s < 1.0e300) ? fabs(log2(s) + offs_a[t] + offs_b[t] - za) : 1.0e9;
+    bad = bad || !(dev <= 1.0e-4);
+  }
+  if (bad && lane == 0) *verdict = 1.0;
+}
+
+template <int SR>
+__global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                             const float* __restrict__ xg, int T, int rows_per_chunk,
+                             const float* __restrict__ weights, float* __restrict__ alpha, float* __restrict__ beta,
+                             int32_t* __restrict__ bptr, float* __restrict__ logz, int64_t tail, int nch1, int mode) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const UttView u = make_view(d, ints, floats, b, T);
+  // behind the score arrays (wfl_lattice_workspace reserves the room):
+  //   alpha + tail: double offs[B][nch1], double Z[B] (ln Z; log2 Z for probability-domain utterances),
+  //                 int32 fmt[B], float wref[B]
+  //   beta + tail:  double offs[B][nch1], double Z[B] as the backward sweep sees it (probability domain), double
+  //                 verdict[B] of prob_certify_kernel (0: certified, 1: re-run in the log domain)
+  double* offs_a = reinterpret_cast<double*>(alpha + tail);
+  double* offs_b = beta ? reinterpret_cast<double*>(beta + tail) : nullptr;
+  double* za = offs_a + (int64_t)d.B * nch1;
+  double* zb = offs_b ? offs_b + (int64_t)d.B * nch1 : nullptr;
+  int32_t* fmt = reinterpret_cast<int32_t*>(za + d.B);
+  float* wrefs = reinterpret_cast<float*>(fmt + d.B);
+  // mode: 1 = every utterance in the log domain (WFL_LATTICE_DOMAIN=log, tropical semiring);
+  //       2 = the launch after prob_chain_kernel: the log-domain sweeps of what that launch left -- utterances whose
+  //           acceptor it does not take, and those whose two probability-domain sweeps disagree about Z
+  if (SR == WFL_SEMIRING_LOG && mode == 2) {
+    if (prob_eligible(u, blockDim.x)) {
+      if (!zb) return;                 // (forward only: nothing to compare)
+      if (zb[d.B + b] == 0.0) return;  // certified by prob_certify_kernel
+    }
+  }
+  if (SR == WFL_SEMIRING_LOG && dir == 0 && threadIdx.x == 0) fmt[b] = kFmtLog;
+  ChainLds L;
+  char* p = smem;
+  L.arcs = (int2*)p, p += (size_t)d.max_arcs * 8;
+  L.eps = (int2*)p, p += (size_t)d.max_eps * 8;
+  L.ptr = (int*)p, p += (size_t)(d.max_states + 1) * 4;
+  L.eptr = (int*)p, p += (size_t)(d.max_states + 1) * 4;
+  L.buf0 = (float*)p, p += (size_t)d.max_states * 4;
+  L.buf1 = (float*)p, p += (size_t)d.max_states * 4;
+  L.rows = (float*)p, p += (size_t)2 * rows_per_chunk * d.max_labels * 4;
+  L.red = (float*)p, p += 64 * 4;
+  L.lvl = (int*)p, p += (size_t)(d.max_levels + 1) * 4;
+  L.heavy = (int*)p;
+  if (dir == 0)
+    run_chain<SR, 0>(d, u, L, T, rows_per_chunk, xg, weights, alpha, bptr, logz, b, offs_a + (int64_t)b * nch1, za);
+  else
+    run_chain<SR, 1>(d, u, L, T, rows_per_chunk, xg, weights, beta, nullptr, nullptr, b, offs_b + (int64_t)b * nch1,
+                     nullptr);
+}
+
+// threads of the sweep workgroups: one state per thread up to 1024 states (the lean frame paths need it); beyond
+// that threads loop
+static int chain_threads(const wfl_lattice_desc& d) {
+  int nt = d.max_states <= 128 ? 128 : d.max_states <= 256 ? 256 : d.max_states <= 512 ? 512 : 1024;
+  while (nt < 256 && nt * kPre < 2 * d.max_labels) nt += 64;  // two rows per chunk must fit the prefetch registers
+  return nt;
+}
+static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
+  const int nt = chain_threads(d);
+  const size_t prob = (size_t)std::max(d.max_states, nt) * 16 + 64 * 4 + prob_rows_floats(d, rows_per_chunk) * 4 +
+                      (size_t)2 * rows_per_chunk * 4 + 64;
+  return std::max(prob, (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 8 +
+         (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 +
+         (size_t)(d.max_states + 1) * 4 + 64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 3: posteriors -> gradient rows
+// ------------------------------------------------------------------------------------------------
+// (banded acceptors: see band_grad_kernel)
+struct BandArcs {
+  int ok, has_self, has_adj, slot_self, slot_adj, wid_self, wid_adj;
+  float w_self, w_adj;
+};
+// lane = state: its in-arcs if they fit the band (ok = 0 otherwise); -inf arcs do not exist (run_chain_prob)
+__device__ __forceinline__ BandArcs band_in_arcs(const UttView& u, const float* __restrict__ weights, int lane) {
+  BandArcs r{1, 0, 0, 0, 0, -1, -1, WFL_NEG_INF, WFL_NEG_INF};
+  if (lane >= u.Q) return r;
+  const int k0 = u.in_ptr[lane], k1 = u.in_ptr[lane + 1];
+  for (int a = k0; a < k1; ++a) {
+    const int wid = u.arc_wid[a];
+    float w = u.arc_w[a];
+    if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+    w = nan_to_neg(w);
+    if (!(w > WFL_NEG_INF)) continue;
+    const int src = u.arc_src[a];
+    if (src == lane && !r.has_self)
+      r.has_self = 1, r.slot_self = u.arc_slot[a], r.wid_self = wid, r.w_self = w;
+    else if (src == lane - 1 && !r.has_adj)
+      r.has_adj = 1, r.slot_adj = u.arc_slot[a], r.wid_adj = wid, r.w_adj = w;
+    else
+      r.ok = 0;
+  }
+  return r;
+}
+__device__ __forceinline__ bool band_shape(const wfl_lattice_desc& d, const UttView& u) {
+  return u.Q >= 1 && u.Q <= 64 && u.E == 0 && d.max_labels <= 64;
+}
+
+constexpr int kChunk = 16;
+#ifdef WFL_DBG_TIMELINE
+__device__ unsigned long long g_dbg[3 * 8192];
+#endif
+__global__ void __launch_bounds__(256)
+    grad_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                const float* __restrict__ xg, int T, int C, const float* __restrict__ weights,
+                const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
+                const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
+                int accumulate, const float* __restrict__ x, const float* __restrict__ row_lse,
+                float* __restrict__ dx, float* __restrict__ dW, int rows_per_block, int TS, int64_t tail, int nch1,
+                int R, int skip_band) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
+#ifdef WFL_DBG_TIMELINE
+  const unsigned long long dbg_t0 = wall_clock64();
+#endif
+  const UttView u = make_view(d, ints, floats, b, T);
+  const int Q = u.Q, A = u.A, E = u.E, K = u.K, Kmax = d.max_labels;
+  // The dense rows never pass through LDS: posteriors are accumulated per (frame, distinct label)
+  // in a compact tile, and the rows are streamed out as base value (0, the existing gradient, or
+  // the softmax term of the fused log_softmax backward) plus the accumulator of the column's label
+  // slot, looked up in a column -> slot map.
+  // alpha / beta rows of the tile: doubles for utterances swept in the probability domain (fmt[b] == kFmtProb), floats
+  // (in the first half of the same room) for the log domain
+  double* ald = (double*)smem;                              // [TS+1][Qmax]
+  double* bed = ald + (size_t)(TS + 1) * d.max_states;      // [TS+1][Qmax]
+  float* al = (float*)ald;
+  float* be = (float*)bed;
+  float* xr = (float*)(bed + (size_t)(TS + 1) * d.max_states);  // [TS][Kmax]: log scores | factors
+  float* acc = xr + (size_t)TS * Kmax;                      // [TS][Kmax] (only if dx)
+  float* dwacc = acc + (dx ? (size_t)TS * Kmax : 0);        // [A + E] (only if dW)
+  int2* sarc = (int2*)(dwacc + (dW ? (size_t)d.max_arcs + d.max_eps : 0));  // [A] by-slot {src | dst << 16, w - z}
+  int* sptr = (int*)(sarc + (dx ? d.max_arcs : 0));         // [K + 1]
+  // work items of the emission gradient: a slot's arc list in chunks of at most kChunk arcs, so that
+  // the blank column of a CTC-like acceptor (two in-arcs per blank state: hundreds of arcs in ONE
+  // slot) is spread over many threads instead of serialising the tile
+  int2* chunk = (int2*)(sptr + (dx ? ((Kmax + 3) & ~1) : 0));  // [NC] {slot, first arc}; NC <= K + A / kChunk (8-byte aligned)
+  double* corr_d = (double*)(chunk + (dx ? Kmax + d.max_arcs / kChunk + 1 : 0));  // [TS] probability domain: 2^(offsets - log2 Z)
+  float* corr = (float*)(corr_d + 33);  // [TS]: offs_alpha(t) + offs_beta(t+1) - log Z
+  float* corr_eps = corr + 33;          // [TS+1]: both at slot t (epsilon arcs)
+  int16_t* colmap = (int16_t*)(corr_eps + 34);  // [C] (only if dx)
+  // scores are stored relative to per-chunk double offsets (run_chain): slot s of alpha belongs to chunk (s-1)/R of
+  // the forward sweep, slot s of beta to chunk (T-1-s)/R of the backward sweep, the boundary slots to offset 0
+  const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
+  const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
+  const double zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];  // ln Z | log2 Z (prob)
+  const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
+  const float* wrefs = reinterpret_cast<const float*>(fmt + d.B);
+  const bool prob = fmt[b] == kFmtProb;
+  if (skip_band) {  // band_grad_kernel served this utterance (the same test decides there)
+    const int band_ok = band_in_arcs(u, weights, tid).ok;
+    if (__syncthreads_and(band_ok) && prob && band_shape(d, u)) return;
+  }
+  const float wref = prob ? wrefs[b] : 0.f;
+  const float* fgp = xg + xg_main_dev(d, T);                    // probability-domain factors of the gathered rows
+  const float* rmaxp = fgp + xg_main_dev(d, T) + (int64_t)b * T;  // their references
+  const double* alpha_d = reinterpret_cast<const double*>(alpha);
+  const double* beta_d = reinterpret_cast<const double*>(beta);
+  const float g0 = gout ? gout[0] : 1.f;
+  const float cf = coef ? coef[b] * g0 : g0;
+  const float z = logz[b];
+  const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
+  const int t_begin = blockIdx.x * rows_per_block;
+  const int t_end = min(T, t_begin + rows_per_block);
+  const float inv_q = 1.f / (float)max(Q, 1);
+  auto fdiv = [](int i, float inv) { return (int)(((float)i + 0.5f) * inv); };
+  if (dW)
+    for (int a = tid; a < A + E; a += NT) dwacc[a] = 0.f;
+  if (dx) {
+    for (int c = tid; c < C; c += NT) colmap[c] = -1;
+    __syncthreads();
+    for (int k = tid; k < K; k += NT) colmap[u.labels[k]] = (int16_t)k;
+    for (int k = tid; k <= K; k += NT) sptr[k] = u.slot_ptr[k];
+    if (tid == 0) {  // chunk table (a few hundred entries at most, once per workgroup)
+      int nc = 0;
+      for (int k = 0; k < K; ++k)
+        for (int a0 = u.slot_ptr[k]; a0 < u.slot_ptr[k + 1]; a0 += kChunk) chunk[nc++] = make_int2(k, a0);
+      sptr[Kmax + 1] = nc;
+    }
+    for (int j = tid; j < A; j += NT) {
+      const int a = u.slot_arc[j];
+      const int wid = u.arc_wid[a];
+      float w = u.arc_w[a];
+      if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+      if (prob) w = fast_exp(nan_to_neg(w) - wref);  // the arc's factor (run_chain_prob)
+      sarc[j] = make_int2(u.arc_src[a] | (u.arc_dst[a] << 16), __float_as_int(w));
+    }
+  }
+  for (int ts0 = t_begin; ts0 < t_end; ts0 += TS) {
+    const int nr = min(TS, t_end - ts0);
+    __syncthreads();
+    // flat, unrolled copy loops: the global loads of several iterations are in flight together
+    // (idx / n by float reciprocal: exact for idx < 2^20, see fdiv)
+    {
+      const int n = (nr + 1) * Q;
+      if (prob) {
+        const double* asrc = alpha_d + u.ab_base + (int64_t)ts0 * Q;
+        const double* bsrc = beta_d + u.ab_base + (int64_t)ts0 * Q;
+#pragma unroll 4
+        for (int i = tid; i < n; i += NT) {
+          const int r = fdiv(i, inv_q), q = i - r * Q;
+          const double av = asrc[i], bv = bsrc[i];
+          ald[r * d.max_states + q] = av;
+          bed[r * d.max_states + q] = bv;
+        }
+      } else {
+        const float* asrc = alpha + u.ab_base + (int64_t)ts0 * Q;
+        const float* bsrc = beta + u.ab_base + (int64_t)ts0 * Q;
+#pragma unroll 4
+        for (int i = tid; i < n; i += NT) {
+          const int r = fdiv(i, inv_q), q = i - r * Q;
+          const float av = asrc[i], bv = bsrc[i];
+          al[r * d.max_states + q] = av;
+          be[r * d.max_states + q] = bv;
+        }
+      }
+      const float* xsrc = (prob ? fgp : xg) + u.xg_base + (int64_t)ts0 * Kmax;
+#pragma unroll 4
+      for (int i = tid; i < nr * Kmax; i += NT) {
+        xr[i] = xsrc[i];
+        if (dx) acc[i] = 0.f;
+      }
+      if (tid <= nr) {
+        const int sl = ts0 + tid;
+        if (prob) {
+          // gamma_t(arc) = p_alpha[t][src] wf f_t[slot] p_beta[t+1][dst] * 2^(offs_a[t] + offs_b[t+1] + (r_t + wref) log2e - log2 Z)
+          if (tid < nr)
+            corr_d[tid] = exp2(offs_a[sl] + offs_b[sl + 1] + ((double)rmaxp[sl] + (double)wref) * kLog2e_d - zd);
+        } else {
+          const double oa = offs_a[sl == 0 ? 0 : 1 + (sl - 1) / R];
+          corr_eps[tid] = (float)(oa + offs_b[sl == T ? 0 : 1 + (T - 1 - sl) / R] - zd);
+          if (tid < nr) corr[tid] = (float)(oa + offs_b[sl + 1 == T ? 0 : 1 + (T - 2 - sl) / R] - zd);
+        }
+      }
+    }
+    __syncthreads();
+    if (!dead) {
+      // emission gradient: one thread per (frame, emission slot) sums the posteriors of the slot's
+      // arcs (by-slot CSR staged in LDS) -- no atomics, all 256 lanes busy
+      if (dx) {
+        const int NC = sptr[Kmax + 1];
+        const float inv_nc = 1.f / (float)max(NC, 1);
+        for (int i = tid; i < nr * NC; i += NT) {
+          const int r = fdiv(i, inv_nc);
+          const int2 ch = chunk[i - r * NC];
+          const int k = ch.x, j1 = min(ch.y + kChunk, sptr[k + 1]);
+          float sum = 0.f;
+          if (prob) {
+            const double* pa = ald + r * d.max_states;
+            const double* pb = bed + (r + 1) * d.max_states;
+            double dsum = 0.0;
+            for (int j = ch.y; j < j1; ++j) {
+              const int2 a = sarc[j];
+              dsum = fma(pa[a.x & 0xffff] * pb[(unsigned)a.x >> 16], (double)__int_as_float(a.y), dsum);
+            }
+            sum = (float)(dsum * (corr_d[r] * (double)xr[r * Kmax + k]));
+          } else {
+            const float* pa = al + r * d.max_states;
+            const float* pb = pa + (be - al) + d.max_states;
+            const float xv = xr[r * Kmax + k] + corr[r];
+            for (int j = ch.y; j < j1; ++j) {
+              const int2 a = sarc[j];
+              const float v = pa[a.x & 0xffff] + xv + __int_as_float(a.y) + pb[(unsigned)a.x >> 16];
+              sum += fast_exp(v);  // exp(-inf) = 0
+            }
+          }
+          if (sptr[k + 1] - sptr[k] <= kChunk)
+            acc[r * Kmax + k] = sum;  // the slot's only chunk
+          else if (sum != 0.f)
+            atomicAdd(&acc[r * Kmax + k], sum);
+        }
+      }
+      // learnable-weight gradient: one arc per thread, frames of the tile in the inner loop
+      if (dW) {
+        for (int a = tid; a < A; a += NT) {
+          const int wid = u.arc_wid[a];
+          if (wid < 0) continue;
+          const float w = u.arc_w[a] + (weights ? nan_to_neg(weights[wid]) : 0.f);
+          const float* px = xr + u.arc_slot[a];
+          float wsum = 0.f;
+          if (prob) {
+            const double* pa = ald + u.arc_src[a];
+            const double* pb = bed + d.max_states + u.arc_dst[a];
+            double ds = 0.0;
+            for (int r = 0; r < nr; ++r)
+              ds = fma(pa[r * d.max_states] * pb[r * d.max_states], corr_d[r] * (double)px[r * Kmax], ds);
+            wsum = (float)(ds * (double)fast_exp(nan_to_neg(w) - wref));
+          } else {
+            const float* pa = al + u.arc_src[a];
+            const float* pb = be + d.max_states + u.arc_dst[a];
+            for (int r = 0; r < nr; ++r)
+              wsum += fast_exp(pa[r * d.max_states] + (px[r * Kmax] + corr[r]) + w + pb[r * d.max_states]);
+          }
+          if (wsum != 0.f) dwacc[a] += wsum;  // this thread owns dwacc[a]
+        }
+      }
+      if (dW && E > 0 && !prob) {  // (probability-domain utterances have no epsilon arcs)
+        const int nslots = nr + ((ts0 + nr == T) ? 1 : 0);  // epsilon slots t = ts0 .. (T included once)
+        for (int i = tid; i < nslots * E; i += NT) {
+          const int r = i / E, e = i - r * E;
+          const int wid = u.eps_wid[e];
+          if (wid < 0) continue;
+          const float w = u.eps_w[e] + (weights ? nan_to_neg(weights[wid]) : 0.f);
+          const float v = al[r * d.max_states + u.eps_src[e]] + w + be[r * d.max_states + u.eps_dst[e]] + corr_eps[r];
+          if (v > WFL_NEG_INF) atomicAdd(&dwacc[A + e], fast_exp(v));
+        }
+      }
+    }
+    if (dx) {
+      __syncthreads();
+      // fused log_softmax backward (ctc.py:107, transducer.py:186-187): with g = cf * posteriors the
+      // gradient w.r.t. the raw scores is g - softmax * sum_c g, and the posteriors of a frame sum to
+      // one, so the base value of a row is -cf * softmax(x)
+      float* gdst = dx + ((int64_t)b * T + ts0) * C;
+      const float* xsrc = row_lse ? x + ((int64_t)b * T + ts0) * C : nullptr;
+      const float* lse = row_lse ? row_lse + (int64_t)b * T + ts0 : nullptr;
+      const bool soft = row_lse && !dead;
+      auto value = [&](int r, int c, float have, float xv, float l) {
+        float v = have;
+        if (soft && l > WFL_NEG_INF) v -= cf * fast_exp(nan_to_neg(xv) - l);
+        const int k = colmap[c];
+        if (k >= 0 && !dead) v += cf * acc[r * Kmax + k];
+        return v;
+      };
+      if (C >= 512) {
+        // wide rows: one float4 per thread and row (rows are only 4-byte aligned: scalar head / tail)
+        const int64_t e0 = ((int64_t)b * T + ts0) * C;
+        for (int r = 0; r < nr; ++r) {
+          const int head = (int)((4 - ((e0 + (int64_t)r * C) & 3)) & 3);
+          const int nvec = (C - head) >> 2;
+          float* grow = gdst + (int64_t)r * C;
+          const float* xrow = soft ? xsrc + (int64_t)r * C : nullptr;
+          const float l = soft ? lse[r] : 0.f;
+          for (int j = tid; j < nvec; j += NT) {
+            const int c = head + 4 * j;
+            float4 have = make_float4(0.f, 0.f, 0.f, 0.f), xv = have;
+            if (accumulate) have = *reinterpret_cast<const float4*>(grow + c);
+            if (soft) xv = *reinterpret_cast<const float4*>(xrow + c);
+            float4 o;
+            o.x = value(r, c, have.x, xv.x, l), o.y = value(r, c + 1, have.y, xv.y, l);
+            o.z = value(r, c + 2, have.z, xv.z, l), o.w = value(r, c + 3, have.w, xv.w, l);
+            *reinterpret_cast<float4*>(grow + c) = o;
+          }
+          const int ntail = C - head - 4 * nvec;  // < 4
+          if (tid < head + ntail) {
+            const int c = tid < head ? tid : head + 4 * nvec + (tid - head);
+            grow[c] = value(r, c, accumulate ? grow[c] : 0.f, soft ? xrow[c] : 0.f, l);
+          }
+        }
+      } else {
+        // narrow rows: a lane owns a column (its label slot looked up once), a wave owns every fourth row
+        const int lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
+        for (int c = lane; c < C; c += 64) {
+          const int k = dead ? -1 : colmap[c];
+#pragma unroll 4
+          for (int r = wv; r < nr; r += nw) {
+            const int i = r * C + c;
+            float v = accumulate ? gdst[i] : 0.f;
+            if (soft) {
+              const float l = lse[r];
+              if (l > WFL_NEG_INF) v -= cf * fast_exp(nan_to_neg(xsrc[i]) - l);
+            }
+            if (k >= 0) v += cf * acc[r * Kmax + k];
+            gdst[i] = v;
+          }
+        }
+      }
+    }
+  }
+  if (dW) {
+    __syncthreads();
+    const float cw = (coef_w ? coef_w[b] : 1.f) * g0;
+    for (int a = tid; a < A + E; a += NT) {
+      const int wid = a < A ? u.arc_wid[a] : u.eps_wid[a - A];
+      const float g = dwacc[a];
+      if (wid >= 0 && g != 0.f) atomicAdd(&dW[wid], g * cw);
+    }
+  }
+#ifdef WFL_DBG_TIMELINE
+  if (tid == 0) {
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 8192) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_dbg[3 * wg] = dbg_t0, g_dbg[3 * wg + 1] = wall_clock64(), g_dbg[3 * wg + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 3 for banded acceptors swept in the probability domain (ASG force alignment, chains without skips: every arc
+// comes from the state itself or from its neighbour, at most 64 states): one WAVE per block of 16 frames, lane = state,
+// no barrier.  The general kernel below stages double-precision tiles of alpha and beta in LDS and walks arc lists
+// behind three barriers per tile -- 170-250 us for the force-alignment lattice of the ASG benchmark, next to which
+// the sweeps take 120; here a lane reads its own alpha (the neighbour's through a DPP wave shift) and beta doubles,
+// forms the two posteriors of its in-arcs, adds them into a compact [16][labels] tile (repeated labels share a
+// slot: LDS float atomics) and the wave expands the tile into the dense rows.  Transition gradients accumulate in
+// two registers per lane over all blocks of the wave: one global atomic per arc and wave.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    band_grad_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                     const float* __restrict__ xg, int T, int C, const float* __restrict__ weights,
+                     const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
+                     const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
+                     int accumulate, float* __restrict__ dx, float* __restrict__ dW, int64_t tail, int nch1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef WFL_BANDGRAD_PRIO
+#define WFL_BANDGRAD_PRIO 0
+#endif
+  if (WFL_BANDGRAD_PRIO) __builtin_amdgcn_s_setprio(WFL_BANDGRAD_PRIO);
+  constexpr int RB = 16;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const UttView u = make_view(d, ints, floats, b, T);
+  const int Q = u.Q, Kmax = d.max_labels;
+  const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
+  const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
+  const double zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];  // log2 Z
+  const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
+  const float wref = reinterpret_cast<const float*>(fmt + d.B)[b];
+  const BandArcs arcs = band_in_arcs(u, weights, lane);
+  const bool shape = fmt[b] == kFmtProb && band_shape(d, u);
+  if (!__syncthreads_and(arcs.ok) || !shape) return;  // the general kernel takes this utterance (same test there)
+  float* acc = reinterpret_cast<float*>(smem) + (size_t)wave * RB * Kmax;  // [RB][Kmax], this wave's
+  int16_t* colmap = reinterpret_cast<int16_t*>(reinterpret_cast<float*>(smem) + (size_t)4 * RB * Kmax);  // [C]
+  if (dx) {
+    for (int c = tid; c < C; c += 256) colmap[c] = -1;
+    __syncthreads();
+    for (int k = tid; k < u.K; k += 256) colmap[u.labels[k]] = (int16_t)k;
+    __syncthreads();
+  }
+  const float g0 = gout ? gout[0] : 1.f;
+  const float cf = coef ? coef[b] * g0 : g0;
+  const float cw = (coef_w ? coef_w[b] : 1.f) * g0;
+  const float z = logz[b];
+  const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
+  const double wfs = arcs.has_self ? (double)fast_exp(arcs.w_self - wref) : 0.0;  // (the sweeps' factors)
+  const double wfa = arcs.has_adj ? (double)fast_exp(arcs.w_adj - wref) : 0.0;
+  // (lanes without a state read the last state's column and multiply it by arc factors of zero: every lane stays
+  // active, so that the per-frame words can be read from ANY lane below -- under `lane < Q` the compiler computes them
+  // for those lanes only)
+  const double* A_ = reinterpret_cast<const double*>(alpha) + u.ab_base + min(lane, Q - 1);
+  const double* B_ = reinterpret_cast<const double*>(beta) + u.ab_base + min(lane, Q - 1);
+  const float* fgu = xg + xg_main_dev(d, T) + u.xg_base;                         // factors of the gathered rows
+  const float* rmu = xg + 2 * xg_main_dev(d, T) + (int64_t)b * T;                // their references
+  const bool one_slot = arcs.slot_self == arcs.slot_adj;
+  double sum_s = 0.0, sum_a = 0.0;
+  const int nblk = (T + RB - 1) / RB, nw = gridDim.x * 4;
+  for (int kb = blockIdx.x * 4 + wave; kb < nblk; kb += nw) {
+    const int t0 = kb * RB, n = min(RB, T - t0);
+    if (dx)
+      for (int i = lane; i < RB * Kmax; i += 64) acc[i] = 0.f;
+    if (!dead) {
+      // gamma_t(arc) = p_alpha[t][src] wf f_t[slot] p_beta[t+1][dst] 2^e_t,
+      // e_t = offs_a[t] + offs_b[t+1] + (r_t + wref) log2e - log2 Z: lane j holds frame t0 + j's as mantissa x 2^exponent
+      double e = 0.0;
+      if (lane < n) e = offs_a[t0 + lane] + offs_b[t0 + lane + 1] + ((double)rmu[t0 + lane] + (double)wref) * kLog2e_d - zd;
+      e = fmin(fmax(e, -2000.0), 2000.0);
+      const double ef = floor(e);
+      const float cm = __builtin_amdgcn_exp2f((float)(e - ef));
+      const int ce = (int)ef;
+      // (eight frames at a time: sixteen frames of operands in flight cost the fourth wave per SIMD)
+      constexpr int HB = RB / 2;
+#pragma unroll 1
+      for (int h = 0; h < RB; h += HB) {
+        if (h >= n) break;
+        double pa[HB], pb[HB];
+        float fs[HB], fa[HB];
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {  // (rows past the end: the last one again, not consumed)
+          const int t = t0 + min(h + j, n - 1);
+          pa[j] = A_[(int64_t)t * Q], pb[j] = B_[(int64_t)(t + 1) * Q];
+          fs[j] = fgu[(int64_t)t * Kmax + arcs.slot_self], fa[j] = fgu[(int64_t)t * Kmax + arcs.slot_adj];
+        }
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          if (h + j < n) {
+            const int lo = __double2loint(pa[j]), hi = __double2hiint(pa[j]);  // the neighbour's alpha (lane 0: none)
+            const double pn = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false),
+                                               __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false));
+            const double cj = ldexp((double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cm), h + j)),
+                                    __builtin_amdgcn_readlane(ce, h + j));
+            const double right = pb[j] * cj;
+            const double ps = pa[j] * wfs * (double)fs[j] * right;
+            const double pd = pn * wfa * (double)fa[j] * right;
+            sum_s += ps, sum_a += pd;
+            if (dx) {
+              float* row = acc + (h + j) * Kmax;
+              if (one_slot) {
+                const float g = (float)(ps + pd);
+                if (g != 0.f) atomicAdd(&row[arcs.slot_self], g);
+              } else {
+                if (ps != 0.0) atomicAdd(&row[arcs.slot_self], (float)ps);
+                if (pd != 0.0) atomicAdd(&row[arcs.slot_adj], (float)pd);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (dx) {
+      // the block's rows are contiguous: dense row value = cf * (the tile entry of the column's label slot)
+      float* g = dx + ((int64_t)b * T + t0) * C;
+      const int total = n * C;
+      const float inv_c = 1.f / (float)C;
+      if ((C & 3) == 0) {
+        for (int i4 = lane; i4 < (total >> 2); i4 += 64) {
+          const int i = i4 << 2;
+          const int r = (int)(((float)i + 0.5f) * inv_c), c = i - r * C;  // (exact for i < 2^20)
+          float4 v = accumulate ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const int k0 = colmap[c], k1 = colmap[c + 1], k2 = colmap[c + 2], k3 = colmap[c + 3];
+          if (k0 >= 0) v.x += cf * acc[r * Kmax + k0];
+          if (k1 >= 0) v.y += cf * acc[r * Kmax + k1];
+          if (k2 >= 0) v.z += cf * acc[r * Kmax + k2];
+          if (k3 >= 0) v.w += cf * acc[r * Kmax + k3];
+          *reinterpret_cast<float4*>(g + i) = v;
+        }
+      } else {
+        for (int i = lane; i < total; i += 64) {
+          const int r = (int)(((float)i + 0.5f) * inv_c), c = i - r * C;
+          const int k = colmap[c];
+          float v = accumulate ? g[i] : 0.f;
+          if (k >= 0) v += cf * acc[r * Kmax + k];
+          g[i] = v;
+        }
+      }
+    }
+  }
+  if (dW && !dead && lane < Q) {
+    if (arcs.wid_self >= 0 && sum_s != 0.0) atomicAdd(&dW[arcs.wid_self], (float)sum_s * cw);
+    if (arcs.wid_adj >= 0 && sum_a != 0.0) atomicAdd(&dW[arcs.wid_adj], (float)sum_a * cw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tropical back-trace: one thread per utterance
+// ------------------------------------------------------------------------------------------------
+__global__ void backtrace_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                                 const float* __restrict__ alpha, const int32_t* __restrict__ bptr, int T,
+                                 int32_t* __restrict__ path, int32_t* __restrict__ path_len, int path_stride) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.B) return;
+  const UttView u = make_view(d, ints, floats, b, T);
+  const int Q = u.Q, A = u.A;
+  int best = -1;
+  float bs = WFL_NEG_INF;
+  for (int q = 0; q < Q; ++q) {
+    const float v = alpha[u.ab_base + (int64_t)T * Q + q] + u.accept_w[q];
+    if (v > bs) bs = v, best = q;
+  }
+  int32_t* out = path + (int64_t)b * path_stride;
+  int n = 0;
+  if (best >= 0) {
+    int q = best, t = T;
+    while (n < path_stride) {
+      const int bp = bptr[u.ab_base + (int64_t)t * Q + q];
+      if (bp < 0) break;
+      if (bp < A) {
+        out[n++] = u.arc_orig[bp];
+        q = u.arc_src[bp];
+        --t;
+      } else {
+        out[n++] = u.eps_orig[bp - A];
+        q = u.eps_src[bp - A];
+      }
+    }
+    for (int i = 0, j = n - 1; i < j; ++i, --j) {
+      const int tmp = out[i];
+      out[i] = out[j], out[j] = tmp;
+    }
+  } else {
+    n = -1;  // no accepting path
+  }
+  path_len[b] = n;
+}
+
+__global__ void reduce_loss_kernel(const float* __restrict__ vals, const float* __restrict__ minus,
+                                   const float* __restrict__ scale, int B, float sign, int accumulate,
+                                   float* __restrict__ out) {
+  __shared__ float red[64];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x)
+    s += sign * (scale ? scale[b] : 1.f) * (minus ? vals[b] - minus[b] : vals[b]);
+  s = block_reduce_sum(s, red);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s / (float)B;
+}
+
+// out[r] = logsumexp_c x[r, c] (NaN = -inf): the forward half of a fused log_softmax.  One wave per row,
+// RU rows per iteration with all NV * RU loads of a lane issued before the first use (16 in flight per
+// lane: the kernel is one streaming read of x and needs the bytes in flight to reach HBM speed).
+template <int NV, int RU>
+__global__ void __launch_bounds__(256) row_lse_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RU; r0 < rows; r0 += nw * RU) {
+    float v[RU][NV];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const float* row = x + min(r0 + u, rows - 1) * C;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[u][i] = c < C ? row[c] : WFL_NEG_INF;
+      }
+    }
+    float m[RU], sum[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      m[u] = WFL_NEG_INF;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[u][i] = nan_to_neg(v[u][i]), m[u] = fmaxf(m[u], v[u][i]);
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) m[u] = wave_all_max(m[u]);  // (DPP; the __shfl reductions go through LDS)
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      sum[u] = 0.f;
+      if (m[u] > WFL_NEG_INF) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum[u] += fast_exp(v[u][i] - m[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) sum[u] = wave_all_sum(sum[u]);
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (lane == 0 && r0 + u < rows) out[r0 + u] = m[u] > WFL_NEG_INF ? m[u] + fast_log(sum[u]) : WFL_NEG_INF;
+  }
+}
+
+// any C: two passes over the row (the second one hits L2)
+__global__ void __launch_bounds__(256) row_lse_wide_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                            float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const float* row = x + r * C;
+    float m = WFL_NEG_INF;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, nan_to_neg(row[c]));
+    m = wave_max(m);
+    float s = 0.f;
+    if (m > WFL_NEG_INF)
+      for (int c = lane; c < C; c += 64) s += fast_exp(nan_to_neg(row[c]) - m);
+    s = wave_sum(s);
+    if (lane == 0) out[r] = m > WFL_NEG_INF ? m + fast_log(s) : WFL_NEG_INF;
+  }
+}
+
+// dst[0..nbytes) = src[0..nbytes): `src` is pinned host memory read through its device-visible address (a kernel
+// launch never waits for the stream to drain; hipMemcpyAsync from pinned memory sometimes does, see wfl_upload)
+__global__ void __launch_bounds__(256) upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
+                                                      int64_t nbytes) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0) {
+    const int64_t done = n16 * 16;
+    if ((int64_t)threadIdx.x < nbytes - done)
+      reinterpret_cast<uint8_t*>(dst)[done + threadIdx.x] = reinterpret_cast<const uint8_t*>(src)[done + threadIdx.x];
+  }
+}
+
+// v *= s[0], skipped when s[0] == 1 (the usual upstream gradient of a scalar loss)
+__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ v, int64_t n4, int64_t n, const float* __restrict__ s) {
+  const float f = s[0];
+  if (f == 1.f) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 t = v4[i];
+    t.x *= f, t.y *= f, t.z *= f, t.w *= f;
+    v4[i] = t;
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] *= f;
+}
+
+}  // namespace wfl
+
+using namespace wfl;
+
+extern "C" {
+
+static int64_t xg_main(const wfl_lattice_desc& d, int T) { return (((int64_t)d.B * T * d.max_labels) + 3) & ~(int64_t)3; }
+
+// Launch shape of the chain kernel: threads per workgroup and emission rows per chunk (also the renormalisation
+// interval, so the gradient kernel needs the same number).
+static void chain_config(const wfl_lattice_desc& d, int& nt, int& rpc) {
+  nt = chain_threads(d);
+  rpc = std::max(2, std::min(16, nt * kPre / std::max(1, d.max_labels)) & ~1);  // even (run_chain)
+}
+// scores (float | double) [..] | double offs[B][nch1] | double Z[B] | int32 fmt[B] | float wref[B]   (see chain_kernel)
+static int64_t ab_main_elems(const wfl_lattice_desc& d, int T) {  // (float units; room for doubles)
+  return 2 * (d.shared ? (int64_t)d.B * (T + 1) * d.max_states : (int64_t)(T + 1) * d.total_states);
+}
+static void ab_tail(const wfl_lattice_desc& d, int T, int64_t& tail, int& nch1) {
+  nch1 = T + 1;  // one offset per time slot (probability domain); the log domain uses one per chunk
+  tail = ab_main_elems(d, T);
+}
+
+int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, int64_t* ab_elems) {
+  if (!d || T < 0) {
+    set_error("lattice_workspace: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  // xg: log-domain rows | probability-domain factors of the same rows | one reference per row
+  if (xg_elems) *xg_elems = 2 * xg_main(*d, T) + (int64_t)d->B * T;
+  if (ab_elems) {
+    int64_t tail;
+    int nch1;
+    ab_tail(*d, T, tail, nch1);
+    // (+ kDumpDoubles doubles behind the tail: where the lanes without a state of the unrolled sweeps "store")
+    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2 + 2 * kDumpDoubles;
+  }
+  return WFL_OK;
+}
+
+static int check_desc(const wfl_lattice_desc* d, const char* who) {
+  if (!d || d->B <= 0) {
+    set_error("%s: empty batch", who);
+    return WFL_ERR_INVALID;
+  }
+  if (d->max_states > 65535 || d->max_labels > 65535) {
+    set_error("%s: lattice too large (states=%d labels=%d; limit 65535)", who, d->max_states, d->max_labels);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  return WFL_OK;
+}
+
+int wfl_lattice_gather(const wfl_lattice_desc* d, const int32_t* ints, const float* x, int T, int C, float* xg,
+                       float* row_lse, void* stream) {
+  if (int rc = check_desc(d, "lattice_gather")) return rc;
+  if (T <= 0) return WFL_OK;
+  auto launch = [&](auto kern, int ru) {
+    dim3 grid((unsigned)std::min(1024, (T + 4 * ru - 1) / (4 * ru)), (unsigned)d->B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, *d, ints, x, T, C, xg, row_lse, xg + xg_main(*d, T),
+                       xg + 2 * xg_main(*d, T));
+  };
+  if (!row_lse || C > 1024)
+    launch(gather_kernel, 1);
+  else if (C <= 128)
+    launch(gather_lse_kernel<2, 4>, 4);
+  else if (C <= 256)
+    launch(gather_lse_kernel<4, 2>, 2);
+  else if (C <= 512)
+    launch(gather_lse_kernel<8, 1>, 1);
+  else
+    launch(gather_lse_kernel<16, 1>, 1);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T,
+                        const float* weights, int semiring, float* alpha, float* beta, int32_t* bptr, float* logz,
+                        void* stream) {
+  if (int rc = check_desc(d, "lattice_forward")) return rc;
+  if (!alpha || !logz) {
+    set_error("lattice_forward: alpha and logz are required");
+    return WFL_ERR_INVALID;
+  }
+  if (d->max_labels > 4 * 256) {
+    set_error("lattice_forward: %d distinct labels per utterance (limit 1024)", d->max_labels);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  int nt, rpc, nch1;
+  int64_t tail;
+  chain_config(*d, nt, rpc);
+  ab_tail(*d, T, tail, nch1);
+  const size_t lds = chain_lds_bytes(*d, rpc);
+  if (lds > (size_t)kLdsBytes) {
+    set_error("lattice_forward: acceptor needs %zu B of LDS (limit %d): %d arcs, %d states", lds, kLdsBytes,
+              d->max_arcs, d->max_states);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  if (semiring == WFL_SEMIRING_LOG) {
+    dim3 grid((unsigned)d->B, beta ? 2u : 1u);
+    auto k = chain_kernel<WFL_SEMIRING_LOG>;
+    if (lds > 48 * 1024)
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)k, (int)lds));
+    static const int log_only = [] {  // WFL_LATTICE_DOMAIN=log: the fp32 log-domain sweeps throughout (A/B tests)
+      const char* e = getenv("WFL_LATTICE_DOMAIN");
+      return (e && std::string(e) == "log") ? 1 : 0;
+    }();
+    if (!log_only) {
+      // probability-domain sweeps of every utterance whose acceptor allows it ...
+      auto launch_prob = [&](auto kern) {
+        if (lds > 48 * 1024)
+          (void)wfl::set_max_dynamic_lds((const void*)kern, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
+                           beta, logz, tail, nch1);
+      };
+      if (nt == 128 && d->max_states <= 64)
+        launch_prob(prob_chain_kernel<128>);  // chain wave + loader wave (the banded sweep)
+      else if (nt <= 256)
+        launch_prob(prob_chain_kernel<256>);
+      else if (nt <= 512)
+        launch_prob(prob_chain_kernel<512>);
+      else
+        launch_prob(prob_chain_kernel<1024>);
+      if (beta)
+        hipLaunchKernelGGL(prob_certify_kernel, dim3((unsigned)d->B, 8u), dim3(256), 0, (hipStream_t)stream, *d, ints,
+                           floats, T, alpha, beta, tail, nch1, nt);
+    }
+    // ... then the log-domain sweeps of the rest (and of utterances whose two sweeps disagree: the certificate)
+    hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
+                       beta, (int32_t*)nullptr, logz, tail, nch1, log_only ? 1 : 2);
+  } else if (semiring == WFL_SEMIRING_TROPICAL) {
+    if (!bptr) {
+      set_error("lattice_forward: tropical semiring needs a back-pointer buffer");
+      return WFL_ERR_INVALID;
+    }
+    dim3 grid((unsigned)d->B, 1u);
+    auto k = chain_kernel<WFL_SEMIRING_TROPICAL>;
+    if (lds > 48 * 1024)
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)k, (int)lds));
+    hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
+                       (float*)nullptr, bptr, logz, tail, nch1, 1);
+  } else {
+    set_error("lattice_forward: unknown semiring %d", semiring);
+    return WFL_ERR_INVALID;
+  }
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T, int C,
+                     const float* weights, const float* alpha, const float* beta, const float* logz, const float* coef,
+                     const float* coef_w, const float* gout, int accumulate, const float* x, const float* row_lse,
+                     float* dx, float* dW, void* stream) {
+  if (int rc = check_desc(d, "lattice_grad")) return rc;
+  if ((row_lse != nullptr) != (x != nullptr)) {
+    set_error("lattice_grad: the fused log-softmax backward needs both x and row_lse");
+    return WFL_ERR_INVALID;
+  }
+  if (!alpha || !beta || !logz || (!dx && !dW)) {
+    set_error("lattice_grad: alpha, beta, logz and at least one output are required");
+    return WFL_ERR_INVALID;
+  }
+  if (T <= 0) return WFL_OK;
+  // frames per LDS sub-tile: alpha, beta, gathered emissions and the per-label accumulators of TS
+  // frames; ~40 KiB at most so that several workgroups are co-resident (each one is a load ->
+  // barrier -> compute -> barrier -> stream-out sequence, overlap comes from co-residency).  Measured on MI355X
+  // (kernel us at 24 / 32 / 40 / 48 KiB): Transducer cfg4 (263 states, 917 arcs: ONE frame per tile at 24 KiB)
+  // 301 / 230 / 239 / 283; ASG force alignment alone 81 / 112 / 78 / 78, under the denominator sweeps 220 / 198 / 174.
+  const size_t row_bytes = 16 * (size_t)d->max_states + 4 * (size_t)d->max_labels * (dx ? 2 : 1);  // (alpha, beta: doubles)
+  const size_t fixed = 16 * (size_t)d->max_states + 4 * (dW ? (size_t)d->max_arcs + d->max_eps : 0) +
+                       (dx ? 8 * (size_t)d->max_arcs + 4 * (((size_t)d->max_labels + 3) & ~(size_t)1) +
+                                8 * ((size_t)d->max_labels + d->max_arcs / kChunk + 1) + 2 * (size_t)C
+                          : 0) +
+                       8 * 33 + 4 * (33 + 34) + 64;  // (+ the per-row offset corrections of at most 32 + 1 rows)
+  if (dx && d->max_labels > 32767) {
+    set_error("lattice_grad: %d distinct labels per utterance (limit 32767)", d->max_labels);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  int nt_chain, rpc, nch1;
+  int64_t tail;
+  chain_config(*d, nt_chain, rpc);
+  ab_tail(*d, T, tail, nch1);
+  static const size_t budget = [] {  // (WFL_GRAD_LDS_KB: tuning knob)
+    const char* e = getenv("WFL_GRAD_LDS_KB");
+    return (size_t)(e ? atoi(e) : 40) * 1024;
+  }();
+  int TS = fixed + row_bytes < budget ? (int)((budget - fixed) / row_bytes) : 1;
+  TS = std::max(1, std::min(TS, 32));
+  const size_t lds = fixed + row_bytes * TS;
+  if (lds > (size_t)kLdsBytes) {
+    set_error("lattice_grad: needs %zu B of LDS (limit %d)", lds, kLdsBytes);
+    return WFL_ERR_UNSUPPORTED;
+  }
+  // Every workgroup takes about the same time and they all fit the chip at once only up to
+  // (resident workgroups per CU) x 256: a grid slightly above that costs a whole second round
+  // (measured: 1856 workgroups on 1536 slots = 2 x 250 us).  Size the grid to ONE round.
+  int per_cu = 1;
+  {  // (the occupancy query costs a few microseconds of host time: remember the last answer)
+    static std::mutex mu;
+    static size_t last_lds = ~(size_t)0;
+    static int last_per_cu = 1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (lds != last_lds) {
+      int n = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, grad_kernel, 256, lds) != hipSuccess || n < 1) n = 1;
+      last_lds = lds, last_per_cu = n;
+    }
+    per_cu = last_per_cu;
+  }
+  const int slots = per_cu * 256;
+  int blocks_t = std::max(1, std::min((T + TS - 1) / TS, slots / std::max(1, d->B)));
+  int rows_per_block = (T + blocks_t - 1) / blocks_t;
+  blocks_t = (T + rows_per_block - 1) / rows_per_block;
+  // banded acceptors swept in the probability domain go to band_grad_kernel; the general launch skips them
+  const char* band_env = getenv("WFL_LATTICE_BAND_GRAD");  // (0: the general kernel for everything -- tests, measurements)
+  const bool band_off = band_env && atoi(band_env) == 0;
+  const int band = !band_off && d->max_states <= 64 && d->max_labels <= 64 && d->max_eps == 0 && !row_lse;
+  if (band) {
+    const int nblk = (T + 15) / 16;
+    const unsigned bx = (unsigned)std::max(1, std::min((nblk + 3) / 4, (1024 + d->B - 1) / d->B));
+    const size_t blds = (size_t)4 * 16 * d->max_labels * 4 + (size_t)2 * C + 16;
+    hipLaunchKernelGGL(band_grad_kernel, dim3(bx, (unsigned)d->B), dim3(256), blds, (hipStream_t)stream, *d, ints, floats,
+                       xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, dx, dW, tail, nch1);
+    WFL_LAUNCH_CHECK();
+  }
+  if (lds > 48 * 1024)
+    WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)grad_kernel, (int)lds));
+  hipLaunchKernelGGL(grad_kernel, dim3((unsigned)blocks_t, (unsigned)d->B), dim3(256), lds, (hipStream_t)stream, *d,
+                     ints, floats, xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, x, row_lse,
+                     dx, dW, rows_per_block, TS, tail, nch1, rpc, band);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_lattice_backtrace(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* alpha,
+                          const int32_t* bptr, int T, int32_t* path, int32_t* path_len, int path_stride, void* stream) {
+  if (int rc = check_desc(d, "lattice_backtrace")) return rc;
+  hipLaunchKernelGGL(backtrace_kernel, dim3((unsigned)((d->B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *d, ints,
+                     floats, alpha, bptr, T, path, path_len, path_stride);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+#ifdef WFL_DBG_TIMELINE
+int wfl_debug_timeline(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
+}
+#endif
+// diagnostic: resident workgroups per CU of the gradient kernel for a given dynamic LDS size
+int wfl_debug_grad_occupancy(int lds_bytes) {
+  int n = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, grad_kernel, 256, (size_t)lds_bytes) != hipSuccess) return -1;
+  return n;
+}
+
+int wfl_row_lse(const float* x, int64_t rows, int C, float* out, void* stream) {
+  if (!x || !out || rows < 0 || C <= 0) {
+    set_error("row_lse: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  if (rows == 0) return WFL_OK;
+  auto launch = [&](auto kern, int ru) {
+    const unsigned grid = (unsigned)std::min<int64_t>((rows + 4 * ru - 1) / (4 * ru), 1 << 16);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, rows, C, out);
+  };
+  if (C <= 64)
+    launch(row_lse_kernel<1, 16>, 16);
+  else if (C <= 128)
+    launch(row_lse_kernel<2, 8>, 8);
+  else if (C <= 256)
+    launch(row_lse_kernel<4, 4>, 4);
+  else if (C <= 512)
+    launch(row_lse_kernel<8, 2>, 2);
+  else if (C <= 1024)
+    launch(row_lse_kernel<16, 1>, 1);
+  else
+    launch(row_lse_wide_kernel, 1);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_upload(void* dst, const void* src_pinned, int64_t nbytes, void* stream) {
+  if (!dst || !src_pinned || nbytes < 0 || (((uintptr_t)dst | (uintptr_t)src_pinned) & 15)) {
+    set_error("upload: bad arguments (both buffers must be 16-byte aligned)");
+    return WFL_ERR_INVALID;
+  }
+  if (nbytes == 0) return WFL_OK;
+  const int64_t n16 = nbytes / 16;
+  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (n16 + 255) / 256));
+  hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(src_pinned),
+                     reinterpret_cast<uint4*>(dst), n16, nbytes);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_scale(float* v, int64_t n, const float* s, void* stream) {
+  if (!v || !s || n < 0 || (((uintptr_t)v) & 15)) {
+    set_error("scale: bad arguments (v must be 16-byte aligned)");
+    return WFL_ERR_INVALID;
+  }
+  if (n == 0) return WFL_OK;
+  // (grid-stride; 512 workgroups keep 2 MB in flight -- enough for HBM speed when there is something to scale -- and
+  // cost half of what 2048 did when s[0] == 1 and every workgroup returns at once: that launch sits on the critical
+  // path of every backward of a scalar loss)
+  const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512, (n / 4 + 255) / 256));
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, n / 4, n, s);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_reduce_loss(const float* vals, const float* minus, const float* scale, int B, float sign, int accumulate,
+                    float* out, void* stream) {
+  if (B <= 0 || !vals || !out) {
+    set_error("reduce_loss: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, vals, minus, scale, B, sign,
+                     accumulate, out);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+}  // extern "C"

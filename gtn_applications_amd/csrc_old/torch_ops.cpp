@@ -1,0 +1,357 @@
+// Autograd nodes of the criteria's hot operator paths, in C++ (module gtn_applications_amd._wfl_torch).
+//
+// The kernels of the CTC step take ~60 us at the reference's benchmark shape; a Python torch.autograd.Function
+// around them costs more than that in interpreter time alone (apply() bookkeeping, the engine's call back into
+// Python for backward, tensor wrapping of the saved state).  This file is the same operator -- counterpart of
+// CTCLossFunction.forward / backward, /root/reference/criterions/ctc.py:31-93 -- as a torch::autograd::Function that
+// calls the C ABI of libwfl.so (include/wfl.h) directly.  Host-side plumbing only: no arithmetic happens here.
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+#include <torch/csrc/autograd/python_variable.h>
+#include <torch/extension.h>
+
+#include <list>
+#include <map>
+#include <string>
+#include <unordered_map>
+
+#include "../../include/wfl.h"
+
+namespace {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+void* current_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check(int rc, const char* what) { TORCH_CHECK(rc == WFL_OK, what, ": ", wfl_last_error()); }
+
+// Loss and gradient of a CTC batch in ONE pipelined launch (wfl_ctc_forward_backward); backward only applies the
+// upstream scalar to the gradient computed here (like torch's own CTC the gradient is produced eagerly).
+//   staged: the uint8 device buffer of engine.CtcTargets (offsets | flat labels | per-utterance factors), addressed
+//   by the byte offsets that follow; ws / nll: the per-stream scratch of engine.ctc_workspace; lse: optional row
+//   log-sum-exps of x (fused log_softmax, ctc.py:107).
+struct CtcStep : public torch::autograd::Function<CtcStep> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& staged, int64_t off_offsets,
+                            int64_t off_flat, int64_t off_scale, int64_t off_coef, int64_t max_len, int64_t blank,
+                            const at::Tensor& ws, const at::Tensor& nll, const c10::optional<at::Tensor>& lse) {
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous() && x.dim() == 3,
+                "ctc_step: x must be a contiguous float32 [B,T,C] device tensor");
+    const auto B = x.size(0), T = x.size(1), C = x.size(2);
+    at::Tensor dx = at::empty_like(x);
+    at::Tensor loss = at::empty({}, x.options());
+    const char* base = static_cast<const char*>(staged.data_ptr());
+    const float* lse_p = lse.has_value() && lse->defined() ? lse->data_ptr<float>() : nullptr;
+    check(wfl_ctc_forward_backward(x.data_ptr<float>(), (int)B, (int)T, (int)C,
+                                   reinterpret_cast<const int32_t*>(base + off_flat),
+                                   reinterpret_cast<const int64_t*>(base + off_offsets), (int)max_len, (int)blank,
+                                   ws.data_ptr<float>(), nll.data_ptr<float>(),
+                                   reinterpret_cast<const float*>(base + off_coef), nullptr, dx.data_ptr<float>(),
+                                   reinterpret_cast<const float*>(base + off_scale), loss.data_ptr<float>(), lse_p,
+                                   current_stream(x)),
+          "ctc_step");
+    ctx->saved_data["x"] = x.detach();
+    ctx->saved_data["staged"] = staged;
+    ctx->saved_data["ws"] = ws;
+    ctx->saved_data["nll"] = nll;
+    ctx->saved_data["dx"] = dx;
+    if (lse_p) ctx->saved_data["lse"] = *lse;
+    ctx->saved_data["ints"] = std::vector<int64_t>{off_offsets, off_flat, off_coef, max_len, blank};
+    return loss;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::Tensor x = ctx->saved_data["x"].toTensor();
+    if (!grads[0].defined())  // (the loss did not take part in what is being differentiated)
+      return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+              at::Tensor(), at::Tensor(), at::Tensor()};
+    at::Tensor g = grads[0].detach().reshape({1});
+    if (!g.is_cuda() || g.scalar_type() != at::kFloat) g = g.to(x.device(), at::kFloat);
+    auto it = ctx->saved_data.find("dx");
+    at::Tensor dx;
+    if (it != ctx->saved_data.end() && it->second.isTensor() && it->second.toTensor().defined()) {
+      dx = it->second.toTensor();
+      ctx->saved_data.erase(it);  // handed out (and scaled in place) once
+      check(wfl_scale(dx.data_ptr<float>(), dx.numel(), g.data_ptr<float>(), current_stream(x)), "ctc_step backward");
+    } else {
+      // a second backward through a retained graph: the same launch again into a fresh buffer, the upstream scalar
+      // applied by the kernel (with the same row log-sum-exps when the log_softmax is fused)
+      const auto v = ctx->saved_data["ints"].toIntVector();
+      at::Tensor staged = ctx->saved_data["staged"].toTensor(), ws = ctx->saved_data["ws"].toTensor(),
+                 nll = ctx->saved_data["nll"].toTensor();
+      const char* base = static_cast<const char*>(staged.data_ptr());
+      auto l = ctx->saved_data.find("lse");
+      const float* lse_p = l != ctx->saved_data.end() ? l->second.toTensor().data_ptr<float>() : nullptr;
+      dx = at::empty_like(x);
+      check(wfl_ctc_forward_backward(x.data_ptr<float>(), (int)x.size(0), (int)x.size(1), (int)x.size(2),
+                                     reinterpret_cast<const int32_t*>(base + v[1]),
+                                     reinterpret_cast<const int64_t*>(base + v[0]), (int)v[3], (int)v[4],
+                                     ws.data_ptr<float>(), nll.data_ptr<float>(),
+                                     reinterpret_cast<const float*>(base + v[2]), g.data_ptr<float>(),
+                                     dx.data_ptr<float>(), nullptr, nullptr, lse_p, current_stream(x)),
+            "ctc_step backward");
+    }
+    return {dx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+            at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Targets of a batch, staged and uploaded without passing through Python objects: what engine.CtcTargets does
+// (flatten list-of-int-lists -> [int64 offsets | int32 labels | six per-utterance factor arrays] in a pinned ring ->
+// one wfl_upload -> small content-keyed cache), for the one operator whose kernels are shorter than that Python code.
+// ------------------------------------------------------------------------------------------------------------
+struct StagedTargets {
+  at::Tensor dev_buf;  // uint8, device
+  std::string key_bytes;  // [offsets | labels] as staged (confirms a cache hit byte for byte)
+  int64_t B = 0, n = 0, max_len = 0, off_flat = 0, off_fac = 0;
+  long label_min = 0, label_max = -1;
+  hipStream_t up_stream = nullptr;  // the stream the upload was queued on, and the ring slot whose event follows it
+  int slot = 0;
+};
+
+struct PinnedRing {  // reusable pinned staging buffers; a slot is reused after the upload that read it has completed
+  static constexpr int kSlots = 8;
+  at::Tensor buf[kSlots];
+  hipEvent_t ev[kSlots] = {};
+  int i = 0;
+  uint8_t* next(int64_t need, int& slot) {
+    slot = i = (i + 1) % kSlots;
+    if (ev[slot]) (void)hipEventSynchronize(ev[slot]);
+    if (!buf[slot].defined() || buf[slot].numel() < need) {
+      int64_t cap = 1 << 18;
+      while (cap < need) cap <<= 1;
+      // every slot at once: a pinned allocation costs hundreds of microseconds, and allocating slot by slot would
+      // spread eight of them over the first eight steps of a run instead of paying them in the first one
+      for (int k = 0; k < kSlots; ++k)
+        if (!buf[k].defined() || buf[k].numel() < cap) {
+          if (ev[k]) (void)hipEventSynchronize(ev[k]);
+          buf[k] = at::empty({cap}, at::TensorOptions().dtype(at::kByte).pinned_memory(true));
+        }
+    }
+    return buf[slot].data_ptr<uint8_t>();
+  }
+  void uploaded(int slot, hipStream_t stream) {
+    if (!ev[slot]) (void)hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming);
+    (void)hipEventRecord(ev[slot], stream);
+  }
+};
+
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+inline uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33, k *= 0xff51afd7ed558ccdULL, k ^= k >> 33, k *= 0xc4ceb9fe1a85ec53ULL, k ^= k >> 33;
+  return k;
+}
+std::pair<uint64_t, uint64_t> hash128(const uint8_t* p, int64_t n) {  // MurmurHash3 x64_128 mixing steps
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  uint64_t h1 = 0x9e3779b97f4a7c15ULL, h2 = 0xd1b54a32d192ed03ULL;
+  const int64_t nb = n / 16;
+  for (int64_t i = 0; i < nb; ++i) {
+    uint64_t k1, k2;
+    memcpy(&k1, p + 16 * i, 8), memcpy(&k2, p + 16 * i + 8, 8);
+    k1 *= c1, k1 = rotl64(k1, 31), k1 *= c2, h1 ^= k1, h1 = rotl64(h1, 27), h1 += h2, h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2, k2 = rotl64(k2, 33), k2 *= c1, h2 ^= k2, h2 = rotl64(h2, 31), h2 += h1, h2 = h2 * 5 + 0x38495ab5;
+  }
+  uint64_t t1 = 0, t2 = 0;
+  const int64_t rem = n - 16 * nb;
+  if (rem > 8) memcpy(&t2, p + 16 * nb + 8, (size_t)(rem - 8));
+  if (rem > 0) memcpy(&t1, p + 16 * nb, (size_t)(rem > 8 ? 8 : rem));
+  t2 *= c2, t2 = rotl64(t2, 33), t2 *= c1, h2 ^= t2;
+  t1 *= c1, t1 = rotl64(t1, 31), t1 *= c2, h1 ^= t1;
+  h1 ^= (uint64_t)n, h2 ^= (uint64_t)n, h1 += h2, h2 += h1, h1 = fmix64(h1), h2 = fmix64(h2), h1 += h2, h2 += h1;
+  return {h1, h2};
+}
+
+struct TargetCache {  // per device: ring + LRU of the last 64 distinct batches
+  PinnedRing ring;
+  using Key = std::tuple<uint64_t, uint64_t, int64_t>;
+  std::list<std::pair<Key, std::shared_ptr<StagedTargets>>> lru;
+  std::map<Key, decltype(lru)::iterator> index;
+};
+std::unordered_map<int, TargetCache> g_targets;
+
+// -> staged targets, or nullptr if `targets` is not a list / tuple of lists / tuples of ints (the caller falls back)
+std::shared_ptr<StagedTargets> stage_targets(const py::handle& targets, const at::Device& dev) {
+  PyObject* t = targets.ptr();
+  if (!PyList_Check(t) && !PyTuple_Check(t)) return nullptr;
+  const Py_ssize_t B = PySequence_Fast_GET_SIZE(t);
+  PyObject** rows = PySequence_Fast_ITEMS(t);
+  // rows: lists / tuples of ints (the benchmarks, `[t.tolist() for t in targets]`) or 1-D CPU int tensors (train.py)
+  auto tensor_row = [](PyObject* r) -> const at::Tensor* {
+    if (!THPVariable_Check(r)) return nullptr;
+    const at::Tensor& v = THPVariable_Unpack(r);
+    const bool ok = v.dim() == 1 && v.device().is_cpu() && (v.scalar_type() == at::kLong || v.scalar_type() == at::kInt);
+    return ok ? &v : nullptr;
+  };
+  int64_t total = 0, max_len = 0;
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    int64_t n;
+    if (PyList_Check(rows[b]) || PyTuple_Check(rows[b]))
+      n = PySequence_Fast_GET_SIZE(rows[b]);
+    else if (const at::Tensor* v = tensor_row(rows[b]))
+      n = v->numel();
+    else
+      return nullptr;
+    total += n, max_len = std::max<int64_t>(max_len, n);
+  }
+  TargetCache& tc = g_targets[dev.index()];
+  const int64_t off_flat = 8 * (B + 1), off_fac = (off_flat + 4 * std::max<int64_t>(total, 1) + 7) & ~(int64_t)7;
+  const int64_t nbytes = off_fac + 4 * B * 6;
+  int slot;
+  uint8_t* base = tc.ring.next(nbytes + 16, slot);
+  int64_t* off = reinterpret_cast<int64_t*>(base);
+  int32_t* flat = reinterpret_cast<int32_t*>(base + off_flat);
+  long lo = 0, hi = -1;
+  bool first = true;
+  int64_t k = 0;
+  auto put = [&](long v) {
+    if (v > INT32_MAX || v < INT32_MIN) throw py::value_error("target label does not fit int32");
+    if (first || v < lo) lo = v;
+    if (first || v > hi) hi = v;
+    first = false;
+    flat[k++] = (int32_t)v;
+  };
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    off[b] = k;
+    if (const at::Tensor* v = tensor_row(rows[b])) {
+      const int64_t n = v->numel(), st = n ? v->stride(0) : 1;
+      if (v->scalar_type() == at::kLong) {
+        const int64_t* p = v->data_ptr<int64_t>();
+        for (int64_t i = 0; i < n; ++i) put((long)p[i * st]);
+      } else {
+        const int32_t* p = v->data_ptr<int32_t>();
+        for (int64_t i = 0; i < n; ++i) put((long)p[i * st]);
+      }
+      continue;
+    }
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(rows[b]);
+    PyObject** it = PySequence_Fast_ITEMS(rows[b]);
+    for (Py_ssize_t i = 0; i < n; ++i) {
+      const long v = PyLong_AsLong(it[i]);
+      if (v == -1 && PyErr_Occurred()) {
+        PyErr_Clear();
+        tc.ring.i = (tc.ring.i + PinnedRing::kSlots - 1) % PinnedRing::kSlots;  // slot not used
+        return nullptr;  // not ints: the Python path normalises (numpy ints, ranges, ...)
+      }
+      put(v);
+    }
+  }
+  off[B] = k;
+  const int64_t nkey = off_flat + 4 * total;
+  const auto h = hash128(base, nkey);
+  const TargetCache::Key key{h.first, h.second, nkey};
+  auto hit = tc.index.find(key);
+  if (hit != tc.index.end() && (int64_t)hit->second->second->key_bytes.size() == nkey &&
+      memcmp(hit->second->second->key_bytes.data(), base, (size_t)nkey) == 0) {
+    tc.lru.splice(tc.lru.begin(), tc.lru, hit->second);
+    tc.ring.i = (tc.ring.i + PinnedRing::kSlots - 1) % PinnedRing::kSlots;  // nothing was uploaded from the slot
+    auto& e = hit->second->second;
+    const hipStream_t now = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    // reused on another stream than the one that uploaded it: order this stream behind the upload (the slot's event
+    // may have been re-recorded since -- later on the same stream, which is still behind the upload)
+    if (now != e->up_stream && tc.ring.ev[e->slot]) (void)hipStreamWaitEvent(now, tc.ring.ev[e->slot], 0);
+    return e;
+  }
+  // per-utterance factors (engine._FACTORS order): scale_none, scale_mean, then both times +1/B and -1/B
+  float* fac = reinterpret_cast<float*>(base + off_fac);
+  const float inv_b = 1.0f / (float)(B > 0 ? B : 1);
+  for (Py_ssize_t b = 0; b < B; ++b) {
+    const float ln = (float)(off[b + 1] - off[b]);
+    const float mean = ln > 0.f ? 1.0f / ln : 1.0f;
+    fac[b] = 1.0f, fac[B + b] = mean, fac[2 * B + b] = inv_b, fac[3 * B + b] = mean * inv_b;
+    fac[4 * B + b] = -inv_b, fac[5 * B + b] = mean * -inv_b;
+  }
+  auto st = std::make_shared<StagedTargets>();
+  st->B = B, st->n = total, st->max_len = max_len, st->off_flat = off_flat, st->off_fac = off_fac;
+  st->label_min = lo, st->label_max = hi;
+  st->key_bytes.assign(reinterpret_cast<const char*>(base), (size_t)nkey);
+  st->dev_buf = at::empty({nbytes}, at::TensorOptions().dtype(at::kByte).device(dev));
+  const hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+  check(wfl_upload(st->dev_buf.data_ptr(), base, nbytes, (void*)stream), "stage_targets");
+  tc.ring.uploaded(slot, stream);
+  st->up_stream = stream, st->slot = slot;
+  if (hit != tc.index.end()) {  // (same hash, different bytes: replace)
+    tc.lru.erase(hit->second);
+    tc.index.erase(hit);
+  }
+  tc.lru.emplace_front(key, st);
+  tc.index[key] = tc.lru.begin();
+  if (tc.lru.size() > 64) {
+    tc.index.erase(tc.lru.back().first);
+    tc.lru.pop_back();
+  }
+  return st;
+}
+
+struct WsKey {
+  int dev;
+  void* stream;
+  int64_t B, T, C, L;
+  bool operator<(const WsKey& o) const { return std::tie(dev, stream, B, T, C, L) < std::tie(o.dev, o.stream, o.B, o.T, o.C, o.L); }
+};
+std::map<WsKey, std::pair<at::Tensor, at::Tensor>> g_ws;  // (engine.ctc_workspace: scratch + nll per stream and shape)
+
+// CTCLoss(log_probs, targets, blank, reduction) for the hot case, everything between the Python call and the launch
+// in this one function.  Returns None when the case is not the hot one (the caller takes the Python path).
+py::object ctc_loss_staged(const at::Tensor& x, const std::shared_ptr<StagedTargets>& st, int64_t blank, bool mean,
+                           bool fused_lse, int64_t lim_len, int64_t lim_c, int64_t lim_c_long) {
+  const auto B = x.size(0), T = x.size(1), C = x.size(2);
+  if (!st) return py::none();
+  if (!(st->max_len <= lim_len && C <= (st->max_len <= 63 ? lim_c : lim_c_long))) return py::none();
+  if (st->B != B) throw py::value_error("got " + std::to_string(st->B) + " targets for a batch of " + std::to_string(B));
+  if (st->label_min < 0 || st->label_max >= C) {
+    const long bad = st->label_min < 0 ? st->label_min : st->label_max;
+    throw py::value_error("CTCLoss: target label " + std::to_string(bad) + " is outside [0, " + std::to_string(C) +
+                          ") (emissions have " + std::to_string(C) + " classes)");
+  }
+  if (blank < 0 || blank >= C)
+    throw py::value_error("CTCLoss: blank index " + std::to_string(blank) + " is outside [0, " + std::to_string(C) + ")");
+  void* stream = current_stream(x);
+  const WsKey wk{x.device().index(), stream, B, T, C, st->max_len};
+  auto w = g_ws.find(wk);
+  if (w == g_ws.end()) {
+    int64_t n = 0;
+    check(wfl_ctc_workspace((int)B, (int)T, (int)C, (int)st->max_len, &n), "ctc_workspace");
+    if (g_ws.size() >= 16) g_ws.clear();
+    w = g_ws.emplace(wk, std::make_pair(at::empty({n}, x.options()), at::empty({B}, x.options()))).first;
+  }
+  c10::optional<at::Tensor> lse;
+  if (fused_lse) {
+    lse = at::empty({B, T}, x.options());
+    check(wfl_row_lse(x.data_ptr<float>(), B * T, (int)C, lse->data_ptr<float>(), stream), "row_lse");
+  }
+  const int64_t fac = st->off_fac + 4 * B * (mean ? 1 : 0);  // scale_<reduction>; cneg_<reduction> is 4 arrays on
+  return py::cast(CtcStep::apply(x, st->dev_buf, 0, st->off_flat, fac, fac + 16 * B, st->max_len, blank, w->second.first,
+                                 w->second.second, lse));
+}
+
+// CTCLoss(log_probs, targets, blank, reduction) for the hot case, everything between the Python call and the launch
+// in this one function.  Returns None when the case is not the hot one (the caller takes the Python path).
+py::object ctc_loss_lists(const at::Tensor& x, const py::handle& targets, int64_t blank, bool mean, bool fused_lse,
+                          int64_t lim_len, int64_t lim_c, int64_t lim_c_long) {
+  return ctc_loss_staged(x, stage_targets(targets, x.device()), blank, mean, fused_lse, lim_len, lim_c, lim_c_long);
+}
+
+std::shared_ptr<StagedTargets> stage_lists(const py::handle& targets, const at::Tensor& like) {
+  return stage_targets(targets, like.device());
+}
+
+at::Tensor ctc_step(const at::Tensor& x, const at::Tensor& staged, int64_t off_offsets, int64_t off_flat,
+                    int64_t off_scale, int64_t off_coef, int64_t max_len, int64_t blank, const at::Tensor& ws,
+                    const at::Tensor& nll, const c10::optional<at::Tensor>& lse) {
+  return CtcStep::apply(x, staged, off_offsets, off_flat, off_scale, off_coef, max_len, blank, ws, nll, lse);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("ctc_step", &ctc_step, "CTC loss + eager gradient in one pipelined launch (C++ autograd node)");
+  py::class_<StagedTargets, std::shared_ptr<StagedTargets>>(m, "StagedTargets")
+      .def_readonly("B", &StagedTargets::B)
+      .def_readonly("n", &StagedTargets::n)
+      .def_readonly("max_len", &StagedTargets::max_len);
+  m.def("stage_lists", &stage_lists, "stage + upload list-of-int-list targets (None if they are something else)");
+  m.def("ctc_loss_staged", &ctc_loss_staged, "the second half of ctc_loss_lists (profiling: bracket the launch alone)");
+  m.def("ctc_loss_lists", &ctc_loss_lists,
+        "CTCLoss for list-of-int-list targets: staging, upload, checks and the pipelined launch in one native call");
+}
