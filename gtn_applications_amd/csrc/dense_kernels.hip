@@ -549,6 +549,8 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   };
   // the scale reference: four fixed elements of the vector (v[0], v[16], v[32], v[48]: one aligned 16-B read)
   auto scale_ref = [&](int cur) { return *reinterpret_cast<const float4*>(L.vecT[cur][0][0]); };
+  constexpr int kVecBuf = 2 * 16 * 4;  // floats of one of the two frame-vector buffers
+  float* const myslot = &vslot(0, q < CP ? q : 0);
   auto chain_step = [&](int n, int cur) {  // n >= 1, cur = (n - 1) & 1
     const float e = L.eh[(DIR == 0 ? n : n + 1) & 3][q < CP ? q : 0];  // beta at n = T-1: a stale row, unused
     const float4 vc4 = *reinterpret_cast<const float4*>(L.vecT[cur][qq][il]);  // this row's chunks of its half
@@ -587,9 +589,9 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     }
     const float y = inv * part;
     const float val = DIR == 0 ? e * y : y;
-    if (owner && q < CP) vslot(cur ^ 1, q) = DIR == 0 ? val : e * y;
     last = val;
-    if (owner && q < C) {
+    if (owner && q < C) {  // (ONE predicated region per frame; the padding states C .. CP-1 of the vector stay zero)
+      myslot[(cur ^ 1) * kVecBuf] = DIR == 0 ? val : e * y;  // vslot(cur ^ 1, q), its address kept across frames
       vlo = min(vlo, __float_as_int(val)), vhi = max(vhi, __float_as_int(val));
       ob[(int64_t)(DIR == 0 ? n : T - 1 - n) * C + q] = val;
     }

@@ -534,7 +534,10 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   // extra LDS round trip on the per-frame critical path (barrier -> broadcast reads + FMAs ->
   // ds_write).  Any power of two is exact; how well it centres the vector only matters for the
   // range check below.
-  int bad = 0;
+  // range check of every stored value, kFloor <= val < 3e38 (NaN fails): the running minimum and maximum of the values'
+  // BIT PATTERNS as signed integers -- positive floats order like their bits, NaN sorts above +inf, anything with the
+  // sign bit below zero -- two instructions per frame, the comparison once after the sweep
+  int vlo = 0x7f7fffff, vhi = 0;
   float last = 0.f;
   auto scale_exp = [&](const float4& v) {
     return __builtin_amdgcn_frexp_expf(vmax(vmax(v.x, v.y), vmax(v.z, v.w))) - kNormExp;
@@ -587,7 +590,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     if (owner && q < CP) vslot(cur ^ 1, q) = DIR == 0 ? val : e * y;
     last = val;
     if (owner && q < C) {
-      bad |= !(val >= kFloor && val < 3.0e38f);
+      vlo = min(vlo, __float_as_int(val)), vhi = max(vhi, __float_as_int(val));
       ob[(int64_t)(DIR == 0 ? n : T - 1 - n) * C + q] = val;
     }
   };
@@ -644,7 +647,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
         next = T > 1 ? L.eh[1][q < CP ? q : 0] * val : 0.f;
       }
       if (owner && q < C) {
-        bad |= !(val >= kFloor && val < 3.0e38f);
+        vlo = min(vlo, __float_as_int(val)), vhi = max(vhi, __float_as_int(val));
         ob[(int64_t)(DIR == 0 ? 0 : T - 1) * C + q] = val;
       }
       last = val;
@@ -690,7 +693,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     }
   }
   // ---- epilogue: range verdict; log Z from the last alpha vector
-  const int any_bad = __syncthreads_or(bad);
+  const int any_bad = __syncthreads_or(!(vlo >= __float_as_int(kFloor) && vhi < __float_as_int(3.0e38f)));
   if (DIR == 0) {
     if (wave < kDenseChainWaves) {
       const float s = wave_all_sum((owner && q < C) ? last : 0.f);
