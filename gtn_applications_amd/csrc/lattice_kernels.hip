@@ -98,6 +98,37 @@ __global__ void __launch_bounds__(256) gather_kernel(wfl_lattice_desc d, const i
   const int K = ints[d.lab_off + bb + 1] - l0;
   const int32_t* labels = ints + d.labels + l0;
   const int Kmax = d.max_labels;
+  if (!row_lse && K <= 64) {
+    // At most one label per lane and no row reduction (the ASG numerator): the lane's column is looked up once, four
+    // rows are in flight per wave, and a row's values go from the register to xg, to the factors and to the row
+    // maximum -- the general loop below reads labels[k], then row[labels[k]], stores, and reads the stored value
+    // back for the factors: three dependent round trips per row and wave.
+    constexpr int RU = 4;
+    const int col = lane < K ? labels[lane] : -1;
+    const float* xb = x + (int64_t)b * T * C;
+    float* gb = xg + (int64_t)b * T * Kmax;
+    float* fb = fg ? fg + (int64_t)b * T * Kmax : nullptr;
+    for (int t0 = (blockIdx.x * 4 + wave) * RU; t0 < T; t0 += gridDim.x * 4 * RU) {
+      float v[RU];
+#pragma unroll
+      for (int q = 0; q < RU; ++q) v[q] = xb[(int64_t)min(t0 + q, T - 1) * C + max(col, 0)];
+#pragma unroll
+      for (int q = 0; q < RU; ++q) {
+        const int t = t0 + q;
+        if (t < T) {  // (uniform)
+          const float val = col >= 0 ? nan_to_neg(v[q]) : WFL_NEG_INF;
+          if (col >= 0) gb[(int64_t)t * Kmax + lane] = val;
+          if (fb) {  // emit_factors, from the register
+            float r = wave_all_max(val);
+            if (!(r > WFL_NEG_INF)) r = 0.f;
+            if (col >= 0) fb[(int64_t)t * Kmax + lane] = __builtin_amdgcn_exp2f((val - r) * 1.4426950408889634f);
+            if (lane == 0) rmax[(int64_t)b * T + t] = r;
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int t = blockIdx.x * 4 + wave; t < T; t += gridDim.x * 4) {
     const float* row = x + ((int64_t)b * T + t) * C;
     float lse = 0.f;
@@ -2200,7 +2231,9 @@ int wfl_lattice_gather(const wfl_lattice_desc* d, const int32_t* ints, const flo
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, *d, ints, x, T, C, xg, row_lse, xg + xg_main(*d, T),
                        xg + 2 * xg_main(*d, T));
   };
-  if (!row_lse || C > 1024)
+  if (!row_lse && d->max_labels <= 64)
+    launch(gather_kernel, 16);  // (its one-label-per-lane path: 64 rows per workgroup and trip, a few trips per wave)
+  else if (!row_lse || C > 1024)
     launch(gather_kernel, 1);
   else if (C <= 128)
     launch(gather_lse_kernel<2, 4>, 4);
