@@ -406,13 +406,26 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   double* Mb = ws.M + ((int64_t)b * 2 + DIR) * T;
   int32_t* Eb = ws.E + ((int64_t)b * 2 + DIR) * T;
 
-  // ---- row maxima of the transition matrix (one wave per row), start weights
-  for (int i = wave; i < CP; i += kDenseChainWaves + 1) {
-    float m = WFL_NEG_INF;
-    if (i < C)
-      for (int j = lane; j < C; j += 64) m = fmaxf(m, W[(1 + i) * C + j]);
-    m = wave_all_max(m);
-    if (lane == 0) L.wr2[i] = i < C ? m * kLog2e : 0.f;
+  // ---- row maxima of the transition matrix (one wave per row), start weights.  Four rows per trip with their loads
+  // (clamped addresses, no test around them) issued together: row by row, and the matrix below element by element
+  // inside its bounds tests, the prologue was ~70 dependent L2 round trips -- a tenth of the sweep at T = 1000.
+  for (int i0 = wave; i0 < CP; i0 += 4 * (kDenseChainWaves + 1)) {
+    float a0[4], a1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ic = min(i0 + u * (kDenseChainWaves + 1), C - 1);
+      a0[u] = W[(1 + ic) * C + min(lane, C - 1)];
+      a1[u] = W[(1 + ic) * C + min(lane + 64, C - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * (kDenseChainWaves + 1);
+      float m = fmaxf(lane < C ? a0[u] : WFL_NEG_INF, lane + 64 < C ? a1[u] : WFL_NEG_INF);
+      if (C > 128)
+        for (int j = lane + 128; j < C; j += 64) m = fmaxf(m, W[(1 + min(i, C - 1)) * C + j]);
+      m = wave_all_max(m);
+      if (lane == 0 && i < CP) L.wr2[i] = i < C ? m * kLog2e : 0.f;
+    }
   }
   for (int i = tid; i < CP; i += kDenseThreads) L.st2[i] = i < C ? nan_to_neg(W[i]) * kLog2e : WFL_NEG_INF;
   __syncthreads();
@@ -430,13 +443,19 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   int hard = 0;
   for (int i = tid; i < 2 * 2 * 16 * 4; i += kDenseThreads) (&L.vecT[0][0][0][0])[i] = 0.f;  // (padding stays 0)
   if (wave < kDenseChainWaves) {
+    // (all of the lane's transition scores first, from clamped addresses: P[] holds the raw scores until the second loop)
+    const int qc = min(q, C - 1);
+#pragma unroll
+    for (int k = 0; k < 16 * NCH; ++k) {
+      const int jc = min(qq * H + k, C - 1);
+      P[k] = DIR == 0 ? W[(1 + qc) * C + jc] : W[(1 + jc) * C + qc];
+    }
 #pragma unroll
     for (int k = 0; k < 16 * NCH; ++k) {
       const int j = qq * H + k;
       float p = 0.f;
       if (k < H && q < C && j < C) {
-        const float w = DIR == 0 ? W[(1 + q) * C + j] : W[(1 + j) * C + q];
-        const float d = w * kLog2e - (DIR == 0 ? L.wr2[q] : L.wr2[j]);
+        const float d = P[k] * kLog2e - (DIR == 0 ? L.wr2[q] : L.wr2[j]);
         hard |= !(d >= -kHardGap);  // -inf, NaN, +inf rows, or a dynamic range the floor check cannot vouch for
         p = __builtin_amdgcn_exp2f(d);
       }
