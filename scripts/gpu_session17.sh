@@ -1,9 +1,6 @@
-timeout 1200 python -m pytest tests -m gpu -x -q -k "ctc or CTC" 2>&1 | tail -3 > gpurun_out/s17_tests.txt
 for i in 1 2 3; do
-for p in new old ps48; do
-L=""; [ $p = new ] || L=$PWD/gtn_applications_amd/libwfl_$p.so
-WFL_LIB_PATH=$L python bench.py --mode abi --steps 400 --warmup 20 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "
+for p in 512 64 8; do
+WFL_CTC_REPAIR_WGS=$p python bench.py --mode abi --steps 400 --warmup 20 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$p', round(d['ms_per_step']*1e3,2), {k: round(v*1e3,2) for k,v in d['roofline']['kernel_ms'].items()})" >> gpurun_out/s17.txt
+d=json.loads(sys.stdin.read()); print('rg=$p', round(d['ms_per_step']*1e3,2), {k: round(v*1e3,2) for k,v in d['roofline']['kernel_ms'].items()})" >> gpurun_out/s17.txt
 done; done
-WFL_LIB_PATH=$PWD/gtn_applications_amd/libwfl_dbg.so python scratch/timeline3.py > gpurun_out/tl3.txt 2>&1
