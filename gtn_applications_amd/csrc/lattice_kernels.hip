@@ -1818,28 +1818,53 @@ __global__ void __launch_bounds__(256)
         return v;
       };
       if (C >= 512) {
-        // wide rows: one float4 per thread and row (rows are only 4-byte aligned: scalar head / tail)
+        // wide rows: one float4 per thread and row (rows are only 4-byte aligned: scalar head / tail).  Four rows at a
+        // time with ALL their loads -- the row's scores, its log-sum-exp, the gradient it accumulates into -- issued
+        // together: row by row, every row cost two dependent round trips to HBM (lse, then x -> exp -> store).
         const int64_t e0 = ((int64_t)b * T + ts0) * C;
-        for (int r = 0; r < nr; ++r) {
-          const int head = (int)((4 - ((e0 + (int64_t)r * C) & 3)) & 3);
-          const int nvec = (C - head) >> 2;
-          float* grow = gdst + (int64_t)r * C;
-          const float* xrow = soft ? xsrc + (int64_t)r * C : nullptr;
-          const float l = soft ? lse[r] : 0.f;
-          for (int j = tid; j < nvec; j += NT) {
-            const int c = head + 4 * j;
-            float4 have = make_float4(0.f, 0.f, 0.f, 0.f), xv = have;
-            if (accumulate) have = *reinterpret_cast<const float4*>(grow + c);
-            if (soft) xv = *reinterpret_cast<const float4*>(xrow + c);
-            float4 o;
-            o.x = value(r, c, have.x, xv.x, l), o.y = value(r, c + 1, have.y, xv.y, l);
-            o.z = value(r, c + 2, have.z, xv.z, l), o.w = value(r, c + 3, have.w, xv.w, l);
-            *reinterpret_cast<float4*>(grow + c) = o;
+        constexpr int RU = 4;
+        for (int r0 = 0; r0 < nr; r0 += RU) {
+          int head[RU], nvec[RU];
+          float lrow[RU];
+#pragma unroll
+          for (int q = 0; q < RU; ++q) {
+            const int r = min(r0 + q, nr - 1);  // (past the tile: the last row again, not stored)
+            head[q] = (int)((4 - ((e0 + (int64_t)r * C) & 3)) & 3);
+            nvec[q] = (C - head[q]) >> 2;
+            lrow[q] = soft ? lse[r] : 0.f;
           }
-          const int ntail = C - head - 4 * nvec;  // < 4
-          if (tid < head + ntail) {
-            const int c = tid < head ? tid : head + 4 * nvec + (tid - head);
-            grow[c] = value(r, c, accumulate ? grow[c] : 0.f, soft ? xrow[c] : 0.f, l);
+          for (int j0 = 0; j0 < (C >> 2); j0 += NT) {
+            const int j = j0 + tid;
+            float4 have[RU], xv[RU];
+#pragma unroll
+            for (int q = 0; q < RU; ++q) {
+              const int r = min(r0 + q, nr - 1);
+              const int c = head[q] + 4 * min(j, nvec[q] - 1);  // (clamped: a valid, aligned address)
+              have[q] = make_float4(0.f, 0.f, 0.f, 0.f), xv[q] = have[q];
+              if (accumulate) have[q] = *reinterpret_cast<const float4*>(gdst + (int64_t)r * C + c);
+              if (soft) xv[q] = *reinterpret_cast<const float4*>(xsrc + (int64_t)r * C + c);
+            }
+#pragma unroll
+            for (int q = 0; q < RU; ++q) {
+              const int r = r0 + q;
+              if (r < nr && j < nvec[q]) {
+                const int c = head[q] + 4 * j;
+                float4 o;
+                o.x = value(r, c, have[q].x, xv[q].x, lrow[q]), o.y = value(r, c + 1, have[q].y, xv[q].y, lrow[q]);
+                o.z = value(r, c + 2, have[q].z, xv[q].z, lrow[q]), o.w = value(r, c + 3, have[q].w, xv[q].w, lrow[q]);
+                *reinterpret_cast<float4*>(gdst + (int64_t)r * C + c) = o;
+              }
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < RU; ++q) {
+            const int r = r0 + q;
+            const int ntail = C - head[q] - 4 * nvec[q];  // < 4
+            if (r < nr && tid < head[q] + ntail) {
+              float* grow = gdst + (int64_t)r * C;
+              const int c = tid < head[q] ? tid : head[q] + 4 * nvec[q] + (tid - head[q]);
+              grow[c] = value(r, c, accumulate ? grow[c] : 0.f, soft ? xsrc[(int64_t)r * C + c] : 0.f, lrow[q]);
+            }
           }
         }
       } else {

@@ -1,4 +1,5 @@
 mkdir -p gpurun_out
+timeout 1200 python -m pytest tests -m gpu -x -q -k "transducer or Transducer or cfg4 or stc or STC or lattice" 2>&1 | tail -3 > gpurun_out/s14_tests.txt
 run() { lbl=$1; shift
 env "$@" python bench.py --workload transducer --steps 40 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "
 import json,sys
