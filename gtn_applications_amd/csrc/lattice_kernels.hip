@@ -937,6 +937,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     }
   }
   const int deg_class = __syncthreads_or(k1 - k0 > 4) ? 2 : (__syncthreads_or(k1 - k0 > 2) ? 1 : 0);
+  const int wave_deg = wave_all_max_int(k1 - k0);  // the most arcs into (out of) a state of this wave
   float wref = block_reduce_max(wmx, L.red);  // every frame multiplies by e^wref once more: part of the offset
   if (!(wref > WFL_NEG_INF)) wref = 0.f;
   if (wref_out && tid == 0) wref_out[b] = wref;
@@ -1372,10 +1373,16 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
                                     __builtin_amdgcn_readlane(__double2loint(pre), 15));  // (lanes >= n added 0)
     }
     // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
-    if (uniform && deg_class == 0)
+    // (uniform-label acceptors: PER WAVE -- the frame loops differ only in how many of the eight arc slots they read,
+    // one barrier per frame in all of them; the alignment graphs of the Transducer have 2-5 arcs into most states and
+    // 8 into a few: waves that do not hold such a state read 4 or 6 vector entries per state and frame, not 8)
+    // (even classes only: the frame loops take the arc slots in pairs)
+    if (uniform && wave_deg <= 2)
       frames_uniform(std::integral_constant<int, 2>{});
-    else if (uniform && deg_class == 1)
+    else if (uniform && wave_deg <= 4)
       frames_uniform(std::integral_constant<int, 4>{});
+    else if (uniform && wave_deg <= 6)
+      frames_uniform(std::integral_constant<int, 6>{});
     else if (uniform)
       frames_uniform(std::integral_constant<int, kLeanDeg>{});
     else if (deg_class == 0)
