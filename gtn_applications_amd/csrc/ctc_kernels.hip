@@ -43,6 +43,9 @@
 
 #include "device_common.h"
 
+#ifndef WFL_MITM_STATS
+#define WFL_MITM_STATS 0
+#endif
 #ifndef WFL_DBG_FAST
 #define WFL_DBG_FAST 0  // scratch/chain_harness.cpp, timeline_fast.py: bit 0 no frames, 1 no staging math, 2 no gathers, 3 idle flusher,
                         // 4 chain launch only, 9 (512) per-item timestamps in the workspace
@@ -89,7 +92,7 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   const int64_t NB = ctc_blocks(T);
   CtcWs w;
   int64_t o = 0;
-  w.ck = o, o += (int64_t)B * 2 * NB * P * 2;
+  w.ck = o, o += (int64_t)B * 2 * (NB + 1) * P * 2;  // (+1 block: the raw checkpoints of ctc_mitm.h, [NB/2 + 1][2][P] x 8 B per sweep)
   o = (o + 1) & ~1ll;
   w.off = o, o += 2 * (int64_t)B * 2 * NB;
   w.z2 = o, o += 2 * (int64_t)B;
@@ -105,6 +108,10 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
 #if WFL_DBG_FAST & 512
   o = (o + 1) & ~1ll;
   w.dbg = o, o += 2 * 4 * ((int64_t)B * NB + 2 * B);  // int64 [item][4] timestamps (scratch/timeline_fast.py)
+#endif
+#if WFL_MITM_STATS
+  o = (o + 1) & ~1ll;
+  w.dbg = o, o += 2 * 8 * 12 * 2 * (int64_t)B;  // int64 [b][dir][wave][8] (ctc_mitm.h)
 #endif
   w.total = o + 2;
   return w;
@@ -1726,6 +1733,8 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+#include "ctc_mitm.h"
+
 // ------------------------------------------------------------------------------------------------
 // Long targets (64 <= L + 1 <= 256): PPL = 2, 3 or 4 target positions per lane, lane i owning the
 // contiguous positions PPL*i .. PPL*i + PPL-1.  Within a frame all positions read the PREVIOUS
@@ -2276,6 +2285,9 @@ int wfl_ctc_workspace_field(int B, int T, int max_len, int field, int64_t* offse
     case WFL_CTC_WS_STATUS: *offset_elems = w.perr, *length_elems = 2; break;
     case WFL_CTC_WS_LOG2Z: *offset_elems = w.z2, *length_elems = 2 * (int64_t)B; break;
     case WFL_CTC_WS_ZRANGE: *offset_elems = w.zloc, *length_elems = 4 * (int64_t)B; break;
+    case WFL_CTC_WS_DEBUG:
+      *offset_elems = WFL_MITM_STATS ? w.dbg : 0, *length_elems = WFL_MITM_STATS ? 2 * 8 * 12 * 2 * (int64_t)B : 0;
+      break;
     default: set_error("ctc_workspace_field: unknown field %d", field); return WFL_ERR_INVALID;
   }
   return WFL_OK;
@@ -2360,7 +2372,29 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   }();
   const size_t compact_lds = (size_t)kFWaves * compact_wave_bytes(C);
   const bool compact = force_tile >= 0 ? force_tile == 1 : 3 * std::max(rows8_lds, sizeof(FastLdsT)) > (size_t)kLdsBytes;
-  if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
+  // meet-in-the-middle step (ctc_mitm.h): the sweeps emit the gradient -- narrow rows (dense LDS tile per emitter)
+  static const int mitm_env = [] {
+    const char* e = getenv("WFL_CTC_MITM");
+    return e ? atoi(e) : 1;
+  }();
+  const size_t mitm_lds = ((sizeof(MitmLds) + 15) & ~(size_t)15) + (size_t)kMEmitters * kBlk * C * 4;
+  if (ppl == 1 && !force_log && mitm_env && !row_lse && mitm_lds <= (size_t)kLdsBytes) {
+    WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)ctc_mitm_kernel<false>, (int)mitm_lds));
+    hipLaunchKernelGGL(ctc_mitm_kernel<false>, dim3((unsigned)(2 * B)), dim3(kMWaves * 64), mitm_lds, (hipStream_t)stream, a,
+                       coef, gout, dx);
+    WFL_LAUNCH_CHECK();
+    a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
+    if (a.token == 0) a.token = 1;
+    auto launch_repair = [&](auto kern) -> int {
+      const size_t lds = std::max(rows_lds, sizeof(ChainLdsT));
+      if (lds > 48 * 1024)
+        WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
+      const dim3 rgrid((unsigned)(2 * B + std::min<int64_t>((items + 3) / 4, 512)));
+      hipLaunchKernelGGL(kern, rgrid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
+      return WFL_OK;
+    };
+    rc = lcompact ? launch_repair(ctc_repair_kernel<false, true>) : launch_repair(ctc_repair_kernel<false, false>);
+  } else if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
     const size_t lds = std::max(compact ? compact_lds : rows8_lds, sizeof(FastLdsT));
     static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)
     const int64_t grad_wgs = ctc_fast_grad_wgs(B, T);

@@ -1,0 +1,742 @@
+// Meet-in-the-middle CTC training step (included by ctc_kernels.hip, inside namespace wfl).
+//
+// criterions/ctc.py:38-94 (forward_score of the composed lattice + its backward) as ONE launch in which the
+// gradient is emitted BY the sweeps instead of being recomputed by a third pass:
+//
+//   * one workgroup per (utterance, direction) -- 2B workgroups, one per CU at B = 128.  The alpha sweep runs
+//     0 -> T, the beta sweep T -> 0 (the same recursion on the reversed target and reversed time), both in the
+//     lane-exponent arithmetic of ctc_fast_chain_body (float mantissa + one integer exponent per lane, five
+//     instructions per frame, renormalised every 16 frames);
+//   * FIRST half of a sweep (blocks n < H0): its state before every 16-frame block -- raw mantissas and lane
+//     exponents, ~0.5 KB -- is published for the partner workgroup (device-coherent stores + a flag);
+//   * SECOND half (n >= H0): the frames the sweep now crosses were crossed by the partner in ITS first half.
+//     "Emitter" waves of the same workgroup take the block's emission factors from the LDS ring the chain wave was
+//     fed from (no second gather, no second exp2, no second reference fold), the sweep's own state before the
+//     block from the LDS mailbox, the partner's state after the block from the published checkpoints, redo the 16
+//     frames of both recursions in registers, normalise by the locally reproduced Z (sum_s alpha beta at the
+//     block's last frame: the certificate's identity -- log Z itself is only known when the alpha sweep ends) and
+//     write the block's dense gradient rows.  Every emission factor is computed once per sweep and x is read
+//     twice (once per direction) instead of 3.5 times; nothing remains to be done when the sweeps end but the
+//     last block of each.
+//
+// Waves of a workgroup (roles are fixed per wave index so that the chain wave's SIMD carries only light waves --
+// waves are placed round-robin on the four SIMDs):
+//     0 chain | 1,2,3,5 stagers | 4 flusher | 8 fetcher | 6,7,9,10,11 emitters
+//   chain    the dependent recursion and nothing else; factors travel ring -> registers a whole block ahead
+//   stagers  gather x (two blocks in flight each), references, exp2 -> LDS ring (as ctc_fast_chain_body's helpers)
+//   flusher  sums the references (double offsets) and, in the first half, publishes the raw checkpoints
+//   fetcher  second half: waits for the partner's flags, loads its checkpoints, mirrors / rescales them into the
+//            sweep's own lane order and leaves them in LDS -- emitters never wait on another CU and never issue a
+//            global load (their global stores are fire-and-forget: vmcnt of a storing wave is never waited on)
+//   emitters one block each, round robin
+// No barrier after the initial one: all hand-offs are LDS mailboxes (DS instructions of a wave execute in order).
+//
+// The certificate (per-block log2 Z against the chain's, posterior mass per frame) and the repair launch are those
+// of the fast pipelined step (ctc_repair_kernel re-runs rejected utterances in the log domain).
+#pragma once
+
+#ifndef WFL_MITM_STATS
+#define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
+#endif
+
+constexpr int kMSlots = 10;    // LDS ring depth in blocks: factors, references, own checkpoints
+constexpr int kMPSlots = 8;    // partner checkpoints handed from the fetcher to the emitters
+constexpr int kMStagers = 4;
+constexpr int kMEmitters = 5;
+constexpr int kMWaves = 12;
+constexpr int kMSpin = 1 << 24;
+
+// role of a wave: 0 chain, 1 stager, 2 flusher, 3 fetcher, 4 emitter; index within the role
+__device__ __forceinline__ void mitm_role(int wave, int& role, int& idx) {
+  // (a switch on a scalar: compiled to scalar compares)
+  switch (wave) {
+    case 0: role = 0, idx = 0; break;
+    case 1: role = 1, idx = 0; break;
+    case 2: role = 1, idx = 1; break;
+    case 3: role = 1, idx = 2; break;
+    case 4: role = 2, idx = 0; break;
+    case 5: role = 1, idx = 3; break;
+    case 6: role = 4, idx = 0; break;
+    case 7: role = 4, idx = 1; break;
+    case 8: role = 3, idx = 0; break;
+    case 9: role = 4, idx = 2; break;
+    case 10: role = 4, idx = 3; break;
+    default: role = 4, idx = 4; break;
+  }
+}
+
+struct MitmLds {
+  float2 ring[kMSlots][kBlk][64];  // (fb, fl) per frame and lane: 80 KiB
+  float4 pck[kMPSlots][64];        // partner state after the block, own lane order: (bb, bl, eb bits, -)
+  float2 ckm[kMSlots][64];         // own state before block n: mantissas ...
+  int cke[kMSlots][64];            // ... and lane exponents
+  float fref[kMSlots][kBlk];       // per-frame references r_t (integer valued; 0 past the block's frames)
+  double offc[kMSlots];            // sum of the references of all blocks before n
+  double poff[kMPSlots];           // the partner's sum before its checkpoint
+  double offtot;
+  int staged[kMSlots];             // == n + 1 once block n sits in slot n % kMSlots
+  int pready[kMPSlots];            // == n + 1 once the partner checkpoint for block n sits in slot n % kMPSlots
+  int egrab[kMEmitters];           // emitter e holds the ring / checkpoint slots of its blocks < egrab[e] in registers
+  int pgrab[kMEmitters];           // ... and the partner checkpoints
+  int consumed;                    // blocks the chain wave has loaded into registers
+  int ckready;                     // own checkpoints handed over by the chain wave
+  int ckdone;                      // ... picked up by the flusher (offc valid)
+  int offdone;                     // offtot valid
+};
+
+__host__ __device__ inline int mitm_first_emitted(int NB, int dir) { return dir == 0 ? NB / 2 : NB - NB / 2; }
+// published checkpoints of sweep (b, dir): [H0][2][P] 8-byte entries (mantissa bits | exponent << 32), blank states
+// then label states, inside the (enlarged) ck region; stride per sweep (NB + 1) * P float2
+__device__ __forceinline__ unsigned long long* mitm_pub(const CtcArgs& a, const CtcWs& w, int b, int dir, int NB) {
+  return (unsigned long long*)(a.ws + w.ck) + (int64_t)(b * 2 + dir) * (NB + 1) * a.P;
+}
+
+#if WFL_MITM_STATS
+#define MITM_T0() const long long _t0 = clock64()
+#define MITM_ACC(var) var += clock64() - _t0
+#else
+#define MITM_T0()
+#define MITM_ACC(var)
+#endif
+
+typedef float mv2f __attribute__((ext_vector_type(2)));
+
+// One 16-frame block of a sweep's second half: gradient rows from the sweep's own state before the block (sa, ea),
+// the partner's state after it (pk) and the block's emission factors (F), all in the sweep's own lane order.
+//   own_j(s)  = ma_j(s) 2^ea(s)    forward through the block (the chain's five-instruction frame)
+//   part_j(s) = mb_j(s) 2^eb(s)    backwards, with K(s) = cf 2^(ea + eb - E) / Zm folded into its start: the coupling
+//                                  factor of the scaled recursion is 2^(ea[i] - ea[i+1]) (bounded by the chain's clamp)
+//   posterior_j(s) = own_j(s) [A part_{j+1}](s)   -- one packed multiply per frame and lane pair
+// DIR: tile row of frame j (the reversed sweep only emits complete blocks, FULL).
+template <int DIR, bool FULL>
+__device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f sa, int ea, float4 pk, float rsum, double off_sum,
+                                                    int cnt, float cf, float g, float gs, bool skipn, bool owner, bool adder,
+                                                    int lane, float* rows, int ycol, int blank, int C, long long* zmm,
+                                                    float* __restrict__ dst) {
+  const int eb = __float_as_int(pk.z);
+  // ---- own sweep forward through the block, kept in registers
+  mv2f pa[kBlk];
+  const mv2f G = {g, gs};
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) {
+    if (FULL || j < cnt) {
+      const mv2f t = F[j] * G;
+      const mv2f o = F[j] * mv2f{sa.x, sa.x};
+      float ox = o.x, oy = o.y;
+      fmac2_shr1(ox, oy, sa.y, t.x, t.y);
+      oy = fmaf(F[j].y, sa.y, oy);
+      sa = mv2f{ox, oy};
+    }
+    pa[j] = sa;
+  }
+  // ---- local Z at the block's last frame, K
+  float bb = pk.x, bl = pk.y;
+  float K = 0.f;
+  bool alive;
+  double zk;  // (lane 0) log2 Z as this block reproduces it
+  {
+    const int eb_next = __builtin_amdgcn_update_dpp(eb, eb, 0x130, 0xf, 0xf, false);  // wave_shl:1 (lane 63: own)
+    const float h = lane == 63 ? 0.f : ldexpf(1.f, min(max(eb_next - eb, -200), 100));
+    const float hs = skipn ? h : 0.f;
+    const float tb0 = bb + bl;
+    float tl0 = bl;
+    fmac2_shl1(tl0, bb, bl, h, hs);
+    const float v = sa.x * tb0 + sa.y * tl0;
+    const int sx = ea + eb;
+    const int own = v > 0.f ? sx + __builtin_amdgcn_frexp_expf(v) : kEmptyE;
+    const int E = __builtin_amdgcn_readlane(wave_prefix_max_i(own), 63);
+    const float term = v > 0.f ? ldexpf(v, max(sx - E, -200)) : 0.f;
+    const float Zm = wave_all_sum(term);
+    alive = Zm > 0.f && Zm < 3.0e38f && E > kEmptyE;
+    if (alive) K = cf * ldexpf(1.f / Zm, min(max(sx - E, -200), 100));
+    zk = alive ? off_sum + (double)E + (double)__builtin_amdgcn_logf(Zm) + (double)rsum : -1.0e300;
+  }
+  // ---- partner sweep backwards through the block (scaled by K), posteriors
+  bb *= K, bl *= K;
+  const int ea_next = __builtin_amdgcn_update_dpp(ea, ea, 0x130, 0xf, 0xf, false);
+  const float hk = lane == 63 ? 0.f : ldexpf(1.f, min(max(ea - ea_next, -200), 100));
+  const float hks = skipn ? hk : 0.f;
+  float gbv[kBlk], glv[kBlk];
+  mv2f wsum = {0.f, 0.f};  // sum_j w_j (gb, gl)[j], w_j = 1 + j / 32: the frames' posterior mass, weighted so that errors cannot cancel
+#pragma unroll
+  for (int j = 0; j < kBlk; ++j) gbv[j] = 0.f, glv[j] = 0.f;
+#pragma unroll
+  for (int j = kBlk - 1; j >= 0; --j) {
+    if (FULL || j < cnt) {
+      // blank i -> blank i, label i.  label i -> label i, blank i+1 (and label i+1 if allowed)
+      const float tb = bb + bl;
+      float tl = bl;
+      fmac2_shl1(tl, bb, bl, hk, hks);
+      const mv2f t = {tb, tl};
+      const mv2f gam = pa[j] * t;
+      gbv[j] = gam.x, glv[j] = gam.y;
+      const float wj = 1.f + (float)j * (1.f / 32.f);
+      wsum = gam * mv2f{wj, wj} + wsum;
+      const mv2f nb = t * F[j];
+      bb = nb.x, bl = nb.y;
+    }
+  }
+  // ---- gradient rows
+  constexpr int R0 = DIR == 0 ? 0 : kBlk - 1, RS = DIR == 0 ? 1 : -1;  // tile row of frame j: R0 + RS * j
+  const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
+  if (lane < (FULL ? kBlk : cnt)) rows[(R0 + RS * lane) * C + blank] = gtot;
+  float* cell = rows + ycol;
+  if (owner) {
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j)
+      if (FULL || j < cnt) cell[(R0 + RS * j) * C] = glv[j];
+  }
+  if (adder) {
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j)
+      if (FULL || j < cnt) atomicAdd(&cell[(R0 + RS * j) * C], glv[j]);
+  }
+  {
+    // certificate (see ctc_fast_grad_body): posterior mass of every frame, the block's log2 Z
+    const float stot = wave_all_sum(wsum.x + wsum.y);
+    const int n = FULL ? kBlk : cnt;
+    const float want = cf * ((float)n + (float)(n * (n - 1)) * (1.f / 64.f));
+    const bool bad_block = alive && !(fabsf(stot - want) <= 2e-4f * fabsf(cf));
+    if (lane == 0) {
+      const long long zq = bad_block ? kZDead : z_fixed(zk);
+      __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
+  const int total = (FULL ? kBlk : cnt) * C;
+  if ((((uintptr_t)dst) & 15) == 0) {
+    const int n4 = total >> 2;
+    const int nfull = n4 >> 6;  // (uniform trip count: no exec juggling in the loop)
+    for (int it = 0; it < nfull; ++it) ((float4*)dst)[it * 64 + lane] = ((const float4*)rows)[it * 64 + lane];
+    if (nfull * 64 + lane < n4) ((float4*)dst)[nfull * 64 + lane] = ((const float4*)rows)[nfull * 64 + lane];
+    for (int q = (n4 << 2) + lane; q < total; q += 64) dst[q] = rows[q];
+  } else {
+    for (int q = lane; q < total; q += 64) dst[q] = rows[q];
+  }
+}
+
+template <bool LSM, int DIR>
+__device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, int b, int em, int H0, int NB, int L, int y,
+                                                 bool skip, bool skipn, bool has_label, const float* __restrict__ coef,
+                                                 const float* __restrict__ gout, float* __restrict__ dx, char* smem,
+                                                 const CtcWs& w) {
+  const int lane = threadIdx.x & 63;
+  const int T = a.T, C = a.C;
+  float* rows = (float*)(smem + ((sizeof(MitmLds) + 15) & ~(size_t)15)) + (size_t)em * kBlk * C;
+  for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+  // Labels that occur once in the target own their gradient column: plain ds_write.  A repeated label's first
+  // occurrence owns the column, the others add to it afterwards; a target label equal to the blank index adds to
+  // the blank column.  (Columns are the same for every block of the sweep: the tile is zeroed once.)
+  bool owner = has_label && y != a.blank;
+  for (int j = 0; j < L; ++j) {
+    const bool same = __builtin_amdgcn_readlane(y, j) == y;
+    if (same && j < lane) owner = false;
+  }
+  const bool adder = has_label && !owner;
+  const int ycol = has_label ? y : 0;
+  const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
+  long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+#if WFL_MITM_STATS
+  long long st_wait0 = 0, st_wait1 = 0, st_wait2 = 0;
+  const long long st_begin = clock64();
+#endif
+  auto give_up = [&]() {
+    if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+    __builtin_trap();
+  };
+  for (int n = H0 + em; n < NB; n += kMEmitters) {
+    const int k = DIR == 0 ? n : NB - 1 - n;
+    const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
+    const int slot = n % kMSlots, ps = n % kMPSlots;
+    {
+      int spin = 0;
+      MITM_T0();
+      while (lds_peek(&S.ckdone) < n + 1) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spin > kMSpin) give_up();
+      }
+      MITM_ACC(st_wait0);
+    }
+    asm volatile("" ::: "memory");
+    mv2f F[kBlk];
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      const float2 f = S.ring[slot][j][lane];
+      F[j] = mv2f{f.x, f.y};
+    }
+    const float2 cko = S.ckm[slot][lane];
+    const int ea = S.cke[slot][lane];
+    const float rr = lane < kBlk ? S.fref[slot][lane] : 0.f;
+    const double off_own = S.offc[slot];
+    lds_post(&S.egrab[em], n + 1);  // (after the reads were issued)
+    {
+      int spin = 0;
+      MITM_T0();
+      while (lds_peek(&S.pready[ps]) != n + 1) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spin > kMSpin) give_up();
+      }
+      MITM_ACC(st_wait1);
+    }
+    asm volatile("" ::: "memory");
+    const float4 pk = S.pck[ps][lane];
+    const double off_sum = off_own + S.poff[ps];
+    lds_post(&S.pgrab[em], n + 1);
+    MITM_T0();
+    const float rsum = wave_all_sum(rr);
+    const int ea_prev = wave_shr1_i(ea, ea);
+    const float g = lane == 0 ? 0.f : ldexpf(1.f, max(ea_prev - ea, -200));
+    const float gs = skip ? g : 0.f;
+    float* dst = dx + ((int64_t)b * T + t0) * C;
+    if (cnt == kBlk)
+      ctc_mitm_emit_block<DIR, true>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+                                     ycol, a.blank, C, zmm, dst);
+    else if (DIR == 0)
+      ctc_mitm_emit_block<0, false>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+                                    ycol, a.blank, C, zmm, dst);
+    MITM_ACC(st_wait2);
+  }
+#if WFL_MITM_STATS
+  if (lane == 0) {
+    const int wave = threadIdx.x >> 6;
+    long long* d = (long long*)(a.ws + w.dbg) + ((int64_t)(b * 2 + DIR) * kMWaves + wave) * 8;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    d[0] = clock64() - st_begin, d[1] = st_wait0, d[2] = st_wait1, d[3] = st_wait2, d[4] = 0, d[5] = hw;
+    d[6] = wall_clock64();
+  }
+#endif
+}
+
+template <bool LSM>
+__device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, const float* __restrict__ coef,
+                                              const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
+  MitmLds& S = *reinterpret_cast<MitmLds*>(smem);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int T = a.T, C = a.C, P = a.P;
+  const int64_t o0 = a.offsets[b];
+  const int L = (int)(a.offsets[b + 1] - o0);
+  int y = -1, yprev = -1, ynext = -1;  // the sweep's own orientation: position `lane` of the (reversed) target
+  if (lane < L) y = a.targets[o0 + (dir == 0 ? lane : L - 1 - lane)];
+  if (lane >= 1 && lane - 1 < L) yprev = a.targets[o0 + (dir == 0 ? lane - 1 : L - lane)];
+  if (lane + 1 < L) ynext = a.targets[o0 + (dir == 0 ? lane + 1 : L - 2 - lane)];
+  const bool has_label = lane < L, has_blank = lane <= L;
+  const bool skip = has_label && lane >= 1 && y != yprev;
+  const bool skipn = lane + 1 < L && ynext != y;
+  const float* xrow = a.x + (int64_t)b * T * C;
+  const int col = has_label ? y : a.blank;
+  const CtcWs w = ctc_ws_layout(a.B, T, P);
+  const int NB = ctc_blocks(T);
+  const int H0 = mitm_first_emitted(NB, dir);  // blocks n < H0 are published, blocks n >= H0 emitted
+  if (dir == 0 && threadIdx.x == 0) {  // certificate accumulators (before the first checkpoint is published)
+    long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+    coherent_store64(zmm, (unsigned long long)(1ll << 62));
+    coherent_store64(zmm + 1, (unsigned long long)(-(1ll << 62) - 1));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  }
+  if (threadIdx.x < kMSlots) S.staged[threadIdx.x] = 0;
+  if (threadIdx.x < kMPSlots) S.pready[threadIdx.x] = 0;
+  if (threadIdx.x < kMEmitters) S.egrab[threadIdx.x] = 0, S.pgrab[threadIdx.x] = 0;
+  if (threadIdx.x == 0) S.consumed = 0, S.ckready = 0, S.ckdone = 0, S.offdone = 0;
+  __syncthreads();
+  int role, ridx;
+  mitm_role(wave, role, ridx);
+#if WFL_MITM_STATS
+  long long st_wait0 = 0, st_wait1 = 0, st_wait2 = 0, st_polls = 0;
+  const long long st_begin = clock64();
+  auto stats_out = [&]() {
+    if (lane == 0) {
+      long long* d = (long long*)(a.ws + w.dbg) + ((int64_t)(b * 2 + dir) * kMWaves + wave) * 8;
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      d[0] = clock64() - st_begin, d[1] = st_wait0, d[2] = st_wait1, d[3] = st_wait2, d[4] = st_polls, d[5] = hw;
+      d[6] = wall_clock64();
+    }
+  };
+#else
+  auto stats_out = [&]() {};
+#endif
+  // a wave gives up (trap) instead of hanging the GPU when a hand-off never arrives
+  auto give_up = [&]() {
+    if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
+    __builtin_trap();
+  };
+  // has emitter-owned block m (m >= H0) been taken into registers?
+  auto grabbed = [&](int m) { return lds_peek(&S.egrab[(m - H0) % kMEmitters]) >= m + 1; };
+  auto pgrabbed = [&](int m) { return lds_peek(&S.pgrab[(m - H0) % kMEmitters]) >= m + 1; };
+
+  if (role == 1) {
+    // ================================================================ stagers
+    const int h = ridx;
+    auto issue = [&](int n, float (&raw)[kBlk]) {
+      const int k = dir == 0 ? n : NB - 1 - n;
+      const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        const int t = dir == 0 ? t0 + j : t0 + cnt - 1 - j;
+        raw[j] = xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
+      }
+    };
+    float lse_raw = 0.f;
+    auto issue_lse = [&](int n) {
+      if (LSM) {
+        const int k = dir == 0 ? n : NB - 1 - n;
+        const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
+        const int t = dir == 0 ? t0 + (lane & 15) : t0 + cnt - 1 - (lane & 15);
+        lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
+      }
+    };
+    auto stage = [&](int n, const float (&raw)[kBlk], float lse_blk) {
+      const int k = dir == 0 ? n : NB - 1 - n;
+      const int cnt = min(kBlk, T - k * kBlk);
+      const int slot = n % kMSlots;
+      float xs[kBlk];
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        const float v = (LSM ? raw[j] - readlane_f(lse_blk, j) : raw[j]) * kLog2e;
+        xs[j] = (v == v) ? v : WFL_NEG_INF;  // NaN policy: impossible
+      }
+      const float m = fold16<true>(xs, lane);  // lane j < 16 (every row): the largest target-label score of frame j
+      const float rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        const float f = __builtin_amdgcn_exp2f(xs[j] - readlane_f(rr, j));
+        const float fb = readlane_f(f, L);
+        S.ring[slot][j][lane] = make_float2(has_blank ? fb : 0.f, has_label ? f : 0.f);
+      }
+      if (lane < kBlk) S.fref[slot][lane] = lane < cnt ? rr : 0.f;
+    };
+    auto wait_slot = [&](int n) {
+      if (n < kMSlots) return;
+      const int m = n - kMSlots;  // the block that held the slot
+      int spin = 0;
+      MITM_T0();
+      while (lds_peek(&S.consumed) < m + 1 || lds_peek(&S.ckdone) < m + 1 || (m >= H0 && !grabbed(m))) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spin > kMSpin) give_up();
+      }
+      MITM_ACC(st_wait0);
+#if WFL_MITM_STATS
+      st_polls += spin;
+#endif
+    };
+    // two blocks of gathers in flight per stager: a round trip to HBM is longer than four chain blocks
+    float ra[kBlk], rb[kBlk];
+    float la = 0.f, lb = 0.f;
+    if (h < NB) issue(h, ra), issue_lse(h), la = lse_raw;
+    if (h + kMStagers < NB) issue(h + kMStagers, rb), issue_lse(h + kMStagers), lb = lse_raw;
+    for (int n = h; n < NB; n += 2 * kMStagers) {
+      wait_slot(n);
+      {
+        MITM_T0();
+        stage(n, ra, la);
+        MITM_ACC(st_wait1);
+      }
+      lds_post(&S.staged[n % kMSlots], n + 1);
+      if (n + 2 * kMStagers < NB) issue(n + 2 * kMStagers, ra), issue_lse(n + 2 * kMStagers), la = lse_raw;
+      const int n2 = n + kMStagers;
+      if (n2 < NB) {
+        wait_slot(n2);
+        {
+          MITM_T0();
+          stage(n2, rb, lb);
+          MITM_ACC(st_wait1);
+        }
+        lds_post(&S.staged[n2 % kMSlots], n2 + 1);
+        if (n2 + 2 * kMStagers < NB) issue(n2 + 2 * kMStagers, rb), issue_lse(n2 + 2 * kMStagers), lb = lse_raw;
+      }
+    }
+    stats_out();
+    return;
+  }
+
+  if (role == 2) {
+    // ================================================================ flusher
+    unsigned long long* pub = mitm_pub(a, w, b, dir, NB);
+    double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
+    unsigned long long* half = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;  // "first half published"
+    double offcum = 0.0;  // sum of r_t over the blocks before the checkpoint
+    if (dir == 0) {
+      // bit 63 of dup[b]: the target cannot be aligned at all -- T < L + adjacent repeats.  Such an utterance has
+      // Z = 0 exactly, in any arithmetic: loss inf, zero gradient, nothing for the certificate to doubt
+      const int repeats = __builtin_popcountll(__builtin_amdgcn_ballot_w64(has_label && lane >= 1 && y == yprev));
+      if (lane == 0) coherent_store64((unsigned long long*)(a.ws + w.dup) + b, T < L + repeats ? 1ull << 63 : 0ull);
+    }
+    for (int kk = 0; kk < NB; ++kk) {
+      {
+        int spin = 0;
+        MITM_T0();
+        while (lds_peek(&S.ckready) < kk + 1) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spin > kMSpin) give_up();
+        }
+        MITM_ACC(st_wait0);
+      }
+      asm volatile("" ::: "memory");
+      const int slot = kk % kMSlots;
+      const float rj = lane < kBlk ? S.fref[slot][lane] : 0.f;
+      if (kk < H0) {
+        // Device-coherent stores (see ctc_log_chain_body), three per checkpoint and never waited for one by one: the
+        // partner only needs them when this sweep has finished its first half (it emits from the middle outwards, so
+        // the LAST checkpoint published is the first one it uses) -- ONE flag per sweep, raised after the stores of
+        // the whole half have been acknowledged.
+        const float2 m = S.ckm[slot][lane];
+        const int e = S.cke[slot][lane];
+        const unsigned long long vb = (unsigned long long)__float_as_uint(m.x) | ((unsigned long long)(unsigned)e << 32);
+        const unsigned long long vl = (unsigned long long)__float_as_uint(m.y) | ((unsigned long long)(unsigned)e << 32);
+        unsigned long long obits;
+        __builtin_memcpy(&obits, &offcum, 8);
+        unsigned long long* dstb = pub + (int64_t)kk * 2 * P + min(lane, P - 1);
+        unsigned long long* dstl = dstb + P;
+        if (lane < P) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dstb), "v"(vb) : "memory");
+        if (lane < P) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dstl), "v"(vl) : "memory");
+        if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(&offs[kk]), "v"(obits) : "memory");
+        if (kk == H0 - 1) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) coherent_store64(half, a.token);
+        }
+      }
+      if (lane == 0) S.offc[slot] = offcum;
+      lds_post(&S.ckdone, kk + 1);
+      offcum += (double)wave_all_sum(rj);
+    }
+    if (lane == 0) S.offtot = offcum;
+    lds_post(&S.offdone, 1);
+    stats_out();
+    return;
+  }
+
+  if (role == 3) {
+    // ================================================================ fetcher
+    const unsigned long long* ppub = mitm_pub(a, w, b, 1 - dir, NB);
+    const double* poffs = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1 - dir) * NB;
+    unsigned long long* phalf = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1 - dir) * NB;
+    if (H0 < NB) {
+      int spin = 0;
+      MITM_T0();
+      while (__hip_atomic_load(phalf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.token) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spin > (1 << 21)) give_up();
+#if WFL_MITM_STATS
+        ++st_polls;
+#endif
+      }
+      MITM_ACC(st_wait1);
+    }
+    // everything the partner published is there now: its checkpoints stream in, kMFetch blocks of loads in flight
+    // mirrored lanes: our blank state 2i is the partner's blank of its position L - i, our label i its label
+    // L - 1 - i; the pair (bb, bl) of a lane gets one exponent (the larger).  The partner's exponents obey the
+    // neighbour clamp in ITS lane order, which is exactly eb[i] >= eb[i+1] - kGap here.
+    constexpr int kMFetch = 4;
+    unsigned long long vb[kMFetch], vl[kMFetch];
+    double po[kMFetch];
+    auto issue = [&](int n, unsigned long long& rb, unsigned long long& rl, double& ro) {
+      const int q = NB - 1 - n;  // the partner's checkpoint: its state before ITS block q = after our block n
+      rb = 0, rl = 0, ro = 0.0;
+      if (n < NB) {
+        if (lane <= L) rb = coherent_load64(&ppub[(int64_t)q * 2 * P + (L - lane)]);
+        if (lane < L) rl = coherent_load64(&ppub[(int64_t)q * 2 * P + P + (L - 1 - lane)]);
+        if (lane == 0) ro = coherent_load_f64(&poffs[q]);
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < kMFetch; ++u) issue(H0 + u, vb[u], vl[u], po[u]);
+    for (int n0 = H0; n0 < NB; n0 += kMFetch) {
+#pragma unroll
+      for (int u = 0; u < kMFetch; ++u) {
+        const int n = n0 + u;
+        if (n < NB) {
+          if (n - H0 >= kMPSlots) {  // slot n % kMPSlots held block n - kMPSlots
+            int spin = 0;
+            MITM_T0();
+            while (!pgrabbed(n - kMPSlots)) {
+              __builtin_amdgcn_s_sleep(4);
+              if (++spin > kMSpin) give_up();
+            }
+            MITM_ACC(st_wait0);
+          }
+          float bb = 0.f, bl = 0.f;
+          int eb = kEmptyE;
+          if (lane <= L) {
+            const int e_b = (int)(unsigned)(vb[u] >> 32), e_l = lane < L ? (int)(unsigned)(vl[u] >> 32) : e_b;
+            eb = max(e_b, e_l);
+            bb = ldexpf(__uint_as_float((unsigned)vb[u]), max(e_b - eb, -200));
+            bl = lane < L ? ldexpf(__uint_as_float((unsigned)vl[u]), max(e_l - eb, -200)) : 0.f;
+          }
+          const int ps = n % kMPSlots;
+          S.pck[ps][lane] = make_float4(bb, bl, __int_as_float(eb), 0.f);
+          if (lane == 0) S.poff[ps] = po[u];
+          lds_post(&S.pready[ps], n + 1);
+        }
+        issue(n + kMFetch, vb[u], vl[u], po[u]);
+      }
+    }
+    if (H0 < NB && lane == 0) coherent_store64(phalf, 0ull);  // sole consumer of the flag: leave it cleared (graph replays)
+    stats_out();
+    return;
+  }
+
+  if (role == 0) {
+    // ================================================================ the chain
+    __builtin_amdgcn_s_setprio(3);
+    float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
+    float pl = 0.f;
+    int e = 0;
+    float g = 0.f, gs = 0.f;
+    bool bad = false;
+    // per-lane power-of-two renormalisation, neighbour-gap clamp, coupling factors for the interval
+    auto lane_renorm = [&]() {
+      const float mx = vmax(pb, pl);
+      bad = bad || !(mx < 3.0e38f);
+      const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
+      const int own = mx > 0.f ? e + k : kEmptyE;
+      const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
+      const int sh = mx > 0.f ? pre - own : 0;                            // >= 0: pulled up by the clamp
+      pb = ldexpf(pb, -(k + min(sh, 200)));  // (mantissa to [0.5, 1), then down by the clamp: one scaling)
+      pl = ldexpf(pl, -(k + min(sh, 200)));
+      e = pre;
+      const int d = wave_shr1_i(e, e) - e;  // <= kGap by construction
+      g = lane == 0 ? 0.f : ldexpf(1.f, max(d, -200));
+      gs = skip ? g : 0.f;
+    };
+    auto frame = [&](const float2 f) {
+      const float c0 = f.x * g, c1 = f.y * gs;
+      float t0 = f.x * pb, t1 = f.y * pb;
+      fmac2_shr1(t0, t1, pl, c0, c1);
+      pl = fmaf(f.y, pl, t1);
+      pb = t0;
+    };
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    auto frames4 = [&](const float2& f0, const float2& f1, const float2& f2, const float2& f3) {
+      v2f Pq = {pb, pl};
+      const v2f G = {g, gs};
+      const v2f F0 = {f0.x, f0.y}, F1 = {f1.x, f1.y}, F2 = {f2.x, f2.y}, F3 = {f3.x, f3.y};
+      asm volatile(WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F0]", "%[Y0]")
+                   WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F1]", "%[Y1]")
+                   WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F2]", "%[Y2]")
+                   WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F3]", "%[Y3]")
+                   : "+{v[2:3]}"(Pq)
+                   : [G] "v"(G), [F0] "v"(F0), [F1] "v"(F1), [F2] "v"(F2), [F3] "v"(F3), [Y0] "v"(f0.y), [Y1] "v"(f1.y),
+                     [Y2] "v"(f2.y), [Y3] "v"(f3.y)
+                   : "v4", "v5", "v6", "v7");
+      pb = Pq.x;
+      pl = Pq.y;
+    };
+    // The factors travel ring -> registers a WHOLE block ahead (two sets of 16 float2, alternating): the reads of
+    // block kk + 1 are issued before the renormalisation and the 16 frames of block kk, so that no LDS round trip
+    // is ever waited for on the dependent path.
+    float2 fa[kBlk], fz[kBlk];
+    {
+      int spin = 0;
+      MITM_T0();
+      while (lds_peek(&S.staged[0]) != 1)
+        if (++spin > kMSpin) give_up();
+      MITM_ACC(st_wait0);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) fa[j] = S.ring[0][j][lane];
+    lds_post(&S.consumed, 1);
+    int nflag = NB > 1 ? lds_peek(&S.staged[1 % kMSlots]) : 0;  // looked at one block ahead of its use
+    auto block = [&](int kk, const float2 (&fcur)[kBlk], float2 (&fnxt)[kBlk], auto steady) {
+      constexpr bool STEADY = decltype(steady)::value;
+      const int k = dir == 0 ? kk : NB - 1 - kk;
+      const int n = STEADY ? kBlk : min(kBlk, T - k * kBlk);
+      if (STEADY || kk + 1 < NB) {
+        if (nflag != kk + 2) {
+          int spin = 0;
+          MITM_T0();
+          while (lds_peek(&S.staged[(kk + 1) % kMSlots]) != kk + 2)
+            if (++spin > kMSpin) give_up();
+          MITM_ACC(st_wait1);
+#if WFL_MITM_STATS
+          st_polls += spin;
+#endif
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) fnxt[j] = S.ring[(kk + 1) % kMSlots][j][lane];
+        lds_post(&S.consumed, kk + 2);  // (after the reads were issued: LDS executes a wave's instructions in order)
+        if (STEADY || kk + 2 < NB) nflag = lds_peek(&S.staged[(kk + 2) % kMSlots]);
+      }
+      lane_renorm();
+      // (slot kk % kMSlots is free: block kk could only be staged after block kk - kMSlots had been flushed and grabbed)
+      S.ckm[kk % kMSlots][lane] = make_float2(pb, pl);
+      S.cke[kk % kMSlots][lane] = e;
+      lds_post(&S.ckready, kk + 1);
+      if (n >= kBlk) {
+#pragma unroll
+        for (int j = 0; j < kBlk; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j)
+          if (j < n) frame(fcur[j]);
+      }
+    };
+    {
+      int kk = 0;
+      block(0, fa, fz, std::false_type{});
+      kk = 1;
+      // blocks 1 .. : complete for both directions while two more blocks follow; two per iteration (register sets swap)
+      for (; kk + 3 < NB; kk += 2) {
+        block(kk, fz, fa, std::true_type{});
+        block(kk + 1, fa, fz, std::true_type{});
+      }
+      for (; kk < NB; kk += 2) {
+        block(kk, fz, fa, std::false_type{});
+        if (kk + 1 < NB) block(kk + 1, fa, fz, std::false_type{});
+      }
+    }
+    lane_renorm();
+    {
+      int spin = 0;
+      MITM_T0();
+      while (lds_peek(&S.offdone) != 1) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spin > kMSpin) give_up();
+      }
+      MITM_ACC(st_wait2);
+    }
+    asm volatile("" ::: "memory");
+    if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = bad ? 1 : 0;
+    if (dir == 0) {
+      // Z = alpha_{T-1}[2L] + alpha_{T-1}[2L-1]   (ctc.py:21 accept states), lanes L and L-1
+      const float zb = readlane_f(pb, L);
+      const float zl = L > 0 ? readlane_f(pl, L - 1) : 0.f;
+      const int eb = __builtin_amdgcn_readlane(e, L);
+      const int el = L > 0 ? __builtin_amdgcn_readlane(e, L - 1) : kEmptyE;
+      if (lane == 0) {
+        const int em = max(zb > 0.f ? eb : kEmptyE, zl > 0.f ? el : kEmptyE);
+        const float s = (zb > 0.f ? ldexpf(zb, max(eb - em, -200)) : 0.f) + (zl > 0.f ? ldexpf(zl, max(el - em, -200)) : 0.f);
+        const bool ok = s > 0.f && s < 3.0e38f;
+        const double z2 = ok ? (double)__builtin_amdgcn_logf(s) + (double)em + S.offtot : -1.0e300;
+        ((double*)(a.ws + w.z2))[b] = z2;
+        publish_nll<true, false>(a, w, b, ok, z2);
+      }
+      stats_out();
+      if (a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
+      return;
+    }
+    stats_out();
+    return;
+  }
+
+  // ================================================================ emitters
+  if (dir == 0)
+    ctc_mitm_emitter<LSM, 0>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
+  else
+    ctc_mitm_emitter<LSM, 1>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
+}
+
+template <bool LSM>
+__global__ void __launch_bounds__(kMWaves * 64)
+    ctc_mitm_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int32_t* perr = (int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr);
+    perr[0] = 0;  // a wave gave up waiting
+    perr[1] = 0;  // utterances the repair launch recomputed
+  }
+  ctc_mitm_body<LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, coef, gout, dx, smem);
+}
