@@ -111,7 +111,7 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
 #endif
 #if WFL_MITM_STATS
   o = (o + 1) & ~1ll;
-  w.dbg = o, o += 2 * 8 * 12 * 2 * (int64_t)B;  // int64 [b][dir][wave][8] (ctc_mitm.h)
+  w.dbg = o, o += 2 * (8 * 16 + 256) * 2 * (int64_t)B;  // int64 [b][dir][wave][8], then [b][dir][256] block clocks (ctc_mitm.h)
 #endif
   w.total = o + 2;
   return w;
@@ -2286,7 +2286,7 @@ int wfl_ctc_workspace_field(int B, int T, int max_len, int field, int64_t* offse
     case WFL_CTC_WS_LOG2Z: *offset_elems = w.z2, *length_elems = 2 * (int64_t)B; break;
     case WFL_CTC_WS_ZRANGE: *offset_elems = w.zloc, *length_elems = 4 * (int64_t)B; break;
     case WFL_CTC_WS_DEBUG:
-      *offset_elems = WFL_MITM_STATS ? w.dbg : 0, *length_elems = WFL_MITM_STATS ? 2 * 8 * 12 * 2 * (int64_t)B : 0;
+      *offset_elems = WFL_MITM_STATS ? w.dbg : 0, *length_elems = WFL_MITM_STATS ? 2 * (8 * 16 + 256) * 2 * (int64_t)B : 0;
       break;
     default: set_error("ctc_workspace_field: unknown field %d", field); return WFL_ERR_INVALID;
   }
@@ -2377,8 +2377,9 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     const char* e = getenv("WFL_CTC_MITM");
     return e ? atoi(e) : 1;
   }();
-  const size_t mitm_lds = ((sizeof(MitmLds) + 15) & ~(size_t)15) + (size_t)kMEmitters * kBlk * C * 4;
-  if (ppl == 1 && !force_log && mitm_env && !row_lse && mitm_lds <= (size_t)kLdsBytes) {
+  const size_t mitm_lds = ((sizeof(MitmLds) + 15) & ~(size_t)15) + (size_t)kMEmitters * kBlk * kMTile * 4;
+  static_assert(((sizeof(MitmLds) + 15) & ~(size_t)15) + (size_t)kMEmitters * kBlk * kMTile * 4 <= (size_t)kLdsBytes, "ctc_mitm.h: LDS");
+  if (ppl == 1 && !force_log && mitm_env && !row_lse && C <= kMTile) {
     WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)ctc_mitm_kernel<false>, (int)mitm_lds));
     hipLaunchKernelGGL(ctc_mitm_kernel<false>, dim3((unsigned)(2 * B)), dim3(kMWaves * 64), mitm_lds, (hipStream_t)stream, a,
                        coef, gout, dx);

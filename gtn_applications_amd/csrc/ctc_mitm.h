@@ -21,7 +21,8 @@
 //
 // Waves of a workgroup (roles are fixed per wave index so that the chain wave's SIMD carries only light waves --
 // waves are placed round-robin on the four SIMDs):
-//     0 chain | 1,2,3,5 stagers | 4 flusher | 8 fetcher | 6,7,9,10,11 emitters
+//     0 chain (4, 8, 12 leave at once: the chain wave has its SIMD to itself) | 1,2,3,5 stagers | 6 flusher |
+//     7 fetcher | 9,10,11,13,14,15 emitters
 //   chain    the dependent recursion and nothing else; factors travel ring -> registers a whole block ahead
 //   stagers  gather x (two blocks in flight each), references, exp2 -> LDS ring (as ctc_fast_chain_body's helpers)
 //   flusher  sums the references (double offsets) and, in the first half, publishes the raw checkpoints
@@ -35,53 +36,68 @@
 // of the fast pipelined step (ctc_repair_kernel re-runs rejected utterances in the log domain).
 #pragma once
 
+#ifndef WFL_MITM_ABL
+#define WFL_MITM_ABL 0  // scratch: switch off parts of the chain wave's steady block (1 renorm, 2 ring reads, 4 checkpoint, 8 frames)
+#endif
 #ifndef WFL_MITM_STATS
 #define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
 #endif
 
 constexpr int kMSlots = 10;    // LDS ring depth in blocks: factors, references, own checkpoints
 constexpr int kMPSlots = 8;    // partner checkpoints handed from the fetcher to the emitters
-constexpr int kMStagers = 4;
-constexpr int kMEmitters = 5;
-constexpr int kMWaves = 12;
+constexpr int kMStagers = 6;
+constexpr int kMEmitters = 7;
+constexpr int kMWaves = 16;
 constexpr int kMSpin = 1 << 24;
+constexpr int kMTile = 128;   // floats per row of an emitter's gradient tile (a compile-time stride: the 16 rows of a label's
+                              // column are one LDS address + immediate offsets); the step takes C <= kMTile
 
 // role of a wave: 0 chain, 1 stager, 2 flusher, 3 fetcher, 4 emitter; index within the role
 __device__ __forceinline__ void mitm_role(int wave, int& role, int& idx) {
   // (a switch on a scalar: compiled to scalar compares)
-  switch (wave) {
+  switch (wave) {  // SIMD of wave w: class w % 4
     case 0: role = 0, idx = 0; break;
-    case 1: role = 1, idx = 0; break;
+    case 4: role = 2, idx = 0; break;   // the chain wave's SIMD (0, 4, 8, 12): light waves there do not slow the chain
+    case 8: role = 3, idx = 0; break;   // (measured; a stager there does, and falls behind itself)
+    case 12: role = 4, idx = 6; break;
+    case 1: role = 1, idx = 0; break;   // two stagers and two emitters on each of the other SIMDs
     case 2: role = 1, idx = 1; break;
     case 3: role = 1, idx = 2; break;
-    case 4: role = 2, idx = 0; break;
     case 5: role = 1, idx = 3; break;
-    case 6: role = 4, idx = 0; break;
-    case 7: role = 4, idx = 1; break;
-    case 8: role = 3, idx = 0; break;
-    case 9: role = 4, idx = 2; break;
-    case 10: role = 4, idx = 3; break;
-    default: role = 4, idx = 4; break;
+    case 6: role = 1, idx = 4; break;
+    case 7: role = 1, idx = 5; break;
+    case 9: role = 4, idx = 0; break;
+    case 10: role = 4, idx = 1; break;
+    case 11: role = 4, idx = 2; break;
+    case 13: role = 4, idx = 3; break;
+    case 14: role = 4, idx = 4; break;
+    default: role = 4, idx = 5; break;
   }
 }
 
 struct MitmLds {
   float2 ring[kMSlots][kBlk][64];  // (fb, fl) per frame and lane: 80 KiB
   float4 pck[kMPSlots][64];        // partner state after the block, own lane order: (bb, bl, eb bits, -)
-  float2 ckm[kMSlots][64];         // own state before block n: mantissas ...
-  int cke[kMSlots][64];            // ... and lane exponents
+  float4 ck[kMSlots][64];          // own state before block n: (blank mantissa, label mantissa, lane exponent bits, -)
   float fref[kMSlots][kBlk];       // per-frame references r_t (integer valued; 0 past the block's frames)
   double offc[kMSlots];            // sum of the references of all blocks before n
   double poff[kMPSlots];           // the partner's sum before its checkpoint
   double offtot;
   int staged[kMSlots];             // == n + 1 once block n sits in slot n % kMSlots
   int pready[kMPSlots];            // == n + 1 once the partner checkpoint for block n sits in slot n % kMPSlots
-  int egrab[kMEmitters];           // emitter e holds the ring / checkpoint slots of its blocks < egrab[e] in registers
-  int pgrab[kMEmitters];           // ... and the partner checkpoints
-  int consumed;                    // blocks the chain wave has loaded into registers
-  int ckready;                     // own checkpoints handed over by the chain wave
+  int egrab[kMSlots];              // == n + 1 once an emitter holds block n's factors and own checkpoint in registers
+  int pgrab[kMPSlots];             // == n + 1 once an emitter holds the partner checkpoint for block n
+  double zref;                     // log2 Z as the sweep's first emitted block reproduced it (every later block normalises by it)
+  int zready;
+  int enext;                       // next block to emit: the emitters take blocks as they become free (a static round robin
+                                   // lets the slowest emitter -- the one next to the chain wave -- hold up the whole ring)
+  int chainpos;                    // p: the chain wave holds the factors of all blocks < p in registers and has handed over its
+                                   // checkpoints < p - 1 (ONE post per block)
   int ckdone;                      // ... picked up by the flusher (offc valid)
   int offdone;                     // offtot valid
+#if WFL_MITM_STATS
+  long long blk_t[256];            // chain wave: clock at the start of every block
+#endif
 };
 
 __host__ __device__ inline int mitm_first_emitted(int NB, int dir) { return dir == 0 ? NB / 2 : NB - NB / 2; }
@@ -110,6 +126,7 @@ typedef float mv2f __attribute__((ext_vector_type(2)));
 // DIR: tile row of frame j (the reversed sweep only emits complete blocks, FULL).
 template <int DIR, bool FULL>
 __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f sa, int ea, float4 pk, float rsum, double off_sum,
+                                                    MitmLds& S, bool first,
                                                     int cnt, float cf, float g, float gs, bool skipn, bool owner, bool adder,
                                                     int lane, float* rows, int ycol, int blank, int C, long long* zmm,
                                                     float* __restrict__ dst) {
@@ -129,12 +146,17 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     }
     pa[j] = sa;
   }
-  // ---- local Z at the block's last frame, K
+  // ---- K(s) = cf 2^(ea + eb) / Z in the block's units.  The emitter's FIRST block reproduces Z itself -- sum_s own(s)
+  // [A partner](s) at its last frame, the certificate's identity -- and folds its log2 Z into the utterance's min / max
+  // for the comparison with the chain's; its later blocks reuse that log2 Z (Z is one number; the blocks only differ in
+  // their offsets, integer-valued doubles): no prefix maximum, no wave sum, no reciprocal.  They are still certified:
+  // their posteriors must sum to one per frame, which compares their own sum_s alpha beta with the reference to 2e-4.
   float bb = pk.x, bl = pk.y;
   float K = 0.f;
   bool alive;
-  double zk;  // (lane 0) log2 Z as this block reproduces it
-  {
+  double zk = -1.0e300;  // (lane 0) log2 Z as this block reproduces it
+  const int sx = ea + eb;
+  if (first) {
     const int eb_next = __builtin_amdgcn_update_dpp(eb, eb, 0x130, 0xf, 0xf, false);  // wave_shl:1 (lane 63: own)
     const float h = lane == 63 ? 0.f : ldexpf(1.f, min(max(eb_next - eb, -200), 100));
     const float hs = skipn ? h : 0.f;
@@ -142,14 +164,36 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     float tl0 = bl;
     fmac2_shl1(tl0, bb, bl, h, hs);
     const float v = sa.x * tb0 + sa.y * tl0;
-    const int sx = ea + eb;
     const int own = v > 0.f ? sx + __builtin_amdgcn_frexp_expf(v) : kEmptyE;
     const int E = __builtin_amdgcn_readlane(wave_prefix_max_i(own), 63);
     const float term = v > 0.f ? ldexpf(v, max(sx - E, -200)) : 0.f;
     const float Zm = wave_all_sum(term);
     alive = Zm > 0.f && Zm < 3.0e38f && E > kEmptyE;
-    if (alive) K = cf * ldexpf(1.f / Zm, min(max(sx - E, -200), 100));
+    if (alive) K = cf * ldexpf(__builtin_amdgcn_rcpf(Zm), min(max(sx - E, -200), 100));  // (v_rcp_f32: 1 ulp)
     zk = alive ? off_sum + (double)E + (double)__builtin_amdgcn_logf(Zm) + (double)rsum : -1.0e300;
+    if (lane == 0) S.zref = zk;
+    lds_post(&S.zready, 1);
+    if (lane == 0) {
+      const long long zq = z_fixed(zk);
+      __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    // (ONE reference per sweep, from its first emitted block whichever emitter took it: results do not depend on
+    // which emitter served which block)
+    for (int spin = 0; lds_peek(&S.zready) != 1; ++spin) {
+      __builtin_amdgcn_s_sleep(2);
+      if (spin > kMSpin) __builtin_trap();
+    }
+    asm volatile("" ::: "memory");
+    const double zref = S.zref;
+    alive = zref > -1.0e299;
+    if (alive) {
+      const double D = off_sum + (double)rsum - zref;  // = -(E + log2 Zm) of this block
+      const double Di = floor(D);
+      const float frac = __builtin_amdgcn_exp2f((float)(D - Di));
+      K = cf * frac * ldexpf(1.f, min(max(sx + (int)Di, -200), 100));
+    }
   }
   // ---- partner sweep backwards through the block (scaled by K), posteriors
   bb *= K, bl *= K;
@@ -179,40 +223,43 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
   // ---- gradient rows
   constexpr int R0 = DIR == 0 ? 0 : kBlk - 1, RS = DIR == 0 ? 1 : -1;  // tile row of frame j: R0 + RS * j
   const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
-  if (lane < (FULL ? kBlk : cnt)) rows[(R0 + RS * lane) * C + blank] = gtot;
+  if (lane < (FULL ? kBlk : cnt)) rows[(R0 + RS * lane) * kMTile + blank] = gtot;
   float* cell = rows + ycol;
   if (owner) {
 #pragma unroll
     for (int j = 0; j < kBlk; ++j)
-      if (FULL || j < cnt) cell[(R0 + RS * j) * C] = glv[j];
+      if (FULL || j < cnt) cell[(R0 + RS * j) * kMTile] = glv[j];
   }
   if (adder) {
 #pragma unroll
     for (int j = 0; j < kBlk; ++j)
-      if (FULL || j < cnt) atomicAdd(&cell[(R0 + RS * j) * C], glv[j]);
+      if (FULL || j < cnt) atomicAdd(&cell[(R0 + RS * j) * kMTile], glv[j]);
   }
   {
-    // certificate (see ctc_fast_grad_body): posterior mass of every frame, the block's log2 Z
+    // certificate (see ctc_fast_grad_body): the posterior mass of every frame
     const float stot = wave_all_sum(wsum.x + wsum.y);
     const int n = FULL ? kBlk : cnt;
     const float want = cf * ((float)n + (float)(n * (n - 1)) * (1.f / 64.f));
     const bool bad_block = alive && !(fabsf(stot - want) <= 2e-4f * fabsf(cf));
-    if (lane == 0) {
-      const long long zq = bad_block ? kZDead : z_fixed(zk);
-      __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (bad_block && lane == 0) __hip_atomic_fetch_min(zmm, kZDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
-  const int total = (FULL ? kBlk : cnt) * C;
-  if ((((uintptr_t)dst) & 15) == 0) {
-    const int n4 = total >> 2;
-    const int nfull = n4 >> 6;  // (uniform trip count: no exec juggling in the loop)
-    for (int it = 0; it < nfull; ++it) ((float4*)dst)[it * 64 + lane] = ((const float4*)rows)[it * 64 + lane];
-    if (nfull * 64 + lane < n4) ((float4*)dst)[nfull * 64 + lane] = ((const float4*)rows)[nfull * 64 + lane];
-    for (int q = (n4 << 2) + lane; q < total; q += 64) dst[q] = rows[q];
+  const int nrows = FULL ? kBlk : cnt;
+  if ((C & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+    // two rows per instruction: lanes 0..31 one row, lanes 32..63 the next (C / 4 <= 32 float4 per row)
+    const int half = lane >> 5, c4 = lane & 31;
+    const float4* src = (const float4*)rows + half * (kMTile / 4) + c4;
+    float4* out = (float4*)dst + half * (C >> 2) + c4;
+    const bool act = c4 < (C >> 2);
+#pragma unroll
+    for (int r = 0; r < kBlk; r += 2) {
+      if (FULL || r < nrows) {
+        if (act && (FULL || r + half < nrows)) out[(r >> 1) * (C >> 1)] = src[(r >> 1) * (kMTile / 2)];
+      }
+    }
   } else {
-    for (int q = lane; q < total; q += 64) dst[q] = rows[q];
+    for (int r = 0; r < nrows; ++r)
+      for (int c = lane; c < C; c += 64) dst[r * C + c] = rows[r * kMTile + c];
   }
 }
 
@@ -223,8 +270,8 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
                                                  const CtcWs& w) {
   const int lane = threadIdx.x & 63;
   const int T = a.T, C = a.C;
-  float* rows = (float*)(smem + ((sizeof(MitmLds) + 15) & ~(size_t)15)) + (size_t)em * kBlk * C;
-  for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
+  float* rows = (float*)(smem + ((sizeof(MitmLds) + 15) & ~(size_t)15)) + (size_t)em * kBlk * kMTile;
+  for (int i = lane; i < kBlk * kMTile; i += 64) rows[i] = 0.f;
   // Labels that occur once in the target own their gradient column: plain ds_write.  A repeated label's first
   // occurrence owns the column, the others add to it afterwards; a target label equal to the blank index adds to
   // the blank column.  (Columns are the same for every block of the sweep: the tile is zeroed once.)
@@ -245,7 +292,11 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
     if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
     __builtin_trap();
   };
-  for (int n = H0 + em; n < NB; n += kMEmitters) {
+  for (;;) {
+    int n = 0;
+    if (lane == 0) n = atomicAdd(&S.enext, 1);
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n >= NB) break;
     const int k = DIR == 0 ? n : NB - 1 - n;
     const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
     const int slot = n % kMSlots, ps = n % kMPSlots;
@@ -265,11 +316,11 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
       const float2 f = S.ring[slot][j][lane];
       F[j] = mv2f{f.x, f.y};
     }
-    const float2 cko = S.ckm[slot][lane];
-    const int ea = S.cke[slot][lane];
+    const float4 cko = S.ck[slot][lane];
+    const int ea = __float_as_int(cko.z);
     const float rr = lane < kBlk ? S.fref[slot][lane] : 0.f;
     const double off_own = S.offc[slot];
-    lds_post(&S.egrab[em], n + 1);  // (after the reads were issued)
+    lds_post(&S.egrab[slot], n + 1);  // (after the reads were issued)
     {
       int spin = 0;
       MITM_T0();
@@ -282,7 +333,7 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
     asm volatile("" ::: "memory");
     const float4 pk = S.pck[ps][lane];
     const double off_sum = off_own + S.poff[ps];
-    lds_post(&S.pgrab[em], n + 1);
+    lds_post(&S.pgrab[ps], n + 1);
     MITM_T0();
     const float rsum = wave_all_sum(rr);
     const int ea_prev = wave_shr1_i(ea, ea);
@@ -290,10 +341,10 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
     const float gs = skip ? g : 0.f;
     float* dst = dx + ((int64_t)b * T + t0) * C;
     if (cnt == kBlk)
-      ctc_mitm_emit_block<DIR, true>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+      ctc_mitm_emit_block<DIR, true>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
                                      ycol, a.blank, C, zmm, dst);
     else if (DIR == 0)
-      ctc_mitm_emit_block<0, false>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+      ctc_mitm_emit_block<0, false>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
                                     ycol, a.blank, C, zmm, dst);
     MITM_ACC(st_wait2);
   }
@@ -313,6 +364,9 @@ template <bool LSM>
 __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, const float* __restrict__ coef,
                                               const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
   MitmLds& S = *reinterpret_cast<MitmLds*>(smem);
+#if WFL_MITM_STATS
+  const long long st_wall0 = wall_clock64();
+#endif
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int T = a.T, C = a.C, P = a.P;
   const int64_t o0 = a.offsets[b];
@@ -329,19 +383,19 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   const int NB = ctc_blocks(T);
   const int H0 = mitm_first_emitted(NB, dir);  // blocks n < H0 are published, blocks n >= H0 emitted
-  if (dir == 0 && threadIdx.x == 0) {  // certificate accumulators (before the first checkpoint is published)
-    long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
-    coherent_store64(zmm, (unsigned long long)(1ll << 62));
-    coherent_store64(zmm + 1, (unsigned long long)(-(1ll << 62) - 1));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  }
   if (threadIdx.x < kMSlots) S.staged[threadIdx.x] = 0;
   if (threadIdx.x < kMPSlots) S.pready[threadIdx.x] = 0;
-  if (threadIdx.x < kMEmitters) S.egrab[threadIdx.x] = 0, S.pgrab[threadIdx.x] = 0;
-  if (threadIdx.x == 0) S.consumed = 0, S.ckready = 0, S.ckdone = 0, S.offdone = 0;
+  if (threadIdx.x < kMSlots) S.egrab[threadIdx.x] = 0;
+  if (threadIdx.x < kMPSlots) S.pgrab[threadIdx.x] = 0;
+  if (threadIdx.x == 0) S.enext = mitm_first_emitted(ctc_blocks(a.T), dir), S.zready = 0;
+  if (threadIdx.x == 0) S.chainpos = 0, S.ckdone = 0, S.offdone = 0;
+#if WFL_MITM_STATS
+  if (threadIdx.x < 256) S.blk_t[threadIdx.x] = 0;
+#endif
   __syncthreads();
   int role, ridx;
   mitm_role(wave, role, ridx);
+  if (role == 5) return;  // (a wave that has ended no longer counts for anything: no barrier after the first)
 #if WFL_MITM_STATS
   long long st_wait0 = 0, st_wait1 = 0, st_wait2 = 0, st_polls = 0;
   const long long st_begin = clock64();
@@ -350,8 +404,10 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       long long* d = (long long*)(a.ws + w.dbg) + ((int64_t)(b * 2 + dir) * kMWaves + wave) * 8;
       unsigned hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      d[0] = clock64() - st_begin, d[1] = st_wait0, d[2] = st_wait1, d[3] = st_wait2, d[4] = st_polls, d[5] = hw;
-      d[6] = wall_clock64();
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      d[0] = clock64() - st_begin, d[1] = st_wait0, d[2] = st_wait1, d[3] = st_wait2, d[4] = st_polls, d[5] = hw | ((long long)(xcc & 15) << 32);
+      d[6] = wall_clock64(), d[7] = st_wall0;
     }
   };
 #else
@@ -363,11 +419,12 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     __builtin_trap();
   };
   // has emitter-owned block m (m >= H0) been taken into registers?
-  auto grabbed = [&](int m) { return lds_peek(&S.egrab[(m - H0) % kMEmitters]) >= m + 1; };
-  auto pgrabbed = [&](int m) { return lds_peek(&S.pgrab[(m - H0) % kMEmitters]) >= m + 1; };
+  auto grabbed = [&](int m) { return lds_peek(&S.egrab[m % kMSlots]) == m + 1; };
+  auto pgrabbed = [&](int m) { return lds_peek(&S.pgrab[m % kMPSlots]) == m + 1; };
 
   if (role == 1) {
     // ================================================================ stagers
+    __builtin_amdgcn_s_setprio(2);  // the chain waits for them; the emitters next to them are throughput work
     const int h = ridx;
     auto issue = [&](int n, float (&raw)[kBlk]) {
       const int k = dir == 0 ? n : NB - 1 - n;
@@ -391,6 +448,12 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       const int k = dir == 0 ? n : NB - 1 - n;
       const int cnt = min(kBlk, T - k * kBlk);
       const int slot = n % kMSlots;
+      if ((WFL_MITM_ABL & 16) && n >= H0) {  // (scratch: what a second half fed with ready-made factors would cost)
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) S.ring[slot][j][lane] = make_float2(has_blank ? 0.7f : 0.f, has_label ? 0.7f + 0.001f * raw[j] : 0.f);
+        if (lane < kBlk) S.fref[slot][lane] = 0.f;
+        return;
+      }
       float xs[kBlk];
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) {
@@ -412,7 +475,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       const int m = n - kMSlots;  // the block that held the slot
       int spin = 0;
       MITM_T0();
-      while (lds_peek(&S.consumed) < m + 1 || lds_peek(&S.ckdone) < m + 1 || (m >= H0 && !grabbed(m))) {
+      while (lds_peek(&S.chainpos) < m + 1 || lds_peek(&S.ckdone) < m + 1 || (m >= H0 && !grabbed(m))) {
         __builtin_amdgcn_s_sleep(2);
         if (++spin > kMSpin) give_up();
       }
@@ -457,6 +520,15 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
     unsigned long long* half = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;  // "first half published"
     double offcum = 0.0;  // sum of r_t over the blocks before the checkpoint
+    if (dir == 0 && lane == 0) {
+      // certificate accumulators of the utterance.  By THIS wave: its stores are acknowledged (vmcnt(0) below) before it
+      // raises the flag that lets the partner's emitters run, and before it hands the first emitted block of this
+      // sweep to the local emitters (ckdone) -- no other wave has to wait for them (measured: the same two stores and a
+      // release fence by the chain wave before the workgroup's barrier cost every alpha sweep 1-2 us of prologue)
+      long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+      coherent_store64(zmm, (unsigned long long)(1ll << 62));
+      coherent_store64(zmm + 1, (unsigned long long)(-(1ll << 62) - 1));
+    }
     if (dir == 0) {
       // bit 63 of dup[b]: the target cannot be aligned at all -- T < L + adjacent repeats.  Such an utterance has
       // Z = 0 exactly, in any arithmetic: loss inf, zero gradient, nothing for the certificate to doubt
@@ -467,7 +539,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       {
         int spin = 0;
         MITM_T0();
-        while (lds_peek(&S.ckready) < kk + 1) {
+        while (lds_peek(&S.chainpos) < kk + 2) {
           __builtin_amdgcn_s_sleep(1);
           if (++spin > kMSpin) give_up();
         }
@@ -481,8 +553,8 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         // partner only needs them when this sweep has finished its first half (it emits from the middle outwards, so
         // the LAST checkpoint published is the first one it uses) -- ONE flag per sweep, raised after the stores of
         // the whole half have been acknowledged.
-        const float2 m = S.ckm[slot][lane];
-        const int e = S.cke[slot][lane];
+        const float4 m = S.ck[slot][lane];
+        const int e = __float_as_int(m.z);
         const unsigned long long vb = (unsigned long long)__float_as_uint(m.x) | ((unsigned long long)(unsigned)e << 32);
         const unsigned long long vl = (unsigned long long)__float_as_uint(m.y) | ((unsigned long long)(unsigned)e << 32);
         unsigned long long obits;
@@ -497,6 +569,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
           if (lane == 0) coherent_store64(half, a.token);
         }
       }
+      if (H0 == 0 && kk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing published: the accumulators' stores)
       if (lane == 0) S.offc[slot] = offcum;
       lds_post(&S.ckdone, kk + 1);
       offcum += (double)wave_all_sum(rj);
@@ -587,8 +660,9 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     bool bad = false;
     // per-lane power-of-two renormalisation, neighbour-gap clamp, coupling factors for the interval
     auto lane_renorm = [&]() {
+      // (no overflow test here: an inf or NaN mantissa stays one -- ldexp, the frames' multiply-adds -- and is
+      // seen after the last frame; the blocks' certificates see it as well)
       const float mx = vmax(pb, pl);
-      bad = bad || !(mx < 3.0e38f);
       const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
       const int own = mx > 0.f ? e + k : kEmptyE;
       const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
@@ -637,8 +711,11 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) fa[j] = S.ring[0][j][lane];
-    lds_post(&S.consumed, 1);
+    lds_post(&S.chainpos, 1);
     int nflag = NB > 1 ? lds_peek(&S.staged[1 % kMSlots]) : 0;  // looked at one block ahead of its use
+    // ring slots of blocks kk, kk + 1, kk + 2, advanced by increments (a lone wave pays ~4 cycles for ANY instruction,
+    // scalar ones included: no division by kMSlots on this wave)
+    int s0 = 0, s1 = 1 % kMSlots, s2 = 2 % kMSlots;
     auto block = [&](int kk, const float2 (&fcur)[kBlk], float2 (&fnxt)[kBlk], auto steady) {
       constexpr bool STEADY = decltype(steady)::value;
       const int k = dir == 0 ? kk : NB - 1 - kk;
@@ -647,25 +724,34 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         if (nflag != kk + 2) {
           int spin = 0;
           MITM_T0();
-          while (lds_peek(&S.staged[(kk + 1) % kMSlots]) != kk + 2)
+          while (lds_peek(&S.staged[s1]) != kk + 2)
             if (++spin > kMSpin) give_up();
           MITM_ACC(st_wait1);
 #if WFL_MITM_STATS
           st_polls += spin;
+          if (lane == 0 && kk < 256) S.blk_t[kk] |= (long long)min(spin, 4095) << 48;  // (stamped below: the stamp keeps these bits)
 #endif
         }
         asm volatile("" ::: "memory");
+        if (!(STEADY && (WFL_MITM_ABL & 2))) {
 #pragma unroll
-        for (int j = 0; j < kBlk; ++j) fnxt[j] = S.ring[(kk + 1) % kMSlots][j][lane];
-        lds_post(&S.consumed, kk + 2);  // (after the reads were issued: LDS executes a wave's instructions in order)
-        if (STEADY || kk + 2 < NB) nflag = lds_peek(&S.staged[(kk + 2) % kMSlots]);
+          for (int j = 0; j < kBlk; ++j) fnxt[j] = S.ring[s1][j][lane];
+        }
+        if (STEADY || kk + 2 < NB) nflag = lds_peek(&S.staged[s2]);
       }
-      lane_renorm();
-      // (slot kk % kMSlots is free: block kk could only be staged after block kk - kMSlots had been flushed and grabbed)
-      S.ckm[kk % kMSlots][lane] = make_float2(pb, pl);
-      S.cke[kk % kMSlots][lane] = e;
-      lds_post(&S.ckready, kk + 1);
-      if (n >= kBlk) {
+#if WFL_MITM_STATS
+      if (lane == 0 && kk < 256) S.blk_t[kk] = (S.blk_t[kk] & (0xfffll << 48)) | (clock64() - st_begin);
+#endif
+      if (!(STEADY && ((WFL_MITM_ABL & 1) || ((WFL_MITM_ABL & 32) && (kk & 1))))) lane_renorm();
+      // (slot s0 is free: block kk could only be staged after block kk - kMSlots had been flushed and grabbed)
+      if (!(STEADY && (WFL_MITM_ABL & 4))) S.ck[s0][lane] = make_float4(pb, pl, __int_as_float(e), 0.f);
+      // ONE post: the factors of block kk + 1 are in registers (their reads were issued above: LDS executes a wave's
+      // instructions in order) and checkpoint kk is written
+      lds_post(&S.chainpos, kk + 2);
+      s0 = s1, s1 = s2, s2 = s2 + 1 == kMSlots ? 0 : s2 + 1;
+      if (STEADY && (WFL_MITM_ABL & 8)) {
+        pb += fcur[0].x + fcur[kBlk - 1].y;
+      } else if (n >= kBlk) {
 #pragma unroll
         for (int j = 0; j < kBlk; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
       } else {
@@ -688,6 +774,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         if (kk + 1 < NB) block(kk + 1, fa, fz, std::false_type{});
       }
     }
+    bad = !(fabsf(pb) < 3.0e38f) || !(fabsf(pl) < 3.0e38f);
     lane_renorm();
     {
       int spin = 0;
@@ -699,7 +786,8 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       MITM_ACC(st_wait2);
     }
     asm volatile("" ::: "memory");
-    if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = bad ? 1 : 0;
+    const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;  // (any lane)
+    if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = any_bad ? 1 : 0;
     if (dir == 0) {
       // Z = alpha_{T-1}[2L] + alpha_{T-1}[2L-1]   (ctc.py:21 accept states), lanes L and L-1
       const float zb = readlane_f(pb, L);
@@ -715,10 +803,16 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         publish_nll<true, false>(a, w, b, ok, z2);
       }
       stats_out();
+#if WFL_MITM_STATS
+      for (int q = lane; q < min(NB, 256); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
+#endif
       if (a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
       return;
     }
     stats_out();
+#if WFL_MITM_STATS
+    for (int q = lane; q < min(NB, 256); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
+#endif
     return;
   }
 
@@ -738,5 +832,9 @@ __global__ void __launch_bounds__(kMWaves * 64)
     perr[0] = 0;  // a wave gave up waiting
     perr[1] = 0;  // utterances the repair launch recomputed
   }
+#ifdef WFL_MITM_FLIP
+  ctc_mitm_body<LSM>(a, (int)blockIdx.x >> 1, 1 - ((int)blockIdx.x & 1), coef, gout, dx, smem);
+#else
   ctc_mitm_body<LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, coef, gout, dx, smem);
+#endif
 }

@@ -14,16 +14,20 @@ dx = torch.empty_like(x)
 for _ in range(5):
     ws, nll, loss = E.ctc_forward_backward(x, tg, C - 1, coef, None, dx, loss_scale=scale, want_loss=True)
 torch.cuda.synchronize()
-d = E.ctc_workspace_field(ws, B, T, tg.max_len, 4).view(torch.int64).cpu().numpy().reshape(B, 2, 12, 8).astype(np.float64)
-names = {0: "chain", 1: "stager0", 2: "stager1", 3: "stager2", 4: "flusher", 5: "stager3", 6: "emit0", 7: "emit1", 8: "fetcher",
-         9: "emit2", 10: "emit3", 11: "emit4"}
+raw = E.ctc_workspace_field(ws, B, T, tg.max_len, 4).view(torch.int64).cpu().numpy()
+d = raw[:B * 2 * 16 * 8].reshape(B, 2, 16, 8).astype(np.float64)
+blkraw = raw[B * 2 * 16 * 8:].reshape(B, 2, 256)
+blk = (blkraw & ((1 << 48) - 1)).astype(np.float64)
+blkpoll = (blkraw >> 48) & 0xfff
+names = {0: "chain", 1: "stager0", 2: "stager1", 3: "stager2", 5: "stager3", 6: "stager4", 7: "stager5", 4: "flusher", 8: "fetcher",
+         9: "emit0", 10: "emit1", 11: "emit2", 13: "emit3", 14: "emit4", 15: "emit5", 12: "emit6"}
 what = {"chain": ("first block", "staged polls", "offdone"), "stager": ("slot wait", "stage compute", "-"),
         "flusher": ("ckready wait", "-", "-"), "fetcher": ("pck slot wait", "partner flag wait", "-"),
         "emit": ("ckdone wait", "pready wait", "compute+store")}
 cyc = 1.0 / 2400.0  # us per cycle (nominal)
 for dirn in (0, 1):
     print("dir %d  (medians over %d utterances, us at 2.4 GHz; polls = count)" % (dirn, B))
-    for wv in range(12):
+    for wv in sorted(names):
         r = d[:, dirn, wv, :]
         nm = names[wv]
         k = "emit" if nm.startswith("emit") else "stager" if nm.startswith("stager") else nm
@@ -32,7 +36,39 @@ for dirn in (0, 1):
             nm, simd, np.median(r[:, 0]) * cyc, what[k][0], np.median(r[:, 1]) * cyc, what[k][1], np.median(r[:, 2]) * cyc,
             what[k][2], np.median(r[:, 3]) * cyc, np.median(r[:, 4])))
 ends = d[:, :, :, 6]
-t0 = ends[ends > 0].min()
-print("wave end wall clock (us after the first wave to end): chain a %.1f b %.1f, last emitter a %.1f b %.1f" % (
-    np.median(ends[:, 0, 0] - t0) / 100, np.median(ends[:, 1, 0] - t0) / 100, np.median(ends[:, 0, 6:].max(axis=1) - t0) / 100,
-    np.median(ends[:, 1, 6:].max(axis=1) - t0) / 100))
+starts = d[:, :, 0, 7]  # chain wave's entry clock per workgroup
+t0 = starts.min()
+wg_end = ends.max(axis=2)
+print("workgroup entry (us after the first): median %.1f p90 %.1f max %.1f" % tuple(np.percentile((starts - t0) / 100, [50, 90, 100])))
+print("chain wave end: median %.1f p90 %.1f max %.1f" % tuple(np.percentile((ends[:, :, 0] - t0) / 100, [50, 90, 100])))
+print("workgroup end:  median %.1f p90 %.1f max %.1f" % tuple(np.percentile((wg_end - t0) / 100, [50, 90, 100])))
+print("workgroup span (entry -> last wave end): median %.1f p90 %.1f max %.1f" % tuple(np.percentile((wg_end - starts) / 100, [50, 90, 100])))
+pro = (d[:, :, 0, 6] - d[:, :, 0, 7]) / 100 - d[:, :, 0, 0] / 2400
+print("chain wave: entry -> counters start (prologue) us: alpha median %.1f, beta median %.1f" % (np.median(pro[:, 0]), np.median(pro[:, 1])))
+hw = d[0, 0, :, 5].astype(np.int64)
+print("utterance 0 alpha workgroup: wave -> simd", [int((h >> 4) & 3) for h in hw], "cu", [int((h >> 8) & 15) for h in hw], "se", [int((h >> 13) & 7) for h in hw])
+NB = (T + 15) // 16
+bt = np.median(blk[:, :, :NB], axis=0) / 2400.0  # us since the chain wave's start
+for dirn in (0, 1):
+    print("dir %d chain block start times (us): " % dirn + " ".join("%d:%.1f" % (k, bt[dirn, k]) for k in range(0, NB, 4)))
+    dts = np.diff(bt[dirn, :NB])
+    h = NB // 2
+    print("   pace us/block: first half median %.3f, second half median %.3f" % (np.median(dts[2:h - 2]), np.median(dts[h + 2:])))
+    print("   per block us: " + " ".join("%.2f" % v for v in dts))
+    print("   polls/block (mean over utterances): " + " ".join("%.0f" % v for v in blkpoll[:, dirn, :NB].mean(axis=0)))
+
+# stragglers: which workgroups end last?
+hwc = d[:, :, 0, 5].astype(np.int64)
+xcc = (hwc >> 32) & 15; cu = (hwc >> 8) & 15; se = (hwc >> 13) & 7
+order = np.argsort(wg_end.reshape(-1))[::-1]
+print("slowest workgroups: (b, dir) xcc se cu | chain end, wg end (us after first entry) | chain staged-poll us")
+for o in order[:12]:
+    bb, dd = divmod(o, 2)
+    print("  (%3d,%d) xcc %d se %d cu %2d | %.1f %.1f | %.1f" % (bb, dd, xcc[bb, dd], se[bb, dd], cu[bb, dd], (ends[bb, dd, 0] - t0) / 100, (wg_end[bb, dd] - t0) / 100, d[bb, dd, 0, 2] / 2400))
+print("fastest:")
+for o in order[-5:]:
+    bb, dd = divmod(o, 2)
+    print("  (%3d,%d) xcc %d se %d cu %2d | %.1f %.1f | %.1f" % (bb, dd, xcc[bb, dd], se[bb, dd], cu[bb, dd], (ends[bb, dd, 0] - t0) / 100, (wg_end[bb, dd] - t0) / 100, d[bb, dd, 0, 2] / 2400))
+for x in range(8):
+    m = xcc == x
+    if m.any(): print("  xcc %d: %3d workgroups, end median %.1f max %.1f" % (x, m.sum(), np.median((wg_end[m] - t0) / 100), ((wg_end[m] - t0) / 100).max()))
