@@ -572,12 +572,21 @@ class HostPool {
   void parallel_for(int n, const std::function<void(int)>& fn) {
     std::lock_guard<std::mutex> run(run_mu_);
     const int k = std::min(nworkers_, std::max(n - 1, 0));  // workers that take part in this job
-    fn_ = &fn, n_ = n, k_ = k;
+    if (k == 0) {  // nothing to share: no generation, nobody woken
+      for (int i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    fn_ = &fn, n_ = n;
     next_.store(0, std::memory_order_relaxed);
-    running_.store(k + 1, std::memory_order_release);
+    running_.store(k + 1, std::memory_order_relaxed);
     // ONE system call wakes every sleeping worker (they sleep on the generation word): posting a semaphore per
-    // worker cost the calling thread ~5 us each, 160 us before the last of 32 workers had even been told
-    gen_.fetch_add(1, std::memory_order_release);
+    // worker cost the calling thread ~5 us each, 160 us before the last of 32 workers had even been told.
+    // The word carries the job's participant count in its low byte: a worker decides whether it takes part from
+    // the SAME atomic load that showed it the generation -- a worker that wakes late (after its generation's job is
+    // over and while the next one is being set up) still sees the old word, hence the old k, and does not touch
+    // fn_ / n_ / next_, which only participants of the published generation may read.
+    count_ += 1;
+    gen_.store((count_ << 8) | (uint32_t)k, std::memory_order_release);
     if (k > 0) syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen_), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
     drain();
     while (sem_wait(&done_) != 0) {
@@ -603,7 +612,7 @@ class HostPool {
       seen = g;
       // (a job cannot finish before each of its k workers has drained, so a participant never misses a generation;
       // workers beyond k may skip some, which is all they would have done with them)
-      if (id < k_) drain();
+      if (id < (int)(g & 0xffu)) drain();
     }
   }
   std::mutex run_mu_;
@@ -612,7 +621,8 @@ class HostPool {
   const std::function<void(int)>* fn_ = nullptr;
   std::atomic<uint32_t> gen_{0};
   std::atomic<int> next_{0}, running_{0};
-  int n_ = 0, k_ = 0;
+  int n_ = 0;
+  uint32_t count_ = 0;  // generation counter (upper 24 bits of gen_), advanced under run_mu_
 };
 
 std::mutex g_pool_mu;

@@ -8,10 +8,11 @@ against the float64 oracle, at the north-star tolerance.
   cfg5  CTC        T=2000 C=512  B=128 -- one GPU's shard of the 8-GPU configuration
 
 Tolerance (north_star: 1e-4 relative on log-semiring loss / grad): every gradient element within
-1e-4 * |expected| + 1e-4 * |coef_b|, where coef_b = scale_b / B is the factor the reference multiplies a
+1e-4 * |expected| + 5e-5 * |coef_b| (the reference's own equivalence bar: tests/transducer_test.py:275-316 uses
+atol 1e-5 at B=5, i.e. 5e-5 of a posterior's scale), where coef_b = scale_b / B is the factor the reference multiplies a
 posterior (a number in [0,1]) with (ctc.py:87, asg.py:171-179, transducer.py:329-336) -- i.e. posteriors are
-right to 1e-4 of their scale; per-utterance losses to 1e-4 relative.  The measured worst cases are written to
-gpurun_out/parity_r02.json.  Nothing here reads /root/reference."""
+right to 5e-5 of their scale; per-utterance losses to 1e-4 relative.  The measured worst cases are written to
+gpurun_out/parity_r03.json.  Nothing here reads /root/reference."""
 import json
 import os
 import random
@@ -27,6 +28,7 @@ from oracle import recurrences as OR  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTOL = 1e-4
+ATOL_SCALE = 5e-5
 STATS = {}
 
 
@@ -38,24 +40,30 @@ def _gpu_and_stats():
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "parity_r02.json"), "w") as f:
+        with open(os.path.join(out, "parity_r03.json"), "w") as f:
             json.dump(STATS, f, indent=1)
     except OSError:
         pass
 
 
 def check(name, got, want, scale):
-    """|got - want| <= RTOL * |want| + RTOL * scale elementwise; records the worst case."""
+    """|got - want| <= RTOL * |want| + ATOL_SCALE * scale elementwise; records the worst case."""
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape and np.isfinite(got).all(), name
     err = np.abs(got - want)
-    tol = RTOL * np.abs(want) + RTOL * scale
-    k = int(np.argmax(err / tol))
+    tol = RTOL * np.abs(want) + ATOL_SCALE * scale
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(tol > 0, err / np.where(tol > 0, tol, 1.0), np.where(err > 0, np.inf, 0.0))
+    k = int(np.argmax(ratio))
     rec = STATS.setdefault(name, dict(max_err_over_tol=0.0, max_abs_err=0.0, max_abs_err_over_scale=0.0, elements=0))
-    rec["max_err_over_tol"] = max(rec["max_err_over_tol"], float((err / tol).flat[k]))
+    rec["max_err_over_tol"] = max(rec["max_err_over_tol"], float(ratio.flat[k]))
     rec["max_abs_err"] = max(rec["max_abs_err"], float(err.max()))
-    rec["max_abs_err_over_scale"] = max(rec["max_abs_err_over_scale"], float(err.max() / scale))
+    if scale > 0:
+        rec["max_abs_err_over_scale"] = max(rec["max_abs_err_over_scale"], float(err.max() / scale))
+    else:  # purely relative check (losses): report the relative error instead
+        rel = err / np.maximum(np.abs(want), 1e-300)
+        rec["max_abs_err_over_scale"] = max(rec["max_abs_err_over_scale"], float(rel.max()))
     rec["elements"] += int(err.size)
     assert err.flat[k] <= tol.flat[k], (f"{name}: |{got.flat[k]:.9g} - {want.flat[k]:.9g}| = {err.flat[k]:.3g} "
                                         f"> {tol.flat[k]:.3g} at flat index {k}")
@@ -89,6 +97,65 @@ def test_cfg2_ctc_every_utterance():
     xg2 = x.cuda().requires_grad_(True)
     (3.0 * ctc.CTCLoss(xg2, targets, C - 1, "mean")).backward()
     check("cfg2_ctc_dx_mean_x3", xg2.grad.cpu().numpy(), want_dx * (3.0 / L), 3.0 / (L * B))
+
+
+def test_cfg1_ctc_plumbing_shape():
+    """BASELINE configs[0] (T=150, C=28, B=8, L=44 -- the reference's CPU plumbing case): the HIP step against the
+    float64 oracle.  (The CPU port at this shape: tests/test_oracle.py::test_c_restatement_at_cfg1_shape.)"""
+    from gtn_applications_amd.criterions import ctc
+
+    B, T, C, L = 8, 150, 28, 44
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, C, generator=g)
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    want_loss, want_dx = OR.ctc_loss_grad_batched(x.numpy(), targets, C - 1)
+    xg = x.cuda().requires_grad_(True)
+    loss = ctc.CTCLoss(xg, targets, C - 1)
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss.mean(), rel=RTOL)
+    check("cfg1_ctc_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / B)
+
+
+def _model_shaped_scores(rs, B, T, C, L, boost, noise, wrong):
+    """log-probabilities that look like a trained model's output: noise + boost on the label a random monotone
+    alignment of the target puts on each frame (blank elsewhere), a fraction `wrong` of frames confidently wrong."""
+    x = (noise * rs.randn(B, T, C)).astype(np.float32)
+    targets = []
+    for b in range(B):
+        y = rs.randint(0, C - 1, size=L)
+        targets.append(y.tolist())
+        cuts = np.sort(rs.choice(np.arange(1, T), size=2 * L, replace=False))
+        lab = np.full(T, C - 1)
+        for i in range(L):
+            lab[cuts[2 * i]:cuts[2 * i + 1]] = y[i]
+        flip = rs.rand(T) < wrong
+        lab = np.where(flip, rs.randint(0, C, size=T), lab)
+        x[b, np.arange(T), lab] += boost
+    return torch.log_softmax(torch.tensor(x), 2), targets
+
+
+@pytest.mark.parametrize("boost,noise,wrong", [(8.0, 1.0, 0.1), (12.0, 2.0, 0.1), (20.0, 1.0, 0.02), (3.0, 1.0, 0.3)])
+def test_cfg2_ctc_model_shaped_scores_stay_on_the_fast_path(boost, noise, wrong):
+    """Peaked log-probabilities (spread up to ~20 nats between the aligned label and the rest): parity on every
+    utterance AND at most 2 of 128 utterances handed to the log-domain repair launch -- the lane-exponent step is
+    the one that runs on data a trained model produces, not only on unit-variance noise."""
+    from gtn_applications_amd import engine as E
+
+    B, T, C, L = 128, 1000, 100, 44
+    rs = np.random.RandomState(int(boost * 10 + wrong * 100))
+    lp, targets = _model_shaped_scores(rs, B, T, C, L, boost, noise, wrong)
+    want_loss, want_dx = OR.ctc_loss_grad_batched(lp.numpy(), targets, C - 1)
+    xd = lp.cuda()
+    tg = E.targets_on_device(targets, xd.device)
+    scale, _, coef = E.loss_factors(tg, "none")
+    dx = torch.full_like(xd, float("nan"))
+    ws, nll = E.ctc_forward_backward(xd, tg, C - 1, coef, None, dx)
+    name = f"cfg2_ctc_model_shaped_b{boost:g}_n{noise:g}_w{wrong:g}"
+    check(name + "_nll", nll.cpu().numpy(), want_loss, 0.0)
+    check(name + "_dx", dx.cpu().numpy(), want_dx, 1.0 / B)
+    repaired = E.ctc_pipeline_repaired(ws, B, T, tg.max_len)
+    STATS[name + "_repaired_utterances"] = repaired
+    assert repaired <= 2, f"{repaired} of {B} utterances left the lane-exponent path"
 
 
 def test_cfg3_asg_every_utterance():

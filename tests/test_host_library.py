@@ -550,6 +550,43 @@ def test_native_batch_builder_equals_per_utterance_graph_algebra(with_transition
     assert f2.tolist() == [2, 2, 1, 0] and o2.tolist() == [0, 3, 4] and l2 == [3, 1]
 
 
+def test_host_pool_jobs_with_different_participant_counts():
+    """The persistent host pool under jobs whose participant counts alternate (B = 3 uses 2 workers, B = 37 all of
+    them), issued from two caller threads: a worker that wakes late must decide from the generation word it saw
+    whether it takes part (pack.cpp HostPool) -- every result byte-equal to the serial one, many times over."""
+    import threading
+
+    rs = np.random.RandomState(11)
+    pieces = ["a", "b", "ab", "ba", "aba", "bab", "c", "ca"]
+    g2i = {"a": 0, "b": 1, "c": 2}
+    tokens = TR.make_token_graph(pieces, "optional", False)
+    lexicon = TR.make_lexicon_graph(pieces, g2i)
+    tokens.arc_sort(True)
+    C = len(pieces) + 1
+    cases = []
+    for B in (3, 37, 2, 17):
+        rows = [[g2i[ch] for _ in range(rs.randint(1, 6)) for ch in pieces[rs.randint(len(pieces))]] for _ in range(B)]
+        flat, off, _ = E.flatten_targets(rows)
+        want = E.PackedLattice.transducer_batch(tokens, lexicon, None, flat, off, C, None, 1)
+        cases.append((flat, off, np.array(want.host_ints), np.array(want.host_floats)))
+    errors = []
+
+    def hammer(order):
+        try:
+            for it in range(60):
+                flat, off, ints, floats = cases[order[it % len(order)]]
+                got = E.PackedLattice.transducer_batch(tokens, lexicon, None, flat, off, C, None, 0)
+                np.testing.assert_array_equal(got.host_ints, ints)
+                np.testing.assert_array_equal(got.host_floats, floats)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=hammer, args=(o,)) for o in ([0, 1, 2, 3], [1, 0, 3, 2])]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors[0]
+
+
 def test_batch_builder_writes_into_the_callers_buffer():
     """wfl_transducer_pack_batch_into: [floats | reserved | pad to 16 B | ints] laid out in the caller's (staging)
     buffer, byte-equal to the library-owned blobs; a buffer that is too small falls back to library storage."""
