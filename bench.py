@@ -6,37 +6,44 @@ configs[1], the reference's CTC benchmark (benchmarks/ctc_benchmark.py:17-31: ra
 randint(C-2), blank C-1, reduction "none") at T=1000, C=100, B=128, L=44 on one MI355X.
 
 A "step" = one pass of the hot path over one batch whose inputs -- emissions AND targets -- are resident in HBM:
-  --mode abi (default for ctc)  `wfl_ctc_forward_backward` through the C ABI of include/wfl.h, the drop-in boundary
-                        of the path, targets staged on the device before the timed region: what the GPU does;
-  --mode api (default for asg / transducer; ctc: reported as `python_api`)  the drop-in operator exactly as the
-                        reference's benchmark scripts call it -- `CTCLoss(x, targets, blank).backward()`
-                        (`ASGLoss(...)`, `Transducer(...)(x, targets)`), autograd and host-side target handling
-                        included.  For CTC at B = 128 the operator is host-bound on slow hosts (66-95 us of Python /
-                        autograd per call against 62-68 us of kernels), which is why it is not the headline.
+  --mode api (default)  the drop-in operator exactly as the reference's benchmark scripts call it --
+                        `CTCLoss(x, targets, blank).backward()` (`ASGLoss(...)`, `Transducer(...)(x, targets)`),
+                        autograd and host-side target handling included (benchmarks/ctc_benchmark.py:26-31).  This
+                        is `value`;
+  --mode abi (ctc only; reported as `abi_kernels_only` next to the headline)  `wfl_ctc_forward_backward` through
+                        the C ABI of include/wfl.h, targets staged on the device before the timed region: what the
+                        GPU does.
   --targets same (default)  the reference benchmarks' own protocol (benchmarks/ctc_benchmark.py:26-31: one target
                         list reused by every iteration): after the first call the targets -- like the emissions --
                         are resident in HBM when a timed step starts (the engine's content-keyed staging cache);
   --targets fresh       every step (warm-up included) gets targets never seen before, so no content-keyed cache
                         of the engine can hit: per-batch host work (flattening, staging, the upload; for the
                         Transducer the whole graph algebra) is inside the timed region.
-`value` is the default of the workload; the operator with the same targets (`python_api`, ctc) and the cold-cache
-operator (`fresh_targets`) are reported next to it, with `hip_graph` (the ABI step captured and replayed).
+`value` is the operator with the reference benchmarks' protocol; the C-ABI step (`abi_kernels_only`, ctc) and the
+cold-cache operator (`fresh_targets`) are reported next to it.
 
 Per-kernel times come from HIP events recorded on the stream each launch goes to, inside the timed region
-(engine.PHASE_EVENTS); `roofline` is computed for the dominant one, `traffic` from the committed PMC passes
-(profiles/r02_pmc_traffic.json, collected with scripts/collect_round.sh on the same commands).
+(engine.PHASE_EVENTS); `roofline.frac` is STEP level -- the batch's algorithmic bytes over the sum of all kernel
+groups of a step (for CTC that is one launch + the repair launch) -- with the dominant kernel's own figure under
+`roofline.dominant_kernel`; `traffic` from the committed PMC passes (profiles/r03_pmc_traffic.json, else r02,
+collected with scripts/collect_round.sh on the same commands).
 
   python bench.py                                   # cfg2 CTC, 1 GPU, finishes in about a minute
   python bench.py --workload asg                    # cfg3
   python bench.py --workload transducer             # cfg4 (the reference's 1000 word pieces)
-  python bench.py --T 2000 --C 512                  # one GPU's shard of cfg5
+  python bench.py --config cfg5                     # one GPU's shard of cfg5 (T=2000, C=512, 128 utterances per GPU)
+  python bench.py --gpus 8 --config cfg5            # cfg5 itself: spawns its own 8 ranks (train.py:344-347 does too)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W   # ... or under a launcher (RANK / WORLD_SIZE set)
 
 Multi-GPU: utterances shard over ranks (same per-GPU batch: weak scaling), no emissions cross GPUs.  CTC has no
-learnable transition weights, hence no data-path collective; --workload asg averages the transition-weight
-gradient over ranks each step (parallel.sync_transition_grads, RCCL all-reduce).  Timing: barrier + synchronize
-on both sides, MAX over ranks.
+learnable transition weights, hence no data-path collective at cfg2; --workload asg averages the transition-weight
+gradient over ranks each step (parallel.sync_transition_grads, RCCL all-reduce); --config cfg5 all-reduces a
+[(C+1), C] fp32 buffer per step through parallel.all_reduce_mean_ although pure CTC has nothing to exchange
+(BASELINE configs[4] names "RCCL all-reduce of transition grads", so the harness exercises the
+collective with the payload an ASG criterion of that size would have) and says so in config.parallelism.  Timing:
+barrier + synchronize on both sides, MAX over ranks.  Without a launcher `--gpus N` (N > 1) starts N worker
+processes itself, one device each, rendezvous on 127.0.0.1.
 """
 import argparse
 import json
@@ -53,10 +60,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+VALU_F32_PEAK_TFLOPS = 157.3  # fp32 vector peak (MI355X_MICROARCH.md)
 
 # which kernels run inside each timed phase of engine.PHASE_EVENTS (short names as rocprofv3 reports them)
 PHASE_KERNEL_NAMES = {
-    "ctc_step": ["ctc_compact_x_kernel", "ctc_fast_pipelined_kernel", "ctc_repair_kernel"],
+    "ctc_step": ["ctc_compact_x_kernel", "ctc_mitm_kernel", "ctc_fast_pipelined_kernel", "ctc_repair_kernel"],
     "ctc_chains": ["ctc_log_chain_kernel"],
     "ctc_grad": ["reduce_loss_kernel", "ctc_grad_kernel"],
     "lattice_gather": ["gather_lse_kernel", "gather_kernel"],
@@ -78,8 +86,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ctc", choices=["ctc", "asg", "transducer"])
-    ap.add_argument("--mode", default=None, choices=["abi", "api"],
-                    help="default: abi for --workload ctc (the C-ABI boundary of the path), api for asg / transducer")
+    ap.add_argument("--config", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="a BASELINE.json configuration by name (sets workload and shape; cfg5 adds the all-reduce)")
+    ap.add_argument("--mode", default="api", choices=["abi", "api"],
+                    help="api: the drop-in operator (headline); abi: the C-ABI call with pre-staged targets (ctc only)")
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="tests only: gloo ranks on the CPU and a stub step -- exercises the rank / timing plumbing, measures nothing")
     ap.add_argument("--targets", default="same", choices=["fresh", "same"])
     ap.add_argument("--B", type=int, default=None)
     ap.add_argument("--T", type=int, default=None)
@@ -92,22 +104,56 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the labelled extra measurements (profiling runs)")
     ap.add_argument("--cpu-sample-utts", type=int, default=None)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config:
+        shape = {"cfg2": ("ctc", 128, 1000, 100), "cfg3": ("asg", 128, 1000, 100), "cfg4": ("transducer", 64, 800, None),
+                 "cfg5": ("ctc", 128, 2000, 512)}[args.config]
+        args.workload = shape[0]
+        args.B, args.T, args.C = args.B or shape[1], args.T or shape[2], args.C or shape[3]
+    return args
 
 
-def dist_setup(n):
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N copies of this command, one rank per device, and wait
+    (the reference spawns its own ranks too: train.py:344-347).  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def dist_setup(n, stub_cpu=False):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if n > 1 or world > 1:
+    if world != max(n, 1) and "WORLD_SIZE" in os.environ:
+        raise SystemExit(f"bench.py: --gpus {n} but the launcher started WORLD_SIZE={world} ranks")
+    if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        if stub_cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            return rank, world, local, dist
+        if torch.cuda.device_count() <= local:
+            raise SystemExit(f"bench.py: rank {rank} wants cuda:{local}, {torch.cuda.device_count()} device(s) visible")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         return rank, world, local, dist
-    torch.cuda.set_device(0)
+    if not stub_cpu:
+        torch.cuda.set_device(0)
     return 0, 1, 0, None
 
 
@@ -115,9 +161,10 @@ def dist_setup(n):
 # workloads: each returns dict(step=fn(i), meta=..., payload=for the CPU baseline, [abi_step]).
 # step(i) runs forward+backward of batch i; with fresh targets batch i has targets no earlier step saw.
 # --------------------------------------------------------------------------------------------------
-def make_ctc(args, rank, n_batches):
+def make_ctc(args, rank, n_batches, dist=None):
     from gtn_applications_amd import _native as N
     from gtn_applications_amd import engine as E
+    from gtn_applications_amd import parallel
     from gtn_applications_amd.criterions import ctc
 
     B, T, C, L = args.B or 128, args.T or 1000, args.C or 100, args.L
@@ -127,10 +174,15 @@ def make_ctc(args, rank, n_batches):
     # benchmarks/ctc_benchmark.py:23-24: randint(N - 2, (B, L)) as a list of int lists
     batches = [torch.randint(C - 2, (B, L), generator=g).tolist() for _ in range(n_batches)]
     xr = x.clone().requires_grad_(True)
+    # cfg5 (BASELINE configs[4]): "RCCL all-reduce of transition grads".  Pure CTC has none, so the harness averages the
+    # buffer an ASG criterion of this size would exchange -- [(C+1), C] fp32, 1.05 MB at C = 512 -- once per step
+    exchange = torch.zeros(C + 1, C, device=x.device) if args.config == "cfg5" else None
 
     def step(i):
         xr.grad = None
         ctc.CTCLoss(xr, batches[i % n_batches], blank).backward()
+        if exchange is not None:
+            parallel.all_reduce_mean_([exchange])
 
     # the C-ABI call underneath, targets pre-staged (kernels only)
     dev = x.device
@@ -143,6 +195,8 @@ def make_ctc(args, rank, n_batches):
     if args.ctc_step == "pipelined":
         def abi_step(i):
             last[0] = E.ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=scale, want_loss=True)
+            if exchange is not None:
+                parallel.all_reduce_mean_([exchange])
     else:
         def abi_step(i):
             tok = E._mark("ctc_chains")
@@ -160,6 +214,7 @@ def make_ctc(args, rank, n_batches):
              (150, 28, 8, 44): " (BASELINE configs[0])"}.get((T, C, B, L), "")
     key = {(1000, 100, 128, 44): "cfg2", (2000, 512, 128, 44): "cfg5_shard"}.get((T, C, B, L))
     meta = dict(workload=f"ctc fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L, key=key, repaired=repaired,
+                exchange_bytes=0 if exchange is None else exchange.numel() * 4,
                 metric=f"utterances/sec fwd+bwd (ctc_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="CTCLoss(x, targets, blank).backward()", algorithmic_bytes_per_utt=8 * T * C)
     return dict(step=step, abi_step=abi_step, meta=meta, payload=("ctc", x, batches[0], blank))
@@ -307,17 +362,21 @@ def cpu_torch_ctc(payload):
                 what=f"torch.nn.functional.ctc_loss fwd+bwd on CPU, {reps} x {B} utterances in {el:.1f} s")
 
 
-def pmc_traffic(key, phase):
-    """HBM bytes per launch of the phase's kernels from the committed rocprofv3 PMC passes (FETCH_SIZE and
+def pmc_traffic(key, phases):
+    """HBM bytes per step of the kernels of `phases` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate `--pmc` runs of this same command, corrected with the factors measured by
     scripts/pmc_calib.hip; see profiles/README.md).  Only for the configurations they were measured on."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if key is None or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rec = json.load(f).get("configs", {}).get(key, {}).get("kernels", {})
-    tot = [rec[n]["hbm_bytes"] for n in PHASE_KERNEL_NAMES.get(phase, []) if n in rec]
-    return float(sum(tot)) if tot else None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if key is None or not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rec = json.load(f).get("configs", {}).get(key, {}).get("kernels", {})
+        names = {n for ph in phases for n in PHASE_KERNEL_NAMES.get(ph.split("/")[0], [])}
+        tot = [rec[n]["hbm_bytes"] for n in names if n in rec]
+        if tot:
+            return float(sum(tot))
+    return None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -367,18 +426,60 @@ def timed_loop(step, steps, warmup, fence, collect_events):
     return elapsed, {**warm, **timed}
 
 
+def stub_main(args):
+    """--stub-cpu (tests/test_parallel.py): the rank / barrier / MAX-over-ranks plumbing of main() with gloo ranks
+    and a stub step.  Measures nothing."""
+    rank, world, local, dist = dist_setup(args.gpus, stub_cpu=True)
+    buf = torch.zeros(8)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+
+    def step(i):
+        buf.add_(1.0)
+        if dist is not None:
+            from gtn_applications_amd import parallel
+
+            parallel.all_reduce_mean_([buf])
+        time.sleep(0.001 * (1 + rank))  # ranks differ: the reported time must be the slowest rank's
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = own = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": world * 1 * args.steps / elapsed, "unit": "utt/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+                          "rank0_ms_per_step": own * 1e3 / args.steps, "config": {"workload": "stub (cpu, gloo)"},
+                          "collective_world_size": dist.get_world_size() if dist is not None else 1}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+    if args.stub_cpu:
+        return stub_main(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     rank, world, local, dist = dist_setup(args.gpus)
     extras_steps = max(10, args.steps // 2)
-    if args.mode is None:
-        args.mode = "abi" if args.workload == "ctc" else "api"
     fresh_extra = world == 1 and not args.no_extras and (args.mode == "abi" or args.targets == "same")
     n_batches = (args.steps + args.warmup) if args.targets == "fresh" else 1 + (extras_steps + 3 if fresh_extra else 0)
     if args.workload == "ctc":
-        wl = make_ctc(args, rank, n_batches)
+        wl = make_ctc(args, rank, n_batches, dist)
     elif args.workload == "asg":
         wl = make_asg(args, rank, n_batches, dist)
     else:
@@ -403,8 +504,14 @@ def main():
     ms = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
     repaired = meta["repaired"]() if args.mode == "abi" else None
-    par = (f"dp{world} (utterance shards, no data-path collective)" if args.workload != "asg"
-           else f"dp{world} (utterance shards; all-reduce(mean) of the transition-weight gradient per step)")
+    if meta.get("exchange_bytes"):
+        par = (f"dp{world} (utterance shards; all-reduce(mean) of a [(C+1), C] fp32 buffer per step, {meta['exchange_bytes']} bytes, "
+               f"through parallel.all_reduce_mean_ -- pure CTC has no transition weights: the payload is the one an ASG "
+               f"criterion of this size would exchange, SURVEY.md 8(e))")
+    elif args.workload == "asg":
+        par = f"dp{world} (utterance shards; all-reduce(mean) of the transition-weight gradient per step)"
+    else:
+        par = f"dp{world} (utterance shards, no data-path collective)"
     out = {
         "metric": meta["metric"], "value": value, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -412,7 +519,8 @@ def main():
         "config": {"workload": meta["workload"], "mode": args.mode, "targets": ("pre-staged" if args.mode != "api" else "fresh (new targets every step)" if args.targets == "fresh" else
                                "same list every step (the reference benchmark's protocol: resident on the device after the first call)"),
                    "timed_call": meta["call"] if args.mode == "api" else "wfl_ctc_forward_backward (C ABI, targets pre-staged)",
-                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": par},
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": par,
+                   "collective_world_size": dist.get_world_size() if dist is not None else 1},
     }
     if repaired is not None:
         out["config"]["utterances_repaired_in_log_domain"] = repaired
@@ -420,27 +528,39 @@ def main():
     if phase_ms:
         dom = max(phase_ms, key=phase_ms.get)
         gpu_ms = float(sum(phase_ms.values()))
-        achieved = alg_bytes / (phase_ms[dom] * 1e-3) / 1e9
+        step_achieved = alg_bytes / (gpu_ms * 1e-3) / 1e9
+        dom_achieved = alg_bytes / (phase_ms[dom] * 1e-3) / 1e9
         out["roofline"] = {
-            "bound": "hbm", "kernel": PHASE_KERNELS.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(meta["key"], dom),
+            "bound": "hbm", "kernel": " + ".join(PHASE_KERNELS.get(k, k) for k in sorted(phase_ms, key=lambda k: -phase_ms[k])),
+            "achieved": step_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": step_achieved / HBM_PEAK_GBPS,
+            "traffic": pmc_traffic(meta["key"], list(phase_ms)),
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": {PHASE_KERNELS.get(k, k): v for k, v in sorted(phase_ms.items(), key=lambda kv: -kv[1])},
-            "step_kernels_ms": gpu_ms, "step_frac": alg_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "note": "achieved = algorithmic bytes of the batch (8*T*C per utterance, + 8*(C+1)*C for ASG's W and dW) / "
-                    "average duration of the dominant kernel group, HIP events on the launch stream inside the timed "
-                    "region (the other groups of kernel_ms are bracketed during the last warm-up steps only: an event "
-                    "pair per launch costs the step ~10 us each); step_* divides by the sum over all kernel groups of a "
-                    "step (groups on forked streams overlap)",
+            "step_kernels_ms": gpu_ms,
+            "dominant_kernel": {"kernel": PHASE_KERNELS.get(dom, dom), "ms": phase_ms[dom], "achieved": dom_achieved,
+                                "frac": dom_achieved / HBM_PEAK_GBPS},
+            "note": "STEP level: achieved = algorithmic bytes of the batch (8*T*C per utterance, + 8*(C+1)*C for ASG's W and "
+                    "dW) / the sum of the average durations of ALL kernel groups of a step, HIP events on the launch stream "
+                    "(the dominant group inside the timed region, the others during the last warm-up steps only: an event "
+                    "pair per launch costs the step ~10 us each; groups on forked streams overlap, so the sum is an upper "
+                    "bound of the step's GPU time); dominant_kernel divides the same bytes by that group alone; traffic = "
+                    "HBM bytes of all the step's kernels from the committed PMC passes",
         }
+        if args.workload == "asg":
+            # the dense sweep is 2*B*T*C^2 multiply-adds (alpha and beta) + as many for the gradient
+            fma = 2.0 * B * meta["T"] * meta["C"] ** 2
+            out["roofline"]["valu"] = {"bound": "valu_f32", "achieved": 2 * fma / (gpu_ms * 1e-3) / 1e12, "peak": VALU_F32_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": 2 * fma / (gpu_ms * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS,
+                                       "note": "2*B*T*C^2 fused multiply-adds of the dense forward + backward sweeps (2 flop each) "
+                                               "over the step's kernel time; fp32 vector peak (no MFMA: the recursion is a "
+                                               "dependent chain of small matrix-vector products in a scaled semiring)"}
     single = rank == 0 and world == 1
     if single and not args.no_extras:
         if args.mode == "abi":
             # the drop-in operator on the same workload, the reference benchmark's protocol (same target list every step)
             el, _ = timed_loop(lambda i: wl["step"](0), extras_steps, 3, fence, False)
             out["python_api"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
-                                 "what": meta["call"] + ": autograd operator, eager, host overhead included (host-bound "
-                                         "where the host needs longer than the kernels: 66-95 us per call depending on the box)"}
+                                 "what": meta["call"] + ": autograd operator, eager, host overhead included"}
         if fresh_extra:
             # cold cache: targets never seen before in every step (batches 1.. of the workload; batch 0 was the main run's)
             el, _ = timed_loop(lambda i: wl["step"](1 + i), extras_steps, 3, fence, False)
@@ -459,29 +579,6 @@ def main():
             out["abi_kernels_only"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
                                        "kernel_ms": ph, "utterances_repaired_in_log_domain": meta["repaired"](),
                                        "what": "wfl_ctc_forward_backward through the C ABI, targets pre-staged: kernels only"}
-        if args.workload == "ctc":
-            try:  # the ABI step captured once in a hipGraph and replayed (no host launch gaps)
-                abi = wl["abi_step"]
-                graph = torch.cuda.CUDAGraph()
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    abi(0)
-                torch.cuda.current_stream().wait_stream(side)
-                with torch.cuda.graph(graph):
-                    abi(0)
-                for _ in range(3):
-                    graph.replay()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(extras_steps):
-                    graph.replay()
-                torch.cuda.synchronize()
-                el = time.perf_counter() - t0
-                out["hip_graph"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
-                                    "what": "the ABI step's kernels captured in one hipGraph and replayed"}
-            except Exception as exc:  # capture is an extra, never fail the bench on it
-                out["hip_graph"] = {"error": str(exc)[:200]}
     if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl["payload"], args.cpu_sample_utts)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -91,6 +91,7 @@ class ASGLossFunction(torch.autograd.Function):
         return g
 
     @staticmethod
+    @E.on_input_device
     def forward(ctx, inputs, transitions, targets, reduction="none"):
         B, T, C = inputs.shape
         if reduction not in ("none", "mean"):  # asg.py:120-121
@@ -136,6 +137,7 @@ class ASGLossFunction(torch.autograd.Function):
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
+    @E.on_input_device
     def backward(ctx, grad_output):
         x, W, fcc, cpos, dx_num, dw_num, fork = ctx.aux
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
@@ -173,6 +175,7 @@ class ASG(torch.nn.Module):
                 f"{limit} (DESIGN.md section 3.3).  Use the Transducer criterion with ngram=1/2 transitions for larger token sets.")
         self.transitions = torch.nn.Parameter(torch.zeros(self.N + 1, self.N))
 
+    @E.on_input_device
     def forward(self, inputs, targets):
         targets = [pack_replabels(t.tolist(), self.num_replabels) for t in targets]
         if self.garbage_idx is not None:  # a garbage token between (and around) the labels: asg.py:203-208

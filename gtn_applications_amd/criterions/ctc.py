@@ -31,6 +31,7 @@ class CTCLossFunction(torch.autograd.Function):
         return g
 
     @staticmethod
+    @E.on_input_device
     def forward(ctx, log_probs, targets, blank_idx=0, reduction="none"):
         B, T, C = log_probs.shape
         if T == 0:
@@ -76,6 +77,7 @@ class CTCLossFunction(torch.autograd.Function):
         return loss if log_probs.is_cuda else loss.cpu()
 
     @staticmethod
+    @E.on_input_device
     def backward(ctx, grad_output):
         kind, x = ctx.aux[0], ctx.aux[1]
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
@@ -112,6 +114,7 @@ class _FusedLogSoftmaxCTCLoss(CTCLossFunction):
     requires grad) -- the module falls back to torch's log_softmax otherwise."""
 
     @staticmethod
+    @E.on_input_device
     def forward(ctx, inputs, targets, blank_idx=0, reduction="none"):
         ctx.fused_log_softmax = True
         return CTCLossFunction.forward(ctx, inputs, targets, blank_idx, reduction)
@@ -131,6 +134,7 @@ def _native_node():
 _NODE = False
 
 
+@E.on_input_device
 def _ctc_loss(log_probs, targets, blank_idx, reduction, fused_log_softmax):
     """CTCLossFunction.apply, with the hot case -- float32 device emissions that require grad, targets the fast
     kernels take -- routed through the C++ autograd node: same checks, same staging, same launch, but neither the
@@ -139,8 +143,7 @@ def _ctc_loss(log_probs, targets, blank_idx, reduction, fused_log_softmax):
     node = _native_node()
     if (node is not None and type(log_probs) is torch.Tensor and log_probs.is_cuda and log_probs.requires_grad
             and log_probs.dtype == torch.float32 and log_probs.dim() == 3 and log_probs.is_contiguous()
-            and torch.is_grad_enabled() and log_probs.shape[1] > 0 and reduction in ("none", "mean")
-            and log_probs.device.index == torch.cuda.current_device()):
+            and torch.is_grad_enabled() and log_probs.shape[1] > 0 and reduction in ("none", "mean")):
         B, T, C = log_probs.shape
         dev = log_probs.device
         if type(targets) in (list, tuple):
@@ -151,7 +154,7 @@ def _ctc_loss(log_probs, targets, blank_idx, reduction, fused_log_softmax):
             if tok is None:
                 loss = node.ctc_loss_lists(log_probs, targets, *lim)
             else:  # (profiling: the event pair brackets the launch, not the staging)
-                E._EVENT_POOL.append(tok[1])  # (recorded too early: take the start event again after the staging)
+                E._event_pool().append(tok[1])  # (recorded too early: take the start event again after the staging)
                 st = node.stage_lists(targets, log_probs)
                 tok = (tok[0], E._event())
                 loss = node.ctc_loss_staged(log_probs, st, *lim)
@@ -188,6 +191,7 @@ class CTC(torch.nn.Module):
         self.blank = blank  # index of blank label
         self.use_pt = use_pt  # use torch.nn.functional.ctc_loss instead of the WFST engine
 
+    @E.on_input_device
     def forward(self, inputs, targets):
         if not self.use_pt and inputs.requires_grad and inputs.dtype == torch.float32 and \
                 E.ctc_fast_path_ok(max((t.numel() for t in targets), default=0), inputs.shape[2]):

@@ -48,6 +48,7 @@ class STCLossFunction(torch.autograd.Function):
         return g
 
     @staticmethod
+    @E.on_input_device
     def forward(ctx, inputs, targets, prob, reduction="none"):
         B, T, Cstar = inputs.shape
         if reduction not in ("none", "mean"):  # stc.py:92-93
@@ -72,6 +73,7 @@ class STCLossFunction(torch.autograd.Function):
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
+    @E.on_input_device
     def backward(ctx, grad_output):
         x, st, cneg = ctx.aux
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
@@ -107,6 +109,7 @@ class STC(torch.nn.Module):
             a = a.tile((1, 1, b.shape[2]))
             return a + torch.log1p(1e-7 - torch.exp(b - a))
 
+    @E.on_input_device
     def forward(self, inputs, targets):
         """inputs: (T, B, C) log-probabilities; targets: list of B label lists."""
         if self.training:

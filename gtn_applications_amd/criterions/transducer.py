@@ -190,6 +190,7 @@ class Transducer(torch.nn.Module):
             self.transition_params = None
         self.reduction = reduction
 
+    @E.on_input_device
     def forward(self, inputs, targets):
         self.tokens.arc_sort(True)
         if self.transitions is None:
@@ -242,6 +243,7 @@ def _transitions_pack(transitions, B, C, device):
 
 class TransducerLossFunction(torch.autograd.Function):
     @staticmethod
+    @E.on_input_device
     def forward(ctx, inputs, targets, tokens, lexicon, transition_params=None, transitions=None,
                 reduction="none"):
         return TransducerLossFunction._forward(ctx, False, inputs, targets, tokens, lexicon, transition_params,
@@ -295,6 +297,7 @@ class TransducerLossFunction(torch.autograd.Function):
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
+    @E.on_input_device
     def backward(ctx, grad_output):
         x, params, num, den, cpos, cneg = ctx.aux
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
@@ -316,6 +319,7 @@ class _FusedLogSoftmaxTransducerLoss(TransducerLossFunction):
     subtracts the rows' log-sum-exp, the gradient kernel differentiates through it."""
 
     @staticmethod
+    @E.on_input_device
     def forward(ctx, inputs, targets, tokens, lexicon, transition_params=None, transitions=None,
                 reduction="none"):
         return TransducerLossFunction._forward(ctx, True, inputs, targets, tokens, lexicon, transition_params,
@@ -369,6 +373,7 @@ class ConvTransduce1DFunction(torch.autograd.Function):
     there is no process-global CTX_GRAPHS: everything backward needs lives on `ctx` (re-entrant)."""
 
     @staticmethod
+    @E.on_input_device
     def forward(ctx, inputs, kernels, kernel_size, stride, kernel_params=None, viterbi=False):
         B, T, C = inputs.shape
         if T < kernel_size:  # padding should be done outside of this function (transducer.py:468-470)
@@ -393,6 +398,7 @@ class ConvTransduce1DFunction(torch.autograd.Function):
         return out if inputs.is_cuda else out.to(inputs.device)
 
     @staticmethod
+    @E.on_input_device
     def backward(ctx, grad_output):
         x, params, tab, kernels, kernel_size, stride, sr = ctx.aux
         B, T, C = x.shape
@@ -444,6 +450,7 @@ class ConvTransduce1D(torch.nn.Module):
         if learn_params:
             self.kernel_params = torch.nn.Parameter(torch.zeros(self.kernels.num_arcs))
 
+    @E.on_input_device
     def forward(self, inputs):
         # inputs are of shape [B, T, C]
         pad = self.kernel_size // 2

@@ -76,19 +76,47 @@ PHASE_STRIDE = 1   # record every PHASE_STRIDE-th launch of a phase (an event pa
 _PHASE_COUNT = {}
 
 
-_EVENT_POOL = []
+_EVENT_POOLS = {}  # device index -> timing events free for reuse (an event belongs to the device it was first recorded on)
+
+
+def _event_pool():
+    idx = torch.cuda.current_device()
+    pool = _EVENT_POOLS.get(idx)
+    if pool is None:
+        pool = _EVENT_POOLS[idx] = []
+    return pool
 
 
 def prealloc_events(n):
     """bench.py: create the timing events of a timed region up front (hipEventCreate costs more than the record)"""
-    while len(_EVENT_POOL) < n:
-        _EVENT_POOL.append(torch.cuda.Event(enable_timing=True))
+    pool = _event_pool()
+    while len(pool) < n:
+        pool.append(torch.cuda.Event(enable_timing=True))
 
 
 def _event():
-    ev = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+    pool = _event_pool()
+    ev = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
     ev.record()
     return ev
+
+
+def on_input_device(fn):
+    """Run a criterion entry point with the device of its first CUDA tensor argument current (the reference's
+    criteria return results on the inputs' device whatever the current device is: ctc.py:69, asg.py:139).  Every
+    per-device resource of the engine -- staging rings, workspaces, streams, timing events -- is looked up through
+    the current device, so the switch is all it takes; nothing is done when it already is the current one."""
+    def wrapped(*args, **kwargs):
+        for a in args:
+            if type(a) is torch.Tensor or isinstance(a, torch.Tensor):
+                if a.is_cuda and a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+
+    wrapped.__name__, wrapped.__doc__ = getattr(fn, "__name__", "wrapped"), fn.__doc__
+    return wrapped
 
 
 def _mark(name):

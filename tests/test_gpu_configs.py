@@ -282,3 +282,38 @@ def test_cfg5_ctc_shard_every_utterance():
         losses.append(want_loss)
         check("cfg5_ctc_shard_dx", dx[lo:lo + 32], want_dx, 1.0 / B)
     assert loss.item() == pytest.approx(float(np.concatenate(losses).mean()), rel=RTOL)
+
+
+def test_criteria_run_on_a_device_that_is_not_the_current_one():
+    """Inputs on cuda:k, k != torch.cuda.current_device() (what rank k of a multi-GPU job would see if it did not call
+    set_device): the per-device staging rings, workspaces and timing events of the engine must be looked up for the
+    inputs' device, results land there, and the values equal the ones cuda:0 gives.  Needs two visible devices."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one device visible")
+    from gtn_applications_amd import engine as E
+    from gtn_applications_amd.criterions import asg, ctc
+
+    B, T, C, L = 16, 200, 40, 12
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, C, generator=g)
+    W = torch.randn(C + 1, C, generator=g)
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    res = {}
+    assert torch.cuda.current_device() == 0
+    for k in (0, 1):
+        dev = torch.device("cuda", k)
+        xg = x.to(dev).requires_grad_(True)
+        E.PHASE_EVENTS = []  # timing events are per device too
+        try:
+            loss = ctc.CTCLoss(xg, targets, C - 1)
+            loss.backward()
+        finally:
+            E.PHASE_EVENTS = None
+        xa, Wa = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+        la = asg.ASGLoss(xa, Wa, targets)
+        la.backward()
+        assert loss.device == dev and xg.grad.device == dev and Wa.grad.device == dev
+        res[k] = [t.cpu() for t in (loss.detach(), xg.grad, la.detach(), xa.grad, Wa.grad)]
+    assert torch.cuda.current_device() == 0
+    for a, b in zip(res[0], res[1]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)

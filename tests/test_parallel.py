@@ -83,3 +83,27 @@ def test_single_process_helpers_are_noops():
     t = torch.ones(3)
     assert P.all_reduce_mean_([t])[0] is t and torch.equal(t, torch.ones(3))
     assert float(P.global_mean_loss(torch.tensor(2.5), 4)) == 2.5
+
+
+def test_bench_starts_its_own_ranks_and_reports_the_slowest():
+    """`python bench.py --gpus 2` with no launcher (train.py:344-347 spawns its own ranks too): two gloo ranks on the
+    CPU with a stub step (--stub-cpu) -- the JSON line says n_gpus == 2, the collective saw two ranks, and the
+    reported time is the MAX over ranks (rank 1's stub step is slower than rank 0's)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-cpu", "--steps", "5",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["collective_world_size"] == 2 and rec["steps"] == 5
+    assert rec["ms_per_step"] >= rec["rank0_ms_per_step"] and rec["ms_per_step"] >= 2.0  # rank 1 sleeps 2 ms per step
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silent 1-rank run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--stub-cpu"],
+                         env=dict(env, RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
