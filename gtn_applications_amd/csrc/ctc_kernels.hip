@@ -489,37 +489,86 @@ __device__ __forceinline__ void fmac2_shr1(float& acc0, float& acc1, float src, 
 
 // Reduce 16 per-lane values over the 64 lanes at once: instead of 16 wave reductions (16 x 18 instructions)
 // the lanes fold the 16 values pairwise -- after the exchange with lane^1 a lane only keeps the 8
-// values whose index has its bit 0, after lane^2 four, ... -- so that lane l (l < 16, every row)
-// ends up with the 64-lane total (MAX: maximum) of value l.  ~55 instructions.
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {  // quad_perm / row_ror moves, all lanes valid
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
+// values whose index has its bit 0, after lane^2 four, ... -- so that lane l (EVERY lane: l % 16)
+// ends up with the 64-lane total (MAX: maximum) of value l % 16.  ~50 instructions:
+//   levels 1, 2 (partner lane^1, lane^2: quad_perm): two selects (what to keep, what to send) and one DPP
+//     operation per pair, the selects of the next pair issued in front of the operation (VALU write -> DPP read
+//     of the same register needs two wait states);
+//   levels 3, 4 (within the row of 16): a lane receives from lane+4 / lane+8 (row_ror:12 / row_ror:8) instead of
+//     lane^4 / lane^8 -- just as good: the sender has the opposite bit, so what it does not keep is what the
+//     receiver keeps, and the four lanes i, i+4, i+8, i+12 cover the row's four quads -- and which value a lane
+//     keeps is decided by the DPP bank mask (a bank is a quad of lanes: bits 2, 3 of the lane), two masked
+//     operations per pair and no select;
+//   rows: v_permlane16_swap / v_permlane32_swap (one VALU instruction each where __shfl_xor is a ds_bpermute
+//     round trip).
+// The leading s_nop covers inputs written by the instruction in front of the block.
+#define WFL_FOLD16_BODY(OP)  \
+  "s_nop 1\n\t"  \
+  "v_cndmask_b32_e64 %[t0], %[v1], %[v0], %[m0]\n\t"  \
+  "v_cndmask_b32_e64 %[t1], %[v0], %[v1], %[m0]\n\t"  \
+  "v_cndmask_b32_e64 %[t2], %[v3], %[v2], %[m0]\n\t"  \
+  "v_cndmask_b32_e64 %[t3], %[v2], %[v3], %[m0]\n\t"  \
+  OP " %[a0], %[t0], %[t1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_cndmask_b32_e64 %[t0], %[v5], %[v4], %[m0]\n\t"  \
+  "v_cndmask_b32_e64 %[t1], %[v4], %[v5], %[m0]\n\t"  \
+  OP " %[a1], %[t2], %[t3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_cndmask_b32_e64 %[t2], %[v7], %[v6], %[m0]\n\t"  \
+  "v_cndmask_b32_e64 %[t3], %[v6], %[v7], %[m0]\n\t"  \
+  OP " %[a2], %[t0], %[t1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_cndmask_b32_e64 %[t0], %[v9], %[v8], %[m0]\n\t"  \
+  "v_cndmask_b32_e64 %[t1], %[v8], %[v9], %[m0]\n\t"  \
+  OP " %[a3], %[t2], %[t3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_cndmask_b32_e64 %[t2], %[v11], %[v10], %[m0]\n\t"  \
+  "v_cndmask_b32_e64 %[t3], %[v10], %[v11], %[m0]\n\t"  \
+  OP " %[a4], %[t0], %[t1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_cndmask_b32_e64 %[t0], %[v13], %[v12], %[m0]\n\t"  \
+  "v_cndmask_b32_e64 %[t1], %[v12], %[v13], %[m0]\n\t"  \
+  OP " %[a5], %[t2], %[t3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_cndmask_b32_e64 %[t2], %[v15], %[v14], %[m0]\n\t"  \
+  "v_cndmask_b32_e64 %[t3], %[v14], %[v15], %[m0]\n\t"  \
+  OP " %[a6], %[t0], %[t1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+  "s_nop 0\n\t"  \
+  OP " %[a7], %[t2], %[t3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_cndmask_b32_e64 %[t0], %[a1], %[a0], %[m1]\n\t"  \
+  "v_cndmask_b32_e64 %[t1], %[a0], %[a1], %[m1]\n\t"  \
+  "v_cndmask_b32_e64 %[t2], %[a3], %[a2], %[m1]\n\t"  \
+  "v_cndmask_b32_e64 %[t3], %[a2], %[a3], %[m1]\n\t"  \
+  OP " %[a0], %[t0], %[t1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_cndmask_b32_e64 %[t0], %[a5], %[a4], %[m1]\n\t"  \
+  "v_cndmask_b32_e64 %[t1], %[a4], %[a5], %[m1]\n\t"  \
+  OP " %[a2], %[t2], %[t3] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"  \
+  "v_cndmask_b32_e64 %[t2], %[a7], %[a6], %[m1]\n\t"  \
+  "v_cndmask_b32_e64 %[t3], %[a6], %[a7], %[m1]\n\t"  \
+  OP " %[a4], %[t0], %[t1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"  \
+  "s_nop 0\n\t"  \
+  OP " %[a6], %[t2], %[t3] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"  \
+  OP " %[a1], %[a0], %[a0] row_ror:12 row_mask:0xf bank_mask:0x5\n\t"  \
+  OP " %[a1], %[a2], %[a2] row_ror:12 row_mask:0xf bank_mask:0xa\n\t"  \
+  OP " %[a3], %[a4], %[a4] row_ror:12 row_mask:0xf bank_mask:0x5\n\t"  \
+  OP " %[a3], %[a6], %[a6] row_ror:12 row_mask:0xf bank_mask:0xa\n\t"  \
+  "s_nop 1\n\t"  \
+  OP " %[a0], %[a1], %[a1] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"  \
+  OP " %[a0], %[a3], %[a3] row_ror:8 row_mask:0xf bank_mask:0xc"
 template <bool MAX>
 __device__ __forceinline__ float fold16(const float (&v)[16], int lane) {
-  auto op = [](float x, float y) { return MAX ? vmax(x, y) : x + y; };
-  float a[8], b[4], c[2];
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {  // partner lane^1: quad_perm [1,0,3,2]
-    const float keep = b0 ? v[2 * m + 1] : v[2 * m], send = b0 ? v[2 * m] : v[2 * m + 1];
-    a[m] = op(keep, dpp_quad<0xb1>(send));
-  }
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {  // partner lane^2: quad_perm [2,3,0,1]
-    const float keep = b1 ? a[2 * m + 1] : a[2 * m], send = b1 ? a[2 * m] : a[2 * m + 1];
-    b[m] = op(keep, dpp_quad<0x4e>(send));
-  }
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {  // partner lane^4 inside the row of 16: rotate by 4 or by 12
-    const float keep = b2 ? b[2 * m + 1] : b[2 * m], send = b2 ? b[2 * m] : b[2 * m + 1];
-    const float up = dpp_quad<0x124>(send), down = dpp_quad<0x12c>(send);  // row_ror:4 (from lane+12 = lane-4), row_ror:12 (from lane+4)
-    c[m] = op(keep, b2 ? up : down);
-  }
-  const float keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
-  float t = op(keep, dpp_quad<0x128>(send));  // partner lane^8: row_ror:8
-  t = op(t, __shfl_xor(t, 16, 64));
-  t = op(t, __shfl_xor(t, 32, 64));
+  float a0, a1, a2, a3, a4, a5, a6, a7, t0, t1, t2, t3;
+  const unsigned long long m0 = 0xaaaaaaaaaaaaaaaaull, m1 = 0xccccccccccccccccull;  // lanes with bit 0 / bit 1 set
+#define WFL_FOLD16_OPERANDS                                                                                             \
+  : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5), [a6] "=&v"(a6),    \
+    [a7] "=&v"(a7), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)                                      \
+  : [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]),    \
+    [v7] "v"(v[7]), [v8] "v"(v[8]), [v9] "v"(v[9]), [v10] "v"(v[10]), [v11] "v"(v[11]), [v12] "v"(v[12]),              \
+    [v13] "v"(v[13]), [v14] "v"(v[14]), [v15] "v"(v[15]), [m0] "s"(m0), [m1] "s"(m1)
+  if (MAX)
+    asm(WFL_FOLD16_BODY("v_max_f32_dpp") WFL_FOLD16_OPERANDS);
+  else
+    asm(WFL_FOLD16_BODY("v_add_f32_dpp") WFL_FOLD16_OPERANDS);
+#undef WFL_FOLD16_OPERANDS
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  v2u sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a0), __float_as_uint(a0), false, false);
+  float t = MAX ? vmax(__uint_as_float(sw.x), __uint_as_float(sw.y)) : __uint_as_float(sw.x) + __uint_as_float(sw.y);
+  sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  t = MAX ? vmax(__uint_as_float(sw.x), __uint_as_float(sw.y)) : __uint_as_float(sw.x) + __uint_as_float(sw.y);
   return t;
 }
 __device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) { return fold16<false>(v, lane); }

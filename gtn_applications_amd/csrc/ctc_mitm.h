@@ -39,6 +39,9 @@
 #ifndef WFL_MITM_ABL
 #define WFL_MITM_ABL 0  // scratch: switch off parts of the chain wave's steady block (1 renorm, 2 ring reads, 4 checkpoint, 8 frames)
 #endif
+#ifndef WFL_MITM_STORE
+#define WFL_MITM_STORE 2  // gradient row stores: 0 plain, 1 non-temporal, 2 sc0 sc1, 3 sc1, 4 sc0 sc1 nt (scratch A/B)
+#endif
 #ifndef WFL_MITM_STATS
 #define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
 #endif
@@ -129,7 +132,10 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
                                                     MitmLds& S, bool first,
                                                     int cnt, float cf, float g, float gs, bool skipn, bool owner, bool adder,
                                                     int lane, float* rows, int ycol, int blank, int C, long long* zmm,
-                                                    float* __restrict__ dst) {
+                                                    float* __restrict__ dst, long long* st_part) {
+#if WFL_MITM_STATS
+  const long long st_e0 = clock64();
+#endif
   const int eb = __float_as_int(pk.z);
   // ---- own sweep forward through the block, kept in registers
   mv2f pa[kBlk];
@@ -146,6 +152,13 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     }
     pa[j] = sa;
   }
+#if WFL_MITM_STATS
+  {
+    // (the clock is read after the forward recursion has produced its last value)
+    const long long now = __builtin_amdgcn_readfirstlane(__float_as_int(sa.x)) * 0 + clock64();
+    st_part[0] += now - st_e0;
+  }
+#endif
   // ---- K(s) = cf 2^(ea + eb) / Z in the block's units.  The emitter's FIRST block reproduces Z itself -- sum_s own(s)
   // [A partner](s) at its last frame, the certificate's identity -- and folds its log2 Z into the utterance's min / max
   // for the comparison with the chain's; its later blocks reuse that log2 Z (Z is one number; the blocks only differ in
@@ -195,6 +208,9 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
       K = cf * frac * ldexpf(1.f, min(max(sx + (int)Di, -200), 100));
     }
   }
+#if WFL_MITM_STATS
+  st_part[2] += __builtin_amdgcn_readfirstlane(__float_as_int(K)) * 0 + clock64() - st_e0;
+#endif
   // ---- partner sweep backwards through the block (scaled by K), posteriors
   bb *= K, bl *= K;
   const int ea_next = __builtin_amdgcn_update_dpp(ea, ea, 0x130, 0xf, 0xf, false);
@@ -220,6 +236,9 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
       bb = nb.x, bl = nb.y;
     }
   }
+#if WFL_MITM_STATS
+  st_part[3] += __builtin_amdgcn_readfirstlane(__float_as_int(bb + wsum.x)) * 0 + clock64() - st_e0;
+#endif
   // ---- gradient rows
   constexpr int R0 = DIR == 0 ? 0 : kBlk - 1, RS = DIR == 0 ? 1 : -1;  // tile row of frame j: R0 + RS * j
   const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
@@ -235,6 +254,9 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     for (int j = 0; j < kBlk; ++j)
       if (FULL || j < cnt) atomicAdd(&cell[(R0 + RS * j) * kMTile], glv[j]);
   }
+#if WFL_MITM_STATS
+  st_part[4] += __builtin_amdgcn_readfirstlane(__float_as_int(gtot)) * 0 + clock64() - st_e0;
+#endif
   {
     // certificate (see ctc_fast_grad_body): the posterior mass of every frame
     const float stot = wave_all_sum(wsum.x + wsum.y);
@@ -244,7 +266,17 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     if (bad_block && lane == 0) __hip_atomic_fetch_min(zmm, kZDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
+#if WFL_MITM_STATS
+  const long long st_e1 = clock64();
+  st_part[5] += st_e1 - st_e0;
+  struct StAcc {
+    long long* p;
+    long long t;
+    __device__ ~StAcc() { p[1] += clock64() - t; }
+  } st_acc{st_part, st_e1};
+#endif
   const int nrows = FULL ? kBlk : cnt;
+  if (WFL_MITM_ABL & 64) return;  // (scratch: a launch that computes the rows and does not store them)
   if ((C & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
     // two rows per instruction: lanes 0..31 one row, lanes 32..63 the next (C / 4 <= 32 float4 per row)
     const int half = lane >> 5, c4 = lane & 31;
@@ -254,12 +286,30 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
 #pragma unroll
     for (int r = 0; r < kBlk; r += 2) {
       if (FULL || r < nrows) {
-        if (act && (FULL || r + half < nrows)) out[(r >> 1) * (C >> 1)] = src[(r >> 1) * (kMTile / 2)];
+        if (act && (FULL || r + half < nrows)) {
+          typedef float nf4 __attribute__((ext_vector_type(4)));
+#if WFL_MITM_STORE == 1
+          __builtin_nontemporal_store(*(const nf4*)&src[(r >> 1) * (kMTile / 2)], (nf4*)&out[(r >> 1) * (C >> 1)]);
+#elif WFL_MITM_STORE == 2
+          const nf4 v = *(const nf4*)&src[(r >> 1) * (kMTile / 2)];
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(&out[(r >> 1) * (C >> 1)]), "v"(v) : "memory");
+#elif WFL_MITM_STORE == 3
+          const nf4 v = *(const nf4*)&src[(r >> 1) * (kMTile / 2)];
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&out[(r >> 1) * (C >> 1)]), "v"(v) : "memory");
+#elif WFL_MITM_STORE == 4
+          const nf4 v = *(const nf4*)&src[(r >> 1) * (kMTile / 2)];
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(&out[(r >> 1) * (C >> 1)]), "v"(v) : "memory");
+#else
+          out[(r >> 1) * (C >> 1)] = src[(r >> 1) * (kMTile / 2)];
+#endif
+        }
       }
     }
   } else {
+#ifndef WFL_MITM_NO_UNALIGNED  // (scratch: instruction counts of the aligned path alone)
     for (int r = 0; r < nrows; ++r)
       for (int c = lane; c < C; c += 64) dst[r * C + c] = rows[r * kMTile + c];
+#endif
   }
 }
 
@@ -286,7 +336,10 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
   long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
 #if WFL_MITM_STATS
   long long st_wait0 = 0, st_wait1 = 0, st_wait2 = 0;
+  long long st_part[6] = {0, 0, 0, 0, 0, 0};
   const long long st_begin = clock64();
+#else
+  long long* st_part = nullptr;
 #endif
   auto give_up = [&]() {
     if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
@@ -339,13 +392,17 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
     const int ea_prev = wave_shr1_i(ea, ea);
     const float g = lane == 0 ? 0.f : ldexpf(1.f, max(ea_prev - ea, -200));
     const float gs = skip ? g : 0.f;
-    float* dst = dx + ((int64_t)b * T + t0) * C;
+    float* dst = dx + ((int64_t)b * T + ((WFL_MITM_ABL & 256) ? (t0 & 63) : t0)) * C;  // (256, scratch: the same stores, no HBM traffic)
+    if (WFL_MITM_ABL & 128) {  // (scratch: the hand-offs without the block's arithmetic and stores)
+      if (n == H0) lds_post(&S.zready, 1);
+      continue;
+    }
     if (cnt == kBlk)
       ctc_mitm_emit_block<DIR, true>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                     ycol, a.blank, C, zmm, dst);
+                                     ycol, a.blank, C, zmm, dst, st_part);
     else if (DIR == 0)
       ctc_mitm_emit_block<0, false>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                    ycol, a.blank, C, zmm, dst);
+                                    ycol, a.blank, C, zmm, dst, st_part);
     MITM_ACC(st_wait2);
   }
 #if WFL_MITM_STATS
@@ -354,8 +411,10 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
     long long* d = (long long*)(a.ws + w.dbg) + ((int64_t)(b * 2 + DIR) * kMWaves + wave) * 8;
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    d[0] = clock64() - st_begin, d[1] = st_wait0, d[2] = st_wait1, d[3] = st_wait2, d[4] = 0, d[5] = hw;
-    d[6] = wall_clock64();
+    d[0] = clock64() - st_begin, d[1] = st_wait0, d[2] = st_wait1, d[3] = st_wait2, d[4] = st_part[0], d[5] = hw;
+    d[6] = wall_clock64(), d[7] = st_part[1];
+    long long* x = (long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B + (int64_t)(b * 2 + DIR) * 256 + 128 + em * 8;
+    for (int q = 0; q < 6; ++q) x[q] = st_part[q];
   }
 #endif
 }
@@ -454,19 +513,21 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         if (lane < kBlk) S.fref[slot][lane] = 0.f;
         return;
       }
-      float xs[kBlk];
+      // The frame's reference r_t = rint(log2(e) * its largest target-label score): the maximum is taken over the RAW
+      // scores (scaling by a positive constant commutes with it; v_max ignores a NaN operand -- the NaN policy's
+      // "impossible" -- and an all-NaN / all -inf frame gets the reference 0), the factor is one fused multiply-add, a
+      // NaN filter and the exp2:  f = 2^(max(x log2 e - r, -inf))  (max(NaN, -inf) = -inf).  Seven instructions per
+      // frame and lane with the two broadcasts (the reference from lane j, the blank's factor from lane L).
+      float xr[kBlk];
 #pragma unroll
-      for (int j = 0; j < kBlk; ++j) {
-        const float v = (LSM ? raw[j] - readlane_f(lse_blk, j) : raw[j]) * kLog2e;
-        xs[j] = (v == v) ? v : WFL_NEG_INF;  // NaN policy: impossible
-      }
-      const float m = fold16<true>(xs, lane);  // lane j < 16 (every row): the largest target-label score of frame j
+      for (int j = 0; j < kBlk; ++j) xr[j] = LSM ? raw[j] - readlane_f(lse_blk, j) : raw[j];
+      const float m = fold16<true>(xr, lane) * kLog2e;  // every lane: the largest target-label score of frame lane % 16
       const float rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
+      const float hb = has_blank ? 1.f : 0.f;
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) {
-        const float f = __builtin_amdgcn_exp2f(xs[j] - readlane_f(rr, j));
-        const float fb = readlane_f(f, L);
-        S.ring[slot][j][lane] = make_float2(has_blank ? fb : 0.f, has_label ? f : 0.f);
+        const float f = __builtin_amdgcn_exp2f(vmax(fmaf(xr[j], kLog2e, -readlane_f(rr, j)), WFL_NEG_INF));
+        S.ring[slot][j][lane] = make_float2(readlane_f(f, L) * hb, has_label ? f : 0.f);
       }
       if (lane < kBlk) S.fref[slot][lane] = lane < cnt ? rr : 0.f;
     };
@@ -804,14 +865,14 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       }
       stats_out();
 #if WFL_MITM_STATS
-      for (int q = lane; q < min(NB, 256); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
+      for (int q = lane; q < min(NB, 128); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
 #endif
       if (a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
       return;
     }
     stats_out();
 #if WFL_MITM_STATS
-    for (int q = lane; q < min(NB, 256); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
+    for (int q = lane; q < min(NB, 128); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
 #endif
     return;
   }

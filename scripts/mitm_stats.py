@@ -34,7 +34,13 @@ for dirn in (0, 1):
         simd = int(np.median((r[:, 5].astype(np.int64) >> 4) & 3))
         print("  %-8s simd %d total %6.1f | %s %6.1f | %s %6.1f | %s %6.1f | polls %7.0f" % (
             nm, simd, np.median(r[:, 0]) * cyc, what[k][0], np.median(r[:, 1]) * cyc, what[k][1], np.median(r[:, 2]) * cyc,
-            what[k][2], np.median(r[:, 3]) * cyc, np.median(r[:, 4])))
+            what[k][2], np.median(r[:, 3]) * cyc, np.median(r[:, 4])) + (
+            " | of compute+store: forward %5.1f, rows->HBM %5.1f" % (np.median(r[:, 4]) * cyc, np.median(r[:, 7]) * cyc) if k == "emit" else ""))
+ex = blkraw[:, :, 128:128 + 56].reshape(B, 2, 7, 8).astype(np.float64)
+nblk = (NB_ := (T + 15) // 16) / 2 / 7.0
+print("emitters, cumulative cycles from block entry (median over utterances and emitters, per block = total / %.2f blocks):" % nblk)
+for i, nm in ((0, "forward done"), (2, "K done"), (3, "backward done"), (4, "fold + tile writes done"), (5, "certificate done"), (1, "(rows -> HBM part)")):
+    print("   %-26s %7.0f cycles/block" % (nm, np.median(ex[:, :, :, i]) / nblk))
 ends = d[:, :, :, 6]
 starts = d[:, :, 0, 7]  # chain wave's entry clock per workgroup
 t0 = starts.min()
