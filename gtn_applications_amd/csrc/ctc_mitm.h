@@ -21,8 +21,8 @@
 //
 // Waves of a workgroup (roles are fixed per wave index so that the chain wave's SIMD carries only light waves --
 // waves are placed round-robin on the four SIMDs):
-//     0 chain (4, 8, 12 leave at once: the chain wave has its SIMD to itself) | 1,2,3,5 stagers | 6 flusher |
-//     7 fetcher | 9,10,11,13,14,15 emitters
+//     0 chain | 4 flusher | 8 fetcher | 1,2,3,5 stagers | 6,7,9,10,11,13,14,15,12 emitters  (SIMD of wave w: w % 4 --
+//     the chain wave shares its SIMD with the two light waves and one emitter)
 //   chain    the dependent recursion and nothing else; factors travel ring -> registers a whole block ahead
 //   stagers  gather x (two blocks in flight each), references, exp2 -> LDS ring (as ctc_fast_chain_body's helpers)
 //   flusher  sums the references (double offsets) and, in the first half, publishes the raw checkpoints
@@ -46,10 +46,23 @@
 #define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
 #endif
 
+#ifndef WFL_MITM_CFG
+#define WFL_MITM_CFG 1  // wave roles: 1 = 4 stagers + 9 emitters (default), 0 = 6 stagers + 7 emitters.  An emitter is
+                        // latency-bound (one block is ~7000 cycles of dependent DPP / LDS work on a shared SIMD), so the
+                        // second half goes at the pace of emitters x blocks per emitter: cfg2 42.0 -> 40.1 us; 3 + 10 with
+                        // an 8-slot ring: 41.4 us (the stagers no longer cover the HBM latency)
+#endif
+#if WFL_MITM_CFG == 1
+constexpr int kMSlots = 9;
+constexpr int kMPSlots = 6;
+constexpr int kMStagers = 4;
+constexpr int kMEmitters = 9;
+#else
 constexpr int kMSlots = 10;    // LDS ring depth in blocks: factors, references, own checkpoints
 constexpr int kMPSlots = 8;    // partner checkpoints handed from the fetcher to the emitters
 constexpr int kMStagers = 6;
 constexpr int kMEmitters = 7;
+#endif
 constexpr int kMWaves = 16;
 constexpr int kMSpin = 1 << 24;
 constexpr int kMTile = 128;   // floats per row of an emitter's gradient tile (a compile-time stride: the 16 rows of a label's
@@ -58,6 +71,27 @@ constexpr int kMTile = 128;   // floats per row of an emitter's gradient tile (a
 // role of a wave: 0 chain, 1 stager, 2 flusher, 3 fetcher, 4 emitter; index within the role
 __device__ __forceinline__ void mitm_role(int wave, int& role, int& idx) {
   // (a switch on a scalar: compiled to scalar compares)
+#if WFL_MITM_CFG == 1
+  switch (wave) {
+    case 0: role = 0, idx = 0; break;
+    case 4: role = 2, idx = 0; break;
+    case 8: role = 3, idx = 0; break;
+    case 12: role = 4, idx = 8; break;
+    case 1: role = 1, idx = 0; break;
+    case 2: role = 1, idx = 1; break;
+    case 3: role = 1, idx = 2; break;
+    case 5: role = 1, idx = 3; break;
+    case 6: role = 4, idx = 0; break;
+    case 7: role = 4, idx = 1; break;
+    case 9: role = 4, idx = 2; break;
+    case 10: role = 4, idx = 3; break;
+    case 11: role = 4, idx = 4; break;
+    case 13: role = 4, idx = 5; break;
+    case 14: role = 4, idx = 6; break;
+    default: role = 4, idx = 7; break;
+  }
+  return;
+#endif
   switch (wave) {  // SIMD of wave w: class w % 4
     case 0: role = 0, idx = 0; break;
     case 4: role = 2, idx = 0; break;   // the chain wave's SIMD (0, 4, 8, 12): light waves there do not slow the chain
@@ -283,26 +317,28 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     const float4* src = (const float4*)rows + half * (kMTile / 4) + c4;
     float4* out = (float4*)dst + half * (C >> 2) + c4;
     const bool act = c4 < (C >> 2);
+    // all the tile reads first, then the stores: a store waits for its own read only (the stores are volatile asm: the
+    // compiler does not move a read across one, and read / wait / store eight times over is eight exposed LDS round trips)
+    typedef float nf4 __attribute__((ext_vector_type(4)));
+    nf4 v[kBlk / 2];
+    asm volatile("" ::: "memory");  // (the tile was written through float pointers)
 #pragma unroll
     for (int r = 0; r < kBlk; r += 2) {
-      if (FULL || r < nrows) {
-        if (act && (FULL || r + half < nrows)) {
-          typedef float nf4 __attribute__((ext_vector_type(4)));
-#if WFL_MITM_STORE == 1
-          __builtin_nontemporal_store(*(const nf4*)&src[(r >> 1) * (kMTile / 2)], (nf4*)&out[(r >> 1) * (C >> 1)]);
-#elif WFL_MITM_STORE == 2
-          const nf4 v = *(const nf4*)&src[(r >> 1) * (kMTile / 2)];
-          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(&out[(r >> 1) * (C >> 1)]), "v"(v) : "memory");
-#elif WFL_MITM_STORE == 3
-          const nf4 v = *(const nf4*)&src[(r >> 1) * (kMTile / 2)];
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&out[(r >> 1) * (C >> 1)]), "v"(v) : "memory");
-#elif WFL_MITM_STORE == 4
-          const nf4 v = *(const nf4*)&src[(r >> 1) * (kMTile / 2)];
-          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(&out[(r >> 1) * (C >> 1)]), "v"(v) : "memory");
+      const float4 q = src[(r >> 1) * (kMTile / 2)];
+      v[r >> 1] = nf4{q.x, q.y, q.z, q.w};
+    }
+#pragma unroll
+    for (int r = 0; r < kBlk; r += 2) {
+      if (act && (FULL || r + half < nrows)) {
+        // write-through (sc0 sc1): the rows leave the L2 as they are produced instead of at the end of the kernel, when
+        // 30 MB of dirty lines would be written back at once (measured: 46.5 -> 44.7 us; non-temporal stores: 61 us)
+#if WFL_MITM_STORE == 2
+        // (s_nop: a VALU write of the data registers right behind a store of more than 64 bits is a hazard the compiler
+        // cannot see through the asm)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(&out[(r >> 1) * (C >> 1)]), "v"(v[r >> 1]) : "memory");
 #else
-          out[(r >> 1) * (C >> 1)] = src[(r >> 1) * (kMTile / 2)];
+        *(nf4*)&out[(r >> 1) * (C >> 1)] = v[r >> 1];
 #endif
-        }
       }
     }
   } else {

@@ -19,8 +19,8 @@ d = raw[:B * 2 * 16 * 8].reshape(B, 2, 16, 8).astype(np.float64)
 blkraw = raw[B * 2 * 16 * 8:].reshape(B, 2, 256)
 blk = (blkraw & ((1 << 48) - 1)).astype(np.float64)
 blkpoll = (blkraw >> 48) & 0xfff
-names = {0: "chain", 1: "stager0", 2: "stager1", 3: "stager2", 5: "stager3", 6: "stager4", 7: "stager5", 4: "flusher", 8: "fetcher",
-         9: "emit0", 10: "emit1", 11: "emit2", 13: "emit3", 14: "emit4", 15: "emit5", 12: "emit6"}
+names = {0: "chain", 1: "stager0", 2: "stager1", 3: "stager2", 5: "stager3", 4: "flusher", 8: "fetcher",
+         6: "emit0", 7: "emit1", 9: "emit2", 10: "emit3", 11: "emit4", 13: "emit5", 14: "emit6", 15: "emit7", 12: "emit8"}
 what = {"chain": ("first block", "staged polls", "offdone"), "stager": ("slot wait", "stage compute", "-"),
         "flusher": ("ckready wait", "-", "-"), "fetcher": ("pck slot wait", "partner flag wait", "-"),
         "emit": ("ckdone wait", "pready wait", "compute+store")}
@@ -36,8 +36,8 @@ for dirn in (0, 1):
             nm, simd, np.median(r[:, 0]) * cyc, what[k][0], np.median(r[:, 1]) * cyc, what[k][1], np.median(r[:, 2]) * cyc,
             what[k][2], np.median(r[:, 3]) * cyc, np.median(r[:, 4])) + (
             " | of compute+store: forward %5.1f, rows->HBM %5.1f" % (np.median(r[:, 4]) * cyc, np.median(r[:, 7]) * cyc) if k == "emit" else ""))
-ex = blkraw[:, :, 128:128 + 56].reshape(B, 2, 7, 8).astype(np.float64)
-nblk = (NB_ := (T + 15) // 16) / 2 / 7.0
+ex = blkraw[:, :, 128:128 + 72].reshape(B, 2, 9, 8).astype(np.float64)
+nblk = (NB_ := (T + 15) // 16) / 2 / 9.0
 print("emitters, cumulative cycles from block entry (median over utterances and emitters, per block = total / %.2f blocks):" % nblk)
 for i, nm in ((0, "forward done"), (2, "K done"), (3, "backward done"), (4, "fold + tile writes done"), (5, "certificate done"), (1, "(rows -> HBM part)")):
     print("   %-26s %7.0f cycles/block" % (nm, np.median(ex[:, :, :, i]) / nblk))
