@@ -122,6 +122,7 @@ _SIGS = {
     # device: dense transitions
     "wfl_dense_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "wfl_dense_max_classes": (c_int, []),
+    "wfl_dense_on_chip_classes": (c_int, []),
     "wfl_dense_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "wfl_dense_grad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "wfl_dense_viterbi": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),

@@ -51,7 +51,9 @@ def unpack_replabels(tokens, num_replabels):
 
 
 def max_classes():
-    """Largest class count the ASG kernels accept (wfl_dense_max_classes: the transition matrix is LDS-resident)."""
+    """Largest class count the ASG kernels accept (wfl_dense_max_classes: an index-width bound, 16384 -- up to
+    wfl_dense_on_chip_classes() the transition matrix is private to a workgroup, beyond it is streamed from L2 by the
+    batched per-frame product of csrc/dense_wide.h).  The reference has no limit (asg.py:198-199)."""
     from .. import _native as N
 
     return int(N.lib.wfl_dense_max_classes())
@@ -167,12 +169,9 @@ class ASG(torch.nn.Module):
         self.garbage_idx = (num_classes + num_replabels) if use_garbage else None
         self.N = num_classes + num_replabels + int(use_garbage)
         limit = max_classes()
-        if self.N > limit:
-            # documented deviation from the reference (asg.py:191-209 has no limit): the fully connected
-            # (N+1) x N transition sweeps keep the matrix on chip; say so here, not at the first training step
+        if self.N > limit:  # (16384: the (N+1) x N matrix alone would be a gigabyte)
             raise NotImplementedError(
-                f"ASG with {self.N} classes (tokens + replabels + garbage): the MI355X dense-transition kernels take at most "
-                f"{limit} (DESIGN.md section 3.3).  Use the Transducer criterion with ngram=1/2 transitions for larger token sets.")
+                f"ASG with {self.N} classes (tokens + replabels + garbage): the dense-transition kernels take at most {limit}")
         self.transitions = torch.nn.Parameter(torch.zeros(self.N + 1, self.N))
 
     @E.on_input_device

@@ -935,31 +935,38 @@ static int dense_chunks(int B, int T) {
   return std::max(1, std::min(T, (target + B - 1) / B));
 }
 
+#include "dense_wide.h"
+
 }  // namespace wfl
 
 using namespace wfl;
 
 extern "C" {
 
+constexpr int kDenseMaxClasses = 16384;  // (wide path: 2 x 4 C^2 bytes of workspace -- 2 GB here; an int32 index limit, not a design one)
+
+// does the (C+1) x C matrix of the log-domain / Viterbi kernels fit the LDS?  (otherwise: dense_wide.h)
+static bool dense_on_chip(int C) { return dense_chain_lds(C, C | 1) <= (size_t)kLdsBytes; }
+
 static int dense_check(const float* x, const float* W, int B, int T, int C, const char* who) {
   if (!x || !W || B <= 0 || T <= 0 || C <= 0) {
     set_error("%s: bad arguments (B=%d T=%d C=%d)", who, B, T, C);
     return WFL_ERR_INVALID;
   }
-  const int ldw = C | 1;
-  if (dense_chain_lds(C, ldw) > (size_t)kLdsBytes) {
-    set_error("%s: C=%d does not fit the LDS-resident transition matrix (limit about 190 classes)", who, C);
+  if (C > kDenseMaxClasses) {
+    set_error("%s: C=%d classes (limit %d)", who, C, kDenseMaxClasses);
     return WFL_ERR_UNSUPPORTED;
   }
   return WFL_OK;
 }
 
-// Largest number of classes the dense-transition kernels take: the (C+1) x C matrix of the log-domain / Viterbi
-// kernels lives in LDS.  (ASG is a letter-level criterion -- the reference's recipes use 28..80 classes; a
-// word-piece sized ASG needs a streamed-W kernel that does not exist yet: callers are told at construction time.)
-extern "C" int wfl_dense_max_classes(void) {
+// Largest number of classes the dense-transition entry points take.  Up to wfl_dense_on_chip_classes() the
+// transition matrix is private to a workgroup (LDS / registers); beyond, the frame update of the whole batch is a
+// tiled matrix product with the matrix streamed from L2 (dense_wide.h) -- asg.py:198-199 has no limit.
+extern "C" int wfl_dense_max_classes(void) { return kDenseMaxClasses; }
+extern "C" int wfl_dense_on_chip_classes(void) {
   int c = 1;
-  while (dense_chain_lds(c + 1, (c + 1) | 1) <= (size_t)kLdsBytes) ++c;
+  while (dense_on_chip(c + 1)) ++c;
   return c;
 }
 
@@ -972,6 +979,15 @@ int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int s
   if (!alpha) {
     set_error("dense_forward: alpha is required");
     return WFL_ERR_INVALID;
+  }
+  if (!dense_on_chip(C)) {
+    if (semiring == WFL_SEMIRING_LOG ? (!ws || !logz) : !bptr) {
+      set_error("dense_forward: missing buffers (log: logz + workspace, tropical: back-pointers)");
+      return WFL_ERR_INVALID;
+    }
+    const int rc = wide_forward(x, W, B, T, C, semiring, alpha, beta, bptr, logz, ws, (hipStream_t)stream);
+    WFL_LAUNCH_CHECK();
+    return rc;
   }
   const int ldw = C | 1;
   const size_t lds = dense_chain_lds(C, ldw);
@@ -1037,6 +1053,11 @@ int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws
     set_error("dense_workspace: bad arguments");
     return WFL_ERR_INVALID;
   }
+  if (!dense_on_chip(C)) {
+    if (partial_elems) *partial_elems = (int64_t)kWideSplit * C * C;
+    if (ws_bytes) *ws_bytes = (int64_t)wide_ws_bytes(B, T, C);
+    return WFL_OK;
+  }
   if (partial_elems) *partial_elems = (int64_t)B * dense_chunks(B, T) * (int64_t)(C + 1) * C;
   if (ws_bytes) *ws_bytes = (int64_t)dense_ws_bytes(B, T);
   return WFL_OK;
@@ -1052,6 +1073,12 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
     return WFL_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (!dense_on_chip(C)) {
+    const int rc = wide_grad(x, B, T, C, alpha, beta, logz, coef, coef_w, gout, accumulate, addend, dW_addend, dx, dW,
+                             dW_partial, ws, st);
+    WFL_LAUNCH_CHECK();
+    return rc;
+  }
   const int chunks = dense_chunks(B, T);
   const int rows = (T + chunks - 1) / chunks;
   const int np = (C * C + 255) / 256;

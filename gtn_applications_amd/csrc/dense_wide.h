@@ -1,0 +1,462 @@
+// Dense (fully connected) transitions for ANY class count (included by dense_kernels.hip, inside namespace wfl).
+//
+// criterions/asg.py:198-199 sizes `transitions` to any N; the kernels above keep the (N+1) x N matrix on chip (LDS:
+// N <= 198, registers: N <= 128).  Beyond that the matrix is 4 N^2 bytes -- 4 MB at N = 1000 -- and cannot be private
+// to a workgroup; but then the per-frame update of ALL utterances,
+//     alpha_t[b][i] = E_t[b][i] * sum_j P[i][j] alpha_{t-1}[b][j]        (beta: the transpose)
+// is a [N x N] x [N x B] matrix product that is worth sharing: the frame is ONE launch for the whole batch (both
+// sweeps: alpha's frame s and beta's frame T-1-s), tiled over (states, utterances) with P streamed from L2 / MALL
+// once per 64 utterances instead of once per utterance.  fp32 FMAs on the vector pipe (fp32 MFMA has the same peak
+// on gfx950; the tiles are small and the launch is latency-bound at N ~ 1000, B ~ 128).
+//
+//   P[i][j]   = exp(W[1+i][j] - rm_i),  rm_i = max_j W[1+i][j]                               in (0, 1]
+//   e_t[b][i] = exp(x[b,t,i] + rm_i - mxp_t[b]),  mxp_t[b] = max_i (x[b,t,i] + rm_i)          in (0, 1]
+//   araw_t    = e_t (.) (P (araw_{t-1} / maxa_{t-1})),  maxa_t[b] = max_i araw_t[b][i]        (atomic max: >= 0)
+//   alpha_t   = araw_t / maxa_t * exp(cuma_t),  cuma_t = cuma_{t-1} + mxp_t + log maxa_t,  cuma_0 = max_i(x_0 + W_0)
+//   braw_t    = P^T (e_{t+1} (.) braw_{t+1} / maxb_{t+1}),  beta_t = braw_t / maxb_t * exp(cb_t),
+//               cb_t = cb_{t+1} + mxp_{t+1} + log maxb_t,  braw_{T-1} = 1, cb_{T-1} = 0
+// The normalisation lags the product by one frame (a frame's maximum is only complete when its launch ends), so a
+// stored value is at most N times / at least 2^-126 of the frame's largest: fp32 holds it.  The cumulative offsets
+// are doubles (they reach 10^4 at T = 1000).  `alpha` / `beta` hold araw / braw; the workspace the rest.
+//
+// Gradient: emission posteriors elementwise; the transition gradient is the second matrix product of the path,
+//     dW[1+i][j] = P[i][j] * sum_{b, t >= 1} U[(b,t)][i] V[(b,t)][j],   V = araw_{t-1} / maxa_{t-1},
+//     U = e_t (.) braw_t / maxb_t * coef_w[b] * exp(cuma_{t-1} + mxp_t + cb_t - log Z_b)
+// over K = B (T-1) rows, split into kWideSplit slabs reduced in a fixed order (deterministic, no atomics).
+// Tropical semiring (ASG.viterbi, asg.py:217-226): the same tiling with (max, +) and the arg max (lowest previous
+// label on ties, as the LDS-resident kernel).
+#pragma once
+
+constexpr int kWideTM = 64, kWideTN = 64, kWideTK = 16;  // output tile (states x utterances) and K chunk
+constexpr int kWideSplit = 8;                             // K slabs of the transition-gradient product
+
+struct WideWs {
+  float* P;      // [C][C]
+  float* PT;     // [C][C]
+  float* rm;     // [C]
+  float* m0;     // [B]
+  float* mxp;    // [B][T]
+  float* maxa;   // [B][T]
+  float* maxb;   // [B][T]
+  double* cuma;  // [B][T]
+  double* cb;    // [B][T]
+};
+__host__ __device__ inline size_t wide_align(size_t n) { return (n + 15) & ~(size_t)15; }
+__host__ __device__ inline WideWs wide_carve(void* ws, int B, int T, int C) {
+  WideWs w;
+  char* p = (char*)ws;
+  w.P = (float*)p, p += wide_align((size_t)4 * C * C);
+  w.PT = (float*)p, p += wide_align((size_t)4 * C * C);
+  w.rm = (float*)p, p += wide_align((size_t)4 * C);
+  w.m0 = (float*)p, p += wide_align((size_t)4 * B);
+  w.mxp = (float*)p, p += wide_align((size_t)4 * B * T);
+  w.maxa = (float*)p, p += wide_align((size_t)4 * B * T);
+  w.maxb = (float*)p, p += wide_align((size_t)4 * B * T);
+  w.cuma = (double*)p, p += wide_align((size_t)8 * B * T);
+  w.cb = (double*)p, p += wide_align((size_t)8 * B * T);
+  return w;
+}
+static size_t wide_ws_bytes(int B, int T, int C) {
+  return 2 * wide_align((size_t)4 * C * C) + wide_align((size_t)4 * C) + wide_align((size_t)4 * B) +
+         3 * wide_align((size_t)4 * B * T) + 2 * wide_align((size_t)8 * B * T) + 64;
+}
+
+__device__ __forceinline__ float wide_clean(float v) { return (v == v) ? v : WFL_NEG_INF; }  // NaN policy: impossible
+
+// one workgroup per row i of W[1:, :]: rm_i, P[i][:], PT[:][i]
+__global__ void __launch_bounds__(256) wide_prep_kernel(const float* __restrict__ W, int C, WideWs w) {
+  __shared__ float red[64];
+  const int i = blockIdx.x;
+  const float* row = W + (int64_t)(1 + i) * C;
+  float m = WFL_NEG_INF;
+  for (int j = threadIdx.x; j < C; j += 256) m = fmaxf(m, wide_clean(row[j]));
+  m = blk_max(m, red);
+  const float ref = (m > -3.0e38f && m < 3.0e38f) ? m : 0.f;  // (a row of -inf: P = 0, any finite reference does)
+  if (threadIdx.x == 0) w.rm[i] = ref;
+  for (int j = threadIdx.x; j < C; j += 256) {
+    const float p = __expf(wide_clean(row[j]) - ref);
+    w.P[(int64_t)i * C + j] = p;
+    w.PT[(int64_t)j * C + i] = p;
+  }
+}
+
+// one wave per (b, t): mxp; t == 0: m0 and alpha's first frame; t == T-1: beta's last frame.  The maxima of the
+// frames in between are zeroed for the frame launches' atomic max.
+__global__ void __launch_bounds__(256) wide_rows_kernel(const float* __restrict__ x, const float* __restrict__ W, int B, int T,
+                                                        int C, WideWs w, float* __restrict__ alpha, float* __restrict__ beta) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (int64_t)B * T) return;
+  const int b = (int)(r / T), t = (int)(r % T);
+  const float* xr = x + r * C;
+  float m = WFL_NEG_INF;
+  for (int i = lane; i < C; i += 64) m = fmaxf(m, wide_clean(xr[i]) + w.rm[i]);
+  m = wave_max(m);
+  const float ref = (m > -3.0e38f && m < 3.0e38f) ? m : 0.f;
+  if (lane == 0) w.mxp[r] = ref;
+  if (t == 0) {
+    float m0 = WFL_NEG_INF;
+    for (int i = lane; i < C; i += 64) m0 = fmaxf(m0, wide_clean(xr[i]) + wide_clean(W[i]));
+    m0 = wave_max(m0);
+    const float r0 = (m0 > -3.0e38f && m0 < 3.0e38f) ? m0 : 0.f;
+    float top = 0.f;
+    for (int i = lane; i < C; i += 64) {
+      const float a = __expf(wide_clean(xr[i]) + wide_clean(W[i]) - r0);
+      alpha[r * C + i] = a;
+      top = fmaxf(top, a);
+    }
+    top = wave_max(top);
+    if (lane == 0) w.m0[b] = r0, w.maxa[r] = top;
+  } else if (lane == 0) {
+    w.maxa[r] = 0.f;
+  }
+  if (beta) {
+    if (t == T - 1) {
+      for (int i = lane; i < C; i += 64) beta[r * C + i] = 1.f;
+      if (lane == 0) w.maxb[r] = 1.f;
+    } else if (lane == 0) {
+      w.maxb[r] = 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void atomic_max_pos(float* p, float v) {  // v >= 0: the bit patterns order like the values
+  atomicMax(reinterpret_cast<int*>(p), __float_as_int(v));
+}
+
+// One frame of both sweeps: blockIdx.z = 0 alpha's frame s (s >= 1), 1 beta's frame T-1-s.  Tile: kWideTM states x
+// kWideTN utterances, 256 threads, 4 x 4 outputs per thread, operands through LDS in chunks of kWideTK.
+__global__ void __launch_bounds__(256) wide_frame_kernel(const float* __restrict__ x, int B, int T, int C, int s, WideWs w,
+                                                         float* __restrict__ alpha, float* __restrict__ beta) {
+  const int dir = blockIdx.z;
+  if (dir == 1 && !beta) return;
+  __shared__ float As[kWideTK][kWideTM + 4];
+  __shared__ float Bs[kWideTK][kWideTN + 4];
+  const int i0 = blockIdx.x * kWideTM, n0 = blockIdx.y * kWideTN;
+  const int t = dir == 0 ? s : T - 1 - s;         // the frame being produced
+  const int tp = dir == 0 ? t - 1 : t + 1;        // the frame it is produced from
+  const float* A = dir == 0 ? w.P : w.PT;
+  const float* vec = dir == 0 ? alpha : beta;
+  const float* vmax = dir == 0 ? w.maxa : w.maxb;
+  const int tid = threadIdx.x, ti = tid & 15, tn = tid >> 4;  // micro tile: states i0 + ti + 16 u, utterances n0 + tn + 16 v
+  float acc[4][4] = {};
+  // loader assignment: 256 threads x 4 elements = a 64 x 16 tile; thread -> (row = tid / 4, k = (tid % 4) * 4 ..)
+  const int lr = tid >> 2, lk = (tid & 3) * 4;
+  const int bn = n0 + lr;  // utterance of this thread's B-operand row
+  float binv = 0.f, bref = 0.f;
+  if (bn < B) {
+    const float mx = vmax[(int64_t)bn * T + tp];
+    binv = mx > 0.f ? 1.f / mx : 0.f;
+    bref = w.mxp[(int64_t)bn * T + tp];
+  }
+  for (int k0 = 0; k0 < C; k0 += kWideTK) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + lk + q;
+      const int ai = i0 + lr;
+      As[lk + q][lr] = (ai < C && k < C) ? A[(int64_t)ai * C + k] : 0.f;
+      float v = 0.f;
+      if (bn < B && k < C) {
+        v = vec[((int64_t)bn * T + tp) * C + k] * binv;
+        if (dir == 1) v *= __expf(wide_clean(x[((int64_t)bn * T + tp) * C + k]) + w.rm[k] - bref);  // e_{t+1} (.) beta_{t+1}
+      }
+      Bs[lk + q][lr] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWideTK; ++k) {
+      float a[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = As[k][ti + 16 * u], bv[u] = Bs[k][tn + 16 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(a[u], bv[v], acc[u][v]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int n = n0 + tn + 16 * v;
+    if (n >= B) continue;
+    const int64_t row = (int64_t)n * T + t;
+    const float ref = dir == 0 ? w.mxp[row] : 0.f;
+    float top = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + ti + 16 * u;
+      if (i >= C) continue;
+      float y = acc[u][v];
+      if (dir == 0) y *= __expf(wide_clean(x[row * C + i]) + w.rm[i] - ref);
+      (dir == 0 ? alpha : beta)[row * C + i] = y;
+      top = fmaxf(top, y);
+    }
+    // (16 threads of a wave share the utterance: lanes ti = 0..15 of the same tn)
+    top = fmaxf(top, __shfl_xor(top, 1, 64));
+    top = fmaxf(top, __shfl_xor(top, 2, 64));
+    top = fmaxf(top, __shfl_xor(top, 4, 64));
+    top = fmaxf(top, __shfl_xor(top, 8, 64));
+    if (ti == 0 && top > 0.f) atomic_max_pos((dir == 0 ? w.maxa : w.maxb) + row, top);
+  }
+}
+
+// per utterance: the cumulative offsets (a serial scan over T by one thread) and log Z
+__global__ void __launch_bounds__(256) wide_scan_kernel(int B, int T, int C, WideWs w, const float* __restrict__ alpha,
+                                                        bool with_beta, float* __restrict__ logz) {
+  __shared__ float red[64];
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    double c = (double)w.m0[b];
+    w.cuma[(int64_t)b * T] = c;
+    for (int t = 1; t < T; ++t) {
+      const float mx = w.maxa[(int64_t)b * T + t];
+      c += (double)w.mxp[(int64_t)b * T + t] + (mx > 0.f ? (double)__logf(mx) : -1.0e300);
+      w.cuma[(int64_t)b * T + t] = c;
+    }
+    if (with_beta) {
+      double d = 0.0;
+      w.cb[(int64_t)b * T + T - 1] = 0.0;
+      for (int t = T - 2; t >= 0; --t) {
+        const float mx = w.maxb[(int64_t)b * T + t];
+        d += (double)w.mxp[(int64_t)b * T + t + 1] + (mx > 0.f ? (double)__logf(mx) : -1.0e300);
+        w.cb[(int64_t)b * T + t] = d;
+      }
+    }
+  }
+  const float* last = alpha + ((int64_t)b * T + T - 1) * C;
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) sum += last[i];
+  sum = blk_sum(sum, red);  // (its barriers also order thread 0's scan before the read below)
+  if (threadIdx.x == 0) {
+    const float mx = w.maxa[(int64_t)b * T + T - 1];
+    const double z = (sum > 0.f && mx > 0.f) ? (double)logf(sum / mx) + w.cuma[(int64_t)b * T + T - 1] : -1.0e300;
+    logz[b] = z > -1.0e299 ? (float)z : WFL_NEG_INF;
+  }
+}
+
+// dx[b,t,i] = (accumulate ? dx : 0) + gout * addend + coef[b] * gout * posterior_t(i); one wave per row
+__global__ void __launch_bounds__(256) wide_grad_x_kernel(int B, int T, int C, WideWs w, const float* __restrict__ alpha,
+                                                          const float* __restrict__ beta, const float* __restrict__ logz,
+                                                          const float* __restrict__ coef, const float* __restrict__ gout,
+                                                          int accumulate, const float* __restrict__ addend,
+                                                          float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (int64_t)B * T) return;
+  const int b = (int)(r / T);
+  const float g = gout ? gout[0] : 1.f;
+  const float ma = w.maxa[r], mb = w.maxb[r], lz = logz[b];
+  float k = 0.f;
+  if (ma > 0.f && mb > 0.f && lz > -3.0e38f)
+    k = (coef ? coef[b] : 1.f) * g * (float)exp(w.cuma[r] + w.cb[r] - (double)lz) / (ma * mb);
+  for (int i = lane; i < C; i += 64) {
+    float v = k != 0.f ? k * alpha[r * C + i] * beta[r * C + i] : 0.f;
+    if (addend) v += g * addend[r * C + i];
+    if (accumulate) v += dx[r * C + i];
+    dx[r * C + i] = v;
+  }
+}
+
+// partial[z][i][j] = sum over the z-th slab of rows k = (b, t >= 1) of U[k][i] V[k][j]   (see the header)
+__global__ void __launch_bounds__(256) wide_grad_w_kernel(const float* __restrict__ x, int B, int T, int C, WideWs w,
+                                                          const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                          const float* __restrict__ logz, const float* __restrict__ coef_w,
+                                                          float* __restrict__ partial) {
+  __shared__ float Us[kWideTK][kWideTM + 4];
+  __shared__ float Vs[kWideTK][kWideTN + 4];
+  __shared__ float ku[kWideTK], kv[kWideTK];
+  __shared__ int64_t krow[kWideTK];
+  const int i0 = blockIdx.x * kWideTM, j0 = blockIdx.y * kWideTN;
+  const int64_t K = (int64_t)B * (T - 1);
+  const int64_t per = (K + kWideSplit - 1) / kWideSplit;
+  const int64_t kbeg = (int64_t)blockIdx.z * per, kend = min(K, kbeg + per);
+  const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
+  float acc[4][4] = {};
+  for (int64_t k0 = kbeg; k0 < kend; k0 += kWideTK) {
+    if (tid < kWideTK) {
+      const int64_t k = k0 + tid;
+      float su = 0.f, sv = 0.f;
+      int64_t row = 0;
+      if (k < kend) {
+        const int b = (int)(k / (T - 1)), t = 1 + (int)(k % (T - 1));
+        row = (int64_t)b * T + t;
+        const float ma = w.maxa[row - 1], mb = w.maxb[row], lz = logz[b];
+        if (ma > 0.f && mb > 0.f && lz > -3.0e38f) {
+          sv = 1.f / ma;
+          su = (coef_w ? coef_w[b] : 1.f) * (float)exp(w.cuma[row - 1] + (double)w.mxp[row] + w.cb[row] - (double)lz) / mb;
+        }
+      }
+      ku[tid] = su, kv[tid] = sv, krow[tid] = row;
+    }
+    __syncthreads();
+    // 16 rows x 64 columns per operand: thread -> (row = tid / 16, columns (tid % 16) + 16 q)
+    {
+      const int kr = tid >> 4, c = tid & 15;
+      const int64_t row = krow[kr];
+      const float su = ku[kr], sv = kv[kr], ref = w.mxp[row];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + c + 16 * q, j = j0 + c + 16 * q;
+        float u = 0.f, v = 0.f;
+        if (su != 0.f && i < C) u = su * beta[row * C + i] * __expf(wide_clean(x[row * C + i]) + w.rm[i] - ref);
+        if (sv != 0.f && j < C) v = sv * alpha[(row - 1) * C + j];
+        Us[kr][c + 16 * q] = u, Vs[kr][c + 16 * q] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWideTK; ++k) {
+      float a[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = Us[k][ti + 16 * u], bv[u] = Vs[k][tj + 16 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(a[u], bv[v], acc[u][v]);
+    }
+    __syncthreads();
+  }
+  float* out = partial + (int64_t)blockIdx.z * C * C;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = i0 + ti + 16 * u, j = j0 + tj + 16 * v;
+      if (i < C && j < C) out[(int64_t)i * C + j] = acc[u][v];
+    }
+}
+
+// dW = (accumulate ? dW : 0) + gout * dW_addend + gout * [start row: sum_b coef_w[b] posterior_0 ; P (.) sum of slabs]
+__global__ void __launch_bounds__(256) wide_reduce_w_kernel(int B, int T, int C, WideWs w, const float* __restrict__ alpha,
+                                                            const float* __restrict__ beta, const float* __restrict__ logz,
+                                                            const float* __restrict__ coef_w, const float* __restrict__ gout,
+                                                            int accumulate, const float* __restrict__ dW_addend,
+                                                            const float* __restrict__ partial, float* __restrict__ dW) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)(C + 1) * C) return;
+  const float g = gout ? gout[0] : 1.f;
+  float v = 0.f;
+  if (e < C) {  // start row
+    const int i = (int)e;
+    for (int b = 0; b < B; ++b) {
+      const int64_t r = (int64_t)b * T;
+      const float ma = w.maxa[r], mb = w.maxb[r], lz = logz[b];
+      if (ma > 0.f && mb > 0.f && lz > -3.0e38f)
+        v += (coef_w ? coef_w[b] : 1.f) * (float)exp(w.cuma[r] + w.cb[r] - (double)lz) / (ma * mb) * alpha[r * C + i] * beta[r * C + i];
+    }
+  } else {
+    const int64_t p = e - C;
+    float s = 0.f;
+    for (int z = 0; z < kWideSplit; ++z) s += partial[(int64_t)z * C * C + p];
+    v = w.P[p] * s;
+  }
+  v *= g;
+  if (dW_addend) v += g * dW_addend[e];
+  if (accumulate) v += dW[e];
+  dW[e] = v;
+}
+
+// Tropical frame: v_t[b][i] = x[b,t,i] + max_j (v_{t-1}[b][j] + W[1+i][j]), bptr = the lowest arg max
+__global__ void __launch_bounds__(256) wide_viterbi_frame_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                 int B, int T, int C, int t, float* __restrict__ alpha,
+                                                                 int32_t* __restrict__ bptr) {
+  __shared__ float As[kWideTK][kWideTM + 4];
+  __shared__ float Bs[kWideTK][kWideTN + 4];
+  const int i0 = blockIdx.x * kWideTM, n0 = blockIdx.y * kWideTN;
+  const int tid = threadIdx.x, ti = tid & 15, tn = tid >> 4;
+  const int lr = tid >> 2, lk = (tid & 3) * 4;
+  float best[4][4];
+  int arg[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) best[u][v] = WFL_NEG_INF, arg[u][v] = -1;
+  for (int k0 = 0; k0 < C; k0 += kWideTK) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + lk + q;
+      const int ai = i0 + lr, bn = n0 + lr;
+      As[lk + q][lr] = (ai < C && k < C) ? wide_clean(W[(int64_t)(1 + ai) * C + k]) : WFL_NEG_INF;
+      Bs[lk + q][lr] = (bn < B && k < C) ? alpha[((int64_t)bn * T + t - 1) * C + k] : WFL_NEG_INF;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWideTK; ++k) {
+      float a[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = As[k][ti + 16 * u], bv[u] = Bs[k][tn + 16 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float cand = a[u] + bv[v];
+          if (cand > best[u][v]) best[u][v] = cand, arg[u][v] = k0 + k;  // strict: the lowest previous label wins ties
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int n = n0 + tn + 16 * v;
+    if (n >= B) continue;
+    const int64_t row = (int64_t)n * T + t;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + ti + 16 * u;
+      if (i >= C) continue;
+      alpha[row * C + i] = wide_clean(x[row * C + i]) + best[u][v];
+      bptr[row * C + i] = arg[u][v];
+    }
+  }
+}
+__global__ void __launch_bounds__(256) wide_viterbi_first_kernel(const float* __restrict__ x, const float* __restrict__ W, int B,
+                                                                 int T, int C, float* __restrict__ alpha,
+                                                                 int32_t* __restrict__ bptr) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * C) return;
+  const int b = (int)(e / C), i = (int)(e % C);
+  const int64_t at = (int64_t)b * T * C + i;
+  alpha[at] = wide_clean(x[at]) + wide_clean(W[i]);
+  bptr[at] = -1;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int wide_forward(const float* x, const float* W, int B, int T, int C, int semiring, float* alpha, float* beta,
+                        int32_t* bptr, float* logz, void* ws, hipStream_t st) {
+  const dim3 tiles((unsigned)((C + kWideTM - 1) / kWideTM), (unsigned)((B + kWideTN - 1) / kWideTN));
+  if (semiring == WFL_SEMIRING_TROPICAL) {
+    hipLaunchKernelGGL(wide_viterbi_first_kernel, dim3((unsigned)(((int64_t)B * C + 255) / 256)), dim3(256), 0, st, x, W, B, T,
+                       C, alpha, bptr);
+    for (int t = 1; t < T; ++t)
+      hipLaunchKernelGGL(wide_viterbi_frame_kernel, tiles, dim3(256), 0, st, x, W, B, T, C, t, alpha, bptr);
+    return WFL_OK;
+  }
+  const WideWs w = wide_carve(ws, B, T, C);
+  hipLaunchKernelGGL(wide_prep_kernel, dim3((unsigned)C), dim3(256), 0, st, W, C, w);
+  hipLaunchKernelGGL(wide_rows_kernel, dim3((unsigned)(((int64_t)B * T + 3) / 4)), dim3(256), 0, st, x, W, B, T, C, w, alpha,
+                     beta);
+  const dim3 grid(tiles.x, tiles.y, beta ? 2u : 1u);
+  for (int s = 1; s < T; ++s) hipLaunchKernelGGL(wide_frame_kernel, grid, dim3(256), 0, st, x, B, T, C, s, w, alpha, beta);
+  hipLaunchKernelGGL(wide_scan_kernel, dim3((unsigned)B), dim3(256), 0, st, B, T, C, w, alpha, beta != nullptr, logz);
+  return WFL_OK;
+}
+
+static int wide_grad(const float* x, int B, int T, int C, const float* alpha, const float* beta, const float* logz,
+                     const float* coef, const float* coef_w, const float* gout, int accumulate, const float* addend,
+                     const float* dW_addend, float* dx, float* dW, float* dW_partial, const void* ws, hipStream_t st) {
+  const WideWs w = wide_carve(const_cast<void*>(ws), B, T, C);
+  if (dx)
+    hipLaunchKernelGGL(wide_grad_x_kernel, dim3((unsigned)(((int64_t)B * T + 3) / 4)), dim3(256), 0, st, B, T, C, w, alpha, beta,
+                       logz, coef, gout, accumulate, addend, dx);
+  if (dW) {
+    if (T > 1) {
+      const dim3 grid((unsigned)((C + kWideTM - 1) / kWideTM), (unsigned)((C + kWideTN - 1) / kWideTN), (unsigned)kWideSplit);
+      hipLaunchKernelGGL(wide_grad_w_kernel, grid, dim3(256), 0, st, x, B, T, C, w, alpha, beta, logz, coef_w, dW_partial);
+    } else {
+      (void)hipMemsetAsync(dW_partial, 0, (size_t)4 * kWideSplit * C * C, st);
+    }
+    hipLaunchKernelGGL(wide_reduce_w_kernel, dim3((unsigned)(((int64_t)(C + 1) * C + 255) / 256)), dim3(256), 0, st, B, T, C, w,
+                       alpha, beta, logz, coef_w, gout, accumulate, dW_addend, dW_partial, dW);
+  }
+  return WFL_OK;
+}

@@ -236,10 +236,12 @@ int wfl_debug_grad_occupancy(int lds_bytes);
  * transition gradient) and the opaque workspace `ws` [ws_bytes] shared by forward and grad
  * (per-frame scale bookkeeping of the probability-domain sweeps, per-utterance range flags). */
 int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws_bytes);
-/* Largest C the dense-transition entry points accept (the (C+1) x C matrix of their log-domain / Viterbi kernels is
- * LDS-resident: about 190 on gfx950); above it they return WFL_ERR_UNSUPPORTED.  The reference has no such limit
- * (asg.py:191-209): the ASG module checks this at construction and says so instead of failing at the first step. */
+/* Largest C the dense-transition entry points accept (asg.py:191-209 has no limit: 16384 is an index-width bound).  Up
+ * to wfl_dense_on_chip_classes() (about 190 on gfx950) the (C+1) x C matrix is private to a workgroup; beyond, the frame
+ * update of the whole batch runs as one tiled matrix product per frame with the matrix streamed from L2
+ * (csrc/dense_wide.h): same entry points, same buffers (sizes from wfl_dense_workspace). */
 int wfl_dense_max_classes(void);
+int wfl_dense_on_chip_classes(void);
 /* forward_score(intersect(emissions, transitions)) (asg.py:114): logz [B]; alpha, beta [B,T,C] are
  * opaque inputs of wfl_dense_grad in the log semiring (scaled probabilities for utterances served
  * by the probability-domain sweep, log scores for utterances it had to hand to the log-domain

@@ -317,3 +317,39 @@ def test_criteria_run_on_a_device_that_is_not_the_current_one():
     assert torch.cuda.current_device() == 0
     for a, b in zip(res[0], res[1]):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("C,B,T,L", [(1000, 6, 60, 12), (333, 70, 33, 9)])
+def test_asg_beyond_the_on_chip_class_limit(C, B, T, L):
+    """asg.py:198-199 sizes `transitions` to any N.  Above wfl_dense_on_chip_classes() the dense sweeps run as one
+    tiled matrix product per frame for the whole batch (csrc/dense_wide.h): ASGLoss with 1000 classes (and a size
+    with partial tiles on both axes) against the float64 oracle -- loss, emission gradient, transition gradient,
+    mean reduction, an upstream scalar -- and ASG.viterbi at that size against the oracle's max-plus recursion."""
+    from gtn_applications_amd import _native as N
+    from gtn_applications_amd.criterions import asg
+
+    assert C > N.lib.wfl_dense_on_chip_classes()
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, T, C, generator=g)
+    W = torch.randn(C + 1, C, generator=g)
+    targets = [torch.randint(C, (int(n),), generator=g).tolist() for n in torch.randint(1, L + 1, (B,), generator=g)]
+    want_loss, want_dx, want_dW = OR.asg_loss_grad_batched(x.numpy(), W.numpy(), targets)
+    xg, Wg = x.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
+    loss = asg.ASGLoss(xg, Wg, targets)
+    (2.0 * loss).backward()
+    assert loss.item() == pytest.approx(want_loss.mean(), rel=RTOL)
+    check(f"asg_wide_c{C}_dx", xg.grad.cpu().numpy(), 2.0 * want_dx, 2.0 / B)
+    check(f"asg_wide_c{C}_dW", Wg.grad.cpu().numpy(), 2.0 * want_dW, 2.0 / B)
+    # the module (garbage + replabels on top: N = C here by construction) and its Viterbi decode
+    crit = asg.ASG(C - 2, 1, True).cuda()
+    with torch.no_grad():
+        crit.transitions.copy_(W.cuda())
+    assert crit.N == C
+    got = crit.viterbi(x.cuda())
+    for b in range(min(B, 3)):
+        path = OR.dense_viterbi(x[b].numpy(), W.numpy())
+        import itertools
+
+        collapsed = [p for p, _ in itertools.groupby(path)]
+        collapsed = [p for p in collapsed if p != crit.garbage_idx]
+        assert got[b].tolist() == asg.unpack_replabels(collapsed, 1)

@@ -2,6 +2,7 @@
 include/wfl.h declares, the graph builders reproduce the reference's builders arc by arc, and the
 C++ graph algebra (compose / remove / project / viterbi_path / pack) agrees with the oracle.
 No device compute is called here."""
+import ctypes
 import json
 import os
 import re
@@ -628,13 +629,20 @@ def test_batch_builder_writes_into_the_callers_buffer():
                 N.lib.wfl_lattice_host_free(h)
 
 
-def test_asg_class_limit_is_reported_at_construction():
-    """documented deviation: the dense-transition kernels keep the (N+1) x N matrix on chip"""
-    limit = asg.max_classes()
-    assert 128 <= limit <= 256 and N.lib.wfl_dense_max_classes() == limit
-    assert asg.ASG(limit - 2, 1, True).N == limit
-    with pytest.raises(NotImplementedError, match="dense-transition kernels take at most"):
-        asg.ASG(limit - 1, 1, True)
+def test_asg_has_no_on_chip_class_limit():
+    """asg.py:198-199 sizes `transitions` to any N: beyond the on-chip limit of the LDS-resident kernels the entry
+    points switch to the batched per-frame product (csrc/dense_wide.h); the workspace query says what it needs."""
+    on_chip = N.lib.wfl_dense_on_chip_classes()
+    assert 128 <= on_chip <= 256 and asg.max_classes() >= 8192
+    crit = asg.ASG(1000, 1, True)
+    assert crit.N == 1002 and tuple(crit.transitions.shape) == (1003, 1002)
+    part, ws = ctypes.c_int64(), ctypes.c_int64()
+    assert N.lib.wfl_dense_workspace(4, 50, 1002, ctypes.byref(part), ctypes.byref(ws)) == 0
+    assert part.value % (1002 * 1002) == 0 and ws.value > 2 * 4 * 1002 * 1002  # K slabs of dW; P, P^T + bookkeeping
+    assert N.lib.wfl_dense_workspace(4, 50, on_chip, ctypes.byref(part), ctypes.byref(ws)) == 0
+    assert ws.value < 1 << 20  # the on-chip kernels' workspace does not hold the matrix
+    with pytest.raises(NotImplementedError):
+        asg.ASG(asg.max_classes(), 1, True)
 
 
 def test_cpp_autograd_extension_is_built_and_exports_the_ctc_node():
