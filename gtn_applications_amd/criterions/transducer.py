@@ -8,6 +8,7 @@ transducer.py:265-281) runs in the C++ host library; everything that touches the
 (transducer.py:283-288,321-336,216-221) -- runs on the lattice engine kernels.
 """
 import itertools
+import os
 
 import math
 
@@ -157,6 +158,10 @@ def _alignment_graph(target, tokens, lexicon, transitions):
     return _ALIGN_CACHE.get(key, build)[:2]
 
 
+# WFL_DENSE_NGRAM=0: the bigram normaliser through the general lattice sweep (A/B tests, measurements)
+_DENSE_NGRAM = os.environ.get("WFL_DENSE_NGRAM", "1") != "0"
+
+
 class Transducer(torch.nn.Module):
     """A generic transducer loss (transducer.py:126-234).
 
@@ -231,6 +236,50 @@ class Transducer(torch.nn.Module):
         return predictions
 
 
+_BIGRAM_SEEN = {}
+
+
+def _dense_bigram(transitions, C):
+    """True iff `transitions` has exactly the structure of make_transitions_graph(2, C) (transducer.py:32-58): start
+    node 0, one node per previous token, C start arcs, C x C bigram arcs `prev a -> cur b` at arc C + a C + b, and
+    an epsilon arc from every node to the accepting end node.  Its normaliser
+    forward_score(intersect(emissions, transitions)) (transducer.py:286-288) is then the fully connected recursion of
+    the dense engine (csrc/dense_kernels.hip) with W[0] = start scores, W[1+b][a] = bigram score and the end
+    arcs' scores added to the last frame -- instead of the general lattice sweep with (C+1) C^2 arcs."""
+    hit = _BIGRAM_SEEN.get(id(transitions))
+    if hit is not None and hit[0] is transitions and hit[1] == C:
+        return hit[2]
+    ok = False
+    if transitions.num_nodes() == C + 2 and transitions.num_arcs() == C + C * C + C + 1:
+        a = transitions.arrays()
+        idx = np.arange(C, dtype=np.int64)
+        ab = np.arange(C * C, dtype=np.int64)
+        eps = np.arange(C + 1, dtype=np.int64)
+        s, d, il, ol = (np.asarray(a[k]) for k in ("src", "dst", "ilabel", "olabel"))
+        n0, n1 = C, C + C * C
+        st, ac = np.flatnonzero(np.asarray(a["start"])), np.flatnonzero(np.asarray(a["accept"]))  # (per-node flags)
+        ok = (st.tolist() == [0] and ac.tolist() == [C + 1]
+              and (s[:n0] == 0).all() and (d[:n0] == 1 + idx).all() and (il[:n0] == idx).all() and (ol[:n0] == idx).all()
+              and (s[n0:n1] == 1 + ab // C).all() and (d[n0:n1] == 1 + ab % C).all() and (il[n0:n1] == ab % C).all()
+              and (ol[n0:n1] == ab % C).all()
+              and (s[n1:] == eps).all() and (d[n1:] == C + 1).all() and (il[n1:] == G.epsilon).all() and (ol[n1:] == G.epsilon).all())
+    if len(_BIGRAM_SEEN) > 64:
+        _BIGRAM_SEEN.clear()
+    _BIGRAM_SEEN[id(transitions)] = (transitions, C, bool(ok))  # (holds the graph: its id stays unique)
+    return bool(ok)
+
+
+def _bigram_dense_operands(x, params, C):
+    """(emissions with the end arcs' scores on the last frame, W [(C+1), C] of the dense engine) for the bigram
+    transition model: params = [start C | bigram a -> b at a C + b | end arcs of nodes 0 .. C]"""
+    Wd = torch.empty((C + 1, C), dtype=torch.float32, device=x.device)
+    Wd[0] = params[:C]
+    Wd[1:] = params[C:C + C * C].view(C, C).t()
+    xd = x.clone()
+    xd[:, -1, :] += params[C + C * C + 1:]
+    return xd, Wd
+
+
 def _transitions_pack(transitions, B, C, device):
     key = ("den", id(transitions), B, C, device.index)
 
@@ -280,30 +329,51 @@ class TransducerLossFunction(torch.autograd.Function):
 
         pack, scale, cpos, cneg, _ = _PACK_CACHE.get(key + (reduction == "mean",), build)
         need_grad = inputs.requires_grad or (transition_params is not None and transition_params.requires_grad)
-        den = None
+        den = dense = None
         if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288
             # independent of the numerator sweep: forked onto a second stream so that the two overlap
             with E.side_stream(dev) as fork:
-                den = E.lattice_forward(x, _transitions_pack(transitions, B, C, dev), weights=params,
-                                        need_beta=need_grad)
+                if _DENSE_NGRAM and _dense_bigram(transitions, C):
+                    xd, Wd = _bigram_dense_operands(x, params, C)
+                    den = E.dense_forward(xd, Wd, need_beta=need_grad)
+                    dense = (xd, Wd)
+                else:
+                    den = E.lattice_forward(x, _transitions_pack(transitions, B, C, dev), weights=params,
+                                            need_beta=need_grad)
         num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax)
         if den is not None:
-            fork.join(den.xg, den.alpha, den.beta, den.logz)
+            if dense is not None:
+                fork.join(dense[0], dense[1], den.alpha, den.beta, den.logz, den.ws)
+            else:
+                fork.join(den.xg, den.alpha, den.beta, den.logz)
             loss = E.reduce_loss(den.logz, scale, 1.0, minus=num.logz)
         else:
             loss = E.reduce_loss(num.logz, scale, -1.0)
-        ctx.aux = (x, params, num, den, cpos, cneg)
+        ctx.aux = (x, params, num, den, cpos, cneg, dense)
         ctx.devices = (inputs.device, None if transition_params is None else transition_params.device)
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
     @E.on_input_device
     def backward(ctx, grad_output):
-        x, params, num, den, cpos, cneg = ctx.aux
+        x, params, num, den, cpos, cneg, dense = ctx.aux
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.zeros_like(params) if (params is not None and ctx.needs_input_grad[4]) else None
-        if dx is not None or dW is not None:
+        if (dx is not None or dW is not None) and dense is not None:
+            # the dense normaliser first (its emission gradient alone, for a moment, in dx: the last frame's rows are
+            # also the gradient of the end arcs' scores), then the numerator's lattice on top
+            xd, Wd = dense
+            C = x.shape[2]
+            ddx = dx if dx is not None else torch.empty_like(x)
+            dWd = torch.empty_like(Wd) if dW is not None else None
+            E.dense_grad(xd, Wd, den, cpos, coef_w=cpos, gout=gout, dx=ddx, accumulate=False, dW=dWd)
+            if dW is not None:
+                dW[:C] = dWd[0]
+                dW[C:C + C * C] = dWd[1:].t().reshape(-1)
+                dW[C + C * C + 1:] = ddx[:, -1, :].sum(dim=0)
+            E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=True, dW=dW)
+        elif dx is not None or dW is not None:
             E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=False, dW=dW)
             if den is not None:
                 E.lattice_grad(den, cpos, coef_w=cpos, gout=gout, dx=dx, accumulate=True, dW=dW)

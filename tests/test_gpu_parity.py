@@ -1026,12 +1026,16 @@ def test_transducer_backoff_transitions(crit, lit, tmp_path):
 
 
 
-@pytest.mark.parametrize("ngram,blank", [(1, "optional"), (2, "none"), (2, "optional")])
-def test_transducer_dense_ngram_transitions_use_the_cooperative_relaxation(crit, ngram, blank):
-    """30 tokens: the n-gram transition graph has 30-way in-degree, above the threshold at which a
-    whole wavefront relaxes a state (lattice engine, general path); loss, emission gradient,
-    transition-parameter gradient and Viterbi against the graph oracle"""
+@pytest.mark.parametrize("ngram,blank,route", [(1, "optional", "lattice"), (2, "none", "lattice"), (2, "optional", "lattice"),
+                                               (2, "none", "dense"), (2, "optional", "dense")])
+def test_transducer_dense_ngram_transitions(crit, ngram, blank, route, monkeypatch):
+    """30 tokens: the n-gram transition graph has 30-way in-degree.  route "lattice": above the threshold at which a
+    whole wavefront relaxes a state (lattice engine, general path); route "dense" (the default for ngram = 2): the
+    normaliser forward_score(intersect(emissions, transitions)) (transducer.py:286-288) through the dense transition
+    engine, start / bigram / end-arc parameters mapped to its W and back.  Loss, emission gradient,
+    transition-parameter gradient (random non-zero parameters, end arcs included) and Viterbi against the graph oracle"""
     tr = crit["transducer"]
+    monkeypatch.setattr(tr, "_DENSE_NGRAM", route == "dense")
     ntok = 30
     tokens = [(i,) for i in range(ntok)]
     g2i = {i: i for i in range(ntok)}
@@ -1042,6 +1046,7 @@ def test_transducer_dense_ngram_transitions_use_the_cooperative_relaxation(crit,
     x = rs.randn(B, T, C).astype(np.float32)
     targets = [rs.randint(0, ntok, size=5).tolist(), rs.randint(0, ntok, size=3).tolist()]
     m = tr.Transducer(tokens, g2i, **kw)
+    assert tr._dense_bigram(m.transitions, C) == (ngram == 2)
     params = (0.3 * rs.randn(m.transition_params.numel())).astype(np.float32)
     with torch.no_grad():
         m.transition_params.copy_(torch.from_numpy(params))
