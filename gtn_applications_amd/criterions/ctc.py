@@ -6,6 +6,8 @@ on host threads (ctc.py:38-65), this sends the whole batch through the CTC fast-
 (csrc/ctc_kernels.hip; up to four target positions per lane) -- or, for targets longer than 255
 labels, through the generic lattice engine (csrc/lattice_kernels.hip).  Both are HIP paths; there is no CPU path.
 """
+import os
+
 import torch
 
 from .. import engine as E
@@ -120,6 +122,27 @@ class _FusedLogSoftmaxCTCLoss(CTCLossFunction):
         return CTCLossFunction.forward(ctx, inputs, targets, blank_idx, reduction)
 
 
+class _EagerLoss(torch.Tensor):
+    """The scalar the C++ CTC node returns.  A plain tensor in every respect (no __torch_function__ dispatch) but one:
+    `loss.backward()` with no arguments -- the call of ctc_benchmark.py:29-31 and of every training loop that uses the
+    criterion's output as its loss -- hands the gradient the forward launch already computed to the emissions' .grad
+    without a trip through the autograd engine (csrc/torch_ops.cpp ctc_fast_backward: the engine's two thread
+    hand-overs, the ones_like fill and the scale launch cost more host time than the step's kernels take).  Anything
+    else -- a gradient argument, retain_graph, create_graph, inputs=, hooks on the emissions, non-leaf emissions,
+    anomaly mode, or the loss used inside a larger expression -- goes through torch.Tensor.backward / the engine."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        if (gradient is None and not retain_graph and not create_graph and inputs is None and _FAST_BACKWARD
+                and not torch.is_anomaly_enabled() and _native_node().ctc_fast_backward(self)):
+            return None
+        return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
+
+
+_FAST_BACKWARD = os.environ.get("WFL_CTC_FAST_BACKWARD", "1") != "0"  # (0: always the autograd engine -- A/B, tests)
+
+
 def _native_node():
     """The C++ autograd node of the pipelined step (csrc/torch_ops.cpp), or None if the extension was not built."""
     global _NODE
@@ -160,6 +183,7 @@ def _ctc_loss(log_probs, targets, blank_idx, reduction, fused_log_softmax):
                 loss = node.ctc_loss_staged(log_probs, st, *lim)
                 E._done(tok)
             if loss is not None:
+                loss.__class__ = _EagerLoss
                 return loss
         tg = E.targets_on_device(targets, dev)
         if E.ctc_fast_path_ok(tg.max_len, C):

@@ -7,6 +7,7 @@
 // calls the C ABI of libwfl.so (include/wfl.h) directly.  Host-side plumbing only: no arithmetic happens here.
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
+#include <torch/csrc/autograd/functions/accumulate_grad.h>
 #include <torch/csrc/autograd/python_variable.h>
 #include <torch/extension.h>
 
@@ -61,6 +62,10 @@ struct CtcStep : public torch::autograd::Function<CtcStep> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    TORCH_CHECK(ctx->saved_data.find("freed") == ctx->saved_data.end(),
+                "Trying to backward through the graph a second time (or directly access saved tensors after they have "
+                "already been freed). Saved intermediate values of the graph are freed when you call .backward() or "
+                "autograd.grad(). Specify retain_graph=True if you need to backward through the graph a second time.");
     at::Tensor x = ctx->saved_data["x"].toTensor();
     if (!grads[0].defined())  // (the loss did not take part in what is being differentiated)
       return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
@@ -342,9 +347,48 @@ at::Tensor ctc_step(const at::Tensor& x, const at::Tensor& staged, int64_t off_o
   return CtcStep::apply(x, staged, off_offsets, off_flat, off_scale, off_coef, max_len, blank, ws, nll, lse);
 }
 
+// `loss.backward()` for the loss a CtcStep node returned, WITHOUT the autograd engine: the gradient was computed by
+// the forward launch (for an upstream gradient of one, which is what a bare .backward() on a scalar means), so all
+// that is left is what AccumulateGrad would do -- hand dx to the leaf's .grad (or add it).  The engine's version of
+// this costs two thread hand-overs (CUDA nodes run on the engine's device thread), a ones_like fill and the scale
+// launch: 40-60 us of host time per step where the step's kernels take 45.  Returns false -- the caller then takes
+// the ordinary torch.Tensor.backward -- whenever anything is not exactly the plain case: the loss is not a fresh
+// CtcStep output, the emissions are not a leaf, hooks are registered on them, the gradient buffer has been handed
+// out already.  Same results, same .grad semantics (first gradient: the buffer itself; later ones: added in place),
+// same error on a second backward.
+bool ctc_fast_backward(const at::Tensor& loss) {
+  auto fn = loss.grad_fn();
+  auto* node = dynamic_cast<torch::autograd::CppNode<CtcStep>*>(fn.get());
+  if (!node || loss.dim() != 0) return false;
+  if (!fn->pre_hooks().empty() || !fn->post_hooks().empty() || !fn->tensor_pre_hooks().empty()) return false;
+  const auto& edge = fn->next_edge(0);
+  auto* acc = dynamic_cast<torch::autograd::AccumulateGrad*>(edge.function.get());
+  if (!acc || !acc->pre_hooks().empty() || !acc->post_hooks().empty()) return false;
+  at::Tensor x = acc->variable;
+  if (!x.defined() || !x.requires_grad()) return false;
+  auto* meta = torch::autograd::impl::get_autograd_meta(x);
+  if (!meta || !meta->hooks_.empty() || meta->cpp_hooks_list_ || meta->post_acc_grad_hooks_) return false;
+  auto& saved = node->ctx_.saved_data;
+  if (saved.find("freed") != saved.end()) return false;  // (the ordinary path raises torch's error)
+  auto it = saved.find("dx");
+  if (it == saved.end() || !it->second.isTensor() || !it->second.toTensor().defined()) return false;
+  at::Tensor dx = it->second.toTensor();
+  saved.clear();  // what the engine's release of the graph does
+  saved["freed"] = true;
+  at::NoGradGuard no_grad;
+  at::Tensor& grad = x.mutable_grad();
+  if (!grad.defined())
+    grad = std::move(dx);
+  else
+    grad.add_(dx);
+  return true;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("ctc_fast_backward", &ctc_fast_backward,
+        "loss.backward() of a CtcStep loss without the autograd engine (false: not the plain case, use the engine)");
   m.def("ctc_step", &ctc_step, "CTC loss + eager gradient in one pipelined launch (C++ autograd node)");
   py::class_<StagedTargets, std::shared_ptr<StagedTargets>>(m, "StagedTargets")
       .def_readonly("B", &StagedTargets::B)

@@ -1354,3 +1354,52 @@ def test_ctc_pipelined_step_keeps_its_forward_progress_under_cu_contention():
     busy_during = not side.query()
     torch.cuda.synchronize()
     assert busy_during, "the competing stream did not outlast the steps: the test did not exercise contention"
+
+
+def test_ctc_loss_backward_without_the_engine_equals_the_engine(monkeypatch):
+    """`CTCLoss(x, targets, blank).backward()` on leaf emissions takes csrc/torch_ops.cpp's ctc_fast_backward (the gradient
+    of the forward launch handed to x.grad, no autograd engine); everything else takes the engine.  Same numbers bit
+    for bit, same .grad semantics: first gradient assigned, later ones added; a second backward raises; retain_graph,
+    a gradient argument, hooks on the emissions and non-leaf emissions all go through the engine and agree."""
+    from gtn_applications_amd.criterions import ctc
+
+    g = torch.Generator().manual_seed(11)
+    B, T, C, L = 16, 120, 40, 9
+    x = torch.randn(B, T, C, generator=g)
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+
+    def grad(fast, how="plain"):
+        monkeypatch.setattr(ctc, "_FAST_BACKWARD", fast)
+        xg = x.cuda().requires_grad_(True)
+        if how == "nonleaf":
+            loss = ctc.CTCLoss(xg * 1.0, targets, C - 1)
+        else:
+            loss = ctc.CTCLoss(xg, targets, C - 1)
+        assert type(loss) is ctc._EagerLoss and loss.dim() == 0
+        if how == "hook":
+            seen = []
+            xg.register_hook(lambda gr: seen.append(1))
+        if how == "retain":
+            loss.backward(retain_graph=True)
+        elif how == "gradient":
+            loss.backward(torch.ones_like(loss))
+        else:
+            loss.backward()
+        if how == "hook":
+            assert seen == [1]
+        return xg, loss
+
+    want, _ = grad(False)
+    for how in ("plain", "retain", "gradient", "hook", "nonleaf"):
+        got, loss = grad(True, how)
+        assert torch.equal(got.grad, want.grad), how
+        if how == "plain":
+            with pytest.raises(RuntimeError, match="second time"):
+                loss.backward()
+            # accumulation: a second step on the same leaf adds
+            ctc.CTCLoss(got, targets, C - 1).backward()
+            torch.testing.assert_close(got.grad, 2 * want.grad)
+            # the loss is an ordinary tensor in expressions: the engine handles (2 * loss).backward()
+            got.grad = None
+            (2.0 * ctc.CTCLoss(got, targets, C - 1)).backward()
+            torch.testing.assert_close(got.grad, 2 * want.grad)
