@@ -1,30 +1,42 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): scripts/collect_round.sh <tag>
 # Everything profiles/ quotes for a round, under gpurun_out/<tag>/:
-#   <cfg>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py <cfg args> --targets same`
+#   <cfg>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py --config <cfg>` (the operator path,
+#                            same targets every step: the reference benchmarks' protocol)
 #   pmc_<cfg>_{FETCH,WRITE}_SIZE.csv -> pmc_traffic.json (scripts/pmc_traffic.py; separate --pmc passes)
-#   bench_lines.jsonl        the default bench.py line of every configuration (operator path; `fresh_targets` beside it)
+#   bench_lines.jsonl        the default bench.py line of every configuration (+ cfg2 through the C ABI, B = 1024)
+#   ngram_lines.txt          benchmarks/transducer_benchmark.py (N = 81, T = 250, L = 44, n-gram 0 / 1 / 2), bigram
+#                            normaliser on the dense engine and, for comparison, on the general lattice sweep
+#   ngram_kernel_stats.csv   rocprofv3 kernel stats of the same script (B = 16)
+#   asg_wide_line.json       ASG with 1000 classes (csrc/dense_wide.h): python bench.py --workload asg --C 1000 --B 32 --T 250
 tag=${1:-r}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp
 cd "$R"; rm -rf "$O"; mkdir -p "$O"
-declare -A ARGS=( [cfg2]="--workload ctc" [cfg3]="--workload asg" [cfg4]="--workload transducer" [cfg5_shard]="--workload ctc --T 2000 --C 512" )
-for cfg in cfg2 cfg3 cfg4 cfg5_shard; do
-  a=${ARGS[$cfg]}
+for cfg in cfg2 cfg3 cfg4 cfg5; do
   steps=50; [ $cfg = cfg2 ] || steps=20
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$cfg -- python bench.py $a --steps $steps --warmup 5 --no-cpu-baseline --no-extras --targets same > $O/stats_$cfg.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$cfg -- python bench.py --config $cfg --steps $steps --warmup 5 --no-cpu-baseline --no-extras > $O/stats_$cfg.log 2>&1
   cp $(find $O/stats_$cfg -name "*kernel_stats.csv" | head -1) $O/${cfg}_kernel_stats.csv
   rm -rf $O/stats_$cfg
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${cfg}_$c -- python bench.py $a --steps 10 --warmup 2 --no-cpu-baseline --no-extras --targets same > $O/pmc_${cfg}_$c.log 2>&1
+    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${cfg}_$c -- python bench.py --config $cfg --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_${cfg}_$c.log 2>&1
     cp $(find $O/pmc_${cfg}_$c -name "*counter_collection.csv" | head -1) $O/pmc_${cfg}_$c.csv
     rm -rf $O/pmc_${cfg}_$c
   done
 done
 python scripts/pmc_traffic.py $O > $O/pmc_traffic.json
-for cfg in cfg2 cfg3 cfg4 cfg5_shard; do
-  python bench.py ${ARGS[$cfg]} --steps 20 --warmup 5 2>/dev/null | tail -1 >> $O/bench_lines.jsonl
+for cfg in cfg2 cfg3 cfg4 cfg5; do
+  python bench.py --config $cfg --steps 30 --warmup 5 2>/dev/null | tail -1 >> $O/bench_lines.jsonl
 done
+python bench.py --config cfg2 --mode abi --B 1024 --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 >> $O/bench_lines.jsonl
+python bench.py --workload asg --C 1000 --B 32 --T 250 --steps 5 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/asg_wide_line.json
+for n in 1 0; do
+  echo "== WFL_DENSE_NGRAM=$n (B=16)" >> $O/ngram_lines.txt
+  WFL_DENSE_NGRAM=$n timeout 600 python benchmarks/transducer_benchmark.py 16 2>/dev/null | grep -i "ngram" >> $O/ngram_lines.txt
+done
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ngram -- python benchmarks/transducer_benchmark.py 16 > $O/stats_ngram.log 2>&1
+cp $(find $O/stats_ngram -name "*kernel_stats.csv" | head -1) $O/ngram_kernel_stats.csv
+rm -rf $O/stats_ngram
 python scripts/kstats.py $O
 rm -f $O/pmc_*_SIZE.csv.bak
