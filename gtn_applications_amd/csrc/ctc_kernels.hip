@@ -2426,12 +2426,38 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     const char* e = getenv("WFL_CTC_MITM");
     return e ? atoi(e) : 1;
   }();
-  const size_t mitm_lds = ((sizeof(MitmLds) + 15) & ~(size_t)15) + (size_t)kMEmitters * kBlk * kMTile * 4;
-  static_assert(((sizeof(MitmLds) + 15) & ~(size_t)15) + (size_t)kMEmitters * kBlk * kMTile * 4 <= (size_t)kLdsBytes, "ctc_mitm.h: LDS");
+  // two workgroup shapes (ctc_mitm.h): 16 waves, one workgroup per CU, while the batch has no more sweeps than the chip
+  // has CUs; 8 waves, two per CU, beyond
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static const int shape_env = [] {
+    const char* e = getenv("WFL_CTC_MITM_WAVES");  // 8 / 16: force a shape (measurements)
+    return e ? atoi(e) : 0;
+  }();
+  const bool small_wg = shape_env ? shape_env == 8 : 2 * (int64_t)B > cus;
+  auto mitm_lds_of = [](auto k) {
+    using K = decltype(k);
+    return ((sizeof(MitmLds<K>) + 15) & ~(size_t)15) + (size_t)K::kEmitters * kBlk * kMTile * 4;
+  };
+  static_assert(((sizeof(MitmLds<MitmK<16>>) + 15) & ~(size_t)15) + (size_t)MitmK<16>::kEmitters * kBlk * kMTile * 4 <= (size_t)kLdsBytes,
+                "ctc_mitm.h: LDS of the 16-wave shape");
+  static_assert(2 * (((sizeof(MitmLds<MitmK<8>>) + 15) & ~(size_t)15) + (size_t)MitmK<8>::kEmitters * kBlk * kMTile * 4) <= (size_t)kLdsBytes,
+                "ctc_mitm.h: two 8-wave workgroups per CU");
   if (ppl == 1 && !force_log && mitm_env && !row_lse && C <= kMTile) {
-    WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)ctc_mitm_kernel<false>, (int)mitm_lds));
-    hipLaunchKernelGGL(ctc_mitm_kernel<false>, dim3((unsigned)(2 * B)), dim3(kMWaves * 64), mitm_lds, (hipStream_t)stream, a,
-                       coef, gout, dx);
+    if (small_wg) {
+      const size_t lds = mitm_lds_of(MitmK<8>{});
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)ctc_mitm_kernel<MitmK<8>, false>, (int)lds));
+      hipLaunchKernelGGL((ctc_mitm_kernel<MitmK<8>, false>), dim3((unsigned)(2 * B)), dim3(MitmK<8>::kWaves * 64), lds,
+                         (hipStream_t)stream, a, coef, gout, dx);
+    } else {
+      const size_t lds = mitm_lds_of(MitmK<16>{});
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)ctc_mitm_kernel<MitmK<16>, false>, (int)lds));
+      hipLaunchKernelGGL((ctc_mitm_kernel<MitmK<16>, false>), dim3((unsigned)(2 * B)), dim3(MitmK<16>::kWaves * 64), lds,
+                         (hipStream_t)stream, a, coef, gout, dx);
+    }
     WFL_LAUNCH_CHECK();
     a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
     if (a.token == 0) a.token = 1;

@@ -46,84 +46,78 @@
 #define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
 #endif
 
-#ifndef WFL_MITM_CFG
-#define WFL_MITM_CFG 1  // wave roles: 1 = 4 stagers + 9 emitters (default), 0 = 6 stagers + 7 emitters.  An emitter is
-                        // latency-bound (one block is ~7000 cycles of dependent DPP / LDS work on a shared SIMD), so the
-                        // second half goes at the pace of emitters x blocks per emitter: cfg2 42.0 -> 40.1 us; 3 + 10 with
-                        // an 8-slot ring: 41.4 us (the stagers no longer cover the HBM latency)
-#endif
-#if WFL_MITM_CFG == 1
-constexpr int kMSlots = 9;
-constexpr int kMPSlots = 6;
-constexpr int kMStagers = 4;
-constexpr int kMEmitters = 9;
-#else
-constexpr int kMSlots = 10;    // LDS ring depth in blocks: factors, references, own checkpoints
-constexpr int kMPSlots = 8;    // partner checkpoints handed from the fetcher to the emitters
-constexpr int kMStagers = 6;
-constexpr int kMEmitters = 7;
-#endif
-constexpr int kMWaves = 16;
 constexpr int kMSpin = 1 << 24;
 constexpr int kMTile = 128;   // floats per row of an emitter's gradient tile (a compile-time stride: the 16 rows of a label's
                               // column are one LDS address + immediate offsets); the step takes C <= kMTile
 
-// role of a wave: 0 chain, 1 stager, 2 flusher, 3 fetcher, 4 emitter; index within the role
-__device__ __forceinline__ void mitm_role(int wave, int& role, int& idx) {
-  // (a switch on a scalar: compiled to scalar compares)
-#if WFL_MITM_CFG == 1
-  switch (wave) {
-    case 0: role = 0, idx = 0; break;
-    case 4: role = 2, idx = 0; break;
-    case 8: role = 3, idx = 0; break;
-    case 12: role = 4, idx = 8; break;
-    case 1: role = 1, idx = 0; break;
-    case 2: role = 1, idx = 1; break;
-    case 3: role = 1, idx = 2; break;
-    case 5: role = 1, idx = 3; break;
-    case 6: role = 4, idx = 0; break;
-    case 7: role = 4, idx = 1; break;
-    case 9: role = 4, idx = 2; break;
-    case 10: role = 4, idx = 3; break;
-    case 11: role = 4, idx = 4; break;
-    case 13: role = 4, idx = 5; break;
-    case 14: role = 4, idx = 6; break;
-    default: role = 4, idx = 7; break;
+// Workgroup shapes.  role of a wave: 0 chain, 1 stager, 2 flusher, 3 fetcher, 4 emitter; index within the role.  Waves
+// are placed round-robin on the four SIMDs (wave w: SIMD w % 4).
+//   MitmK<16>  one workgroup per CU (2 B <= CUs: the BASELINE shape).  4 stagers + 9 emitters: an emitter is latency-bound
+//              (one block is ~7000 cycles of dependent DPP / LDS work on a shared SIMD), so the second half goes at the pace
+//              of emitters x blocks per emitter -- cfg2 42.0 us with 6 + 7, 40.1 with 4 + 9, 41.4 with 3 + 10 and an 8-slot
+//              ring (the stagers no longer cover the HBM latency).  The chain wave shares its SIMD with the two light
+//              waves and one emitter (a stager there slows the chain, and falls behind itself).
+//   MitmK<8>   two workgroups per CU (half the waves, half the LDS) for batches with more sweeps than CUs: every wave of
+//              the step is latency-bound, so two chains per CU use the vector pipes the single chain leaves idle.
+template <int WAVES>
+struct MitmK;
+template <>
+struct MitmK<16> {
+  static constexpr int kSlots = 9;    // LDS ring depth in blocks: factors, references, own checkpoints
+  static constexpr int kPSlots = 6;   // partner checkpoints handed from the fetcher to the emitters
+  static constexpr int kStagers = 4, kEmitters = 9, kWaves = 16;
+  __device__ static __forceinline__ void role(int wave, int& role, int& idx) {
+    switch (wave) {  // (a switch on a scalar: compiled to scalar compares)
+      case 0: role = 0, idx = 0; break;
+      case 4: role = 2, idx = 0; break;
+      case 8: role = 3, idx = 0; break;
+      case 12: role = 4, idx = 8; break;
+      case 1: role = 1, idx = 0; break;
+      case 2: role = 1, idx = 1; break;
+      case 3: role = 1, idx = 2; break;
+      case 5: role = 1, idx = 3; break;
+      case 6: role = 4, idx = 0; break;
+      case 7: role = 4, idx = 1; break;
+      case 9: role = 4, idx = 2; break;
+      case 10: role = 4, idx = 3; break;
+      case 11: role = 4, idx = 4; break;
+      case 13: role = 4, idx = 5; break;
+      case 14: role = 4, idx = 6; break;
+      default: role = 4, idx = 7; break;
+    }
   }
-  return;
-#endif
-  switch (wave) {  // SIMD of wave w: class w % 4
-    case 0: role = 0, idx = 0; break;
-    case 4: role = 2, idx = 0; break;   // the chain wave's SIMD (0, 4, 8, 12): light waves there do not slow the chain
-    case 8: role = 3, idx = 0; break;   // (measured; a stager there does, and falls behind itself)
-    case 12: role = 4, idx = 6; break;
-    case 1: role = 1, idx = 0; break;   // two stagers and two emitters on each of the other SIMDs
-    case 2: role = 1, idx = 1; break;
-    case 3: role = 1, idx = 2; break;
-    case 5: role = 1, idx = 3; break;
-    case 6: role = 1, idx = 4; break;
-    case 7: role = 1, idx = 5; break;
-    case 9: role = 4, idx = 0; break;
-    case 10: role = 4, idx = 1; break;
-    case 11: role = 4, idx = 2; break;
-    case 13: role = 4, idx = 3; break;
-    case 14: role = 4, idx = 4; break;
-    default: role = 4, idx = 5; break;
+};
+template <>
+struct MitmK<8> {
+  static constexpr int kSlots = 5, kPSlots = 3;
+  static constexpr int kStagers = 2, kEmitters = 3, kWaves = 8;
+  __device__ static __forceinline__ void role(int wave, int& role, int& idx) {
+    switch (wave) {
+      case 0: role = 0, idx = 0; break;
+      case 4: role = 2, idx = 0; break;
+      case 1: role = 3, idx = 0; break;
+      case 2: role = 1, idx = 0; break;
+      case 3: role = 1, idx = 1; break;
+      case 5: role = 4, idx = 0; break;
+      case 6: role = 4, idx = 1; break;
+      default: role = 4, idx = 2; break;
+    }
   }
-}
+};
 
+template <class K>
 struct MitmLds {
-  float2 ring[kMSlots][kBlk][64];  // (fb, fl) per frame and lane: 80 KiB
-  float4 pck[kMPSlots][64];        // partner state after the block, own lane order: (bb, bl, eb bits, -)
-  float4 ck[kMSlots][64];          // own state before block n: (blank mantissa, label mantissa, lane exponent bits, -)
-  float fref[kMSlots][kBlk];       // per-frame references r_t (integer valued; 0 past the block's frames)
-  double offc[kMSlots];            // sum of the references of all blocks before n
-  double poff[kMPSlots];           // the partner's sum before its checkpoint
+  float2 ring[K::kSlots][kBlk][64];  // (fb, fl) per frame and lane: 80 KiB
+  float4 pck[K::kPSlots][64];        // partner state after the block, own lane order: (bb, bl, eb bits, -)
+  float4 ck[K::kSlots][64];          // own state before block n: (blank mantissa, label mantissa, lane exponent bits, -)
+  float fref[K::kSlots][kBlk];       // per-frame references r_t (integer valued; 0 past the block's frames)
+  double offc[K::kSlots];            // sum of the references of all blocks before n
+  double poff[K::kPSlots];           // the partner's sum before its checkpoint
   double offtot;
-  int staged[kMSlots];             // == n + 1 once block n sits in slot n % kMSlots
-  int pready[kMPSlots];            // == n + 1 once the partner checkpoint for block n sits in slot n % kMPSlots
-  int egrab[kMSlots];              // == n + 1 once an emitter holds block n's factors and own checkpoint in registers
-  int pgrab[kMPSlots];             // == n + 1 once an emitter holds the partner checkpoint for block n
+  int staged[K::kSlots];             // == n + 1 once block n sits in slot n % K::kSlots
+  int pready[K::kPSlots];            // == n + 1 once the partner checkpoint for block n sits in slot n % K::kPSlots
+  int egrab[K::kSlots];              // == n + 1 once an emitter holds block n's factors and own checkpoint in registers
+  int pgrab[K::kPSlots];             // == n + 1 once an emitter holds the partner checkpoint for block n
   double zref;                     // log2 Z as the sweep's first emitted block reproduced it (every later block normalises by it)
   int zready;
   int enext;                       // next block to emit: the emitters take blocks as they become free (a static round robin
@@ -161,9 +155,9 @@ typedef float mv2f __attribute__((ext_vector_type(2)));
 //                                  factor of the scaled recursion is 2^(ea[i] - ea[i+1]) (bounded by the chain's clamp)
 //   posterior_j(s) = own_j(s) [A part_{j+1}](s)   -- one packed multiply per frame and lane pair
 // DIR: tile row of frame j (the reversed sweep only emits complete blocks, FULL).
-template <int DIR, bool FULL>
+template <class K, int DIR, bool FULL>
 __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f sa, int ea, float4 pk, float rsum, double off_sum,
-                                                    MitmLds& S, bool first,
+                                                    MitmLds<K>& S, bool first,
                                                     int cnt, float cf, float g, float gs, bool skipn, bool owner, bool adder,
                                                     int lane, float* rows, int ycol, int blank, int C, long long* zmm,
                                                     float* __restrict__ dst, long long* st_part) {
@@ -193,13 +187,13 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     st_part[0] += now - st_e0;
   }
 #endif
-  // ---- K(s) = cf 2^(ea + eb) / Z in the block's units.  The emitter's FIRST block reproduces Z itself -- sum_s own(s)
+  // ---- Kn(s) = cf 2^(ea + eb) / Z in the block's units.  The emitter's FIRST block reproduces Z itself -- sum_s own(s)
   // [A partner](s) at its last frame, the certificate's identity -- and folds its log2 Z into the utterance's min / max
   // for the comparison with the chain's; its later blocks reuse that log2 Z (Z is one number; the blocks only differ in
   // their offsets, integer-valued doubles): no prefix maximum, no wave sum, no reciprocal.  They are still certified:
   // their posteriors must sum to one per frame, which compares their own sum_s alpha beta with the reference to 2e-4.
   float bb = pk.x, bl = pk.y;
-  float K = 0.f;
+  float Kn = 0.f;
   bool alive;
   double zk = -1.0e300;  // (lane 0) log2 Z as this block reproduces it
   const int sx = ea + eb;
@@ -216,7 +210,7 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     const float term = v > 0.f ? ldexpf(v, max(sx - E, -200)) : 0.f;
     const float Zm = wave_all_sum(term);
     alive = Zm > 0.f && Zm < 3.0e38f && E > kEmptyE;
-    if (alive) K = cf * ldexpf(__builtin_amdgcn_rcpf(Zm), min(max(sx - E, -200), 100));  // (v_rcp_f32: 1 ulp)
+    if (alive) Kn = cf * ldexpf(__builtin_amdgcn_rcpf(Zm), min(max(sx - E, -200), 100));  // (v_rcp_f32: 1 ulp)
     zk = alive ? off_sum + (double)E + (double)__builtin_amdgcn_logf(Zm) + (double)rsum : -1.0e300;
     if (lane == 0) S.zref = zk;
     lds_post(&S.zready, 1);
@@ -239,14 +233,14 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
       const double D = off_sum + (double)rsum - zref;  // = -(E + log2 Zm) of this block
       const double Di = floor(D);
       const float frac = __builtin_amdgcn_exp2f((float)(D - Di));
-      K = cf * frac * ldexpf(1.f, min(max(sx + (int)Di, -200), 100));
+      Kn = cf * frac * ldexpf(1.f, min(max(sx + (int)Di, -200), 100));
     }
   }
 #if WFL_MITM_STATS
-  st_part[2] += __builtin_amdgcn_readfirstlane(__float_as_int(K)) * 0 + clock64() - st_e0;
+  st_part[2] += __builtin_amdgcn_readfirstlane(__float_as_int(Kn)) * 0 + clock64() - st_e0;
 #endif
-  // ---- partner sweep backwards through the block (scaled by K), posteriors
-  bb *= K, bl *= K;
+  // ---- partner sweep backwards through the block (scaled by Kn), posteriors
+  bb *= Kn, bl *= Kn;
   const int ea_next = __builtin_amdgcn_update_dpp(ea, ea, 0x130, 0xf, 0xf, false);
   const float hk = lane == 63 ? 0.f : ldexpf(1.f, min(max(ea - ea_next, -200), 100));
   const float hks = skipn ? hk : 0.f;
@@ -349,14 +343,14 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
   }
 }
 
-template <bool LSM, int DIR>
-__device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, int b, int em, int H0, int NB, int L, int y,
+template <class K, bool LSM, int DIR>
+__device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S, int b, int em, int H0, int NB, int L, int y,
                                                  bool skip, bool skipn, bool has_label, const float* __restrict__ coef,
                                                  const float* __restrict__ gout, float* __restrict__ dx, char* smem,
                                                  const CtcWs& w) {
   const int lane = threadIdx.x & 63;
   const int T = a.T, C = a.C;
-  float* rows = (float*)(smem + ((sizeof(MitmLds) + 15) & ~(size_t)15)) + (size_t)em * kBlk * kMTile;
+  float* rows = (float*)(smem + ((sizeof(MitmLds<K>) + 15) & ~(size_t)15)) + (size_t)em * kBlk * kMTile;
   for (int i = lane; i < kBlk * kMTile; i += 64) rows[i] = 0.f;
   // Labels that occur once in the target own their gradient column: plain ds_write.  A repeated label's first
   // occurrence owns the column, the others add to it afterwards; a target label equal to the blank index adds to
@@ -388,7 +382,7 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
     if (n >= NB) break;
     const int k = DIR == 0 ? n : NB - 1 - n;
     const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
-    const int slot = n % kMSlots, ps = n % kMPSlots;
+    const int slot = n % K::kSlots, ps = n % K::kPSlots;
     {
       int spin = 0;
       MITM_T0();
@@ -434,31 +428,31 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds& S, i
       continue;
     }
     if (cnt == kBlk)
-      ctc_mitm_emit_block<DIR, true>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+      ctc_mitm_emit_block<K, DIR, true>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
                                      ycol, a.blank, C, zmm, dst, st_part);
     else if (DIR == 0)
-      ctc_mitm_emit_block<0, false>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+      ctc_mitm_emit_block<K, 0, false>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
                                     ycol, a.blank, C, zmm, dst, st_part);
     MITM_ACC(st_wait2);
   }
 #if WFL_MITM_STATS
   if (lane == 0) {
     const int wave = threadIdx.x >> 6;
-    long long* d = (long long*)(a.ws + w.dbg) + ((int64_t)(b * 2 + DIR) * kMWaves + wave) * 8;
+    long long* d = (long long*)(a.ws + w.dbg) + ((int64_t)(b * 2 + DIR) * K::kWaves + wave) * 8;
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     d[0] = clock64() - st_begin, d[1] = st_wait0, d[2] = st_wait1, d[3] = st_wait2, d[4] = st_part[0], d[5] = hw;
     d[6] = wall_clock64(), d[7] = st_part[1];
-    long long* x = (long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B + (int64_t)(b * 2 + DIR) * 256 + 128 + em * 8;
+    long long* x = (long long*)(a.ws + w.dbg) + 2 * 8 * K::kWaves * (int64_t)a.B + (int64_t)(b * 2 + DIR) * 256 + 128 + em * 8;
     for (int q = 0; q < 6; ++q) x[q] = st_part[q];
   }
 #endif
 }
 
-template <bool LSM>
+template <class K, bool LSM>
 __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, const float* __restrict__ coef,
                                               const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
-  MitmLds& S = *reinterpret_cast<MitmLds*>(smem);
+  MitmLds<K>& S = *reinterpret_cast<MitmLds<K>*>(smem);
 #if WFL_MITM_STATS
   const long long st_wall0 = wall_clock64();
 #endif
@@ -478,10 +472,10 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   const int NB = ctc_blocks(T);
   const int H0 = mitm_first_emitted(NB, dir);  // blocks n < H0 are published, blocks n >= H0 emitted
-  if (threadIdx.x < kMSlots) S.staged[threadIdx.x] = 0;
-  if (threadIdx.x < kMPSlots) S.pready[threadIdx.x] = 0;
-  if (threadIdx.x < kMSlots) S.egrab[threadIdx.x] = 0;
-  if (threadIdx.x < kMPSlots) S.pgrab[threadIdx.x] = 0;
+  if (threadIdx.x < K::kSlots) S.staged[threadIdx.x] = 0;
+  if (threadIdx.x < K::kPSlots) S.pready[threadIdx.x] = 0;
+  if (threadIdx.x < K::kSlots) S.egrab[threadIdx.x] = 0;
+  if (threadIdx.x < K::kPSlots) S.pgrab[threadIdx.x] = 0;
   if (threadIdx.x == 0) S.enext = mitm_first_emitted(ctc_blocks(a.T), dir), S.zready = 0;
   if (threadIdx.x == 0) S.chainpos = 0, S.ckdone = 0, S.offdone = 0;
 #if WFL_MITM_STATS
@@ -489,14 +483,14 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
 #endif
   __syncthreads();
   int role, ridx;
-  mitm_role(wave, role, ridx);
+  K::role(wave, role, ridx);
   if (role == 5) return;  // (a wave that has ended no longer counts for anything: no barrier after the first)
 #if WFL_MITM_STATS
   long long st_wait0 = 0, st_wait1 = 0, st_wait2 = 0, st_polls = 0;
   const long long st_begin = clock64();
   auto stats_out = [&]() {
     if (lane == 0) {
-      long long* d = (long long*)(a.ws + w.dbg) + ((int64_t)(b * 2 + dir) * kMWaves + wave) * 8;
+      long long* d = (long long*)(a.ws + w.dbg) + ((int64_t)(b * 2 + dir) * K::kWaves + wave) * 8;
       unsigned hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       unsigned xcc;
@@ -514,8 +508,8 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     __builtin_trap();
   };
   // has emitter-owned block m (m >= H0) been taken into registers?
-  auto grabbed = [&](int m) { return lds_peek(&S.egrab[m % kMSlots]) == m + 1; };
-  auto pgrabbed = [&](int m) { return lds_peek(&S.pgrab[m % kMPSlots]) == m + 1; };
+  auto grabbed = [&](int m) { return lds_peek(&S.egrab[m % K::kSlots]) == m + 1; };
+  auto pgrabbed = [&](int m) { return lds_peek(&S.pgrab[m % K::kPSlots]) == m + 1; };
 
   if (role == 1) {
     // ================================================================ stagers
@@ -542,7 +536,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     auto stage = [&](int n, const float (&raw)[kBlk], float lse_blk) {
       const int k = dir == 0 ? n : NB - 1 - n;
       const int cnt = min(kBlk, T - k * kBlk);
-      const int slot = n % kMSlots;
+      const int slot = n % K::kSlots;
       if ((WFL_MITM_ABL & 16) && n >= H0) {  // (scratch: what a second half fed with ready-made factors would cost)
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) S.ring[slot][j][lane] = make_float2(has_blank ? 0.7f : 0.f, has_label ? 0.7f + 0.001f * raw[j] : 0.f);
@@ -568,8 +562,8 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       if (lane < kBlk) S.fref[slot][lane] = lane < cnt ? rr : 0.f;
     };
     auto wait_slot = [&](int n) {
-      if (n < kMSlots) return;
-      const int m = n - kMSlots;  // the block that held the slot
+      if (n < K::kSlots) return;
+      const int m = n - K::kSlots;  // the block that held the slot
       int spin = 0;
       MITM_T0();
       while (lds_peek(&S.chainpos) < m + 1 || lds_peek(&S.ckdone) < m + 1 || (m >= H0 && !grabbed(m))) {
@@ -585,17 +579,17 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     float ra[kBlk], rb[kBlk];
     float la = 0.f, lb = 0.f;
     if (h < NB) issue(h, ra), issue_lse(h), la = lse_raw;
-    if (h + kMStagers < NB) issue(h + kMStagers, rb), issue_lse(h + kMStagers), lb = lse_raw;
-    for (int n = h; n < NB; n += 2 * kMStagers) {
+    if (h + K::kStagers < NB) issue(h + K::kStagers, rb), issue_lse(h + K::kStagers), lb = lse_raw;
+    for (int n = h; n < NB; n += 2 * K::kStagers) {
       wait_slot(n);
       {
         MITM_T0();
         stage(n, ra, la);
         MITM_ACC(st_wait1);
       }
-      lds_post(&S.staged[n % kMSlots], n + 1);
-      if (n + 2 * kMStagers < NB) issue(n + 2 * kMStagers, ra), issue_lse(n + 2 * kMStagers), la = lse_raw;
-      const int n2 = n + kMStagers;
+      lds_post(&S.staged[n % K::kSlots], n + 1);
+      if (n + 2 * K::kStagers < NB) issue(n + 2 * K::kStagers, ra), issue_lse(n + 2 * K::kStagers), la = lse_raw;
+      const int n2 = n + K::kStagers;
       if (n2 < NB) {
         wait_slot(n2);
         {
@@ -603,8 +597,8 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
           stage(n2, rb, lb);
           MITM_ACC(st_wait1);
         }
-        lds_post(&S.staged[n2 % kMSlots], n2 + 1);
-        if (n2 + 2 * kMStagers < NB) issue(n2 + 2 * kMStagers, rb), issue_lse(n2 + 2 * kMStagers), lb = lse_raw;
+        lds_post(&S.staged[n2 % K::kSlots], n2 + 1);
+        if (n2 + 2 * K::kStagers < NB) issue(n2 + 2 * K::kStagers, rb), issue_lse(n2 + 2 * K::kStagers), lb = lse_raw;
       }
     }
     stats_out();
@@ -643,7 +637,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         MITM_ACC(st_wait0);
       }
       asm volatile("" ::: "memory");
-      const int slot = kk % kMSlots;
+      const int slot = kk % K::kSlots;
       const float rj = lane < kBlk ? S.fref[slot][lane] : 0.f;
       if (kk < H0) {
         // Device-coherent stores (see ctc_log_chain_body), three per checkpoint and never waited for one by one: the
@@ -717,10 +711,10 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       for (int u = 0; u < kMFetch; ++u) {
         const int n = n0 + u;
         if (n < NB) {
-          if (n - H0 >= kMPSlots) {  // slot n % kMPSlots held block n - kMPSlots
+          if (n - H0 >= K::kPSlots) {  // slot n % K::kPSlots held block n - K::kPSlots
             int spin = 0;
             MITM_T0();
-            while (!pgrabbed(n - kMPSlots)) {
+            while (!pgrabbed(n - K::kPSlots)) {
               __builtin_amdgcn_s_sleep(4);
               if (++spin > kMSpin) give_up();
             }
@@ -734,7 +728,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
             bb = ldexpf(__uint_as_float((unsigned)vb[u]), max(e_b - eb, -200));
             bl = lane < L ? ldexpf(__uint_as_float((unsigned)vl[u]), max(e_l - eb, -200)) : 0.f;
           }
-          const int ps = n % kMPSlots;
+          const int ps = n % K::kPSlots;
           S.pck[ps][lane] = make_float4(bb, bl, __int_as_float(eb), 0.f);
           if (lane == 0) S.poff[ps] = po[u];
           lds_post(&S.pready[ps], n + 1);
@@ -809,10 +803,10 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) fa[j] = S.ring[0][j][lane];
     lds_post(&S.chainpos, 1);
-    int nflag = NB > 1 ? lds_peek(&S.staged[1 % kMSlots]) : 0;  // looked at one block ahead of its use
+    int nflag = NB > 1 ? lds_peek(&S.staged[1 % K::kSlots]) : 0;  // looked at one block ahead of its use
     // ring slots of blocks kk, kk + 1, kk + 2, advanced by increments (a lone wave pays ~4 cycles for ANY instruction,
-    // scalar ones included: no division by kMSlots on this wave)
-    int s0 = 0, s1 = 1 % kMSlots, s2 = 2 % kMSlots;
+    // scalar ones included: no division by K::kSlots on this wave)
+    int s0 = 0, s1 = 1 % K::kSlots, s2 = 2 % K::kSlots;
     auto block = [&](int kk, const float2 (&fcur)[kBlk], float2 (&fnxt)[kBlk], auto steady) {
       constexpr bool STEADY = decltype(steady)::value;
       const int k = dir == 0 ? kk : NB - 1 - kk;
@@ -840,12 +834,12 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       if (lane == 0 && kk < 256) S.blk_t[kk] = (S.blk_t[kk] & (0xfffll << 48)) | (clock64() - st_begin);
 #endif
       if (!(STEADY && ((WFL_MITM_ABL & 1) || ((WFL_MITM_ABL & 32) && (kk & 1))))) lane_renorm();
-      // (slot s0 is free: block kk could only be staged after block kk - kMSlots had been flushed and grabbed)
+      // (slot s0 is free: block kk could only be staged after block kk - K::kSlots had been flushed and grabbed)
       if (!(STEADY && (WFL_MITM_ABL & 4))) S.ck[s0][lane] = make_float4(pb, pl, __int_as_float(e), 0.f);
       // ONE post: the factors of block kk + 1 are in registers (their reads were issued above: LDS executes a wave's
       // instructions in order) and checkpoint kk is written
       lds_post(&S.chainpos, kk + 2);
-      s0 = s1, s1 = s2, s2 = s2 + 1 == kMSlots ? 0 : s2 + 1;
+      s0 = s1, s1 = s2, s2 = s2 + 1 == K::kSlots ? 0 : s2 + 1;
       if (STEADY && (WFL_MITM_ABL & 8)) {
         pb += fcur[0].x + fcur[kBlk - 1].y;
       } else if (n >= kBlk) {
@@ -901,27 +895,28 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       }
       stats_out();
 #if WFL_MITM_STATS
-      for (int q = lane; q < min(NB, 128); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
+      for (int q = lane; q < min(NB, 128); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * K::kWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
 #endif
       if (a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
       return;
     }
     stats_out();
 #if WFL_MITM_STATS
-    for (int q = lane; q < min(NB, 128); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * kMWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
+    for (int q = lane; q < min(NB, 128); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * K::kWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
 #endif
     return;
   }
 
   // ================================================================ emitters
   if (dir == 0)
-    ctc_mitm_emitter<LSM, 0>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
+    ctc_mitm_emitter<K, LSM, 0>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
   else
-    ctc_mitm_emitter<LSM, 1>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
+    ctc_mitm_emitter<K, LSM, 1>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
 }
 
-template <bool LSM>
-__global__ void __launch_bounds__(kMWaves * 64)
+template <class K, bool LSM>
+__global__ void __launch_bounds__(K::kWaves * 64, 4)  // (second argument: waves per SIMD -- at most 128 VGPRs, so that two
+                                                     // 8-wave workgroups share a CU)
     ctc_mitm_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -930,8 +925,8 @@ __global__ void __launch_bounds__(kMWaves * 64)
     perr[1] = 0;  // utterances the repair launch recomputed
   }
 #ifdef WFL_MITM_FLIP
-  ctc_mitm_body<LSM>(a, (int)blockIdx.x >> 1, 1 - ((int)blockIdx.x & 1), coef, gout, dx, smem);
+  ctc_mitm_body<K, LSM>(a, (int)blockIdx.x >> 1, 1 - ((int)blockIdx.x & 1), coef, gout, dx, smem);
 #else
-  ctc_mitm_body<LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, coef, gout, dx, smem);
+  ctc_mitm_body<K, LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, coef, gout, dx, smem);
 #endif
 }
