@@ -46,10 +46,6 @@
 #ifndef WFL_MITM_STATS
 #define WFL_MITM_STATS 0
 #endif
-#ifndef WFL_DBG_FAST
-#define WFL_DBG_FAST 0  // scratch/chain_harness.cpp, timeline_fast.py: bit 0 no frames, 1 no staging math, 2 no gathers, 3 idle flusher,
-                        // 4 chain launch only, 9 (512) per-item timestamps in the workspace
-#endif
 
 namespace wfl {
 
@@ -105,10 +101,6 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   w.dup = o, o += 2 * (int64_t)B;             // uint64 dup[b]: bit i = target label i also occurs elsewhere in the target (or is the blank)
   w.own = o, o += 64 * (int64_t)B;            // int32 own[b][64]: lane of the first occurrence of the lane's label (63: the blank's slot)
   w.zloc = o, o += 4 * (int64_t)B;            // int64 zloc[b][2]: min / max over the blocks of log2 Z (x 2^16) as their gradient waves reproduced it
-#if WFL_DBG_FAST & 512
-  o = (o + 1) & ~1ll;
-  w.dbg = o, o += 2 * 4 * ((int64_t)B * NB + 2 * B);  // int64 [item][4] timestamps (scratch/timeline_fast.py)
-#endif
 #if WFL_MITM_STATS
   o = (o + 1) & ~1ll;
   w.dbg = o, o += 2 * (8 * 16 + 256) * 2 * (int64_t)B;  // int64 [b][dir][wave][8], then [b][dir][256] block clocks (ctc_mitm.h)
@@ -652,7 +644,7 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) {
         const int t = dir == 0 ? t0 + j : t0 + cnt - 1 - j;
-        raw[j] = (WFL_DBG_FAST & 4) ? 0.01f * t : esrc[(int64_t)min(max(t, 0), T - 1) * estride + eidx];  // clamped: valid address, unused past the block
+        raw[j] = esrc[(int64_t)min(max(t, 0), T - 1) * estride + eidx];  // clamped: valid address, unused past the block
       }
       if (LSM) {
         const int t = dir == 0 ? t0 + (lane & 15) : t0 + cnt - 1 - (lane & 15);
@@ -663,12 +655,6 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       const int k = dir == 0 ? n : NB - 1 - n;
       const int cnt = min(kBlk, T - k * kBlk);
       const int slot = n % kFSlots;
-      if (WFL_DBG_FAST & 2) {
-#pragma unroll
-        for (int j = 0; j < kBlk; ++j) S.ring[slot][j][lane] = make_float2(has_blank ? 0.4f : 0.f, has_label ? 0.4f + 0.001f * raw[j] : 0.f);
-        if (lane < kBlk) S.fref[n % kCkSlots][lane] = 0.f;
-        return;
-      }
       float xs[kBlk];
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) {
@@ -733,7 +719,6 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       const int e = S.cke[kk % kCkSlots][lane];
       const float rj = lane < kBlk ? S.fref[kk % kCkSlots][lane] : 0.f;
       lds_post(&S.ckdone, kk + 1);
-      if (WFL_DBG_FAST & 8) continue;
       // checkpoint = state BEFORE block kk, as base-2 logs relative to a wave-uniform exponent
       const int emax = __builtin_amdgcn_readlane(wave_prefix_max_i(e), 63);
       const float de = (float)(e - emax);
@@ -774,10 +759,6 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
   } else if (wave == 0) {
     // ---------------------------------------------------------------- the chain
     __builtin_amdgcn_s_setprio(3);  // issue-bound: wins the arbitration against the helper wave on its SIMD
-#if WFL_DBG_FAST & 512
-    long long* dbgc = (long long*)(a.ws + w.dbg) + ((int64_t)a.B * NB + b * 2 + dir) * 4;
-    if (SIGNAL && lane == 0) dbgc[0] = wall_clock64();
-#endif
     float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
     float pl = 0.f;
     int e = 0;
@@ -881,9 +862,7 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
         S.cke[kk % kCkSlots][lane] = had ? e : kEmptyE;
         lds_post(&S.ckready, kk + 1);
       }
-      if (WFL_DBG_FAST & 1) {
-        pb += fcur[0].x + fcur[kHalf - 1].y;
-      } else if (n >= kHalf) {
+      if (n >= kHalf) {
 #pragma unroll
         for (int j = 0; j < kHalf; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
       } else {
@@ -906,9 +885,6 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
       }
     }
     lane_renorm();
-#if WFL_DBG_FAST & 512
-    if (SIGNAL && lane == 0) dbgc[1] = wall_clock64();
-#endif
     __syncthreads();  // the flusher has summed all references
     if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = bad ? 1 : 0;
     if (dir == 0) {
@@ -1354,10 +1330,6 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   const int NB = ctc_blocks(T);
   const CtcWs w = ctc_ws_layout(a.B, T, P);
   if (!valid) return;  // (uniform over the wave)
-#if WFL_DBG_FAST & 512
-  long long* dbg = (long long*)(a.ws + w.dbg) + ((int64_t)b * NB + k) * 4;
-  if (lane == 0) dbg[0] = wall_clock64();
-#endif
   // ---- first, what needs a round trip and depends on nothing: the two flags, the parked factors, the utterance
   const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
   const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
@@ -1462,9 +1434,6 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
     }
     load_checkpoints();
   }
-#if WFL_DBG_FAST & 512
-  if (lane == 0) dbg[1] = wall_clock64();
-#endif
   // labels that occur once in the target (and are not the blank) own their gradient column: plain ds_write instead
   // of ds_add_f32 (see ctc_grad_body); the mask was computed once per utterance by its alpha chain workgroup
   const bool dup = has_label && ((dupmask >> lane) & 1ull) != 0;
@@ -1591,9 +1560,6 @@ __device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid,
   } else {
     for (int i = lane; i < total; i += 64) dst[i] = rows[i];
   }
-#if WFL_DBG_FAST & 512
-  if (lane == 0) dbg[2] = wall_clock64();
-#endif
 }
 
 template <bool COMPACT>
@@ -2364,7 +2330,6 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
   } else {
     hipLaunchKernelGGL(ctc_fast_chain_kernel, dim3((unsigned)B, 2u), dim3(kFWaves * 64), 0, (hipStream_t)stream, a);
     WFL_LAUNCH_CHECK();
-    if (WFL_DBG_FAST & 16) return WFL_OK;
     const int64_t items = (int64_t)B * std::max(ctc_blocks(T) - 1, 1);
     hipLaunchKernelGGL(ctc_certify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     WFL_LAUNCH_CHECK();

@@ -134,6 +134,21 @@ def _done(tok):
         PHASE_EVENTS.append((tok[0], tok[1], _event()))
 
 
+_WFLPY = None
+
+
+def _staging_helper():
+    """the CPython helper of the target staging (csrc/wflpy.c), or its numpy stand-in when the extension is missing"""
+    global _WFLPY
+    if _WFLPY is None:
+        try:
+            from . import _wflpy as mod
+        except ImportError:
+            from . import _wflpy_np as mod
+        _WFLPY = mod
+    return _WFLPY
+
+
 def flatten_any(targets):
     """Targets as the criteria receive them -- a list of int sequences or of 1-D LongTensors (train.py hands over
     tensors, the benchmarks lists) -> (flat int32 array, offsets int64 [B+1], lengths).  Tensors are flattened
@@ -632,7 +647,7 @@ class CtcTargets:
 
 def _stage_targets(targets, device, flat=None, lens=None):
     """Fill a staging slot with [offsets | flat | factors]; returns what CtcTargets needs plus a content key."""
-    from . import _wflpy
+    _wflpy = _staging_helper()
 
     key = device.index if device.type == "cuda" else -1
     ring = _STAGING.get(key)
@@ -849,7 +864,7 @@ def targets_on_device(targets, device):
     derived objects).  A CtcTargets built earlier is passed through."""
     if isinstance(targets, CtcTargets):
         return targets
-    from . import _wflpy
+    _wflpy = _staging_helper()
 
     st = _stage_targets(targets, device)
     data = _TARGET_CACHE.data

@@ -460,11 +460,11 @@ def test_transition_builder_matches_reference_script_goldens(golden_dir, tmp_pat
         whole = TB.build_transitions(gold["lines"], gold["tokens"], c["prune"], c["blank"], c["add_self_loops"],
                                      c["disable_backoff"])
         assert [a[:4] for a in dump(whole)["arcs"]] == want["arcs"], name
-    # the CLI writes a file that load_criterion's reader takes back (binary by default, text with --text)
+    # the CLI writes a file that load_criterion's reader takes back (text by default, the binary layout with --binary)
     data, toks = tmp_path / "text", tmp_path / "tokens"
     data.write_text("\n".join(gold["lines"]) + "\n")
     toks.write_text("\n".join(gold["tokens"]) + "\n")
-    for extra in ([], ["--text"]):
+    for extra in ([], ["--binary"], ["--text"]):
         out = str(tmp_path / ("trans" + "".join(extra)))
         g = TB.main(["--data_path", str(data), "--tokens", str(toks), "--prune", "0", "1", "--blank", "optional",
                      "--save_path", out] + extra)
@@ -682,3 +682,29 @@ def test_cpython_helper_factors_and_content_key():
     other[500] ^= 1
     assert _wflpy.content_key(other.ctypes.data, 1000) != _wflpy.content_key(buf.ctypes.data, 1000)
     assert _wflpy.same_bytes(buf.ctypes.data, buf.tobytes()) and not _wflpy.same_bytes(other.ctypes.data, buf.tobytes())
+
+
+def test_numpy_stand_in_of_the_staging_helper_equals_it():
+    """engine._staging_helper falls back to _wflpy_np when csrc/wflpy.c was not built: same flattening, same factors,
+    same byte comparison (the content key may differ: it only keys a per-process cache)."""
+    from gtn_applications_amd import _wflpy, _wflpy_np
+
+    rows = [[3, 1, 4], [], [1, 5, 9, 2, 6], (5, 3)]
+    B = len(rows)
+    out = {}
+    for name, mod in (("c", _wflpy), ("np", _wflpy_np)):
+        off = np.zeros(B + 1, np.int64)
+        flat = np.full(16, -7, np.int32)
+        fac = np.zeros(6 * B, np.float32)
+        res = mod.flatten_into(rows, flat.ctypes.data, flat.size, off.ctypes.data)
+        mod.factors_into(off.ctypes.data, B, fac.ctypes.data)
+        assert mod.flatten_into(rows, flat.ctypes.data, 3, off.ctypes.data) is None and off[B] == 10  # too small: size reported
+        key = mod.content_key(flat.ctypes.data, 40)
+        assert key == mod.content_key(flat.ctypes.data, 40) and len(key) == 2
+        assert mod.same_bytes(flat.ctypes.data, flat[:10].tobytes()) and not mod.same_bytes(flat.ctypes.data, b"\\x01" * 8)
+        with pytest.raises(TypeError):
+            mod.flatten_into([np.arange(3)], flat.ctypes.data, flat.size, off.ctypes.data)
+        out[name] = (res, off.copy(), flat.copy(), fac.copy())
+    assert out["c"][0] == out["np"][0] == (10, 5, 1, 9)
+    for a, b in zip(out["c"][1:], out["np"][1:]):
+        np.testing.assert_array_equal(a, b)
