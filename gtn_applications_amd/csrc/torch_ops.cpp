@@ -111,8 +111,16 @@ struct StagedTargets {
   std::string key_bytes;  // [offsets | labels] as staged (confirms a cache hit byte for byte)
   int64_t B = 0, n = 0, max_len = 0, off_flat = 0, off_fac = 0;
   long label_min = 0, label_max = -1;
-  hipStream_t up_stream = nullptr;  // the stream the upload was queued on, and the ring slot whose event follows it
+  hipStream_t up_stream = nullptr;  // the stream the upload was queued on ...
+  hipEvent_t up_event = nullptr;    // ... and this batch's OWN event behind it (the staging slot's event is re-recorded
+                                    // by later uploads, possibly on another stream)
   int slot = 0;
+  StagedTargets() = default;
+  StagedTargets(const StagedTargets&) = delete;
+  StagedTargets& operator=(const StagedTargets&) = delete;
+  ~StagedTargets() {
+    if (up_event) (void)hipEventDestroy(up_event);
+  }
 };
 
 struct PinnedRing {  // reusable pinned staging buffers; a slot is reused after the upload that read it has completed
@@ -252,9 +260,8 @@ std::shared_ptr<StagedTargets> stage_targets(const py::handle& targets, const at
     tc.ring.i = (tc.ring.i + PinnedRing::kSlots - 1) % PinnedRing::kSlots;  // nothing was uploaded from the slot
     auto& e = hit->second->second;
     const hipStream_t now = c10::hip::getCurrentHIPStream(dev.index()).stream();
-    // reused on another stream than the one that uploaded it: order this stream behind the upload (the slot's event
-    // may have been re-recorded since -- later on the same stream, which is still behind the upload)
-    if (now != e->up_stream && tc.ring.ev[e->slot]) (void)hipStreamWaitEvent(now, tc.ring.ev[e->slot], 0);
+    // reused on another stream than the one that uploaded it: order this stream behind the upload
+    if (now != e->up_stream && e->up_event) (void)hipStreamWaitEvent(now, e->up_event, 0);
     return e;
   }
   // per-utterance factors (engine._FACTORS order): scale_none, scale_mean, then both times +1/B and -1/B
@@ -275,6 +282,7 @@ std::shared_ptr<StagedTargets> stage_targets(const py::handle& targets, const at
   check(wfl_upload(st->dev_buf.data_ptr(), base, nbytes, (void*)stream), "stage_targets");
   tc.ring.uploaded(slot, stream);
   st->up_stream = stream, st->slot = slot;
+  if (hipEventCreateWithFlags(&st->up_event, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(st->up_event, stream);
   if (hit != tc.index.end()) {  // (same hash, different bytes: replace)
     tc.lru.erase(hit->second);
     tc.index.erase(hit);

@@ -222,13 +222,19 @@ class PackedLattice:
             N.lib.wfl_lattice_host_free(host_handle)
         self.device = device
         self._host = None
+        self._uploaded = None
         if cuda:
             blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
             upload(blob, buf, nbytes)
             ev = ring.events[slot]
             if ev is None:
                 ev = ring.events[slot] = torch.cuda.Event()
-            ev.record()
+            ev.record()  # (the staging slot: reusable once this upload has read it)
+            # the lattice's OWN event: packs are cached and may be used from another stream later, by which time the
+            # slot's event may have been re-recorded on some other stream (lattice_forward orders itself behind this one)
+            own = torch.cuda.Event()
+            own.record()
+            self._uploaded = (stream_ptr(), own)
         elif device is not None:
             blob = buf.to(device)
         else:
@@ -330,6 +336,9 @@ def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_L
     transducer.py:283,287)."""
     B, T, C = x.shape
     d = pack.desc
+    up = getattr(pack, "_uploaded", None)
+    if up is not None and up[0] != stream_ptr():  # a cached pack uploaded on another stream
+        torch.cuda.current_stream().wait_event(up[1])
     if d.B != B:
         raise ValueError(f"lattice batch has {d.B} utterances, emissions have {B}")
     n_xg, n_ab = ctypes.c_int64(), ctypes.c_int64()
@@ -599,10 +608,12 @@ class CtcTargets:
             ev = ring.events[slot]
             if ev is None:
                 ev = ring.events[slot] = torch.cuda.Event()
-            ev.record()
-            # (a later user on ANOTHER stream orders itself behind the upload: targets_on_device; the slot's event
-            # may be re-recorded by then -- later on this same stream, which is still behind the upload)
-            self._uploaded = (stream_ptr(), ev)
+            ev.record()  # (the staging slot: reusable once this upload has read it)
+            # the targets' OWN event: a later user on ANOTHER stream orders itself behind the upload (targets_on_device);
+            # the slot's event may have been re-recorded by then, possibly on a different stream
+            own = torch.cuda.Event()
+            own.record()
+            self._uploaded = (stream_ptr(), own)
         else:  # host-only uses (tests of the packers): same layout, no device
             self.dev_buf = torch.from_numpy(view[:nbytes].copy())
             self._uploaded = None
