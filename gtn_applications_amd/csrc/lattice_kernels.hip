@@ -1599,7 +1599,175 @@ __device__ __forceinline__ bool band_shape(const wfl_lattice_desc& d, const UttV
   return u.Q >= 1 && u.Q <= 64 && u.E == 0 && d.max_labels <= 64;
 }
 
+// The dense gradient rows of a tile: base value (0, the existing gradient, or -cf * softmax(x) for the fused
+// log-softmax backward) plus the accumulator of the column's label slot (`acc` [nr][Kmax], found through `colmap`);
+// the rows never pass through LDS.  Shared by the general gradient kernel and the state-occupancy one.
+__device__ __forceinline__ void stream_grad_rows(int b, int ts0, int nr, int T, int C, int Kmax, int tid, int NT,
+                                                 float* __restrict__ dx, const float* __restrict__ x,
+                                                 const float* __restrict__ row_lse, int accumulate, bool dead, float cf,
+                                                 const float* acc, const int16_t* colmap) {
+  // fused log_softmax backward (ctc.py:107, transducer.py:186-187): with g = cf * posteriors the
+  // gradient w.r.t. the raw scores is g - softmax * sum_c g, and the posteriors of a frame sum to
+  // one, so the base value of a row is -cf * softmax(x)
+  float* gdst = dx + ((int64_t)b * T + ts0) * C;
+  const float* xsrc = row_lse ? x + ((int64_t)b * T + ts0) * C : nullptr;
+  const float* lse = row_lse ? row_lse + (int64_t)b * T + ts0 : nullptr;
+  const bool soft = row_lse && !dead;
+  auto value = [&](int r, int c, float have, float xv, float l) {
+    float v = have;
+    if (soft && l > WFL_NEG_INF) v -= cf * fast_exp(nan_to_neg(xv) - l);
+    const int k = colmap[c];
+    if (k >= 0 && !dead) v += cf * acc[r * Kmax + k];
+    return v;
+  };
+  if (C >= 512) {
+    // wide rows: one float4 per thread and row (rows are only 4-byte aligned: scalar head / tail).  Four rows at a
+    // time with ALL their loads -- the row's scores, its log-sum-exp, the gradient it accumulates into -- issued
+    // together: row by row, every row cost two dependent round trips to HBM (lse, then x -> exp -> store).
+    const int64_t e0 = ((int64_t)b * T + ts0) * C;
+    constexpr int RU = 4;
+    for (int r0 = 0; r0 < nr; r0 += RU) {
+      int head[RU], nvec[RU];
+      float lrow[RU];
+#pragma unroll
+      for (int q = 0; q < RU; ++q) {
+        const int r = min(r0 + q, nr - 1);  // (past the tile: the last row again, not stored)
+        head[q] = (int)((4 - ((e0 + (int64_t)r * C) & 3)) & 3);
+        nvec[q] = (C - head[q]) >> 2;
+        lrow[q] = soft ? lse[r] : 0.f;
+      }
+      for (int j0 = 0; j0 < (C >> 2); j0 += NT) {
+        const int j = j0 + tid;
+        float4 have[RU], xv[RU];
+#pragma unroll
+        for (int q = 0; q < RU; ++q) {
+          const int r = min(r0 + q, nr - 1);
+          const int c = head[q] + 4 * min(j, nvec[q] - 1);  // (clamped: a valid, aligned address)
+          have[q] = make_float4(0.f, 0.f, 0.f, 0.f), xv[q] = have[q];
+          if (accumulate) have[q] = *reinterpret_cast<const float4*>(gdst + (int64_t)r * C + c);
+          if (soft) xv[q] = *reinterpret_cast<const float4*>(xsrc + (int64_t)r * C + c);
+        }
+#pragma unroll
+        for (int q = 0; q < RU; ++q) {
+          const int r = r0 + q;
+          if (r < nr && j < nvec[q]) {
+            const int c = head[q] + 4 * j;
+            float4 o;
+            o.x = value(r, c, have[q].x, xv[q].x, lrow[q]), o.y = value(r, c + 1, have[q].y, xv[q].y, lrow[q]);
+            o.z = value(r, c + 2, have[q].z, xv[q].z, lrow[q]), o.w = value(r, c + 3, have[q].w, xv[q].w, lrow[q]);
+            *reinterpret_cast<float4*>(gdst + (int64_t)r * C + c) = o;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RU; ++q) {
+        const int r = r0 + q;
+        const int ntail = C - head[q] - 4 * nvec[q];  // < 4
+        if (r < nr && tid < head[q] + ntail) {
+          float* grow = gdst + (int64_t)r * C;
+          const int c = tid < head[q] ? tid : head[q] + 4 * nvec[q] + (tid - head[q]);
+          grow[c] = value(r, c, accumulate ? grow[c] : 0.f, soft ? xsrc[(int64_t)r * C + c] : 0.f, lrow[q]);
+        }
+      }
+    }
+  } else {
+    // narrow rows: a lane owns a column (its label slot looked up once), a wave owns every fourth row
+    const int lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
+    for (int c = lane; c < C; c += 64) {
+      const int k = dead ? -1 : colmap[c];
+#pragma unroll 4
+      for (int r = wv; r < nr; r += nw) {
+        const int i = r * C + c;
+        float v = accumulate ? gdst[i] : 0.f;
+        if (soft) {
+          const float l = lse[r];
+          if (l > WFL_NEG_INF) v -= cf * fast_exp(nan_to_neg(xsrc[i]) - l);
+        }
+        if (k >= 0) v += cf * acc[r * Kmax + k];
+        gdst[i] = v;
+      }
+    }
+  }
+}
+
 constexpr int kChunk = 16;
+// Is utterance `u` one whose emission gradient is a sum of STATE occupancies?  Every arc INTO a state carries the same
+// emission label ("uniform-label" acceptors: CTC-like chains, force alignment, the Transducer's alignment graphs -- the
+// label belongs to the destination state), no epsilon arcs, swept in the probability domain.  Then
+//     sum over the arcs a into q of  alpha_t[src a] w_a f_t[label q] beta_{t+1}[q]  =  alpha_{t+1}[q] beta_{t+1}[q]
+// -- the left factor is what the forward sweep stored -- and the frame's gradient is one product per STATE (263 at the
+// Transducer benchmark) instead of one per ARC (917), with no source / destination gathers and no alpha / beta tile in
+// LDS.  (block-uniform; the general kernel applies the same test and skips what occ_grad_kernel served)
+__device__ __forceinline__ bool occ_eligible(const UttView& u, bool prob) {
+  int bad = !prob | (u.E > 0);
+  if (!bad)
+    for (int q = threadIdx.x; q < u.Q; q += blockDim.x) {
+      const int i0 = u.in_ptr[q], i1 = u.in_ptr[q + 1];
+      for (int k = i0 + 1; k < i1; ++k) bad |= u.arc_slot[k] != u.arc_slot[i0];
+    }
+  return !__syncthreads_or(bad);
+}
+
+// Emission gradient of uniform-label acceptors from state occupancies (see occ_eligible): tiles of up to 32 frames whose
+// only LDS is the per-(frame, label) accumulator; a thread multiplies alpha and beta of one (frame, state) where they lie
+// (rows of Q doubles: coalesced) and adds the product to its label's accumulator (ds_add_f32: a label's few states
+// collide); the dense rows are streamed out as in the general kernel.  No learnable-weight gradient here (dW == NULL).
+__global__ void __launch_bounds__(256)
+    occ_grad_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T, int C,
+                    const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
+                    const float* __restrict__ coef, const float* __restrict__ gout, int accumulate,
+                    const float* __restrict__ x, const float* __restrict__ row_lse, float* __restrict__ dx,
+                    int rows_per_block, int TS, int64_t tail, int nch1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
+  const UttView u = make_view(d, ints, floats, b, T);
+  const int Q = u.Q, K = u.K, Kmax = d.max_labels;
+  float* acc = (float*)smem;                                  // [TS][Kmax]
+  double* corr = (double*)(acc + (((size_t)TS * Kmax + 1) & ~(size_t)1));  // [TS]
+  int16_t* lab = (int16_t*)(corr + TS);                       // [Qmax]: label slot of the state (-1: no in-arc)
+  int16_t* colmap = lab + ((d.max_states + 3) & ~3);          // [C]
+  const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
+  const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
+  const double zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];  // log2 Z
+  const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
+  if (!occ_eligible(u, fmt[b] == kFmtProb)) return;
+  const double* alpha_d = reinterpret_cast<const double*>(alpha) + u.ab_base;
+  const double* beta_d = reinterpret_cast<const double*>(beta) + u.ab_base;
+  const float g0 = gout ? gout[0] : 1.f;
+  const float cf = coef ? coef[b] * g0 : g0;
+  const float z = logz[b];
+  const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
+  for (int c = tid; c < C; c += NT) colmap[c] = -1;
+  for (int q = tid; q < Q; q += NT) lab[q] = u.in_ptr[q] < u.in_ptr[q + 1] ? (int16_t)u.arc_slot[u.in_ptr[q]] : (int16_t)-1;
+  __syncthreads();
+  for (int k = tid; k < K; k += NT) colmap[u.labels[k]] = (int16_t)k;
+  const int t_begin = blockIdx.x * rows_per_block;
+  const int t_end = min(T, t_begin + rows_per_block);
+  const float inv_q = 1.f / (float)max(Q, 1);
+  for (int ts0 = t_begin; ts0 < t_end; ts0 += TS) {
+    const int nr = min(TS, t_end - ts0);
+    __syncthreads();
+    for (int i = tid; i < nr * Kmax; i += NT) acc[i] = 0.f;
+    // frame t's arcs end in slot t + 1 of both sweeps: gamma = p_alpha p_beta 2^(offs_a + offs_b - log2 Z) there
+    if (tid < nr) corr[tid] = exp2(offs_a[ts0 + tid + 1] + offs_b[ts0 + tid + 1] - zd);
+    __syncthreads();
+    if (!dead) {
+      const double* asrc = alpha_d + (int64_t)(ts0 + 1) * Q;
+      const double* bsrc = beta_d + (int64_t)(ts0 + 1) * Q;
+      const int n = nr * Q;
+#pragma unroll 4
+      for (int i = tid; i < n; i += NT) {
+        const int r = (int)(((float)i + 0.5f) * inv_q), q = i - r * Q;  // (exact for i < 2^20)
+        const double g = asrc[i] * bsrc[i];
+        const int k = lab[q];
+        if (k >= 0 && g != 0.0) atomicAdd(&acc[r * Kmax + k], (float)(g * corr[r]));
+      }
+    }
+    __syncthreads();
+    stream_grad_rows(b, ts0, nr, T, C, Kmax, tid, NT, dx, x, row_lse, accumulate, dead, cf, acc, colmap);
+  }
+}
+
 #ifdef WFL_DBG_TIMELINE
 __device__ unsigned long long g_dbg[3 * 8192];
 #endif
@@ -1610,7 +1778,7 @@ __global__ void __launch_bounds__(256)
                 const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
                 int accumulate, const float* __restrict__ x, const float* __restrict__ row_lse,
                 float* __restrict__ dx, float* __restrict__ dW, int rows_per_block, int TS, int64_t tail, int nch1,
-                int R, int skip_band) {
+                int R, int skip_band, int skip_occ) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
 #ifdef WFL_DBG_TIMELINE
@@ -1653,6 +1821,7 @@ __global__ void __launch_bounds__(256)
     const int band_ok = band_in_arcs(u, weights, tid).ok;
     if (__syncthreads_and(band_ok) && prob && band_shape(d, u)) return;
   }
+  if (skip_occ && occ_eligible(u, prob)) return;  // occ_grad_kernel served this utterance (the same test decides there)
   const float wref = prob ? wrefs[b] : 0.f;
   const float* fgp = xg + xg_main_dev(d, T);                    // probability-domain factors of the gathered rows
   const float* rmaxp = fgp + xg_main_dev(d, T) + (int64_t)b * T;  // their references
@@ -1810,88 +1979,7 @@ __global__ void __launch_bounds__(256)
     }
     if (dx) {
       __syncthreads();
-      // fused log_softmax backward (ctc.py:107, transducer.py:186-187): with g = cf * posteriors the
-      // gradient w.r.t. the raw scores is g - softmax * sum_c g, and the posteriors of a frame sum to
-      // one, so the base value of a row is -cf * softmax(x)
-      float* gdst = dx + ((int64_t)b * T + ts0) * C;
-      const float* xsrc = row_lse ? x + ((int64_t)b * T + ts0) * C : nullptr;
-      const float* lse = row_lse ? row_lse + (int64_t)b * T + ts0 : nullptr;
-      const bool soft = row_lse && !dead;
-      auto value = [&](int r, int c, float have, float xv, float l) {
-        float v = have;
-        if (soft && l > WFL_NEG_INF) v -= cf * fast_exp(nan_to_neg(xv) - l);
-        const int k = colmap[c];
-        if (k >= 0 && !dead) v += cf * acc[r * Kmax + k];
-        return v;
-      };
-      if (C >= 512) {
-        // wide rows: one float4 per thread and row (rows are only 4-byte aligned: scalar head / tail).  Four rows at a
-        // time with ALL their loads -- the row's scores, its log-sum-exp, the gradient it accumulates into -- issued
-        // together: row by row, every row cost two dependent round trips to HBM (lse, then x -> exp -> store).
-        const int64_t e0 = ((int64_t)b * T + ts0) * C;
-        constexpr int RU = 4;
-        for (int r0 = 0; r0 < nr; r0 += RU) {
-          int head[RU], nvec[RU];
-          float lrow[RU];
-#pragma unroll
-          for (int q = 0; q < RU; ++q) {
-            const int r = min(r0 + q, nr - 1);  // (past the tile: the last row again, not stored)
-            head[q] = (int)((4 - ((e0 + (int64_t)r * C) & 3)) & 3);
-            nvec[q] = (C - head[q]) >> 2;
-            lrow[q] = soft ? lse[r] : 0.f;
-          }
-          for (int j0 = 0; j0 < (C >> 2); j0 += NT) {
-            const int j = j0 + tid;
-            float4 have[RU], xv[RU];
-#pragma unroll
-            for (int q = 0; q < RU; ++q) {
-              const int r = min(r0 + q, nr - 1);
-              const int c = head[q] + 4 * min(j, nvec[q] - 1);  // (clamped: a valid, aligned address)
-              have[q] = make_float4(0.f, 0.f, 0.f, 0.f), xv[q] = have[q];
-              if (accumulate) have[q] = *reinterpret_cast<const float4*>(gdst + (int64_t)r * C + c);
-              if (soft) xv[q] = *reinterpret_cast<const float4*>(xsrc + (int64_t)r * C + c);
-            }
-#pragma unroll
-            for (int q = 0; q < RU; ++q) {
-              const int r = r0 + q;
-              if (r < nr && j < nvec[q]) {
-                const int c = head[q] + 4 * j;
-                float4 o;
-                o.x = value(r, c, have[q].x, xv[q].x, lrow[q]), o.y = value(r, c + 1, have[q].y, xv[q].y, lrow[q]);
-                o.z = value(r, c + 2, have[q].z, xv[q].z, lrow[q]), o.w = value(r, c + 3, have[q].w, xv[q].w, lrow[q]);
-                *reinterpret_cast<float4*>(gdst + (int64_t)r * C + c) = o;
-              }
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < RU; ++q) {
-            const int r = r0 + q;
-            const int ntail = C - head[q] - 4 * nvec[q];  // < 4
-            if (r < nr && tid < head[q] + ntail) {
-              float* grow = gdst + (int64_t)r * C;
-              const int c = tid < head[q] ? tid : head[q] + 4 * nvec[q] + (tid - head[q]);
-              grow[c] = value(r, c, accumulate ? grow[c] : 0.f, soft ? xsrc[(int64_t)r * C + c] : 0.f, lrow[q]);
-            }
-          }
-        }
-      } else {
-        // narrow rows: a lane owns a column (its label slot looked up once), a wave owns every fourth row
-        const int lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
-        for (int c = lane; c < C; c += 64) {
-          const int k = dead ? -1 : colmap[c];
-#pragma unroll 4
-          for (int r = wv; r < nr; r += nw) {
-            const int i = r * C + c;
-            float v = accumulate ? gdst[i] : 0.f;
-            if (soft) {
-              const float l = lse[r];
-              if (l > WFL_NEG_INF) v -= cf * fast_exp(nan_to_neg(xsrc[i]) - l);
-            }
-            if (k >= 0) v += cf * acc[r * Kmax + k];
-            gdst[i] = v;
-          }
-        }
-      }
+      stream_grad_rows(b, ts0, nr, T, C, Kmax, tid, NT, dx, x, row_lse, accumulate, dead, cf, acc, colmap);
     }
   }
   if (dW) {
@@ -2428,11 +2516,35 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
                        xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, dx, dW, tail, nch1);
     WFL_LAUNCH_CHECK();
   }
+  // uniform-label acceptors without learnable weights (the Transducer's alignment graphs, long CTC targets): the
+  // emission gradient from state occupancies (occ_grad_kernel); the general launch skips what it served
+  static const bool occ_off = [] {
+    const char* e = getenv("WFL_LATTICE_OCC_GRAD");  // (0: the general kernel for everything -- tests, measurements)
+    return e && atoi(e) == 0;
+  }();
+  const int occ = !occ_off && dx && !dW && !band && d->max_eps == 0 && d->max_labels <= 32767;
+  int occ_done = 0;
+  if (occ) {
+    const int wgs_t = std::max(1, std::min((T + 15) / 16, 2048 / std::max(1, d->B)));
+    const int rows_o = (T + wgs_t - 1) / wgs_t;
+    const int blocks_o = (T + rows_o - 1) / rows_o;
+    const int ts_o = std::min(32, rows_o);
+    const size_t olds = (((size_t)ts_o * d->max_labels + 1) & ~(size_t)1) * 4 + 8 * (size_t)ts_o +
+                        2 * (((size_t)d->max_states + 3) & ~(size_t)3) + 2 * (size_t)C + 16;
+    if (olds <= (size_t)kLdsBytes) {
+      if (olds > 48 * 1024) WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)occ_grad_kernel, (int)olds));
+      hipLaunchKernelGGL(occ_grad_kernel, dim3((unsigned)blocks_o, (unsigned)d->B), dim3(256), olds, (hipStream_t)stream, *d,
+                         ints, floats, T, C, alpha, beta, logz, coef, gout, accumulate, x, row_lse, dx, rows_o, ts_o, tail,
+                         nch1);
+      WFL_LAUNCH_CHECK();
+      occ_done = 1;
+    }
+  }
   if (lds > 48 * 1024)
     WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)grad_kernel, (int)lds));
   hipLaunchKernelGGL(grad_kernel, dim3((unsigned)blocks_t, (unsigned)d->B), dim3(256), lds, (hipStream_t)stream, *d,
                      ints, floats, xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, x, row_lse,
-                     dx, dW, rows_per_block, TS, tail, nch1, rpc, band);
+                     dx, dW, rows_per_block, TS, tail, nch1, rpc, band, occ_done);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

@@ -784,8 +784,10 @@ def test_asg_beyond_128_classes(crit, C):
     assert loss.item() == pytest.approx(want[0], rel=RTOL)
     close(xt.grad, want[1])
     close(Wt.grad, want[2], atol=2e-4)
-    with pytest.raises(Exception, match="does not fit the LDS-resident transition matrix"):
-        crit["asg"].ASGLoss(dev(rs.randn(1, 10, 300).astype(np.float32)), dev(np.zeros((301, 300), np.float32)), [[1, 2]], "mean")
+    # beyond the on-chip limit the same call runs on the batched per-frame product (csrc/dense_wide.h; parity at 333 and
+    # 1000 classes: tests/test_gpu_configs.py::test_asg_beyond_the_on_chip_class_limit)
+    big = crit["asg"].ASGLoss(dev(rs.randn(1, 10, 300).astype(np.float32)), dev(np.zeros((301, 300), np.float32)), [[1, 2]], "mean")
+    assert np.isfinite(big.item())
 
 
 def test_dense_more_classes_than_the_fast_path_supports():
