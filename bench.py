@@ -69,7 +69,7 @@ PHASE_KERNEL_NAMES = {
     "ctc_grad": ["reduce_loss_kernel", "ctc_grad_kernel"],
     "lattice_gather": ["gather_lse_kernel", "gather_kernel"],
     "lattice_chain": ["prob_chain_kernel", "prob_certify_kernel", "chain_kernel"],
-    "lattice_grad": ["grad_kernel"],
+    "lattice_grad": ["occ_grad_kernel", "band_grad_kernel", "grad_kernel"],
     "lattice_gather/shared": ["gather_kernel"],
     "lattice_chain/shared": ["prob_chain_kernel", "prob_certify_kernel", "chain_kernel"],
     "lattice_grad/shared": ["grad_kernel"],

@@ -64,7 +64,11 @@ struct MitmK;
 template <>
 struct MitmK<16> {
   static constexpr int kSlots = 9;    // LDS ring depth in blocks: factors, references, own checkpoints
+#if WFL_MITM_STATS
+  static constexpr int kPSlots = 5;   // (the statistics build keeps 64 block clocks in LDS)
+#else
   static constexpr int kPSlots = 6;   // partner checkpoints handed from the fetcher to the emitters
+#endif
   static constexpr int kStagers = 4, kEmitters = 9, kWaves = 16;
   __device__ static __forceinline__ void role(int wave, int& role, int& idx) {
     switch (wave) {  // (a switch on a scalar: compiled to scalar compares)
@@ -127,7 +131,7 @@ struct MitmLds {
   int ckdone;                      // ... picked up by the flusher (offc valid)
   int offdone;                     // offtot valid
 #if WFL_MITM_STATS
-  long long blk_t[256];            // chain wave: clock at the start of every block
+  long long blk_t[64];             // chain wave: clock at the start of every block (the first 64)
 #endif
 };
 
@@ -479,7 +483,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
   if (threadIdx.x == 0) S.enext = mitm_first_emitted(ctc_blocks(a.T), dir), S.zready = 0;
   if (threadIdx.x == 0) S.chainpos = 0, S.ckdone = 0, S.offdone = 0;
 #if WFL_MITM_STATS
-  if (threadIdx.x < 256) S.blk_t[threadIdx.x] = 0;
+  if (threadIdx.x < 64) S.blk_t[threadIdx.x] = 0;
 #endif
   __syncthreads();
   int role, ridx;
@@ -820,7 +824,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
           MITM_ACC(st_wait1);
 #if WFL_MITM_STATS
           st_polls += spin;
-          if (lane == 0 && kk < 256) S.blk_t[kk] |= (long long)min(spin, 4095) << 48;  // (stamped below: the stamp keeps these bits)
+          if (lane == 0 && kk < 64) S.blk_t[kk] |= (long long)min(spin, 4095) << 48;  // (stamped below: the stamp keeps these bits)
 #endif
         }
         asm volatile("" ::: "memory");
@@ -831,7 +835,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         if (STEADY || kk + 2 < NB) nflag = lds_peek(&S.staged[s2]);
       }
 #if WFL_MITM_STATS
-      if (lane == 0 && kk < 256) S.blk_t[kk] = (S.blk_t[kk] & (0xfffll << 48)) | (clock64() - st_begin);
+      if (lane == 0 && kk < 64) S.blk_t[kk] = (S.blk_t[kk] & (0xfffll << 48)) | (clock64() - st_begin);
 #endif
       if (!(STEADY && ((WFL_MITM_ABL & 1) || ((WFL_MITM_ABL & 32) && (kk & 1))))) lane_renorm();
       // (slot s0 is free: block kk could only be staged after block kk - K::kSlots had been flushed and grabbed)
@@ -895,14 +899,14 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       }
       stats_out();
 #if WFL_MITM_STATS
-      for (int q = lane; q < min(NB, 128); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * K::kWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
+      for (int q = lane; q < min(NB, 64); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * K::kWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
 #endif
       if (a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
       return;
     }
     stats_out();
 #if WFL_MITM_STATS
-    for (int q = lane; q < min(NB, 128); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * K::kWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
+    for (int q = lane; q < min(NB, 64); q += 64) ((long long*)(a.ws + w.dbg) + 2 * 8 * K::kWaves * (int64_t)a.B)[(int64_t)(b * 2 + dir) * 256 + q] = S.blk_t[q];
 #endif
     return;
   }
