@@ -11,4 +11,4 @@ for f in "$1" "$2"; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/graph.cpp.o build/pack.cpp.o build/lattice_kernels.hip.o build/dense_kernels.hip.o build/conv_kernels.hip.o /tmp/dbg/ctc_ab$i.o -o /root/repo/scripts/_build/libwfl_ablab$i.so ) &
 done; wait
 cd /root/repo
-timeout 2400 /usr/local/graft/bin/gpurun --timeout 900 -- "scripts/mitm_abl_gpu.sh ab1 ab2 ab1 ab2" 2>&1 | grep -E "ABL|mitm" 
+timeout 2400 /usr/local/graft/bin/gpurun --timeout 900 -- "scripts/mitm_abl_gpu.sh ab1 ab2 ab1 ab2" 2>&1 | grep -iE "ABL|mitm"
