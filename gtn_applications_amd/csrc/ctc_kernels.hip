@@ -130,6 +130,9 @@ struct CtcArgs {
   // fast pipelined step with persistent gradient waves, optional: kParkStride floats per gradient wave, where a wave
   // leaves the emission factors of its SECOND item before it starts waiting for the checkpoints of its first
   float* park;
+  // lane-exponent steps, optional: a word of pinned HOST memory where the repair launch leaves the number of utterances
+  // it recomputed -- read by the NEXT call on this workspace, without a synchronisation (wfl_ctc_forward_backward)
+  int32_t* host_repaired;
 };
 constexpr int kXcStride = 64;
 constexpr int kParkStride = 17 * 64;  // 16 frames x 64 lanes of factors + the per-lane reference word
@@ -1730,6 +1733,14 @@ __global__ void __launch_bounds__(256)
     }
     // the loss of the fast launch stands unless an utterance was repaired
     if (blockIdx.x == 0 && threadIdx.x < 64 && a.loss_out) reduce_loss_when_done(a, w, lane, true);
+    if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 128 && a.host_repaired) {
+      // how many utterances this launch recomputes (the certificates were written by the launch before): for the next
+      // call's choice of path.  A plain word in pinned host memory, system scope; nobody waits for it.
+      int n = 0;
+      for (int u = lane; u < a.B; u += 64) n += utterance_rejected(a, w, u) ? 1 : 0;
+      n = (int)wave_all_sum((float)n);  // (B <= 2^24: exact)
+      if (lane == 0) __hip_atomic_store(a.host_repaired, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;
   }
   // gradient workgroups: a small persistent grid (the launch is empty on data the fast chains can represent,
@@ -2357,6 +2368,43 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   const int64_t items = (int64_t)B * ctc_blocks(T);
   const int ppl = (max_len + 1 + 63) / 64;  // target positions per lane
   const dim3 grid((unsigned)(2 * B + (items + 3) / 4));
+  // Which step?  The lane-exponent step + repair launch costs fast + log-domain time when the certificate rejects
+  // (scores without structure and a spread of 2 nats or more: DESIGN.md section 4); the log-domain pipelined step alone
+  // is cheaper than that.  The repair launch leaves its count in a pinned host word per workspace; when the LAST
+  // lane-exponent step on this workspace recomputed more than an eighth of its utterances, this call goes straight to
+  // the log-domain step, and every 16th such call tries the lane-exponent step again (the data may have changed).
+  // Results are within the parity bar on either path (bit-identical only on the same path).  WFL_CTC_ADAPTIVE=0: off.
+  static const bool adaptive_on = [] {
+    const char* e = getenv("WFL_CTC_ADAPTIVE");
+    return !(e && atoi(e) == 0);
+  }();
+  bool prefer_log = false;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing((hipStream_t)stream, &capturing);  // (a captured step must not allocate, and replays one choice)
+  if (adaptive_on && ppl == 1 && capturing == hipStreamCaptureStatusNone) {
+    struct Seen {
+      int32_t* host = nullptr;
+      unsigned skipped = 0;
+    };
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, Seen> table;  // (device, workspace)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (table.size() > 64) {  // (workspaces come and go with the shapes: start over rather than grow)
+      for (auto& kv : table)
+        if (kv.second.host) (void)hipHostFree(kv.second.host);
+      table.clear();
+    }
+    Seen& e = table[{dev, (const void*)ws}];
+    if (!e.host && hipHostMalloc((void**)&e.host, 64, hipHostMallocDefault) == hipSuccess) e.host[0] = 0;
+    a.host_repaired = e.host;
+    if (e.host && (int64_t) * (volatile int32_t*)e.host * 8 > B) {
+      prefer_log = (++e.skipped & 15) != 0;
+    } else {
+      e.skipped = 0;
+    }
+  }
   // log-domain kernels (4-wave workgroups): dense row tiles while five workgroups share a CU with them, compact beyond
   const bool lcompact = ppl == 1 && C > 120;
   const size_t rows_lds = lcompact ? (size_t)4 * compact_wave_bytes(C) : (size_t)4 * (kBlk + 1) * C * 4;
@@ -2374,10 +2422,11 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   int rc = WFL_OK;
   // lane-exponent chains + certificate + repair launch: when the 8-wave gradient workgroups fit the LDS
   // (WFL_CTC_PIPELINE=log selects the log-domain chains)
-  static const bool force_log = [] {
+  static const bool env_log = [] {
     const char* e = getenv("WFL_CTC_PIPELINE");
     return e && std::string(e) == "log";
   }();
+  const bool force_log = env_log || prefer_log;
   const size_t rows8_lds = (size_t)kFWaves * kBlk * C * 4;
   // gradient rows as a dense LDS tile while three workgroups still fit a CU with it (C <= 100), compact beyond
   static const int force_tile = [] {

@@ -1405,3 +1405,39 @@ def test_ctc_loss_backward_without_the_engine_equals_the_engine(monkeypatch):
             got.grad = None
             (2.0 * ctc.CTCLoss(got, targets, C - 1)).backward()
             torch.testing.assert_close(got.grad, 2 * want.grad)
+
+
+def test_ctc_step_picks_the_log_domain_launch_while_the_certificate_keeps_rejecting():
+    """Scores without structure and a spread of 3 nats: the lane-exponent step's certificate rejects every utterance
+    (fast launch + log-domain repair launch).  The repair launch leaves its count in a pinned host word of the
+    workspace; the following calls on that workspace go straight to the log-domain step (no repairs reported, ~2/3
+    of the time), every 16th one tries the lane-exponent step again, and benign data brings the step back to it.
+    Every call -- whichever launch served it -- is within the parity bar of the float64 oracle."""
+    from gtn_applications_amd import engine as E
+
+    B, T, C, L = 16, 200, 40, 9
+    g = torch.Generator().manual_seed(21)
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    wild = 3.0 * torch.randn(B, T, C, generator=g)
+    calm = torch.randn(B, T, C, generator=g)
+    want = {id(t): OR.ctc_loss_grad_batched(t.numpy(), targets, C - 1) for t in (wild, calm)}
+
+    def step(x):
+        xd = x.cuda()
+        tg = E.targets_on_device(targets, xd.device)
+        scale, _, coef = E.loss_factors(tg, "none")
+        dx = torch.full_like(xd, float("nan"))
+        ws, nll = E.ctc_forward_backward(xd, tg, C - 1, coef, None, dx)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(nll.cpu().numpy(), want[id(x)][0], rtol=1e-4)
+        np.testing.assert_allclose(dx.cpu().numpy(), want[id(x)][1], rtol=1e-4, atol=1e-4 / B)
+        return E.ctc_pipeline_repaired(ws, B, T, tg.max_len)
+
+    first = step(wild)
+    assert first * 8 > B, "unstructured scores with a spread of 3 nats are expected to fail the certificate"
+    later = [step(wild) for _ in range(20)]
+    assert later.count(0) >= 17 and max(later) * 8 > B, later  # log-domain launches, with a lane-exponent probe in between
+    back = [step(calm) for _ in range(20)]
+    assert back[-1] == 0 and max(back) == 0, back
+    # ... and the step is on the lane-exponent launch again: wild data is caught by the certificate at once
+    assert step(wild) * 8 > B
