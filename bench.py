@@ -139,7 +139,7 @@ def dist_setup(n, stub_cpu=False):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(n, 1) and "WORLD_SIZE" in os.environ:
         raise SystemExit(f"bench.py: --gpus {n} but the launcher started WORLD_SIZE={world} ranks")
-    if world > 1:
+    if world > 1 or os.environ.get("WFL_BENCH_FORCE_DIST"):  # (the variable: RCCL plumbing on a 1-GPU box, world size 1)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
