@@ -119,7 +119,12 @@ struct StagedTargets {
   StagedTargets(const StagedTargets&) = delete;
   StagedTargets& operator=(const StagedTargets&) = delete;
   ~StagedTargets() {
-    if (up_event) (void)hipEventDestroy(up_event);
+    if (up_event) free_events(dev_index).push_back(up_event);  // (creating an event costs more than recording one: kept for the next batch)
+  }
+  int dev_index = 0;  // (an event belongs to the device it was created on)
+  static std::vector<hipEvent_t>& free_events(int dev) {
+    static std::unordered_map<int, std::vector<hipEvent_t>> pools;
+    return pools[dev];
   }
 };
 
@@ -240,7 +245,15 @@ std::shared_ptr<StagedTargets> stage_targets(const py::handle& targets, const at
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(rows[b]);
     PyObject** it = PySequence_Fast_ITEMS(rows[b]);
     for (Py_ssize_t i = 0; i < n; ++i) {
-      const long v = PyLong_AsLong(it[i]);
+      long v;
+      PyObject* o = it[i];
+      // (exact ints of one 30-bit digit -- every label there is -- without the call: CPython 3.10's long layout)
+      if (PyLong_CheckExact(o) && (Py_SIZE(o) == 1 || Py_SIZE(o) == 0)) {
+        v = Py_SIZE(o) ? (long)reinterpret_cast<PyLongObject*>(o)->ob_digit[0] : 0;
+        put(v);
+        continue;
+      }
+      v = PyLong_AsLong(o);
       if (v == -1 && PyErr_Occurred()) {
         PyErr_Clear();
         tc.ring.i = (tc.ring.i + PinnedRing::kSlots - 1) % PinnedRing::kSlots;  // slot not used
@@ -282,7 +295,15 @@ std::shared_ptr<StagedTargets> stage_targets(const py::handle& targets, const at
   check(wfl_upload(st->dev_buf.data_ptr(), base, nbytes, (void*)stream), "stage_targets");
   tc.ring.uploaded(slot, stream);
   st->up_stream = stream, st->slot = slot;
-  if (hipEventCreateWithFlags(&st->up_event, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(st->up_event, stream);
+  {
+    st->dev_index = dev.index();
+    auto& pool = StagedTargets::free_events(st->dev_index);
+    if (!pool.empty())
+      st->up_event = pool.back(), pool.pop_back();
+    else if (hipEventCreateWithFlags(&st->up_event, hipEventDisableTiming) != hipSuccess)
+      st->up_event = nullptr;
+    if (st->up_event) (void)hipEventRecord(st->up_event, stream);
+  }
   if (hit != tc.index.end()) {  // (same hash, different bytes: replace)
     tc.lru.erase(hit->second);
     tc.index.erase(hit);
