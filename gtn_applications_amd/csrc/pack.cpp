@@ -566,6 +566,7 @@ namespace {
 class HostPool {
  public:
   explicit HostPool(int nthreads) : nworkers_(nthreads) {
+    if (const char* e = getenv("WFL_HOST_SPIN_US")) spin_ns_ = (long long)std::max(0, atoi(e)) * 1000;
     sem_init(&done_, 0, 0);
     for (int i = 0; i < nthreads; ++i) std::thread([this, i] { worker(i); }).detach();
   }
@@ -607,6 +608,20 @@ class HostPool {
     uint32_t seen = 0;
     for (;;) {
       uint32_t g;
+      // Optionally stay hot for a while before sleeping (WFL_HOST_SPIN_US): measured on the 256-core box with 1000 us,
+      // same box A/B over the fresh-target steps of cfg3 / cfg4: no consistent gain (0.70-0.75 ms either way at cfg4)
+      // and more variance (a polling worker on the caller's sibling hyperthread) -- the build of 64 alignment graphs
+      // takes ~400 us on 32 threads against 60 us each alone because the graph algebra allocates, not because the
+      // workers wake slowly.  Off by default.
+      if (spin_ns_ > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0; (g = gen_.load(std::memory_order_acquire)) == seen; ++it) {
+          __builtin_ia32_pause();
+          if ((it & 63) == 63 &&
+              std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > spin_ns_)
+            break;
+        }
+      }
       while ((g = gen_.load(std::memory_order_acquire)) == seen)
         syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen_), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
       seen = g;
@@ -623,6 +638,10 @@ class HostPool {
   std::atomic<int> next_{0}, running_{0};
   int n_ = 0;
   uint32_t count_ = 0;  // generation counter (upper 24 bits of gen_), advanced under run_mu_
+  long long spin_ns_ = 0;  // how long a worker polls for the next job before it sleeps (WFL_HOST_SPIN_US; default: not at all)
+ public:
+  bool hot() const { return spin_ns_ > 0; }
+ private:
 };
 
 std::mutex g_pool_mu;
@@ -778,8 +797,12 @@ wfl_lattice_host* merge_direct(std::vector<Builder>& parts, int np, int B, int C
       if (!src.empty()) memcpy(F + *bulk_foff[f] + fpos[f][p], src.data(), src.size() * sizeof(float));
     }
   };
-  // (serial: ~2 MB of memcpy takes 50 us here, a second pass over the pool 140 us in wake-ups alone)
-  for (int p = 0; p < np; ++p) copy_part(p);
+  // (serial unless the pool's workers are kept polling: ~2 MB of memcpy takes 50 us here, a second pass over a
+  // sleeping pool 140 us in wake-ups alone)
+  if (np >= 16 && host_pool().hot())
+    host_pool().parallel_for(np, copy_part);
+  else
+    for (int p = 0; p < np; ++p) copy_part(p);
   return h;
 }
 
