@@ -123,8 +123,10 @@ struct StagedTargets {
   }
   int dev_index = 0;  // (an event belongs to the device it was created on)
   static std::vector<hipEvent_t>& free_events(int dev) {
-    static std::unordered_map<int, std::vector<hipEvent_t>> pools;
-    return pools[dev];
+    // (never destroyed: the target caches are torn down by static destructors at exit, in no particular order, and
+    // their entries come through here)
+    static auto* pools = new std::unordered_map<int, std::vector<hipEvent_t>>();
+    return (*pools)[dev];
   }
 };
 

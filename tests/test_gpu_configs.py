@@ -353,3 +353,23 @@ def test_asg_beyond_the_on_chip_class_limit(C, B, T, L):
         collapsed = [p for p, _ in itertools.groupby(path)]
         collapsed = [p for p in collapsed if p != crit.garbage_idx]
         assert got[b].tolist() == asg.unpack_replabels(collapsed, 1)
+
+
+def test_ctc_batches_with_more_sweeps_than_cus():
+    """B = 160 at the cfg2 shape: 320 sweeps on 256 CUs -- the meet-in-the-middle step switches to its 8-wave workgroups,
+    two per CU (csrc/ctc_mitm.h MitmK<8>).  Every utterance against the float64 oracle, ragged targets included
+    (lengths 1 .. 44, one empty), plus the mean reduction."""
+    from gtn_applications_amd.criterions import ctc
+
+    B, T, C, L = 160, 1000, 100, 44
+    g = torch.Generator().manual_seed(160)
+    x = torch.randn(B, T, C, generator=g)
+    lens = torch.randint(1, L + 1, (B,), generator=g).tolist()
+    lens[7] = 0
+    targets = [torch.randint(C - 2, (n,), generator=g).tolist() for n in lens]
+    want_loss, want_dx = OR.ctc_loss_grad_batched(x.numpy(), targets, C - 1)
+    xg = x.cuda().requires_grad_(True)
+    loss = ctc.CTCLoss(xg, targets, C - 1)
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss.mean(), rel=RTOL)
+    check("ctc_b160_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / B)
