@@ -2452,26 +2452,37 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     return e ? atoi(e) : 0;
   }();
   const bool small_wg = shape_env ? shape_env == 8 : 2 * (int64_t)B > cus;
-  auto mitm_lds_of = [](auto k) {
+  auto mitm_lds_of = [&](auto k, bool wide) {
     using K = decltype(k);
-    return ((sizeof(MitmLds<K>) + 15) & ~(size_t)15) + (size_t)K::kEmitters * kBlk * kMTile * 4;
+    const size_t tiles = wide ? (size_t)K::kEmitters * kBlk * kCS * 4 + (((size_t)C + 15) & ~(size_t)15)  // compact tiles + column map
+                              : (size_t)K::kEmitters * kBlk * kMTile * 4;
+    return ((sizeof(MitmLds<K>) + 15) & ~(size_t)15) + tiles;
   };
   static_assert(((sizeof(MitmLds<MitmK<16>>) + 15) & ~(size_t)15) + (size_t)MitmK<16>::kEmitters * kBlk * kMTile * 4 <= (size_t)kLdsBytes,
                 "ctc_mitm.h: LDS of the 16-wave shape");
   static_assert(2 * (((sizeof(MitmLds<MitmK<8>>) + 15) & ~(size_t)15) + (size_t)MitmK<8>::kEmitters * kBlk * kMTile * 4) <= (size_t)kLdsBytes,
                 "ctc_mitm.h: two 8-wave workgroups per CU");
-  if (ppl == 1 && !force_log && mitm_env && !row_lse && C <= kMTile) {
-    if (small_wg) {
-      const size_t lds = mitm_lds_of(MitmK<8>{});
-      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)ctc_mitm_kernel<MitmK<8>, false>, (int)lds));
-      hipLaunchKernelGGL((ctc_mitm_kernel<MitmK<8>, false>), dim3((unsigned)(2 * B)), dim3(MitmK<8>::kWaves * 64), lds,
-                         (hipStream_t)stream, a, coef, gout, dx);
-    } else {
-      const size_t lds = mitm_lds_of(MitmK<16>{});
-      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)ctc_mitm_kernel<MitmK<16>, false>, (int)lds));
-      hipLaunchKernelGGL((ctc_mitm_kernel<MitmK<16>, false>), dim3((unsigned)(2 * B)), dim3(MitmK<16>::kWaves * 64), lds,
-                         (hipStream_t)stream, a, coef, gout, dx);
-    }
+  // rows wider than the dense tile: the emitters accumulate in the compact tile and expand through a column map
+  // (WIDE); its LDS: one byte per class behind the tiles
+  static const int wide_env = [] {
+    const char* e = getenv("WFL_CTC_MITM_WIDE");  // 0: rows wider than 128 classes through the round-2 pipelined launch
+    return e ? atoi(e) : 1;
+  }();
+  const bool wide = C > kMTile;
+  const bool wide_fits = small_wg ? 2 * mitm_lds_of(MitmK<8>{}, true) <= (size_t)kLdsBytes : mitm_lds_of(MitmK<16>{}, true) <= (size_t)kLdsBytes;
+  if (ppl == 1 && !force_log && mitm_env && !row_lse && (!wide || (wide_env && wide_fits))) {
+    auto launch_mitm = [&](auto kern, auto k) -> int {
+      using K = decltype(k);
+      const size_t lds = mitm_lds_of(k, wide);
+      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)(2 * B)), dim3(K::kWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
+      return WFL_OK;
+    };
+    if (small_wg)
+      rc = wide ? launch_mitm(ctc_mitm_kernel<MitmK<8>, false, true>, MitmK<8>{}) : launch_mitm(ctc_mitm_kernel<MitmK<8>, false, false>, MitmK<8>{});
+    else
+      rc = wide ? launch_mitm(ctc_mitm_kernel<MitmK<16>, false, true>, MitmK<16>{}) : launch_mitm(ctc_mitm_kernel<MitmK<16>, false, false>, MitmK<16>{});
+    if (rc) return rc;
     WFL_LAUNCH_CHECK();
     a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
     if (a.token == 0) a.token = 1;

@@ -130,6 +130,7 @@ struct MitmLds {
                                    // checkpoints < p - 1 (ONE post per block)
   int ckdone;                      // ... picked up by the flusher (offc valid)
   int offdone;                     // offtot valid
+  int cmap_ready;                  // (wide rows) the column -> slot map behind the emitters' tiles is written
 #if WFL_MITM_STATS
   long long blk_t[64];             // chain wave: clock at the start of every block (the first 64)
 #endif
@@ -159,11 +160,11 @@ typedef float mv2f __attribute__((ext_vector_type(2)));
 //                                  factor of the scaled recursion is 2^(ea[i] - ea[i+1]) (bounded by the chain's clamp)
 //   posterior_j(s) = own_j(s) [A part_{j+1}](s)   -- one packed multiply per frame and lane pair
 // DIR: tile row of frame j (the reversed sweep only emits complete blocks, FULL).
-template <class K, int DIR, bool FULL>
+template <class K, int DIR, bool FULL, bool WIDE>
 __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f sa, int ea, float4 pk, float rsum, double off_sum,
                                                     MitmLds<K>& S, bool first,
                                                     int cnt, float cf, float g, float gs, bool skipn, bool owner, bool adder,
-                                                    int lane, float* rows, int ycol, int blank, int C, long long* zmm,
+                                                    int lane, float* rows, const unsigned char* cmap, int ycol, int blank, int C, long long* zmm,
                                                     float* __restrict__ dst, long long* st_part) {
 #if WFL_MITM_STATS
   const long long st_e0 = clock64();
@@ -274,17 +275,20 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
   // ---- gradient rows
   constexpr int R0 = DIR == 0 ? 0 : kBlk - 1, RS = DIR == 0 ? 1 : -1;  // tile row of frame j: R0 + RS * j
   const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
-  if (lane < (FULL ? kBlk : cnt)) rows[(R0 + RS * lane) * kMTile + blank] = gtot;
+  // (WIDE: the compact tile of ctc_kernels.hip -- [16][kCS] floats, one slot per target position, 63 the blank, 64 zero --
+  // `ycol` is then the slot, `blank` 63, and the dense rows are expanded through the column map while they are written)
+  constexpr int TS = WIDE ? kCS : kMTile;
+  if (lane < (FULL ? kBlk : cnt)) rows[(R0 + RS * lane) * TS + blank] = gtot;
   float* cell = rows + ycol;
   if (owner) {
 #pragma unroll
     for (int j = 0; j < kBlk; ++j)
-      if (FULL || j < cnt) cell[(R0 + RS * j) * kMTile] = glv[j];
+      if (FULL || j < cnt) cell[(R0 + RS * j) * TS] = glv[j];
   }
   if (adder) {
 #pragma unroll
     for (int j = 0; j < kBlk; ++j)
-      if (FULL || j < cnt) atomicAdd(&cell[(R0 + RS * j) * kMTile], glv[j]);
+      if (FULL || j < cnt) atomicAdd(&cell[(R0 + RS * j) * TS], glv[j]);
   }
 #if WFL_MITM_STATS
   st_part[4] += __builtin_amdgcn_readfirstlane(__float_as_int(gtot)) * 0 + clock64() - st_e0;
@@ -309,6 +313,11 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
 #endif
   const int nrows = FULL ? kBlk : cnt;
   if (WFL_MITM_ABL & 64) return;  // (scratch: a launch that computes the rows and does not store them)
+  if (WIDE) {
+    asm volatile("" ::: "memory");  // (the tile was written through float pointers)
+    compact_expand(rows, cmap, dst, nullptr, 0.f, nrows, C, 1.f, true, false, lane);
+    return;
+  }
   if ((C & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
     // two rows per instruction: lanes 0..31 one row, lanes 32..63 the next (C / 4 <= 32 float4 per row)
     const int half = lane >> 5, c4 = lane & 31;
@@ -347,25 +356,44 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
   }
 }
 
-template <class K, bool LSM, int DIR>
+template <class K, bool LSM, int DIR, bool WIDE>
 __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S, int b, int em, int H0, int NB, int L, int y,
                                                  bool skip, bool skipn, bool has_label, const float* __restrict__ coef,
                                                  const float* __restrict__ gout, float* __restrict__ dx, char* smem,
                                                  const CtcWs& w) {
   const int lane = threadIdx.x & 63;
   const int T = a.T, C = a.C;
-  float* rows = (float*)(smem + ((sizeof(MitmLds<K>) + 15) & ~(size_t)15)) + (size_t)em * kBlk * kMTile;
-  for (int i = lane; i < kBlk * kMTile; i += 64) rows[i] = 0.f;
+  constexpr int kTileFloats = WIDE ? kBlk * kCS : kBlk * kMTile;
+  float* const tiles = (float*)(smem + ((sizeof(MitmLds<K>) + 15) & ~(size_t)15));
+  float* rows = tiles + (size_t)em * kTileFloats;
+  unsigned char* cmap = (unsigned char*)(tiles + (size_t)K::kEmitters * kTileFloats);  // (WIDE) [C] bytes, one per workgroup
+  for (int i = lane; i < kTileFloats; i += 64) rows[i] = 0.f;
   // Labels that occur once in the target own their gradient column: plain ds_write.  A repeated label's first
   // occurrence owns the column, the others add to it afterwards; a target label equal to the blank index adds to
   // the blank column.  (Columns are the same for every block of the sweep: the tile is zeroed once.)
   bool owner = has_label && y != a.blank;
+  int first = lane;  // lane of the label's first occurrence: its slot in the compact tile
   for (int j = 0; j < L; ++j) {
     const bool same = __builtin_amdgcn_readlane(y, j) == y;
-    if (same && j < lane) owner = false;
+    if (same && j < lane) owner = false, first = min(first, j);
   }
   const bool adder = has_label && !owner;
-  const int ycol = has_label ? y : 0;
+  const int ycol = WIDE ? (has_label ? (y == a.blank ? 63 : first) : 64) : (has_label ? y : 0);
+  if (WIDE) {
+    // the column -> slot map of the utterance, written by emitter 0 (a wave's DS operations execute in order: no
+    // barrier between the fill and the labels' entries), the other emitters look at the flag before their first block
+    if (em == 0) {
+      for (int i = lane; i < ((C + 15) & ~15) / 4; i += 64) ((unsigned int*)cmap)[i] = 0x40404040u;  // 64: the zero slot
+      if (owner) cmap[y] = (unsigned char)lane;
+      if (lane == 0) cmap[a.blank] = 63;
+      lds_post(&S.cmap_ready, 1);
+    } else {
+      for (int spin = 0; lds_peek(&S.cmap_ready) != 1; ++spin) {
+        __builtin_amdgcn_s_sleep(8);
+        if (spin > kMSpin) __builtin_trap();
+      }
+    }
+  }
   const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
   long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
 #if WFL_MITM_STATS
@@ -432,11 +460,11 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
       continue;
     }
     if (cnt == kBlk)
-      ctc_mitm_emit_block<K, DIR, true>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                     ycol, a.blank, C, zmm, dst, st_part);
+      ctc_mitm_emit_block<K, DIR, true, WIDE>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+                                     cmap, ycol, WIDE ? 63 : a.blank, C, zmm, dst, st_part);
     else if (DIR == 0)
-      ctc_mitm_emit_block<K, 0, false>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                    ycol, a.blank, C, zmm, dst, st_part);
+      ctc_mitm_emit_block<K, 0, false, WIDE>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+                                    cmap, ycol, WIDE ? 63 : a.blank, C, zmm, dst, st_part);
     MITM_ACC(st_wait2);
   }
 #if WFL_MITM_STATS
@@ -453,7 +481,7 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
 #endif
 }
 
-template <class K, bool LSM>
+template <class K, bool LSM, bool WIDE>
 __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, const float* __restrict__ coef,
                                               const float* __restrict__ gout, float* __restrict__ dx, char* smem) {
   MitmLds<K>& S = *reinterpret_cast<MitmLds<K>*>(smem);
@@ -481,7 +509,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
   if (threadIdx.x < K::kSlots) S.egrab[threadIdx.x] = 0;
   if (threadIdx.x < K::kPSlots) S.pgrab[threadIdx.x] = 0;
   if (threadIdx.x == 0) S.enext = mitm_first_emitted(ctc_blocks(a.T), dir), S.zready = 0;
-  if (threadIdx.x == 0) S.chainpos = 0, S.ckdone = 0, S.offdone = 0;
+  if (threadIdx.x == 0) S.chainpos = 0, S.ckdone = 0, S.offdone = 0, S.cmap_ready = 0;
 #if WFL_MITM_STATS
   if (threadIdx.x < 64) S.blk_t[threadIdx.x] = 0;
 #endif
@@ -913,12 +941,12 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
 
   // ================================================================ emitters
   if (dir == 0)
-    ctc_mitm_emitter<K, LSM, 0>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
+    ctc_mitm_emitter<K, LSM, 0, WIDE>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
   else
-    ctc_mitm_emitter<K, LSM, 1>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
+    ctc_mitm_emitter<K, LSM, 1, WIDE>(a, S, b, ridx, H0, NB, L, y, skip, skipn, has_label, coef, gout, dx, smem, w);
 }
 
-template <class K, bool LSM>
+template <class K, bool LSM, bool WIDE = false>
 __global__ void __launch_bounds__(K::kWaves * 64, 4)  // (second argument: waves per SIMD -- at most 128 VGPRs, so that two
                                                      // 8-wave workgroups share a CU)
     ctc_mitm_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
@@ -929,8 +957,8 @@ __global__ void __launch_bounds__(K::kWaves * 64, 4)  // (second argument: waves
     perr[1] = 0;  // utterances the repair launch recomputed
   }
 #ifdef WFL_MITM_FLIP
-  ctc_mitm_body<K, LSM>(a, (int)blockIdx.x >> 1, 1 - ((int)blockIdx.x & 1), coef, gout, dx, smem);
+  ctc_mitm_body<K, LSM, WIDE>(a, (int)blockIdx.x >> 1, 1 - ((int)blockIdx.x & 1), coef, gout, dx, smem);
 #else
-  ctc_mitm_body<K, LSM>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, coef, gout, dx, smem);
+  ctc_mitm_body<K, LSM, WIDE>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, coef, gout, dx, smem);
 #endif
 }
