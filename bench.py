@@ -486,8 +486,9 @@ def main():
         wl = make_transducer(args, rank, n_batches)
     meta = wl["meta"]
     if args.workload == "ctc":  # which launches the CTC step is at this row width (csrc/ctc_kernels.hip wfl_ctc_forward_backward)
-        names = (["ctc_mitm_kernel", "ctc_repair_kernel"] if meta["C"] <= 128
-                 else ["ctc_compact_x_kernel", "ctc_fast_pipelined_kernel", "ctc_repair_kernel"])
+        legacy_wide = meta["C"] > 128 and os.environ.get("WFL_CTC_MITM_WIDE", "1") == "0"
+        names = (["ctc_compact_x_kernel", "ctc_fast_pipelined_kernel", "ctc_repair_kernel"] if legacy_wide
+                 else ["ctc_mitm_kernel", "ctc_repair_kernel"])
         PHASE_KERNEL_NAMES["ctc_step"] = names
         PHASE_KERNELS["ctc_step"] = " + ".join(names)
     if args.mode == "abi" and "abi_step" not in wl:

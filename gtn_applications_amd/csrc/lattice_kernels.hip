@@ -856,6 +856,13 @@ __device__ __forceinline__ int64_t xg_main_dev(const wfl_lattice_desc& d, int T)
   return (((int64_t)d.B * T * d.max_labels) + 3) & ~(int64_t)3;
 }
 constexpr double kLog2e_d = 1.4426950408889634074;
+// The sweeps' per-frame stores: write-through (sc1) when the gradient runs beside the sweeps and reads them from
+// another XCD (WFL_SWEEP_WT), plain otherwise.
+#ifdef WFL_SWEEP_WT
+#define WFL_SWEEP_STORE(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define WFL_SWEEP_STORE(ptr, v) (*(ptr) = (v))
+#endif
 constexpr int kDumpDoubles = 1024;  // scratch behind the alpha / beta tails (see run_chain_prob)
 constexpr int kBandDepth = 4;
 // floats of the probability-domain sweeps' row tile: two chunks of the tile path, or the banded sweep's two tiles of
@@ -1226,7 +1233,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
           }
           p = acc0 + acc1;
           to[tid] = p;
-          *po = p;
+          WFL_SWEEP_STORE(po, p);
           po += pstep;
 #pragma unroll
           for (int k = 0; k < DEG; ++k) c[k] = cn[k];
@@ -1250,7 +1257,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         p = acc0 + acc1;
         if (tid < Q) {
           to[tid] = p;
-          orow[tid] = p;
+          WFL_SWEEP_STORE(orow + tid, p);
         }
 #pragma unroll
         for (int k = 0; k < DEG; ++k) c[k] = cn[k];
@@ -1312,7 +1319,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
           const double sum = acc0 + acc1;
           p = DIR == 0 ? sum * (double)f : sum;
           to[tid] = DIR == 0 ? p : p * (double)f;
-          *po = p;
+          WFL_SWEEP_STORE(po, p);
           po += pstep;
           lds_barrier();
         }
@@ -1336,7 +1343,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         p = DIR == 0 ? sum * (double)f : sum;
         if (tid < Q) {
           to[tid] = DIR == 0 ? p : p * (double)f;
-          orow[tid] = p;
+          WFL_SWEEP_STORE(orow + tid, p);
         }
         orow = DIR == 0 ? orow + Q : orow - Q;
         if (DIR == 0 || i + 2 < n) fptr = DIR == 0 ? fptr + Kmax : fptr - Kmax;
