@@ -113,6 +113,10 @@ _SIGS = {
         c_int,
         [POINTER(LatticeDesc), _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P],
     ),
+    "wfl_lattice_forward_grad": (
+        c_int, [POINTER(LatticeDesc), _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(c_int), _P]),
+    "wfl_lattice_grad_rest": (
+        c_int, [POINTER(LatticeDesc), _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "wfl_lattice_backtrace": (c_int, [POINTER(LatticeDesc), _P, _P, _P, _P, c_int, _P, _P, c_int, _P]),
     "wfl_debug_grad_occupancy": (c_int, [c_int]),
     # device: ConvTransduce1D

@@ -16,6 +16,9 @@
 // This replaces gtn.intersect(emissions, A) + gtn.forward_score / viterbi_path + gtn.backward
 // (criterions/ctc.py:49-51,78-81; asg.py:111-113; stc.py:85-87; transducer.py:283,321-325) without
 // ever materialising the T*|A| composed lattice.  Memory/latency-bound DP: no MFMA by design.
+#include <atomic>
+#include <map>
+#include <mutex>
 #include <cstdlib>
 #include <string>
 #include <type_traits>
@@ -856,13 +859,49 @@ __device__ __forceinline__ int64_t xg_main_dev(const wfl_lattice_desc& d, int T)
   return (((int64_t)d.B * T * d.max_labels) + 3) & ~(int64_t)3;
 }
 constexpr double kLog2e_d = 1.4426950408889634074;
-// The sweeps' per-frame stores: write-through (sc1) when the gradient runs beside the sweeps and reads them from
-// another XCD (WFL_SWEEP_WT), plain otherwise.
-#ifdef WFL_SWEEP_WT
-#define WFL_SWEEP_STORE(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#else
 #define WFL_SWEEP_STORE(ptr, v) (*(ptr) = (v))
-#endif
+// ---- progress words of the sweeps (the in-launch gradient, prob_chain_occ_kernel) ---------------------------------
+// One 64-bit word per (utterance, direction) behind the dump area of the alpha / beta tails:
+//     [63:32] launch token   [31:28] XCC id of the sweep's workgroup   [27:0] chunks whose stores have reached L2
+// written by thread 0 of the sweep with one write-through store, polled by the gradient workgroups of the same launch.
+// The token (a per-launch counter from the host) makes words left by earlier launches read as "not yet".
+constexpr uint32_t kProgSkip = 0x0fffffffu;  // the utterance is not swept in the probability domain
+__device__ __forceinline__ uint32_t xcc_id() {
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+  return v & 15u;
+}
+__device__ __forceinline__ void prog_publish(uint64_t* w, uint32_t token, uint32_t chunks) {
+  __hip_atomic_store(w, ((uint64_t)token << 32) | ((uint64_t)xcc_id() << 28) | chunks, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__host__ __device__ inline int64_t prog_offset_doubles(const wfl_lattice_desc& d, int nch1) {  // from the tail's start
+  return (int64_t)d.B * nch1 + 2 * (int64_t)d.B + 1024 + 1;
+}
+// header of the in-flight gradient, behind the progress words and `bad` of the alpha tail (int32 units)
+struct OccHeader {
+  uint32_t* bad;    // [B]
+  int32_t* nx;      // [8]  utterances whose sweeps run on XCD x
+  uint32_t* next;   // [8]  next job of XCD x
+  int32_t* list;    // [8][B]
+  uint32_t* busy;   // [8][256]  == token while a sweep runs on CU (xcc, HW_ID[15:8])
+};
+__device__ __forceinline__ uint32_t cu_key() {  // this wave's CU among the 8 x 256 the ids can name
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+  return (xcc_id() & 7u) * 256u + ((v >> 8) & 255u);
+}
+__device__ __forceinline__ OccHeader occ_header(const wfl_lattice_desc& d, float* alpha, int64_t tail, int nch1) {
+  OccHeader h;
+  double* ta = reinterpret_cast<double*>(alpha + tail) + prog_offset_doubles(d, nch1);
+  h.bad = reinterpret_cast<uint32_t*>(ta + d.B);
+  h.nx = reinterpret_cast<int32_t*>(h.bad + ((d.B + 1) & ~1));
+  h.next = reinterpret_cast<uint32_t*>(h.nx + 8);
+  h.list = h.nx + 16;
+  h.busy = reinterpret_cast<uint32_t*>(h.list + 8 * (int64_t)d.B);
+  return h;
+}
+
 constexpr int kDumpDoubles = 1024;  // scratch behind the alpha / beta tails (see run_chain_prob)
 constexpr int kBandDepth = 4;
 // floats of the probability-domain sweeps' row tile: two chunks of the tile path, or the banded sweep's two tiles of
@@ -915,12 +954,14 @@ __device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {  // NT
 
 // BAND: the register-resident banded sweep is compiled in (chain wave + loader wave workgroups); UNR: full chunks as
 // straight-line code (not for the 1024-thread instantiation: its 128-register budget would spill)
-template <int DIR, bool BAND, bool UNR = true>
+// PUB: the sweep publishes its progress (prog_publish) for the gradient workgroups of the same launch
+template <int DIR, bool BAND, bool UNR = true, bool PUB = false>
 __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const UttView& u, const ProbLds& L, int T, int R,
                                const float* __restrict__ fg, const float* __restrict__ rmax,
                                const float* __restrict__ weights, double* __restrict__ out, float* __restrict__ logz,
                                int b, double* __restrict__ offs, double* __restrict__ z64, float* __restrict__ wref_out,
-                               double* __restrict__ dump) {  // dump: kDumpDoubles doubles nobody reads
+                               double* __restrict__ dump,  // dump: kDumpDoubles doubles nobody reads
+                               uint64_t* prog = nullptr, uint32_t token = 0) {
   const int tid = threadIdx.x, NT = blockDim.x;
   const int Q = u.Q, Kmax = d.max_labels;
   // ---- this thread's state: its in-arcs (forward) / out-arcs (backward) in registers
@@ -1407,8 +1448,19 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         if (e < pn * Kmax) dst[e] = pre[j];
       }
       if (tid < pn) L.refs[(size_t)((c + 1) & 1) * R + tid] = rpre;
+      if (PUB) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (see below)
       __syncthreads();
+      // Chunk c - 1 is in L2: its stores are older than this chunk's prefetch loads and its (at most 16) frame stores,
+      // vmcnt counts loads and stores in issue order, and every thread has just waited until at most 16 of its
+      // operations were outstanding.  (One chunk of lag costs the gradient nothing; waiting for THIS chunk's stores
+      // would put a store round trip, ~1.5 us, behind every 16 frames.)
+      if (PUB && tid == 0 && c > 0) prog_publish(prog, token, (uint32_t)c);
     }
+  }
+  if (PUB) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) prog_publish(prog, token, (uint32_t)max(nchunks, 1));
   }
   // log2 of the total: alpha over the accept states at slot T, beta over the start states at slot 0
   {
@@ -1425,18 +1477,13 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
 
 // The probability-domain sweeps as their own kernel (their register budget is not the general path's): utterances it
 // does not take are left to the log-domain launch that follows (chain_kernel, mode 2).
-template <int MAXT>
-__global__ void __launch_bounds__(MAXT)
-    prob_chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
-                      const float* __restrict__ xg, int T, int rows_per_chunk, const float* __restrict__ weights,
-                      float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz, int64_t tail,
-                      int nch1) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifndef WFL_BAND_PRIO
-#define WFL_BAND_PRIO 0
-#endif
-  if (MAXT == 128 && WFL_BAND_PRIO) __builtin_amdgcn_s_setprio(WFL_BAND_PRIO);
-  const int b = blockIdx.x, dir = blockIdx.y;
+template <int MAXT, bool PUB>
+__device__ __forceinline__ void prob_chain_body(const wfl_lattice_desc& d, const int32_t* __restrict__ ints,
+                                                const float* __restrict__ floats, const float* __restrict__ xg, int T,
+                                                int rows_per_chunk, const float* __restrict__ weights,
+                                                float* __restrict__ alpha, float* __restrict__ beta,
+                                                float* __restrict__ logz, int64_t tail, int nch1, int b, int dir, char* smem,
+                                                uint32_t token) {
   const UttView u = make_view(d, ints, floats, b, T);
   double* offs_a = reinterpret_cast<double*>(alpha + tail);  // (tail layout: see chain_kernel)
   double* offs_b = beta ? reinterpret_cast<double*>(beta + tail) : nullptr;
@@ -1444,7 +1491,12 @@ __global__ void __launch_bounds__(MAXT)
   double* zb = offs_b ? offs_b + (int64_t)d.B * nch1 : nullptr;
   int32_t* fmt = reinterpret_cast<int32_t*>(za + d.B);
   float* wrefs = reinterpret_cast<float*>(fmt + d.B);
-  if (!prob_eligible(u, blockDim.x)) return;
+  uint64_t* prog = PUB ? reinterpret_cast<uint64_t*>((dir == 0 ? offs_a : offs_b) + prog_offset_doubles(d, nch1)) + b : nullptr;
+  if (!prob_eligible(u, blockDim.x)) {
+    if (PUB && threadIdx.x == 0) prog_publish(prog, token, kProgSkip);
+    return;
+  }
+  if (PUB && threadIdx.x == 0) prog_publish(prog, token, 0u);  // "resident" (occ_gate_kernel waits for it)
   ProbLds P;
   char* p = smem;
   const size_t nvec = max((size_t)d.max_states, (size_t)blockDim.x);  // (one entry per THREAD: every lane may write)
@@ -1457,13 +1509,28 @@ __global__ void __launch_bounds__(MAXT)
   const float* rmax = fg + xg_main_dev(d, T);
   if (dir == 0) {
     if (threadIdx.x == 0) fmt[b] = kFmtProb;
-    run_chain_prob<0, MAXT == 128, MAXT <= 512>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
-                      offs_a + (int64_t)b * nch1, za, wrefs, offs_a + (int64_t)d.B * nch1 + 2 * (int64_t)d.B);
+    run_chain_prob<0, MAXT == 128, MAXT <= 512, PUB>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
+                      offs_a + (int64_t)b * nch1, za, wrefs, offs_a + (int64_t)d.B * nch1 + 2 * (int64_t)d.B, prog, token);
   } else {
     if (threadIdx.x == 0) zb[d.B + b] = 0.0;  // the certificate's verdict: raised by prob_certify_kernel
-    run_chain_prob<1, MAXT == 128, MAXT <= 512>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
-                      offs_b + (int64_t)b * nch1, zb, nullptr, offs_b + (int64_t)d.B * nch1 + 2 * (int64_t)d.B);
+    run_chain_prob<1, MAXT == 128, MAXT <= 512, PUB>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
+                      offs_b + (int64_t)b * nch1, zb, nullptr, offs_b + (int64_t)d.B * nch1 + 2 * (int64_t)d.B, prog, token);
   }
+}
+
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT)
+    prob_chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                      const float* __restrict__ xg, int T, int rows_per_chunk, const float* __restrict__ weights,
+                      float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz, int64_t tail,
+                      int nch1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef WFL_BAND_PRIO
+#define WFL_BAND_PRIO 0
+#endif
+  if (MAXT == 128 && WFL_BAND_PRIO) __builtin_amdgcn_s_setprio(WFL_BAND_PRIO);
+  prob_chain_body<MAXT, false>(d, ints, floats, xg, T, rows_per_chunk, weights, alpha, beta, logz, tail, nch1, blockIdx.x,
+                               blockIdx.y, smem, 0u);
 }
 
 // Certificate of the probability-domain sweeps.  A double holds a spread of 2^1000 between the largest state and
@@ -1474,7 +1541,8 @@ __global__ void __launch_bounds__(MAXT)
 // utterance; verdict[b] = 1 sends the utterance to the log-domain launch that follows.
 __global__ void __launch_bounds__(256)
     prob_certify_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T,
-                        const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt) {
+                        const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt,
+                        uint32_t token, int ntiles) {
   // grid (B, kCertSplit): every wave takes the checked slots s = wave index, + number of waves, ... on its own
   // (wave-level reductions only); a wave that finds a violation raises the utterance's verdict (cleared by the beta
   // sweep of prob_chain_kernel before it started)
@@ -1489,6 +1557,19 @@ __global__ void __launch_bounds__(256)
   if (!prob_eligible(u, chain_nt)) {
     if (tid == 0) *verdict = 1.0;  // (not swept in the probability domain at all: the log-domain launch takes it)
     return;
+  }
+  if (token) {  // a gradient workgroup of the sweeps' launch could not vouch for what it read (occ_grad_tiles)
+    const OccHeader h = occ_header(d, const_cast<float*>(alpha), tail, nch1);
+    bool redo = h.bad[b] == token;
+    if (!redo) {  // every job of the utterance's XCD drawn?  (an XCD without gradient workgroups leaves them)
+      const uint64_t va = reinterpret_cast<const uint64_t*>(reinterpret_cast<const double*>(alpha + tail) + prog_offset_doubles(d, nch1))[b];
+      const uint32_t x = ((uint32_t)va >> 28) & 7u;
+      redo = h.next[x] < (uint32_t)h.nx[x] * (uint32_t)ntiles;
+    }
+    if (redo) {
+      if (tid == 0) *verdict = 1.0;
+      return;
+    }
   }
   if (za == -__builtin_inf() && zbv == -__builtin_inf()) return;  // no accepting path: exact in any arithmetic
   const double* pa = reinterpret_cast<const double*>(alpha) + u.ab_base;
@@ -1628,53 +1709,63 @@ __device__ __forceinline__ void stream_grad_rows(int b, int ts0, int nr, int T, 
     return v;
   };
   if (C >= 512) {
-    // wide rows: one float4 per thread and row (rows are only 4-byte aligned: scalar head / tail).  Four rows at a
-    // time with ALL their loads -- the row's scores, its log-sum-exp, the gradient it accumulates into -- issued
-    // together: row by row, every row cost two dependent round trips to HBM (lse, then x -> exp -> store).
+    // wide rows: one float4 per thread and row (rows are only 4-byte aligned: scalar heads / tails, all rows' in one
+    // pass at the end).  A trip is four rows with ALL their loads -- the rows' scores, their log-sum-exps, the gradient
+    // they accumulate into -- issued together, and the NEXT trip's loads are issued before this one's values are
+    // computed and stored: trip by trip, a tile of 32 rows was eight dependent round trips to HBM plus eight more for
+    // the heads and tails (55 us of a workgroup's 77 per tile at the Transducer benchmark).
     const int64_t e0 = ((int64_t)b * T + ts0) * C;
     constexpr int RU = 4;
-    for (int r0 = 0; r0 < nr; r0 += RU) {
-      int head[RU], nvec[RU];
-      float lrow[RU];
+    const int njb = ((C >> 2) + NT - 1) / NT, ntrips = ((nr + RU - 1) / RU) * njb;
+    auto row_head = [&](int r) { return (int)((4 - ((e0 + (int64_t)r * C) & 3)) & 3); };
+    struct Trip {
+      float4 have[RU], xv[RU];
+      float l[RU];
+    };
+    auto issue = [&](int trip, Trip& t) {  // (clamped everywhere: valid, aligned addresses; no branch around a load)
+      const int r0 = (trip / njb) * RU, j = (trip % njb) * NT + tid;
 #pragma unroll
       for (int q = 0; q < RU; ++q) {
-        const int r = min(r0 + q, nr - 1);  // (past the tile: the last row again, not stored)
-        head[q] = (int)((4 - ((e0 + (int64_t)r * C) & 3)) & 3);
-        nvec[q] = (C - head[q]) >> 2;
-        lrow[q] = soft ? lse[r] : 0.f;
+        const int r = min(r0 + q, nr - 1);
+        const int head = row_head(r), nvec = (C - head) >> 2;
+        const int c = head + 4 * min(j, nvec - 1);
+        t.have[q] = make_float4(0.f, 0.f, 0.f, 0.f), t.xv[q] = t.have[q];
+        t.l[q] = soft ? lse[r] : 0.f;
+        if (accumulate) t.have[q] = *reinterpret_cast<const float4*>(gdst + (int64_t)r * C + c);
+        if (soft) t.xv[q] = *reinterpret_cast<const float4*>(xsrc + (int64_t)r * C + c);
       }
-      for (int j0 = 0; j0 < (C >> 2); j0 += NT) {
-        const int j = j0 + tid;
-        float4 have[RU], xv[RU];
-#pragma unroll
-        for (int q = 0; q < RU; ++q) {
-          const int r = min(r0 + q, nr - 1);
-          const int c = head[q] + 4 * min(j, nvec[q] - 1);  // (clamped: a valid, aligned address)
-          have[q] = make_float4(0.f, 0.f, 0.f, 0.f), xv[q] = have[q];
-          if (accumulate) have[q] = *reinterpret_cast<const float4*>(gdst + (int64_t)r * C + c);
-          if (soft) xv[q] = *reinterpret_cast<const float4*>(xsrc + (int64_t)r * C + c);
-        }
-#pragma unroll
-        for (int q = 0; q < RU; ++q) {
-          const int r = r0 + q;
-          if (r < nr && j < nvec[q]) {
-            const int c = head[q] + 4 * j;
-            float4 o;
-            o.x = value(r, c, have[q].x, xv[q].x, lrow[q]), o.y = value(r, c + 1, have[q].y, xv[q].y, lrow[q]);
-            o.z = value(r, c + 2, have[q].z, xv[q].z, lrow[q]), o.w = value(r, c + 3, have[q].w, xv[q].w, lrow[q]);
-            *reinterpret_cast<float4*>(gdst + (int64_t)r * C + c) = o;
-          }
-        }
-      }
+    };
+    auto finish = [&](int trip, const Trip& t, bool live_trip) {
+      const int r0 = (trip / njb) * RU, j = (trip % njb) * NT + tid;
 #pragma unroll
       for (int q = 0; q < RU; ++q) {
         const int r = r0 + q;
-        const int ntail = C - head[q] - 4 * nvec[q];  // < 4
-        if (r < nr && tid < head[q] + ntail) {
-          float* grow = gdst + (int64_t)r * C;
-          const int c = tid < head[q] ? tid : head[q] + 4 * nvec[q] + (tid - head[q]);
-          grow[c] = value(r, c, accumulate ? grow[c] : 0.f, soft ? xsrc[(int64_t)r * C + c] : 0.f, lrow[q]);
+        const int head = row_head(min(r, nr - 1)), nvec = (C - head) >> 2;
+        if (live_trip && r < nr && j < nvec) {
+          const int c = head + 4 * j;
+          float4 o;
+          o.x = value(r, c, t.have[q].x, t.xv[q].x, t.l[q]), o.y = value(r, c + 1, t.have[q].y, t.xv[q].y, t.l[q]);
+          o.z = value(r, c + 2, t.have[q].z, t.xv[q].z, t.l[q]), o.w = value(r, c + 3, t.have[q].w, t.xv[q].w, t.l[q]);
+          *reinterpret_cast<float4*>(gdst + (int64_t)r * C + c) = o;
         }
+      }
+    };
+    Trip ta, tb;
+    issue(0, ta);
+    for (int trip = 0; trip < ntrips; trip += 2) {
+      issue(min(trip + 1, ntrips - 1), tb);
+      finish(trip, ta, true);
+      issue(min(trip + 2, ntrips - 1), ta);
+      finish(trip + 1, tb, trip + 1 < ntrips);
+    }
+    // heads and tails: up to 3 + 3 elements per row, eight slots per row, every row of the tile in one pass
+    for (int e = tid; e < nr * 8; e += NT) {
+      const int r = e >> 3, k = e & 7;
+      const int head = row_head(r), nvec = (C - head) >> 2, ntail = C - head - 4 * nvec;  // ntail < 4
+      if (k < head + ntail) {
+        float* grow = gdst + (int64_t)r * C;
+        const int c = k < head ? k : head + 4 * nvec + (k - head);
+        grow[c] = value(r, c, accumulate ? grow[c] : 0.f, soft ? xsrc[(int64_t)r * C + c] : 0.f, soft ? lse[r] : 0.f);
       }
     }
   } else {
@@ -1719,6 +1810,185 @@ __device__ __forceinline__ bool occ_eligible(const UttView& u, bool prob) {
 // only LDS is the per-(frame, label) accumulator; a thread multiplies alpha and beta of one (frame, state) where they lie
 // (rows of Q doubles: coalesced) and adds the product to its label's accumulator (ds_add_f32: a label's few states
 // collide); the dense rows are streamed out as in the general kernel.  No learnable-weight gradient here (dW == NULL).
+//
+// LIVE: the workgroup runs INSIDE the launch of the sweeps (prob_chain_occ_kernel) and takes its tile as soon as both
+// sweeps have passed it:
+//   * it polls the two progress words of its utterance (relaxed agent-scope loads by one thread, s_sleep in between);
+//   * alpha, beta and the per-slot offsets are read with L1-bypassing loads -- the sweeps' plain stores are in the L2
+//     of THEIR XCD, which is this workgroup's XCD by construction of the grid (the XCC ids in the progress words are
+//     compared with this workgroup's: a mismatch, or a poll that gives up, marks the utterance in `bad` and the
+//     certificate sends it to the log-domain launch and the general gradient kernel, as it does utterances whose
+//     sweeps disagree);
+//   * log2 Z is not known yet: sum_q alpha_s[q] beta_s[q] at the tile's first slot IS Z (every path passes through
+//     exactly one state per slot; the identity the certificate checks at every 8th slot to 1e-4), so the tile
+//     normalises by its own.
+#ifdef WFL_LIVE_STATS
+__device__ unsigned long long g_live[16];  // cycles (s_memtime) summed over workgroups: 0 busy-wait 1 job wait 2 setup 3 zloc 4 products 5 rows 6 jobs 7 polls
+#define LIVE_T(v) const unsigned long long v = wall_clock64()
+#define LIVE_ADD(k, a, b) if (threadIdx.x == 0) atomicAdd(&g_live[k], (b) - (a))
+#else
+#define LIVE_T(v)
+#define LIVE_ADD(k, a, b)
+#endif
+struct OccLive {
+  const uint64_t* prog_a;
+  const uint64_t* prog_b;
+  uint32_t* bad;
+  uint32_t token;
+  int R;          // frames per chunk of the sweeps
+  int force_bad;  // (tests: behave as if the XCC ids differed)
+};
+__device__ __forceinline__ double ld_l2(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LIVE>
+__device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const UttView& u, int b, int T, int C,
+                                               const float* __restrict__ alpha, const float* __restrict__ beta,
+                                               const float* __restrict__ logz, const float* __restrict__ coef,
+                                               const float* __restrict__ gout, int accumulate, const float* __restrict__ x,
+                                               const float* __restrict__ row_lse, float* __restrict__ dx, int t_begin,
+                                               int t_end, int TS, int64_t tail, int nch1, char* smem, const OccLive& live) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int Q = u.Q, K = u.K, Kmax = d.max_labels;
+  double* red = (double*)smem;                                // [16] + the workgroup's verdict on its tile (LIVE)
+  int* state = (int*)(red + 16);
+  float* acc = (float*)(red + 18);                            // [TS][Kmax]
+  double* corr = (double*)(acc + (((size_t)TS * Kmax + 1) & ~(size_t)1));  // [TS]
+  int16_t* lab = (int16_t*)(corr + TS);                       // [Qmax]: label slot of the state (-1: no in-arc)
+  int16_t* colmap = lab + ((d.max_states + 3) & ~3);          // [C]
+  const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
+  const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
+  double zd = 0.0;
+  bool dead = false;
+  if (!LIVE) {
+    zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];  // log2 Z
+    const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
+    if (!occ_eligible(u, fmt[b] == kFmtProb)) return;
+    const float z = logz[b];
+    dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
+  } else if (!occ_eligible(u, true)) {
+    return;
+  }
+  LIVE_T(t_s0);
+  const double* alpha_d = reinterpret_cast<const double*>(alpha) + u.ab_base;
+  const double* beta_d = reinterpret_cast<const double*>(beta) + u.ab_base;
+  const float g0 = gout ? gout[0] : 1.f;
+  const float cf = coef ? coef[b] * g0 : g0;
+  for (int c = tid; c < C; c += NT) colmap[c] = -1;
+  for (int q = tid; q < Q; q += NT) lab[q] = u.in_ptr[q] < u.in_ptr[q + 1] ? (int16_t)u.arc_slot[u.in_ptr[q]] : (int16_t)-1;
+  __syncthreads();
+  for (int k = tid; k < K; k += NT) colmap[u.labels[k]] = (int16_t)k;
+  const float inv_q = 1.f / (float)max(Q, 1);
+  for (int ts0 = t_begin; ts0 < t_end; ts0 += TS) {
+    const int nr = min(TS, t_end - ts0);
+    __syncthreads();
+    LIVE_T(t_w0);
+    if (LIVE) LIVE_ADD(2, t_s0, t_w0);
+    if (LIVE) {
+      // frames ts0 .. ts0 + nr - 1 need slots ts0 + 1 .. ts0 + nr of both sweeps: the forward sweep has stored slots
+      // <= chunks * R, the backward sweep slots >= T - chunks * R
+      if (tid == 0) {
+        const uint32_t need_a = (uint32_t)((ts0 + nr + live.R - 1) / live.R);
+        const uint32_t need_b = (uint32_t)((T - ts0 - 1 + live.R - 1) / live.R);
+        const uint32_t me = xcc_id();
+        int st = -2;  // (gave up: ~2 s)
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+          const uint64_t va = __hip_atomic_load(live.prog_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t vb = __hip_atomic_load(live.prog_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(va >> 32) == live.token && (uint32_t)(vb >> 32) == live.token) {
+            const uint32_t ca = (uint32_t)va & 0x0fffffffu, cb = (uint32_t)vb & 0x0fffffffu;
+            if (ca == kProgSkip || cb == kProgSkip) {
+              st = 0;  // not swept in the probability domain: the general kernel's utterance
+              break;
+            }
+            if ((((uint32_t)va >> 28) & 15u) != me || (((uint32_t)vb >> 28) & 15u) != me || live.force_bad) {
+              st = -1;
+              break;
+            }
+            if (ca >= need_a && cb >= need_b) {
+              st = 1;
+              break;
+            }
+          }
+          __builtin_amdgcn_s_sleep(64);
+        }
+        if (st < 0) __hip_atomic_store(live.bad, live.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *state = st;
+      }
+      __syncthreads();
+      if (*state != 1) return;
+      LIVE_T(t_w1);
+      LIVE_ADD(1, t_w0, t_w1);
+      // the tile's own log2 Z, from its first slot
+      double part = 0.0;
+      for (int q = tid; q < Q; q += NT)
+        part = fma(ld_l2(alpha_d + (int64_t)(ts0 + 1) * Q + q), ld_l2(beta_d + (int64_t)(ts0 + 1) * Q + q), part);
+      const double tot = block_reduce_sum_f64(part, red);
+      dead = !(tot > 0.0 && tot < 1.0e300);
+      zd = dead ? 0.0 : log2(tot) + ld_l2(offs_a + ts0 + 1) + ld_l2(offs_b + ts0 + 1);
+      LIVE_T(t_w2);
+      LIVE_ADD(3, t_w1, t_w2);
+    }
+    LIVE_T(t_p0);
+    for (int i = tid; i < nr * Kmax; i += NT) acc[i] = 0.f;
+    // frame t's arcs end in slot t + 1 of both sweeps: gamma = p_alpha p_beta 2^(offs_a + offs_b - log2 Z) there
+    if (tid < nr)
+      corr[tid] = LIVE ? exp2(ld_l2(offs_a + ts0 + tid + 1) + ld_l2(offs_b + ts0 + tid + 1) - zd)
+                       : exp2(offs_a[ts0 + tid + 1] + offs_b[ts0 + tid + 1] - zd);
+    __syncthreads();
+    if (!dead) {
+      const double* asrc = alpha_d + (int64_t)(ts0 + 1) * Q;
+      const double* bsrc = beta_d + (int64_t)(ts0 + 1) * Q;
+      const int n = nr * Q;
+      if (LIVE) {
+        // (the L1-bypassing loads are relaxed atomics, which the compiler does not move across the LDS atomics below:
+        // left to it, every pair of loads is waited for before the next is issued -- batches of 16 by hand)
+        constexpr int U = 8;
+        for (int i0 = tid; i0 < n; i0 += U * NT) {
+          double av[U], bv[U];
+#pragma unroll
+          for (int k = 0; k < U; ++k) {
+            const int i = min(i0 + k * NT, n - 1);
+            av[k] = ld_l2(asrc + i), bv[k] = ld_l2(bsrc + i);
+          }
+#pragma unroll
+          for (int k = 0; k < U; ++k) {
+            const int i = i0 + k * NT;
+            const int r = (int)(((float)i + 0.5f) * inv_q), q = i - r * Q;  // (exact for i < 2^20)
+            const double g = av[k] * bv[k];
+            if (i < n) {
+              const int kk = lab[q];
+              if (kk >= 0 && g != 0.0) atomicAdd(&acc[r * Kmax + kk], (float)(g * corr[r]));
+            }
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int i = tid; i < n; i += NT) {
+          const int r = (int)(((float)i + 0.5f) * inv_q), q = i - r * Q;  // (exact for i < 2^20)
+          const double g = asrc[i] * bsrc[i];
+          const int k = lab[q];
+          if (k >= 0 && g != 0.0) atomicAdd(&acc[r * Kmax + k], (float)(g * corr[r]));
+        }
+      }
+    }
+    __syncthreads();
+    LIVE_T(t_p1);
+    stream_grad_rows(b, ts0, nr, T, C, Kmax, tid, NT, dx, x, row_lse, accumulate, dead, cf, acc, colmap);
+    LIVE_T(t_p2);
+    if (LIVE) {
+      LIVE_ADD(4, t_p0, t_p1);
+      LIVE_ADD(5, t_p1, t_p2);
+      LIVE_ADD(6, 0ull, 1ull);
+    }
+  }
+}
+// LDS of occ_grad_tiles (bytes)
+static size_t occ_lds_bytes(const wfl_lattice_desc& d, int TS, int C) {
+  return 18 * 8 + (((size_t)TS * d.max_labels + 1) & ~(size_t)1) * 4 + 8 * (size_t)TS +
+         2 * (((size_t)d.max_states + 3) & ~(size_t)3) + 2 * (size_t)C + 16;
+}
+
 __global__ void __launch_bounds__(256)
     occ_grad_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T, int C,
                     const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
@@ -1726,52 +1996,145 @@ __global__ void __launch_bounds__(256)
                     const float* __restrict__ x, const float* __restrict__ row_lse, float* __restrict__ dx,
                     int rows_per_block, int TS, int64_t tail, int nch1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
+  const int b = blockIdx.y;
   const UttView u = make_view(d, ints, floats, b, T);
-  const int Q = u.Q, K = u.K, Kmax = d.max_labels;
-  float* acc = (float*)smem;                                  // [TS][Kmax]
-  double* corr = (double*)(acc + (((size_t)TS * Kmax + 1) & ~(size_t)1));  // [TS]
-  int16_t* lab = (int16_t*)(corr + TS);                       // [Qmax]: label slot of the state (-1: no in-arc)
-  int16_t* colmap = lab + ((d.max_states + 3) & ~3);          // [C]
-  const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
-  const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
-  const double zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];  // log2 Z
-  const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
-  if (!occ_eligible(u, fmt[b] == kFmtProb)) return;
-  const double* alpha_d = reinterpret_cast<const double*>(alpha) + u.ab_base;
-  const double* beta_d = reinterpret_cast<const double*>(beta) + u.ab_base;
-  const float g0 = gout ? gout[0] : 1.f;
-  const float cf = coef ? coef[b] * g0 : g0;
-  const float z = logz[b];
-  const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
-  for (int c = tid; c < C; c += NT) colmap[c] = -1;
-  for (int q = tid; q < Q; q += NT) lab[q] = u.in_ptr[q] < u.in_ptr[q + 1] ? (int16_t)u.arc_slot[u.in_ptr[q]] : (int16_t)-1;
-  __syncthreads();
-  for (int k = tid; k < K; k += NT) colmap[u.labels[k]] = (int16_t)k;
   const int t_begin = blockIdx.x * rows_per_block;
-  const int t_end = min(T, t_begin + rows_per_block);
-  const float inv_q = 1.f / (float)max(Q, 1);
-  for (int ts0 = t_begin; ts0 < t_end; ts0 += TS) {
-    const int nr = min(TS, t_end - ts0);
-    __syncthreads();
-    for (int i = tid; i < nr * Kmax; i += NT) acc[i] = 0.f;
-    // frame t's arcs end in slot t + 1 of both sweeps: gamma = p_alpha p_beta 2^(offs_a + offs_b - log2 Z) there
-    if (tid < nr) corr[tid] = exp2(offs_a[ts0 + tid + 1] + offs_b[ts0 + tid + 1] - zd);
-    __syncthreads();
-    if (!dead) {
-      const double* asrc = alpha_d + (int64_t)(ts0 + 1) * Q;
-      const double* bsrc = beta_d + (int64_t)(ts0 + 1) * Q;
-      const int n = nr * Q;
-#pragma unroll 4
-      for (int i = tid; i < n; i += NT) {
-        const int r = (int)(((float)i + 0.5f) * inv_q), q = i - r * Q;  // (exact for i < 2^20)
-        const double g = asrc[i] * bsrc[i];
-        const int k = lab[q];
-        if (k >= 0 && g != 0.0) atomicAdd(&acc[r * Kmax + k], (float)(g * corr[r]));
+  occ_grad_tiles<false>(d, u, b, T, C, alpha, beta, logz, coef, gout, accumulate, x, row_lse, dx, t_begin,
+                        min(T, t_begin + rows_per_block), TS, tail, nch1, smem, OccLive{});
+}
+
+// The occupancy gradient BESIDE the sweeps.  The sweeps of a batch of B utterances are 2 B workgroups that each run for
+// the whole launch at the pace of one dependent frame after the other, on a chip with 256 CUs; the gradient is a
+// bandwidth-bound pass over alpha, beta and the emissions that can start in the middle of the utterance as soon as the
+// two sweeps have crossed and then follows them outwards.  Three launches on two streams (wfl_lattice_forward_grad):
+//     stream      prob_chain_pub_kernel   the sweeps, publishing a progress word per (utterance, direction);
+//                                         ids [0, 2 Bp): direction id / Bp, utterance id % Bp (Bp = B rounded up to 8),
+//                                         so that the two sweeps of an utterance land on the same XCD (ids are dealt to
+//                                         the XCDs round-robin)
+//     side        occ_gate_kernel         one wave: waits until every sweep workgroup has announced itself (from then on
+//                                         nothing the gradient does can keep a sweep off the chip), then sorts the
+//                                         utterances by the XCD their sweeps run on and resets the job counters
+//     side        occ_live_kernel         persistent 256-thread workgroups (their own register budget: 5 per SIMD; a
+//                                         kernel that also held the sweeps' code would get 1 workgroup per CU): each
+//                                         reads the id of the XCD it runs on and draws (tile, utterance) jobs of THAT
+//                                         XCD, tiles in middle-out order -- the sweeps' plain stores are in that XCD's
+//                                         L2 (see occ_grad_tiles)
+// The kernels themselves do not rely on how workgroups are dealt to XCDs: an utterance whose sweeps ended up on
+// different XCDs is handed to the certificate (`bad`), one whose XCD hosts no gradient workgroup likewise (left-over
+// jobs are detected by the certificate through the job counters).
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT)
+    prob_chain_pub_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
+                          const float* __restrict__ xg, int T, int rows_per_chunk, const float* __restrict__ weights,
+                          float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz, int64_t tail,
+                          int nch1, int Bp, uint32_t token) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x % Bp;
+  if (b >= d.B) return;
+#ifndef WFL_DBG_NO_PRIO
+  __builtin_amdgcn_s_setprio(2);
+#endif
+  // the gradient workgroups leave a CU alone while a sweep runs on it (occ_live_kernel)
+  uint32_t* busy = occ_header(d, alpha, tail, nch1).busy + cu_key();
+  if (threadIdx.x == 0) __hip_atomic_store(busy, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  prob_chain_body<MAXT, true>(d, ints, floats, xg, T, rows_per_chunk, weights, alpha, beta, logz, tail, nch1, b,
+                              blockIdx.x / Bp, smem, token);
+  if (threadIdx.x == 0) __hip_atomic_store(busy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(64)
+    occ_gate_kernel(wfl_lattice_desc d, float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1,
+                    uint32_t token, int force_bad) {
+  const int lane = threadIdx.x;
+  const uint64_t* pa = reinterpret_cast<const uint64_t*>(reinterpret_cast<double*>(alpha + tail) + prog_offset_doubles(d, nch1));
+  const uint64_t* pb = reinterpret_cast<const uint64_t*>(reinterpret_cast<double*>(beta + tail) + prog_offset_doubles(d, nch1));
+  const OccHeader h = occ_header(d, alpha, tail, nch1);
+  int count[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (wave-uniform)
+  for (int b0 = 0; b0 < d.B; b0 += 64) {
+    const int b = b0 + lane;
+    int xcd = -1;  // -1: not for the in-flight gradient
+    if (b < d.B) {
+      bool seen = false;
+      for (int spin = 0; spin < (1 << 22) && !seen; ++spin) {  // (gives up after ~7 s: the utterance goes to `bad`)
+        const uint64_t va = __hip_atomic_load(pa + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t vb = __hip_atomic_load(pb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(va >> 32) == token && (uint32_t)(vb >> 32) == token) {
+          seen = true;
+          const uint32_t xa = ((uint32_t)va >> 28) & 15u, xb = ((uint32_t)vb >> 28) & 15u;
+          const bool skip = ((uint32_t)va & 0x0fffffffu) == kProgSkip || ((uint32_t)vb & 0x0fffffffu) == kProgSkip;
+          if (!skip) xcd = (xa == xb && xa < 8 && !force_bad) ? (int)xa : -2;
+        } else {
+          __builtin_amdgcn_s_sleep(64);
+        }
       }
+      if (!seen) xcd = -2;
+      if (xcd == -2) h.bad[b] = token;
     }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const uint64_t m = __ballot(xcd == x);
+      if (xcd == x) h.list[x * d.B + count[x] + __popcll(m & ((1ull << lane) - 1))] = b;
+      count[x] += __popcll(m);
+    }
+  }
+  // (the header is written only now, after every sweep of this launch has been seen: the buffers may be the previous
+  // call's, whose certificate reads its header until the stream reaches this call's sweeps)
+  if (lane < 8) h.next[lane] = 0;
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+    if (lane == 0) h.nx[x] = count[x];
+}
+
+__global__ void __launch_bounds__(256)
+    occ_live_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T, int C,
+                    float* __restrict__ alpha, float* __restrict__ beta, const float* __restrict__ coef,
+                    const float* __restrict__ x, const float* __restrict__ row_lse, float* __restrict__ dx, int rows_o,
+                    int ntiles, int rows_per_chunk, int64_t tail, int nch1, uint32_t token) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ uint32_t job_s;
+  const OccHeader h = occ_header(d, alpha, tail, nch1);
+  const uint32_t me = xcc_id() & 7u;
+  const int nx = h.nx[me];
+  const double* ta = reinterpret_cast<const double*>(alpha + tail) + prog_offset_doubles(d, nch1);
+  const double* tb = reinterpret_cast<const double*>(beta + tail) + prog_offset_doubles(d, nch1);
+  // middle-out: mid, mid - 1, mid + 1, mid - 2, ... and the rest of the longer side
+  const int mid = ntiles / 2, nlo = mid, nhi = ntiles - mid, pair = min(nlo, nhi);
+#ifndef WFL_LIVE_SHARE_CU
+  // A sweep is a chain of dependent frames that any neighbour on its CU slows down, and the launch ends when the
+  // last sweep does: workgroups that find one on their CU sit out until it is done; the others -- half the chip at
+  // the Transducer benchmark's 128 sweeps -- draw the jobs meanwhile.
+  LIVE_T(t_b0);
+  if (threadIdx.x == 0) {
+    const uint32_t* busy = h.busy + cu_key();
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+      if (__hip_atomic_load(busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) break;
+      __builtin_amdgcn_s_sleep(127);
+    }
+  }
+  LIVE_T(t_b1);
+  LIVE_ADD(0, t_b0, t_b1);
+#endif
+  for (;;) {
     __syncthreads();
-    stream_grad_rows(b, ts0, nr, T, C, Kmax, tid, NT, dx, x, row_lse, accumulate, dead, cf, acc, colmap);
+    if (threadIdx.x == 0) job_s = __hip_atomic_fetch_add(h.next + me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t job = job_s;
+    if (nx <= 0 || job >= (uint32_t)nx * (uint32_t)ntiles) return;
+    const int r = (int)(job / (uint32_t)nx), b = h.list[me * d.B + (int)(job % (uint32_t)nx)];
+    int tile;
+    if (r < 2 * pair)
+      tile = (r & 1) ? mid - 1 - (r >> 1) : mid + (r >> 1);
+    else
+      tile = nhi > nlo ? mid + pair + (r - 2 * pair) : mid - 1 - pair - (r - 2 * pair);
+    const UttView u = make_view(d, ints, floats, b, T);
+    OccLive live;
+    live.prog_a = reinterpret_cast<const uint64_t*>(ta) + b;
+    live.prog_b = reinterpret_cast<const uint64_t*>(tb) + b;
+    live.bad = h.bad + b;
+    live.token = token, live.R = rows_per_chunk, live.force_bad = 0;
+    const int t_begin = tile * rows_o;
+    occ_grad_tiles<true>(d, u, b, T, C, alpha, beta, nullptr, coef, nullptr, 0, x, row_lse, dx, t_begin,
+                         min(T, t_begin + rows_o), rows_o, tail, nch1, smem, live);
   }
 }
 
@@ -2332,7 +2695,8 @@ int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, i
     int nch1;
     ab_tail(*d, T, tail, nch1);
     // (+ kDumpDoubles doubles behind the tail: where the lanes without a state of the unrolled sweeps "store")
-    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2 + 2 * kDumpDoubles;
+    // (+ behind that: a progress word per utterance, and -- alpha only -- `bad` and the OccHeader lists)
+    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2 + 2 * kDumpDoubles + 12 * (int64_t)d->B + 32 + 2048;
   }
   return WFL_OK;
 }
@@ -2374,9 +2738,72 @@ int wfl_lattice_gather(const wfl_lattice_desc* d, const int32_t* ints, const flo
   return WFL_OK;
 }
 
+// One side stream and a join event per device for the gradient that runs beside the sweeps (created on first
+// use, never destroyed: they must outlive every stream they were waited on from, and static destruction order is not
+// ours to choose).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t join = nullptr;
+  std::mutex mu;
+};
+static SideStream* side_stream_of_device() {
+  static std::mutex mu;
+  static auto* table = new std::map<int, SideStream*>();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = table->find(dev);
+  if (it != table->end()) return it->second;
+  auto* s = new SideStream();
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess) {
+    delete s;
+    s = nullptr;
+  }
+  (*table)[dev] = s;
+  return s;
+}
+static int device_cus() {
+  int dev = 0, n = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+  return n > 0 ? n : 256;
+}
+
+// what wfl_lattice_forward_grad adds to the sweeps' launch
+struct InLaunchGrad {
+  int C;
+  const float* coef;
+  const float* x;
+  const float* row_lse;
+  float* dx;
+  int done;  // out: 1 if the launch computed the occupancy gradient
+};
+static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T,
+                                const float* weights, int semiring, float* alpha, float* beta, int32_t* bptr, float* logz,
+                                void* stream, InLaunchGrad* g);
+
 int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T,
                         const float* weights, int semiring, float* alpha, float* beta, int32_t* bptr, float* logz,
                         void* stream) {
+  return lattice_forward_impl(d, ints, floats, xg, T, weights, semiring, alpha, beta, bptr, logz, stream, nullptr);
+}
+
+int wfl_lattice_forward_grad(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T,
+                             int C, const float* weights, float* alpha, float* beta, float* logz, const float* coef,
+                             const float* x, const float* row_lse, float* dx, int* in_launch, void* stream) {
+  if (!beta || !dx || !in_launch || (row_lse != nullptr) != (x != nullptr)) {
+    set_error("lattice_forward_grad: beta, dx and in_launch are required; x and row_lse go together");
+    return WFL_ERR_INVALID;
+  }
+  InLaunchGrad g{C, coef, x, row_lse, dx, 0};
+  const int rc = lattice_forward_impl(d, ints, floats, xg, T, weights, WFL_SEMIRING_LOG, alpha, beta, nullptr, logz, stream, &g);
+  *in_launch = g.done;
+  return rc;
+}
+
+static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T,
+                                const float* weights, int semiring, float* alpha, float* beta, int32_t* bptr, float* logz,
+                                void* stream, InLaunchGrad* g) {
   if (int rc = check_desc(d, "lattice_forward")) return rc;
   if (!alpha || !logz) {
     set_error("lattice_forward: alpha and logz are required");
@@ -2413,7 +2840,68 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
         hipLaunchKernelGGL(kern, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
                            beta, logz, tail, nch1);
       };
-      if (nt == 128 && d->max_states <= 64)
+      // The occupancy gradient beside the sweeps (prob_chain_pub_kernel + occ_gate_kernel + occ_live_kernel): uniform-
+      // label acceptors without epsilon arcs, full 16-frame chunks (the sweeps' publication counts on them).
+      // WFL_LATTICE_FUSED_GRAD=0: never; WFL_LATTICE_FUSED_TILE: frames per gradient tile (default 32);
+      // WFL_LATTICE_FUSED_WGS: gradient workgroups per CU (default 5); WFL_LATTICE_FUSED_BADXCD=1: every utterance is
+      // reported as swept on two XCDs (tests of the fall-back).
+      static const int fused_env = [] {
+        const char* e = getenv("WFL_LATTICE_FUSED_GRAD");
+        return e ? atoi(e) : 1;
+      }();
+      static const int fused_tile = [] {
+        const char* e = getenv("WFL_LATTICE_FUSED_TILE");
+        return e ? std::max(1, std::min(32, atoi(e))) : 32;
+      }();
+      static const int fused_wgs = [] {
+        const char* e = getenv("WFL_LATTICE_FUSED_WGS");
+        return e ? std::max(1, atoi(e)) : 5;
+      }();
+      const char* bad_env = getenv("WFL_LATTICE_FUSED_BADXCD");
+      uint32_t token = 0;
+      int nt_o = 0;
+      if (g && fused_env && beta && T > 0 && nt >= 256 && nt <= 512 && rpc == 16 && d->max_eps == 0 && d->max_labels <= 32767) {
+        const int ntiles = (T + fused_tile - 1) / fused_tile;
+        const int rows_o = (T + ntiles - 1) / ntiles;
+        nt_o = (T + rows_o - 1) / rows_o;
+        const size_t plds = (size_t)std::max(d->max_states, nt) * 16 + 64 * 4 + prob_rows_floats(*d, rpc) * 4 + (size_t)2 * rpc * 4 + 64;
+        const size_t olds = occ_lds_bytes(*d, rows_o, g->C);
+        SideStream* side = olds <= (size_t)kLdsBytes ? side_stream_of_device() : nullptr;
+        if (side) {
+          static std::atomic<uint32_t> counter{0};
+          do token = (counter.fetch_add(1) + 1) * 2654435761u; while (token == 0);
+          const int Bp = (d->B + 7) & ~7;
+          hipStream_t main_s = (hipStream_t)stream;
+          std::lock_guard<std::mutex> lock(side->mu);  // (the events are the device's, not the call's)
+          // (no fork event: the gate kernel waits for THIS launch's token in the progress words, which the sweeps write
+          // once the stream has reached them -- an event behind the gather would put ~7 us of packet processing in front
+          // of the sweeps.  Whatever the side stream does before that only touches the header, and only after every
+          // sweep has announced itself, i.e. after everything queued on the stream before this call.)
+          auto launch_pub = [&](auto kern) {
+            if (plds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)kern, (int)plds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(2 * Bp)), dim3(nt), plds, main_s, *d, ints, floats, xg, T, rpc, weights,
+                               alpha, beta, logz, tail, nch1, Bp, token);
+          };
+          if (nt <= 256)
+            launch_pub(prob_chain_pub_kernel<256>);
+          else
+            launch_pub(prob_chain_pub_kernel<512>);
+          hipLaunchKernelGGL(occ_gate_kernel, dim3(1), dim3(64), 0, side->stream, *d, alpha, beta, tail, nch1, token,
+                             bad_env && atoi(bad_env) == 1 ? 1 : 0);
+          if (olds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)occ_live_kernel, (int)olds);
+          const int64_t jobs = (int64_t)d->B * nt_o;
+          const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>(jobs, (int64_t)fused_wgs * device_cus()));
+#ifndef WFL_DBG_NO_LIVE  // (timing experiments: the publishing sweeps alone)
+          hipLaunchKernelGGL(occ_live_kernel, dim3(wgs), dim3(256), olds, side->stream, *d, ints, floats, T, g->C, alpha, beta,
+                             g->coef, g->x, g->row_lse, g->dx, rows_o, nt_o, rpc, tail, nch1, token);
+#endif
+          WFL_HIP_CHECK(hipEventRecord(side->join, side->stream));
+          WFL_HIP_CHECK(hipStreamWaitEvent(main_s, side->join, 0));
+          g->done = 1;
+        }
+      }
+      if (g && g->done) {
+      } else if (nt == 128 && d->max_states <= 64)
         launch_prob(prob_chain_kernel<128>);  // chain wave + loader wave (the banded sweep)
       else if (nt <= 256)
         launch_prob(prob_chain_kernel<256>);
@@ -2423,7 +2911,7 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
         launch_prob(prob_chain_kernel<1024>);
       if (beta)
         hipLaunchKernelGGL(prob_certify_kernel, dim3((unsigned)d->B, 8u), dim3(256), 0, (hipStream_t)stream, *d, ints,
-                           floats, T, alpha, beta, tail, nch1, nt);
+                           floats, T, alpha, beta, tail, nch1, nt, token, nt_o);
     }
     // ... then the log-domain sweeps of the rest (and of utterances whose two sweeps disagree: the certificate)
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
@@ -2447,10 +2935,34 @@ int wfl_lattice_forward(const wfl_lattice_desc* d, const int32_t* ints, const fl
   return WFL_OK;
 }
 
+static int lattice_grad_impl(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T, int C,
+                             const float* weights, const float* alpha, const float* beta, const float* logz, const float* coef,
+                             const float* coef_w, const float* gout, int accumulate, const float* x, const float* row_lse,
+                             float* dx, float* dW, void* stream, int occ_in_launch);
+
 int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T, int C,
                      const float* weights, const float* alpha, const float* beta, const float* logz, const float* coef,
                      const float* coef_w, const float* gout, int accumulate, const float* x, const float* row_lse,
                      float* dx, float* dW, void* stream) {
+  return lattice_grad_impl(d, ints, floats, xg, T, C, weights, alpha, beta, logz, coef, coef_w, gout, accumulate, x, row_lse,
+                           dx, dW, stream, 0);
+}
+
+// What is left of the gradient after wfl_lattice_forward_grad reported in_launch = 1: the utterances the occupancy
+// gradient does not serve (and those the certificate sent to the log-domain sweeps), by the general kernel, which
+// overwrites their rows of dx.  The rows the launch wrote were computed with grad_output = 1: scale them first if it
+// is not (wfl_scale), then call this with the real gout.
+int wfl_lattice_grad_rest(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T, int C,
+                          const float* weights, const float* alpha, const float* beta, const float* logz, const float* coef,
+                          const float* gout, const float* x, const float* row_lse, float* dx, void* stream) {
+  return lattice_grad_impl(d, ints, floats, xg, T, C, weights, alpha, beta, logz, coef, nullptr, gout, 0, x, row_lse, dx,
+                           nullptr, stream, 1);
+}
+
+static int lattice_grad_impl(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T, int C,
+                             const float* weights, const float* alpha, const float* beta, const float* logz, const float* coef,
+                             const float* coef_w, const float* gout, int accumulate, const float* x, const float* row_lse,
+                             float* dx, float* dW, void* stream, int occ_in_launch) {
   if (int rc = check_desc(d, "lattice_grad")) return rc;
   if ((row_lse != nullptr) != (x != nullptr)) {
     set_error("lattice_grad: the fused log-softmax backward needs both x and row_lse");
@@ -2530,14 +3042,13 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
     return e && atoi(e) == 0;
   }();
   const int occ = !occ_off && dx && !dW && !band && d->max_eps == 0 && d->max_labels <= 32767;
-  int occ_done = 0;
-  if (occ) {
+  int occ_done = occ_in_launch;
+  if (occ && !occ_in_launch) {
     const int wgs_t = std::max(1, std::min((T + 15) / 16, 2048 / std::max(1, d->B)));
     const int rows_o = (T + wgs_t - 1) / wgs_t;
     const int blocks_o = (T + rows_o - 1) / rows_o;
     const int ts_o = std::min(32, rows_o);
-    const size_t olds = (((size_t)ts_o * d->max_labels + 1) & ~(size_t)1) * 4 + 8 * (size_t)ts_o +
-                        2 * (((size_t)d->max_states + 3) & ~(size_t)3) + 2 * (size_t)C + 16;
+    const size_t olds = occ_lds_bytes(*d, ts_o, C);
     if (olds <= (size_t)kLdsBytes) {
       if (olds > 48 * 1024) WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)occ_grad_kernel, (int)olds));
       hipLaunchKernelGGL(occ_grad_kernel, dim3((unsigned)blocks_o, (unsigned)d->B), dim3(256), olds, (hipStream_t)stream, *d,
@@ -2565,6 +3076,16 @@ int wfl_lattice_backtrace(const wfl_lattice_desc* d, const int32_t* ints, const 
   return WFL_OK;
 }
 
+#ifdef WFL_LIVE_STATS
+int wfl_debug_live_stats(unsigned long long* out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_live), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_live), z, sizeof(z));
+  }
+  return rc;
+}
+#endif
 #ifdef WFL_DBG_TIMELINE
 int wfl_debug_timeline(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);

@@ -327,13 +327,16 @@ class PackedLattice:
 class LatticeState:
     """Everything the backward pass needs from a forward pass of the lattice engine."""
 
-    __slots__ = ("pack", "T", "C", "xg", "alpha", "beta", "logz", "weights", "bptr", "x", "row_lse")
+    __slots__ = ("pack", "T", "C", "xg", "alpha", "beta", "logz", "weights", "bptr", "x", "row_lse", "in_launch")
 
 
-def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_LOG, log_softmax=False):
+def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_LOG, log_softmax=False, grad_into=None):
     """forward_score(intersect(emissions, A_b)) for every b: returns a LatticeState whose `logz`
     holds the per-utterance score (gtn call sites: ctc.py:50, asg.py:111, stc.py:86,
-    transducer.py:283,287)."""
+    transducer.py:283,287).
+
+    grad_into = (coef, dx): ask the sweeps' launch to compute the emission gradient for grad_output = 1 as well
+    (wfl_lattice_forward_grad); `st.in_launch` says whether it did -- lattice_grad_rest finishes the job."""
     B, T, C = x.shape
     d = pack.desc
     up = getattr(pack, "_uploaded", None)
@@ -362,12 +365,24 @@ def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_L
     N.check(N.lib.wfl_lattice_gather(pack._desc_ref, ptr(pack.ints), ptr(x), T, C, ptr(st.xg), ptr(st.row_lse), s))
     _done(tok)
     tok = _mark("lattice_chain" + tag)
-    N.check(
-        N.lib.wfl_lattice_forward(
-            pack._desc_ref, ptr(pack.ints), ptr(pack.floats), ptr(st.xg), T, ptr(weights), semiring,
-            ptr(st.alpha), ptr(st.beta), ptr(st.bptr), ptr(st.logz), s,
+    st.in_launch = False
+    if grad_into is not None and st.beta is not None:
+        coef, dx = grad_into
+        flag = ctypes.c_int(0)
+        N.check(
+            N.lib.wfl_lattice_forward_grad(
+                pack._desc_ref, ptr(pack.ints), ptr(pack.floats), ptr(st.xg), T, C, ptr(weights), ptr(st.alpha),
+                ptr(st.beta), ptr(st.logz), ptr(coef), ptr(st.x), ptr(st.row_lse), ptr(dx), ctypes.byref(flag), s,
+            )
         )
-    )
+        st.in_launch = bool(flag.value)
+    else:
+        N.check(
+            N.lib.wfl_lattice_forward(
+                pack._desc_ref, ptr(pack.ints), ptr(pack.floats), ptr(st.xg), T, ptr(weights), semiring,
+                ptr(st.alpha), ptr(st.beta), ptr(st.bptr), ptr(st.logz), s,
+            )
+        )
     _done(tok)
     return st
 
@@ -378,7 +393,7 @@ def lattice_formats(st):
     certificate's repair: the two probability-domain sweeps disagreed about Z).  Diagnostics and tests; the layout is
     the tail of the alpha buffer described in csrc/lattice_kernels.hip (chain_kernel)."""
     B, T = st.pack.desc.B, st.T
-    tail = st.alpha.numel() - (2 * (B * (T + 1) + B) + 2 * B + 2 + 2 * 1024)  # (kDumpDoubles behind the tail)
+    tail = st.alpha.numel() - (2 * (B * (T + 1) + B) + 2 * B + 2 + 2 * 1024 + 12 * B + 32 + 2048)  # (dump + progress words + gradient header)
     off = tail + 2 * (B * (T + 1) + B)
     return st.alpha[off:off + B].view(torch.int32)
 
@@ -392,6 +407,20 @@ def lattice_grad(st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW
             p._desc_ref, ptr(p.ints), ptr(p.floats), ptr(st.xg), st.T, st.C, ptr(st.weights), ptr(st.alpha),
             ptr(st.beta), ptr(st.logz), ptr(coef), ptr(coef_w), ptr(gout), int(bool(accumulate)), ptr(st.x),
             ptr(st.row_lse), ptr(dx), ptr(dW), stream_ptr(),
+        )
+    )
+    _done(tok)
+
+
+def lattice_grad_rest(st, coef, gout, dx):
+    """After a forward pass with st.in_launch: dx (already scaled by grad_output) gets the rows of the utterances the
+    launch did not serve (wfl_lattice_grad_rest)."""
+    p = st.pack
+    tok = _mark("lattice_grad" + ("/shared" if p.desc.shared else ""))
+    N.check(
+        N.lib.wfl_lattice_grad_rest(
+            p._desc_ref, ptr(p.ints), ptr(p.floats), ptr(st.xg), st.T, st.C, ptr(st.weights), ptr(st.alpha),
+            ptr(st.beta), ptr(st.logz), ptr(coef), ptr(gout), ptr(st.x), ptr(st.row_lse), ptr(dx), stream_ptr(),
         )
     )
     _done(tok)

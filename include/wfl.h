@@ -218,6 +218,25 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
                      const float* gout, int accumulate, const float* x, const float* row_lse,
                      float* dx, float* dW, void* stream);
 
+/* Stage 2 + the emission gradient in ONE launch (log semiring).  Same sweeps and outputs as
+ * wfl_lattice_forward; when the batch allows it (uniform-label acceptors without epsilon arcs:
+ * the Transducer's alignment graphs of transducer.py:262-281, CTC-like chains) the launch also
+ * holds gradient workgroups that follow the two sweeps outwards from the middle of each utterance
+ * and write   dx[b,t,c] = coef[b] * sum_{arcs with label c} gamma_t(arc)      (grad_output = 1)
+ * (through the fused log-softmax if row_lse != NULL, as wfl_lattice_grad), and *in_launch is set to 1.
+ * Otherwise *in_launch = 0, nothing is written to dx and wfl_lattice_grad does the whole job.
+ * After in_launch = 1: scale dx by grad_output if it is not 1 (wfl_scale), then call
+ * wfl_lattice_grad_rest, which overwrites the rows of the utterances the launch did not serve
+ * (other acceptors; utterances the certificate sent to the log-domain sweeps). */
+int wfl_lattice_forward_grad(const wfl_lattice_desc* d, const int32_t* ints, const float* floats,
+                             const float* xg, int T, int C, const float* weights, float* alpha,
+                             float* beta, float* logz, const float* coef, const float* x,
+                             const float* row_lse, float* dx, int* in_launch, void* stream);
+int wfl_lattice_grad_rest(const wfl_lattice_desc* d, const int32_t* ints, const float* floats,
+                          const float* xg, int T, int C, const float* weights, const float* alpha,
+                          const float* beta, const float* logz, const float* coef, const float* gout,
+                          const float* x, const float* row_lse, float* dx, void* stream);
+
 /* Tropical back-trace (gtn.viterbi_path, transducer.py:221): path[b, 0..len_b) = caller's arc
  * ids along the best path, in order, including epsilon arcs; path_len[b] its length
  * (<= T + max_levels*(T+1)); path stride = path_stride. */

@@ -1,0 +1,25 @@
+"""Per-phase cycle sums of the in-flight gradient workgroups (a -DWFL_LIVE_STATS=1 build through WFL_LIB_PATH)."""
+import ctypes, sys, random
+sys.path.insert(0, "/root/repo")
+import torch, bench
+from gtn_applications_amd import _native as N
+from gtn_applications_amd.criterions import transducer as TR
+B, T, Lp = 64, 800, 15
+tokens, g2i = bench.word_pieces()
+C = len(tokens) + 1
+rnd = random.Random(0)
+x = torch.randn(B, T, C, generator=torch.Generator().manual_seed(0)).cuda().requires_grad_(True)
+tg = [torch.tensor([g2i[ch] for _ in range(Lp) for ch in rnd.choice(tokens)]) for _ in range(B)]
+crit = TR.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+buf = (ctypes.c_ulonglong * 16)()
+f = ctypes.CDLL(N.LIB_PATH).wfl_debug_live_stats
+for it in range(6):
+    x.grad = None
+    crit(x, tg).backward()
+    torch.cuda.synchronize()
+    f(buf, 1)
+    v = list(buf)
+    jobs = max(1, v[6])
+    names = ["busy-wait", "job wait", "setup", "zloc", "products", "rows"]
+    if it >= 3:
+        print("jobs %d: " % v[6] + "  ".join("%s %.1f us" % (n, v[i] / jobs / 100.0) for i, n in enumerate(names)))
