@@ -7,6 +7,7 @@ reference's per-sample rebuild of the C^2-arc transitions graph (asg.py:54-69,10
 transitions tensor is the graph.
 """
 import itertools
+import os
 
 import torch
 
@@ -57,6 +58,33 @@ def max_classes():
     from .. import _native as N
 
     return int(N.lib.wfl_dense_max_classes())
+
+
+_EARLY_GRAD = os.environ.get("WFL_ASG_EARLY_GRAD", "1") != "0"  # (0: the gradient kernels in backward -- A/B, tests)
+
+
+class _EarlyGrads:
+    """The gradients the forward launches wrote for grad_output = 1, until backward claims them."""
+
+    __slots__ = ("dx", "dW", "inputs", "transitions", "taken")
+
+    def __init__(self, dx, dW, inputs, transitions):
+        self.dx, self.dW, self.inputs, self.transitions, self.taken = dx, dW, inputs, transitions, False
+
+    def peek(self):
+        if self.taken:
+            raise RuntimeError("Trying to backward through the graph a second time (`loss.backward()` handed the ASG "
+                               "loss's gradient buffers to the leaves)")
+        return self.dx, self.dW
+
+    def take(self):
+        """E.EagerLoss.backward: the buffers become the leaves' .grad (once)"""
+        if self.taken or not all(E.plain_leaf(t) for t, g in ((self.inputs, self.dx), (self.transitions, self.dW))
+                                 if g is not None):
+            return None
+        self.taken = True
+        dx, dW, self.dx, self.dW = self.dx, self.dW, None, None
+        return [(t, g) for t, g in ((self.inputs, dx), (self.transitions, dW)) if g is not None]
 
 
 class ASGLossFunction(torch.autograd.Function):
@@ -136,11 +164,37 @@ class ASGLossFunction(torch.autograd.Function):
         loss = E.reduce_loss(fcc.logz, scale, 1.0, minus=fal.logz)
         ctx.aux = (x, W, fcc, cpos, dx_num, dw_num, fork if need_grad else None)
         ctx.devices = (inputs.device, transitions.device)
+        ctx.early = None
+        if need_grad and _EARLY_GRAD:
+            # The denominator's gradient right behind its sweeps, for grad_output = 1 (as the numerator's): between the
+            # forward and the backward kernels of a step the GPU otherwise waits ~30 us for the host to come back
+            # through the autograd engine.  backward scales the two buffers by grad_output; `loss.backward()` takes
+            # them as they are (E.EagerLoss).
+            dx = torch.empty_like(x) if need_dx else None
+            dW = torch.empty_like(W) if need_dw else None
+            fork.join(dx_num, dw_num)
+            E.dense_grad(x, W, fcc, cpos, coef_w=cpos, gout=None, dx=dx, accumulate=False, dW=dW, addend=dx_num,
+                         dW_addend=dw_num)
+            ctx.early = _EarlyGrads(dx, dW, inputs, transitions)
+            ctx.aux = None
+            if all(E.plain_leaf(t) for t, g in ((inputs, dx), (transitions, dW)) if g is not None):
+                ctx.eager_take = ctx.early.take
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
     @E.on_input_device
     def backward(ctx, grad_output):
+        if ctx.early is not None:
+            # (scaled COPIES: the engine may come back -- retain_graph -- and must find the buffers as they were)
+            dx, dW = ctx.early.peek()
+            gout = E.as_device_f32(grad_output.detach().reshape(1), (dx if dx is not None else dW).device)
+            dx = dx * gout if dx is not None and ctx.needs_input_grad[0] else None
+            dW = dW * gout if dW is not None and ctx.needs_input_grad[1] else None
+            if dx is not None and ctx.devices[0].type != "cuda":
+                dx = dx.to(ctx.devices[0])
+            if dW is not None and ctx.devices[1].type != "cuda":
+                dW = dW.to(ctx.devices[1])
+            return dx, dW, None, None
         x, W, fcc, cpos, dx_num, dw_num, fork = ctx.aux
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] and dx_num is not None else None
@@ -157,7 +211,9 @@ class ASGLossFunction(torch.autograd.Function):
         return dx, dW, None, None
 
 
-ASGLoss = ASGLossFunction.apply
+def ASGLoss(*args):
+    """asg.py:183 (`ASGLoss = ASGLossFunction.apply`): same call, same result."""
+    return E.make_eager(ASGLossFunction.apply(*args))
 
 
 class ASG(torch.nn.Module):

@@ -201,8 +201,8 @@ class Transducer(torch.nn.Module):
         if self.transitions is None:
             # transducer.py:186-187 applies log_softmax here; the engine fuses it into the gather
             # (forward) and the gradient rows (backward) instead of materialising [B,T,C] twice
-            return _eager(_FusedLogSoftmaxTransducerLoss.apply(inputs, targets, self.tokens, self.lexicon, None, None,
-                                                               self.reduction))
+            return E.make_eager(_FusedLogSoftmaxTransducerLoss.apply(inputs, targets, self.tokens, self.lexicon, None,
+                                                                     None, self.reduction))
         return TransducerLoss(inputs, targets, self.tokens, self.lexicon, self.transition_params,
                               self.transitions, self.reduction)
 
@@ -358,25 +358,26 @@ class TransducerLossFunction(torch.autograd.Function):
         else:
             loss = E.reduce_loss(num.logz, scale, -1.0)
         ctx.aux = (x, params, num, den, cpos, cneg, dense)
-        ctx.dx_early = dx_early
+        ctx.early = None
         ctx.devices = (inputs.device, None if transition_params is None else transition_params.device)
-        if dx_early is not None and inputs.is_cuda and inputs.is_leaf:
-            ctx.leaf = inputs  # (for _EagerLoss.backward; cleared with the rest of the state)
+        if dx_early is not None:
+            ctx.early = _EarlyGrad(dx_early, num, cneg, inputs)  # (holds no reference to ctx: no cycle to collect)
+            ctx.eager_take = ctx.early.take if E.plain_leaf(inputs) else None
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
     @E.on_input_device
     def backward(ctx, grad_output):
-        if ctx.aux is None:
-            raise RuntimeError("Trying to backward through the graph a second time (the Transducer loss hands its "
-                               "gradient buffer over on the first pass)")
+        if ctx.early is not None:  # the launch of the sweeps wrote the gradient for grad_output = 1
+            if ctx.early.dx is None:
+                raise RuntimeError("Trying to backward through the graph a second time (`loss.backward()` handed the "
+                                   "Transducer loss's gradient buffer to the emissions)")
+            gout = E.as_device_f32(grad_output.detach().reshape(1), ctx.early.dx.device)
+            dx = ctx.early.dx * gout  # (a scaled COPY: under retain_graph the engine comes back for the buffer)
+            E.lattice_grad_rest(ctx.early.num, ctx.early.cneg, gout, dx)
+            return (dx if ctx.devices[0].type == "cuda" else dx.to(ctx.devices[0])), None, None, None, None, None, None
         x, params, num, den, cpos, cneg, dense = ctx.aux
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
-        if ctx.dx_early is not None:  # the launch of the sweeps wrote the gradient for grad_output = 1
-            dx, ctx.dx_early, ctx.aux, ctx.leaf = ctx.dx_early, None, None, None
-            E.scale_inplace(dx, gout)
-            E.lattice_grad_rest(num, cneg, gout, dx)
-            return (dx if ctx.devices[0].type == "cuda" else dx.to(ctx.devices[0])), None, None, None, None, None, None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.zeros_like(params) if (params is not None and ctx.needs_input_grad[4]) else None
         if (dx is not None or dW is not None) and dense is not None:
@@ -415,34 +416,22 @@ class _FusedLogSoftmaxTransducerLoss(TransducerLossFunction):
                                                transitions, reduction)
 
 
-class _EagerLoss(torch.Tensor):
-    """The loss of a Transducer without a transition model whose gradient the sweeps' launch has already computed.  A
-    plain tensor but for `loss.backward()` with no arguments on leaf emissions (transducer_benchmark.py:47-49, a
-    training loop's loss): grad_output is 1 by definition, so the buffer only needs the rows of the utterances the
-    launch did not serve and becomes the emissions' .grad -- no ones_like fill, no scale pass over [B, T, C].
-    Anything else (a gradient argument, retain_graph, inputs=, hooks, non-leaf emissions, anomaly mode, the loss inside
-    a larger expression) goes through torch.Tensor.backward / the autograd engine, which scales the buffer by
-    grad_output."""
+class _EarlyGrad:
+    """The emission gradient the sweeps' launch wrote for grad_output = 1, until backward claims it."""
 
-    __torch_function__ = torch._C._disabled_torch_function_impl
+    __slots__ = ("dx", "num", "cneg", "inputs")
 
-    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
-        ctx = self.grad_fn
-        leaf = getattr(ctx, "leaf", None)
-        if (gradient is None and not retain_graph and not create_graph and inputs is None and leaf is not None
-                and getattr(ctx, "dx_early", None) is not None and not torch.is_anomaly_enabled()
-                and not leaf._backward_hooks and not getattr(leaf, "_post_accumulate_grad_hooks", None)
-                and self.dim() == 0):
-            x, params, num, den, cpos, cneg, dense = ctx.aux
-            dx, ctx.dx_early, ctx.aux, ctx.leaf = ctx.dx_early, None, None, None
-            with torch.cuda.device(dx.device):
-                E.lattice_grad_rest(num, cneg, None, dx)
-                if leaf.grad is None:
-                    leaf.grad = dx
-                else:
-                    leaf.grad.add_(dx)
+    def __init__(self, dx, num, cneg, inputs):
+        self.dx, self.num, self.cneg, self.inputs = dx, num, cneg, inputs
+
+    def take(self):
+        """E.EagerLoss.backward: the buffer only lacks the rows of the utterances the launch did not serve."""
+        if self.dx is None or not E.plain_leaf(self.inputs):
             return None
-        return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
+        dx, self.dx = self.dx, None
+        with torch.cuda.device(dx.device):
+            E.lattice_grad_rest(self.num, self.cneg, None, dx)
+        return [(self.inputs, dx)]
 
 
 _IN_LAUNCH_GRAD = os.environ.get("WFL_TRANSDUCER_IN_LAUNCH_GRAD", "1") != "0"  # (0: gradient in backward -- A/B, tests)
@@ -450,13 +439,7 @@ _IN_LAUNCH_GRAD = os.environ.get("WFL_TRANSDUCER_IN_LAUNCH_GRAD", "1") != "0"  #
 
 def TransducerLoss(*args):
     """transducer.py:346 (`TransducerLoss = TransducerLossFunction.apply`): same call, same result."""
-    return _eager(TransducerLossFunction.apply(*args))
-
-
-def _eager(loss):
-    if getattr(loss.grad_fn, "dx_early", None) is not None and type(loss) is torch.Tensor:
-        loss.__class__ = _EagerLoss
-    return loss
+    return E.make_eager(TransducerLossFunction.apply(*args))
 
 
 # -------------------------------------------------------------------------------------------------

@@ -2866,7 +2866,10 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
         nt_o = (T + rows_o - 1) / rows_o;
         const size_t plds = (size_t)std::max(d->max_states, nt) * 16 + 64 * 4 + prob_rows_floats(*d, rpc) * 4 + (size_t)2 * rpc * 4 + 64;
         const size_t olds = occ_lds_bytes(*d, rows_o, g->C);
-        SideStream* side = olds <= (size_t)kLdsBytes ? side_stream_of_device() : nullptr;
+        // (not while the stream is being captured into a graph: the side stream's launches would not be part of it)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+        SideStream* side = olds <= (size_t)kLdsBytes && cap == hipStreamCaptureStatusNone ? side_stream_of_device() : nullptr;
         if (side) {
           static std::atomic<uint32_t> counter{0};
           do token = (counter.fetch_add(1) + 1) * 2654435761u; while (token == 0);

@@ -493,6 +493,47 @@ class side_stream:
                 t.record_stream(self.cur)
 
 
+class EagerLoss(torch.Tensor):
+    """A scalar loss whose gradients the forward launches have already computed (for grad_output = 1).  A plain tensor
+    in every respect but one: `loss.backward()` with no arguments -- the call of the reference's benchmarks
+    (transducer_benchmark.py:47-49) and of a training loop that uses the criterion's output as its loss -- hands those
+    buffers to the leaves' .grad without a trip through the autograd engine (its two thread hand-overs, the ones_like
+    fill and the scale passes over [B, T, C] leave the GPU idle between the forward and the backward kernels).  The
+    autograd node says whether that is possible through `eager_take()` -> [(leaf, grad), ...] or None (non-leaf inputs,
+    hooks, ...).  Anything else -- a gradient argument, retain_graph, create_graph, inputs=, anomaly mode, the loss
+    inside a larger expression -- goes through torch.Tensor.backward / the engine, where the node scales the buffers
+    by grad_output."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        take = getattr(self.grad_fn, "eager_take", None)
+        if (take is not None and gradient is None and not retain_graph and not create_graph and inputs is None
+                and self.dim() == 0 and not torch.is_anomaly_enabled()):
+            pairs = take()
+            if pairs is not None:
+                for leaf, g in pairs:
+                    if leaf.grad is None:
+                        leaf.grad = g
+                    else:
+                        leaf.grad.add_(g)
+                return None
+        return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
+
+
+def plain_leaf(t):
+    """May EagerLoss.backward write t.grad itself?  (a leaf that requires grad, on the device, without hooks)"""
+    return (type(t) in (torch.Tensor, torch.nn.Parameter) and t.is_leaf and t.requires_grad and t.is_cuda
+            and not t._backward_hooks and not getattr(t, "_post_accumulate_grad_hooks", None))
+
+
+def make_eager(loss):
+    """-> loss, as an EagerLoss if its autograd node offers `eager_take`"""
+    if type(loss) is torch.Tensor and getattr(loss.grad_fn, "eager_take", None) is not None:
+        loss.__class__ = EagerLoss
+    return loss
+
+
 def scale_inplace(v, s):
     """v *= s[0] on the device without a host sync (skipped by the kernel when s[0] == 1)."""
     N.check(N.lib.wfl_scale(ptr(v), v.numel(), ptr(s), stream_ptr()))

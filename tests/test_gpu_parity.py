@@ -938,6 +938,84 @@ def test_transducer_reference_literals(crit, lit):
     assert [p.tolist() for p in m.viterbi(em)] == v["blank_norepeat"]["labels"]
 
 
+def _word_piece_batch(B, T, seed, pieces=15):
+    """a batch of the Transducer benchmark's kind (benchmarks/transducer_benchmark.py:18-53): alignment graphs of
+    ~260 states, the size at which the sweeps run as 512-thread workgroups and the gradient beside them"""
+    import random
+
+    import bench
+
+    tokens, g2i = bench.word_pieces()
+    rnd = random.Random(seed)
+    x = torch.randn(B, T, len(tokens) + 1, generator=torch.Generator().manual_seed(seed)).cuda()
+    tg = [torch.tensor([g2i[ch] for _ in range(pieces) for ch in rnd.choice(tokens)]) for _ in range(B)]
+    return tokens, g2i, x, tg
+
+
+@pytest.mark.parametrize("B,T", [(6, 200), (70, 48)])
+def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(crit, monkeypatch, B, T):
+    """csrc/lattice_kernels.hip wfl_lattice_forward_grad: the emission gradient computed by the persistent workgroups
+    that follow the two sweeps (tile-local log Z, L1-bypassing reads of alpha / beta) against the gradient kernel that
+    runs after them in backward -- through `loss.backward()` (the buffer becomes .grad as it is) and through the
+    autograd engine with a grad_output that is not 1 (the buffer is scaled).  B = 70: more utterances than the gate
+    kernel's wave has lanes, not a multiple of the 8 XCDs."""
+    tr = crit["transducer"]
+    tokens, g2i, x, tg = _word_piece_batch(B, T, 11)
+    m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+
+    def run(scale):
+        xi = x.clone().requires_grad_(True)
+        loss = m(xi, tg)
+        (loss if scale is None else loss * scale).backward()
+        return loss.detach().clone(), xi.grad.clone(), type(loss).__name__
+
+    monkeypatch.setattr(tr, "_IN_LAUNCH_GRAD", False)
+    ref_loss, ref_dx, kind = run(None)
+    assert kind == "Tensor"
+    monkeypatch.setattr(tr, "_IN_LAUNCH_GRAD", True)
+    loss, dx, kind = run(None)
+    assert kind == "EagerLoss"
+    assert loss.item() == pytest.approx(ref_loss.item(), rel=1e-6)
+    close(dx, ref_dx.cpu().numpy(), rtol=1e-4, atol=1e-6, msg="loss.backward()")
+    loss, dx, _ = run(2.5)
+    close(dx, 2.5 * ref_dx.cpu().numpy(), rtol=1e-4, atol=2.5e-6, msg="autograd engine, grad_output 2.5")
+    # .grad accumulates; a second backward through the same graph is refused (the buffer was handed over)
+    xi = x.clone().requires_grad_(True)
+    m(xi, tg).backward()
+    loss = m(xi, tg)
+    loss.backward()
+    close(xi.grad, 2 * ref_dx.cpu().numpy(), rtol=1e-4, atol=2e-6, msg="accumulated .grad")
+    with pytest.raises(RuntimeError):
+        loss.backward()
+    # through the engine the buffer survives for a retained graph
+    xi = x.clone().requires_grad_(True)
+    loss = m(xi, tg) * 1.0
+    loss.backward(retain_graph=True)
+    loss.backward()
+    close(xi.grad, 2 * ref_dx.cpu().numpy(), rtol=1e-4, atol=2e-6, msg="retain_graph")
+
+
+def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificate(crit, monkeypatch):
+    """WFL_LATTICE_FUSED_BADXCD=1 makes the gate kernel report every utterance as swept on two XCDs (what a different
+    workgroup-to-XCD dealing would look like): no gradient workgroup may touch them, the certificate sends them to the
+    log-domain sweeps and wfl_lattice_grad_rest writes their rows -- same loss, same gradient."""
+    tr = crit["transducer"]
+    tokens, g2i, x, tg = _word_piece_batch(5, 150, 12)
+    m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+
+    def run():
+        xi = x.clone().requires_grad_(True)
+        loss = m(xi, tg)
+        loss.backward()
+        return loss.item(), xi.grad.clone()
+
+    ref_loss, ref_dx = run()
+    monkeypatch.setenv("WFL_LATTICE_FUSED_BADXCD", "1")
+    loss, dx = run()
+    assert loss == pytest.approx(ref_loss, rel=2e-5)
+    close(dx, ref_dx.cpu().numpy(), rtol=2e-3, atol=2e-6, msg="fall-back")  # (fp32 log-domain sweeps against fp64 probabilities)
+
+
 def test_transducer_equals_ctc(crit, lit):
     """tests/transducer_test.py:275-316: CTC == Transducer(blank optional, no repeats)."""
     c = lit["ctc_compare_targets"]
