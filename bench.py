@@ -68,7 +68,8 @@ PHASE_KERNEL_NAMES = {
     "ctc_chains": ["ctc_log_chain_kernel"],
     "ctc_grad": ["reduce_loss_kernel", "ctc_grad_kernel"],
     "lattice_gather": ["gather_lse_kernel", "gather_kernel"],
-    "lattice_chain": ["prob_chain_kernel", "prob_certify_kernel", "chain_kernel"],
+    "lattice_chain": ["prob_chain_kernel", "prob_chain_pub_kernel", "occ_gate_kernel", "occ_live_kernel",
+                      "prob_certify_kernel", "chain_kernel"],  # (occ_*: the gradient that runs beside the sweeps)
     "lattice_grad": ["occ_grad_kernel", "band_grad_kernel", "grad_kernel"],
     "lattice_gather/shared": ["gather_kernel"],
     "lattice_chain/shared": ["prob_chain_kernel", "prob_certify_kernel", "chain_kernel"],

@@ -2044,7 +2044,7 @@ __global__ void __launch_bounds__(MAXT)
 
 __global__ void __launch_bounds__(64)
     occ_gate_kernel(wfl_lattice_desc d, float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1,
-                    uint32_t token, int force_bad) {
+                    uint32_t token, int force_bad, uint32_t* __restrict__ host_gave_up) {
   const int lane = threadIdx.x;
   const uint64_t* pa = reinterpret_cast<const uint64_t*>(reinterpret_cast<double*>(alpha + tail) + prog_offset_doubles(d, nch1));
   const uint64_t* pb = reinterpret_cast<const uint64_t*>(reinterpret_cast<double*>(beta + tail) + prog_offset_doubles(d, nch1));
@@ -2067,7 +2067,13 @@ __global__ void __launch_bounds__(64)
           __builtin_amdgcn_s_sleep(64);
         }
       }
-      if (!seen) xcd = -2;
+      if (!seen) {
+        // The sweeps never showed up beside this kernel: something runs the streams' kernels one after the other (a
+        // counter-collecting profiler, AMD_SERIALIZE_KERNEL, a debugger).  Tell the host: it stops asking for the
+        // gradient beside the sweeps (wfl_lattice_forward_grad), which can only wait out its watchdog there.
+        xcd = -2;
+        __hip_atomic_store(host_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       if (xcd == -2) h.bad[b] = token;
     }
 #pragma unroll
@@ -2763,6 +2769,21 @@ static SideStream* side_stream_of_device() {
   (*table)[dev] = s;
   return s;
 }
+// Pinned host word the gate kernel raises when it gave up waiting for the sweeps (see occ_gate_kernel); also raised
+// up front when the environment says that kernels of different streams do not overlap.
+static uint32_t* live_gave_up_word() {
+  static uint32_t* w = [] {
+    uint32_t* p = nullptr;
+    if (hipHostMalloc((void**)&p, 64, hipHostMallocMapped) != hipSuccess || !p) return (uint32_t*)nullptr;
+    *p = 0;
+    for (const char* name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"}) {
+      const char* e = getenv(name);
+      if (e && atoi(e) != 0) *p = 1;
+    }
+    return p;
+  }();
+  return w;
+}
 static int device_cus() {
   int dev = 0, n = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2869,7 +2890,11 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
         // (not while the stream is being captured into a graph: the side stream's launches would not be part of it)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-        SideStream* side = olds <= (size_t)kLdsBytes && cap == hipStreamCaptureStatusNone ? side_stream_of_device() : nullptr;
+        uint32_t* gave_up = live_gave_up_word();
+        SideStream* side = olds <= (size_t)kLdsBytes && cap == hipStreamCaptureStatusNone && gave_up &&
+                                   *(volatile uint32_t*)gave_up == 0
+                               ? side_stream_of_device()
+                               : nullptr;
         if (side) {
           static std::atomic<uint32_t> counter{0};
           do token = (counter.fetch_add(1) + 1) * 2654435761u; while (token == 0);
@@ -2890,7 +2915,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
           else
             launch_pub(prob_chain_pub_kernel<512>);
           hipLaunchKernelGGL(occ_gate_kernel, dim3(1), dim3(64), 0, side->stream, *d, alpha, beta, tail, nch1, token,
-                             bad_env && atoi(bad_env) == 1 ? 1 : 0);
+                             bad_env && atoi(bad_env) == 1 ? 1 : 0, gave_up);
           if (olds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)occ_live_kernel, (int)olds);
           const int64_t jobs = (int64_t)d->B * nt_o;
           const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>(jobs, (int64_t)fused_wgs * device_cus()));
