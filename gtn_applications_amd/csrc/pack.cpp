@@ -608,11 +608,13 @@ class HostPool {
     uint32_t seen = 0;
     for (;;) {
       uint32_t g;
-      // Optionally stay hot for a while before sleeping (WFL_HOST_SPIN_US): measured on the 256-core box with 1000 us,
-      // same box A/B over the fresh-target steps of cfg3 / cfg4: no consistent gain (0.70-0.75 ms either way at cfg4)
-      // and more variance (a polling worker on the caller's sibling hyperthread) -- the build of 64 alignment graphs
-      // takes ~400 us on 32 threads against 60 us each alone because the graph algebra allocates, not because the
-      // workers wake slowly.  Off by default.
+      // Stay hot for a moment before sleeping (WFL_HOST_SPIN_US, default 100; 0: sleep at once).  A batch is packed in
+      // two parallel phases a few microseconds apart (build, merge): workers that went to sleep after the first are
+      // woken again for the second, and the merge then runs on one thread (see build_batch: it is only shared out
+      // when the pool is hot).  Same-box A/B over the fresh-target steps of cfg4, three rounds each: 0.79 / 0.79 /
+      // 1.06 ms without, 0.64-0.69 ms with 50, 100 or 200 us; cfg3 unchanged (0.518).  1000 us gained nothing more
+      // and put polling workers on the caller's sibling hyperthreads between steps.  The build itself stays at
+      // ~350 us for 64 alignment graphs on 32 threads against 60 us each alone: the graph algebra allocates.
       if (spin_ns_ > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned it = 0; (g = gen_.load(std::memory_order_acquire)) == seen; ++it) {
@@ -638,7 +640,7 @@ class HostPool {
   std::atomic<int> next_{0}, running_{0};
   int n_ = 0;
   uint32_t count_ = 0;  // generation counter (upper 24 bits of gen_), advanced under run_mu_
-  long long spin_ns_ = 0;  // how long a worker polls for the next job before it sleeps (WFL_HOST_SPIN_US; default: not at all)
+  long long spin_ns_ = 100000;  // how long a worker polls for the next job before it sleeps (WFL_HOST_SPIN_US, microseconds)
  public:
   bool hot() const { return spin_ns_ > 0; }
  private:
