@@ -885,7 +885,13 @@ struct OccHeader {
   uint32_t* next;   // [8]  next job of XCD x
   int32_t* list;    // [8][B]
   uint32_t* busy;   // [8][256]  == token while a sweep runs on CU (xcc, HW_ID[15:8])
+  uint32_t* meta;   // [2]       the launch's token and its tiles per utterance (for served_beside_the_sweeps)
 };
+// Did the gradient workgroups that ran beside the sweeps write utterance b's rows?  Not if one of them gave up on it
+// (`bad`), nor if jobs of its XCD were left undrawn (an XCD that hosted sweeps but no gradient workgroup).  Read by the
+// general gradient kernel of wfl_lattice_grad_rest, launches later.
+__device__ __forceinline__ bool served_beside_the_sweeps(const wfl_lattice_desc& d, const float* alpha, int64_t tail, int nch1,
+                                                         int b);
 __device__ __forceinline__ uint32_t cu_key() {  // this wave's CU among the 8 x 256 the ids can name
   uint32_t v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
@@ -899,9 +905,20 @@ __device__ __forceinline__ OccHeader occ_header(const wfl_lattice_desc& d, float
   h.next = reinterpret_cast<uint32_t*>(h.nx + 8);
   h.list = h.nx + 16;
   h.busy = reinterpret_cast<uint32_t*>(h.list + 8 * (int64_t)d.B);
+  h.meta = h.busy + 8 * 256;
   return h;
 }
 
+__device__ __forceinline__ bool served_beside_the_sweeps(const wfl_lattice_desc& d, const float* alpha, int64_t tail, int nch1,
+                                                         int b) {
+  const OccHeader h = occ_header(d, const_cast<float*>(alpha), tail, nch1);
+  const uint32_t token = h.meta[0], ntiles = h.meta[1];
+  if (h.bad[b] == token) return false;
+  const uint64_t va = reinterpret_cast<const uint64_t*>(reinterpret_cast<const double*>(alpha + tail) + prog_offset_doubles(d, nch1))[b];
+  if ((uint32_t)(va >> 32) != token || ((uint32_t)va & 0x0fffffffu) == kProgSkip) return false;
+  const uint32_t x = ((uint32_t)va >> 28) & 7u;
+  return h.next[x] >= (uint32_t)h.nx[x] * ntiles;
+}
 constexpr int kDumpDoubles = 1024;  // scratch behind the alpha / beta tails (see run_chain_prob)
 constexpr int kBandDepth = 4;
 // floats of the probability-domain sweeps' row tile: two chunks of the tile path, or the banded sweep's two tiles of
@@ -1541,8 +1558,7 @@ __global__ void __launch_bounds__(MAXT)
 // utterance; verdict[b] = 1 sends the utterance to the log-domain launch that follows.
 __global__ void __launch_bounds__(256)
     prob_certify_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T,
-                        const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt,
-                        uint32_t token, int ntiles) {
+                        const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt) {
   // grid (B, kCertSplit): every wave takes the checked slots s = wave index, + number of waves, ... on its own
   // (wave-level reductions only); a wave that finds a violation raises the utterance's verdict (cleared by the beta
   // sweep of prob_chain_kernel before it started)
@@ -1557,19 +1573,6 @@ __global__ void __launch_bounds__(256)
   if (!prob_eligible(u, chain_nt)) {
     if (tid == 0) *verdict = 1.0;  // (not swept in the probability domain at all: the log-domain launch takes it)
     return;
-  }
-  if (token) {  // a gradient workgroup of the sweeps' launch could not vouch for what it read (occ_grad_tiles)
-    const OccHeader h = occ_header(d, const_cast<float*>(alpha), tail, nch1);
-    bool redo = h.bad[b] == token;
-    if (!redo) {  // every job of the utterance's XCD drawn?  (an XCD without gradient workgroups leaves them)
-      const uint64_t va = reinterpret_cast<const uint64_t*>(reinterpret_cast<const double*>(alpha + tail) + prog_offset_doubles(d, nch1))[b];
-      const uint32_t x = ((uint32_t)va >> 28) & 7u;
-      redo = h.next[x] < (uint32_t)h.nx[x] * (uint32_t)ntiles;
-    }
-    if (redo) {
-      if (tid == 0) *verdict = 1.0;
-      return;
-    }
   }
   if (za == -__builtin_inf() && zbv == -__builtin_inf()) return;  // no accepting path: exact in any arithmetic
   const double* pa = reinterpret_cast<const double*>(alpha) + u.ab_base;
@@ -1816,9 +1819,8 @@ __device__ __forceinline__ bool occ_eligible(const UttView& u, bool prob) {
 //   * it polls the two progress words of its utterance (relaxed agent-scope loads by one thread, s_sleep in between);
 //   * alpha, beta and the per-slot offsets are read with L1-bypassing loads -- the sweeps' plain stores are in the L2
 //     of THEIR XCD, which is this workgroup's XCD by construction of the grid (the XCC ids in the progress words are
-//     compared with this workgroup's: a mismatch, or a poll that gives up, marks the utterance in `bad` and the
-//     certificate sends it to the log-domain launch and the general gradient kernel, as it does utterances whose
-//     sweeps disagree);
+//     compared with this workgroup's: a mismatch, or a poll that gives up, marks the utterance in `bad` and the general
+//     gradient kernel of wfl_lattice_grad_rest writes its rows later, from the same alpha and beta);
 //   * log2 Z is not known yet: sum_q alpha_s[q] beta_s[q] at the tile's first slot IS Z (every path passes through
 //     exactly one state per slot; the identity the certificate checks at every 8th slot to 1e-4), so the tile
 //     normalises by its own.
@@ -1943,7 +1945,10 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
       if (LIVE) {
         // (the L1-bypassing loads are relaxed atomics, which the compiler does not move across the LDS atomics below:
         // left to it, every pair of loads is waited for before the next is issued -- batches of 16 by hand)
-        constexpr int U = 8;
+#ifndef WFL_LIVE_U
+#define WFL_LIVE_U 8
+#endif
+        constexpr int U = WFL_LIVE_U;
         for (int i0 = tid; i0 < n; i0 += U * NT) {
           double av[U], bv[U];
 #pragma unroll
@@ -2020,8 +2025,8 @@ __global__ void __launch_bounds__(256)
 //                                         XCD, tiles in middle-out order -- the sweeps' plain stores are in that XCD's
 //                                         L2 (see occ_grad_tiles)
 // The kernels themselves do not rely on how workgroups are dealt to XCDs: an utterance whose sweeps ended up on
-// different XCDs is handed to the certificate (`bad`), one whose XCD hosts no gradient workgroup likewise (left-over
-// jobs are detected by the certificate through the job counters).
+// different XCDs is marked in `bad`, one whose XCD hosts no gradient workgroup shows in the job counters: the general
+// gradient kernel of wfl_lattice_grad_rest serves both (served_beside_the_sweeps).
 template <int MAXT>
 __global__ void __launch_bounds__(MAXT)
     prob_chain_pub_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
@@ -2044,7 +2049,7 @@ __global__ void __launch_bounds__(MAXT)
 
 __global__ void __launch_bounds__(64)
     occ_gate_kernel(wfl_lattice_desc d, float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1,
-                    uint32_t token, int force_bad, uint32_t* __restrict__ host_gave_up) {
+                    uint32_t token, int force_bad, uint32_t* __restrict__ host_gave_up, int ntiles) {
   const int lane = threadIdx.x;
   const uint64_t* pa = reinterpret_cast<const uint64_t*>(reinterpret_cast<double*>(alpha + tail) + prog_offset_doubles(d, nch1));
   const uint64_t* pb = reinterpret_cast<const uint64_t*>(reinterpret_cast<double*>(beta + tail) + prog_offset_doubles(d, nch1));
@@ -2084,8 +2089,9 @@ __global__ void __launch_bounds__(64)
     }
   }
   // (the header is written only now, after every sweep of this launch has been seen: the buffers may be the previous
-  // call's, whose certificate reads its header until the stream reaches this call's sweeps)
+  // call's, whose gradient kernel (wfl_lattice_grad_rest) may read its header until the stream reaches this call's sweeps)
   if (lane < 8) h.next[lane] = 0;
+  if (lane == 0) h.meta[0] = token, h.meta[1] = (uint32_t)ntiles;
 #pragma unroll
   for (int x = 0; x < 8; ++x)
     if (lane == 0) h.nx[x] = count[x];
@@ -2197,7 +2203,9 @@ __global__ void __launch_bounds__(256)
     const int band_ok = band_in_arcs(u, weights, tid).ok;
     if (__syncthreads_and(band_ok) && prob && band_shape(d, u)) return;
   }
-  if (skip_occ && occ_eligible(u, prob)) return;  // occ_grad_kernel served this utterance (the same test decides there)
+  // occ_grad_kernel served this utterance (the same test decides there); skip_occ == 2: the gradient workgroups beside
+  // the sweeps did, unless they say otherwise
+  if (skip_occ && occ_eligible(u, prob) && (skip_occ != 2 || served_beside_the_sweeps(d, alpha, tail, nch1, b))) return;
   const float wref = prob ? wrefs[b] : 0.f;
   const float* fgp = xg + xg_main_dev(d, T);                    // probability-domain factors of the gathered rows
   const float* rmaxp = fgp + xg_main_dev(d, T) + (int64_t)b * T;  // their references
@@ -2702,7 +2710,7 @@ int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, i
     ab_tail(*d, T, tail, nch1);
     // (+ kDumpDoubles doubles behind the tail: where the lanes without a state of the unrolled sweeps "store")
     // (+ behind that: a progress word per utterance, and -- alpha only -- `bad` and the OccHeader lists)
-    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2 + 2 * kDumpDoubles + 12 * (int64_t)d->B + 32 + 2048;
+    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2 + 2 * kDumpDoubles + 12 * (int64_t)d->B + 32 + 2048 + 4;
   }
   return WFL_OK;
 }
@@ -2853,6 +2861,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
       const char* e = getenv("WFL_LATTICE_DOMAIN");
       return (e && std::string(e) == "log") ? 1 : 0;
     }();
+    SideStream* join_side = nullptr;
     if (!log_only) {
       // probability-domain sweeps of every utterance whose acceptor allows it ...
       auto launch_prob = [&](auto kern) {
@@ -2881,7 +2890,10 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
       const char* bad_env = getenv("WFL_LATTICE_FUSED_BADXCD");
       uint32_t token = 0;
       int nt_o = 0;
-      if (g && fused_env && beta && T > 0 && nt >= 256 && nt <= 512 && rpc == 16 && d->max_eps == 0 && d->max_labels <= 32767) {
+      // (only while every sweep gets a CU of its own at once: beyond that the gate would wait for the LAST round of
+      // sweeps to be placed, i.e. the gradient would start when the sweeps are nearly over)
+      if (g && fused_env && beta && T > 0 && nt >= 256 && nt <= 512 && rpc == 16 && d->max_eps == 0 && d->max_labels <= 32767 &&
+          2 * ((d->B + 7) & ~7) <= device_cus()) {
         const int ntiles = (T + fused_tile - 1) / fused_tile;
         const int rows_o = (T + ntiles - 1) / ntiles;
         nt_o = (T + rows_o - 1) / rows_o;
@@ -2915,7 +2927,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
           else
             launch_pub(prob_chain_pub_kernel<512>);
           hipLaunchKernelGGL(occ_gate_kernel, dim3(1), dim3(64), 0, side->stream, *d, alpha, beta, tail, nch1, token,
-                             bad_env && atoi(bad_env) == 1 ? 1 : 0, gave_up);
+                             bad_env && atoi(bad_env) == 1 ? 1 : 0, gave_up, nt_o);
           if (olds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)occ_live_kernel, (int)olds);
           const int64_t jobs = (int64_t)d->B * nt_o;
           const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>(jobs, (int64_t)fused_wgs * device_cus()));
@@ -2924,7 +2936,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
                              g->coef, g->x, g->row_lse, g->dx, rows_o, nt_o, rpc, tail, nch1, token);
 #endif
           WFL_HIP_CHECK(hipEventRecord(side->join, side->stream));
-          WFL_HIP_CHECK(hipStreamWaitEvent(main_s, side->join, 0));
+          join_side = side;  // (joined below, behind the certificate: it and the log-domain launch overlap the gradient's tail)
           g->done = 1;
         }
       }
@@ -2939,11 +2951,15 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
         launch_prob(prob_chain_kernel<1024>);
       if (beta)
         hipLaunchKernelGGL(prob_certify_kernel, dim3((unsigned)d->B, 8u), dim3(256), 0, (hipStream_t)stream, *d, ints,
-                           floats, T, alpha, beta, tail, nch1, nt, token, nt_o);
+                           floats, T, alpha, beta, tail, nch1, nt);
     }
     // ... then the log-domain sweeps of the rest (and of utterances whose two sweeps disagree: the certificate)
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,
                        beta, (int32_t*)nullptr, logz, tail, nch1, log_only ? 1 : 2);
+    // (the gradient beside the sweeps: joined only here -- the certificate and the log-domain launch, which normally
+    // finds nothing to do, ran under its tail.  An utterance the log-domain launch re-sweeps while gradient workgroups
+    // still read its alpha / beta gets rows of garbage from them; wfl_lattice_grad_rest overwrites exactly those.)
+    if (join_side) WFL_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, join_side->join, 0));
   } else if (semiring == WFL_SEMIRING_TROPICAL) {
     if (!bptr) {
       set_error("lattice_forward: tropical semiring needs a back-pointer buffer");
@@ -3070,7 +3086,7 @@ static int lattice_grad_impl(const wfl_lattice_desc* d, const int32_t* ints, con
     return e && atoi(e) == 0;
   }();
   const int occ = !occ_off && dx && !dW && !band && d->max_eps == 0 && d->max_labels <= 32767;
-  int occ_done = occ_in_launch;
+  int occ_done = occ_in_launch ? 2 : 0;
   if (occ && !occ_in_launch) {
     const int wgs_t = std::max(1, std::min((T + 15) / 16, 2048 / std::max(1, d->B)));
     const int rows_o = (T + wgs_t - 1) / wgs_t;

@@ -393,7 +393,7 @@ def lattice_formats(st):
     certificate's repair: the two probability-domain sweeps disagreed about Z).  Diagnostics and tests; the layout is
     the tail of the alpha buffer described in csrc/lattice_kernels.hip (chain_kernel)."""
     B, T = st.pack.desc.B, st.T
-    tail = st.alpha.numel() - (2 * (B * (T + 1) + B) + 2 * B + 2 + 2 * 1024 + 12 * B + 32 + 2048)  # (dump + progress words + gradient header)
+    tail = st.alpha.numel() - (2 * (B * (T + 1) + B) + 2 * B + 2 + 2 * 1024 + 12 * B + 32 + 2048 + 4)  # (dump + progress words + gradient header)
     off = tail + 2 * (B * (T + 1) + B)
     return st.alpha[off:off + B].view(torch.int32)
 
