@@ -229,23 +229,16 @@ def make_asg(args, rank, n_batches, dist):
     g = torch.Generator().manual_seed(rank)
     x = torch.randn(B, T, C, generator=g).cuda().requires_grad_(True)
 
-    class Crit(torch.nn.Module):  # asg_benchmark.py:21-22: a free (C+1) x C transitions tensor with requires_grad
-        def __init__(self):
-            super().__init__()
-            self.transitions = torch.nn.Parameter(torch.randn(C + 1, C, generator=torch.Generator().manual_seed(7)))
-
-        def forward(self, inputs, targets):
-            return asg.ASGLoss(inputs, self.transitions, targets)
-
-    crit = Crit().cuda()
+    # asg_benchmark.py:20-22: a free (C+1) x C transitions tensor with requires_grad (here a leaf ON the device)
+    transitions = torch.randn(C + 1, C, generator=torch.Generator().manual_seed(7)).cuda().requires_grad_(True)
     batches = [torch.randint(C - 2, (B, L), generator=g).tolist() for _ in range(n_batches)]
 
     def step(i):
         x.grad = None
-        crit.transitions.grad = None
-        crit(x, batches[i % n_batches]).backward()
+        transitions.grad = None
+        asg.ASGLoss(x, transitions, batches[i % n_batches]).backward()
         if dist is not None:  # the one exchange step of the path (train.py:205-208: DDP averages criterion grads)
-            parallel.sync_transition_grads(crit)
+            parallel.all_reduce_mean_([transitions.grad])
 
     which = " (BASELINE configs[2])" if (T, C, B, L) == (1000, 100, 128, 44) else ""
     meta = dict(workload=f"asg fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L,
@@ -253,7 +246,7 @@ def make_asg(args, rank, n_batches, dist):
                 metric=f"utterances/sec fwd+bwd (asg_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="ASGLoss(x, transitions, targets).backward()",
                 algorithmic_bytes_per_utt=8 * T * C, algorithmic_bytes_per_batch=8 * (C + 1) * C)
-    return dict(step=step, meta=meta, payload=("asg", x.detach(), crit.transitions.detach(), batches[0]))
+    return dict(step=step, meta=meta, payload=("asg", x.detach(), transitions.detach(), batches[0]))
 
 
 def word_pieces():

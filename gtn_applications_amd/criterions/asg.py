@@ -71,19 +71,20 @@ class _EarlyGrads:
     def __init__(self, dx, dW, inputs, transitions):
         self.dx, self.dW, self.inputs, self.transitions, self.taken = dx, dW, inputs, transitions, False
 
-    def peek(self):
-        if self.taken:
-            raise RuntimeError("Trying to backward through the graph a second time (`loss.backward()` handed the ASG "
-                               "loss's gradient buffers to the leaves)")
-        return self.dx, self.dW
+    def fresh(self):
+        return not self.taken
+
+    def claim(self):
+        self.taken = True
+        dx, dW, self.dx, self.dW = self.dx, self.dW, None, None
+        return dx, dW
 
     def take(self):
-        """E.EagerLoss.backward: the buffers become the leaves' .grad (once)"""
+        """E.EagerLoss.backward: the buffers become the leaves' .grad"""
         if self.taken or not all(E.plain_leaf(t) for t, g in ((self.inputs, self.dx), (self.transitions, self.dW))
                                  if g is not None):
             return None
-        self.taken = True
-        dx, dW, self.dx, self.dW = self.dx, self.dW, None, None
+        dx, dW = self.claim()
         return [(t, g) for t, g in ((self.inputs, dx), (self.transitions, dW)) if g is not None]
 
 
@@ -165,31 +166,33 @@ class ASGLossFunction(torch.autograd.Function):
         ctx.aux = (x, W, fcc, cpos, dx_num, dw_num, fork if need_grad else None)
         ctx.devices = (inputs.device, transitions.device)
         ctx.early = None
-        if need_grad and _EARLY_GRAD:
+        if need_grad and _EARLY_GRAD and all(E.plain_leaf(t) for t in (inputs, transitions) if t.requires_grad):
             # The denominator's gradient right behind its sweeps, for grad_output = 1 (as the numerator's): between the
             # forward and the backward kernels of a step the GPU otherwise waits ~30 us for the host to come back
-            # through the autograd engine.  backward scales the two buffers by grad_output; `loss.backward()` takes
-            # them as they are (E.EagerLoss).
+            # through the autograd engine.  `loss.backward()` takes the two buffers as they are (E.EagerLoss); should
+            # the engine run after all, backward scales them by grad_output.  Only when every gradient goes to a plain
+            # leaf tensor (the reference's asg_benchmark.py:19-31 protocol on device tensors): with an nn.Parameter --
+            # the ASG module, anything under DistributedDataParallel -- the engine has to run, and then the buffers
+            # only add two scale launches behind the step (measured at cfg3: 0.487 against 0.476 ms).
             dx = torch.empty_like(x) if need_dx else None
             dW = torch.empty_like(W) if need_dw else None
             fork.join(dx_num, dw_num)
             E.dense_grad(x, W, fcc, cpos, coef_w=cpos, gout=None, dx=dx, accumulate=False, dW=dW, addend=dx_num,
                          dW_addend=dw_num)
             ctx.early = _EarlyGrads(dx, dW, inputs, transitions)
-            ctx.aux = None
-            if all(E.plain_leaf(t) for t, g in ((inputs, dx), (transitions, dW)) if g is not None):
-                ctx.eager_take = ctx.early.take
+            ctx.eager_take = ctx.early.take
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
     @E.on_input_device
     def backward(ctx, grad_output):
-        if ctx.early is not None:
-            # (scaled COPIES: the engine may come back -- retain_graph -- and must find the buffers as they were)
-            dx, dW = ctx.early.peek()
+        if ctx.early is not None and ctx.early.fresh():
+            # the buffers of the forward launches, scaled in place (wfl_scale returns at once when grad_output is 1); a
+            # second pass over a retained graph finds them used and recomputes below
+            dx, dW = ctx.early.claim()
             gout = E.as_device_f32(grad_output.detach().reshape(1), (dx if dx is not None else dW).device)
-            dx = dx * gout if dx is not None and ctx.needs_input_grad[0] else None
-            dW = dW * gout if dW is not None and ctx.needs_input_grad[1] else None
+            dx = E.scale_inplace(dx, gout) if dx is not None and ctx.needs_input_grad[0] else None
+            dW = E.scale_inplace(dW, gout) if dW is not None and ctx.needs_input_grad[1] else None
             if dx is not None and ctx.devices[0].type != "cuda":
                 dx = dx.to(ctx.devices[0])
             if dW is not None and ctx.devices[1].type != "cuda":

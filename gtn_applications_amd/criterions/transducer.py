@@ -368,12 +368,13 @@ class TransducerLossFunction(torch.autograd.Function):
     @staticmethod
     @E.on_input_device
     def backward(ctx, grad_output):
-        if ctx.early is not None:  # the launch of the sweeps wrote the gradient for grad_output = 1
-            if ctx.early.dx is None:
-                raise RuntimeError("Trying to backward through the graph a second time (`loss.backward()` handed the "
-                                   "Transducer loss's gradient buffer to the emissions)")
-            gout = E.as_device_f32(grad_output.detach().reshape(1), ctx.early.dx.device)
-            dx = ctx.early.dx * gout  # (a scaled COPY: under retain_graph the engine comes back for the buffer)
+        if ctx.early is not None and ctx.early.dx is not None:
+            # the launch of the sweeps wrote the gradient for grad_output = 1: scaled in place (wfl_scale returns at once
+            # when grad_output is 1), then the rows of the utterances that launch did not serve.  A second pass over a
+            # retained graph finds the buffer gone and recomputes below.
+            dx, ctx.early.dx = ctx.early.dx, None
+            gout = E.as_device_f32(grad_output.detach().reshape(1), dx.device)
+            E.scale_inplace(dx, gout)
             E.lattice_grad_rest(ctx.early.num, ctx.early.cneg, gout, dx)
             return (dx if ctx.devices[0].type == "cuda" else dx.to(ctx.devices[0])), None, None, None, None, None, None
         x, params, num, den, cpos, cneg, dense = ctx.aux

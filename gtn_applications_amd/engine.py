@@ -500,9 +500,10 @@ class EagerLoss(torch.Tensor):
     buffers to the leaves' .grad without a trip through the autograd engine (its two thread hand-overs, the ones_like
     fill and the scale passes over [B, T, C] leave the GPU idle between the forward and the backward kernels).  The
     autograd node says whether that is possible through `eager_take()` -> [(leaf, grad), ...] or None (non-leaf inputs,
-    hooks, ...).  Anything else -- a gradient argument, retain_graph, create_graph, inputs=, anomaly mode, the loss
+    hooks, parameters, ...).  Anything else -- a gradient argument, retain_graph, create_graph, inputs=, anomaly mode, the loss
     inside a larger expression -- goes through torch.Tensor.backward / the engine, where the node scales the buffers
-    by grad_output."""
+    by grad_output (in place, a launch that returns at once when grad_output is 1; a second pass over a retained graph
+    recomputes)."""
 
     __torch_function__ = torch._C._disabled_torch_function_impl
 
@@ -522,8 +523,10 @@ class EagerLoss(torch.Tensor):
 
 
 def plain_leaf(t):
-    """May EagerLoss.backward write t.grad itself?  (a leaf that requires grad, on the device, without hooks)"""
-    return (type(t) in (torch.Tensor, torch.nn.Parameter) and t.is_leaf and t.requires_grad and t.is_cuda
+    """May EagerLoss.backward write t.grad itself?  A plain leaf tensor that requires grad, on the device, without
+    hooks -- and NOT an nn.Parameter: DistributedDataParallel (train.py:205-208 wraps criteria that have parameters)
+    hangs its gradient all-reduce on the parameter's AccumulateGrad node, which only the autograd engine runs."""
+    return (type(t) is torch.Tensor and t.is_leaf and t.requires_grad and t.is_cuda
             and not t._backward_hooks and not getattr(t, "_post_accumulate_grad_hooks", None))
 
 

@@ -979,20 +979,20 @@ def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(c
     close(dx, ref_dx.cpu().numpy(), rtol=1e-4, atol=1e-6, msg="loss.backward()")
     loss, dx, _ = run(2.5)
     close(dx, 2.5 * ref_dx.cpu().numpy(), rtol=1e-4, atol=2.5e-6, msg="autograd engine, grad_output 2.5")
-    # .grad accumulates; a second backward through the same graph is refused (the buffer was handed over)
+    # .grad accumulates; a second backward through the same graph finds the buffer handed over and recomputes
     xi = x.clone().requires_grad_(True)
     m(xi, tg).backward()
     loss = m(xi, tg)
     loss.backward()
     close(xi.grad, 2 * ref_dx.cpu().numpy(), rtol=1e-4, atol=2e-6, msg="accumulated .grad")
-    with pytest.raises(RuntimeError):
-        loss.backward()
-    # through the engine the buffer survives for a retained graph
+    loss.backward()
+    close(xi.grad, 3 * ref_dx.cpu().numpy(), rtol=1e-4, atol=3e-6, msg="second backward")
+    # through the engine: the buffer scaled in place on the first pass, recomputed on the second (retained graph)
     xi = x.clone().requires_grad_(True)
-    loss = m(xi, tg) * 1.0
+    loss = m(xi, tg) * 1.5
     loss.backward(retain_graph=True)
     loss.backward()
-    close(xi.grad, 2 * ref_dx.cpu().numpy(), rtol=1e-4, atol=2e-6, msg="retain_graph")
+    close(xi.grad, 3 * ref_dx.cpu().numpy(), rtol=1e-4, atol=3e-6, msg="retain_graph")
 
 
 def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificate(crit, monkeypatch):
