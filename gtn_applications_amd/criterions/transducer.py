@@ -141,15 +141,19 @@ def _zero_weight_view(graph):
     return g
 
 
-def _alignment_graph(target, tokens, lexicon, transitions):
+def _alignment_graph(target, tokens, lexicon, transitions, direct=False):
     """transducer.py:265-281: every frame-level alignment of every decomposition of `target` into
-    tokens, optionally intersected with the transition model.  Returns (graph, weight ids)."""
-    key = (tuple(target), id(tokens), id(lexicon), id(transitions))
+    tokens, optionally intersected with the transition model.  Returns (graph, weight ids).
+    direct=True: the alignments written down without the composition where the token graph allows it
+    (G.token_alignments -- what the native batch packer does; isomorphic, not identical)."""
+    key = (tuple(target), id(tokens), id(lexicon), id(transitions), bool(direct))
 
     def build():
         tgt = make_chain_graph(target)
         tokens_target = G.remove(G.project_output(G.compose(tgt, lexicon)))
-        ali = G.project_input(G.remove(G.compose(tokens, tokens_target)))
+        ali = G.token_alignments(tokens, tokens_target) if direct else None
+        if ali is None:
+            ali = G.project_input(G.remove(G.compose(tokens, tokens_target)))
         if transitions is None:
             return ali, None, (tokens, lexicon)
         ali, from_trans, _ = G.compose(transitions, ali, provenance=True)

@@ -75,6 +75,8 @@ struct wfl_graph {
   // lazily built: 0 not looked at yet, 1 `lex_trie` is valid, -1 the graph is not lexicon-shaped
   mutable int lex_state = 0;
   mutable std::shared_ptr<wfl::LexTrie> lex_trie;
+  // lazily found: 0 not looked at yet, N > 0 the graph is make_token_graph(N tokens, blank optional, no repeats), -1 not
+  mutable int tok_state = 0;
 
   int num_nodes() const { return (int)start.size(); }
   int64_t num_arcs() const { return (int64_t)src.size(); }
@@ -82,6 +84,7 @@ struct wfl_graph {
     out_by_il_ok = out_by_ol_ok = false;
     lex_state = 0;
     lex_trie.reset();
+    tok_state = 0;
   }
   const wfl::Adjacency& out_sorted(bool by_olabel) const;
 };
@@ -92,6 +95,14 @@ namespace wfl {
 // prefix trie of the entries instead of composing with the reference's unshared-prefix lexicon graph.  Returns
 // nullptr (no error set) if `lexicon` does not have that shape: the caller composes generically.
 wfl_graph* lexicon_decompose(const wfl_graph* lexicon, const int32_t* target, int len);
+// All frame-level alignments of the token sequences of `tokens_target` (an acceptor over token labels, one start
+// node), as the acceptor project_input(remove(compose(tokens, tokens_target))) would give it (transducer.py:273-276),
+// written down directly for the token graph of make_token_graph(N, blank="optional", allow_repeats=False)
+// (transducer.py:78-123; the Transducer benchmark's): composing with its N^2 token -> token arcs is half of the
+// packer's time per utterance.  Returns nullptr (no error set) if `tokens` does not have that shape or
+// `tokens_target` more than one start node: the caller composes generically.  The result is isomorphic to the generic
+// one, not identical (node and arc order differ).
+wfl_graph* token_alignments(const wfl_graph* tokens, const wfl_graph* tokens_target);
 }  // namespace wfl
 
 struct wfl_lattice_host {

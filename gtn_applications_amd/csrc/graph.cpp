@@ -174,6 +174,110 @@ wfl_graph* lexicon_decompose(const wfl_graph* lexicon, const int32_t* target, in
   return out;
 }
 
+// Is `g` exactly what make_token_graph(N, "optional", False) builds?  Node 0 start + accept (idle), nodes 1..N the tokens
+// (accept), node N + 1 the blank; arcs: 0 -> blank [N : eps], blank -> 0 [eps : eps], then per token i:
+// 0 -> i+1 [i : i], i+1 -> i+1 [i : eps], i+1 -> blank [N : eps], i+1 -> j+1 [j : j] for every j != i.
+static int token_graph_shape(const wfl_graph& g) {
+  const int64_t nodes = g.num_nodes(), arcs = g.num_arcs();
+  const int64_t N = nodes - 2;
+  if (N < 1 || arcs != 2 + N * (3 + (N - 1))) return -1;
+  for (int64_t n = 0; n < nodes; ++n)
+    if (g.start[n] != (n == 0) || g.accept[n] != (n <= N)) return -1;
+  auto is = [&](int64_t a, int64_t s, int64_t d, int64_t il, int64_t ol) {
+    return g.src[a] == s && g.dst[a] == d && g.il[a] == il && g.ol[a] == ol && g.w[a] == 0.f;
+  };
+  const int64_t B = N + 1;
+  if (!is(0, 0, B, N, WFL_EPSILON) || !is(1, B, 0, WFL_EPSILON, WFL_EPSILON)) return -1;
+  int64_t a = 2;
+  for (int64_t i = 0; i < N; ++i) {
+    if (!is(a, 0, i + 1, i, i) || !is(a + 1, i + 1, i + 1, i, WFL_EPSILON) || !is(a + 2, i + 1, B, N, WFL_EPSILON)) return -1;
+    a += 3;
+    for (int64_t j = 0; j < N; ++j)
+      if (j != i) {
+        if (!is(a, i + 1, j + 1, j, j)) return -1;
+        ++a;
+      }
+  }
+  return (int)N;
+}
+
+wfl_graph* token_alignments(const wfl_graph* tokens, const wfl_graph* tt) {
+  int N;
+  {
+    std::lock_guard<std::mutex> lock(tokens->mu);
+    if (tokens->tok_state == 0) tokens->tok_state = token_graph_shape(*tokens);
+    N = tokens->tok_state;
+  }
+  if (N < 0) return nullptr;
+  const int M = tt->num_nodes();
+  const int64_t A = tt->num_arcs();
+  int u0 = -1;
+  for (int u = 0; u < M; ++u)
+    if (tt->start[u]) {
+      if (u0 >= 0) return nullptr;
+      u0 = u;
+    }
+  if (u0 < 0) return nullptr;
+  for (int64_t a = 0; a < A; ++a)
+    if (tt->il[a] < 0 || tt->il[a] >= N || tt->il[a] != tt->ol[a]) return nullptr;  // (an acceptor over the tokens)
+  // out-arcs of tokens_target by node (counting sort: a few hundred arcs)
+  std::vector<int32_t> ptr(M + 1, 0), order(A);
+  for (int64_t a = 0; a < A; ++a) ++ptr[tt->src[a] + 1];
+  for (int u = 0; u < M; ++u) ptr[u + 1] += ptr[u];
+  {
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t a = 0; a < A; ++a) order[fill[tt->src[a]]++] = (int32_t)a;
+  }
+  // states: 0 = (idle, u0) | 1 + u = (blank, u) | then one per distinct (token k, node v) some arc of tokens_target
+  // enters v with; `tok_of[a]` = the state arc a of tokens_target leads to
+  auto* out = new wfl_graph();
+  out->start.assign(1 + M, 0), out->accept.assign(1 + M, 0);
+  out->start[0] = 1, out->accept[0] = tt->accept[u0];
+  for (int u = 0; u < M; ++u) out->accept[1 + u] = tt->accept[u];
+  std::vector<int32_t> tok_of(A), in_ptr(M + 1, 0), in_order(A);
+  for (int64_t a = 0; a < A; ++a) ++in_ptr[tt->dst[a] + 1];
+  for (int v = 0; v < M; ++v) in_ptr[v + 1] += in_ptr[v];
+  {
+    std::vector<int32_t> fill(in_ptr.begin(), in_ptr.end() - 1);
+    for (int64_t a = 0; a < A; ++a) in_order[fill[tt->dst[a]]++] = (int32_t)a;
+  }
+  std::vector<int32_t> tok_label, tok_node;  // per token state
+  for (int v = 0; v < M; ++v)
+    for (int i = in_ptr[v]; i < in_ptr[v + 1]; ++i) {  // (a node has a handful of in-arcs: quadratic is fine)
+      const int32_t a = in_order[i];
+      int32_t id = -1;
+      for (int j = in_ptr[v]; j < i; ++j)
+        if (tt->il[in_order[j]] == tt->il[a]) {
+          id = tok_of[in_order[j]];
+          break;
+        }
+      if (id < 0) {
+        id = out->num_nodes();
+        out->start.push_back(0), out->accept.push_back(tt->accept[v]);
+        tok_label.push_back(tt->il[a]), tok_node.push_back(v);
+      }
+      tok_of[a] = id;
+    }
+  auto arc = [&](int32_t s, int32_t d, int32_t lab, float w) {
+    out->src.push_back(s), out->dst.push_back(d), out->il.push_back(lab), out->ol.push_back(lab), out->w.push_back(w);
+  };
+  auto leave = [&](int32_t s, int u, int32_t not_token) {  // blank, then every token arc of tokens_target out of u
+    arc(s, 1 + u, N, 0.f);
+    for (int i = ptr[u]; i < ptr[u + 1]; ++i) {
+      const int32_t a = order[i];
+      if (tt->il[a] != not_token) arc(s, tok_of[a], tt->il[a], tt->w[a]);
+    }
+  };
+  leave(0, u0, -1);
+  for (int u = 0; u < M; ++u) leave(1 + u, u, -1);
+  for (size_t t = 0; t < tok_label.size(); ++t) {
+    const int32_t s = 1 + M + (int32_t)t;
+    arc(s, s, tok_label[t], 0.f);  // one more frame of the token
+    leave(s, tok_node[t], tok_label[t]);
+  }
+  return out;
+}
+
 }  // namespace wfl
 
 const wfl::Adjacency& wfl_graph::out_sorted(bool by_olabel) const {
@@ -633,6 +737,11 @@ wfl_graph* wfl_graph_viterbi_path(const wfl_graph* g) {
 // ---------------------------------------------------------------------------------------------
 // equal / isomorphic
 // ---------------------------------------------------------------------------------------------
+wfl_graph* wfl_graph_token_alignments(const wfl_graph* tokens, const wfl_graph* tokens_target) {
+  if (!tokens || !tokens_target) return nullptr;
+  return wfl::token_alignments(tokens, tokens_target);
+}
+
 int wfl_graph_equal(const wfl_graph* a, const wfl_graph* b) {
   if (a->num_nodes() != b->num_nodes() || a->num_arcs() != b->num_arcs()) return 0;
   if (a->start != b->start || a->accept != b->accept) return 0;

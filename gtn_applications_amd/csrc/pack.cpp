@@ -848,13 +848,23 @@ bool alignment_acceptor(const wfl_graph* tokens, const wfl_graph* lexicon, const
   }
   GraphOwner tokens_target(tt);
   PROF(1)
-  GraphOwner c2(wfl_graph_compose(tokens, tokens_target.g, nullptr, nullptr));
-  if (!c2.g) return false;
+  // alignments = project_input(remove(compose(tokens, tokens_target))): written down directly for the benchmark's token
+  // graph (wfl::token_alignments), the generic graph algebra otherwise (WFL_PACK_GENERIC=1: always)
+  static const bool generic_only = [] {
+    const char* e = getenv("WFL_PACK_GENERIC");
+    return e && atoi(e) != 0;
+  }();
+  wfl_graph* direct = generic_only ? nullptr : wfl::token_alignments(tokens, tokens_target.g);
   PROF(2)
-  GraphOwner ali(wfl_graph_remove(c2.g, WFL_EPSILON, WFL_EPSILON, nullptr));
-  if (!ali.g) return false;
+  if (!direct) {
+    GraphOwner c2(wfl_graph_compose(tokens, tokens_target.g, nullptr, nullptr));
+    if (!c2.g) return false;
+    direct = wfl_graph_remove(c2.g, WFL_EPSILON, WFL_EPSILON, nullptr);
+    if (!direct) return false;
+    direct->ol = direct->il;  // project_input
+  }
+  GraphOwner ali(direct);
   PROF(3)
-  ali.g->ol = ali.g->il;  // project_input
   const wfl_graph* fin = ali.g;
   int32_t* prov = nullptr;
   wfl_graph* with_trans = nullptr;

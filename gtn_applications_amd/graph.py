@@ -172,6 +172,13 @@ def viterbi_path(g):
     return Graph(False, _handle=N.check_handle(N.lib.wfl_graph_viterbi_path(g._h)))
 
 
+def token_alignments(tokens, tokens_target):
+    """project_input(remove(compose(tokens, tokens_target))) written down directly (wfl_graph_token_alignments), or
+    None if `tokens` is not make_token_graph(N, blank="optional", allow_repeats=False)."""
+    h = N.lib.wfl_graph_token_alignments(tokens._h, tokens_target._h)
+    return Graph(False, _handle=h) if h else None
+
+
 def equal(a, b):
     return bool(N.lib.wfl_graph_equal(a._h, b._h))
 

@@ -81,6 +81,11 @@ wfl_graph* wfl_graph_project(const wfl_graph* g, int output);
  * Ties: maximum weight, then fewest non-epsilon output labels ("we take the shortest",
  * transducer.py:226-227), then first found.  Result is a chain graph. */
 wfl_graph* wfl_graph_viterbi_path(const wfl_graph* g);
+/* project_input(remove(compose(tokens, tokens_target))) (transducer.py:273-276) without the composition, for
+ * tokens = make_token_graph(N, blank="optional", allow_repeats=False) (transducer.py:78-123) and a
+ * single-start acceptor over the tokens: isomorphic to what the three calls give.  NULL (and no
+ * error) if `tokens` does not have that shape -- use the three calls. */
+wfl_graph* wfl_graph_token_alignments(const wfl_graph* tokens, const wfl_graph* tokens_target);
 /* gtn.equal / gtn.isomorphic (tests/transducer_test.py:47-55,376-418) */
 int wfl_graph_equal(const wfl_graph* a, const wfl_graph* b);
 int wfl_graph_isomorphic(const wfl_graph* a, const wfl_graph* b);

@@ -518,7 +518,9 @@ def test_target_labels_are_range_checked_before_any_kernel_sees_them():
 def test_native_batch_builder_equals_per_utterance_graph_algebra(with_transitions):
     """wfl_transducer_pack_batch (thread pool over the batch, transducer.py:262-281,296) produces exactly the
     packed batch that composing / removing / projecting utterance by utterance and then packing does --
-    serial and threaded, several times over (the pool is persistent)."""
+    serial and threaded, several times over (the pool is persistent).  For this token graph (blank optional, no
+    repeats) the packer writes the alignments down without the composition (wfl_graph_token_alignments): the
+    per-utterance side does the same, and that graph is checked to be isomorphic to the composed one."""
     rs = np.random.RandomState(4)
     pieces = ["a", "b", "ab", "ba", "aba", "bab", "c", "ca"]
     g2i = {"a": 0, "b": 1, "c": 2}
@@ -532,7 +534,9 @@ def test_native_batch_builder_equals_per_utterance_graph_algebra(with_transition
     tokens.arc_sort(True)
     for B in (1, 3, 37):
         rows = [[g2i[ch] for _ in range(rs.randint(1, 6)) for ch in pieces[rs.randint(len(pieces))]] for _ in range(B)]
-        graphs, wids = zip(*[TR._alignment_graph(r, tokens, lexicon, trans) for r in rows])
+        graphs, wids = zip(*[TR._alignment_graph(r, tokens, lexicon, trans, direct=True) for r in rows])
+        for r, g in zip(rows, graphs):
+            assert G.isomorphic(g, TR._alignment_graph(r, tokens, lexicon, trans)[0])
         want = E.PackedLattice.from_graphs(list(graphs), C, None, wids=list(wids) if with_transitions else None)
         flat, off, _ = E.flatten_targets(rows)
         for nthreads in (1, 0, 0):
@@ -549,6 +553,37 @@ def test_native_batch_builder_equals_per_utterance_graph_algebra(with_transition
 
     f2, o2, l2 = E.flatten_any([torch.tensor([2, 2, 1]), torch.tensor([0])])
     assert f2.tolist() == [2, 2, 1, 0] and o2.tolist() == [0, 3, 4] and l2 == [3, 1]
+
+
+def test_token_alignments_written_down_directly_are_the_composed_ones():
+    """wfl_graph_token_alignments against project_input(remove(compose(tokens, tokens_target))) (transducer.py:273-276)
+    on the benchmark's 1000 word pieces: isomorphic for targets of 0 .. 15 pieces (repeated pieces, single graphemes,
+    several decompositions); other token graphs are refused (NULL -> the caller composes)."""
+    import random
+
+    import bench
+
+    pieces, g2i = bench.word_pieces()
+    tokens = TR.make_token_graph(pieces, "optional", False)
+    lexicon = TR.make_lexicon_graph(pieces, g2i)
+    tokens.arc_sort(True)
+    rnd = random.Random(3)
+    for trial in range(24):
+        n = (1, 2, 3, 5, 15)[trial % 5]
+        words = [rnd.choice(pieces) for _ in range(n)]
+        if trial % 4 == 0 and n > 1:
+            words[1] = words[0]  # the same piece twice in a row: only through a blank
+        target = [g2i[ch] for w in words for ch in w]
+        tt = G.remove(G.project_output(G.compose(TR.make_chain_graph(target), lexicon)))
+        direct = G.token_alignments(tokens, tt)
+        assert direct is not None
+        composed = G.project_input(G.remove(G.compose(tokens, tt)))
+        assert direct.num_nodes() == composed.num_nodes() and direct.num_arcs() == composed.num_arcs()
+        assert G.isomorphic(direct, composed), words
+    small = ["a", "b", "ab"]
+    tt = G.remove(G.project_output(G.compose(TR.make_chain_graph([0, 1]), TR.make_lexicon_graph(small, {"a": 0, "b": 1}))))
+    for blank, repeats in (("optional", True), ("none", True), ("forced", True)):
+        assert G.token_alignments(TR.make_token_graph(small, blank, repeats), tt) is None
 
 
 def test_host_pool_jobs_with_different_participant_counts():
