@@ -318,6 +318,10 @@ class TransducerLossFunction(torch.autograd.Function):
 
         key = ("num", flat.tobytes(), tuple(lens), id(tokens), id(lexicon), id(transitions), C, dev.index)
 
+        full_key = key + (reduction == "mean",)
+        if full_key not in _PACK_CACHE.data:
+            N.lib.wfl_host_pool_wake()  # (new targets: the packer's threads are awake by the time its job is submitted)
+
         def build():
             # per-sample graph algebra of transducer.py:262-281 for the whole batch: one native call, threaded
             # over the utterances like the reference's gtn.parallel_for (transducer.py:296)
@@ -331,7 +335,7 @@ class TransducerLossFunction(torch.autograd.Function):
             fac = pack.extra
             return pack, fac[:B], fac[B:2 * B], fac[2 * B:], (tokens, lexicon, transitions)
 
-        pack, scale, cpos, cneg, _ = _PACK_CACHE.get(key + (reduction == "mean",), build)
+        pack, scale, cpos, cneg, _ = _PACK_CACHE.get(full_key, build)
         need_grad = inputs.requires_grad or (transition_params is not None and transition_params.requires_grad)
         den = dense = None
         if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288

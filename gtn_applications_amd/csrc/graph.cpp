@@ -258,6 +258,13 @@ wfl_graph* token_alignments(const wfl_graph* tokens, const wfl_graph* tt) {
       }
       tok_of[a] = id;
     }
+  {  // (an upper bound of the arc count, so that no vector grows arc by arc)
+    size_t bound = 1 + (size_t)(ptr[u0 + 1] - ptr[u0]);
+    for (int u = 0; u < M; ++u) bound += 1 + (size_t)(ptr[u + 1] - ptr[u]);
+    for (size_t t = 0; t < tok_node.size(); ++t) bound += 2 + (size_t)(ptr[tok_node[t] + 1] - ptr[tok_node[t]]);
+    for (auto* v : {&out->src, &out->dst, &out->il, &out->ol}) v->reserve(bound);
+    out->w.reserve(bound);
+  }
   auto arc = [&](int32_t s, int32_t d, int32_t lab, float w) {
     out->src.push_back(s), out->dst.push_back(d), out->il.push_back(lab), out->ol.push_back(lab), out->w.push_back(w);
   };

@@ -152,6 +152,11 @@ typedef struct wfl_lattice_host wfl_lattice_host; /* opaque: descriptor + host b
  * (-1: none).  Replaces what gtn.intersect(emissions, A_b) needs to know about A_b. */
 wfl_lattice_host* wfl_lattice_pack(const wfl_graph* const* graphs, const int32_t* const* wid,
                                    int n_graphs, int B, int shared, int C);
+/* Hint that a batch is about to be packed: wakes the host pool's sleeping workers so that the job
+ * submitted a few tens of microseconds later finds them polling (no-op when the pool does not
+ * spin, WFL_HOST_SPIN_US=0). */
+void wfl_host_pool_wake(void);
+
 /* TransducerLossFunction.forward's per-sample host work for a whole batch (transducer.py:262-281 under
  * gtn.parallel_for, :296): for every target b (flat int32 graphemes + offsets[B+1])
  *     tokens_target = remove(project_output(compose(chain(target_b), lexicon)))
