@@ -109,6 +109,7 @@ _SIGS = {
     "wfl_lattice_host_floats": (_P, [_P]),
     # device: generic lattice engine
     "wfl_lattice_workspace": (c_int, [POINTER(LatticeDesc), c_int, POINTER(c_int64), POINTER(c_int64)]),
+    "wfl_lattice_formats_offset": (c_int, [POINTER(LatticeDesc), c_int, POINTER(c_int64)]),
     "wfl_lattice_gather": (c_int, [POINTER(LatticeDesc), _P, _P, c_int, c_int, _P, _P, _P]),
     "wfl_lattice_forward": (c_int, [POINTER(LatticeDesc), _P, _P, _P, c_int, _P, c_int, _P, _P, _P, _P, _P]),
     "wfl_lattice_grad": (

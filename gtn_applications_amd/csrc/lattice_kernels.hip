@@ -2715,6 +2715,19 @@ int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, i
   return WFL_OK;
 }
 
+// where, in the alpha buffer (float units), the int32 [B] sweep formats of a log-semiring forward pass live
+int wfl_lattice_formats_offset(const wfl_lattice_desc* d, int T, int64_t* offset) {
+  if (!d || T < 0 || !offset) {
+    set_error("lattice_formats_offset: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  int64_t tail;
+  int nch1;
+  ab_tail(*d, T, tail, nch1);
+  *offset = tail + 2 * ((int64_t)d->B * nch1 + d->B);  // behind offs[B][nch1] and Z[B] (doubles)
+  return WFL_OK;
+}
+
 static int check_desc(const wfl_lattice_desc* d, const char* who) {
   if (!d || d->B <= 0) {
     set_error("%s: empty batch", who);

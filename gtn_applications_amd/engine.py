@@ -390,11 +390,12 @@ def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_L
 def lattice_formats(st):
     """int32 [B] (device): how each utterance of a log-semiring forward pass was swept -- 1: fp64 probability domain,
     0: fp32 log domain (acceptor with epsilon arcs / in- or out-degree above 8 / more than 1024 states, or the
-    certificate's repair: the two probability-domain sweeps disagreed about Z).  Diagnostics and tests; the layout is
-    the tail of the alpha buffer described in csrc/lattice_kernels.hip (chain_kernel)."""
-    B, T = st.pack.desc.B, st.T
-    tail = st.alpha.numel() - (2 * (B * (T + 1) + B) + 2 * B + 2 + 2 * 1024 + 12 * B + 32 + 2048 + 4)  # (dump + progress words + gradient header)
-    off = tail + 2 * (B * (T + 1) + B)
+    certificate's repair: the two probability-domain sweeps disagreed about Z).  Diagnostics and tests
+    (wfl_lattice_formats_offset)."""
+    B = st.pack.desc.B
+    pos = ctypes.c_int64()
+    N.check(N.lib.wfl_lattice_formats_offset(st.pack._desc_ref, st.T, ctypes.byref(pos)))
+    off = pos.value
     return st.alpha[off:off + B].view(torch.int32)
 
 

@@ -199,6 +199,10 @@ const float* wfl_lattice_host_floats(const wfl_lattice_host* h);
 /* Bytes of scratch the calls below need: xg [B,T,max_labels], alpha/beta [sum_b (T+1) Q_b].
  * Returned through the out pointers (element counts of float32). */
 int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, int64_t* ab_elems);
+/* Diagnostics: offset (float32 elements) in the alpha buffer of the int32 [B] array that says how each
+ * utterance of a log-semiring wfl_lattice_forward was swept (1: fp64 probability domain, 0: fp32 log
+ * domain -- acceptor shape, or the certificate's repair). */
+int wfl_lattice_formats_offset(const wfl_lattice_desc* d, int T, int64_t* offset);
 
 /* Stage 1 (all CUs, coalesced): xg[b,t,k] = x[b,t,labels_b[k]].
  * If row_lse != NULL it also receives logsumexp_c x[b,t,c] and xg is written log-softmaxed
