@@ -2470,7 +2470,14 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   }();
   const bool wide = C > kMTile;
   const bool wide_fits = small_wg ? 2 * mitm_lds_of(MitmK<8>{}, true) <= (size_t)kLdsBytes : mitm_lds_of(MitmK<16>{}, true) <= (size_t)kLdsBytes;
-  if (ppl == 1 && !force_log && mitm_env && !row_lse && (!wide || (wide_env && wide_fits))) {
+  static const int lsm_env = [] {
+    const char* e = getenv("WFL_CTC_MITM_LSM");  // 0: the fused log_softmax criterion through the round-2 pipelined launch
+    return e ? atoi(e) : 1;
+  }();
+  // (fused log_softmax with rows wider than 128 classes stays on the pipelined pair: expanding the compact tile AND
+  // forming the softmax term from full rows in the emitters measured 0.498 against 0.470 ms at T = 2000, C = 512)
+  if (ppl == 1 && !force_log && mitm_env && (!row_lse || (lsm_env && (!wide || lsm_env == 2))) &&
+      (!wide || (wide_env && wide_fits))) {
     auto launch_mitm = [&](auto kern, auto k) -> int {
       using K = decltype(k);
       const size_t lds = mitm_lds_of(k, wide);
@@ -2478,7 +2485,12 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       hipLaunchKernelGGL(kern, dim3((unsigned)(2 * B)), dim3(K::kWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
       return WFL_OK;
     };
-    if (small_wg)
+    if (row_lse) {  // the fused log_softmax criterion (raw scores in, gradient w.r.t. raw scores out)
+      if (small_wg)
+        rc = wide ? launch_mitm(ctc_mitm_kernel<MitmK<8>, true, true>, MitmK<8>{}) : launch_mitm(ctc_mitm_kernel<MitmK<8>, true, false>, MitmK<8>{});
+      else
+        rc = wide ? launch_mitm(ctc_mitm_kernel<MitmK<16>, true, true>, MitmK<16>{}) : launch_mitm(ctc_mitm_kernel<MitmK<16>, true, false>, MitmK<16>{});
+    } else if (small_wg)
       rc = wide ? launch_mitm(ctc_mitm_kernel<MitmK<8>, false, true>, MitmK<8>{}) : launch_mitm(ctc_mitm_kernel<MitmK<8>, false, false>, MitmK<8>{});
     else
       rc = wide ? launch_mitm(ctc_mitm_kernel<MitmK<16>, false, true>, MitmK<16>{}) : launch_mitm(ctc_mitm_kernel<MitmK<16>, false, false>, MitmK<16>{});
@@ -2494,7 +2506,8 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       hipLaunchKernelGGL(kern, rgrid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
       return WFL_OK;
     };
-    rc = lcompact ? launch_repair(ctc_repair_kernel<false, true>) : launch_repair(ctc_repair_kernel<false, false>);
+    rc = lcompact ? (row_lse ? launch_repair(ctc_repair_kernel<true, true>) : launch_repair(ctc_repair_kernel<false, true>))
+                  : (row_lse ? launch_repair(ctc_repair_kernel<true, false>) : launch_repair(ctc_repair_kernel<false, false>));
   } else if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
     const size_t lds = std::max(compact ? compact_lds : rows8_lds, sizeof(FastLdsT));
     static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)

@@ -160,12 +160,16 @@ typedef float mv2f __attribute__((ext_vector_type(2)));
 //                                  factor of the scaled recursion is 2^(ea[i] - ea[i+1]) (bounded by the chain's clamp)
 //   posterior_j(s) = own_j(s) [A part_{j+1}](s)   -- one packed multiply per frame and lane pair
 // DIR: tile row of frame j (the reversed sweep only emits complete blocks, FULL).
-template <class K, int DIR, bool FULL, bool WIDE>
+// LSM (fused log_softmax: the gradient w.r.t. RAW scores): the rows leave as  cf (gamma - softmax(x)),  the softmax
+// term formed from the raw rows (`xsrc`, laid out like `dst`) and the rows' log-sum-exps (`lse_rows`: lane r < 16 holds
+// that of tile row r) while the tile is written out -- the sweeps never see more than the gathered target columns.
+template <class K, int DIR, bool FULL, bool WIDE, bool LSM = false>
 __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f sa, int ea, float4 pk, float rsum, double off_sum,
                                                     MitmLds<K>& S, bool first,
                                                     int cnt, float cf, float g, float gs, bool skipn, bool owner, bool adder,
                                                     int lane, float* rows, const unsigned char* cmap, int ycol, int blank, int C, long long* zmm,
-                                                    float* __restrict__ dst, long long* st_part) {
+                                                    float* __restrict__ dst, long long* st_part,
+                                                    const float* __restrict__ xsrc = nullptr, float lse_rows = 0.f) {
 #if WFL_MITM_STATS
   const long long st_e0 = clock64();
 #endif
@@ -313,45 +317,84 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
 #endif
   const int nrows = FULL ? kBlk : cnt;
   if (WFL_MITM_ABL & 64) return;  // (scratch: a launch that computes the rows and does not store them)
+  const bool soft = LSM && alive;  // (no accepting path: zero gradient, softmax term included)
+  auto softterm = [&](float xv, float l) { return l > WFL_NEG_INF ? cf * __expf((xv == xv ? xv : WFL_NEG_INF) - l) : 0.f; };
   if (WIDE) {
     asm volatile("" ::: "memory");  // (the tile was written through float pointers)
-    compact_expand(rows, cmap, dst, nullptr, 0.f, nrows, C, 1.f, true, false, lane);
+    if (LSM)
+      compact_expand(rows, cmap, dst, xsrc, lse_rows, nrows, C, cf, true, soft, lane);
+    else
+      compact_expand(rows, cmap, dst, nullptr, 0.f, nrows, C, 1.f, true, false, lane);
     return;
   }
-  if ((C & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+  if ((C & 3) == 0 && (((uintptr_t)dst) & 15) == 0 && (!LSM || (((uintptr_t)xsrc) & 15) == 0)) {
     // two rows per instruction: lanes 0..31 one row, lanes 32..63 the next (C / 4 <= 32 float4 per row)
     const int half = lane >> 5, c4 = lane & 31;
     const float4* src = (const float4*)rows + half * (kMTile / 4) + c4;
     float4* out = (float4*)dst + half * (C >> 2) + c4;
     const bool act = c4 < (C >> 2);
-    // all the tile reads first, then the stores: a store waits for its own read only (the stores are volatile asm: the
-    // compiler does not move a read across one, and read / wait / store eight times over is eight exposed LDS round trips)
     typedef float nf4 __attribute__((ext_vector_type(4)));
-    nf4 v[kBlk / 2];
-    asm volatile("" ::: "memory");  // (the tile was written through float pointers)
-#pragma unroll
-    for (int r = 0; r < kBlk; r += 2) {
-      const float4 q = src[(r >> 1) * (kMTile / 2)];
-      v[r >> 1] = nf4{q.x, q.y, q.z, q.w};
-    }
-#pragma unroll
-    for (int r = 0; r < kBlk; r += 2) {
+    auto store = [&](int r, const nf4& q) {
       if (act && (FULL || r + half < nrows)) {
         // write-through (sc0 sc1): the rows leave the L2 as they are produced instead of at the end of the kernel, when
         // 30 MB of dirty lines would be written back at once (measured: 46.5 -> 44.7 us; non-temporal stores: 61 us)
 #if WFL_MITM_STORE == 2
         // (s_nop: a VALU write of the data registers right behind a store of more than 64 bits is a hazard the compiler
         // cannot see through the asm)
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(&out[(r >> 1) * (C >> 1)]), "v"(v[r >> 1]) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(&out[(r >> 1) * (C >> 1)]), "v"(q) : "memory");
 #else
-        *(nf4*)&out[(r >> 1) * (C >> 1)] = v[r >> 1];
+        *(nf4*)&out[(r >> 1) * (C >> 1)] = q;
 #endif
       }
+    };
+    if (LSM) {
+      // in two halves of eight rows (the raw rows of all sixteen in registers next to the tile's spilled 64 of them):
+      // the half's raw rows requested first (clamped to the block's rows), consumed behind its tile reads
+#pragma unroll
+      for (int h8 = 0; h8 < kBlk; h8 += kBlk / 2) {
+        nf4 xv[kBlk / 4], v[kBlk / 4];
+#pragma unroll
+        for (int r = 0; r < kBlk / 2; r += 2)
+          xv[r >> 1] = *((const nf4*)(xsrc + (int64_t)min(h8 + r + half, nrows - 1) * C) + (act ? c4 : 0));
+        asm volatile("" ::: "memory");  // (the tile was written through float pointers)
+#pragma unroll
+        for (int r = 0; r < kBlk / 2; r += 2) {
+          const float4 q = src[((h8 + r) >> 1) * (kMTile / 2)];
+          v[r >> 1] = nf4{q.x, q.y, q.z, q.w};
+        }
+        if (soft) {
+#pragma unroll
+          for (int r = 0; r < kBlk / 2; r += 2) {
+            const float l0 = readlane_f(lse_rows, h8 + r), l1 = readlane_f(lse_rows, h8 + r + 1);
+            const float l = half ? l1 : l0;
+            nf4& o = v[r >> 1];
+            const nf4 xq = xv[r >> 1];
+            o.x -= softterm(xq.x, l), o.y -= softterm(xq.y, l), o.z -= softterm(xq.z, l), o.w -= softterm(xq.w, l);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < kBlk / 2; r += 2) store(h8 + r, v[r >> 1]);
+      }
+    } else {
+      // all the tile reads first, then the stores: a store waits for its own read only (the stores are volatile asm: the
+      // compiler does not move a read across one, and read / wait / store eight times over is eight exposed LDS round trips)
+      nf4 v[kBlk / 2];
+      asm volatile("" ::: "memory");  // (the tile was written through float pointers)
+#pragma unroll
+      for (int r = 0; r < kBlk; r += 2) {
+        const float4 q = src[(r >> 1) * (kMTile / 2)];
+        v[r >> 1] = nf4{q.x, q.y, q.z, q.w};
+      }
+#pragma unroll
+      for (int r = 0; r < kBlk; r += 2) store(r, v[r >> 1]);
     }
   } else {
 #ifndef WFL_MITM_NO_UNALIGNED  // (scratch: instruction counts of the aligned path alone)
-    for (int r = 0; r < nrows; ++r)
-      for (int c = lane; c < C; c += 64) dst[r * C + c] = rows[r * kMTile + c];
+    for (int r = 0; r < nrows; ++r) {
+      const float l = LSM ? readlane_f(lse_rows, r) : 0.f;
+      for (int c = lane; c < C; c += 64)
+        dst[r * C + c] = rows[r * kMTile + c] - ((LSM && soft) ? softterm(xsrc[r * C + c], l) : 0.f);
+    }
 #endif
   }
 }
@@ -459,12 +502,14 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
       if (n == H0) lds_post(&S.zready, 1);
       continue;
     }
+    const float* xsrc = LSM ? a.x + ((int64_t)b * T + t0) * C : nullptr;
+    const float lse_rows = LSM ? a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)] : 0.f;  // (tile row r = frame t0 + r)
     if (cnt == kBlk)
-      ctc_mitm_emit_block<K, DIR, true, WIDE>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                     cmap, ycol, WIDE ? 63 : a.blank, C, zmm, dst, st_part);
+      ctc_mitm_emit_block<K, DIR, true, WIDE, LSM>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+                                     cmap, ycol, WIDE ? 63 : a.blank, C, zmm, dst, st_part, xsrc, lse_rows);
     else if (DIR == 0)
-      ctc_mitm_emit_block<K, 0, false, WIDE>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                    cmap, ycol, WIDE ? 63 : a.blank, C, zmm, dst, st_part);
+      ctc_mitm_emit_block<K, 0, false, WIDE, LSM>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
+                                    cmap, ycol, WIDE ? 63 : a.blank, C, zmm, dst, st_part, xsrc, lse_rows);
     MITM_ACC(st_wait2);
   }
 #if WFL_MITM_STATS

@@ -158,6 +158,30 @@ def test_cfg2_ctc_model_shaped_scores_stay_on_the_fast_path(boost, noise, wrong)
     assert repaired <= 2, f"{repaired} of {B} utterances left the lane-exponent path"
 
 
+def test_cfg2_ctc_module_raw_scores_every_utterance():
+    """The CTC MODULE (ctc.py:99-121, use_pt=False) at BASELINE configs[1]'s shape: raw scores in, log_softmax fused into
+    the meet-in-the-middle launch (the emitters form cf (gamma - softmax(x)) from the raw rows while they write the
+    tile out), every utterance's gradient w.r.t. the RAW scores against the float64 oracle through log_softmax."""
+    from gtn_applications_amd.criterions import ctc
+
+    B, T, C, L = 128, 1000, 100, 44
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, T, C, generator=g)  # (ctc_benchmark.py:21-22: unit-variance scores)
+    targets = torch.randint(C - 2, (B, L), generator=g)
+    lp = torch.log_softmax(x.double(), 2)
+    want_loss, dlp = OR.ctc_loss_grad_batched(lp.numpy(), targets.tolist(), C - 1)  # (dlp = -gamma_b / B)
+    # module: mean over the batch of nll_b / L_b; d/dx = dlp - softmax * sum_c dlp
+    dlp = torch.tensor(dlp, dtype=torch.float64) / L
+    want_dx = (dlp - torch.exp(lp) * dlp.sum(dim=2, keepdim=True)).numpy()
+    xg = x.cuda().requires_grad_(True)
+    loss = ctc.CTC(C - 1, False)(xg, [t for t in targets])
+    loss.backward()
+    assert loss.item() == pytest.approx((want_loss / L).mean(), rel=RTOL)
+    check("cfg2_ctc_module_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / (L * B))
+    rows = xg.grad.sum(dim=2).abs().max().item()  # the gradient through a softmax sums to zero over a row
+    assert rows <= 5e-5 / (L * B) * C
+
+
 def test_cfg3_asg_every_utterance():
     """BASELINE configs[2]: ASGLoss at B=128 with random learned transitions, dx and dW of the whole batch."""
     from gtn_applications_amd.criterions import asg
