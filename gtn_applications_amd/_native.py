@@ -118,6 +118,7 @@ _SIGS = {
     ),
     "wfl_lattice_forward_grad": (
         c_int, [POINTER(LatticeDesc), _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(c_int), _P]),
+    "wfl_lattice_side_join": (c_int, [_P]),
     "wfl_lattice_grad_rest": (
         c_int, [POINTER(LatticeDesc), _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "wfl_lattice_backtrace": (c_int, [POINTER(LatticeDesc), _P, _P, _P, _P, c_int, _P, _P, c_int, _P]),

@@ -354,7 +354,7 @@ class TransducerLossFunction(torch.autograd.Function):
         if transitions is None and inputs.requires_grad and _IN_LAUNCH_GRAD:
             dx_early = torch.empty_like(x)
         num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax,
-                                grad_into=(cneg, dx_early) if dx_early is not None else None)
+                                grad_into=(cneg, dx_early) if dx_early is not None else None, defer_join=True)
         if not num.in_launch:
             dx_early = None
         if den is not None:
@@ -365,6 +365,8 @@ class TransducerLossFunction(torch.autograd.Function):
             loss = E.reduce_loss(den.logz, scale, 1.0, minus=num.logz)
         else:
             loss = E.reduce_loss(num.logz, scale, -1.0)
+        if num.in_launch:
+            E.lattice_side_join()  # (behind the loss reduction: it ran under the tail of the gradient beside the sweeps)
         ctx.aux = (x, params, num, den, cpos, cneg, dense)
         ctx.early = None
         ctx.devices = (inputs.device, None if transition_params is None else transition_params.device)

@@ -2818,7 +2818,8 @@ struct InLaunchGrad {
   const float* x;
   const float* row_lse;
   float* dx;
-  int done;  // out: 1 if the launch computed the occupancy gradient
+  int done;        // out: 1 if the launch computed the occupancy gradient
+  int defer_join;  // in: the caller joins the side stream itself (wfl_lattice_side_join), behind more of its own launches
 };
 static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T,
                                 const float* weights, int semiring, float* alpha, float* beta, int32_t* bptr, float* logz,
@@ -2837,10 +2838,19 @@ int wfl_lattice_forward_grad(const wfl_lattice_desc* d, const int32_t* ints, con
     set_error("lattice_forward_grad: beta, dx and in_launch are required; x and row_lse go together");
     return WFL_ERR_INVALID;
   }
-  InLaunchGrad g{C, coef, x, row_lse, dx, 0};
+  InLaunchGrad g{C, coef, x, row_lse, dx, 0, *in_launch == 2};
   const int rc = lattice_forward_impl(d, ints, floats, xg, T, weights, WFL_SEMIRING_LOG, alpha, beta, nullptr, logz, stream, &g);
   *in_launch = g.done;
   return rc;
+}
+
+int wfl_lattice_side_join(void* stream) {
+  SideStream* side = side_stream_of_device();
+  if (!side) return WFL_OK;
+  std::lock_guard<std::mutex> lock(side->mu);
+  WFL_HIP_CHECK(hipEventRecord(side->join, side->stream));
+  WFL_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, side->join, 0));
+  return WFL_OK;
 }
 
 static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, const float* floats, const float* xg, int T,
@@ -2972,7 +2982,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
     // (the gradient beside the sweeps: joined only here -- the certificate and the log-domain launch, which normally
     // finds nothing to do, ran under its tail.  An utterance the log-domain launch re-sweeps while gradient workgroups
     // still read its alpha / beta gets rows of garbage from them; wfl_lattice_grad_rest overwrites exactly those.)
-    if (join_side) WFL_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, join_side->join, 0));
+    if (join_side && !(g && g->defer_join)) WFL_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, join_side->join, 0));
   } else if (semiring == WFL_SEMIRING_TROPICAL) {
     if (!bptr) {
       set_error("lattice_forward: tropical semiring needs a back-pointer buffer");

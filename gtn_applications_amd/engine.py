@@ -330,13 +330,22 @@ class LatticeState:
     __slots__ = ("pack", "T", "C", "xg", "alpha", "beta", "logz", "weights", "bptr", "x", "row_lse", "in_launch")
 
 
-def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_LOG, log_softmax=False, grad_into=None):
+def lattice_side_join():
+    """The current stream waits for the gradient workgroups that ran beside the sweeps (lattice_forward with
+    defer_join=True)."""
+    N.check(N.lib.wfl_lattice_side_join(stream_ptr()))
+
+
+def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_LOG, log_softmax=False, grad_into=None,
+                    defer_join=False):
     """forward_score(intersect(emissions, A_b)) for every b: returns a LatticeState whose `logz`
     holds the per-utterance score (gtn call sites: ctc.py:50, asg.py:111, stc.py:86,
     transducer.py:283,287).
 
     grad_into = (coef, dx): ask the sweeps' launch to compute the emission gradient for grad_output = 1 as well
-    (wfl_lattice_forward_grad); `st.in_launch` says whether it did -- lattice_grad_rest finishes the job."""
+    (wfl_lattice_forward_grad); `st.in_launch` says whether it did -- lattice_grad_rest finishes the job.
+    defer_join=True: if it did, the caller MUST call lattice_side_join() before anything else touches dx, alpha or
+    beta (it queues the loss reduction first, which then runs under the gradient's tail)."""
     B, T, C = x.shape
     d = pack.desc
     up = getattr(pack, "_uploaded", None)
@@ -368,7 +377,7 @@ def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_L
     st.in_launch = False
     if grad_into is not None and st.beta is not None:
         coef, dx = grad_into
-        flag = ctypes.c_int(0)
+        flag = ctypes.c_int(2 if defer_join else 0)
         N.check(
             N.lib.wfl_lattice_forward_grad(
                 pack._desc_ref, ptr(pack.ints), ptr(pack.floats), ptr(st.xg), T, C, ptr(weights), ptr(st.alpha),

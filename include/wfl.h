@@ -242,6 +242,11 @@ int wfl_lattice_grad(const wfl_lattice_desc* d, const int32_t* ints, const float
  * After in_launch = 1: scale dx by grad_output if it is not 1 (wfl_scale), then call
  * wfl_lattice_grad_rest, which overwrites the rows of the utterances the launch did not serve
  * (other acceptors; utterances the certificate sent to the log-domain sweeps). */
+/* *in_launch on ENTRY: 2 = do not wait for the gradient workgroups before returning to the stream --
+ * the caller queues more of its own launches first (the loss reduction) and then calls
+ * wfl_lattice_side_join(stream), without which nothing may touch dx, alpha or beta afterwards;
+ * any other value: the call joins before it returns. */
+int wfl_lattice_side_join(void* stream);
 int wfl_lattice_forward_grad(const wfl_lattice_desc* d, const int32_t* ints, const float* floats,
                              const float* xg, int T, int C, const float* weights, float* alpha,
                              float* beta, float* logz, const float* coef, const float* x,
