@@ -1945,10 +1945,7 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
       if (LIVE) {
         // (the L1-bypassing loads are relaxed atomics, which the compiler does not move across the LDS atomics below:
         // left to it, every pair of loads is waited for before the next is issued -- batches of 16 by hand)
-#ifndef WFL_LIVE_U
-#define WFL_LIVE_U 8
-#endif
-        constexpr int U = WFL_LIVE_U;
+        constexpr int U = 8;  // (4: one more workgroup per SIMD, 0.414 against 0.409 ms at cfg4)
         for (int i0 = tid; i0 < n; i0 += U * NT) {
           double av[U], bv[U];
 #pragma unroll
@@ -2036,9 +2033,7 @@ __global__ void __launch_bounds__(MAXT)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x % Bp;
   if (b >= d.B) return;
-#ifndef WFL_DBG_NO_PRIO
   __builtin_amdgcn_s_setprio(2);
-#endif
   // the gradient workgroups leave a CU alone while a sweep runs on it (occ_live_kernel)
   uint32_t* busy = occ_header(d, alpha, tail, nch1).busy + cu_key();
   if (threadIdx.x == 0) __hip_atomic_store(busy, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2150,9 +2145,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-#ifdef WFL_DBG_TIMELINE
-__device__ unsigned long long g_dbg[3 * 8192];
-#endif
 __global__ void __launch_bounds__(256)
     grad_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
                 const float* __restrict__ xg, int T, int C, const float* __restrict__ weights,
@@ -2163,9 +2155,6 @@ __global__ void __launch_bounds__(256)
                 int R, int skip_band, int skip_occ) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
-#ifdef WFL_DBG_TIMELINE
-  const unsigned long long dbg_t0 = wall_clock64();
-#endif
   const UttView u = make_view(d, ints, floats, b, T);
   const int Q = u.Q, A = u.A, E = u.E, K = u.K, Kmax = d.max_labels;
   // The dense rows never pass through LDS: posteriors are accumulated per (frame, distinct label)
@@ -2375,18 +2364,6 @@ __global__ void __launch_bounds__(256)
       if (wid >= 0 && g != 0.f) atomicAdd(&dW[wid], g * cw);
     }
   }
-#ifdef WFL_DBG_TIMELINE
-  if (tid == 0) {
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    if (wg < 8192) {
-      unsigned hw;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      unsigned xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      g_dbg[3 * wg] = dbg_t0, g_dbg[3 * wg + 1] = wall_clock64(), g_dbg[3 * wg + 2] = ((unsigned long long)xcc << 32) | hw;
-    }
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2954,10 +2931,8 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
           if (olds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)occ_live_kernel, (int)olds);
           const int64_t jobs = (int64_t)d->B * nt_o;
           const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>(jobs, (int64_t)fused_wgs * device_cus()));
-#ifndef WFL_DBG_NO_LIVE  // (timing experiments: the publishing sweeps alone)
           hipLaunchKernelGGL(occ_live_kernel, dim3(wgs), dim3(256), olds, side->stream, *d, ints, floats, T, g->C, alpha, beta,
                              g->coef, g->x, g->row_lse, g->dx, rows_o, nt_o, rpc, tail, nch1, token);
-#endif
           WFL_HIP_CHECK(hipEventRecord(side->join, side->stream));
           join_side = side;  // (joined below, behind the certificate: it and the log-domain launch overlap the gradient's tail)
           g->done = 1;
@@ -3151,11 +3126,6 @@ int wfl_debug_live_stats(unsigned long long* out, int reset) {
     rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_live), z, sizeof(z));
   }
   return rc;
-}
-#endif
-#ifdef WFL_DBG_TIMELINE
-int wfl_debug_timeline(unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n);
 }
 #endif
 // diagnostic: resident workgroups per CU of the gradient kernel for a given dynamic LDS size
