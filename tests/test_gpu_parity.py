@@ -995,6 +995,43 @@ def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(c
     close(xi.grad, 3 * ref_dx.cpu().numpy(), rtol=1e-4, atol=3e-6, msg="retain_graph")
 
 
+def test_transducer_gradient_beside_the_sweeps_under_cu_contention(crit):
+    """The gradient workgroups wait on progress words of the sweeps (another launch, another stream), the gate kernel on
+    the sweeps' announcement: safe only while everything gets CUs eventually.  A third stream keeps every CU busy with
+    GEMMs and device-wide copies while 12 steps run: every step must give the uncontended loss and gradient (to the
+    bar between two orders of the same float32 sums: a tile's own log Z), and none may fall back wholesale (the
+    probability-domain formats stay)."""
+    tr = crit["transducer"]
+    tokens, g2i, x, tg = _word_piece_batch(24, 320, 13)
+    m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+
+    def run():
+        xi = x.clone().requires_grad_(True)
+        loss = m(xi, tg)
+        loss.backward()
+        return loss.detach().clone(), xi.grad.clone()
+
+    ref_loss, ref_dx = run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda")
+    big = torch.empty(256 * 1024 * 1024 // 4, device="cuda")
+    stop = torch.zeros((), device="cuda")
+    with torch.cuda.stream(side):  # ~1 s of all-CU work queued ahead
+        for _ in range(60):
+            c = a @ a
+            big.copy_(big.roll(1)[: big.numel()])
+            stop += c[0, 0] * 0
+    for step in range(12):
+        loss, dx = run()
+        torch.cuda.current_stream().synchronize()
+        assert loss.item() == pytest.approx(ref_loss.item(), rel=1e-6), f"step {step}"
+        close(dx, ref_dx.cpu().numpy(), rtol=1e-4, atol=1e-6, msg=f"step {step}")
+    busy_during = not side.query()
+    torch.cuda.synchronize()
+    assert busy_during, "the competing stream did not outlast the steps: the test did not exercise contention"
+
+
 def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificate(crit, monkeypatch):
     """WFL_LATTICE_FUSED_BADXCD=1 makes the gate kernel report every utterance as swept on two XCDs (what a different
     workgroup-to-XCD dealing would look like): no gradient workgroup may touch them, the certificate sends them to the
