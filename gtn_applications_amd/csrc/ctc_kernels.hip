@@ -236,7 +236,10 @@ struct ChainLdsT {
   float2 ring[kRing][kBlk][64];  // 24 KiB
   float2 ckbuf[2][64];           // checkpoint hand-off chain wave -> helper wave
   double offbuf[2];
+  float refsum[kRing];           // sum of the per-frame references of the block in the ring slot (integer valued)
 };
+template <bool MAX>
+__device__ __forceinline__ float fold16(const float (&v)[16], int lane);
 
 // only_flagged != 0: repair pass -- run only for utterances whose fast-chain result was rejected.
 // SIGNAL: publish ready[b][dir][block] (agent-scope release) after each checkpoint reached HBM, for the
@@ -291,13 +294,25 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
     }
   };
+  // Per-frame references r_t = rint(largest score of the frame over the target's labels and the blank): the helper
+  // hands the chain FACTORS 2^(x_t - r_t), the block's sum of references goes to the double offset.
   auto stage = [&](int kk) {
+    const int k = dir == 0 ? kk : NB - 1 - kk;
+    const int n = min(kBlk, T - k * kBlk);
+    float xs[kBlk];
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) xs[j] = to_score(LSM ? raw[j] - readlane_f(lse_raw, j) : raw[j]);
+    const float m = fold16<true>(xs, lane);  // every lane: the largest score of frame lane % 16 (lanes > L hold the blank's)
+    const float rr = m > 0.5f * kNegBig ? rintf(m) : 0.f;
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {
-      const float xs = to_score(LSM ? raw[j] - readlane_f(lse_raw, j) : raw[j]);
-      const float xblank = readlane_f(xs, L);
-      ring[kk % kRing][j][lane] = make_float2(has_blank ? xblank : kNegBig, has_label ? xs : kNegBig);
+      // the frame's FACTOR 2^(x_t - r_t) <= ~1.4 (0 for an impossible label): the chain multiplies, see below
+      const float f = xs[j] > 0.5f * kNegBig ? __builtin_amdgcn_exp2f(xs[j] - readlane_f(rr, j)) : 0.f;
+      const float fblank = readlane_f(f, L);
+      ring[kk % kRing][j][lane] = make_float2(has_blank ? fblank : 0.f, has_label ? f : 0.f);
     }
+    const float rs = wave_all_sum(lane < n ? rr : 0.f);
+    if (lane == 0) S.refsum[kk % kRing] = rs;
   };
   if (wave == 1 || wave == 2) {
     if (h < NB) {
@@ -308,9 +323,26 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
   }
   __syncthreads();
 
-  float ab = (lane == 0) ? 0.f : kNegBig;  // virtual slot "before the first frame"
-  float al = kNegBig;
+  // The chain itself runs in the PROBABILITY domain on doubles: alpha' = (alpha + shifted alpha) * factor, renormalised
+  // by an exact power of two per block (offset in `off`, log2 units).  The fp32 log-add chain it replaces
+  // (max + log2(1 + 2^-d) per arc, two transcendentals each) reproduced log Z to ~1e-4 nats over 1000 frames and the
+  // posteriors to 6e-5 .. 1.3e-4 of the coefficient against the float64 oracle -- its per-frame errors do not average
+  // out; a product of independently rounded factors does (2e-6).  Checkpoints keep their format (log2 of the state as
+  // float2 + the double offset): the gradient blocks recompute 16 frames from them as before.
+  double ab = (lane == 0) ? 1.0 : 0.0;  // virtual slot "before the first frame"
+  double al = 0.0;
   double off = 0.0;
+  auto shr1_d = [&](double v) {  // lane i receives lane i-1's value, lane 0 receives 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  };
+  auto log2_ck = [&](double v) {  // log2 of a checkpointed state as a float (sentinel for 0): exponent + log2(mantissa)
+    if (!(v > 0.0)) return kNegBig;
+    const int ex = ((__double2hiint(v) >> 20) & 0x7ff) - 1023;
+    const float mant = (float)__hiloint2double((__double2hiint(v) & 0x800fffff) | 0x3ff00000, __double2loint(v));
+    return (float)ex + __builtin_amdgcn_logf(mant);
+  };
   float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
   double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
   unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
@@ -343,9 +375,11 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
     }
   };
   float2 e[kBlk], en[kBlk];
+  float rs_cur = 0.f, rs_next = 0.f;  // reference sums of the block in `e` / `en`
   if (wave == 0) {
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) e[j] = ring[0][j][lane];
+    rs_cur = S.refsum[0];
   }
   for (int kk = 0; kk < NB; ++kk) {
     if (wave == 0) {
@@ -354,25 +388,26 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       if (kk + 1 < NB) {  // block kk+1 is already staged (the helper runs two blocks ahead)
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) en[j] = ring[(kk + 1) % kRing][j][lane];
+        rs_next = S.refsum[(kk + 1) % kRing];
       }
-      if (kk > 0) {  // renormalise: wave maximum -> double offset
-        const float m = wave_all_max(fmaxf(ab, al));
-        if (m > 0.5f * kNegBig) {
-          ab = fmaxf(ab - m, 4.f * kNegBig);  // keeps dead states at sentinel magnitude over any T
-          al = fmaxf(al - m, 4.f * kNegBig);
-          off += (double)m;
+      if (kk > 0) {  // renormalise: the largest state's binary exponent -> double offset (exact)
+        const double mx = fmax(ab, al);
+        const int ex = mx > 0.0 ? ((__double2hiint(mx) >> 20) & 0x7ff) - 1023 : -(1 << 20);
+        const int em = wave_all_max_int(ex);
+        if (em > -(1 << 20)) {
+          ab = __builtin_amdgcn_ldexp(ab, -em);
+          al = __builtin_amdgcn_ldexp(al, -em);
+          off += (double)em;
         }
       }
-      ckbuf[kk & 1][lane] = make_float2(ab, al);  // checkpoint: state BEFORE this block
+      ckbuf[kk & 1][lane] = make_float2(log2_ck(ab), log2_ck(al));  // checkpoint: state BEFORE this block
       if (lane == 0) offbuf[kk & 1] = off;
-      auto frame = [&](const float2 em) {
-        const float pal = wave_shr1(al, kNegBig);
-        const float nb = lse2_b2(ab, pal);
-        // LSE(al, ab, pal) = LSE(al, nb) when the skip arc exists, LSE(al, ab) otherwise: two 1-exp
-        // log-adds per frame instead of a 2-exp and a 3-exp one
-        const float nl = lse2_b2(al, skip ? nb : ab);
-        ab = nb + em.x;  // no clamp: sentinels only add up (|sum| <= T * 1e30 << FLT_MAX)
-        al = nl + em.y;
+      auto frame = [&](const float2 f) {
+        const double pal = shr1_d(al);
+        const double nb = ab + pal;
+        const double nl = al + (skip ? nb : ab);  // (al + ab + pal when the skip arc exists)
+        ab = nb * (double)f.x;
+        al = nl * (double)f.y;
       };
       if (n == kBlk) {  // straight-line: a per-frame branch costs the lone wave more than the frame's math
 #pragma unroll
@@ -384,6 +419,8 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       }
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) e[j] = en[j];
+      off += (double)rs_cur;  // (the block's references: part of every state's score from here on)
+      rs_cur = rs_next;
     } else {
       if (kk > 0 && wave == kFlusher) flush_checkpoint(kk - 1);
       if ((kk & 1) == h && wave <= 2) {
@@ -396,12 +433,15 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
   if (wave == kFlusher) flush_checkpoint(NB - 1);
   if (dir == 0 && wave == 0) {
     // logZ = LSE(alpha_{T-1}[2L], alpha_{T-1}[2L-1])   (ctc.py:21 accept states)
-    const float a_last = readlane_f(ab, L);
-    const float l_last = L > 0 ? readlane_f(al, L - 1) : kNegBig;
+    auto readlane_d = [&](double v, int l) {
+      return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    };
+    const double a_last = readlane_d(ab, L);
+    const double l_last = L > 0 ? readlane_d(al, L - 1) : 0.0;
     if (lane == 0) {
-      const float zr = lse2_b2(a_last, l_last);
-      const bool alive = zr > 0.5f * kNegBig;
-      const double z2 = alive ? (double)zr + off : -1.0e300;
+      const double tot = a_last + l_last;
+      const bool alive = tot > 0.0;
+      const double z2 = alive ? log2(tot) + off : -1.0e300;
       ((double*)(a.ws + w.z2))[b] = z2;
       publish_nll<SIGNAL, REPAIR>(a, w, b, alive, z2);
     }
@@ -1144,10 +1184,24 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) xl[j] = xrow[(int64_t)min(t0 + j, T - 1) * C + col];  // all 16 gathers in flight
 #pragma unroll
-    for (int j = 0; j < kBlk; ++j) {
-      const float xs = to_score(lsm ? xl[j] - readlane_f(lse_blk, j) : xl[j]);
-      xb[j] = has_blank ? readlane_f(xs, L) : kNegBig;
-      xl[j] = has_label ? xs : kNegBig;
+    for (int j = 0; j < kBlk; ++j) xl[j] = to_score(lsm ? xl[j] - readlane_f(lse_blk, j) : xl[j]);
+    // The block in the probability domain on doubles, with per-frame references as in the chain (ctc_log_chain_body):
+    // alpha'_j beta~'_j = alpha_j beta~_j 2^-R for every frame j < n, R = the sum of the block's references.  The fp32
+    // log-add recursions this replaces carried the states that HOLD the posterior mass at ~2^-100 of the wave's largest
+    // state (random scores: alpha peaks at the late states, beta at the early ones, their product in between), i.e.
+    // rounded every operation at ulp(100) = 7.6e-6: posteriors off by 2..4e-5 mid-utterance, 1.3e-4 at worst
+    // (measured against the float64 oracle).  A double does not care where the mass sits.
+    float ref_sum;
+    {
+      const float m = fold16<true>(xl, lane);  // every lane: the largest score of frame lane % 16 (lanes > L: the blank's)
+      const float rr = m > 0.5f * kNegBig ? rintf(m) : 0.f;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {  // (xb, xl hold FACTORS 2^(x - r) from here on: 0 for impossible / absent states)
+        const float f = xl[j] > 0.5f * kNegBig ? __builtin_amdgcn_exp2f(xl[j] - readlane_f(rr, j)) : 0.f;
+        xb[j] = has_blank ? readlane_f(f, L) : 0.f;
+        xl[j] = has_label ? f : 0.f;
+      }
+      ref_sum = wave_all_sum(lane < n ? rr : 0.f);
     }
     const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
     const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
@@ -1173,35 +1227,52 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
       __hip_atomic_store(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(rdy + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // posterior_t(s) = 2^(alpha_t(s) + beta~_t(s) + U), U = off_alpha(k) + off_beta(k) - log2 Z
-    float U = PIPE ? 0.f : (float)(offa[k] + offb[NB - 1 - k] - z2);
+    // posterior_t(s) = alpha_t(s) beta~_t(s) scale,  scale = 2^(off_alpha(k) + off_beta(k) + R - log2 Z)
     const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
-    float pa_b[kBlk], pa_l[kBlk];
-    float ab = ca.x, al = ca.y;
+    auto from_log2 = [](float lg) -> double {  // a checkpointed state: 2^lg, 0 for the sentinel
+      if (!(lg > 0.5f * kNegBig)) return 0.0;
+      const float fl = floorf(lg);
+      return __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(lg - fl), (int)fl);
+    };
+    auto shr1_d = [](double v) {  // lane i receives lane i-1's value, lane 0 receives 0
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+      return __hiloint2double(hi, lo);
+    };
+    auto shl1_d = [](double v) {  // lane i receives lane i+1's value, lane 63 receives 0
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+      return __hiloint2double(hi, lo);
+    };
+    double pa_b[kBlk], pa_l[kBlk];
+    double ab = from_log2(ca.x), al = from_log2(ca.y);
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {  // alpha forward through the block, kept in registers
-      const float pal = wave_shr1(al, kNegBig);
-      const float nb = lse2_b2(ab, pal);
-      const float nl = lse2_b2(al, skip ? nb : ab);
-      ab = nb + xb[j];
-      al = nl + xl[j];
+      const double pal = shr1_d(al);
+      const double nb = ab + pal;
+      const double nl = al + (skip ? nb : ab);
+      ab = nb * (double)xb[j];
+      al = nl * (double)xl[j];
       pa_b[j] = ab, pa_l[j] = al;
     }
+    double bbd = from_log2(bb), bld = from_log2(bl);
+    double scale;
     if (PIPE) {
-      // local log2 Z at the block's last frame: sum_s 2^(alpha_{n-1}(s) + [transition-propagated beta](s))
-      const float tb0 = lse2_b2(bb, bl);
-      const float tbn0 = wave_shl1(tb0, kNegBig), bbn0 = wave_shl1(bb, kNegBig);
-      const float tl0 = lse2_b2(bl, skipn ? tbn0 : bbn0);
-      float ub = kNegBig, ul = kNegBig;
+      // the block's own Z at its last frame: sum_s alpha_{n-1}(s) [transition-propagated beta](s)
+      const double tb0 = bbd + bld;
+      const double tbn0 = shl1_d(tb0), bbn0 = shl1_d(bbd);  // (both shifts outside any divergent select: see below)
+      const double tl0 = bld + (skipn ? tbn0 : bbn0);
+      double zs = 0.0;
 #pragma unroll
       for (int j = 0; j < kBlk; ++j)
-        if (j == n - 1) ub = pa_b[j] + tb0, ul = pa_l[j] + tl0;
-      const float m = wave_all_max(vmax(ub, ul));
-      const float ssum = wave_all_sum(__builtin_amdgcn_exp2f(ub - m) + __builtin_amdgcn_exp2f(ul - m));
-      if (m > 0.5f * kNegBig && ssum > 0.f)
-        U = -(m + __builtin_amdgcn_logf(ssum));
-      else
-        U = kNegBig;  // no accepting path through this block: every posterior is 2^-huge = 0
+        if (j == n - 1) zs = pa_b[j] * tb0 + pa_l[j] * tl0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) zs += __shfl_xor(zs, o, 64);
+      scale = zs > 0.0 && zs < 1.0e300 ? 1.0 / zs : 0.0;  // (0: no accepting path through this block)
+      alive_blk = scale > 0.0;
+    } else {
+      const double e = offa[k] + offb[NB - 1 - k] - z2 + (double)ref_sum;
+      scale = (z2 > -1.0e299 && e < 1000.0) ? exp2(e) : 0.0;
     }
     float gbv[kBlk];
 #pragma unroll
@@ -1210,15 +1281,14 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
     for (int j = kBlk - 1; j >= 0; --j) {  // beta backwards, in the forward lane mapping
       if (j < n) {
         // blank i -> blank i, label i.  label i -> label i, blank i+1 (and label i+1 if allowed):
-        // LSE(bl, bb[i+1], bl[i+1]) = LSE(bl, tb[i+1]) -- the neighbour's freshly computed value
-        const float tb = lse2_b2(bb, bl);
+        // bl + bb[i+1] + bl[i+1] = bl + tb[i+1] -- the neighbour's freshly computed value
+        const double tb = bbd + bld;
         // (both shifts are taken unconditionally: a DPP inside a divergent branch would read
         // neighbours that are masked off)
-        const float tbn = wave_shl1(tb, kNegBig), bbn = wave_shl1(bb, kNegBig);
-        const float tl = lse2_b2(bl, skipn ? tbn : bbn);
-        // dead / non-existent states carry sentinels: exp2 of them is exactly 0, no select needed
-        const float gb = __builtin_amdgcn_exp2f(pa_b[j] + tb + U);
-        const float gl = __builtin_amdgcn_exp2f(pa_l[j] + tl + U);
+        const double tbn = shl1_d(tb), bbn = shl1_d(bbd);
+        const double tl = bld + (skipn ? tbn : bbn);
+        const float gb = (float)(pa_b[j] * tb * scale);
+        const float gl = (float)(pa_l[j] * tl * scale);
         // blank column: the 16 frames' lane values are summed over the wave together after the loop
         // (per-lane ds_add_f32 instead was measured at 49 us for the kernel vs 28 us: LDS float atomics
         // serialise per active lane; one wave reduction per frame costs 18 instructions x 16)
@@ -1230,13 +1300,12 @@ __device__ __forceinline__ void ctc_grad_body(const CtcArgs& a, bool valid, int 
           if (uniq) rows[j * C + y] = (lsm ? rows[j * C + y] : 0.f) + gl * cf;  // sole writer of this column
           if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl * cf);
         }
-        bb = tb + xb[j];
-        bl = tl + xl[j];
+        bbd = tb * (double)xb[j];
+        bld = tl * (double)xl[j];
       }
     }
     const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
     if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * kCS + 63 : lane * C + a.blank], gtot * cf);
-    if (PIPE) alive_blk = U > 0.5f * kNegBig;
     if (lsm && !alive_blk && !COMPACT)  // no accepting path: zero gradient, softmax term included
       for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
   }

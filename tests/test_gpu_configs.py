@@ -158,6 +158,32 @@ def test_cfg2_ctc_model_shaped_scores_stay_on_the_fast_path(boost, noise, wrong)
     assert repaired <= 2, f"{repaired} of {B} utterances left the lane-exponent path"
 
 
+@pytest.mark.parametrize("spread", [1.5, 2.5])
+def test_cfg2_ctc_scores_the_lane_exponent_step_rejects_are_repaired_to_the_same_bar(spread):
+    """log_softmax(spread * randn): a quarter (1.5) / all (2.5) of the utterances leave the lane-exponent step through its
+    certificate and are recomputed by the repair launch -- the probability-domain chain and gradient blocks on doubles
+    (ctc_log_chain_body, ctc_grad_body) -- to the SAME north-star bar as everything else, every utterance against the
+    float64 oracle.  (Their fp32 log-add predecessors were at 6e-5 .. 1.9e-4 of the coefficient here.)"""
+    from gtn_applications_amd import engine as E
+
+    B, T, C, L = 128, 1000, 100, 44
+    g = torch.Generator().manual_seed(int(spread * 10))
+    lp = torch.log_softmax(spread * torch.randn(B, T, C, generator=g), 2)
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    want_loss, want_dx = OR.ctc_loss_grad_batched(lp.numpy(), targets, C - 1)
+    xd = lp.cuda()
+    tg = E.targets_on_device(targets, xd.device)
+    scale, _, coef = E.loss_factors(tg, "none")
+    dx = torch.full_like(xd, float("nan"))
+    ws, nll = E.ctc_forward_backward(xd, tg, C - 1, coef, None, dx)
+    name = f"cfg2_ctc_spread{spread:g}"
+    check(name + "_nll", nll.cpu().numpy(), want_loss, 0.0)
+    check(name + "_dx", dx.cpu().numpy(), want_dx, 1.0 / B)
+    # (how many went through the repair launch is recorded, not asserted: after a step with many of them the library
+    # runs the log-domain pipelined launch -- the same bodies -- for everything, and then nothing is "repaired")
+    STATS[name + "_repaired_utterances"] = E.ctc_pipeline_repaired(ws, B, T, tg.max_len)
+
+
 def test_cfg2_ctc_module_raw_scores_every_utterance():
     """The CTC MODULE (ctc.py:99-121, use_pt=False) at BASELINE configs[1]'s shape: raw scores in, log_softmax fused into
     the meet-in-the-middle launch (the emitters form cf (gamma - softmax(x)) from the raw rows while they write the
