@@ -86,6 +86,7 @@ _SIGS = {
     "wfl_graph_compose": (_P, [_P, _P, POINTER(_P), POINTER(_P)]),
     "wfl_graph_token_alignments": (_P, [_P, _P]),
     "wfl_host_pool_wake": (None, []),
+    "wfl_ctc_adaptive_reset": (None, []),
     "wfl_graph_remove": (_P, [_P, c_int, c_int, POINTER(_P)]),
     "wfl_graph_project": (_P, [_P, c_int]),
     "wfl_graph_viterbi_path": (_P, [_P]),

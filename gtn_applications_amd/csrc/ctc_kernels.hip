@@ -1846,6 +1846,7 @@ struct LongLds {
   float ring_xb[kRing][kBlk];
   float2 ckbuf[2][64 * PPL];
   double offbuf[2];
+  float refsum[kRing];  // sum of the per-frame references of the block in the ring slot (integer valued)
 };
 
 template <int PPL>
@@ -1880,6 +1881,41 @@ __device__ __forceinline__ float long_read(const float (&v)[PPL], int pos) {
   return readlane_f(s, pos / PPL);
 }
 
+template <int PPL>
+__device__ __forceinline__ double long_read_d(const double (&v)[PPL], int pos) {
+  const int slot = pos % PPL;
+  double s = v[0];
+#pragma unroll
+  for (int p = 1; p < PPL; ++p) s = slot == p ? v[p] : s;  // wave-uniform select
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), pos / PPL),
+                          __builtin_amdgcn_readlane(__double2loint(s), pos / PPL));
+}
+// the probability-domain arithmetic of the log-domain bodies (see ctc_log_chain_body): shifts of doubles, log2 of a
+// state for its float checkpoint, 2^checkpoint as a double, the binary exponent of a positive double
+__device__ __forceinline__ double dshr1(double v) {  // lane i receives lane i-1's value, lane 0 receives 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dshl1(double v) {  // lane i receives lane i+1's value, lane 63 receives 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int dexponent(double v) {  // (v > 0)
+  return ((__double2hiint(v) >> 20) & 0x7ff) - 1023;
+}
+__device__ __forceinline__ float dlog2_ck(double v) {
+  if (!(v > 0.0)) return kNegBig;
+  const float mant = (float)__hiloint2double((__double2hiint(v) & 0x800fffff) | 0x3ff00000, __double2loint(v));
+  return (float)dexponent(v) + __builtin_amdgcn_logf(mant);
+}
+__device__ __forceinline__ double dfrom_log2(float lg) {
+  if (!(lg > 0.5f * kNegBig)) return 0.0;
+  const float fl = floorf(lg);
+  return __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(lg - fl), (int)fl);
+}
+
 template <int PPL, bool SIGNAL, bool LSM = false>
 __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int dir, LongLds<PPL>& S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1909,18 +1945,34 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
       lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
     }
   };
+  // (probability domain on doubles with per-frame references, as ctc_log_chain_body: the ring holds FACTORS 2^(x - r_t))
   auto stage = [&](int kk) {
+    const int kq = dir == 0 ? kk : NB - 1 - kk;
+    const int nq = min(kBlk, T - kq * kBlk);
+    float mxs[kBlk];
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {
-      float xs[PPL];
       const float lj = LSM ? readlane_f(lse_raw, j) : 0.f;
+      float m = kNegBig;
 #pragma unroll
-      for (int p = 0; p < PPL; ++p) xs[p] = to_score(raw[j][p] - lj);
-      const float xblank = long_read<PPL>(xs, L);  // position L has no label: its column is the blank
-      if (lane == 0) S.ring_xb[kk % kRing][j] = xblank;
-#pragma unroll
-      for (int p = 0; p < PPL; ++p) S.ring_xl[kk % kRing][j][lane][p] = c.has_label[p] ? xs[p] : kNegBig;
+      for (int p = 0; p < PPL; ++p) raw[j][p] = to_score(raw[j][p] - lj), m = vmax(m, raw[j][p]);
+      mxs[j] = m;
     }
+    const float mm = fold16<true>(mxs, lane);  // every lane: the largest score of frame lane % 16 (positions past L: the blank's)
+    const float rr = mm > 0.5f * kNegBig ? rintf(mm) : 0.f;
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j) {
+      float fs[PPL];
+      const float rj = readlane_f(rr, j);
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) fs[p] = raw[j][p] > 0.5f * kNegBig ? __builtin_amdgcn_exp2f(raw[j][p] - rj) : 0.f;
+      const float fblank = long_read<PPL>(fs, L);  // position L has no label: its column is the blank
+      if (lane == 0) S.ring_xb[kk % kRing][j] = fblank;
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) S.ring_xl[kk % kRing][j][lane][p] = c.has_label[p] ? fs[p] : 0.f;
+    }
+    const float rs = wave_all_sum(lane < nq ? rr : 0.f);
+    if (lane == 0) S.refsum[kk % kRing] = rs;
   };
   if (wave == 1 || wave == 2) {
     if (h < NB) {
@@ -1931,10 +1983,10 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
   }
   __syncthreads();
 
-  float ab[PPL], al[PPL];
+  double ab[PPL], al[PPL];
 #pragma unroll
-  for (int p = 0; p < PPL; ++p) ab[p] = kNegBig, al[p] = kNegBig;
-  if (lane == 0) ab[0] = 0.f;  // virtual slot "before the first frame"
+  for (int p = 0; p < PPL; ++p) ab[p] = 0.0, al[p] = 0.0;
+  if (lane == 0) ab[0] = 1.0;  // virtual slot "before the first frame"
   double off = 0.0;
   float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
   double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
@@ -1968,6 +2020,7 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
     }
   };
   float e[kBlk][PPL], en[kBlk][PPL], eb[kBlk], ebn[kBlk];
+  float rs_cur = 0.f, rs_next = 0.f;  // reference sums of the block in `e` / `en`
   if (wave == 0) {
 #pragma unroll
     for (int j = 0; j < kBlk; ++j) {
@@ -1975,6 +2028,7 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
 #pragma unroll
       for (int p = 0; p < PPL; ++p) e[j][p] = S.ring_xl[0][j][lane][p];
     }
+    rs_cur = S.refsum[0];
   }
   for (int kk = 0; kk < NB; ++kk) {
     if (wave == 0) {
@@ -1987,38 +2041,36 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
 #pragma unroll
           for (int p = 0; p < PPL; ++p) en[j][p] = S.ring_xl[(kk + 1) % kRing][j][lane][p];
         }
+        rs_next = S.refsum[(kk + 1) % kRing];
       }
-      if (kk > 0) {
-        float mx = kNegBig;
+      if (kk > 0) {  // renormalise: the largest state's binary exponent -> double offset (exact)
+        double mx = 0.0;
 #pragma unroll
-        for (int p = 0; p < PPL; ++p) mx = vmax(mx, vmax(ab[p], al[p]));
-        const float m = wave_all_max(mx);
-        if (m > 0.5f * kNegBig) {
+        for (int p = 0; p < PPL; ++p) mx = fmax(mx, fmax(ab[p], al[p]));
+        const int em = wave_all_max_int(mx > 0.0 ? dexponent(mx) : -(1 << 20));
+        if (em > -(1 << 20)) {
 #pragma unroll
-          for (int p = 0; p < PPL; ++p) {
-            ab[p] = fmaxf(ab[p] - m, 4.f * kNegBig);
-            al[p] = fmaxf(al[p] - m, 4.f * kNegBig);
-          }
-          off += (double)m;
+          for (int p = 0; p < PPL; ++p) ab[p] = __builtin_amdgcn_ldexp(ab[p], -em), al[p] = __builtin_amdgcn_ldexp(al[p], -em);
+          off += (double)em;
         }
       }
 #pragma unroll
-      for (int p = 0; p < PPL; ++p) S.ckbuf[kk & 1][PPL * lane + p] = make_float2(ab[p], al[p]);
+      for (int p = 0; p < PPL; ++p) S.ckbuf[kk & 1][PPL * lane + p] = make_float2(dlog2_ck(ab[p]), dlog2_ck(al[p]));
       if (lane == 0) S.offbuf[kk & 1] = off;
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) {
         if (j < n) {  // (n is uniform; only the last block is short)
-          float pal[PPL], nb[PPL], nl[PPL];
-          pal[0] = wave_shr1(al[PPL - 1], kNegBig);
+          double pal[PPL], nb[PPL], nl[PPL];
+          pal[0] = dshr1(al[PPL - 1]);
 #pragma unroll
           for (int p = 1; p < PPL; ++p) pal[p] = al[p - 1];
 #pragma unroll
           for (int p = 0; p < PPL; ++p) {
-            nb[p] = lse2_b2(ab[p], pal[p]);
-            nl[p] = lse2_b2(al[p], c.skip[p] ? nb[p] : ab[p]);
+            nb[p] = ab[p] + pal[p];
+            nl[p] = al[p] + (c.skip[p] ? nb[p] : ab[p]);
           }
 #pragma unroll
-          for (int p = 0; p < PPL; ++p) ab[p] = nb[p] + eb[j], al[p] = nl[p] + e[j][p];
+          for (int p = 0; p < PPL; ++p) ab[p] = nb[p] * (double)eb[j], al[p] = nl[p] * (double)e[j][p];
         }
       }
 #pragma unroll
@@ -2027,6 +2079,8 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
 #pragma unroll
         for (int p = 0; p < PPL; ++p) e[j][p] = en[j][p];
       }
+      off += (double)rs_cur;  // (the block's references: part of every state's score from here on)
+      rs_cur = rs_next;
     } else {
       if (kk > 0 && wave == kFlusher) flush_checkpoint(kk - 1);
       if ((kk & 1) == h && wave <= 2) {
@@ -2038,12 +2092,12 @@ __device__ __forceinline__ void ctc_long_chain_body(const CtcArgs& a, int b, int
   }
   if (wave == kFlusher) flush_checkpoint(NB - 1);
   if (dir == 0 && wave == 0) {
-    const float a_last = long_read<PPL>(ab, L);
-    const float l_last = L > 0 ? long_read<PPL>(al, L - 1) : kNegBig;
+    const double a_last = long_read_d<PPL>(ab, L);
+    const double l_last = L > 0 ? long_read_d<PPL>(al, L - 1) : 0.0;
     if (lane == 0) {
-      const float zr = lse2_b2(a_last, l_last);
-      const bool alive = zr > 0.5f * kNegBig;
-      const double z2 = alive ? (double)zr + off : -1.0e300;
+      const double tot = a_last + l_last;
+      const bool alive = tot > 0.0;
+      const double z2 = alive ? log2(tot) + off : -1.0e300;
       ((double*)(a.ws + w.z2))[b] = z2;
       a.nll[b] = alive ? (float)(-z2 * 0.6931471805599453) : __builtin_inff();
     }
@@ -2122,15 +2176,31 @@ __device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid,
 #pragma unroll
     for (int p = 0; p < PPL; ++p) xl[j][p] = row[y[p]];
   }
+  // The block in the probability domain on doubles with per-frame references (see ctc_grad_body): xl / xb hold FACTORS.
+  float ref_sum;
+  {
+    float mxs[kBlk];
 #pragma unroll
-  for (int j = 0; j < kBlk; ++j) {
-    float xs[PPL];
-    const float lj = lsm ? readlane_f(lse_blk, j) : 0.f;
+    for (int j = 0; j < kBlk; ++j) {
+      const float lj = lsm ? readlane_f(lse_blk, j) : 0.f;
+      float m = kNegBig;
 #pragma unroll
-    for (int p = 0; p < PPL; ++p) xs[p] = to_score(xl[j][p] - lj);
-    xb[j] = long_read<PPL>(xs, L);
+      for (int p = 0; p < PPL; ++p) xl[j][p] = to_score(xl[j][p] - lj), m = vmax(m, xl[j][p]);
+      mxs[j] = m;
+    }
+    const float mm = fold16<true>(mxs, lane);  // every lane: the largest score of frame lane % 16
+    const float rr = mm > 0.5f * kNegBig ? rintf(mm) : 0.f;
 #pragma unroll
-    for (int p = 0; p < PPL; ++p) xl[j][p] = has_label[p] ? xs[p] : kNegBig;
+    for (int j = 0; j < kBlk; ++j) {
+      float fs[PPL];
+      const float rj = readlane_f(rr, j);
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) fs[p] = xl[j][p] > 0.5f * kNegBig ? __builtin_amdgcn_exp2f(xl[j][p] - rj) : 0.f;
+      xb[j] = long_read<PPL>(fs, L);
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) xl[j][p] = has_label[p] ? fs[p] : 0.f;
+    }
+    ref_sum = wave_all_sum(lane < n ? rr : 0.f);
   }
   const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
   const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
@@ -2144,94 +2214,90 @@ __device__ __forceinline__ void ctc_long_grad_body(const CtcArgs& a, bool valid,
     __builtin_memcpy(&v, &bits, 8);
     return v;
   };
-  float ab[PPL], al[PPL], bb[PPL], bl[PPL];
+  double ab[PPL], al[PPL], bb[PPL], bl[PPL];
 #pragma unroll
   for (int p = 0; p < PPL; ++p) {
     const int pos = PPL * lane + p;
     const float2 ca = pos < P ? load_ck(&cka[(int64_t)k * P + pos]) : make_float2(kNegBig, kNegBig);
-    ab[p] = ca.x, al[p] = ca.y;
-    bb[p] = pos <= L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - pos)]).x : kNegBig;
-    bl[p] = pos < L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - pos)]).y : kNegBig;
+    ab[p] = dfrom_log2(ca.x), al[p] = dfrom_log2(ca.y);
+    bb[p] = dfrom_log2(pos <= L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - pos)]).x : kNegBig);
+    bl[p] = dfrom_log2(pos < L ? load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - pos)]).y : kNegBig);
   }
   if (PIPE && lane == 0) {
     unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
     __hip_atomic_store(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(rdy + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  float U = PIPE ? 0.f : (float)(offa[k] + offb[NB - 1 - k] - ((const double*)(a.ws + w.z2))[b]);
   const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
-  float pa_b[kBlk][PPL], pa_l[kBlk][PPL];
+  double pa_b[kBlk][PPL], pa_l[kBlk][PPL];
 #pragma unroll
   for (int j = 0; j < kBlk; ++j) {  // alpha forward through the block, kept in registers
-    float pal[PPL], nb[PPL], nl[PPL];
-    pal[0] = wave_shr1(al[PPL - 1], kNegBig);
+    double pal[PPL], nb[PPL], nl[PPL];
+    pal[0] = dshr1(al[PPL - 1]);
 #pragma unroll
     for (int p = 1; p < PPL; ++p) pal[p] = al[p - 1];
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
-      nb[p] = lse2_b2(ab[p], pal[p]);
-      nl[p] = lse2_b2(al[p], skip[p] ? nb[p] : ab[p]);
+      nb[p] = ab[p] + pal[p];
+      nl[p] = al[p] + (skip[p] ? nb[p] : ab[p]);
     }
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
-      ab[p] = nb[p] + xb[j], al[p] = nl[p] + xl[j][p];
+      ab[p] = nb[p] * (double)xb[j], al[p] = nl[p] * (double)xl[j][p];
       pa_b[j][p] = ab[p], pa_l[j][p] = al[p];
     }
   }
   // transition-propagated beta of one frame: tb (blank states), tl (label states)
-  auto propagate = [&](float (&tb)[PPL], float (&tl)[PPL]) {
+  auto propagate = [&](double (&tb)[PPL], double (&tl)[PPL]) {
 #pragma unroll
-    for (int p = 0; p < PPL; ++p) tb[p] = lse2_b2(bb[p], bl[p]);
-    const float tb_next_lane = wave_shl1(tb[0], kNegBig), bb_next_lane = wave_shl1(bb[0], kNegBig);
+    for (int p = 0; p < PPL; ++p) tb[p] = bb[p] + bl[p];
+    const double tb_next_lane = dshl1(tb[0]), bb_next_lane = dshl1(bb[0]);  // (both shifts outside any divergent select)
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
-      const float tbn = p + 1 < PPL ? tb[p + 1 < PPL ? p + 1 : 0] : tb_next_lane;
-      const float bbn = p + 1 < PPL ? bb[p + 1 < PPL ? p + 1 : 0] : bb_next_lane;
-      tl[p] = lse2_b2(bl[p], skipn[p] ? tbn : bbn);
+      const double tbn = p + 1 < PPL ? tb[p + 1 < PPL ? p + 1 : 0] : tb_next_lane;
+      const double bbn = p + 1 < PPL ? bb[p + 1 < PPL ? p + 1 : 0] : bb_next_lane;
+      tl[p] = bl[p] + (skipn[p] ? tbn : bbn);
     }
   };
-  if (PIPE) {
-    float tb[PPL], tl[PPL];
+  double scale;
+  if (PIPE) {  // the block's own Z at its last frame
+    double tb[PPL], tl[PPL];
     propagate(tb, tl);
-    float u = kNegBig;
+    double zs = 0.0;
 #pragma unroll
     for (int j = 0; j < kBlk; ++j)
       if (j == n - 1) {
 #pragma unroll
-        for (int p = 0; p < PPL; ++p) u = vmax(u, vmax(pa_b[j][p] + tb[p], pa_l[j][p] + tl[p]));
+        for (int p = 0; p < PPL; ++p) zs += pa_b[j][p] * tb[p] + pa_l[j][p] * tl[p];
       }
-    const float m = wave_all_max(u);
-    float part = 0.f;
 #pragma unroll
-    for (int j = 0; j < kBlk; ++j)
-      if (j == n - 1) {
-#pragma unroll
-        for (int p = 0; p < PPL; ++p)
-          part += __builtin_amdgcn_exp2f(pa_b[j][p] + tb[p] - m) + __builtin_amdgcn_exp2f(pa_l[j][p] + tl[p] - m);
-      }
-    const float ssum = wave_all_sum(part);
-    U = (m > 0.5f * kNegBig && ssum > 0.f) ? -(m + __builtin_amdgcn_logf(ssum)) : kNegBig;
+    for (int o = 32; o > 0; o >>= 1) zs += __shfl_xor(zs, o, 64);
+    scale = zs > 0.0 && zs < 1.0e300 ? 1.0 / zs : 0.0;
+  } else {
+    const double z2 = ((const double*)(a.ws + w.z2))[b];
+    const double e = offa[k] + offb[NB - 1 - k] - z2 + (double)ref_sum;
+    scale = (z2 > -1.0e299 && e < 1000.0) ? exp2(e) : 0.0;
   }
 #pragma unroll
   for (int j = kBlk - 1; j >= 0; --j) {
     if (j < n) {
-      float tb[PPL], tl[PPL];
+      double tb[PPL], tl[PPL];
       propagate(tb, tl);
       float gbs = 0.f;
 #pragma unroll
       for (int p = 0; p < PPL; ++p) {
-        gbs += __builtin_amdgcn_exp2f(pa_b[j][p] + tb[p] + U);
-        const float gl = __builtin_amdgcn_exp2f(pa_l[j][p] + tl[p] + U);
+        gbs += (float)(pa_b[j][p] * tb[p] * scale);
+        const float gl = (float)(pa_l[j][p] * tl[p] * scale);
         if (uniq[p]) rows[j * C + y[p]] = (lsm ? rows[j * C + y[p]] : 0.f) + gl * cf;
         if (dup[p] && gl != 0.f) atomicAdd(&rows[j * C + y[p]], gl * cf);
       }
       const float gsum = wave_reduce_sum_lane63(gbs);
       if (lane == 63 && gsum != 0.f) atomicAdd(&rows[j * C + a.blank], gsum * cf);
 #pragma unroll
-      for (int p = 0; p < PPL; ++p) bb[p] = tb[p] + xb[j], bl[p] = tl[p] + xl[j][p];
+      for (int p = 0; p < PPL; ++p) bb[p] = tb[p] * (double)xb[j], bl[p] = tl[p] * (double)xl[j][p];
     }
   }
-  if (lsm && !(U > 0.5f * kNegBig))  // no accepting path: zero gradient, softmax term included
+  if (lsm && !(scale > 0.0))  // no accepting path: zero gradient, softmax term included
     for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
   {
     float* dst = dx + ((int64_t)b * T + t0) * C;
@@ -2419,6 +2485,25 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
   return WFL_OK;
 }
 
+// what the repair launch of the last lane-exponent step on a workspace reported (see wfl_ctc_forward_backward)
+struct AdaptiveSeen {
+  int32_t* host = nullptr;
+  unsigned skipped = 0;
+};
+static std::mutex g_adaptive_mu;
+static std::map<std::pair<int, const void*>, AdaptiveSeen> g_adaptive_table;
+
+// Forget what earlier steps reported: the next call on any workspace tries the lane-exponent step again.  (A workspace
+// is identified by its address; a caller that hands the same address to unrelated data -- tests, a new data set --
+// can start it from scratch.)
+void wfl_ctc_adaptive_reset(void) {
+  std::lock_guard<std::mutex> lock(g_adaptive_mu);
+  for (auto& kv : g_adaptive_table) {
+    if (kv.second.host) kv.second.host[0] = 0;
+    kv.second.skipped = 0;
+  }
+}
+
 int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
                              int max_len, int blank, float* ws, float* nll, const float* coef, const float* gout,
                              float* dx, const float* loss_scale, float* loss_out, const float* row_lse, void* stream) {
@@ -2451,12 +2536,9 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing((hipStream_t)stream, &capturing);  // (a captured step must not allocate, and replays one choice)
   if (adaptive_on && ppl == 1 && capturing == hipStreamCaptureStatusNone) {
-    struct Seen {
-      int32_t* host = nullptr;
-      unsigned skipped = 0;
-    };
-    static std::mutex mu;
-    static std::map<std::pair<int, const void*>, Seen> table;  // (device, workspace)
+    using Seen = AdaptiveSeen;
+    std::mutex& mu = g_adaptive_mu;
+    auto& table = g_adaptive_table;  // (device, workspace)
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);

@@ -351,6 +351,11 @@ int wfl_ctc_workspace_field(int B, int T, int max_len, int field, int64_t* offse
 int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
                     const int64_t* offsets, int max_len, int blank, int flags, float* ws, float* nll,
                     void* stream);
+/* The adaptive choice between the lane-exponent step and the log-domain step (see
+ * wfl_ctc_forward_backward) remembers, per workspace ADDRESS, how many utterances the last
+ * lane-exponent step had to repair.  This forgets it: the next call tries the lane-exponent step. */
+void wfl_ctc_adaptive_reset(void);
+
 /* wfl_ctc_forward and wfl_ctc_grad as ONE pipelined launch: gradient waves wait for the checkpoints
  * they need and run while the chains are still sweeping.  Same outputs (nll, dx); posteriors are
  * normalised per 16-frame block by the Z the block reproduces.

@@ -184,6 +184,26 @@ def test_cfg2_ctc_scores_the_lane_exponent_step_rejects_are_repaired_to_the_same
     STATS[name + "_repaired_utterances"] = E.ctc_pipeline_repaired(ws, B, T, tg.max_len)
 
 
+@pytest.mark.parametrize("L", [100, 150, 200])
+def test_ctc_long_targets_at_benchmark_length_every_utterance(L):
+    """Targets of 64 .. 255 labels (character targets of real utterances; two to four target positions per lane:
+    ctc_long_chain_body / ctc_long_grad_body, probability domain on doubles) at T = 1000, C = 100: every utterance against
+    the float64 oracle at the common bar.  (The fp32 log-add version of these kernels was at 0.9 .. 1.3e-4 of the
+    coefficient here.)"""
+    from gtn_applications_amd.criterions import ctc
+
+    B, T, C = 32, 1000, 100
+    g = torch.Generator().manual_seed(L)
+    lp = torch.log_softmax(torch.randn(B, T, C, generator=g), 2)
+    targets = [torch.randint(C - 2, (int(n),), generator=g).tolist() for n in torch.randint(L - 30, L + 1, (B,), generator=g)]
+    want_loss, want_dx = OR.ctc_loss_grad_batched(lp.numpy(), targets, C - 1)
+    xg = lp.cuda().requires_grad_(True)
+    loss = ctc.CTCLoss(xg, targets, C - 1, "none")
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss.mean(), rel=RTOL)
+    check(f"ctc_long_L{L}_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / B)
+
+
 def test_cfg2_ctc_module_raw_scores_every_utterance():
     """The CTC MODULE (ctc.py:99-121, use_pt=False) at BASELINE configs[1]'s shape: raw scores in, log_softmax fused into
     the meet-in-the-middle launch (the emitters form cf (gamma - softmax(x)) from the raw rows while they write the
