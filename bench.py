@@ -19,7 +19,8 @@ A "step" = one pass of the hot path over one batch whose inputs -- emissions AND
   --targets fresh       every step (warm-up included) gets targets never seen before, so no content-keyed cache
                         of the engine can hit: per-batch host work (flattening, staging, the upload; for the
                         Transducer the whole graph algebra) is inside the timed region.
-`value` is the operator with the reference benchmarks' protocol; the C-ABI step (`abi_kernels_only`, ctc) and the
+`value` is the operator with the reference benchmarks' protocol; the CTC module on raw scores (`module_raw_scores`), the
+C-ABI step (`abi_kernels_only`, ctc) and the
 cold-cache operator (`fresh_targets`) are reported next to it.
 
 Per-kernel times come from HIP events recorded on the stream each launch goes to, inside the timed region
@@ -185,6 +186,15 @@ def make_ctc(args, rank, n_batches, dist=None):
         if exchange is not None:
             parallel.all_reduce_mean_([exchange])
 
+    # the CTC MODULE (criterions/ctc.py:99-121, use_pt=False): raw scores in, log_softmax fused into the step -- what a
+    # training loop calls; reported next to the headline as `module_raw_scores`
+    module = ctc.CTC(blank, False)
+    module_targets = [torch.tensor(t) for t in batches[0]]
+
+    def module_step(i):
+        xr.grad = None
+        module(xr, module_targets).backward()
+
     # the C-ABI call underneath, targets pre-staged (kernels only)
     dev = x.device
     tg = E.targets_on_device(batches[0], dev)
@@ -218,7 +228,7 @@ def make_ctc(args, rank, n_batches, dist=None):
                 exchange_bytes=0 if exchange is None else exchange.numel() * 4,
                 metric=f"utterances/sec fwd+bwd (ctc_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="CTCLoss(x, targets, blank).backward()", algorithmic_bytes_per_utt=8 * T * C)
-    return dict(step=step, abi_step=abi_step, meta=meta, payload=("ctc", x, batches[0], blank))
+    return dict(step=step, abi_step=abi_step, module_step=module_step, meta=meta, payload=("ctc", x, batches[0], blank))
 
 
 def make_asg(args, rank, n_batches, dist):
@@ -579,6 +589,11 @@ def main():
             out["abi_kernels_only"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
                                        "kernel_ms": ph, "utterances_repaired_in_log_domain": meta["repaired"](),
                                        "what": "wfl_ctc_forward_backward through the C ABI, targets pre-staged: kernels only"}
+        if args.workload == "ctc" and args.mode == "api" and args.config != "cfg5":
+            el, _ = timed_loop(wl["module_step"], extras_steps, 3, fence, False)
+            out["module_raw_scores"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
+                                        "what": "CTC(blank, use_pt=False)(x, targets).backward() on RAW scores: log_softmax "
+                                                "fused into the step (one row_lse pass + the same launch), same targets every step"}
     if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl["payload"], args.cpu_sample_utts)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
