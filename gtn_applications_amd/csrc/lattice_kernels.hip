@@ -2055,7 +2055,7 @@ __global__ void __launch_bounds__(64)
     int xcd = -1;  // -1: not for the in-flight gradient
     if (b < d.B) {
       bool seen = false;
-      for (int spin = 0; spin < (1 << 22) && !seen; ++spin) {  // (gives up after ~7 s: the utterance goes to `bad`)
+      for (int spin = 0; spin < (1 << 20) && !seen; ++spin) {  // (gives up after ~2 s: the utterance goes to `bad`)
         const uint64_t va = __hip_atomic_load(pa + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t vb = __hip_atomic_load(pb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(va >> 32) == token && (uint32_t)(vb >> 32) == token) {
