@@ -332,6 +332,7 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
   double ab = (lane == 0) ? 1.0 : 0.0;  // virtual slot "before the first frame"
   double al = 0.0;
   double off = 0.0;
+  const double skd = skip ? 1.0 : 0.0;
   auto shr1_d = [&](double v) {  // lane i receives lane i-1's value, lane 0 receives 0
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
@@ -405,7 +406,7 @@ __device__ __forceinline__ void ctc_log_chain_body(const CtcArgs& a, int b, int 
       auto frame = [&](const float2 f) {
         const double pal = shr1_d(al);
         const double nb = ab + pal;
-        const double nl = al + (skip ? nb : ab);  // (al + ab + pal when the skip arc exists)
+        const double nl = fma(skd, pal, al + ab);  // al + ab (+ pal when the skip arc exists): no select on a double
         ab = nb * (double)f.x;
         al = nl * (double)f.y;
       };
