@@ -2772,7 +2772,7 @@ static SideStream* side_stream_of_device() {
 static uint32_t* live_gave_up_word() {
   static uint32_t* w = [] {
     uint32_t* p = nullptr;
-    if (hipHostMalloc((void**)&p, 64, hipHostMallocMapped) != hipSuccess || !p) return (uint32_t*)nullptr;
+    if (hipHostMalloc((void**)&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !p) return (uint32_t*)nullptr;
     *p = 0;
     for (const char* name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"}) {
       const char* e = getenv(name);
