@@ -2637,6 +2637,14 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       hipLaunchKernelGGL(kern, dim3((unsigned)(2 * B)), dim3(K::kWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
       return WFL_OK;
     };
+    // wide rows beyond the cache: the sweeps exchange what they gathered as compact rows (ctc_mitm.h, stagers) in the
+    // region the round-2 compact pre-pass used.  WFL_CTC_MITM_XCHG=0: every sweep gathers all its frames from x.
+    static const int xchg_env = [] {
+      const char* e = getenv("WFL_CTC_MITM_XCHG");
+      return e ? atoi(e) : 1;
+    }();
+    a.xc = (wide && xchg_env && ctc_use_xc(B, T, C, max_len)) ? ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3)
+                                                              : nullptr;
     if (row_lse) {  // the fused log_softmax criterion (raw scores in, gradient w.r.t. raw scores out)
       if (small_wg)
         rc = wide ? launch_mitm(ctc_mitm_kernel<MitmK<8>, true, true>, MitmK<8>{}) : launch_mitm(ctc_mitm_kernel<MitmK<8>, true, false>, MitmK<8>{});
@@ -2648,6 +2656,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
       rc = wide ? launch_mitm(ctc_mitm_kernel<MitmK<16>, false, true>, MitmK<16>{}) : launch_mitm(ctc_mitm_kernel<MitmK<16>, false, false>, MitmK<16>{});
     if (rc) return rc;
     WFL_LAUNCH_CHECK();
+    a.xc = nullptr;  // (only the first halves' frames are in it)
     a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
     if (a.token == 0) a.token = 1;
     auto launch_repair = [&](auto kern) -> int {

@@ -592,14 +592,63 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     // ================================================================ stagers
     __builtin_amdgcn_s_setprio(2);  // the chain waits for them; the emitters next to them are throughput work
     const int h = ridx;
+    // Wide rows from HBM (a.xc != NULL: the caller reserved [B][T][64] floats): the frames a sweep crosses in its SECOND
+    // half were gathered by the partner in ITS first half -- 45 scattered columns of a 2 KB row, most of the row's
+    // cache lines for 4 bytes each.  The first-half stagers therefore leave what they gathered as compact rows (slot
+    // = target position in forward orientation, slot L the blank: 256 contiguous bytes per frame, write-through) with a
+    // flag per block, and a second-half stager reads those instead of gathering again -- from kXcLag blocks behind the
+    // middle on (the stagers run ahead of their chain, so right behind the middle the partner's rows are not there yet;
+    // with the lag the flag is always up when it is looked at).  x is then gathered ~1.1 times instead of twice.
+    const bool xchg = WIDE && a.xc != nullptr;
+    constexpr int kXcLag = K::kSlots + 3;
+    const int H0p = mitm_first_emitted(NB, 1 - dir);  // the partner's first half: its blocks n < H0p
+    float* const xcb = xchg ? const_cast<float*>(a.xc) + (int64_t)b * T * kXcStride : nullptr;
+    const int pslot = dir == 0 ? lane : (lane < L ? L - 1 - lane : lane);  // forward-orientation slot of this lane's column
+    unsigned long long* const xflag = (unsigned long long*)(a.ws + w.ready);  // [b][dir][NB]: entry 1 + n (0: the half flag)
     auto issue = [&](int n, float (&raw)[kBlk]) {
       const int k = dir == 0 ? n : NB - 1 - n;
       const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
+      if (xchg && n >= H0 + kXcLag) {
+        // the partner crossed this block as ITS block NB - 1 - n and published it
+        const unsigned long long* f = xflag + (int64_t)(b * 2 + (1 - dir)) * NB + 1 + (NB - 1 - n);
+        int spin = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.token) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spin > kMSpin) give_up();
+        }
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+          const int t = dir == 0 ? t0 + j : t0 + cnt - 1 - j;
+          const unsigned bits = __hip_atomic_load(
+              reinterpret_cast<const unsigned*>(xcb + (int64_t)min(max(t, 0), T - 1) * kXcStride + min(pslot, kXcStride - 1)),
+              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          raw[j] = __uint_as_float(bits);
+        }
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) {
         const int t = dir == 0 ? t0 + j : t0 + cnt - 1 - j;
         raw[j] = xrow[(int64_t)min(max(t, 0), T - 1) * C + col];  // clamped: valid address, unused past the block
       }
+    };
+    // first half: leave block n's gathered values for the partner (only the blocks it will read: see issue)
+    auto publish_xc = [&](int n, const float (&raw)[kBlk]) {
+      if (!xchg || n > NB - 1 - H0p - kXcLag) return;
+      const int k = dir == 0 ? n : NB - 1 - n;
+      const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
+      if (lane <= L) {
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+          const int t = dir == 0 ? t0 + j : t0 + cnt - 1 - j;
+          if (j < cnt)
+            __hip_atomic_store(reinterpret_cast<unsigned*>(xcb + (int64_t)t * kXcStride + pslot), __float_as_uint(raw[j]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows are acknowledged (and so is whatever else this wave had in flight)
+      if (lane == 0)
+        __hip_atomic_store(xflag + (int64_t)(b * 2 + dir) * NB + 1 + n, a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     float lse_raw = 0.f;
     auto issue_lse = [&](int n) {
@@ -665,6 +714,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         MITM_ACC(st_wait1);
       }
       lds_post(&S.staged[n % K::kSlots], n + 1);
+      publish_xc(n, ra);
       if (n + 2 * K::kStagers < NB) issue(n + 2 * K::kStagers, ra), issue_lse(n + 2 * K::kStagers), la = lse_raw;
       const int n2 = n + K::kStagers;
       if (n2 < NB) {
@@ -675,6 +725,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
           MITM_ACC(st_wait1);
         }
         lds_post(&S.staged[n2 % K::kSlots], n2 + 1);
+        publish_xc(n2, rb);
         if (n2 + 2 * K::kStagers < NB) issue(n2 + 2 * K::kStagers, rb), issue_lse(n2 + 2 * K::kStagers), lb = lse_raw;
       }
     }
