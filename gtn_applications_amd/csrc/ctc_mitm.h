@@ -600,7 +600,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     // middle on (the stagers run ahead of their chain, so right behind the middle the partner's rows are not there yet;
     // with the lag the flag is always up when it is looked at).  x is then gathered ~1.1 times instead of twice.
     const bool xchg = WIDE && a.xc != nullptr;
-    constexpr int kXcLag = K::kSlots + 3;
+    constexpr int kXcLag = K::kSlots + 3;  // (4 .. 20 measured at cfg5: the same to 1 %)
     const int H0p = mitm_first_emitted(NB, 1 - dir);  // the partner's first half: its blocks n < H0p
     float* const xcb = xchg ? const_cast<float*>(a.xc) + (int64_t)b * T * kXcStride : nullptr;
     const int pslot = dir == 0 ? lane : (lane < L ? L - 1 - lane : lane);  // forward-orientation slot of this lane's column
