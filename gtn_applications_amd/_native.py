@@ -101,6 +101,7 @@ _SIGS = {
     "wfl_transducer_pack_batch": (_P, [_P, _P, _P, _P, _P, c_int, c_int, c_int]),
     "wfl_transducer_pack_batch_into": (_P, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_int64]),
     "wfl_lattice_host_external": (c_int64, [_P]),
+    "wfl_transducer_decode_batch": (c_int, [_P, _P, _P, c_int, _P, c_int64, _P, c_int]),
     "wfl_lattice_pack_ctc": (_P, [_P, _P, c_int, c_int, c_int]),
     "wfl_lattice_pack_asg_fal": (_P, [_P, _P, c_int, c_int]),
     "wfl_lattice_pack_stc": (_P, [_P, _P, c_int, c_int, c_float, c_int]),
@@ -120,6 +121,7 @@ _SIGS = {
     "wfl_lattice_forward_grad": (
         c_int, [POINTER(LatticeDesc), _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(c_int), _P]),
     "wfl_lattice_side_join": (c_int, [_P]),
+    "wfl_lattice_diagnostics": (c_int, [_P, c_int]),
     "wfl_lattice_grad_rest": (
         c_int, [POINTER(LatticeDesc), _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "wfl_lattice_backtrace": (c_int, [POINTER(LatticeDesc), _P, _P, _P, _P, c_int, _P, _P, c_int, _P]),
@@ -143,6 +145,7 @@ _SIGS = {
     "wfl_ctc_forward_backward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
                                          _P, _P]),
     "wfl_row_lse": (c_int, [_P, c_int64, c_int, _P, _P]),
+    "wfl_row_argmax": (c_int, [_P, c_int64, c_int, _P, _P]),
     "wfl_upload": (c_int, [_P, _P, c_int64, _P]),
     "wfl_reduce_loss": (c_int, [_P, _P, _P, c_int, c_float, c_int, _P, _P]),
     "wfl_scale": (c_int, [_P, c_int64, _P, _P]),

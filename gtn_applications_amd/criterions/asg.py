@@ -81,7 +81,7 @@ class _EarlyGrads:
 
     def take(self):
         """E.EagerLoss.backward: the buffers become the leaves' .grad"""
-        if self.taken or not all(E.plain_leaf(t) for t, g in ((self.inputs, self.dx), (self.transitions, self.dW))
+        if self.taken or not all(E.takes_grad(t, g) for t, g in ((self.inputs, self.dx), (self.transitions, self.dW))
                                  if g is not None):
             return None
         dx, dW = self.claim()
@@ -181,11 +181,13 @@ class ASGLossFunction(torch.autograd.Function):
                          dW_addend=dw_num)
             ctx.early = _EarlyGrads(dx, dW, inputs, transitions)
             ctx.eager_take = ctx.early.take
+            E.watch_node_hooks(ctx)
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
     @E.on_input_device
     def backward(ctx, grad_output):
+        E.check_not_released(ctx)
         if ctx.early is not None and ctx.early.fresh():
             # the buffers of the forward launches, scaled in place (wfl_scale returns at once when grad_output is 1); a
             # second pass over a retained graph finds them used and recomputes below

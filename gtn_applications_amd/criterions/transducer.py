@@ -216,28 +216,43 @@ class Transducer(torch.nn.Module):
         B, T, C = outputs.shape
         dev = E.require_gpu()
         x = E.as_device_f32(outputs.detach(), dev)
+        labels = None
         if self.transitions is not None:
-            pack = _transitions_pack(self.transitions, B, C, dev)
             params = E.as_device_f32(self.transition_params.detach(), dev)
+            if _DENSE_NGRAM and _dense_unigram(self.transitions, C):
+                # one node, one self-loop per token: the best path takes, frame by frame, the first maximum of x + p
+                labels = E.row_argmax(x + params[:C]).cpu().numpy().reshape(-1)
+                offsets = np.arange(B + 1, dtype=np.int64) * T
+            elif _DENSE_NGRAM and _dense_bigram(self.transitions, C):
+                # the fully connected recursion of the dense engine in the max-plus semiring (as the normaliser of the
+                # loss takes its log-semiring one): its best state per frame IS the label path, no epsilon to remove
+                xd, Wd = _bigram_dense_operands(x, params, C)
+                labels = E.dense_viterbi(xd, Wd).cpu().numpy().reshape(-1)
+                offsets = np.arange(B + 1, dtype=np.int64) * T
+        if labels is not None:
+            pass
+        elif self.transitions is not None:
+            pack = _transitions_pack(self.transitions, B, C, dev)
             arc_paths, _ = E.lattice_viterbi(x, pack, weights=params)
             olab = self.transitions.arrays()["olabel"]
-            frame_paths = []
-            for p in arc_paths:
-                labs = olab[p] if p is not None else np.zeros(0, np.int32)
-                frame_paths.append([int(v) for v in labs if v != G.epsilon])  # gtn.remove of back-off arcs
+            # gtn.remove of the back-off arcs (transducer.py:218), for the whole batch at once
+            lens = np.fromiter((0 if p is None else len(p) for p in arc_paths), np.int64, B)
+            arcs = np.concatenate([p for p in arc_paths if p is not None and len(p)] or [np.zeros(0, np.int32)])
+            labs = olab[arcs]
+            keep = labs != G.epsilon
+            offsets = np.zeros(B + 1, np.int64)
+            np.cumsum(np.bincount(np.repeat(np.arange(B), lens)[keep], minlength=B), out=offsets[1:])
+            labels = np.ascontiguousarray(labs[keep], dtype=np.int32)
         else:
             # viterbi_path of the bare emissions graph: per frame, the first maximal label
-            mx = x.max(dim=2, keepdim=True).values
-            cols = torch.arange(C, device=dev).expand(B, T, C)
-            frame_paths = torch.where(x == mx, cols, torch.full_like(cols, C)).min(dim=2).values.cpu().tolist()
+            labels = E.row_argmax(x).cpu().numpy().reshape(-1)
+            offsets = np.arange(B + 1, dtype=np.int64) * T
         self.tokens.arc_sort()
-        predictions = []
-        for labels in frame_paths:
-            path = G.compose(make_chain_graph(labels), self.tokens)
-            path = G.viterbi_path(path)  # ambiguous decodings: the shortest wins (transducer.py:226-228)
-            path = G.remove(G.project_output(path))
-            predictions.append(torch.IntTensor(path.labels_to_list()))
-        return predictions
+        # one native call for the batch (the reference's gtn.parallel_for over process(b), transducer.py:232);
+        # ambiguous decodings: the shortest wins (transducer.py:226-228)
+        out, out_off = G.transducer_decode_batch(self.tokens, labels, offsets)
+        flat = torch.from_numpy(out)  # (int32: torch.IntTensor, as transducer.py:233)
+        return [flat[out_off[b]:out_off[b + 1]].clone() for b in range(B)]
 
 
 _BIGRAM_SEEN = {}
@@ -271,6 +286,17 @@ def _dense_bigram(transitions, C):
         _BIGRAM_SEEN.clear()
     _BIGRAM_SEEN[id(transitions)] = (transitions, C, bool(ok))  # (holds the graph: its id stays unique)
     return bool(ok)
+
+
+def _dense_unigram(transitions, C):
+    """True iff `transitions` is make_transitions_graph(1, C) (transducer.py:32-58 with ngram = 1): one start + accept
+    node with a self-loop per token, arc i labelled i."""
+    if transitions.num_nodes() != 1 or transitions.num_arcs() != C:
+        return False
+    a = transitions.arrays()
+    idx = np.arange(C)
+    return bool(a["start"][0] and a["accept"][0] and (a["src"] == 0).all() and (a["dst"] == 0).all()
+                and (a["ilabel"] == idx).all() and (a["olabel"] == idx).all())
 
 
 def _bigram_dense_operands(x, params, C):
@@ -373,11 +399,14 @@ class TransducerLossFunction(torch.autograd.Function):
         if dx_early is not None:
             ctx.early = _EarlyGrad(dx_early, num, cneg, inputs)  # (holds no reference to ctx: no cycle to collect)
             ctx.eager_take = ctx.early.take if E.plain_leaf(inputs) else None
+            if ctx.eager_take is not None:
+                E.watch_node_hooks(ctx)
         return loss if inputs.is_cuda else loss.cpu()
 
     @staticmethod
     @E.on_input_device
     def backward(ctx, grad_output):
+        E.check_not_released(ctx)
         if ctx.early is not None and ctx.early.dx is not None:
             # the launch of the sweeps wrote the gradient for grad_output = 1: scaled in place (wfl_scale returns at once
             # when grad_output is 1), then the rows of the utterances that launch did not serve.  A second pass over a
@@ -437,7 +466,7 @@ class _EarlyGrad:
 
     def take(self):
         """E.EagerLoss.backward: the buffer only lacks the rows of the utterances the launch did not serve."""
-        if self.dx is None or not E.plain_leaf(self.inputs):
+        if self.dx is None or not E.takes_grad(self.inputs, self.dx):
             return None
         dx, self.dx = self.dx, None
         with torch.cuda.device(dx.device):

@@ -77,6 +77,8 @@ struct wfl_graph {
   mutable std::shared_ptr<wfl::LexTrie> lex_trie;
   // lazily found: 0 not looked at yet, N > 0 the graph is make_token_graph(N tokens, blank optional, no repeats), -1 not
   mutable int tok_state = 0;
+  // lazily found: 0 not looked at yet, 1 + mode (wfl::kTok*) with `tok_n` tokens, -1 no make_token_graph at all
+  mutable int tok_mode = 0, tok_n = 0;
 
   int num_nodes() const { return (int)start.size(); }
   int64_t num_arcs() const { return (int64_t)src.size(); }
@@ -85,6 +87,7 @@ struct wfl_graph {
     lex_state = 0;
     lex_trie.reset();
     tok_state = 0;
+    tok_mode = 0, tok_n = 0;
   }
   const wfl::Adjacency& out_sorted(bool by_olabel) const;
 };
@@ -103,6 +106,13 @@ wfl_graph* lexicon_decompose(const wfl_graph* lexicon, const int32_t* target, in
 // `tokens_target` more than one start node: the caller composes generically.  The result is isomorphic to the generic
 // one, not identical (node and arc order differ).
 wfl_graph* token_alignments(const wfl_graph* tokens, const wfl_graph* tokens_target);
+// The four graphs make_token_graph can build (transducer.py:78-123): (blank, allow_repeats)
+enum { kTokNoneRepeats = 0, kTokOptionalRepeats = 1, kTokForcedRepeats = 2, kTokOptionalNoRepeats = 3 };
+// which of them `tokens` is, arc for arc (cached on the graph), with its number of tokens; -1: none
+int token_graph_kind(const wfl_graph* tokens, int* n_tokens);
+// the token sequence a frame-label sequence transduces to through such a graph (Transducer.viterbi's decode stage,
+// transducer.py:221-229); false (nothing set) if `tokens` is not one of them or a label is outside its alphabet
+bool token_decode(const wfl_graph* tokens, const int32_t* labels, int64_t n, std::vector<int32_t>& out);
 }  // namespace wfl
 
 struct wfl_lattice_host {

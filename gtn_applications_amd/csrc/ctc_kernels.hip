@@ -81,7 +81,7 @@ __device__ __forceinline__ float to_score(float raw) {
 //   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
 // ------------------------------------------------------------------------------------------------
 struct CtcWs {
-  int64_t ck, off, z2, flag, pbad, ready, done, perr, dup, own, zloc, total, dbg;
+  int64_t ck, off, z2, flag, pbad, ready, done, perr, dup, own, zloc, suspect, zcnt, total, dbg;
 };
 __host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
 __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
@@ -101,6 +101,9 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   w.dup = o, o += 2 * (int64_t)B;             // uint64 dup[b]: bit i = target label i also occurs elsewhere in the target (or is the blank)
   w.own = o, o += 64 * (int64_t)B;            // int32 own[b][64]: lane of the first occurrence of the lane's label (63: the blank's slot)
   w.zloc = o, o += 4 * (int64_t)B;            // int64 zloc[b][2]: min / max over the blocks of log2 Z (x 2^16) as their gradient waves reproduced it
+  w.suspect = o, o += 2;                      // uint64: == the meet-in-the-middle launch's token once ANY of its certificates has a doubt (ctc_mitm.h)
+  w.zcnt = o, o += B;                         // int32 zcnt[b]: sweeps of b whose first emitted block has folded its log2 Z into zloc
+  o = (o + 1) & ~1ll;
 #if WFL_MITM_STATS
   o = (o + 1) & ~1ll;
   w.dbg = o, o += 2 * (8 * 16 + 256) * 2 * (int64_t)B;  // int64 [b][dir][wave][8], then [b][dir][256] block clocks (ctc_mitm.h)
@@ -133,6 +136,9 @@ struct CtcArgs {
   // lane-exponent steps, optional: a word of pinned HOST memory where the repair launch leaves the number of utterances
   // it recomputed -- read by the NEXT call on this workspace, without a synchronisation (wfl_ctc_forward_backward)
   int32_t* host_repaired;
+  // repair launch behind the meet-in-the-middle launch: that launch's token -- it raised ws.suspect to it if any
+  // certificate had a doubt, otherwise the repair launch has nothing to look at (0: the word is not maintained)
+  unsigned long long suspect_token;
 };
 constexpr int kXcStride = 64;
 constexpr int kParkStride = 17 * 64;  // 16 frames x 64 lanes of factors + the per-lane reference word
@@ -1791,6 +1797,13 @@ __global__ void __launch_bounds__(256)
   const int lane = threadIdx.x & 63;
   const CtcWs w = ctc_ws_layout(a.B, a.T, a.P);
   const int nchain = 2 * a.B;
+  if (a.suspect_token != 0 && *(const unsigned long long*)(a.ws + w.suspect) != a.suspect_token) {
+    // The launch before found nothing to doubt (it says so in ONE word: see ctc_mitm.h): nothing to evaluate, the
+    // loss it reduced stands.  (The usual case: what the launch then costs is its dispatch and this load.)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_repaired)
+      __hip_atomic_store(a.host_repaired, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   if ((int)blockIdx.x < nchain) {
     const int b = (int)blockIdx.x >> 1, dir = (int)blockIdx.x & 1;
     if (utterance_rejected_wave(a, w, b, lane)) {  // (uniform over the workgroup: every wave evaluates it)
@@ -2657,6 +2670,7 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
     if (rc) return rc;
     WFL_LAUNCH_CHECK();
     a.xc = nullptr;  // (only the first halves' frames are in it)
+    a.suspect_token = a.token;
     a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
     if (a.token == 0) a.token = 1;
     auto launch_repair = [&](auto kern) -> int {

@@ -69,13 +69,54 @@ struct MitmK<16> {
 #else
   static constexpr int kPSlots = 6;   // partner checkpoints handed from the fetcher to the emitters
 #endif
-  static constexpr int kStagers = 4, kEmitters = 9, kWaves = 16;
+#ifndef WFL_MITM_EMIT8
+#define WFL_MITM_EMIT8 0  // 1: no emitter on the chain wave's SIMD (wave 12 ends at once: 8 emitters)
+#endif
+#ifndef WFL_MITM_LAYOUT
+#define WFL_MITM_LAYOUT 0  // 1 (scratch): the chain wave alone on its SIMD -- flusher and fetcher on waves 13 / 14, six emitters
+#endif
+  static constexpr int kStagers = WFL_MITM_LAYOUT == 2 ? 5 : WFL_MITM_LAYOUT == 3 ? 6 : 4,
+                       kEmitters = WFL_MITM_LAYOUT == 1 ? 6 : WFL_MITM_LAYOUT == 2 ? 8 : WFL_MITM_LAYOUT == 3 ? 7 : WFL_MITM_EMIT8 ? 8 : 9,
+                       kWaves = 16;
   __device__ static __forceinline__ void role(int wave, int& role, int& idx) {
+#if WFL_MITM_LAYOUT == 2 || WFL_MITM_LAYOUT == 3
+    // (scratch) five / six stagers, eight / seven emitters
+    constexpr int NS = WFL_MITM_LAYOUT == 2 ? 5 : 6;
+    switch (wave) {
+      case 0: role = 0, idx = 0; return;
+      case 4: role = 2, idx = 0; return;
+      case 8: role = 3, idx = 0; return;
+      default: break;
+    }
+    // the other waves in order: 1 2 3 5 6 7 9 10 11 13 14 15 12
+    const int order = wave == 12 ? 12 : wave - 1 - (wave > 4) - (wave > 8) - (wave > 12);
+    if (order < NS) role = 1, idx = order; else role = 4, idx = order - NS;
+    return;
+#endif
+#if WFL_MITM_LAYOUT == 1
+    switch (wave) {
+      case 0: role = 0, idx = 0; break;
+      case 4: case 8: case 12: role = 5, idx = 0; break;
+      case 13: role = 2, idx = 0; break;
+      case 14: role = 3, idx = 0; break;
+      case 1: role = 1, idx = 0; break;
+      case 2: role = 1, idx = 1; break;
+      case 3: role = 1, idx = 2; break;
+      case 5: role = 1, idx = 3; break;
+      case 6: role = 4, idx = 0; break;
+      case 7: role = 4, idx = 1; break;
+      case 9: role = 4, idx = 2; break;
+      case 10: role = 4, idx = 3; break;
+      case 11: role = 4, idx = 4; break;
+      default: role = 4, idx = 5; break;
+    }
+    return;
+#endif
     switch (wave) {  // (a switch on a scalar: compiled to scalar compares)
       case 0: role = 0, idx = 0; break;
       case 4: role = 2, idx = 0; break;
       case 8: role = 3, idx = 0; break;
-      case 12: role = 4, idx = 8; break;
+      case 12: role = WFL_MITM_EMIT8 ? 5 : 4, idx = 8; break;
       case 1: role = 1, idx = 0; break;
       case 2: role = 1, idx = 1; break;
       case 3: role = 1, idx = 2; break;
@@ -168,6 +209,7 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
                                                     MitmLds<K>& S, bool first,
                                                     int cnt, float cf, float g, float gs, bool skipn, bool owner, bool adder,
                                                     int lane, float* rows, const unsigned char* cmap, int ycol, int blank, int C, long long* zmm,
+                                                    int32_t* zcnt, unsigned long long* suspect, unsigned long long suspect_token,
                                                     float* __restrict__ dst, long long* st_part,
                                                     const float* __restrict__ xsrc = nullptr, float lse_rows = 0.f) {
 #if WFL_MITM_STATS
@@ -227,6 +269,7 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
       const long long zq = z_fixed(zk);
       __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(zcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (behind them: see the alpha chain's end)
     }
   } else {
     // (ONE reference per sweep, from its first emitted block whichever emitter took it: results do not depend on
@@ -303,7 +346,10 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     const int n = FULL ? kBlk : cnt;
     const float want = cf * ((float)n + (float)(n * (n - 1)) * (1.f / 64.f));
     const bool bad_block = alive && !(fabsf(stot - want) <= 2e-4f * fabsf(cf));
-    if (bad_block && lane == 0) __hip_atomic_fetch_min(zmm, kZDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bad_block && lane == 0) {
+      __hip_atomic_fetch_min(zmm, kZDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      coherent_store64(suspect, suspect_token);
+    }
   }
   // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
 #if WFL_MITM_STATS
@@ -439,6 +485,8 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
   }
   const float cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
   long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+  int32_t* zcnt = (int32_t*)(a.ws + w.zcnt) + b;
+  unsigned long long* suspect = (unsigned long long*)(a.ws + w.suspect);
 #if WFL_MITM_STATS
   long long st_wait0 = 0, st_wait1 = 0, st_wait2 = 0;
   long long st_part[6] = {0, 0, 0, 0, 0, 0};
@@ -506,10 +554,10 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
     const float lse_rows = LSM ? a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)] : 0.f;  // (tile row r = frame t0 + r)
     if (cnt == kBlk)
       ctc_mitm_emit_block<K, DIR, true, WIDE, LSM>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                     cmap, ycol, WIDE ? 63 : a.blank, C, zmm, dst, st_part, xsrc, lse_rows);
+                                     cmap, ycol, WIDE ? 63 : a.blank, C, zmm, zcnt, suspect, a.token, dst, st_part, xsrc, lse_rows);
     else if (DIR == 0)
       ctc_mitm_emit_block<K, 0, false, WIDE, LSM>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                    cmap, ycol, WIDE ? 63 : a.blank, C, zmm, dst, st_part, xsrc, lse_rows);
+                                    cmap, ycol, WIDE ? 63 : a.blank, C, zmm, zcnt, suspect, a.token, dst, st_part, xsrc, lse_rows);
     MITM_ACC(st_wait2);
   }
 #if WFL_MITM_STATS
@@ -562,6 +610,8 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
   int role, ridx;
   K::role(wave, role, ridx);
   if (role == 5) return;  // (a wave that has ended no longer counts for anything: no barrier after the first)
+  if ((WFL_MITM_ABL & 4096) && role == 4) return;   // (scratch: no emitter waves at all)
+  if ((WFL_MITM_ABL & (16384 | 4096)) && role == 3) return;  // (scratch: no fetcher; nobody would take its blocks)
 #if WFL_MITM_STATS
   long long st_wait0 = 0, st_wait1 = 0, st_wait2 = 0, st_polls = 0;
   const long long st_begin = clock64();
@@ -608,6 +658,11 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     auto issue = [&](int n, float (&raw)[kBlk]) {
       const int k = dir == 0 ? n : NB - 1 - n;
       const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
+      if (WFL_MITM_ABL & 2048) {  // (scratch: no gathers)
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) raw[j] = 0.01f * (float)(lane + j + n);
+        return;
+      }
       if (xchg && n >= H0 + kXcLag) {
         // the partner crossed this block as ITS block NB - 1 - n and published it
         const unsigned long long* f = xflag + (int64_t)(b * 2 + (1 - dir)) * NB + 1 + (NB - 1 - n);
@@ -663,7 +718,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       const int k = dir == 0 ? n : NB - 1 - n;
       const int cnt = min(kBlk, T - k * kBlk);
       const int slot = n % K::kSlots;
-      if ((WFL_MITM_ABL & 16) && n >= H0) {  // (scratch: what a second half fed with ready-made factors would cost)
+      if (((WFL_MITM_ABL & 16) && n >= H0) || (WFL_MITM_ABL & 512)) {  // (scratch: what a second half fed with ready-made factors would cost)
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) S.ring[slot][j][lane] = make_float2(has_blank ? 0.7f : 0.f, has_label ? 0.7f + 0.001f * raw[j] : 0.f);
         if (lane < kBlk) S.fref[slot][lane] = 0.f;
@@ -692,7 +747,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       const int m = n - K::kSlots;  // the block that held the slot
       int spin = 0;
       MITM_T0();
-      while (lds_peek(&S.chainpos) < m + 1 || lds_peek(&S.ckdone) < m + 1 || (m >= H0 && !grabbed(m))) {
+      while (lds_peek(&S.chainpos) < m + 1 || lds_peek(&S.ckdone) < m + 1 || (!(WFL_MITM_ABL & 4096) && m >= H0 && !grabbed(m))) {
         __builtin_amdgcn_s_sleep(2);
         if (++spin > kMSpin) give_up();
       }
@@ -747,6 +802,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
       coherent_store64(zmm, (unsigned long long)(1ll << 62));
       coherent_store64(zmm + 1, (unsigned long long)(-(1ll << 62) - 1));
+      __hip_atomic_store((int32_t*)(a.ws + w.zcnt) + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (dir == 0) {
       // bit 63 of dup[b]: the target cannot be aligned at all -- T < L + adjacent repeats.  Such an utterance has
@@ -759,7 +815,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         int spin = 0;
         MITM_T0();
         while (lds_peek(&S.chainpos) < kk + 2) {
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep((WFL_MITM_ABL & 1024) ? 8 : 1);
           if (++spin > kMSpin) give_up();
         }
         MITM_ACC(st_wait0);
@@ -767,7 +823,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       asm volatile("" ::: "memory");
       const int slot = kk % K::kSlots;
       const float rj = lane < kBlk ? S.fref[slot][lane] : 0.f;
-      if (kk < H0) {
+      if (kk < H0 && !(WFL_MITM_ABL & 8192)) {
         // Device-coherent stores (see ctc_log_chain_body), three per checkpoint and never waited for one by one: the
         // partner only needs them when this sweep has finished its first half (it emits from the middle outwards, so
         // the LAST checkpoint published is the first one it uses) -- ONE flag per sweep, raised after the stores of
@@ -885,12 +941,18 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
       const int own = mx > 0.f ? e + k : kEmptyE;
       const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
-      const int sh = mx > 0.f ? pre - own : 0;                            // >= 0: pulled up by the clamp
-      pb = ldexpf(pb, -(k + min(sh, 200)));  // (mantissa to [0.5, 1), then down by the clamp: one scaling)
-      pl = ldexpf(pl, -(k + min(sh, 200)));
+      // mantissa to [0.5, 1), then down by what the clamp pulled the exponent up: ONE scaling by 2^(e - pre)
+      // (= 2^-(k + pre - own); a lane pulled up by more than ~150 flushes to zero either way, an empty lane is zero
+      // and stays zero whatever the exponent; v_ldexp_f32 takes any integer)
+      const int shf = e - pre;
+      pb = ldexpf(pb, shf);
+      pl = ldexpf(pl, shf);
       e = pre;
-      const int d = wave_shr1_i(e, e) - e;  // <= kGap by construction
-      g = lane == 0 ? 0.f : ldexpf(1.f, max(d, -200));
+      // g = 2^(e[i-1] - e[i]) <= 2^kGap by construction; lane 0 has no source lane: the DPP subtraction leaves its
+      // -300 alone and 2^-300 is zero
+      int d = -300;
+      asm("s_nop 1\n\tv_sub_u32_dpp %0, %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(e));
+      g = ldexpf(1.f, d);
       gs = skip ? g : 0.f;
     };
     auto frame = [&](const float2 f) {
@@ -1007,6 +1069,13 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     asm volatile("" ::: "memory");
     const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;  // (any lane)
     if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = any_bad ? 1 : 0;
+    // ONE word for the launch behind this one: raised (to this launch's token: nothing to zero) by whoever finds a
+    // reason to doubt an utterance -- a chain that overflowed (here), a block whose posteriors do not sum to one (the
+    // emitters), the alpha chain comparing its log2 Z with what the first emitted blocks of both sweeps reproduced
+    // (below).  The repair launch evaluates the certificates in full only if it is up (ctc_repair_kernel).
+    unsigned long long* suspect = (unsigned long long*)(a.ws + w.suspect);
+    if (any_bad && lane == 0) coherent_store64(suspect, a.token);
+    const bool cannot_align = T < L + __builtin_popcountll(__builtin_amdgcn_ballot_w64(has_label && lane >= 1 && y == yprev));
     if (dir == 0) {
       // Z = alpha_{T-1}[2L] + alpha_{T-1}[2L-1]   (ctc.py:21 accept states), lanes L and L-1
       const float zb = readlane_f(pb, L);
@@ -1020,6 +1089,17 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         const double z2 = ok ? (double)__builtin_amdgcn_logf(s) + (double)em + S.offtot : -1.0e300;
         ((double*)(a.ws + w.z2))[b] = z2;
         publish_nll<true, false>(a, w, b, ok, z2);
+        // utterance_rejected()'s comparison, here and now.  The two first emitted blocks folded their log2 Z into zloc
+        // half a sweep ago; should one of them not have arrived yet (its workgroup started late: nothing orders
+        // workgroups) the count says so and the doubt is raised for the repair launch to settle.
+        const long long* zmm = (const long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+        const long long lo = (long long)coherent_load64(zmm), hi = (long long)coherent_load64(zmm + 1);
+        const int cnt = __hip_atomic_load((const int32_t*)(a.ws + w.zcnt) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long zq = z_fixed(z2);
+        constexpr long long tol = 10;  // (utterance_rejected)
+        const int nfirst = (H0 < NB ? 1 : 0) + (mitm_first_emitted(NB, 1) < NB ? 1 : 0);  // sweeps that emit at all
+        const bool doubt = zq == kZDead ? !cannot_align : (lo < zq - tol || hi > zq + tol || cnt != nfirst);
+        if (doubt) coherent_store64(suspect, a.token);
       }
       stats_out();
 #if WFL_MITM_STATS

@@ -78,6 +78,20 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
     for (int i = tid; i < C; i += NT) (((T - 1) & 1) ? L.x1 : L.x0)[i] = nan_to_neg(xb[(int64_t)(T - 1) * C + i]);
   if (DIR == 0 && T > 1)
     for (int i = tid; i < C; i += NT) L.x1[i] = nan_to_neg(xb[(int64_t)C + i]);
+  // The emission row of step s + 1 reaches LDS at the end of step s; it is REQUESTED a step earlier still (registers
+  // `pre`: requested during step s - 1, written during step s), and the per-frame barriers order LDS traffic only --
+  // neither the row's round trip nor the acknowledgement of the frame's own stores (scores, back-pointers) sits on
+  // the frame-to-frame path (with __syncthreads and a row requested in the step that writes it, a frame of the
+  // max-plus sweep took ~2.6 us at C = 82: 0.65 of the 0.8 ms of a bigram Transducer.viterbi).
+  auto row_needed_by = [&](int step) { return DIR == 0 ? step : T - step; };  // (= tx of that step)
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  if (T > 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + j * NT;
+      if (i < C) pre[j] = xb[(int64_t)row_needed_by(2) * C + i];
+    }
+  }
   __syncthreads();
   for (int step = 1; step < T; ++step) {
     const int t = DIR == 0 ? step : T - 1 - step;       // slot being produced
@@ -88,12 +102,12 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
     const float* xr = (tx & 1) ? L.x1 : L.x0;
     const int txn = DIR == 0 ? t + 1 : t;               // row the next step needs
     const bool has_next = step + 1 < T;
-    float pre[4];
-    if (has_next) {
+    float pre2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (step + 2 < T) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = tid + j * NT;
-        if (i < C) pre[j] = xb[(int64_t)txn * C + i];
+        if (i < C) pre2[j] = xb[(int64_t)row_needed_by(step + 2) * C + i];
       }
     }
     // ---- partial reductions
@@ -115,7 +129,7 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
       L.pm[idx] = m;
       L.ps[idx] = SR == WFL_SEMIRING_LOG ? sum : __int_as_float(am);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- merge partials, add the emission (alpha only), publish
     for (int s = tid; s < C; s += NT) {
       float m = L.pm[s];
@@ -146,7 +160,9 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
         if (i < C) xn[i] = nan_to_neg(pre[j]);
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pre[j] = pre2[j];
+    lds_barrier();
   }
   if (DIR == 0 && logz && T > 0) {
     const float* fin = ((T - 1) & 1) ? L.a1 : L.a0;
@@ -310,20 +326,53 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-__global__ void dense_backtrace_kernel(const float* __restrict__ alpha, const int32_t* __restrict__ bptr, int B, int T,
-                                       int C, int32_t* __restrict__ path) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One workgroup per utterance.  Following the back-pointers is a chain of T dependent loads: from global memory that
+// is a memory round trip per frame (measured: 0.5 ms of the 0.8 ms of a bigram Transducer.viterbi at T = 250), so
+// the rows travel to LDS in chunks (coalesced, all threads) and one lane walks the chunk there (~50 cycles a step).
+constexpr int kBtChunkWords = 12 * 1024;  // 48 KiB of back-pointers per chunk
+__global__ void __launch_bounds__(256) dense_backtrace_kernel(const float* __restrict__ alpha, const int32_t* __restrict__ bptr,
+                                                               int B, int T, int C, int32_t* __restrict__ path) {
+  __shared__ int32_t rows[kBtChunkWords];
+  __shared__ int32_t walk[1024];  // the chunk's stretch of the path, written out coalesced
+  __shared__ int cur_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= B || T <= 0) return;
-  const float* fin = alpha + ((int64_t)b * T + (T - 1)) * C;
-  int cur = 0;
-  float best = fin[0];
-  for (int i = 1; i < C; ++i)
-    if (fin[i] > best) best = fin[i], cur = i;
+  if (tid < 64) {  // arg max of the last frame: the first maximum (lowest state)
+    const float* fin = alpha + ((int64_t)b * T + (T - 1)) * C;
+    float best = -__builtin_inff();
+    int arg = 0x3fffffff;
+    for (int i = tid; i < C; i += 64) {
+      const float v = fin[i];
+      if (v > best || arg == 0x3fffffff) best = v, arg = i;
+    }
+    const float m = wave_all_max(best);
+    arg = -wave_all_max_int(-(best == m ? arg : 0x3fffffff));
+    if (tid == 0) cur_s = arg == 0x3fffffff ? 0 : arg;
+  }
+  const int rows_per_chunk = max(1, min(kBtChunkWords / C, 1024));
   int32_t* out = path + (int64_t)b * T;
-  for (int t = T - 1; t >= 0; --t) {
-    out[t] = cur;
-    if (t > 0) cur = bptr[((int64_t)b * T + t) * C + cur];
-    if (cur < 0) cur = 0;  // unreachable state (all -inf): keep the path well-formed
+  // frames (t0, t1]: rows t0 + 1 .. t1 of bptr are needed to step from t1 down to t0
+  for (int t1 = T - 1; t1 >= 0; t1 -= rows_per_chunk) {
+    const int t0 = max(t1 - rows_per_chunk, -1);  // the walk covers frames t1 .. t0 + 1
+    const int nrow = t1 - t0;
+    const int32_t* src = bptr + ((int64_t)b * T + (t0 + 1)) * C;
+    if (C <= kBtChunkWords)
+      for (int i = tid; i < nrow * C; i += 256) rows[i] = src[i];
+    __syncthreads();
+    if (tid == 0) {
+      int cur = cur_s;
+      for (int t = t1; t > t0; --t) {
+        walk[t - t0 - 1] = cur;
+        if (t > 0) {
+          cur = C <= kBtChunkWords ? rows[(t - t0 - 1) * C + cur] : src[(int64_t)(t - t0 - 1) * C + cur];
+          if (cur < 0) cur = 0;  // unreachable state (all -inf): keep the path well-formed
+        }
+      }
+      cur_s = cur;
+    }
+    __syncthreads();
+    for (int i = tid; i < nrow; i += 256) out[t0 + 1 + i] = walk[i];
+    __syncthreads();
   }
 }
 
@@ -1133,8 +1182,7 @@ int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float
   }
   if (int rc = wfl_dense_forward(x, W, B, T, C, WFL_SEMIRING_TROPICAL, alpha, nullptr, bptr, nullptr, nullptr, stream))
     return rc;
-  hipLaunchKernelGGL(dense_backtrace_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, alpha,
-                     bptr, B, T, C, path);
+  hipLaunchKernelGGL(dense_backtrace_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, alpha, bptr, B, T, C, path);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

@@ -201,6 +201,91 @@ static int token_graph_shape(const wfl_graph& g) {
   return (int)N;
 }
 
+// Which make_token_graph(N tokens, blank, allow_repeats) (transducer.py:78-123) is `g`, arc for arc?  Returns the mode
+// (kTokNoneRepeats ...) and N, or -1.  All four graphs the factory can build transduce a frame-label sequence the same
+// way wherever they accept it -- collapse repeated labels, drop the blank N -- which is what token_decode relies on.
+static int token_graph_mode(const wfl_graph& g, int* n_tokens) {
+  const int64_t nodes = g.num_nodes(), arcs = g.num_arcs();
+  auto is = [&](int64_t a, int64_t s, int64_t d, int64_t il, int64_t ol) {
+    return a < arcs && g.src[a] == s && g.dst[a] == d && g.il[a] == il && g.ol[a] == ol && g.w[a] == 0.f;
+  };
+  auto flags = [&](int64_t N, bool blank, bool tok_accept) {
+    if (nodes != N + 1 + (blank ? 1 : 0)) return false;
+    for (int64_t n = 0; n < nodes; ++n) {
+      const bool st = n == 0, ac = n == 0 || (n <= N && tok_accept);
+      if ((g.start[n] != 0) != st || (g.accept[n] != 0) != ac) return false;
+    }
+    return true;
+  };
+  // blank "none", repeats allowed: N + 1 nodes, per token  0 -> i+1 [i : i], i+1 -> i+1 [i : eps], i+1 -> 0 [eps : eps]
+  if (nodes >= 2 && arcs == 3 * (nodes - 1)) {
+    const int64_t N = nodes - 1;
+    bool ok = flags(N, false, true);
+    for (int64_t i = 0; ok && i < N; ++i)
+      ok = is(3 * i, 0, i + 1, i, i) && is(3 * i + 1, i + 1, i + 1, i, WFL_EPSILON) && is(3 * i + 2, i + 1, 0, WFL_EPSILON, WFL_EPSILON);
+    if (ok) return *n_tokens = (int)N, kTokNoneRepeats;
+  }
+  if (nodes >= 3 && arcs == 2 + 3 * (nodes - 2)) {
+    const int64_t N = nodes - 2, B = N + 1;
+    if (is(0, 0, B, N, WFL_EPSILON) && is(1, B, 0, WFL_EPSILON, WFL_EPSILON)) {
+      // blank "optional", repeats allowed: 0 -> i+1 [i : i], i+1 -> i+1 [i : eps], i+1 -> 0 [eps : eps]
+      bool ok = flags(N, true, true);
+      for (int64_t i = 0; ok && i < N; ++i)
+        ok = is(2 + 3 * i, 0, i + 1, i, i) && is(3 + 3 * i, i + 1, i + 1, i, WFL_EPSILON) && is(4 + 3 * i, i + 1, 0, WFL_EPSILON, WFL_EPSILON);
+      if (ok) return *n_tokens = (int)N, kTokOptionalRepeats;
+      // blank "forced", repeats allowed: blank -> i+1 [i : i], i+1 -> i+1 [i : eps], i+1 -> blank [N : eps]
+      ok = flags(N, true, false);
+      for (int64_t i = 0; ok && i < N; ++i)
+        ok = is(2 + 3 * i, B, i + 1, i, i) && is(3 + 3 * i, i + 1, i + 1, i, WFL_EPSILON) && is(4 + 3 * i, i + 1, B, N, WFL_EPSILON);
+      if (ok) return *n_tokens = (int)N, kTokForcedRepeats;
+    }
+  }
+  const int N = token_graph_shape(g);  // blank "optional", no repeats
+  if (N > 0) return *n_tokens = N, kTokOptionalNoRepeats;
+  return -1;
+}
+
+int token_graph_kind(const wfl_graph* tokens, int* n_tokens) {
+  std::lock_guard<std::mutex> lock(tokens->mu);
+  if (tokens->tok_mode == 0) {
+    int n = 0;
+    const int m = token_graph_mode(*tokens, &n);
+    tokens->tok_mode = m < 0 ? -1 : 1 + m;
+    tokens->tok_n = n;
+  }
+  *n_tokens = tokens->tok_n;
+  return tokens->tok_mode < 0 ? -1 : tokens->tok_mode - 1;
+}
+
+// remove(project_output(viterbi_path(compose(chain(labels), tokens)))) (transducer.py:221-229) for one frame-label
+// sequence, written down directly for the token graphs of make_token_graph.  With those (all weights zero) every
+// accepted sequence has exactly one path with the fewest output labels -- a token's self-loop wherever a label repeats
+// -- so the shortest decoding the reference picks is: collapse repeats, drop blanks; and the graphs differ only in what
+// they accept.  Returns false if `tokens` is none of them or a label is outside its alphabet (the caller composes).
+bool token_decode(const wfl_graph* tokens, const int32_t* labels, int64_t n, std::vector<int32_t>& out) {
+  int N = 0;
+  const int mode = token_graph_kind(tokens, &N);
+  if (mode < 0) return false;
+  const int32_t blank = mode == kTokNoneRepeats ? -2 : N;  // (no blank label in the alphabet of the first graph)
+  for (int64_t i = 0; i < n; ++i)
+    if (labels[i] < 0 || (labels[i] >= N && labels[i] != blank)) return false;
+  out.clear();
+  if (n == 0) return true;  // (a chain without arcs has no accepting node: no path, no labels)
+  if (mode == kTokForcedRepeats) {
+    // accepted iff the sequence starts and ends with a blank and tokens are separated by blanks
+    bool ok = labels[0] == blank && labels[n - 1] == blank;
+    for (int64_t i = 1; ok && i < n; ++i)
+      ok = labels[i] == blank || labels[i - 1] == blank || labels[i] == labels[i - 1];
+    if (!ok) return true;  // no accepting path: viterbi_path gives the empty graph
+  }
+  int32_t prev = -3;
+  for (int64_t i = 0; i < n; ++i) {
+    if (labels[i] != blank && labels[i] != prev) out.push_back(labels[i]);
+    prev = labels[i];
+  }
+  return true;
+}
+
 wfl_graph* token_alignments(const wfl_graph* tokens, const wfl_graph* tt) {
   int N;
   {

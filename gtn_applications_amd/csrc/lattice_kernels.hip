@@ -2042,20 +2042,35 @@ __global__ void __launch_bounds__(MAXT)
   if (threadIdx.x == 0) __hip_atomic_store(busy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// `verdict` (one word per call, outside the sweeps' buffers): the launch's token once the header below is complete, its
+// complement if the gate gave up -- what occ_live_kernel looks at before it touches the header.  `host_words` (pinned):
+// [0] gates that gave up, [1] gates that went through, counted for the host's back-off (wfl_lattice_diagnostics).
 __global__ void __launch_bounds__(64)
     occ_gate_kernel(wfl_lattice_desc d, float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1,
-                    uint32_t token, int force_bad, uint32_t* __restrict__ host_gave_up, int ntiles) {
+                    uint32_t token, int force_bad, uint32_t* __restrict__ host_words, uint32_t* __restrict__ verdict,
+                    int ntiles, int max_spins) {
   const int lane = threadIdx.x;
   const uint64_t* pa = reinterpret_cast<const uint64_t*>(reinterpret_cast<double*>(alpha + tail) + prog_offset_doubles(d, nch1));
   const uint64_t* pb = reinterpret_cast<const uint64_t*>(reinterpret_cast<double*>(beta + tail) + prog_offset_doubles(d, nch1));
   const OccHeader h = occ_header(d, alpha, tail, nch1);
-  int count[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (wave-uniform)
-  for (int b0 = 0; b0 < d.B; b0 += 64) {
-    const int b = b0 + lane;
+  // First every sweep of the launch must have announced itself -- until then NOTHING is written to alpha / beta: the
+  // buffers may be a previous call's, whose gradient kernel (wfl_lattice_grad_rest) may read its header until the
+  // stream reaches this call's sweeps.  The wait is bounded (max_spins polls of ~2 us: the side stream was forked
+  // from the caller's stream right in front of the sweeps, so they are microseconds away unless something runs the
+  // streams' kernels one after the other -- a counter-collecting profiler, AMD_SERIALIZE_KERNEL, a debugger).  On a
+  // give-up the gate writes its verdict and the host counter and ends: the gradient workgroups behind it see the
+  // verdict and end too, the header keeps whatever token it had, and wfl_lattice_grad_rest -- which believes
+  // "served beside the sweeps" only under THIS launch's token -- computes every row.
+  constexpr int kMaxRounds = 4;  // (B <= 256: the launch is only taken while every sweep gets a CU of its own)
+  int xcds[kMaxRounds];
+  bool gave_up = false;
+#pragma unroll
+  for (int r = 0; r < kMaxRounds; ++r) {
+    const int b = r * 64 + lane;
     int xcd = -1;  // -1: not for the in-flight gradient
     if (b < d.B) {
       bool seen = false;
-      for (int spin = 0; spin < (1 << 20) && !seen; ++spin) {  // (gives up after ~2 s: the utterance goes to `bad`)
+      for (int spin = 0; spin < max_spins && !seen; ++spin) {
         const uint64_t va = __hip_atomic_load(pa + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t vb = __hip_atomic_load(pb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(va >> 32) == token && (uint32_t)(vb >> 32) == token) {
@@ -2067,15 +2082,23 @@ __global__ void __launch_bounds__(64)
           __builtin_amdgcn_s_sleep(64);
         }
       }
-      if (!seen) {
-        // The sweeps never showed up beside this kernel: something runs the streams' kernels one after the other (a
-        // counter-collecting profiler, AMD_SERIALIZE_KERNEL, a debugger).  Tell the host: it stops asking for the
-        // gradient beside the sweeps (wfl_lattice_forward_grad), which can only wait out its watchdog there.
-        xcd = -2;
-        __hip_atomic_store(host_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      if (xcd == -2) h.bad[b] = token;
+      gave_up |= !seen;
     }
+    xcds[r] = xcd;
+    if (__any(gave_up)) break;  // (the rest would only wait as long again)
+  }
+  if (__any(gave_up)) {
+    if (lane == 0) {
+      __hip_atomic_store(verdict, ~token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(host_words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  int count[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (wave-uniform)
+#pragma unroll
+  for (int r = 0; r < kMaxRounds; ++r) {
+    const int b = r * 64 + lane, xcd = xcds[r];
+    if (b < d.B && xcd == -2) h.bad[b] = token;
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
       const uint64_t m = __ballot(xcd == x);
@@ -2083,22 +2106,28 @@ __global__ void __launch_bounds__(64)
       count[x] += __popcll(m);
     }
   }
-  // (the header is written only now, after every sweep of this launch has been seen: the buffers may be the previous
-  // call's, whose gradient kernel (wfl_lattice_grad_rest) may read its header until the stream reaches this call's sweeps)
   if (lane < 8) h.next[lane] = 0;
   if (lane == 0) h.meta[0] = token, h.meta[1] = (uint32_t)ntiles;
 #pragma unroll
   for (int x = 0; x < 8; ++x)
     if (lane == 0) h.nx[x] = count[x];
+  if (lane == 0) {
+    __hip_atomic_store(verdict, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(host_words + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 __global__ void __launch_bounds__(256)
     occ_live_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T, int C,
                     float* __restrict__ alpha, float* __restrict__ beta, const float* __restrict__ coef,
                     const float* __restrict__ x, const float* __restrict__ row_lse, float* __restrict__ dx, int rows_o,
-                    int ntiles, int rows_per_chunk, int64_t tail, int nch1, uint32_t token) {
+                    int ntiles, int rows_per_chunk, int64_t tail, int nch1, uint32_t token,
+                    const uint32_t* __restrict__ verdict) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint32_t job_s;
+  // (the gate in front of this kernel on the side stream: anything but the launch's token means it gave up and the
+  // header is not this launch's -- nothing to do here, wfl_lattice_grad_rest computes every row)
+  if (__hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) return;
   const OccHeader h = occ_header(d, alpha, tail, nch1);
   const uint32_t me = xcc_id() & 7u;
   const int nx = h.nx[me];
@@ -2624,6 +2653,60 @@ __global__ void __launch_bounds__(256) row_lse_wide_kernel(const float* __restri
   }
 }
 
+// out[r] = first index of the row's maximum (NaN = -inf): one wave per row, the row in registers for C <= 64 NV
+template <int NV, int RU>
+__global__ void __launch_bounds__(256) row_argmax_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                          int32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RU; r0 < rows; r0 += nw * RU) {
+    float v[RU][NV];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const float* row = x + min(r0 + u, rows - 1) * C;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[u][i] = c < C ? row[c] : WFL_NEG_INF;
+      }
+    }
+    float m[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      m[u] = WFL_NEG_INF;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[u][i] = nan_to_neg(v[u][i]), m[u] = fmaxf(m[u], v[u][i]);
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) m[u] = wave_all_max(m[u]);
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      int first = 0x3fffffff;
+#pragma unroll
+      for (int i = NV - 1; i >= 0; --i)
+        if (v[u][i] == m[u] && lane + 64 * i < C) first = lane + 64 * i;
+      first = -wave_all_max_int(-first);
+      if (lane == 0 && r0 + u < rows) out[r0 + u] = first;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) row_argmax_wide_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                               int32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const float* row = x + r * C;
+    float m = WFL_NEG_INF;
+    int first = 0x3fffffff;
+    for (int c = lane; c < C; c += 64) {
+      const float v = nan_to_neg(row[c]);
+      if (v > m || first == 0x3fffffff) m = v, first = c;  // (ascending c: the first of equals stays)
+    }
+    const float mm = wave_all_max(m);
+    first = -wave_all_max_int(-(m == mm ? first : 0x3fffffff));
+    if (lane == 0) out[r] = first;
+  }
+}
+
 // dst[0..nbytes) = src[0..nbytes): `src` is pinned host memory read through its device-visible address (a kernel
 // launch never waits for the stream to drain; hipMemcpyAsync from pinned memory sometimes does, see wfl_upload)
 __global__ void __launch_bounds__(256) upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
@@ -2748,8 +2831,12 @@ int wfl_lattice_gather(const wfl_lattice_desc* d, const int32_t* ints, const flo
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t join = nullptr;
+  hipEvent_t fork = nullptr;       // recorded on the caller's stream in front of the sweeps; the side stream waits for it
+  uint32_t* verdicts = nullptr;    // device: one word per call, a ring (occ_gate_kernel -> occ_live_kernel)
+  uint32_t next_verdict = 0;
   std::mutex mu;
 };
+constexpr uint32_t kVerdictRing = 256;
 static SideStream* side_stream_of_device() {
   static std::mutex mu;
   static auto* table = new std::map<int, SideStream*>();
@@ -2760,27 +2847,68 @@ static SideStream* side_stream_of_device() {
   if (it != table->end()) return it->second;
   auto* s = new SideStream();
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
+      hipMalloc((void**)&s->verdicts, kVerdictRing * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(s->verdicts, 0, kVerdictRing * sizeof(uint32_t)) != hipSuccess) {
     delete s;
     s = nullptr;
   }
   (*table)[dev] = s;
   return s;
 }
-// Pinned host word the gate kernel raises when it gave up waiting for the sweeps (see occ_gate_kernel); also raised
-// up front when the environment says that kernels of different streams do not overlap.
-static uint32_t* live_gave_up_word() {
-  static uint32_t* w = [] {
+// The gradient beside the sweeps needs kernels of two streams to run at the same time.  Whether they do is only known
+// afterwards: the gate kernel counts its give-ups and its successes in two pinned host words, the host reads them at
+// the next call (no synchronisation) and backs off -- the next 1, 2, 4, ... 1024 calls take the plain path, then one
+// call tries again; a success resets the back-off.  An environment that announces serialised launches switches the
+// path off up front.  All of it is visible through wfl_lattice_diagnostics.
+struct LiveState {
+  std::mutex mu;
+  uint32_t* host = nullptr;  // pinned: [0] give-ups, [1] successes (written by occ_gate_kernel)
+  bool env_serial = false;
+  uint32_t seen_gave_up = 0, seen_ok = 0;
+  uint32_t backoff_left = 0, backoff_len = 0;
+  uint64_t attempts = 0, skipped = 0;
+  int max_spins = 1 << 11;  // gate polls of ~2 us each: ~4 ms (WFL_LATTICE_GATE_SPINS) -- a process's first launch of the
+                            // sweeps loads their code, which takes longer than a millisecond
+  bool fork = true;        // WFL_LATTICE_FUSED_FORK=0: no fork event (the round-3 protocol; measurements)
+};
+static LiveState& live_state() {
+  static LiveState* st = [] {
+    auto* s = new LiveState();
     uint32_t* p = nullptr;
-    if (hipHostMalloc((void**)&p, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !p) return (uint32_t*)nullptr;
-    *p = 0;
+    if (hipHostMalloc((void**)&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
+      p[0] = p[1] = 0;
+      s->host = p;
+    }
     for (const char* name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"}) {
       const char* e = getenv(name);
-      if (e && atoi(e) != 0) *p = 1;
+      if (e && atoi(e) != 0) s->env_serial = true;
     }
-    return p;
+    if (const char* e = getenv("WFL_LATTICE_GATE_SPINS")) s->max_spins = std::max(1, atoi(e));
+    if (const char* e = getenv("WFL_LATTICE_FUSED_FORK")) s->fork = atoi(e) != 0;
+    if (!s->fork && !getenv("WFL_LATTICE_GATE_SPINS")) s->max_spins = 1 << 20;  // (no fork: the gate waits out the stream's backlog)
+    return s;
   }();
-  return w;
+  return *st;
+}
+// May this call try the gradient beside the sweeps?  (accounts for what earlier gates reported)
+static bool live_try(LiveState& ls) {
+  std::lock_guard<std::mutex> lock(ls.mu);
+  if (!ls.host || ls.env_serial) return false;
+  const uint32_t gave = *(volatile uint32_t*)&ls.host[0], ok = *(volatile uint32_t*)&ls.host[1];
+  if (ok != ls.seen_ok) ls.seen_ok = ok, ls.backoff_len = 0;
+  if (gave != ls.seen_gave_up) {
+    ls.seen_gave_up = gave;
+    ls.backoff_len = ls.backoff_len ? std::min(ls.backoff_len * 2, 1024u) : 1u;
+    ls.backoff_left = ls.backoff_len;
+  }
+  if (ls.backoff_left > 0) {
+    --ls.backoff_left, ++ls.skipped;
+    return false;
+  }
+  ++ls.attempts;
+  return true;
 }
 static int device_cus() {
   int dev = 0, n = 256;
@@ -2902,21 +3030,37 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
         // (not while the stream is being captured into a graph: the side stream's launches would not be part of it)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-        uint32_t* gave_up = live_gave_up_word();
-        SideStream* side = olds <= (size_t)kLdsBytes && cap == hipStreamCaptureStatusNone && gave_up &&
-                                   *(volatile uint32_t*)gave_up == 0
+        LiveState& ls = live_state();
+        SideStream* side = olds <= (size_t)kLdsBytes && cap == hipStreamCaptureStatusNone && d->B <= 256 && live_try(ls)
                                ? side_stream_of_device()
                                : nullptr;
+        // WFL_LATTICE_FUSED_SERIAL=1 (tests): the gate is launched on the caller's stream IN FRONT of the sweeps, as a
+        // stack that runs kernels one after the other would order them -- it cannot see them and gives up
+        static const bool serial_test = [] {
+          const char* e = getenv("WFL_LATTICE_FUSED_SERIAL");
+          return e && atoi(e) != 0;
+        }();
         if (side) {
           static std::atomic<uint32_t> counter{0};
           do token = (counter.fetch_add(1) + 1) * 2654435761u; while (token == 0);
           const int Bp = (d->B + 7) & ~7;
           hipStream_t main_s = (hipStream_t)stream;
           std::lock_guard<std::mutex> lock(side->mu);  // (the events are the device's, not the call's)
-          // (no fork event: the gate kernel waits for THIS launch's token in the progress words, which the sweeps write
-          // once the stream has reached them -- an event behind the gather would put ~7 us of packet processing in front
-          // of the sweeps.  Whatever the side stream does before that only touches the header, and only after every
-          // sweep has announced itself, i.e. after everything queued on the stream before this call.)
+          // The side stream forks from the caller's stream right in front of the sweeps: the gate then waits for THIS
+          // launch's token in the progress words for microseconds (the sweeps are the next thing the caller's stream
+          // runs), whatever backlog the stream has -- without the fork it waited out the backlog, and its give-up had to
+          // be seconds away.  It writes nothing before every sweep has announced itself.
+          uint32_t* verdict = side->verdicts + (side->next_verdict++ % kVerdictRing);
+          hipStream_t gate_s = serial_test ? main_s : side->stream;
+          if (ls.fork && !serial_test) {
+            WFL_HIP_CHECK(hipEventRecord(side->fork, main_s));
+            WFL_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+          }
+          auto launch_gate = [&]() {
+            hipLaunchKernelGGL(occ_gate_kernel, dim3(1), dim3(64), 0, gate_s, *d, alpha, beta, tail, nch1, token,
+                               bad_env && atoi(bad_env) == 1 ? 1 : 0, ls.host, verdict, nt_o, ls.max_spins);
+          };
+          if (serial_test) launch_gate();
           auto launch_pub = [&](auto kern) {
             if (plds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)kern, (int)plds);
             hipLaunchKernelGGL(kern, dim3((unsigned)(2 * Bp)), dim3(nt), plds, main_s, *d, ints, floats, xg, T, rpc, weights,
@@ -2926,13 +3070,12 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
             launch_pub(prob_chain_pub_kernel<256>);
           else
             launch_pub(prob_chain_pub_kernel<512>);
-          hipLaunchKernelGGL(occ_gate_kernel, dim3(1), dim3(64), 0, side->stream, *d, alpha, beta, tail, nch1, token,
-                             bad_env && atoi(bad_env) == 1 ? 1 : 0, gave_up, nt_o);
+          if (!serial_test) launch_gate();
           if (olds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)occ_live_kernel, (int)olds);
           const int64_t jobs = (int64_t)d->B * nt_o;
           const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>(jobs, (int64_t)fused_wgs * device_cus()));
           hipLaunchKernelGGL(occ_live_kernel, dim3(wgs), dim3(256), olds, side->stream, *d, ints, floats, T, g->C, alpha, beta,
-                             g->coef, g->x, g->row_lse, g->dx, rows_o, nt_o, rpc, tail, nch1, token);
+                             g->coef, g->x, g->row_lse, g->dx, rows_o, nt_o, rpc, tail, nch1, token, verdict);
           WFL_HIP_CHECK(hipEventRecord(side->join, side->stream));
           join_side = side;  // (joined below, behind the certificate: it and the log-domain launch overlap the gradient's tail)
           g->done = 1;
@@ -3157,6 +3300,51 @@ int wfl_row_lse(const float* x, int64_t rows, int C, float* out, void* stream) {
     launch(row_lse_kernel<16, 1>, 1);
   else
     launch(row_lse_wide_kernel, 1);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_lattice_diagnostics(uint64_t* out, int n) {
+  if (!out || n < 0) {
+    set_error("lattice_diagnostics: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  LiveState& ls = live_state();
+  std::lock_guard<std::mutex> lock(ls.mu);
+  const uint64_t v[8] = {ls.attempts,
+                         ls.host ? (uint64_t) * (volatile uint32_t*)&ls.host[0] : 0,
+                         ls.host ? (uint64_t) * (volatile uint32_t*)&ls.host[1] : 0,
+                         ls.skipped,
+                         ls.backoff_left,
+                         ls.env_serial ? 1u : 0u,
+                         (uint64_t)ls.max_spins,
+                         ls.fork ? 1u : 0u};
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return WFL_OK;
+}
+
+int wfl_row_argmax(const float* x, int64_t rows, int C, int32_t* out, void* stream) {
+  if (!x || !out || rows < 0 || C <= 0) {
+    set_error("row_argmax: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  if (rows == 0) return WFL_OK;
+  auto launch = [&](auto kern, int ru) {
+    const unsigned grid = (unsigned)std::min<int64_t>((rows + 4 * ru - 1) / (4 * ru), 1 << 16);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, rows, C, out);
+  };
+  if (C <= 64)
+    launch(row_argmax_kernel<1, 16>, 16);
+  else if (C <= 128)
+    launch(row_argmax_kernel<2, 8>, 8);
+  else if (C <= 256)
+    launch(row_argmax_kernel<4, 4>, 4);
+  else if (C <= 512)
+    launch(row_argmax_kernel<8, 2>, 2);
+  else if (C <= 1024)
+    launch(row_argmax_kernel<16, 1>, 1);
+  else
+    launch(row_argmax_wide_kernel, 1);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

@@ -973,6 +973,89 @@ wfl_lattice_host* wfl_transducer_pack_batch_into(const wfl_graph* tokens, const 
   return h;
 }
 
+// Transducer.viterbi's decode stage for a whole batch (transducer.py:221-232: the body of process(b) behind the best
+// frame path, under gtn.parallel_for).  The token graphs make_token_graph builds are decoded directly
+// (wfl::token_decode); anything else goes through compose / viterbi_path per utterance on the host pool.
+int wfl_transducer_decode_batch(const wfl_graph* tokens, const int32_t* labels, const int64_t* offsets, int B,
+                                int32_t* out, int64_t out_capacity, int64_t* out_offsets, int nthreads) {
+  if (!tokens || !offsets || !out_offsets || B < 0 || (!labels && B > 0 && offsets[B] > offsets[0]) || (!out && out_capacity > 0)) {
+    set_error("transducer_decode_batch: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  for (int b = 0; b < B; ++b)
+    if (offsets[b + 1] < offsets[b]) {
+      set_error("transducer_decode_batch: offsets must not decrease");
+      return WFL_ERR_INVALID;
+    }
+  static const bool generic_only = [] {
+    const char* e = getenv("WFL_DECODE_GENERIC");
+    return e && atoi(e) != 0;
+  }();
+  int ntok = 0;
+  const bool direct = !generic_only && wfl::token_graph_kind(tokens, &ntok) >= 0;
+  std::vector<std::vector<int32_t>> parts(B);
+  std::vector<std::string> errors(B);
+  std::atomic<int> failed{0};
+  auto generic = [&](int b) {
+    const int32_t* lab = labels + offsets[b];
+    const int64_t len = offsets[b + 1] - offsets[b];
+    wfl_graph chain;  // make_chain_graph (transducer.py:23-29)
+    chain.start.assign(len + 1, 0), chain.accept.assign(len + 1, 0);
+    chain.start[0] = 1;
+    if (len > 0) chain.accept[len] = 1;
+    for (int64_t i = 0; i < len; ++i)
+      chain.src.push_back((int32_t)i), chain.dst.push_back((int32_t)i + 1), chain.il.push_back(lab[i]), chain.ol.push_back(lab[i]),
+          chain.w.push_back(0.f);
+    GraphOwner composed(wfl_graph_compose(&chain, tokens, nullptr, nullptr));
+    GraphOwner best(composed.g ? wfl_graph_viterbi_path(composed.g) : nullptr);
+    if (!best.g) {
+      errors[b] = wfl_last_error();
+      failed.store(1);
+      return;
+    }
+    // remove(project_output(path)).labels_to_list(): the path's output labels without the epsilons
+    for (int64_t a = 0; a < best.g->num_arcs(); ++a)
+      if (best.g->ol[a] != WFL_EPSILON) parts[b].push_back(best.g->ol[a]);
+  };
+  auto one = [&](int b) {
+    if (direct && wfl::token_decode(tokens, labels + offsets[b], offsets[b + 1] - offsets[b], parts[b])) return;
+    generic(b);
+  };
+  if (direct) {
+    // a pass over the labels: microseconds per utterance, not worth waking anybody (out-of-alphabet sequences fall
+    // through to the graph algebra one by one)
+    for (int b = 0; b < B; ++b) one(b);
+  } else {
+    tokens->out_sorted(false);  // built once, before the threads ask for it
+    if (nthreads == 1 || B == 1) {
+      for (int b = 0; b < B; ++b) one(b);
+    } else {
+      host_pool().parallel_for(B, one);
+    }
+  }
+  if (failed.load()) {
+    for (int b = 0; b < B; ++b)
+      if (!errors[b].empty()) {
+        set_error("transducer_decode_batch: utterance %d: %s", b, errors[b].c_str());
+        break;
+      }
+    return WFL_ERR_INVALID;
+  }
+  int64_t total = 0;
+  for (int b = 0; b < B; ++b) {
+    out_offsets[b] = total;
+    total += (int64_t)parts[b].size();
+  }
+  out_offsets[B] = total;
+  if (total > out_capacity) {
+    set_error("transducer_decode_batch: %lld labels do not fit the output buffer (%lld)", (long long)total, (long long)out_capacity);
+    return WFL_ERR_INVALID;
+  }
+  for (int b = 0; b < B; ++b)
+    if (!parts[b].empty()) memcpy(out + out_offsets[b], parts[b].data(), parts[b].size() * sizeof(int32_t));
+  return WFL_OK;
+}
+
 void wfl_host_pool_wake(void) { host_pool().wake(); }
 
 void wfl_lattice_host_free(wfl_lattice_host* h) { delete h; }

@@ -330,6 +330,15 @@ class LatticeState:
     __slots__ = ("pack", "T", "C", "xg", "alpha", "beta", "logz", "weights", "bptr", "x", "row_lse", "in_launch")
 
 
+def lattice_diagnostics():
+    """Counters of the gradient beside the sweeps (wfl_lattice_diagnostics): how often it was launched, how often its
+    gate gave up (the call then fell back to the plain gradient for every row), the back-off state."""
+    out = (ctypes.c_uint64 * 8)()
+    N.check(N.lib.wfl_lattice_diagnostics(out, 8))
+    names = ("launched", "gate_gave_up", "gate_ok", "skipped_in_backoff", "backoff_left", "env_serialised", "gate_spins", "fork")
+    return dict(zip(names, (int(v) for v in out)))
+
+
 def lattice_side_join():
     """The current stream waits for the gradient workgroups that ran beside the sweeps (lattice_forward with
     defer_join=True)."""
@@ -518,9 +527,12 @@ class EagerLoss(torch.Tensor):
     __torch_function__ = torch._C._disabled_torch_function_impl
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
-        take = getattr(self.grad_fn, "eager_take", None)
+        node = self.grad_fn
+        take = getattr(node, "eager_take", None)
+        # (hooks on the loss itself -- register_hook, retain_grad -- and on its node only run inside the engine)
         if (take is not None and gradient is None and not retain_graph and not create_graph and inputs is None
-                and self.dim() == 0 and not torch.is_anomaly_enabled()):
+                and self.dim() == 0 and not torch.is_anomaly_enabled() and not self._backward_hooks
+                and not self.retains_grad and not getattr(node, "_wfl_hooked", False)):
             pairs = take()
             if pairs is not None:
                 for leaf, g in pairs:
@@ -528,8 +540,47 @@ class EagerLoss(torch.Tensor):
                         leaf.grad = g
                     else:
                         leaf.grad.add_(g)
+                # the graph is spent, as after a pass of the engine without retain_graph: its buffers go, and a second
+                # backward() raises instead of accumulating a recomputed gradient
+                release_node(node)
                 return None
         return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
+
+
+def watch_node_hooks(ctx):
+    """forward() of a criterion that offers `eager_take`: remember (ctx._wfl_hooked) whether somebody registers a hook on
+    the autograd node -- the engine runs those, EagerLoss.backward does not, so it must stand back.  The node offers no
+    way to ask afterwards; the wrappers hold the node weakly (no cycle that would keep the forward's buffers alive)."""
+    import weakref
+
+    ref = weakref.ref(ctx)
+    ctx._wfl_hooked = False
+    for name in ("register_hook", "register_prehook"):
+        orig = getattr(type(ctx), name)
+
+        def wrapped(fn, _orig=orig):
+            node = ref()
+            node._wfl_hooked = True
+            return _orig(node, fn)
+
+        setattr(ctx, name, wrapped)
+
+
+def release_node(ctx):
+    """After EagerLoss.backward handed the forward's gradients over: drop what backward would recompute from."""
+    ctx._wfl_freed = True
+    ctx.aux = None
+    ctx.early = None
+    ctx.eager_take = None
+
+
+def check_not_released(ctx):
+    """first line of backward(): the error torch raises for a second pass over a freed graph"""
+    if getattr(ctx, "_wfl_freed", False):
+        raise RuntimeError(
+            "Trying to backward through the graph a second time (or directly access saved tensors after they have "
+            "already been freed). Saved intermediate values of the graph are freed when you call .backward() or "
+            "autograd.grad(). Specify retain_graph=True if you need to backward through the graph a second time.")
 
 
 def plain_leaf(t):
@@ -538,6 +589,12 @@ def plain_leaf(t):
     hangs its gradient all-reduce on the parameter's AccumulateGrad node, which only the autograd engine runs."""
     return (type(t) is torch.Tensor and t.is_leaf and t.requires_grad and t.is_cuda
             and not t._backward_hooks and not getattr(t, "_post_accumulate_grad_hooks", None))
+
+
+def takes_grad(t, g):
+    """plain_leaf(t), and the gradient buffer g lives where t does (ASG transitions may sit on another GPU than the
+    inputs: the engine copies across, `t.grad = g` would raise)"""
+    return plain_leaf(t) and g.device == t.device and g.shape == t.shape
 
 
 def make_eager(loss):
@@ -835,6 +892,15 @@ def row_lse(x):
     B, T, C = x.shape
     out = torch.empty((B, T), dtype=_F32, device=x.device)
     N.check(N.lib.wfl_row_lse(ptr(x), B * T, C, ptr(out), stream_ptr()))
+    return out
+
+
+def row_argmax(x):
+    """[B,T] int32: per frame the first maximal class of x [B,T,C] -- viterbi_path of the bare emissions graph
+    (transducer.py:205-216 without transitions)."""
+    B, T, C = x.shape
+    out = torch.empty((B, T), dtype=torch.int32, device=x.device)
+    N.check(N.lib.wfl_row_argmax(ptr(x), B * T, C, ptr(out), stream_ptr()))
     return out
 
 

@@ -179,6 +179,21 @@ def token_alignments(tokens, tokens_target):
     return Graph(False, _handle=h) if h else None
 
 
+def transducer_decode_batch(tokens, labels, offsets, nthreads=0):
+    """Transducer.viterbi's decode stage for a whole batch in one native call (wfl_transducer_decode_batch;
+    transducer.py:221-232 under gtn.parallel_for): per utterance the output labels of
+    viterbi_path(compose(chain(labels_b), tokens)).  labels: flat int32, offsets: int64 [B+1].
+    Returns (flat int32 token labels, int64 offsets [B+1])."""
+    labels = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64).reshape(-1)
+    B = len(offsets) - 1
+    out = np.empty(max(int(offsets[-1] - offsets[0]), 1), np.int32)
+    out_off = np.zeros(B + 1, np.int64)
+    N.check(N.lib.wfl_transducer_decode_batch(tokens._h, labels.ctypes.data, offsets.ctypes.data, B, out.ctypes.data,
+                                              out.size, out_off.ctypes.data, int(nthreads)))
+    return out[:out_off[B]], out_off
+
+
 def equal(a, b):
     return bool(N.lib.wfl_graph_equal(a._h, b._h))
 

@@ -178,6 +178,18 @@ wfl_lattice_host* wfl_transducer_pack_batch_into(const wfl_graph* tokens, const 
                                                  const int64_t* offsets, int B, int C, int nthreads, void* dst,
                                                  int64_t dst_bytes, int64_t reserve_floats);
 int64_t wfl_lattice_host_external(const wfl_lattice_host* h);
+/* Transducer.viterbi's decode stage for a whole batch -- transducer.py:221-232, the part of process(b) behind the best
+ * frame path, run under gtn.parallel_for (transducer.py:232) and called in every training step (train.py:278-279):
+ *     out_b = labels_to_list(remove(project_output(viterbi_path(compose(chain(labels_b), tokens)))))
+ * labels: the frame-level label paths, flat, utterance b = labels[offsets[b] .. offsets[b+1]) (back-off epsilons already
+ * removed).  out (caller's buffer, out_capacity int32; offsets[B] - offsets[0] always suffices for make_token_graph
+ * graphs) receives the token sequences back to back, out_offsets[B+1] their boundaries; an utterance without an
+ * accepting path decodes to nothing.  Ties (allow_repeats) go to the path with the fewest output labels, as
+ * wfl_graph_viterbi_path breaks them.  The graphs make_token_graph builds (transducer.py:78-123) are recognised arc
+ * for arc and decoded directly -- collapse repeated labels, drop blanks, within what the graph accepts --; any other
+ * `tokens` goes through the graph algebra per utterance on the host pool (nthreads: 1 = serial in the caller). */
+int wfl_transducer_decode_batch(const wfl_graph* tokens, const int32_t* labels, const int64_t* offsets, int B,
+                                int32_t* out, int64_t out_capacity, int64_t* out_offsets, int nthreads);
 /* Bulk builders for the three fixed-topology label graphs (no per-arc host calls):
  *   CTC  create_ctc_graph          ctc.py:15-29     targets flat + offsets[B+1], blank
  *   ASG  create_force_align_graph  asg.py:72-81 composed with the transitions graph asg.py:54-69:
@@ -251,6 +263,16 @@ int wfl_lattice_forward_grad(const wfl_lattice_desc* d, const int32_t* ints, con
                              const float* xg, int T, int C, const float* weights, float* alpha,
                              float* beta, float* logz, const float* coef, const float* x,
                              const float* row_lse, float* dx, int* in_launch, void* stream);
+/* What became of the gradient workgroups beside the sweeps (wfl_lattice_forward_grad), process-wide counters:
+ *   out[0] calls that launched them            out[1] of those, gates that GAVE UP waiting for the sweeps (kernels of
+ *   out[2] gates that went through                     two streams did not run at the same time: a serialising
+ *   out[3] calls that took the plain path              profiler, a debugger) -- the call fell back to
+ *          during the back-off after a give-up         wfl_lattice_grad_rest for every row, results unaffected
+ *   out[4] calls left in the current back-off   out[5] 1 = the environment announces serialised launches
+ *   out[6] the gate's bound (polls of ~2 us)           (AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING): never tried
+ *   out[7] 1 = the side stream forks from the caller's stream (default)
+ * The device counters behind out[1..2] are read without synchronisation: they lag the stream. n <= 8 words. */
+int wfl_lattice_diagnostics(uint64_t* out, int n);
 int wfl_lattice_grad_rest(const wfl_lattice_desc* d, const int32_t* ints, const float* floats,
                           const float* xg, int T, int C, const float* weights, const float* alpha,
                           const float* beta, const float* logz, const float* coef, const float* gout,
@@ -375,6 +397,9 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
                              float* loss_out, const float* row_lse, void* stream);
 /* out[r] = logsumexp_c x[r*C + c] for r < rows (NaN counts as -inf) */
 int wfl_row_lse(const float* x, int64_t rows, int C, float* out, void* stream);
+/* out[r] = the first c with x[r*C + c] == max_c x[r*C + c] (NaN counts as -inf; a row without a finite score: 0) --
+ * viterbi_path of the bare emissions graph (transducer.py:205-216 without transitions), one frame per row */
+int wfl_row_argmax(const float* x, int64_t rows, int C, int32_t* out, void* stream);
 /* dense gradient rows, recomputed block by block from the checkpoints of wfl_ctc_forward */
 int wfl_ctc_grad(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
                  int max_len, int blank, const float* ws, const float* nll, const float* coef,

@@ -56,6 +56,77 @@ def lattice_forward_backward(x, src, dst, lab, w, start, accept, num_states):
     return float(logz), dx, darc
 
 
+def _eps_depths(num_states, esrc, edst):
+    """longest epsilon path ending at / starting from every node (the epsilon arcs must not form a cycle)"""
+    din, dout = np.zeros(num_states, np.int64), np.zeros(num_states, np.int64)
+    for _ in range(num_states + 1):
+        nin, nout = din.copy(), dout.copy()
+        np.maximum.at(nin, edst, din[esrc] + 1)
+        np.maximum.at(nout, esrc, dout[edst] + 1)
+        if (nin == din).all() and (nout == dout).all():
+            return din, dout
+        din, dout = nin, nout
+    raise ValueError("epsilon arcs form a cycle")
+
+
+def lattice_forward_backward_eps(x, src, dst, lab, w, start, accept, num_states):
+    """lattice_forward_backward for an acceptor WITH epsilon arcs (lab < 0: back-off arcs of a transition model,
+    the </s> arcs of make_transitions_graph -- criterions/transducer.py:32-58,279-288): after every frame (and before
+    the first) the epsilon arcs are followed, in topological order of their acyclic subgraph,
+        alpha_t[q] = LSE(direct_t[q], LSE_{eps arcs p->q} alpha_t[p] + w),   beta_t likewise backwards.
+    Returns (logZ, dx[T,C], darc[num_arcs]); an epsilon arc's entry sums its posteriors over the T + 1 closures.
+    """
+    x = np.asarray(x, dtype=np.float64)
+    T, C = x.shape
+    src, dst, lab = (np.asarray(v, dtype=np.int64) for v in (src, dst, lab))
+    w = np.asarray(w, dtype=np.float64)
+    w = np.where(np.isnan(w), NEG, w)
+    x = np.where(np.isnan(x), NEG, x)
+    ie, il = np.flatnonzero(lab < 0), np.flatnonzero(lab >= 0)
+    ls, ld, ll, lw = src[il], dst[il], lab[il], w[il]
+    es, ed, ew = src[ie], dst[ie], w[ie]
+    din, dout = _eps_depths(num_states, es, ed)
+    fwd_groups = [np.flatnonzero(din[es] == d) for d in range(int(din.max()) + 1)] if len(ie) else []
+    bwd_groups = [np.flatnonzero(dout[ed] == d) for d in range(int(dout.max()) + 1)] if len(ie) else []
+
+    def close_fwd(a):
+        for g in fwd_groups:
+            if len(g):
+                np.logaddexp.at(a, ed[g], a[es[g]] + ew[g])
+
+    def close_bwd(b):
+        for g in bwd_groups:
+            if len(g):
+                np.logaddexp.at(b, es[g], b[ed[g]] + ew[g])
+
+    alpha = np.full((T + 1, num_states), NEG)
+    beta = np.full((T + 1, num_states), NEG)
+    with np.errstate(all="ignore"):
+        alpha[0, list(start)] = 0.0
+        close_fwd(alpha[0])
+        for t in range(T):
+            np.logaddexp.at(alpha[t + 1], ld, alpha[t, ls] + x[t, ll] + lw)
+            close_fwd(alpha[t + 1])
+        beta[T, list(accept)] = 0.0
+        close_bwd(beta[T])
+        for t in range(T - 1, -1, -1):
+            np.logaddexp.at(beta[t], ls, beta[t + 1, ld] + x[t, ll] + lw)
+            close_bwd(beta[t])
+        logz = _lse(alpha[T, list(accept)]) if len(accept) else NEG
+        dx = np.zeros((T, C))
+        darc = np.zeros(len(src))
+        if np.isfinite(logz):
+            for t in range(T):
+                g = np.exp(alpha[t, ls] + x[t, ll] + lw + beta[t + 1, ld] - logz)
+                g = np.where(np.isfinite(g), g, 0.0)
+                np.add.at(dx[t], ll, g)
+                darc[il] += g
+            if len(ie):
+                g = np.exp(alpha[:, es] + ew[None, :] + beta[:, ed] - logz)
+                darc[ie] += np.where(np.isfinite(g), g, 0.0).sum(axis=0)
+    return float(logz), dx, darc
+
+
 def ctc_arcs(target, blank):
     """Arc list of the CTC label graph (criterions/ctc.py:15-29)."""
     L = len(target)
@@ -317,3 +388,34 @@ def asg_loss_grad_batched(x, W, targets, reduction="none"):
         np.add.at(gW, np.asarray(wid, dtype=np.int64), garc)
         dW -= gW.reshape(W.shape) * cf[b]
     return losses, dx, dW
+
+
+def transducer_transitions_loss_grad(x, numerators, transitions, params, scales):
+    """The Transducer criterion WITH a transition model (criterions/transducer.py:279-290,312-348) through the
+    epsilon-aware recurrence above, for arc lists instead of graphs:
+        loss_b = scale_b * (logZ(emissions_b o transitions) - logZ(emissions_b o numerator_b)),  loss = mean_b loss_b
+    x [B,T,C] raw scores; numerators[b] = (src, dst, lab, wid, start, accept, num_states) -- the acceptor
+    transitions o alignments_b with, per arc, the arc of `transitions` behind it (wid: its weight is params[wid]);
+    transitions = (src, dst, lab, start, accept, num_states), arc a weighted params[a].
+    Returns (loss, per-utterance losses, dx [B,T,C], dparams, counts) -- counts[k] = the sum of the two expected arc
+    counts (normaliser + numerator, scaled like dparams) whose DIFFERENCE dparams[k] is: what a relative accuracy of
+    the two forward_score gradients translates to when they nearly cancel (a blank arc that both use all the time)."""
+    x = np.asarray(x, dtype=np.float64)
+    params = np.asarray(params, dtype=np.float64)
+    B = x.shape[0]
+    tsrc, tdst, tlab, tstart, taccept, tn = transitions
+    losses, dx, dp = np.zeros(B), np.zeros_like(x), np.zeros_like(params)
+    counts = np.zeros_like(params)
+    for b in range(B):
+        nsrc, ndst, nlab, nwid, nstart, naccept, nn = numerators[b]
+        nwid = np.asarray(nwid, dtype=np.int64)
+        zn, gn, an = lattice_forward_backward_eps(x[b], nsrc, ndst, nlab, params[nwid], nstart, naccept, nn)
+        zd, gd, ad = lattice_forward_backward_eps(x[b], tsrc, tdst, tlab, params, tstart, taccept, tn)
+        sc = scales[b]
+        losses[b] = sc * (zd - zn)
+        dx[b] = sc * (gd - gn) / B
+        dp += sc * ad / B
+        np.add.at(dp, nwid, -sc * an / B)
+        counts += sc * ad / B
+        np.add.at(counts, nwid, sc * an / B)
+    return float(losses.mean()), losses, dx, dp, counts

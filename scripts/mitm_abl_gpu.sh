@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 for v in "$@"; do
   echo "== ABL $v"
   rm -rf /tmp/abl$v
-  WFL_LIB_PATH=$PWD/scripts/_build/libwfl_abl$v.so timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/abl$v -- python bench.py --mode abi --steps 30 --warmup 3 --no-cpu-baseline --no-extras > /tmp/abl$v.log 2>&1
+  WFL_LIB_PATH=$PWD/scripts/_build/libwfl_abl$v.so timeout 60 rocprofv3 --kernel-trace --output-format csv -d /tmp/abl$v -- python bench.py --mode abi --steps 30 --warmup 3 --no-cpu-baseline --no-extras > /tmp/abl$v.log 2>&1
   python - "$(find /tmp/abl$v -name '*kernel_trace.csv' | head -1)" <<'PY'
 import csv, sys, collections, statistics
 d = collections.defaultdict(list)

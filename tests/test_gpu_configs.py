@@ -443,3 +443,50 @@ def test_ctc_batches_with_more_sweeps_than_cus():
     loss.backward()
     assert loss.item() == pytest.approx(want_loss.mean(), rel=RTOL)
     check("ctc_b160_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / B)
+
+
+def test_cfg4_transducer_viterbi_decodes_the_batch_in_one_native_call():
+    """Transducer.viterbi at BASELINE configs[3]'s size (transducer.py:199-234; called in every training step,
+    train.py:278-279): frame labels by the row-argmax kernel (first maximum, NaN = impossible), token sequences by
+    wfl_transducer_decode_batch.  Every utterance against the collapse the token graph stands for, two utterances
+    against the reference's own chain of graph calls on the host library."""
+    import itertools
+
+    from gtn_applications_amd import graph as G
+    from gtn_applications_amd.criterions import transducer as TR
+
+    tokens, g2i = _word_piece_setup()
+    B, T = 64, 800
+    C = len(tokens) + 1
+    x = torch.randn(B, T, C, generator=torch.Generator().manual_seed(1))
+    x[0, 5, :] = x[0, 5, 17]          # a frame of equal scores: the first label wins
+    x[1, 7, 3] = float("nan")         # a NaN is an impossible arc, not a maximum
+    x[2, :40, C - 1] = 9.0            # a stretch of blanks
+    x[3, 100:140, 11] = 9.0           # a stretch of one token
+    crit = TR.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+    got = crit.viterbi(x.cuda())
+    assert len(got) == B and all(p.dtype == torch.int32 and p.device.type == "cpu" for p in got)
+    xn = np.nan_to_num(x.numpy(), nan=-np.inf)
+    frames = xn.argmax(axis=2)  # (numpy: the first maximum)
+    assert frames[0, 5] == 0
+    for b in range(B):
+        want = [k for k, _ in itertools.groupby(frames[b].tolist()) if k != C - 1]
+        assert got[b].tolist() == want, b
+    crit.tokens.arc_sort()
+    for b in (0, 3, B - 1):
+        path = G.viterbi_path(G.compose(TR.make_chain_graph(frames[b].tolist()), crit.tokens))
+        assert got[b].tolist() == G.remove(G.project_output(path)).labels_to_list()
+
+
+def test_row_argmax_first_maximum_any_width():
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(3)
+    for C in (1, 7, 64, 65, 100, 129, 300, 513, 1001, 1500):
+        x = rs.randint(-3, 4, size=(3, 37, C)).astype(np.float32)  # (many ties)
+        x[0, 0, :] = -np.inf
+        if C > 2:
+            x[1, 1, 1] = np.nan
+        got = E.row_argmax(torch.tensor(x).cuda()).cpu().numpy()
+        want = np.nan_to_num(x, nan=-np.inf).argmax(axis=2)
+        assert (got == want).all(), C

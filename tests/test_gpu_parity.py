@@ -979,14 +979,34 @@ def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(c
     close(dx, ref_dx.cpu().numpy(), rtol=1e-4, atol=1e-6, msg="loss.backward()")
     loss, dx, _ = run(2.5)
     close(dx, 2.5 * ref_dx.cpu().numpy(), rtol=1e-4, atol=2.5e-6, msg="autograd engine, grad_output 2.5")
-    # .grad accumulates; a second backward through the same graph finds the buffer handed over and recomputes
+    # .grad accumulates; a second backward through the same graph raises, as after a pass of the engine (the graph is spent)
     xi = x.clone().requires_grad_(True)
     m(xi, tg).backward()
     loss = m(xi, tg)
     loss.backward()
     close(xi.grad, 2 * ref_dx.cpu().numpy(), rtol=1e-4, atol=2e-6, msg="accumulated .grad")
-    loss.backward()
-    close(xi.grad, 3 * ref_dx.cpu().numpy(), rtol=1e-4, atol=3e-6, msg="second backward")
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    assert loss.grad_fn.aux is None  # (the forward's buffers went with the graph)
+    # hooks on the loss or on its node only run inside the engine: backward() must go there, same numbers
+    for how in ("tensor hook", "retain_grad", "node hook", "node prehook"):
+        xi = x.clone().requires_grad_(True)
+        loss = m(xi, tg)
+        seen = []
+        if how == "tensor hook":
+            loss.register_hook(lambda g: seen.append(float(g)))
+        elif how == "retain_grad":
+            loss.retain_grad()
+        elif how == "node hook":
+            loss.grad_fn.register_hook(lambda gi, go: seen.append(1.0))
+        else:
+            loss.grad_fn.register_prehook(lambda go: seen.append(1.0))
+        loss.backward()
+        close(xi.grad, ref_dx.cpu().numpy(), rtol=1e-4, atol=1e-6, msg=how)
+        if how == "retain_grad":
+            assert float(loss.grad) == 1.0
+        else:
+            assert seen == [1.0], how
     # through the engine: the buffer scaled in place on the first pass, recomputed on the second (retained graph)
     xi = x.clone().requires_grad_(True)
     loss = m(xi, tg) * 1.5
@@ -1030,6 +1050,71 @@ def test_transducer_gradient_beside_the_sweeps_under_cu_contention(crit):
     busy_during = not side.query()
     torch.cuda.synchronize()
     assert busy_during, "the competing stream did not outlast the steps: the test did not exercise contention"
+
+
+_GATE_SCRIPT = r"""
+import json, sys, torch
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(tests)r)
+import numpy as np
+from gtn_applications_amd import engine as E
+from gtn_applications_amd.criterions import transducer as tr
+from test_gpu_parity import _word_piece_batch
+tokens, g2i, x, tg = _word_piece_batch(6, 200, 11)
+m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+out = []
+for step in range(14):
+    xi = x.clone().requires_grad_(True)
+    loss = m(xi, tg)
+    loss.backward()
+    torch.cuda.synchronize()
+    out.append((loss.item(), float(xi.grad.double().abs().sum()), float(xi.grad.double().sum(dim=2).abs().max()), E.lattice_diagnostics()))
+np.save(sys.argv[1], xi.grad.cpu().numpy())
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_transducer_gradient_beside_the_sweeps_gate_gives_up_cleanly_and_reports_it(crit, tmp_path):
+    """A stack that runs the kernels of different streams one after the other (a counter-collecting profiler, a
+    debugger): the gate kernel in front of the gradient workgroups cannot see the sweeps.  WFL_LATTICE_FUSED_SERIAL=1
+    puts it in front of them on the caller's stream (what such a stack does to the launch order).  It must give up
+    within its bound (microseconds, not seconds), write nothing into the sweeps' buffers, and the call must fall back
+    to the plain gradient for every row -- same loss, same gradient as the overlapped step -- and SAY so:
+    wfl_lattice_diagnostics counts the give-ups, the following calls back off (1, 2, 4, ... calls on the plain path
+    between attempts).  In a process of its own (the switches are read once)."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _GATE_SCRIPT % dict(root=root, tests=os.path.join(root, "tests"))
+
+    def run(env_extra, name):
+        env = dict(os.environ)
+        env.update(env_extra)
+        t0 = time.time()
+        res = subprocess.run([sys.executable, "-c", script, str(tmp_path / name)], capture_output=True, text=True, env=env,
+                             timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        line = [l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return json.loads(line[7:]), np.load(tmp_path / (name + ".npy")), time.time() - t0
+
+    ref, ref_dx, _ = run({}, "ref")
+    d = ref[-1][3]
+    # (the very first launch of a process may load the sweeps' code for longer than the gate waits: one give-up, one
+    # call on the plain path, at most)
+    assert d["launched"] >= 13 and d["gate_gave_up"] <= 1 and d["gate_ok"] >= 12 and d["skipped_in_backoff"] <= 1, d
+    got, dx, _ = run({"WFL_LATTICE_FUSED_SERIAL": "1"}, "serial")
+    for step, (a, b) in enumerate(zip(ref, got)):
+        assert b[0] == pytest.approx(a[0], rel=1e-6), step
+        assert b[1] == pytest.approx(a[1], rel=1e-5), step
+        assert b[2] <= 1e-6, step  # rows through the fused log_softmax sum to zero: no row was left unwritten
+    close(dx, ref_dx, rtol=1e-4, atol=1e-6, msg="gate gave up")
+    d = got[-1][3]
+    # steps 0, 2, 5 and 10 launch and give up; the 1, 2, 4 and (so far 3 of) 8 calls behind them back off
+    assert d["gate_gave_up"] == 4 and d["gate_ok"] == 0 and d["launched"] == 4 and d["skipped_in_backoff"] == 10, d
+    assert d["gate_spins"] <= 1 << 12, d  # the bound: milliseconds per give-up, not seconds
 
 
 def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificate(crit, monkeypatch):

@@ -743,3 +743,42 @@ def test_numpy_stand_in_of_the_staging_helper_equals_it():
     assert out["c"][0] == out["np"][0] == (10, 5, 1, 9)
     for a, b in zip(out["c"][1:], out["np"][1:]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("blank,repeats", [("none", True), ("optional", True), ("forced", True), ("optional", False)])
+def test_batched_decode_written_down_directly_equals_the_graph_algebra(blank, repeats):
+    """wfl_transducer_decode_batch (the batch-parallel decode stage of Transducer.viterbi, transducer.py:221-232):
+    for every graph make_token_graph can build the direct decode equals, utterance by utterance,
+    remove(project_output(viterbi_path(compose(chain(labels), tokens)))) -- on random label sequences, on sequences
+    the graph rejects, on labels outside its alphabet and on the empty sequence."""
+    rs = np.random.RandomState(7)
+    ntok = 5
+    tokens = TR.make_token_graph([(i,) for i in range(ntok)], blank=blank, allow_repeats=repeats)
+    hi = ntok + (1 if blank != "none" else 0)
+    seqs = [rs.randint(0, hi, size=rs.randint(1, 14)).tolist() for _ in range(120)]
+    seqs += [rs.randint(0, 2, size=12).tolist() for _ in range(20)]  # (long runs of repeats)
+    if blank != "none":
+        b = ntok
+        seqs += [[b, 1, 1, b, 1, b], [b, 1, b, 2, 2, b, b], [1, b], [b, 1], [b], [b, b], [b, 1, 2, b], [3, 3, b, 3]]
+    seqs += [[], [0], [ntok + 1, 0], [0, ntok + 3]]  # (outside the alphabet: the graph algebra decides)
+    flat = np.array([v for s in seqs for v in s], np.int32)
+    offs = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum([len(s) for s in seqs], out=offs[1:])
+    tokens.arc_sort()
+    out, out_off = G.transducer_decode_batch(tokens, flat, offs)
+    want = []
+    for s in seqs:
+        path = G.viterbi_path(G.compose(TR.make_chain_graph(s), tokens))
+        want.append(G.remove(G.project_output(path)).labels_to_list())
+    got = [out[out_off[i]:out_off[i + 1]].tolist() for i in range(len(seqs))]
+    assert got == want
+    if blank == "forced":
+        assert any(len(w) == 0 and len(s) > 2 for w, s in zip(want, seqs))  # (rejected sequences were among them)
+    # the same through the graph algebra on the pool (what any other token graph gets)
+    other = G.Graph(False)
+    a = tokens.arrays()
+    other.add_nodes(a["start"], a["accept"])
+    other.add_arcs(a["src"], a["dst"], a["ilabel"], a["olabel"], a["weight"])
+    other.add_arc(0, 0, 1000, 1000, 0.0)  # (one arc more: no longer a make_token_graph, same language on these labels)
+    out2, off2 = G.transducer_decode_batch(other, flat, offs)
+    assert [out2[off2[i]:off2[i + 1]].tolist() for i in range(len(seqs))] == want
