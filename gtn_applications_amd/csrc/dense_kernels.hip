@@ -83,6 +83,17 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
   // neither the row's round trip nor the acknowledgement of the frame's own stores (scores, back-pointers) sits on
   // the frame-to-frame path (with __syncthreads and a row requested in the step that writes it, a frame of the
   // max-plus sweep took ~2.6 us at C = 82: 0.65 of the 0.8 ms of a bigram Transducer.viterbi).
+  // (one (state, slice) per thread and a slice of at most kSpanRegs terms: its weights stay in registers)
+  constexpr int kSpanRegs = 64;
+  const bool wregs = C <= NT && span <= kSpanRegs;  // block-uniform
+  const int wj0 = (tid / C) * span;
+  float wr[kSpanRegs];
+#pragma unroll
+  for (int jj = 0; jj < kSpanRegs; ++jj) {
+    wr[jj] = WFL_NEG_INF;  // (a slice's tail beyond C: never the maximum, exp(-inf) = 0)
+    if (wregs && tid < R * C && jj < span && wj0 + jj < C)
+      wr[jj] = DIR == 0 ? L.W[(1 + tid % C) * ldw + wj0 + jj] : L.W[(1 + wj0 + jj) * ldw + tid % C];
+  }
   auto row_needed_by = [&](int step) { return DIR == 0 ? step : T - step; };  // (= tx of that step)
   float pre[4] = {0.f, 0.f, 0.f, 0.f};
   if (T > 2) {
@@ -111,6 +122,45 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
       }
     }
     // ---- partial reductions
+    if (wregs) {
+      // the thread's slice of W in registers (wr, loaded once): a frame only reads the previous vector from LDS, the
+      // same address across the 82-odd threads of a slice (a broadcast) -- reading W itself every frame, rows a
+      // stride of C apart, bank-conflicted a 28-term slice into ~6000 cycles (measured: 2.6 us per frame at C = 82)
+      // (the slice's terms at compile-time offsets from ONE base address, NO branch per term -- behind a branch every
+      // LDS read was waited for on its own: a0 / a1 / x0 / x1 are padded by kSpanRegs zeros, and a term beyond the
+      // slice carries wr = -inf: never the maximum, exp(-inf) = 0.  The trip count is the slice rounded up to 16 / 32 / 64.)
+      auto partials = [&](auto bucket) {
+        constexpr int S = decltype(bucket)::value;
+        const float* fp = from + wj0;
+        const float* xp = xr + wj0;
+        float m = WFL_NEG_INF;
+        int am = -1;
+#pragma unroll
+        for (int jj = 0; jj < S; ++jj) {
+          const float v = DIR == 0 ? fp[jj] + wr[jj] : wr[jj] + xp[jj] + fp[jj];
+          if (v > m) m = v, am = jj;
+        }
+        if (am >= 0) am += wj0;
+        float sum = 0.f;
+        if (SR == WFL_SEMIRING_LOG && m > WFL_NEG_INF) {
+#pragma unroll
+          for (int jj = 0; jj < S; ++jj) {
+            const float v = DIR == 0 ? fp[jj] + wr[jj] : wr[jj] + xp[jj] + fp[jj];
+            sum += fast_exp(v - m);
+          }
+        }
+        L.pm[tid] = m;
+        L.ps[tid] = SR == WFL_SEMIRING_LOG ? sum : __int_as_float(am);
+      };
+      if (tid < R * C) {
+        if (span <= 16)
+          partials(std::integral_constant<int, 16>{});
+        else if (span <= 32)
+          partials(std::integral_constant<int, 32>{});
+        else
+          partials(std::integral_constant<int, kSpanRegs>{});
+      }
+    } else
     for (int idx = tid; idx < R * C; idx += NT) {
       const int s = idx % C, r = idx / C;  // s: state being produced, r: which slice of the other index
       const int j0 = r * span, j1 = min(C, j0 + span);
@@ -130,6 +180,18 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
       L.ps[idx] = SR == WFL_SEMIRING_LOG ? sum : __int_as_float(am);
     }
     lds_barrier();
+    // (the next step's emission row goes to LDS, and the row after it moves up, BEFORE this frame's stores are issued:
+    // the counter the loads are waited on is shared with the stores, and behind them the wait was a store round trip)
+    if (has_next) {
+      float* xn = (txn & 1) ? L.x1 : L.x0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid + j * NT;
+        if (i < C) xn[i] = nan_to_neg(pre[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pre[j] = pre2[j];
     // ---- merge partials, add the emission (alpha only), publish
     for (int s = tid; s < C; s += NT) {
       float m = L.pm[s];
@@ -152,16 +214,6 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
       ob[(int64_t)t * C + s] = val;
       if (SR == WFL_SEMIRING_TROPICAL) bptr[((int64_t)b * T + t) * C + s] = am;
     }
-    if (has_next) {
-      float* xn = (txn & 1) ? L.x1 : L.x0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = tid + j * NT;
-        if (i < C) xn[i] = nan_to_neg(pre[j]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pre[j] = pre2[j];
     lds_barrier();
   }
   if (DIR == 0 && logz && T > 0) {
@@ -192,10 +244,12 @@ __global__ void __launch_bounds__(256)
   DenseLds L;
   float* p = (float*)smem;
   L.W = p, p += (size_t)(C + 1) * ldw;
-  L.a0 = p, p += C;
-  L.a1 = p, p += C;
-  L.x0 = p, p += C;
-  L.x1 = p, p += C;
+  constexpr int kPad = 64;  // (dense_chain reads up to kSpanRegs terms past the vectors' ends: zeros)
+  L.a0 = p, p += C + kPad;
+  L.a1 = p, p += C + kPad;
+  L.x0 = p, p += C + kPad;
+  L.x1 = p, p += C + kPad;
+  for (int i = tid; i < kPad; i += NT) L.a0[C + i] = L.a1[C + i] = L.x0[C + i] = L.x1[C + i] = 0.f;
   L.pm = p, p += (size_t)R * C;
   L.ps = p, p += (size_t)R * C;
   L.red = p;
@@ -209,7 +263,7 @@ __global__ void __launch_bounds__(256)
 
 static size_t dense_chain_lds(int C, int ldw) {
   const int R = C <= 256 ? 256 / C : 1;
-  return 4 * ((size_t)(C + 1) * ldw + 4 * (size_t)C + 2 * (size_t)R * C + 64) + 64;
+  return 4 * ((size_t)(C + 1) * ldw + 4 * ((size_t)C + 64) + 2 * (size_t)R * C + 64) + 64;
 }
 
 // ------------------------------------------------------------------------------------------------

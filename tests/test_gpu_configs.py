@@ -490,3 +490,22 @@ def test_row_argmax_first_maximum_any_width():
         got = E.row_argmax(torch.tensor(x).cuda()).cpu().numpy()
         want = np.nan_to_num(x, nan=-np.inf).argmax(axis=2)
         assert (got == want).all(), C
+
+
+@pytest.mark.parametrize("argv", [["--config", "cfg5"], ["--workload", "asg"]])
+def test_bench_collective_path_executes_on_one_gpu(argv):
+    """bench.py's multi-GPU branch as far as a 1-GPU box allows (train.py:137-142,201-208): with
+    WFL_BENCH_FORCE_DIST=1 the process group is RCCL ("nccl") at world size 1, the barrier / MAX-over-ranks timing runs,
+    and the step's all-reduce(mean) -- the [(C+1), C] buffer of cfg5, the transition-weight gradient of the ASG step --
+    goes through parallel.all_reduce_mean_ on the device.  No scaling number comes out of this (there is one GPU)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, WFL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-extras"] + argv, capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["collective_world_size"] == 1
+    assert "all-reduce(mean)" in line["config"]["parallelism"]
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
