@@ -30,6 +30,12 @@ class WflUnsupported(WflError):
     pass
 
 
+class CtcCall(ctypes.Structure):
+    """Mirror of `wfl_ctc_call` (include/wfl.h)."""
+
+    _fields_ = [("n_labels", c_int64), ("host_state", c_void_p)]
+
+
 class LatticeDesc(ctypes.Structure):
     """Mirror of `wfl_lattice_desc` (include/wfl.h) -- field order and types must match."""
 
@@ -86,7 +92,6 @@ _SIGS = {
     "wfl_graph_compose": (_P, [_P, _P, POINTER(_P), POINTER(_P)]),
     "wfl_graph_token_alignments": (_P, [_P, _P]),
     "wfl_host_pool_wake": (None, []),
-    "wfl_ctc_adaptive_reset": (None, []),
     "wfl_graph_remove": (_P, [_P, c_int, c_int, POINTER(_P)]),
     "wfl_graph_project": (_P, [_P, c_int]),
     "wfl_graph_viterbi_path": (_P, [_P]),
@@ -144,6 +149,8 @@ _SIGS = {
     "wfl_ctc_grad": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "wfl_ctc_forward_backward": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
                                          _P, _P]),
+    "wfl_ctc_forward_backward_call": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
+                                              _P, _P, _P]),
     "wfl_row_lse": (c_int, [_P, c_int64, c_int, _P, _P]),
     "wfl_row_argmax": (c_int, [_P, c_int64, c_int, _P, _P]),
     "wfl_upload": (c_int, [_P, _P, c_int64, _P]),

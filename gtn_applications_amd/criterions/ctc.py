@@ -196,8 +196,9 @@ def _ctc_loss(log_probs, targets, blank_idx, reduction, fused_log_softmax):
             lse = E.row_lse(log_probs.detach()) if fused_log_softmax else None
             fac = tg._off_fac + 4 * B * (0 if reduction == "none" else 1)  # byte offset of scale_<reduction>
             tok = E._mark("ctc_step")
+            words, _ = E.ctc_host_state(log_probs, tg.max_len)
             loss = node.ctc_step(log_probs, tg.dev_buf, 0, tg._off_flat, fac, fac + 16 * B, tg.max_len, int(blank_idx),
-                                 ws, nll, lse)
+                                 ws, nll, lse, tg.n, 0 if words is None else words.data_ptr())
             E._done(tok)
             return loss
     fn = _FusedLogSoftmaxCTCLoss if fused_log_softmax else CTCLossFunction

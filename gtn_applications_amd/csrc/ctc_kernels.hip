@@ -139,6 +139,9 @@ struct CtcArgs {
   // repair launch behind the meet-in-the-middle launch: that launch's token -- it raised ws.suspect to it if any
   // certificate had a doubt, otherwise the repair launch has nothing to look at (0: the word is not maintained)
   unsigned long long suspect_token;
+  // meet-in-the-middle launch: number of labels the caller vouches for behind `targets` (0: unknown) -- what lets the
+  // workgroups ask for their labels before the offsets have arrived (ctc_mitm.h)
+  long long n_labels;
 };
 constexpr int kXcStride = 64;
 constexpr int kParkStride = 17 * 64;  // 16 frames x 64 lanes of factors + the per-lane reference word
@@ -2499,34 +2502,37 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
   return WFL_OK;
 }
 
-// what the repair launch of the last lane-exponent step on a workspace reported (see wfl_ctc_forward_backward)
-struct AdaptiveSeen {
-  int32_t* host = nullptr;
-  unsigned skipped = 0;
-};
-static std::mutex g_adaptive_mu;
-static std::map<std::pair<int, const void*>, AdaptiveSeen> g_adaptive_table;
-
-// Forget what earlier steps reported: the next call on any workspace tries the lane-exponent step again.  (A workspace
-// is identified by its address; a caller that hands the same address to unrelated data -- tests, a new data set --
-// can start it from scratch.)
-void wfl_ctc_adaptive_reset(void) {
-  std::lock_guard<std::mutex> lock(g_adaptive_mu);
-  for (auto& kv : g_adaptive_table) {
-    if (kv.second.host) kv.second.host[0] = 0;
-    kv.second.skipped = 0;
-  }
-}
+static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
+                                     int max_len, int blank, float* ws, float* nll, const float* coef, const float* gout,
+                                     float* dx, const float* loss_scale, float* loss_out, const float* row_lse,
+                                     const wfl_ctc_call* call, void* stream);
 
 int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
                              int max_len, int blank, float* ws, float* nll, const float* coef, const float* gout,
                              float* dx, const float* loss_scale, float* loss_out, const float* row_lse, void* stream) {
+  return ctc_forward_backward_impl(x, B, T, C, targets, offsets, max_len, blank, ws, nll, coef, gout, dx, loss_scale, loss_out,
+                                   row_lse, nullptr, stream);
+}
+
+int wfl_ctc_forward_backward_call(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
+                                  int max_len, int blank, float* ws, float* nll, const float* coef, const float* gout,
+                                  float* dx, const float* loss_scale, float* loss_out, const float* row_lse,
+                                  const wfl_ctc_call* call, void* stream) {
+  return ctc_forward_backward_impl(x, B, T, C, targets, offsets, max_len, blank, ws, nll, coef, gout, dx, loss_scale, loss_out,
+                                   row_lse, call, stream);
+}
+
+static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const int32_t* targets, const int64_t* offsets,
+                                     int max_len, int blank, float* ws, float* nll, const float* coef, const float* gout,
+                                     float* dx, const float* loss_scale, float* loss_out, const float* row_lse,
+                                     const wfl_ctc_call* call, void* stream) {
   if (int rc = ctc_check(B, T, C, max_len, blank, "ctc_forward_backward")) return rc;
   if (!x || !targets || !offsets || !ws || !nll || !dx) {
     set_error("ctc_forward_backward: null buffer");
     return WFL_ERR_INVALID;
   }
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll, 0ull, loss_scale, loss_out, row_lse};
+  a.n_labels = call && call->n_labels > 0 ? call->n_labels : 0;
   // launch token: process-wide counter mixed with the workspace address -- uninitialised memory or flags
   // left by a launch that used the block earlier cannot equal it; consumers clear the flags they used,
   // so replaying the SAME launch from a hipGraph (same token, same workspace) starts from cleared flags
@@ -2549,25 +2555,16 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   bool prefer_log = false;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing((hipStream_t)stream, &capturing);  // (a captured step must not allocate, and replays one choice)
-  if (adaptive_on && ppl == 1 && capturing == hipStreamCaptureStatusNone) {
-    using Seen = AdaptiveSeen;
-    std::mutex& mu = g_adaptive_mu;
-    auto& table = g_adaptive_table;  // (device, workspace)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(mu);
-    if (table.size() > 64) {  // (workspaces come and go with the shapes: start over rather than grow)
-      for (auto& kv : table)
-        if (kv.second.host) (void)hipHostFree(kv.second.host);
-      table.clear();
-    }
-    Seen& e = table[{dev, (const void*)ws}];
-    if (!e.host && hipHostMalloc((void**)&e.host, 64, hipHostMallocDefault) == hipSuccess) e.host[0] = 0;
-    a.host_repaired = e.host;
-    if (e.host && (int64_t) * (volatile int32_t*)e.host * 8 > B) {
-      prefer_log = (++e.skipped & 15) != 0;
+  // (the memory of the choice is the CALLER's: two int32 of pinned host memory per criterion / workspace -- [0] written
+  // by the repair launch, system scope, read here without a synchronisation; [1] this function's counter.  Without
+  // it every call starts with the lane-exponent step.)
+  int32_t* state = call ? call->host_state : nullptr;
+  if (adaptive_on && ppl == 1 && capturing == hipStreamCaptureStatusNone && state) {
+    a.host_repaired = state;
+    if ((int64_t) * (volatile int32_t*)state * 8 > B) {
+      prefer_log = (++state[1] & 15) != 0;
     } else {
-      e.skipped = 0;
+      state[1] = 0;
     }
   }
   // log-domain kernels (4-wave workgroups): dense row tiles while five workgroups share a CU with them, compact beyond
@@ -2607,10 +2604,17 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
   }();
   // two workgroup shapes (ctc_mitm.h): 16 waves, one workgroup per CU, while the batch has no more sweeps than the chip
   // has CUs; 8 waves, two per CU, beyond
-  static const int cus = [] {
+  const int cus = [] {  // (of the CURRENT device: a process may drive several)
+    static std::mutex mu;
+    static std::map<int, int> seen;
     int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = seen.find(dev);
+    if (it != seen.end()) return it->second;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    seen[dev] = n;
+    return n;
   }();
   static const int shape_env = [] {
     const char* e = getenv("WFL_CTC_MITM_WAVES");  // 8 / 16: force a shape (measurements)

@@ -35,7 +35,8 @@ void check(int rc, const char* what) { TORCH_CHECK(rc == WFL_OK, what, ": ", wfl
 struct CtcStep : public torch::autograd::Function<CtcStep> {
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& staged, int64_t off_offsets,
                             int64_t off_flat, int64_t off_scale, int64_t off_coef, int64_t max_len, int64_t blank,
-                            const at::Tensor& ws, const at::Tensor& nll, const c10::optional<at::Tensor>& lse) {
+                            const at::Tensor& ws, const at::Tensor& nll, const c10::optional<at::Tensor>& lse,
+                            int64_t n_labels, int64_t host_state) {
     TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous() && x.dim() == 3,
                 "ctc_step: x must be a contiguous float32 [B,T,C] device tensor");
     const auto B = x.size(0), T = x.size(1), C = x.size(2);
@@ -43,13 +44,15 @@ struct CtcStep : public torch::autograd::Function<CtcStep> {
     at::Tensor loss = at::empty({}, x.options());
     const char* base = static_cast<const char*>(staged.data_ptr());
     const float* lse_p = lse.has_value() && lse->defined() ? lse->data_ptr<float>() : nullptr;
-    check(wfl_ctc_forward_backward(x.data_ptr<float>(), (int)B, (int)T, (int)C,
-                                   reinterpret_cast<const int32_t*>(base + off_flat),
-                                   reinterpret_cast<const int64_t*>(base + off_offsets), (int)max_len, (int)blank,
-                                   ws.data_ptr<float>(), nll.data_ptr<float>(),
-                                   reinterpret_cast<const float*>(base + off_coef), nullptr, dx.data_ptr<float>(),
-                                   reinterpret_cast<const float*>(base + off_scale), loss.data_ptr<float>(), lse_p,
-                                   current_stream(x)),
+    // (what the step remembers between calls is the caller's: wfl_ctc_call in include/wfl.h)
+    const wfl_ctc_call call{n_labels, reinterpret_cast<int32_t*>(host_state)};
+    check(wfl_ctc_forward_backward_call(x.data_ptr<float>(), (int)B, (int)T, (int)C,
+                                        reinterpret_cast<const int32_t*>(base + off_flat),
+                                        reinterpret_cast<const int64_t*>(base + off_offsets), (int)max_len, (int)blank,
+                                        ws.data_ptr<float>(), nll.data_ptr<float>(),
+                                        reinterpret_cast<const float*>(base + off_coef), nullptr, dx.data_ptr<float>(),
+                                        reinterpret_cast<const float*>(base + off_scale), loss.data_ptr<float>(), lse_p,
+                                        &call, current_stream(x)),
           "ctc_step");
     ctx->saved_data["x"] = x.detach();
     ctx->saved_data["staged"] = staged;
@@ -57,7 +60,7 @@ struct CtcStep : public torch::autograd::Function<CtcStep> {
     ctx->saved_data["nll"] = nll;
     ctx->saved_data["dx"] = dx;
     if (lse_p) ctx->saved_data["lse"] = *lse;
-    ctx->saved_data["ints"] = std::vector<int64_t>{off_offsets, off_flat, off_coef, max_len, blank};
+    ctx->saved_data["ints"] = std::vector<int64_t>{off_offsets, off_flat, off_coef, max_len, blank, n_labels};
     return loss;
   }
 
@@ -69,7 +72,7 @@ struct CtcStep : public torch::autograd::Function<CtcStep> {
     at::Tensor x = ctx->saved_data["x"].toTensor();
     if (!grads[0].defined())  // (the loss did not take part in what is being differentiated)
       return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-              at::Tensor(), at::Tensor(), at::Tensor()};
+              at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     at::Tensor g = grads[0].detach().reshape({1});
     if (!g.is_cuda() || g.scalar_type() != at::kFloat) g = g.to(x.device(), at::kFloat);
     auto it = ctx->saved_data.find("dx");
@@ -88,16 +91,17 @@ struct CtcStep : public torch::autograd::Function<CtcStep> {
       auto l = ctx->saved_data.find("lse");
       const float* lse_p = l != ctx->saved_data.end() ? l->second.toTensor().data_ptr<float>() : nullptr;
       dx = at::empty_like(x);
-      check(wfl_ctc_forward_backward(x.data_ptr<float>(), (int)x.size(0), (int)x.size(1), (int)x.size(2),
-                                     reinterpret_cast<const int32_t*>(base + v[1]),
-                                     reinterpret_cast<const int64_t*>(base + v[0]), (int)v[3], (int)v[4],
-                                     ws.data_ptr<float>(), nll.data_ptr<float>(),
-                                     reinterpret_cast<const float*>(base + v[2]), g.data_ptr<float>(),
-                                     dx.data_ptr<float>(), nullptr, nullptr, lse_p, current_stream(x)),
+      const wfl_ctc_call call{v[5], nullptr};  // (a recomputation: not a step whose outcome is to be remembered)
+      check(wfl_ctc_forward_backward_call(x.data_ptr<float>(), (int)x.size(0), (int)x.size(1), (int)x.size(2),
+                                          reinterpret_cast<const int32_t*>(base + v[1]),
+                                          reinterpret_cast<const int64_t*>(base + v[0]), (int)v[3], (int)v[4],
+                                          ws.data_ptr<float>(), nll.data_ptr<float>(),
+                                          reinterpret_cast<const float*>(base + v[2]), g.data_ptr<float>(),
+                                          dx.data_ptr<float>(), nullptr, nullptr, lse_p, &call, current_stream(x)),
             "ctc_step backward");
     }
     return {dx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-            at::Tensor(), at::Tensor(), at::Tensor()};
+            at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
@@ -327,6 +331,48 @@ struct WsKey {
 };
 std::map<WsKey, std::pair<at::Tensor, at::Tensor>> g_ws;  // (engine.ctc_workspace: scratch + nll per stream and shape)
 
+// The step's memory between calls (wfl_ctc_call::host_state: two pinned int32 per stream and shape, written by the
+// repair launch without anybody waiting).  Handed out from pinned pages that are never freed: a launch still in flight
+// may write its word whatever happens to the workspace cache above.
+struct HostStatePool {
+  static constexpr size_t kWords = 1024;
+  std::mutex mu;
+  std::map<WsKey, int32_t*> table;
+  std::vector<int32_t*> pages;
+  size_t used = kWords;
+};
+HostStatePool& host_state_pool() {
+  static auto* p = new HostStatePool();  // (never destroyed: see above)
+  return *p;
+}
+int32_t* ctc_host_state(const WsKey& k) {
+  HostStatePool& P = host_state_pool();
+  std::lock_guard<std::mutex> lock(P.mu);
+  auto it = P.table.find(k);
+  if (it != P.table.end()) return it->second;
+  // (a stream that is being captured into a graph: no allocation, no memory -- the captured step replays one choice)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)k.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  if (P.used + 2 > HostStatePool::kWords) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, HostStatePool::kWords * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return nullptr;
+    memset(p, 0, HostStatePool::kWords * sizeof(int32_t));
+    P.pages.push_back(static_cast<int32_t*>(p));
+    P.used = 0;
+  }
+  int32_t* w = P.pages.back() + P.used;
+  P.used += 2;
+  P.table[k] = w;
+  return w;
+}
+// forget what the steps remembered: the next call of every shape starts with the lane-exponent step (tests that run
+// unrelated data through one shape)
+void ctc_reset_host_state() {
+  HostStatePool& P = host_state_pool();
+  std::lock_guard<std::mutex> lock(P.mu);
+  for (int32_t* page : P.pages) memset(page, 0, HostStatePool::kWords * sizeof(int32_t));
+}
+
 // CTCLoss(log_probs, targets, blank, reduction) for the hot case, everything between the Python call and the launch
 // in this one function.  Returns None when the case is not the hot one (the caller takes the Python path).
 py::object ctc_loss_staged(const at::Tensor& x, const std::shared_ptr<StagedTargets>& st, int64_t blank, bool mean,
@@ -358,7 +404,7 @@ py::object ctc_loss_staged(const at::Tensor& x, const std::shared_ptr<StagedTarg
   }
   const int64_t fac = st->off_fac + 4 * B * (mean ? 1 : 0);  // scale_<reduction>; cneg_<reduction> is 4 arrays on
   return py::cast(CtcStep::apply(x, st->dev_buf, 0, st->off_flat, fac, fac + 16 * B, st->max_len, blank, w->second.first,
-                                 w->second.second, lse));
+                                 w->second.second, lse, st->n, reinterpret_cast<int64_t>(ctc_host_state(wk))));
 }
 
 // CTCLoss(log_probs, targets, blank, reduction) for the hot case, everything between the Python call and the launch
@@ -374,8 +420,9 @@ std::shared_ptr<StagedTargets> stage_lists(const py::handle& targets, const at::
 
 at::Tensor ctc_step(const at::Tensor& x, const at::Tensor& staged, int64_t off_offsets, int64_t off_flat,
                     int64_t off_scale, int64_t off_coef, int64_t max_len, int64_t blank, const at::Tensor& ws,
-                    const at::Tensor& nll, const c10::optional<at::Tensor>& lse) {
-  return CtcStep::apply(x, staged, off_offsets, off_flat, off_scale, off_coef, max_len, blank, ws, nll, lse);
+                    const at::Tensor& nll, const c10::optional<at::Tensor>& lse, int64_t n_labels, int64_t host_state) {
+  return CtcStep::apply(x, staged, off_offsets, off_flat, off_scale, off_coef, max_len, blank, ws, nll, lse, n_labels,
+                        host_state);
 }
 
 // `loss.backward()` for the loss a CtcStep node returned, WITHOUT the autograd engine: the gradient was computed by
@@ -421,6 +468,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ctc_fast_backward", &ctc_fast_backward,
         "loss.backward() of a CtcStep loss without the autograd engine (false: not the plain case, use the engine)");
   m.def("ctc_step", &ctc_step, "CTC loss + eager gradient in one pipelined launch (C++ autograd node)");
+  m.def("ctc_reset_host_state", &ctc_reset_host_state, "zero the steps' memory of which launch to start with");
   py::class_<StagedTargets, std::shared_ptr<StagedTargets>>(m, "StagedTargets")
       .def_readonly("B", &StagedTargets::B)
       .def_readonly("n", &StagedTargets::n)

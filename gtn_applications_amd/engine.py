@@ -928,6 +928,38 @@ def ctc_workspace(x, max_len):
     return hit
 
 
+_CTC_STATE = {}
+
+
+def ctc_host_state(x, max_len):
+    """The CTC step's memory between calls (`wfl_ctc_call.host_state`, include/wfl.h): two int32 of pinned host memory
+    per (device, stream, shape) -- the repair launch leaves there how many utterances it recomputed, the next call of
+    the shape reads it (no synchronisation) and picks its launch.  Owned here, by the caller of the C ABI: never
+    freed while a launch may still write it, zeroed by ctc_reset_state().  Returns (pinned tensor, CtcCall struct)."""
+    B, T, C = x.shape
+    idx = x.device.index
+    key = (idx, torch._C._cuda_getCurrentRawStream(idx), B, T, C, max_len)
+    hit = _CTC_STATE.get(key)
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing():
+            # (a step captured into a graph replays ONE choice and must not allocate: no memory, lane-exponent step first)
+            return None, N.CtcCall(0, None)
+        words = torch.zeros(2, dtype=torch.int32).pin_memory()
+        hit = _CTC_STATE[key] = (words, N.CtcCall(0, words.data_ptr()))
+    return hit
+
+
+def ctc_reset_state():
+    """Forget which launch the CTC steps preferred (tests that run unrelated data through one shape)."""
+    for words, _ in _CTC_STATE.values():
+        words.zero_()
+    try:
+        from . import _wfl_torch
+    except ImportError:
+        return
+    _wfl_torch.ctc_reset_host_state()
+
+
 def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_loss=False, lse=None, shared_ws=False):
     """Loss and gradient in one pipelined launch (wfl_ctc_forward_backward): returns (ws, nll) or,
     with want_loss, (ws, nll, mean_b(loss_scale[b] * nll[b]) as a 0-dim device tensor).  `coef` / `loss_scale`
@@ -946,10 +978,12 @@ def ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=None, want_los
         nll = torch.empty(B, dtype=_F32, device=x.device)
     loss = torch.empty((), dtype=_F32, device=x.device) if want_loss else None
     tok = _mark("ctc_step")
+    words, call = ctc_host_state(x, tg.max_len)
+    call.n_labels = tg.n
     N.check(
-        N.lib.wfl_ctc_forward_backward(ptr(x), B, T, C, ptr(tg.addr("flat")), ptr(tg.addr("offsets")), tg.max_len, blank,
-                                       ptr(ws), ptr(nll), ptr(coef), ptr(gout), ptr(dx), ptr(loss_scale), ptr(loss),
-                                       ptr(lse), stream_ptr())
+        N.lib.wfl_ctc_forward_backward_call(ptr(x), B, T, C, ptr(tg.addr("flat")), ptr(tg.addr("offsets")), tg.max_len,
+                                            blank, ptr(ws), ptr(nll), ptr(coef), ptr(gout), ptr(dx), ptr(loss_scale),
+                                            ptr(loss), ptr(lse), ctypes.byref(call), stream_ptr())
     )
     _done(tok)
     return (ws, nll, loss) if want_loss else (ws, nll)

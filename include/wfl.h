@@ -13,7 +13,10 @@
  *   - device entry points take caller-owned DEVICE buffers and a hipStream_t (passed as void*),
  *     enqueue work asynchronously and never synchronise, allocate or free device memory;
  *   - host graph entry points (wfl_graph_*) work on opaque handles and never touch the GPU;
- *   - no hidden global state: re-entrant from several host threads (autograd worker threads).
+ *   - no hidden global state: re-entrant from several host threads (autograd worker threads).  What a step remembers
+ *     between calls (the CTC step's choice of launch) lives in memory the caller hands in (wfl_ctc_call); the gradient
+ *     beside the lattice sweeps keeps process-wide COUNTERS of whether kernels of two streams overlap on this stack
+ *     (wfl_lattice_diagnostics) -- they pick between two launch plans with identical results.
  *
  * Emissions are always float32 [B, T, C] row-major ("the emissions graph": gtn.linear_graph +
  * set_weights, ctc.py:40-44, asg.py:96-100, stc.py:74-78, transducer.py:262-264 -- here the
@@ -373,10 +376,23 @@ int wfl_ctc_workspace_field(int B, int T, int max_len, int field, int64_t* offse
 int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
                     const int64_t* offsets, int max_len, int blank, int flags, float* ws, float* nll,
                     void* stream);
-/* The adaptive choice between the lane-exponent step and the log-domain step (see
- * wfl_ctc_forward_backward) remembers, per workspace ADDRESS, how many utterances the last
- * lane-exponent step had to repair.  This forgets it: the next call tries the lane-exponent step. */
-void wfl_ctc_adaptive_reset(void);
+/* Per-call extras of wfl_ctc_forward_backward_call -- everything the step remembers or assumes beyond its arguments
+ * is the CALLER's:
+ *   n_labels    the number of labels behind `targets` the caller vouches for (= offsets[B] as the host knows it; 0:
+ *               unknown).  With it a workgroup asks for its labels together with its offsets (one memory round trip at
+ *               kernel entry instead of two) under the guess that every target has max_len labels -- true for bucketed
+ *               batches and the benchmark's; a ragged batch asks again, results are the same.
+ *   host_state  2 x int32 of PINNED host memory (hipHostMalloc / a pin_memory tensor), zeroed by the caller once, one per
+ *               criterion / workspace and never shared between concurrent calls -- or NULL.  [0] is written by the
+ *               repair launch (how many utterances of the last lane-exponent step it recomputed; system scope, nobody
+ *               waits for it), [1] is the step's own counter.  When the LAST lane-exponent step recomputed more than an
+ *               eighth of its utterances the call goes straight to the log-domain step, and every 16th such call tries
+ *               the lane-exponent step again.  NULL: every call starts with the lane-exponent step.  Results are within
+ *               the parity bar on either path (bit-identical only on the same path); zero the words to forget. */
+typedef struct wfl_ctc_call {
+  int64_t n_labels;
+  int32_t* host_state;
+} wfl_ctc_call;
 
 /* wfl_ctc_forward and wfl_ctc_grad as ONE pipelined launch: gradient waves wait for the checkpoints
  * they need and run while the chains are still sweeping.  Same outputs (nll, dx); posteriors are
@@ -395,6 +411,12 @@ int wfl_ctc_forward_backward(const float* x, int B, int T, int C, const int32_t*
                              const int64_t* offsets, int max_len, int blank, float* ws, float* nll,
                              const float* coef, const float* gout, float* dx, const float* loss_scale,
                              float* loss_out, const float* row_lse, void* stream);
+/* wfl_ctc_forward_backward with the per-call extras above (call may be NULL: the same as the function above, which
+ * keeps no memory between calls) */
+int wfl_ctc_forward_backward_call(const float* x, int B, int T, int C, const int32_t* targets,
+                                  const int64_t* offsets, int max_len, int blank, float* ws, float* nll,
+                                  const float* coef, const float* gout, float* dx, const float* loss_scale,
+                                  float* loss_out, const float* row_lse, const wfl_ctc_call* call, void* stream);
 /* out[r] = logsumexp_c x[r*C + c] for r < rows (NaN counts as -inf) */
 int wfl_row_lse(const float* x, int64_t rows, int C, float* out, void* stream);
 /* out[r] = the first c with x[r*C + c] == max_c x[r*C + c] (NaN counts as -inf; a row without a finite score: 0) --

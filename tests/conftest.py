@@ -19,13 +19,14 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def _fresh_ctc_step_choice():
-    """The CTC step remembers, per workspace ADDRESS, whether the last lane-exponent step had to repair many utterances
-    (and then runs the log-domain step for a while).  Tests hand recycled addresses to unrelated data: every test starts
-    from scratch, so that what it compares bit for bit ran on the path it means."""
+    """The CTC step remembers, per (device, stream, shape), whether the last lane-exponent step had to repair many
+    utterances (and then runs the log-domain step for a while) -- in two pinned words the CALLER of the C ABI owns
+    (engine.ctc_host_state / the C++ operator's pool; wfl_ctc_call in include/wfl.h).  Tests run unrelated data through
+    the same shapes: every test starts from scratch, so that what it compares bit for bit ran on the path it means."""
     try:
-        from gtn_applications_amd import _native as N
+        from gtn_applications_amd import engine as E
 
-        N.lib.wfl_ctc_adaptive_reset()
+        E.ctc_reset_state()
     except Exception:  # (collection on a machine without the library: the tests themselves will say so)
         pass
     yield
