@@ -560,9 +560,12 @@ def main():
         sum_ms = float(sum(phase_ms.values()))
         # groups on forked streams overlap (ASG: numerator under the denominator's sweeps; Transducer: the gradient
         # beside the sweeps): their sum exceeds the step.  The step's GPU time is then bounded by its wall time.
-        gpu_ms = min(sum_ms, ms) if args.mode == "api" else sum_ms
-        basis = "wall time of the step (its kernel groups overlap on forked streams: their sum is larger)" if gpu_ms < sum_ms else \
-                "sum of the step's kernel groups (HIP events)"
+        forked = args.workload in ("asg", "transducer")
+        gpu_ms = ms if forked else (min(sum_ms, ms) if args.mode == "api" else sum_ms)
+        basis = ("wall time of the step (its kernel groups run on forked streams and overlap: neither their sum nor any one "
+                 "of them is the step)" if forked else
+                 "wall time of the step (smaller than the sum of its bracketed kernel groups: the brackets cost)" if gpu_ms < sum_ms
+                 else "sum of the step's kernel groups (HIP events)")
         step_achieved = alg_bytes / (gpu_ms * 1e-3) / 1e9
         dom_achieved = alg_bytes / (phase_ms[dom] * 1e-3) / 1e9
         out["roofline"] = {

@@ -107,6 +107,31 @@ __global__ void __launch_bounds__(1024, 1) k(int NB, int L, float* out, long lon
     pb = Pq.x;
     pl = Pq.y;
   };
+  // four instructions per frame: (pb, pl + pb) by one packed fma with the constant pair (0, 1), the two DPP
+  // multiply-adds with the block's g / gs, ONE packed multiply by the frame's factors -- no F * G product
+#define WFL_FRAME4(F, NOP)                                                              \
+  "v_pk_fma_f32 v[4:5], v[2:3], %[C01], v[2:3] op_sel_hi:[0,1,1]\n\t" NOP              \
+  "v_fmac_f32_dpp v4, v3, %[Gx] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"             \
+  "v_fmac_f32_dpp v5, v3, %[Gy] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"             \
+  "v_pk_mul_f32 v[2:3], v[4:5], " F "\n\t"
+  auto frames4b = [&](const float2& f0, const float2& f1, const float2& f2, const float2& f3) {
+    v2f Pq = {pb, pl};
+    const v2f C01 = {0.f, 1.f};
+    const v2f F0 = {f0.x, f0.y}, F1 = {f1.x, f1.y}, F2 = {f2.x, f2.y}, F3 = {f3.x, f3.y};
+    if (MODE & 512)
+      asm volatile(WFL_FRAME4("%[F0]", "") WFL_FRAME4("%[F1]", "") WFL_FRAME4("%[F2]", "") WFL_FRAME4("%[F3]", "")
+                   : "+{v[2:3]}"(Pq)
+                   : [C01] "v"(C01), [Gx] "v"(g), [Gy] "v"(gs), [F0] "v"(F0), [F1] "v"(F1), [F2] "v"(F2), [F3] "v"(F3)
+                   : "v4", "v5");
+    else
+      asm volatile(WFL_FRAME4("%[F0]", "s_nop 0\n\t") WFL_FRAME4("%[F1]", "s_nop 0\n\t") WFL_FRAME4("%[F2]", "s_nop 0\n\t")
+                   WFL_FRAME4("%[F3]", "s_nop 0\n\t")
+                   : "+{v[2:3]}"(Pq)
+                   : [C01] "v"(C01), [Gx] "v"(g), [Gy] "v"(gs), [F0] "v"(F0), [F1] "v"(F1), [F2] "v"(F2), [F3] "v"(F3)
+                   : "v4", "v5");
+    pb = Pq.x;
+    pl = Pq.y;
+  };
   float2 fa[kBlk], fz[kBlk];
 #pragma unroll
   for (int j = 0; j < kBlk; ++j) fa[j] = S.ring[0][j][lane], fz[j] = S.ring[1][j][lane];
@@ -134,7 +159,10 @@ __global__ void __launch_bounds__(1024, 1) k(int NB, int L, float* out, long lon
       lds_post(&S.chainpos, kk + 2);
     }
     s0 = s1, s1 = s2, s2 = s2 + 1 == kSlots ? 0 : s2 + 1;
-    if (MODE & 8) {
+    if ((MODE & 8) && (MODE & 256)) {
+#pragma unroll
+      for (int j = 0; j < kBlk; j += 4) frames4b(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
+    } else if (MODE & 8) {
 #pragma unroll
       for (int j = 0; j < kBlk; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
     } else {
@@ -415,6 +443,16 @@ void runp(const char* what) {
 }
 
 int main() {
+  if (getenv("FRAME_ONLY")) {
+    for (int waves : {1, 16}) {
+      run<8>("frames only, five instructions", waves);
+      run<8 + 256>("frames only, four instructions + s_nop 0", waves);
+      run<8 + 256 + 512>("frames only, four instructions, NO nop (hazard: timing only)", waves);
+      run<31>("full block, five-instruction frames", waves);
+      run<31 + 256>("full block, four-instruction frames + s_nop 0", waves);
+    }
+    return 0;
+  }
   if (getenv("PIPE_ONLY") == nullptr) {
   for (int waves : {1, 16}) {
     run<31>("full block (renorm, reads, ck, frames, flag)", waves);
