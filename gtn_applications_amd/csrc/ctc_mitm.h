@@ -42,9 +42,6 @@
 #ifndef WFL_MITM_STORE
 #define WFL_MITM_STORE 2  // gradient row stores: 0 plain, 1 non-temporal, 2 sc0 sc1, 3 sc1, 4 sc0 sc1 nt (scratch A/B)
 #endif
-#ifndef WFL_MITM_EMIT4
-#define WFL_MITM_EMIT4 1  // 0: the emitters redo the own sweep with the five-instruction frame
-#endif
 #ifndef WFL_MITM_STATS
 #define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
 #endif
@@ -225,19 +222,12 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
 #pragma unroll
   for (int j = 0; j < kBlk; ++j) {
     if (FULL || j < cnt) {
-#if WFL_MITM_EMIT4
-      // (the chain wave's four-instruction frame: (pb, pl + pb) += (g, gs) q, then one packed multiply by the factors)
-      float ux = sa.x, uy = sa.y + sa.x;
-      fmac2_shr1(ux, uy, sa.y, G.x, G.y);
-      sa = mv2f{ux, uy} * F[j];
-#else
       const mv2f t = F[j] * G;
       const mv2f o = F[j] * mv2f{sa.x, sa.x};
       float ox = o.x, oy = o.y;
       fmac2_shr1(ox, oy, sa.y, t.x, t.y);
       oy = fmaf(F[j].y, sa.y, oy);
       sa = mv2f{ox, oy};
-#endif
     }
     pa[j] = sa;
   }
@@ -991,32 +981,6 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       pb = t0;
     };
     typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef WFL_MITM_FRAME4
-#define WFL_MITM_FRAME4 1  // 0: the five-instruction frame of ctc_fast_chain_body (F * G formed per frame)
-#endif
-#if WFL_MITM_FRAME4
-    // FOUR instructions per frame:  (pb, pl + pb)  by one packed fma with the constant pair (0, 1);  pb += g q  and
-    // (pl + pb) += gs q  by the two DPP multiply-adds (q = the label state of lane i - 1, g / gs fixed for the block);
-    // ONE packed multiply by the frame's factors (fb, fl).  The same recursion as WFL_FRAME's
-    // fb pb + (fb g) q,  fl (pl + pb) + (fl gs) q  without the product F * G per frame.  (s_nop 0: the DPP read of v3
-    // needs two wait states behind the packed multiply that wrote it; the packed fma is the other one.)
-#define WFL_FRAME_4I(F)                                                        \
-  "v_pk_fma_f32 v[4:5], v[2:3], %[C01], v[2:3] op_sel_hi:[0,1,1]\n\ts_nop 0\n\t" \
-  "v_fmac_f32_dpp v4, v3, %[Gx] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"      \
-  "v_fmac_f32_dpp v5, v3, %[Gy] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"      \
-  "v_pk_mul_f32 v[2:3], v[4:5], " F "\n\t"
-    const v2f C01 = {0.f, 1.f};
-    auto frames4 = [&](const float2& f0, const float2& f1, const float2& f2, const float2& f3) {
-      v2f Pq = {pb, pl};
-      const v2f F0 = {f0.x, f0.y}, F1 = {f1.x, f1.y}, F2 = {f2.x, f2.y}, F3 = {f3.x, f3.y};
-      asm volatile(WFL_FRAME_4I("%[F0]") WFL_FRAME_4I("%[F1]") WFL_FRAME_4I("%[F2]") WFL_FRAME_4I("%[F3]")
-                   : "+{v[2:3]}"(Pq)
-                   : [C01] "v"(C01), [Gx] "v"(g), [Gy] "v"(gs), [F0] "v"(F0), [F1] "v"(F1), [F2] "v"(F2), [F3] "v"(F3)
-                   : "v4", "v5");
-      pb = Pq.x;
-      pl = Pq.y;
-    };
-#else
     auto frames4 = [&](const float2& f0, const float2& f1, const float2& f2, const float2& f3) {
       v2f Pq = {pb, pl};
       const v2f G = {g, gs};
@@ -1032,7 +996,6 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       pb = Pq.x;
       pl = Pq.y;
     };
-#endif
     // The factors travel ring -> registers a WHOLE block ahead (two sets of 16 float2, alternating): the reads of
     // block kk + 1 are issued before the renormalisation and the 16 frames of block kk, so that no LDS round trip
     // is ever waited for on the dependent path.
