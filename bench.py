@@ -99,8 +99,6 @@ def parse():
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--C", type=int, default=None)
     ap.add_argument("--L", type=int, default=44)
-    ap.add_argument("--ctc-chain", default="default", choices=["default", "log", "fast"],
-                    help="CTC chain kernel of the split abi step: library default, log-domain, or lane-exponent + certificate")
     ap.add_argument("--ctc-step", default="pipelined", choices=["split", "pipelined"],
                     help="abi CTC step: forward and gradient kernels back to back, or one pipelined launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,7 +205,7 @@ def make_ctc(args, rank, n_batches, dist=None):
     scale, _, coef = E.loss_factors(tg, "none")
     gout = torch.ones(1, device=dev)
     dx = torch.empty_like(x)
-    chain_flags = {"default": E.CTC_DEFAULT_FLAGS, "log": 0, "fast": N.CTC_FAST_CHAIN}[args.ctc_chain]
+    chain_flags = E.CTC_DEFAULT_FLAGS
     last = [None]
     if args.ctc_step == "pipelined":
         def abi_step(i):

@@ -15,7 +15,6 @@ WFL_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 1, 2, 3
 EPSILON = -1
 SEMIRING_LOG, SEMIRING_TROPICAL = 0, 1
-CTC_FAST_CHAIN = 2
 CTC_WS_REJECTED, CTC_WS_STATUS, CTC_WS_LOG2Z, CTC_WS_ZRANGE = 0, 1, 2, 3
 CONV_SPIKE, CONV_BLANK_OPTIONAL = 1, 2
 

@@ -30,13 +30,15 @@
 // drifting to O(T) (plain fp32 log-domain, which is what gtn.forward_score does, already loses the
 // 4th digit of the posteriors at T = 1000).
 //
-// Kernels.  The training step (wfl_ctc_forward_backward) is ctc_fast_pipelined_kernel: chains and gradient in
-// ONE launch, the gradient waves waiting on device-coherent per-block flags while the chains sweep; its chains
-// and gradient blocks run in lane-exponent (probability-domain) arithmetic, every block certifies what it
-// computed, and ctc_repair_kernel re-runs rejected utterances with the log-domain bodies.  ctc_pipelined_kernel
-// is the same single launch with the log-domain bodies throughout (WFL_CTC_PIPELINE=log, long targets).
-// ctc_log_chain_kernel + ctc_grad_kernel (+ wfl_reduce_loss) are the three-launch step behind
-// wfl_ctc_forward / wfl_ctc_grad; WFL_CTC_FAST_CHAIN selects ctc_fast_chain_kernel + ctc_certify_kernel there.
+// Kernels.  The training step (wfl_ctc_forward_backward) is ctc_mitm_kernel (ctc_mitm.h: the sweeps emit the gradient)
+// for targets of up to 63 labels, with ctc_fast_pipelined_kernel (chains + recomputing gradient waves in one launch)
+// behind it for the fused log_softmax criterion on rows wider than 128 classes; both run in lane-exponent
+// (probability-domain) arithmetic, every block certifies what it computed, and ctc_repair_kernel re-runs rejected
+// utterances with the log-domain bodies.  ctc_pipelined_kernel is the single launch with the log-domain bodies
+// throughout (WFL_CTC_PIPELINE=log, a step whose predecessor was mostly repaired), ctc_long_pipelined_kernel the one
+// for targets of 64-255 labels.  ctc_log_chain_kernel + ctc_grad_kernel (+ wfl_reduce_loss) are the forward-only /
+// three-launch path behind wfl_ctc_forward / wfl_ctc_grad.  (Retired in round 4: the standalone lane-exponent chain
+// launch with its certify kernel -- WFL_CTC_FAST_CHAIN -- and the dbg_* kernels.)
 #include <atomic>
 #include <string>
 #include <type_traits>
@@ -465,8 +467,8 @@ __global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST chains ("lane-exponent" arithmetic): the chains of ctc_fast_pipelined_kernel, and (grid (B, 2) x 512,
-// WFL_CTC_FAST_CHAIN) of the three-launch step.
+// FAST chains ("lane-exponent" arithmetic): the chains of ctc_fast_pipelined_kernel (ctc_mitm.h's chain wave runs the
+// same frame).
 //
 // The log-domain frame is a chain of ~15 DEPENDENT instructions with 4 transcendentals (~155 cycles
 // for a lone wave).  Here a state is a float mantissa with an integer exponent PER LANE (shared by
@@ -493,11 +495,9 @@ __global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_
 // order, so "data, then flag" needs no wait).  Measured at cfg2: 33.5 us for the sweep (grid (B, 2))
 // against 68 us for the log-domain chain; inside the pipelined launch 36-39 us.
 //
-// What cannot be represented is flushed to zero or overflows; the results are certified.  Three-launch
-// step: ctc_certify_kernel checks, at every 16-frame boundary, that the two independently computed sweeps
-// reproduce Z (|log2 sum_s alpha*beta~ - log2 Z| < 1.5e-3), rejected utterances are recomputed by
-// ctc_log_chain_kernel in the same forward call.  Pipelined step: every gradient block reproduces log2 Z and
-// checks that the posteriors of its frames sum to one (ctc_fast_grad_body); ctc_repair_kernel evaluates.
+// What cannot be represented is flushed to zero or overflows; the results are certified: every gradient block
+// reproduces log2 Z and checks that the posteriors of its frames sum to one (ctc_fast_grad_body, ctc_mitm_emit_block);
+// ctc_repair_kernel evaluates.
 // Checkpoints have the SAME format as the log-domain chain's (base-2 logs relative to a double offset), so
 // the gradient kernels do not care which chain produced them.
 // ------------------------------------------------------------------------------------------------
@@ -959,52 +959,6 @@ __device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int
     return;
   }
   __syncthreads();
-}
-
-__global__ void __launch_bounds__(kFWaves * 64) ctc_fast_chain_kernel(CtcArgs a) {
-  __shared__ FastLdsT S;
-  ctc_fast_chain_body<false>(a, blockIdx.x, blockIdx.y, S);
-}
-
-// certificate: one wave per (utterance, interior 16-frame boundary); 4 waves per workgroup
-__global__ void __launch_bounds__(256) ctc_certify_kernel(CtcArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int T = a.T, P = a.P;
-  const int NB = ctc_blocks(T);
-  const int per = max(NB - 1, 1);
-  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-  if (item >= (int64_t)a.B * per) return;
-  const int b = (int)(item / per), k = (int)(item % per) + 1;
-  const CtcWs w = ctc_ws_layout(a.B, T, P);
-  int32_t* flag = (int32_t*)(a.ws + w.flag) + b;
-  const double z2 = ((const double*)(a.ws + w.z2))[b];
-  if (k == 1) {
-    const int32_t* pbad = (const int32_t*)(a.ws + w.pbad) + b * 2;
-    if (lane == 0 && (!(z2 > -1.0e299) || pbad[0] != 0 || pbad[1] != 0)) atomicOr(flag, 1);
-  }
-  if (k >= NB || !(z2 > -1.0e299)) return;
-  const int64_t o0 = a.offsets[b];
-  const int L = (int)(a.offsets[b + 1] - o0);
-  const int y = lane < L ? a.targets[o0 + lane] : -1;
-  const int ynext = lane + 1 < L ? a.targets[o0 + lane + 1] : -1;
-  const bool skipn = lane + 1 < L && ynext != y;
-  const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
-  const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
-  const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
-  const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
-  // boundary k (between frames 16k-1 and 16k): alpha checkpoint k = state after frame 16k-1; the beta
-  // checkpoint taken before beta processed block k-1 (processing index NB-k) = full beta of frame 16k.
-  const float2 al = lane < P ? cka[(int64_t)k * P + lane] : make_float2(kNegBig, kNegBig);
-  const float bb = lane <= L ? ckb[(int64_t)(NB - k) * P + (L - lane)].x : kNegBig;
-  const float bl = lane < L ? ckb[(int64_t)(NB - k) * P + (L - 1 - lane)].y : kNegBig;
-  const float tb = lse2_b2(bb, bl);
-  const float tbn = wave_shl1(tb, kNegBig), bbn = wave_shl1(bb, kNegBig);
-  const float tl = lse2_b2(bl, skipn ? tbn : bbn);
-  const float u = al.x + tb, v = lane < L ? al.y + tl : kNegBig;
-  const float m = wave_all_max(fmaxf(u, v));
-  const float ssum = wave_all_sum(__builtin_amdgcn_exp2f(u - m) + __builtin_amdgcn_exp2f(v - m));
-  const double dev = (double)m + (double)__builtin_amdgcn_logf(ssum) + offa[k] + offb[NB - k] - z2;
-  if (lane == 0 && !(fabs(dev) < 1.5e-3)) atomicOr(flag, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1781,17 +1735,6 @@ __global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_
   }
 }
 
-#ifdef WFL_DBG_GRADONLY  // (register counts of the two halves alone: hipcc -S -DWFL_DBG_GRADONLY)
-__global__ void __launch_bounds__(kFWaves * 64) dbg_fast_chain_only(CtcArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  ctc_fast_chain_body<true, false>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, *reinterpret_cast<FastLdsT*>(smem));
-}
-__global__ void __launch_bounds__(kFWaves * 64) dbg_fast_grad_only(CtcArgs a, const float* coef, const float* gout, float* dx) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  FastUtt utt;
-  ctc_fast_grad_body<false, true, false>(a, true, (int)blockIdx.x, (int)blockIdx.y, coef, gout, dx, smem, utt);
-}
-#endif
 
 template <bool LSM, bool COMPACT>
 __global__ void __launch_bounds__(256)
@@ -2478,9 +2421,14 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
     set_error("ctc_forward: null buffer");
     return WFL_ERR_INVALID;
   }
+  if (flags != 0) {
+    set_error("ctc_forward: flags must be 0 (the three-launch lane-exponent step of rounds 1-3 is retired: "
+              "wfl_ctc_forward_backward is the training step)");
+    return WFL_ERR_UNSUPPORTED;
+  }
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll};
   const int ppl = (max_len + 1 + 63) / 64;  // target positions per lane
-  if (ppl > 1) {  // long targets: multi-position lanes, log-domain chain only
+  if (ppl > 1) {  // long targets: multi-position lanes
     const dim3 grid((unsigned)B, 2u);
     if (ppl == 2)
       hipLaunchKernelGGL(ctc_long_chain_kernel<2>, grid, dim3(192), 0, (hipStream_t)stream, a);
@@ -2488,15 +2436,8 @@ int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
       hipLaunchKernelGGL(ctc_long_chain_kernel<3>, grid, dim3(192), 0, (hipStream_t)stream, a);
     else
       hipLaunchKernelGGL(ctc_long_chain_kernel<4>, grid, dim3(192), 0, (hipStream_t)stream, a);
-  } else if (!(flags & WFL_CTC_FAST_CHAIN)) {
-    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 0);
   } else {
-    hipLaunchKernelGGL(ctc_fast_chain_kernel, dim3((unsigned)B, 2u), dim3(kFWaves * 64), 0, (hipStream_t)stream, a);
-    WFL_LAUNCH_CHECK();
-    const int64_t items = (int64_t)B * std::max(ctc_blocks(T) - 1, 1);
-    hipLaunchKernelGGL(ctc_certify_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
-    WFL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 1);
+    hipLaunchKernelGGL(ctc_log_chain_kernel, dim3((unsigned)B, 2u), dim3(192), 0, (hipStream_t)stream, a, 0);
   }
   WFL_LAUNCH_CHECK();
   return WFL_OK;

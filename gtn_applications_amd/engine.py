@@ -865,7 +865,7 @@ def check_labels(tg, C, what):
 def ctc_fast_path_ok(max_len, C):
     """Does the CTC fast path (csrc/ctc_kernels.hip) take this shape?  Otherwise: the generic lattice engine."""
     return max_len <= CTC_FAST_MAX_LEN and C <= (CTC_FAST_MAX_CLASSES if max_len <= 63 else CTC_FAST_MAX_CLASSES_LONG)
-CTC_DEFAULT_FLAGS = 0  # chain kernel used by the criteria (see include/wfl.h, WFL_CTC_FAST_CHAIN)
+CTC_DEFAULT_FLAGS = 0  # (wfl_ctc_forward's flags: must be 0)
 
 
 def ctc_forward(x, tg, blank, flags=None):
@@ -1020,12 +1020,6 @@ def ctc_grad(x, tg, blank, ws, nll, coef, gout, dx):
         N.lib.wfl_ctc_grad(ptr(x), B, T, C, ptr(tg.dev_flat), ptr(tg.dev_offsets), tg.max_len, blank, ptr(ws),
                            ptr(nll), ptr(coef), ptr(gout), ptr(dx), stream_ptr())
     )
-
-
-def ctc_rejected(ws, B, T, max_len):
-    """int32 [B] view of the workspace: 1 where the fast chain's result was rejected by the certificate
-    and the log-domain chain re-ran (three-launch step; tests / diagnostics)."""
-    return ctc_workspace_field(ws, B, T, max_len, N.CTC_WS_REJECTED).view(torch.int32)
 
 
 def loss_factors(tg, reduction, norm_lens=None):

@@ -357,10 +357,9 @@ int wfl_conv_grad(const float* x, int B, int T, int C, const int32_t* ktab, int 
  *   Base-2 log-domain arithmetic, block-renormalised; the chain stores one checkpoint per 16
  *   frames and the gradient kernel recomputes inside the blocks (csrc/ctc_kernels.hip).
  * ------------------------------------------------------------------------------------------------ */
-#define WFL_CTC_FAST_CHAIN 2 /* flags of wfl_ctc_forward: lane-exponent chains + certificate + log-domain repair */
 int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems);
 /* Diagnostics: offset (in floats) and length of a bookkeeping field inside the CTC workspace.
- *   WFL_CTC_WS_REJECTED  int32[B]    three-launch step with WFL_CTC_FAST_CHAIN: 1 = rejected by the certificate
+ *   WFL_CTC_WS_REJECTED  int32[B]    (unused since round 4: the three-launch lane-exponent step is retired; zeros)
  *   WFL_CTC_WS_STATUS    int32[2]    pipelined step: [0] a gradient wave gave up waiting, [1] utterances repaired
  *   WFL_CTC_WS_LOG2Z     double[B]   log2 Z per utterance
  *   WFL_CTC_WS_ZRANGE    int64[B][2] pipelined lane-exponent step: min / max over the blocks of log2 Z * 2^16
@@ -372,7 +371,8 @@ int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems);
 #define WFL_CTC_WS_DEBUG 4
 int wfl_ctc_workspace_field(int B, int T, int max_len, int field, int64_t* offset_elems, int64_t* length_elems);
 /* alpha and beta chains: writes nll[B] = -log Z_b and the 16-frame checkpoints into ws.
- * flags = 0: log-domain chain (default). */
+ * flags must be 0 (the log-domain chain; the lane-exponent variant of this call was retired in round 4 --
+ * wfl_ctc_forward_backward is the training step). */
 int wfl_ctc_forward(const float* x, int B, int T, int C, const int32_t* targets,
                     const int64_t* offsets, int max_len, int blank, int flags, float* ws, float* nll,
                     void* stream);
