@@ -190,6 +190,10 @@ def make_ctc(args, rank, n_batches, dist=None):
         xr.grad = None
         ctc.CTCLoss(xr * 1.0, batches[i % n_batches], blank).backward()
 
+    def engine_view_step(i):
+        xr.grad = None
+        ctc.CTCLoss(xr.view_as(xr), batches[i % n_batches], blank).backward()
+
     # the CTC MODULE (criterions/ctc.py:99-121, use_pt=False): raw scores in, log_softmax fused into the step -- what a
     # training loop calls; reported next to the headline as `module_raw_scores`
     module = ctc.CTC(blank, False)
@@ -232,7 +236,8 @@ def make_ctc(args, rank, n_batches, dist=None):
                 exchange_bytes=0 if exchange is None else exchange.numel() * 4,
                 metric=f"utterances/sec fwd+bwd (ctc_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="CTCLoss(x, targets, blank).backward()", algorithmic_bytes_per_utt=8 * T * C)
-    return dict(step=step, abi_step=abi_step, module_step=module_step, engine_step=engine_step, meta=meta,
+    return dict(step=step, abi_step=abi_step, module_step=module_step, engine_step=engine_step,
+                engine_view_step=engine_view_step, meta=meta,
                 payload=("ctc", x, batches[0], blank))
 
 
@@ -264,13 +269,19 @@ def make_asg(args, rank, n_batches, dist):
         par.grad = None
         asg.ASGLoss(x * 1.0, par, batches[i % n_batches]).backward()
 
+    def engine_view_step(i):
+        x.grad = None
+        par.grad = None
+        asg.ASGLoss(x.view_as(x), par, batches[i % n_batches]).backward()
+
     which = " (BASELINE configs[2])" if (T, C, B, L) == (1000, 100, 128, 44) else ""
     meta = dict(workload=f"asg fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L,
                 key="cfg3" if which else None,
                 metric=f"utterances/sec fwd+bwd (asg_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="ASGLoss(x, transitions, targets).backward()",
                 algorithmic_bytes_per_utt=8 * T * C, algorithmic_bytes_per_batch=8 * (C + 1) * C)
-    return dict(step=step, engine_step=engine_step, meta=meta, payload=("asg", x.detach(), transitions.detach(), batches[0]))
+    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, meta=meta,
+                payload=("asg", x.detach(), transitions.detach(), batches[0]))
 
 
 def word_pieces():
@@ -303,13 +314,18 @@ def make_transducer(args, rank, n_batches):
         x.grad = None
         crit(x * 1.0, batches[i % n_batches]).backward()
 
+    def engine_view_step(i):
+        x.grad = None
+        crit(x.view_as(x), batches[i % n_batches]).backward()
+
     which = " (BASELINE configs[3])" if (T, B) == (800, 64) else ""
     meta = dict(workload=f"transducer fwd+bwd, 1000 word pieces (word_pieces_tokens_1000.txt) T={T} C={C} B={B}{which}",
                 B=B, T=T, C=C, L=Lp, key="cfg4" if which else None,
                 metric=f"utterances/sec fwd+bwd (transducer_benchmark word decompositions T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="Transducer(tokens, ..., blank='optional', allow_repeats=False, reduction='mean')(x, targets).backward()",
                 algorithmic_bytes_per_utt=8 * T * C)
-    return dict(step=step, engine_step=engine_step, meta=meta, payload=("transducer", x.detach(), crit, batches[0]))
+    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, meta=meta,
+                payload=("transducer", x.detach(), crit, batches[0]))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -610,6 +626,13 @@ def main():
             out["same_targets"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
                                    "what": "operator path, one target list reused by every iteration (the reference "
                                            "benchmark scripts' protocol; content-keyed host caches hit)"}
+        if args.mode == "api" and "engine_view_step" in wl:
+            el, _ = timed_loop(lambda i: wl["engine_view_step"](0), extras_steps, 3, fence, False)
+            out["through_autograd_engine_view"] = {
+                "value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
+                "what": "as through_autograd_engine, the non-leaf emissions being a VIEW of the leaf (x.view_as(x): no "
+                        "kernel of its own, forward or backward) -- the autograd engine's share alone, without the two "
+                        "elementwise passes x * 1.0 adds"}
         if args.mode == "api" and "engine_step" in wl:
             el, _ = timed_loop(lambda i: wl["engine_step"](0), extras_steps, 3, fence, False)
             out["through_autograd_engine"] = {

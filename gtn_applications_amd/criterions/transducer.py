@@ -288,6 +288,21 @@ def _dense_bigram(transitions, C):
     return bool(ok)
 
 
+class _UnigramNormaliser:
+    """forward_score(intersect(emissions, transitions)) (transducer.py:286-288) for make_transitions_graph(1, C): one
+    start + accept node with a self-loop per token, so  log Z_b = sum_t logsumexp_c (x[b,t,c] + p_c)."""
+
+    __slots__ = ("xp", "lse", "logz")
+
+    def __init__(self, x, params):
+        self.xp = x + params[:x.shape[2]]
+        self.lse = E.row_lse(self.xp)
+        self.logz = self.lse.sum(dim=1)
+
+    def posteriors(self):
+        return torch.exp(self.xp - self.lse.unsqueeze(2))
+
+
 def _dense_unigram(transitions, C):
     """True iff `transitions` is make_transitions_graph(1, C) (transducer.py:32-58 with ngram = 1): one start + accept
     node with a self-loop per token, arc i labelled i."""
@@ -367,7 +382,12 @@ class TransducerLossFunction(torch.autograd.Function):
         if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288
             # independent of the numerator sweep: forked onto a second stream so that the two overlap
             with E.side_stream(dev) as fork:
-                if _DENSE_NGRAM and _dense_bigram(transitions, C):
+                if _DENSE_NGRAM and _dense_unigram(transitions, C):
+                    # one state, one self-loop per token: the frames are independent and the normaliser is a sum of
+                    # row log-sum-exps of x + p -- no sweep at all
+                    den = _UnigramNormaliser(x, params)
+                    dense = "unigram"
+                elif _DENSE_NGRAM and _dense_bigram(transitions, C):
                     xd, Wd = _bigram_dense_operands(x, params, C)
                     den = E.dense_forward(xd, Wd, need_beta=need_grad)
                     dense = (xd, Wd)
@@ -384,7 +404,9 @@ class TransducerLossFunction(torch.autograd.Function):
         if not num.in_launch:
             dx_early = None
         if den is not None:
-            if dense is not None:
+            if dense == "unigram":
+                fork.join(den.xp, den.lse, den.logz)
+            elif dense is not None:
                 fork.join(dense[0], dense[1], den.alpha, den.beta, den.logz, den.ws)
             else:
                 fork.join(den.xg, den.alpha, den.beta, den.logz)
@@ -420,7 +442,15 @@ class TransducerLossFunction(torch.autograd.Function):
         gout = E.as_device_f32(grad_output.detach().reshape(1), x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.zeros_like(params) if (params is not None and ctx.needs_input_grad[4]) else None
-        if (dx is not None or dW is not None) and dense is not None:
+        if (dx is not None or dW is not None) and dense == "unigram":
+            # posterior of label c in frame t under the unigram model: softmax(x + p), whatever the other frames do
+            post = den.posteriors() * (cpos * gout).view(-1, 1, 1)
+            if dW is not None:
+                dW += post.sum(dim=(0, 1))
+            if dx is not None:
+                dx.copy_(post)
+            E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=True, dW=dW)
+        elif (dx is not None or dW is not None) and dense is not None:
             # the dense normaliser first (its emission gradient alone, for a moment, in dx: the last frame's rows are
             # also the gradient of the end arcs' scores), then the numerator's lattice on top
             xd, Wd = dense

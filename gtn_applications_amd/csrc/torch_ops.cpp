@@ -253,12 +253,15 @@ std::shared_ptr<StagedTargets> stage_targets(const py::handle& targets, const at
     for (Py_ssize_t i = 0; i < n; ++i) {
       long v;
       PyObject* o = it[i];
-      // (exact ints of one 30-bit digit -- every label there is -- without the call: CPython 3.10's long layout)
+#if PY_VERSION_HEX < 0x030C0000
+      // (exact ints of one 30-bit digit -- every label there is -- without the call: the long layout of CPython <= 3.11;
+      // from 3.12 on the digits live under long_value and Py_SIZE is not defined for ints: PyLong_AsLong below)
       if (PyLong_CheckExact(o) && (Py_SIZE(o) == 1 || Py_SIZE(o) == 0)) {
         v = Py_SIZE(o) ? (long)reinterpret_cast<PyLongObject*>(o)->ob_digit[0] : 0;
         put(v);
         continue;
       }
+#endif
       v = PyLong_AsLong(o);
       if (v == -1 && PyErr_Occurred()) {
         PyErr_Clear();
