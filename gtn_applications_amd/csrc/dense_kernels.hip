@@ -1025,6 +1025,191 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
   }
 }
 
+// The same gradient with the outer-product accumulation on the MATRIX cores.  The transition gradient
+//     dW[1+i][j] = P[i][j] * sum_{(b,t)} U[(b,t)][i] A[(b,t)][j]
+// is a matrix product over K = B (T - 1) rows -- the one GEMM-shaped piece of the dense path (the sweeps are
+// matrix-VECTOR products per utterance: nothing for a matrix core).  v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate:
+// exact fp32 FMAs, the vector pipe's peak rate) takes its operands straight from the staged LDS tiles: lane l feeds
+// U[4g + l / 16][16 mi + l % 16] and A[4g + l / 16][16 nj + l % 16] for the k-group g -- rows of consecutive columns,
+// no transpose.  Four waves, a 2 x 2 grid of blocks of up to 4 x 4 tiles each; a wave's accumulators are 4 VGPRs per
+// tile.  Per stage of 16 frames a wave issues <= 64 MFMAs (2048 cycles of its SIMD's matrix pipe) where the 8 x 8
+// register tiles of dense_fast_grad_kernel cost every wave 1024 FMAs (~4400 issue cycles) -- and the vector pipe is
+// free for the staging arithmetic of the next stage meanwhile.  Staging, scales and the emission gradient are those
+// of dense_fast_grad_kernel.  (WFL_DENSE_GRAD_MFMA=0: the vector-pipe kernel.)
+typedef float mfma_v4f __attribute__((ext_vector_type(4)));
+template <int CP, int TS>
+__global__ void __launch_bounds__(256, 2)
+    dense_mfma_grad_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, int B,
+                           const float* __restrict__ alpha, const float* __restrict__ beta, const void* wsp,
+                           const float* __restrict__ coef, const float* __restrict__ coef_w,
+                           const float* __restrict__ gout, int accumulate, const float* __restrict__ addend,
+                           float* __restrict__ dx, float* __restrict__ partial, int rows_per_block) {
+  constexpr int NT = 256, NI = (TS * CP + NT - 1) / NT;
+  constexpr int CPT = (CP + 15) / 16, CPP = CPT * 16, H = (CPT + 1) / 2;  // tiles per side, padded width, tiles per wave side
+  static_assert(TS <= 64 && TS % 4 == 0, "stages are whole k-groups; the scale words come from the first wave");
+  __shared__ __attribute__((aligned(16))) float A[TS][CPP];
+  __shared__ __attribute__((aligned(16))) float U[TS][CPP];
+  __shared__ float sc[2][TS][4];
+  __shared__ float wr2[CPP], s0[CPP];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const DenseWs ws = dense_ws_carve(const_cast<void*>(wsp), B, T);
+  if (ws.flag[2 * b] | ws.flag[2 * b + 1]) return;  // recomputed by the log-domain kernels
+  const float g0 = gout ? gout[0] : 1.f;
+  const float cf = (coef ? coef[b] : 1.f) * g0;
+  const float cw = (coef_w ? coef_w[b] : 1.f) * g0;
+  const double z2 = ws.z2[b];
+  const double *Ma = ws.M + (int64_t)b * 2 * T, *Mb = Ma + T;
+  const int32_t *Ea = ws.E + (int64_t)b * 2 * T, *Eb = Ea + T;
+  const float* mx2 = ws.mx2 + (int64_t)b * T;
+  const int t_begin = blockIdx.x * rows_per_block, t_end = min(T, t_begin + rows_per_block);
+  const int64_t base = (int64_t)b * T * C;
+  for (int i = tid; i < CPP; i += NT) wr2[i] = i < C ? ws.wr2[i] : 0.f, s0[i] = 0.f;
+  if constexpr (CPP > CP)
+    for (int i = tid; i < TS * (CPP - CP); i += NT) {  // the tiles' columns beyond CP: zeros, written once
+      const int r = i / (CPP - CP), c = CP + i % (CPP - CP);
+      A[r][c] = 0.f, U[r][c] = 0.f;
+    }
+  int er[NI], ei[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int idx = tid + k * NT;
+    er[k] = idx / CP, ei[k] = idx - er[k] * CP;
+    if (idx >= TS * CP || ei[k] >= C) er[k] = -1, ei[k] = 0;
+  }
+  // TWO stages in flight (register sets X and Y, used alternately): a stage's loads are issued two stages before they
+  // are consumed -- with one set they flew under ONE stage's products (~2000 cycles of the matrix pipe) and every
+  // stage waited out the rest of an HBM round trip (measured: 5.9 us per stage of 16 frames, two workgroups per CU).
+  struct Stage {
+    float ra[NI], rb[NI], rx[NI], rp[NI], rd[NI], re[NI];
+    double q_ma, q_mb, q_mp;  // lane r < TS: scale words of frame t0 + r (and of the frame before it)
+    int32_t q_ea, q_eb, q_ep;
+    float q_m2;
+  };
+  const float* const ab = alpha + base;
+  const float* const bb = beta + base;
+  const float* const xb = x + base;
+  float* const dxb = dx ? dx + base : nullptr;
+  const float* const prev_dx = (dx && accumulate) ? dx + base : nullptr;
+  const float* const addb = addend ? addend + base : nullptr;
+  auto issue = [&](Stage& S, int t0) {
+    if (tid < TS) {
+      const int t = min(max(t0, 0) + tid, T - 1), tp = max(t - 1, 0);
+      S.q_ma = Ma[t], S.q_ea = Ea[t], S.q_mb = Mb[t], S.q_eb = Eb[t], S.q_m2 = mx2[t], S.q_mp = Ma[tp], S.q_ep = Ea[tp];
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int t = min(t0 + max(er[k], 0), t_end - 1);  // (a stage past the end: the last frame again, never used)
+      const unsigned o = 4u * (__umul24((unsigned)t, (unsigned)C) + (unsigned)ei[k]);
+      S.ra[k] = at_byte(ab, o), S.rb[k] = at_byte(bb, o), S.rx[k] = at_byte(xb, o);
+      S.rp[k] = at_byte(ab, t > 0 ? o - 4u * (unsigned)C : o);
+      if (prev_dx) S.rd[k] = at_byte(prev_dx, o);
+      if (addb) S.re[k] = at_byte(addb, o);
+    }
+  };
+  auto scales = [&](const Stage& S, int t0, int buf) {  // first wave: the stage's per-frame powers of two
+    if (tid < TS) {
+      const int t = t0 + tid;
+      const double lb = S.q_mb + (double)S.q_eb;
+      const float eg = (float)(S.q_ma + (double)S.q_ea + lb - z2);
+      float ex = WFL_NEG_INF;
+      if (t > 0) ex = (float)(S.q_mp + (double)S.q_ep + (double)S.q_m2 + lb - z2);
+      sc[buf][tid][0] = __builtin_amdgcn_exp2f(0.5f * eg);
+      sc[buf][tid][1] = __builtin_amdgcn_exp2f(0.5f * ex);
+      sc[buf][tid][2] = S.q_m2;
+    }
+  };
+  // this wave's block of tiles
+  const int wave = tid >> 6, lane = tid & 63;
+  const int mi0 = (wave >> 1) * H, nj0 = (wave & 1) * H;
+  const int nmi = max(0, min(H, CPT - mi0)), nnj = max(0, min(H, CPT - nj0));  // (wave-uniform)
+  const int lrow = lane >> 4, lcol = lane & 15;
+  mfma_v4f acc[H][H];
+#pragma unroll
+  for (int i = 0; i < H; ++i)
+#pragma unroll
+    for (int j = 0; j < H; ++j) acc[i][j] = mfma_v4f{0.f, 0.f, 0.f, 0.f};
+  // one stage: the staged tiles of frames [t0, t0 + TS) from S's registers, then the products; S is refilled with the
+  // stage two further on (and its scale words computed) while the other set's stage runs
+  auto stage = [&](Stage& S, int t0, int buf) {
+    __syncthreads();  // the previous stage's products are done with A / U; sc[buf] is visible
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      if (er[k] < 0) continue;
+      const int r = er[k], i = ei[k], t = t0 + r;
+      float uu = 0.f, aa = 0.f;
+      if (t < t_end) {
+        const float hg = sc[buf][r][0], hx = sc[buf][r][1];
+        const float g = (S.ra[k] * hg) * (S.rb[k] * hg);
+        if (dxb)
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(dxb) + 4u * (__umul24((unsigned)t, (unsigned)C) + (unsigned)i)) =
+              (prev_dx ? S.rd[k] : 0.f) + (addb ? g0 * S.re[k] : 0.f) + cf * g;
+        if (partial) {
+          if (t > 0) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(nan_to_neg(S.rx[k]), kLog2e, wr2[i]) - sc[buf][r][2]);
+            uu = e * S.rb[k] * hx * cw;
+            aa = S.rp[k] * hx;
+          } else {
+            s0[i] = g * cw;
+          }
+        }
+      }
+      U[r][i] = uu, A[r][i] = aa;  // (rows beyond the stage's last frame: zeros -- they take part in the products)
+    }
+    __syncthreads();
+    issue(S, t0 + 2 * TS);  // in flight during this stage's products AND the whole next stage
+    if (partial) {
+#pragma unroll
+      for (int g = 0; g < TS / 4; ++g) {
+        float fu[H], fa[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) fu[i] = i < nmi ? U[4 * g + lrow][16 * (mi0 + i) + lcol] : 0.f;
+#pragma unroll
+        for (int j = 0; j < H; ++j) fa[j] = j < nnj ? A[4 * g + lrow][16 * (nj0 + j) + lcol] : 0.f;
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+#pragma unroll
+          for (int j = 0; j < H; ++j)
+            if (i < nmi && j < nnj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[i], fa[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  // sc[] has one slot per register set: X's scale words are rewritten (for X's NEXT stage) while Y's stage runs
+  Stage X, Y;
+  issue(X, t_begin);
+  issue(Y, t_begin + TS);
+  scales(X, t_begin, 0);
+  for (int t0 = t_begin; t0 < t_end; t0 += 2 * TS) {
+    scales(Y, t0 + TS, 1);      // (Y's words arrived long ago; visible behind stage X's first barrier... its second)
+    stage(X, t0, 0);
+    if (t0 + TS < t_end) {
+      scales(X, t0 + 2 * TS, 0);  // X was refilled inside stage(X): its words are waited for here, a stage later
+      stage(Y, t0 + TS, 1);
+    }
+  }
+  if (partial) {
+    __syncthreads();
+    float* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(C + 1) * C;
+    for (int i = tid; i < C; i += NT) dst[i] = s0[i];
+    // accumulator v of tile (mi, nj) at lane l: state i = 16 mi + 4 (l / 16) + v, previous state j = 16 nj + l % 16
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        if (!(i < nmi && j < nnj)) continue;
+        const int sj = 16 * (nj0 + j) + lcol;
+        float wv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) wv[v] = W[(1 + min(16 * (mi0 + i) + 4 * lrow + v, C - 1)) * C + min(sj, C - 1)];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int si = 16 * (mi0 + i) + 4 * lrow + v;
+          const float p = __builtin_amdgcn_exp2f(fmaf(wv[v], kLog2e, -wr2[min(si, CPP - 1)]));
+          if (si < C && sj < C) dst[(1 + si) * C + sj] = acc[i][j][v] * p;
+        }
+      }
+  }
+}
+
 // frames per LDS stage of dense_fast_grad_kernel: 16 where a thread stages few elements per frame (wide matrices:
 // 192 / 256 threads), 8 for the one-wave workgroups of the small ones (16 frames would double their operand registers).
 // cfg3 (C = 100): 128 -> 122 us with 16; more workgroups per utterance than 512 / B lose (768: 160 us, 1024: 155 us).
@@ -1193,14 +1378,23 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
 #define WFL_FAST_GRAD(CP)                                                                                       \
   hipLaunchKernelGGL((dense_fast_grad_kernel<CP, grad_stage<CP>()>), grid, dim3(((CP / 8) * (CP / 8) + 63) / 64 * 64), 0, st, \
                      x, W, T, C, B, alpha, beta, ws, coef, coef_w, gout, accumulate, addend, dx, part, rows)
+  static const bool use_mfma = [] {
+    const char* e = getenv("WFL_DENSE_GRAD_MFMA");  // 0: the transition gradient's products on the vector pipe (A/B)
+    return !(e && atoi(e) == 0);
+  }();
+#define WFL_MFMA_GRAD(CP)                                                                                       \
+  hipLaunchKernelGGL((dense_mfma_grad_kernel<CP, 16>), grid, dim3(256), 0, st, x, W, T, C, B, alpha, beta, ws, coef, coef_w, \
+                     gout, accumulate, addend, dx, part, rows)
   if (cp == 32)
     WFL_FAST_GRAD(32);
-  else if (cp == 64)
-    WFL_FAST_GRAD(64);
-  else if (cp == 104)
-    WFL_FAST_GRAD(104);
-  else if (cp == 128)
-    WFL_FAST_GRAD(128);
+  else if (cp == 64) {
+    if (use_mfma && part) WFL_MFMA_GRAD(64); else WFL_FAST_GRAD(64);
+  } else if (cp == 104) {
+    if (use_mfma && part) WFL_MFMA_GRAD(104); else WFL_FAST_GRAD(104);
+  } else if (cp == 128) {
+    if (use_mfma && part) WFL_MFMA_GRAD(128); else WFL_FAST_GRAD(128);
+  }
+#undef WFL_MFMA_GRAD
 #undef WFL_FAST_GRAD
   WFL_LAUNCH_CHECK();
   // log-domain gradient for what the fast sweeps did not serve
