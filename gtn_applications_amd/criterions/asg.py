@@ -6,6 +6,7 @@ the numerator on the lattice engine with arcs that index the (C+1) x C transitio
 reference's per-sample rebuild of the C^2-arc transitions graph (asg.py:54-69,103) disappears: the
 transitions tensor is the graph.
 """
+import ctypes
 import itertools
 import os
 
@@ -49,6 +50,25 @@ def unpack_replabels(tokens, num_replabels):
             out.extend([prev - num_replabels] * (tok + 1))
             prev = -1
     return out
+
+
+_NODE = False
+_PHASES = ("lattice_gather", "lattice_chain", "lattice_grad", "dense_chain", "dense_grad")
+
+
+def _native_node():
+    """csrc/torch_ops.cpp (the step's launches in one native call), or None if the extension was not built /
+    WFL_ASG_NATIVE=0 (A/B, tests: the Python spelling of the same sequence below)."""
+    global _NODE
+    if _NODE is False:
+        _NODE = None
+        if os.environ.get("WFL_ASG_NATIVE", "1") != "0":
+            try:
+                from .. import _wfl_torch as mod
+                _NODE = mod if hasattr(mod, "asg_forward") else None
+            except ImportError:
+                pass
+    return _NODE
 
 
 def max_classes():
@@ -143,12 +163,46 @@ class ASGLossFunction(torch.autograd.Function):
             pack = tg.cache[("asg_fal", C)] = E.PackedLattice.asg_force_align(tg.flat, tg.offsets, C, dev)
         need_dx, need_dw = inputs.requires_grad, transitions.requires_grad
         need_grad = need_dx or need_dw
+        node = _native_node()
+        timed = node is not None and E.phase_due(_PHASES)  # (a step whose launch groups bench.py brackets with events)
+        if node is not None and not timed and not torch.cuda.is_current_stream_capturing():
+            # every launch below in one native call (csrc/torch_ops.cpp::asg_forward): the same sequence, ~60 us of host
+            # time instead of ~200 (what a step costs at a training batch of 8, where the kernels take less than that)
+            early = need_grad and _EARLY_GRAD and all(E.plain_leaf(t) for t in (inputs, transitions) if t.requires_grad)
+            fork = E.side_stream(dev)
+            up = getattr(pack, "_uploaded", None)
+            if up is not None and up[0] not in (E.stream_ptr(), fork.side.cuda_stream):
+                fork.side.wait_event(up[1])  # (a cached pack uploaded on a third stream)
+            loss, da, db, dz, ws, dx_num, dw_num, dx, dW = node.asg_forward(
+                x, W, ctypes.addressof(pack.desc), pack.ints, pack.floats, scale, cpos, cneg, need_dx, need_dw, early,
+                fork.side.cuda_stream)
+            fcc = E.DenseState()
+            fcc.B, fcc.T, fcc.C, fcc.alpha, fcc.beta, fcc.logz, fcc.ws = B, T, C, da, db, dz, ws
+            ctx.aux = (x, W, fcc, cpos, dx_num, dw_num, fork if need_grad else None)
+            ctx.devices = (inputs.device, transitions.device)
+            ctx.early = None
+            if early:
+                ctx.early = _EarlyGrads(dx, dW, inputs, transitions)
+                ctx.eager_take = ctx.early.take
+                E.watch_node_hooks(ctx)
+            return loss if inputs.is_cuda else loss.cpu()
         # numerator (force-aligned lattice) and denominator (fully connected) sweeps are independent and
         # both latency-bound: fork the numerator onto a second stream so that they overlap.  The numerator is
         # the shorter of the two, so its gradient (for grad_output = 1) is computed right behind its sweeps, still
         # under the denominator's; backward adds it, scaled by grad_output, inside the denominator's gradient kernel.
         # (its buffers first, on this stream: the numerator's stream is the longer one, a fill there is a fill on the
         # step's critical path)
+        E._PHASE_FORCE = timed
+        try:
+            return ASGLossFunction._forward_launches(ctx, inputs, transitions, x, W, tg, pack, scale, cpos, cneg, need_dx,
+                                                     need_dw, dev)
+        finally:
+            E._PHASE_FORCE = False
+
+    @staticmethod
+    def _forward_launches(ctx, inputs, transitions, x, W, tg, pack, scale, cpos, cneg, need_dx, need_dw, dev):
+        """The step's launches, one engine call after the other (asg_forward of csrc/torch_ops.cpp is the same sequence)."""
+        need_grad = need_dx or need_dw
         dx_num = torch.empty_like(x) if need_dx else None
         dw_num = torch.zeros_like(W) if need_dw else None
         with E.side_stream(dev) as fork:

@@ -5,6 +5,8 @@
 // Python for backward, tensor wrapping of the saved state).  This file is the same operator -- counterpart of
 // CTCLossFunction.forward / backward, /root/reference/criterions/ctc.py:31-93 -- as a torch::autograd::Function that
 // calls the C ABI of libwfl.so (include/wfl.h) directly.  Host-side plumbing only: no arithmetic happens here.
+#include <c10/hip/HIPCachingAllocator.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 #include <torch/csrc/autograd/functions/accumulate_grad.h>
@@ -13,6 +15,7 @@
 
 #include <list>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 
@@ -465,12 +468,120 @@ bool ctc_fast_backward(const at::Tensor& loss) {
   return true;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Every launch of an ASG step's forward in ONE native call: counterpart of ASGLossFunction.forward,
+// /root/reference/criterions/asg.py:84-139 (the per-sample graph loop under gtn.parallel_for and the reduction), after
+// the targets have been packed (engine.PackedLattice.asg_force_align, cached per batch).  The Python spelling of the same
+// sequence (criterions/asg.py, kept as the fall-back when this module is missing and for phase timing) is ~15 tensor
+// allocations, 8 ctypes calls, a stream context and three events: 180-205 us of interpreter time per step, against
+// 450 us of kernels at the benchmark shape and ~100 us at a training batch of 8.  Host-side plumbing only.
+//   numerator (force-aligned lattice, lattice engine) on `side_stream`, forked from the current stream; its gradient
+//   for grad_output = 1 right behind its sweeps; denominator (dense engine) on the current stream; the loss reduction
+//   after the numerator's sweeps; `early`: the denominator's gradient (+ the numerator's, as its addend) for
+//   grad_output = 1 as well.
+// Returns {loss, den_alpha, den_beta, den_logz, den_ws, dx_num, dw_num, dx, dW} (undefined where not asked for).
+// ------------------------------------------------------------------------------------------------------------
+struct EventRing {  // fork / join events of the native steps, per device (created on first use, never destroyed)
+  static constexpr int kN = 32;
+  hipEvent_t ev[kN] = {};
+  unsigned next = 0;
+  hipEvent_t take() {
+    hipEvent_t& e = ev[next++ % kN];
+    if (!e) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate");
+    return e;
+  }
+};
+EventRing& event_ring(int dev) {
+  static std::mutex mu;
+  static auto* rings = new std::map<int, EventRing>();
+  std::lock_guard<std::mutex> lock(mu);
+  return (*rings)[dev];
+}
+void order_after(hipStream_t waiter, hipStream_t signaller, int dev) {  // waiter's later work after signaller's earlier work
+  hipEvent_t e = event_ring(dev).take();
+  TORCH_CHECK(hipEventRecord(e, signaller) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess, "stream ordering");
+}
+void used_on(const at::Tensor& t, const c10::hip::HIPStream& s) {
+  if (t.defined()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), s);
+}
+float* fptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+
+std::vector<at::Tensor> asg_forward(const at::Tensor& x, const at::Tensor& W, int64_t desc_ptr, const at::Tensor& ints,
+                                    const at::Tensor& floats, const at::Tensor& scale, const at::Tensor& cpos,
+                                    const at::Tensor& cneg, bool need_dx, bool need_dw, bool early, int64_t side_stream) {
+  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous() && x.dim() == 3,
+              "asg_forward: x must be a contiguous float32 [B,T,C] device tensor");
+  TORCH_CHECK(W.is_cuda() && W.scalar_type() == at::kFloat && W.is_contiguous(), "asg_forward: W must be contiguous float32");
+  const int dev = x.device().index();
+  const int B = (int)x.size(0), T = (int)x.size(1), C = (int)x.size(2);
+  const auto* d = reinterpret_cast<const wfl_lattice_desc*>(desc_ptr);
+  const c10::hip::HIPStream main_s = c10::hip::getCurrentHIPStream(dev);
+  const c10::hip::HIPStream side_s = c10::hip::getStreamFromExternal(reinterpret_cast<hipStream_t>(side_stream), dev);
+  hipStream_t ms = main_s.stream(), ss = side_s.stream();
+  const bool need_grad = need_dx || need_dw;
+  const auto f32 = x.options();
+  // (the numerator's gradient buffers first, on this stream: a fill on the numerator's stream would sit on its critical path)
+  at::Tensor dx_num = need_dx ? at::empty_like(x) : at::Tensor();
+  at::Tensor dw_num = need_dw ? at::zeros_like(W) : at::Tensor();
+  used_on(dx_num, side_s), used_on(dw_num, side_s);
+  const int32_t* ip = ints.data_ptr<int32_t>();
+  at::Tensor xg, al, be, lz;
+  hipEvent_t swept = event_ring(dev).take();
+  order_after(ss, ms, dev);
+  {
+    c10::hip::HIPStreamGuard guard(side_s);  // (the numerator's buffers belong to its stream: freed when this call returns)
+    int64_t n_xg = 0, n_ab = 0;
+    check(wfl_lattice_workspace(d, T, &n_xg, &n_ab), "asg_forward");
+    xg = at::empty({std::max<int64_t>(n_xg, 1)}, f32);
+    al = at::empty({std::max<int64_t>(n_ab, 1)}, f32);
+    if (need_grad) be = at::empty({std::max<int64_t>(n_ab, 1)}, f32);
+    lz = at::empty({B}, f32);
+    check(wfl_lattice_gather(d, ip, x.data_ptr<float>(), T, C, xg.data_ptr<float>(), nullptr, ss), "asg_forward");
+    check(wfl_lattice_forward(d, ip, floats.data_ptr<float>(), xg.data_ptr<float>(), T, W.data_ptr<float>(), WFL_SEMIRING_LOG,
+                              al.data_ptr<float>(), fptr(be), nullptr, lz.data_ptr<float>(), ss),
+          "asg_forward");
+    TORCH_CHECK(hipEventRecord(swept, ss) == hipSuccess, "hipEventRecord");
+    if (need_grad)
+      check(wfl_lattice_grad(d, ip, floats.data_ptr<float>(), xg.data_ptr<float>(), T, C, W.data_ptr<float>(),
+                             al.data_ptr<float>(), be.data_ptr<float>(), lz.data_ptr<float>(), cneg.data_ptr<float>(),
+                             cneg.data_ptr<float>(), nullptr, 0, nullptr, nullptr, fptr(dx_num), fptr(dw_num), ss),
+            "asg_forward");
+  }
+  int64_t n_part = 0, n_ws = 0;
+  check(wfl_dense_workspace(B, T, C, &n_part, &n_ws), "asg_forward");
+  at::Tensor da = at::empty({B, T, C}, f32), db = need_grad ? at::empty({B, T, C}, f32) : at::Tensor();
+  at::Tensor dz = at::empty({B}, f32), ws = at::empty({n_ws}, f32.dtype(at::kByte));
+  check(wfl_dense_forward(x.data_ptr<float>(), W.data_ptr<float>(), B, T, C, WFL_SEMIRING_LOG, da.data_ptr<float>(), fptr(db),
+                          nullptr, dz.data_ptr<float>(), ws.data_ptr(), ms),
+        "asg_forward");
+  // the loss only needs the numerator's sweeps; its gradient keeps running
+  TORCH_CHECK(hipStreamWaitEvent(ms, swept, 0) == hipSuccess, "hipStreamWaitEvent");
+  used_on(lz, main_s);
+  at::Tensor loss = at::empty({}, f32);
+  check(wfl_reduce_loss(dz.data_ptr<float>(), lz.data_ptr<float>(), scale.data_ptr<float>(), B, 1.0f, 0, loss.data_ptr<float>(), ms),
+        "asg_forward");
+  at::Tensor dx, dW;
+  if (early && need_grad) {
+    if (need_dx) dx = at::empty_like(x);
+    if (need_dw) dW = at::empty_like(W);
+    at::Tensor part = need_dw ? at::empty({n_part}, f32) : at::Tensor();
+    order_after(ms, ss, dev);
+    check(wfl_dense_grad(x.data_ptr<float>(), W.data_ptr<float>(), B, T, C, da.data_ptr<float>(), db.data_ptr<float>(),
+                         dz.data_ptr<float>(), cpos.data_ptr<float>(), cpos.data_ptr<float>(), nullptr, 0, fptr(dx_num),
+                         fptr(dw_num), fptr(dx), fptr(dW), fptr(part), ws.data_ptr(), ms),
+          "asg_forward");
+  }
+  return {loss, da, db, dz, ws, dx_num, dw_num, dx, dW};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ctc_fast_backward", &ctc_fast_backward,
         "loss.backward() of a CtcStep loss without the autograd engine (false: not the plain case, use the engine)");
   m.def("ctc_step", &ctc_step, "CTC loss + eager gradient in one pipelined launch (C++ autograd node)");
+  m.def("asg_forward", &asg_forward, "every launch of an ASG step's forward in one native call (criterions/asg.py)");
   m.def("ctc_reset_host_state", &ctc_reset_host_state, "zero the steps' memory of which launch to start with");
   py::class_<StagedTargets, std::shared_ptr<StagedTargets>>(m, "StagedTargets")
       .def_readonly("B", &StagedTargets::B)

@@ -119,10 +119,27 @@ def on_input_device(fn):
     return wrapped
 
 
+_PHASE_FORCE = False
+
+
+def phase_due(names):
+    """Will a launch group of `names` be bracketed in THIS step?  For operator paths that issue all their launches in
+    one native call (criterions/asg.py): they take the Python spelling of the same sequence in the steps whose groups
+    are being timed -- under PHASE_STRIDE every PHASE_STRIDE-th step -- with `_PHASE_FORCE` set around it."""
+    if PHASE_EVENTS is None or (PHASE_ONLY is not None and not any(n in PHASE_ONLY for n in names)):
+        return False
+    if PHASE_STRIDE > 1:
+        key = "step:" + names[0]
+        k = _PHASE_COUNT[key] = _PHASE_COUNT.get(key, 0) + 1
+        if k % PHASE_STRIDE:
+            return False
+    return True
+
+
 def _mark(name):
     if PHASE_EVENTS is None or (PHASE_ONLY is not None and name not in PHASE_ONLY):
         return None
-    if PHASE_STRIDE > 1:
+    if PHASE_STRIDE > 1 and not _PHASE_FORCE:
         k = _PHASE_COUNT[name] = _PHASE_COUNT.get(name, 0) + 1
         if k % PHASE_STRIDE:
             return None

@@ -690,6 +690,37 @@ def test_asg_vs_oracle(crit, B, T, C, reduction):
     close(W4.grad, 0.5 * want[2], atol=2e-5)
 
 
+@pytest.mark.parametrize("leaf", [True, False])
+def test_asg_native_call_is_the_python_sequence(crit, leaf):
+    """csrc/torch_ops.cpp::asg_forward issues the launches of ASGLossFunction.forward (asg.py:84-139) in one native
+    call; criterions/asg.py keeps the same sequence spelled in Python (no extension, phase timing).  Same kernels, same
+    buffers: loss and dx bit for bit, dW up to the order of its atomics -- as leaves (the forward's gradient handed to .grad) and through the engine."""
+    asg = crit["asg"]
+    if asg._native_node() is None:
+        pytest.skip("the torch extension is not built")
+    rs = np.random.RandomState(11)
+    B, T, C = 5, 60, 28
+    x = rs.randn(B, T, C).astype(np.float32)
+    W = (0.5 * rs.randn(C + 1, C)).astype(np.float32)
+    targets = [rs.randint(0, C, size=rs.randint(1, 20)).tolist() for _ in range(B)]
+
+    def run():
+        xt, Wt = dev(x, grad=True), dev(W, grad=True)
+        loss = asg.ASGLoss(xt if leaf else xt * 1.0, Wt if leaf else Wt * 1.0, targets, "mean")
+        (loss if leaf else loss * 0.75).backward()
+        return loss.detach().cpu().numpy(), xt.grad.cpu().numpy(), Wt.grad.cpu().numpy()
+
+    native = run()
+    node, asg._NODE = asg._NODE, None
+    try:
+        python = run()
+    finally:
+        asg._NODE = node
+    assert np.array_equal(native[0], python[0]) and np.array_equal(native[1], python[1])
+    # (the numerator's transition gradient is accumulated with float atomics: the order differs from run to run)
+    np.testing.assert_allclose(native[2], python[2], rtol=1e-5, atol=1e-7)
+
+
 def test_asg_viterbi_vs_oracle_integer_scores(crit):
     rs = np.random.RandomState(2)
     B, T, C = 4, 30, 7
