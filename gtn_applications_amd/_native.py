@@ -15,6 +15,7 @@ WFL_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 1, 2, 3
 EPSILON = -1
 SEMIRING_LOG, SEMIRING_TROPICAL = 0, 1
+DENSE_MAIN, DENSE_REPAIR, DENSE_REDUCE, DENSE_ALL = 1, 2, 4, 7  # parts of wfl_dense_forward_parts / wfl_dense_grad_parts
 CTC_WS_REJECTED, CTC_WS_STATUS, CTC_WS_LOG2Z, CTC_WS_ZRANGE = 0, 1, 2, 3
 CONV_SPIKE, CONV_BLANK_OPTIONAL = 1, 2
 
@@ -136,10 +137,12 @@ _SIGS = {
                               _P]),
     # device: dense transitions
     "wfl_dense_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "wfl_dense_forward_parts": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "wfl_dense_max_classes": (c_int, []),
     "wfl_dense_on_chip_classes": (c_int, []),
     "wfl_dense_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "wfl_dense_grad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "wfl_dense_grad_parts": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "wfl_dense_viterbi": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     # device: CTC fast path
     "wfl_ctc_workspace": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int64)]),

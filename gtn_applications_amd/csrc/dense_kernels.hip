@@ -1263,10 +1263,19 @@ static int dense_fast_cp(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 104 
 
 int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int semiring, float* alpha, float* beta,
                       int32_t* bptr, float* logz, void* ws, void* stream) {
+  return wfl_dense_forward_parts(x, W, B, T, C, semiring, alpha, beta, bptr, logz, ws, WFL_DENSE_ALL, stream);
+}
+
+int wfl_dense_forward_parts(const float* x, const float* W, int B, int T, int C, int semiring, float* alpha, float* beta,
+                            int32_t* bptr, float* logz, void* ws, int parts, void* stream) {
   if (int rc = dense_check(x, W, B, T, C, "dense_forward")) return rc;
+  const bool main_part = parts & WFL_DENSE_MAIN, repair_part = parts & WFL_DENSE_REPAIR;
   if (!alpha) {
     set_error("dense_forward: alpha is required");
     return WFL_ERR_INVALID;
+  }
+  if (!dense_on_chip(C) || semiring != WFL_SEMIRING_LOG) {
+    if (!main_part) return WFL_OK;  // (one piece: it goes with the main part)
   }
   if (!dense_on_chip(C)) {
     if (semiring == WFL_SEMIRING_LOG ? (!ws || !logz) : !bptr) {
@@ -1303,18 +1312,21 @@ int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int s
       hipLaunchKernelGGL((dense_fast_chain_kernel<CP, false>), grid, dim3(kDenseThreads), 0, st, x, W, T, C, ws, B,     \
                          alpha, beta, logz);                                                                            \
   } while (0)
-    if (cp == 32)
-      WFL_FAST_CHAIN(32);
-    else if (cp == 64)
-      WFL_FAST_CHAIN(64);
-    else if (cp == 104)
-      WFL_FAST_CHAIN(104);
-    else if (cp == 128)
-      WFL_FAST_CHAIN(128);
+    if (main_part) {
+      if (cp == 32)
+        WFL_FAST_CHAIN(32);
+      else if (cp == 64)
+        WFL_FAST_CHAIN(64);
+      else if (cp == 104)
+        WFL_FAST_CHAIN(104);
+      else if (cp == 128)
+        WFL_FAST_CHAIN(128);
+      WFL_LAUNCH_CHECK();
+      if (!cp)  // no fast path for this C: every utterance is served by the log-domain kernels
+        WFL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.flag, 1, (size_t)2 * B, st));
+    }
 #undef WFL_FAST_CHAIN
-    WFL_LAUNCH_CHECK();
-    if (!cp)  // no fast path for this C: every utterance is served by the log-domain kernels
-      WFL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.flag, 1, (size_t)2 * B, st));
+    if (!repair_part) return WFL_OK;
     // log-domain sweep: everything when there is no fast path, otherwise only flagged utterances
     auto k = dense_chain_kernel<WFL_SEMIRING_LOG>;
     if (lds > 48 * 1024)
@@ -1355,13 +1367,23 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
                    const float* logz, const float* coef, const float* coef_w, const float* gout, int accumulate,
                    const float* addend, const float* dW_addend, float* dx, float* dW, float* dW_partial, const void* ws,
                    void* stream) {
+  return wfl_dense_grad_parts(x, W, B, T, C, alpha, beta, logz, coef, coef_w, gout, accumulate, addend, dW_addend, dx, dW,
+                              dW_partial, ws, WFL_DENSE_ALL, stream);
+}
+
+int wfl_dense_grad_parts(const float* x, const float* W, int B, int T, int C, const float* alpha, const float* beta,
+                         const float* logz, const float* coef, const float* coef_w, const float* gout, int accumulate,
+                         const float* addend, const float* dW_addend, float* dx, float* dW, float* dW_partial,
+                         const void* ws, int parts, void* stream) {
   if (int rc = dense_check(x, W, B, T, C, "dense_grad")) return rc;
+  const bool main_part = parts & WFL_DENSE_MAIN, repair_part = parts & WFL_DENSE_REPAIR, reduce_part = parts & WFL_DENSE_REDUCE;
   if (!alpha || !beta || !logz || !ws || (!dx && !dW) || (dW && !dW_partial)) {
     set_error("dense_grad: missing buffers");
     return WFL_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
   if (!dense_on_chip(C)) {
+    if (!main_part) return WFL_OK;  // (one piece: it goes with the main part)
     const int rc = wide_grad(x, B, T, C, alpha, beta, logz, coef, coef_w, gout, accumulate, addend, dW_addend, dx, dW,
                              dW_partial, ws, st);
     WFL_LAUNCH_CHECK();
@@ -1385,7 +1407,8 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
 #define WFL_MFMA_GRAD(CP)                                                                                       \
   hipLaunchKernelGGL((dense_mfma_grad_kernel<CP, 16>), grid, dim3(256), 0, st, x, W, T, C, B, alpha, beta, ws, coef, coef_w, \
                      gout, accumulate, addend, dx, part, rows)
-  if (cp == 32)
+  if (!main_part) {
+  } else if (cp == 32)
     WFL_FAST_GRAD(32);
   else if (cp == 64) {
     if (use_mfma && part) WFL_MFMA_GRAD(64); else WFL_FAST_GRAD(64);
@@ -1401,7 +1424,8 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
 #define WFL_DENSE_GRAD(NP)                                                                                 \
   hipLaunchKernelGGL(dense_grad_kernel<NP>, grid, dim3(256), lds, st, x, W, T, C, alpha, beta, logz, coef, \
                      coef_w, gout, accumulate, addend, dx, part, rows, flags)
-  if (np <= 4)
+  if (!repair_part) {
+  } else if (np <= 4)
     WFL_DENSE_GRAD(4);
   else if (np <= 16)
     WFL_DENSE_GRAD(16);
@@ -1413,7 +1437,7 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
     WFL_DENSE_GRAD(64);  // (C > 128: several passes over the frames, 16384 transition pairs each)
 #undef WFL_DENSE_GRAD
   WFL_LAUNCH_CHECK();
-  if (dW) {
+  if (dW && reduce_part) {
     const int n = (C + 1) * C;
     hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, dW_partial, B * chunks,
                        n, dW, accumulate, dW_addend, gout);

@@ -507,6 +507,15 @@ void used_on(const at::Tensor& t, const c10::hip::HIPStream& s) {
 }
 float* fptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 
+c10::hip::HIPStream& fill_stream(int dev) {  // a third stream per device: the step's one fill, off both critical paths
+  static std::mutex mu;
+  static auto* streams = new std::map<int, c10::hip::HIPStream>();
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = streams->find(dev);
+  if (it == streams->end()) it = streams->emplace(dev, c10::hip::getStreamFromPool(false, (c10::DeviceIndex)dev)).first;
+  return it->second;
+}
+
 std::vector<at::Tensor> asg_forward(const at::Tensor& x, const at::Tensor& W, int64_t desc_ptr, const at::Tensor& ints,
                                     const at::Tensor& floats, const at::Tensor& scale, const at::Tensor& cpos,
                                     const at::Tensor& cneg, bool need_dx, bool need_dw, bool early, int64_t side_stream) {
@@ -520,14 +529,26 @@ std::vector<at::Tensor> asg_forward(const at::Tensor& x, const at::Tensor& W, in
   const c10::hip::HIPStream side_s = c10::hip::getStreamFromExternal(reinterpret_cast<hipStream_t>(side_stream), dev);
   hipStream_t ms = main_s.stream(), ss = side_s.stream();
   const bool need_grad = need_dx || need_dw;
+  early = early && need_grad;
   const auto f32 = x.options();
-  // (the numerator's gradient buffers first, on this stream: a fill on the numerator's stream would sit on its critical path)
+  EventRing& ring = event_ring(dev);
+  // What sits on the caller's stream is what the step's time is made of: the denominator's sweeps, its gradient, the
+  // reduction of the transition-gradient partials, the loss reduction.  The numerator and the zero fill of its
+  // transition gradient run beside it.
   at::Tensor dx_num = need_dx ? at::empty_like(x) : at::Tensor();
-  at::Tensor dw_num = need_dw ? at::zeros_like(W) : at::Tensor();
-  used_on(dx_num, side_s), used_on(dw_num, side_s);
+  used_on(dx_num, side_s);
+  at::Tensor dw_num;
+  hipEvent_t filled = nullptr;
+  if (need_dw) {
+    const c10::hip::HIPStream& fs = fill_stream(dev);
+    c10::hip::HIPStreamGuard guard(fs);  // (the buffer belongs to that stream: nothing of an earlier step can still be using it)
+    dw_num = at::zeros_like(W);
+    filled = ring.take();
+    TORCH_CHECK(hipEventRecord(filled, fs.stream()) == hipSuccess, "hipEventRecord");
+    used_on(dw_num, side_s), used_on(dw_num, main_s);
+  }
   const int32_t* ip = ints.data_ptr<int32_t>();
   at::Tensor xg, al, be, lz;
-  hipEvent_t swept = event_ring(dev).take();
   order_after(ss, ms, dev);
   {
     c10::hip::HIPStreamGuard guard(side_s);  // (the numerator's buffers belong to its stream: freed when this call returns)
@@ -541,37 +562,48 @@ std::vector<at::Tensor> asg_forward(const at::Tensor& x, const at::Tensor& W, in
     check(wfl_lattice_forward(d, ip, floats.data_ptr<float>(), xg.data_ptr<float>(), T, W.data_ptr<float>(), WFL_SEMIRING_LOG,
                               al.data_ptr<float>(), fptr(be), nullptr, lz.data_ptr<float>(), ss),
           "asg_forward");
-    TORCH_CHECK(hipEventRecord(swept, ss) == hipSuccess, "hipEventRecord");
+    if (filled) TORCH_CHECK(hipStreamWaitEvent(ss, filled, 0) == hipSuccess, "hipStreamWaitEvent");
     if (need_grad)
       check(wfl_lattice_grad(d, ip, floats.data_ptr<float>(), xg.data_ptr<float>(), T, C, W.data_ptr<float>(),
                              al.data_ptr<float>(), be.data_ptr<float>(), lz.data_ptr<float>(), cneg.data_ptr<float>(),
                              cneg.data_ptr<float>(), nullptr, 0, nullptr, nullptr, fptr(dx_num), fptr(dw_num), ss),
             "asg_forward");
   }
+  hipEvent_t num_done = ring.take();
+  TORCH_CHECK(hipEventRecord(num_done, ss) == hipSuccess, "hipEventRecord");
   int64_t n_part = 0, n_ws = 0;
   check(wfl_dense_workspace(B, T, C, &n_part, &n_ws), "asg_forward");
   at::Tensor da = at::empty({B, T, C}, f32), db = need_grad ? at::empty({B, T, C}, f32) : at::Tensor();
   at::Tensor dz = at::empty({B}, f32), ws = at::empty({n_ws}, f32.dtype(at::kByte));
-  check(wfl_dense_forward(x.data_ptr<float>(), W.data_ptr<float>(), B, T, C, WFL_SEMIRING_LOG, da.data_ptr<float>(), fptr(db),
-                          nullptr, dz.data_ptr<float>(), ws.data_ptr(), ms),
-        "asg_forward");
-  // the loss only needs the numerator's sweeps; its gradient keeps running
-  TORCH_CHECK(hipStreamWaitEvent(ms, swept, 0) == hipSuccess, "hipStreamWaitEvent");
-  used_on(lz, main_s);
   at::Tensor loss = at::empty({}, f32);
+  at::Tensor dx, dW, part;
+  if (early) {
+    if (need_dx) dx = at::empty_like(x);
+    if (need_dw) dW = at::empty_like(W), part = at::empty({n_part}, f32);
+  }
+  auto dense_forward = [&](int parts, hipStream_t st) {
+    check(wfl_dense_forward_parts(x.data_ptr<float>(), W.data_ptr<float>(), B, T, C, WFL_SEMIRING_LOG, da.data_ptr<float>(),
+                                  fptr(db), nullptr, dz.data_ptr<float>(), ws.data_ptr(), parts, st),
+          "asg_forward");
+  };
+  auto dense_grad = [&](int parts, hipStream_t st) {
+    check(wfl_dense_grad_parts(x.data_ptr<float>(), W.data_ptr<float>(), B, T, C, da.data_ptr<float>(), db.data_ptr<float>(),
+                               dz.data_ptr<float>(), cpos.data_ptr<float>(), cpos.data_ptr<float>(), nullptr, 0, fptr(dx_num),
+                               fptr(dw_num), fptr(dx), fptr(dW), fptr(part), ws.data_ptr(), parts, st),
+          "asg_forward");
+  };
+  // One wait on this stream (for the numerator's launches) and nothing else between its kernels: a wait or an event
+  // record between two launches keeps the second from being dispatched under the first one's tail -- ~6 us each,
+  // measured (scripts/step_timeline.sh) -- so the loss reduction comes last, back to back with the gradient's
+  // launches, rather than on the numerator's stream with an event each way.  (The log-domain launches stay here too:
+  // beside the gradient kernel, which fills every SIMD's registers, an "empty" launch of 2 B workgroups only gets
+  // through as that kernel's workgroups retire: measured 86 us.)
+  dense_forward(WFL_DENSE_ALL, ms);
+  TORCH_CHECK(hipStreamWaitEvent(ms, num_done, 0) == hipSuccess, "hipStreamWaitEvent");
+  used_on(lz, main_s);
+  if (early) dense_grad(WFL_DENSE_ALL, ms);
   check(wfl_reduce_loss(dz.data_ptr<float>(), lz.data_ptr<float>(), scale.data_ptr<float>(), B, 1.0f, 0, loss.data_ptr<float>(), ms),
         "asg_forward");
-  at::Tensor dx, dW;
-  if (early && need_grad) {
-    if (need_dx) dx = at::empty_like(x);
-    if (need_dw) dW = at::empty_like(W);
-    at::Tensor part = need_dw ? at::empty({n_part}, f32) : at::Tensor();
-    order_after(ms, ss, dev);
-    check(wfl_dense_grad(x.data_ptr<float>(), W.data_ptr<float>(), B, T, C, da.data_ptr<float>(), db.data_ptr<float>(),
-                         dz.data_ptr<float>(), cpos.data_ptr<float>(), cpos.data_ptr<float>(), nullptr, 0, fptr(dx_num),
-                         fptr(dw_num), fptr(dx), fptr(dW), fptr(part), ws.data_ptr(), ms),
-          "asg_forward");
-  }
   return {loss, da, db, dz, ws, dx_num, dw_num, dx, dW};
 }
 

@@ -320,6 +320,24 @@ int wfl_dense_grad(const float* x, const float* W, int B, int T, int C, const fl
                    const float* beta, const float* logz, const float* coef, const float* coef_w,
                    const float* gout, int accumulate, const float* addend, const float* dW_addend,
                    float* dx, float* dW, float* dW_partial, const void* ws, void* stream);
+/* The same two calls in parts, for a caller that runs them on two streams (criterions/asg.py through
+ * csrc/torch_ops.cpp::asg_forward): the probability-domain launches serve every utterance whose transition matrix has a
+ * bounded dynamic range, the log-domain launches behind them only what those flagged (normally nothing: they return at
+ * once) -- different utterances, disjoint rows of every output.  A caller may put WFL_DENSE_REPAIR on a second stream,
+ * ordered after the WFL_DENSE_MAIN part of wfl_dense_forward_parts (it reads the flags that part writes), and run
+ * WFL_DENSE_REDUCE (the sum of the per-workgroup transition-gradient partials into dW) once both gradient parts are done.
+ * WFL_DENSE_ALL on one stream is wfl_dense_forward / wfl_dense_grad.  Beyond wfl_dense_on_chip_classes() and in the
+ * tropical semiring the work is one piece: it goes with WFL_DENSE_MAIN, the other parts do nothing. */
+#define WFL_DENSE_MAIN 1
+#define WFL_DENSE_REPAIR 2
+#define WFL_DENSE_REDUCE 4
+#define WFL_DENSE_ALL 7
+int wfl_dense_forward_parts(const float* x, const float* W, int B, int T, int C, int semiring,
+                            float* alpha, float* beta, int32_t* bptr, float* logz, void* ws, int parts, void* stream);
+int wfl_dense_grad_parts(const float* x, const float* W, int B, int T, int C, const float* alpha,
+                         const float* beta, const float* logz, const float* coef, const float* coef_w,
+                         const float* gout, int accumulate, const float* addend, const float* dW_addend,
+                         float* dx, float* dW, float* dW_partial, const void* ws, int parts, void* stream);
 /* viterbi_path(intersect(emissions, transitions)).labels_to_list() (asg.py:225-226):
  * path [B,T] int32 emission labels.  Ties: lowest previous label, then lowest final label. */
 int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float* alpha,

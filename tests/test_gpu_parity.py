@@ -721,6 +721,44 @@ def test_asg_native_call_is_the_python_sequence(crit, leaf):
     np.testing.assert_allclose(native[2], python[2], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("hard", [False, True])
+def test_dense_calls_in_parts_equal_the_whole(crit, hard):
+    """wfl_dense_forward_parts / wfl_dense_grad_parts (include/wfl.h): the probability-domain launches, the log-domain
+    launches for what those flag, and the reduction of the transition-gradient partials, asked for one after the other,
+    leave what wfl_dense_forward / wfl_dense_grad leave -- with a transition matrix every utterance keeps in the
+    probability domain, and with a forbidden transition (-inf: every utterance goes to the log-domain launches)."""
+    from gtn_applications_amd import _native as N
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(3)
+    B, T, C = 6, 50, 28
+    x = dev(rs.randn(B, T, C).astype(np.float32))
+    Wn = (0.5 * rs.randn(C + 1, C)).astype(np.float32)
+    if hard:
+        Wn[4, 7] = -np.inf
+    W = dev(Wn)
+    coef = dev(rs.rand(B).astype(np.float32))
+    whole = E.dense_forward(x, W)
+    assert bool(E.dense_flagged(whole).all().item()) == hard
+    dx0, dW0 = torch.empty_like(x), torch.empty_like(W)
+    E.dense_grad(x, W, whole, coef, coef_w=coef, dx=dx0, dW=dW0)
+    st = E.DenseState()
+    st.B, st.T, st.C = B, T, C
+    st.alpha, st.beta = torch.empty_like(whole.alpha), torch.empty_like(whole.beta)
+    st.logz, st.ws = torch.empty_like(whole.logz), torch.empty_like(whole.ws)
+    p, s = E.ptr, E.stream_ptr()
+    for part in (N.DENSE_MAIN, N.DENSE_REPAIR):
+        N.check(N.lib.wfl_dense_forward_parts(p(x), p(W), B, T, C, N.SEMIRING_LOG, p(st.alpha), p(st.beta), None, p(st.logz),
+                                              p(st.ws), part, s))
+    assert torch.equal(st.logz, whole.logz)
+    dx1, dW1 = torch.full_like(x, float("nan")), torch.full_like(W, float("nan"))
+    partials = torch.empty(E._dense_sizes(B, T, C)[0], dtype=torch.float32, device=x.device)
+    for part in (N.DENSE_REPAIR, N.DENSE_MAIN, N.DENSE_REDUCE):
+        N.check(N.lib.wfl_dense_grad_parts(p(x), p(W), B, T, C, p(st.alpha), p(st.beta), p(st.logz), p(coef), p(coef), None, 0,
+                                           None, None, p(dx1), p(dW1), p(partials), p(st.ws), part, s))
+    assert torch.equal(dx1, dx0) and torch.equal(dW1, dW0)
+
+
 def test_asg_viterbi_vs_oracle_integer_scores(crit):
     rs = np.random.RandomState(2)
     B, T, C = 4, 30, 7
