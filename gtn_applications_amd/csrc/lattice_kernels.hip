@@ -250,6 +250,24 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
   return r;
 }
 
+// ---- state values of the general sweep (run_chain) -------------------------------------------------------------
+// Tropical semiring: float (sums and comparisons of the caller's floats: ties stay ties).  Log semiring: DOUBLE -- in LDS
+// and in HBM.  The states that carry the posteriors lie 20-50 nats below the frame's largest state (measured on the
+// reference's n-gram benchmark graphs), where a float32 resolves 2-4e-6: float state vectors relative to the frame's
+// maximum put 3e-5 .. 5e-5 on the posteriors at T = 250 and 1.0 .. 2.5e-4 at T = 1000 whatever the renormalisation
+// interval or the accuracy of exp / log.  With doubles a frame's error is that of its
+// exponentials (float, of differences to the state's own largest term) and of one double log per state.
+template <int SR>
+struct ChainVal {
+  using type = float;
+};
+template <>
+struct ChainVal<WFL_SEMIRING_LOG> {
+  using type = double;
+};
+__device__ __forceinline__ float lse_exp(float d) { return fast_exp(d); }   // d <= 0: a term relative to the largest
+__device__ __forceinline__ double lse_log(double s) { return log(s); }       // s >= 1 (a sum that contains its largest term)
+
 // One relaxation of a state over its labelled in-arcs (values read from `from`).  The first four
 // arcs are independent LDS chains whose terms stay in registers (most states of the criteria's
 // acceptors have in-degree <= 4); longer lists continue with a streaming max / rescale loop over
@@ -270,84 +288,43 @@ __device__ __forceinline__ Arc4 load_arc4(const int2* arcs, int k0, int k1) {
   return r;
 }
 
-template <int SR>
-__device__ __forceinline__ void relax_labelled(const ChainLds& L, const Arc4& a4, const float* from, const float* row,
-                                               int k0, int kt0, int kt1, float& val, int& arg) {
-  const float v0 = from[a4.other[0]] + row[a4.slot[0]] + a4.w[0];
-  const float v1 = from[a4.other[1]] + row[a4.slot[1]] + a4.w[1];
-  const float v2 = from[a4.other[2]] + row[a4.slot[2]] + a4.w[2];
-  const float v3 = from[a4.other[3]] + row[a4.slot[3]] + a4.w[3];
-  float m = v0;
+template <int SR, typename VT>
+__device__ __forceinline__ void relax_labelled(const ChainLds& L, const Arc4& a4, const VT* from, const float* row,
+                                               int k0, int kt0, int kt1, VT& val, int& arg) {
+  const VT v0 = from[a4.other[0]] + (VT)row[a4.slot[0]] + (VT)a4.w[0];
+  const VT v1 = from[a4.other[1]] + (VT)row[a4.slot[1]] + (VT)a4.w[1];
+  const VT v2 = from[a4.other[2]] + (VT)row[a4.slot[2]] + (VT)a4.w[2];
+  const VT v3 = from[a4.other[3]] + (VT)row[a4.slot[3]] + (VT)a4.w[3];
+  VT m = v0;
   int am = v0 > WFL_NEG_INF ? k0 : -1;
   if (v1 > m) m = v1, am = k0 + 1;
   if (v2 > m) m = v2, am = k0 + 2;
   if (v3 > m) m = v3, am = k0 + 3;
   auto term = [&](int k) {
     const int2 a = L.arcs[k];
-    return from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
+    return from[a.x & 0xffff] + (VT)row[(unsigned)a.x >> 16] + (VT)__int_as_float(a.y);
   };
   if (SR == WFL_SEMIRING_LOG) {
-    float s = 0.f;
-    if (m > WFL_NEG_INF) s = fast_exp(v0 - m) + fast_exp(v1 - m) + fast_exp(v2 - m) + fast_exp(v3 - m);
+    VT s = 0;
+    if (m > WFL_NEG_INF)
+      s = (VT)lse_exp((float)(v0 - m)) + (VT)lse_exp((float)(v1 - m)) + (VT)lse_exp((float)(v2 - m)) + (VT)lse_exp((float)(v3 - m));
     for (int k = kt0; k < kt1; ++k) {
-      const float v = term(k);
+      const VT v = term(k);
       if (v > m) {
-        s = s * fast_exp(m - v) + 1.f;  // m == -inf: s is 0 and exp(-inf) = 0
+        s = s * (VT)lse_exp((float)(m - v)) + 1;  // m == -inf: s is 0 and exp(-inf) = 0
         m = v;
       } else if (v > WFL_NEG_INF) {
-        s += fast_exp(v - m);
+        s += (VT)lse_exp((float)(v - m));
       }
     }
-    if (m > WFL_NEG_INF) m += fast_log(s);
+    if (m > WFL_NEG_INF) m += (VT)lse_log((double)s);
   } else {
     for (int k = kt0; k < kt1; ++k) {
-      const float v = term(k);
+      const VT v = term(k);
       if (v > m) m = v, am = k;
     }
   }
   val = m, arg = am;
-}
-
-// Lean per-frame update for the common layout (one state per thread, no epsilon levels, log
-// semiring, in-degree <= DEG everywhere): the arcs' LDS addresses are precomputed, absent arcs are
-// padded with weight -inf, and there is no branch -- the chain is one dependent instruction stream
-// per frame, so its length is what bounds the sweep.
-constexpr int kLeanDeg = 8;
-struct LeanArcs {
-  const float* fa[kLeanDeg];  // address of the source state's score in the buffer read by even steps
-  const float* fb[kLeanDeg];  // ... by odd steps
-  int ro[kLeanDeg];           // byte offset of the arc's emission inside a row of the tile
-  int lo[kLeanDeg];           // source state * 4: ds_bpermute address when the whole acceptor is one wave
-  float w[kLeanDeg];
-};
-
-// log-sum of DEG terms (see lean_relax)
-template <int DEG>
-__device__ __forceinline__ float lean_lse(const float (&v)[kLeanDeg]) {
-  if (DEG == 2) {
-    const float m = vmax(v[0], v[1]);
-    const float d = vmax(v[0], -1.0e30f) - vmax(v[1], -1.0e30f);
-    const float e = __builtin_amdgcn_exp2f(-fabsf(d) * 1.4426950408889634f);
-    return fmaf(__builtin_amdgcn_logf(1.f + e), 0.6931471805599453f, m);
-  } else {
-    float m = vmax(vmax(v[0], v[1]), vmax(v[2], v[3]));
-    if (DEG == 8) m = vmax(m, vmax(vmax(v[4], v[5]), vmax(v[6], v[7])));
-    const float mc = vmax(m, -1.0e30f);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < DEG; ++i) s += __builtin_amdgcn_exp2f((v[i] - mc) * 1.4426950408889634f);
-    return fmaf(__builtin_amdgcn_logf(s), 0.6931471805599453f, mc);
-  }
-}
-
-template <int DEG>
-__device__ __forceinline__ float lean_relax(const float* const (&fp)[kLeanDeg], const int (&ro)[kLeanDeg],
-                                            const float (&w)[kLeanDeg], const float* row) {
-  float v[kLeanDeg];
-#pragma unroll
-  for (int i = 0; i < DEG; ++i)
-    v[i] = *fp[i] + *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + ro[i]) + w[i];
-  return lean_lse<DEG>(v);
 }
 
 // High in-degree states (dense n-gram transition graphs: 81 in-arcs per state in the reference's
@@ -363,12 +340,19 @@ __device__ __forceinline__ float row16_max(float v) {  // every lane of the 16-l
   v = fmaxf(v, dpp_f32<0x118, 0xf>(WFL_NEG_INF, v));
   return __shfl(v, 15, 16);
 }
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_f32<0x111, 0xf>(0.f, v);
-  v += dpp_f32<0x112, 0xf>(0.f, v);
-  v += dpp_f32<0x114, 0xf>(0.f, v);
-  v += dpp_f32<0x118, 0xf>(0.f, v);
-  return __shfl(v, 15, 16);
+__device__ __forceinline__ double row16_max(double v) {  // (doubles: through the cross-lane network, 8 bytes a step)
+  v = fmax(v, __shfl_xor(v, 1, 16));
+  v = fmax(v, __shfl_xor(v, 2, 16));
+  v = fmax(v, __shfl_xor(v, 4, 16));
+  v = fmax(v, __shfl_xor(v, 8, 16));
+  return v;
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += __shfl_xor(v, 1, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 8, 16);
+  return v;
 }
 __device__ __forceinline__ int row16_min(int v) {
   v = min(v, __shfl_xor(v, 1, 16));
@@ -380,30 +364,30 @@ __device__ __forceinline__ int row16_min(int v) {
 
 // epsilon closure of a state with many epsilon in-arcs (the back-off state of an n-gram graph collects
 // one from every history): same 16-lane cooperation; `val` / `arg` enter with the labelled result
-template <int SR>
-__device__ __forceinline__ void relax_eps_row16(const ChainLds& L, const float* vals, int k0, int k1, int A, float& val,
+template <int SR, typename VT>
+__device__ __forceinline__ void relax_eps_row16(const ChainLds& L, const VT* vals, int k0, int k1, int A, VT& val,
                                                 int& arg) {
   const int r = threadIdx.x & 15;
-  float m = r == 0 ? val : WFL_NEG_INF, s = (r == 0 && val > WFL_NEG_INF) ? 1.f : 0.f;
+  VT m = r == 0 ? val : (VT)WFL_NEG_INF, s = (r == 0 && val > WFL_NEG_INF) ? 1 : 0;
   int am = 0x7fffffff;  // (the labelled result wins ties: it is "earlier" than every epsilon arc)
   for (int k = k0 + r; k < k1; k += 16) {
     const int2 a = L.eps[k];
-    const float v = vals[a.x] + __int_as_float(a.y);
+    const VT v = vals[a.x] + (VT)__int_as_float(a.y);
     if (SR == WFL_SEMIRING_LOG) {
       if (v > m) {
-        s = s * fast_exp(m - v) + 1.f;
+        s = s * (VT)lse_exp((float)(m - v)) + 1;
         m = v;
       } else if (v > WFL_NEG_INF) {
-        s += fast_exp(v - m);
+        s += (VT)lse_exp((float)(v - m));
       }
     } else if (v > m) {
       m = v, am = A + k;
     }
   }
-  const float mt = row16_max(m);
+  const VT mt = row16_max(m);
   if (SR == WFL_SEMIRING_LOG) {
-    const float st = row16_sum(m > WFL_NEG_INF ? s * fast_exp(m - mt) : 0.f);
-    val = mt > WFL_NEG_INF ? mt + fast_log(st) : WFL_NEG_INF;
+    const double st = row16_sum(m > WFL_NEG_INF ? (double)s * (double)lse_exp((float)(m - mt)) : 0.0);
+    val = mt > WFL_NEG_INF ? mt + (VT)lse_log(st) : (VT)WFL_NEG_INF;
   } else {
     // an epsilon arc replaces the labelled back-pointer only if it is strictly better than it
     const int cand = row16_min((m == mt && mt > val) ? am : 0x7fffffff);
@@ -413,25 +397,26 @@ __device__ __forceinline__ void relax_eps_row16(const ChainLds& L, const float* 
 }
 
 // all 64 lanes of the wave must call this (rows without a state pass k0 == k1)
-template <int SR>
-__device__ __forceinline__ void relax_labelled_row16(const ChainLds& L, const float* from, const float* row, int k0,
-                                                     int k1, float& val, int& arg) {
+template <int SR, typename VT>
+__device__ __forceinline__ void relax_labelled_row16(const ChainLds& L, const VT* from, const float* row, int k0,
+                                                     int k1, VT& val, int& arg) {
   const int r = threadIdx.x & 15;
-  float m = WFL_NEG_INF, s = 0.f;
+  VT m = WFL_NEG_INF, s = 0;
   int am = 0x7fffffff;
-  auto term = [&](int k) {  // -inf past the end of the list
-    if (k >= k1) return WFL_NEG_INF;
+  auto term = [&](int k) -> VT {  // -inf past the end of the list
+    if (k >= k1) return (VT)WFL_NEG_INF;
     const int2 a = L.arcs[k];
-    return from[a.x & 0xffff] + row[(unsigned)a.x >> 16] + __int_as_float(a.y);
+    return from[a.x & 0xffff] + (VT)row[(unsigned)a.x >> 16] + (VT)__int_as_float(a.y);
   };
   // four independent arcs per step: their LDS round trips overlap instead of queueing behind each other
   for (int k = k0 + r; k < k1; k += 64) {
-    const float v0 = term(k), v1 = term(k + 16), v2 = term(k + 32), v3 = term(k + 48);
-    const float m4 = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+    const VT v0 = term(k), v1 = term(k + 16), v2 = term(k + 32), v3 = term(k + 48);
+    const VT m4 = v0 > v1 ? (v0 > v2 ? (v0 > v3 ? v0 : v3) : (v2 > v3 ? v2 : v3)) : (v1 > v2 ? (v1 > v3 ? v1 : v3) : (v2 > v3 ? v2 : v3));
     if (SR == WFL_SEMIRING_LOG) {
       if (m4 > WFL_NEG_INF) {
-        const float mn = fmaxf(m, m4);
-        s = s * fast_exp(m - mn) + fast_exp(v0 - mn) + fast_exp(v1 - mn) + fast_exp(v2 - mn) + fast_exp(v3 - mn);
+        const VT mn = m > m4 ? m : m4;
+        s = s * (VT)lse_exp((float)(m - mn)) + (VT)lse_exp((float)(v0 - mn)) + (VT)lse_exp((float)(v1 - mn)) +
+            (VT)lse_exp((float)(v2 - mn)) + (VT)lse_exp((float)(v3 - mn));
         m = mn;
       }
     } else {
@@ -442,10 +427,10 @@ __device__ __forceinline__ void relax_labelled_row16(const ChainLds& L, const fl
       if (v3 > m) m = v3, am = k + 48;
     }
   }
-  const float mt = row16_max(m);
+  const VT mt = row16_max(m);
   if (SR == WFL_SEMIRING_LOG) {
-    const float st = row16_sum(m > WFL_NEG_INF ? s * fast_exp(m - mt) : 0.f);
-    val = mt > WFL_NEG_INF ? mt + fast_log(st) : WFL_NEG_INF;
+    const double st = row16_sum(m > WFL_NEG_INF ? (double)s * (double)lse_exp((float)(m - mt)) : 0.0);
+    val = mt > WFL_NEG_INF ? mt + (VT)lse_log(st) : (VT)WFL_NEG_INF;
     arg = -1;
   } else {
     const int cand = row16_min((m == mt && mt > WFL_NEG_INF) ? am : 0x7fffffff);
@@ -454,44 +439,52 @@ __device__ __forceinline__ void relax_labelled_row16(const ChainLds& L, const fl
   }
 }
 
-template <int SR>
-__device__ __forceinline__ void relax_eps(const ChainLds& L, float* vals, int q, int k0, int k1, int A, float& val,
-                                          int& arg) {
+template <int SR, typename VT>
+__device__ __forceinline__ void relax_eps(const ChainLds& L, VT* vals, int q, int k0, int k1, int A, VT& val, int& arg) {
   // combine the current value of q with its epsilon arcs (other endpoints are already final)
-  float m = val;
+  VT m = val;
   int am = arg;
   for (int k = k0; k < k1; ++k) {
     const int2 a = L.eps[k];
-    const float v = vals[a.x] + __int_as_float(a.y);
+    const VT v = vals[a.x] + (VT)__int_as_float(a.y);
     if (v > m) m = v, am = A + k;
   }
   if (SR == WFL_SEMIRING_LOG) {
     if (m > WFL_NEG_INF) {
-      float s = fast_exp(val - m);
+      VT s = (VT)lse_exp((float)(val - m));
       for (int k = k0; k < k1; ++k) {
         const int2 a = L.eps[k];
-        s += fast_exp(vals[a.x] + __int_as_float(a.y) - m);
+        s += (VT)lse_exp((float)(vals[a.x] + (VT)__int_as_float(a.y) - m));
       }
-      m += fast_log(s);
+      m += (VT)lse_log((double)s);
     }
   }
   val = m, arg = am;
 }
 
+constexpr int kLeanDeg = 8;  // most arcs into (and out of) a state of an acceptor the probability-domain sweeps take
 constexpr int kPre = 8;  // prefetch registers per thread: rows_per_chunk * max_labels <= kPre * blockDim
 
+// The general sweep: any acceptor that fits LDS -- epsilon arcs in topological levels, states of any in-degree (more
+// than kHeavyDeg arcs: a row of 16 lanes per state), both semirings.  What the probability-domain sweeps
+// (run_chain_prob) do not take comes here: acceptors with epsilon arcs or high degrees, utterances whose certificate
+// failed, the tropical semiring.  (Until round 4 this function also held four "lean" frame loops for chains and low-degree
+// acceptors in the fp32 log domain; the probability-domain sweeps serve those since round 2, and what reaches this
+// function on their behalf -- a certificate failure -- is rare enough for the general loop.)
 template <int SR, int DIR>
 __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const ChainLds& L, int T, int rows_per_chunk,
-                          const float* __restrict__ xg, const float* __restrict__ weights, float* __restrict__ out,
+                          const float* __restrict__ xg, const float* __restrict__ weights, float* __restrict__ out_f,
                           int32_t* __restrict__ bptr, float* __restrict__ logz, int b, double* __restrict__ offs,
                           double* __restrict__ z64) {
+  using VT = typename ChainVal<SR>::type;
   const int tid = threadIdx.x, NT = blockDim.x;
-  // Block renormalisation (log semiring): plain fp32 log scores drift to O(T) -- thousands at T = 800..1000, where
-  // one ulp is 2.4e-4 .. 4.9e-4 and the posteriors lose their third digit (measured against the float64 oracle at
-  // BASELINE configs 3 and 4).  So at the start of every chunk of R frames the maximum of the state vector moves
-  // into a double offset: stored scores stay O(R * |x|), offs[1 + c] is what the slots produced in chunk c are
-  // relative to (offs[0] = 0: the boundary slot), and the gradient kernel adds offs_alpha + offs_beta - log Z in
-  // double before it exponentiates.
+  VT* const out = reinterpret_cast<VT*>(out_f);  // (indexed like the float array: u.ab_base + slot * Q + q)
+  VT* const buf0 = reinterpret_cast<VT*>(L.buf0);
+  VT* const buf1 = reinterpret_cast<VT*>(L.buf1);
+  // Renormalisation (log semiring): at the start of every chunk of R frames the maximum of the state vector moves into
+  // a double offset: offs[1 + c] is what the slots produced in chunk c are relative to (offs[0] = 0: the boundary
+  // slot), and the gradient kernel adds offs_alpha + offs_beta - log Z before it exponentiates.  With double states
+  // this only keeps magnitudes small for the float conversions of differences; it carries no accuracy any more.
   double cum = 0.0;
   if (SR == WFL_SEMIRING_LOG && tid == 0) offs[0] = 0.0;
   const int Q = u.Q, A = u.A, E = u.E, nlev = u.nlev, Kmax = d.max_labels;
@@ -520,16 +513,16 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
 
   // epsilon closure of `vals` for this direction; `tslot` is the time slot for back-pointers
   bool eps_heavy = false;  // set once the acceptor is staged (below)
-  auto closure = [&](float* vals, int tslot) {
+  auto closure = [&](VT* vals, int tslot) {
     if (nlev <= 1) return;
     for (int step = 1; step < nlev; ++step) {
       const int lev = DIR == 0 ? step : nlev - 1 - step;
       __syncthreads();
       for (int q = L.lvl[lev] + tid; q < L.lvl[lev + 1]; q += NT) {
         if (L.eptr[q + 1] - L.eptr[q] > kHeavyDeg) continue;  // cooperative pass below
-        float v = vals[q];
+        VT v = vals[q];
         int arg = -2;
-        relax_eps<SR>(L, vals, q, L.eptr[q], L.eptr[q + 1], A, v, arg);
+        relax_eps<SR, VT>(L, vals, q, L.eptr[q], L.eptr[q + 1], A, v, arg);
         vals[q] = v;
         if (SR == WFL_SEMIRING_TROPICAL && DIR == 0 && arg != -2) bptr[u.ab_base + (int64_t)tslot * Q + q] = arg;
       }
@@ -537,9 +530,9 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
         for (int q = L.lvl[lev] + (tid >> 4); q < L.lvl[lev + 1]; q += NT >> 4) {
           const int k0 = L.eptr[q], k1 = L.eptr[q + 1];
           if (k1 - k0 <= kHeavyDeg) continue;  // uniform within the row
-          float v = vals[q];
+          VT v = vals[q];
           int arg = -2;
-          relax_eps_row16<SR>(L, vals, k0, k1, A, v, arg);
+          relax_eps_row16<SR, VT>(L, vals, k0, k1, A, v, arg);
           if ((tid & 15) == 0) {
             vals[q] = v;
             if (SR == WFL_SEMIRING_TROPICAL && DIR == 0 && arg != -2) bptr[u.ab_base + (int64_t)tslot * Q + q] = arg;
@@ -550,7 +543,7 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   };
 
   const int t_first = DIR == 0 ? 0 : T;  // time slot of the boundary vector
-  float* cur = (t_first & 1) ? L.buf1 : L.buf0;
+  VT* cur = (t_first & 1) ? buf1 : buf0;
   __syncthreads();
   {
     int eh = 0;
@@ -558,7 +551,7 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
     eps_heavy = __syncthreads_or(eh) != 0;
   }
   for (int q = tid; q < Q; q += NT) {
-    cur[q] = DIR == 0 ? u.start_w[q] : u.accept_w[q];
+    cur[q] = (VT)(DIR == 0 ? u.start_w[q] : u.accept_w[q]);
     if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + q] = -1;
   }
   closure(cur, t_first);
@@ -587,248 +580,115 @@ __device__ void run_chain(const wfl_lattice_desc& d, const UttView& u, const Cha
   const int kq0 = tid < Q ? L.ptr[tid] : 0, kq1 = tid < Q ? L.ptr[tid + 1] : 0;
   const Arc4 mine = load_arc4(L.arcs, kq0, kq1);
   const bool direct = nlev <= 1;  // no epsilon closure: the relaxed value is final
-  const int deg = kq1 - kq0;
-  const int any_gt2 = __syncthreads_or(deg > 2), any_gt4 = __syncthreads_or(deg > 4);
-  const int any_gt8 = __syncthreads_or(deg > kLeanDeg);
   if (tid == 0) L.heavy[Q] = 0;
   __syncthreads();
   for (int q = tid; q < Q; q += NT)
     if (L.ptr[q + 1] - L.ptr[q] > kHeavyDeg) L.heavy[atomicAdd(&L.heavy[Q], 1)] = q;
   __syncthreads();
   const int n_heavy = L.heavy[Q];
-  const bool lean = SR == WFL_SEMIRING_LOG && Q <= NT && direct && !any_gt8;  // block-uniform
-  LeanArcs la;
+  for (int c = 0; c < nchunks; ++c) {
+    int f0, n;
+    chunk_frames(c, f0, n);
+    const float* tile = L.rows + (size_t)(c & 1) * R * Kmax;
+    float pre[kPre];
+    int pf0 = 0, pn = 0;
+    if (c + 1 < nchunks) {
+      chunk_frames(c + 1, pf0, pn);
+      const float* src = xg + u.xg_base + (int64_t)pf0 * Kmax;
 #pragma unroll
-  for (int i = 0; i < kLeanDeg; ++i) {
-    const bool ok = kq0 + i < kq1;
-    const int2 a = ok ? L.arcs[kq0 + i] : make_int2(0, __float_as_int(WFL_NEG_INF));
-    la.fa[i] = L.buf0 + (a.x & 0xffff), la.fb[i] = L.buf1 + (a.x & 0xffff);
-    la.ro[i] = (int)((unsigned)a.x >> 16) * 4, la.w[i] = __int_as_float(a.y);
-    la.lo[i] = (a.x & 0xffff) * 4;
-  }
-  // single-wave acceptors keep the score vector in registers (one state per lane) and fetch the
-  // source states with ds_bpermute: no LDS write -> barrier -> read round trip on the chain
-  float sc = (NT == 64 && tid < Q) ? cur[tid] : WFL_NEG_INF;
-  // banded acceptors (force alignment, CTC-like chains): every in-arc is a self loop or comes from
-  // the neighbouring state -- the neighbour's score is one DPP wave shift away, no LDS at all
-  const int adj = DIR == 0 ? tid - 1 : tid + 1;
-  float w_self = WFL_NEG_INF, w_adj = WFL_NEG_INF;
-  int ro_self = 0, ro_adj = 0, banded_ok = deg <= 2;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (kq0 + i >= kq1) continue;
-    const int other = la.lo[i] >> 2;
-    if (other == tid && w_self == WFL_NEG_INF)
-      w_self = la.w[i], ro_self = la.ro[i];
-    else if (other == adj && w_adj == WFL_NEG_INF)
-      w_adj = la.w[i], ro_adj = la.ro[i];
-    else if (la.w[i] > WFL_NEG_INF)
-      banded_ok = 0;
-  }
-  const bool banded = lean && NT == 64 && __syncthreads_and(banded_ok);
-  // rows_per_chunk is even, so the first step of every chunk reads the same buffer: forward steps
-  // read slot t (chunks start at even t), backward steps read slot t + 1 = T - c * R - i
-  const bool first_reads_buf1 = DIR == 0 ? false : (T & 1);
-  auto sweep = [&](auto variant) {
-    constexpr int V = decltype(variant)::value;  // 0: general path, 1: banded, otherwise the lean in-degree bound
-    for (int c = 0; c < nchunks; ++c) {
-      int f0, n;
-      chunk_frames(c, f0, n);
-      const float* tile = L.rows + (size_t)(c & 1) * R * Kmax;
-      float pre[kPre];
-      int pf0 = 0, pn = 0;
-      if (c + 1 < nchunks) {
-        chunk_frames(c + 1, pf0, pn);
-        const float* src = xg + u.xg_base + (int64_t)pf0 * Kmax;
-#pragma unroll
-        for (int j = 0; j < kPre; ++j) {
-          const int e = tid + j * NT;
-          if (e < pn * Kmax) pre[j] = src[e];
-        }
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) pre[j] = src[e];
       }
-      if (SR == WFL_SEMIRING_LOG) {
-        if (c > 0) {
-          float m;
-          if (V != 0 && NT == 64) {  // the vector lives in registers
-            m = wave_all_max(sc);
-            if (m > WFL_NEG_INF && m < __builtin_inff())
-              sc -= m;
-            else
-              m = 0.f;
-          } else {
-            const int tf = DIR == 0 ? f0 : f0 + n;  // slot the first frame of the chunk reads
-            float* fromb = V != 0 ? (first_reads_buf1 ? L.buf1 : L.buf0) : ((tf & 1) ? L.buf1 : L.buf0);
-            float v = WFL_NEG_INF;
-            for (int q = tid; q < Q; q += NT) v = fmaxf(v, fromb[q]);
-            m = block_reduce_max(v, L.red);
-            if (m > WFL_NEG_INF && m < __builtin_inff()) {
-              for (int q = tid; q < Q; q += NT) fromb[q] -= m;
-            } else {
-              m = 0.f;
-            }
-            __syncthreads();
-          }
-          cum += (double)m;
-        }
-        if (tid == 0) offs[1 + c] = cum;
-      }
-      // single-wave variants: the emissions of frame i+1 are read from the tile while frame i is
-      // being computed (they do not depend on the chain), so only the score exchange is serial
-      auto row_of = [&](int i) {
-        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-        return reinterpret_cast<const char*>(tile + (size_t)(t - f0) * Kmax);
-      };
-      if (V == 1) {
-        float xs = *reinterpret_cast<const float*>(row_of(0) + ro_self);
-        float xa = *reinterpret_cast<const float*>(row_of(0) + ro_adj);
-        for (int i = 0; i < n; ++i) {
-          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-          const char* rn = row_of(i + 1 < n ? i + 1 : i);
-          const float xs_n = *reinterpret_cast<const float*>(rn + ro_self);
-          const float xa_n = *reinterpret_cast<const float*>(rn + ro_adj);
-          const float nb = DIR == 0 ? wave_shr1(sc, WFL_NEG_INF) : wave_shl1(sc, WFL_NEG_INF);
-          float v[kLeanDeg];
-          v[0] = sc + (xs + w_self);
-          v[1] = nb + (xa + w_adj);
-          sc = lean_lse<2>(v);
-          if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
-          xs = xs_n, xa = xa_n;
-        }
-      } else if (V != 0 && NT == 64) {
-        constexpr int DEG = V >= 2 ? V : 2;
-        float xr[kLeanDeg];
-#pragma unroll
-        for (int k = 0; k < DEG; ++k) xr[k] = *reinterpret_cast<const float*>(row_of(0) + la.ro[k]) + la.w[k];
-        for (int i = 0; i < n; ++i) {
-          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-          const char* rn = row_of(i + 1 < n ? i + 1 : i);
-          float xn[kLeanDeg], v[kLeanDeg];
-#pragma unroll
-          for (int k = 0; k < DEG; ++k) xn[k] = *reinterpret_cast<const float*>(rn + la.ro[k]) + la.w[k];
-#pragma unroll
-          for (int k = 0; k < DEG; ++k)
-            v[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(la.lo[k], __float_as_int(sc))) + xr[k];
-          sc = lean_lse<DEG>(v);
-          if (tid < Q) out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = sc;
-#pragma unroll
-          for (int k = 0; k < DEG; ++k) xr[k] = xn[k];
-        }
-      } else if (V != 0) {
-        auto step = [&](int i, const float* const (&fp)[kLeanDeg], float* to) {
-          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-          const float* row = tile + (size_t)(t - f0) * Kmax;
-          const float v = lean_relax<(V >= 2 ? V : 2)>(fp, la.ro, la.w, row);
-          if (tid < Q) {
-            to[tid] = v;
-            out[u.ab_base + (int64_t)(DIR == 0 ? t + 1 : t) * Q + tid] = v;
-          }
-          lds_barrier();
-        };
-        float* const to_first = first_reads_buf1 ? L.buf0 : L.buf1;
-        float* const to_second = first_reads_buf1 ? L.buf1 : L.buf0;
-        int i = 0;
-        if (first_reads_buf1) {
-          for (; i + 1 < n; i += 2) {
-            step(i, la.fb, to_first);
-            step(i + 1, la.fa, to_second);
-          }
-          if (i < n) step(i, la.fb, to_first);
+    }
+    if (SR == WFL_SEMIRING_LOG) {
+      if (c > 0) {
+        const int tf = DIR == 0 ? f0 : f0 + n;  // slot the first frame of the chunk reads
+        VT* fromb = (tf & 1) ? buf1 : buf0;
+        float v = WFL_NEG_INF;
+        for (int q = tid; q < Q; q += NT) v = fmaxf(v, (float)fromb[q]);
+        float m = block_reduce_max(v, L.red);
+        if (m > WFL_NEG_INF && m < __builtin_inff()) {
+          for (int q = tid; q < Q; q += NT) fromb[q] -= (VT)m;
         } else {
-          for (; i + 1 < n; i += 2) {
-            step(i, la.fa, to_first);
-            step(i + 1, la.fb, to_second);
-          }
-          if (i < n) step(i, la.fa, to_first);
+          m = 0.f;
         }
-      } else {
-        for (int i = 0; i < n; ++i) {
-          // forward: consume frame t, produce slot t+1.  backward: consume frame t, produce slot t.
-          const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-          const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
-          const float* from = (slot_from & 1) ? L.buf1 : L.buf0;
-          float* to = (slot_to & 1) ? L.buf1 : L.buf0;
-          const float* row = tile + (size_t)(t - f0) * Kmax;
-          float* orow = out + u.ab_base + (int64_t)slot_to * Q;
-          if (tid < Q && kq1 - kq0 <= kHeavyDeg) {
-            float v;
-            int arg;
-            relax_labelled<SR>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
-            to[tid] = v;
-            if (direct) orow[tid] = v;
-            if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
-          }
-          for (int q = tid + NT; q < Q; q += NT) {
-            float v;
-            int arg;
-            const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
-            if (k1 - k0 > kHeavyDeg) continue;
-            relax_labelled<SR>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
+        __syncthreads();
+        cum += (double)m;
+      }
+      if (tid == 0) offs[1 + c] = cum;
+    }
+    for (int i = 0; i < n; ++i) {
+      // forward: consume frame t, produce slot t+1.  backward: consume frame t, produce slot t.
+      const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+      const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
+      const VT* from = (slot_from & 1) ? buf1 : buf0;
+      VT* to = (slot_to & 1) ? buf1 : buf0;
+      const float* row = tile + (size_t)(t - f0) * Kmax;
+      VT* orow = out + u.ab_base + (int64_t)slot_to * Q;
+      if (tid < Q && kq1 - kq0 <= kHeavyDeg) {
+        VT v;
+        int arg;
+        relax_labelled<SR, VT>(L, mine, from, row, kq0, kq0 + 4, kq1, v, arg);
+        to[tid] = v;
+        if (direct) orow[tid] = v;
+        if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + tid] = arg;
+      }
+      for (int q = tid + NT; q < Q; q += NT) {
+        VT v;
+        int arg;
+        const int k0 = L.ptr[q], k1 = L.ptr[q + 1];
+        if (k1 - k0 > kHeavyDeg) continue;
+        relax_labelled<SR, VT>(L, load_arc4(L.arcs, k0, k1), from, row, k0, k0 + 4, k1, v, arg);
+        to[q] = v;
+        if (direct) orow[q] = v;
+        if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
+      }
+      if (n_heavy) {  // one 16-lane row per high in-degree state, NT / 16 states at a time
+        const int grow = tid >> 4, nrows = NT >> 4;
+        for (int h0 = 0; h0 < n_heavy; h0 += nrows) {  // (uniform trip count: DPP rows need the whole wave)
+          const int hq = h0 + grow;
+          const int q = hq < n_heavy ? L.heavy[hq] : -1;
+          const int k0 = q >= 0 ? L.ptr[q] : 0, k1 = q >= 0 ? L.ptr[q + 1] : 0;
+          VT v;
+          int arg;
+          relax_labelled_row16<SR, VT>(L, from, row, k0, k1, v, arg);
+          if (q >= 0 && (tid & 15) == 0) {
             to[q] = v;
             if (direct) orow[q] = v;
             if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
           }
-          if (n_heavy) {  // one 16-lane row per high in-degree state, NT / 16 states at a time
-            const int grow = tid >> 4, nrows = NT >> 4;
-            for (int h0 = 0; h0 < n_heavy; h0 += nrows) {  // (uniform trip count: DPP rows need the whole wave)
-              const int hq = h0 + grow;
-              const int q = hq < n_heavy ? L.heavy[hq] : -1;
-              const int k0 = q >= 0 ? L.ptr[q] : 0, k1 = q >= 0 ? L.ptr[q + 1] : 0;
-              float v;
-              int arg;
-              relax_labelled_row16<SR>(L, from, row, k0, k1, v, arg);
-              if (q >= 0 && (tid & 15) == 0) {
-                to[q] = v;
-                if (direct) orow[q] = v;
-                if (SR == WFL_SEMIRING_TROPICAL && DIR == 0) bptr[u.ab_base + (int64_t)slot_to * Q + q] = arg;
-              }
-            }
-          }
-          closure(to, slot_to);
-          __syncthreads();
-          if (!direct)
-            for (int q = tid; q < Q; q += NT) orow[q] = to[q];
         }
       }
-      if (c + 1 < nchunks) {
-        float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
-#pragma unroll
-        for (int j = 0; j < kPre; ++j) {
-          const int e = tid + j * NT;
-          if (e < pn * Kmax) dst[e] = pre[j];
-        }
-        __syncthreads();
-      }
+      closure(to, slot_to);
+      __syncthreads();
+      if (!direct)
+        for (int q = tid; q < Q; q += NT) orow[q] = to[q];
     }
-  };
-  if (!lean)
-    sweep(std::integral_constant<int, 0>{});
-  else if (banded)
-    sweep(std::integral_constant<int, 1>{});
-  else if (any_gt4)
-    sweep(std::integral_constant<int, 8>{});
-  else if (any_gt2)
-    sweep(std::integral_constant<int, 4>{});
-  else
-    sweep(std::integral_constant<int, 2>{});
-  if (lean && NT == 64 && T > 0) {  // the final vector lives in registers: publish it for the log Z reduction
-    float* fin = ((DIR == 0 ? T : 0) & 1) ? L.buf1 : L.buf0;
-    if (tid < Q) fin[tid] = sc;
-    __syncthreads();
+    if (c + 1 < nchunks) {
+      float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) dst[e] = pre[j];
+      }
+      __syncthreads();
+    }
   }
   if (DIR == 0 && logz) {
-    const float* fin = (T & 1) ? L.buf1 : L.buf0;
+    const VT* fin = (T & 1) ? buf1 : buf0;
     float m = WFL_NEG_INF;
-    for (int q = tid; q < Q; q += NT) m = fmaxf(m, fin[q] + u.accept_w[q]);
+    for (int q = tid; q < Q; q += NT) m = fmaxf(m, (float)(fin[q] + (VT)u.accept_w[q]));
     m = block_reduce_max(m, L.red);
-    float z = m;
+    double z = m;
     if (SR == WFL_SEMIRING_LOG && m > WFL_NEG_INF) {
       float s = 0.f;
-      for (int q = tid; q < Q; q += NT) s += fast_exp(fin[q] + u.accept_w[q] - m);
+      for (int q = tid; q < Q; q += NT) s += fast_exp((float)(fin[q] + (VT)u.accept_w[q] - (VT)m));
       s = block_reduce_sum(s, L.red);
-      z = m + fast_log(s);
+      z = (double)m + lse_log((double)s);
     }
     if (tid == 0) {
-      const double zd = (double)z + cum;  // (-inf + cum = -inf: no accepting path)
+      const double zd = z + cum;  // (-inf + cum = -inf: no accepting path)
       logz[b] = (float)zd;
       if (SR == WFL_SEMIRING_LOG) z64[b] = zd;
     }
@@ -1628,8 +1488,8 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
   L.eps = (int2*)p, p += (size_t)d.max_eps * 8;
   L.ptr = (int*)p, p += (size_t)(d.max_states + 1) * 4;
   L.eptr = (int*)p, p += (size_t)(d.max_states + 1) * 4;
-  L.buf0 = (float*)p, p += (size_t)d.max_states * 4;
-  L.buf1 = (float*)p, p += (size_t)d.max_states * 4;
+  L.buf0 = (float*)p, p += (size_t)d.max_states * 8;  // (doubles in the log semiring: ChainVal)
+  L.buf1 = (float*)p, p += (size_t)d.max_states * 8;
   L.rows = (float*)p, p += (size_t)2 * rows_per_chunk * d.max_labels * 4;
   L.red = (float*)p, p += 64 * 4;
   L.lvl = (int*)p, p += (size_t)(d.max_levels + 1) * 4;
@@ -1652,7 +1512,7 @@ static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
   const int nt = chain_threads(d);
   const size_t prob = (size_t)std::max(d.max_states, nt) * 16 + 64 * 4 + prob_rows_floats(d, rows_per_chunk) * 4 +
                       (size_t)2 * rows_per_chunk * 4 + 64;
-  return std::max(prob, (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 8 +
+  return std::max(prob, (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 16 +
          (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 +
          (size_t)(d.max_states + 1) * 4 + 64);
 }
@@ -2190,12 +2050,10 @@ __global__ void __launch_bounds__(256)
   // in a compact tile, and the rows are streamed out as base value (0, the existing gradient, or
   // the softmax term of the fused log_softmax backward) plus the accumulator of the column's label
   // slot, looked up in a column -> slot map.
-  // alpha / beta rows of the tile: doubles for utterances swept in the probability domain (fmt[b] == kFmtProb), floats
-  // (in the first half of the same room) for the log domain
+  // alpha / beta rows of the tile: doubles -- probabilities for utterances swept in the probability domain
+  // (fmt[b] == kFmtProb), log scores for the general sweep's (run_chain: ChainVal)
   double* ald = (double*)smem;                              // [TS+1][Qmax]
   double* bed = ald + (size_t)(TS + 1) * d.max_states;      // [TS+1][Qmax]
-  float* al = (float*)ald;
-  float* be = (float*)bed;
   float* xr = (float*)(bed + (size_t)(TS + 1) * d.max_states);  // [TS][Kmax]: log scores | factors
   float* acc = xr + (size_t)TS * Kmax;                      // [TS][Kmax] (only if dx)
   float* dwacc = acc + (dx ? (size_t)TS * Kmax : 0);        // [A + E] (only if dW)
@@ -2205,9 +2063,9 @@ __global__ void __launch_bounds__(256)
   // the blank column of a CTC-like acceptor (two in-arcs per blank state: hundreds of arcs in ONE
   // slot) is spread over many threads instead of serialising the tile
   int2* chunk = (int2*)(sptr + (dx ? ((Kmax + 3) & ~1) : 0));  // [NC] {slot, first arc}; NC <= K + A / kChunk (8-byte aligned)
-  double* corr_d = (double*)(chunk + (dx ? Kmax + d.max_arcs / kChunk + 1 : 0));  // [TS] probability domain: 2^(offsets - log2 Z)
-  float* corr = (float*)(corr_d + 33);  // [TS]: offs_alpha(t) + offs_beta(t+1) - log Z
-  float* corr_eps = corr + 33;          // [TS+1]: both at slot t (epsilon arcs)
+  double* corr_d = (double*)(chunk + (dx ? Kmax + d.max_arcs / kChunk + 1 : 0));  // [TS] probability domain: 2^(offsets - log2 Z);
+                                                                                  // log domain: offs_alpha(t) + offs_beta(t+1) - log Z
+  double* corr_eps = corr_d + 33;       // [TS+1] log domain: both offsets at slot t (epsilon arcs)
   int16_t* colmap = (int16_t*)(corr_eps + 34);  // [C] (only if dx)
   // scores are stored relative to per-chunk double offsets (run_chain): slot s of alpha belongs to chunk (s-1)/R of
   // the forward sweep, slot s of beta to chunk (T-1-s)/R of the backward sweep, the boundary slots to offset 0
@@ -2266,7 +2124,7 @@ __global__ void __launch_bounds__(256)
     // (idx / n by float reciprocal: exact for idx < 2^20, see fdiv)
     {
       const int n = (nr + 1) * Q;
-      if (prob) {
+      {  // (doubles in both formats)
         const double* asrc = alpha_d + u.ab_base + (int64_t)ts0 * Q;
         const double* bsrc = beta_d + u.ab_base + (int64_t)ts0 * Q;
 #pragma unroll 4
@@ -2275,16 +2133,6 @@ __global__ void __launch_bounds__(256)
           const double av = asrc[i], bv = bsrc[i];
           ald[r * d.max_states + q] = av;
           bed[r * d.max_states + q] = bv;
-        }
-      } else {
-        const float* asrc = alpha + u.ab_base + (int64_t)ts0 * Q;
-        const float* bsrc = beta + u.ab_base + (int64_t)ts0 * Q;
-#pragma unroll 4
-        for (int i = tid; i < n; i += NT) {
-          const int r = fdiv(i, inv_q), q = i - r * Q;
-          const float av = asrc[i], bv = bsrc[i];
-          al[r * d.max_states + q] = av;
-          be[r * d.max_states + q] = bv;
         }
       }
       const float* xsrc = (prob ? fgp : xg) + u.xg_base + (int64_t)ts0 * Kmax;
@@ -2301,8 +2149,8 @@ __global__ void __launch_bounds__(256)
             corr_d[tid] = exp2(offs_a[sl] + offs_b[sl + 1] + ((double)rmaxp[sl] + (double)wref) * kLog2e_d - zd);
         } else {
           const double oa = offs_a[sl == 0 ? 0 : 1 + (sl - 1) / R];
-          corr_eps[tid] = (float)(oa + offs_b[sl == T ? 0 : 1 + (T - 1 - sl) / R] - zd);
-          if (tid < nr) corr[tid] = (float)(oa + offs_b[sl + 1 == T ? 0 : 1 + (T - 2 - sl) / R] - zd);
+          corr_eps[tid] = oa + offs_b[sl == T ? 0 : 1 + (T - 1 - sl) / R] - zd;
+          if (tid < nr) corr_d[tid] = oa + offs_b[sl + 1 == T ? 0 : 1 + (T - 2 - sl) / R] - zd;
         }
       }
     }
@@ -2328,13 +2176,15 @@ __global__ void __launch_bounds__(256)
             }
             sum = (float)(dsum * (corr_d[r] * (double)xr[r * Kmax + k]));
           } else {
-            const float* pa = al + r * d.max_states;
-            const float* pb = pa + (be - al) + d.max_states;
-            const float xv = xr[r * Kmax + k] + corr[r];
+            // log posterior of an arc: a sum of doubles (the two scores are ~1e3 apart from each other and from log Z
+            // after a few hundred frames), rounded to float only as the argument of the exponential
+            const double* pa = ald + r * d.max_states;
+            const double* pb = bed + (r + 1) * d.max_states;
+            const double xv = (double)xr[r * Kmax + k] + corr_d[r];
             for (int j = ch.y; j < j1; ++j) {
               const int2 a = sarc[j];
-              const float v = pa[a.x & 0xffff] + xv + __int_as_float(a.y) + pb[(unsigned)a.x >> 16];
-              sum += fast_exp(v);  // exp(-inf) = 0
+              const double v = pa[a.x & 0xffff] + pb[(unsigned)a.x >> 16] + (xv + (double)__int_as_float(a.y));
+              sum += fast_exp((float)v);  // exp(-inf) = 0
             }
           }
           if (sptr[k + 1] - sptr[k] <= kChunk)
@@ -2359,10 +2209,10 @@ __global__ void __launch_bounds__(256)
               ds = fma(pa[r * d.max_states] * pb[r * d.max_states], corr_d[r] * (double)px[r * Kmax], ds);
             wsum = (float)(ds * (double)fast_exp(nan_to_neg(w) - wref));
           } else {
-            const float* pa = al + u.arc_src[a];
-            const float* pb = be + d.max_states + u.arc_dst[a];
+            const double* pa = ald + u.arc_src[a];
+            const double* pb = bed + d.max_states + u.arc_dst[a];
             for (int r = 0; r < nr; ++r)
-              wsum += fast_exp(pa[r * d.max_states] + (px[r * Kmax] + corr[r]) + w + pb[r * d.max_states]);
+              wsum += fast_exp((float)(pa[r * d.max_states] + pb[r * d.max_states] + ((double)px[r * Kmax] + corr_d[r] + (double)w)));
           }
           if (wsum != 0.f) dwacc[a] += wsum;  // this thread owns dwacc[a]
         }
@@ -2374,7 +2224,7 @@ __global__ void __launch_bounds__(256)
           const int wid = u.eps_wid[e];
           if (wid < 0) continue;
           const float w = u.eps_w[e] + (weights ? nan_to_neg(weights[wid]) : 0.f);
-          const float v = al[r * d.max_states + u.eps_src[e]] + w + be[r * d.max_states + u.eps_dst[e]] + corr_eps[r];
+          const float v = (float)(ald[r * d.max_states + u.eps_src[e]] + bed[r * d.max_states + u.eps_dst[e]] + (corr_eps[r] + (double)w));
           if (v > WFL_NEG_INF) atomicAdd(&dwacc[A + e], fast_exp(v));
         }
       }
@@ -3168,7 +3018,7 @@ static int lattice_grad_impl(const wfl_lattice_desc* d, const int32_t* ints, con
                        (dx ? 8 * (size_t)d->max_arcs + 4 * (((size_t)d->max_labels + 3) & ~(size_t)1) +
                                 8 * ((size_t)d->max_labels + d->max_arcs / kChunk + 1) + 2 * (size_t)C
                           : 0) +
-                       8 * 33 + 4 * (33 + 34) + 64;  // (+ the per-row offset corrections of at most 32 + 1 rows)
+                       8 * (33 + 34) + 64;  // (+ the per-row offset corrections of at most 32 + 1 rows: doubles)
   if (dx && d->max_labels > 32767) {
     set_error("lattice_grad: %d distinct labels per utterance (limit 32767)", d->max_labels);
     return WFL_ERR_UNSUPPORTED;

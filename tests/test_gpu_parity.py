@@ -1100,7 +1100,7 @@ def test_transducer_gradient_beside_the_sweeps_under_cu_contention(crit):
 
     ref_loss, ref_dx = run()
     torch.cuda.synchronize()
-    side = torch.cuda.Stream()
+    side = _stream_that_runs_beside_the_current_one()
     a = torch.randn(8192, 8192, device="cuda")
     big = torch.empty(256 * 1024 * 1024 // 4, device="cuda")
     stop = torch.zeros((), device="cuda")
@@ -1585,6 +1585,26 @@ def test_lattice_certificate_sends_what_a_double_cannot_hold_to_the_log_domain(c
         close(dx[b], gx, rtol=2e-3 if b == 0 else 1e-4, atol=2e-3 if b == 0 else 1e-5, msg=f"utterance {b}")
 
 
+def _stream_that_runs_beside_the_current_one():
+    """HIP streams share a few hardware queues (round-robin over the streams a process has created): a new stream may sit
+    on the CURRENT stream's queue, and work queued on it then runs in front of the current stream's instead of beside it
+    (seen when this file runs inside the whole suite: the 'competing' work simply delayed the steps).  Try streams until
+    a kernel of the current stream finishes while a long one on the candidate is still running."""
+    probe = torch.zeros((), device="cuda")
+    for _ in range(8):
+        cand = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(cand):
+            torch.cuda._sleep(20_000_000)  # (10 ms at the shader clock, 0.2 s if the counter is the 100 MHz one)
+        probe += 1
+        torch.cuda.current_stream().synchronize()
+        beside = not cand.query()
+        torch.cuda.synchronize()
+        if beside:
+            return cand
+    pytest.skip("no stream that runs beside the current one (hardware queues shared)")
+
+
 def test_ctc_pipelined_step_keeps_its_forward_progress_under_cu_contention():
     """The gradient workgroups of the pipelined launch wait on flags raised by the chain workgroups of the SAME launch:
     safe only while the chains get CUs.  In data-parallel training another stream (RCCL all-reduce, the model's
@@ -1604,25 +1624,38 @@ def test_ctc_pipelined_step_keeps_its_forward_progress_under_cu_contention():
     torch.cuda.synchronize()
     assert not E.ctc_pipeline_gave_up(ws, B, T, tg.max_len)
     ref_nll, ref_loss = ref_nll.clone(), ref_loss.clone()
-    side = torch.cuda.Stream()
-    a = torch.randn(8192, 8192, device="cuda")
+    # (GEMMs of ~1.5 ms: a step's workgroups get onto the chip where the competing stream's kernels hand over; with
+    # 8192^3 GEMMs of 7 ms the steps were seen to take seconds each on a bad day -- most of the step's workgroups
+    # resident and spinning for the last few, the GEMM crawling on the CUs they left -- and the suite minutes)
+    a = torch.randn(4096, 4096, device="cuda")
     big = torch.empty(256 * 1024 * 1024 // 4, device="cuda")
     stop = torch.zeros((), device="cuda")
-    with torch.cuda.stream(side):  # ~1 s of all-CU work queued ahead: GEMMs (compute) and fills / copies (bandwidth)
-        for _ in range(60):
-            c = a @ a
-            big.copy_(big.roll(1)[: big.numel()])
-            stop += c[0, 0] * 0
-    for step in range(30):
-        dx = torch.full_like(x, float("nan"))
-        ws, nll, loss = E.ctc_forward_backward(x, tg, C - 1, coef, None, dx, loss_scale=scale, want_loss=True)
-        assert side.query() is False or step > 0, "the competing stream finished before the first step was queued"
-        torch.cuda.current_stream().synchronize()
-        assert not E.ctc_pipeline_gave_up(ws, B, T, tg.max_len), f"step {step}: a gradient wave gave up waiting"
-        assert torch.equal(nll, ref_nll) and torch.equal(loss, ref_loss) and torch.equal(dx, ref_dx), f"step {step}"
-    busy_during = not side.query()
-    torch.cuda.synchronize()
-    assert busy_during, "the competing stream did not outlast the steps: the test did not exercise contention"
+    beside = 0
+    for attempt in range(4):
+        # (HIP streams share a few hardware queues and the mapping is the runtime's: when the competing stream lands on
+        # this stream's queue its work runs IN FRONT of the steps, not beside them -- seen inside the whole suite -- and
+        # the attempt says nothing; another stream then)
+        side = _stream_that_runs_beside_the_current_one()
+        with torch.cuda.stream(side):  # ~0.4 s of all-CU work queued ahead: GEMMs (compute) and fills / copies (bandwidth)
+            for _ in range(240):
+                c = a @ a
+                big.copy_(big.roll(1)[: big.numel()])
+                stop += c[0, 0] * 0
+        beside = 0
+        for step in range(30):
+            dx = torch.full_like(x, float("nan"))
+            ws, nll, loss = E.ctc_forward_backward(x, tg, C - 1, coef, None, dx, loss_scale=scale, want_loss=True)
+            torch.cuda.current_stream().synchronize()
+            beside += not side.query()  # the step ended while the competing work was still running
+            assert not E.ctc_pipeline_gave_up(ws, B, T, tg.max_len), f"step {step}: a gradient wave gave up waiting"
+            same = (torch.equal(nll, ref_nll), torch.equal(loss, ref_loss), torch.equal(dx, ref_dx))
+            assert all(same), (f"step {step}: nll / loss / dx equal: {same}; max |dx - ref| "
+                               f"{(dx - ref_dx).abs().nan_to_num(float('inf')).max().item():.3g}, utterances that differ "
+                               f"{(dx != ref_dx).flatten(1).any(1).nonzero().flatten().tolist()[:8]}")
+        torch.cuda.synchronize()
+        if beside >= 10:
+            break
+    assert beside >= 10, f"only {beside} of 30 steps ran beside the competing stream in 4 attempts: contention not exercised"
 
 
 def test_ctc_loss_backward_without_the_engine_equals_the_engine(monkeypatch):
