@@ -436,10 +436,17 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     }
   } else {
 #ifndef WFL_MITM_NO_UNALIGNED  // (scratch: instruction counts of the aligned path alone)
+    // (rows that are not 16-byte aligned: C % 4 != 0 or an offset view.  The row stride passes through an opaque asm so
+    // that nothing of this loop is computed ahead of the emitter's block loop: unrolled and hoisted, its row offsets were
+    // ~580 SGPRs spilled to VGPR lanes in front of that loop -- in every launch, also those that never come here)
+    int Cs = C;
+    asm volatile("" : "+s"(Cs));
+#pragma unroll 1
     for (int r = 0; r < nrows; ++r) {
       const float l = LSM ? readlane_f(lse_rows, r) : 0.f;
-      for (int c = lane; c < C; c += 64)
-        dst[r * C + c] = rows[r * kMTile + c] - ((LSM && soft) ? softterm(xsrc[r * C + c], l) : 0.f);
+#pragma unroll 1
+      for (int c = lane; c < Cs; c += 64)
+        dst[r * Cs + c] = rows[r * kMTile + c] - ((LSM && soft) ? softterm(xsrc[r * Cs + c], l) : 0.f);
     }
 #endif
   }
