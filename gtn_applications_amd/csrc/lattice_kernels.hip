@@ -840,6 +840,9 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
                                double* __restrict__ dump,  // dump: kDumpDoubles doubles nobody reads
                                uint64_t* prog = nullptr, uint32_t token = 0) {
   const int tid = threadIdx.x, NT = blockDim.x;
+  // (the LDS pointers as locals: read through the struct they stayed a 48-byte object in scratch, loaded at every chunk)
+  double *const lbuf0 = L.buf0, *const lbuf1 = L.buf1;
+  float *const lrows = L.rows, *const lrefs = L.refs, *const lred = L.red;
   const int Q = u.Q, Kmax = d.max_labels;
   // ---- this thread's state: its in-arcs (forward) / out-arcs (backward) in registers
   const int32_t* ptr = DIR == 0 ? u.in_ptr : u.out_ptr;
@@ -863,7 +866,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
   }
   const int deg_class = __syncthreads_or(k1 - k0 > 4) ? 2 : (__syncthreads_or(k1 - k0 > 2) ? 1 : 0);
   const int wave_deg = wave_all_max_int(k1 - k0);  // the most arcs into (out of) a state of this wave
-  float wref = block_reduce_max(wmx, L.red);  // every frame multiplies by e^wref once more: part of the offset
+  float wref = block_reduce_max(wmx, lred);  // every frame multiplies by e^wref once more: part of the offset
   if (!(wref > WFL_NEG_INF)) wref = 0.f;
   if (wref_out && tid == 0) wref_out[b] = wref;
   double wf[kLeanDeg];  // (float exponential: the gradient kernel recomputes the same factor)
@@ -904,7 +907,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
   double p = 0.0;
   if (tid < Q) p = (DIR == 0 ? u.start_w[tid] : u.accept_w[tid]) > WFL_NEG_INF ? 1.0 : 0.0;  // (boundary weights are 0 / -inf)
   double cum = 0.0;  // log2 of everything factored out of the stored probabilities so far
-  double* cur = (t_first & 1) ? L.buf1 : L.buf0;
+  double* cur = (t_first & 1) ? lbuf1 : lbuf0;
   if (tid < Q) {
     cur[tid] = p;
     out[u.ab_base + (int64_t)t_first * Q + tid] = p;
@@ -923,7 +926,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     constexpr int RB = 16, D = kBandDepth, NV = 4;
     const int K4 = Kmax >> 2, nch = (T + RB - 1) / RB;
     constexpr int kSlot = 64 * 4 * NV;     // floats per tile (every loader lane stores its NV float4: no divergence)
-    float* ring = L.rows;                  // [2][kSlot], rows of RB * Kmax <= kSlot floats
+    float* ring = lrows;                  // [2][kSlot], rows of RB * Kmax <= kSlot floats
     float* rref = ring + 2 * kSlot;        // [2][64]: per-frame references of the chunk (first RB entries)
     auto chunk_lo = [&](int c, int n) { return DIR == 0 ? c * RB : T - c * RB - n; };  // lowest frame of chunk c
     if (tid >= 64) {
@@ -1070,15 +1073,15 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     int f0, n;
     chunk_frames(0, f0, n);
     const float* src = fg + u.xg_base + (int64_t)f0 * Kmax;
-    for (int e = tid; e < n * Kmax; e += NT) L.rows[e] = src[e];
-    if (tid < n) L.refs[tid] = rmax[(int64_t)b * T + f0 + tid];
+    for (int e = tid; e < n * Kmax; e += NT) lrows[e] = src[e];
+    if (tid < n) lrefs[tid] = rmax[(int64_t)b * T + f0 + tid];
   }
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     int f0, n;
     chunk_frames(c, f0, n);
-    const float* tile = L.rows + (size_t)(c & 1) * R * Kmax;
-    const float* rtile = L.refs + (size_t)(c & 1) * R;
+    const float* tile = lrows + (size_t)(c & 1) * R * Kmax;
+    const float* rtile = lrefs + (size_t)(c & 1) * R;
     float pre[kPre], rpre = 0.f;
     int pf0 = 0, pn = 0;
     if (c + 1 < nchunks) {
@@ -1093,11 +1096,11 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     }
     if (c > 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
       const int ex = (tid < Q && p > 0.0) ? ilogb(p) : -(1 << 30);
-      const int emax = block_reduce_max_int(ex, (int*)L.red);
+      const int emax = block_reduce_max_int(ex, (int*)lred);
       if (emax > -(1 << 30) && emax < 2000) {
         p = scalbn(p, -emax);
         cum += (double)emax;
-        double* fromb = ((DIR == 0 ? f0 : f0 + n) & 1) ? L.buf1 : L.buf0;
+        double* fromb = ((DIR == 0 ? f0 : f0 + n) & 1) ? lbuf1 : lbuf0;
         if (tid < Q) fromb[tid] = p;
       }
       __syncthreads();
@@ -1133,8 +1136,8 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         const bool mine = tid < Q;
         double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
         const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
-        const double* bA = par ? L.buf1 : L.buf0;
-        const double* bB = par ? L.buf0 : L.buf1;
+        const double* bA = par ? lbuf1 : lbuf0;
+        const double* bB = par ? lbuf0 : lbuf1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const double* from = (i & 1) ? bB : bA;
@@ -1160,8 +1163,8 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         return;
       }
       for (int i = 0; i < n; ++i) {
-        const double* from = par ? L.buf1 : L.buf0;
-        double* to = par ? L.buf0 : L.buf1;
+        const double* from = par ? lbuf1 : lbuf0;
+        double* to = par ? lbuf0 : lbuf1;
         double ps[DEG];
 #pragma unroll
         for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
@@ -1190,7 +1193,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         // beta: the LDS vector holds G = f[label(d)] * beta[d] for the frame about to be consumed; at the chunk's
         // first frame it still holds plain beta (the tile of this chunk was not there when it was written)
         const int t0 = f0 + n - 1;
-        const double* fromb = ((t0 + 1) & 1) ? L.buf1 : L.buf0;
+        const double* fromb = ((t0 + 1) & 1) ? lbuf1 : lbuf0;
         if (tid < Q) {  // (own entry only: no hazard before the write)
           double* fb = const_cast<double*>(fromb);
           fb[tid] = fb[tid] * (double)tile[(size_t)(t0 - f0) * Kmax + my_slot];
@@ -1216,8 +1219,8 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         const bool mine = tid < Q;
         double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
         const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
-        const double* bA = par ? L.buf1 : L.buf0;  // read by the even frames of the chunk, written by the odd ones
-        const double* bB = par ? L.buf0 : L.buf1;
+        const double* bA = par ? lbuf1 : lbuf0;  // read by the even frames of the chunk, written by the odd ones
+        const double* bB = par ? lbuf0 : lbuf1;
         const int fstep = DIR == 0 ? Kmax : -Kmax;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -1244,8 +1247,8 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         return;
       }
       for (int i = 0; i < n; ++i) {
-        const double* from = par ? L.buf1 : L.buf0;
-        double* to = par ? L.buf0 : L.buf1;
+        const double* from = par ? lbuf1 : lbuf0;
+        double* to = par ? lbuf0 : lbuf1;
         double ps[DEG];
 #pragma unroll
         for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
@@ -1318,13 +1321,13 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       frames(std::integral_constant<int, kLeanDeg>{});
     cum += chunk_log2;
     if (c + 1 < nchunks) {
-      float* dst = L.rows + (size_t)((c + 1) & 1) * R * Kmax;
+      float* dst = lrows + (size_t)((c + 1) & 1) * R * Kmax;
 #pragma unroll
       for (int j = 0; j < kPre; ++j) {
         const int e = tid + j * NT;
         if (e < pn * Kmax) dst[e] = pre[j];
       }
-      if (tid < pn) L.refs[(size_t)((c + 1) & 1) * R + tid] = rpre;
+      if (tid < pn) lrefs[(size_t)((c + 1) & 1) * R + tid] = rpre;
       if (PUB) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (see below)
       __syncthreads();
       // Chunk c - 1 is in L2: its stores are older than this chunk's prefetch loads and its (at most 16) frame stores,
@@ -1342,7 +1345,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
   // log2 of the total: alpha over the accept states at slot T, beta over the start states at slot 0
   {
     const float bw = tid < Q ? (DIR == 0 ? u.accept_w[tid] : u.start_w[tid]) : WFL_NEG_INF;
-    const double tot = block_reduce_sum_f64(bw > WFL_NEG_INF ? p : 0.0, (double*)L.red);
+    const double tot = block_reduce_sum_f64(bw > WFL_NEG_INF ? p : 0.0, (double*)lred);
     if (tid == 0) {
       const bool ok = tot > 0.0 && tot < 1.0e300;
       const double z2 = ok ? log2(tot) + cum : (tot == 0.0 ? -__builtin_inf() : __builtin_nan(""));
