@@ -200,6 +200,119 @@ __global__ void __launch_bounds__(256) wide_frame_kernel(const float* __restrict
   }
 }
 
+// The same frame on the matrix cores, tiled so that the launch fills the chip: the vector-pipe kernel above makes
+// 64 x 64 output tiles -- at N = 1000, B = 32 that is 16 x 1 x 2 = 32 workgroups on 256 CUs, each walking K = 1000 by
+// itself: 156 us per frame, 39 ms per step at T = 250.  Here a workgroup owns a 16-state x 16-utterance tile
+// (v_mfma_f32_16x16x4_f32), its four waves each take a quarter of K and the partial tiles meet in LDS: 63 x 2 x 2 = 252
+// workgroups at that shape, ~250 K steps of dependent products per wave instead of 1000 k-chunks behind barriers.
+// Operands straight from L2 into the products' registers (P, 4 MB, stays in L2 / MALL across the frame's workgroups): a
+// lane loads four consecutive k of its row -- lanes l and l + 16 j of a product then hold k = kb + 4 j + c for the c-th of
+// four products, the same four k on both operands, which is all the instruction asks for.
+typedef float wide_v4f __attribute__((ext_vector_type(4)));
+constexpr int kWideMfmaWaves = 8;
+__global__ void __launch_bounds__(64 * kWideMfmaWaves) wide_frame_mfma_kernel(const float* __restrict__ x, int B, int T, int C, int s,
+                                                                             WideWs w, float* __restrict__ alpha,
+                                                                             float* __restrict__ beta) {
+  const int dir = blockIdx.z;
+  if (dir == 1 && !beta) return;
+  __shared__ float part[kWideMfmaWaves - 1][64][4];
+  const int i0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+  const int t = dir == 0 ? s : T - 1 - s;   // the frame being produced
+  const int tp = dir == 0 ? t - 1 : t + 1;  // the frame it is produced from
+  const float* A = dir == 0 ? w.P : w.PT;
+  const float* vec = dir == 0 ? alpha : beta;
+  const float* vmax = dir == 0 ? w.maxa : w.maxb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;  // operand row (state / utterance) and k group of this lane
+  const int ai = min(i0 + lr, C - 1), bn = min(n0 + lr, B - 1);
+  const bool a_ok = i0 + lr < C, b_ok = n0 + lr < B;
+  // A workgroup is one dependent chain -- loads, products, reduction, store -- with nothing else on its CU to hide a
+  // round trip behind (252 workgroups at N = 1000, B = 32): EVERY load of the chain is issued up front, the operands of
+  // all of a wave's K steps and what the epilogue multiplies with, so that the chain pays one round trip, not five.
+  const float mx = vmax[(int64_t)bn * T + tp];   // the utterance's scale (lane's column of the OUTPUT tile too)
+  const float bref = w.mxp[(int64_t)bn * T + tp];
+  const int64_t orow = (int64_t)bn * T + t;
+  const float oref = dir == 0 ? w.mxp[orow] : 0.f;
+  float ox[4], orm[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int i = min(i0 + 4 * lg + v, C - 1);
+    ox[v] = dir == 0 ? x[orow * C + i] : 0.f;
+    orm[v] = dir == 0 ? w.rm[i] : 0.f;
+  }
+  const float* arow = A + (int64_t)ai * C;
+  const float* brow = vec + ((int64_t)bn * T + tp) * C;
+  const float* xrow = x + ((int64_t)bn * T + tp) * C;
+  const int nsteps = (C + 15) / 16;  // K in steps of 16 (four products); the waves take interleaved steps
+  const bool vec4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(vec) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(A)) & 15) == 0;
+  auto load4 = [&](const float* row, int k) -> wide_v4f {  // row[k .. k+3], zeros beyond C
+    if (vec4) {
+      if (k + 3 < C) {
+        const float4 q = *reinterpret_cast<const float4*>(row + k);
+        return wide_v4f{q.x, q.y, q.z, q.w};
+      }
+      return wide_v4f{0.f, 0.f, 0.f, 0.f};  // (C % 4 == 0: a group of four is inside or outside)
+    }
+    wide_v4f r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = k + c < C ? row[k + c] : 0.f;
+    return r;
+  };
+  wide_v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // (two chains of dependent products)
+  constexpr int kU = 8;  // steps per trip: one trip up to N = 1024
+  for (int st0 = wave; st0 < nsteps; st0 += kWideMfmaWaves * kU) {
+    wide_v4f av[kU], bv[kU], xv[kU], rv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int k = (st0 + kWideMfmaWaves * u) * 16 + 4 * lg;  // (steps past the end: k >= C, zeros)
+      av[u] = load4(arow, k), bv[u] = load4(brow, k);
+      if (dir == 1) xv[u] = load4(xrow, k), rv[u] = load4(w.rm, k);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int k = (st0 + kWideMfmaWaves * u) * 16 + 4 * lg;
+      if (!a_ok) av[u] = wide_v4f{0.f, 0.f, 0.f, 0.f};
+      if (dir == 1) {  // e_{t+1} (.) beta_{t+1}
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bv[u][c] *= k + c < C ? __expf(wide_clean(xv[u][c]) + rv[u][c] - bref) : 0.f;
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bv[u][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bv[u][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], bv[u][2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][3], bv[u][3], acc1, 0, 0, 0);
+    }
+  }
+  wide_v4f acc = acc0 + acc1;
+  // acc[v]: state i0 + 4 lg + v, utterance n0 + lr.  The other waves hand their partial tiles to wave 0.
+  if (wave > 0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[wave - 1][lane][v] = acc[v];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int q = 0; q < kWideMfmaWaves - 1; ++q)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] += part[q][lane][v];
+  const float binv = (b_ok && mx > 0.f) ? 1.f / mx : 0.f;  // (the operand's scale, applied to the lane's output column)
+  float top = 0.f;
+  if (b_ok) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = i0 + 4 * lg + v;
+      if (i >= C) continue;
+      float y = acc[v] * binv;
+      if (dir == 0) y *= __expf(wide_clean(ox[v]) + orm[v] - oref);
+      (dir == 0 ? alpha : beta)[orow * C + i] = y;
+      top = fmaxf(top, y);
+    }
+  }
+  // (lanes lr, lr + 16, lr + 32, lr + 48 share the utterance)
+  top = fmaxf(top, __shfl_xor(top, 16, 64));
+  top = fmaxf(top, __shfl_xor(top, 32, 64));
+  if (lg == 0 && b_ok && top > 0.f) atomic_max_pos((dir == 0 ? w.maxa : w.maxb) + orow, top);
+}
+
 // per utterance: the cumulative offsets (a serial scan over T by one thread) and log Z
 __global__ void __launch_bounds__(256) wide_scan_kernel(int B, int T, int C, WideWs w, const float* __restrict__ alpha,
                                                         bool with_beta, float* __restrict__ logz) {
@@ -435,8 +548,18 @@ static int wide_forward(const float* x, const float* W, int B, int T, int C, int
   hipLaunchKernelGGL(wide_prep_kernel, dim3((unsigned)C), dim3(256), 0, st, W, C, w);
   hipLaunchKernelGGL(wide_rows_kernel, dim3((unsigned)(((int64_t)B * T + 3) / 4)), dim3(256), 0, st, x, W, B, T, C, w, alpha,
                      beta);
-  const dim3 grid(tiles.x, tiles.y, beta ? 2u : 1u);
-  for (int s = 1; s < T; ++s) hipLaunchKernelGGL(wide_frame_kernel, grid, dim3(256), 0, st, x, B, T, C, s, w, alpha, beta);
+  static const bool use_mfma = [] {
+    const char* e = getenv("WFL_DENSE_WIDE_MFMA");  // 0: the vector-pipe frame kernel (A/B, tests)
+    return !(e && atoi(e) == 0);
+  }();
+  if (use_mfma) {
+    const dim3 grid((unsigned)((C + 15) / 16), (unsigned)((B + 15) / 16), beta ? 2u : 1u);
+    for (int s = 1; s < T; ++s)
+      hipLaunchKernelGGL(wide_frame_mfma_kernel, grid, dim3(64 * kWideMfmaWaves), 0, st, x, B, T, C, s, w, alpha, beta);
+  } else {
+    const dim3 grid(tiles.x, tiles.y, beta ? 2u : 1u);
+    for (int s = 1; s < T; ++s) hipLaunchKernelGGL(wide_frame_kernel, grid, dim3(256), 0, st, x, B, T, C, s, w, alpha, beta);
+  }
   hipLaunchKernelGGL(wide_scan_kernel, dim3((unsigned)B), dim3(256), 0, st, B, T, C, w, alpha, beta != nullptr, logz);
   return WFL_OK;
 }
