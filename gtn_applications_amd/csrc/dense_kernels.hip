@@ -27,13 +27,27 @@ namespace wfl {
 
 struct DenseLds {
   float* W;    // [(C+1) * ldw]
-  float* a0;   // [C]
-  float* a1;   // [C]
+  void* a0;    // [C] state vector: double in the log semiring, float in the tropical one (DenseVal)
+  void* a1;    // [C]
   float* x0;   // [C]
   float* x1;   // [C]
-  float* pm;   // [R*C] partial max
+  void* pm;    // [R*C] partial max (DenseVal)
   float* ps;   // [R*C] partial sum (or arg for tropical)
-  float* red;  // [64]
+  float* red;  // [2][32] (reductions; the frames' maxima, double-buffered)
+};
+// State values of the generic dense sweep.  Log semiring: DOUBLE in LDS -- the scores reach thousands at T = 1000, where a
+// float resolves 2.4e-4, and that resolution was paid at every add of the recursion and again in alpha + beta - log Z
+// (measured 1.0 .. 2.5e-4 on the posteriors).  What goes to HBM stays float: the frame's vector RELATIVE to the largest
+// state of the frame before (a double per frame in the workspace, DenseWs::M) -- values of a few tens at most, and the
+// gradient kernel adds the two frame references and log Z (DenseWs::z2, a double) in double.  Tropical: float throughout
+// (sums and comparisons of the caller's floats: ties stay ties), raw scores.
+template <int SR>
+struct DenseVal {
+  using type = float;
+};
+template <>
+struct DenseVal<WFL_SEMIRING_LOG> {
+  using type = double;
 };
 
 __device__ __forceinline__ float blk_max(float v, float* red) {
@@ -60,19 +74,36 @@ __device__ __forceinline__ float blk_sum(float v, float* red) {
 // DIR 0: alpha sweep, DIR 1: beta sweep.  SR tropical only for DIR 0 (writes back-pointers).
 template <int SR, int DIR>
 __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int b, int T, int C, int ldw,
-                            float* __restrict__ out, int32_t* __restrict__ bptr, float* __restrict__ logz) {
+                            float* __restrict__ out, int32_t* __restrict__ bptr, float* __restrict__ logz,
+                            double* __restrict__ Mref, double* __restrict__ z64) {
+  using VT = typename DenseVal<SR>::type;
+  constexpr bool kLog = SR == WFL_SEMIRING_LOG;
+  VT* const a0 = reinterpret_cast<VT*>(L.a0);
+  VT* const a1 = reinterpret_cast<VT*>(L.a1);
+  VT* const pmv = reinterpret_cast<VT*>(L.pm);
   const int tid = threadIdx.x, NT = blockDim.x;
+  const int lane = tid & 63, wv = tid >> 6, nwv = (NT + 63) >> 6;
+  double ref = 0.0;  // what the frame's stored values are relative to (log semiring): the previous frame's largest state
   const int R = C <= NT ? NT / C : 1;       // partial reductions per state
   const int span = (C + R - 1) / R;         // terms per partial
   const float* xb = x + (int64_t)b * T * C;
   float* ob = out + (int64_t)b * T * C;
   const int t0 = DIR == 0 ? 0 : T - 1;
-  float* cur = (t0 & 1) ? L.a1 : L.a0;
-  for (int i = tid; i < C; i += NT) {
-    const float v = DIR == 0 ? nan_to_neg(xb[i]) + L.W[i] : 0.f;
-    cur[i] = v;
-    ob[(int64_t)t0 * C + i] = v;
-    if (SR == WFL_SEMIRING_TROPICAL) bptr[(int64_t)b * T * C + i] = -1;
+  VT* cur = (t0 & 1) ? a1 : a0;
+  {
+    float top = WFL_NEG_INF;
+    for (int i = tid; i < C; i += NT) {
+      const float v = DIR == 0 ? nan_to_neg(xb[i]) + L.W[i] : 0.f;
+      cur[i] = (VT)v;
+      ob[(int64_t)t0 * C + i] = v;  // (relative to ref = 0)
+      top = fmaxf(top, v);
+      if (SR == WFL_SEMIRING_TROPICAL) bptr[(int64_t)b * T * C + i] = -1;
+    }
+    if (kLog) {
+      top = wave_max(top);
+      if (lane == 0) L.red[(t0 & 1) * 32 + wv] = top;
+      if (tid == 0 && Mref) Mref[t0] = 0.0;
+    }
   }
   if (DIR == 1 && T > 0)  // the beta sweep consumes x[t+1]; stage row T-1 for the first step
     for (int i = tid; i < C; i += NT) (((T - 1) & 1) ? L.x1 : L.x0)[i] = nan_to_neg(xb[(int64_t)(T - 1) * C + i]);
@@ -107,8 +138,8 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
   for (int step = 1; step < T; ++step) {
     const int t = DIR == 0 ? step : T - 1 - step;       // slot being produced
     const int tf = DIR == 0 ? t - 1 : t + 1;            // slot read
-    const float* from = (tf & 1) ? L.a1 : L.a0;
-    float* to = (t & 1) ? L.a1 : L.a0;
+    const VT* from = (tf & 1) ? a1 : a0;
+    VT* to = (t & 1) ? a1 : a0;
     const int tx = DIR == 0 ? t : t + 1;                // emissions row used by this step
     const float* xr = (tx & 1) ? L.x1 : L.x0;
     const int txn = DIR == 0 ? t + 1 : t;               // row the next step needs
@@ -131,13 +162,13 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
       // slice carries wr = -inf: never the maximum, exp(-inf) = 0.  The trip count is the slice rounded up to 16 / 32 / 64.)
       auto partials = [&](auto bucket) {
         constexpr int S = decltype(bucket)::value;
-        const float* fp = from + wj0;
+        const VT* fp = from + wj0;
         const float* xp = xr + wj0;
-        float m = WFL_NEG_INF;
+        VT m = WFL_NEG_INF;
         int am = -1;
 #pragma unroll
         for (int jj = 0; jj < S; ++jj) {
-          const float v = DIR == 0 ? fp[jj] + wr[jj] : wr[jj] + xp[jj] + fp[jj];
+          const VT v = DIR == 0 ? fp[jj] + (VT)wr[jj] : (VT)wr[jj] + (VT)xp[jj] + fp[jj];
           if (v > m) m = v, am = jj;
         }
         if (am >= 0) am += wj0;
@@ -145,11 +176,11 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
         if (SR == WFL_SEMIRING_LOG && m > WFL_NEG_INF) {
 #pragma unroll
           for (int jj = 0; jj < S; ++jj) {
-            const float v = DIR == 0 ? fp[jj] + wr[jj] : wr[jj] + xp[jj] + fp[jj];
-            sum += fast_exp(v - m);
+            const VT v = DIR == 0 ? fp[jj] + (VT)wr[jj] : (VT)wr[jj] + (VT)xp[jj] + fp[jj];
+            sum += fast_exp((float)(v - m));
           }
         }
-        L.pm[tid] = m;
+        pmv[tid] = m;
         L.ps[tid] = SR == WFL_SEMIRING_LOG ? sum : __int_as_float(am);
       };
       if (tid < R * C) {
@@ -164,19 +195,19 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
     for (int idx = tid; idx < R * C; idx += NT) {
       const int s = idx % C, r = idx / C;  // s: state being produced, r: which slice of the other index
       const int j0 = r * span, j1 = min(C, j0 + span);
-      float m = WFL_NEG_INF;
+      VT m = WFL_NEG_INF;
       int am = -1;
       for (int j = j0; j < j1; ++j) {
-        const float v = DIR == 0 ? from[j] + L.W[(1 + s) * ldw + j] : L.W[(1 + j) * ldw + s] + xr[j] + from[j];
+        const VT v = DIR == 0 ? from[j] + (VT)L.W[(1 + s) * ldw + j] : (VT)L.W[(1 + j) * ldw + s] + (VT)xr[j] + from[j];
         if (v > m) m = v, am = j;
       }
       float sum = 0.f;
       if (SR == WFL_SEMIRING_LOG && m > WFL_NEG_INF)
         for (int j = j0; j < j1; ++j) {
-          const float v = DIR == 0 ? from[j] + L.W[(1 + s) * ldw + j] : L.W[(1 + j) * ldw + s] + xr[j] + from[j];
-          sum += fast_exp(v - m);
+          const VT v = DIR == 0 ? from[j] + (VT)L.W[(1 + s) * ldw + j] : (VT)L.W[(1 + j) * ldw + s] + (VT)xr[j] + from[j];
+          sum += fast_exp((float)(v - m));
         }
-      L.pm[idx] = m;
+      pmv[idx] = m;
       L.ps[idx] = SR == WFL_SEMIRING_LOG ? sum : __int_as_float(am);
     }
     lds_barrier();
@@ -193,42 +224,57 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
 #pragma unroll
     for (int j = 0; j < 4; ++j) pre[j] = pre2[j];
     // ---- merge partials, add the emission (alpha only), publish
+    if (kLog) {  // this frame's reference: the largest state of the frame before (its waves' maxima, left before the last barrier)
+      float rf = L.red[(tf & 1) * 32];
+      for (int q = 1; q < nwv; ++q) rf = fmaxf(rf, L.red[(tf & 1) * 32 + q]);
+      ref = (rf > WFL_NEG_INF && rf < __builtin_inff()) ? (double)rf : 0.0;
+      if (tid == 0 && Mref) Mref[t] = ref;
+    }
+    float top = WFL_NEG_INF;
     for (int s = tid; s < C; s += NT) {
-      float m = L.pm[s];
+      VT m = pmv[s];
       int am = SR == WFL_SEMIRING_LOG ? 0 : __float_as_int(L.ps[s]);
       for (int r = 1; r < R; ++r) {
-        const float v = L.pm[r * C + s];
+        const VT v = pmv[r * C + s];
         if (v > m) {
           m = v;
           if (SR != WFL_SEMIRING_LOG) am = __float_as_int(L.ps[r * C + s]);
         }
       }
-      float val = m;
+      VT val = m;
       if (SR == WFL_SEMIRING_LOG && m > WFL_NEG_INF) {
         float sum = 0.f;
-        for (int r = 0; r < R; ++r) sum += L.ps[r * C + s] * fast_exp(L.pm[r * C + s] - m);
-        val = m + fast_log(sum);
+        for (int r = 0; r < R; ++r) sum += L.ps[r * C + s] * fast_exp((float)(pmv[r * C + s] - m));
+        val = m + (VT)log((double)sum);
       }
-      if (DIR == 0) val += xr[s];
+      if (DIR == 0) val += (VT)xr[s];
       to[s] = val;
-      ob[(int64_t)t * C + s] = val;
+      ob[(int64_t)t * C + s] = (float)(val - (VT)ref);
+      top = fmaxf(top, (float)val);
       if (SR == WFL_SEMIRING_TROPICAL) bptr[((int64_t)b * T + t) * C + s] = am;
+    }
+    if (kLog) {
+      top = wave_max(top);
+      if (lane == 0) L.red[(t & 1) * 32 + wv] = top;
     }
     lds_barrier();
   }
   if (DIR == 0 && logz && T > 0) {
-    const float* fin = ((T - 1) & 1) ? L.a1 : L.a0;
+    const VT* fin = ((T - 1) & 1) ? a1 : a0;
     float m = WFL_NEG_INF;
-    for (int i = tid; i < C; i += NT) m = fmaxf(m, fin[i]);
+    for (int i = tid; i < C; i += NT) m = fmaxf(m, (float)fin[i]);
     m = blk_max(m, L.red);
-    float z = m;
+    double z = m;
     if (SR == WFL_SEMIRING_LOG && m > WFL_NEG_INF) {
       float s = 0.f;
-      for (int i = tid; i < C; i += NT) s += fast_exp(fin[i] - m);
+      for (int i = tid; i < C; i += NT) s += fast_exp((float)(fin[i] - (VT)m));
       s = blk_sum(s, L.red);
-      z = m + fast_log(s);
+      z = (double)m + log((double)s);
     }
-    if (tid == 0) logz[b] = z;
+    if (tid == 0) {
+      logz[b] = (float)z;
+      if (kLog && z64) *z64 = z;  // ln Z for the log-domain gradient (DenseWs::z2 holds log2 Z for the others)
+    }
   }
 }
 
@@ -236,34 +282,41 @@ template <int SR>
 __global__ void __launch_bounds__(256)
     dense_chain_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, int ldw,
                        float* __restrict__ alpha, float* __restrict__ beta, int32_t* __restrict__ bptr,
-                       float* __restrict__ logz, const int32_t* __restrict__ only_flagged) {
+                       float* __restrict__ logz, const int32_t* __restrict__ only_flagged, double* __restrict__ Mws,
+                       double* __restrict__ z2ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
   if (only_flagged && !(only_flagged[2 * b] | only_flagged[2 * b + 1])) return;  // served by the fast sweep
   const int R = C <= NT ? NT / C : 1;
   DenseLds L;
-  float* p = (float*)smem;
-  L.W = p, p += (size_t)(C + 1) * ldw;
   constexpr int kPad = 64;  // (dense_chain reads up to kSpanRegs terms past the vectors' ends: zeros)
-  L.a0 = p, p += C + kPad;
-  L.a1 = p, p += C + kPad;
+  // (the arrays that hold doubles in the log semiring first: 8-byte aligned whatever (C+1) * ldw is)
+  double* pd = (double*)smem;
+  L.a0 = pd, pd += C + kPad;
+  L.a1 = pd, pd += C + kPad;
+  L.pm = pd, pd += (size_t)R * C;
+  float* p = (float*)pd;
+  L.W = p, p += (size_t)(C + 1) * ldw;
   L.x0 = p, p += C + kPad;
   L.x1 = p, p += C + kPad;
-  for (int i = tid; i < kPad; i += NT) L.a0[C + i] = L.a1[C + i] = L.x0[C + i] = L.x1[C + i] = 0.f;
-  L.pm = p, p += (size_t)R * C;
+  for (int i = tid; i < kPad; i += NT) L.x0[C + i] = L.x1[C + i] = 0.f;
+  // (the state vectors: zeros throughout -- their padding is read whether they hold C doubles or C floats)
+  for (int i = tid; i < 2 * (C + kPad); i += NT) ((float*)L.a0)[i] = ((float*)L.a1)[i] = 0.f;
   L.ps = p, p += (size_t)R * C;
   L.red = p;
   for (int i = tid; i < (C + 1) * C; i += NT) L.W[(i / C) * ldw + (i % C)] = nan_to_neg(W[i]);
   __syncthreads();
+  // (log semiring: the frames' references go to DenseWs::M [B][2][T], ln Z to DenseWs::z2 -- see DenseVal)
   if (dir == 0)
-    dense_chain<SR, 0>(L, x, b, T, C, ldw, alpha, bptr, logz);
+    dense_chain<SR, 0>(L, x, b, T, C, ldw, alpha, bptr, logz, Mws ? Mws + (int64_t)b * 2 * T : nullptr, z2ws ? z2ws + b : nullptr);
   else
-    dense_chain<WFL_SEMIRING_LOG, 1>(L, x, b, T, C, ldw, beta, nullptr, nullptr);
+    dense_chain<WFL_SEMIRING_LOG, 1>(L, x, b, T, C, ldw, beta, nullptr, nullptr, Mws ? Mws + (int64_t)b * 2 * T + T : nullptr, nullptr);
 }
 
 static size_t dense_chain_lds(int C, int ldw) {
   const int R = C <= 256 ? 256 / C : 1;
-  return 4 * ((size_t)(C + 1) * ldw + 4 * ((size_t)C + 64) + 2 * (size_t)R * C + 64) + 64;
+  // (a0, a1, pm sized for doubles)
+  return 4 * ((size_t)(C + 1) * ldw + 6 * ((size_t)C + 64) + 3 * (size_t)R * C + 64) + 64;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -275,17 +328,23 @@ __global__ void __launch_bounds__(256)
                       const float* __restrict__ alpha, const float* __restrict__ beta, const float* __restrict__ logz,
                       const float* __restrict__ coef, const float* __restrict__ coef_w, const float* __restrict__ gout,
                       int accumulate, const float* __restrict__ addend, float* __restrict__ dx,
-                      float* __restrict__ partial, int rows_per_block, const int32_t* __restrict__ only_flagged) {
+                      float* __restrict__ partial, int rows_per_block, const int32_t* __restrict__ only_flagged,
+                      const double* __restrict__ Mws, const double* __restrict__ z2ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* ap = (float*)smem;  // [C] alpha_{t-1}
-  float* xb = ap + C;        // [C] x_t + beta_t - logZ
+  float* ap = (float*)smem;  // [C] alpha_{t-1} (relative to its frame's reference)
+  float* xb = ap + C;        // [C] x_t + beta_t + (the references of alpha_{t-1} and beta_t - ln Z)
   const int b = blockIdx.y, tid = threadIdx.x, NT = 256;
   if (only_flagged && !(only_flagged[2 * b] | only_flagged[2 * b + 1])) return;
   const float g0 = gout ? gout[0] : 1.f;
   const float cf = (coef ? coef[b] : 1.f) * g0;
   const float cw = (coef_w ? coef_w[b] : 1.f) * g0;
-  const float z = logz[b];
-  const bool dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());
+  const float zf = logz[b];
+  const bool dead = !(zf > WFL_NEG_INF) || !(zf < __builtin_inff());
+  // alpha, beta: floats relative to a double per frame (DenseWs::M, written by dense_chain), ln Z a double: the three
+  // are thousands apart at T = 1000, their sum is formed in double and only then rounded
+  const double* Ma = Mws + (int64_t)b * 2 * T;
+  const double* Mb = Ma + T;
+  const double zd = dead ? 0.0 : z2ws[b];
   const int t_begin = blockIdx.x * rows_per_block, t_end = min(T, t_begin + rows_per_block);
   const int npairs = C * C;
   const int64_t base = (int64_t)b * T * C;
@@ -304,16 +363,18 @@ __global__ void __launch_bounds__(256)
   }
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
+    const float k_post = (float)(Ma[t] + Mb[t] - zd);                  // alpha_t + beta_t - ln Z
+    const float k_pair = (float)(Ma[t > 0 ? t - 1 : 0] + Mb[t] - zd);  // alpha_{t-1} + ... + beta_t - ln Z
     for (int i = tid; i < C; i += NT) {
       const float a = alpha[base + (int64_t)t * C + i], be = beta[base + (int64_t)t * C + i];
       if (dx && first_pass) {
-        const float post = dead ? 0.f : fast_exp(a + be - z);
+        const float post = dead ? 0.f : fast_exp(a + be + k_post);
         const int64_t o = base + (int64_t)t * C + i;
         dx[o] = (accumulate ? dx[o] : 0.f) + (addend ? g0 * addend[o] : 0.f) + cf * (post == post ? post : 0.f);
       }
       if (partial) {
         ap[i] = t > 0 ? alpha[base + (int64_t)(t - 1) * C + i] : WFL_NEG_INF;
-        xb[i] = nan_to_neg(x[base + (int64_t)t * C + i]) + be - z;
+        xb[i] = nan_to_neg(x[base + (int64_t)t * C + i]) + be + k_pair;
       }
     }
     if (!partial) continue;
@@ -333,7 +394,7 @@ __global__ void __launch_bounds__(256)
       for (int i = tid; i < C; i += NT) {
         float v = 0.f;
         if (t_begin == 0 && !dead) {
-          const float p = fast_exp(alpha[base + i] + beta[base + i] - z);
+          const float p = fast_exp(alpha[base + i] + beta[base + i] + (float)(Ma[0] + Mb[0] - zd));
           v = (p == p) ? p * cw : 0.f;
         }
         dst[i] = v;
@@ -1332,7 +1393,7 @@ int wfl_dense_forward_parts(const float* x, const float* W, int B, int T, int C,
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)k, (int)lds));
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, x, W, T, C, ldw, alpha, beta, (int32_t*)nullptr, logz,
-                       cp ? (const int32_t*)w.flag : (const int32_t*)nullptr);
+                       cp ? (const int32_t*)w.flag : (const int32_t*)nullptr, w.M, w.z2);
   } else {
     if (!bptr) {
       set_error("dense_forward: tropical semiring needs a back-pointer buffer");
@@ -1342,7 +1403,7 @@ int wfl_dense_forward_parts(const float* x, const float* W, int B, int T, int C,
     if (lds > 48 * 1024)
       WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)k, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)B, 1u), dim3(256), lds, st, x, W, T, C, ldw, alpha, (float*)nullptr, bptr,
-                       logz, (const int32_t*)nullptr);
+                       logz, (const int32_t*)nullptr, (double*)nullptr, (double*)nullptr);
   }
   WFL_LAUNCH_CHECK();
   return WFL_OK;
@@ -1396,7 +1457,8 @@ int wfl_dense_grad_parts(const float* x, const float* W, int B, int T, int C, co
   dim3 grid((unsigned)chunks, (unsigned)B);
   float* part = dW ? dW_partial : nullptr;
   const int cp = dense_fast_cp(C);
-  const int32_t* flags = cp ? dense_ws_carve(const_cast<void*>(ws), B, T).flag : nullptr;
+  const DenseWs gws = dense_ws_carve(const_cast<void*>(ws), B, T);
+  const int32_t* flags = cp ? gws.flag : nullptr;
 #define WFL_FAST_GRAD(CP)                                                                                       \
   hipLaunchKernelGGL((dense_fast_grad_kernel<CP, grad_stage<CP>()>), grid, dim3(((CP / 8) * (CP / 8) + 63) / 64 * 64), 0, st, \
                      x, W, T, C, B, alpha, beta, ws, coef, coef_w, gout, accumulate, addend, dx, part, rows)
@@ -1423,7 +1485,7 @@ int wfl_dense_grad_parts(const float* x, const float* W, int B, int T, int C, co
   // log-domain gradient for what the fast sweeps did not serve
 #define WFL_DENSE_GRAD(NP)                                                                                 \
   hipLaunchKernelGGL(dense_grad_kernel<NP>, grid, dim3(256), lds, st, x, W, T, C, alpha, beta, logz, coef, \
-                     coef_w, gout, accumulate, addend, dx, part, rows, flags)
+                     coef_w, gout, accumulate, addend, dx, part, rows, flags, gws.M, gws.z2)
   if (!repair_part) {
   } else if (np <= 4)
     WFL_DENSE_GRAD(4);

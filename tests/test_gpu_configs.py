@@ -252,6 +252,36 @@ def test_cfg3_asg_every_utterance():
     check("cfg3_asg_dx_mean", xg2.grad.cpu().numpy(), want_dx / L, 1.0 / (L * B))
 
 
+def test_asg_at_benchmark_length_with_a_forbidden_transition():
+    """A transition of -1e4 (a forbidden label bigram; -inf likewise) is outside what the probability-domain dense sweeps represent:
+    every utterance then takes the log-domain launches (dense_chain_kernel / dense_grad_kernel, csrc/dense_kernels.hip)
+    -- doubles in LDS, frames stored relative to a double per frame, alpha + beta - ln Z summed in double.  At the
+    benchmark's T = 1000, C = 100, every utterance of a batch of 16 against the float64 oracle, at the common bar
+    (asg.py:54-69,100-139; until round 4 these launches were plain fp32 log-adds: 1.0 .. 2.5e-4 of the coefficient)."""
+    from gtn_applications_amd import engine as E
+    from gtn_applications_amd.criterions import asg
+
+    B, T, C, L = 16, 1000, 100, 44
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, T, C, generator=g)
+    W = torch.randn(C + 1, C, generator=g)
+    W[1 + 5, 7] = -1.0e4  # label 7 never directly before label 5 (as good as -inf; the batched oracle wants finite scores)
+    targets = torch.randint(C - 2, (B, L), generator=g)
+    targets[targets == 5] = 9  # (the targets do not ask for it)
+    targets = targets.tolist()
+    want_loss, want_dx, want_dW = OR.asg_loss_grad_batched(x.numpy(), W.numpy(), targets)
+    st = E.dense_forward(x.cuda(), W.cuda())
+    assert bool(E.dense_flagged(st).all().item())  # the log-domain launches served the batch
+    xg, Wg = x.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
+    loss = asg.ASGLoss(xg, Wg, targets)
+    loss.backward()
+    assert loss.item() == pytest.approx(want_loss.mean(), rel=RTOL)
+    check("asg_forbidden_transition_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / B)
+    dW = Wg.grad.cpu().numpy()
+    assert dW[1 + 5, 7] == 0.0
+    check("asg_forbidden_transition_dW", dW, want_dW, 1.0 / B)
+
+
 def _word_piece_setup():
     with open(os.path.join(ROOT, "tests", "golden", "word_pieces_tokens_1000.txt")) as fid:
         tokens = sorted(l.strip() for l in fid)
