@@ -1313,14 +1313,19 @@ static int dense_check(const float* x, const float* W, int B, int T, int C, cons
 // transition matrix is private to a workgroup (LDS / registers); beyond, the frame update of the whole batch is a
 // tiled matrix product with the matrix streamed from L2 (dense_wide.h) -- asg.py:198-199 has no limit.
 extern "C" int wfl_dense_max_classes(void) { return kDenseMaxClasses; }
-extern "C" int wfl_dense_on_chip_classes(void) {
-  int c = 1;
-  while (dense_on_chip(c + 1)) ++c;
-  return c;
-}
-
 // smallest instantiated padded class count >= C (0: no fast path)
 static int dense_fast_cp(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 104 ? 104 : C <= 128 ? 128 : 0; }
+// Log semiring: a workgroup keeps the matrix to itself only where the register-resident probability-domain sweeps exist
+// (up to 128 classes; the LDS-resident log-domain kernels then serve what those flag).  From 129 classes on the frame of
+// the whole batch is dense_wide.h's product on the matrix cores: at N = 150, B = 128, T = 1000 a step takes 16.7 ms there
+// against 33.6 ms with one LDS-resident log-domain workgroup per utterance (Viterbi stays on chip up to
+// 195 classes, what the LDS holds: 9.6 against 44 ms, the tropical frame has no matrix-core form).
+static bool dense_log_on_chip(int C) { return dense_fast_cp(C) != 0; }
+extern "C" int wfl_dense_on_chip_classes(void) {  // (the log semiring's limit: what sizes wfl_dense_workspace)
+  int c = 1;
+  while (dense_log_on_chip(c + 1)) ++c;
+  return c;
+}
 
 int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int semiring, float* alpha, float* beta,
                       int32_t* bptr, float* logz, void* ws, void* stream) {
@@ -1335,10 +1340,11 @@ int wfl_dense_forward_parts(const float* x, const float* W, int B, int T, int C,
     set_error("dense_forward: alpha is required");
     return WFL_ERR_INVALID;
   }
-  if (!dense_on_chip(C) || semiring != WFL_SEMIRING_LOG) {
+  const bool wide = semiring == WFL_SEMIRING_LOG ? !dense_log_on_chip(C) : !dense_on_chip(C);
+  if (wide || semiring != WFL_SEMIRING_LOG) {
     if (!main_part) return WFL_OK;  // (one piece: it goes with the main part)
   }
-  if (!dense_on_chip(C)) {
+  if (wide) {
     if (semiring == WFL_SEMIRING_LOG ? (!ws || !logz) : !bptr) {
       set_error("dense_forward: missing buffers (log: logz + workspace, tropical: back-pointers)");
       return WFL_ERR_INVALID;
@@ -1414,7 +1420,7 @@ int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws
     set_error("dense_workspace: bad arguments");
     return WFL_ERR_INVALID;
   }
-  if (!dense_on_chip(C)) {
+  if (!dense_log_on_chip(C)) {
     if (partial_elems) *partial_elems = (int64_t)kWideSplit * C * C;
     if (ws_bytes) *ws_bytes = (int64_t)wide_ws_bytes(B, T, C);
     return WFL_OK;
@@ -1443,7 +1449,7 @@ int wfl_dense_grad_parts(const float* x, const float* W, int B, int T, int C, co
     return WFL_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (!dense_on_chip(C)) {
+  if (!dense_log_on_chip(C)) {
     if (!main_part) return WFL_OK;  // (one piece: it goes with the main part)
     const int rc = wide_grad(x, B, T, C, alpha, beta, logz, coef, coef_w, gout, accumulate, addend, dW_addend, dx, dW,
                              dW_partial, ws, st);

@@ -300,9 +300,11 @@ int wfl_debug_grad_occupancy(int lds_bytes);
  * (per-frame scale bookkeeping of the probability-domain sweeps, per-utterance range flags). */
 int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws_bytes);
 /* Largest C the dense-transition entry points accept (asg.py:191-209 has no limit: 16384 is an index-width bound).  Up
- * to wfl_dense_on_chip_classes() (about 190 on gfx950) the (C+1) x C matrix is private to a workgroup; beyond, the frame
- * update of the whole batch runs as one tiled matrix product per frame with the matrix streamed from L2
- * (csrc/dense_wide.h): same entry points, same buffers (sizes from wfl_dense_workspace). */
+ * to wfl_dense_on_chip_classes() (128) the (C+1) x C matrix is private to a workgroup -- registers for the
+ * probability-domain sweeps, LDS for the log-domain launches behind them; beyond, the frame update of the whole batch
+ * runs as one tiled matrix product per frame on the matrix cores, the matrix streamed from L2 (csrc/dense_wide.h): same
+ * entry points, same buffers (sizes from wfl_dense_workspace).  wfl_dense_viterbi keeps the matrix in LDS up to 195
+ * classes (the max-plus frame has no matrix-core form) and takes the tiled per-frame launch beyond. */
 int wfl_dense_max_classes(void);
 int wfl_dense_on_chip_classes(void);
 /* forward_score(intersect(emissions, transitions)) (asg.py:114): logz [B]; alpha, beta [B,T,C] are
