@@ -7,6 +7,7 @@ transducer.py:265-281) runs in the C++ host library; everything that touches the
 -- `intersect(emissions, .)`, `forward_score`, `viterbi_path`, `backward`
 (transducer.py:283-288,321-336,216-221) -- runs on the lattice engine kernels.
 """
+import ctypes
 import itertools
 import os
 
@@ -335,6 +336,25 @@ def _transitions_pack(transitions, B, C, device):
     return _PACK_CACHE.get(key, build)[0]
 
 
+_NODE = False
+_PHASES = ("lattice_gather", "lattice_chain", "lattice_grad")
+
+
+def _native_node():
+    """csrc/torch_ops.cpp (the step's launches in one native call), or None if the extension was not built /
+    WFL_TRANSDUCER_NATIVE=0 (A/B, tests: the Python spelling of the same sequence)."""
+    global _NODE
+    if _NODE is False:
+        _NODE = None
+        if os.environ.get("WFL_TRANSDUCER_NATIVE", "1") != "0":
+            try:
+                from .. import _wfl_torch as mod
+                _NODE = mod if hasattr(mod, "lattice_loss_forward") else None
+            except ImportError:
+                pass
+    return _NODE
+
+
 class TransducerLossFunction(torch.autograd.Function):
     @staticmethod
     @E.on_input_device
@@ -379,6 +399,30 @@ class TransducerLossFunction(torch.autograd.Function):
         pack, scale, cpos, cneg, _ = _PACK_CACHE.get(full_key, build)
         need_grad = inputs.requires_grad or (transition_params is not None and transition_params.requires_grad)
         den = dense = None
+        node = _native_node() if transitions is None else None
+        timed = node is not None and E.phase_due(_PHASES)  # (a step whose launch groups bench.py brackets with events)
+        if node is not None and not timed and not torch.cuda.is_current_stream_capturing():
+            # gather, sweeps (with the gradient beside them), loss reduction and join in one native call
+            # (csrc/torch_ops.cpp::lattice_loss_forward): the sequence below, without the interpreter between the launches
+            up = getattr(pack, "_uploaded", None)
+            if up is not None and up[0] != E.stream_ptr():  # a cached pack uploaded on another stream
+                torch.cuda.current_stream().wait_event(up[1])
+            want_dx = inputs.requires_grad and _IN_LAUNCH_GRAD
+            (loss, xg, al, be, lz, lse, dx_early), in_launch = node.lattice_loss_forward(
+                x, ctypes.addressof(pack.desc), pack.ints, pack.floats, scale, cneg, bool(log_softmax), want_dx, need_grad)
+            num = E.LatticeState()
+            num.pack, num.T, num.C, num.weights, num.bptr = pack, T, C, None, None
+            num.xg, num.alpha, num.beta, num.logz = xg, al, be, lz
+            num.x, num.row_lse, num.in_launch = (x if log_softmax else None), lse, in_launch
+            ctx.aux = (x, params, num, None, cpos, cneg, None)
+            ctx.early = None
+            ctx.devices = (inputs.device, None)
+            if in_launch:
+                ctx.early = _EarlyGrad(dx_early, num, cneg, inputs)
+                ctx.eager_take = ctx.early.take if E.plain_leaf(inputs) else None
+                if ctx.eager_take is not None:
+                    E.watch_node_hooks(ctx)
+            return loss if inputs.is_cuda else loss.cpu()
         if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288
             # independent of the numerator sweep: forked onto a second stream so that the two overlap
             with E.side_stream(dev) as fork:
@@ -399,8 +443,12 @@ class TransducerLossFunction(torch.autograd.Function):
         dx_early = None
         if transitions is None and inputs.requires_grad and _IN_LAUNCH_GRAD:
             dx_early = torch.empty_like(x)
-        num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax,
-                                grad_into=(cneg, dx_early) if dx_early is not None else None, defer_join=True)
+        E._PHASE_FORCE = timed
+        try:
+            num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax,
+                                    grad_into=(cneg, dx_early) if dx_early is not None else None, defer_join=True)
+        finally:
+            E._PHASE_FORCE = False
         if not num.in_launch:
             dx_early = None
         if den is not None:

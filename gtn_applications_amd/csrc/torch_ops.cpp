@@ -607,6 +607,54 @@ std::vector<at::Tensor> asg_forward(const at::Tensor& x, const at::Tensor& W, in
   return {loss, da, db, dz, ws, dx_num, dw_num, dx, dW};
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The launches of a Transducer step WITHOUT a transition model in one native call: counterpart of
+// TransducerLossFunction.forward, /root/reference/criterions/transducer.py:239-315, after the batch of alignment
+// acceptors has been packed (wfl_transducer_pack_batch, cached per batch): gather (+ row log-sum-exps when the
+// log_softmax of transducer.py:186-187 is fused), the sweeps -- with the emission gradient beside them when asked for and
+// possible --, the loss reduction, the join.  Same sequence as criterions/transducer.py spells in Python (kept for
+// phase timing, transition models and builds without this module).
+// Returns ({loss, xg, alpha, beta, logz, row_lse, dx}, in_launch); dx undefined unless in_launch.
+// ------------------------------------------------------------------------------------------------------------
+std::pair<std::vector<at::Tensor>, bool> lattice_loss_forward(const at::Tensor& x, int64_t desc_ptr, const at::Tensor& ints,
+                                                              const at::Tensor& floats, const at::Tensor& scale,
+                                                              const at::Tensor& cneg, bool log_softmax, bool want_dx,
+                                                              bool need_beta) {
+  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous() && x.dim() == 3,
+              "lattice_loss_forward: x must be a contiguous float32 [B,T,C] device tensor");
+  const int B = (int)x.size(0), T = (int)x.size(1), C = (int)x.size(2);
+  const auto* d = reinterpret_cast<const wfl_lattice_desc*>(desc_ptr);
+  void* st = current_stream(x);
+  const auto f32 = x.options();
+  int64_t n_xg = 0, n_ab = 0;
+  check(wfl_lattice_workspace(d, T, &n_xg, &n_ab), "lattice_loss_forward");
+  at::Tensor xg = at::empty({std::max<int64_t>(n_xg, 1)}, f32), al = at::empty({std::max<int64_t>(n_ab, 1)}, f32);
+  at::Tensor be = need_beta ? at::empty({std::max<int64_t>(n_ab, 1)}, f32) : at::Tensor();
+  at::Tensor lz = at::empty({B}, f32), loss = at::empty({}, f32);
+  at::Tensor lse = log_softmax ? at::empty({B, T}, f32) : at::Tensor();
+  at::Tensor dx = (want_dx && need_beta) ? at::empty_like(x) : at::Tensor();
+  const int32_t* ip = ints.data_ptr<int32_t>();
+  check(wfl_lattice_gather(d, ip, x.data_ptr<float>(), T, C, xg.data_ptr<float>(), fptr(lse), st), "lattice_loss_forward");
+  int flag = 0;
+  if (dx.defined()) {
+    flag = 2;  // (the join comes behind the loss reduction, which then runs under the gradient's tail)
+    check(wfl_lattice_forward_grad(d, ip, floats.data_ptr<float>(), xg.data_ptr<float>(), T, C, nullptr, al.data_ptr<float>(),
+                                   be.data_ptr<float>(), lz.data_ptr<float>(), cneg.data_ptr<float>(),
+                                   log_softmax ? x.data_ptr<float>() : nullptr, fptr(lse), dx.data_ptr<float>(), &flag, st),
+          "lattice_loss_forward");
+  } else {
+    check(wfl_lattice_forward(d, ip, floats.data_ptr<float>(), xg.data_ptr<float>(), T, nullptr, WFL_SEMIRING_LOG,
+                              al.data_ptr<float>(), fptr(be), nullptr, lz.data_ptr<float>(), st),
+          "lattice_loss_forward");
+  }
+  check(wfl_reduce_loss(lz.data_ptr<float>(), nullptr, scale.data_ptr<float>(), B, -1.0f, 0, loss.data_ptr<float>(), st),
+        "lattice_loss_forward");
+  const bool in_launch = flag != 0 && dx.defined();
+  if (in_launch) check(wfl_lattice_side_join(st), "lattice_loss_forward");
+  if (!in_launch) dx = at::Tensor();
+  return {{loss, xg, al, be, lz, lse, dx}, in_launch};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -614,6 +662,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "loss.backward() of a CtcStep loss without the autograd engine (false: not the plain case, use the engine)");
   m.def("ctc_step", &ctc_step, "CTC loss + eager gradient in one pipelined launch (C++ autograd node)");
   m.def("asg_forward", &asg_forward, "every launch of an ASG step's forward in one native call (criterions/asg.py)");
+  m.def("lattice_loss_forward", &lattice_loss_forward,
+        "gather, sweeps (+ the gradient beside them), loss reduction and join of a Transducer step without transitions");
   m.def("ctc_reset_host_state", &ctc_reset_host_state, "zero the steps' memory of which launch to start with");
   py::class_<StagedTargets, std::shared_ptr<StagedTargets>>(m, "StagedTargets")
       .def_readonly("B", &StagedTargets::B)

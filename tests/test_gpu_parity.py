@@ -1018,6 +1018,31 @@ def _word_piece_batch(B, T, seed, pieces=15):
     return tokens, g2i, x, tg
 
 
+@pytest.mark.parametrize("leaf", [True, False])
+def test_transducer_native_call_is_the_python_sequence(crit, monkeypatch, leaf):
+    """csrc/torch_ops.cpp::lattice_loss_forward issues the launches of a Transducer step without a transition model
+    (transducer.py:239-315) in one native call; criterions/transducer.py keeps the same sequence in Python.  Same
+    kernels, same buffers: the loss bit for bit, the gradient to the last digits (the gradient beside the sweeps
+    normalises tile by tile) -- as leaves and through the autograd engine with a grad_output that is not 1."""
+    tr = crit["transducer"]
+    if tr._native_node() is None:
+        pytest.skip("the torch extension is not built")
+    tokens, g2i, x, tg = _word_piece_batch(6, 120, 3)
+    m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+
+    def run():
+        xi = x.clone().requires_grad_(True)
+        loss = m(xi if leaf else xi * 1.0, tg)
+        (loss if leaf else loss * 0.75).backward()
+        return loss.detach().cpu().numpy(), xi.grad.cpu().numpy()
+
+    native = run()
+    monkeypatch.setattr(tr, "_NODE", None)
+    python = run()
+    assert np.array_equal(native[0], python[0])
+    np.testing.assert_allclose(native[1], python[1], rtol=1e-5, atol=1e-8)
+
+
 @pytest.mark.parametrize("B,T", [(6, 200), (70, 48)])
 def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(crit, monkeypatch, B, T):
     """csrc/lattice_kernels.hip wfl_lattice_forward_grad: the emission gradient computed by the persistent workgroups
