@@ -1087,23 +1087,34 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     if (c + 1 < nchunks) {
       chunk_frames(c + 1, pf0, pn);
       const float* src = fg + u.xg_base + (int64_t)pf0 * Kmax;
+      // (clamped addresses, no test around a load: behind a divergent branch the compiler waits for everything the wave
+      // has outstanding -- here the sixteen stores of the chunk before, a store round trip at the top of every chunk;
+      // phase timers, scratch/sweep_phase_timers.patch: 1200-1400 cycles of a chunk's 9300 in this section)
+      const int last = pn * Kmax - 1;
 #pragma unroll
-      for (int j = 0; j < kPre; ++j) {
-        const int e = tid + j * NT;
-        if (e < pn * Kmax) pre[j] = src[e];
-      }
-      if (tid < pn) rpre = rmax[(int64_t)b * T + pf0 + tid];
+      for (int j = 0; j < kPre; ++j) pre[j] = src[min(tid + j * NT, last)];
+      rpre = rmax[(int64_t)b * T + pf0 + min(tid, pn - 1)];
     }
-    if (c > 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
-      const int ex = (tid < Q && p > 0.0) ? ilogb(p) : -(1 << 30);
-      const int emax = block_reduce_max_int(ex, (int*)lred);
+    // (every 4th chunk: a renormalisation is three barriers, ~1100 cycles of a chunk's 9300, and a double has room for
+    // far more than 64 frames of factors <= 1 -- what it has no room for, the certificate catches)
+    if (c > 0 && (c & 3) == 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
+      // (LDS-only barriers: __syncthreads() also waits for the wave's global operations -- the loads issued just above,
+      // i.e. an HBM round trip in every chunk: 1300-1400 cycles in this section)
+      const int ex = (tid < Q && p > 0.0) ? __builtin_amdgcn_frexp_exp(p) - 1 : -(1 << 30);
+      int* red = (int*)lred;
+      const int wmax = wave_all_max_int(ex);
+      lds_barrier();
+      if ((tid & 63) == 0) red[tid >> 6] = wmax;
+      lds_barrier();
+      int emax = red[0];
+      for (int i = 1; i < (NT + 63) >> 6; ++i) emax = max(emax, red[i]);
       if (emax > -(1 << 30) && emax < 2000) {
-        p = scalbn(p, -emax);
+        p = ldexp(p, -emax);
         cum += (double)emax;
         double* fromb = ((DIR == 0 ? f0 : f0 + n) & 1) ? lbuf1 : lbuf0;
         if (tid < Q) fromb[tid] = p;
       }
-      __syncthreads();
+      lds_barrier();
     }
     // Software pipeline: the arc coefficients c[k] = wf[k] * f_t[slot_k] of a frame do not depend on the chain, so
     // they are formed while the previous frame's sources are still on their way from LDS; after the barrier only the
