@@ -783,8 +783,13 @@ constexpr int kDumpDoubles = 1024;  // scratch behind the alpha / beta tails (se
 constexpr int kBandDepth = 4;
 // floats of the probability-domain sweeps' row tile: two chunks of the tile path, or the banded sweep's two tiles of
 // 16 rows (+ their references)
-__host__ __device__ inline size_t prob_rows_floats(const wfl_lattice_desc& d, int rows_per_chunk) {
-  const size_t tile = (size_t)2 * rows_per_chunk * d.max_labels;
+// (a tile slot has room for every thread's kPre prefetch registers: the hand-over stores them all, no test)
+__host__ __device__ inline size_t prob_tile_floats(const wfl_lattice_desc& d, int rows_per_chunk, int nt) {
+  const size_t rows = (size_t)rows_per_chunk * d.max_labels, regs = (size_t)kPre * nt;
+  return rows > regs ? rows : regs;
+}
+__host__ __device__ inline size_t prob_rows_floats(const wfl_lattice_desc& d, int rows_per_chunk, int nt) {
+  const size_t tile = 2 * prob_tile_floats(d, rows_per_chunk, nt);
   const size_t band = d.max_states <= 64 ? (size_t)2 * 1024 + 2 * 64 : 0;
   return tile > band ? tile : band;
 }  // chunks of 16 frames the banded sweep loads ahead of the one it works on
@@ -792,8 +797,8 @@ __host__ __device__ inline size_t prob_rows_floats(const wfl_lattice_desc& d, in
 struct ProbLds {
   double* buf0;  // [Q]
   double* buf1;  // [Q]
-  float* rows;   // [2][R][Kmax] emission factors of the current / next chunk
-  float* refs;   // [2][R]       their references
+  float* rows;   // [2][prob_tile_floats] emission factors of the current / next chunk, rows of Kmax
+  float* refs;   // [2][threads] their references (the first R of each)
   float* red;    // [64] (reductions; reused as int)
 };
 
@@ -864,8 +869,11 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       wmx = fmaxf(wmx, aw[i]);
     }
   }
-  const int deg_class = __syncthreads_or(k1 - k0 > 4) ? 2 : (__syncthreads_or(k1 - k0 > 2) ? 1 : 0);
-  const int wave_deg = wave_all_max_int(k1 - k0);  // the most arcs into (out of) a state of this wave
+  // (readfirstlane: these are wave-uniform, and the compiler must KNOW it -- a branch it takes for divergent becomes two
+  // masked regions with a static path around both, and on that path the loads of the chunk loop's prefetch stay
+  // unconsumed: see hand_over)
+  const int deg_class = __builtin_amdgcn_readfirstlane(__syncthreads_or(k1 - k0 > 4) ? 2 : (__syncthreads_or(k1 - k0 > 2) ? 1 : 0));
+  const int wave_deg = __builtin_amdgcn_readfirstlane(wave_all_max_int(k1 - k0));  // the most arcs into (out of) a state of this wave
   float wref = block_reduce_max(wmx, lred);  // every frame multiplies by e^wref once more: part of the offset
   if (!(wref > WFL_NEG_INF)) wref = 0.f;
   if (wref_out && tid == 0) wref_out[b] = wref;
@@ -900,8 +908,8 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     if (i0 < i1) my_slot = u.arc_slot[i0];
     for (int k = i0 + 1; k < i1; ++k) uni_ok &= u.arc_slot[k] == my_slot;
   }
-  const bool uniform = __syncthreads_and(uni_ok);
-  const bool wave_live = (tid & ~63) < Q;  // (waves without a state only take part in the barriers)
+  const bool uniform = __builtin_amdgcn_readfirstlane(__syncthreads_and(uni_ok)) != 0;
+  const bool wave_live = __builtin_amdgcn_readfirstlane((int)((tid & ~63) < Q)) != 0;  // (waves without a state only take part in the barriers)
 
   const int t_first = DIR == 0 ? 0 : T;
   double p = 0.0;
@@ -1064,6 +1072,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     __syncthreads();
   }
   const int nchunks = banded ? 0 : (T + R - 1) / R;
+  const size_t tstride = prob_tile_floats(d, R, NT);
   auto chunk_frames = [&](int c, int& f0, int& n) {
     const int s0 = c * R;
     n = min(R, T - s0);
@@ -1076,25 +1085,82 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     for (int e = tid; e < n * Kmax; e += NT) lrows[e] = src[e];
     if (tid < n) lrefs[tid] = rmax[(int64_t)b * T + f0 + tid];
   }
+  // (vmcnt(0) as the BUILTIN, which the compiler's wait-count pass sees: loads of the set-up above that some path left
+  // unconsumed would otherwise make it wait for "everything" at the first reuse of their registers inside the chunk
+  // loop -- at the top of every chunk, where "everything" is the chunk before's sixteen stores)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
+#ifdef WFL_EXP_WAIT0
+  long long e_pre = 0, e_ren = 0, e_offs = 0, e_fr = 0, e_hand = 0;
+  const long long exp_begin = clock64();
+#endif
+  // The chunk loop, one copy per frame-loop variant with the choice made OUTSIDE it (the variants are loop-invariant:
+  // block-uniform `uniform` / `deg_class`, wave-uniform `wave_deg`).  Chosen inside, the seven-way chain reached the
+  // wait-count pass as flag-driven regions with a static path around all of them -- on which the prefetched rows stay
+  // unconsumed, so the first reuse of their registers, at the top of the next chunk, waited for "everything": the
+  // sixteen stores of the chunk before, a store round trip per chunk (see hand_over).
+  // Likewise the waves without a state (LIVE) and the chunks of sixteen straight-line frames (FULL): compile-time
+  // choices inside the body, so that every copy of it is ONE path from the prefetch to the hand-over.
+  auto sweep = [&](auto sel_, auto live_) {
+  constexpr int SEL = decltype(sel_)::value;
+  constexpr bool LIVE = decltype(live_)::value;
+  auto chunk = [&](int c, auto full_) {
+    constexpr bool FULL = decltype(full_)::value;
+#ifdef WFL_EXP_WAIT0
+    const long long eA = clock64();
+#endif
     int f0, n;
     chunk_frames(c, f0, n);
-    const float* tile = lrows + (size_t)(c & 1) * R * Kmax;
-    const float* rtile = lrefs + (size_t)(c & 1) * R;
-    float pre[kPre], rpre = 0.f;
-    int pf0 = 0, pn = 0;
-    if (c + 1 < nchunks) {
-      chunk_frames(c + 1, pf0, pn);
-      const float* src = fg + u.xg_base + (int64_t)pf0 * Kmax;
-      // (clamped addresses, no test around a load: behind a divergent branch the compiler waits for everything the wave
-      // has outstanding -- here the sixteen stores of the chunk before, a store round trip at the top of every chunk;
-      // phase timers, scratch/sweep_phase_timers.patch: 1200-1400 cycles of a chunk's 9300 in this section)
-      const int last = pn * Kmax - 1;
-#pragma unroll
-      for (int j = 0; j < kPre; ++j) pre[j] = src[min(tid + j * NT, last)];
+    const float* tile = lrows + (size_t)(c & 1) * tstride;
+    const float* rtile = lrefs + (size_t)(c & 1) * NT;
+    // The next chunk's rows, requested now and moved to LDS at the chunk's end (hand_over, called at the end of EVERY path
+    // through the frame loops below).  Three things keep the waits the compiler puts in front of these registers' uses
+    // from covering the sixteen score stores of the chunk (loads and stores share the in-order vmcnt counter, the
+    // wait-count pass is static and takes the FEWEST operations any path issues in between):
+    //  - no test around a load (clamped addresses; the last chunk asks for itself again, nobody reads that) and no
+    //    initial value for the registers (`rpre = 0` was a write to a register with a load pending on the paths that
+    //    skip its use: an `s_waitcnt vmcnt(0)` at the top of every chunk, i.e. a store round trip, 850 cycles);
+    //  - the move to LDS sits INSIDE each frame path, so that behind the straight-line sixteen frames the count is
+    //    exact ("all but the 16 youngest") -- at the join of all paths the waves without a state (no stores) made it
+    //    "all", 500-800 cycles per chunk (phase timers, scratch/sweep_phase_timers.patch: hand-over 820 -> 490 with the
+    //    16-byte accesses alone);
+    //  - 16-byte loads and LDS stores (rows are padded to four labels: pack.cpp, pad_labels).
+    float pre[kPre], rpre;
+    int pf0, pn;
+    chunk_frames(min(c + 1, nchunks - 1), pf0, pn);
+    {
+      const float4* src4 = reinterpret_cast<const float4*>(fg + u.xg_base + (int64_t)pf0 * Kmax);
+      const int last4 = ((pn * Kmax) >> 2) - 1;
       rpre = rmax[(int64_t)b * T + pf0 + min(tid, pn - 1)];
+#pragma unroll
+      for (int j = 0; j < kPre / 4; ++j) {
+        const float4 q = src4[min(tid + j * NT, last4)];
+        pre[4 * j] = q.x, pre[4 * j + 1] = q.y, pre[4 * j + 2] = q.z, pre[4 * j + 3] = q.w;
+      }
     }
+    // (every thread stores every register: the slots have room, see prob_tile_floats.  `path`: 0 behind the sixteen
+    // straight-line frames, 1 a wave without a state, 2 behind a frame loop -- each ends in its own, empty, asm
+    // statement, or the compiler merges the identical tails of the three behind their join and the count is "all" again)
+    auto hand_over = [&](auto path) {
+      lrefs[(size_t)((c + 1) & 1) * NT + tid] = rpre;
+      float4* dst4 = reinterpret_cast<float4*>(lrows + (size_t)((c + 1) & 1) * tstride);
+#pragma unroll
+      for (int j = 0; j < kPre / 4; ++j)
+        dst4[tid + j * NT] = make_float4(pre[4 * j], pre[4 * j + 1], pre[4 * j + 2], pre[4 * j + 3]);
+      if constexpr (decltype(path)::value == 0)
+        asm volatile("; rows handed over behind sixteen straight-line frames" ::: "memory");
+      else if constexpr (decltype(path)::value == 1)
+        asm volatile("; rows handed over by a wave without a state" ::: "memory");
+      else
+        asm volatile("; rows handed over behind a frame loop" ::: "memory");
+    };
+    using PathUnrolled = std::integral_constant<int, 0>;
+    using PathIdle = std::integral_constant<int, 1>;
+    using PathLoop = std::integral_constant<int, 2>;
+#ifdef WFL_EXP_WAIT0
+    const long long eB = clock64();
+    e_pre += eB - eA;
+#endif
     // (every 4th chunk: a renormalisation is three barriers, ~1100 cycles of a chunk's 9300, and a double has room for
     // far more than 64 frames of factors <= 1 -- what it has no room for, the certificate catches)
     if (c > 0 && (c & 3) == 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
@@ -1116,6 +1182,10 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       }
       lds_barrier();
     }
+#ifdef WFL_EXP_WAIT0
+    const long long eC = clock64();
+    e_ren += eC - eB;
+#endif
     // Software pipeline: the arc coefficients c[k] = wf[k] * f_t[slot_k] of a frame do not depend on the chain, so
     // they are formed while the previous frame's sources are still on their way from LDS; after the barrier only the
     // DEG source reads (issued back to back) and DEG multiply-adds (two independent accumulators) remain.
@@ -1135,15 +1205,11 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     // barriers, the row pointer and the tile pointer advance by scalar adds, the ping-pong buffers swap by parity.
     auto frames = [&](auto deg) {
       constexpr int DEG = decltype(deg)::value;
-      if (!wave_live) {
-        for (int i = 0; i < n; ++i) lds_barrier();
-        return;
-      }
       double c[kLeanDeg], cn[kLeanDeg];
       coeffs(0, c, deg);
       double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
       int par = (DIR == 0 ? f0 : f0 + n) & 1;  // parity of the slot the frame reads from
-      if (UNR && n == 16) {  // (a full chunk as straight-line code with unconditional stores: see frames_uniform)
+      if constexpr (FULL) {  // (a full chunk as straight-line code with unconditional stores: see frames_uniform)
         const bool mine = tid < Q;
         double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
         const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
@@ -1171,6 +1237,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
           for (int k = 0; k < DEG; ++k) c[k] = cn[k];
           lds_barrier();
         }
+        hand_over(PathUnrolled{});
         return;
       }
       for (int i = 0; i < n; ++i) {
@@ -1197,6 +1264,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         par ^= 1;
         lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
       }
+      hand_over(PathLoop{});
     };
     auto frames_uniform = [&](auto deg) {
       constexpr int DEG = decltype(deg)::value;
@@ -1211,16 +1279,12 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         }
         lds_barrier();
       }
-      if (!wave_live) {
-        for (int i = 0; i < n; ++i) lds_barrier();
-        return;
-      }
       double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
       int par = (DIR == 0 ? f0 : f0 + n) & 1;
       // alpha: this frame's factor of the state; beta: the factor of the NEXT frame to be consumed (t - 1), with
       // which the owner publishes; past the chunk (the tile is not there yet) plain beta is published
       const float* fptr = tile + (size_t)(DIR == 0 ? 0 : max(n - 2, 0)) * Kmax + my_slot;
-      if (UNR && n == 16) {
+      if constexpr (FULL) {
         // A full chunk as straight-line code whose stores EVERY lane executes (lanes without a state store to a dump
         // and to their own, never read, LDS entry).  The threads of this workgroup also prefetch the next chunk's rows:
         // loads and stores share the in-order vmcnt counter and the compiler counts, for the wait in front of the
@@ -1255,6 +1319,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
           po += pstep;
           lds_barrier();
         }
+        hand_over(PathUnrolled{});
         return;
       }
       for (int i = 0; i < n; ++i) {
@@ -1284,6 +1349,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       }
       // (beta: the chunk's last step published plain beta -- no factor past the chunk -- which is what the
       // renormalisation and the next chunk's first step expect)
+      hand_over(PathLoop{});
     };
     // The chunk's per-slot offsets at once, outside the frame loop (n <= 16 frames): lane i of every row of 16 takes
     // the chunk's i-th frame in sweep order, an inclusive prefix sum over the row (DPP) gives the offset after each
@@ -1316,29 +1382,34 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     // one barrier per frame in all of them; the alignment graphs of the Transducer have 2-5 arcs into most states and
     // 8 into a few: waves that do not hold such a state read 4 or 6 vector entries per state and frame, not 8)
     // (even classes only: the frame loops take the arc slots in pairs)
-    if (uniform && wave_deg <= 2)
+#ifdef WFL_EXP_WAIT0
+    const long long eD = clock64();
+    e_offs += eD - eC;
+#endif
+    if constexpr (!LIVE) {  // only the barriers (the frame loops below: one per frame, one more in front of beta's)
+      if (DIR == 1 && uniform) lds_barrier();
+      for (int i = 0; i < n; ++i) lds_barrier();
+      hand_over(PathIdle{});
+    } else if constexpr (SEL == 0)
       frames_uniform(std::integral_constant<int, 2>{});
-    else if (uniform && wave_deg <= 4)
+    else if constexpr (SEL == 1)
       frames_uniform(std::integral_constant<int, 4>{});
-    else if (uniform && wave_deg <= 6)
+    else if constexpr (SEL == 2)
       frames_uniform(std::integral_constant<int, 6>{});
-    else if (uniform)
+    else if constexpr (SEL == 3)
       frames_uniform(std::integral_constant<int, kLeanDeg>{});
-    else if (deg_class == 0)
+    else if constexpr (SEL == 4)
       frames(std::integral_constant<int, 2>{});
-    else if (deg_class == 1)
+    else if constexpr (SEL == 5)
       frames(std::integral_constant<int, 4>{});
     else
       frames(std::integral_constant<int, kLeanDeg>{});
+#ifdef WFL_EXP_WAIT0
+    const long long eE = clock64();
+    e_fr += eE - eD;
+#endif
     cum += chunk_log2;
     if (c + 1 < nchunks) {
-      float* dst = lrows + (size_t)((c + 1) & 1) * R * Kmax;
-#pragma unroll
-      for (int j = 0; j < kPre; ++j) {
-        const int e = tid + j * NT;
-        if (e < pn * Kmax) dst[e] = pre[j];
-      }
-      if (tid < pn) lrefs[(size_t)((c + 1) & 1) * R + tid] = rpre;
       if (PUB) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (see below)
       __syncthreads();
       // Chunk c - 1 is in L2: its stores are older than this chunk's prefetch loads and its (at most 16) frame stores,
@@ -1347,7 +1418,34 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       // would put a store round trip, ~1.5 us, behind every 16 frames.)
       if (PUB && tid == 0 && c > 0) prog_publish(prog, token, (uint32_t)c);
     }
-  }
+#ifdef WFL_EXP_WAIT0
+    e_hand += clock64() - eE;
+#endif
+  };
+  // chunks whose sixteen frames run as straight-line code (nchunks is 0 when the banded sweep above has done the work)
+  const int nfull = (UNR && R == 16) ? min(T / 16, nchunks) : 0;
+  for (int c = 0; c < nfull; ++c) chunk(c, std::true_type{});
+  for (int c = nfull; c < nchunks; ++c) chunk(c, std::false_type{});
+  };
+  if (!wave_live)
+    sweep(std::integral_constant<int, 7>{}, std::false_type{});
+  else if (uniform && wave_deg <= 2)
+    sweep(std::integral_constant<int, 0>{}, std::true_type{});
+  else if (uniform && wave_deg <= 4)
+    sweep(std::integral_constant<int, 1>{}, std::true_type{});
+  else if (uniform && wave_deg <= 6)
+    sweep(std::integral_constant<int, 2>{}, std::true_type{});
+  else if (uniform)
+    sweep(std::integral_constant<int, 3>{}, std::true_type{});
+  else if (deg_class == 0)
+    sweep(std::integral_constant<int, 4>{}, std::true_type{});
+  else if (deg_class == 1)
+    sweep(std::integral_constant<int, 5>{}, std::true_type{});
+  else
+    sweep(std::integral_constant<int, 6>{}, std::true_type{});
+#ifdef WFL_EXP_WAIT0
+  if (tid == 0 && b == 0 && !banded) printf("dir %d: loop %lld = prefetch %lld + renorm %lld + offsets %lld + frames %lld + hand-over %lld (%d chunks)\n", DIR, clock64() - exp_begin, e_pre, e_ren, e_offs, e_fr, e_hand, nchunks);
+#endif
   if (PUB) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1394,7 +1492,7 @@ __device__ __forceinline__ void prob_chain_body(const wfl_lattice_desc& d, const
   P.buf0 = (double*)p, p += nvec * 8;
   P.buf1 = (double*)p, p += nvec * 8;
   P.red = (float*)p, p += 64 * 4;
-  P.rows = (float*)p, p += prob_rows_floats(d, rows_per_chunk) * 4;
+  P.rows = (float*)p, p += prob_rows_floats(d, rows_per_chunk, blockDim.x) * 4;
   P.refs = (float*)p;
   const float* fg = xg + xg_main_dev(d, T);
   const float* rmax = fg + xg_main_dev(d, T);
@@ -1524,8 +1622,8 @@ static int chain_threads(const wfl_lattice_desc& d) {
 }
 static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
   const int nt = chain_threads(d);
-  const size_t prob = (size_t)std::max(d.max_states, nt) * 16 + 64 * 4 + prob_rows_floats(d, rows_per_chunk) * 4 +
-                      (size_t)2 * rows_per_chunk * 4 + 64;
+  const size_t prob = (size_t)std::max(d.max_states, nt) * 16 + 64 * 4 + prob_rows_floats(d, rows_per_chunk, nt) * 4 +
+                      (size_t)2 * nt * 4 + 64;
   return std::max(prob, (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 16 +
          (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 +
          (size_t)(d.max_states + 1) * 4 + 64);
@@ -2889,7 +2987,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
         const int ntiles = (T + fused_tile - 1) / fused_tile;
         const int rows_o = (T + ntiles - 1) / ntiles;
         nt_o = (T + rows_o - 1) / rows_o;
-        const size_t plds = (size_t)std::max(d->max_states, nt) * 16 + 64 * 4 + prob_rows_floats(*d, rpc) * 4 + (size_t)2 * rpc * 4 + 64;
+        const size_t plds = (size_t)std::max(d->max_states, nt) * 16 + 64 * 4 + prob_rows_floats(*d, rpc, nt) * 4 + (size_t)2 * nt * 4 + 64;
         const size_t olds = occ_lds_bytes(*d, rows_o, g->C);
         // (not while the stream is being captured into a graph: the side stream's launches would not be part of it)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
