@@ -1085,46 +1085,49 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     for (int e = tid; e < n * Kmax; e += NT) lrows[e] = src[e];
     if (tid < n) lrefs[tid] = rmax[(int64_t)b * T + f0 + tid];
   }
-  // (vmcnt(0) as the BUILTIN, which the compiler's wait-count pass sees: loads of the set-up above that some path left
-  // unconsumed would otherwise make it wait for "everything" at the first reuse of their registers inside the chunk
-  // loop -- at the top of every chunk, where "everything" is the chunk before's sixteen stores)
+  // (vmcnt(0), once, as the BUILTIN -- which the compiler's wait-count pass sees, unlike an asm statement: no load of
+  // the set-up above is pending, on any path, when the chunk loop starts)
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
-#ifdef WFL_EXP_WAIT0
+#ifdef WFL_SWEEP_PHASE_TIMERS
   long long e_pre = 0, e_ren = 0, e_offs = 0, e_fr = 0, e_hand = 0;
   const long long exp_begin = clock64();
 #endif
-  // The chunk loop, one copy per frame-loop variant with the choice made OUTSIDE it (the variants are loop-invariant:
-  // block-uniform `uniform` / `deg_class`, wave-uniform `wave_deg`).  Chosen inside, the seven-way chain reached the
-  // wait-count pass as flag-driven regions with a static path around all of them -- on which the prefetched rows stay
-  // unconsumed, so the first reuse of their registers, at the top of the next chunk, waited for "everything": the
-  // sixteen stores of the chunk before, a store round trip per chunk (see hand_over).
-  // Likewise the waves without a state (LIVE) and the chunks of sixteen straight-line frames (FULL): compile-time
-  // choices inside the body, so that every copy of it is ONE path from the prefetch to the hand-over.
+  // The chunk loop.  A chunk asks for the next chunk's rows at its start (registers), sweeps its sixteen frames -- a
+  // score store each -- and moves the rows to LDS at its end (hand_over).  Loads and stores share ONE in-order counter
+  // (vmcnt) and the compiler's wait-count pass is static: in front of the first use (or overwrite) of a register with a
+  // load pending it waits until as many operations may be outstanding as the path with the FEWEST operations since that
+  // load has issued.  With the straight-line frames on every path that is "all but the sixteen youngest" -- the loads,
+  // issued 5000 cycles earlier, and nothing else.  With ANY static path that issues fewer stores, or none, it is "all":
+  // the wave waits for its own last stores, a store round trip (~800 cycles) at the chunk's end and another at the next
+  // chunk's top -- 1800 of a chunk's 8100 cycles (WFL_SWEEP_PHASE_TIMERS; rocprof: prob_chain_pub_kernel<512> 192 ->
+  // 160 us at the Transducer benchmark).  Such paths were, and what removed each:
+  //  - the waves without a state (no stores), the chunks taken by a frame LOOP (a count the pass cannot know) and the
+  //    seven frame-loop variants, all chosen at run time inside the chunk: the chain of uniform tests reaches the pass as
+  //    flag-driven regions with a static path around ALL of them, on which the rows are never consumed -- so the first
+  //    reuse of their registers, at the top of the next chunk, waited for everything.  Now the variant (SEL), the waves
+  //    without a state (LIVE) and the straight-line chunks (FULL) are compile-time choices of the body, made outside
+  //    the loop: every copy of the body is one path from the prefetch to the hand-over;
+  //  - the hand-over behind the join of the frame paths: it sits at the end of each path now, and each ends in its own
+  //    (empty) asm statement -- identical tails are merged behind the join again otherwise;
+  //  - a test around a load or around the use of a loaded register (the path that skips it leaves the load pending):
+  //    clamped addresses, every thread stores every register (the tile slots have room: prob_tile_floats), the last
+  //    chunk asks for itself again; and no initial value for those registers (`rpre = 0` is a write to a register with
+  //    a load pending on such a path).
+  // 16-byte loads and LDS stores on the way (rows are padded to four labels: pack.cpp, pad_labels).
   auto sweep = [&](auto sel_, auto live_) {
   constexpr int SEL = decltype(sel_)::value;
   constexpr bool LIVE = decltype(live_)::value;
   auto chunk = [&](int c, auto full_) {
     constexpr bool FULL = decltype(full_)::value;
-#ifdef WFL_EXP_WAIT0
+#ifdef WFL_SWEEP_PHASE_TIMERS
     const long long eA = clock64();
 #endif
     int f0, n;
     chunk_frames(c, f0, n);
     const float* tile = lrows + (size_t)(c & 1) * tstride;
     const float* rtile = lrefs + (size_t)(c & 1) * NT;
-    // The next chunk's rows, requested now and moved to LDS at the chunk's end (hand_over, called at the end of EVERY path
-    // through the frame loops below).  Three things keep the waits the compiler puts in front of these registers' uses
-    // from covering the sixteen score stores of the chunk (loads and stores share the in-order vmcnt counter, the
-    // wait-count pass is static and takes the FEWEST operations any path issues in between):
-    //  - no test around a load (clamped addresses; the last chunk asks for itself again, nobody reads that) and no
-    //    initial value for the registers (`rpre = 0` was a write to a register with a load pending on the paths that
-    //    skip its use: an `s_waitcnt vmcnt(0)` at the top of every chunk, i.e. a store round trip, 850 cycles);
-    //  - the move to LDS sits INSIDE each frame path, so that behind the straight-line sixteen frames the count is
-    //    exact ("all but the 16 youngest") -- at the join of all paths the waves without a state (no stores) made it
-    //    "all", 500-800 cycles per chunk (phase timers, scratch/sweep_phase_timers.patch: hand-over 820 -> 490 with the
-    //    16-byte accesses alone);
-    //  - 16-byte loads and LDS stores (rows are padded to four labels: pack.cpp, pad_labels).
+    // the next chunk's rows (see above: no test, no initial value)
     float pre[kPre], rpre;
     int pf0, pn;
     chunk_frames(min(c + 1, nchunks - 1), pf0, pn);
@@ -1138,9 +1141,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         pre[4 * j] = q.x, pre[4 * j + 1] = q.y, pre[4 * j + 2] = q.z, pre[4 * j + 3] = q.w;
       }
     }
-    // (every thread stores every register: the slots have room, see prob_tile_floats.  `path`: 0 behind the sixteen
-    // straight-line frames, 1 a wave without a state, 2 behind a frame loop -- each ends in its own, empty, asm
-    // statement, or the compiler merges the identical tails of the three behind their join and the count is "all" again)
+    // (`path`: 0 behind the sixteen straight-line frames, 1 a wave without a state, 2 behind a frame loop)
     auto hand_over = [&](auto path) {
       lrefs[(size_t)((c + 1) & 1) * NT + tid] = rpre;
       float4* dst4 = reinterpret_cast<float4*>(lrows + (size_t)((c + 1) & 1) * tstride);
@@ -1157,7 +1158,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     using PathUnrolled = std::integral_constant<int, 0>;
     using PathIdle = std::integral_constant<int, 1>;
     using PathLoop = std::integral_constant<int, 2>;
-#ifdef WFL_EXP_WAIT0
+#ifdef WFL_SWEEP_PHASE_TIMERS
     const long long eB = clock64();
     e_pre += eB - eA;
 #endif
@@ -1182,7 +1183,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       }
       lds_barrier();
     }
-#ifdef WFL_EXP_WAIT0
+#ifdef WFL_SWEEP_PHASE_TIMERS
     const long long eC = clock64();
     e_ren += eC - eB;
 #endif
@@ -1382,7 +1383,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     // one barrier per frame in all of them; the alignment graphs of the Transducer have 2-5 arcs into most states and
     // 8 into a few: waves that do not hold such a state read 4 or 6 vector entries per state and frame, not 8)
     // (even classes only: the frame loops take the arc slots in pairs)
-#ifdef WFL_EXP_WAIT0
+#ifdef WFL_SWEEP_PHASE_TIMERS
     const long long eD = clock64();
     e_offs += eD - eC;
 #endif
@@ -1404,7 +1405,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       frames(std::integral_constant<int, 4>{});
     else
       frames(std::integral_constant<int, kLeanDeg>{});
-#ifdef WFL_EXP_WAIT0
+#ifdef WFL_SWEEP_PHASE_TIMERS
     const long long eE = clock64();
     e_fr += eE - eD;
 #endif
@@ -1418,7 +1419,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       // would put a store round trip, ~1.5 us, behind every 16 frames.)
       if (PUB && tid == 0 && c > 0) prog_publish(prog, token, (uint32_t)c);
     }
-#ifdef WFL_EXP_WAIT0
+#ifdef WFL_SWEEP_PHASE_TIMERS
     e_hand += clock64() - eE;
 #endif
   };
@@ -1443,7 +1444,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     sweep(std::integral_constant<int, 5>{}, std::true_type{});
   else
     sweep(std::integral_constant<int, 6>{}, std::true_type{});
-#ifdef WFL_EXP_WAIT0
+#ifdef WFL_SWEEP_PHASE_TIMERS
   if (tid == 0 && b == 0 && !banded) printf("dir %d: loop %lld = prefetch %lld + renorm %lld + offsets %lld + frames %lld + hand-over %lld (%d chunks)\n", DIR, clock64() - exp_begin, e_pre, e_ren, e_offs, e_fr, e_hand, nchunks);
 #endif
   if (PUB) {
