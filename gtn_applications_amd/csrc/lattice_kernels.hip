@@ -1989,7 +1989,7 @@ __global__ void __launch_bounds__(256)
 //     side        occ_gate_kernel         one wave: waits until every sweep workgroup has announced itself (from then on
 //                                         nothing the gradient does can keep a sweep off the chip), then sorts the
 //                                         utterances by the XCD their sweeps run on and resets the job counters
-//     side        occ_live_kernel         persistent 256-thread workgroups (their own register budget: 5 per SIMD; a
+//     side        occ_live_kernel         persistent 256-thread workgroups (their own register budget: three per CU resident; a
 //                                         kernel that also held the sweeps' code would get 1 workgroup per CU): each
 //                                         reads the id of the XCD it runs on and draws (tile, utterance) jobs of THAT
 //                                         XCD, tiles in middle-out order -- the sweeps' plain stores are in that XCD's
@@ -2974,9 +2974,12 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
         const char* e = getenv("WFL_LATTICE_FUSED_TILE");
         return e ? std::max(1, std::min(32, atoi(e))) : 32;
       }();
+      // persistent gradient workgroups per CU: as many as are resident at once (four waves of 130 VGPRs each: three per
+      // CU).  More only queue behind those and start when the jobs are gone; measured at the Transducer benchmark with
+      // the sweeps at 160 us: 2 -> 0.399 ms, 3 -> 0.362, 4 -> 0.364, 5 (the value until then) -> 0.369, 8 -> 0.37
       static const int fused_wgs = [] {
         const char* e = getenv("WFL_LATTICE_FUSED_WGS");
-        return e ? std::max(1, atoi(e)) : 5;
+        return e ? std::max(1, atoi(e)) : 3;
       }();
       const char* bad_env = getenv("WFL_LATTICE_FUSED_BADXCD");
       uint32_t token = 0;
