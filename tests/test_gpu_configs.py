@@ -342,6 +342,37 @@ def test_cfg4_transducer_word_pieces():
         check("cfg4_transducer_dx_oracle_graph", dx[b], want_dx, sc / B)
 
 
+def test_transducer_acceptors_of_more_than_512_states():
+    """Targets long enough for the alignment acceptor to need the 1024-thread sweep workgroups (their chunks run as frame
+    loops, not as straight-line code; 90 KB of LDS): 300 letters, blank optional -> 601 states.  Every utterance, loss
+    and emission gradient, against the float64 recurrence; the last frames form a partial chunk (T % 16 != 0)."""
+    from gtn_applications_amd.criterions import transducer as TR
+
+    letters = [chr(ord("a") + i) for i in range(26)]
+    g2i = {c: i for i, c in enumerate(letters)}
+    B, T, L = 3, 650, 300
+    C = len(letters) + 1
+    rs = np.random.RandomState(5)
+    targets = [[int(v) for v in rs.randint(0, 26, size=L - 7 * b)] for b in range(B)]
+    x = torch.randn(B, T, C, generator=torch.Generator().manual_seed(5))
+    crit = TR.Transducer(letters, g2i, blank="optional", allow_repeats=False, reduction="mean")
+    xg = x.cuda().requires_grad_(True)
+    loss = crit(xg, [torch.tensor(t) for t in targets])
+    loss.backward()
+    dx = xg.grad.cpu().numpy()
+    crit.tokens.arc_sort(True)
+    losses = []
+    for b in range(B):
+        a = TR._alignment_graph(targets[b], crit.tokens, crit.lexicon, None)[0].arrays()
+        assert len(a["start"]) > 512 or b > 0
+        arcs = (a["src"], a["dst"], a["ilabel"], np.nonzero(a["start"])[0], np.nonzero(a["accept"])[0], len(a["start"]))
+        sc = 1.0 / len(targets[b])
+        want_loss, want_dx = _lattice_oracle(x[b].numpy(), arcs, sc, B)
+        losses.append(want_loss)
+        check("transducer_601_states_dx", dx[b], want_dx, sc / B)
+    assert loss.item() == pytest.approx(float(np.mean(losses)), rel=RTOL)
+
+
 def test_transducer_word_pieces_reference_golden(golden_dir):
     """the reference's Transducer module itself (run on the oracle's WFST primitives by
     oracle/pin_against_reference.py --write-round2-golden) with the 1000 word pieces, short input"""
