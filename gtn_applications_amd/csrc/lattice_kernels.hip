@@ -1116,114 +1116,138 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
   //    a load pending on such a path).
   // 16-byte loads and LDS stores on the way (rows are padded to four labels: pack.cpp, pad_labels).
   auto sweep = [&](auto sel_, auto live_) {
-  constexpr int SEL = decltype(sel_)::value;
-  constexpr bool LIVE = decltype(live_)::value;
-  auto chunk = [&](int c, auto full_) {
-    constexpr bool FULL = decltype(full_)::value;
+    constexpr int SEL = decltype(sel_)::value;
+    constexpr bool LIVE = decltype(live_)::value;
+    auto chunk = [&](int c, auto full_) {
+      constexpr bool FULL = decltype(full_)::value;
 #ifdef WFL_SWEEP_PHASE_TIMERS
-    const long long eA = clock64();
+      const long long eA = clock64();
 #endif
-    int f0, n;
-    chunk_frames(c, f0, n);
-    const float* tile = lrows + (size_t)(c & 1) * tstride;
-    const float* rtile = lrefs + (size_t)(c & 1) * NT;
-    // the next chunk's rows (see above: no test, no initial value)
-    float pre[kPre], rpre;
-    int pf0, pn;
-    chunk_frames(min(c + 1, nchunks - 1), pf0, pn);
-    {
-      const float4* src4 = reinterpret_cast<const float4*>(fg + u.xg_base + (int64_t)pf0 * Kmax);
-      const int last4 = ((pn * Kmax) >> 2) - 1;
-      rpre = rmax[(int64_t)b * T + pf0 + min(tid, pn - 1)];
+      int f0, n;
+      chunk_frames(c, f0, n);
+      const float* tile = lrows + (size_t)(c & 1) * tstride;
+      const float* rtile = lrefs + (size_t)(c & 1) * NT;
+      // the next chunk's rows (see above: no test, no initial value)
+      float pre[kPre], rpre;
+      int pf0, pn;
+      chunk_frames(min(c + 1, nchunks - 1), pf0, pn);
+      {
+        const float4* src4 = reinterpret_cast<const float4*>(fg + u.xg_base + (int64_t)pf0 * Kmax);
+        const int last4 = ((pn * Kmax) >> 2) - 1;
+        rpre = rmax[(int64_t)b * T + pf0 + min(tid, pn - 1)];
 #pragma unroll
-      for (int j = 0; j < kPre / 4; ++j) {
-        const float4 q = src4[min(tid + j * NT, last4)];
-        pre[4 * j] = q.x, pre[4 * j + 1] = q.y, pre[4 * j + 2] = q.z, pre[4 * j + 3] = q.w;
+        for (int j = 0; j < kPre / 4; ++j) {
+          const float4 q = src4[min(tid + j * NT, last4)];
+          pre[4 * j] = q.x, pre[4 * j + 1] = q.y, pre[4 * j + 2] = q.z, pre[4 * j + 3] = q.w;
+        }
       }
-    }
-    // (`path`: 0 behind the sixteen straight-line frames, 1 a wave without a state, 2 behind a frame loop)
-    auto hand_over = [&](auto path) {
-      lrefs[(size_t)((c + 1) & 1) * NT + tid] = rpre;
-      float4* dst4 = reinterpret_cast<float4*>(lrows + (size_t)((c + 1) & 1) * tstride);
+      // (`path`: 0 behind the sixteen straight-line frames, 1 a wave without a state, 2 behind a frame loop)
+      auto hand_over = [&](auto path) {
+        lrefs[(size_t)((c + 1) & 1) * NT + tid] = rpre;
+        float4* dst4 = reinterpret_cast<float4*>(lrows + (size_t)((c + 1) & 1) * tstride);
 #pragma unroll
-      for (int j = 0; j < kPre / 4; ++j)
-        dst4[tid + j * NT] = make_float4(pre[4 * j], pre[4 * j + 1], pre[4 * j + 2], pre[4 * j + 3]);
-      if constexpr (decltype(path)::value == 0)
-        asm volatile("; rows handed over behind sixteen straight-line frames" ::: "memory");
-      else if constexpr (decltype(path)::value == 1)
-        asm volatile("; rows handed over by a wave without a state" ::: "memory");
-      else
-        asm volatile("; rows handed over behind a frame loop" ::: "memory");
-    };
-    using PathUnrolled = std::integral_constant<int, 0>;
-    using PathIdle = std::integral_constant<int, 1>;
-    using PathLoop = std::integral_constant<int, 2>;
+        for (int j = 0; j < kPre / 4; ++j)
+          dst4[tid + j * NT] = make_float4(pre[4 * j], pre[4 * j + 1], pre[4 * j + 2], pre[4 * j + 3]);
+        if constexpr (decltype(path)::value == 0)
+          asm volatile("; rows handed over behind sixteen straight-line frames" ::: "memory");
+        else if constexpr (decltype(path)::value == 1)
+          asm volatile("; rows handed over by a wave without a state" ::: "memory");
+        else
+          asm volatile("; rows handed over behind a frame loop" ::: "memory");
+      };
+      using PathUnrolled = std::integral_constant<int, 0>;
+      using PathIdle = std::integral_constant<int, 1>;
+      using PathLoop = std::integral_constant<int, 2>;
 #ifdef WFL_SWEEP_PHASE_TIMERS
-    const long long eB = clock64();
-    e_pre += eB - eA;
+      const long long eB = clock64();
+      e_pre += eB - eA;
 #endif
-    // (every 4th chunk: a renormalisation is three barriers, ~1100 cycles of a chunk's 9300, and a double has room for
-    // far more than 64 frames of factors <= 1 -- what it has no room for, the certificate catches)
-    if (c > 0 && (c & 3) == 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
-      // (LDS-only barriers: __syncthreads() also waits for the wave's global operations -- the loads issued just above,
-      // i.e. an HBM round trip in every chunk: 1300-1400 cycles in this section)
-      const int ex = (tid < Q && p > 0.0) ? __builtin_amdgcn_frexp_exp(p) - 1 : -(1 << 30);
-      int* red = (int*)lred;
-      const int wmax = wave_all_max_int(ex);
-      lds_barrier();
-      if ((tid & 63) == 0) red[tid >> 6] = wmax;
-      lds_barrier();
-      int emax = red[0];
-      for (int i = 1; i < (NT + 63) >> 6; ++i) emax = max(emax, red[i]);
-      if (emax > -(1 << 30) && emax < 2000) {
-        p = ldexp(p, -emax);
-        cum += (double)emax;
-        double* fromb = ((DIR == 0 ? f0 : f0 + n) & 1) ? lbuf1 : lbuf0;
-        if (tid < Q) fromb[tid] = p;
+      // (every 4th chunk: a renormalisation is three barriers, ~1100 cycles of a chunk's 9300, and a double has room for
+      // far more than 64 frames of factors <= 1 -- what it has no room for, the certificate catches)
+      if (c > 0 && (c & 3) == 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
+        // (LDS-only barriers: __syncthreads() also waits for the wave's global operations -- the loads issued just above,
+        // i.e. an HBM round trip in every chunk: 1300-1400 cycles in this section)
+        const int ex = (tid < Q && p > 0.0) ? __builtin_amdgcn_frexp_exp(p) - 1 : -(1 << 30);
+        int* red = (int*)lred;
+        const int wmax = wave_all_max_int(ex);
+        lds_barrier();
+        if ((tid & 63) == 0) red[tid >> 6] = wmax;
+        lds_barrier();
+        int emax = red[0];
+        for (int i = 1; i < (NT + 63) >> 6; ++i) emax = max(emax, red[i]);
+        if (emax > -(1 << 30) && emax < 2000) {
+          p = ldexp(p, -emax);
+          cum += (double)emax;
+          double* fromb = ((DIR == 0 ? f0 : f0 + n) & 1) ? lbuf1 : lbuf0;
+          if (tid < Q) fromb[tid] = p;
+        }
+        lds_barrier();
       }
-      lds_barrier();
-    }
 #ifdef WFL_SWEEP_PHASE_TIMERS
-    const long long eC = clock64();
-    e_ren += eC - eB;
+      const long long eC = clock64();
+      e_ren += eC - eB;
 #endif
-    // Software pipeline: the arc coefficients c[k] = wf[k] * f_t[slot_k] of a frame do not depend on the chain, so
-    // they are formed while the previous frame's sources are still on their way from LDS; after the barrier only the
-    // DEG source reads (issued back to back) and DEG multiply-adds (two independent accumulators) remain.
-    auto coeffs = [&](int i, double (&c)[kLeanDeg], auto deg) {
-      constexpr int DEG = decltype(deg)::value;
-      const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
-      const float* row = tile + (size_t)(t - f0) * Kmax;
-      float f[DEG];
+      // Software pipeline: the arc coefficients c[k] = wf[k] * f_t[slot_k] of a frame do not depend on the chain, so
+      // they are formed while the previous frame's sources are still on their way from LDS; after the barrier only the
+      // DEG source reads (issued back to back) and DEG multiply-adds (two independent accumulators) remain.
+      auto coeffs = [&](int i, double (&c)[kLeanDeg], auto deg) {
+        constexpr int DEG = decltype(deg)::value;
+        const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+        const float* row = tile + (size_t)(t - f0) * Kmax;
+        float f[DEG];
 #pragma unroll
-      for (int k = 0; k < DEG; ++k) f[k] = row[aslot[k]];
+        for (int k = 0; k < DEG; ++k) f[k] = row[aslot[k]];
 #pragma unroll
-      for (int k = 0; k < DEG; ++k) c[k] = wf[k] * (double)f[k];
-    };
-    // Frame loops.  The workgroup's waves meet at ONE LDS-only barrier per frame and a wave issues an instruction every
-    // ~5 cycles, so the instruction count of a frame is its time (SQ counters at cfg4: 27 VALU + 19 SALU + 5 LDS
-    // instructions per live wave and frame, waves waiting 63 % of their cycles): waves without a state only run the
-    // barriers, the row pointer and the tile pointer advance by scalar adds, the ping-pong buffers swap by parity.
-    auto frames = [&](auto deg) {
-      constexpr int DEG = decltype(deg)::value;
-      double c[kLeanDeg], cn[kLeanDeg];
-      coeffs(0, c, deg);
-      double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
-      int par = (DIR == 0 ? f0 : f0 + n) & 1;  // parity of the slot the frame reads from
-      if constexpr (FULL) {  // (a full chunk as straight-line code with unconditional stores: see frames_uniform)
-        const bool mine = tid < Q;
-        double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
-        const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
-        const double* bA = par ? lbuf1 : lbuf0;
-        const double* bB = par ? lbuf0 : lbuf1;
+        for (int k = 0; k < DEG; ++k) c[k] = wf[k] * (double)f[k];
+      };
+      // Frame loops.  The workgroup's waves meet at ONE LDS-only barrier per frame and a wave issues an instruction every
+      // ~5 cycles, so the instruction count of a frame is its time (SQ counters at cfg4: 27 VALU + 19 SALU + 5 LDS
+      // instructions per live wave and frame, waves waiting 63 % of their cycles): waves without a state only run the
+      // barriers, the row pointer and the tile pointer advance by scalar adds, the ping-pong buffers swap by parity.
+      auto frames = [&](auto deg) {
+        constexpr int DEG = decltype(deg)::value;
+        double c[kLeanDeg], cn[kLeanDeg];
+        coeffs(0, c, deg);
+        double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
+        int par = (DIR == 0 ? f0 : f0 + n) & 1;  // parity of the slot the frame reads from
+        if constexpr (FULL) {  // (a full chunk as straight-line code with unconditional stores: see frames_uniform)
+          const bool mine = tid < Q;
+          double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
+          const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
+          const double* bA = par ? lbuf1 : lbuf0;
+          const double* bB = par ? lbuf0 : lbuf1;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const double* from = (i & 1) ? bB : bA;
-          double* to = const_cast<double*>((i & 1) ? bA : bB);
+          for (int i = 0; i < 16; ++i) {
+            const double* from = (i & 1) ? bB : bA;
+            double* to = const_cast<double*>((i & 1) ? bA : bB);
+            double ps[DEG];
+#pragma unroll
+            for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+            if (i + 1 < 16) coeffs(i + 1, cn, deg);
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < DEG; k += 2) {
+              acc0 = fma(ps[k], c[k], acc0);
+              acc1 = fma(ps[k + 1], c[k + 1], acc1);
+            }
+            p = acc0 + acc1;
+            to[tid] = p;
+            WFL_SWEEP_STORE(po, p);
+            po += pstep;
+#pragma unroll
+            for (int k = 0; k < DEG; ++k) c[k] = cn[k];
+            lds_barrier();
+          }
+          hand_over(PathUnrolled{});
+          return;
+        }
+        for (int i = 0; i < n; ++i) {
+          const double* from = par ? lbuf1 : lbuf0;
+          double* to = par ? lbuf0 : lbuf1;
           double ps[DEG];
 #pragma unroll
           for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
-          if (i + 1 < 16) coeffs(i + 1, cn, deg);
+          if (i + 1 < n) coeffs(i + 1, cn, deg);
           double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
           for (int k = 0; k < DEG; k += 2) {
@@ -1231,82 +1255,82 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
             acc1 = fma(ps[k + 1], c[k + 1], acc1);
           }
           p = acc0 + acc1;
-          to[tid] = p;
-          WFL_SWEEP_STORE(po, p);
-          po += pstep;
+          if (tid < Q) {
+            to[tid] = p;
+            WFL_SWEEP_STORE(orow + tid, p);
+          }
 #pragma unroll
           for (int k = 0; k < DEG; ++k) c[k] = cn[k];
+          orow = DIR == 0 ? orow + Q : orow - Q;
+          par ^= 1;
+          lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
+        }
+        hand_over(PathLoop{});
+      };
+      auto frames_uniform = [&](auto deg) {
+        constexpr int DEG = decltype(deg)::value;
+        if (DIR == 1) {
+          // beta: the LDS vector holds G = f[label(d)] * beta[d] for the frame about to be consumed; at the chunk's
+          // first frame it still holds plain beta (the tile of this chunk was not there when it was written)
+          const int t0 = f0 + n - 1;
+          const double* fromb = ((t0 + 1) & 1) ? lbuf1 : lbuf0;
+          if (tid < Q) {  // (own entry only: no hazard before the write)
+            double* fb = const_cast<double*>(fromb);
+            fb[tid] = fb[tid] * (double)tile[(size_t)(t0 - f0) * Kmax + my_slot];
+          }
           lds_barrier();
         }
-        hand_over(PathUnrolled{});
-        return;
-      }
-      for (int i = 0; i < n; ++i) {
-        const double* from = par ? lbuf1 : lbuf0;
-        double* to = par ? lbuf0 : lbuf1;
-        double ps[DEG];
+        double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
+        int par = (DIR == 0 ? f0 : f0 + n) & 1;
+        // alpha: this frame's factor of the state; beta: the factor of the NEXT frame to be consumed (t - 1), with
+        // which the owner publishes; past the chunk (the tile is not there yet) plain beta is published
+        const float* fptr = tile + (size_t)(DIR == 0 ? 0 : max(n - 2, 0)) * Kmax + my_slot;
+        if constexpr (FULL) {
+          // A full chunk as straight-line code whose stores EVERY lane executes (lanes without a state store to a dump
+          // and to their own, never read, LDS entry).  The threads of this workgroup also prefetch the next chunk's rows:
+          // loads and stores share the in-order vmcnt counter and the compiler counts, for the wait in front of the
+          // prefetched rows, only the operations that are issued on EVERY path -- with the stores inside `if (tid < Q)`
+          // or inside a loop of unknown trip count that wait became "everything", i.e. the last frame's store round trip
+          // (~1.5 us) at the end of every chunk.
+          const bool mine = tid < Q;
+          double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
+          const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
+          const double* bA = par ? lbuf1 : lbuf0;  // read by the even frames of the chunk, written by the odd ones
+          const double* bB = par ? lbuf0 : lbuf1;
+          const int fstep = DIR == 0 ? Kmax : -Kmax;
 #pragma unroll
-        for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
-        if (i + 1 < n) coeffs(i + 1, cn, deg);
-        double acc0 = 0.0, acc1 = 0.0;
+          for (int i = 0; i < 16; ++i) {
+            const double* from = (i & 1) ? bB : bA;
+            double* to = const_cast<double*>((i & 1) ? bA : bB);
+            double ps[DEG];
 #pragma unroll
-        for (int k = 0; k < DEG; k += 2) {
-          acc0 = fma(ps[k], c[k], acc0);
-          acc1 = fma(ps[k + 1], c[k + 1], acc1);
+            for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+            const float fr = fptr[(DIR == 0 || i < 15) ? i * fstep : 14 * fstep];
+            const float f = (DIR == 0 || i < 15) ? fr : 1.f;
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < DEG; k += 2) {
+              acc0 = fma(ps[k], wf[k], acc0);
+              acc1 = fma(ps[k + 1], wf[k + 1], acc1);
+            }
+            const double sum = acc0 + acc1;
+            p = DIR == 0 ? sum * (double)f : sum;
+            to[tid] = DIR == 0 ? p : p * (double)f;
+            WFL_SWEEP_STORE(po, p);
+            po += pstep;
+            lds_barrier();
+          }
+          hand_over(PathUnrolled{});
+          return;
         }
-        p = acc0 + acc1;
-        if (tid < Q) {
-          to[tid] = p;
-          WFL_SWEEP_STORE(orow + tid, p);
-        }
-#pragma unroll
-        for (int k = 0; k < DEG; ++k) c[k] = cn[k];
-        orow = DIR == 0 ? orow + Q : orow - Q;
-        par ^= 1;
-        lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
-      }
-      hand_over(PathLoop{});
-    };
-    auto frames_uniform = [&](auto deg) {
-      constexpr int DEG = decltype(deg)::value;
-      if (DIR == 1) {
-        // beta: the LDS vector holds G = f[label(d)] * beta[d] for the frame about to be consumed; at the chunk's
-        // first frame it still holds plain beta (the tile of this chunk was not there when it was written)
-        const int t0 = f0 + n - 1;
-        const double* fromb = ((t0 + 1) & 1) ? lbuf1 : lbuf0;
-        if (tid < Q) {  // (own entry only: no hazard before the write)
-          double* fb = const_cast<double*>(fromb);
-          fb[tid] = fb[tid] * (double)tile[(size_t)(t0 - f0) * Kmax + my_slot];
-        }
-        lds_barrier();
-      }
-      double* orow = out + u.ab_base + (int64_t)(DIR == 0 ? f0 + 1 : f0 + n - 1) * Q;
-      int par = (DIR == 0 ? f0 : f0 + n) & 1;
-      // alpha: this frame's factor of the state; beta: the factor of the NEXT frame to be consumed (t - 1), with
-      // which the owner publishes; past the chunk (the tile is not there yet) plain beta is published
-      const float* fptr = tile + (size_t)(DIR == 0 ? 0 : max(n - 2, 0)) * Kmax + my_slot;
-      if constexpr (FULL) {
-        // A full chunk as straight-line code whose stores EVERY lane executes (lanes without a state store to a dump
-        // and to their own, never read, LDS entry).  The threads of this workgroup also prefetch the next chunk's rows:
-        // loads and stores share the in-order vmcnt counter and the compiler counts, for the wait in front of the
-        // prefetched rows, only the operations that are issued on EVERY path -- with the stores inside `if (tid < Q)`
-        // or inside a loop of unknown trip count that wait became "everything", i.e. the last frame's store round trip
-        // (~1.5 us) at the end of every chunk.
-        const bool mine = tid < Q;
-        double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
-        const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
-        const double* bA = par ? lbuf1 : lbuf0;  // read by the even frames of the chunk, written by the odd ones
-        const double* bB = par ? lbuf0 : lbuf1;
-        const int fstep = DIR == 0 ? Kmax : -Kmax;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const double* from = (i & 1) ? bB : bA;
-          double* to = const_cast<double*>((i & 1) ? bA : bB);
+        for (int i = 0; i < n; ++i) {
+          const double* from = par ? lbuf1 : lbuf0;
+          double* to = par ? lbuf0 : lbuf1;
           double ps[DEG];
 #pragma unroll
           for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
-          const float fr = fptr[(DIR == 0 || i < 15) ? i * fstep : 14 * fstep];
-          const float f = (DIR == 0 || i < 15) ? fr : 1.f;
+          const float fr = *fptr;
+          const float f = (DIR == 0 || i + 1 < n) ? fr : 1.f;
           double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
           for (int k = 0; k < DEG; k += 2) {
@@ -1315,118 +1339,94 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
           }
           const double sum = acc0 + acc1;
           p = DIR == 0 ? sum * (double)f : sum;
-          to[tid] = DIR == 0 ? p : p * (double)f;
-          WFL_SWEEP_STORE(po, p);
-          po += pstep;
+          if (tid < Q) {
+            to[tid] = DIR == 0 ? p : p * (double)f;
+            WFL_SWEEP_STORE(orow + tid, p);
+          }
+          orow = DIR == 0 ? orow + Q : orow - Q;
+          if (DIR == 0 || i + 2 < n) fptr = DIR == 0 ? fptr + Kmax : fptr - Kmax;
+          par ^= 1;
           lds_barrier();
         }
-        hand_over(PathUnrolled{});
-        return;
-      }
-      for (int i = 0; i < n; ++i) {
-        const double* from = par ? lbuf1 : lbuf0;
-        double* to = par ? lbuf0 : lbuf1;
-        double ps[DEG];
+        // (beta: the chunk's last step published plain beta -- no factor past the chunk -- which is what the
+        // renormalisation and the next chunk's first step expect)
+        hand_over(PathLoop{});
+      };
+      // The chunk's per-slot offsets at once, outside the frame loop (n <= 16 frames): lane i of every row of 16 takes
+      // the chunk's i-th frame in sweep order, an inclusive prefix sum over the row (DPP) gives the offset after each
+      // frame, wave 0 stores them in one instruction.  Inside the loop the same bookkeeping was an LDS read whose wait
+      // sat in front of every frame's barrier.
+      double chunk_log2;
+      {
+        const int li = tid & 15;
+        const float rsel = rtile[(DIR == 0 ? li : n - 1 - li) & 15];
+        double pre = li < n ? ((double)rsel + (double)wref) * kLog2e_d : 0.0;
 #pragma unroll
-        for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
-        const float fr = *fptr;
-        const float f = (DIR == 0 || i + 1 < n) ? fr : 1.f;
-        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < DEG; k += 2) {
-          acc0 = fma(ps[k], wf[k], acc0);
-          acc1 = fma(ps[k + 1], wf[k + 1], acc1);
+        for (int o = 1; o < 16; o <<= 1) {
+          const int lo = __double2loint(pre), hi = __double2hiint(pre);  // row_shr:o, lanes without a source read 0
+          const int slo = o == 1   ? __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true)
+                          : o == 2 ? __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true)
+                          : o == 4 ? __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true)
+                                   : __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true);
+          const int shi = o == 1   ? __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true)
+                          : o == 2 ? __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true)
+                          : o == 4 ? __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true)
+                                   : __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true);
+          pre += __hiloint2double(shi, slo);
         }
-        const double sum = acc0 + acc1;
-        p = DIR == 0 ? sum * (double)f : sum;
-        if (tid < Q) {
-          to[tid] = DIR == 0 ? p : p * (double)f;
-          WFL_SWEEP_STORE(orow + tid, p);
-        }
-        orow = DIR == 0 ? orow + Q : orow - Q;
-        if (DIR == 0 || i + 2 < n) fptr = DIR == 0 ? fptr + Kmax : fptr - Kmax;
-        par ^= 1;
-        lds_barrier();
+        if (tid < n) offs[DIR == 0 ? f0 + tid + 1 : f0 + n - 1 - tid] = cum + pre;
+        chunk_log2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pre), 15),
+                                      __builtin_amdgcn_readlane(__double2loint(pre), 15));  // (lanes >= n added 0)
       }
-      // (beta: the chunk's last step published plain beta -- no factor past the chunk -- which is what the
-      // renormalisation and the next chunk's first step expect)
-      hand_over(PathLoop{});
+      // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
+      // (uniform-label acceptors: PER WAVE -- the frame loops differ only in how many of the eight arc slots they read,
+      // one barrier per frame in all of them; the alignment graphs of the Transducer have 2-5 arcs into most states and
+      // 8 into a few: waves that do not hold such a state read 4 or 6 vector entries per state and frame, not 8)
+      // (even classes only: the frame loops take the arc slots in pairs)
+#ifdef WFL_SWEEP_PHASE_TIMERS
+      const long long eD = clock64();
+      e_offs += eD - eC;
+#endif
+      if constexpr (!LIVE) {  // only the barriers (the frame loops below: one per frame, one more in front of beta's)
+        if (DIR == 1 && uniform) lds_barrier();
+        for (int i = 0; i < n; ++i) lds_barrier();
+        hand_over(PathIdle{});
+      } else if constexpr (SEL == 0)
+        frames_uniform(std::integral_constant<int, 2>{});
+      else if constexpr (SEL == 1)
+        frames_uniform(std::integral_constant<int, 4>{});
+      else if constexpr (SEL == 2)
+        frames_uniform(std::integral_constant<int, 6>{});
+      else if constexpr (SEL == 3)
+        frames_uniform(std::integral_constant<int, kLeanDeg>{});
+      else if constexpr (SEL == 4)
+        frames(std::integral_constant<int, 2>{});
+      else if constexpr (SEL == 5)
+        frames(std::integral_constant<int, 4>{});
+      else
+        frames(std::integral_constant<int, kLeanDeg>{});
+#ifdef WFL_SWEEP_PHASE_TIMERS
+      const long long eE = clock64();
+      e_fr += eE - eD;
+#endif
+      cum += chunk_log2;
+      if (c + 1 < nchunks) {
+        if (PUB) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (see below)
+        __syncthreads();
+        // Chunk c - 1 is in L2: its stores are older than this chunk's prefetch loads and its (at most 16) frame stores,
+        // vmcnt counts loads and stores in issue order, and every thread has just waited until at most 16 of its
+        // operations were outstanding.  (One chunk of lag costs the gradient nothing; waiting for THIS chunk's stores
+        // would put a store round trip, ~1.5 us, behind every 16 frames.)
+        if (PUB && tid == 0 && c > 0) prog_publish(prog, token, (uint32_t)c);
+      }
+#ifdef WFL_SWEEP_PHASE_TIMERS
+      e_hand += clock64() - eE;
+#endif
     };
-    // The chunk's per-slot offsets at once, outside the frame loop (n <= 16 frames): lane i of every row of 16 takes
-    // the chunk's i-th frame in sweep order, an inclusive prefix sum over the row (DPP) gives the offset after each
-    // frame, wave 0 stores them in one instruction.  Inside the loop the same bookkeeping was an LDS read whose wait
-    // sat in front of every frame's barrier.
-    double chunk_log2;
-    {
-      const int li = tid & 15;
-      const float rsel = rtile[(DIR == 0 ? li : n - 1 - li) & 15];
-      double pre = li < n ? ((double)rsel + (double)wref) * kLog2e_d : 0.0;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        const int lo = __double2loint(pre), hi = __double2hiint(pre);  // row_shr:o, lanes without a source read 0
-        const int slo = o == 1   ? __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true)
-                        : o == 2 ? __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true)
-                        : o == 4 ? __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true)
-                                 : __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true);
-        const int shi = o == 1   ? __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true)
-                        : o == 2 ? __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true)
-                        : o == 4 ? __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true)
-                                 : __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true);
-        pre += __hiloint2double(shi, slo);
-      }
-      if (tid < n) offs[DIR == 0 ? f0 + tid + 1 : f0 + n - 1 - tid] = cum + pre;
-      chunk_log2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pre), 15),
-                                    __builtin_amdgcn_readlane(__double2loint(pre), 15));  // (lanes >= n added 0)
-    }
-    // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
-    // (uniform-label acceptors: PER WAVE -- the frame loops differ only in how many of the eight arc slots they read,
-    // one barrier per frame in all of them; the alignment graphs of the Transducer have 2-5 arcs into most states and
-    // 8 into a few: waves that do not hold such a state read 4 or 6 vector entries per state and frame, not 8)
-    // (even classes only: the frame loops take the arc slots in pairs)
-#ifdef WFL_SWEEP_PHASE_TIMERS
-    const long long eD = clock64();
-    e_offs += eD - eC;
-#endif
-    if constexpr (!LIVE) {  // only the barriers (the frame loops below: one per frame, one more in front of beta's)
-      if (DIR == 1 && uniform) lds_barrier();
-      for (int i = 0; i < n; ++i) lds_barrier();
-      hand_over(PathIdle{});
-    } else if constexpr (SEL == 0)
-      frames_uniform(std::integral_constant<int, 2>{});
-    else if constexpr (SEL == 1)
-      frames_uniform(std::integral_constant<int, 4>{});
-    else if constexpr (SEL == 2)
-      frames_uniform(std::integral_constant<int, 6>{});
-    else if constexpr (SEL == 3)
-      frames_uniform(std::integral_constant<int, kLeanDeg>{});
-    else if constexpr (SEL == 4)
-      frames(std::integral_constant<int, 2>{});
-    else if constexpr (SEL == 5)
-      frames(std::integral_constant<int, 4>{});
-    else
-      frames(std::integral_constant<int, kLeanDeg>{});
-#ifdef WFL_SWEEP_PHASE_TIMERS
-    const long long eE = clock64();
-    e_fr += eE - eD;
-#endif
-    cum += chunk_log2;
-    if (c + 1 < nchunks) {
-      if (PUB) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (see below)
-      __syncthreads();
-      // Chunk c - 1 is in L2: its stores are older than this chunk's prefetch loads and its (at most 16) frame stores,
-      // vmcnt counts loads and stores in issue order, and every thread has just waited until at most 16 of its
-      // operations were outstanding.  (One chunk of lag costs the gradient nothing; waiting for THIS chunk's stores
-      // would put a store round trip, ~1.5 us, behind every 16 frames.)
-      if (PUB && tid == 0 && c > 0) prog_publish(prog, token, (uint32_t)c);
-    }
-#ifdef WFL_SWEEP_PHASE_TIMERS
-    e_hand += clock64() - eE;
-#endif
-  };
-  // chunks whose sixteen frames run as straight-line code (nchunks is 0 when the banded sweep above has done the work)
-  const int nfull = (UNR && R == 16) ? min(T / 16, nchunks) : 0;
-  for (int c = 0; c < nfull; ++c) chunk(c, std::true_type{});
-  for (int c = nfull; c < nchunks; ++c) chunk(c, std::false_type{});
+    // chunks whose sixteen frames run as straight-line code (nchunks is 0 when the banded sweep above has done the work)
+    const int nfull = (UNR && R == 16) ? min(T / 16, nchunks) : 0;
+    for (int c = 0; c < nfull; ++c) chunk(c, std::true_type{});
+    for (int c = nfull; c < nchunks; ++c) chunk(c, std::false_type{});
   };
   if (!wave_live)
     sweep(std::integral_constant<int, 7>{}, std::false_type{});
