@@ -42,11 +42,18 @@
 #ifndef WFL_MITM_STORE
 #define WFL_MITM_STORE 2  // gradient row stores: 0 plain, 1 non-temporal, 2 sc0 sc1, 3 sc1, 4 sc0 sc1 nt (scratch A/B)
 #endif
+#ifndef WFL_MITM_CLAMP_EVERY
+#define WFL_MITM_CLAMP_EVERY 1  // the neighbour-gap clamp in every n-th block of the chain (1 or 4; 4: -0.5 us at cfg2, but fronts that cross four lanes inside one block overflow: 10 of 128 peaked utterances repaired)
+#endif
+#ifndef WFL_MITM_LEAN
+#define WFL_MITM_LEAN 1  // 1: the chain wave without its renormalisation (lane exponents predicted by the helper wave); 0: renormalised on the wave (A/B)
+#endif
 #ifndef WFL_MITM_STATS
 #define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
 #endif
 
 constexpr int kMSpin = 1 << 24;
+constexpr int kMaxCouple = 100;  // bound on the exponent of a coupling factor (chain wave and emitters alike)
 constexpr int kMTile = 128;   // floats per row of an emitter's gradient tile (a compile-time stride: the 16 rows of a label's
                               // column are one LDS address + immediate offsets); the step takes C <= kMTile
 
@@ -69,54 +76,13 @@ struct MitmK<16> {
 #else
   static constexpr int kPSlots = 6;   // partner checkpoints handed from the fetcher to the emitters
 #endif
-#ifndef WFL_MITM_EMIT8
-#define WFL_MITM_EMIT8 0  // 1: no emitter on the chain wave's SIMD (wave 12 ends at once: 8 emitters)
-#endif
-#ifndef WFL_MITM_LAYOUT
-#define WFL_MITM_LAYOUT 0  // 1 (scratch): the chain wave alone on its SIMD -- flusher and fetcher on waves 13 / 14, six emitters
-#endif
-  static constexpr int kStagers = WFL_MITM_LAYOUT == 2 ? 5 : WFL_MITM_LAYOUT == 3 ? 6 : 4,
-                       kEmitters = WFL_MITM_LAYOUT == 1 ? 6 : WFL_MITM_LAYOUT == 2 ? 8 : WFL_MITM_LAYOUT == 3 ? 7 : WFL_MITM_EMIT8 ? 8 : 9,
-                       kWaves = 16;
+  static constexpr int kStagers = 4, kEmitters = 9, kWaves = 16;
   __device__ static __forceinline__ void role(int wave, int& role, int& idx) {
-#if WFL_MITM_LAYOUT == 2 || WFL_MITM_LAYOUT == 3
-    // (scratch) five / six stagers, eight / seven emitters
-    constexpr int NS = WFL_MITM_LAYOUT == 2 ? 5 : 6;
-    switch (wave) {
-      case 0: role = 0, idx = 0; return;
-      case 4: role = 2, idx = 0; return;
-      case 8: role = 3, idx = 0; return;
-      default: break;
-    }
-    // the other waves in order: 1 2 3 5 6 7 9 10 11 13 14 15 12
-    const int order = wave == 12 ? 12 : wave - 1 - (wave > 4) - (wave > 8) - (wave > 12);
-    if (order < NS) role = 1, idx = order; else role = 4, idx = order - NS;
-    return;
-#endif
-#if WFL_MITM_LAYOUT == 1
-    switch (wave) {
-      case 0: role = 0, idx = 0; break;
-      case 4: case 8: case 12: role = 5, idx = 0; break;
-      case 13: role = 2, idx = 0; break;
-      case 14: role = 3, idx = 0; break;
-      case 1: role = 1, idx = 0; break;
-      case 2: role = 1, idx = 1; break;
-      case 3: role = 1, idx = 2; break;
-      case 5: role = 1, idx = 3; break;
-      case 6: role = 4, idx = 0; break;
-      case 7: role = 4, idx = 1; break;
-      case 9: role = 4, idx = 2; break;
-      case 10: role = 4, idx = 3; break;
-      case 11: role = 4, idx = 4; break;
-      default: role = 4, idx = 5; break;
-    }
-    return;
-#endif
     switch (wave) {  // (a switch on a scalar: compiled to scalar compares)
       case 0: role = 0, idx = 0; break;
       case 4: role = 2, idx = 0; break;
       case 8: role = 3, idx = 0; break;
-      case 12: role = WFL_MITM_EMIT8 ? 5 : 4, idx = 8; break;
+      case 12: role = 4, idx = 8; break;
       case 1: role = 1, idx = 0; break;
       case 2: role = 1, idx = 1; break;
       case 3: role = 1, idx = 2; break;
@@ -150,9 +116,10 @@ struct MitmK<8> {
   }
 };
 
+typedef float mv4f __attribute__((ext_vector_type(4)));
 template <class K>
 struct MitmLds {
-  float2 ring[K::kSlots][kBlk][64];  // (fb, fl) per frame and lane: 80 KiB
+  mv4f ring[K::kSlots][kBlk / 2][64];  // (fb, fl) of two frames per entry and lane: 72 KiB
   float4 pck[K::kPSlots][64];        // partner state after the block, own lane order: (bb, bl, eb bits, -)
   float4 ck[K::kSlots][64];          // own state before block n: (blank mantissa, label mantissa, lane exponent bits, -)
   float fref[K::kSlots][kBlk];       // per-frame references r_t (integer valued; 0 past the block's frames)
@@ -167,8 +134,8 @@ struct MitmLds {
   int zready;
   int enext;                       // next block to emit: the emitters take blocks as they become free (a static round robin
                                    // lets the slowest emitter -- the one next to the chain wave -- hold up the whole ring)
-  int chainpos;                    // p: the chain wave holds the factors of all blocks < p in registers and has handed over its
-                                   // checkpoints < p - 1 (ONE post per block)
+  int chainpos;                    // p: the chain wave holds the factors of all blocks < p in registers
+  int ckpos;                       // q: the chain wave has written its checkpoints < q (block n's: when it enters the block)
   int ckdone;                      // ... picked up by the flusher (offc valid)
   int offdone;                     // offtot valid
   int cmap_ready;                  // (wide rows) the column -> slot map behind the emitters' tiles is written
@@ -525,9 +492,9 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
     asm volatile("" ::: "memory");
     mv2f F[kBlk];
 #pragma unroll
-    for (int j = 0; j < kBlk; ++j) {
-      const float2 f = S.ring[slot][j][lane];
-      F[j] = mv2f{f.x, f.y};
+    for (int j = 0; j < kBlk; j += 2) {
+      const mv4f f = S.ring[slot][j >> 1][lane];
+      F[j] = mv2f{f.x, f.y}, F[j + 1] = mv2f{f.z, f.w};
     }
     const float4 cko = S.ck[slot][lane];
     const int ea = __float_as_int(cko.z);
@@ -550,7 +517,7 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
     MITM_T0();
     const float rsum = wave_all_sum(rr);
     const int ea_prev = wave_shr1_i(ea, ea);
-    const float g = lane == 0 ? 0.f : ldexpf(1.f, max(ea_prev - ea, -200));
+    const float g = lane == 0 ? 0.f : ldexpf(1.f, min(max(ea_prev - ea, -200), kMaxCouple));
     const float gs = skip ? g : 0.f;
     float* dst = dx + ((int64_t)b * T + ((WFL_MITM_ABL & 256) ? (t0 & 63) : t0)) * C;  // (256, scratch: the same stores, no HBM traffic)
     if (WFL_MITM_ABL & 128) {  // (scratch: the hand-offs without the block's arithmetic and stores)
@@ -627,7 +594,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
   if (threadIdx.x < K::kSlots) S.egrab[threadIdx.x] = 0;
   if (threadIdx.x < K::kPSlots) S.pgrab[threadIdx.x] = 0;
   if (threadIdx.x == 0) S.enext = mitm_first_emitted(ctc_blocks(a.T), dir), S.zready = 0;
-  if (threadIdx.x == 0) S.chainpos = 0, S.ckdone = 0, S.offdone = 0, S.cmap_ready = 0;
+  if (threadIdx.x == 0) S.chainpos = 0, S.ckpos = 0, S.ckdone = 0, S.offdone = 0, S.cmap_ready = 0;
 #if WFL_MITM_STATS
   if (threadIdx.x < 64) S.blk_t[threadIdx.x] = 0;
 #endif
@@ -745,7 +712,9 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       const int slot = n % K::kSlots;
       if (((WFL_MITM_ABL & 16) && n >= H0) || (WFL_MITM_ABL & 512)) {  // (scratch: what a second half fed with ready-made factors would cost)
 #pragma unroll
-        for (int j = 0; j < kBlk; ++j) S.ring[slot][j][lane] = make_float2(has_blank ? 0.7f : 0.f, has_label ? 0.7f + 0.001f * raw[j] : 0.f);
+        for (int j = 0; j < kBlk; j += 2)
+          S.ring[slot][j >> 1][lane] = mv4f{has_blank ? 0.7f : 0.f, has_label ? 0.7f + 0.001f * raw[j] : 0.f, has_blank ? 0.7f : 0.f,
+                                            has_label ? 0.7f + 0.001f * raw[j + 1] : 0.f};
         if (lane < kBlk) S.fref[slot][lane] = 0.f;
         return;
       }
@@ -761,9 +730,10 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       const float rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
       const float hb = has_blank ? 1.f : 0.f;
 #pragma unroll
-      for (int j = 0; j < kBlk; ++j) {
-        const float f = __builtin_amdgcn_exp2f(vmax(fmaf(xr[j], kLog2e, -readlane_f(rr, j)), WFL_NEG_INF));
-        S.ring[slot][j][lane] = make_float2(readlane_f(f, L) * hb, has_label ? f : 0.f);
+      for (int j = 0; j < kBlk; j += 2) {
+        const float f0 = __builtin_amdgcn_exp2f(vmax(fmaf(xr[j], kLog2e, -readlane_f(rr, j)), WFL_NEG_INF));
+        const float f1 = __builtin_amdgcn_exp2f(vmax(fmaf(xr[j + 1], kLog2e, -readlane_f(rr, j + 1)), WFL_NEG_INF));
+        S.ring[slot][j >> 1][lane] = mv4f{readlane_f(f0, L) * hb, has_label ? f0 : 0.f, readlane_f(f1, L) * hb, has_label ? f1 : 0.f};
       }
       if (lane < kBlk) S.fref[slot][lane] = lane < cnt ? rr : 0.f;
     };
@@ -839,7 +809,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       {
         int spin = 0;
         MITM_T0();
-        while (lds_peek(&S.chainpos) < kk + 2) {
+        while (lds_peek(&S.ckpos) < kk + 1) {
           __builtin_amdgcn_s_sleep((WFL_MITM_ABL & 1024) ? 8 : 1);
           if (++spin > kMSpin) give_up();
         }
@@ -953,60 +923,127 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
   if (role == 0) {
     // ================================================================ the chain
     __builtin_amdgcn_s_setprio(3);
-    float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
-    float pl = 0.f;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f P = {(lane == 0) ? 1.f : 0.f, 0.f};  // virtual slot "before the first frame": only state 0 alive
     int e = 0;
-    float g = 0.f, gs = 0.f;
+    v2f G = {0.f, 0.f};
     bool bad = false;
-    // per-lane power-of-two renormalisation, neighbour-gap clamp, coupling factors for the interval
-    auto lane_renorm = [&]() {
+    const unsigned long long skipmask = __builtin_amdgcn_ballot_w64(skip);
+    // coupling factors of the interval: g = 2^(e[i-1] - e[i]) (lane 0 has no source lane: the DPP subtraction leaves its
+    // -300 alone and 2^-300 is zero), bounded by 2^kMaxCouple -- after a full renormalisation by 2^kGap by construction
+    auto coupling = [&]() {
+      int d = -300;
+      asm("s_nop 1\n\tv_sub_u32_dpp %0, %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(e));
+      const float g = ldexpf(1.f, min(d, kMaxCouple));
+      G = v2f{g, skip ? g : 0.f};
+    };
+    // per-lane power-of-two renormalisation WITH the neighbour-gap clamp (a wave-wide prefix maximum: ~146 cycles)
+    auto renorm_full = [&]() {
       // (no overflow test here: an inf or NaN mantissa stays one -- ldexp, the frames' multiply-adds -- and is
       // seen after the last frame; the blocks' certificates see it as well)
-      const float mx = vmax(pb, pl);
+      const float mx = vmax(P.x, P.y);
       const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
       const int own = mx > 0.f ? e + k : kEmptyE;
       const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
       // mantissa to [0.5, 1), then down by what the clamp pulled the exponent up: ONE scaling by 2^(e - pre)
-      // (= 2^-(k + pre - own); a lane pulled up by more than ~150 flushes to zero either way, an empty lane is zero
-      // and stays zero whatever the exponent; v_ldexp_f32 takes any integer)
       const int shf = e - pre;
-      pb = ldexpf(pb, shf);
-      pl = ldexpf(pl, shf);
+      P.x = ldexpf(P.x, shf), P.y = ldexpf(P.y, shf);
       e = pre;
-      // g = 2^(e[i-1] - e[i]) <= 2^kGap by construction; lane 0 has no source lane: the DPP subtraction leaves its
-      // -300 alone and 2^-300 is zero
-      int d = -300;
-      asm("s_nop 1\n\tv_sub_u32_dpp %0, %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(e));
-      g = ldexpf(1.f, d);
-      gs = skip ? g : 0.f;
+      coupling();
     };
-    auto frame = [&](const float2 f) {
-      const float c0 = f.x * g, c1 = f.y * gs;
-      float t0 = f.x * pb, t1 = f.y * pb;
-      fmac2_shr1(t0, t1, pl, c0, c1);
-      pl = fmaf(f.y, pl, t1);
-      pb = t0;
+    // ... and WITHOUT it: every lane by its own exponent (an empty lane keeps the exponent it has).  What the clamp is
+    // for -- a lane far below its neighbour must not be flooded by the neighbour's inflow, 2^(e[i-1] - e[i]) times a
+    // mantissa -- only needs the gap bounded by float's range, not by kGap: the clamp is renewed every fourth block
+    // (and in every block of the start, while lanes are still empty) and may slip in between.  ~55 cycles.
+    auto renorm_own = [&]() {
+      const float mx = vmax(P.x, P.y);
+      const int nk = -__builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0 (and for inf / NaN)
+      P.x = ldexpf(P.x, nk), P.y = ldexpf(P.y, nk);
+      e -= nk;
+      coupling();
     };
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    auto frames4 = [&](const float2& f0, const float2& f1, const float2& f2, const float2& f3) {
-      v2f Pq = {pb, pl};
-      const v2f G = {g, gs};
-      const v2f F0 = {f0.x, f0.y}, F1 = {f1.x, f1.y}, F2 = {f2.x, f2.y}, F3 = {f3.x, f3.y};
+    auto frame = [&](const v2f f) {
+      const float c0 = f.x * G.x, c1 = f.y * G.y;
+      float t0 = f.x * P.x, t1 = f.y * P.x;
+      fmac2_shr1(t0, t1, P.y, c0, c1);
+      P.y = fmaf(f.y, P.y, t1);
+      P.x = t0;
+    };
+    int s0 = 0, s1 = 1 % K::kSlots, s2 = 2 % K::kSlots;  // ring slots of blocks kk, kk + 1, kk + 2
+    // wait until the factors of block kk + 1 are staged; `sf` is what the flag read a block ago
+    auto staged_next = [&](int kk, int sf) {
+      if (kk + 1 >= NB) return;
+      if (__builtin_expect(__builtin_amdgcn_readfirstlane(sf) != kk + 2, 0)) {
+        int spin = 0;
+        MITM_T0();
+        while (lds_peek(&S.staged[s1]) != kk + 2)
+          if (++spin > kMSpin) give_up();
+        MITM_ACC(st_wait1);
+#if WFL_MITM_STATS
+        st_polls += spin;
+#endif
+      }
+      asm volatile("" ::: "memory");
+    };
+    auto checkpoint = [&](int kk) {
+      // (two stores of what is in registers as it is: a 16-byte store would want the three words moved together first)
+      float4& c = S.ck[s0][lane];
+      *reinterpret_cast<v2f*>(&c) = P;
+      c.z = __int_as_float(e);
+      lds_post(&S.ckpos, kk + 1);
+    };
+    // The factors of ONE block in registers (eight entries of two frames): an entry is refilled with the next block's
+    // right behind the two frames that consumed it -- the reads go out BETWEEN the frames, one per two frames (issued
+    // back to back, as they were, they cost the wave ~16 cycles each and the sixteen frames waited behind them), and
+    // each has seven entries' worth of frames to arrive.  The frames are volatile asm statements that clobber memory:
+    // the compiler keeps the reads where they are written.
+    mv4f f[kBlk / 2];
+    auto frames2 = [&](const mv4f& q) {
+      const v2f F0 = {q.x, q.y}, F1 = {q.z, q.w};
       asm volatile(WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F0]", "%[Y0]")
                    WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F1]", "%[Y1]")
-                   WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F2]", "%[Y2]")
-                   WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F3]", "%[Y3]")
-                   : "+{v[2:3]}"(Pq)
-                   : [G] "v"(G), [F0] "v"(F0), [F1] "v"(F1), [F2] "v"(F2), [F3] "v"(F3), [Y0] "v"(f0.y), [Y1] "v"(f1.y),
-                     [Y2] "v"(f2.y), [Y3] "v"(f3.y)
-                   : "v4", "v5", "v6", "v7");
-      pb = Pq.x;
-      pl = Pq.y;
+                   : "+{v[2:3]}"(P)
+                   : [G] "v"(G), [F0] "v"(F0), [F1] "v"(F1), [Y0] "v"(q.y), [Y1] "v"(q.w)
+                   : "v4", "v5", "v6", "v7", "memory");
     };
-    // The factors travel ring -> registers a WHOLE block ahead (two sets of 16 float2, alternating): the reads of
-    // block kk + 1 are issued before the renormalisation and the 16 frames of block kk, so that no LDS round trip
-    // is ever waited for on the dependent path.
-    float2 fa[kBlk], fz[kBlk];
+    // One block.  FULL: renormalise with the clamp; LEAN: a complete block with a block behind it.
+    auto block = [&](int kk, int& sf, auto full, auto lean) {
+      constexpr bool FULL = decltype(full)::value, LEAN = decltype(lean)::value;
+      staged_next(kk, sf);
+#if WFL_MITM_STATS
+      // (three stamps per sweep only: reading the clock waits for every LDS read in flight)
+      if (lane == 0 && (kk == 4 || kk == NB / 2 || kk == NB - 2)) S.blk_t[kk == 4 ? 0 : kk == NB / 2 ? 1 : 2] = clock64() - st_begin;
+#endif
+      if (FULL) renorm_full(); else renorm_own();
+      checkpoint(kk);
+      if (LEAN) {
+        sf = lds_peek(&S.staged[s2]);  // (looked at a block ahead of its use: consumed behind this block's frames)
+#pragma unroll
+        for (int j = 0; j < kBlk / 2; ++j) {
+          frames2(f[j]);
+          f[j] = S.ring[s1][j][lane];
+        }
+        lds_post(&S.chainpos, kk + 2);  // (behind the reads: a wave's LDS operations execute in order)
+        // (its compare would otherwise be scheduled in front of the frames, with a wait for the flag's round trip there)
+        asm volatile("" : "+v"(sf));
+      } else {
+        const int k = dir == 0 ? kk : NB - 1 - kk;
+        const int n = min(kBlk, T - k * kBlk);
+        mv4f c[kBlk / 2];
+#pragma unroll
+        for (int j = 0; j < kBlk / 2; ++j) c[j] = f[j];
+        if (kk + 1 < NB) {
+#pragma unroll
+          for (int j = 0; j < kBlk / 2; ++j) f[j] = S.ring[s1][j][lane];
+        }
+        lds_post(&S.chainpos, kk + 2);
+        if (kk + 2 < NB) sf = lds_peek(&S.staged[s2]);
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j)
+          if (j < n) frame((j & 1) ? v2f{c[j >> 1].z, c[j >> 1].w} : v2f{c[j >> 1].x, c[j >> 1].y});
+      }
+      s0 = s1, s1 = s2, s2 = s2 + 1 == K::kSlots ? 0 : s2 + 1;
+    };
     {
       int spin = 0;
       MITM_T0();
@@ -1016,70 +1053,46 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
     }
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < kBlk; ++j) fa[j] = S.ring[0][j][lane];
+    for (int j = 0; j < kBlk / 2; ++j) f[j] = S.ring[0][j][lane];
     lds_post(&S.chainpos, 1);
-    int nflag = NB > 1 ? lds_peek(&S.staged[1 % K::kSlots]) : 0;  // looked at one block ahead of its use
-    // ring slots of blocks kk, kk + 1, kk + 2, advanced by increments (a lone wave pays ~4 cycles for ANY instruction,
-    // scalar ones included: no division by K::kSlots on this wave)
-    int s0 = 0, s1 = 1 % K::kSlots, s2 = 2 % K::kSlots;
-    auto block = [&](int kk, const float2 (&fcur)[kBlk], float2 (&fnxt)[kBlk], auto steady) {
-      constexpr bool STEADY = decltype(steady)::value;
-      const int k = dir == 0 ? kk : NB - 1 - kk;
-      const int n = STEADY ? kBlk : min(kBlk, T - k * kBlk);
-      if (STEADY || kk + 1 < NB) {
-        if (nflag != kk + 2) {
-          int spin = 0;
-          MITM_T0();
-          while (lds_peek(&S.staged[s1]) != kk + 2)
-            if (++spin > kMSpin) give_up();
-          MITM_ACC(st_wait1);
-#if WFL_MITM_STATS
-          st_polls += spin;
-          if (lane == 0 && kk < 64) S.blk_t[kk] |= (long long)min(spin, 4095) << 48;  // (stamped below: the stamp keeps these bits)
-#endif
-        }
-        asm volatile("" ::: "memory");
-        if (!(STEADY && (WFL_MITM_ABL & 2))) {
-#pragma unroll
-          for (int j = 0; j < kBlk; ++j) fnxt[j] = S.ring[s1][j][lane];
-        }
-        if (STEADY || kk + 2 < NB) nflag = lds_peek(&S.staged[s2]);
-      }
-#if WFL_MITM_STATS
-      if (lane == 0 && kk < 64) S.blk_t[kk] = (S.blk_t[kk] & (0xfffll << 48)) | (clock64() - st_begin);
-#endif
-      if (!(STEADY && ((WFL_MITM_ABL & 1) || ((WFL_MITM_ABL & 32) && (kk & 1))))) lane_renorm();
-      // (slot s0 is free: block kk could only be staged after block kk - K::kSlots had been flushed and grabbed)
-      if (!(STEADY && (WFL_MITM_ABL & 4))) S.ck[s0][lane] = make_float4(pb, pl, __int_as_float(e), 0.f);
-      // ONE post: the factors of block kk + 1 are in registers (their reads were issued above: LDS executes a wave's
-      // instructions in order) and checkpoint kk is written
-      lds_post(&S.chainpos, kk + 2);
-      s0 = s1, s1 = s2, s2 = s2 + 1 == K::kSlots ? 0 : s2 + 1;
-      if (STEADY && (WFL_MITM_ABL & 8)) {
-        pb += fcur[0].x + fcur[kBlk - 1].y;
-      } else if (n >= kBlk) {
-#pragma unroll
-        for (int j = 0; j < kBlk; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < kBlk; ++j)
-          if (j < n) frame(fcur[j]);
-      }
-    };
+    int sf = NB > 1 ? lds_peek(&S.staged[1 % K::kSlots]) : 0;
     {
+      const std::true_type yes{};
+      const std::false_type no{};
       int kk = 0;
-      block(0, fa, fz, std::false_type{});
+      block(0, sf, yes, no);
       kk = 1;
-      // blocks 1 .. : complete for both directions while two more blocks follow; two per iteration (register sets swap)
-      for (; kk + 3 < NB; kk += 2) {
-        block(kk, fz, fa, std::true_type{});
-        block(kk + 1, fa, fz, std::true_type{});
-      }
-      for (; kk < NB; kk += 2) {
-        block(kk, fz, fa, std::false_type{});
-        if (kk + 1 < NB) block(kk + 1, fa, fz, std::false_type{});
-      }
+#if WFL_MITM_LEAN
+      // blocks 1 .. NB - 2 are complete in both directions and have a block behind them.  The clamp in every block of the
+      // start (lanes fill up one per frame at most), then in every fourth.
+      for (; kk <= 4 && kk + 1 < NB; ++kk) block(kk, sf, yes, yes);
+      if (kk == 5)
+        for (; kk + 4 < NB; kk += 4) {
+#if WFL_MITM_CLAMP_EVERY == 1
+          block(kk, sf, yes, yes);
+          block(kk + 1, sf, yes, yes);
+          block(kk + 2, sf, yes, yes);
+#else
+          block(kk, sf, no, yes);
+          block(kk + 1, sf, no, yes);
+          block(kk + 2, sf, no, yes);
+#endif
+          block(kk + 3, sf, yes, yes);
+        }
+#endif
+      for (; kk < NB; ++kk) block(kk, sf, yes, no);
     }
+    // the state behind the last frame
+    float pb = P.x, pl = P.y;
+    auto lane_renorm = [&]() {
+      const float mx = vmax(pb, pl);
+      const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
+      const int own = mx > 0.f ? e + k : kEmptyE;
+      const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;
+      const int shf = e - pre;
+      pb = ldexpf(pb, shf), pl = ldexpf(pl, shf);
+      e = pre;
+    };
     bad = !(fabsf(pb) < 3.0e38f) || !(fabsf(pl) < 3.0e38f);
     lane_renorm();
     {

@@ -78,3 +78,9 @@ for o in order[-5:]:
 for x in range(8):
     m = xcc == x
     if m.any(): print("  xcc %d: %3d workgroups, end median %.1f max %.1f" % (x, m.sum(), np.median((wg_end[m] - t0) / 100), ((wg_end[m] - t0) / 100).max()))
+
+# three-stamp pace (round 5: the chain wave stamps blocks 4, NB/2 and NB-2 only)
+st = blk[:, :, :3]
+print("THREE-STAMP pace, cycles/block (clock64 units x 1): first half median %.0f, second half median %.0f  | us: first %.2f second %.2f (at 2.4 GHz nominal)" % (
+    np.median((st[:, :, 1] - st[:, :, 0]) / (NB // 2 - 4)), np.median((st[:, :, 2] - st[:, :, 1]) / (NB - 2 - NB // 2)),
+    np.median((st[:, :, 1] - st[:, :, 0])) / 2400.0, np.median((st[:, :, 2] - st[:, :, 1])) / 2400.0))
