@@ -26,7 +26,7 @@ cold-cache operator (`fresh_targets`) are reported next to it.
 Per-kernel times come from HIP events recorded on the stream each launch goes to, inside the timed region
 (engine.PHASE_EVENTS); `roofline.frac` is STEP level -- the batch's algorithmic bytes over the sum of all kernel
 groups of a step (for CTC that is one launch + the repair launch) -- with the dominant kernel's own figure under
-`roofline.dominant_kernel`; `traffic` from the committed PMC passes (profiles/r03_pmc_traffic.json, else r02,
+`roofline.dominant_kernel`; `traffic` from the committed PMC passes (the newest profiles/rNN_pmc_traffic.json,
 collected with scripts/collect_round.sh on the same commands).
 
   python bench.py                                   # cfg2 CTC, 1 GPU, finishes in about a minute
@@ -60,6 +60,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+FORCE_DIST = os.environ.get("WFL_BENCH_FORCE_DIST") == "1"  # one-GPU boxes: the collective code path at world size 1
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 VALU_F32_PEAK_TFLOPS = 157.3  # fp32 vector peak (MI355X_MICROARCH.md)
 
@@ -76,7 +77,7 @@ PHASE_KERNEL_NAMES = {
     "lattice_chain/shared": ["prob_chain_kernel", "prob_certify_kernel", "chain_kernel"],
     "lattice_grad/shared": ["grad_kernel"],
     "dense_chain": ["dense_fast_chain_kernel", "dense_chain_kernel"],
-    "dense_grad": ["dense_fast_grad_kernel", "dense_reduce_kernel"],
+    "dense_grad": ["dense_mfma_grad_kernel", "dense_fast_grad_kernel", "dense_grad_kernel", "dense_reduce_kernel"],
 }
 PHASE_KERNELS = {k: " + ".join(n for n in v if n != "ctc_compact_x_kernel") + (" (transitions graph)" if k.endswith("/shared") else "")
                  for k, v in PHASE_KERNEL_NAMES.items()}  # (the compact pre-pass only runs for wide rows beyond the cache)
@@ -182,7 +183,7 @@ def make_ctc(args, rank, n_batches, dist=None):
         xr.grad = None
         ctc.CTCLoss(xr, batches[i % n_batches], blank).backward()
         if exchange is not None:
-            parallel.all_reduce_mean_([exchange])
+            parallel.all_reduce_mean_([exchange], force=FORCE_DIST)
 
     # what a training loop gets (train.py:262-266): the emissions are the model's OUTPUT, not a leaf, so loss.backward()
     # goes through the autograd engine (the criterion's short cut for leaf emissions does not apply)
@@ -203,6 +204,15 @@ def make_ctc(args, rank, n_batches, dist=None):
         xr.grad = None
         module(xr, module_targets).backward()
 
+    # ... and the step train.py:262-279 runs: the MODULE on a model's output (raw scores that are not a leaf), targets it
+    # has never seen (a new batch every step, as tensors): nothing the reference benchmark's protocol lets a cache hit
+    # (as a DataLoader hands them over: built outside the timed region)
+    fresh_tensors = [[torch.tensor(t) for t in bt] for bt in batches]
+
+    def training_step(i):
+        xr.grad = None
+        module(xr * 1.0, fresh_tensors[(1 + i % max(1, n_batches - 1)) % n_batches]).backward()
+
     # the C-ABI call underneath, targets pre-staged (kernels only)
     dev = x.device
     tg = E.targets_on_device(batches[0], dev)
@@ -215,7 +225,7 @@ def make_ctc(args, rank, n_batches, dist=None):
         def abi_step(i):
             last[0] = E.ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=scale, want_loss=True)
             if exchange is not None:
-                parallel.all_reduce_mean_([exchange])
+                parallel.all_reduce_mean_([exchange], force=FORCE_DIST)
     else:
         def abi_step(i):
             tok = E._mark("ctc_chains")
@@ -225,6 +235,22 @@ def make_ctc(args, rank, n_batches, dist=None):
             E.reduce_loss(nll, scale, 1.0)
             E.ctc_grad(x, tg, blank, ws, nll, coef, gout, dx)
             E._done(tok)
+
+    def launch_clock(reps=24):
+        """Duration of the meet-in-the-middle launch ALONE, measured on the device: the constant 100 MHz clock at the entry
+        of every workgroup and at the exit of its last wave (workspace field WFL_CTC_WS_CLOCK; the HIP-event bracket of
+        the step also holds the repair launch behind it).  Median over `reps` launches, each synchronised."""
+        if args.ctc_step != "pipelined" or C > 128 and os.environ.get("WFL_CTC_MITM_WIDE", "1") == "0":
+            return None
+        spans = []
+        for _ in range(reps):
+            ws, _nll, _loss = E.ctc_forward_backward(x, tg, blank, coef, gout, dx, loss_scale=scale, want_loss=True)
+            torch.cuda.synchronize()
+            clk = E.ctc_workspace_field(ws, B, T, tg.max_len, N.CTC_WS_CLOCK).view(torch.int64).view(2 * B, 2).cpu().numpy()
+            if (clk[:, 1] <= clk[:, 0]).any():
+                return None  # (a launch that did not go through the meet-in-the-middle kernel)
+            spans.append((int(clk[:, 1].max()) - int(clk[:, 0].min())) * 1e-5)  # 10 ns ticks -> ms
+        return float(np.median(spans))
 
     def repaired():  # utterances of the last abi step that the certificate sent to the log-domain repair launch
         return E.ctc_pipeline_repaired(last[0][0], B, T, tg.max_len) if last[0] is not None else None
@@ -237,7 +263,7 @@ def make_ctc(args, rank, n_batches, dist=None):
                 metric=f"utterances/sec fwd+bwd (ctc_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="CTCLoss(x, targets, blank).backward()", algorithmic_bytes_per_utt=8 * T * C)
     return dict(step=step, abi_step=abi_step, module_step=module_step, engine_step=engine_step,
-                engine_view_step=engine_view_step, meta=meta,
+                engine_view_step=engine_view_step, meta=meta, launch_clock=launch_clock, training_step=training_step,
                 payload=("ctc", x, batches[0], blank))
 
 
@@ -258,7 +284,7 @@ def make_asg(args, rank, n_batches, dist):
         transitions.grad = None
         asg.ASGLoss(x, transitions, batches[i % n_batches]).backward()
         if dist is not None:  # the one exchange step of the path (train.py:205-208: DDP averages criterion grads)
-            parallel.all_reduce_mean_([transitions.grad])
+            parallel.all_reduce_mean_([transitions.grad], force=FORCE_DIST)
 
     # a training loop's shape (train.py:205-208,262-266): emissions that are a model's output (non-leaf) and transitions
     # that are the ASG module's nn.Parameter -- both keep loss.backward() on the autograd engine
@@ -274,13 +300,18 @@ def make_asg(args, rank, n_batches, dist):
         par.grad = None
         asg.ASGLoss(x.view_as(x), par, batches[i % n_batches]).backward()
 
+    def training_step(i):  # non-leaf emissions, nn.Parameter transitions, a batch of targets never seen before
+        x.grad = None
+        par.grad = None
+        asg.ASGLoss(x * 1.0, par, batches[(1 + i % max(1, n_batches - 1)) % n_batches]).backward()
+
     which = " (BASELINE configs[2])" if (T, C, B, L) == (1000, 100, 128, 44) else ""
     meta = dict(workload=f"asg fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L,
                 key="cfg3" if which else None,
                 metric=f"utterances/sec fwd+bwd (asg_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="ASGLoss(x, transitions, targets).backward()",
                 algorithmic_bytes_per_utt=8 * T * C, algorithmic_bytes_per_batch=8 * (C + 1) * C)
-    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, meta=meta,
+    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, training_step=training_step, meta=meta,
                 payload=("asg", x.detach(), transitions.detach(), batches[0]))
 
 
@@ -318,13 +349,17 @@ def make_transducer(args, rank, n_batches):
         x.grad = None
         crit(x.view_as(x), batches[i % n_batches]).backward()
 
+    def training_step(i):  # non-leaf emissions, a batch of targets never seen before
+        x.grad = None
+        crit(x * 1.0, batches[(1 + i % max(1, n_batches - 1)) % n_batches]).backward()
+
     which = " (BASELINE configs[3])" if (T, B) == (800, 64) else ""
     meta = dict(workload=f"transducer fwd+bwd, 1000 word pieces (word_pieces_tokens_1000.txt) T={T} C={C} B={B}{which}",
                 B=B, T=T, C=C, L=Lp, key="cfg4" if which else None,
                 metric=f"utterances/sec fwd+bwd (transducer_benchmark word decompositions T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="Transducer(tokens, ..., blank='optional', allow_repeats=False, reduction='mean')(x, targets).backward()",
                 algorithmic_bytes_per_utt=8 * T * C)
-    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, meta=meta,
+    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, training_step=training_step, meta=meta,
                 payload=("transducer", x.detach(), crit, batches[0]))
 
 
@@ -404,17 +439,22 @@ def pmc_traffic(key, phases):
     """HBM bytes per step of the kernels of `phases` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate `--pmc` runs of this same command, corrected with the factors measured by
     scripts/pmc_calib.hip; see profiles/README.md).  Only for the configurations they were measured on."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if key is None or not os.path.exists(path):
+    import glob
+    # the newest round's passes first (profiles/rNN_pmc_traffic.json)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True):
+        if key is None:
             continue
         with open(path) as f:
             rec = json.load(f).get("configs", {}).get(key, {}).get("kernels", {})
         names = {n for ph in phases for n in PHASE_KERNEL_NAMES.get(ph.split("/")[0], [])}
         tot = [rec[n]["hbm_bytes"] for n in names if n in rec]
         if tot:
+            PMC_SOURCE[0] = os.path.basename(path)
             return float(sum(tot))
     return None
+
+
+PMC_SOURCE = [None]  # which committed file `traffic` came from (printed in the line)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -591,6 +631,7 @@ def main():
             "step_kernels_ms": sum_ms, "time_basis": basis, "step_ms_used": gpu_ms,
             "dominant_kernel": {"kernel": PHASE_KERNELS.get(dom, dom), "ms": phase_ms[dom], "achieved": dom_achieved,
                                 "frac": dom_achieved / HBM_PEAK_GBPS},
+            "traffic_source": PMC_SOURCE[0],
             "note": "STEP level: achieved = algorithmic bytes of the batch (8*T*C per utterance, + 8*(C+1)*C for ASG's W and "
                     "dW) / the sum of the average durations of ALL kernel groups of a step, HIP events on the launch stream "
                     "(the dominant group inside the timed region, the others during the last warm-up steps only: an event "
@@ -598,14 +639,36 @@ def main():
                     "bound of the step's GPU time); dominant_kernel divides the same bytes by that group alone; traffic = "
                     "HBM bytes of all the step's kernels from the committed PMC passes",
         }
+        if args.workload == "ctc" and rank == 0 and "launch_clock" in wl:
+            # the single longest kernel by itself: the group's bracket also holds the (normally empty) repair launch
+            lc = wl["launch_clock"]()
+            if lc:
+                out["roofline"]["dominant_kernel"] = {
+                    "kernel": "ctc_mitm_kernel", "ms": lc, "achieved": alg_bytes / (lc * 1e-3) / 1e9,
+                    "frac": alg_bytes / (lc * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "how": "device clock (100 MHz) from the first workgroup's entry to the last wave's exit, median of 24 "
+                           "synchronised launches after the timed region; the step's HIP-event bracket above also holds "
+                           "ctc_repair_kernel"}
         if args.workload == "asg":
             # the dense sweep is 2*B*T*C^2 multiply-adds (alpha and beta) + as many for the gradient
             fma = 2.0 * B * meta["T"] * meta["C"] ** 2
             out["roofline"]["valu"] = {"bound": "valu_f32", "achieved": 2 * fma / (gpu_ms * 1e-3) / 1e12, "peak": VALU_F32_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": 2 * fma / (gpu_ms * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS,
                                        "note": "2*B*T*C^2 fused multiply-adds of the dense forward + backward sweeps (2 flop each) "
-                                               "over the step's kernel time; fp32 vector peak (no MFMA: the recursion is a "
-                                               "dependent chain of small matrix-vector products in a scaled semiring)"}
+                                               "over the step's kernel time, against the fp32 vector peak: the sweeps are "
+                                               "dependent chains of small matrix-vector products in a scaled semiring on the "
+                                               "vector pipes"}
+            # the transition gradient's outer products run on the matrix cores (dense_mfma_grad_kernel:
+            # v_mfma_f32_16x16x4_f32, fp32 in / fp32 accumulate -- exact fp32, at the vector rate on this chip): a
+            # deviation from north_star's "no MFMA", stated here because it IS a contraction (dW = sum_t a_t u_t^T)
+            mfma_ms = next((v for k, v in phase_ms.items() if k == "dense_grad"), None)
+            out["roofline"]["mfma"] = {
+                "bound": "mfma_f32", "kernel": "dense_mfma_grad_kernel (dW = sum over frames of outer products, 2*B*T*C^2 flop) "
+                "+ dense_reduce_kernel", "achieved": (2 * fma / (mfma_ms * 1e-3) / 1e12) if mfma_ms else None,
+                "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (2 * fma / (mfma_ms * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS) if mfma_ms else None,
+                "note": "fp32-input MFMA peak = the fp32 vector peak on MI355X (157.3 TFLOP/s); the kernel is bound by its "
+                        "A / U / dx streams, not by the matrix cores"}
     single = rank == 0 and world == 1
     if single and not args.no_extras:
         if args.mode == "abi":
@@ -620,6 +683,15 @@ def main():
                                     "what": "operator path, new targets in every step: per-batch host work (flattening, "
                                             "staging and upload; Transducer: the graph algebra) inside the timed region, "
                                             "no content-keyed cache can hit"}
+        if fresh_extra and "training_step" in wl and args.mode == "api":
+            el, _ = timed_loop(wl["training_step"], extras_steps, 3, fence, False)
+            out["training_step"] = {
+                "value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
+                "what": "what a training loop gets (train.py:262-279): emissions that are a model's OUTPUT (x * 1.0: not a "
+                        "leaf, so loss.backward() runs the autograd engine, incl. that product and its backward) AND a batch "
+                        "of targets never seen before in every step (no content-keyed cache can hit)" +
+                        ("; the CTC module on raw scores (log_softmax fused), targets as tensors" if args.workload == "ctc" else
+                         "; transitions as an nn.Parameter" if args.workload == "asg" else "")}
         if args.mode == "api" and args.targets == "fresh":
             # the reference benchmarks' own protocol: the same target list every iteration
             el, _ = timed_loop(lambda i: wl["step"](0), extras_steps, 3, fence, False)

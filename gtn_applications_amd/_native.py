@@ -16,7 +16,7 @@ ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 1, 2, 3
 EPSILON = -1
 SEMIRING_LOG, SEMIRING_TROPICAL = 0, 1
 DENSE_MAIN, DENSE_REPAIR, DENSE_REDUCE, DENSE_ALL = 1, 2, 4, 7  # parts of wfl_dense_forward_parts / wfl_dense_grad_parts
-CTC_WS_REJECTED, CTC_WS_STATUS, CTC_WS_LOG2Z, CTC_WS_ZRANGE = 0, 1, 2, 3
+CTC_WS_REJECTED, CTC_WS_STATUS, CTC_WS_LOG2Z, CTC_WS_ZRANGE, CTC_WS_DEBUG, CTC_WS_CLOCK = 0, 1, 2, 3, 4, 5
 CONV_SPIKE, CONV_BLANK_OPTIONAL = 1, 2
 
 

@@ -83,7 +83,7 @@ __device__ __forceinline__ float to_score(float raw) {
 //   int32  flag[b], pbad[b][dir]   bookkeeping of the fast chain's certificate (see below)
 // ------------------------------------------------------------------------------------------------
 struct CtcWs {
-  int64_t ck, off, z2, flag, pbad, ready, done, perr, dup, own, zloc, suspect, zcnt, total, dbg;
+  int64_t ck, off, z2, flag, pbad, ready, done, perr, dup, own, zloc, suspect, zcnt, clk, total, dbg;
 };
 __host__ __device__ inline int ctc_blocks(int T) { return (T + kBlk - 1) / kBlk; }
 __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
@@ -106,6 +106,8 @@ __host__ __device__ inline CtcWs ctc_ws_layout(int B, int T, int P) {
   w.suspect = o, o += 2;                      // uint64: == the meet-in-the-middle launch's token once ANY of its certificates has a doubt (ctc_mitm.h)
   w.zcnt = o, o += B;                         // int32 zcnt[b]: sweeps of b whose first emitted block has folded its log2 Z into zloc
   o = (o + 1) & ~1ll;
+  w.clk = o, o += 8 * (int64_t)B;             // int64 clk[b][dir][2]: the constant 100 MHz clock when the sweep's workgroup entered the
+                                              // meet-in-the-middle launch and when its last wave left it (bench.py: the launch alone)
 #if WFL_MITM_STATS
   o = (o + 1) & ~1ll;
   w.dbg = o, o += 2 * (8 * 16 + 256) * 2 * (int64_t)B;  // int64 [b][dir][wave][8], then [b][dir][256] block clocks (ctc_mitm.h)
@@ -2406,6 +2408,7 @@ int wfl_ctc_workspace_field(int B, int T, int max_len, int field, int64_t* offse
     case WFL_CTC_WS_STATUS: *offset_elems = w.perr, *length_elems = 2; break;
     case WFL_CTC_WS_LOG2Z: *offset_elems = w.z2, *length_elems = 2 * (int64_t)B; break;
     case WFL_CTC_WS_ZRANGE: *offset_elems = w.zloc, *length_elems = 4 * (int64_t)B; break;
+    case WFL_CTC_WS_CLOCK: *offset_elems = w.clk, *length_elems = 8 * (int64_t)B; break;
     case WFL_CTC_WS_DEBUG:
       *offset_elems = WFL_MITM_STATS ? w.dbg : 0, *length_elems = WFL_MITM_STATS ? 2 * (8 * 16 + 256) * 2 * (int64_t)B : 0;
       break;

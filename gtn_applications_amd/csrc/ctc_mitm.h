@@ -1170,9 +1170,9 @@ __global__ void __launch_bounds__(K::kWaves * 64, 4)  // (second argument: waves
     perr[0] = 0;  // a wave gave up waiting
     perr[1] = 0;  // utterances the repair launch recomputed
   }
-#ifdef WFL_MITM_FLIP
-  ctc_mitm_body<K, LSM, WIDE>(a, (int)blockIdx.x >> 1, 1 - ((int)blockIdx.x & 1), coef, gout, dx, smem);
-#else
+  // the launch's own clock: entry of the workgroup, exit of its last wave (two words per sweep; nobody waits for them)
+  unsigned long long* clk = (unsigned long long*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).clk) + (int64_t)blockIdx.x * 2;
+  if (threadIdx.x == 0) clk[0] = wall_clock64(), clk[1] = 0ull;  // (in front of the body's barrier: no wave leaves before it)
   ctc_mitm_body<K, LSM, WIDE>(a, (int)blockIdx.x >> 1, (int)blockIdx.x & 1, coef, gout, dx, smem);
-#endif
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_max(clk + 1, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -27,13 +27,15 @@ def shard_batch(inputs, targets, rank=None, world=None):
     return inputs[lo:hi], targets[lo:hi]
 
 
-def all_reduce_mean_(tensors, group=None):
-    """In-place average over ranks of a list of tensors with ONE collective (flattened)."""
+def all_reduce_mean_(tensors, group=None, force=False):
+    """In-place average over ranks of a list of tensors with ONE collective (flattened).  A group of one rank has
+    nothing to exchange and returns at once -- unless `force`: the collective is then issued all the same (the only
+    way a one-GPU box can run the RCCL call of the multi-GPU path: tests, bench.py under WFL_BENCH_FORCE_DIST=1)."""
     tensors = [t for t in tensors if t is not None]
     if not tensors or not dist.is_available() or not dist.is_initialized():
         return tensors
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return tensors
     flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

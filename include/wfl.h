@@ -383,12 +383,15 @@ int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems);
  *   WFL_CTC_WS_STATUS    int32[2]    pipelined step: [0] a gradient wave gave up waiting, [1] utterances repaired
  *   WFL_CTC_WS_LOG2Z     double[B]   log2 Z per utterance
  *   WFL_CTC_WS_ZRANGE    int64[B][2] pipelined lane-exponent step: min / max over the blocks of log2 Z * 2^16
- *   WFL_CTC_WS_DEBUG     per-wave cycle counters of a -DWFL_MITM_STATS=1 build (length 0 in a normal build) */
+ *   WFL_CTC_WS_DEBUG     per-wave cycle counters of a -DWFL_MITM_STATS=1 build (length 0 in a normal build)
+ *   WFL_CTC_WS_CLOCK     int64[B][2][2] meet-in-the-middle step: the device's constant 100 MHz clock at the entry of every sweep's
+ *                        workgroup and at the exit of its last wave (the launch's own duration, measured on the device) */
 #define WFL_CTC_WS_REJECTED 0
 #define WFL_CTC_WS_STATUS 1
 #define WFL_CTC_WS_LOG2Z 2
 #define WFL_CTC_WS_ZRANGE 3
 #define WFL_CTC_WS_DEBUG 4
+#define WFL_CTC_WS_CLOCK 5
 int wfl_ctc_workspace_field(int B, int T, int max_len, int field, int64_t* offset_elems, int64_t* length_elems);
 /* alpha and beta chains: writes nll[B] = -log Z_b and the 16-frame checkpoints into ws.
  * flags must be 0 (the log-domain chain; the lane-exponent variant of this call was retired in round 4 --
