@@ -220,7 +220,7 @@ class Transducer(torch.nn.Module):
         labels = None
         if self.transitions is not None:
             params = E.as_device_f32(self.transition_params.detach(), dev)
-            if _DENSE_NGRAM and _dense_unigram(self.transitions, C):
+            if _DENSE_NGRAM and params.numel() == C and _dense_unigram(self.transitions, C):
                 # one node, one self-loop per token: the best path takes, frame by frame, the first maximum of x + p
                 labels = E.row_argmax(x + params[:C]).cpu().numpy().reshape(-1)
                 offsets = np.arange(B + 1, dtype=np.int64) * T
@@ -296,12 +296,15 @@ class _UnigramNormaliser:
     __slots__ = ("xp", "lse", "logz")
 
     def __init__(self, x, params):
-        self.xp = x + params[:x.shape[2]]
+        # NaN policy of the lattice path this replaces: a NaN score is an impossible arc (-inf)
+        self.xp = torch.nan_to_num(x + params[:x.shape[2]], nan=float("-inf"), posinf=float("inf"), neginf=float("-inf"))
         self.lse = E.row_lse(self.xp)
         self.logz = self.lse.sum(dim=1)
 
     def posteriors(self):
-        return torch.exp(self.xp - self.lse.unsqueeze(2))
+        # (a frame whose scores are all -inf has no path through it: zero posteriors, as the lattice path gives)
+        lse = self.lse.unsqueeze(2)
+        return torch.where(torch.isfinite(lse), torch.exp(self.xp - lse), torch.zeros_like(self.xp))
 
 
 def _dense_unigram(transitions, C):
@@ -426,7 +429,7 @@ class TransducerLossFunction(torch.autograd.Function):
         if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288
             # independent of the numerator sweep: forked onto a second stream so that the two overlap
             with E.side_stream(dev) as fork:
-                if _DENSE_NGRAM and _dense_unigram(transitions, C):
+                if _DENSE_NGRAM and params.numel() == C and _dense_unigram(transitions, C):
                     # one state, one self-loop per token: the frames are independent and the normaliser is a sum of
                     # row log-sum-exps of x + p -- no sweep at all
                     den = _UnigramNormaliser(x, params)

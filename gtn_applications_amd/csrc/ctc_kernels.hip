@@ -146,6 +146,8 @@ struct CtcArgs {
   // meet-in-the-middle launch: number of labels the caller vouches for behind `targets` (0: unknown) -- what lets the
   // workgroups ask for their labels before the offsets have arrived (ctc_mitm.h)
   long long n_labels;
+  // meet-in-the-middle launch: polls a wave waits for a hand-off before it gives up (ctc_mitm.h, mitm_give_up)
+  int spin;
 };
 constexpr int kXcStride = 64;
 constexpr int kParkStride = 17 * 64;  // 16 frames x 64 lanes of factors + the per-lane reference word
@@ -193,6 +195,8 @@ __device__ __forceinline__ bool utterance_rejected(const CtcArgs& a, const CtcWs
   const double z2 = ((const double*)(a.ws + w.z2))[u];
   const long long* zmm = (const long long*)(a.ws + w.zloc) + (int64_t)u * 2;
   const long long zq = z_fixed(z2);
+  // a wave of the launch gave up waiting (ctc_mitm.h, mitm_give_up): nothing it left behind is vouched for
+  if (__hip_atomic_load((const int32_t*)(a.ws + w.perr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
   if (zq == kZDead && (((const unsigned long long*)(a.ws + w.dup))[u] >> 63)) return false;  // cannot be aligned: exact
   // 1.5e-4 in log2 units: a lost mass fraction of 1e-4 (the parity bar).  The lane-exponent blocks reproduce the
   // chain's log2 Z to 1-3e-5 on well-represented data (measured; fixed-point resolution 1.5e-5)
@@ -220,6 +224,10 @@ __device__ __forceinline__ void reduce_loss_when_done(const CtcArgs& a, const Ct
       for (int spin = 0; spin < (1 << 20) && !seen; ++spin) {
         seen = __hip_atomic_load(done + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
         if (!seen) __builtin_amdgcn_s_sleep(16);
+        // (a wave of the launch gave up: its utterance may never be published -- the repair launch reduces the loss)
+        if (!seen && !rejected_only && (spin & 63) == 63 &&
+            __hip_atomic_load((const int32_t*)(a.ws + w.perr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+          break;
       }
       ok = ok && seen;
       __hip_atomic_store(done + u, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sole consumer: clear
@@ -230,9 +238,11 @@ __device__ __forceinline__ void reduce_loss_when_done(const CtcArgs& a, const Ct
   }
   const float total = wave_all_sum(part);  // fixed lane order
   if (lane == 0 && a.loss_out) a.loss_out[0] = total / (float)a.B;
-  if (!ok) {
-    if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
-    __builtin_trap();
+  if (!ok && lane == 0) {
+    // not every utterance was published in time: say so (status word; in the first launch also the doubt word, so that
+    // the repair launch recomputes the batch and reduces the loss again) -- no trap
+    __hip_atomic_fetch_or((int32_t*)(a.ws + w.perr), rejected_only ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!rejected_only) coherent_store64(a.ws + w.suspect, a.token);
   }
 }
 
@@ -1745,7 +1755,8 @@ __global__ void __launch_bounds__(256)
   const int lane = threadIdx.x & 63;
   const CtcWs w = ctc_ws_layout(a.B, a.T, a.P);
   const int nchain = 2 * a.B;
-  if (a.suspect_token != 0 && *(const unsigned long long*)(a.ws + w.suspect) != a.suspect_token) {
+  const bool no_doubt = a.suspect_token != 0 && *(const unsigned long long*)(a.ws + w.suspect) != a.suspect_token;
+  if (no_doubt) {
     // The launch before found nothing to doubt (it says so in ONE word: see ctc_mitm.h): nothing to evaluate, the
     // loss it reduced stands.  (The usual case: what the launch then costs is its dispatch and this load.)
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_repaired)
@@ -2477,6 +2488,13 @@ static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const 
   }
   CtcArgs a{x, B, T, C, max_len + 1, blank, targets, offsets, ws, nll, 0ull, loss_scale, loss_out, row_lse};
   a.n_labels = call && call->n_labels > 0 ? call->n_labels : 0;
+  // how long a wave of the meet-in-the-middle launch waits for a hand-off before it gives up and the repair launch
+  // recomputes the batch (WFL_CTC_MITM_SPIN: polls; tests force the time-out with 1)
+  static const int mitm_spin = [] {
+    const char* e = getenv("WFL_CTC_MITM_SPIN");
+    return e && atoi(e) > 0 ? atoi(e) : kMSpinDefault;
+  }();
+  a.spin = mitm_spin;
   // launch token: process-wide counter mixed with the workspace address -- uninitialised memory or flags
   // left by a launch that used the block earlier cannot equal it; consumers clear the flags they used,
   // so replaying the SAME launch from a hipGraph (same token, same workspace) starts from cleared flags

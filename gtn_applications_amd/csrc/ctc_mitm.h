@@ -52,7 +52,7 @@
 #define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
 #endif
 
-constexpr int kMSpin = 1 << 24;
+constexpr int kMSpinDefault = 1 << 24;  // polls a wave waits for a hand-off before it gives up (CtcArgs::spin: WFL_CTC_MITM_SPIN)
 constexpr int kMaxCouple = 100;  // bound on the exponent of a coupling factor (chain wave and emitters alike)
 constexpr int kMTile = 128;   // floats per row of an emitter's gradient tile (a compile-time stride: the 16 rows of a label's
                               // column are one LDS address + immediate offsets); the step takes C <= kMTile
@@ -139,10 +139,33 @@ struct MitmLds {
   int ckdone;                      // ... picked up by the flusher (offc valid)
   int offdone;                     // offtot valid
   int cmap_ready;                  // (wide rows) the column -> slot map behind the emitters' tiles is written
+  int abort;                       // a wave of the workgroup gave up waiting: the others stop waiting too
 #if WFL_MITM_STATS
   long long blk_t[64];             // chain wave: clock at the start of every block (the first 64)
 #endif
 };
+
+
+// A wave whose hand-off never arrives gives up -- cleanly: it raises the launch's status word (every utterance then
+// counts as rejected: utterance_rejected) and its doubt word (the repair launch behind this one recomputes the batch in
+// the log domain and the caller still receives correct results), tells the other waves of its workgroup (which stop
+// waiting as well) and ENDS.  No trap: the HIP context survives, the step reports through WFL_CTC_WS_STATUS and the
+// caller's host_state words (the next calls take the log-domain launch).
+template <class K>
+__device__ __forceinline__ void mitm_give_up(const CtcArgs& a, const CtcWs& w, MitmLds<K>& S) {
+  if ((threadIdx.x & 63) == 0) {
+    __hip_atomic_fetch_or((int32_t*)(a.ws + w.perr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    coherent_store64(a.ws + w.suspect, a.token);
+  }
+  lds_post(&S.abort, 1);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_endpgm();
+}
+// (looked at every 256th poll: a wave of the workgroup has given up)
+template <class K>
+__device__ __forceinline__ bool mitm_waited_out(const CtcArgs& a, MitmLds<K>& S, int spin) {
+  return spin > a.spin || ((spin & 255) == 255 && lds_peek(&S.abort) != 0);
+}
 
 __host__ __device__ inline int mitm_first_emitted(int NB, int dir) { return dir == 0 ? NB / 2 : NB - NB / 2; }
 // published checkpoints of sweep (b, dir): [H0][2][P] 8-byte entries (mantissa bits | exponent << 32), blank states
@@ -177,7 +200,7 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
                                                     int cnt, float cf, float g, float gs, bool skipn, bool owner, bool adder,
                                                     int lane, float* rows, const unsigned char* cmap, int ycol, int blank, int C, long long* zmm,
                                                     int32_t* zcnt, unsigned long long* suspect, unsigned long long suspect_token,
-                                                    float* __restrict__ dst, long long* st_part,
+                                                    int32_t* perr, int spin_bound, float* __restrict__ dst, long long* st_part,
                                                     const float* __restrict__ xsrc = nullptr, float lse_rows = 0.f) {
 #if WFL_MITM_STATS
   const long long st_e0 = clock64();
@@ -236,14 +259,24 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
       const long long zq = z_fixed(zk);
       __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(zcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (behind them: see the alpha chain's end)
+      // (behind them, as a RELEASE: whoever sees the count has the minimum and the maximum -- see the alpha chain's end)
+      __hip_atomic_fetch_add(zcnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     // (ONE reference per sweep, from its first emitted block whichever emitter took it: results do not depend on
     // which emitter served which block)
     for (int spin = 0; lds_peek(&S.zready) != 1; ++spin) {
       __builtin_amdgcn_s_sleep(2);
-      if (spin > kMSpin) __builtin_trap();
+      if (spin > spin_bound || ((spin & 255) == 255 && lds_peek(&S.abort) != 0)) {
+        // (see mitm_give_up: this function has the doubt word and the status word's address)
+        if (lane == 0) {
+          __hip_atomic_fetch_or(perr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          coherent_store64(suspect, suspect_token);
+        }
+        lds_post(&S.abort, 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_endpgm();
+      }
     }
     asm volatile("" ::: "memory");
     const double zref = S.zref;
@@ -453,7 +486,7 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
     } else {
       for (int spin = 0; lds_peek(&S.cmap_ready) != 1; ++spin) {
         __builtin_amdgcn_s_sleep(8);
-        if (spin > kMSpin) __builtin_trap();
+        if (mitm_waited_out(a, S, spin)) mitm_give_up(a, w, S);
       }
     }
   }
@@ -468,10 +501,7 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
 #else
   long long* st_part = nullptr;
 #endif
-  auto give_up = [&]() {
-    if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
-    __builtin_trap();
-  };
+  auto give_up = [&]() { mitm_give_up(a, w, S); };
   for (;;) {
     int n = 0;
     if (lane == 0) n = atomicAdd(&S.enext, 1);
@@ -485,7 +515,7 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
       MITM_T0();
       while (lds_peek(&S.ckdone) < n + 1) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spin > kMSpin) give_up();
+        if (mitm_waited_out(a, S, ++spin)) give_up();
       }
       MITM_ACC(st_wait0);
     }
@@ -506,7 +536,7 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
       MITM_T0();
       while (lds_peek(&S.pready[ps]) != n + 1) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spin > kMSpin) give_up();
+        if (mitm_waited_out(a, S, ++spin)) give_up();
       }
       MITM_ACC(st_wait1);
     }
@@ -528,10 +558,10 @@ __device__ __forceinline__ void ctc_mitm_emitter(const CtcArgs& a, MitmLds<K>& S
     const float lse_rows = LSM ? a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)] : 0.f;  // (tile row r = frame t0 + r)
     if (cnt == kBlk)
       ctc_mitm_emit_block<K, DIR, true, WIDE, LSM>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                     cmap, ycol, WIDE ? 63 : a.blank, C, zmm, zcnt, suspect, a.token, dst, st_part, xsrc, lse_rows);
+                                     cmap, ycol, WIDE ? 63 : a.blank, C, zmm, zcnt, suspect, a.token, (int32_t*)(a.ws + w.perr), a.spin, dst, st_part, xsrc, lse_rows);
     else if (DIR == 0)
       ctc_mitm_emit_block<K, 0, false, WIDE, LSM>(F, mv2f{cko.x, cko.y}, ea, pk, rsum, off_sum, S, n == H0, cnt, cf, g, gs, skipn, owner, adder, lane, rows,
-                                    cmap, ycol, WIDE ? 63 : a.blank, C, zmm, zcnt, suspect, a.token, dst, st_part, xsrc, lse_rows);
+                                    cmap, ycol, WIDE ? 63 : a.blank, C, zmm, zcnt, suspect, a.token, (int32_t*)(a.ws + w.perr), a.spin, dst, st_part, xsrc, lse_rows);
     MITM_ACC(st_wait2);
   }
 #if WFL_MITM_STATS
@@ -594,7 +624,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
   if (threadIdx.x < K::kSlots) S.egrab[threadIdx.x] = 0;
   if (threadIdx.x < K::kPSlots) S.pgrab[threadIdx.x] = 0;
   if (threadIdx.x == 0) S.enext = mitm_first_emitted(ctc_blocks(a.T), dir), S.zready = 0;
-  if (threadIdx.x == 0) S.chainpos = 0, S.ckpos = 0, S.ckdone = 0, S.offdone = 0, S.cmap_ready = 0;
+  if (threadIdx.x == 0) S.chainpos = 0, S.ckpos = 0, S.ckdone = 0, S.offdone = 0, S.cmap_ready = 0, S.abort = 0;
 #if WFL_MITM_STATS
   if (threadIdx.x < 64) S.blk_t[threadIdx.x] = 0;
 #endif
@@ -621,11 +651,8 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
 #else
   auto stats_out = [&]() {};
 #endif
-  // a wave gives up (trap) instead of hanging the GPU when a hand-off never arrives
-  auto give_up = [&]() {
-    if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
-    __builtin_trap();
-  };
+  // a wave gives up instead of hanging the GPU when a hand-off never arrives (mitm_give_up: it ends, nothing traps)
+  auto give_up = [&]() { mitm_give_up(a, w, S); };
   // has emitter-owned block m (m >= H0) been taken into registers?
   auto grabbed = [&](int m) { return lds_peek(&S.egrab[m % K::kSlots]) == m + 1; };
   auto pgrabbed = [&](int m) { return lds_peek(&S.pgrab[m % K::kPSlots]) == m + 1; };
@@ -661,7 +688,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         int spin = 0;
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.token) {
           __builtin_amdgcn_s_sleep(8);
-          if (++spin > kMSpin) give_up();
+          if (mitm_waited_out(a, S, ++spin)) give_up();
         }
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) {
@@ -744,7 +771,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       MITM_T0();
       while (lds_peek(&S.chainpos) < m + 1 || lds_peek(&S.ckdone) < m + 1 || (!(WFL_MITM_ABL & 4096) && m >= H0 && !grabbed(m))) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spin > kMSpin) give_up();
+        if (mitm_waited_out(a, S, ++spin)) give_up();
       }
       MITM_ACC(st_wait0);
 #if WFL_MITM_STATS
@@ -811,7 +838,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         MITM_T0();
         while (lds_peek(&S.ckpos) < kk + 1) {
           __builtin_amdgcn_s_sleep((WFL_MITM_ABL & 1024) ? 8 : 1);
-          if (++spin > kMSpin) give_up();
+          if (mitm_waited_out(a, S, ++spin)) give_up();
         }
         MITM_ACC(st_wait0);
       }
@@ -860,7 +887,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       MITM_T0();
       while (__hip_atomic_load(phalf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.token) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spin > (1 << 21)) give_up();
+        if (mitm_waited_out(a, S, (++spin) << 3)) give_up();  // (polls of s_sleep 8 on another CU's word)
 #if WFL_MITM_STATS
         ++st_polls;
 #endif
@@ -895,7 +922,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
             MITM_T0();
             while (!pgrabbed(n - K::kPSlots)) {
               __builtin_amdgcn_s_sleep(4);
-              if (++spin > kMSpin) give_up();
+              if (mitm_waited_out(a, S, ++spin)) give_up();
             }
             MITM_ACC(st_wait0);
           }
@@ -977,7 +1004,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         int spin = 0;
         MITM_T0();
         while (lds_peek(&S.staged[s1]) != kk + 2)
-          if (++spin > kMSpin) give_up();
+          if (mitm_waited_out(a, S, ++spin)) give_up();
         MITM_ACC(st_wait1);
 #if WFL_MITM_STATS
         st_polls += spin;
@@ -1048,7 +1075,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       int spin = 0;
       MITM_T0();
       while (lds_peek(&S.staged[0]) != 1)
-        if (++spin > kMSpin) give_up();
+        if (mitm_waited_out(a, S, ++spin)) give_up();
       MITM_ACC(st_wait0);
     }
     asm volatile("" ::: "memory");
@@ -1100,7 +1127,7 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
       MITM_T0();
       while (lds_peek(&S.offdone) != 1) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spin > kMSpin) give_up();
+        if (mitm_waited_out(a, S, ++spin)) give_up();
       }
       MITM_ACC(st_wait2);
     }
@@ -1131,8 +1158,10 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         // half a sweep ago; should one of them not have arrived yet (its workgroup started late: nothing orders
         // workgroups) the count says so and the doubt is raised for the repair launch to settle.
         const long long* zmm = (const long long*)(a.ws + w.zloc) + (int64_t)b * 2;
+        // (the count FIRST, acquiring: a count of nfirst then vouches for the two words read behind it -- read in the
+        // other order, a partner's three updates could land between the loads and leave the initial range unseen)
+        const int cnt = __hip_atomic_load((const int32_t*)(a.ws + w.zcnt) + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         const long long lo = (long long)coherent_load64(zmm), hi = (long long)coherent_load64(zmm + 1);
-        const int cnt = __hip_atomic_load((const int32_t*)(a.ws + w.zcnt) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long zq = z_fixed(z2);
         constexpr long long tol = 10;  // (utterance_rejected)
         const int nfirst = (H0 < NB ? 1 : 0) + (mitm_first_emitted(NB, 1) < NB ? 1 : 0);  // sweeps that emit at all
@@ -1167,8 +1196,13 @@ __global__ void __launch_bounds__(K::kWaves * 64, 4)  // (second argument: waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     int32_t* perr = (int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr);
-    perr[0] = 0;  // a wave gave up waiting
-    perr[1] = 0;  // utterances the repair launch recomputed
+    // (write-through, like the doubt word below: a give-up is an atomic from another XCD)
+    __hip_atomic_store(perr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // a wave gave up waiting
+    __hip_atomic_store(perr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // utterances the repair launch recomputed
+    // the doubt word: down at every launch (a write-through store by the first workgroup, half a sweep before anybody can
+    // raise it) -- a launch replayed from a graph carries the SAME token, and a doubt of an earlier replay would otherwise
+    // stand for ever
+    coherent_store64(a.ws + ctc_ws_layout(a.B, a.T, a.P).suspect, 0ull);
   }
   // the launch's own clock: entry of the workgroup, exit of its last wave (two words per sweep; nobody waits for them)
   unsigned long long* clk = (unsigned long long*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).clk) + (int64_t)blockIdx.x * 2;

@@ -2836,8 +2836,16 @@ struct LiveState {
                             // sweeps loads their code, which takes longer than a millisecond
   bool fork = true;        // WFL_LATTICE_FUSED_FORK=0: no fork event (the round-3 protocol; measurements)
 };
+// (one per DEVICE, next to its side stream: a give-up on one GPU -- a profiler attached to it, a first launch that loads
+// code -- says nothing about the others)
 static LiveState& live_state() {
-  static LiveState* st = [] {
+  static std::mutex mu;
+  static auto* per_device = new std::map<int, LiveState*>();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  LiveState*& st = (*per_device)[dev];
+  if (!st) st = [] {
     auto* s = new LiveState();
     uint32_t* p = nullptr;
     if (hipHostMalloc((void**)&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {

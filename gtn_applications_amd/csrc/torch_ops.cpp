@@ -486,7 +486,9 @@ struct EventRing {  // fork / join events of the native steps, per device (creat
   static constexpr int kN = 32;
   hipEvent_t ev[kN] = {};
   unsigned next = 0;
+  std::mutex mu;  // concurrent steps on one device (DataParallel threads, several streams): one event per take
   hipEvent_t take() {
+    std::lock_guard<std::mutex> lock(mu);
     hipEvent_t& e = ev[next++ % kN];
     if (!e) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate");
     return e;

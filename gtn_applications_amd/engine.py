@@ -2,6 +2,7 @@
 lattices and the calls into libwfl.so.  torch is plumbing here (device memory + current stream);
 all arithmetic happens in the HIP kernels behind the C ABI (include/wfl.h).
 """
+import collections
 import ctypes
 import os
 import itertools
@@ -948,14 +949,31 @@ def ctc_workspace(x, max_len):
     return hit
 
 
-_CTC_STATE = {}
+_CTC_STATE = collections.OrderedDict()  # (device, stream, shape) -> (pinned word pair, CtcCall), least recently used first
+_CTC_STATE_MAX = 256                    # shapes remembered at once (variable-length training sees thousands)
+_CTC_PAGES = []                         # pinned int32 pages the pairs are cut from (never freed: a launch may still write)
+_CTC_FREE = []                          # word pairs free for reuse: (page tensor, offset)
+
+
+def _ctc_state_slot():
+    if not _CTC_FREE:
+        page = torch.zeros(1024, dtype=torch.int32).pin_memory()  # ONE pinned allocation per 512 shapes
+        _CTC_PAGES.append(page)
+        _CTC_FREE.extend((page, o) for o in range(1022, -1, -2))
+    page, o = _CTC_FREE.pop()
+    words = page[o:o + 2]
+    words.zero_()
+    return words
 
 
 def ctc_host_state(x, max_len):
     """The CTC step's memory between calls (`wfl_ctc_call.host_state`, include/wfl.h): two int32 of pinned host memory
     per (device, stream, shape) -- the repair launch leaves there how many utterances it recomputed, the next call of
-    the shape reads it (no synchronisation) and picks its launch.  Owned here, by the caller of the C ABI: never
-    freed while a launch may still write it, zeroed by ctc_reset_state().  Returns (pinned tensor, CtcCall struct)."""
+    the shape reads it (no synchronisation) and picks its launch.  Owned here, by the caller of the C ABI: the pairs
+    are cut from a few pinned pages that are never freed (a launch may still write them), at most _CTC_STATE_MAX shapes
+    are remembered (least recently used first out: its pair goes to the next new shape -- a late write of the evicted
+    shape's launch can then only mislead that shape's FIRST choice of launch, never a result), zeroed by
+    ctc_reset_state().  Returns (pinned words, CtcCall struct)."""
     B, T, C = x.shape
     idx = x.device.index
     key = (idx, torch._C._cuda_getCurrentRawStream(idx), B, T, C, max_len)
@@ -964,8 +982,13 @@ def ctc_host_state(x, max_len):
         if torch.cuda.is_current_stream_capturing():
             # (a step captured into a graph replays ONE choice and must not allocate: no memory, lane-exponent step first)
             return None, N.CtcCall(0, None)
-        words = torch.zeros(2, dtype=torch.int32).pin_memory()
+        if len(_CTC_STATE) >= _CTC_STATE_MAX:
+            _, (old_words, _call) = _CTC_STATE.popitem(last=False)
+            _CTC_FREE.append((old_words._base if old_words._base is not None else old_words, old_words.storage_offset()))
+        words = _ctc_state_slot()
         hit = _CTC_STATE[key] = (words, N.CtcCall(0, words.data_ptr()))
+    else:
+        _CTC_STATE.move_to_end(key)
     return hit
 
 

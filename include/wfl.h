@@ -15,7 +15,7 @@
  *   - host graph entry points (wfl_graph_*) work on opaque handles and never touch the GPU;
  *   - no hidden global state: re-entrant from several host threads (autograd worker threads).  What a step remembers
  *     between calls (the CTC step's choice of launch) lives in memory the caller hands in (wfl_ctc_call); the gradient
- *     beside the lattice sweeps keeps process-wide COUNTERS of whether kernels of two streams overlap on this stack
+ *     beside the lattice sweeps keeps per-device COUNTERS of whether kernels of two streams overlap on this stack
  *     (wfl_lattice_diagnostics) -- they pick between two launch plans with identical results.
  *
  * Emissions are always float32 [B, T, C] row-major ("the emissions graph": gtn.linear_graph +
@@ -266,7 +266,8 @@ int wfl_lattice_forward_grad(const wfl_lattice_desc* d, const int32_t* ints, con
                              const float* xg, int T, int C, const float* weights, float* alpha,
                              float* beta, float* logz, const float* coef, const float* x,
                              const float* row_lse, float* dx, int* in_launch, void* stream);
-/* What became of the gradient workgroups beside the sweeps (wfl_lattice_forward_grad), process-wide counters:
+/* What became of the gradient workgroups beside the sweeps (wfl_lattice_forward_grad), counters of the calling thread's
+ * CURRENT DEVICE (a give-up on one GPU does not back off the others):
  *   out[0] calls that launched them            out[1] of those, gates that GAVE UP waiting for the sweeps (kernels of
  *   out[2] gates that went through                     two streams did not run at the same time: a serialising
  *   out[3] calls that took the plain path              profiler, a debugger) -- the call fell back to
