@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) dense_backtrace_kernel(const float* __res
 }
 
 // =================================================================================================
-// Probability-domain sweeps (log semiring, C <= 128)
+// Probability-domain sweeps (log semiring, C <= 192)
 //
 //   P[i][j]     = 2^((W[1+i][j] - rowmax_i) * log2 e)                     in (0, 1], rows of the thread
 //   e_t[i]      = 2^((x[t,i] + rowmax_i) * log2 e - mx2_t)                mx2_t = max_i of the exponent
@@ -525,7 +525,7 @@ struct DenseWs {
   double* z2;     // [B]        log2 Z
   int32_t* E;     // [B][2][T]  cumulative renormalisation exponents, indexed by frame
   float* mx2;     // [B][T]     per-frame emission offset (log2) for t >= 1
-  float* wr2;     // [128]      row maxima of W[1:, :] in log2 units
+  float* wr2;     // [256]      row maxima of W[1:, :] in log2 units
   int32_t* flag;  // [B][2]     1: the fast sweep could not represent this utterance
 };
 
@@ -536,25 +536,32 @@ __host__ __device__ inline DenseWs dense_ws_carve(void* ws, int B, int T) {
   w.z2 = (double*)p, p += (size_t)8 * B;
   w.E = (int32_t*)p, p += (size_t)4 * B * 2 * T;
   w.mx2 = (float*)p, p += (size_t)4 * B * T;
-  w.wr2 = (float*)p, p += (size_t)4 * 128;
+  w.wr2 = (float*)p, p += (size_t)4 * 256;
   w.flag = (int32_t*)p;
   return w;
 }
 static size_t dense_ws_bytes(int B, int T) {
-  return (size_t)8 * B * 2 * T + (size_t)8 * B + (size_t)4 * B * 2 * T + (size_t)4 * B * T + 4 * 128 + (size_t)8 * B + 64;
+  return (size_t)8 * B * 2 * T + (size_t)8 * B + (size_t)4 * B * 2 * T + (size_t)4 * B * T + 4 * 256 + (size_t)8 * B + 64;
 }
 
-constexpr int kDenseChainWaves = 4, kDenseThreads = (kDenseChainWaves + 1) * 64;
+// chain waves of a sweep: a wave covers 32 states -- four up to 128 classes (one per SIMD), one per 32 states beyond (160
+// and 192 classes: five / six, two on some SIMDs; a lane then keeps up to 96 transition factors in registers)
+template <int CP>
+constexpr int dense_chain_waves() { return CP <= 128 ? 4 : CP / 32; }
+template <int CP>
+constexpr int dense_threads() { return (dense_chain_waves<CP>() + 1) * 64; }
 template <int CP>
 struct FastLds {
   static constexpr int H = CP / 2;                 // states per half of the vector (both halves equally full)
   static constexpr int NCH = (H + 15) / 16;        // 16-element chunks per half
   static constexpr int LASTN = H - 16 * (NCH - 1); // elements of the last chunk (the others are full)
-  float vecT[2][2][16][4];  // frame vector (ping-pong): [half][position in chunk][chunk]: a lane's NCH elements contiguous
+  static constexpr int NC4 = (NCH + 3) / 4 * 4;    // ... rounded up to whole 16-byte reads
+  static constexpr int NW = dense_chain_waves<CP>();
+  float vecT[2][2][16][NC4];  // frame vector (ping-pong): [half][position in chunk][chunk]: a lane's NCH elements contiguous
   float eh[4][CP];         // ring of e_t rows staged by the helper wave
   float wr2[CP];
   float st2[CP];           // start weights W[0, :] in log2 units
-  float wsum[kDenseChainWaves];
+  float wsum[NW];
   float sinv[2];           // 2^-kk of step n at [n & 1], written by the helper wave one interval ahead
   double mtot;
 };
@@ -563,6 +570,7 @@ template <int CP, int DIR, bool PAIR>
 __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, const float* __restrict__ W, int T, int C,
                                                  void* wsp, int B, float* __restrict__ out, float* __restrict__ logz,
                                                  FastLds<CP>& L) {
+  constexpr int kDenseChainWaves = FastLds<CP>::NW, kDenseThreads = dense_threads<CP>();
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const DenseWs ws = dense_ws_carve(wsp, B, T);
   const float* xb = x + (int64_t)b * T * C;
@@ -605,7 +613,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   const bool owner = qq == 0;                              // the lane that finishes the state
   float P[16 * NCH];
   int hard = 0;
-  for (int i = tid; i < 2 * 2 * 16 * 4; i += kDenseThreads) (&L.vecT[0][0][0][0])[i] = 0.f;  // (padding stays 0)
+  for (int i = tid; i < 2 * 2 * 16 * FastLds<CP>::NC4; i += kDenseThreads) (&L.vecT[0][0][0][0])[i] = 0.f;  // (padding stays 0)
   if (wave < kDenseChainWaves) {
     // (all of the lane's transition scores first, from clamped addresses: P[] holds the raw scores until the second loop)
     const int qc = min(q, C - 1);
@@ -632,58 +640,70 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   }
 
   // ---- helper wave state: a lane covers two states -- lane and lane + 64, or (PAIR: an even number of classes and
-  // an 8-byte aligned tensor) 2 lane and 2 lane + 1, whose scores then arrive in ONE 8-byte load per row
+  // an 8-byte aligned tensor) 2 lane and 2 lane + 1, whose scores then arrive in ONE 8-byte load per row -- and, beyond
+  // 128 classes, a third: 128 + lane
   // item r is the emission row the chain multiplies in at step r: frame r (alpha), frame T - r (beta)
-  const int i0 = PAIR ? 2 * lane : lane, i1 = PAIR ? 2 * lane + 1 : lane + 64;
-  const bool has0 = i0 < CP, has1 = i1 < CP;
-  const float add0 = L.wr2[has0 ? i0 : 0], add1 = L.wr2[has1 ? i1 : 0];
+  constexpr int NS = CP <= 128 ? 2 : 3;
+  static_assert(CP <= 192, "states per helper lane");
+  int ist[NS];
+  ist[0] = PAIR ? 2 * lane : lane, ist[1] = PAIR ? 2 * lane + 1 : lane + 64;
+  if constexpr (NS > 2) ist[2] = lane + 128;
+  bool has[NS];
+  float add[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) has[s] = ist[s] < CP, add[s] = L.wr2[has[s] ? ist[s] : 0];
   // Emission rows travel HBM -> registers kDepth items ahead of their use.  (The first version kept 4 in flight: with
   // ~1.7 us of load latency under load that alone pinned the sweep at latency / 4 = ~1000 cycles per frame, whatever
   // the matrix-vector product cost -- measured with three different product layouts.)
-  // As deep as the 6-bit vmcnt counter allows: 31 rows of two loads, 48 rows of one.  With 16, the sweep ran at 343 us
-  // alone but at 375 us next to the numerator's gradient kernel streaming 170 MB on the other stream (the round trip
-  // grows past the 5.4 us that 16 frames cover); with 31: 358 us.
-  constexpr int kDepth = PAIR ? 48 : 31;
-  float raw[kDepth][2];
+  // As deep as the 6-bit vmcnt counter allows: 31 rows of two loads, 48 rows of one (three states: 21 / 31).  With 16,
+  // the sweep ran at 343 us alone but at 375 us next to the numerator's gradient kernel streaming 170 MB on the other
+  // stream (the round trip grows past the 5.4 us that 16 frames cover); with 31: 358 us.
+  constexpr int kDepth = NS == 2 ? (PAIR ? 48 : 31) : (PAIR ? 31 : 21);
+  float raw[kDepth][NS];
   double mrun = 0.0;
   auto item_ok = [&](int r) { return DIR == 0 ? r < T : (r >= 1 && r < T); };
-  auto issue = [&](int r, float (&dst)[2]) {
+  auto issue = [&](int r, float (&dst)[NS]) {
     if (!item_ok(r)) return;
     const float* row = xb + (int64_t)(DIR == 0 ? r : T - r) * C;
-    dst[0] = i0 < C ? row[i0] : WFL_NEG_INF;
-    dst[1] = i1 < C ? row[i1] : WFL_NEG_INF;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) dst[s] = ist[s] < C ? row[ist[s]] : WFL_NEG_INF;
   };
   // CHECKED = false: the caller guarantees 3 <= r and that the item exists (no branches: the main loop
   // must stay straight-line so that the loads of later items stay in flight across this one's use)
-  auto stage = [&](int r, const float (&src)[2], auto checked) {
+  auto stage = [&](int r, const float (&src)[NS], auto checked) {
     constexpr bool CHECKED = decltype(checked)::value;
     if (CHECKED && !item_ok(r)) {
       if (DIR == 1 && r == 0 && lane == 0) Mb[T - 1] = 0.0;
       return;
     }
     const bool first = CHECKED && DIR == 0 && r == 0;
-    const float s0 = i0 < C ? fmaf(nan_to_neg(src[0]), kLog2e, first ? L.st2[i0] : add0) : WFL_NEG_INF;
-    const float s1 = i1 < C ? fmaf(nan_to_neg(src[1]), kLog2e, first ? L.st2[i1] : add1) : WFL_NEG_INF;
-    const float m = wave_all_max(vmax(s0, s1));
+    float sv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sv[s] = ist[s] < C ? fmaf(nan_to_neg(src[s]), kLog2e, first ? L.st2[ist[s]] : add[s]) : WFL_NEG_INF;
+    float mloc = vmax(sv[0], sv[1]);
+    if constexpr (NS > 2) mloc = vmax(mloc, sv[2]);
+    const float m = wave_all_max(mloc);
     float* dst = L.eh[r & 3];
-    if (has0) dst[i0] = i0 < C ? __builtin_amdgcn_exp2f(s0 - m) : 0.f;
-    if (has1) dst[i1] = i1 < C ? __builtin_amdgcn_exp2f(s1 - m) : 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (has[s]) dst[ist[s]] = ist[s] < C ? __builtin_amdgcn_exp2f(sv[s] - m) : 0.f;
     mrun += (double)m;
     if (lane == 0) {
       Mb[DIR == 0 ? r : T - 1 - r] = mrun;
       if (DIR == 0) ws.mx2[(int64_t)b * T + r] = m;
     }
   };
-  auto issue_fast = [&](int r, float (&dst)[2]) {  // straight-line: the row index is clamped, items past the end are unused
+  auto issue_fast = [&](int r, float (&dst)[NS]) {  // straight-line: the row index is clamped, items past the end are unused
     const int rr = DIR == 0 ? min(r, T - 1) : max(T - r, 0);
     const float* row = xb + (int64_t)rr * C;
     if (PAIR) {  // (C is even: the last pair starts at C - 2)
-      const float2 v = *reinterpret_cast<const float2*>(row + min(i0, C - 2));
+      const float2 v = *reinterpret_cast<const float2*>(row + min(ist[0], C - 2));
       dst[0] = v.x, dst[1] = v.y;
     } else {
-      dst[0] = row[i0 < C ? i0 : 0];
-      dst[1] = row[i1 < C ? i1 : 0];
+      dst[0] = row[ist[0] < C ? ist[0] : 0];
+      dst[1] = row[ist[1] < C ? ist[1] : 0];
     }
+    if constexpr (NS > 2) dst[2] = row[ist[2] < C ? ist[2] : 0];
   };
   // straight-line staging of item r >= 2 (no early return: later items' loads stay in flight across this one's
   // use); items past the end only skip their bookkeeping
@@ -696,14 +716,18 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   double gM = 0.0;
   float gm2 = 0.f;
   int gE = 0;
-  auto stage_fast = [&](int r, const float (&src)[2], int k) {
+  auto stage_fast = [&](int r, const float (&src)[NS], int k) {
     const bool ok = r < T;
-    const float s0 = i0 < C ? fmaf(nan_to_neg(src[0]), kLog2e, add0) : WFL_NEG_INF;
-    const float s1 = i1 < C ? fmaf(nan_to_neg(src[1]), kLog2e, add1) : WFL_NEG_INF;
-    const float m = wave_all_max(vmax(s0, s1));
+    float sv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sv[s] = ist[s] < C ? fmaf(nan_to_neg(src[s]), kLog2e, add[s]) : WFL_NEG_INF;
+    float mloc = vmax(sv[0], sv[1]);
+    if constexpr (NS > 2) mloc = vmax(mloc, sv[2]);
+    const float m = wave_all_max(mloc);
     float* dst = L.eh[r & 3];
-    if (has0) dst[i0] = i0 < C ? __builtin_amdgcn_exp2f(s0 - m) : 0.f;
-    if (has1) dst[i1] = i1 < C ? __builtin_amdgcn_exp2f(s1 - m) : 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (has[s]) dst[ist[s]] = ist[s] < C ? __builtin_amdgcn_exp2f(sv[s] - m) : 0.f;
     mrun += ok ? (double)m : 0.0;
     gM = lane == k ? mrun : gM;
     gm2 = lane == k ? m : gm2;
@@ -732,13 +756,15 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
   };
   // the scale reference: four fixed elements of the vector (v[0], v[16], v[32], v[48]: one aligned 16-B read)
   auto scale_ref = [&](int cur) { return *reinterpret_cast<const float4*>(L.vecT[cur][0][0]); };
-  constexpr int kVecBuf = 2 * 16 * 4;  // floats of one of the two frame-vector buffers
+  constexpr int kVecBuf = 2 * 16 * FastLds<CP>::NC4;  // floats of one of the two frame-vector buffers
   float* const myslot = &vslot(0, q < CP ? q : 0);
   auto chain_step = [&](int n, int cur) {  // n >= 1, cur = (n - 1) & 1
     const float e = L.eh[(DIR == 0 ? n : n + 1) & 3][q < CP ? q : 0];  // beta at n = T-1: a stale row, unused
     const float4 vc4 = *reinterpret_cast<const float4*>(L.vecT[cur][qq][il]);  // this row's chunks of its half
+    float4 vc8 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (NCH > 4) vc8 = *reinterpret_cast<const float4*>(&L.vecT[cur][qq][il][4]);
     const float inv = L.sinv[n & 1];
-    const float vc[4] = {vc4.x, vc4.y, vc4.z, vc4.w};
+    const float vc[8] = {vc4.x, vc4.y, vc4.z, vc4.w, vc8.x, vc8.y, vc8.z, vc8.w};
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // element k of the row's chunk, broadcast to the row's 16 lanes by the multiply-add's DPP source
     // (chunk c holds N valid elements: 16, or LASTN in the last one -- at C = 100 the halves are 52 long, so the
@@ -759,6 +785,9 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     if constexpr (NCH > 1) { WFL_BC16(1, NCH == 2 ? LASTN : 16) }
     if constexpr (NCH > 2) { WFL_BC16(2, NCH == 3 ? LASTN : 16) }
     if constexpr (NCH > 3) { WFL_BC16(3, NCH == 4 ? LASTN : 16) }
+    if constexpr (NCH > 4) { WFL_BC16(4, NCH == 5 ? LASTN : 16) }
+    if constexpr (NCH > 5) { WFL_BC16(5, NCH == 6 ? LASTN : 16) }
+    static_assert(NCH <= 6, "chunks of the frame vector per lane");
 #undef WFL_BC16
 #undef WFL_BC
     float part = (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -888,7 +917,10 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
     }
     __syncthreads();
     if (tid == 0) {
-      const double z2 = L.mtot + (double)__builtin_amdgcn_logf((L.wsum[0] + L.wsum[1]) + (L.wsum[2] + L.wsum[3]));
+      float zs = (L.wsum[0] + L.wsum[1]) + (L.wsum[2] + L.wsum[3]);
+#pragma unroll
+      for (int k = 4; k < kDenseChainWaves; ++k) zs += L.wsum[k];
+      const double z2 = L.mtot + (double)__builtin_amdgcn_logf(zs);
       ws.z2[b] = z2;
       logz[b] = (float)(z2 * 0.6931471805599453);
     }
@@ -897,7 +929,7 @@ __device__ __forceinline__ void dense_fast_sweep(const float* __restrict__ x, co
 }
 
 template <int CP, bool PAIR>
-__global__ void __launch_bounds__(kDenseThreads)
+__global__ void __launch_bounds__(dense_threads<CP>())
     dense_fast_chain_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, void* wsp, int B,
                             float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz) {
   __shared__ __attribute__((aligned(16))) FastLds<CP> L;
@@ -1275,7 +1307,7 @@ __global__ void __launch_bounds__(256, 2)
 // 192 / 256 threads), 8 for the one-wave workgroups of the small ones (16 frames would double their operand registers).
 // cfg3 (C = 100): 128 -> 122 us with 16; more workgroups per utterance than 512 / B lose (768: 160 us, 1024: 155 us).
 template <int CP>
-constexpr int grad_stage() { return CP >= 104 ? 16 : 8; }
+constexpr int grad_stage() { return CP > 128 ? 8 : CP >= 104 ? 16 : 8; }  // (beyond 128 classes: up to nine waves per workgroup, fewer registers each)
 static int dense_chunks(int B, int T) {
   static const int target = [] {
     const char* e = getenv("WFL_DENSE_GRAD_WGS");  // (measurements) workgroups the gradient launch aims at
@@ -1314,12 +1346,13 @@ static int dense_check(const float* x, const float* W, int B, int T, int C, cons
 // tiled matrix product with the matrix streamed from L2 (dense_wide.h) -- asg.py:198-199 has no limit.
 extern "C" int wfl_dense_max_classes(void) { return kDenseMaxClasses; }
 // smallest instantiated padded class count >= C (0: no fast path)
-static int dense_fast_cp(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 104 ? 104 : C <= 128 ? 128 : 0; }
-// Log semiring: a workgroup keeps the matrix to itself only where the register-resident probability-domain sweeps exist
-// (up to 128 classes; the LDS-resident log-domain kernels then serve what those flag).  From 129 classes on the frame of
-// the whole batch is dense_wide.h's product on the matrix cores: at N = 150, B = 128, T = 1000 a step takes 16.7 ms there
-// against 33.6 ms with one LDS-resident log-domain workgroup per utterance (Viterbi stays on chip up to
-// 195 classes, what the LDS holds: 9.6 against 44 ms, the tropical frame has no matrix-core form).
+static int dense_fast_cp(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 104 ? 104 : C <= 128 ? 128 : C <= 160 ? 160 : C <= 192 ? 192 : 0; }
+// Log semiring: a workgroup keeps the matrix to itself where the register-resident probability-domain sweeps exist -- up to
+// 192 classes since round 5 (five / six chain waves of 32 states beyond 128: a lane holds up to 96 factors of P; the
+// LDS-resident log-domain kernels serve what those flag, they fit up to 195).  Beyond, the frame of the whole batch is
+// dense_wide.h's product on the matrix cores, one launch per frame.  N = 150, B = 128, T = 1000: 0.88 ms per step with
+// the register-resident sweeps against 16.7 ms per-frame launches and 33.6 ms with one LDS-resident log-domain workgroup
+// per utterance (profiles/r05_asg_129_to_200_classes.txt; Viterbi stays on the LDS-resident kernel up to 195 classes).
 static bool dense_log_on_chip(int C) { return dense_fast_cp(C) != 0; }
 extern "C" int wfl_dense_on_chip_classes(void) {  // (the log semiring's limit: what sizes wfl_dense_workspace)
   int c = 1;
@@ -1373,10 +1406,10 @@ int wfl_dense_forward_parts(const float* x, const float* W, int B, int T, int C,
 #define WFL_FAST_CHAIN(CP)                                                                                              \
   do {                                                                                                                  \
     if (pair)                                                                                                           \
-      hipLaunchKernelGGL((dense_fast_chain_kernel<CP, true>), grid, dim3(kDenseThreads), 0, st, x, W, T, C, ws, B, alpha, \
+      hipLaunchKernelGGL((dense_fast_chain_kernel<CP, true>), grid, dim3(dense_threads<CP>()), 0, st, x, W, T, C, ws, B, alpha, \
                          beta, logz);                                                                                   \
     else                                                                                                                \
-      hipLaunchKernelGGL((dense_fast_chain_kernel<CP, false>), grid, dim3(kDenseThreads), 0, st, x, W, T, C, ws, B,     \
+      hipLaunchKernelGGL((dense_fast_chain_kernel<CP, false>), grid, dim3(dense_threads<CP>()), 0, st, x, W, T, C, ws, B, \
                          alpha, beta, logz);                                                                            \
   } while (0)
     if (main_part) {
@@ -1388,6 +1421,10 @@ int wfl_dense_forward_parts(const float* x, const float* W, int B, int T, int C,
         WFL_FAST_CHAIN(104);
       else if (cp == 128)
         WFL_FAST_CHAIN(128);
+      else if (cp == 160)
+        WFL_FAST_CHAIN(160);
+      else if (cp == 192)
+        WFL_FAST_CHAIN(192);
       WFL_LAUNCH_CHECK();
       if (!cp)  // no fast path for this C: every utterance is served by the log-domain kernels
         WFL_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)w.flag, 1, (size_t)2 * B, st));
@@ -1484,6 +1521,10 @@ int wfl_dense_grad_parts(const float* x, const float* W, int B, int T, int C, co
     if (use_mfma && part) WFL_MFMA_GRAD(104); else WFL_FAST_GRAD(104);
   } else if (cp == 128) {
     if (use_mfma && part) WFL_MFMA_GRAD(128); else WFL_FAST_GRAD(128);
+  } else if (cp == 160) {  // (beyond 128 classes: the 8 x 8 register tiles of the vector pipe -- (CP / 8)^2 threads)
+    WFL_FAST_GRAD(160);
+  } else if (cp == 192) {
+    WFL_FAST_GRAD(192);
   }
 #undef WFL_MFMA_GRAD
 #undef WFL_FAST_GRAD

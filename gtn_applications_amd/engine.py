@@ -670,12 +670,13 @@ def dense_forward(x, W, need_beta=True):
 
 
 def dense_flagged(st):
-    """[B] bool: utterances the probability-domain sweep handed to the log-domain kernels (none beyond 128 classes:
-    there the frames of the whole batch are one product per frame, csrc/dense_wide.h, with no second arithmetic)."""
+    """[B] bool: utterances the probability-domain sweep handed to the log-domain kernels (none beyond the on-chip class
+    count: there the frames of the whole batch are one product per frame, csrc/dense_wide.h, with no second arithmetic).
+    (the workspace's layout: csrc/dense_kernels.hip::dense_ws_carve)"""
     B, T = st.B, st.T
     if st.C > N.lib.wfl_dense_on_chip_classes():
         return torch.zeros(B, dtype=torch.bool, device=st.ws.device)
-    off = 8 * B * 2 * T + 8 * B + 4 * B * 2 * T + 4 * B * T + 4 * 128
+    off = 8 * B * 2 * T + 8 * B + 4 * B * 2 * T + 4 * B * T + 4 * 256
     return st.ws[off:off + 8 * B].view(torch.int32).view(B, 2).ne(0).any(dim=1)
 
 

@@ -800,10 +800,11 @@ def _dense_check(x, W, expect_flagged, need_dw=True):
     np.testing.assert_allclose(st1.logz.cpu().numpy(), logz, rtol=1e-6)
 
 
-@pytest.mark.parametrize("C,T", [(5, 37), (32, 20), (33, 65), (64, 12), (100, 150), (104, 9), (105, 40), (128, 33)])
+@pytest.mark.parametrize("C,T", [(5, 37), (32, 20), (33, 65), (64, 12), (100, 150), (104, 9), (105, 40), (128, 33),
+                                 (129, 40), (150, 130), (160, 33), (161, 21), (187, 64), (192, 45)])
 def test_dense_probability_domain_sweeps_every_padding_bucket(C, T):
-    """the probability-domain sweeps (C <= 128) on well-conditioned data: served without fallback,
-    loss / emission gradient / transition gradient match the float64 recurrences"""
+    """the probability-domain sweeps (C <= 192: four chain waves up to 128 classes, five / six beyond) on well-conditioned
+    data: served without fallback, loss / emission gradient / transition gradient match the float64 recurrences"""
     rs = np.random.RandomState(C * 7 + T)
     B = 3
     x = (2.0 * rs.randn(B, T, C)).astype(np.float32)
@@ -835,9 +836,10 @@ def test_dense_sweep_emissions_that_are_only_four_byte_aligned():
     assert E.dense_flagged(b).cpu().tolist() == [False] * B
 
 
-@pytest.mark.parametrize("C", [130, 188])
+@pytest.mark.parametrize("C", [130, 188, 200])
 def test_asg_beyond_128_classes(crit, C):
-    """ASG just above the 128 classes of the register-resident sweeps: the batched per-frame product (csrc/dense_wide.h)"""
+    """ASG above the 128 classes of the four-wave register-resident sweeps: five / six chain waves up to 192 classes,
+    the batched per-frame product (csrc/dense_wide.h) beyond"""
     rs = np.random.RandomState(C)
     B, T = 2, 40
     x = rs.randn(B, T, C).astype(np.float32)
@@ -858,9 +860,9 @@ def test_asg_beyond_128_classes(crit, C):
 
 def test_dense_more_classes_than_the_fast_path_supports():
     rs = np.random.RandomState(5)
-    x = rs.randn(2, 25, 150).astype(np.float32)
-    W = (0.3 * rs.randn(151, 150)).astype(np.float32)
-    _dense_check(x, W, [False, False], need_dw=False)  # beyond 128 classes: the batched per-frame product (dense_wide.h)
+    x = rs.randn(2, 25, 230).astype(np.float32)
+    W = (0.3 * rs.randn(231, 230)).astype(np.float32)
+    _dense_check(x, W, [False, False], need_dw=False)  # beyond 192 classes: the batched per-frame product (dense_wide.h)
 
 
 def test_dense_range_flags_hand_utterances_to_the_log_domain_kernels():
