@@ -353,14 +353,35 @@ def make_transducer(args, rank, n_batches):
         x.grad = None
         crit(x * 1.0, batches[(1 + i % max(1, n_batches - 1)) % n_batches]).backward()
 
+    # ... and the same with the NEXT batch's targets handed to criterion.prepare() while this step is queued: their graph
+    # algebra, packing and upload run on a side thread / stream (what a prefetching loader does for the inputs)
+    pending = {}
+
+    def fresh_prepared_step(i):  # (the `fresh_targets` protocol -- leaf emissions, batch 1 + i -- with prepare() one step ahead)
+        x.grad = None
+        k = (1 + i) % n_batches
+        cur = pending.pop(("f", k), None) or crit.prepare(batches[k])
+        loss = crit(x, cur)
+        pending[("f", (2 + i) % n_batches)] = crit.prepare(batches[(2 + i) % n_batches])
+        loss.backward()
+
+    def training_step_prepared(i):
+        x.grad = None
+        k = (1 + i % max(1, n_batches - 1)) % n_batches
+        cur = pending.pop(k, None) or crit.prepare(batches[k])
+        loss = crit(x * 1.0, cur)
+        kn = (1 + (i + 1) % max(1, n_batches - 1)) % n_batches
+        pending[kn] = crit.prepare(batches[kn])
+        loss.backward()
+
     which = " (BASELINE configs[3])" if (T, B) == (800, 64) else ""
     meta = dict(workload=f"transducer fwd+bwd, 1000 word pieces (word_pieces_tokens_1000.txt) T={T} C={C} B={B}{which}",
                 B=B, T=T, C=C, L=Lp, key="cfg4" if which else None,
                 metric=f"utterances/sec fwd+bwd (transducer_benchmark word decompositions T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="Transducer(tokens, ..., blank='optional', allow_repeats=False, reduction='mean')(x, targets).backward()",
                 algorithmic_bytes_per_utt=8 * T * C)
-    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, training_step=training_step, meta=meta,
-                payload=("transducer", x.detach(), crit, batches[0]))
+    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, training_step=training_step,
+                training_step_prepared=training_step_prepared, fresh_prepared_step=fresh_prepared_step, meta=meta, payload=("transducer", x.detach(), crit, batches[0]))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -692,6 +713,18 @@ def main():
                         "of targets never seen before in every step (no content-keyed cache can hit)" +
                         ("; the CTC module on raw scores (log_softmax fused), targets as tensors" if args.workload == "ctc" else
                          "; transitions as an nn.Parameter" if args.workload == "asg" else "")}
+        if fresh_extra and "fresh_prepared_step" in wl and args.mode == "api":
+            el, _ = timed_loop(wl["fresh_prepared_step"], extras_steps, 3, fence, False)
+            out["fresh_targets_prepared"] = {
+                "value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
+                "what": "fresh_targets with criterion.prepare() called one step ahead (Transducer.prepare: the batch's graph "
+                        "algebra, packing and upload on a side thread and stream)"}
+        if fresh_extra and "training_step_prepared" in wl and args.mode == "api":
+            el, _ = timed_loop(wl["training_step_prepared"], extras_steps, 3, fence, False)
+            out["training_step_prepared"] = {
+                "value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
+                "what": "training_step with criterion.prepare(next batch's targets) called while the current step is queued: "
+                        "the per-batch graph algebra, packing and upload on a side thread and stream (Transducer.prepare)"}
         if args.mode == "api" and args.targets == "fresh":
             # the reference benchmarks' own protocol: the same target list every iteration
             el, _ = timed_loop(lambda i: wl["step"](0), extras_steps, 3, fence, False)

@@ -10,6 +10,7 @@ transducer.py:265-281) runs in the C++ host library; everything that touches the
 import ctypes
 import itertools
 import os
+import threading
 
 import math
 
@@ -131,6 +132,74 @@ def make_kernel_graph(x, blank_idx, blank_optional, spike=False, calc_grad=False
 # alignment graphs per (tokens, lexicon, transitions, target) and packed batches: content-keyed LRUs
 _ALIGN_CACHE = E.LRU(4096)
 _PACK_CACHE = E.LRU(32)
+# One batch is packed at a time (the cache, the staging ring and the packer's host pool are shared between the caller's
+# thread and the prefetch thread of Transducer.prepare)
+_PACK_LOCK = threading.RLock()
+_PREP = {"pool": None, "streams": {}}
+
+
+class PreparedTargets:
+    """A batch of targets whose alignment acceptors are being (or have been) built, packed and uploaded ahead of the
+    step that uses them: what `Transducer.prepare(targets)` returns and `Transducer.forward(inputs, prepared)` accepts
+    in the place of the target list.  The per-batch host work of the criterion (the graph algebra of
+    transducer.py:262-281 for every utterance: ~0.3 ms at the benchmark's size) then runs on a side thread while the
+    previous step is on the GPU -- what a DataLoader's prefetch does for the inputs."""
+
+    __slots__ = ("targets", "future", "B")
+
+    def __init__(self, targets, future, B):
+        self.targets, self.future, self.B = targets, future, B
+
+    def result(self):
+        return self.future.result()
+
+    def __len__(self):
+        return self.B
+
+
+def _pack_entry(targets, tokens, lexicon, transitions, C, dev, reduction):
+    """(cache key, flat labels info) of a batch and its cache entry (built if it is not there): the per-sample graph
+    algebra of transducer.py:262-281 for the whole batch -- one native call, threaded over the utterances like the
+    reference's gtn.parallel_for (transducer.py:296) -- and the asynchronous upload on the CURRENT stream."""
+    flat, offsets, lens = E.flatten_any(targets)
+    B = len(lens)
+    key = ("num", flat.tobytes(), tuple(lens), id(tokens), id(lexicon), id(transitions), C, dev.index)
+    full_key = key + (reduction == "mean",)
+    with _PACK_LOCK:
+        if full_key not in _PACK_CACHE.data:
+            N.lib.wfl_host_pool_wake()  # (new targets: the packer's threads are awake by the time its job is submitted)
+
+        def build():
+            if reduction == "mean":  # transducer.py:302-305: normalise by the (grapheme) target length
+                sc = np.array([1.0 / n if n > 0 else 1.0 for n in lens], dtype=np.float32)
+            else:
+                sc = np.ones(B, dtype=np.float32)
+            # (loss scale, +scale/B, -scale/B) travel with the packed batch: one asynchronous upload, no kernels
+            pack = E.PackedLattice.transducer_batch(tokens, lexicon, transitions, flat, offsets, C, dev,
+                                                    extra=np.concatenate([sc, sc / B, -sc / B]))
+            fac = pack.extra
+            return pack, fac[:B], fac[B:2 * B], fac[2 * B:], (tokens, lexicon, transitions)
+
+        entry = _PACK_CACHE.get(full_key, build)
+    return B, entry
+
+
+def _prepare(targets, tokens, lexicon, transitions, C, dev, reduction):
+    """_pack_entry on the prefetch thread, its upload on a stream of its own (the step that uses the pack orders itself
+    behind the pack's event)."""
+    if _PREP["pool"] is None:
+        import concurrent.futures
+
+        _PREP["pool"] = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="wfl-prepare")
+    stream = _PREP["streams"].get(dev.index)
+    if stream is None:
+        stream = _PREP["streams"][dev.index] = torch.cuda.Stream(device=dev)
+
+    def job():
+        with torch.cuda.device(dev), torch.cuda.stream(stream):
+            return _pack_entry(targets, tokens, lexicon, transitions, C, dev, reduction)
+
+    return _PREP["pool"].submit(job)
 
 
 def _zero_weight_view(graph):
@@ -184,6 +253,7 @@ class Transducer(torch.nn.Module):
             raise ValueError("Invalid value specificed for blank. Must be in ['optional', 'forced', 'none']")
         self.tokens = make_token_graph(tokens, blank=blank, allow_repeats=allow_repeats)
         self.lexicon = make_lexicon_graph(tokens, graphemes_to_idx)
+        self._num_emission_classes = len(tokens) + int(blank != "none")  # (width of the emissions: prepare())
         self.ngram = ngram
         if ngram > 0 and transitions is not None:
             raise ValueError("Only one of ngram and transitions may be specified")
@@ -199,6 +269,20 @@ class Transducer(torch.nn.Module):
             self.transitions = None
             self.transition_params = None
         self.reduction = reduction
+
+    def prepare(self, targets, device=None):
+        """Start building, packing and uploading the alignment acceptors of a batch the criterion will see later -- on a
+        side thread and a stream of its own; returns at once.  Hand the result to forward() in the place of `targets`:
+
+            nxt = criterion.prepare(next_targets)        # e.g. right after the step's launches, or in the loader's collate
+            loss = criterion(emissions, cur); loss.backward(); ...; cur = nxt
+
+        (reference: transducer.py:262-281 runs this per step, inside forward.)  `device`: where the emissions will
+        live (default: the current device)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.tokens.arc_sort(True)
+        return PreparedTargets(targets, _prepare(targets, self.tokens, self.lexicon, self.transitions,
+                                                 self._num_emission_classes, dev, self.reduction), len(targets))
 
     @E.on_input_device
     def forward(self, inputs, targets):
@@ -375,31 +459,23 @@ class TransducerLossFunction(torch.autograd.Function):
             raise ValueError("TransducerLoss: empty emissions (T == 0)")
         dev = E.require_gpu()
         x = E.as_device_f32(inputs.detach(), dev)
-        flat, offsets, lens = E.flatten_any(targets)
-        if len(lens) != B:
-            raise ValueError(f"got {len(lens)} targets for a batch of {B}")
         params = E.as_device_f32(transition_params.detach(), dev) if transitions is not None else None
-
-        key = ("num", flat.tobytes(), tuple(lens), id(tokens), id(lexicon), id(transitions), C, dev.index)
-
-        full_key = key + (reduction == "mean",)
-        if full_key not in _PACK_CACHE.data:
-            N.lib.wfl_host_pool_wake()  # (new targets: the packer's threads are awake by the time its job is submitted)
-
-        def build():
-            # per-sample graph algebra of transducer.py:262-281 for the whole batch: one native call, threaded
-            # over the utterances like the reference's gtn.parallel_for (transducer.py:296)
-            if reduction == "mean":  # transducer.py:302-305: normalise by the (grapheme) target length
-                sc = np.array([1.0 / n if n > 0 else 1.0 for n in lens], dtype=np.float32)
-            else:
-                sc = np.ones(B, dtype=np.float32)
-            # (loss scale, +scale/B, -scale/B) travel with the packed batch: one asynchronous upload, no kernels
-            pack = E.PackedLattice.transducer_batch(tokens, lexicon, transitions, flat, offsets, C, dev,
-                                                    extra=np.concatenate([sc, sc / B, -sc / B]))
-            fac = pack.extra
-            return pack, fac[:B], fac[B:2 * B], fac[2 * B:], (tokens, lexicon, transitions)
-
-        pack, scale, cpos, cneg, _ = _PACK_CACHE.get(full_key, build)
+        if isinstance(targets, PreparedTargets):
+            nb, entry = targets.result()
+            pack = entry[0]
+            if pack.desc.B != B or pack.device != dev or entry[4] != (tokens, lexicon, transitions):
+                # prepared for other emissions (another device, another criterion): pack again, here
+                nb, entry = _pack_entry(targets.targets, tokens, lexicon, transitions, C, dev, reduction)
+        else:
+            nb, entry = _pack_entry(targets, tokens, lexicon, transitions, C, dev, reduction)
+        if nb != B:
+            raise ValueError(f"got {nb} targets for a batch of {B}")
+        pack, scale, cpos, cneg, _ = entry
+        up = getattr(pack, "_uploaded", None)
+        if up is not None and up[0] != E.stream_ptr() and not getattr(pack, "_seen_here", None) == E.stream_ptr():
+            # uploaded on another stream (the prefetch thread's, or an earlier step's): its memory stays this stream's too
+            pack._blob.record_stream(torch.cuda.current_stream())
+            pack._seen_here = E.stream_ptr()
         need_grad = inputs.requires_grad or (transition_params is not None and transition_params.requires_grad)
         den = dense = None
         node = _native_node() if transitions is None else None

@@ -161,3 +161,40 @@ def test_forced_all_reduce_issues_the_rccl_collective_on_one_rank(nccl_world_of_
     torch.cuda.synchronize()
     torch.testing.assert_close(buf, want[0], rtol=0, atol=0)
     torch.testing.assert_close(other, want[1], rtol=0, atol=0)
+
+
+def test_transducer_prepare_packs_the_next_batch_on_a_side_thread():
+    """Transducer.prepare(targets) -> PreparedTargets: the batch's alignment acceptors built, packed and uploaded on a
+    side thread and stream; forward(inputs, prepared) gives what forward(inputs, targets) gives (the loss bit for bit,
+    the gradient to the rounding of its atomic adds), also when the handle was prepared several steps ahead and under a
+    transition model; a handle for another batch size is an error like a list of the wrong length."""
+    from gtn_applications_amd.criterions import transducer
+
+    rs = np.random.RandomState(2)
+    tokens = ["a", "b", "ab", "ba", "aba", "bb"]
+    g2i = {"a": 0, "b": 1}
+    for kwargs in (dict(blank="optional", allow_repeats=False, reduction="mean"), dict(ngram=2, blank="optional", reduction="none")):
+        crit = transducer.Transducer(tokens, g2i, **kwargs).cuda()
+        if crit.transition_params is not None:
+            with torch.no_grad():
+                crit.transition_params.copy_(torch.tensor(0.2 * rs.randn(crit.transition_params.numel()).astype(np.float32)))
+        B, T, C = 5, 40, len(tokens) + 1
+        batches = [[torch.tensor(rs.randint(0, 2, size=rs.randint(1, 6))) for _ in range(B)] for _ in range(4)]
+        x = torch.tensor(rs.randn(B, T, C).astype(np.float32)).cuda()
+        want = []
+        for tg in batches:
+            xr = x.clone().requires_grad_(True)
+            loss = crit(xr, tg)
+            loss.backward()
+            want.append((loss.item(), xr.grad.clone()))
+        handles = [crit.prepare(tg) for tg in batches]  # all of them ahead
+        assert all(len(h) == B for h in handles)
+        for h, (wl, wg) in zip(handles, want):
+            xr = x.clone().requires_grad_(True)
+            loss = crit(xr, h)
+            loss.backward()
+            assert loss.item() == wl
+            torch.testing.assert_close(xr.grad, wg, rtol=1e-5, atol=1e-8)
+        # a handle prepared for a batch of another size than the emissions: an error, as with a plain list
+        with pytest.raises(ValueError):
+            crit(x[:3], handles[0])
