@@ -46,7 +46,7 @@
 #define WFL_MITM_CLAMP_EVERY 1  // the neighbour-gap clamp in every n-th block of the chain (1 or 4; 4: -0.5 us at cfg2, but fronts that cross four lanes inside one block overflow: 10 of 128 peaked utterances repaired)
 #endif
 #ifndef WFL_MITM_LEAN
-#define WFL_MITM_LEAN 1  // 1: the chain wave without its renormalisation (lane exponents predicted by the helper wave); 0: renormalised on the wave (A/B)
+#define WFL_MITM_LEAN 1  // the chain wave's complete blocks: 1 the factor reads between the frames, 0 plain blocks only (A/B)
 #endif
 #ifndef WFL_MITM_STATS
 #define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
@@ -257,10 +257,14 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
     lds_post(&S.zready, 1);
     if (lane == 0) {
       const long long zq = z_fixed(zk);
-      __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // (behind them, as a RELEASE: whoever sees the count has the minimum and the maximum -- see the alpha chain's end)
-      __hip_atomic_fetch_add(zcnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // the minimum and the maximum FIRST, acknowledged (their return values are waited for), then the count: whoever
+      // sees the count has both -- see the alpha chain's end.  (Ordered by hand: a RELEASE on the count and an ACQUIRE at
+      // its reader are an L2 write-back and an L2 invalidate at agent scope on this chip -- with 256 workgroups
+      // streaming their gradient rows at that moment they cost the launch 6 of its 41 us, measured.)
+      const long long was_lo = __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long was_hi = __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(was_lo), "v"(was_hi) : "memory");
+      __hip_atomic_fetch_add(zcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     // (ONE reference per sweep, from its first emitted block whichever emitter took it: results do not depend on
@@ -1158,9 +1162,10 @@ __device__ __forceinline__ void ctc_mitm_body(const CtcArgs& a, int b, int dir, 
         // half a sweep ago; should one of them not have arrived yet (its workgroup started late: nothing orders
         // workgroups) the count says so and the doubt is raised for the repair launch to settle.
         const long long* zmm = (const long long*)(a.ws + w.zloc) + (int64_t)b * 2;
-        // (the count FIRST, acquiring: a count of nfirst then vouches for the two words read behind it -- read in the
+        // (the count FIRST, and waited for: a count of nfirst then vouches for the two words read behind it -- read in the
         // other order, a partner's three updates could land between the loads and leave the initial range unseen)
-        const int cnt = __hip_atomic_load((const int32_t*)(a.ws + w.zcnt) + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const int cnt = __hip_atomic_load((const int32_t*)(a.ws + w.zcnt) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(cnt) : "memory");  // (it has ARRIVED before the two loads below are issued)
         const long long lo = (long long)coherent_load64(zmm), hi = (long long)coherent_load64(zmm + 1);
         const long long zq = z_fixed(z2);
         constexpr long long tol = 10;  // (utterance_rejected)

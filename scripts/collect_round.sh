@@ -9,6 +9,8 @@
 #                            normaliser on the dense engine and, for comparison, on the general lattice sweep
 #   ngram_kernel_stats.csv   rocprofv3 kernel stats of the same script (B = 16)
 #   asg_wide_line.json       ASG with 1000 classes (csrc/dense_wide.h): python bench.py --workload asg --C 1000 --B 32 --T 250
+#   stc_conv_lines.jsonl, asg_129_to_200_classes.txt, <cfg>_step_timeline.txt, host_overhead.txt, viterbi_times.txt,
+#   ctc_long_probe.txt, ctc_module_time.txt   (round 5: the scripts of the same names)
 tag=${1:-r}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
@@ -39,4 +41,14 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ngr
 cp $(find $O/stats_ngram -name "*kernel_stats.csv" | head -1) $O/ngram_kernel_stats.csv
 rm -rf $O/stats_ngram
 python scripts/kstats.py $O
+# round 5: STC / ConvTransduce1D at a size, ASG beyond 128 classes, step timelines, host overhead, resource table input
+python scripts/at_size_lines.py > $O/stc_conv_lines.jsonl 2> $O/stc_conv_lines.log
+python scripts/asg_classes_time.py > $O/asg_129_to_200_classes.txt 2>/dev/null
+for cfg in cfg2 cfg3 cfg4; do
+  bash scripts/step_timeline.sh --config $cfg > $O/${cfg}_step_timeline.txt 2>/dev/null
+done
+python scripts/host_overhead.py > $O/host_overhead.txt 2>/dev/null
+python scripts/viterbi_time.py > $O/viterbi_times.txt 2>/dev/null
+python scripts/ctc_long_probe.py > $O/ctc_long_probe.txt 2>/dev/null
+python scripts/ctc_module_time.py > $O/ctc_module_time.txt 2>/dev/null
 rm -f $O/pmc_*_SIZE.csv.bak

@@ -19,7 +19,7 @@ for k, v in d.items():
     print("  %-40s calls %3d median %7.2f us  mean %7.2f  min %7.2f  max %7.2f" % (k, len(v), statistics.median(v), sum(v) / len(v), min(v), max(v)))
 PY
   if [ $round = 1 ]; then
-    WFL_LIB_PATH=$PWD/scripts/_build/libwfl_mm_${v}s.so timeout 60 python scripts/mitm_stats.py 2>&1 | grep -E "THREE|prologue|chain wave end|workgroup end|chain    simd|stager0|emit0 " | head -20
+    WFL_LIB_PATH=$PWD/scripts/_build/libwfl_mm_${v}s.so timeout 60 python scripts/mitm_stats.py 2>&1 | grep -E "THREE|prologue|chain wave end|workgroup end" | head -20
   fi
 done
 done
