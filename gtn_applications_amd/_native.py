@@ -132,6 +132,8 @@ _SIGS = {
     "wfl_lattice_backtrace": (c_int, [POINTER(LatticeDesc), _P, _P, _P, _P, c_int, _P, _P, c_int, _P]),
     "wfl_debug_grad_occupancy": (c_int, [c_int]),
     # device: ConvTransduce1D
+    "wfl_stc_augment": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "wfl_stc_augment_grad": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P]),
     "wfl_conv_forward": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "wfl_conv_grad": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P,
                               _P]),

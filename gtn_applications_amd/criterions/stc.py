@@ -8,6 +8,7 @@ import math
 
 import torch
 
+from .. import _native as N
 from .. import engine as E
 from .. import graph as G
 
@@ -87,6 +88,33 @@ class STCLossFunction(torch.autograd.Function):
 STCLoss = STCLossFunction.apply
 
 
+class _StcAugment(torch.autograd.Function):
+    """stc.py:199-220 -- the batch's classes selected, <star> = logsumexp over the non-blank classes and <star>\\token
+    appended -- as ONE launch each way (wfl_stc_augment / wfl_stc_augment_grad) instead of six torch ops over [B, T, C]
+    whose intermediates autograd keeps: (T, B, C) log-probabilities in, (B, T, 2K) out."""
+
+    @staticmethod
+    def forward(ctx, inputs, select, inv):
+        T, B, C = inputs.shape
+        K = select.numel()
+        x = inputs.detach().contiguous()
+        out = torch.empty((B, T, 2 * K), dtype=torch.float32, device=x.device)
+        lse = torch.empty(T * B, dtype=torch.float32, device=x.device)
+        N.check(N.lib.wfl_stc_augment(E.ptr(x), T, B, C, E.ptr(select), K, E.ptr(out), E.ptr(lse), E.stream_ptr()))
+        ctx.aux = (x, select, inv, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, select, inv, lse = ctx.aux
+        T, B, C = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        N.check(N.lib.wfl_stc_augment_grad(E.ptr(x), T, B, C, E.ptr(select), E.ptr(inv), select.numel(), E.ptr(lse),
+                                           E.ptr(g), E.ptr(dx), E.stream_ptr()))
+        return dx, None, None
+
+
 class STC(torch.nn.Module):
     """The Star Temporal Classification loss (stc.py:135-221).
 
@@ -115,6 +143,19 @@ class STC(torch.nn.Module):
         if self.training:
             self.nstep += 1
         prob = self.plast + (self.p0 - self.plast) * math.exp(-self.nstep * math.log(2) / self.thalf)
+        if inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 3 and inputs.shape[2] > 1:
+            # keep only blank and the tokens present in this batch (stc.py:205-209), then the augmentation in one launch
+            select_idx = [STC_BLANK_IDX] + list(set(t for target in targets for t in target if t != STC_BLANK_IDX))
+            target_map = {t: i for i, t in enumerate(select_idx)}
+            C = inputs.shape[2]
+            inv_host = torch.full((C,), -1, dtype=torch.int32)
+            sel_host = torch.tensor(select_idx, dtype=torch.int32)
+            inv_host[sel_host.long()] = torch.arange(len(select_idx), dtype=torch.int32)
+            both = torch.cat([sel_host, inv_host]).to(inputs.device, non_blocking=True)
+            mapped = [[target_map[t] for t in target] for target in targets]
+            with torch.cuda.device(inputs.device):
+                log_probs = _StcAugment.apply(inputs, both[:len(select_idx)], both[len(select_idx):])
+            return STCLoss(log_probs, mapped, prob, self.reduction)
         log_probs = inputs.permute(1, 0, 2)  # (T, B, C) -> (B, T, C)
         with torch.set_grad_enabled(log_probs.requires_grad):
             lse = torch.logsumexp(log_probs[:, :, 1:], 2, keepdim=True)  # <star>

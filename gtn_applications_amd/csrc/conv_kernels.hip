@@ -248,6 +248,81 @@ __global__ void __launch_bounds__(256)
 
 using namespace wfl;
 
+namespace wfl {
+
+// ------------------------------------------------------------------------------------------------
+// STC: the alphabet augmentation of stc.py:199-220 in one launch each way (the reference does it with six torch ops over
+// [B, T, C] and autograd keeps their intermediates).  From log-probabilities x [T, B, C] (the module's input layout) and
+// the K selected classes of a batch (the blank, 0, first):
+//     out[b, t, k]         = x[t, b, select[k]]                                  k < K
+//     out[b, t, K]         = lse = logsumexp_{c >= 1} x[t, b, c]                 <star>
+//     out[b, t, K + k]     = lse + log1p(1e-7 - exp(x[t, b, select[k]] - lse))   1 <= k < K    <star> \ token
+// and its gradient
+//     dx[t, b, c] = [c >= 1] p_c A + [inv[c] >= 0] g[inv[c]] - [inv[c] >= 1] g[K + inv[c]] w_{inv[c]}
+//     p_c = exp(x_c - lse),  w_k = u_k / (1 + 1e-7 - u_k),  u_k = exp(x[select[k]] - lse),  A = g[K] + sum_{k >= 1} g[K + k] (1 + w_k)
+// One wave per (t, b) row; the row's log-sum-exp is kept for the backward.  expf / log1pf, not the fast intrinsics: the
+// result is compared with torch's to 1e-6.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stc_augment_kernel(const float* __restrict__ x, int T, int B, int C,
+                                                         const int32_t* __restrict__ select, int K, float* __restrict__ out,
+                                                         float* __restrict__ lse_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // t * B + b
+  if (row >= (int64_t)T * B) return;
+  const int t = (int)(row / B), b = (int)(row % B);
+  const float* xr = x + row * C;
+  float m = WFL_NEG_INF;
+  for (int c = 1 + lane; c < C; c += 64) m = fmaxf(m, nan_to_neg(xr[c]));
+  m = wave_all_max(m);
+  float sum = 0.f;
+  if (m > WFL_NEG_INF)
+    for (int c = 1 + lane; c < C; c += 64) sum += expf(nan_to_neg(xr[c]) - m);
+  sum = wave_all_sum(sum);
+  const float lse = m > WFL_NEG_INF ? m + logf(sum) : WFL_NEG_INF;
+  float* o = out + ((int64_t)b * T + t) * 2 * K;
+  if (lane == 0) {
+    o[K] = lse;
+    lse_out[row] = lse;
+  }
+  for (int k = lane; k < K; k += 64) {
+    const float v = xr[select[k]];
+    o[k] = v;
+    if (k >= 1) o[K + k] = lse + log1pf(1e-7f - expf(v - lse));
+  }
+}
+
+__global__ void __launch_bounds__(256) stc_augment_grad_kernel(const float* __restrict__ x, int T, int B, int C,
+                                                              const int32_t* __restrict__ select, const int32_t* __restrict__ inv,
+                                                              int K, const float* __restrict__ lse_in, const float* __restrict__ g,
+                                                              float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)T * B) return;
+  const int t = (int)(row / B), b = (int)(row % B);
+  const float* xr = x + row * C;
+  const float* gr = g + ((int64_t)b * T + t) * 2 * K;
+  const float lse = lse_in[row];
+  float acc = 0.f;
+  for (int k = 1 + lane; k < K; k += 64) {
+    const float u = expf(xr[select[k]] - lse);
+    acc += gr[K + k] * (1.f + u / (1.f + 1e-7f - u));
+  }
+  const float A = gr[K] + wave_all_sum(acc);
+  float* d = dx + row * C;
+  for (int c = lane; c < C; c += 64) {
+    const float xc = xr[c];
+    float v = c >= 1 ? expf(xc - lse) * A : 0.f;
+    const int k = inv[c];
+    if (k >= 0) v += gr[k];
+    if (k >= 1) {
+      const float u = expf(xc - lse);
+      v -= gr[K + k] * (u / (1.f + 1e-7f - u));
+    }
+    d[c] = v;
+  }
+}
+}  // namespace wfl
+
 extern "C" {
 
 static int conv_check(const float* x, int B, int T, int C, const int32_t* ktab, int K, int ks, int stride, int blank,
@@ -320,6 +395,31 @@ int wfl_conv_grad(const float* x, int B, int T, int C, const int32_t* ktab, int 
   if (int rc = semiring == WFL_SEMIRING_LOG ? launch(conv_grad_kernel<WFL_SEMIRING_LOG>)
                                              : launch(conv_grad_kernel<WFL_SEMIRING_TROPICAL>))
     return rc;
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_stc_augment(const float* x, int T, int B, int C, const int32_t* select, int K, float* out, float* lse, void* stream) {
+  if (!x || !select || !out || !lse || T <= 0 || B <= 0 || C <= 1 || K <= 0 || K > C) {
+    wfl::set_error("stc_augment: bad arguments (T=%d B=%d C=%d K=%d)", T, B, C, K);
+    return WFL_ERR_INVALID;
+  }
+  const int64_t rows = (int64_t)T * B;
+  hipLaunchKernelGGL(wfl::stc_augment_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, T, B, C, select, K,
+                     out, lse);
+  WFL_LAUNCH_CHECK();
+  return WFL_OK;
+}
+
+int wfl_stc_augment_grad(const float* x, int T, int B, int C, const int32_t* select, const int32_t* inv, int K, const float* lse,
+                         const float* g, float* dx, void* stream) {
+  if (!x || !select || !inv || !lse || !g || !dx || T <= 0 || B <= 0 || C <= 1 || K <= 0 || K > C) {
+    wfl::set_error("stc_augment_grad: bad arguments (T=%d B=%d C=%d K=%d)", T, B, C, K);
+    return WFL_ERR_INVALID;
+  }
+  const int64_t rows = (int64_t)T * B;
+  hipLaunchKernelGGL(wfl::stc_augment_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, T, B, C,
+                     select, inv, K, lse, g, dx);
   WFL_LAUNCH_CHECK();
   return WFL_OK;
 }

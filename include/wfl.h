@@ -367,6 +367,15 @@ int wfl_conv_grad(const float* x, int B, int T, int C, const int32_t* ktab, int 
                   int blank, int flags, const float* params, int semiring, const float* delta,
                   float* dx, float* dparams, void* stream);
 
+/* STC's alphabet augmentation (stc.py:199-220) in one launch each way.  x: log-probabilities [T, B, C] (the module's
+ * input layout); select[K]: the classes of the batch, the blank (0) first, each once; inv[C]: select's inverse (-1 for a
+ * class that is not selected).  out [B, T, 2K] = (selected columns | <star> = logsumexp over c >= 1 | <star>\token for
+ * select[1..]), lse [T * B] the rows' <star> (kept for the backward); dx [T, B, C] is OVERWRITTEN with the gradient for
+ * the upstream g [B, T, 2K]. */
+int wfl_stc_augment(const float* x, int T, int B, int C, const int32_t* select, int K, float* out, float* lse, void* stream);
+int wfl_stc_augment_grad(const float* x, int T, int B, int C, const int32_t* select, const int32_t* inv, int K,
+                         const float* lse, const float* g, float* dx, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Device kernels: CTC fast path (create_ctc_graph + intersect + forward_score + backward of
  * ctc.py:15-94; banded recursion with register-resident state, no lattice arrays).

@@ -47,7 +47,7 @@ def main():
         mod(lp, targets).backward()
 
     ms = timed(stc_mod)
-    print(json.dumps({"workload": f"STC module fwd+bwd (alphabet augmentation in torch + STCLoss) T={T} C={Cp} B={B} L={L} (stc.py:174-221)",
+    print(json.dumps({"workload": f"STC module fwd+bwd (alphabet augmentation + STCLoss) T={T} C={Cp} B={B} L={L} (stc.py:174-221)",
                       "ms_per_step": ms, "value": B / ms * 1e3, "unit": "utt/s"}))
 
     with open(os.path.join(ROOT, "benchmarks", "word_pieces_tokens_1000.txt")) as f:

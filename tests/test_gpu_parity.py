@@ -954,6 +954,29 @@ def test_stc_golden_cases(crit, cases):
         close(x.grad, c["grad"], msg=name)
 
 
+def test_stc_module_fused_augmentation_equals_the_torch_spelling(crit):
+    """stc.py:199-220 (select the batch's classes, <star> = logsumexp over the non-blank classes, <star>\\token) as one
+    launch each way (wfl_stc_augment / _grad: device inputs) against the same steps written with torch ops (host
+    inputs take that path): loss and the gradient w.r.t. the (T, B, C) log-probabilities, also with a class count that
+    is not a multiple of the wave, a -inf log-probability and a batch that uses few of the classes."""
+    stc = crit["stc"]
+    rs = np.random.RandomState(21)
+    for (T, B, C, lens) in [(37, 3, 11, (4, 1, 7)), (60, 2, 130, (9, 12)), (25, 4, 65, (3, 3, 2, 5))]:
+        x = torch.log_softmax(torch.tensor(rs.randn(T, B, C).astype(np.float32)), 2)
+        x[3, 0, 2] = float("-inf")
+        targets = [rs.randint(1, min(C, 20), size=n).tolist() for n in lens]
+        res = []
+        for device in ("cpu", "cuda"):
+            xi = x.detach().clone().to(device).requires_grad_(True)
+            m = stc.STC(0, 0.4, 0.1, 50, "mean")
+            m.nstep = 7
+            loss = m(xi, targets)
+            (3.0 * loss).backward()
+            res.append((loss.item(), xi.grad.cpu().numpy()))
+        assert res[1][0] == pytest.approx(res[0][0], rel=2e-5)
+        np.testing.assert_allclose(res[1][1], res[0][1], rtol=2e-4, atol=2e-6)
+
+
 def test_stc_function_vs_oracle(crit):
     rs = np.random.RandomState(9)
     B, T, Cp = 3, 40, 6  # Cp selected columns -> Cstar = 2*Cp
