@@ -2355,14 +2355,9 @@ static int ctc_check(int B, int T, int C, int max_len, int blank, const char* wh
 }
 
 // The compact emission copy pays when x does not stay in the Infinity Cache between the three sweeps (256 MiB) and
-// its rows are wide enough for a 45-label gather to waste most of what it touches.  WFL_CTC_COMPACT_X=0|1 overrides.
+// its rows are wide enough for a 45-label gather to waste most of what it touches.
 static bool ctc_use_xc(int B, int T, int C, int max_len) {
-  static const int force = [] {
-    const char* e = getenv("WFL_CTC_COMPACT_X");
-    return e ? atoi(e) : -1;
-  }();
   if (max_len + 1 > 64) return false;  // (the lane-exponent step: one target position per lane)
-  if (force >= 0) return force != 0;
   return (int64_t)B * T * C * 4 >= (192ll << 20) && C >= 192;
 }
 
@@ -2376,13 +2371,8 @@ static int64_t ctc_fast_grad_wgs(int B, int T) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
-  static const int grad_wgs_env = [] {
-    const char* e = getenv("WFL_CTC_GRAD_WGS");
-    return e ? atoi(e) : -1;
-  }();
   const int64_t all_wgs = ((int64_t)B * ctc_blocks(T) + kFWaves - 1) / kFWaves;
-  if (grad_wgs_env > 0) return std::min<int64_t>(all_wgs, grad_wgs_env);
-  if (grad_wgs_env < 0 && 2 * (int64_t)B <= 3 * n_cus / 2) return std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
+  if (2 * (int64_t)B <= 3 * n_cus / 2) return std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
   return all_wgs;
 }
 // parking area of the persistent gradient waves (CtcArgs::park), behind the compact emission copy.  OFF unless
@@ -2390,10 +2380,7 @@ static int64_t ctc_fast_grad_wgs(int B, int T) {
 // shorten that item's start-up (3.1 instead of 5.3 us from start to checkpoints on the launch's own timeline), but the
 // 35 MB they add to the launch's traffic (302 instead of 267 MB) cost more in back-to-back steps: 61.5 against 60.4 us.
 static int64_t ctc_park_floats(int B, int T) {
-  static const bool off = [] {
-    const char* e = getenv("WFL_CTC_PARK");
-    return !(e && atoi(e) == 1);
-  }();
+  constexpr bool off = true;  // (measured slower, see above: the parking area is never reserved)
   const int64_t wgs = ctc_fast_grad_wgs(B, T), all_wgs = ((int64_t)B * ctc_blocks(T) + kFWaves - 1) / kFWaves;
   return (off || wgs >= all_wgs) ? 0 : wgs * kFWaves * kParkStride;
 }
@@ -2553,12 +2540,8 @@ static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const 
   const bool force_log = env_log || prefer_log;
   const size_t rows8_lds = (size_t)kFWaves * kBlk * C * 4;
   // gradient rows as a dense LDS tile while three workgroups still fit a CU with it (C <= 100), compact beyond
-  static const int force_tile = [] {
-    const char* e = getenv("WFL_CTC_ROWS");  // "dense" / "compact": measurements
-    return !e ? -1 : std::string(e) == "compact" ? 1 : 0;
-  }();
   const size_t compact_lds = (size_t)kFWaves * compact_wave_bytes(C);
-  const bool compact = force_tile >= 0 ? force_tile == 1 : 3 * std::max(rows8_lds, sizeof(FastLdsT)) > (size_t)kLdsBytes;
+  const bool compact = 3 * std::max(rows8_lds, sizeof(FastLdsT)) > (size_t)kLdsBytes;
   // meet-in-the-middle step (ctc_mitm.h): the sweeps emit the gradient -- narrow rows (dense LDS tile per emitter)
   static const int mitm_env = [] {
     const char* e = getenv("WFL_CTC_MITM");
@@ -2578,11 +2561,7 @@ static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const 
     seen[dev] = n;
     return n;
   }();
-  static const int shape_env = [] {
-    const char* e = getenv("WFL_CTC_MITM_WAVES");  // 8 / 16: force a shape (measurements)
-    return e ? atoi(e) : 0;
-  }();
-  const bool small_wg = shape_env ? shape_env == 8 : 2 * (int64_t)B > cus;
+  const bool small_wg = 2 * (int64_t)B > cus;
   auto mitm_lds_of = [&](auto k, bool wide) {
     using K = decltype(k);
     const size_t tiles = wide ? (size_t)K::kEmitters * kBlk * kCS * 4 + (((size_t)C + 15) & ~(size_t)15)  // compact tiles + column map
@@ -2617,12 +2596,8 @@ static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const 
       return WFL_OK;
     };
     // wide rows beyond the cache: the sweeps exchange what they gathered as compact rows (ctc_mitm.h, stagers) in the
-    // region the round-2 compact pre-pass used.  WFL_CTC_MITM_XCHG=0: every sweep gathers all its frames from x.
-    static const int xchg_env = [] {
-      const char* e = getenv("WFL_CTC_MITM_XCHG");
-      return e ? atoi(e) : 1;
-    }();
-    a.xc = (wide && xchg_env && ctc_use_xc(B, T, C, max_len)) ? ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3)
+    // region the round-2 compact pre-pass used
+    a.xc = (wide && ctc_use_xc(B, T, C, max_len)) ? ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3)
                                                               : nullptr;
     if (row_lse) {  // the fused log_softmax criterion (raw scores in, gradient w.r.t. raw scores out)
       if (small_wg)
@@ -2651,17 +2626,11 @@ static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const 
                   : (row_lse ? launch_repair(ctc_repair_kernel<true, false>) : launch_repair(ctc_repair_kernel<false, false>));
   } else if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
     const size_t lds = std::max(compact ? compact_lds : rows8_lds, sizeof(FastLdsT));
-    static const bool dbg_nograd = getenv("WFL_DBG_NOGRAD") != nullptr;  // (scratch measurements: chains only)
     const int64_t grad_wgs = ctc_fast_grad_wgs(B, T);
-    const dim3 grid8((unsigned)(2 * B + (dbg_nograd ? 0 : grad_wgs)));
-    static const int place_env = [] {
-      // Measured on one box, cfg2: placement cuts the memory-side traffic of the launch 278 -> 223 MB (x[b] lands in
-      // one L2 instead of several) and COSTS 2 us (59.8 -> 62.0; +2 % at cfg5): eight utterance groups with their own
-      // chains finish less evenly than 128 utterances spread over everything.  Off by default; WFL_CTC_XCD=1 enables.
-      const char* e = getenv("WFL_CTC_XCD");
-      return e ? atoi(e) : 0;
-    }();
-    a.place = place_env && (B & 7) == 0;
+    const dim3 grid8((unsigned)(2 * B + grad_wgs));
+    // (keeping an utterance's chains and gradient items on one XCD was measured at cfg2: memory-side traffic 278 -> 223 MB
+    // and 2 us SLOWER -- eight utterance groups finish less evenly than 128 utterances spread over everything: not used)
+    a.place = 0;
     float* behind = ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3);
     a.park = ctc_park_floats(B, T) ? behind + (ctc_use_xc(B, T, C, max_len) ? (int64_t)B * T * kXcStride : 0) : nullptr;
     if (compact && ctc_use_xc(B, T, C, max_len)) {  // (wide rows: they use the compact gradient tile)

@@ -1309,10 +1309,7 @@ __global__ void __launch_bounds__(256, 2)
 template <int CP>
 constexpr int grad_stage() { return CP > 128 ? 8 : CP >= 104 ? 16 : 8; }  // (beyond 128 classes: up to nine waves per workgroup, fewer registers each)
 static int dense_chunks(int B, int T) {
-  static const int target = [] {
-    const char* e = getenv("WFL_DENSE_GRAD_WGS");  // (measurements) workgroups the gradient launch aims at
-    return e && atoi(e) > 0 ? atoi(e) : 512;
-  }();
+  constexpr int target = 512;  // workgroups the gradient launch aims at (768: 160 us, 1024: 155 us against 122 at cfg3)
   return std::max(1, std::min(T, (target + B - 1) / B));
 }
 
@@ -1398,11 +1395,7 @@ int wfl_dense_forward_parts(const float* x, const float* W, int B, int T, int C,
     const DenseWs w = dense_ws_carve(ws, B, T);
     const dim3 grid((unsigned)B, beta ? 2u : 1u);
     // (one 8-byte load per emission row where the rows are 8-byte aligned: see the helper wave)
-    static const bool pair_off = [] {
-      const char* e = getenv("WFL_DENSE_PAIR");  // (0: measurements)
-      return e && atoi(e) == 0;
-    }();
-    const bool pair = !pair_off && (C & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
+    const bool pair = (C & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
 #define WFL_FAST_CHAIN(CP)                                                                                              \
   do {                                                                                                                  \
     if (pair)                                                                                                           \

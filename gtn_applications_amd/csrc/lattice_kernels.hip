@@ -2978,17 +2978,11 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
         const char* e = getenv("WFL_LATTICE_FUSED_GRAD");
         return e ? atoi(e) : 1;
       }();
-      static const int fused_tile = [] {
-        const char* e = getenv("WFL_LATTICE_FUSED_TILE");
-        return e ? std::max(1, std::min(32, atoi(e))) : 32;
-      }();
+      constexpr int fused_tile = 32;  // frames per gradient job
       // persistent gradient workgroups per CU: as many as are resident at once (four waves of 130 VGPRs each: three per
       // CU).  More only queue behind those and start when the jobs are gone; measured at the Transducer benchmark with
       // the sweeps at 160 us: 2 -> 0.399 ms, 3 -> 0.362, 4 -> 0.364, 5 (the value until then) -> 0.369, 8 -> 0.37
-      static const int fused_wgs = [] {
-        const char* e = getenv("WFL_LATTICE_FUSED_WGS");
-        return e ? std::max(1, atoi(e)) : 3;
-      }();
+      constexpr int fused_wgs = 3;
       const char* bad_env = getenv("WFL_LATTICE_FUSED_BADXCD");
       uint32_t token = 0;
       int nt_o = 0;
@@ -3151,10 +3145,7 @@ static int lattice_grad_impl(const wfl_lattice_desc* d, const int32_t* ints, con
   int64_t tail;
   chain_config(*d, nt_chain, rpc);
   ab_tail(*d, T, tail, nch1);
-  static const size_t budget = [] {  // (WFL_GRAD_LDS_KB: tuning knob)
-    const char* e = getenv("WFL_GRAD_LDS_KB");
-    return (size_t)(e ? atoi(e) : 40) * 1024;
-  }();
+  constexpr size_t budget = 40 * 1024;  // LDS per workgroup that sizes the tiles
   int TS = fixed + row_bytes < budget ? (int)((budget - fixed) / row_bytes) : 1;
   TS = std::max(1, std::min(TS, 32));
   const size_t lds = fixed + row_bytes * TS;

@@ -574,7 +574,6 @@ namespace {
 class HostPool {
  public:
   explicit HostPool(int nthreads) : nworkers_(nthreads) {
-    if (const char* e = getenv("WFL_HOST_SPIN_US")) spin_ns_ = (long long)std::max(0, atoi(e)) * 1000;
     sem_init(&done_, 0, 0);
     for (int i = 0; i < nthreads; ++i) std::thread([this, i] { worker(i); }).detach();
   }
