@@ -66,7 +66,7 @@ VALU_F32_PEAK_TFLOPS = 157.3  # fp32 vector peak (MI355X_MICROARCH.md)
 
 # which kernels run inside each timed phase of engine.PHASE_EVENTS (short names as rocprofv3 reports them)
 PHASE_KERNEL_NAMES = {
-    "ctc_step": ["ctc_compact_x_kernel", "ctc_mitm_kernel", "ctc_fast_pipelined_kernel", "ctc_repair_kernel"],
+    "ctc_step": ["ctc_mitm_kernel", "ctc_repair_kernel"],
     "ctc_chains": ["ctc_log_chain_kernel"],
     "ctc_grad": ["reduce_loss_kernel", "ctc_grad_kernel"],
     "lattice_gather": ["gather_lse_kernel", "gather_kernel"],
@@ -79,8 +79,8 @@ PHASE_KERNEL_NAMES = {
     "dense_chain": ["dense_fast_chain_kernel", "dense_chain_kernel"],
     "dense_grad": ["dense_mfma_grad_kernel", "dense_fast_grad_kernel", "dense_grad_kernel", "dense_reduce_kernel"],
 }
-PHASE_KERNELS = {k: " + ".join(n for n in v if n != "ctc_compact_x_kernel") + (" (transitions graph)" if k.endswith("/shared") else "")
-                 for k, v in PHASE_KERNEL_NAMES.items()}  # (the compact pre-pass only runs for wide rows beyond the cache)
+PHASE_KERNELS = {k: " + ".join(v) + (" (transitions graph)" if k.endswith("/shared") else "")
+                 for k, v in PHASE_KERNEL_NAMES.items()}
 
 
 def parse():
@@ -240,7 +240,7 @@ def make_ctc(args, rank, n_batches, dist=None):
         """Duration of the meet-in-the-middle launch ALONE, measured on the device: the constant 100 MHz clock at the entry
         of every workgroup and at the exit of its last wave (workspace field WFL_CTC_WS_CLOCK; the HIP-event bracket of
         the step also holds the repair launch behind it).  Median over `reps` launches, each synchronised."""
-        if args.ctc_step != "pipelined" or C > 128 and os.environ.get("WFL_CTC_MITM_WIDE", "1") == "0":
+        if args.ctc_step != "pipelined":
             return None
         spans = []
         for _ in range(reps):
@@ -584,12 +584,6 @@ def main():
     else:
         wl = make_transducer(args, rank, n_batches)
     meta = wl["meta"]
-    if args.workload == "ctc":  # which launches the CTC step is at this row width (csrc/ctc_kernels.hip wfl_ctc_forward_backward)
-        legacy_wide = meta["C"] > 128 and os.environ.get("WFL_CTC_MITM_WIDE", "1") == "0"
-        names = (["ctc_compact_x_kernel", "ctc_fast_pipelined_kernel", "ctc_repair_kernel"] if legacy_wide
-                 else ["ctc_mitm_kernel", "ctc_repair_kernel"])
-        PHASE_KERNEL_NAMES["ctc_step"] = names
-        PHASE_KERNELS["ctc_step"] = " + ".join(names)
     if args.mode == "abi" and "abi_step" not in wl:
         raise SystemExit("--mode abi exists for --workload ctc only")
 

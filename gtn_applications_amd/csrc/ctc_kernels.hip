@@ -31,14 +31,15 @@
 // 4th digit of the posteriors at T = 1000).
 //
 // Kernels.  The training step (wfl_ctc_forward_backward) is ctc_mitm_kernel (ctc_mitm.h: the sweeps emit the gradient)
-// for targets of up to 63 labels, with ctc_fast_pipelined_kernel (chains + recomputing gradient waves in one launch)
-// behind it for the fused log_softmax criterion on rows wider than 128 classes; both run in lane-exponent
-// (probability-domain) arithmetic, every block certifies what it computed, and ctc_repair_kernel re-runs rejected
-// utterances with the log-domain bodies.  ctc_pipelined_kernel is the single launch with the log-domain bodies
+// for targets of up to 63 labels -- plain or with the fused log_softmax, rows of any width the entry point admits; it
+// runs in lane-exponent (probability-domain) arithmetic, every block certifies what it computed, and ctc_repair_kernel
+// re-runs rejected utterances with the log-domain bodies.  ctc_pipelined_kernel is the single launch with the log-domain bodies
 // throughout (WFL_CTC_PIPELINE=log, a step whose predecessor was mostly repaired), ctc_long_pipelined_kernel the one
 // for targets of 64-255 labels.  ctc_log_chain_kernel + ctc_grad_kernel (+ wfl_reduce_loss) are the forward-only /
 // three-launch path behind wfl_ctc_forward / wfl_ctc_grad.  (Retired in round 4: the standalone lane-exponent chain
-// launch with its certify kernel -- WFL_CTC_FAST_CHAIN -- and the dbg_* kernels.)
+// launch with its certify kernel -- WFL_CTC_FAST_CHAIN -- and the dbg_* kernels.  Retired in round 5: the round-2
+// lane-exponent launch whose gradient waves recomputed the blocks, ctc_fast_pipelined_kernel, with its compact
+// pre-pass and its switches WFL_CTC_MITM / _WIDE / _LSM.)
 #include <atomic>
 #include <string>
 #include <type_traits>
@@ -130,13 +131,10 @@ struct CtcArgs {
   // torch.nn.functional.log_softmax of ctc.py:107 (forward: subtracted at the gather; backward: the rows
   // start at -cf * softmax(x) because the posteriors of a frame sum to one)
   const float* row_lse;
-  // fast pipelined step, optional: xc[b][t][kXcStride] = the emissions the sweeps gather -- slot i = x[b][t][y_i]
-  // (target position i), slot L = x[b][t][blank] -- written by ctc_compact_x_kernel (see wfl_ctc_forward_backward)
+  // meet-in-the-middle launch, wide rows beyond the cache, optional: xc[b][t][kXcStride] = the emissions a sweep's first
+  // half gathered -- slot i = x[b][t][y_i] (target position i), slot L = x[b][t][blank] -- left there for the partner's
+  // second half (ctc_mitm.h, stagers)
   const float* xc;
-  int place;  // fast pipelined step: 1 = keep an utterance's chains and gradient items on one XCD (speed only)
-  // fast pipelined step with persistent gradient waves, optional: kParkStride floats per gradient wave, where a wave
-  // leaves the emission factors of its SECOND item before it starts waiting for the checkpoints of its first
-  float* park;
   // lane-exponent steps, optional: a word of pinned HOST memory where the repair launch leaves the number of utterances
   // it recomputed -- read by the NEXT call on this workspace, without a synchronisation (wfl_ctc_forward_backward)
   int32_t* host_repaired;
@@ -150,7 +148,6 @@ struct CtcArgs {
   int spin;
 };
 constexpr int kXcStride = 64;
-constexpr int kParkStride = 17 * 64;  // 16 frames x 64 lanes of factors + the per-lane reference word
 
 // ---- pieces shared by the chains of the pipelined launches -------------------------------------------
 __device__ __forceinline__ void coherent_store64(void* p, unsigned long long v) {
@@ -479,8 +476,7 @@ __global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST chains ("lane-exponent" arithmetic): the chains of ctc_fast_pipelined_kernel (ctc_mitm.h's chain wave runs the
-// same frame).
+// "Lane-exponent" arithmetic: the sweeps of the meet-in-the-middle launch (ctc_mitm.h).
 //
 // The log-domain frame is a chain of ~15 DEPENDENT instructions with 4 transcendentals (~155 cycles
 // for a lone wave).  Here a state is a float mantissa with an integer exponent PER LANE (shared by
@@ -499,19 +495,15 @@ __global__ void __launch_bounds__(192) ctc_log_chain_kernel(CtcArgs a, int only_
 // chain at 47 us (measured; scratch/ctc_kernels_fp64_chain.hip.txt).
 //
 // A lone wave is ISSUE-bound, not latency-bound (measured: ~4.5 cycles per VALU instruction whether
-// dependent or not), so the design minimises the chain wave's instruction count: wave 0 runs the
-// chain and nothing else; waves 1..kFHelpers stage whole blocks of factors (gather, NaN policy, the 16
-// per-frame maxima in one fold, exp2, blank broadcast) into an LDS ring; wave kFHelpers+1 turns the raw
-// (mantissa, exponent) checkpoints into the log2 format of the gradient kernels and writes them out.
-// No barrier inside the sweep: the waves meet in LDS mailboxes (ds_write / ds_read of a wave execute in
-// order, so "data, then flag" needs no wait).  Measured at cfg2: 33.5 us for the sweep (grid (B, 2))
-// against 68 us for the log-domain chain; inside the pipelined launch 36-39 us.
+// dependent or not), so the design minimises the chain wave's instruction count: one wave runs the
+// chain and nothing else; stager waves prepare whole blocks of factors (gather, NaN policy, the 16
+// per-frame maxima in one fold, exp2, blank broadcast) in an LDS ring; a flusher wave publishes the raw
+// (mantissa, exponent) checkpoints.  No barrier inside the sweep: the waves meet in LDS mailboxes (ds_write /
+// ds_read of a wave execute in order, so "data, then flag" needs no wait).
 //
 // What cannot be represented is flushed to zero or overflows; the results are certified: every gradient block
-// reproduces log2 Z and checks that the posteriors of its frames sum to one (ctc_fast_grad_body, ctc_mitm_emit_block);
+// reproduces log2 Z and checks that the posteriors of its frames sum to one (ctc_mitm_emit_block);
 // ctc_repair_kernel evaluates.
-// Checkpoints have the SAME format as the log-domain chain's (base-2 logs relative to a double offset), so
-// the gradient kernels do not care which chain produced them.
 // ------------------------------------------------------------------------------------------------
 constexpr int kGap = 5;       // max exponent drop from lane i-1 to lane i
 constexpr int kEmptyE = -(1 << 28);
@@ -630,26 +622,6 @@ __device__ __forceinline__ float fold16(const float (&v)[16], int lane) {
 }
 __device__ __forceinline__ float fold16_sum(const float (&v)[16], int lane) { return fold16<false>(v, lane); }
 
-constexpr int kFHelpers = 4;  // waves 1..4 stage emission factors (whole blocks, round robin); wave 5 flushes checkpoints
-constexpr int kFWaves = 8;    // workgroup of the fast kernels (waves 6, 7 of a chain workgroup leave at once).  Workgroup
-                              // shapes that are not a multiple of 4 waves do not spread evenly over the SIMDs (measured with
-                              // 5 waves: no additional workgroup became resident).
-constexpr int kFSlots = kFHelpers + 1;  // LDS ring depth in blocks (factors): the chain reads block kk+1 while the helpers stage
-                                        // kk+2 .. ; 40 KiB -- with the 51 KB of gradient rows at C = 100 three workgroups share a CU
-constexpr int kCkSlots = 8;   // depth of the checkpoint hand-off (and of the per-frame references the flusher sums)
-
-struct FastLdsT {
-  float2 ring[kFSlots][kBlk][64];  // (fb, fl) per frame and lane: 40 KiB
-  float fref[kCkSlots][kBlk];      // per-frame reference r_t (integer valued)
-  float2 ckm[kCkSlots][64];        // checkpoint hand-off chain wave -> flusher: mantissas ...
-  int cke[kCkSlots][64];           // ... and per-lane exponents
-  int staged[kFSlots];             // == n + 1 once block n sits in slot n % kFSlots
-  int consumed;                    // blocks the chain wave has loaded into registers
-  int ckready;                     // checkpoints handed over
-  int ckdone;                      // checkpoints the flusher has picked up
-  double offtot;                   // sum of all r_t
-};
-
 // LDS mailboxes between the waves of a workgroup.  DS instructions of a wave execute in issue order and
 // the LDS serves one instruction at a time, so "data, then flag" from the producer and "flag, then data"
 // from the consumer need no wait in between -- only the compiler has to keep the order.
@@ -663,315 +635,16 @@ __device__ __forceinline__ void lds_post(int* p, int v) {
   *(volatile lds_int_t*)(lds_int_t*)p = v;
 }
 
-// No barrier inside the sweep: every wave runs at its own pace.  Helper h owns blocks h, h+6, h+12, ...
-// entirely (16 gathers issued six chain blocks ahead of their use, one reference per FRAME), the chain
-// wave only multiplies and adds, and the flusher turns the raw (mantissa, exponent) checkpoints into
-// the log2 format of the gradient kernel.
-template <bool SIGNAL, bool LSM = false, bool XC = false>  // XC: emissions from the compact copy (CtcArgs::xc)
-__device__ __forceinline__ void ctc_fast_chain_body(const CtcArgs& a, int b, int dir, FastLdsT& S) {
-  // (wave index as a scalar: block numbers, frame numbers and row addresses of the helpers then live in SGPRs)
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int T = a.T, C = a.C, P = a.P;
-  const int64_t o0 = a.offsets[b];
-  const int L = (int)(a.offsets[b + 1] - o0);
-  int y = -1, yprev = -1;
-  if (lane < L) y = a.targets[o0 + (dir == 0 ? lane : L - 1 - lane)];
-  if (lane >= 1 && lane - 1 < L) yprev = a.targets[o0 + (dir == 0 ? lane - 1 : L - lane)];
-  const bool has_label = lane < L, has_blank = lane <= L;
-  const bool skip = has_label && lane >= 1 && y != yprev;
-  const float* xrow = a.x + (int64_t)b * T * C;
-  const int col = has_label ? y : a.blank;
-  // where this lane's emission of a frame comes from: its column of x, or its slot of the compact copy (the beta
-  // sweep's lanes hold the target mirrored).  A template parameter: the step's hot kernel is at its 80-register cap.
-  const float* esrc = XC ? a.xc + (int64_t)b * T * kXcStride : xrow;
-  const int estride = XC ? kXcStride : C;
-  const int eidx = XC ? (has_label ? (dir == 0 ? lane : L - 1 - lane) : L) : col;
-  const CtcWs w = ctc_ws_layout(a.B, T, P);
-  const int NB = ctc_blocks(T);
-  if (!SIGNAL && dir == 0 && threadIdx.x == 0) ((int32_t*)(a.ws + w.flag))[b] = 0;
-  if (SIGNAL && dir == 0 && threadIdx.x == 0) {  // certificate accumulators (before the first checkpoint is published)
-    long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
-    coherent_store64(zmm, (unsigned long long)(1ll << 62));
-    coherent_store64(zmm + 1, (unsigned long long)(-(1ll << 62) - 1));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  }
-  if (threadIdx.x < kFSlots) S.staged[threadIdx.x] = 0;
-  if (threadIdx.x == 0) S.consumed = 0, S.ckready = 0, S.ckdone = 0;
-  __syncthreads();
-  if (wave > kFHelpers + 1) return;  // (a wave that has ended no longer counts for the workgroup's barriers)
-
-  if (wave >= 1 && wave <= kFHelpers) {
-    // ---------------------------------------------------------------- helpers
-    float lse_raw = 0.f;
-    auto issue = [&](int n, float (&raw)[kBlk]) {
-      const int k = dir == 0 ? n : NB - 1 - n;
-      const int t0 = k * kBlk, cnt = min(kBlk, T - t0);
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j) {
-        const int t = dir == 0 ? t0 + j : t0 + cnt - 1 - j;
-        raw[j] = esrc[(int64_t)min(max(t, 0), T - 1) * estride + eidx];  // clamped: valid address, unused past the block
-      }
-      if (LSM) {
-        const int t = dir == 0 ? t0 + (lane & 15) : t0 + cnt - 1 - (lane & 15);
-        lse_raw = a.row_lse[(int64_t)b * T + min(max(t, 0), T - 1)];
-      }
-    };
-    auto stage = [&](int n, const float (&raw)[kBlk]) {
-      const int k = dir == 0 ? n : NB - 1 - n;
-      const int cnt = min(kBlk, T - k * kBlk);
-      const int slot = n % kFSlots;
-      float xs[kBlk];
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j) {
-        const float v = (LSM ? raw[j] - readlane_f(lse_raw, j) : raw[j]) * kLog2e;
-        xs[j] = (v == v) ? v : WFL_NEG_INF;  // NaN policy: impossible
-      }
-      // reference of frame j: its largest target-label emission, rounded (all 16 wave maxima in one fold;
-      // lane j < 16 of every row ends up with frame j's)
-      const float m = fold16<true>(xs, lane);
-      const float rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j) {
-        const float f = __builtin_amdgcn_exp2f(xs[j] - readlane_f(rr, j));
-        const float fb = readlane_f(f, L);
-        S.ring[slot][j][lane] = make_float2(has_blank ? fb : 0.f, has_label ? f : 0.f);
-      }
-      if (lane < kBlk) S.fref[n % kCkSlots][lane] = lane < cnt ? rr : 0.f;
-    };
-    const int h = wave - 1;
-    float raw[kBlk];
-    if (h < NB) issue(h, raw);
-    for (int n = h; n < NB; n += kFHelpers) {
-      // slot n % kFSlots held block n - kFSlots: free once the chain has it in registers and the flusher
-      // has taken its references
-      while ((n >= kFSlots && lds_peek(&S.consumed) < n - kFSlots + 1) || (n >= kCkSlots && lds_peek(&S.ckdone) < n - kCkSlots + 1))
-        __builtin_amdgcn_s_sleep(1);
-      stage(n, raw);
-      lds_post(&S.staged[n % kFSlots], n + 1);
-      if (n + kFHelpers < NB) issue(n + kFHelpers, raw);
-    }
-  } else if (wave == kFHelpers + 1) {
-    // ---------------------------------------------------------------- flusher
-    float2* ck = (float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + dir) * NB) * P;
-    double* offs = (double*)(a.ws + w.off) + (int64_t)(b * 2 + dir) * NB;
-    unsigned long long* ready = (unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + dir) * NB;
-    constexpr int kLag = 4;  // checkpoints between a store and the flag that vouches for it (3 * kLag <= 63: vmcnt is 6 bits)
-    double offcum = 0.0;  // sum of r_t over the blocks before the checkpoint
-    if (SIGNAL && dir == 0) {
-      // which target labels own their gradient column (occur once, are not the blank): one mask per utterance for
-      // all its gradient waves, stored before the first checkpoint (acknowledged before any flag is raised)
-      bool dupl = false;
-      int own = lane;  // lane of the label's first occurrence: the slot of its column in the compact gradient tile
-      for (int j = 0; j < L; ++j) {
-        const bool same = __builtin_amdgcn_readlane(y, j) == y;
-        dupl = dupl || (same && j != lane);
-        if (same && j < own) own = j;
-      }
-      dupl = has_label && (dupl || y == a.blank);
-      if (y == a.blank) own = 63;  // (a target label equal to the blank index shares the blank's slot)
-      __hip_atomic_store((int32_t*)(a.ws + w.own) + (int64_t)b * 64 + lane, own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long mask = __builtin_amdgcn_ballot_w64(dupl);
-      // bit 63 (no label lives in lane 63): the target cannot be aligned at all -- T < L + adjacent repeats.  Such an
-      // utterance has Z = 0 exactly, in any arithmetic: loss inf, zero gradient, nothing for the certificate to doubt
-      const int repeats = __builtin_popcountll(__builtin_amdgcn_ballot_w64(has_label && lane >= 1 && y == yprev));
-      if (T < L + repeats) mask |= 1ull << 63;
-      if (lane == 0) coherent_store64((unsigned long long*)(a.ws + w.dup) + b, mask);
-    }
-    for (int kk = 0; kk < NB; ++kk) {
-      while (lds_peek(&S.ckready) < kk + 1) __builtin_amdgcn_s_sleep(1);
-      asm volatile("" ::: "memory");
-      const float2 m = S.ckm[kk % kCkSlots][lane];
-      const int e = S.cke[kk % kCkSlots][lane];
-      const float rj = lane < kBlk ? S.fref[kk % kCkSlots][lane] : 0.f;
-      lds_post(&S.ckdone, kk + 1);
-      // checkpoint = state BEFORE block kk, as base-2 logs relative to a wave-uniform exponent
-      const int emax = __builtin_amdgcn_readlane(wave_prefix_max_i(e), 63);
-      const float de = (float)(e - emax);
-      const float lb = m.x > 0.f ? __builtin_amdgcn_logf(m.x) + de : kNegBig;
-      const float ll = m.y > 0.f ? __builtin_amdgcn_logf(m.y) + de : kNegBig;
-      const double offk = offcum + (double)(emax > kEmptyE ? emax : 0);
-      if (!SIGNAL) {
-        if (lane < P) ck[(int64_t)kk * P + lane] = make_float2(lb, ll);
-        if (lane == 0) offs[kk] = offk;
-      } else {
-        // Device-coherent stores (see ctc_log_chain_body), but this wave cannot afford to wait for the
-        // acknowledgement of every checkpoint: a block of the fast chain is shorter than a store round
-        // trip.  The flag of checkpoint kk - kLag is raised once everything older than the last
-        // 3 * kLag vector-memory instructions has been acknowledged (stores are acknowledged in issue
-        // order; EXACTLY three are issued per iteration -- before the first kLag iterations the third one
-        // writes "not ready" to the block's own flag).
-        const float2 v = make_float2(lb, ll);
-        unsigned long long bits, obits;
-        __builtin_memcpy(&bits, &v, 8);
-        __builtin_memcpy(&obits, &offk, 8);
-        float2* dst = &ck[(int64_t)kk * P + lane];
-        if (lane < P) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(bits) : "memory");
-        if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(&offs[kk]), "v"(obits) : "memory");
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kLag) : "memory");
-        const int pub = kk - kLag;
-        unsigned long long* fl = &ready[pub >= 0 ? pub : kk];
-        const unsigned long long val = pub >= 0 ? a.token : 0ull;
-        if (lane == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(fl), "v"(val) : "memory");
-      }
-      offcum += (double)wave_all_sum(rj);
-    }
-    if (SIGNAL) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        for (int kk = max(NB - kLag, 0); kk < NB; ++kk) coherent_store64(&ready[kk], a.token);
-    }
-    if (lane == 0) S.offtot = offcum;
-  } else if (wave == 0) {
-    // ---------------------------------------------------------------- the chain
-    __builtin_amdgcn_s_setprio(3);  // issue-bound: wins the arbitration against the helper wave on its SIMD
-    float pb = (lane == 0) ? 1.f : 0.f;  // virtual slot "before the first frame": only state 0 alive
-    float pl = 0.f;
-    int e = 0;
-    float g = 0.f, gs = 0.f;
-    bool had = false, bad = false;
-    // per-lane power-of-two renormalisation, neighbour-gap clamp, coupling factors for the interval
-    auto lane_renorm = [&]() {
-      const float mx = vmax(pb, pl);
-      bad = bad || !(mx < 3.0e38f);
-      const int k = __builtin_amdgcn_frexp_expf(mx);  // 0 for mx == 0
-      const int own = mx > 0.f ? e + k : kEmptyE;
-      const int pre = wave_prefix_max_i(own + kGap * lane) - kGap * lane;  // >= e[i-1] - kGap (transitively)
-      const int sh = mx > 0.f ? pre - own : 0;                            // >= 0: pulled up by the clamp
-      pb = ldexpf(pb, -(k + min(sh, 200)));  // (mantissa to [0.5, 1), then down by the clamp: one scaling)
-      pl = ldexpf(pl, -(k + min(sh, 200)));
-      e = pre;
-      const int d = wave_shr1_i(e, e) - e;  // <= kGap by construction
-      g = lane == 0 ? 0.f : ldexpf(1.f, max(d, -200));
-      gs = skip ? g : 0.f;
-      had = vmax(pb, pl) > 0.f;
-    };
-    // pb' = fb (pb + g q), pl' = fl (pl + pb + gs q) with q = pl of lane i-1, arranged so that only TWO
-    // dependent instructions separate pl' from pl (the DPP multiply-add and the final fma): the products
-    // with pb and the coefficient products do not depend on the newest pl
-    auto frame = [&](const float2 f) {
-      const float c0 = f.x * g, c1 = f.y * gs;
-      float t0 = f.x * pb, t1 = f.y * pb;
-      fmac2_shr1(t0, t1, pl, c0, c1);
-      pl = fmaf(f.y, pl, t1);
-      pb = t0;
-    };
-    // Four frames in FIVE instructions each (the wave is issue-bound: ~4.5 cycles per VALU instruction whether
-    // dependent or not): packed multiplies for the two coefficient products and the two pb products, the two
-    // DPP multiply-adds, and the fma that adds fl * pl.  State pair P = (pb, pl) and the running pair t swap
-    // roles every frame; they are pinned to v[2:3] / v[4:5] because the template has to name their halves.
-    // The two packed multiplies between the write of pl and its DPP read are the required wait states.
-    typedef float v2f __attribute__((ext_vector_type(2)));
+// The five-instruction frame of the lane-exponent arithmetic (ctc_mitm.h): packed multiplies for the two coefficient
+// products and the two pb products, the two DPP multiply-adds, and the fma that adds fl * pl.  State pair P = (pb, pl)
+// and the running pair TT swap roles every frame; the two packed multiplies between the write of pl and its DPP read
+// are the required wait states.  v[6:7] are scratch.
 #define WFL_FRAME(P, PH, TT, TL, TH, F, FY)                                   \
   "v_pk_mul_f32 v[6:7], " F ", %[G]\n\t"                                      \
   "v_pk_mul_f32 " TT ", " F ", " P " op_sel_hi:[1,0]\n\t"                     \
   "v_fmac_f32_dpp " TL ", " PH ", v6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
   "v_fmac_f32_dpp " TH ", " PH ", v7 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
   "v_fmac_f32 " TH ", " FY ", " PH "\n\t"
-    auto frames4 = [&](const float2& f0, const float2& f1, const float2& f2, const float2& f3) {
-      v2f P = {pb, pl};
-      const v2f G = {g, gs};
-      const v2f F0 = {f0.x, f0.y}, F1 = {f1.x, f1.y}, F2 = {f2.x, f2.y}, F3 = {f3.x, f3.y};
-      asm volatile(WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F0]", "%[Y0]")
-                   WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F1]", "%[Y1]")
-                   WFL_FRAME("v[2:3]", "v3", "v[4:5]", "v4", "v5", "%[F2]", "%[Y2]")
-                   WFL_FRAME("v[4:5]", "v5", "v[2:3]", "v2", "v3", "%[F3]", "%[Y3]")
-                   : "+{v[2:3]}"(P)
-                   : [G] "v"(G), [F0] "v"(F0), [F1] "v"(F1), [F2] "v"(F2), [F3] "v"(F3), [Y0] "v"(f0.y), [Y1] "v"(f1.y),
-                     [Y2] "v"(f2.y), [Y3] "v"(f3.y)
-                   : "v4", "v5", "v6", "v7");
-      pb = P.x;
-      pl = P.y;
-    };
-    // The factors travel ring -> registers in HALF blocks (two sets of 8 float2, alternating: no copies and half the
-    // registers of whole blocks -- the kernel's register count decides how many gradient workgroups share the CU).
-    constexpr int kHalf = kBlk / 2;
-    float2 ha[kHalf], hb[kHalf];
-    while (lds_peek(&S.staged[0]) != 1) {
-    }
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < kHalf; ++j) ha[j] = S.ring[0][j][lane];
-    int nflag = NB > 1 ? lds_peek(&S.staged[1]) : 0;  // looked at one block ahead of its use: off the dependent path
-    int done_seen = 0;
-    // q: half-block index (block q / 2, frames (q & 1) * 8 ...)
-    // STEADY: an interior block (complete, followed by another one) -- the bulk of the sweep runs without the
-    // boundary tests (a uniform branch costs the lone wave more than an arithmetic instruction)
-    auto half = [&](int q, const float2 (&fcur)[kHalf], float2 (&fnxt)[kHalf], auto steady) {
-      constexpr bool STEADY = decltype(steady)::value;
-      const int kk = q >> 1, second = q & 1;
-      const int k = dir == 0 ? kk : NB - 1 - kk;
-      const int n = STEADY ? kHalf : min(kBlk, T - k * kBlk) - second * kHalf;  // frames of this half that exist (may be <= 0)
-      if (second) {
-        // the next half opens block kk + 1: it has to be staged
-        if (STEADY || kk + 1 < NB) {
-          if (nflag != kk + 2)
-            while (lds_peek(&S.staged[(kk + 1) % kFSlots]) != kk + 2) {
-            }
-          asm volatile("" ::: "memory");
-          if (STEADY || kk + 2 < NB) nflag = lds_peek(&S.staged[(kk + 2) % kFSlots]);
-          done_seen = lds_peek(&S.ckdone);
-#pragma unroll
-          for (int j = 0; j < kHalf; ++j)
-            fnxt[j] = S.ring[(kk + 1) % kFSlots][j][lane];
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < kHalf; ++j)
-          fnxt[j] = S.ring[kk % kFSlots][kHalf + j][lane];
-        lds_post(&S.consumed, kk + 1);  // (after the reads were issued: LDS executes a wave's instructions in order)
-        lane_renorm();
-        if (kk >= kCkSlots && done_seen < kk - kCkSlots + 1)
-          while (lds_peek(&S.ckdone) < kk - kCkSlots + 1) {
-          }
-        S.ckm[kk % kCkSlots][lane] = make_float2(pb, pl);
-        S.cke[kk % kCkSlots][lane] = had ? e : kEmptyE;
-        lds_post(&S.ckready, kk + 1);
-      }
-      if (n >= kHalf) {
-#pragma unroll
-        for (int j = 0; j < kHalf; j += 4) frames4(fcur[j], fcur[j + 1], fcur[j + 2], fcur[j + 3]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < kHalf; ++j)
-          if (j < n) frame(fcur[j]);
-      }
-    };
-    {
-      half(0, ha, hb, std::false_type{});
-      half(1, hb, ha, std::false_type{});
-      int kk = 1;
-      for (; kk + 2 < NB; ++kk) {  // blocks 1 .. NB-3: complete for both directions, two more blocks follow
-        half(2 * kk, ha, hb, std::true_type{});
-        half(2 * kk + 1, hb, ha, std::true_type{});
-      }
-      for (; kk < NB; ++kk) {
-        half(2 * kk, ha, hb, std::false_type{});
-        half(2 * kk + 1, hb, ha, std::false_type{});
-      }
-    }
-    lane_renorm();
-    __syncthreads();  // the flusher has summed all references
-    if (lane == 0) ((int32_t*)(a.ws + w.pbad))[b * 2 + dir] = bad ? 1 : 0;
-    if (dir == 0) {
-      // Z = alpha_{T-1}[2L] + alpha_{T-1}[2L-1]   (ctc.py:21 accept states), lanes L and L-1
-      const float zb = readlane_f(pb, L);
-      const float zl = L > 0 ? readlane_f(pl, L - 1) : 0.f;
-      const int eb = __builtin_amdgcn_readlane(e, L);
-      const int el = L > 0 ? __builtin_amdgcn_readlane(e, L - 1) : kEmptyE;
-      if (lane == 0) {
-        const int em = max(zb > 0.f ? eb : kEmptyE, zl > 0.f ? el : kEmptyE);
-        const float s = (zb > 0.f ? ldexpf(zb, max(eb - em, -200)) : 0.f) + (zl > 0.f ? ldexpf(zl, max(el - em, -200)) : 0.f);
-        const bool ok = s > 0.f && s < 3.0e38f;
-        const double z2 = ok ? (double)__builtin_amdgcn_logf(s) + (double)em + S.offtot : -1.0e300;
-        ((double*)(a.ws + w.z2))[b] = z2;
-        publish_nll<SIGNAL, false>(a, w, b, ok, z2);
-      }
-      if (SIGNAL && a.loss_out && b == 0) reduce_loss_when_done(a, w, lane, false);
-    }
-    return;
-  }
-  __syncthreads();
-}
 
 // ------------------------------------------------------------------------------------------------
 // gradient: one wave per (utterance, 16-frame block), 4 waves per workgroup
@@ -1312,304 +985,6 @@ __device__ __forceinline__ void fmac2_shl1(float& acc, float s0, float s1, float
       : "v"(s0), "v"(s1), "v"(c0), "v"(c1));
 }
 
-// ------------------------------------------------------------------------------------------------
-// Gradient of one 16-frame block in lane-exponent arithmetic (the fast pipelined launch).  The
-// log-domain block (ctc_grad_body) costs ~2500 instructions, 160 of them transcendentals, and the
-// gradient part of the launch is bound by VALU issue; here the two sweeps are multiply-adds like the
-// chain's (the block is exactly what the chain runs between two of its renormalisations: same
-// per-lane exponents with the same neighbour clamp, same per-frame references, same growth bound).
-// Everything that does not depend on the checkpoints -- gathers, references, the 16 exp2 per lane --
-// is done BEFORE the wave starts waiting for them.
-//   alpha_j(s) = ma_j(s) 2^ea(s), beta~_j(s) = mb_j(s) 2^eb(s), exponents fixed over the block;
-//   Z_local = sum_s alpha_{n-1}(s) [A beta~_n](s)  (relative to the checkpoints' offsets and the
-//   block's references); posterior = ma mb' K(s) with K(s) = 2^(ea + eb - E) / Zm folded into ma.
-// ------------------------------------------------------------------------------------------------
-// Emission factors of one block's frames for the lane's column: f_j = 2^(x log2e - r_j), r_j = round(largest
-// target-label score of frame j) -- rr holds r_j in the lanes with (lane & 15) == j.
-template <bool LSM>
-__device__ __forceinline__ void fast_block_factors(const float* __restrict__ esrc, int estride, int eidx, int t0, int n, int T,
-                                                   float lse_blk, int lane, float (&f)[kBlk], float& rr) {
-#pragma unroll
-  for (int j = 0; j < kBlk; ++j) f[j] = esrc[(int64_t)min(t0 + j, T - 1) * estride + eidx];  // all 16 gathers in flight
-#pragma unroll
-  for (int j = 0; j < kBlk; ++j) {
-    const float v = (LSM ? f[j] - readlane_f(lse_blk, j) : f[j]) * kLog2e;
-    f[j] = (v == v && j < n) ? v : WFL_NEG_INF;  // NaN policy: impossible
-  }
-  const float m = fold16<true>(f, lane);  // lane j < 16 (every row): the maximum of frame j
-  rr = (m > -3.0e38f && m < 3.0e38f) ? rintf(m) : 0.f;
-#pragma unroll
-  for (int j = 0; j < kBlk; ++j) f[j] = __builtin_amdgcn_exp2f(f[j] - readlane_f(rr, j));
-}
-
-// A persistent gradient wave has nothing to do until the checkpoints of its first item exist (half the chain time
-// at the earliest) and is then busy to the end of the launch: it computes the factors of its SECOND item -- gathers,
-// references, exp2: a third of an item -- in that idle time and leaves them in its slot of a.park.
-template <bool LSM, bool XC>
-__device__ __forceinline__ void ctc_fast_park_factors(const CtcArgs& a, int b, int k, float* __restrict__ park) {
-  const int lane = threadIdx.x & 63;
-  const int T = a.T, t0 = k * kBlk, n = min(kBlk, T - t0);
-  const int64_t o0 = a.offsets[b];
-  const int L = (int)(a.offsets[b + 1] - o0);
-  const int col = lane < L ? a.targets[o0 + lane] : a.blank;
-  const float* esrc = XC ? a.xc + (int64_t)b * T * kXcStride : a.x + (int64_t)b * T * a.C;
-  float lse_blk = 0.f;
-  if (LSM) lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
-  float f[kBlk], rr;
-  fast_block_factors<LSM>(esrc, XC ? kXcStride : a.C, XC ? (lane < L ? lane : L) : col, t0, n, T, lse_blk, lane, f, rr);
-#pragma unroll
-  for (int j = 0; j < kBlk; ++j) park[j * 64 + lane] = f[j];
-  park[kBlk * 64 + lane] = rr;
-}
-
-// what a gradient wave keeps of its utterance from one item to the next (a persistent wave's items belong to one
-// utterance whenever the stride is a multiple of the batch)
-struct FastUtt {
-  int b = -1, L = 0, y = -1, yprev = -1, ynext = -1;
-  float cf = 0.f;
-};
-
-template <bool LSM, bool CERT, bool COMPACT = false, bool XC = false>
-__device__ __forceinline__ void ctc_fast_grad_body(const CtcArgs& a, bool valid, int b, int k, const float* __restrict__ coef,
-                                                   const float* __restrict__ gout, float* __restrict__ dx, char* smem,
-                                                   FastUtt& u, const float* __restrict__ parked = nullptr) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int T = a.T, C = a.C, P = a.P;
-  const int NB = ctc_blocks(T);
-  const CtcWs w = ctc_ws_layout(a.B, T, P);
-  if (!valid) return;  // (uniform over the wave)
-  // ---- first, what needs a round trip and depends on nothing: the two flags, the parked factors, the utterance
-  const unsigned long long* ra = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 0) * NB + k;
-  const unsigned long long* rb = (const unsigned long long*)(a.ws + w.ready) + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k);
-  const unsigned long long seen_a = __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long seen_b = __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  float xs[kBlk], rr = 0.f;  // emission factors of the block's frames (this lane's column), per-frame references
-  if (parked) {  // (uniform) this wave computed them while it waited for its first item: ctc_fast_park_factors
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j) xs[j] = parked[j * 64 + lane];
-    rr = parked[kBlk * 64 + lane];
-  }
-  if (u.b != b) {  // (uniform)
-    const int64_t o0 = a.offsets[b];
-    u.L = (int)(a.offsets[b + 1] - o0);
-    u.y = lane < u.L ? a.targets[o0 + lane] : -1;
-    u.yprev = (lane >= 1 && lane - 1 < u.L) ? a.targets[o0 + lane - 1] : -1;
-    u.ynext = lane + 1 < u.L ? a.targets[o0 + lane + 1] : -1;
-    u.cf = (coef ? coef[b] : 1.f) * (gout ? gout[0] : 1.f);
-    u.b = b;
-  }
-  // Gradient rows of the wave: the dense LDS tile [16][C] (scattered into, copied out in one piece) for narrow rows,
-  // the COMPACT tile + column map (see compact_expand) for wide ones.
-  char* wbase = smem + (size_t)wave * (COMPACT ? compact_wave_bytes(C) : (size_t)kBlk * C * 4);
-  float* rows = (float*)wbase;
-  unsigned char* cmap = (unsigned char*)(wbase + (size_t)kCTileBytes);  // (COMPACT only)
-  const int t0 = k * kBlk, n = min(kBlk, T - t0);
-  const float cf = u.cf;
-  float lse_blk = 0.f;  // lane j < 16: log-sum-exp of frame t0 + j
-  if (COMPACT)
-    compact_init(rows, cmap, C, lane);
-  else
-    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
-  if (LSM) {
-    lse_blk = a.row_lse[(int64_t)b * T + min(t0 + (lane & 15), T - 1)];
-    if (!COMPACT) lsm_seed_rows(rows, a.x + ((int64_t)b * T + t0) * C, n, C, lse_blk, cf, lane);
-  }
-  const int L = u.L, y = u.y, yprev = u.yprev, ynext = u.ynext;
-  const bool has_label = lane < L;
-  const bool skip = has_label && lane >= 1 && y != yprev;  // label i-1 -> label i
-  const bool skipn = lane + 1 < L && ynext != y;           // label i -> label i+1
-  const int col = has_label ? y : a.blank;
-  const float* xrow = a.x + (int64_t)b * T * C;
-  const float* esrc = XC ? a.xc + (int64_t)b * T * kXcStride : xrow;  // (see ctc_fast_chain_body)
-  const int estride = XC ? kXcStride : C;
-  const int eidx = XC ? (has_label ? lane : L) : col;
-
-  // ---- the two checkpoints: a block of a later round finds them published when it starts -- their loads then
-  // travel together with the gathers instead of after them
-  auto flags_up = [&]() {
-    return __hip_atomic_load(ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token &&
-           __hip_atomic_load(rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.token;
-  };
-  float2 ca = make_float2(kNegBig, kNegBig);
-  float cbb = kNegBig, cbl = kNegBig;
-  double off_sum = 0.0;
-  unsigned long long dupmask = 0;
-  auto load_checkpoints = [&]() {
-    const float2* cka = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 0) * NB) * P;
-    const float2* ckb = (const float2*)(a.ws + w.ck) + ((int64_t)(b * 2 + 1) * NB) * P;
-    const double* offa = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 0) * NB;
-    const double* offb = (const double*)(a.ws + w.off) + (int64_t)(b * 2 + 1) * NB;
-    auto load_ck = [&](const float2* p) {
-      const unsigned long long bits = coherent_load64(p);
-      float2 v;
-      __builtin_memcpy(&v, &bits, 8);
-      return v;
-    };
-    // (mirrored lanes of the beta sweep: blank state 2i <-> reversed position L-i; label of position i <-> L-1-i)
-    if (lane < P) ca = load_ck(&cka[(int64_t)k * P + lane]);
-    if (lane <= L) cbb = load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - lane)]).x;
-    if (lane < L) cbl = load_ck(&ckb[(int64_t)(NB - 1 - k) * P + (L - 1 - lane)]).y;
-    if (CERT && lane == 0) off_sum = coherent_load_f64(&offa[k]) + coherent_load_f64(&offb[NB - 1 - k]);
-    dupmask = coherent_load64((const unsigned long long*)(a.ws + w.dup) + b);
-  };
-  const bool early = seen_a == a.token && seen_b == a.token;  // (uniform)
-  if (early) load_checkpoints();
-
-  // ---- emission factors of the block's frames: f = 2^(x log2e - r_j), r_j = round(largest target-label score)
-  float fl[kBlk], fb[kBlk];
-  float rsum;
-  {
-    if (!parked) fast_block_factors<LSM>(esrc, estride, eidx, t0, n, T, lse_blk, lane, xs, rr);
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j) {
-      fb[j] = readlane_f(xs[j], L);
-      fl[j] = has_label ? xs[j] : 0.f;
-    }
-    rsum = wave_all_sum(lane < n ? rr : 0.f);
-  }
-
-  // ---- wait for alpha checkpoint k and beta checkpoint NB-1-k (see ctc_grad_body), unless they were there already
-  if (!early) {
-    int ok = 0;
-    for (int spin = 0; spin < (1 << 20); ++spin) {  // (bounded: a lost signal must not hang the GPU)
-      ok = flags_up();
-      if (ok) break;
-      __builtin_amdgcn_s_sleep(16);
-    }
-    if (!ok) {
-      if (lane == 0) atomicOr((int32_t*)(a.ws + w.perr), 1);
-      __builtin_trap();
-    }
-    load_checkpoints();
-  }
-  // labels that occur once in the target (and are not the blank) own their gradient column: plain ds_write instead
-  // of ds_add_f32 (see ctc_grad_body); the mask was computed once per utterance by its alpha chain workgroup
-  const bool dup = has_label && ((dupmask >> lane) & 1ull) != 0;
-  const bool uniq = has_label && !dup;
-  int slot = lane;  // COMPACT: where this lane's label accumulates
-  if (COMPACT) {
-    slot = __hip_atomic_load((const int32_t*)(a.ws + w.own) + (int64_t)b * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (has_label && slot == lane) cmap[y] = (unsigned char)lane;  // (first occurrences only: one writer per column)
-    if (lane == 0) cmap[a.blank] = 63;
-  }
-  if (lane == 0) {  // this wave was the only consumer of the two flags: leave them cleared
-    unsigned long long* rdy = (unsigned long long*)(a.ws + w.ready);
-    coherent_store64(rdy + (int64_t)(b * 2 + 0) * NB + k, 0ull);
-    coherent_store64(rdy + (int64_t)(b * 2 + 1) * NB + (NB - 1 - k), 0ull);
-  }
-
-  // ---- per-lane exponents (neighbour-gap clamp as in the chain), mantissas, coupling factors
-  const float ma = vmax(ca.x, ca.y), mbt = vmax(cbb, cbl);
-  int ea = ma > 0.5f * kNegBig ? (int)floorf(ma) + 1 : kEmptyE;
-  ea = wave_prefix_max_i(ea + kGap * lane) - kGap * lane;  // ea[i] >= ea[i-1] - kGap
-  int eb = mbt > 0.5f * kNegBig ? (int)floorf(mbt) + 1 : kEmptyE;
-  {  // eb[i] >= eb[i+1] - kGap: the same scan on the reversed lanes
-    int er = __shfl(eb, 63 - lane, 64);
-    er = wave_prefix_max_i(er + kGap * lane) - kGap * lane;
-    eb = __shfl(er, 63 - lane, 64);
-  }
-  float pb = __builtin_amdgcn_exp2f(ca.x - (float)ea), pl = __builtin_amdgcn_exp2f(ca.y - (float)ea);
-  float bb = __builtin_amdgcn_exp2f(cbb - (float)eb), bl = __builtin_amdgcn_exp2f(cbl - (float)eb);
-  const int ea_prev = wave_shr1_i(ea, ea);  // (taken unconditionally: inside the ?: the DPP would run with lane 0 masked off)
-  const float g = lane == 0 ? 0.f : ldexpf(1.f, max(ea_prev - ea, -200));
-  const float gs = skip ? g : 0.f;
-  const int eb_next = __builtin_amdgcn_update_dpp(eb, eb, 0x130, 0xf, 0xf, false);  // wave_shl:1 (lane 63: own)
-  const float h = lane == 63 ? 0.f : ldexpf(1.f, max(eb_next - eb, -200));
-  const float hs = skipn ? h : 0.f;
-
-  // ---- alpha forward through the block, kept in registers
-  float pa_b[kBlk], pa_l[kBlk];
-#pragma unroll
-  for (int j = 0; j < kBlk; ++j) {
-    if (j < n) {
-      const float c0 = fb[j] * g, c1 = fl[j] * gs;
-      float u0 = fb[j] * pb, u1 = fl[j] * pb;
-      fmac2_shr1(u0, u1, pl, c0, c1);
-      pl = fmaf(fl[j], pl, u1);
-      pb = u0;
-    }
-    pa_b[j] = pb, pa_l[j] = pl;
-  }
-  // ---- local Z at the block's last frame
-  float K = 0.f;
-  bool alive;
-  double zk;  // (lane 0) log2 Z as this block reproduces it
-  {
-    const float tb0 = bb + bl;
-    float tl0 = bl;
-    fmac2_shl1(tl0, bb, bl, h, hs);
-    const float v = pb * tb0 + pl * tl0;  // (pb, pl): alpha of frame n-1
-    const int sx = ea + eb;
-    const int own = v > 0.f ? sx + __builtin_amdgcn_frexp_expf(v) : kEmptyE;
-    const int E = __builtin_amdgcn_readlane(wave_prefix_max_i(own), 63);
-    const float term = v > 0.f ? ldexpf(v, max(sx - E, -200)) : 0.f;
-    const float Zm = wave_all_sum(term);
-    alive = Zm > 0.f && Zm < 3.0e38f && E > kEmptyE;
-    // (exponent clamped from above too: a lane whose alpha beta is ~0 at the last frame may sit far above E;
-    // if that distorts a posterior that matters, the per-frame sum check below rejects the block)
-    if (alive) K = cf * ldexpf(1.f / Zm, min(max(sx - E, -200), 100));
-    zk = alive ? off_sum + (double)E + (double)__builtin_amdgcn_logf(Zm) + (double)rsum : -1.0e300;
-  }
-  // ---- beta backwards (forward lane mapping), posteriors, gradient rows
-  float gbv[kBlk];
-  float wsum = 0.f;  // sum_j w_j (gb + gl)[j], w_j = 1 + j / 32: the frames' posterior mass, weighted so that errors cannot cancel
-#pragma unroll
-  for (int j = 0; j < kBlk; ++j) gbv[j] = 0.f;
-#pragma unroll
-  for (int j = kBlk - 1; j >= 0; --j) {
-    if (j < n) {
-      // blank i -> blank i, label i.  label i -> label i, blank i+1 (and label i+1 if allowed)
-      const float tb = bb + bl;
-      float tl = bl;
-      fmac2_shl1(tl, bb, bl, h, hs);
-      const float gb = pa_b[j] * K * tb;
-      const float gl = pa_l[j] * K * tl;
-      gbv[j] = gb;
-      wsum = fmaf(gb + gl, 1.f + (float)j * (1.f / 32.f), wsum);
-      if (COMPACT) {
-        if (uniq) rows[j * kCS + lane] = gl;
-        if (dup && gl != 0.f) atomicAdd(&rows[j * kCS + slot], gl);
-      } else {
-        if (uniq) rows[j * C + y] = (LSM ? rows[j * C + y] : 0.f) + gl;  // sole writer of this column
-        if (dup && gl != 0.f) atomicAdd(&rows[j * C + y], gl);
-      }
-      bb = tb * fb[j];
-      bl = tl * fl[j];
-    }
-  }
-  const float gtot = fold16_sum(gbv, lane);  // lane l < 16: blank posterior of frame l
-  if (lane < n && gtot != 0.f) atomicAdd(&rows[COMPACT ? lane * kCS + 63 : lane * C + a.blank], gtot);
-  if (CERT) {
-    // certificate, part two: the posteriors of every frame of the block must sum to one (the exponents are fixed
-    // over the block; an occupancy that moves by more than the float range within 16 frames shows here; the
-    // frames are summed with distinct weights, one register instead of sixteen), part one: the block's log2 Z
-    // for the comparison with the chain's
-    const float stot = wave_all_sum(wsum);
-    const float want = cf * ((float)n + (float)(n * (n - 1)) * (1.f / 64.f));  // cf * sum_{j<n} w_j
-    const bool bad_block = alive && !(fabsf(stot - want) <= 2e-4f * fabsf(cf));
-    if (lane == 0) {
-      long long* zmm = (long long*)(a.ws + w.zloc) + (int64_t)b * 2;
-      const long long zq = bad_block ? kZDead : z_fixed(zk);
-      __hip_atomic_fetch_min(zmm, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_max(zmm + 1, zq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  if (LSM && !alive && !COMPACT)  // no accepting path: zero gradient, softmax term included
-    for (int i = lane; i < kBlk * C; i += 64) rows[i] = 0.f;
-  // (rows are private to the wave: LDS operations of one wave complete in order, no barrier needed)
-  float* dst = dx + ((int64_t)b * T + t0) * C;
-  if (COMPACT)
-    compact_expand(rows, cmap, dst, a.x + ((int64_t)b * T + t0) * C, lse_blk, n, C, cf, alive, LSM && alive, lane);
-  const int total = COMPACT ? 0 : n * C;
-  if ((((uintptr_t)dst) & 15) == 0) {
-    const int n4 = total >> 2;
-    for (int i = lane; i < n4; i += 64) ((float4*)dst)[i] = ((const float4*)rows)[i];
-    for (int i = (n4 << 2) + lane; i < total; i += 64) dst[i] = rows[i];
-  } else {
-    for (int i = lane; i < total; i += 64) dst[i] = rows[i];
-  }
-}
-
 template <bool COMPACT>
 __global__ void __launch_bounds__(256)
     ctc_grad_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dx) {
@@ -1656,97 +1031,6 @@ __global__ void __launch_bounds__(256)
   const int k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
   ctc_grad_body<true, LSM, COMPACT>(a, valid, b, k, coef, gout, dx, smem);
 }
-
-// ------------------------------------------------------------------------------------------------
-// Compact copy of the emissions the sweeps gather (wide rows, inputs beyond the Infinity Cache): one pass over x
-// leaves, per frame, the <= 64 scores the alpha chains, the beta chains and the gradient blocks each gather --
-// three passes over x (a 45-label gather touches three quarters of the lines of a 2-KB row) become one, the other
-// two read 256 contiguous bytes per frame.  One wave per row, kXcRows rows per iteration with their loads in flight.
-// ------------------------------------------------------------------------------------------------
-constexpr int kXcRows = 8;
-__global__ void __launch_bounds__(256)
-    ctc_compact_x_kernel(const float* __restrict__ x, const int32_t* __restrict__ targets,
-                         const int64_t* __restrict__ offsets, int T, int C, int blank, float* __restrict__ xc) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int64_t o0 = offsets[b];
-  const int L = (int)(offsets[b + 1] - o0);
-  const int col = lane < L ? targets[o0 + lane] : blank;
-  const float* xrow = x + (int64_t)b * T * C;
-  float* dst = xc + (int64_t)b * T * kXcStride;
-  const int nw = gridDim.x * 4;
-  for (int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kXcRows; t0 < T; t0 += nw * kXcRows) {
-    float v[kXcRows];
-#pragma unroll
-    for (int u = 0; u < kXcRows; ++u) v[u] = xrow[(int64_t)min(t0 + u, T - 1) * C + col];
-#pragma unroll
-    for (int u = 0; u < kXcRows; ++u)
-      if (t0 + u < T) dst[(int64_t)(t0 + u) * kXcStride + lane] = v[u];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// FAST pipelined step: the same single launch with the lane-exponent chains (8 waves per workgroup:
-// gradient workgroups carry 8 blocks), followed by ctc_repair_kernel.  The gradient waves reproduce
-// log2 Z per block (zloc); the repair launch evaluates that certificate and re-runs rejected
-// utterances -- chains and gradient -- in the log domain.  On data the fast chains can represent the
-// repair launch exits at once.
-// ------------------------------------------------------------------------------------------------
-template <bool LSM, bool COMPACT, bool XC = false>
-__global__ void __launch_bounds__(kFWaves * 64) __attribute__((amdgpu_waves_per_eu(6, 6)))  // <= 80 VGPRs: three workgroups per CU
-    ctc_fast_pipelined_kernel(CtcArgs a, const float* __restrict__ coef, const float* __restrict__ gout,
-                              float* __restrict__ dx) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nchain = 2 * a.B;
-  if ((int)blockIdx.x < nchain) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      int32_t* perr = (int32_t*)(a.ws + ctc_ws_layout(a.B, a.T, a.P).perr);
-      perr[0] = 0;  // a gradient wave gave up waiting
-      perr[1] = 0;  // utterances the repair launch recomputed
-    }
-    if (threadIdx.x >= 64) __builtin_amdgcn_s_setprio(2);  // (the chain wave raises itself to 3)
-    // XCD placement (speed only): workgroup i is observed to run on XCD i % 8, and every XCD has its own L2.  The two
-    // chains and all gradient items of an utterance are kept on ONE XCD (utterance b on XCD b % 8), so that x[b], the
-    // checkpoints and the flags of b are fetched into one L2 instead of up to eight.
-    int b = (int)blockIdx.x >> 1, dir = (int)blockIdx.x & 1;
-    if (a.place) {
-      const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-      b = (slot >> 1) * 8 + xcd, dir = slot & 1;
-    }
-    ctc_fast_chain_body<true, LSM, XC>(a, b, dir, *reinterpret_cast<FastLdsT*>(smem));
-    return;
-  }
-  // Gradient waves are persistent: a wave takes item after item (stride: all gradient waves of the launch), in
-  // readiness order -- the middle blocks of every utterance first, their checkpoints exist at half time.  With one
-  // item per wave and more items than resident waves, the second half of the items waited for workgroup slots and
-  // then paid their start-up (dispatch, three dependent loads) after the chains had finished.
-  const int NB = ctc_blocks(a.T);
-  const int mid = (NB - 1) / 2;
-  const int gwgs = (int)(gridDim.x - nchain), g = (int)(blockIdx.x - nchain);
-  // (same placement as the chains where the counts allow it: utterance b's items on XCD b % 8)
-  const bool placed = a.place && (gwgs & 7) == 0;
-  const int xcd = placed ? g & 7 : 0, mult = placed ? 8 : 1, nb = placed ? a.B >> 3 : a.B;  // utterances of this XCD
-  const int stride = (placed ? gwgs >> 3 : gwgs) * kFWaves;
-  const int first = __builtin_amdgcn_readfirstlane((placed ? g >> 3 : g) * kFWaves + (int)(threadIdx.x >> 6));
-  auto item = [&](int li, int& b, int& k) {
-    const int r = li / nb;  // rank in readiness order
-    b = (li % nb) * mult + xcd;
-    k = (r & 1) ? mid + (r + 1) / 2 : mid - r / 2;
-  };
-  float* park = nullptr;
-  if (a.park && first + stride < nb * NB) {
-    park = a.park + (int64_t)__builtin_amdgcn_readfirstlane(g * kFWaves + (int)(threadIdx.x >> 6)) * kParkStride;
-    int b2, k2;
-    item(first + stride, b2, k2);
-    ctc_fast_park_factors<LSM, XC>(a, b2, k2, park);
-  }
-  FastUtt utt;
-  for (int li = first; li < nb * NB; li += stride) {
-    int b, k;
-    item(li, b, k);
-    ctc_fast_grad_body<LSM, true, COMPACT, XC>(a, true, b, k, coef, gout, dx, smem, utt, li == first + stride ? park : nullptr);
-  }
-}
-
 
 template <bool LSM, bool COMPACT>
 __global__ void __launch_bounds__(256)
@@ -2354,35 +1638,11 @@ static int ctc_check(int B, int T, int C, int max_len, int blank, const char* wh
   return WFL_OK;
 }
 
-// The compact emission copy pays when x does not stay in the Infinity Cache between the three sweeps (256 MiB) and
-// its rows are wide enough for a 45-label gather to waste most of what it touches.
+// The exchange of gathered emissions between an utterance's two sweeps pays when x does not stay in the Infinity Cache
+// between them (256 MiB) and its rows are wide enough for a 45-label gather to waste most of what it touches.
 static bool ctc_use_xc(int B, int T, int C, int max_len) {
   if (max_len + 1 > 64) return false;  // (the lane-exponent step: one target position per lane)
   return (int64_t)B * T * C * 4 >= (192ll << 20) && C >= 192;
-}
-
-// Gradient workgroups of the fast pipelined launch: one item per wave, or -- small batches, where the launch is
-// latency-bound and all chains plus a full complement of gradient workgroups are resident at once (three workgroups
-// per CU) -- as many workgroups as there are free slots, their waves looping over the items (WFL_CTC_GRAD_WGS: 0 = one
-// item per wave, n = that many workgroups).
-static int64_t ctc_fast_grad_wgs(int B, int T) {
-  static const int n_cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
-  const int64_t all_wgs = ((int64_t)B * ctc_blocks(T) + kFWaves - 1) / kFWaves;
-  if (2 * (int64_t)B <= 3 * n_cus / 2) return std::min<int64_t>(all_wgs, 3 * (int64_t)n_cus - 2 * B);
-  return all_wgs;
-}
-// parking area of the persistent gradient waves (CtcArgs::park), behind the compact emission copy.  OFF unless
-// WFL_CTC_PARK=1 -- measured at cfg2: the factors of a wave's second item, computed while it waits for its first,
-// shorten that item's start-up (3.1 instead of 5.3 us from start to checkpoints on the launch's own timeline), but the
-// 35 MB they add to the launch's traffic (302 instead of 267 MB) cost more in back-to-back steps: 61.5 against 60.4 us.
-static int64_t ctc_park_floats(int B, int T) {
-  constexpr bool off = true;  // (measured slower, see above: the parking area is never reserved)
-  const int64_t wgs = ctc_fast_grad_wgs(B, T), all_wgs = ((int64_t)B * ctc_blocks(T) + kFWaves - 1) / kFWaves;
-  return (off || wgs >= all_wgs) ? 0 : wgs * kFWaves * kParkStride;
 }
 
 int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems) {
@@ -2390,8 +1650,7 @@ int wfl_ctc_workspace(int B, int T, int C, int max_len, int64_t* ws_elems) {
     set_error("ctc_workspace: bad arguments");
     return WFL_ERR_INVALID;
   }
-  *ws_elems = ctc_ws_layout(B, T, max_len + 1).total + 4 + (ctc_use_xc(B, T, C, max_len) ? (int64_t)B * T * kXcStride : 0) +
-              ctc_park_floats(B, T);
+  *ws_elems = ctc_ws_layout(B, T, max_len + 1).total + 4 + (ctc_use_xc(B, T, C, max_len) ? (int64_t)B * T * kXcStride : 0);
   return WFL_OK;
 }
 
@@ -2531,22 +1790,13 @@ static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const 
     return WFL_OK;
   };
   int rc = WFL_OK;
-  // lane-exponent chains + certificate + repair launch: when the 8-wave gradient workgroups fit the LDS
-  // (WFL_CTC_PIPELINE=log selects the log-domain chains)
+  // targets of at most 63 labels: the meet-in-the-middle launch (lane-exponent sweeps that emit the gradient themselves,
+  // ctc_mitm.h) + certificate + repair launch; WFL_CTC_PIPELINE=log selects the log-domain pipelined launch
   static const bool env_log = [] {
     const char* e = getenv("WFL_CTC_PIPELINE");
     return e && std::string(e) == "log";
   }();
   const bool force_log = env_log || prefer_log;
-  const size_t rows8_lds = (size_t)kFWaves * kBlk * C * 4;
-  // gradient rows as a dense LDS tile while three workgroups still fit a CU with it (C <= 100), compact beyond
-  const size_t compact_lds = (size_t)kFWaves * compact_wave_bytes(C);
-  const bool compact = 3 * std::max(rows8_lds, sizeof(FastLdsT)) > (size_t)kLdsBytes;
-  // meet-in-the-middle step (ctc_mitm.h): the sweeps emit the gradient -- narrow rows (dense LDS tile per emitter)
-  static const int mitm_env = [] {
-    const char* e = getenv("WFL_CTC_MITM");
-    return e ? atoi(e) : 1;
-  }();
   // two workgroup shapes (ctc_mitm.h): 16 waves, one workgroup per CU, while the batch has no more sweeps than the chip
   // has CUs; 8 waves, two per CU, beyond
   const int cus = [] {  // (of the CURRENT device: a process may drive several)
@@ -2574,20 +1824,10 @@ static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const 
                 "ctc_mitm.h: two 8-wave workgroups per CU");
   // rows wider than the dense tile: the emitters accumulate in the compact tile and expand through a column map
   // (WIDE); its LDS: one byte per class behind the tiles
-  static const int wide_env = [] {
-    const char* e = getenv("WFL_CTC_MITM_WIDE");  // 0: rows wider than 128 classes through the round-2 pipelined launch
-    return e ? atoi(e) : 1;
-  }();
   const bool wide = C > kMTile;
+  // (the LDS of the wide shape is bounded by the class count the entry point admits: both shapes always fit)
   const bool wide_fits = small_wg ? 2 * mitm_lds_of(MitmK<8>{}, true) <= (size_t)kLdsBytes : mitm_lds_of(MitmK<16>{}, true) <= (size_t)kLdsBytes;
-  static const int lsm_env = [] {
-    const char* e = getenv("WFL_CTC_MITM_LSM");  // 0: the fused log_softmax criterion through the round-2 pipelined launch
-    return e ? atoi(e) : 1;
-  }();
-  // (fused log_softmax with rows wider than 128 classes stays on the pipelined pair: expanding the compact tile AND
-  // forming the softmax term from full rows in the emitters measured 0.498 against 0.470 ms at T = 2000, C = 512)
-  if (ppl == 1 && !force_log && mitm_env && (!row_lse || (lsm_env && (!wide || lsm_env == 2))) &&
-      (!wide || (wide_env && wide_fits))) {
+  if (ppl == 1 && !force_log && (!wide || wide_fits)) {
     auto launch_mitm = [&](auto kern, auto k) -> int {
       using K = decltype(k);
       const size_t lds = mitm_lds_of(k, wide);
@@ -2612,47 +1852,6 @@ static int ctc_forward_backward_impl(const float* x, int B, int T, int C, const 
     WFL_LAUNCH_CHECK();
     a.xc = nullptr;  // (only the first halves' frames are in it)
     a.suspect_token = a.token;
-    a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
-    if (a.token == 0) a.token = 1;
-    auto launch_repair = [&](auto kern) -> int {
-      const size_t lds = std::max(rows_lds, sizeof(ChainLdsT));
-      if (lds > 48 * 1024)
-        WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
-      const dim3 rgrid((unsigned)(2 * B + std::min<int64_t>((items + 3) / 4, 512)));
-      hipLaunchKernelGGL(kern, rgrid, dim3(256), lds, (hipStream_t)stream, a, coef, gout, dx);
-      return WFL_OK;
-    };
-    rc = lcompact ? (row_lse ? launch_repair(ctc_repair_kernel<true, true>) : launch_repair(ctc_repair_kernel<false, true>))
-                  : (row_lse ? launch_repair(ctc_repair_kernel<true, false>) : launch_repair(ctc_repair_kernel<false, false>));
-  } else if (ppl == 1 && !force_log && (compact ? compact_lds : rows8_lds) <= (size_t)kLdsBytes) {
-    const size_t lds = std::max(compact ? compact_lds : rows8_lds, sizeof(FastLdsT));
-    const int64_t grad_wgs = ctc_fast_grad_wgs(B, T);
-    const dim3 grid8((unsigned)(2 * B + grad_wgs));
-    // (keeping an utterance's chains and gradient items on one XCD was measured at cfg2: memory-side traffic 278 -> 223 MB
-    // and 2 us SLOWER -- eight utterance groups finish less evenly than 128 utterances spread over everything: not used)
-    a.place = 0;
-    float* behind = ws + ((ctc_ws_layout(B, T, max_len + 1).total + 3) & ~(int64_t)3);
-    a.park = ctc_park_floats(B, T) ? behind + (ctc_use_xc(B, T, C, max_len) ? (int64_t)B * T * kXcStride : 0) : nullptr;
-    if (compact && ctc_use_xc(B, T, C, max_len)) {  // (wide rows: they use the compact gradient tile)
-      float* xc = behind;
-      // (a streaming variant -- coalesced float4 rows through an LDS tile -- is no faster: 141 vs 143 us at cfg5.  The
-      // pass also absorbs the write-back of the previous step's gradient, still dirty in the Infinity Cache.)
-      const unsigned gx = (unsigned)std::max(1, std::min((T + 4 * kXcRows - 1) / (4 * kXcRows), 64));
-      hipLaunchKernelGGL(ctc_compact_x_kernel, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, targets, offsets,
-                         T, C, blank, xc);
-      WFL_LAUNCH_CHECK();
-      a.xc = xc;
-    }
-    auto launch_fast = [&](auto kern) -> int {
-      WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)kern, (int)lds));
-      hipLaunchKernelGGL(kern, grid8, dim3(kFWaves * 64), lds, (hipStream_t)stream, a, coef, gout, dx);
-      return WFL_OK;
-    };
-    rc = a.xc ? (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, true, true>) : launch_fast(ctc_fast_pipelined_kernel<false, true, true>))
-         : compact ? (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, true>) : launch_fast(ctc_fast_pipelined_kernel<false, true>))
-                   : (row_lse ? launch_fast(ctc_fast_pipelined_kernel<true, false>) : launch_fast(ctc_fast_pipelined_kernel<false, false>));
-    if (rc) return rc;
-    WFL_LAUNCH_CHECK();
     a.token = counter.fetch_add(0x9e3779b97f4a7c15ull) ^ (unsigned long long)(uintptr_t)ws;
     if (a.token == 0) a.token = 1;
     auto launch_repair = [&](auto kern) -> int {

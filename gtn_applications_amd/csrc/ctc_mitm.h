@@ -5,7 +5,7 @@
 //
 //   * one workgroup per (utterance, direction) -- 2B workgroups, one per CU at B = 128.  The alpha sweep runs
 //     0 -> T, the beta sweep T -> 0 (the same recursion on the reversed target and reversed time), both in the
-//     lane-exponent arithmetic of ctc_fast_chain_body (float mantissa + one integer exponent per lane, five
+//     lane-exponent arithmetic of ctc_kernels.hip (float mantissa + one integer exponent per lane, five
 //     instructions per frame, renormalised every 16 frames);
 //   * FIRST half of a sweep (blocks n < H0): its state before every 16-frame block -- raw mantissas and lane
 //     exponents, ~0.5 KB -- is published for the partner workgroup (device-coherent stores + a flag);
@@ -24,7 +24,7 @@
 //     0 chain | 4 flusher | 8 fetcher | 1,2,3,5 stagers | 6,7,9,10,11,13,14,15,12 emitters  (SIMD of wave w: w % 4 --
 //     the chain wave shares its SIMD with the two light waves and one emitter)
 //   chain    the dependent recursion and nothing else; factors travel ring -> registers a whole block ahead
-//   stagers  gather x (two blocks in flight each), references, exp2 -> LDS ring (as ctc_fast_chain_body's helpers)
+//   stagers  gather x (two blocks in flight each), references, exp2 -> LDS ring
 //   flusher  sums the references (double offsets) and, in the first half, publishes the raw checkpoints
 //   fetcher  second half: waits for the partner's flags, loads its checkpoints, mirrors / rescales them into the
 //            sweep's own lane order and leaves them in LDS -- emitters never wait on another CU and never issue a
@@ -345,7 +345,7 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
   st_part[4] += __builtin_amdgcn_readfirstlane(__float_as_int(gtot)) * 0 + clock64() - st_e0;
 #endif
   {
-    // certificate (see ctc_fast_grad_body): the posterior mass of every frame
+    // certificate: the posterior mass of every frame
     const float stot = wave_all_sum(wsum.x + wsum.y);
     const int n = FULL ? kBlk : cnt;
     const float want = cf * ((float)n + (float)(n * (n - 1)) * (1.f / 64.f));

@@ -1128,7 +1128,7 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
 // tile.  Per stage of 16 frames a wave issues <= 64 MFMAs (2048 cycles of its SIMD's matrix pipe) where the 8 x 8
 // register tiles of dense_fast_grad_kernel cost every wave 1024 FMAs (~4400 issue cycles) -- and the vector pipe is
 // free for the staging arithmetic of the next stage meanwhile.  Staging, scales and the emission gradient are those
-// of dense_fast_grad_kernel.  (WFL_DENSE_GRAD_MFMA=0: the vector-pipe kernel.)
+// of dense_fast_grad_kernel.
 typedef float mfma_v4f __attribute__((ext_vector_type(4)));
 template <int CP, int TS>
 __global__ void __launch_bounds__(256, 2)
@@ -1498,10 +1498,7 @@ int wfl_dense_grad_parts(const float* x, const float* W, int B, int T, int C, co
 #define WFL_FAST_GRAD(CP)                                                                                       \
   hipLaunchKernelGGL((dense_fast_grad_kernel<CP, grad_stage<CP>()>), grid, dim3(((CP / 8) * (CP / 8) + 63) / 64 * 64), 0, st, \
                      x, W, T, C, B, alpha, beta, ws, coef, coef_w, gout, accumulate, addend, dx, part, rows)
-  static const bool use_mfma = [] {
-    const char* e = getenv("WFL_DENSE_GRAD_MFMA");  // 0: the transition gradient's products on the vector pipe (A/B)
-    return !(e && atoi(e) == 0);
-  }();
+  constexpr bool use_mfma = true;  // (the vector-pipe kernel serves the calls without a transition gradient and 32 / 160 / 192 classes)
 #define WFL_MFMA_GRAD(CP)                                                                                       \
   hipLaunchKernelGGL((dense_mfma_grad_kernel<CP, 16>), grid, dim3(256), 0, st, x, W, T, C, B, alpha, beta, ws, coef, coef_w, \
                      gout, accumulate, addend, dx, part, rows)

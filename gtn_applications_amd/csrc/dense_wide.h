@@ -124,85 +124,10 @@ __device__ __forceinline__ void atomic_max_pos(float* p, float v) {  // v >= 0: 
   atomicMax(reinterpret_cast<int*>(p), __float_as_int(v));
 }
 
-// One frame of both sweeps: blockIdx.z = 0 alpha's frame s (s >= 1), 1 beta's frame T-1-s.  Tile: kWideTM states x
-// kWideTN utterances, 256 threads, 4 x 4 outputs per thread, operands through LDS in chunks of kWideTK.
-__global__ void __launch_bounds__(256) wide_frame_kernel(const float* __restrict__ x, int B, int T, int C, int s, WideWs w,
-                                                         float* __restrict__ alpha, float* __restrict__ beta) {
-  const int dir = blockIdx.z;
-  if (dir == 1 && !beta) return;
-  __shared__ float As[kWideTK][kWideTM + 4];
-  __shared__ float Bs[kWideTK][kWideTN + 4];
-  const int i0 = blockIdx.x * kWideTM, n0 = blockIdx.y * kWideTN;
-  const int t = dir == 0 ? s : T - 1 - s;         // the frame being produced
-  const int tp = dir == 0 ? t - 1 : t + 1;        // the frame it is produced from
-  const float* A = dir == 0 ? w.P : w.PT;
-  const float* vec = dir == 0 ? alpha : beta;
-  const float* vmax = dir == 0 ? w.maxa : w.maxb;
-  const int tid = threadIdx.x, ti = tid & 15, tn = tid >> 4;  // micro tile: states i0 + ti + 16 u, utterances n0 + tn + 16 v
-  float acc[4][4] = {};
-  // loader assignment: 256 threads x 4 elements = a 64 x 16 tile; thread -> (row = tid / 4, k = (tid % 4) * 4 ..)
-  const int lr = tid >> 2, lk = (tid & 3) * 4;
-  const int bn = n0 + lr;  // utterance of this thread's B-operand row
-  float binv = 0.f, bref = 0.f;
-  if (bn < B) {
-    const float mx = vmax[(int64_t)bn * T + tp];
-    binv = mx > 0.f ? 1.f / mx : 0.f;
-    bref = w.mxp[(int64_t)bn * T + tp];
-  }
-  for (int k0 = 0; k0 < C; k0 += kWideTK) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = k0 + lk + q;
-      const int ai = i0 + lr;
-      As[lk + q][lr] = (ai < C && k < C) ? A[(int64_t)ai * C + k] : 0.f;
-      float v = 0.f;
-      if (bn < B && k < C) {
-        v = vec[((int64_t)bn * T + tp) * C + k] * binv;
-        if (dir == 1) v *= __expf(wide_clean(x[((int64_t)bn * T + tp) * C + k]) + w.rm[k] - bref);  // e_{t+1} (.) beta_{t+1}
-      }
-      Bs[lk + q][lr] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kWideTK; ++k) {
-      float a[4], bv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = As[k][ti + 16 * u], bv[u] = Bs[k][tn + 16 * u];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(a[u], bv[v], acc[u][v]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int n = n0 + tn + 16 * v;
-    if (n >= B) continue;
-    const int64_t row = (int64_t)n * T + t;
-    const float ref = dir == 0 ? w.mxp[row] : 0.f;
-    float top = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + ti + 16 * u;
-      if (i >= C) continue;
-      float y = acc[u][v];
-      if (dir == 0) y *= __expf(wide_clean(x[row * C + i]) + w.rm[i] - ref);
-      (dir == 0 ? alpha : beta)[row * C + i] = y;
-      top = fmaxf(top, y);
-    }
-    // (16 threads of a wave share the utterance: lanes ti = 0..15 of the same tn)
-    top = fmaxf(top, __shfl_xor(top, 1, 64));
-    top = fmaxf(top, __shfl_xor(top, 2, 64));
-    top = fmaxf(top, __shfl_xor(top, 4, 64));
-    top = fmaxf(top, __shfl_xor(top, 8, 64));
-    if (ti == 0 && top > 0.f) atomic_max_pos((dir == 0 ? w.maxa : w.maxb) + row, top);
-  }
-}
-
-// The same frame on the matrix cores, tiled so that the launch fills the chip: the vector-pipe kernel above makes
-// 64 x 64 output tiles -- at N = 1000, B = 32 that is 16 x 1 x 2 = 32 workgroups on 256 CUs, each walking K = 1000 by
-// itself: 156 us per frame, 39 ms per step at T = 250.  Here a workgroup owns a 16-state x 16-utterance tile
+// One frame of both sweeps (blockIdx.z = 0 alpha's frame s (s >= 1), 1 beta's frame T-1-s) on the matrix cores, tiled so
+// that the launch fills the chip.  (Round 3's vector-pipe kernel -- deleted in round 5 -- made 64 x 64 output tiles: at
+// N = 1000, B = 32 that was 16 x 1 x 2 = 32 workgroups on 256 CUs, each walking K = 1000 by itself: 156 us per frame,
+// 39 ms per step at T = 250.)  Here a workgroup owns a 16-state x 16-utterance tile
 // (v_mfma_f32_16x16x4_f32), its four waves each take a quarter of K and the partial tiles meet in LDS: 63 x 2 x 2 = 252
 // workgroups at that shape, ~250 K steps of dependent products per wave instead of 1000 k-chunks behind barriers.
 // Operands straight from L2 into the products' registers (P, 4 MB, stays in L2 / MALL across the frame's workgroups): a
@@ -548,17 +473,10 @@ static int wide_forward(const float* x, const float* W, int B, int T, int C, int
   hipLaunchKernelGGL(wide_prep_kernel, dim3((unsigned)C), dim3(256), 0, st, W, C, w);
   hipLaunchKernelGGL(wide_rows_kernel, dim3((unsigned)(((int64_t)B * T + 3) / 4)), dim3(256), 0, st, x, W, B, T, C, w, alpha,
                      beta);
-  static const bool use_mfma = [] {
-    const char* e = getenv("WFL_DENSE_WIDE_MFMA");  // 0: the vector-pipe frame kernel (A/B, tests)
-    return !(e && atoi(e) == 0);
-  }();
-  if (use_mfma) {
+  {
     const dim3 grid((unsigned)((C + 15) / 16), (unsigned)((B + 15) / 16), beta ? 2u : 1u);
     for (int s = 1; s < T; ++s)
       hipLaunchKernelGGL(wide_frame_mfma_kernel, grid, dim3(64 * kWideMfmaWaves), 0, st, x, B, T, C, s, w, alpha, beta);
-  } else {
-    const dim3 grid(tiles.x, tiles.y, beta ? 2u : 1u);
-    for (int s = 1; s < T; ++s) hipLaunchKernelGGL(wide_frame_kernel, grid, dim3(256), 0, st, x, B, T, C, s, w, alpha, beta);
   }
   hipLaunchKernelGGL(wide_scan_kernel, dim3((unsigned)B), dim3(256), 0, st, B, T, C, w, alpha, beta != nullptr, logz);
   return WFL_OK;

@@ -2810,8 +2810,8 @@ static SideStream* side_stream_of_device() {
   if (it != table->end()) return it->second;
   auto* s = new SideStream();
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->join, wfl::order_event_flags()) != hipSuccess ||
+      hipEventCreateWithFlags(&s->fork, wfl::order_event_flags()) != hipSuccess ||
       hipMalloc((void**)&s->verdicts, kVerdictRing * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(s->verdicts, 0, kVerdictRing * sizeof(uint32_t)) != hipSuccess) {
     delete s;
@@ -2834,7 +2834,7 @@ struct LiveState {
   uint64_t attempts = 0, skipped = 0;
   int max_spins = 1 << 11;  // gate polls of ~2 us each: ~4 ms (WFL_LATTICE_GATE_SPINS) -- a process's first launch of the
                             // sweeps loads their code, which takes longer than a millisecond
-  bool fork = true;        // WFL_LATTICE_FUSED_FORK=0: no fork event (the round-3 protocol; measurements)
+  bool fork = true;        // the side stream forks from the caller's right in front of the sweeps (without: the round-3 protocol, whose gate waited out the stream's backlog)
 };
 // (one per DEVICE, next to its side stream: a give-up on one GPU -- a profiler attached to it, a first launch that loads
 // code -- says nothing about the others)
@@ -2856,9 +2856,6 @@ static LiveState& live_state() {
       const char* e = getenv(name);
       if (e && atoi(e) != 0) s->env_serial = true;
     }
-    if (const char* e = getenv("WFL_LATTICE_GATE_SPINS")) s->max_spins = std::max(1, atoi(e));
-    if (const char* e = getenv("WFL_LATTICE_FUSED_FORK")) s->fork = atoi(e) != 0;
-    if (!s->fork && !getenv("WFL_LATTICE_GATE_SPINS")) s->max_spins = 1 << 20;  // (no fork: the gate waits out the stream's backlog)
     return s;
   }();
   return *st;
@@ -2971,13 +2968,8 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
       };
       // The occupancy gradient beside the sweeps (prob_chain_pub_kernel + occ_gate_kernel + occ_live_kernel): uniform-
       // label acceptors without epsilon arcs, full 16-frame chunks (the sweeps' publication counts on them).
-      // WFL_LATTICE_FUSED_GRAD=0: never; WFL_LATTICE_FUSED_TILE: frames per gradient tile (default 32);
-      // WFL_LATTICE_FUSED_WGS: gradient workgroups per CU (default 5); WFL_LATTICE_FUSED_BADXCD=1: every utterance is
-      // reported as swept on two XCDs (tests of the fall-back).
-      static const int fused_env = [] {
-        const char* e = getenv("WFL_LATTICE_FUSED_GRAD");
-        return e ? atoi(e) : 1;
-      }();
+      // WFL_LATTICE_FUSED_BADXCD=1: every utterance is reported as swept on two XCDs (tests of the fall-back).
+      constexpr int fused_env = 1;
       constexpr int fused_tile = 32;  // frames per gradient job
       // persistent gradient workgroups per CU: as many as are resident at once (four waves of 130 VGPRs each: three per
       // CU).  More only queue behind those and start when the jobs are gone; measured at the Transducer benchmark with
@@ -3187,11 +3179,7 @@ static int lattice_grad_impl(const wfl_lattice_desc* d, const int32_t* ints, con
   }
   // uniform-label acceptors without learnable weights (the Transducer's alignment graphs, long CTC targets): the
   // emission gradient from state occupancies (occ_grad_kernel); the general launch skips what it served
-  static const bool occ_off = [] {
-    const char* e = getenv("WFL_LATTICE_OCC_GRAD");  // (0: the general kernel for everything -- tests, measurements)
-    return e && atoi(e) == 0;
-  }();
-  const int occ = !occ_off && dx && !dW && !band && d->max_eps == 0 && d->max_labels <= 32767;
+  const int occ = dx && !dW && !band && d->max_eps == 0 && d->max_labels <= 32767;
   int occ_done = occ_in_launch ? 2 : 0;
   if (occ && !occ_in_launch) {
     const int wgs_t = std::max(1, std::min((T + 15) / 16, 2048 / std::max(1, d->B)));

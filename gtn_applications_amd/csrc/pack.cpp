@@ -349,6 +349,12 @@ wfl_lattice_host* merge_direct(std::vector<Builder>& parts, int np, int B, int C
 
 }  // namespace
 
+// WFL_PACK_TRACE: per-phase host microseconds of the batch packers on stderr (scripts/pack_trace.py)
+static bool pack_trace_on() {
+  static const bool on = getenv("WFL_PACK_TRACE") != nullptr;
+  return on;
+}
+
 extern "C" {
 
 wfl_lattice_host* wfl_lattice_pack(const wfl_graph* const* graphs, const int32_t* const* wid, int n_graphs, int B,
@@ -416,7 +422,7 @@ wfl_lattice_host* wfl_lattice_pack_asg_fal(const int32_t* targets, const int64_t
     return build_batch(B, C, [&](int b, Builder& bld, PackScratch&) {
       return bld.add_force_align(targets + offsets[b], (int)(offsets[b + 1] - offsets[b]));
     });
-  static const bool trace = getenv("WFL_PACK_TRACE") != nullptr;
+  const bool trace = pack_trace_on();
   const auto t0 = std::chrono::steady_clock::now();
   // pass 1: distinct labels of each target (sorted) and the slot of every position
   // (scratch kept per thread; bound to plain references once -- every access to a thread_local of a shared library
@@ -866,12 +872,8 @@ bool alignment_acceptor(const wfl_graph* tokens, const wfl_graph* lexicon, const
   GraphOwner tokens_target(tt);
   PROF(1)
   // alignments = project_input(remove(compose(tokens, tokens_target))): written down directly for the benchmark's token
-  // graph (wfl::token_alignments), the generic graph algebra otherwise (WFL_PACK_GENERIC=1: always)
-  static const bool generic_only = [] {
-    const char* e = getenv("WFL_PACK_GENERIC");
-    return e && atoi(e) != 0;
-  }();
-  wfl_graph* direct = generic_only ? nullptr : wfl::token_alignments(tokens, tokens_target.g);
+  // graph (wfl::token_alignments), the generic graph algebra otherwise
+  wfl_graph* direct = wfl::token_alignments(tokens, tokens_target.g);
   PROF(2)
   if (!direct) {
     GraphOwner c2(wfl_graph_compose(tokens, tokens_target.g, nullptr, nullptr));
@@ -925,7 +927,7 @@ wfl_lattice_host* wfl_transducer_pack_batch_into(const wfl_graph* tokens, const 
   // build the shared operands' label-sorted adjacency once, before the threads ask for it
   tokens->out_sorted(true), lexicon->out_sorted(false);
   if (transitions) transitions->out_sorted(true);
-  static const bool trace = getenv("WFL_PACK_TRACE") != nullptr;
+  const bool trace = pack_trace_on();
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t0 = now();
   // The per-utterance builders are kept across batches: their vectors were grown by the pool's threads, and handing
@@ -986,12 +988,8 @@ int wfl_transducer_decode_batch(const wfl_graph* tokens, const int32_t* labels, 
       set_error("transducer_decode_batch: offsets must not decrease");
       return WFL_ERR_INVALID;
     }
-  static const bool generic_only = [] {
-    const char* e = getenv("WFL_DECODE_GENERIC");
-    return e && atoi(e) != 0;
-  }();
   int ntok = 0;
-  const bool direct = !generic_only && wfl::token_graph_kind(tokens, &ntok) >= 0;
+  const bool direct = wfl::token_graph_kind(tokens, &ntok) >= 0;
   std::vector<std::vector<int32_t>> parts(B);
   std::vector<std::string> errors(B);
   std::atomic<int> failed{0};

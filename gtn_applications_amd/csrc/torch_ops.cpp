@@ -22,6 +22,8 @@
 #include "../../include/wfl.h"
 
 namespace {
+// ordering-only events of this device: no timestamp, no system-scope fence when recorded (csrc/device_common.h)
+unsigned order_event_flags() { return hipEventDisableTiming | hipEventDisableSystemFence; }
 
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
@@ -490,7 +492,7 @@ struct EventRing {  // fork / join events of the native steps, per device (creat
   hipEvent_t take() {
     std::lock_guard<std::mutex> lock(mu);
     hipEvent_t& e = ev[next++ % kN];
-    if (!e) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate");
+    if (!e) TORCH_CHECK(hipEventCreateWithFlags(&e, order_event_flags()) == hipSuccess, "hipEventCreate");
     return e;
   }
 };

@@ -1,5 +1,5 @@
 """Step time of the CTC MODULE (criterions/ctc.py CTC(blank, use_pt=False): raw scores in, log_softmax fused into the
-step) at the cfg2 / cfg5-shard shapes.  WFL_CTC_MITM_LSM=0 selects the round-2 pipelined launch."""
+step) at the cfg2 / cfg5-shard shapes."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 import torch

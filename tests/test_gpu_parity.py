@@ -464,8 +464,8 @@ def test_ctc_pipeline_env_selects_log_domain_launch():
     assert float(g0) == pytest.approx(float(g1), rel=1e-4)
 
 
-def test_ctc_fast_pipelined_step_random_shapes():
-    """lane-exponent pipelined step (with and without the fused log_softmax) against the three-launch log-domain
+def test_ctc_lane_exponent_step_random_shapes():
+    """lane-exponent step (the meet-in-the-middle launch, with and without the fused log_softmax) against the three-launch log-domain
     step over random shapes: T around the 16-frame block boundaries, 2 <= C <= 1001 (dense and compact gradient tiles), targets
     of 0..63 labels, infeasible utterances, -inf / NaN entries, score spreads that make the certificate reject
     some utterances (repaired in the log domain within the same call)"""
