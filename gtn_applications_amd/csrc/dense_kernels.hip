@@ -320,6 +320,195 @@ static size_t dense_chain_lds(int C, int ldw) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// ASG.viterbi (asg.py:211-236) for up to 256 classes: the max-plus sweep with the transition matrix in REGISTERS and
+// no back-pointers, then a back-trace that re-derives the one back-pointer per frame it needs.
+//
+// dense_chain_kernel<tropical> above keeps W in LDS slices, tracks the arg max term by term (five instructions a term),
+// merges partial maxima behind a second barrier and stores C back-pointers per frame: 2.3 us per frame at C = 100 --
+// 2.3 ms per call at the ASG benchmark's shape, five times the training step it is called beside (train.py:279).  Here
+// a state's row of W is split over the two lanes of a pair (SPAN = ceil(C / 2) registers each), a frame is SPAN / 4
+// 16-byte reads of the previous vector (two addresses per wave: the pair's halves), SPAN / 2 packed adds and as many
+// three-operand maxima, one DPP exchange inside the pair, one LDS write, one barrier.  The arithmetic is the old
+// kernel's, operation for operation -- (alpha[j] + W[s][j]) rounded, the maximum, + x[t][s] -- so the stored vectors
+// are bit-identical, and so is the path: the back-trace takes  arg max_j alpha[t-1][j] + W[cur][j]  over the STORED
+// vector with the lowest j winning ties (what the old sweep's strict comparisons in ascending j did).
+// ------------------------------------------------------------------------------------------------
+typedef float vit_v2f __attribute__((ext_vector_type(2)));
+constexpr int kVitPrefetch = 8;  // emission rows in flight per thread (their loads share a counter with the frames' stores)
+template <int SPAN, int R>  // R lanes per state (adjacent: 2 or 4), SPAN previous states per lane
+__global__ void __launch_bounds__(512)
+    dense_viterbi_sweep_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C,
+                               float* __restrict__ alpha) {
+  static_assert(SPAN % 4 == 0 && SPAN <= 128, "16-byte reads of the previous vector; the slice lives in registers");
+  static_assert(R == 2 || R == 4, "the lanes of a state meet inside a quad");
+  // the two vectors, each with R * SPAN readable entries (entries >= C: zeros, met by weights of -inf)
+  __shared__ __attribute__((aligned(16))) float av[2][R * SPAN];
+  const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  const int s = tid / R, r = tid & (R - 1), j0 = r * SPAN;
+  const bool owner = r == 0 && s < C;
+  const float* xb = x + (int64_t)b * T * C;
+  float* ob = alpha + (int64_t)b * T * C;
+  const int sc = min(s, C - 1);  // (clamped: every thread loads, no branch around a load -- behind one, each is a round trip)
+  vit_v2f w[SPAN / 2];
+  {
+    const float* wrow = W + (int64_t)(1 + sc) * C;
+#pragma unroll
+    for (int q = 0; q < SPAN / 2; ++q) {
+      const int ja = j0 + 2 * q, jb = ja + 1;
+      w[q].x = wrow[min(ja, C - 1)], w[q].y = wrow[min(jb, C - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < SPAN / 2; ++q) {
+      const int ja = j0 + 2 * q, jb = ja + 1;
+      w[q].x = (s < C && ja < C) ? nan_to_neg(w[q].x) : WFL_NEG_INF;
+      w[q].y = (s < C && jb < C) ? nan_to_neg(w[q].y) : WFL_NEG_INF;
+    }
+  }
+  for (int i = tid; i < 2 * R * SPAN; i += NT) (&av[0][0])[i] = 0.f;
+  __syncthreads();
+  if (owner) {
+    const float v = nan_to_neg(xb[s]) + nan_to_neg(W[s]);
+    av[0][s] = v;
+    ob[s] = v;
+  }
+  // One frame: `xv` is x[t][s] (raw).
+  auto frame = [&](int t, float xv) {
+    const float4* from = reinterpret_cast<const float4*>(&av[(t - 1) & 1][j0]);
+    float m0 = WFL_NEG_INF, m1 = WFL_NEG_INF;
+#pragma unroll
+    for (int q = 0; q < SPAN / 4; ++q) {
+      const float4 a = from[q];
+      const vit_v2f lo = vit_v2f{a.x, a.y} + w[2 * q], hi = vit_v2f{a.z, a.w} + w[2 * q + 1];
+      m0 = __builtin_fmaxf(__builtin_fmaxf(m0, lo.x), lo.y);
+      m1 = __builtin_fmaxf(__builtin_fmaxf(m1, hi.x), hi.y);
+    }
+    float m = __builtin_fmaxf(m0, m1);
+    // the rest of the state's row: the other lanes of the pair / quad (quad_perm [1, 0, 3, 2], then [2, 3, 0, 1])
+    m = __builtin_fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, true)));
+    if (R == 4) m = __builtin_fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, true)));
+    const float val = m + nan_to_neg(xv);
+    if (owner) {
+      av[t & 1][s] = val;
+      ob[(int64_t)t * C + s] = val;
+    }
+    lds_barrier();
+  };
+  // Emission rows: two register sets of kVitPrefetch rows, used alternately -- a set is requested while the other one's
+  // frames run and nothing is copied between them (a copy is a wait for the set's loads AND, the counter being shared
+  // and in order, for every store issued before them: a store round trip per group).
+  const float* xs = xb + sc;
+  float xa[kVitPrefetch], xz[kVitPrefetch];
+  int t = 1;
+  const int tfull = 1 + ((T - 1) / (2 * kVitPrefetch)) * (2 * kVitPrefetch);  // frames [1, tfull): whole double groups
+  if (t < tfull) {
+#pragma unroll
+    for (int k = 0; k < kVitPrefetch; ++k) xa[k] = xs[(int64_t)(t + k) * C];
+  }
+  __syncthreads();
+  for (; t < tfull; t += 2 * kVitPrefetch) {
+#pragma unroll
+    for (int k = 0; k < kVitPrefetch; ++k) xz[k] = xs[(int64_t)(t + kVitPrefetch + k) * C];
+#pragma unroll
+    for (int k = 0; k < kVitPrefetch; ++k) frame(t + k, xa[k]);
+#pragma unroll
+    for (int k = 0; k < kVitPrefetch; ++k) xa[k] = xs[(int64_t)min(t + 2 * kVitPrefetch + k, T - 1) * C];
+#pragma unroll
+    for (int k = 0; k < kVitPrefetch; ++k) frame(t + kVitPrefetch + k, xz[k]);
+  }
+  for (; t < T; ++t) frame(t, xs[(int64_t)t * C]);  // (< 2 * kVitPrefetch frames)
+}
+
+// The path from the stored vectors: one workgroup per utterance; the rows of alpha travel to LDS in chunks (coalesced,
+// all threads), wave 0 walks a chunk: lane l holds W[cur][l + 64 i] (re-read when the state changes: from LDS when the
+// matrix fits beside the chunk, from L2 otherwise) and a step is <= 4 LDS reads, as many adds, a wave-wide maximum and
+// the lowest lane / slot that attains it.  Two chunk buffers: waves 1 .. 3 fetch the next chunk while wave 0 walks this one.
+constexpr int kVitChunkFloats = 4 * 1024;  // 16 KiB of stored vectors per chunk
+template <bool WLDS, int NJ>  // NJ = ceil(C / 64): previous states per lane
+__global__ void __launch_bounds__(256)
+    dense_viterbi_backtrace_kernel(const float* __restrict__ alpha, const float* __restrict__ W, int B, int T, int C,
+                                   int32_t* __restrict__ path) {
+  extern __shared__ __attribute__((aligned(16))) char vsmem[];
+  float* rowbuf = reinterpret_cast<float*>(vsmem);                    // [2][kVitChunkFloats + 256] (a padded row beyond the last)
+  int32_t* walk = reinterpret_cast<int32_t*>(rowbuf + 2 * (kVitChunkFloats + 256));  // [rows per chunk] the chunk's stretch of the path
+  int* cur_s = walk + 1024;
+  float* wl = reinterpret_cast<float*>(cur_s + 4);                  // [C * C] (WLDS): transitions INTO state i at wl[i * C + j]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (b >= B || T <= 0) return;
+  if (WLDS)
+    for (int i = tid; i < C * C; i += 256) wl[i] = nan_to_neg(W[C + i]);
+  if (tid < 64) {  // arg max of the last frame: the first maximum (lowest state)
+    const float* fin = alpha + ((int64_t)b * T + (T - 1)) * C;
+    float best = -__builtin_inff();
+    int arg = 0x3fffffff;
+    for (int i = tid; i < C; i += 64) {
+      const float v = fin[i];
+      if (v > best || arg == 0x3fffffff) best = v, arg = i;
+    }
+    const float m = wave_all_max(best);
+    arg = -wave_all_max_int(-(best == m ? arg : 0x3fffffff));
+    if (tid == 0) *cur_s = arg == 0x3fffffff ? 0 : arg;
+  }
+  const int rows_per_chunk = max(1, min(kVitChunkFloats / C, 1024));
+  int32_t* out = path + (int64_t)b * T;
+  const float* ab = alpha + (int64_t)b * T * C;
+  int jc[NJ];  // this lane's previous states, clamped (a clamped slot's weight is -inf)
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) jc[i] = min(lane + 64 * i, C - 1);
+  // the walk from frame t1 down to t0 + 1 reads the vectors of frames t1 - 1 .. t0 (frame -1: none, the walk ends);
+  // buffer k holds rows[k] = vector of frame t0 + k, k = 0 .. t1 - t0 - 1
+  auto fetch = [&](int t1, float* rows, int from, int step) {
+    const int t0 = max(t1 - rows_per_chunk, -1), first = max(t0, 0);
+    for (int i = from; i < (t1 - first) * C; i += step) rows[(first - t0) * C + i] = ab[(int64_t)first * C + i];
+  };
+  fetch(T - 1, rowbuf, tid, 256);
+  int which = 0;
+  for (int t1 = T - 1; t1 >= 0; t1 -= rows_per_chunk, which ^= 1) {
+    const int t0 = max(t1 - rows_per_chunk, -1);
+    const int nrow = t1 - t0;  // frames t0 + 1 .. t1 get their label
+    float* rows = rowbuf + which * (kVitChunkFloats + 256);
+    __syncthreads();
+    if (tid >= 64 && t0 >= 0) fetch(t0, rowbuf + (which ^ 1) * (kVitChunkFloats + 256), tid - 64, 192);
+    if (tid < 64) {
+      int cur = __builtin_amdgcn_readfirstlane(*cur_s);
+      float wr[NJ], pv[NJ];
+      int held = -1;
+      // (the vector a step adds to is requested a step ahead: its address does not depend on the state)
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) pv[i] = rows[max(t1 - 1 - t0, 0) * C + jc[i]];
+      for (int t = t1; t > t0; --t) {
+        if (lane == 0) walk[t - t0 - 1] = cur;
+        if (t == 0) break;
+        if (held != cur) {  // (wave-uniform)
+#pragma unroll
+          for (int i = 0; i < NJ; ++i) {
+            const float raw = WLDS ? wl[cur * C + jc[i]] : nan_to_neg(W[(int64_t)(1 + cur) * C + jc[i]]);
+            wr[i] = lane + 64 * i < C ? raw : WFL_NEG_INF;
+          }
+          held = cur;
+        }
+        float v[NJ], m = WFL_NEG_INF;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) v[i] = pv[i] + wr[i], m = vmax(m, v[i]);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) pv[i] = rows[max(t - 2 - t0, 0) * C + jc[i]];  // (the next step's; a spare read at the chunk's end)
+        const float top = wave_all_max(m);
+        // the lowest previous state that attains the maximum: slot by slot, the lowest lane of the first slot with a hit
+        int nxt = 0;
+#pragma unroll
+        for (int i = NJ - 1; i >= 0; --i) {
+          const unsigned long long hit = __ballot(v[i] == top);
+          nxt = hit ? 64 * i + (int)__builtin_ctzll(hit) : nxt;
+        }
+        cur = top > WFL_NEG_INF ? nxt : 0;  // unreachable state (all -inf): keep the path well-formed
+      }
+      if (lane == 0) *cur_s = cur;
+    }
+    __syncthreads();
+    for (int i = tid; i < nrow; i += 256) out[t0 + 1 + i] = walk[i];  // (the next chunk's walk starts behind the loop's first barrier)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // gradient
 // ------------------------------------------------------------------------------------------------
 template <int NP>
@@ -1349,7 +1538,7 @@ static int dense_fast_cp(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 104 
 // LDS-resident log-domain kernels serve what those flag, they fit up to 195).  Beyond, the frame of the whole batch is
 // dense_wide.h's product on the matrix cores, one launch per frame.  N = 150, B = 128, T = 1000: 0.88 ms per step with
 // the register-resident sweeps against 16.7 ms per-frame launches and 33.6 ms with one LDS-resident log-domain workgroup
-// per utterance (profiles/r05_asg_129_to_200_classes.txt; Viterbi stays on the LDS-resident kernel up to 195 classes).
+// per utterance (profiles/r05_asg_129_to_200_classes.txt; Viterbi: dense_viterbi_sweep_kernel, registers up to 256 classes).
 static bool dense_log_on_chip(int C) { return dense_fast_cp(C) != 0; }
 extern "C" int wfl_dense_on_chip_classes(void) {  // (the log semiring's limit: what sizes wfl_dense_workspace)
   int c = 1;
@@ -1549,6 +1738,56 @@ int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float
                       void* stream) {
   if (!path) {
     set_error("dense_viterbi: path is required");
+    return WFL_ERR_INVALID;
+  }
+  if (C <= 256) {
+    // transition rows in registers, no back-pointers (`bptr` is not written): dense_viterbi_sweep_kernel
+    if (int rc = dense_check(x, W, B, T, C, "dense_viterbi")) return rc;
+    if (!alpha) {
+      set_error("dense_viterbi: alpha is required");
+      return WFL_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // four lanes per state up to 128 classes (a quarter of the row each: half the per-frame work of a lane), two beyond
+    const int lanes = C <= 128 ? 4 : 2;
+    const unsigned nt = (unsigned)std::min(512, ((lanes * C + 63) / 64) * 64);
+#define WFL_VIT_SWEEP(SPAN, R) \
+  hipLaunchKernelGGL((dense_viterbi_sweep_kernel<SPAN, R>), dim3((unsigned)B), dim3(nt), 0, st, x, W, T, C, alpha)
+    if (C <= 32)
+      WFL_VIT_SWEEP(8, 4);
+    else if (C <= 64)
+      WFL_VIT_SWEEP(16, 4);
+    else if (C <= 112)
+      WFL_VIT_SWEEP(28, 4);
+    else if (C <= 128)
+      WFL_VIT_SWEEP(32, 4);
+    else if (C <= 192)
+      WFL_VIT_SWEEP(96, 2);
+    else
+      WFL_VIT_SWEEP(128, 2);
+#undef WFL_VIT_SWEEP
+    WFL_LAUNCH_CHECK();
+    const size_t fixed = 2 * ((size_t)kVitChunkFloats + 256) * 4 + 1024 * 4 + 16;
+    const bool wlds = fixed + (size_t)C * C * 4 <= (size_t)kLdsBytes;
+    const size_t lds = fixed + (wlds ? (size_t)C * C * 4 : 0);
+    auto launch_bt = [&](auto k) -> int {
+      if (lds > 48 * 1024) WFL_HIP_CHECK(wfl::set_max_dynamic_lds((const void*)k, (int)lds));
+      hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(256), lds, st, alpha, W, B, T, C, path);
+      return WFL_OK;
+    };
+    const int nj = (C + 63) / 64;
+    int rc = WFL_OK;
+    if (wlds)
+      rc = nj == 1 ? launch_bt(dense_viterbi_backtrace_kernel<true, 1>) : nj == 2 ? launch_bt(dense_viterbi_backtrace_kernel<true, 2>)
+           : nj == 3 ? launch_bt(dense_viterbi_backtrace_kernel<true, 3>) : launch_bt(dense_viterbi_backtrace_kernel<true, 4>);
+    else
+      rc = nj == 3 ? launch_bt(dense_viterbi_backtrace_kernel<false, 3>) : launch_bt(dense_viterbi_backtrace_kernel<false, 4>);
+    if (rc) return rc;
+    WFL_LAUNCH_CHECK();
+    return WFL_OK;
+  }
+  if (!bptr) {
+    set_error("dense_viterbi: beyond 256 classes the back-pointer buffer is required");
     return WFL_ERR_INVALID;
   }
   if (int rc = wfl_dense_forward(x, W, B, T, C, WFL_SEMIRING_TROPICAL, alpha, nullptr, bptr, nullptr, nullptr, stream))

@@ -1,7 +1,7 @@
 // Dense (fully connected) transitions for ANY class count (included by dense_kernels.hip, inside namespace wfl).
 //
 // criterions/asg.py:198-199 sizes `transitions` to any N; the kernels above keep the (N+1) x N matrix on chip (registers:
-// N <= 128 -- the log semiring's sweeps; LDS: N <= 195 -- their log-domain launches and Viterbi).  Beyond that the matrix is 4 N^2 bytes -- 4 MB at N = 1000 -- and cannot be private
+// N <= 192 -- the log semiring's sweeps, N <= 256 -- Viterbi; LDS: N <= 195 -- the log-domain launches).  Beyond that the matrix is 4 N^2 bytes -- 4 MB at N = 1000 -- and cannot be private
 // to a workgroup; but then the per-frame update of ALL utterances,
 //     alpha_t[b][i] = E_t[b][i] * sum_j P[i][j] alpha_{t-1}[b][j]        (beta: the transpose)
 // is a [N x N] x [N x B] matrix product that is worth sharing: the frame is ONE launch for the whole batch (both

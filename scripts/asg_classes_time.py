@@ -1,7 +1,10 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from gtn_applications_amd.criterions import asg
-for (B, T, C) in [(128, 1000, 100), (128, 1000, 129), (128, 1000, 150), (128, 1000, 190), (128, 1000, 200), (32, 250, 1000)]:
+SHAPES = [(128, 1000, 100), (128, 1000, 129), (128, 1000, 150), (128, 1000, 190), (128, 1000, 200), (32, 250, 1000)]
+if len(sys.argv) > 1:  # B,T,C [B,T,C ...]
+    SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for (B, T, C) in SHAPES:
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, T, C, generator=g).cuda().requires_grad_(True)
     W = torch.randn(C + 1, C, generator=g).cuda().requires_grad_(True)
