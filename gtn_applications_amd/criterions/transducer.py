@@ -281,7 +281,8 @@ class Transducer(torch.nn.Module):
         live (default: the current device)."""
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.tokens.arc_sort(True)
-        return PreparedTargets(targets, _prepare(targets, self.tokens, self.lexicon, self.transitions,
+        return PreparedTargets(targets, _prepare(targets, self.tokens, self.lexicon,
+                                                 _numerator_transitions(self.transitions, self._num_emission_classes),
                                                  self._num_emission_classes, dev, self.reduction), len(targets))
 
     @E.on_input_device
@@ -373,6 +374,34 @@ def _dense_bigram(transitions, C):
     return bool(ok)
 
 
+_NUM_TRANSITIONS = {}
+
+
+def _numerator_transitions(transitions, C):
+    """The transition graph the NUMERATOR's alignments are intersected with.  make_transitions_graph(2, C) reaches its
+    accepting node through one epsilon arc per history (transducer.py:32-58), so every alignment acceptor ends in an
+    epsilon arc -- and an acceptor with an epsilon arc is swept in the log domain by the general kernels (0.37 + 0.22 ms
+    at the n-gram benchmark's shape against 0.03 + 0.05 for the same acceptor without it).  That arc's score depends on
+    the LAST emitted label only (node 1 + c after label c), so it is the dense normaliser's trick again: the end arcs'
+    scores ride on the last frame's emissions (_bigram_dense_operands) and the graph loses its epsilon arcs -- every
+    node accepts instead.  Arcs 0 .. C + C^2 - 1 keep their indices: `transition_params` serves both graphs.  Anything
+    but the dense bigram: the graph itself."""
+    if transitions is None or not (_DENSE_NGRAM and _dense_bigram(transitions, C)):
+        return transitions
+    hit = _NUM_TRANSITIONS.get(id(transitions))
+    if hit is not None and hit[0] is transitions:
+        return hit[1]
+    a = transitions.arrays()
+    n1 = C + C * C
+    g = G.Graph(False)
+    g.add_nodes(np.asarray(a["start"]), np.ones(C + 2, dtype=np.asarray(a["accept"]).dtype))
+    g.add_arcs(np.asarray(a["src"])[:n1], np.asarray(a["dst"])[:n1], np.asarray(a["ilabel"])[:n1], np.asarray(a["olabel"])[:n1])
+    if len(_NUM_TRANSITIONS) > 64:
+        _NUM_TRANSITIONS.clear()
+    _NUM_TRANSITIONS[id(transitions)] = (transitions, g)
+    return g
+
+
 class _UnigramNormaliser:
     """forward_score(intersect(emissions, transitions)) (transducer.py:286-288) for make_transitions_graph(1, C): one
     start + accept node with a self-loop per token, so  log Z_b = sum_t logsumexp_c (x[b,t,c] + p_c)."""
@@ -460,14 +489,16 @@ class TransducerLossFunction(torch.autograd.Function):
         dev = E.require_gpu()
         x = E.as_device_f32(inputs.detach(), dev)
         params = E.as_device_f32(transition_params.detach(), dev) if transitions is not None else None
+        num_transitions = _numerator_transitions(transitions, C)  # (the bigram model without its end arcs: see there)
+        folded = num_transitions is not transitions
         if isinstance(targets, PreparedTargets):
             nb, entry = targets.result()
             pack = entry[0]
-            if pack.desc.B != B or pack.device != dev or entry[4] != (tokens, lexicon, transitions):
+            if pack.desc.B != B or pack.device != dev or entry[4] != (tokens, lexicon, num_transitions):
                 # prepared for other emissions (another device, another criterion): pack again, here
-                nb, entry = _pack_entry(targets.targets, tokens, lexicon, transitions, C, dev, reduction)
+                nb, entry = _pack_entry(targets.targets, tokens, lexicon, num_transitions, C, dev, reduction)
         else:
-            nb, entry = _pack_entry(targets, tokens, lexicon, transitions, C, dev, reduction)
+            nb, entry = _pack_entry(targets, tokens, lexicon, num_transitions, C, dev, reduction)
         if nb != B:
             raise ValueError(f"got {nb} targets for a batch of {B}")
         pack, scale, cpos, cneg, _ = entry
@@ -502,6 +533,11 @@ class TransducerLossFunction(torch.autograd.Function):
                 if ctx.eager_take is not None:
                     E.watch_node_hooks(ctx)
             return loss if inputs.is_cuda else loss.cpu()
+        x_num = x
+        bigram_ops = None
+        if folded:  # (both sweeps read the emissions with the end arcs' scores on the last frame: before the fork)
+            bigram_ops = _bigram_dense_operands(x, params, C)
+            x_num = bigram_ops[0]
         if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288
             # independent of the numerator sweep: forked onto a second stream so that the two overlap
             with E.side_stream(dev) as fork:
@@ -511,7 +547,7 @@ class TransducerLossFunction(torch.autograd.Function):
                     den = _UnigramNormaliser(x, params)
                     dense = "unigram"
                 elif _DENSE_NGRAM and _dense_bigram(transitions, C):
-                    xd, Wd = _bigram_dense_operands(x, params, C)
+                    xd, Wd = bigram_ops if bigram_ops is not None else _bigram_dense_operands(x, params, C)
                     den = E.dense_forward(xd, Wd, need_beta=need_grad)
                     dense = (xd, Wd)
                 else:
@@ -524,7 +560,7 @@ class TransducerLossFunction(torch.autograd.Function):
             dx_early = torch.empty_like(x)
         E._PHASE_FORCE = timed
         try:
-            num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax,
+            num = E.lattice_forward(x_num, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax,
                                     grad_into=(cneg, dx_early) if dx_early is not None else None, defer_join=True)
         finally:
             E._PHASE_FORCE = False
@@ -543,6 +579,7 @@ class TransducerLossFunction(torch.autograd.Function):
         if num.in_launch:
             E.lattice_side_join()  # (behind the loss reduction: it ran under the tail of the gradient beside the sweeps)
         ctx.aux = (x, params, num, den, cpos, cneg, dense)
+        ctx.folded = folded
         ctx.early = None
         ctx.devices = (inputs.device, None if transition_params is None else transition_params.device)
         if dx_early is not None:
@@ -588,8 +625,15 @@ class TransducerLossFunction(torch.autograd.Function):
             if dW is not None:
                 dW[:C] = dWd[0]
                 dW[C:C + C * C] = dWd[1:].t().reshape(-1)
-                dW[C + C * C + 1:] = ddx[:, -1, :].sum(dim=0)
-            E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=True, dW=dW)
+            if getattr(ctx, "folded", False):
+                # the numerator read the same emissions: its end arcs' gradient is in its last frame's rows too
+                E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=ddx, accumulate=True, dW=dW)
+                if dW is not None:
+                    dW[C + C * C + 1:] = ddx[:, -1, :].sum(dim=0)
+            else:
+                if dW is not None:
+                    dW[C + C * C + 1:] = ddx[:, -1, :].sum(dim=0)
+                E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=True, dW=dW)
         elif dx is not None or dW is not None:
             E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=False, dW=dW)
             if den is not None:

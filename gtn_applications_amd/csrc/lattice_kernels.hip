@@ -2170,7 +2170,9 @@ __global__ void __launch_bounds__(256)
   float* xr = (float*)(bed + (size_t)(TS + 1) * d.max_states);  // [TS][Kmax]: log scores | factors
   float* acc = xr + (size_t)TS * Kmax;                      // [TS][Kmax] (only if dx)
   float* dwacc = acc + (dx ? (size_t)TS * Kmax : 0);        // [A + E] (only if dW)
-  int2* sarc = (int2*)(dwacc + (dW ? (size_t)d.max_arcs + d.max_eps : 0));  // [A] by-slot {src | dst << 16, w - z}
+  const size_t nae = (size_t)d.max_arcs + d.max_eps;
+  int* lead = (int*)(dwacc + (dW ? nae : 0));               // [A + E, rounded up to even] (only if dW): first arc with the same weight id
+  int2* sarc = (int2*)(lead + (dW ? ((nae + 1) & ~(size_t)1) : 0));  // [A] by-slot {src | dst << 16, w - z}
   int* sptr = (int*)(sarc + (dx ? d.max_arcs : 0));         // [K + 1]
   // work items of the emission gradient: a slot's arc list in chunks of at most kChunk arcs, so that
   // the blank column of a CTC-like acceptor (two in-arcs per blank state: hundreds of arcs in ONE
@@ -2208,17 +2210,44 @@ __global__ void __launch_bounds__(256)
   const int t_end = min(T, t_begin + rows_per_block);
   const float inv_q = 1.f / (float)max(Q, 1);
   auto fdiv = [](int i, float inv) { return (int)(((float)i + 0.5f) * inv); };
-  if (dW)
+  if (dW) {
+    // Arcs that share a learnable weight (every blank self-loop of a CTC-like alignment under a bigram model: 45 per
+    // utterance at the n-gram benchmark) are summed HERE before anything goes to the global gradient: with one global
+    // atomic per arc, 21 600 of a launch's 106 000 landed on ONE address and the launch took 173 us for 9 us of work
+    // (same-address atomics are served one after the other: ~8 ns each).  lead[a]: the first arc with a's weight id.
+    int* widc = reinterpret_cast<int*>(dwacc);  // (the ids, for the search; zeroed below)
+    for (int a = tid; a < A + E; a += NT) widc[a] = a < A ? u.arc_wid[a] : u.eps_wid[a - A];
+    __syncthreads();
+    const bool search = A + E <= 1024;  // (quadratic in the arc count: beyond, every arc is its own leader)
+    for (int a = tid; a < A + E; a += NT) {
+      int l = a;
+      if (search) {
+        const int wid = widc[a];
+        for (int c = 0; c < a; ++c)
+          if (widc[c] == wid) {
+            l = c;
+            break;
+          }
+      }
+      lead[a] = l;
+    }
+    __syncthreads();
     for (int a = tid; a < A + E; a += NT) dwacc[a] = 0.f;
+  }
   if (dx) {
     for (int c = tid; c < C; c += NT) colmap[c] = -1;
     __syncthreads();
     for (int k = tid; k < K; k += NT) colmap[u.labels[k]] = (int16_t)k;
     for (int k = tid; k <= K; k += NT) sptr[k] = u.slot_ptr[k];
-    if (tid == 0) {  // chunk table (a few hundred entries at most, once per workgroup)
+    __syncthreads();
+    if (tid == 0) {  // chunk table (a few hundred entries at most, once per workgroup) -- from the LDS copy of the slot
+                     // pointers: read from global memory here, every slot was two dependent round trips of ONE thread
+                     // (K = 83 labels: ~150 of the kernel's 208 us at the n-gram benchmark's shape)
       int nc = 0;
-      for (int k = 0; k < K; ++k)
-        for (int a0 = u.slot_ptr[k]; a0 < u.slot_ptr[k + 1]; a0 += kChunk) chunk[nc++] = make_int2(k, a0);
+      for (int k = 0; k < K; ++k) {
+        const int a1 = sptr[k + 1];
+        for (int a0 = sptr[k]; a0 < a1; a0 += kChunk) chunk[nc++] = make_int2(k, a0);
+      }
       sptr[Kmax + 1] = nc;
     }
     for (int j = tid; j < A; j += NT) {
@@ -2349,8 +2378,15 @@ __global__ void __launch_bounds__(256)
   }
   if (dW) {
     __syncthreads();
+    for (int a = tid; a < A + E; a += NT) {
+      const int l = lead[a];
+      const float g = dwacc[a];
+      if (l != a && g != 0.f) atomicAdd(&dwacc[l], g);  // (LDS; leaders are only added to, the others only read)
+    }
+    __syncthreads();
     const float cw = (coef_w ? coef_w[b] : 1.f) * g0;
     for (int a = tid; a < A + E; a += NT) {
+      if (lead[a] != a) continue;
       const int wid = a < A ? u.arc_wid[a] : u.eps_wid[a - A];
       const float g = dwacc[a];
       if (wid >= 0 && g != 0.f) atomicAdd(&dW[wid], g * cw);
@@ -3124,7 +3160,8 @@ static int lattice_grad_impl(const wfl_lattice_desc* d, const int32_t* ints, con
   // (kernel us at 24 / 32 / 40 / 48 KiB): Transducer cfg4 (263 states, 917 arcs: ONE frame per tile at 24 KiB)
   // 301 / 230 / 239 / 283; ASG force alignment alone 81 / 112 / 78 / 78, under the denominator sweeps 220 / 198 / 174.
   const size_t row_bytes = 16 * (size_t)d->max_states + 4 * (size_t)d->max_labels * (dx ? 2 : 1);  // (alpha, beta: doubles)
-  const size_t fixed = 16 * (size_t)d->max_states + 4 * (dW ? (size_t)d->max_arcs + d->max_eps : 0) +
+  const size_t nae = (size_t)d->max_arcs + d->max_eps;  // (learnable-weight accumulators + the arcs' leaders: grad_kernel)
+  const size_t fixed = 16 * (size_t)d->max_states + (dW ? 4 * nae + 4 * ((nae + 1) & ~(size_t)1) : 0) +
                        (dx ? 8 * (size_t)d->max_arcs + 4 * (((size_t)d->max_labels + 3) & ~(size_t)1) +
                                 8 * ((size_t)d->max_labels + d->max_arcs / kChunk + 1) + 2 * (size_t)C
                           : 0) +
