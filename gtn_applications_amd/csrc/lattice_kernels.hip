@@ -2533,6 +2533,7 @@ __global__ void __launch_bounds__(256)
     }
   }
   if (dW && !dead && lane < Q) {
+    // (measured at the ASG benchmark with these two compiled out: the kernel and the step do not change)
     if (arcs.wid_self >= 0 && sum_s != 0.0) atomicAdd(&dW[arcs.wid_self], (float)sum_s * cw);
     if (arcs.wid_adj >= 0 && sum_a != 0.0) atomicAdd(&dW[arcs.wid_adj], (float)sum_a * cw);
   }

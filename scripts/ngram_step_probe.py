@@ -49,4 +49,4 @@ if len(sys.argv) > 3:
         step()
     pr.disable()
     torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(45)
