@@ -108,6 +108,18 @@ class _EarlyGrads:
         return [(t, g) for t, g in ((self.inputs, dx), (self.transitions, dW)) if g is not None]
 
 
+class PackedNumerator:
+    """A numerator lattice packed elsewhere, in the place of ASGLoss's `targets`: acceptors whose learnable arc weights
+    index `transitions` row-major, with the loss factors (scale, +scale/B, -scale/B) that travel with them.  What the
+    Transducer with the bigram transition model hands over (criterions/transducer.py::_bigram_route): its loss IS
+    forward_score(emissions o transitions) - forward_score(emissions o alignments o transitions), the ASG step."""
+
+    __slots__ = ("pack", "scale", "cpos", "cneg", "B")
+
+    def __init__(self, pack, scale, cpos, cneg, B):
+        self.pack, self.scale, self.cpos, self.cneg, self.B = pack, scale, cpos, cneg, B
+
+
 class ASGLossFunction(torch.autograd.Function):
     @staticmethod
     def create_transitions_graph(transitions, calc_grad=False):
@@ -154,13 +166,18 @@ class ASGLossFunction(torch.autograd.Function):
         dev = E.require_gpu()
         x = E.as_device_f32(inputs.detach(), dev)
         W = E.as_device_f32(transitions.detach(), dev)
-        tg = E.targets_on_device(targets, dev)
-        if tg.B != B:
-            raise ValueError(f"got {tg.B} targets for a batch of {B}")
-        scale, cpos, cneg = E.loss_factors(tg, reduction)
-        pack = tg.cache.get(("asg_fal", C))
-        if pack is None:
-            pack = tg.cache[("asg_fal", C)] = E.PackedLattice.asg_force_align(tg.flat, tg.offsets, C, dev)
+        if isinstance(targets, PackedNumerator):
+            if targets.B != B:
+                raise ValueError(f"got {targets.B} targets for a batch of {B}")
+            tg, pack, scale, cpos, cneg = None, targets.pack, targets.scale, targets.cpos, targets.cneg
+        else:
+            tg = E.targets_on_device(targets, dev)
+            if tg.B != B:
+                raise ValueError(f"got {tg.B} targets for a batch of {B}")
+            scale, cpos, cneg = E.loss_factors(tg, reduction)
+            pack = tg.cache.get(("asg_fal", C))
+            if pack is None:
+                pack = tg.cache[("asg_fal", C)] = E.PackedLattice.asg_force_align(tg.flat, tg.offsets, C, dev)
         need_dx, need_dw = inputs.requires_grad, transitions.requires_grad
         need_grad = need_dx or need_dw
         node = _native_node()

@@ -378,28 +378,81 @@ _NUM_TRANSITIONS = {}
 
 
 def _numerator_transitions(transitions, C):
-    """The transition graph the NUMERATOR's alignments are intersected with.  make_transitions_graph(2, C) reaches its
-    accepting node through one epsilon arc per history (transducer.py:32-58), so every alignment acceptor ends in an
-    epsilon arc -- and an acceptor with an epsilon arc is swept in the log domain by the general kernels (0.37 + 0.22 ms
-    at the n-gram benchmark's shape against 0.03 + 0.05 for the same acceptor without it).  That arc's score depends on
-    the LAST emitted label only (node 1 + c after label c), so it is the dense normaliser's trick again: the end arcs'
-    scores ride on the last frame's emissions (_bigram_dense_operands) and the graph loses its epsilon arcs -- every
-    node accepts instead.  Arcs 0 .. C + C^2 - 1 keep their indices: `transition_params` serves both graphs.  Anything
-    but the dense bigram: the graph itself."""
+    """The transition graph the NUMERATOR's alignments are intersected with when the Transducer carries the dense
+    bigram model (_bigram_route).  make_transitions_graph(2, C) reaches its accepting node through one epsilon arc per
+    history (transducer.py:32-58), so every alignment acceptor ends in an epsilon arc -- and an acceptor with an epsilon
+    arc is swept in the log domain by the general kernels (0.37 + 0.22 ms at the n-gram benchmark's shape against
+    0.05 + 0.07 for the same acceptor without it).  That arc's score depends on the LAST emitted label only (node 1 + c
+    after label c), so it is the dense normaliser's trick again: the end arcs' scores ride on the last frame's emissions
+    and the graph loses its epsilon arcs -- every node accepts instead.  The remaining arcs are laid out like the dense
+    engine's matrix W [(C+1), C] row-major (include/wfl.h): arc c = start -> c, arc (1 + b) C + a = bigram a -> b, so that
+    numerator and normaliser read their weights from ONE tensor, as ASG's do.  Anything but the dense bigram: the graph
+    itself."""
     if transitions is None or not (_DENSE_NGRAM and _dense_bigram(transitions, C)):
         return transitions
     hit = _NUM_TRANSITIONS.get(id(transitions))
     if hit is not None and hit[0] is transitions:
         return hit[1]
     a = transitions.arrays()
-    n1 = C + C * C
+    idx = np.arange(C, dtype=np.int32)
+    prev = np.tile(idx, C)    # a: fastest
+    cur = np.repeat(idx, C)   # b
+    src = np.concatenate([np.zeros(C, np.int32), 1 + prev])
+    dst = np.concatenate([1 + idx, 1 + cur])
+    lab = np.concatenate([idx, cur])
     g = G.Graph(False)
     g.add_nodes(np.asarray(a["start"]), np.ones(C + 2, dtype=np.asarray(a["accept"]).dtype))
-    g.add_arcs(np.asarray(a["src"])[:n1], np.asarray(a["dst"])[:n1], np.asarray(a["ilabel"])[:n1], np.asarray(a["olabel"])[:n1])
+    g.add_arcs(src, dst, lab, lab)
     if len(_NUM_TRANSITIONS) > 64:
         _NUM_TRANSITIONS.clear()
     _NUM_TRANSITIONS[id(transitions)] = (transitions, g)
     return g
+
+
+def _numerator_entry(targets, tokens, lexicon, graph, C, dev, reduction, B):
+    """The packed alignment acceptors of a batch (their cache entry): from a PreparedTargets handle if it was made for
+    this criterion and device, else packed here."""
+    if isinstance(targets, PreparedTargets):
+        nb, entry = targets.result()
+        pack = entry[0]
+        if pack.desc.B != B or pack.device != dev or entry[4] != (tokens, lexicon, graph):
+            # prepared for other emissions (another device, another criterion): pack again, here
+            nb, entry = _pack_entry(targets.targets, tokens, lexicon, graph, C, dev, reduction)
+    else:
+        nb, entry = _pack_entry(targets, tokens, lexicon, graph, C, dev, reduction)
+    if nb != B:
+        raise ValueError(f"got {nb} targets for a batch of {B}")
+    pack = entry[0]
+    up = getattr(pack, "_uploaded", None)
+    if up is not None and up[0] != E.stream_ptr() and not getattr(pack, "_seen_here", None) == E.stream_ptr():
+        # uploaded on another stream (the prefetch thread's, or an earlier step's): its memory stays this stream's too
+        pack._blob.record_stream(torch.cuda.current_stream())
+        pack._seen_here = E.stream_ptr()
+    return entry
+
+
+def _bigram_route(inputs, targets, tokens, lexicon, transition_params=None, transitions=None, reduction="none"):
+    """TransducerLoss with the dense bigram model as the ASG step it is (None: not that case).  Emissions with the end
+    arcs' scores on the last frame and the matrix W of the dense engine are formed from `transition_params` =
+    [start C | bigram a -> b at C + a C + b | end arcs of nodes 0 .. C] by differentiable torch ops -- autograd maps the
+    two gradients back -- and ASGLoss (one native call: csrc/torch_ops.cpp::asg_forward) does the rest."""
+    if transitions is None or transition_params is None or inputs.dim() != 3:
+        return None
+    B, T, C = inputs.shape
+    if T == 0 or not (_DENSE_NGRAM and _dense_bigram(transitions, C)) or transition_params.numel() != C + C * C + C + 1:
+        return None
+    from . import asg as _asg
+
+    dev = E.require_gpu()
+    x = inputs if inputs.dtype == torch.float32 else inputs.float()
+    p = transition_params.to(device=x.device, dtype=torch.float32)
+    n1 = C + C * C
+    Wd = torch.cat([p[:C].view(1, C), p[C:n1].view(C, C).t()], dim=0)
+    xd = torch.cat([x[:, :-1], x[:, -1:] + p[n1 + 1:]], dim=1)
+    with torch.cuda.device(dev):
+        pack, scale, cpos, cneg, _ = _numerator_entry(targets, tokens, lexicon, _numerator_transitions(transitions, C), C, dev,
+                                                       reduction, B)
+    return _asg.ASGLoss(xd, Wd, _asg.PackedNumerator(pack, scale, cpos, cneg, B), "none")
 
 
 class _UnigramNormaliser:
@@ -489,24 +542,7 @@ class TransducerLossFunction(torch.autograd.Function):
         dev = E.require_gpu()
         x = E.as_device_f32(inputs.detach(), dev)
         params = E.as_device_f32(transition_params.detach(), dev) if transitions is not None else None
-        num_transitions = _numerator_transitions(transitions, C)  # (the bigram model without its end arcs: see there)
-        folded = num_transitions is not transitions
-        if isinstance(targets, PreparedTargets):
-            nb, entry = targets.result()
-            pack = entry[0]
-            if pack.desc.B != B or pack.device != dev or entry[4] != (tokens, lexicon, num_transitions):
-                # prepared for other emissions (another device, another criterion): pack again, here
-                nb, entry = _pack_entry(targets.targets, tokens, lexicon, num_transitions, C, dev, reduction)
-        else:
-            nb, entry = _pack_entry(targets, tokens, lexicon, num_transitions, C, dev, reduction)
-        if nb != B:
-            raise ValueError(f"got {nb} targets for a batch of {B}")
-        pack, scale, cpos, cneg, _ = entry
-        up = getattr(pack, "_uploaded", None)
-        if up is not None and up[0] != E.stream_ptr() and not getattr(pack, "_seen_here", None) == E.stream_ptr():
-            # uploaded on another stream (the prefetch thread's, or an earlier step's): its memory stays this stream's too
-            pack._blob.record_stream(torch.cuda.current_stream())
-            pack._seen_here = E.stream_ptr()
+        pack, scale, cpos, cneg, _ = _numerator_entry(targets, tokens, lexicon, transitions, C, dev, reduction, B)
         need_grad = inputs.requires_grad or (transition_params is not None and transition_params.requires_grad)
         den = dense = None
         node = _native_node() if transitions is None else None
@@ -533,11 +569,6 @@ class TransducerLossFunction(torch.autograd.Function):
                 if ctx.eager_take is not None:
                     E.watch_node_hooks(ctx)
             return loss if inputs.is_cuda else loss.cpu()
-        x_num = x
-        bigram_ops = None
-        if folded:  # (both sweeps read the emissions with the end arcs' scores on the last frame: before the fork)
-            bigram_ops = _bigram_dense_operands(x, params, C)
-            x_num = bigram_ops[0]
         if transitions is not None:  # normaliser: forward_score(emissions o transitions), transducer.py:286-288
             # independent of the numerator sweep: forked onto a second stream so that the two overlap
             with E.side_stream(dev) as fork:
@@ -547,7 +578,7 @@ class TransducerLossFunction(torch.autograd.Function):
                     den = _UnigramNormaliser(x, params)
                     dense = "unigram"
                 elif _DENSE_NGRAM and _dense_bigram(transitions, C):
-                    xd, Wd = bigram_ops if bigram_ops is not None else _bigram_dense_operands(x, params, C)
+                    xd, Wd = _bigram_dense_operands(x, params, C)
                     den = E.dense_forward(xd, Wd, need_beta=need_grad)
                     dense = (xd, Wd)
                 else:
@@ -560,7 +591,7 @@ class TransducerLossFunction(torch.autograd.Function):
             dx_early = torch.empty_like(x)
         E._PHASE_FORCE = timed
         try:
-            num = E.lattice_forward(x_num, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax,
+            num = E.lattice_forward(x, pack, weights=params, need_beta=need_grad, log_softmax=log_softmax,
                                     grad_into=(cneg, dx_early) if dx_early is not None else None, defer_join=True)
         finally:
             E._PHASE_FORCE = False
@@ -579,7 +610,6 @@ class TransducerLossFunction(torch.autograd.Function):
         if num.in_launch:
             E.lattice_side_join()  # (behind the loss reduction: it ran under the tail of the gradient beside the sweeps)
         ctx.aux = (x, params, num, den, cpos, cneg, dense)
-        ctx.folded = folded
         ctx.early = None
         ctx.devices = (inputs.device, None if transition_params is None else transition_params.device)
         if dx_early is not None:
@@ -625,15 +655,9 @@ class TransducerLossFunction(torch.autograd.Function):
             if dW is not None:
                 dW[:C] = dWd[0]
                 dW[C:C + C * C] = dWd[1:].t().reshape(-1)
-            if getattr(ctx, "folded", False):
-                # the numerator read the same emissions: its end arcs' gradient is in its last frame's rows too
-                E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=ddx, accumulate=True, dW=dW)
-                if dW is not None:
-                    dW[C + C * C + 1:] = ddx[:, -1, :].sum(dim=0)
-            else:
-                if dW is not None:
-                    dW[C + C * C + 1:] = ddx[:, -1, :].sum(dim=0)
-                E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=True, dW=dW)
+            if dW is not None:
+                dW[C + C * C + 1:] = ddx[:, -1, :].sum(dim=0)
+            E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=True, dW=dW)
         elif dx is not None or dW is not None:
             E.lattice_grad(num, cneg, coef_w=cneg, gout=gout, dx=dx, accumulate=False, dW=dW)
             if den is not None:
@@ -680,6 +704,9 @@ _IN_LAUNCH_GRAD = os.environ.get("WFL_TRANSDUCER_IN_LAUNCH_GRAD", "1") != "0"  #
 
 def TransducerLoss(*args):
     """transducer.py:346 (`TransducerLoss = TransducerLossFunction.apply`): same call, same result."""
+    routed = _bigram_route(*args)
+    if routed is not None:
+        return routed
     return E.make_eager(TransducerLossFunction.apply(*args))
 
 
