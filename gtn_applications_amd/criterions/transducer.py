@@ -388,6 +388,8 @@ def _numerator_transitions(transitions, C):
     engine's matrix W [(C+1), C] row-major (include/wfl.h): arc c = start -> c, arc (1 + b) C + a = bigram a -> b, so that
     numerator and normaliser read their weights from ONE tensor, as ASG's do.  Anything but the dense bigram: the graph
     itself."""
+    if transitions is not None and _DENSE_NGRAM and transitions.num_nodes() == 1 and _dense_unigram(transitions, C):
+        return None  # (the unigram model's scores are added to the emissions: _unigram_route)
     if transitions is None or not (_DENSE_NGRAM and _dense_bigram(transitions, C)):
         return transitions
     hit = _NUM_TRANSITIONS.get(id(transitions))
@@ -702,11 +704,28 @@ class _EarlyGrad:
 _IN_LAUNCH_GRAD = os.environ.get("WFL_TRANSDUCER_IN_LAUNCH_GRAD", "1") != "0"  # (0: gradient in backward -- A/B, tests)
 
 
+def _unigram_route(inputs, targets, tokens, lexicon, transition_params=None, transitions=None, reduction="none"):
+    """TransducerLoss with the unigram model (make_transitions_graph(1, C): one node, a self-loop per label) as the
+    transition-free step on other emissions (None: not that case).  Every arc with label c carries p_c in numerator and
+    normaliser alike, so with x' = x + p the normaliser is  sum_t logsumexp_c x'[t]  and the loss is the negated
+    numerator score of log_softmax(x') -- the fused log_softmax criterion (one native call, the gradient beside the
+    sweeps); autograd sums the emission gradient over (b, t) into `transition_params`."""
+    if transitions is None or transition_params is None or inputs.dim() != 3 or not _DENSE_NGRAM:
+        return None
+    C = inputs.shape[2]
+    if inputs.shape[1] == 0 or transition_params.numel() != C or not _dense_unigram(transitions, C):
+        return None
+    x = inputs if inputs.dtype == torch.float32 else inputs.float()
+    p = transition_params.to(device=x.device, dtype=torch.float32)
+    return E.make_eager(_FusedLogSoftmaxTransducerLoss.apply(x + p, targets, tokens, lexicon, None, None, reduction))
+
+
 def TransducerLoss(*args):
     """transducer.py:346 (`TransducerLoss = TransducerLossFunction.apply`): same call, same result."""
-    routed = _bigram_route(*args)
-    if routed is not None:
-        return routed
+    for route in (_bigram_route, _unigram_route):
+        routed = route(*args)
+        if routed is not None:
+            return routed
     return E.make_eager(TransducerLossFunction.apply(*args))
 
 
