@@ -48,6 +48,10 @@
 #ifndef WFL_MITM_LEAN
 #define WFL_MITM_LEAN 1  // the chain wave's complete blocks: 1 the factor reads between the frames, 0 plain blocks only (A/B)
 #endif
+#ifndef WFL_MITM_LSM_ROWS
+#define WFL_MITM_LSM_ROWS 8  // fused log_softmax: rows of a block written out per pass (4: quarters -- 1 % slower at the module's cfg2 shape)
+#endif
+constexpr int kLsmRows = WFL_MITM_LSM_ROWS;
 #ifndef WFL_MITM_STATS
 #define WFL_MITM_STATS 0  // 1: per-wave wait / busy cycle counts in the workspace (scratch/mitm_stats.py)
 #endif
@@ -398,23 +402,27 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
       }
     };
     if (LSM) {
-      // in two halves of eight rows (the raw rows of all sixteen in registers next to the tile's spilled 64 of them):
+      // in WFL_MITM_LSM_ROWS rows at a time (8: two halves; the raw rows of all sixteen in registers next to the tile spill 64 of them):
       // the half's raw rows requested first (clamped to the block's rows), consumed behind its tile reads
+      // (the raw rows' stride through an opaque asm: their per-lane addresses are then formed HERE -- hoisted above the
+      // block's recursion they were four 64-bit values per lane held across it, spilled to scratch)
+      int Cx = C;
+      asm volatile("" : "+s"(Cx));
 #pragma unroll
-      for (int h8 = 0; h8 < kBlk; h8 += kBlk / 2) {
-        nf4 xv[kBlk / 4], v[kBlk / 4];
+      for (int h8 = 0; h8 < kBlk; h8 += kLsmRows) {
+        nf4 xv[kLsmRows / 2], v[kLsmRows / 2];
 #pragma unroll
-        for (int r = 0; r < kBlk / 2; r += 2)
-          xv[r >> 1] = *((const nf4*)(xsrc + (int64_t)min(h8 + r + half, nrows - 1) * C) + (act ? c4 : 0));
+        for (int r = 0; r < kLsmRows; r += 2)
+          xv[r >> 1] = *((const nf4*)(xsrc + (int64_t)min(h8 + r + half, nrows - 1) * Cx) + (act ? c4 : 0));
         asm volatile("" ::: "memory");  // (the tile was written through float pointers)
 #pragma unroll
-        for (int r = 0; r < kBlk / 2; r += 2) {
+        for (int r = 0; r < kLsmRows; r += 2) {
           const float4 q = src[((h8 + r) >> 1) * (kMTile / 2)];
           v[r >> 1] = nf4{q.x, q.y, q.z, q.w};
         }
         if (soft) {
 #pragma unroll
-          for (int r = 0; r < kBlk / 2; r += 2) {
+          for (int r = 0; r < kLsmRows; r += 2) {
             const float l0 = readlane_f(lse_rows, h8 + r), l1 = readlane_f(lse_rows, h8 + r + 1);
             const float l = half ? l1 : l0;
             nf4& o = v[r >> 1];
@@ -423,7 +431,7 @@ __device__ __forceinline__ void ctc_mitm_emit_block(const mv2f (&F)[kBlk], mv2f 
           }
         }
 #pragma unroll
-        for (int r = 0; r < kBlk / 2; r += 2) store(h8 + r, v[r >> 1]);
+        for (int r = 0; r < kLsmRows; r += 2) store(h8 + r, v[r >> 1]);
       }
     } else {
       // all the tile reads first, then the stores: a store waits for its own read only (the stores are volatile asm: the
