@@ -3007,7 +3007,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
       // label acceptors without epsilon arcs, full 16-frame chunks (the sweeps' publication counts on them).
       // WFL_LATTICE_FUSED_BADXCD=1: every utterance is reported as swept on two XCDs (tests of the fall-back).
       constexpr int fused_env = 1;
-      constexpr int fused_tile = 32;  // frames per gradient job
+      constexpr int fused_tile = 32;  // frames per gradient job (16 / 24 / 48 re-measured in round 5 with the sweeps at 160 us: all within 1 %)
       // persistent gradient workgroups per CU: as many as are resident at once (four waves of 130 VGPRs each: three per
       // CU).  More only queue behind those and start when the jobs are gone; measured at the Transducer benchmark with
       // the sweeps at 160 us: 2 -> 0.399 ms, 3 -> 0.362, 4 -> 0.364, 5 (the value until then) -> 0.369, 8 -> 0.37
