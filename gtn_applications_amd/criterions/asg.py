@@ -52,6 +52,31 @@ def unpack_replabels(tokens, num_replabels):
     return out
 
 
+def collapse_and_unpack(paths, garbage_idx, num_replabels):
+    """asg.py:228-234 for a whole batch (numpy [B,T] label paths): repeats collapsed, the garbage label dropped,
+    replabels unpacked (unpack_replabels above: a replabel r right behind a label repeats that label r + 1 times, any
+    other replabel is dropped) -- as array operations instead of a Python loop over 128 x 1000 labels.
+    Returns a list of B torch.IntTensor."""
+    import numpy as np
+
+    B = paths.shape[0]
+    flat, lens = E.collapse_rows(paths, drop=garbage_idx)
+    R = num_replabels
+    is_lab = flat >= R
+    prev_lab = np.zeros(len(flat), dtype=bool)
+    prev_lab[1:] = is_lab[:-1]
+    starts = np.zeros(B, dtype=np.int64)
+    np.cumsum(lens[:-1], out=starts[1:])
+    prev_lab[starts[lens > 0]] = False  # (a row's first token has no predecessor)
+    prev_tok = np.roll(flat, 1)
+    counts = np.where(is_lab, 1, np.where(prev_lab, flat + 1, 0)).astype(np.int64)
+    values = np.where(is_lab, flat, prev_tok) - R
+    out = np.repeat(values, counts).astype(np.int32)
+    rows = np.repeat(np.arange(B), lens)
+    out_lens = np.bincount(rows, weights=counts, minlength=B).astype(np.int64)
+    return E.split_rows(out, out_lens, torch.int32)
+
+
 _NODE = False
 _PHASES = ("lattice_gather", "lattice_chain", "lattice_grad", "dense_chain", "dense_grad")
 
@@ -324,11 +349,5 @@ class ASG(torch.nn.Module):
         dev = E.require_gpu()
         x = E.as_device_f32(outputs.detach(), dev)
         W = E.as_device_f32(self.transitions.detach(), dev)
-        paths = E.dense_viterbi(x, W).cpu().tolist()
-        predictions = []
-        for path in paths:
-            collapsed = [p for p, _ in itertools.groupby(path)]
-            if self.garbage_idx is not None:
-                collapsed = [p for p in collapsed if p != self.garbage_idx]
-            predictions.append(torch.IntTensor(unpack_replabels(collapsed, self.num_replabels)))
-        return predictions
+        paths = E.dense_viterbi(x, W).cpu().numpy()
+        return collapse_and_unpack(paths, self.garbage_idx, self.num_replabels)

@@ -231,12 +231,6 @@ class CTC(torch.nn.Module):
 
     def viterbi(self, outputs):
         """Greedy decode (ctc.py:126-135): argmax, collapse repeats, drop blank."""
-        best = torch.argmax(outputs, dim=2).to("cpu")
-        result = []
-        for row in best:
-            if row.numel():
-                keep = torch.ones_like(row, dtype=torch.bool)
-                keep[1:] = row[1:] != row[:-1]
-                row = row[keep]
-            result.append(row[row != self.blank])
-        return result
+        best = torch.argmax(outputs, dim=2).to("cpu").numpy()
+        flat, lens = E.collapse_rows(best, drop=self.blank)  # (the whole batch at once: no loop over the rows)
+        return E.split_rows(flat, lens, torch.int64)

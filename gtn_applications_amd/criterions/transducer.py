@@ -338,7 +338,7 @@ class Transducer(torch.nn.Module):
         # ambiguous decodings: the shortest wins (transducer.py:226-228)
         out, out_off = G.transducer_decode_batch(self.tokens, labels, offsets)
         flat = torch.from_numpy(out)  # (int32: torch.IntTensor, as transducer.py:233)
-        return [flat[out_off[b]:out_off[b + 1]].clone() for b in range(B)]
+        return list(torch.split(flat, np.diff(out_off).tolist()))  # (views of one tensor: one call instead of B slices + clones)
 
 
 _BIGRAM_SEEN = {}

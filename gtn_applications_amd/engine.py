@@ -919,6 +919,28 @@ def row_lse(x):
     return out
 
 
+def collapse_rows(paths, drop=None):
+    """The collapse every criterion's viterbi ends with (ctc.py:130-134, asg.py:228-233), for a whole batch at once:
+    rows of `paths` (numpy [B,T] ints) with runs of equal labels reduced to one label, then the entries equal to `drop`
+    removed.  Returns (flat values, row-major; lengths [B]) -- a Python loop over the rows costs milliseconds at a
+    benchmark batch (128 rows of 1000 frames), this costs tens of microseconds."""
+    import numpy as np
+
+    B, T = paths.shape
+    keep = np.ones((B, T), dtype=bool)
+    if T > 1:
+        np.not_equal(paths[:, 1:], paths[:, :-1], out=keep[:, 1:])
+    if drop is not None:
+        keep &= paths != drop
+    return paths[keep], keep.sum(axis=1)
+
+
+def split_rows(flat, lens, dtype):
+    """list of B tensors (views of one CPU tensor of `dtype`) holding the rows of (flat, lens)"""
+    t = torch.from_numpy(flat).to(dtype)
+    return list(torch.split(t, [int(n) for n in lens]))
+
+
 def row_argmax(x):
     """[B,T] int32: per frame the first maximal class of x [B,T,C] -- viterbi_path of the bare emissions graph
     (transducer.py:205-216 without transitions)."""

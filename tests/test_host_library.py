@@ -782,3 +782,40 @@ def test_batched_decode_written_down_directly_equals_the_graph_algebra(blank, re
     other.add_arc(0, 0, 1000, 1000, 0.0)  # (one arc more: no longer a make_token_graph, same language on these labels)
     out2, off2 = G.transducer_decode_batch(other, flat, offs)
     assert [out2[off2[i]:off2[i + 1]].tolist() for i in range(len(seqs))] == want
+
+
+def test_batched_viterbi_post_processing_equals_the_row_by_row_spelling():
+    """ASG.viterbi / CTC.viterbi collapse, drop and unpack their paths for the whole batch with array operations
+    (criterions/asg.py::collapse_and_unpack, engine.collapse_rows); the reference does it row by row
+    (asg.py:228-234, ctc.py:130-134).  Same lists."""
+    import itertools
+
+    import numpy as np
+    import torch
+
+    from gtn_applications_amd import engine as E
+    from gtn_applications_amd.criterions import asg
+
+    rs = np.random.RandomState(0)
+    for trial in range(60):
+        B, T = rs.randint(1, 9), rs.randint(1, 60)
+        R = rs.randint(1, 4)
+        C = R + rs.randint(1, 6) + 1
+        garbage = None if trial % 3 == 0 else C - 1
+        # (few classes and long runs: repeats, replabels behind labels / behind replabels / at a row's start, empty results)
+        paths = rs.randint(0, C, size=(B, T)).astype(np.int32)
+        if trial % 2:
+            paths = np.repeat(paths[:, ::3], 3, axis=1)[:, :T]
+        want = []
+        for row in paths.tolist():
+            col = [p for p, _ in itertools.groupby(row)]
+            if garbage is not None:
+                col = [p for p in col if p != garbage]
+            want.append(asg.unpack_replabels(col, R))
+        got = asg.collapse_and_unpack(paths, garbage, R)
+        assert [g.tolist() for g in got] == want
+        assert all(g.dtype == torch.int32 for g in got)
+        blank = C - 1
+        flat, lens = E.collapse_rows(paths.astype(np.int64), drop=blank)
+        rows = [r.tolist() for r in E.split_rows(flat, lens, torch.int64)]
+        assert rows == [[p for p in (q for q, _ in itertools.groupby(row)) if p != blank] for row in paths.tolist()]
