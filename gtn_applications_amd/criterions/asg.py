@@ -52,6 +52,53 @@ def unpack_replabels(tokens, num_replabels):
     return out
 
 
+def pack_targets_batch(targets, num_replabels, garbage_idx):
+    """ASG.forward's target preparation (asg.py:201-208: pack_replabels per target, then a garbage label between and
+    around the labels) for a whole batch of 1-D CPU tensors as array operations; returns a list of B int64 tensors
+    (views of one).  A run of n equal labels becomes groups of up to 1 + num_replabels: the label (shifted by
+    num_replabels), then -- for a group of s >= 2 -- the replabel s - 2."""
+    import numpy as np
+
+    B = len(targets)
+    lens = np.fromiter((t.numel() for t in targets), np.int64, B)
+    total = int(lens.sum())
+    flat = torch.cat([t.reshape(-1) for t in targets]).to(torch.int64).numpy() if total else np.zeros(0, np.int64)
+    R, P = num_replabels, num_replabels + 1
+    starts = np.zeros(B, dtype=np.int64)
+    np.cumsum(lens[:-1], out=starts[1:])
+    rows = np.repeat(np.arange(B), lens)
+    if total:
+        brk = np.ones(total, dtype=bool)
+        brk[1:] = flat[1:] != flat[:-1]
+        brk[starts[lens > 0]] = True
+        run_start = np.flatnonzero(brk)
+        run_id = np.cumsum(brk) - 1
+        pos = (np.arange(total) - run_start[run_id]) % P          # position inside the group
+        run_end = np.empty(total, dtype=bool)                      # last element of its run
+        run_end[:-1] = brk[1:]
+        run_end[-1] = True
+        is_label = pos == 0
+        is_rep = (pos >= 1) & (run_end | (pos == P - 1))            # last element of a group of >= 2
+        keep = is_label | is_rep
+        vals = np.where(is_label, flat + R, pos - 1)[keep]
+        out_rows = rows[keep]
+        out_lens = np.bincount(out_rows, minlength=B).astype(np.int64)
+    else:
+        vals, out_lens = np.zeros(0, np.int64), np.zeros(B, np.int64)
+    if garbage_idx is not None:  # [g, t0, g, t1, ..., g]
+        new_lens = 2 * out_lens + 1
+        new_starts = np.zeros(B, dtype=np.int64)
+        np.cumsum(new_lens[:-1], out=new_starts[1:])
+        res = np.full(int(new_lens.sum()), garbage_idx, dtype=np.int64)
+        if len(vals):
+            old_starts = np.zeros(B, dtype=np.int64)
+            np.cumsum(out_lens[:-1], out=old_starts[1:])
+            r = np.repeat(np.arange(B), out_lens)
+            res[new_starts[r] + 2 * (np.arange(len(vals)) - old_starts[r]) + 1] = vals
+        vals, out_lens = res, new_lens
+    return list(torch.split(torch.from_numpy(np.ascontiguousarray(vals, dtype=np.int64)), out_lens.tolist()))
+
+
 def collapse_and_unpack(paths, garbage_idx, num_replabels):
     """asg.py:228-234 for a whole batch (numpy [B,T] label paths): repeats collapsed, the garbage label dropped,
     replabels unpacked (unpack_replabels above: a replabel r right behind a label repeats that label r + 1 times, any
@@ -333,6 +380,11 @@ class ASG(torch.nn.Module):
 
     @E.on_input_device
     def forward(self, inputs, targets):
+        if len(targets) and all(type(t) is torch.Tensor and not t.is_cuda for t in targets):
+            # (what train.py hands over: the whole batch as array operations -- row by row in Python this preparation cost
+            # more host time than the step's kernels take at a training batch)
+            targets = pack_targets_batch(targets, self.num_replabels, self.garbage_idx)
+            return ASGLoss(inputs, self.transitions, targets, "mean")
         targets = [pack_replabels(t.tolist(), self.num_replabels) for t in targets]
         if self.garbage_idx is not None:  # a garbage token between (and around) the labels: asg.py:203-208
             for idx, tgt in enumerate(targets):

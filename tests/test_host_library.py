@@ -819,3 +819,31 @@ def test_batched_viterbi_post_processing_equals_the_row_by_row_spelling():
         flat, lens = E.collapse_rows(paths.astype(np.int64), drop=blank)
         rows = [r.tolist() for r in E.split_rows(flat, lens, torch.int64)]
         assert rows == [[p for p in (q for q, _ in itertools.groupby(row)) if p != blank] for row in paths.tolist()]
+
+
+def test_batched_asg_target_preparation_equals_the_row_by_row_spelling():
+    """ASG.forward prepares a batch of tensor targets with array operations (criterions/asg.py::pack_targets_batch); the
+    reference packs replabels and interleaves the garbage label target by target (asg.py:201-208).  Same lists."""
+    import numpy as np
+    import torch
+
+    from gtn_applications_amd.criterions import asg
+
+    rs = np.random.RandomState(1)
+    for trial in range(80):
+        B = rs.randint(1, 9)
+        R = rs.randint(1, 4)
+        ntok = rs.randint(1, 4)  # (few tokens: long runs, runs longer than the replabels cover)
+        garbage = None if trial % 3 == 0 else ntok + R
+        targets = [torch.from_numpy(rs.randint(0, ntok, size=rs.randint(0, 14)).astype(np.int64)) for _ in range(B)]
+        want = [asg.pack_replabels(t.tolist(), R) for t in targets]
+        if garbage is not None:
+            for i, tgt in enumerate(want):
+                inter = [garbage] * (2 * len(tgt) + 1)
+                inter[1::2] = tgt
+                want[i] = inter
+        got = asg.pack_targets_batch(targets, R, garbage)
+        assert [g.tolist() for g in got] == want
+        # and the round trip the criterion relies on (asg.py:35-49)
+        if garbage is None:
+            assert [asg.unpack_replabels(g.tolist(), R) for g in got] == [t.tolist() for t in targets]
