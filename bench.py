@@ -213,6 +213,9 @@ def make_ctc(args, rank, n_batches, dist=None):
         xr.grad = None
         module(xr * 1.0, fresh_tensors[(1 + i % max(1, n_batches - 1)) % n_batches]).backward()
 
+    def viterbi_step(i):  # (train.py:279 decodes every training batch for its error rate)
+        module.viterbi(xr.detach())
+
     # the C-ABI call underneath, targets pre-staged (kernels only)
     dev = x.device
     tg = E.targets_on_device(batches[0], dev)
@@ -263,7 +266,7 @@ def make_ctc(args, rank, n_batches, dist=None):
                 metric=f"utterances/sec fwd+bwd (ctc_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="CTCLoss(x, targets, blank).backward()", algorithmic_bytes_per_utt=8 * T * C)
     return dict(step=step, abi_step=abi_step, module_step=module_step, engine_step=engine_step,
-                engine_view_step=engine_view_step, meta=meta, launch_clock=launch_clock, training_step=training_step,
+                engine_view_step=engine_view_step, meta=meta, launch_clock=launch_clock, training_step=training_step, viterbi_step=viterbi_step,
                 payload=("ctc", x, batches[0], blank))
 
 
@@ -305,14 +308,24 @@ def make_asg(args, rank, n_batches, dist):
         par.grad = None
         asg.ASGLoss(x * 1.0, par, batches[(1 + i % max(1, n_batches - 1)) % n_batches]).backward()
 
+    vit_module = asg.ASG(C - 2, 1, True) if C > 2 else None  # (C classes: tokens + one replabel + garbage)
+    if vit_module is not None:
+        vit_module.transitions.data = transitions.detach().clone()
+
+    def viterbi_step(i):  # (train.py:279 decodes every training batch for its error rate)
+        vit_module.viterbi(x.detach())
+
     which = " (BASELINE configs[2])" if (T, C, B, L) == (1000, 100, 128, 44) else ""
     meta = dict(workload=f"asg fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L,
                 key="cfg3" if which else None,
                 metric=f"utterances/sec fwd+bwd (asg_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="ASGLoss(x, transitions, targets).backward()",
                 algorithmic_bytes_per_utt=8 * T * C, algorithmic_bytes_per_batch=8 * (C + 1) * C)
-    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, training_step=training_step, meta=meta,
-                payload=("asg", x.detach(), transitions.detach(), batches[0]))
+    wl = dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, training_step=training_step, meta=meta,
+              payload=("asg", x.detach(), transitions.detach(), batches[0]))
+    if vit_module is not None:
+        wl["viterbi_step"] = viterbi_step
+    return wl
 
 
 def word_pieces():
@@ -380,8 +393,12 @@ def make_transducer(args, rank, n_batches):
                 metric=f"utterances/sec fwd+bwd (transducer_benchmark word decompositions T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="Transducer(tokens, ..., blank='optional', allow_repeats=False, reduction='mean')(x, targets).backward()",
                 algorithmic_bytes_per_utt=8 * T * C)
+    def viterbi_step(i):  # (train.py:279 decodes every training batch for its error rate)
+        crit.viterbi(x.detach())
+
     return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, training_step=training_step,
-                training_step_prepared=training_step_prepared, fresh_prepared_step=fresh_prepared_step, meta=meta, payload=("transducer", x.detach(), crit, batches[0]))
+                training_step_prepared=training_step_prepared, fresh_prepared_step=fresh_prepared_step, viterbi_step=viterbi_step,
+                meta=meta, payload=("transducer", x.detach(), crit, batches[0]))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -707,6 +724,13 @@ def main():
                         "of targets never seen before in every step (no content-keyed cache can hit)" +
                         ("; the CTC module on raw scores (log_softmax fused), targets as tensors" if args.workload == "ctc" else
                          "; transitions as an nn.Parameter" if args.workload == "asg" else "")}
+        if "viterbi_step" in wl and args.mode == "api":
+            nv = max(3, min(extras_steps, 20))
+            el, _ = timed_loop(wl["viterbi_step"], nv, 2, fence, False)
+            out["viterbi"] = {
+                "ms_per_call": el * 1e3 / nv,
+                "what": "criterion.viterbi(outputs) on the same batch, as train.py:279 calls it in every training step: "
+                        "device decode, copy to the host, collapse / unpack there (not part of `value`)"}
         if fresh_extra and "fresh_prepared_step" in wl and args.mode == "api":
             el, _ = timed_loop(wl["fresh_prepared_step"], extras_steps, 3, fence, False)
             out["fresh_targets_prepared"] = {

@@ -51,4 +51,11 @@ python scripts/host_overhead.py > $O/host_overhead.txt 2>/dev/null
 python scripts/viterbi_time.py > $O/viterbi_times.txt 2>/dev/null
 python scripts/ctc_long_probe.py > $O/ctc_long_probe.txt 2>/dev/null
 python scripts/ctc_module_time.py > $O/ctc_module_time.txt 2>/dev/null
+# round 5, later: what train.py calls per step besides the loss, the n-gram Transducer's step, the Viterbi kernels
+python scripts/viterbi_module_time.py > $O/viterbi_module_times.txt 2>/dev/null
+for b in 16 32; do for n in 1 2; do python scripts/ngram_step_probe.py $b $n 2>/dev/null | grep -v amdgpu >> $O/ngram_step_probe.txt; done; done
+bash scripts/cmd_timeline.sh gather python scripts/ngram_step_probe.py 32 2 > $O/ngram_bigram_step_timeline.txt 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vit -- python scripts/asg_classes_time.py 128,1000,100 128,1000,150 > $O/stats_vit.log 2>&1
+grep -i "viterbi\|Name" $(find $O/stats_vit -name "*kernel_stats.csv" | head -1) > $O/viterbi_kernel_stats.csv
+rm -rf $O/stats_vit
 rm -f $O/pmc_*_SIZE.csv.bak
