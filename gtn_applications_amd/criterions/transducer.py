@@ -446,15 +446,74 @@ def _bigram_route(inputs, targets, tokens, lexicon, transition_params=None, tran
     from . import asg as _asg
 
     dev = E.require_gpu()
-    x = inputs if inputs.dtype == torch.float32 else inputs.float()
-    p = transition_params.to(device=x.device, dtype=torch.float32)
-    n1 = C + C * C
-    Wd = torch.cat([p[:C].view(1, C), p[C:n1].view(C, C).t()], dim=0)
-    xd = torch.cat([x[:, :-1], x[:, -1:] + p[n1 + 1:]], dim=1)
     with torch.cuda.device(dev):
         pack, scale, cpos, cneg, _ = _numerator_entry(targets, tokens, lexicon, _numerator_transitions(transitions, C), C, dev,
                                                        reduction, B)
-    return _asg.ASGLoss(xd, Wd, _asg.PackedNumerator(pack, scale, cpos, cneg, B), "none")
+    return _BigramAsAsg.apply(inputs, transition_params, _asg.PackedNumerator(pack, scale, cpos, cneg, B))
+
+
+class _InnerCtx:
+    """What ASGLossFunction's forward / backward keep on their autograd context, for a caller that runs them inside a
+    node of its own (_BigramAsAsg): plain attributes, and the two hook registrars E.watch_node_hooks looks for."""
+
+    needs_input_grad = (True, True, False, False)
+
+    def register_hook(self, fn):
+        return None
+
+    def register_prehook(self, fn):
+        return None
+
+
+class _BigramAsAsg(torch.autograd.Function):
+    """_bigram_route's step as ONE autograd node: the operands of the ASG step from (emissions, transition_params) --
+    three small torch ops -- ASGLossFunction's forward on them (csrc/torch_ops.cpp::asg_forward), and in backward its
+    two gradients mapped back to the caller's tensors.  (Spelled with differentiable torch ops around ASGLoss the step
+    carried eight more autograd nodes: ~0.1 ms of host time where the step is host-bound.)"""
+
+    @staticmethod
+    @E.on_input_device
+    def forward(ctx, inputs, transition_params, packed):
+        from . import asg as _asg
+
+        B, T, C = inputs.shape
+        dev = E.require_gpu()
+        x = E.as_device_f32(inputs.detach(), dev)
+        p = E.as_device_f32(transition_params.detach(), dev).reshape(-1)
+        n1 = C + C * C
+        Wd = torch.cat([p[:C].view(1, C), p[C:n1].view(C, C).t()], dim=0)
+        xd = x.clone()
+        xd[:, -1, :] += p[n1 + 1:]
+        # (what ASGLossFunction.forward asks its operands: which gradients the step will be asked for -- the end arcs'
+        # gradient is the last frame's rows of the emission gradient, so the parameters alone ask for that one too)
+        xd.requires_grad_(inputs.requires_grad or transition_params.requires_grad)
+        Wd.requires_grad_(transition_params.requires_grad)
+        ctx.bigram = (C, inputs.device, transition_params.device, transition_params.shape)
+        ctx.inner = _InnerCtx()
+        loss = _asg.ASGLossFunction.forward(ctx.inner, xd, Wd, packed, "none")
+        return loss if inputs.is_cuda else loss.cpu()
+
+    @staticmethod
+    @E.on_input_device
+    def backward(ctx, grad_output):
+        from . import asg as _asg
+
+        C, in_dev, par_dev, par_shape = ctx.bigram
+        need_x, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ctx.inner.needs_input_grad = (need_x or need_p, need_p, False, False)
+        dxd, dWd, _, _ = _asg.ASGLossFunction.backward(ctx.inner, grad_output)
+        dp = None
+        if need_p:
+            # the end arcs' scores rode on the last frame's emissions: their gradient is that frame's rows, summed
+            # (the emission gradient is computed for it even when the caller's emissions ask for none)
+            end = dxd[:, -1, :].sum(dim=0)
+            dp = torch.cat([dWd[0], dWd[1:].t().reshape(-1), end.new_zeros(1), end]).reshape(par_shape)
+            if par_dev.type != "cuda":
+                dp = dp.to(par_dev)
+        dx = None
+        if need_x:
+            dx = dxd if in_dev.type == "cuda" else dxd.to(in_dev)
+        return dx, dp, None
 
 
 class _UnigramNormaliser:

@@ -229,3 +229,14 @@ def test_dense_ngram_routes_equal_the_general_path(ngram, kind):
         torch.testing.assert_close(l1, l0, rtol=2e-5, atol=2e-5)
         torch.testing.assert_close(dx1, dx0, rtol=1e-4, atol=2e-6)
         torch.testing.assert_close(dp1, dp0, rtol=1e-4, atol=2e-5)
+    # one of the two gradients alone (the bigram's end arcs take theirs from the emission gradient's last frame)
+    crit.transition_params.grad = None
+    crit(x0.clone(), targets).backward()
+    torch.testing.assert_close(crit.transition_params.grad.cpu(), dp0, rtol=1e-4, atol=2e-5)
+    crit.transition_params.requires_grad_(False)
+    try:
+        x = x0.clone().requires_grad_(True)
+        crit(x, targets).backward()
+        torch.testing.assert_close(x.grad.cpu(), dx0, rtol=1e-4, atol=2e-6)
+    finally:
+        crit.transition_params.requires_grad_(True)
