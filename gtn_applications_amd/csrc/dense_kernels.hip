@@ -1786,15 +1786,29 @@ int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float
     WFL_LAUNCH_CHECK();
     return WFL_OK;
   }
-  if (!bptr) {
-    set_error("dense_viterbi: beyond 256 classes the back-pointer buffer is required");
-    return WFL_ERR_INVALID;
+  {
+    // beyond 256 classes: one tiled max-plus launch per frame for the whole batch (csrc/dense_wide.h), no back-pointers
+    // either (`bptr` is not written), then the walk that re-derives the ones it follows
+    if (int rc = dense_check(x, W, B, T, C, "dense_viterbi")) return rc;
+    if (!alpha) {
+      set_error("dense_viterbi: alpha is required");
+      return WFL_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wide_viterbi_first_max_kernel, dim3((unsigned)(((int64_t)B * C + 255) / 256)), dim3(256), 0, st, x, W, B, T,
+                       C, alpha);
+    const dim3 grid((unsigned)((C + 15) / 16), (unsigned)((B + 15) / 16));
+    const bool vec4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(alpha)) & 15) == 0;
+    for (int t = 1; t < T; ++t) {
+      if (vec4)
+        hipLaunchKernelGGL(wide_viterbi_max_kernel<true>, grid, dim3(64 * kVitWideWaves), 0, st, x, W, B, T, C, t, alpha);
+      else
+        hipLaunchKernelGGL(wide_viterbi_max_kernel<false>, grid, dim3(64 * kVitWideWaves), 0, st, x, W, B, T, C, t, alpha);
+    }
+    hipLaunchKernelGGL(dense_viterbi_walk_kernel, dim3((unsigned)B), dim3(64), 0, st, alpha, W, B, T, C, path);
+    WFL_LAUNCH_CHECK();
+    return WFL_OK;
   }
-  if (int rc = wfl_dense_forward(x, W, B, T, C, WFL_SEMIRING_TROPICAL, alpha, nullptr, bptr, nullptr, nullptr, stream))
-    return rc;
-  hipLaunchKernelGGL(dense_backtrace_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, alpha, bptr, B, T, C, path);
-  WFL_LAUNCH_CHECK();
-  return WFL_OK;
 }
 
 }  // extern "C"

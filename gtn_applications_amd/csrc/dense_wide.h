@@ -447,6 +447,134 @@ __global__ void __launch_bounds__(256) wide_viterbi_frame_kernel(const float* __
     }
   }
 }
+// The same frame WITHOUT back-pointers, for wfl_dense_viterbi (whose back-trace re-derives the one back-pointer per frame
+// it follows: dense_viterbi_walk_kernel): v_t[b][i] = (max_j (v_{t-1}[b][j] + W[1+i][j])) + x[b,t,i], the same additions in
+// the same order as the kernel above -- the stored vectors are identical.  That kernel's 64 x 64 tiles are 16 workgroups
+// at N = 1000, B = 32, each walking all 1000 previous labels behind barriers: 236 us per frame, 59 ms per call.  Here a
+// workgroup owns 16 states x 16 utterances, its sixteen waves each take every sixteenth group of four previous labels, two
+// groups' loads in flight (operands straight from L2: the matrix and the previous vectors stay there across the frame's
+// workgroups; with four waves and one group at a time a wave waited out 62 L2 round trips: 27 us per frame) and meet in
+// LDS: 63 x 2 workgroups at that shape.
+// VEC4: rows of W and of the vectors are 16-byte aligned (C % 4 == 0, aligned bases): 16-byte loads
+constexpr int kVitWideWaves = 16;
+template <bool VEC4>
+__global__ void __launch_bounds__(64 * kVitWideWaves)
+    wide_viterbi_max_kernel(const float* __restrict__ x, const float* __restrict__ W, int B, int T, int C, int t,
+                            float* __restrict__ alpha) {
+  __shared__ float part[kVitWideWaves][16][17];
+  const int i0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, il = lane & 15, ng = lane >> 4;
+  const float* wrow = W + (int64_t)(1 + min(i0 + il, C - 1)) * C;
+  const float* arow[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) arow[v] = alpha + ((int64_t)min(n0 + ng + 4 * v, B - 1) * T + (t - 1)) * C;
+  float best[4] = {WFL_NEG_INF, WFL_NEG_INF, WFL_NEG_INF, WFL_NEG_INF};
+  const int ngroups = (C + 3) >> 2;
+  auto load = [&](int g, float (&wv)[4], float (&av)[4][4]) {  // (g clamped by the caller: a valid group, maybe a repeated one)
+    const int k = 4 * g;
+    if (VEC4) {
+      const float4 q = *reinterpret_cast<const float4*>(wrow + k);
+      wv[0] = q.x, wv[1] = q.y, wv[2] = q.z, wv[3] = q.w;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 a = *reinterpret_cast<const float4*>(arow[v] + k);
+        av[v][0] = a.x, av[v][1] = a.y, av[v][2] = a.z, av[v][3] = a.w;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int kc = min(k + c, C - 1);
+        wv[c] = k + c < C ? wrow[kc] : WFL_NEG_INF;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) av[v][c] = arow[v][kc];
+      }
+    }
+  };
+  auto fold = [&](float (&wv)[4], const float (&av)[4][4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wv[c] = wide_clean(wv[c]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      best[v] = fmaxf(fmaxf(best[v], fmaxf(wv[0] + av[v][0], wv[1] + av[v][1])), fmaxf(wv[2] + av[v][2], wv[3] + av[v][3]));
+  };
+  // (two groups per trip: the second one clamped to the wave's last -- folding a group twice changes no maximum)
+  for (int g = wave; g < ngroups; g += 2 * kVitWideWaves) {
+    float w0[4], a0[4][4], w1[4], a1[4][4];
+    load(g, w0, a0);
+    load(min(g + kVitWideWaves, ngroups - 1), w1, a1);
+    fold(w0, a0);
+    fold(w1, a1);
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) part[wave][ng + 4 * v][il] = best[v];
+  __syncthreads();
+  if (tid < 256) {  // thread (n, i) of the tile: the waves' maxima, + the emission
+    const int i = i0 + (tid & 15), n = n0 + (tid >> 4);
+    if (i < C && n < B) {
+      float m = part[0][tid >> 4][tid & 15];
+#pragma unroll
+      for (int w = 1; w < kVitWideWaves; ++w) m = fmaxf(m, part[w][tid >> 4][tid & 15]);
+      const int64_t at = ((int64_t)n * T + t) * C + i;
+      alpha[at] = wide_clean(x[at]) + m;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) wide_viterbi_first_max_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                     int B, int T, int C, float* __restrict__ alpha) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * C) return;
+  const int b = (int)(e / C), i = (int)(e % C);
+  const int64_t at = (int64_t)b * T * C + i;
+  alpha[at] = wide_clean(x[at]) + wide_clean(W[i]);
+}
+// The path from the stored vectors for ANY class count (dense_viterbi_backtrace_kernel keeps the vectors' chunks and
+// the matrix in LDS and serves up to 256 classes): one wave per utterance, a step reads the previous frame's vector and
+// the current state's row of W from L2, C / 64 values per lane, keeps the lane's first maximum, then the wave's
+// maximum and the lowest label that attains it.
+__global__ void __launch_bounds__(64) dense_viterbi_walk_kernel(const float* __restrict__ alpha, const float* __restrict__ W, int B,
+                                                                int T, int C, int32_t* __restrict__ path) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= B || T <= 0) return;
+  const float* ab = alpha + (int64_t)b * T * C;
+  int32_t* out = path + (int64_t)b * T;
+  int cur;
+  {
+    float best = WFL_NEG_INF;
+    int arg = 0x3fffffff;
+    for (int i = lane; i < C; i += 64) {
+      const float v = ab[(int64_t)(T - 1) * C + i];
+      if (v > best || arg == 0x3fffffff) best = v, arg = i;
+    }
+    const float m = wave_all_max(best);
+    arg = -wave_all_max_int(-(best == m ? arg : 0x3fffffff));
+    cur = arg == 0x3fffffff ? 0 : arg;
+  }
+  for (int t = T - 1; t >= 0; --t) {
+    if (lane == 0) out[t] = cur;
+    if (t == 0) break;
+    const float* prev = ab + (int64_t)(t - 1) * C;
+    const float* wrow = W + (int64_t)(1 + cur) * C;
+    float best = WFL_NEG_INF;
+    int arg = 0x3fffffff;
+    for (int j0 = lane; j0 < C; j0 += 64 * 8) {  // (eight loads of each operand in flight: clamped addresses, no test around them)
+      float pv[8], wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = min(j0 + 64 * u, C - 1);
+        pv[u] = prev[j], wv[u] = wrow[j];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + 64 * u;
+        const float v = j < C ? pv[u] + wide_clean(wv[u]) : WFL_NEG_INF;
+        if (v > best) best = v, arg = j;  // (strict, ascending j: the lane's lowest)
+      }
+    }
+    const float top = wave_all_max(best);
+    const int lowest = -wave_all_max_int(-((best == top && top > WFL_NEG_INF) ? arg : 0x3fffffff));
+    cur = lowest == 0x3fffffff ? 0 : lowest;  // unreachable state (all -inf): keep the path well-formed
+  }
+}
 __global__ void __launch_bounds__(256) wide_viterbi_first_kernel(const float* __restrict__ x, const float* __restrict__ W, int B,
                                                                  int T, int C, float* __restrict__ alpha,
                                                                  int32_t* __restrict__ bptr) {

@@ -698,8 +698,7 @@ def dense_grad(x, W, st, coef, coef_w=None, gout=None, dx=None, accumulate=False
 def dense_viterbi(x, W):
     B, T, C = x.shape
     alpha = torch.empty((B, T, C), dtype=_F32, device=x.device)
-    # (back-pointers only beyond 256 classes: include/wfl.h)
-    bptr = torch.empty((B, T, C), dtype=torch.int32, device=x.device) if C > 256 else None
+    bptr = None  # (no back-pointer buffer: include/wfl.h)
     path = torch.empty((B, T), dtype=torch.int32, device=x.device)
     N.check(N.lib.wfl_dense_viterbi(ptr(x), ptr(W), B, T, C, ptr(alpha), ptr(bptr), ptr(path),
                                     stream_ptr()))

@@ -305,7 +305,7 @@ int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws
  * probability-domain sweeps, LDS for the log-domain launches behind them; beyond, the frame update of the whole batch
  * runs as one tiled matrix product per frame on the matrix cores, the matrix streamed from L2 (csrc/dense_wide.h): same
  * entry points, same buffers (sizes from wfl_dense_workspace).  wfl_dense_viterbi keeps the matrix in registers up
- * to 256 classes (the max-plus frame has no matrix-core form) and takes the tiled per-frame launch beyond. */
+ * to 256 classes (the max-plus frame has no matrix-core form) and takes a tiled per-frame launch beyond. */
 int wfl_dense_max_classes(void);
 int wfl_dense_on_chip_classes(void);
 /* forward_score(intersect(emissions, transitions)) (asg.py:114): logz [B]; alpha, beta [B,T,C] are
@@ -343,9 +343,9 @@ int wfl_dense_grad_parts(const float* x, const float* W, int B, int T, int C, co
                          float* dx, float* dW, float* dW_partial, const void* ws, int parts, void* stream);
 /* viterbi_path(intersect(emissions, transitions)).labels_to_list() (asg.py:225-226):
  * path [B,T] int32 emission labels.  Ties: lowest previous label, then lowest final label.
- * alpha [B,T,C]: the max-plus vectors (an output).  bptr [B,T,C] int32: scratch of the launches beyond 256 classes --
- * up to 256 classes it is neither read nor written and may be NULL (the back-trace re-derives the one back-pointer per
- * frame it follows from the stored vectors). */
+ * alpha [B,T,C]: the max-plus vectors (an output).  bptr: unused since round 5 (neither read nor written, may be NULL):
+ * the back-trace re-derives the one back-pointer per frame it follows from the stored vectors; wfl_dense_forward in the
+ * tropical semiring still fills a back-pointer buffer. */
 int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float* alpha,
                       int32_t* bptr, int32_t* path, void* stream);
 

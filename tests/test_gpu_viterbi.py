@@ -1,5 +1,6 @@
-"""ASG.viterbi (asg.py:211-236) on the register-resident max-plus sweep + recomputing back-trace (C <= 256:
-csrc/dense_kernels.hip dense_viterbi_sweep_kernel / dense_viterbi_backtrace_kernel) against
+"""ASG.viterbi (asg.py:211-236) on the max-plus sweeps without back-pointers + the back-traces that re-derive the ones
+they follow (C <= 256: csrc/dense_kernels.hip dense_viterbi_sweep_kernel / dense_viterbi_backtrace_kernel, transition rows
+in registers; beyond: csrc/dense_wide.h wide_viterbi_max_kernel / dense_viterbi_walk_kernel) against
 
   * the launch it replaced -- wfl_dense_forward in the tropical semiring, which stores a back-pointer per (frame, state):
     the stored vectors must be IDENTICAL (same additions in the same order) and the path the one its back-pointers give,
@@ -59,7 +60,9 @@ def same_values(a, b):
 
 
 SHAPES = [(3, 17, 5), (4, 50, 32), (4, 33, 33), (2, 40, 64), (2, 41, 65), (3, 64, 100), (2, 30, 104), (2, 25, 105),
-          (2, 20, 128), (2, 18, 129), (1, 19, 192), (2, 21, 193), (1, 16, 256), (2, 1, 7), (2, 2, 3), (1, 300, 82)]
+          (2, 20, 128), (2, 18, 129), (1, 19, 192), (2, 21, 193), (1, 16, 256), (2, 1, 7), (2, 2, 3), (1, 300, 82),
+          # beyond 256 classes: one tiled launch per frame (csrc/dense_wide.h), 16-byte loads when C % 4 == 0
+          (2, 12, 257), (3, 9, 300), (17, 7, 333), (2, 6, 1000), (1, 5, 1031)]
 
 
 @pytest.mark.parametrize("B,T,C", SHAPES)
@@ -86,7 +89,7 @@ def test_viterbi_equals_the_back_pointer_launch(B, T, C, kind):
     assert np.array_equal(p_new, p_old)
 
 
-@pytest.mark.parametrize("C", [7, 82, 100, 150, 256])
+@pytest.mark.parametrize("C", [7, 82, 100, 150, 256, 300])
 def test_viterbi_vs_oracle_integer_scores(C):
     rs = np.random.RandomState(C)
     B, T = 3, 40
