@@ -1319,6 +1319,8 @@ __global__ void __launch_bounds__(((CP / 8) * (CP / 8) + 63) / 64 * 64)
 // free for the staging arithmetic of the next stage meanwhile.  Staging, scales and the emission gradient are those
 // of dense_fast_grad_kernel.
 typedef float mfma_v4f __attribute__((ext_vector_type(4)));
+// (stages of 8 frames with three workgroups per CU -- 168 VGPRs -- instead of 16 frames with two, re-measured in round 5:
+// cfg3 0.439 -> 0.449 ms, 0.446 with 768 workgroups instead of 512: not kept)
 template <int CP, int TS>
 __global__ void __launch_bounds__(256, 2)
     dense_mfma_grad_kernel(const float* __restrict__ x, const float* __restrict__ W, int T, int C, int B,
