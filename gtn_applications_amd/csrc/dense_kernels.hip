@@ -1364,7 +1364,7 @@ __global__ void __launch_bounds__(256, 2)
   // are consumed -- with one set they flew under ONE stage's products (~2000 cycles of the matrix pipe) and every
   // stage waited out the rest of an HBM round trip (measured: 5.9 us per stage of 16 frames, two workgroups per CU).
   struct Stage {
-    float ra[NI], rb[NI], rx[NI], rp[NI], rd[NI], re[NI];
+    float ra[NI], rb[NI], rx[NI], rp[NI], re[NI];  // (no accumulate-into-dx here: those calls take dense_fast_grad_kernel)
     double q_ma, q_mb, q_mp;  // lane r < TS: scale words of frame t0 + r (and of the frame before it)
     int32_t q_ea, q_eb, q_ep;
     float q_m2;
@@ -1373,7 +1373,6 @@ __global__ void __launch_bounds__(256, 2)
   const float* const bb = beta + base;
   const float* const xb = x + base;
   float* const dxb = dx ? dx + base : nullptr;
-  const float* const prev_dx = (dx && accumulate) ? dx + base : nullptr;
   const float* const addb = addend ? addend + base : nullptr;
   auto issue = [&](Stage& S, int t0) {
     if (tid < TS) {
@@ -1386,7 +1385,6 @@ __global__ void __launch_bounds__(256, 2)
       const unsigned o = 4u * (__umul24((unsigned)t, (unsigned)C) + (unsigned)ei[k]);
       S.ra[k] = at_byte(ab, o), S.rb[k] = at_byte(bb, o), S.rx[k] = at_byte(xb, o);
       S.rp[k] = at_byte(ab, t > 0 ? o - 4u * (unsigned)C : o);
-      if (prev_dx) S.rd[k] = at_byte(prev_dx, o);
       if (addb) S.re[k] = at_byte(addb, o);
     }
   };
@@ -1426,7 +1424,7 @@ __global__ void __launch_bounds__(256, 2)
         const float g = (S.ra[k] * hg) * (S.rb[k] * hg);
         if (dxb)
           *reinterpret_cast<float*>(reinterpret_cast<char*>(dxb) + 4u * (__umul24((unsigned)t, (unsigned)C) + (unsigned)i)) =
-              (prev_dx ? S.rd[k] : 0.f) + (addb ? g0 * S.re[k] : 0.f) + cf * g;
+              (addb ? g0 * S.re[k] : 0.f) + cf * g;
         if (partial) {
           if (t > 0) {
             const float e = __builtin_amdgcn_exp2f(fmaf(nan_to_neg(S.rx[k]), kLog2e, wr2[i]) - sc[buf][r][2]);
@@ -1697,11 +1695,11 @@ int wfl_dense_grad_parts(const float* x, const float* W, int B, int T, int C, co
   } else if (cp == 32)
     WFL_FAST_GRAD(32);
   else if (cp == 64) {
-    if (use_mfma && part) WFL_MFMA_GRAD(64); else WFL_FAST_GRAD(64);
+    if (use_mfma && part && !accumulate) WFL_MFMA_GRAD(64); else WFL_FAST_GRAD(64);
   } else if (cp == 104) {
-    if (use_mfma && part) WFL_MFMA_GRAD(104); else WFL_FAST_GRAD(104);
+    if (use_mfma && part && !accumulate) WFL_MFMA_GRAD(104); else WFL_FAST_GRAD(104);
   } else if (cp == 128) {
-    if (use_mfma && part) WFL_MFMA_GRAD(128); else WFL_FAST_GRAD(128);
+    if (use_mfma && part && !accumulate) WFL_MFMA_GRAD(128); else WFL_FAST_GRAD(128);
   } else if (cp == 160) {  // (beyond 128 classes: the 8 x 8 register tiles of the vector pipe -- (CP / 8)^2 threads)
     WFL_FAST_GRAD(160);
   } else if (cp == 192) {
@@ -1766,7 +1764,8 @@ int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float
     else if (C <= 192)
       WFL_VIT_SWEEP(96, 2);
     else
-      WFL_VIT_SWEEP(128, 2);
+      WFL_VIT_SWEEP(128, 2);  // (256 VGPRs, 12 B of scratch; four lanes per state on 1024 threads -- 128 VGPRs each -- spill more and
+                              // take 2.08 instead of 1.38 ms at C = 200)
 #undef WFL_VIT_SWEEP
     WFL_LAUNCH_CHECK();
     const size_t fixed = 2 * ((size_t)kVitChunkFloats + 256) * 4 + 1024 * 4 + 16;
