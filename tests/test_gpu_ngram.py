@@ -240,3 +240,41 @@ def test_dense_ngram_routes_equal_the_general_path(ngram, kind):
         torch.testing.assert_close(x.grad.cpu(), dx0, rtol=1e-4, atol=2e-6)
     finally:
         crit.transition_params.requires_grad_(True)
+
+
+@pytest.mark.parametrize("ngram", [1, 2])
+def test_dense_ngram_routes_on_degenerate_batches(ngram):
+    """The short cuts of TransducerLoss (unigram / bigram) on the shapes the general path also has to get right: one
+    frame, an empty target next to ordinary ones, emissions that live on the CPU."""
+    from gtn_applications_amd.criterions import transducer as TR
+
+    torch.manual_seed(11)
+    N = 9
+    tokens = [(i,) for i in range(N)]
+    crit = TR.Transducer(tokens, {i: i for i in range(N)}, ngram=ngram, reduction="mean", blank="optional",
+                         allow_repeats=False).cuda()
+    with torch.no_grad():
+        crit.transition_params.normal_(0, 0.5)
+    C = N + 1
+    cases = [(1, [[3]]), (1, [[]]), (6, [[], [2, 2, 5], [7]]), (4, [[1, 2, 3, 4]])]
+    for T, tg in cases:
+        B = len(tg)
+        targets = [torch.tensor(t, dtype=torch.long) for t in tg]
+        x0 = torch.randn(B, T, C)
+        outs = []
+        for how in ("direct", "module", "module_cpu_input"):
+            x = (x0.clone() if how == "module_cpu_input" else x0.clone().cuda()).requires_grad_(True)
+            crit.transition_params.grad = None
+            if how == "direct":
+                crit.tokens.arc_sort(True)
+                loss = TR.TransducerLossFunction.apply(x, targets, crit.tokens, crit.lexicon, crit.transition_params,
+                                                       crit.transitions, crit.reduction)
+            else:
+                loss = crit(x, targets)
+            loss.backward()
+            assert x.grad.device == x.device
+            outs.append((loss.detach().cpu(), x.grad.cpu(), crit.transition_params.grad.cpu().clone()))
+        for l1, dx1, dp1 in outs[1:]:
+            torch.testing.assert_close(l1, outs[0][0], rtol=2e-5, atol=2e-5)
+            torch.testing.assert_close(dx1, outs[0][1], rtol=1e-4, atol=2e-6)
+            torch.testing.assert_close(dp1, outs[0][2], rtol=1e-4, atol=2e-5)
