@@ -847,3 +847,27 @@ def test_batched_asg_target_preparation_equals_the_row_by_row_spelling():
         # and the round trip the criterion relies on (asg.py:35-49)
         if garbage is None:
             assert [asg.unpack_replabels(g.tolist(), R) for g in got] == [t.tolist() for t in targets]
+
+
+def test_series_log_of_the_general_sweep_is_a_double_precision_log():
+    """csrc/lattice_kernels.hip::lse_log (the log of every log-add of the general lattice sweep) restated: mantissa in
+    [sqrt(1/2), sqrt(2)), 2 atanh((m - 1) / (m + 1)) by nine terms of its series, + e ln 2.  Against math.log over the
+    sums it sees (1 .. a few thousand terms, each <= 1)."""
+    import math
+
+    import numpy as np
+
+    rs = np.random.RandomState(0)
+    s = np.concatenate([1 + rs.rand(100000) * 10, np.exp(rs.rand(100000) * 14), [1.0, 2.0, 1 + 1e-12, 1e6, 3.999999, 4.0]])
+    m, e = np.frexp(s)
+    low = m < 0.70710678118654752
+    m = np.where(low, m * 2, m)
+    e = np.where(low, e - 1, e)
+    z = (m - 1) / (m + 1)
+    z2 = z * z
+    p = np.full_like(z, 1.0 / 17)
+    for k in (15, 13, 11, 9, 7, 5, 3, 1):
+        p = p * z2 + 1.0 / k
+    got = e * 0.69314718055994531 + 2 * z * p
+    assert np.abs(got - np.log(s)).max() < 4e-15
+    assert got[200000] == 0.0  # log 1
