@@ -245,7 +245,7 @@ __device__ void dense_chain(const DenseLds& L, const float* __restrict__ x, int 
       if (SR == WFL_SEMIRING_LOG && m > WFL_NEG_INF) {
         float sum = 0.f;
         for (int r = 0; r < R; ++r) sum += L.ps[r * C + s] * fast_exp((float)(pmv[r * C + s] - m));
-        val = m + (VT)log((double)sum);
+        val = m + (VT)lse_log((double)sum);  // (sum >= 1: it contains the largest partial's own sum)
       }
       if (DIR == 0) val += (VT)xr[s];
       to[s] = val;
