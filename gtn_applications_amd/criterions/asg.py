@@ -107,7 +107,17 @@ def collapse_and_unpack(paths, garbage_idx, num_replabels):
     import numpy as np
 
     B = paths.shape[0]
-    flat, lens = E.collapse_rows(paths, drop=garbage_idx)
+    if isinstance(paths, torch.Tensor):
+        # on the device: the same collapse as five small launches, and only what survives it travels to the host
+        keep = torch.ones_like(paths, dtype=torch.bool)
+        if paths.shape[1] > 1:
+            keep[:, 1:] = paths[:, 1:] != paths[:, :-1]
+        if garbage_idx is not None:
+            keep &= paths != garbage_idx
+        lens = keep.sum(dim=1).cpu().numpy()
+        flat = paths[keep].cpu().numpy()
+    else:
+        flat, lens = E.collapse_rows(paths, drop=garbage_idx)
     R = num_replabels
     is_lab = flat >= R
     prev_lab = np.zeros(len(flat), dtype=bool)
@@ -401,5 +411,4 @@ class ASG(torch.nn.Module):
         dev = E.require_gpu()
         x = E.as_device_f32(outputs.detach(), dev)
         W = E.as_device_f32(self.transitions.detach(), dev)
-        paths = E.dense_viterbi(x, W).cpu().numpy()
-        return collapse_and_unpack(paths, self.garbage_idx, self.num_replabels)
+        return collapse_and_unpack(E.dense_viterbi(x, W), self.garbage_idx, self.num_replabels)

@@ -108,3 +108,20 @@ def test_viterbi_at_the_benchmark_shape_equals_the_back_pointer_launch():
     a_new, p_new = new_launch(x, W)
     assert same_values(a_new, a_old)
     assert np.array_equal(p_new, p_old)
+
+
+def test_collapse_on_the_device_equals_the_host_spelling():
+    """ASG.viterbi collapses its paths on the device before they travel (criterions/asg.py::collapse_and_unpack with a
+    tensor); the same function on a numpy array is pinned to the reference's row-by-row spelling on the CPU
+    (tests/test_host_library.py).  Same lists."""
+    from gtn_applications_amd.criterions import asg
+
+    rs = np.random.RandomState(4)
+    for trial in range(12):
+        B, T, R = rs.randint(1, 9), rs.randint(1, 70), rs.randint(1, 4)
+        C = R + rs.randint(1, 6) + 1
+        garbage = None if trial % 3 == 0 else C - 1
+        paths = np.repeat(rs.randint(0, C, size=(B, (T + 2) // 3)).astype(np.int32), 3, axis=1)[:, :T]
+        want = [t.tolist() for t in asg.collapse_and_unpack(paths, garbage, R)]
+        got = [t.tolist() for t in asg.collapse_and_unpack(torch.from_numpy(paths).cuda(), garbage, R)]
+        assert got == want
