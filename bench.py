@@ -10,6 +10,13 @@ A "step" = one pass of the hot path over one batch whose inputs -- emissions AND
                         `CTCLoss(x, targets, blank).backward()` (`ASGLoss(...)`, `Transducer(...)(x, targets)`),
                         autograd and host-side target handling included (benchmarks/ctc_benchmark.py:26-31).  This
                         is `value`;
+  --emissions output (default)  the emissions handed to the criterion are NOT a leaf of the autograd graph: that is what
+                        the reference's own benchmark hands over (ctc_benchmark.py:22: `randn(..., requires_grad=True)
+                        .cuda()` is the output of a copy) and what every training loop does (train.py:262-266: a
+                        model's output), so `loss.backward()` has a graph below the emissions to run.  The producer
+                        here is `x.view_as(x)` of a device-resident leaf: a graph node with no kernel of its own, so
+                        the step's bytes stay the criterion's;
+  --emissions leaf      the emissions ARE the leaf (round 1-5's headline; reported as `leaf_emissions` next to `value`);
   --mode abi (ctc only; reported as `abi_kernels_only` next to the headline)  `wfl_ctc_forward_backward` through
                         the C ABI of include/wfl.h, targets staged on the device before the timed region: what the
                         GPU does.
@@ -96,6 +103,8 @@ def parse():
     ap.add_argument("--stub-cpu", action="store_true",
                     help="tests only: gloo ranks on the CPU and a stub step -- exercises the rank / timing plumbing, measures nothing")
     ap.add_argument("--targets", default="same", choices=["fresh", "same"])
+    ap.add_argument("--emissions", default="output", choices=["output", "leaf"],
+                    help="output: the criterion's input is a producer's output (x.view_as(x); headline); leaf: it is the leaf itself")
     ap.add_argument("--B", type=int, default=None)
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--C", type=int, default=None)
@@ -179,21 +188,32 @@ def make_ctc(args, rank, n_batches, dist=None):
     # buffer an ASG criterion of this size would exchange -- [(C+1), C] fp32, 1.05 MB at C = 512 -- once per step
     exchange = torch.zeros(C + 1, C, device=x.device) if args.config == "cfg5" else None
 
+    # the headline protocol: the emissions are a producer's OUTPUT (ctc_benchmark.py:22, train.py:262-266), so
+    # loss.backward() has the graph below them to run on the autograd engine
     def step(i):
+        xr.grad = None
+        ctc.CTCLoss(xr.view_as(xr), batches[i % n_batches], blank).backward()
+        if exchange is not None:
+            parallel.all_reduce_mean_([exchange], force=FORCE_DIST)
+
+    def leaf_step(i):  # (the emissions ARE the leaf: the gradient of the forward launch becomes x.grad, no engine)
         xr.grad = None
         ctc.CTCLoss(xr, batches[i % n_batches], blank).backward()
         if exchange is not None:
             parallel.all_reduce_mean_([exchange], force=FORCE_DIST)
 
-    # what a training loop gets (train.py:262-266): the emissions are the model's OUTPUT, not a leaf, so loss.backward()
-    # goes through the autograd engine (the criterion's short cut for leaf emissions does not apply)
+    # ... with a producer that has kernels of its own (x * 1.0 and its backward: two elementwise passes over [B,T,C])
     def engine_step(i):
         xr.grad = None
         ctc.CTCLoss(xr * 1.0, batches[i % n_batches], blank).backward()
 
-    def engine_view_step(i):
+    def engine_proper_step(i):  # torch.Tensor.backward from the loss down (the criterion's short cut switched off)
         xr.grad = None
-        ctc.CTCLoss(xr.view_as(xr), batches[i % n_batches], blank).backward()
+        old, ctc._FAST_BACKWARD = ctc._FAST_BACKWARD, False
+        try:
+            ctc.CTCLoss(xr.view_as(xr), batches[i % n_batches], blank).backward()
+        finally:
+            ctc._FAST_BACKWARD = old
 
     # the CTC MODULE (criterions/ctc.py:99-121, use_pt=False): raw scores in, log_softmax fused into the step -- what a
     # training loop calls; reported next to the headline as `module_raw_scores`
@@ -265,8 +285,8 @@ def make_ctc(args, rank, n_batches, dist=None):
                 exchange_bytes=0 if exchange is None else exchange.numel() * 4,
                 metric=f"utterances/sec fwd+bwd (ctc_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="CTCLoss(x, targets, blank).backward()", algorithmic_bytes_per_utt=8 * T * C)
-    return dict(step=step, abi_step=abi_step, module_step=module_step, engine_step=engine_step,
-                engine_view_step=engine_view_step, meta=meta, launch_clock=launch_clock, training_step=training_step, viterbi_step=viterbi_step,
+    return dict(step=step, leaf_step=leaf_step, abi_step=abi_step, module_step=module_step, engine_step=engine_step,
+                engine_proper_step=engine_proper_step, meta=meta, launch_clock=launch_clock, training_step=training_step, viterbi_step=viterbi_step,
                 payload=("ctc", x, batches[0], blank))
 
 
@@ -282,11 +302,18 @@ def make_asg(args, rank, n_batches, dist):
     transitions = torch.randn(C + 1, C, generator=torch.Generator().manual_seed(7)).cuda().requires_grad_(True)
     batches = [torch.randint(C - 2, (B, L), generator=g).tolist() for _ in range(n_batches)]
 
-    def step(i):
+    def step(i):  # (emissions that are a producer's output: asg_benchmark.py:20 hands over `.cuda()` of a host leaf)
+        x.grad = None
+        transitions.grad = None
+        asg.ASGLoss(x.view_as(x), transitions, batches[i % n_batches]).backward()
+        if dist is not None:  # the one exchange step of the path (train.py:205-208: DDP averages criterion grads)
+            parallel.all_reduce_mean_([transitions.grad], force=FORCE_DIST)
+
+    def leaf_step(i):
         x.grad = None
         transitions.grad = None
         asg.ASGLoss(x, transitions, batches[i % n_batches]).backward()
-        if dist is not None:  # the one exchange step of the path (train.py:205-208: DDP averages criterion grads)
+        if dist is not None:
             parallel.all_reduce_mean_([transitions.grad], force=FORCE_DIST)
 
     # a training loop's shape (train.py:205-208,262-266): emissions that are a model's output (non-leaf) and transitions
@@ -297,11 +324,6 @@ def make_asg(args, rank, n_batches, dist):
         x.grad = None
         par.grad = None
         asg.ASGLoss(x * 1.0, par, batches[i % n_batches]).backward()
-
-    def engine_view_step(i):
-        x.grad = None
-        par.grad = None
-        asg.ASGLoss(x.view_as(x), par, batches[i % n_batches]).backward()
 
     def training_step(i):  # non-leaf emissions, nn.Parameter transitions, a batch of targets never seen before
         x.grad = None
@@ -321,7 +343,7 @@ def make_asg(args, rank, n_batches, dist):
                 metric=f"utterances/sec fwd+bwd (asg_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",
                 call="ASGLoss(x, transitions, targets).backward()",
                 algorithmic_bytes_per_utt=8 * T * C, algorithmic_bytes_per_batch=8 * (C + 1) * C)
-    wl = dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, training_step=training_step, meta=meta,
+    wl = dict(step=step, leaf_step=leaf_step, engine_step=engine_step, training_step=training_step, meta=meta,
               payload=("asg", x.detach(), transitions.detach(), batches[0]))
     if vit_module is not None:
         wl["viterbi_step"] = viterbi_step
@@ -350,17 +372,17 @@ def make_transducer(args, rank, n_batches):
                for _ in range(n_batches)]
     crit = transducer.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
 
-    def step(i):
+    def step(i):  # (emissions that are a producer's output: transducer_benchmark.py:33 hands over `.cuda()` of a host leaf)
+        x.grad = None
+        crit(x.view_as(x), batches[i % n_batches]).backward()
+
+    def leaf_step(i):
         x.grad = None
         crit(x, batches[i % n_batches]).backward()
 
-    def engine_step(i):  # (non-leaf emissions, as under train.py:262-266)
+    def engine_step(i):  # (a producer with kernels of its own, as under train.py:262-266)
         x.grad = None
         crit(x * 1.0, batches[i % n_batches]).backward()
-
-    def engine_view_step(i):
-        x.grad = None
-        crit(x.view_as(x), batches[i % n_batches]).backward()
 
     def training_step(i):  # non-leaf emissions, a batch of targets never seen before
         x.grad = None
@@ -396,7 +418,7 @@ def make_transducer(args, rank, n_batches):
     def viterbi_step(i):  # (train.py:279 decodes every training batch for its error rate)
         crit.viterbi(x.detach())
 
-    return dict(step=step, engine_step=engine_step, engine_view_step=engine_view_step, training_step=training_step,
+    return dict(step=step, leaf_step=leaf_step, engine_step=engine_step, training_step=training_step,
                 training_step_prepared=training_step_prepared, fresh_prepared_step=fresh_prepared_step, viterbi_step=viterbi_step,
                 meta=meta, payload=("transducer", x.detach(), crit, batches[0]))
 
@@ -609,7 +631,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step = wl["abi_step"] if args.mode == "abi" else wl["step"] if args.targets == "fresh" else (lambda i: wl["step"](0))
+    api_step = wl["leaf_step"] if args.emissions == "leaf" else wl["step"]
+    step = wl["abi_step"] if args.mode == "abi" else api_step if args.targets == "fresh" else (lambda i: api_step(0))
     elapsed, phase_ms = timed_loop(step, args.steps, args.warmup, fence, True)
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
@@ -635,6 +658,11 @@ def main():
         "config": {"workload": meta["workload"], "mode": args.mode, "targets": ("pre-staged" if args.mode != "api" else "fresh (new targets every step)" if args.targets == "fresh" else
                                "same list every step (the reference benchmark's protocol: resident on the device after the first call)"),
                    "timed_call": meta["call"] if args.mode == "api" else "wfl_ctc_forward_backward (C ABI, targets pre-staged)",
+                   "emissions": ("n/a (C ABI)" if args.mode != "api" else
+                                 "the leaf itself (loss.backward() hands the gradient to x.grad)" if args.emissions == "leaf" else
+                                 "a producer's output, not a leaf (x.view_as(x) of a device-resident leaf; ctc_benchmark.py:22 and "
+                                 "train.py:262-266 hand over non-leaf emissions): loss.backward() runs the graph below them on the "
+                                 "autograd engine"),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": par,
                    "collective_world_size": dist.get_world_size() if dist is not None else 1},
     }
@@ -705,12 +733,12 @@ def main():
     if single and not args.no_extras:
         if args.mode == "abi":
             # the drop-in operator on the same workload, the reference benchmark's protocol (same target list every step)
-            el, _ = timed_loop(lambda i: wl["step"](0), extras_steps, 3, fence, False)
+            el, _ = timed_loop(lambda i: api_step(0), extras_steps, 3, fence, False)
             out["python_api"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
                                  "what": meta["call"] + ": autograd operator, eager, host overhead included"}
         if fresh_extra:
             # cold cache: targets never seen before in every step (batches 1.. of the workload; batch 0 was the main run's)
-            el, _ = timed_loop(lambda i: wl["step"](1 + i), extras_steps, 3, fence, False)
+            el, _ = timed_loop(lambda i: api_step(1 + i), extras_steps, 3, fence, False)
             out["fresh_targets"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
                                     "what": "operator path, new targets in every step: per-batch host work (flattening, "
                                             "staging and upload; Transducer: the graph algebra) inside the timed region, "
@@ -745,25 +773,33 @@ def main():
                         "the per-batch graph algebra, packing and upload on a side thread and stream (Transducer.prepare)"}
         if args.mode == "api" and args.targets == "fresh":
             # the reference benchmarks' own protocol: the same target list every iteration
-            el, _ = timed_loop(lambda i: wl["step"](0), extras_steps, 3, fence, False)
+            el, _ = timed_loop(lambda i: api_step(0), extras_steps, 3, fence, False)
             out["same_targets"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
                                    "what": "operator path, one target list reused by every iteration (the reference "
                                            "benchmark scripts' protocol; content-keyed host caches hit)"}
-        if args.mode == "api" and "engine_view_step" in wl:
-            el, _ = timed_loop(lambda i: wl["engine_view_step"](0), extras_steps, 3, fence, False)
-            out["through_autograd_engine_view"] = {
+        if args.mode == "api" and "leaf_step" in wl:
+            other = wl["step"] if args.emissions == "leaf" else wl["leaf_step"]
+            el, _ = timed_loop(lambda i: other(0), extras_steps, 3, fence, False)
+            out["leaf_emissions" if args.emissions != "leaf" else "output_emissions"] = {
                 "value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
-                "what": "as through_autograd_engine, the non-leaf emissions being a VIEW of the leaf (x.view_as(x): no "
-                        "kernel of its own, forward or backward) -- the autograd engine's share alone, without the two "
-                        "elementwise passes x * 1.0 adds"}
+                "what": ("the same call with the emissions being the LEAF itself (rounds 1-5's headline): loss.backward() hands "
+                         "the forward launch's gradient to x.grad, no graph below the emissions, no autograd engine"
+                         if args.emissions != "leaf" else
+                         "the same call on emissions that are a producer's output (x.view_as(x)): the default headline protocol")}
+        if args.mode == "api" and "engine_proper_step" in wl:
+            el, _ = timed_loop(lambda i: wl["engine_proper_step"](0), extras_steps, 3, fence, False)
+            out["autograd_engine_from_the_loss"] = {
+                "value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
+                "what": "the headline call with the criterion's short cut switched off (WFL_CTC_FAST_BACKWARD=0): "
+                        "torch.Tensor.backward from the loss down -- ones_like fill, the criterion's node, the scale launch, "
+                        "then the graph below the emissions"}
         if args.mode == "api" and "engine_step" in wl:
             el, _ = timed_loop(lambda i: wl["engine_step"](0), extras_steps, 3, fence, False)
             out["through_autograd_engine"] = {
                 "value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,
-                "what": "the same call on emissions that are NOT a leaf (x * 1.0: a model's output, train.py:262-266" +
+                "what": "the same call with a producer that has kernels of its own (x * 1.0: a model's output, train.py:262-266" +
                         ("; transitions as an nn.Parameter, train.py:205-208" if args.workload == "asg" else "") +
-                        "): loss.backward() runs the autograd engine, the criterion's hand-over of the forward's "
-                        "gradient to leaf .grad does not apply -- what a training loop gets, incl. the x * 1.0 and its backward"}
+                        "): incl. the x * 1.0 and its backward, two elementwise passes over [B,T,C]"}
         if args.workload == "ctc" and args.mode == "api":
             el, ph = timed_loop(wl["abi_step"], extras_steps, 3, fence, True)
             out["abi_kernels_only"] = {"value": B * extras_steps / el, "unit": "utt/s", "ms_per_step": el * 1e3 / extras_steps,

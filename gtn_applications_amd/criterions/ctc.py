@@ -125,22 +125,42 @@ class _FusedLogSoftmaxCTCLoss(CTCLossFunction):
 class _EagerLoss(torch.Tensor):
     """The scalar the C++ CTC node returns.  A plain tensor in every respect (no __torch_function__ dispatch) but one:
     `loss.backward()` with no arguments -- the call of ctc_benchmark.py:29-31 and of every training loop that uses the
-    criterion's output as its loss -- hands the gradient the forward launch already computed to the emissions' .grad
-    without a trip through the autograd engine (csrc/torch_ops.cpp ctc_fast_backward: the engine's two thread
-    hand-overs, the ones_like fill and the scale launch cost more host time than the step's kernels take).  Anything
-    else -- a gradient argument, retain_graph, create_graph, inputs=, hooks on the emissions, non-leaf emissions,
-    anomaly mode, or the loss used inside a larger expression -- goes through torch.Tensor.backward / the engine."""
+    criterion's output as its loss -- does not run the criterion's own node on the autograd engine: the forward launch
+    already computed the gradient, so for leaf emissions it is handed to their .grad directly, and for emissions that
+    are a producer's output (a model's, train.py:262-266) the engine is started at THEIR edge with that gradient
+    (csrc/torch_ops.cpp ctc_fast_backward: the ones_like fill, the trip through this node and the scale launch cost
+    more host time than the step's kernels take).  Anything else -- a gradient argument, retain_graph, create_graph,
+    inputs=, hooks on the loss (or on leaf emissions), anomaly mode, the loss used inside a larger expression, a torch
+    other than the one the node was compiled against -- goes through torch.Tensor.backward / the engine."""
 
     __torch_function__ = torch._C._disabled_torch_function_impl
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
-        if (gradient is None and not retain_graph and not create_graph and inputs is None and _FAST_BACKWARD
+        if (gradient is None and not retain_graph and not create_graph and inputs is None and fast_backward_enabled()
                 and not torch.is_anomaly_enabled() and _native_node().ctc_fast_backward(self)):
             return None
         return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
 
 
 _FAST_BACKWARD = os.environ.get("WFL_CTC_FAST_BACKWARD", "1") != "0"  # (0: always the autograd engine -- A/B, tests)
+_FAST_BACKWARD_OK = None
+
+
+def fast_backward_enabled():
+    """The short cut reads autograd structures through torch's C++ headers (Node hooks, AccumulateGrad, Engine::execute):
+    it is only taken under the torch release the extension was compiled against -- any other falls back to
+    torch.Tensor.backward, which is always correct (tests/test_host_library.py pins the fall-back)."""
+    global _FAST_BACKWARD_OK
+    if _FAST_BACKWARD_OK is None:
+        node = _native_node()
+        built = getattr(node, "built_for_torch", None)
+        _FAST_BACKWARD_OK = bool(built) and built() == torch_release(torch.__version__)
+    return _FAST_BACKWARD and _FAST_BACKWARD_OK
+
+
+def torch_release(version):
+    """'2.10.0+rocm7.0' -> '2.10.0' (TORCH_VERSION in the headers carries no local build tag)."""
+    return str(version).split("+")[0]
 
 
 def _native_node():

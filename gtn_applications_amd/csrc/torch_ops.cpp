@@ -9,6 +9,7 @@
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
+#include <torch/csrc/autograd/engine.h>
 #include <torch/csrc/autograd/functions/accumulate_grad.h>
 #include <torch/csrc/autograd/python_variable.h>
 #include <torch/extension.h>
@@ -433,27 +434,42 @@ at::Tensor ctc_step(const at::Tensor& x, const at::Tensor& staged, int64_t off_o
                         host_state);
 }
 
-// `loss.backward()` for the loss a CtcStep node returned, WITHOUT the autograd engine: the gradient was computed by
-// the forward launch (for an upstream gradient of one, which is what a bare .backward() on a scalar means), so all
-// that is left is what AccumulateGrad would do -- hand dx to the leaf's .grad (or add it).  The engine's version of
-// this costs two thread hand-overs (CUDA nodes run on the engine's device thread), a ones_like fill and the scale
-// launch: 40-60 us of host time per step where the step's kernels take 45.  Returns false -- the caller then takes
-// the ordinary torch.Tensor.backward -- whenever anything is not exactly the plain case: the loss is not a fresh
-// CtcStep output, the emissions are not a leaf, hooks are registered on them, the gradient buffer has been handed
-// out already.  Same results, same .grad semantics (first gradient: the buffer itself; later ones: added in place),
-// same error on a second backward.
+// `loss.backward()` for the loss a CtcStep node returned, without running THIS node on the autograd engine: the gradient
+// was computed by the forward launch (for an upstream gradient of one, which is what a bare .backward() on a scalar
+// means), so what is left is to hand dx on.
+//   * Leaf emissions (ctc_benchmark.py's protocol on device-resident inputs): what AccumulateGrad would do -- dx becomes
+//     the leaf's .grad (or is added to it).  No engine at all.
+//   * Emissions that are some producer's OUTPUT (a model's, train.py:262-266; `.cuda()` of a host leaf,
+//     ctc_benchmark.py:22): the engine is started AT the emissions' edge with dx as its root gradient
+//     (x.backward(dx) without needing x): same graph below, same hooks on x and on everything under it -- but no
+//     ones_like fill, no trip through this node and no scale launch.
+// The engine's version of the first costs two thread hand-overs (device nodes run on the engine's device thread), a
+// ones_like fill and the scale launch: 40-60 us of host time per step where the step's kernels take 45.  Returns false --
+// the caller then takes the ordinary torch.Tensor.backward -- whenever anything is not exactly the plain case: the loss
+// is not a fresh CtcStep output, hooks are registered on the loss or its node (or, for a leaf, on the emissions: the
+// engine runs those), the gradient buffer has been handed out already.  Same results, same .grad semantics (first
+// gradient: the buffer itself; later ones: added in place), same error on a second backward.
+// Only what torch's public headers declare is read here: Node::{pre,post,tensor_pre,retains_grad}_hooks(),
+// next_edge(), AccumulateGrad::variable / tensor_post_acc_grad_hooks(), Engine::execute (built_for_torch() below lets
+// the Python side refuse this path under another torch than the one these headers came from).
 bool ctc_fast_backward(const at::Tensor& loss) {
   auto fn = loss.grad_fn();
   auto* node = dynamic_cast<torch::autograd::CppNode<CtcStep>*>(fn.get());
   if (!node || loss.dim() != 0) return false;
-  if (!fn->pre_hooks().empty() || !fn->post_hooks().empty() || !fn->tensor_pre_hooks().empty()) return false;
-  const auto& edge = fn->next_edge(0);
+  if (!fn->pre_hooks().empty() || !fn->post_hooks().empty() || !fn->tensor_pre_hooks().empty() ||
+      !fn->retains_grad_hooks().empty())
+    return false;
+  const torch::autograd::Edge edge = fn->next_edge(0);
+  if (!edge.function) return false;
   auto* acc = dynamic_cast<torch::autograd::AccumulateGrad*>(edge.function.get());
-  if (!acc || !acc->pre_hooks().empty() || !acc->post_hooks().empty()) return false;
-  at::Tensor x = acc->variable;
-  if (!x.defined() || !x.requires_grad()) return false;
-  auto* meta = torch::autograd::impl::get_autograd_meta(x);
-  if (!meta || !meta->hooks_.empty() || meta->cpp_hooks_list_ || meta->post_acc_grad_hooks_) return false;
+  at::Tensor x;
+  if (acc) {
+    if (!acc->pre_hooks().empty() || !acc->post_hooks().empty() || !acc->tensor_pre_hooks().empty() ||
+        acc->tensor_post_acc_grad_hooks())
+      return false;
+    x = acc->variable;
+    if (!x.defined() || !x.requires_grad()) return false;
+  }
   auto& saved = node->ctx_.saved_data;
   if (saved.find("freed") != saved.end()) return false;  // (the ordinary path raises torch's error)
   auto it = saved.find("dx");
@@ -461,14 +477,23 @@ bool ctc_fast_backward(const at::Tensor& loss) {
   at::Tensor dx = it->second.toTensor();
   saved.clear();  // what the engine's release of the graph does
   saved["freed"] = true;
-  at::NoGradGuard no_grad;
-  at::Tensor& grad = x.mutable_grad();
-  if (!grad.defined())
-    grad = std::move(dx);
-  else
-    grad.add_(dx);
+  if (acc) {
+    at::NoGradGuard no_grad;
+    at::Tensor& grad = x.mutable_grad();
+    if (!grad.defined())
+      grad = std::move(dx);
+    else
+      grad.add_(dx);
+    return true;
+  }
+  py::gil_scoped_release no_gil;  // (the engine takes the GIL itself where it runs Python nodes and hooks)
+  torch::autograd::Engine::get_default_engine().execute({edge}, {std::move(dx)}, /*keep_graph=*/false,
+                                                        /*create_graph=*/false, /*accumulate_grad=*/true, {});
   return true;
 }
+
+// the torch these nodes were compiled against (criterions/ctc.py compares it with the running one)
+std::string built_for_torch() { return TORCH_VERSION; }
 
 
 // ------------------------------------------------------------------------------------------------------------
@@ -664,6 +689,7 @@ std::pair<std::vector<at::Tensor>, bool> lattice_loss_forward(const at::Tensor& 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ctc_fast_backward", &ctc_fast_backward,
         "loss.backward() of a CtcStep loss without the autograd engine (false: not the plain case, use the engine)");
+  m.def("built_for_torch", &built_for_torch, "torch version whose headers this module was compiled against");
   m.def("ctc_step", &ctc_step, "CTC loss + eager gradient in one pipelined launch (C++ autograd node)");
   m.def("asg_forward", &asg_forward, "every launch of an ASG step's forward in one native call (criterions/asg.py)");
   m.def("lattice_loss_forward", &lattice_loss_forward,

@@ -27,6 +27,18 @@ def shard_batch(inputs, targets, rank=None, world=None):
     return inputs[lo:hi], targets[lo:hi]
 
 
+def _all_reduce_sum_(flat, group=None):
+    """dist.all_reduce(SUM) of one flat tensor.  RCCL ("nccl") reduces device buffers in place over xGMI; a gloo group
+    (CPU tests; two ranks sharing one GPU in tests/test_gpu_world2.py) gets device payloads staged through the host."""
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
 def all_reduce_mean_(tensors, group=None, force=False):
     """In-place average over ranks of a list of tensors with ONE collective (flattened).  A group of one rank has
     nothing to exchange and returns at once -- unless `force`: the collective is then issued all the same (the only
@@ -38,7 +50,7 @@ def all_reduce_mean_(tensors, group=None, force=False):
     if world == 1 and not force:
         return tensors
     flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum_(flat, group)
     flat /= world
     off = 0
     for t in tensors:
@@ -62,5 +74,5 @@ def global_mean_loss(local_mean, n_local, group=None):
         return local_mean
     buf = torch.stack([local_mean.detach().to(torch.float32) * n_local,
                        torch.tensor(float(n_local), device=local_mean.device)])
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum_(buf, group)
     return buf[0] / buf[1]

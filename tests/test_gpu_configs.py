@@ -12,7 +12,7 @@ Tolerance (north_star: 1e-4 relative on log-semiring loss / grad): every gradien
 atol 1e-5 at B=5, i.e. 5e-5 of a posterior's scale), where coef_b = scale_b / B is the factor the reference multiplies a
 posterior (a number in [0,1]) with (ctc.py:87, asg.py:171-179, transducer.py:329-336) -- i.e. posteriors are
 right to 5e-5 of their scale; per-utterance losses to 1e-4 relative.  The measured worst cases are written to
-gpurun_out/parity_r05.json.  Nothing here reads /root/reference."""
+gpurun_out/parity_r06.json.  Nothing here reads /root/reference."""
 import json
 import os
 import random
@@ -28,7 +28,7 @@ from oracle import recurrences as OR  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTOL = 1e-4
-ATOL_SCALE = 5e-5
+ATOL_SCALE = 2e-5  # (the worst at-size case of round 5 sits at 1.0e-5 of scale: profiles/r05_parity_worst_cases.json)
 STATS = {}
 
 
@@ -40,7 +40,7 @@ def _gpu_and_stats():
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "parity_r05.json"), "w") as f:
+        with open(os.path.join(out, "parity_r06.json"), "w") as f:
             json.dump(STATS, f, indent=1)
     except OSError:
         pass

@@ -1756,6 +1756,94 @@ def test_ctc_loss_backward_without_the_engine_equals_the_engine(monkeypatch):
             torch.testing.assert_close(got.grad, 2 * want.grad)
 
 
+def test_ctc_loss_backward_started_at_non_leaf_emissions_equals_the_engine(monkeypatch):
+    """Emissions that are a producer's output (train.py:262-266; ctc_benchmark.py:22): `loss.backward()` starts the
+    autograd engine AT the emissions' edge with the forward launch's gradient (csrc/torch_ops.cpp ctc_fast_backward),
+    skipping the criterion's own node.  Everything under the emissions must behave as under torch.Tensor.backward: the
+    producer's backward, tensor hooks and retain_grad on the emissions, accumulation into the leaf, two losses sharing
+    one producer; a hook or retain_grad on the LOSS, and a torch other than the one the extension was built for, fall
+    back to the engine proper."""
+    from gtn_applications_amd.criterions import ctc
+
+    g = torch.Generator().manual_seed(12)
+    B, T, C, L = 8, 90, 30, 7
+    x = torch.randn(B, T, C, generator=g)
+    w = torch.rand(C, generator=g) + 0.5
+    targets = torch.randint(C - 2, (B, L), generator=g).tolist()
+    taken = []
+    real = ctc._native_node().ctc_fast_backward
+
+    class Spy:  # (records whether the short cut handled the call)
+        def __getattr__(self, name):
+            return getattr(ctc._NODE_REAL, name)
+
+        def ctc_fast_backward(self, loss):
+            ok = real(loss)
+            taken.append(ok)
+            return ok
+
+    monkeypatch.setattr(ctc, "_NODE_REAL", ctc._native_node(), raising=False)
+    monkeypatch.setattr(ctc, "_NODE", Spy())
+
+    def run(fast, how):
+        monkeypatch.setattr(ctc, "_FAST_BACKWARD", fast)
+        del taken[:]
+        xg = x.cuda().requires_grad_(True)
+        wd = w.cuda()
+        seen = {}
+        if how == "view":
+            em = xg.view_as(xg)
+        else:
+            em = xg * wd  # a producer with a backward of its own
+        if how == "hook":
+            em.register_hook(lambda gr: seen.setdefault("hook", gr.clone()))
+        if how == "retain_grad":
+            em.retain_grad()
+        loss = ctc.CTCLoss(em, targets, C - 1)
+        assert type(loss) is ctc._EagerLoss
+        if how == "loss_hook":
+            loss.register_hook(lambda gr: seen.setdefault("loss_hook", gr.clone()))
+        if how == "loss_retain_grad":
+            loss.retain_grad()
+        if how == "two_losses":
+            other = ctc.CTCLoss(em, targets[::-1], C - 1, "mean")
+            loss.backward()
+            other.backward()
+        else:
+            loss.backward()
+        if how == "retain_grad":
+            seen["em_grad"] = em.grad.clone()
+        if how == "loss_retain_grad":
+            seen["loss_grad"] = loss.grad.clone()
+        return xg.grad.clone(), seen, list(taken)
+
+    for how, shortcut in (("mul", True), ("view", True), ("hook", True), ("retain_grad", True), ("two_losses", True),
+                          ("loss_hook", False), ("loss_retain_grad", False)):
+        want, want_seen, _ = run(False, how)
+        got, got_seen, took = run(True, how)
+        assert torch.equal(got, want), how
+        assert sorted(got_seen) == sorted(want_seen), how
+        for k in want_seen:
+            assert torch.equal(got_seen[k], want_seen[k]), (how, k)
+        assert took and all(t is shortcut for t in took), (how, took)
+    assert "hook" in run(True, "hook")[1] and "em_grad" in run(True, "retain_grad")[1]
+    # a second backward raises torch's error on both routes
+    monkeypatch.setattr(ctc, "_FAST_BACKWARD", True)
+    xg = x.cuda().requires_grad_(True)
+    loss = ctc.CTCLoss(xg * 1.0, targets, C - 1)
+    loss.backward()
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    # another torch than the extension's: the short cut is refused, the engine gives the same gradient
+    want = run(True, "mul")[0]
+    monkeypatch.setattr(ctc, "_FAST_BACKWARD_OK", None)
+    monkeypatch.setattr(ctc, "torch_release", lambda v: "0.0.0")
+    assert not ctc.fast_backward_enabled()
+    got, _, took = run(True, "mul")
+    assert took == [] and torch.equal(got, want)
+    monkeypatch.setattr(ctc, "_FAST_BACKWARD_OK", None)
+
+
 def test_ctc_step_picks_the_log_domain_launch_while_the_certificate_keeps_rejecting():
     """Scores without structure and a spread of 3 nats: the lane-exponent step's certificate rejects every utterance
     (fast launch + log-domain repair launch).  The repair launch leaves its count in a pinned host word of the
