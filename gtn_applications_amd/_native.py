@@ -17,6 +17,7 @@ EPSILON = -1
 SEMIRING_LOG, SEMIRING_TROPICAL = 0, 1
 DENSE_MAIN, DENSE_REPAIR, DENSE_REDUCE, DENSE_ALL = 1, 2, 4, 7  # parts of wfl_dense_forward_parts / wfl_dense_grad_parts
 CTC_WS_REJECTED, CTC_WS_STATUS, CTC_WS_LOG2Z, CTC_WS_ZRANGE, CTC_WS_DEBUG, CTC_WS_CLOCK = 0, 1, 2, 3, 4, 5
+DENSE_WS_FLAGS = 0  # wfl_dense_workspace_field (include/wfl.h: WFL_DENSE_WS_FLAGS)
 CONV_SPIKE, CONV_BLANK_OPTIONAL = 1, 2
 
 
@@ -142,6 +143,7 @@ _SIGS = {
     "wfl_dense_forward_parts": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "wfl_dense_max_classes": (c_int, []),
     "wfl_dense_on_chip_classes": (c_int, []),
+    "wfl_dense_workspace_field": (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "wfl_dense_workspace": (c_int, [c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "wfl_dense_grad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "wfl_dense_grad_parts": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),

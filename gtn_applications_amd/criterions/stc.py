@@ -143,11 +143,20 @@ class STC(torch.nn.Module):
         if self.training:
             self.nstep += 1
         prob = self.plast + (self.p0 - self.plast) * math.exp(-self.nstep * math.log(2) / self.thalf)
-        if inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 3 and inputs.shape[2] > 1:
-            # keep only blank and the tokens present in this batch (stc.py:205-209), then the augmentation in one launch
-            select_idx = [STC_BLANK_IDX] + list(set(t for target in targets for t in target if t != STC_BLANK_IDX))
-            target_map = {t: i for i, t in enumerate(select_idx)}
+        labels = set(t for target in targets for t in target)
+        # (one launch each way for the alphabet augmentation -- unless a target names the blank itself: the reference's
+        # select list then holds column 0 twice (stc.py:205), which the torch spelling below reproduces as it stands;
+        # an empty batch / zero frames also go there)
+        if (inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 3 and inputs.shape[2] > 1
+                and inputs.shape[0] * inputs.shape[1] > 0 and STC_BLANK_IDX not in labels):
             C = inputs.shape[2]
+            bad = [t for t in labels if not 0 <= int(t) < C]
+            if bad:  # (index_select of stc.py:207 raises; the kernel would read x[t, b, label] out of bounds)
+                raise IndexError(f"index out of range in self: target label {bad[0]} for {C} classes")
+            # keep only blank and the tokens present in this batch (stc.py:205-209: the same list, in the same order,
+            # as the torch spelling below), then the augmentation in one launch
+            select_idx = [STC_BLANK_IDX] + list(labels)
+            target_map = {t: i for i, t in enumerate(select_idx)}
             inv_host = torch.full((C,), -1, dtype=torch.int32)
             sel_host = torch.tensor(select_idx, dtype=torch.int32)
             inv_host[sel_host.long()] = torch.arange(len(select_idx), dtype=torch.int32)
@@ -160,7 +169,7 @@ class STC(torch.nn.Module):
         with torch.set_grad_enabled(log_probs.requires_grad):
             lse = torch.logsumexp(log_probs[:, :, 1:], 2, keepdim=True)  # <star>
             # keep only blank and the tokens present in this batch
-            select_idx = [STC_BLANK_IDX] + list(set(t for target in targets for t in target))
+            select_idx = [STC_BLANK_IDX] + list(labels)
             target_map = {t: i for i, t in enumerate(select_idx)}
             select = torch.IntTensor(select_idx).to(log_probs.device)
             log_probs = log_probs.index_select(2, select)

@@ -1546,6 +1546,24 @@ extern "C" int wfl_dense_on_chip_classes(void) {  // (the log semiring's limit: 
   return c;
 }
 
+// Where a field of the opaque workspace lies (diagnostics / tests: engine.dense_flagged reads the per-utterance flags
+// through this instead of restating dense_ws_carve).
+extern "C" int wfl_dense_workspace_field(int B, int T, int field, int64_t* offset_bytes, int64_t* length_bytes) {
+  if (B <= 0 || T <= 0 || !offset_bytes || !length_bytes) {
+    set_error("dense_workspace_field: bad arguments");
+    return WFL_ERR_INVALID;
+  }
+  const DenseWs w = dense_ws_carve(nullptr, B, T);
+  switch (field) {
+    case WFL_DENSE_WS_FLAGS:  // int32 [B][2]: non-zero = handed to the log-domain kernels (forward, backward sweep)
+      *offset_bytes = (int64_t)((char*)w.flag - (char*)nullptr), *length_bytes = (int64_t)8 * B;
+      return WFL_OK;
+    default:
+      set_error("dense_workspace_field: unknown field %d", field);
+      return WFL_ERR_INVALID;
+  }
+}
+
 int wfl_dense_forward(const float* x, const float* W, int B, int T, int C, int semiring, float* alpha, float* beta,
                       int32_t* bptr, float* logz, void* ws, void* stream) {
   return wfl_dense_forward_parts(x, W, B, T, C, semiring, alpha, beta, bptr, logz, ws, WFL_DENSE_ALL, stream);

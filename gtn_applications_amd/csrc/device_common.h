@@ -4,6 +4,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -24,10 +26,23 @@
 
 namespace wfl {
 // Flags of the events that only order one stream of this device behind another (fork / join of the side streams).
-// Nothing on the host ever inspects them, so they need neither a timestamp nor the system-scope fence a default event
-// performs when it is recorded (measured, same box, alternating: Transducer benchmark step 0.358 -> 0.350 ms).
-constexpr unsigned kOrderEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
-inline unsigned order_event_flags() { return kOrderEventFlags; }
+// Nothing on the host or on another device ever inspects them, so they need neither a timestamp nor the SYSTEM-scope
+// fence a default event performs when it is recorded (a write-back of every XCD's L2 to memory: measured, same box,
+// alternating: Transducer benchmark step 0.358 -> 0.350 ms without it).  What they do need is that the side stream's
+// results are visible to the kernels the other stream launches behind the join: a DEVICE-scope release, which is what
+// hipEventReleaseToDevice asks for (hip_runtime_api.h: "Use a device-scope release when recording this event").
+// Round 5 used hipEventDisableSystemFence instead -- documented for timing-only events, with visibility resting on each
+// kernel packet's own release; WFL_ORDER_EVENTS=nofence selects that again for A/B.
+inline unsigned order_event_flags_from_env() {
+  const char* v = getenv("WFL_ORDER_EVENTS");
+  if (v && !strcmp(v, "nofence")) return hipEventDisableTiming | hipEventDisableSystemFence;
+  if (v && !strcmp(v, "default")) return hipEventDisableTiming;
+  return hipEventDisableTiming | hipEventReleaseToDevice;
+}
+inline unsigned order_event_flags() {
+  static const unsigned flags = order_event_flags_from_env();
+  return flags;
+}
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of once per launch: the
 // call costs the host a microsecond or two, and the CTC operator is host-bound at B = 128
 inline hipError_t set_max_dynamic_lds(const void* kern, int bytes) {

@@ -14,6 +14,8 @@
 #include <torch/csrc/autograd/python_variable.h>
 #include <torch/extension.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <list>
 #include <map>
 #include <mutex>
@@ -23,8 +25,17 @@
 #include "../../include/wfl.h"
 
 namespace {
-// ordering-only events of this device: no timestamp, no system-scope fence when recorded (csrc/device_common.h)
-unsigned order_event_flags() { return hipEventDisableTiming | hipEventDisableSystemFence; }
+// ordering-only events of this device: no timestamp, a device-scope release when recorded (csrc/device_common.h has the
+// reasoning and the WFL_ORDER_EVENTS switch; kept in step by hand: this file does not include the kernels' headers)
+unsigned order_event_flags() {
+  static const unsigned flags = [] {
+    const char* v = getenv("WFL_ORDER_EVENTS");
+    if (v && !strcmp(v, "nofence")) return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+    if (v && !strcmp(v, "default")) return (unsigned)hipEventDisableTiming;
+    return (unsigned)(hipEventDisableTiming | hipEventReleaseToDevice);
+  }();
+  return flags;
+}
 
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;

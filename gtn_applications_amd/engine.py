@@ -6,6 +6,7 @@ import collections
 import ctypes
 import os
 import itertools
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -216,14 +217,12 @@ class PackedLattice:
             external = staged is not None and N.lib.wfl_lattice_host_external(host_handle) == off_i
             if external:
                 slot, buf, view = staged
-                ring = _LATTICE_STAGING[device.index]
+                ring = _lattice_ring(device)
             elif cuda:
                 # through a ring of reusable PINNED buffers and one asynchronous copy: a pageable copy is synchronous
                 # (it would wait for everything queued on the stream before it -- the previous step's kernels), and
                 # a fresh pinned allocation per batch costs a hipHostMalloc
-                ring = _LATTICE_STAGING.get(device.index)
-                if ring is None:
-                    ring = _LATTICE_STAGING[device.index] = _StagingRing(slots=4, nbytes=1 << 22)
+                ring = _lattice_ring(device)
                 if staged is not None:
                     ring.i -= 1  # (the slot offered to the packer was too small: take it again, grown)
                 slot, buf, view = ring.next(nbytes, True)
@@ -308,9 +307,7 @@ class PackedLattice:
         staged = None
         if device is not None and device.type == "cuda":
             # the packer writes the blobs straight into the pinned staging slot they are uploaded from
-            ring = _LATTICE_STAGING.get(device.index)
-            if ring is None:
-                ring = _LATTICE_STAGING[device.index] = _StagingRing(slots=4, nbytes=1 << 22)
+            ring = _lattice_ring(device)
             staged = ring.next(ring.nbytes, True)
             h = N.lib.wfl_transducer_pack_batch_into(tokens._h, lexicon._h, tr, flat.ctypes.data, offsets.ctypes.data,
                                                      len(offsets) - 1, int(C), int(nthreads), staged[1].data_ptr(),
@@ -672,12 +669,13 @@ def dense_forward(x, W, need_beta=True):
 def dense_flagged(st):
     """[B] bool: utterances the probability-domain sweep handed to the log-domain kernels (none beyond the on-chip class
     count: there the frames of the whole batch are one product per frame, csrc/dense_wide.h, with no second arithmetic).
-    (the workspace's layout: csrc/dense_kernels.hip::dense_ws_carve)"""
+    (the workspace's layout is the library's: wfl_dense_workspace_field)"""
     B, T = st.B, st.T
     if st.C > N.lib.wfl_dense_on_chip_classes():
         return torch.zeros(B, dtype=torch.bool, device=st.ws.device)
-    off = 8 * B * 2 * T + 8 * B + 4 * B * 2 * T + 4 * B * T + 4 * 256
-    return st.ws[off:off + 8 * B].view(torch.int32).view(B, 2).ne(0).any(dim=1)
+    off, n = ctypes.c_int64(), ctypes.c_int64()
+    N.check(N.lib.wfl_dense_workspace_field(B, T, N.DENSE_WS_FLAGS, ctypes.byref(off), ctypes.byref(n)))
+    return st.ws[off.value:off.value + n.value].view(torch.int32).view(B, 2).ne(0).any(dim=1)
 
 
 def dense_grad(x, W, st, coef, coef_w=None, gout=None, dx=None, accumulate=False, dW=None, addend=None, dW_addend=None):
@@ -744,6 +742,19 @@ class _StagingRing:
 
 _STAGING = {}
 _LATTICE_STAGING = {}
+
+
+def _lattice_ring(device):
+    """The pinned staging ring of the lattice packers on `device` -- one PER HOST THREAD: Transducer.prepare packs the
+    next batch on a side thread while the caller's thread packs (ASG force alignment, Viterbi, CTC lattices) right
+    after the loss; a ring's cursor, its `ring.i -= 1` retake and its per-slot events are not atomic, and two threads
+    handed the same pinned slot would upload each other's bytes.  (The C++ operator's ring, csrc/torch_ops.cpp
+    PinnedRing, is per device and only touched under the GIL without releasing it.)"""
+    key = (device.index, threading.get_ident())
+    ring = _LATTICE_STAGING.get(key)
+    if ring is None:
+        ring = _LATTICE_STAGING[key] = _StagingRing(slots=4, nbytes=1 << 22)
+    return ring
 _FACTORS = ("scale_none", "scale_mean", "cpos_none", "cpos_mean", "cneg_none", "cneg_mean")
 
 
@@ -824,9 +835,9 @@ def _stage_targets(targets, device, flat=None, lens=None):
     _wflpy = _staging_helper()
 
     key = device.index if device.type == "cuda" else -1
-    ring = _STAGING.get(key)
+    ring = _STAGING.get((key, threading.get_ident()))  # (per host thread, as _lattice_ring)
     if ring is None:
-        ring = _STAGING[key] = _StagingRing()
+        ring = _STAGING[(key, threading.get_ident())] = _StagingRing()
     pinned = device.type == "cuda"
     B = len(lens) if flat is not None else len(targets)
     off_flat = 8 * (B + 1)

@@ -301,13 +301,18 @@ int wfl_debug_grad_occupancy(int lds_bytes);
  * (per-frame scale bookkeeping of the probability-domain sweeps, per-utterance range flags). */
 int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws_bytes);
 /* Largest C the dense-transition entry points accept (asg.py:191-209 has no limit: 16384 is an index-width bound).  Up
- * to wfl_dense_on_chip_classes() (128) the (C+1) x C matrix is private to a workgroup -- registers for the
+ * to wfl_dense_on_chip_classes() (192) the (C+1) x C matrix is private to a workgroup -- registers for the
  * probability-domain sweeps, LDS for the log-domain launches behind them; beyond, the frame update of the whole batch
  * runs as one tiled matrix product per frame on the matrix cores, the matrix streamed from L2 (csrc/dense_wide.h): same
  * entry points, same buffers (sizes from wfl_dense_workspace).  wfl_dense_viterbi keeps the matrix in registers up
  * to 256 classes (the max-plus frame has no matrix-core form) and takes a tiled per-frame launch beyond. */
 int wfl_dense_max_classes(void);
 int wfl_dense_on_chip_classes(void);
+/* Byte offset / length of a field of the opaque dense workspace (diagnostics and tests, like wfl_ctc_workspace_field):
+ * WFL_DENSE_WS_FLAGS = int32 [B][2], non-zero where a probability-domain sweep (forward, backward) handed the
+ * utterance to the log-domain kernels. */
+#define WFL_DENSE_WS_FLAGS 0
+int wfl_dense_workspace_field(int B, int T, int field, int64_t* offset_bytes, int64_t* length_bytes);
 /* forward_score(intersect(emissions, transitions)) (asg.py:114): logz [B]; alpha, beta [B,T,C] are
  * opaque inputs of wfl_dense_grad in the log semiring (scaled probabilities for utterances served
  * by the probability-domain sweep, log scores for utterances it had to hand to the log-domain

@@ -367,6 +367,22 @@ def test_ctc_workspace_fields_lie_inside_the_workspace():
     assert N.lib.wfl_ctc_workspace_field(4, 100, 10, 99, ctypes.byref(off), ctypes.byref(n)) != 0  # unknown field
 
 
+def test_dense_workspace_flags_lie_inside_the_workspace():
+    """wfl_dense_workspace_field: the per-utterance flags engine.dense_flagged reads are inside what
+    wfl_dense_workspace sizes, 8 bytes per utterance, 4-byte aligned; an unknown field is an error."""
+    import ctypes
+
+    from gtn_applications_amd import _native as N
+
+    for (B, T, C) in [(1, 1, 3), (5, 83, 28), (128, 1000, 100), (16, 250, 192)]:
+        part, total = ctypes.c_int64(), ctypes.c_int64()
+        N.check(N.lib.wfl_dense_workspace(B, T, C, ctypes.byref(part), ctypes.byref(total)))
+        off, n = ctypes.c_int64(), ctypes.c_int64()
+        N.check(N.lib.wfl_dense_workspace_field(B, T, N.DENSE_WS_FLAGS, ctypes.byref(off), ctypes.byref(n)))
+        assert n.value == 8 * B and off.value % 4 == 0 and 0 < off.value and off.value + n.value <= total.value
+    assert N.lib.wfl_dense_workspace_field(4, 100, 99, ctypes.byref(off), ctypes.byref(n)) != 0
+
+
 def test_targets_on_device_accepts_tensors_and_lists_alike():
     """the criterion modules pass lists of 1-D tensors (one torch.cat), the functions lists of lists: same flat
     labels, offsets and lengths either way; empty targets included"""
