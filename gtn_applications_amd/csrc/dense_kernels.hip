@@ -1658,7 +1658,7 @@ int wfl_dense_workspace(int B, int T, int C, int64_t* partial_elems, int64_t* ws
     return WFL_ERR_INVALID;
   }
   if (!dense_log_on_chip(C)) {
-    if (partial_elems) *partial_elems = (int64_t)kWideSplit * C * C;
+    if (partial_elems) *partial_elems = (int64_t)wide_split(C) * C * C;
     if (ws_bytes) *ws_bytes = (int64_t)wide_ws_bytes(B, T, C);
     return WFL_OK;
   }

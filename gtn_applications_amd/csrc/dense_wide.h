@@ -22,13 +22,21 @@
 // Gradient: emission posteriors elementwise; the transition gradient is the second matrix product of the path,
 //     dW[1+i][j] = P[i][j] * sum_{b, t >= 1} U[(b,t)][i] V[(b,t)][j],   V = araw_{t-1} / maxa_{t-1},
 //     U = e_t (.) braw_t / maxb_t * coef_w[b] * exp(cuma_{t-1} + mxp_t + cb_t - log Z_b)
-// over K = B (T-1) rows, split into kWideSplit slabs reduced in a fixed order (deterministic, no atomics).
+// over K = B (T-1) rows, split into wide_split(C) slabs reduced in a fixed order (deterministic, no atomics).
 // Tropical semiring (ASG.viterbi, asg.py:217-226): the same tiling with (max, +) and the arg max (lowest previous
 // label on ties, as the LDS-resident kernel).
 #pragma once
 
 constexpr int kWideTM = 64, kWideTN = 64, kWideTK = 16;  // output tile (states x utterances) and K chunk
-constexpr int kWideSplit = 8;                             // K slabs of the transition-gradient product
+// K slabs of the transition-gradient product: as many as bring the launch to ~2048 workgroups (between 8 and 128).  A
+// workgroup walks its slab in chunks of 16 rows behind three barriers each -- ~4 us a chunk, measured -- so the launch
+// takes (rows per slab / 16) chunks whatever the class count: with 8 slabs, C = 200 ... 320 at B = 128, T = 1000 were 128 ... 200
+// workgroups of 1000 chunks (4.1 ms, four times the sweeps); the slabs cost 4 C^2 bytes each (C = 1000: 8, as before).
+__host__ __device__ inline int wide_split(int C) {
+  const int tiles = ((C + kWideTM - 1) / kWideTM) * ((C + kWideTN - 1) / kWideTN);
+  const int s = 2048 / (tiles > 0 ? tiles : 1);
+  return s < 8 ? 8 : s > 128 ? 128 : s;
+}
 
 struct WideWs {
   float* P;      // [C][C]
@@ -238,33 +246,295 @@ __global__ void __launch_bounds__(64 * kWideMfmaWaves) wide_frame_mfma_kernel(co
   if (lg == 0 && b_ok && top > 0.f) atomic_max_pos((dir == 0 ? w.maxa : w.maxb) + orow, top);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The frames of ONE utterance's sweep in ONE workgroup, the matrix in its registers: the step for class counts just
+// beyond what dense_fast_chain_kernel keeps on chip (193 .. 320).  There the per-frame launch above is a poor fit: the
+// product of a frame is only ~10 MFLOP for the whole batch, a launch is ~7 us of stream time whatever it computes, and a
+// sweep is T of them (C = 200, T = 1000, B = 128: 14.9 ms fwd + bwd against 1.1 ms at C = 190).  But 4 C^2 bytes
+// (160 KB at C = 200, 410 KB at C = 320) still fit ONE compute unit's register file (512 KB): grid (B, 2), 1024 threads,
+// a group of 16 lanes owns NR consecutive rows of P (P^T for beta), a lane NR float4 column chunks of each
+// (P[row0 + r][64 k + 4 l .. + 3]: NR * NR * 4 <= 100 registers), the frame vector ping-pongs in LDS.  A frame:
+//     NR 16-byte LDS reads of the vector (the wave's four groups read the same addresses: broadcast), 4 NR^2
+//     multiply-adds, NR all-reductions over the group's 16 lanes (four DPP adds each), the emission factor, one
+//     LDS-only barrier.
+// Same recurrence, same stored format as the per-frame launches (araw / braw and their per-frame divisors in
+// maxa / maxb: the header of this file), so wide_rows_kernel in front and wide_scan_kernel / wide_grad behind are
+// unchanged.  The divisor of a frame is the largest entry of the frame before it, exactly as there: the waves' lanes
+// fold theirs into one LDS word per frame with ds_max (four words in rotation: written in frame n, read in n + 1,
+// cleared in n + 2).
+// Nothing in the frame is conditional: every lane takes part in loads and stores -- lane l of a group works on row
+// l % NR, so up to four lanes compute, and store, the same value -- because emission scores are requested kWideAhead frames
+// ahead and loads and stores share ONE in-order counter (vmcnt): behind a test the compiler's static wait-count pass
+// must assume the path that skipped the later loads, and waits for the youngest of them instead of the oldest
+// (csrc/lattice_kernels.hip, the comment above the chunk loop of run_chain_prob, has the long version).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NR>
+constexpr int wide_ahead() { return NR <= 4 ? 8 : 4; }  // emission scores in flight per lane (frames)
+constexpr int kWideResidentMaxT = 8192;  // the utterance's row references are staged in LDS (4 T bytes)
+__host__ __device__ inline int wide_resident_rows(int C) { return C <= 256 ? 4 : C <= 320 ? 5 : 0; }  // NR (0: does not fit)
+static size_t wide_resident_lds(int NR, int T) { return (size_t)2 * 64 * NR * 4 + 16 + (size_t)8 * T; }
+
+__device__ __forceinline__ float group16_sum(float v) {  // every lane of a row of 16 receives the row's sum
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ float group16_max(float v) {  // v >= 0; every lane of a row of 16 receives the row's maximum
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true)));
+  return v;
+}
+typedef float wide_v2f __attribute__((ext_vector_type(2)));
+
+template <int NR>
+__global__ void __launch_bounds__(1024) wide_resident_sweep_kernel(const float* __restrict__ x, int B, int T, int C, WideWs w,
+                                                                   float* __restrict__ alpha, float* __restrict__ beta) {
+  extern __shared__ __attribute__((aligned(16))) char wide_smem[];
+  constexpr int CP = 64 * NR;
+  constexpr bool PK = NR <= 4;  // packed multiply-adds
+  float* vbuf = reinterpret_cast<float*>(wide_smem);           // [2][CP] frame vector, ping-pong
+  int* dmax = reinterpret_cast<int*>(vbuf + 2 * CP);           // [4] largest entry of a frame, as bits
+  float* mxp_l = reinterpret_cast<float*>(dmax + 4);           // [T]
+  float* dlog = mxp_l + T;                                     // [T] the frames' divisors (stored to maxa / maxb at the end)
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+  const int row0 = NR * grp;
+  const float* A = dir == 0 ? w.P : w.PT;
+  float* out = dir == 0 ? alpha : beta;
+  float* dvec = dir == 0 ? w.maxa : w.maxb;
+  const float* xb = x + (int64_t)b * T * C;
+  const int64_t bt = (int64_t)b * T;
+  // ---- the lane's share of the matrix (every load first, from clamped addresses; masked in a second pass: with the test
+  // next to the load the compiler sinks each load under its test -- 4 NR^2 dependent L2 round trips in a row)
+  float Pl[NR][NR][4];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        Pl[r][k][c] = A[(int64_t)min(row0 + r, C - 1) * C + min(64 * k + 4 * l16 + c, C - 1)];
+  asm volatile("" ::: "memory");
+  // (pairs of columns where the frame's multiply-adds are packed -- v_pk_fma_f32, two per instruction at the same issue
+  // cost; plain floats for NR = 5, which has no room for register pairs)
+  wide_v2f Pr[PK ? NR : 1][PK ? NR : 1][2];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float v = (row0 + r < C && 64 * k + 4 * l16 + c < C) ? Pl[r][k][c] : 0.f;
+        if constexpr (PK)
+          Pr[r][k][c >> 1][c & 1] = v;
+        else
+          Pl[r][k][c] = v;
+      }
+  // ---- the row this lane finishes: l16 % NR of the group's (lanes NR .. 15 duplicate lanes 0 .. NR-1: same value to the
+  // same address).  A lane whose row does not exist (rows C .. 64 NR - 1) stores into the sweep's LAST frame instead, at a
+  // column of its own -- that frame is written for good by the last step, behind a wait for every earlier store
+  const int rsel = l16 % NR;
+  const int myrow = row0 + rsel;
+  const bool live = myrow < C;
+  const int rowc = min(myrow, C - 1);
+  const float rm = w.rm[rowc];
+  for (int t = tid; t < T; t += 1024) mxp_l[t] = w.mxp[bt + t];
+  const int t0 = dir == 0 ? 0 : T - 1;
+  for (int i = tid; i < 2 * CP; i += 1024) {
+    float v = 0.f;
+    if (i < C) {
+      v = out[(bt + t0) * C + i];
+      if (dir == 1) v *= __expf(wide_clean(xb[(int64_t)t0 * C + i]) + w.rm[i] - w.mxp[bt + t0]);
+    }
+    vbuf[i] = v;
+  }
+  if (tid == 0) dmax[0] = __float_as_int(dvec[bt + t0]), dmax[1] = 0, dmax[2] = 0, dmax[3] = 0;
+  float* dump = out + (bt + (dir == 0 ? T - 1 : 0)) * C + max(myrow - C, 0);  // (see `live` above)
+  // where the lane stores (one row further every step; the parked lanes stay where they are) and where its scores come from
+  const int64_t fstep = dir == 0 ? (int64_t)C : -(int64_t)C;
+  float* po = live ? out + (bt + (dir == 0 ? 1 : T - 2)) * C + myrow : dump;
+  const int64_t pstep = live ? fstep : 0;
+  // step n (1 .. T-1) produces frame tf(n) from frame tf(n - 1)
+  auto tf = [&](int n) { return dir == 0 ? n : T - 1 - n; };
+  constexpr int kWideAhead = wide_ahead<NR>();
+  float xr[kWideAhead];
+#pragma unroll
+  for (int u = 0; u < kWideAhead; ++u) xr[u] = xb[(int64_t)tf(min(1 + u, T - 1)) * C + rowc];
+  __syncthreads();
+  auto step = [&](int n, float xv, auto last_) {
+    constexpr bool LAST = decltype(last_)::value;  // the sweep's last step: only lanes with a row store (see `dump`)
+    const int t = tf(n), tp = tf(n - 1);
+    const float* vc = vbuf + ((n - 1) & 1) * CP;
+    float* vn = vbuf + (n & 1) * CP;
+    const float dprev = __int_as_float(dmax[(n - 1) & 3]);
+    const float mx = mxp_l[t];
+    // (one accumulator per row: NR independent chains already; a second one per row costs the NR = 5 instantiation
+    // registers it does not have -- 100 of its 128 hold the matrix)
+    float tot[NR];
+    if constexpr (PK) {
+      wide_v2f acc[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] = wide_v2f{0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const float4 v4 = *reinterpret_cast<const float4*>(vc + 64 * k + 4 * l16);
+        const wide_v2f lo = {v4.x, v4.y}, hi = {v4.z, v4.w};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          acc[r] = __builtin_elementwise_fma(Pr[r][k][0], lo, acc[r]);
+          acc[r] = __builtin_elementwise_fma(Pr[r][k][1], hi, acc[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) tot[r] = acc[r][0] + acc[r][1];
+    } else {
+      // (one scalar accumulator per row: NR independent chains; the NR = 5 instantiation has no registers for more -- 100
+      // of its 128 hold the matrix, and register PAIRS for the packed form cost it 60 spills)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) tot[r] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const float4 v4 = *reinterpret_cast<const float4*>(vc + 64 * k + 4 * l16);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          tot[r] = fmaf(Pl[r][k][0], v4.x, tot[r]);
+          tot[r] = fmaf(Pl[r][k][1], v4.y, tot[r]);
+          tot[r] = fmaf(Pl[r][k][2], v4.z, tot[r]);
+          tot[r] = fmaf(Pl[r][k][3], v4.w, tot[r]);
+        }
+      }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const float s = group16_sum(tot[r]);
+      mine = rsel == r ? s : mine;
+    }
+    const float inv = dprev > 0.f ? 1.f / dprev : 0.f;  // (a dead utterance stays dead: as the per-frame launch)
+    const float e = __expf(wide_clean(xv) + rm - mx);
+    const float ys = mine * inv;
+    const float glob = live ? (dir == 0 ? ys * e : ys) : 0.f;
+    vn[myrow] = live ? ys * e : 0.f;                     // (myrow < CP; rows beyond C stay 0)
+    if (!LAST || live) *po = glob;
+    po += pstep;
+    // the frame's largest entry: one LDS atomic per wave (64 lanes on one LDS word are served one after the other; the
+    // wave's own maximum over the cross-lane network and four scalar reads, not six LDS permutes in a row).  Four words in
+    // rotation: written in step n, read in n + 1, cleared in n + 2.
+    const int gm = __float_as_int(group16_max(glob));    // (glob >= 0: the bit patterns order like the values)
+    const int wm = max(max(__builtin_amdgcn_readlane(gm, 0), __builtin_amdgcn_readlane(gm, 16)),
+                       max(__builtin_amdgcn_readlane(gm, 32), __builtin_amdgcn_readlane(gm, 48)));
+    if ((tid & 63) == 0) atomicMax(&dmax[n & 3], wm);
+    if (tid == 0) dmax[(n + 1) & 3] = 0, dlog[tp] = dprev;
+    lds_barrier();
+  };
+  int n = 1;
+  // (whole groups whose requests stay inside the utterance: straight-line code, no test between the steps, no clamp)
+  const float* px = xb + (int64_t)tf(min(1 + kWideAhead, T - 1)) * C + rowc;  // the scores of step n + kWideAhead
+  for (; n + 2 * kWideAhead <= T; n += kWideAhead) {
+#pragma unroll
+    for (int u = 0; u < kWideAhead; ++u) {
+      step(n + u, xr[u], std::false_type{});
+      xr[u] = px[u * fstep];
+    }
+    px += kWideAhead * fstep;
+  }
+  for (; n + 1 < T; ++n) step(n, xb[(int64_t)tf(n) * C + rowc], std::false_type{});  // (the last steps: their scores requested where they are used)
+  if (n < T) {
+    // the last frame holds what the lanes without a row parked there: every store so far must have landed before it is written
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+    step(n, xb[(int64_t)tf(n) * C + rowc], std::true_type{});
+  }
+  if (tid == 0) dlog[tf(T - 1)] = __int_as_float(dmax[(T - 1) & 3]);
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) dvec[bt + t] = dlog[t];
+}
+
+// wide_forward's frames for class counts whose matrix fits one CU's registers (see above); false: not this case
+static bool wide_resident_frames(const float* x, int B, int T, int C, const WideWs& w, float* alpha, float* beta, hipStream_t st) {
+  const int NR = wide_resident_rows(C);
+  static const bool off = [] {
+    const char* e = getenv("WFL_DENSE_WIDE_RESIDENT");
+    return e && atoi(e) == 0;
+  }();
+  if (NR == 0 || off || T < 2 || T > kWideResidentMaxT) return false;
+  const size_t lds = wide_resident_lds(NR, T);
+  const dim3 grid((unsigned)B, beta ? 2u : 1u);
+  if (NR == 4)
+    hipLaunchKernelGGL(wide_resident_sweep_kernel<4>, grid, dim3(1024), lds, st, x, B, T, C, w, alpha, beta);
+  else
+    hipLaunchKernelGGL(wide_resident_sweep_kernel<5>, grid, dim3(1024), lds, st, x, B, T, C, w, alpha, beta);
+  return true;
+}
+
 // per utterance: the cumulative offsets (a serial scan over T by one thread) and log Z
 __global__ void __launch_bounds__(256) wide_scan_kernel(int B, int T, int C, WideWs w, const float* __restrict__ alpha,
                                                         bool with_beta, float* __restrict__ logz) {
   __shared__ float red[64];
   const int b = blockIdx.x;
-  if (threadIdx.x == 0) {
-    double c = (double)w.m0[b];
-    w.cuma[(int64_t)b * T] = c;
-    for (int t = 1; t < T; ++t) {
-      const float mx = w.maxa[(int64_t)b * T + t];
-      c += (double)w.mxp[(int64_t)b * T + t] + (mx > 0.f ? (double)__logf(mx) : -1.0e300);
-      w.cuma[(int64_t)b * T + t] = c;
-    }
-    if (with_beta) {
-      double d = 0.0;
-      w.cb[(int64_t)b * T + T - 1] = 0.0;
-      for (int t = T - 2; t >= 0; --t) {
-        const float mx = w.maxb[(int64_t)b * T + t];
-        d += (double)w.mxp[(int64_t)b * T + t + 1] + (mx > 0.f ? (double)__logf(mx) : -1.0e300);
-        w.cb[(int64_t)b * T + t] = d;
+  // (256 threads, a contiguous run of frames each: the run's sum, a serial pass over the 256 sums, the run again -- one
+  // thread walking all T frames through dependent loads took 0.26 ms at T = 1000, a fifth of the resident sweeps)
+  __shared__ double runs[256];
+  const int tid = threadIdx.x;
+  const int per = (T - 1 + 255) / 256;  // terms 1 .. T-1 (alpha: frame t; beta: frame T-1-t)
+  const int64_t bt = (int64_t)b * T;
+  auto term_a = [&](int t) {
+    const float mx = w.maxa[bt + t];
+    return (double)w.mxp[bt + t] + (mx > 0.f ? (double)__logf(mx) : -1.0e300);
+  };
+  auto term_b = [&](int t) {  // what frame t adds on the way down from T-1
+    const float mx = w.maxb[bt + t];
+    return (double)w.mxp[bt + t + 1] + (mx > 0.f ? (double)__logf(mx) : -1.0e300);
+  };
+  const int lo = 1 + tid * per, hi = min(T, lo + per);
+  {
+    double sum = 0.0;
+    for (int t = lo; t < hi; ++t) sum += term_a(t);
+    runs[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      double c = (double)w.m0[b];
+      w.cuma[bt] = c;
+      for (int i = 0; i < 256; ++i) {
+        const double r = runs[i];
+        runs[i] = c;
+        c += r;
       }
     }
+    __syncthreads();
+    double c = runs[tid];
+    for (int t = lo; t < hi; ++t) c += term_a(t), w.cuma[bt + t] = c;
+    __syncthreads();
   }
+  if (with_beta) {
+    // frame t = T-1-k for k = 1 .. T-1, in the same runs
+    double sum = 0.0;
+    for (int k = lo; k < hi; ++k) sum += term_b(T - 1 - k);
+    runs[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      double d = 0.0;
+      w.cb[bt + T - 1] = 0.0;
+      for (int i = 0; i < 256; ++i) {
+        const double r = runs[i];
+        runs[i] = d;
+        d += r;
+      }
+    }
+    __syncthreads();
+    double d = runs[tid];
+    for (int k = lo; k < hi; ++k) d += term_b(T - 1 - k), w.cb[bt + T - 1 - k] = d;
+  }
+  __syncthreads();
   const float* last = alpha + ((int64_t)b * T + T - 1) * C;
   float sum = 0.f;
   for (int i = threadIdx.x; i < C; i += 256) sum += last[i];
-  sum = blk_sum(sum, red);  // (its barriers also order thread 0's scan before the read below)
+  sum = blk_sum(sum, red);  // (the scan's last barrier orders cuma before the read below)
   if (threadIdx.x == 0) {
     const float mx = w.maxa[(int64_t)b * T + T - 1];
     const double z = (sum > 0.f && mx > 0.f) ? (double)logf(sum / mx) + w.cuma[(int64_t)b * T + T - 1] : -1.0e300;
@@ -306,7 +576,8 @@ __global__ void __launch_bounds__(256) wide_grad_w_kernel(const float* __restric
   __shared__ int64_t krow[kWideTK];
   const int i0 = blockIdx.x * kWideTM, j0 = blockIdx.y * kWideTN;
   const int64_t K = (int64_t)B * (T - 1);
-  const int64_t per = (K + kWideSplit - 1) / kWideSplit;
+  const int nsplit = (int)gridDim.z;
+  const int64_t per = (K + nsplit - 1) / nsplit;
   const int64_t kbeg = (int64_t)blockIdx.z * per, kend = min(K, kbeg + per);
   const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
   float acc[4][4] = {};
@@ -385,7 +656,8 @@ __global__ void __launch_bounds__(256) wide_reduce_w_kernel(int B, int T, int C,
   } else {
     const int64_t p = e - C;
     float s = 0.f;
-    for (int z = 0; z < kWideSplit; ++z) s += partial[(int64_t)z * C * C + p];
+    const int nsplit = wide_split(C);
+    for (int z = 0; z < nsplit; ++z) s += partial[(int64_t)z * C * C + p];
     v = w.P[p] * s;
   }
   v *= g;
@@ -601,7 +873,7 @@ static int wide_forward(const float* x, const float* W, int B, int T, int C, int
   hipLaunchKernelGGL(wide_prep_kernel, dim3((unsigned)C), dim3(256), 0, st, W, C, w);
   hipLaunchKernelGGL(wide_rows_kernel, dim3((unsigned)(((int64_t)B * T + 3) / 4)), dim3(256), 0, st, x, W, B, T, C, w, alpha,
                      beta);
-  {
+  if (!wide_resident_frames(x, B, T, C, w, alpha, beta, st)) {
     const dim3 grid((unsigned)((C + 15) / 16), (unsigned)((B + 15) / 16), beta ? 2u : 1u);
     for (int s = 1; s < T; ++s)
       hipLaunchKernelGGL(wide_frame_mfma_kernel, grid, dim3(64 * kWideMfmaWaves), 0, st, x, B, T, C, s, w, alpha, beta);
@@ -619,10 +891,10 @@ static int wide_grad(const float* x, int B, int T, int C, const float* alpha, co
                        logz, coef, gout, accumulate, addend, dx);
   if (dW) {
     if (T > 1) {
-      const dim3 grid((unsigned)((C + kWideTM - 1) / kWideTM), (unsigned)((C + kWideTN - 1) / kWideTN), (unsigned)kWideSplit);
+      const dim3 grid((unsigned)((C + kWideTM - 1) / kWideTM), (unsigned)((C + kWideTN - 1) / kWideTN), (unsigned)wide_split(C));
       hipLaunchKernelGGL(wide_grad_w_kernel, grid, dim3(256), 0, st, x, B, T, C, w, alpha, beta, logz, coef_w, dW_partial);
     } else {
-      (void)hipMemsetAsync(dW_partial, 0, (size_t)4 * kWideSplit * C * C, st);
+      (void)hipMemsetAsync(dW_partial, 0, (size_t)4 * wide_split(C) * C * C, st);
     }
     hipLaunchKernelGGL(wide_reduce_w_kernel, dim3((unsigned)(((int64_t)(C + 1) * C + 255) / 256)), dim3(256), 0, st, B, T, C, w,
                        alpha, beta, logz, coef_w, gout, accumulate, dW_addend, dW_partial, dW);

@@ -776,7 +776,7 @@ class CtcTargets:
         self.B, self.n, self._lens = B, n, None
         view = host[1]
         if device.type == "cuda":
-            ring = _STAGING[device.index]
+            ring = _STAGING[(device.index, threading.get_ident())]  # (the ring _stage_targets filled: same thread)
             self.dev_buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             upload(self.dev_buf, host[0], nbytes)
             ev = ring.events[slot]

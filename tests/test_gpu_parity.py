@@ -812,6 +812,26 @@ def test_dense_probability_domain_sweeps_every_padding_bucket(C, T):
     _dense_check(x, W, [False] * B)
 
 
+@pytest.mark.parametrize("C,T", [(193, 2), (193, 40), (200, 9), (200, 61), (255, 8), (256, 17), (257, 5), (257, 33),
+                                 (300, 26), (320, 12), (320, 45), (321, 7)])
+def test_dense_register_resident_sweeps_beyond_the_on_chip_limit(C, T):
+    """193 .. 320 classes: the frames of an utterance's sweep run inside ONE workgroup whose registers hold the transition
+    matrix (csrc/dense_wide.h wide_resident_sweep_kernel: four rows x four column chunks per lane up to 256 classes, five
+    x five up to 320; the stored format is the per-frame launches', which 321 classes still take) -- every bucket edge,
+    utterance lengths around the emission prefetch depth (whole groups of 8 / 4 steps, a tail, a single step), an
+    emission row holding -inf and NaN entries, a dead utterance: loss / emission gradient / transition gradient against
+    the float64 recurrences."""
+    rs = np.random.RandomState(C * 11 + T)
+    B = 3
+    x = (2.0 * rs.randn(B, T, C)).astype(np.float32)
+    W = rs.randn(C + 1, C).astype(np.float32)
+    if T > 4:
+        x[1, 2, ::3] = -np.inf
+        x[1, 3, 5] = np.nan
+        x[2, 1, :] = -np.inf  # no path through frame 1: logZ = -inf, zero gradient
+    _dense_check(x, W, [False] * B)
+
+
 def test_dense_sweep_emissions_that_are_only_four_byte_aligned():
     """With an even class count the sweep's helper wave loads a row's scores as 8-byte pairs; a tensor that starts on an
     odd float (a view into a larger buffer) takes the two-load form instead: same results either way."""
