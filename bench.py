@@ -280,7 +280,7 @@ def make_ctc(args, rank, n_batches, dist=None):
 
     which = {(1000, 100, 128, 44): " (BASELINE configs[1])", (2000, 512, 128, 44): " (BASELINE configs[4], one GPU's shard)",
              (150, 28, 8, 44): " (BASELINE configs[0])"}.get((T, C, B, L), "")
-    key = {(1000, 100, 128, 44): "cfg2", (2000, 512, 128, 44): "cfg5"}.get((T, C, B, L))
+    key = {(1000, 100, 128, 44): "cfg2", (2000, 512, 128, 44): "cfg5", (1000, 100, 1024, 44): "cfg2_B1024"}.get((T, C, B, L))
     meta = dict(workload=f"ctc fwd+bwd T={T} C={C} B={B} L={L}{which}", B=B, T=T, C=C, L=L, key=key, repaired=repaired,
                 exchange_bytes=0 if exchange is None else exchange.numel() * 4,
                 metric=f"utterances/sec fwd+bwd (ctc_benchmark T={T},C={C},B={B}); HBM GB/s vs peak",

@@ -1818,11 +1818,20 @@ int wfl_dense_viterbi(const float* x, const float* W, int B, int T, int C, float
                        C, alpha);
     const dim3 grid((unsigned)((C + 15) / 16), (unsigned)((B + 15) / 16));
     const bool vec4 = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(alpha)) & 15) == 0;
-    for (int t = 1; t < T; ++t) {
-      if (vec4)
-        hipLaunchKernelGGL(wide_viterbi_max_kernel<true>, grid, dim3(64 * kVitWideWaves), 0, st, x, W, B, T, C, t, alpha);
-      else
-        hipLaunchKernelGGL(wide_viterbi_max_kernel<false>, grid, dim3(64 * kVitWideWaves), 0, st, x, W, B, T, C, t, alpha);
+    static const bool resident_off = [] {
+      const char* e = getenv("WFL_DENSE_WIDE_RESIDENT");
+      return e && atoi(e) == 0;
+    }();
+    if (wide_resident_rows(C) == 5 && T >= 2 && !resident_off) {
+      // up to 320 classes: the frames of an utterance inside one workgroup, the matrix in its registers (same vectors)
+      hipLaunchKernelGGL(wide_resident_viterbi_kernel<5>, dim3((unsigned)B), dim3(1024), 0, st, x, W, B, T, C, alpha);
+    } else {
+      for (int t = 1; t < T; ++t) {
+        if (vec4)
+          hipLaunchKernelGGL(wide_viterbi_max_kernel<true>, grid, dim3(64 * kVitWideWaves), 0, st, x, W, B, T, C, t, alpha);
+        else
+          hipLaunchKernelGGL(wide_viterbi_max_kernel<false>, grid, dim3(64 * kVitWideWaves), 0, st, x, W, B, T, C, t, alpha);
+      }
     }
     hipLaunchKernelGGL(dense_viterbi_walk_kernel, dim3((unsigned)B), dim3(64), 0, st, alpha, W, B, T, C, path);
     WFL_LAUNCH_CHECK();

@@ -791,6 +791,99 @@ __global__ void __launch_bounds__(64 * kVitWideWaves)
     }
   }
 }
+// The max-plus frames of ONE utterance in ONE workgroup, the matrix in its registers: wide_resident_sweep_kernel's layout
+// (a group of 16 lanes owns NR consecutive rows of W, a lane NR float4 column chunks of each; the previous vector in LDS)
+// for wfl_dense_viterbi between 257 and 320 classes, where the per-frame launches above cost ~8 us of stream time per
+// frame (C = 320, T = 1000, B = 128: 8.6 ms).  Every sum is ONE fp32 addition of the same two operands as in
+// wide_viterbi_max_kernel and a maximum does not depend on the order it is taken in: the stored vectors are identical,
+// bit for bit, and so is the path dense_viterbi_walk_kernel reads off them.
+template <int NR>
+__global__ void __launch_bounds__(1024) wide_resident_viterbi_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                     int B, int T, int C, float* __restrict__ alpha) {
+  constexpr int CP = 64 * NR;
+  __shared__ __attribute__((aligned(16))) float vbuf[2][CP];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+  const int row0 = NR * grp;
+  const float* xb = x + (int64_t)b * T * C;
+  float* ob = alpha + (int64_t)b * T * C;
+  float Wl[NR][NR][4];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        Wl[r][k][c] = W[(int64_t)(1 + min(row0 + r, C - 1)) * C + min(64 * k + 4 * l16 + c, C - 1)];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        Wl[r][k][c] = (row0 + r < C && 64 * k + 4 * l16 + c < C) ? wide_clean(Wl[r][k][c]) : WFL_NEG_INF;
+  const int rsel = l16 % NR;
+  const int myrow = row0 + rsel;
+  const bool live = myrow < C;
+  const int rowc = min(myrow, C - 1);
+  for (int i = tid; i < 2 * CP; i += 1024) (&vbuf[0][0])[i] = i < C ? ob[i] : WFL_NEG_INF;  // frame 0 (wide_viterbi_first_max_kernel)
+  // (lanes without a row park their stores in the LAST frame, at a column of their own: wide_resident_sweep_kernel)
+  float* po = live ? ob + (int64_t)C + myrow : ob + (int64_t)(T - 1) * C + max(myrow - C, 0);
+  const int64_t pstep = live ? (int64_t)C : 0;
+  constexpr int kAhead = 4;
+  float xr[kAhead];
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u) xr[u] = xb[(int64_t)min(1 + u, T - 1) * C + rowc];
+  __syncthreads();
+  auto step = [&](int n, float xv, auto last_) {
+    constexpr bool LAST = decltype(last_)::value;
+    const float* vc = vbuf[(n - 1) & 1];
+    float* vn = vbuf[n & 1];
+    float best[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) best[r] = WFL_NEG_INF;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const float4 v4 = *reinterpret_cast<const float4*>(vc + 64 * k + 4 * l16);
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        best[r] = fmaxf(fmaxf(best[r], fmaxf(Wl[r][k][0] + v4.x, Wl[r][k][1] + v4.y)), fmaxf(Wl[r][k][2] + v4.z, Wl[r][k][3] + v4.w));
+    }
+    float mine = WFL_NEG_INF;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float m = best[r];  // the row's maximum over the group's 16 lanes (any order: exact)
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0xB1, 0xf, 0xf, false)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x4E, 0xf, 0xf, false)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x141, 0xf, 0xf, false)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x140, 0xf, 0xf, false)));
+      mine = rsel == r ? m : mine;
+    }
+    const float y = wide_clean(xv) + mine;
+    vn[myrow] = live ? y : WFL_NEG_INF;
+    if (!LAST || live) *po = y;
+    po += pstep;
+    lds_barrier();
+  };
+  int n = 1;
+  const float* px = xb + (int64_t)min(1 + kAhead, T - 1) * C + rowc;
+  for (; n + 2 * kAhead <= T; n += kAhead) {
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      step(n + u, xr[u], std::false_type{});
+      xr[u] = px[(int64_t)u * C];
+    }
+    px += (int64_t)kAhead * C;
+  }
+  for (; n + 1 < T; ++n) step(n, xb[(int64_t)n * C + rowc], std::false_type{});
+  if (n < T) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): what was parked in the last frame has landed
+    __syncthreads();
+    step(n, xb[(int64_t)n * C + rowc], std::true_type{});
+  }
+}
+
 __global__ void __launch_bounds__(256) wide_viterbi_first_max_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                      int B, int T, int C, float* __restrict__ alpha) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;

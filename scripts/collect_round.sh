@@ -27,6 +27,15 @@ for cfg in cfg2 cfg3 cfg4 cfg5; do
     rm -rf $O/pmc_${cfg}_$c
   done
 done
+# round 6: the CTC launch at B = 1024 (eight utterance pairs per CU: no chain-latency excuse) through the C ABI, kernel stats + PMC
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg2_B1024 -- python bench.py --config cfg2 --mode abi --B 1024 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/stats_cfg2_B1024.log 2>&1 </dev/null
+f=$(find $O/stats_cfg2_B1024 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/cfg2_B1024_kernel_stats.csv
+rm -rf $O/stats_cfg2_B1024
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_cfg2_B1024_$c -- python bench.py --config cfg2 --mode abi --B 1024 --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_cfg2_B1024_$c.log 2>&1 </dev/null
+  f=$(find $O/pmc_cfg2_B1024_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/pmc_cfg2_B1024_$c.csv
+  rm -rf $O/pmc_cfg2_B1024_$c
+done
 python scripts/pmc_traffic.py $O > $O/pmc_traffic.json
 for cfg in cfg2 cfg3 cfg4 cfg5; do
   python bench.py --config $cfg --steps 30 --warmup 5 2>/dev/null | tail -1 >> $O/bench_lines.jsonl
@@ -44,6 +53,9 @@ python scripts/kstats.py $O
 # round 5: STC / ConvTransduce1D at a size, ASG beyond 128 classes, step timelines, host overhead, resource table input
 python scripts/at_size_lines.py > $O/stc_conv_lines.jsonl 2> $O/stc_conv_lines.log
 python scripts/asg_classes_time.py > $O/asg_129_to_200_classes.txt 2>/dev/null
+python scripts/asg_classes_time.py 128,1000,190 128,1000,200 128,1000,256 128,1000,320 128,1000,330 > $O/asg_193_to_320_classes.txt 2>/dev/null
+python scripts/dense_split_time.py 128,1000,190 128,1000,200 128,1000,256 128,1000,320 32,250,1000 >> $O/asg_193_to_320_classes.txt 2>/dev/null
+python scripts/engine_path_probe.py > $O/engine_path_probe.txt 2>/dev/null
 for cfg in cfg2 cfg3 cfg4; do
   bash scripts/step_timeline.sh --config $cfg > $O/${cfg}_step_timeline.txt 2>/dev/null
 done
@@ -56,6 +68,6 @@ python scripts/viterbi_module_time.py > $O/viterbi_module_times.txt 2>/dev/null
 for b in 16 32; do for n in 1 2; do python scripts/ngram_step_probe.py $b $n 2>/dev/null | grep -v amdgpu >> $O/ngram_step_probe.txt; done; done
 bash scripts/cmd_timeline.sh gather python scripts/ngram_step_probe.py 32 2 > $O/ngram_bigram_step_timeline.txt 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vit -- python scripts/asg_classes_time.py 128,1000,100 128,1000,150 > $O/stats_vit.log 2>&1
-grep -i "viterbi\|Name" $(find $O/stats_vit -name "*kernel_stats.csv" | head -1) > $O/viterbi_kernel_stats.csv
+f=$(find $O/stats_vit -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -i "viterbi\|Name" $f > $O/viterbi_kernel_stats.csv
 rm -rf $O/stats_vit
 rm -f $O/pmc_*_SIZE.csv.bak

@@ -62,7 +62,10 @@ def same_values(a, b):
 SHAPES = [(3, 17, 5), (4, 50, 32), (4, 33, 33), (2, 40, 64), (2, 41, 65), (3, 64, 100), (2, 30, 104), (2, 25, 105),
           (2, 20, 128), (2, 18, 129), (1, 19, 192), (2, 21, 193), (1, 16, 256), (2, 1, 7), (2, 2, 3), (1, 300, 82),
           # beyond 256 classes: one tiled launch per frame (csrc/dense_wide.h), 16-byte loads when C % 4 == 0
-          (2, 12, 257), (3, 9, 300), (17, 7, 333), (2, 6, 1000), (1, 5, 1031)]
+          # (257 .. 320: the frames of an utterance inside one workgroup, the matrix in its registers -- wide_resident_viterbi_kernel:
+          # whole groups of its four-frame emission prefetch, a tail, two frames, the largest class count it takes, one more)
+          (2, 12, 257), (3, 9, 300), (2, 2, 258), (3, 23, 320), (2, 40, 301), (1, 10, 321),
+          (17, 7, 333), (2, 6, 1000), (1, 5, 1031)]
 
 
 @pytest.mark.parametrize("B,T,C", SHAPES)
