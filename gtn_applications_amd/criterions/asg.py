@@ -267,7 +267,8 @@ class ASGLossFunction(torch.autograd.Function):
         if node is not None and not timed and not torch.cuda.is_current_stream_capturing():
             # every launch below in one native call (csrc/torch_ops.cpp::asg_forward): the same sequence, ~60 us of host
             # time instead of ~200 (what a step costs at a training batch of 8, where the kernels take less than that)
-            early = need_grad and _EARLY_GRAD and all(E.plain_leaf(t) for t in (inputs, transitions) if t.requires_grad)
+            early = need_grad and _EARLY_GRAD and all(E.may_hand_over(t) and t.device == x.device
+                                                      for t in (inputs, transitions) if t.requires_grad)
             fork = E.side_stream(dev)
             up = getattr(pack, "_uploaded", None)
             if up is not None and up[0] not in (E.stream_ptr(), fork.side.cuda_stream):
@@ -319,14 +320,15 @@ class ASGLossFunction(torch.autograd.Function):
         ctx.aux = (x, W, fcc, cpos, dx_num, dw_num, fork if need_grad else None)
         ctx.devices = (inputs.device, transitions.device)
         ctx.early = None
-        if need_grad and _EARLY_GRAD and all(E.plain_leaf(t) for t in (inputs, transitions) if t.requires_grad):
+        if need_grad and _EARLY_GRAD and all(E.may_hand_over(t) and t.device == x.device
+                                             for t in (inputs, transitions) if t.requires_grad):
             # The denominator's gradient right behind its sweeps, for grad_output = 1 (as the numerator's): between the
             # forward and the backward kernels of a step the GPU otherwise waits ~30 us for the host to come back
             # through the autograd engine.  `loss.backward()` takes the two buffers as they are (E.EagerLoss); should
-            # the engine run after all, backward scales them by grad_output.  Only when every gradient goes to a plain
-            # leaf tensor (the reference's asg_benchmark.py:19-31 protocol on device tensors): with an nn.Parameter --
-            # the ASG module, anything under DistributedDataParallel -- the engine has to run, and then the buffers
-            # only add two scale launches behind the step (measured at cfg3: 0.487 against 0.476 ms).
+            # the engine run this node after all, backward scales them by grad_output.  Plain leaf tensors (the reference's
+            # asg_benchmark.py:19-31 protocol on device tensors) get them as .grad; a model's output, an nn.Parameter
+            # (the ASG module, anything under DistributedDataParallel) get them as the root gradients of an engine
+            # pass that starts at those tensors (E.EagerLoss.backward).
             dx = torch.empty_like(x) if need_dx else None
             dW = torch.empty_like(W) if need_dw else None
             fork.join(dx_num, dw_num)

@@ -626,7 +626,7 @@ class TransducerLossFunction(torch.autograd.Function):
             ctx.devices = (inputs.device, None)
             if in_launch:
                 ctx.early = _EarlyGrad(dx_early, num, cneg, inputs)
-                ctx.eager_take = ctx.early.take if E.plain_leaf(inputs) else None
+                ctx.eager_take = ctx.early.take if E.may_hand_over(inputs) else None
                 if ctx.eager_take is not None:
                     E.watch_node_hooks(ctx)
             return loss if inputs.is_cuda else loss.cpu()
@@ -675,7 +675,7 @@ class TransducerLossFunction(torch.autograd.Function):
         ctx.devices = (inputs.device, None if transition_params is None else transition_params.device)
         if dx_early is not None:
             ctx.early = _EarlyGrad(dx_early, num, cneg, inputs)  # (holds no reference to ctx: no cycle to collect)
-            ctx.eager_take = ctx.early.take if E.plain_leaf(inputs) else None
+            ctx.eager_take = ctx.early.take if E.may_hand_over(inputs) else None
             if ctx.eager_take is not None:
                 E.watch_node_hooks(ctx)
         return loss if inputs.is_cuda else loss.cpu()

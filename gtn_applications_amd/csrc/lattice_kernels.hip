@@ -158,14 +158,22 @@ __global__ void __launch_bounds__(256) gather_kernel(wfl_lattice_desc d, const i
   }
 }
 
-// The fused-log_softmax gather for C <= 64 * NV classes: the row is read ONCE into registers (NV loads in flight per
-// lane; the generic kernel above walks it three times with one load in flight), reduced with DPP, and the label columns
-// are picked out of L1/L2.  One wave per row, RU rows per iteration for the narrow cases.
+// The fused-log_softmax gather for C <= 64 * NV classes: the row is read ONCE, into registers (NV loads in flight per
+// lane; the generic kernel above walks it three times with one load in flight) and reduced with DPP.  One wave per row,
+// RU rows per iteration for the narrow cases.
+// Round 6: the label columns are picked out of an LDS copy of the row, through an LDS copy of the utterance's label
+// list, and the factors are formed from the values still in registers.  Until then a row cost FOUR dependent round
+// trips -- the row, labels[k], row[labels[k]], and the stored value read back for the factors -- and the second read of
+// the row missed: 32 waves per CU x 4 KB rows are four times the L1, 32 CUs of them the XCD's whole L2, so at the
+// Transducer benchmark the launch fetched 272 MB for 205 MB of emissions (profiles/r05_pmc_traffic.json).  Now one round
+// trip per row and every byte of x once.
 template <int NV, int RU>
 __global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints,
                                                           const float* __restrict__ x, int T, int C,
                                                           float* __restrict__ xg, float* __restrict__ row_lse,
                                                           float* __restrict__ fg, float* __restrict__ rmax) {
+  __shared__ float srow[4][64 * NV];   // a wave's current row
+  __shared__ int16_t slab[1024];       // the utterance's label columns (wfl_lattice_forward: at most 1024 per utterance)
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bb = d.shared ? 0 : b;
@@ -173,6 +181,12 @@ __global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, con
   const int K = ints[d.lab_off + bb + 1] - l0;
   const int32_t* labels = ints + d.labels + l0;
   const int Kmax = d.max_labels;
+  const bool lds_labels = K <= 1024 && C <= 32767;
+  if (lds_labels)
+    for (int k = threadIdx.x; k < K; k += 256) slab[k] = (int16_t)labels[k];
+  __syncthreads();
+  float* mine = srow[wave];
+  constexpr int KR = 2;  // label slots per lane kept in registers for the factors (K <= 128: every recipe's case)
   for (int t0 = (blockIdx.x * 4 + wave) * RU; t0 < T; t0 += gridDim.x * 4 * RU) {
     float v[RU][NV];
 #pragma unroll
@@ -181,7 +195,7 @@ __global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, con
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
-        v[u][i] = c < C ? row[c] : WFL_NEG_INF;
+        v[u][i] = row[min(c, C - 1)];  // (clamped, no test: the NV loads of a row go out back to back)
       }
     }
 #pragma unroll
@@ -189,7 +203,7 @@ __global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, con
       if (t0 + u >= T) break;
       float m = WFL_NEG_INF;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) v[u][i] = nan_to_neg(v[u][i]), m = fmaxf(m, v[u][i]);
+      for (int i = 0; i < NV; ++i) v[u][i] = lane + 64 * i < C ? nan_to_neg(v[u][i]) : WFL_NEG_INF, m = fmaxf(m, v[u][i]);
       m = wave_all_max(m);
       float sum = 0.f;
       if (m > WFL_NEG_INF) {
@@ -198,17 +212,43 @@ __global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, con
       }
       sum = wave_all_sum(sum);
       const float lse = (m > WFL_NEG_INF) ? m + fast_log(sum) : WFL_NEG_INF;
-      const float* row = x + ((int64_t)b * T + t0 + u) * C;
-      if (lane == 0) row_lse[(int64_t)b * T + t0 + u] = lse;
-      float* dst = xg + ((int64_t)b * T + t0 + u) * Kmax;
+      const int64_t r = (int64_t)b * T + t0 + u;
+      if (lane == 0) row_lse[r] = lse;
+      float* dst = xg + r * Kmax;
+      if (lds_labels && K <= 64 * KR) {
+        // the row through LDS (the wave's own slot: its DS operations execute in order, no barrier), the labels from LDS
+#pragma unroll
+        for (int i = 0; i < NV; ++i) mine[lane + 64 * i] = v[u][i];
+        float g[KR];
+        float vmx = WFL_NEG_INF;
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+          const int k = lane + 64 * j;
+          g[j] = k < K ? mine[slab[k]] - lse : WFL_NEG_INF;   // (the LDS copy is NaN-cleaned: what the old `nan_to_neg(row[label]) - lse` gave)
+          if (k < K) dst[k] = g[j];
+          vmx = fmaxf(vmx, k < K ? g[j] : WFL_NEG_INF);
+        }
+        if (fg) {  // emit_factors, from the registers
+          float rr = wave_all_max(vmx);
+          if (!(rr > WFL_NEG_INF)) rr = 0.f;
+          float* fdst = fg + r * Kmax;
+#pragma unroll
+          for (int j = 0; j < KR; ++j) {
+            const int k = lane + 64 * j;
+            if (k < K) fdst[k] = __builtin_amdgcn_exp2f((g[j] - rr) * 1.4426950408889634f);
+          }
+          if (lane == 0) rmax[r] = rr;
+        }
+        continue;
+      }
+      const float* row = x + r * C;
       float vmx = WFL_NEG_INF;
       for (int k = lane; k < K; k += 64) {
-        const float v = nan_to_neg(row[labels[k]]) - lse;
-        dst[k] = v;
-        vmx = fmaxf(vmx, v);
+        const float vv = nan_to_neg(row[labels[k]]) - lse;
+        dst[k] = vv;
+        vmx = fmaxf(vmx, vv);
       }
-      emit_factors(dst, fg ? fg + ((int64_t)b * T + t0 + u) * Kmax : nullptr,
-                   rmax ? rmax + (int64_t)b * T + t0 + u : nullptr, K, lane, vmx);
+      emit_factors(dst, fg ? fg + r * Kmax : nullptr, rmax ? rmax + r : nullptr, K, lane, vmx);
     }
   }
 }

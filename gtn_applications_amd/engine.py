@@ -532,9 +532,10 @@ class EagerLoss(torch.Tensor):
     in every respect but one: `loss.backward()` with no arguments -- the call of the reference's benchmarks
     (transducer_benchmark.py:47-49) and of a training loop that uses the criterion's output as its loss -- hands those
     buffers to the leaves' .grad without a trip through the autograd engine (its two thread hand-overs, the ones_like
-    fill and the scale passes over [B, T, C] leave the GPU idle between the forward and the backward kernels).  The
-    autograd node says whether that is possible through `eager_take()` -> [(leaf, grad), ...] or None (non-leaf inputs,
-    hooks, parameters, ...).  Anything else -- a gradient argument, retain_graph, create_graph, inputs=, anomaly mode, the loss
+    fill and the scale passes over [B, T, C] leave the GPU idle between the forward and the backward kernels) -- or,
+    when an input is somebody's output, a parameter or a hooked leaf, starts the engine AT the inputs with those
+    buffers as the root gradients (no ones_like, no trip through the criterion's node, no scale launches).  The
+    autograd node offers them through `eager_take()` -> [(tensor, grad), ...] or None.  Anything else -- a gradient argument, retain_graph, create_graph, inputs=, anomaly mode, the loss
     inside a larger expression -- goes through torch.Tensor.backward / the engine, where the node scales the buffers
     by grad_output (in place, a launch that returns at once when grad_output is 1; a second pass over a retained graph
     recomputes)."""
@@ -550,14 +551,22 @@ class EagerLoss(torch.Tensor):
                 and not self.retains_grad and not getattr(node, "_wfl_hooked", False)):
             pairs = take()
             if pairs is not None:
-                for leaf, g in pairs:
-                    if leaf.grad is None:
-                        leaf.grad = g
-                    else:
-                        leaf.grad.add_(g)
                 # the graph is spent, as after a pass of the engine without retain_graph: its buffers go, and a second
                 # backward() raises instead of accumulating a recomputed gradient
                 release_node(node)
+                if all(plain_leaf(t) for t, _ in pairs):
+                    for leaf, g in pairs:
+                        if leaf.grad is None:
+                            leaf.grad = g
+                        else:
+                            leaf.grad.add_(g)
+                else:
+                    # somebody's output (a model's, train.py:262-266), an nn.Parameter (DistributedDataParallel's
+                    # reducer hangs on its AccumulateGrad node), a leaf with hooks: the autograd engine, started AT
+                    # these tensors with the gradients the forward launches computed -- everything below them runs as
+                    # under torch.Tensor.backward, only this node, the ones_like fill in front of it and its scale
+                    # launches do not
+                    torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
                 return None
         return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
 
@@ -606,10 +615,16 @@ def plain_leaf(t):
             and not t._backward_hooks and not getattr(t, "_post_accumulate_grad_hooks", None))
 
 
+def may_hand_over(t):
+    """May EagerLoss.backward pass a gradient of t on itself -- to .grad if plain_leaf(t), else by starting the autograd
+    engine at t?  Any float32 device tensor that requires grad (a model's output, an nn.Parameter, a leaf with hooks)."""
+    return isinstance(t, torch.Tensor) and t.requires_grad and t.is_cuda and t.dtype == torch.float32
+
+
 def takes_grad(t, g):
-    """plain_leaf(t), and the gradient buffer g lives where t does (ASG transitions may sit on another GPU than the
-    inputs: the engine copies across, `t.grad = g` would raise)"""
-    return plain_leaf(t) and g.device == t.device and g.shape == t.shape
+    """may_hand_over(t), and the gradient buffer g lives where t does (ASG transitions may sit on another GPU than the
+    inputs: the engine running the criterion's node copies across; neither `t.grad = g` nor a root gradient may)"""
+    return may_hand_over(t) and g.device == t.device and g.shape == t.shape and g.dtype == t.dtype
 
 
 def make_eager(loss):

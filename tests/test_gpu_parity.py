@@ -1175,6 +1175,93 @@ def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(c
     close(xi.grad, 3 * ref_dx.cpu().numpy(), rtol=1e-4, atol=3e-6, msg="retain_graph")
 
 
+def test_eager_loss_starts_the_engine_at_inputs_that_are_not_plain_leaves(crit, monkeypatch):
+    """engine.EagerLoss.backward when an input is a model's output (train.py:262-266), an nn.Parameter (the ASG module;
+    DistributedDataParallel hangs its all-reduce on the parameter's AccumulateGrad node) or a leaf with a hook: the
+    gradients the forward launches computed are handed to ONE pass of the autograd engine that starts at those inputs
+    (torch.autograd.backward(inputs, grads)) -- the producer's backward, tensor hooks, retain_grad and the parameter's
+    accumulation behave as under torch.Tensor.backward from the loss, with the same numbers; ASG and Transducer."""
+    from gtn_applications_amd import engine as E
+
+    asg, tr = crit["asg"], crit["transducer"]
+    rs = np.random.RandomState(31)
+    B, T, C = 5, 60, 9
+    x = torch.tensor(rs.randn(B, T, C).astype(np.float32))
+    W = torch.tensor((0.3 * rs.randn(C + 1, C)).astype(np.float32))
+    wcol = torch.tensor(rs.rand(C).astype(np.float32) + 0.5).cuda()
+    targets = [rs.randint(0, C, size=n).tolist() for n in (4, 7, 1, 9, 3)]
+    started = []
+    real = torch.autograd.backward
+
+    def spy(tensors, grad_tensors=None, *a, **k):
+        started.append(len(tensors) if isinstance(tensors, (list, tuple)) else 1)
+        return real(tensors, grad_tensors, *a, **k)
+
+    def asg_run(eager, how):
+        monkeypatch.setattr(asg, "_EARLY_GRAD", eager)
+        del started[:]
+        xi = x.cuda().requires_grad_(True)
+        par = torch.nn.Parameter(W.cuda().clone())
+        seen = {}
+        em = xi * wcol if how != "leaf_hook" else xi
+        if how == "em_hook":
+            em.register_hook(lambda g: seen.setdefault("em", g.clone()))
+        if how == "leaf_hook":
+            xi.register_hook(lambda g: seen.setdefault("leaf", g.clone()))
+        if how == "retain_grad":
+            em.retain_grad()
+        loss = asg.ASGLoss(em, par, targets, "mean")
+        monkeypatch.setattr(torch.autograd, "backward", spy)
+        try:
+            loss.backward()
+        finally:
+            monkeypatch.setattr(torch.autograd, "backward", real)
+        if how == "retain_grad":
+            seen["em_grad"] = em.grad.clone()
+        return xi.grad.clone(), par.grad.clone(), seen, type(loss).__name__, list(started)
+
+    for how in ("product", "em_hook", "leaf_hook", "retain_grad"):
+        want = asg_run(False, how)
+        got = asg_run(True, how)
+        assert want[3] == "Tensor" and got[3] == "EagerLoss", how
+        # (torch.Tensor.backward calls torch.autograd.backward once with the loss; the eager route with both inputs)
+        assert got[4] == [2], (how, got[4])
+        close(got[0], want[0].cpu().numpy(), rtol=1e-5, atol=1e-7, msg=how + " dx")
+        close(got[1], want[1].cpu().numpy(), rtol=1e-5, atol=1e-7, msg=how + " dW")
+        assert sorted(got[2]) == sorted(want[2]), how
+        for k in want[2]:
+            close(got[2][k], want[2][k].cpu().numpy(), rtol=1e-5, atol=1e-7, msg=how + " " + k)
+    # plain leaves still get .grad without any engine pass
+    monkeypatch.setattr(asg, "_EARLY_GRAD", True)
+    xi, Wi = x.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
+    del started[:]
+    monkeypatch.setattr(torch.autograd, "backward", spy)
+    try:
+        asg.ASGLoss(xi, Wi, targets, "mean").backward()
+    finally:
+        monkeypatch.setattr(torch.autograd, "backward", real)
+    assert started == [] and xi.grad is not None and Wi.grad is not None
+    # Transducer: the gradient beside the sweeps handed to the producer of non-leaf emissions
+    tokens, g2i, xt, tg = _word_piece_batch(6, 120, 5)
+    m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+
+    def tr_run(in_launch):
+        monkeypatch.setattr(tr, "_IN_LAUNCH_GRAD", in_launch)
+        xi = xt.clone().requires_grad_(True)
+        em = xi * 1.25
+        got_hook = []
+        em.register_hook(lambda g: got_hook.append(g.clone()))
+        loss = m(em, tg)
+        loss.backward()
+        return xi.grad.clone(), got_hook[0], type(loss).__name__
+
+    want, got = tr_run(False), tr_run(True)
+    assert want[2] == "Tensor" and got[2] == "EagerLoss"
+    close(got[0], want[0].cpu().numpy(), rtol=1e-4, atol=1e-6, msg="transducer dx")
+    close(got[1], want[1].cpu().numpy(), rtol=1e-4, atol=1e-6, msg="transducer hook")
+    assert E.may_hand_over(torch.nn.Parameter(torch.zeros(2, device="cuda"))) and not E.may_hand_over(torch.zeros(2, requires_grad=True))
+
+
 def test_transducer_gradient_beside_the_sweeps_under_cu_contention(crit):
     """The gradient workgroups wait on progress words of the sweeps (another launch, another stream), the gate kernel on
     the sweeps' announcement: safe only while everything gets CUs eventually.  A third stream keeps every CU busy with
