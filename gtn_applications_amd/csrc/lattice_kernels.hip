@@ -769,10 +769,19 @@ constexpr double kLog2e_d = 1.4426950408889634074;
 // written by thread 0 of the sweep with one write-through store, polled by the gradient workgroups of the same launch.
 // The token (a per-launch counter from the host) makes words left by earlier launches read as "not yet".
 constexpr uint32_t kProgSkip = 0x0fffffffu;  // the utterance is not swept in the probability domain
+// bit 27 of the chunk field, set from a sweep's crossing on when it stores OCCUPANCIES instead of its own vector beyond
+// the middle (run_chain_prob, "meet in the middle"); the count is the 27 bits below it
+constexpr uint32_t kProgMitm = 1u << 27, kProgCount = kProgMitm - 1u;
+constexpr int kFmtOcc = 2;  // fmt[b]: probability-domain sweeps that met in the middle (see run_chain_prob)
+// the middle slot of sweeps that met in the middle (run_chain_prob: T a multiple of 16)
+__host__ __device__ inline int mitm_middle(int T) { return 16 * ((T / 16) / 2); }
 __device__ __forceinline__ uint32_t xcc_id() {
   uint32_t v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
   return v & 15u;
+}
+__device__ __forceinline__ double ld_l2(const double* p) {  // L1-bypassing: what another CU of this XCD stored during the launch
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void prog_publish(uint64_t* w, uint32_t token, uint32_t chunks) {
   __hip_atomic_store(w, ((uint64_t)token << 32) | ((uint64_t)xcc_id() << 28) | chunks, __ATOMIC_RELAXED,
@@ -877,6 +886,22 @@ __device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {  // NT
   return !__syncthreads_or(bad);
 }
 
+// What a sweep needs of its partner (the other direction of the same utterance, same launch) to meet it in the middle.
+#ifdef WFL_MITM_FAKE_LOADS  // (timing experiment: every partner load hits the same few lines)
+#define WFL_MITM_SLOT(s) ((s) & 1)
+#else
+#define WFL_MITM_SLOT(s) (s)
+#endif
+struct MitmArgs {
+  int req = 0;                       // the launch asks for it (wfl_lattice_forward_grad, T a multiple of 16, ...)
+  double* oth = nullptr;             // the partner's score rows of this utterance ([T+1][Q] doubles)
+  const double* oth_offs = nullptr;  // its per-slot offsets
+  const uint64_t* oth_prog = nullptr;  // its progress word
+  int32_t* fmt = nullptr;            // forward sweep: fmt[b] <- kFmtOcc
+  uint32_t* mitm_b = nullptr;        // backward sweep: its own flag (0 / 1), where the alpha buffer keeps `bad`
+  int spins = 1 << 18;
+};
+
 // BAND: the register-resident banded sweep is compiled in (chain wave + loader wave workgroups); UNR: full chunks as
 // straight-line code (not for the 1024-thread instantiation: its 128-register budget would spill)
 // PUB: the sweep publishes its progress (prog_publish) for the gradient workgroups of the same launch
@@ -886,7 +911,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
                                const float* __restrict__ weights, double* __restrict__ out, float* __restrict__ logz,
                                int b, double* __restrict__ offs, double* __restrict__ z64, float* __restrict__ wref_out,
                                double* __restrict__ dump,  // dump: kDumpDoubles doubles nobody reads
-                               uint64_t* prog = nullptr, uint32_t token = 0) {
+                               uint64_t* prog = nullptr, uint32_t token = 0, const MitmArgs& mm = MitmArgs()) {
   const int tid = threadIdx.x, NT = blockDim.x;
   // (the LDS pointers as locals: read through the struct they stayed a 48-byte object in scratch, loaded at every chunk)
   double *const lbuf0 = L.buf0, *const lbuf1 = L.buf1;
@@ -1158,11 +1183,28 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
   //    chunk asks for itself again; and no initial value for those registers (`rpre = 0` is a write to a register with
   //    a load pending on such a path).
   // 16-byte loads and LDS stores on the way (rows are padded to four labels: pack.cpp, pad_labels).
+  // ---- meeting the partner in the middle (PUB launches that ask for it: MitmArgs).  The emission gradient of a
+  // uniform-label acceptor only needs the state occupancies gamma_s[q] = alpha_s[q] beta_s[q] / Z, and past the middle
+  // slot m a sweep can form them itself: the partner passed those slots in ITS first half and its vectors lie in the
+  // L2 of the XCD both run on.  So a sweep stores its own vector (doubles) up to m, then occupancies (floats, Z taken at
+  // m: every path passes through exactly one state per slot) into the first half of its own rows:
+  //     alpha buffer: slots 0 .. m alpha (doubles), m+1 .. T gamma (floats);   beta buffer: slots m+1 .. T beta, 0 .. m gamma
+  // (gamma_m by the forward sweep, into the beta buffer).  16 bytes per (slot, state) written and read back by the
+  // gradient become 8 + 4 written, 8 read by the partner and 4 by the gradient, and the gradient needs neither offsets
+  // nor a Z of its own.  Both sweeps must agree; each decides for itself at its crossing (the partner's progress word:
+  // same launch, same XCD, its half stored) and says so in its progress word (kProgMitm), fmt[b] / mitm_b[b].
+  double pbA[8], pbB[8];  // the partner's values of this thread's state: frames 0-7 / 8-15 of the chunk
+  double oo_cur = 0.0;    // lane li: the partner's offset at the slot of the chunk's li-th frame
+  double zlog2 = 0.0;     // log2 Z (+inf: no accepting path)
+  bool mitm_on = false;
+  const int tidc = min(tid, Q - 1);
+  auto slot_of = [&](int c, int i) { return DIR == 0 ? c * 16 + i + 1 : T - c * 16 - 1 - i; };
   auto sweep = [&](auto sel_, auto live_) {
     constexpr int SEL = decltype(sel_)::value;
     constexpr bool LIVE = decltype(live_)::value;
-    auto chunk = [&](int c, auto full_) {
+    auto chunk = [&](int c, auto full_, auto mitm_) {
       constexpr bool FULL = decltype(full_)::value;
+      constexpr bool MITM = PUB && FULL && LIVE && SEL < 4 && decltype(mitm_)::value;  // (uniform-label frame loops)
 #ifdef WFL_SWEEP_PHASE_TIMERS
       const long long eA = clock64();
 #endif
@@ -1183,6 +1225,15 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
           const float4 q = src4[min(tid + j * NT, last4)];
           pre[4 * j] = q.x, pre[4 * j + 1] = q.y, pre[4 * j + 2] = q.z, pre[4 * j + 3] = q.w;
         }
+      }
+      double oo_next = 0.0;
+      double corrv = 0.0;  // (MITM) lane li: 2^(own offset + the partner's - log2 Z) at the slot of the chunk's li-th frame
+      if constexpr (MITM) {
+        // the partner's values for the second half of this chunk (its first half came with the chunk before, at frame 7),
+        // and its offset for the next chunk's frames: L1-bypassing loads (another CU wrote them during this launch)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pbB[j] = ld_l2(mm.oth + (int64_t)WFL_MITM_SLOT(slot_of(c, 8 + j)) * Q + tidc);
+        oo_next = ld_l2(mm.oth_offs + slot_of(min(c + 1, nchunks - 1), tid & 15));
       }
       // (`path`: 0 behind the sixteen straight-line frames, 1 a wave without a state, 2 behind a frame loop)
       auto hand_over = [&](auto path) {
@@ -1338,9 +1389,29 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
           const bool mine = tid < Q;
           double* po = mine ? orow + tid : dump + (tid & (kDumpDoubles - 1));
           const int64_t pstep = mine ? (DIR == 0 ? (int64_t)Q : -(int64_t)Q) : 0;
+          // (past the middle: occupancies, floats, into the first half of the same rows)
+          float* pof = mine ? reinterpret_cast<float*>(orow) + tid : reinterpret_cast<float*>(dump) + (tid & (kDumpDoubles - 1));
+          const int64_t pfstep = 2 * pstep;
+          const int cn = min(c + 1, nchunks - 1);
           const double* bA = par ? lbuf1 : lbuf0;  // read by the even frames of the chunk, written by the odd ones
           const double* bB = par ? lbuf0 : lbuf1;
           const int fstep = DIR == 0 ? Kmax : -Kmax;
+          // (MITM) the occupancy of frame i is formed one frame late, in the shadow of frame i + 1's LDS reads: on the
+          // frame's own path -- sum, LDS write, barrier -- its three multiplies, two lane reads and conversion cost the
+          // sweep 85 ns a frame (193 instead of 159 us at the Transducer benchmark)
+          double p_late = 0.0;
+          auto emit_gamma = [&](int i, double pv) {
+            // gamma = own value x the partner's x 2^(both offsets - log2 Z) (the frame's power of two: lane i of corrv)
+            const double pbv = i < 8 ? pbA[i & 7] : pbB[i & 7];
+            const double cr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(corrv), i),
+                                               __builtin_amdgcn_readlane(__double2loint(corrv), i));
+            *pof = (float)(pv * pbv * cr);
+            pof += pfstep;
+            if (i == 7) {  // the first half of the NEXT chunk (the last chunk asks for itself again: not consumed)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) pbA[j] = ld_l2(mm.oth + (int64_t)WFL_MITM_SLOT(slot_of(cn, j)) * Q + tidc);
+            }
+          };
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const double* from = (i & 1) ? bB : bA;
@@ -1348,6 +1419,13 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
             double ps[DEG];
 #pragma unroll
             for (int k = 0; k < DEG; ++k) ps[k] = from[asrc[k]];
+            if constexpr (MITM) {
+              if (i > 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                emit_gamma(i - 1, p_late);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
             const float fr = fptr[(DIR == 0 || i < 15) ? i * fstep : 14 * fstep];
             const float f = (DIR == 0 || i < 15) ? fr : 1.f;
             double acc0 = 0.0, acc1 = 0.0;
@@ -1359,10 +1437,15 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
             const double sum = acc0 + acc1;
             p = DIR == 0 ? sum * (double)f : sum;
             to[tid] = DIR == 0 ? p : p * (double)f;
-            WFL_SWEEP_STORE(po, p);
-            po += pstep;
+            if constexpr (MITM) {
+              p_late = p;
+            } else {
+              WFL_SWEEP_STORE(po, p);
+              po += pstep;
+            }
             lds_barrier();
           }
+          if constexpr (MITM) emit_gamma(15, p_late);
           hand_over(PathUnrolled{});
           return;
         }
@@ -1420,6 +1503,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         if (tid < n) offs[DIR == 0 ? f0 + tid + 1 : f0 + n - 1 - tid] = cum + pre;
         chunk_log2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pre), 15),
                                       __builtin_amdgcn_readlane(__double2loint(pre), 15));  // (lanes >= n added 0)
+        if constexpr (MITM) corrv = exp2(cum + pre + oo_cur - zlog2);  // (zlog2 = +inf, no accepting path: 0)
       }
       // (block-uniform: absent arcs have wf = 0, so any class >= the true degree is exact)
       // (uniform-label acceptors: PER WAVE -- the frame loops differ only in how many of the eight arc slots they read,
@@ -1460,16 +1544,89 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         // vmcnt counts loads and stores in issue order, and every thread has just waited until at most 16 of its
         // operations were outstanding.  (One chunk of lag costs the gradient nothing; waiting for THIS chunk's stores
         // would put a store round trip, ~1.5 us, behind every 16 frames.)
-        if (PUB && tid == 0 && c > 0) prog_publish(prog, token, (uint32_t)c);
+        if (PUB && tid == 0 && c > 0) prog_publish(prog, token, (uint32_t)c | (MITM || mitm_on ? kProgMitm : 0u));
       }
+      if constexpr (MITM) oo_cur = oo_next;
 #ifdef WFL_SWEEP_PHASE_TIMERS
       e_hand += clock64() - eE;
 #endif
     };
     // chunks whose sixteen frames run as straight-line code (nchunks is 0 when the banded sweep above has done the work)
     const int nfull = (UNR && R == 16) ? min(T / 16, nchunks) : 0;
-    for (int c = 0; c < nfull; ++c) chunk(c, std::true_type{});
-    for (int c = nfull; c < nchunks; ++c) chunk(c, std::false_type{});
+    // meeting in the middle: the launch asks, a uniform-label acceptor, whole chunks only (T a multiple of 16: the two
+    // sweeps' chunk boundaries coincide), at least two chunks a side.  c0: this sweep's chunks up to the middle slot.
+    // (every wave of the workgroup takes the same decision and the crossing's barriers: `uniform` is block-uniform, the
+    // waves without a state -- SEL 7 -- included)
+    const bool mitm_try = PUB && uniform && mm.req != 0 && nfull == nchunks && nchunks >= 4;
+    const int c0 = DIR == 0 ? nchunks / 2 : nchunks - nchunks / 2;
+    int cfirst = nfull;  // (first chunk of the occupancy half, if it comes to that)
+    for (int c = 0; c < nfull; ++c) {
+      if constexpr (PUB) {
+        if (mitm_try && c == c0) {
+          // ---- the crossing.  Everything this sweep stored so far must be in L2 before the partner is told so.
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          int* red = (int*)lred;
+          if (tid == 0) {
+            prog_publish(prog, token, (uint32_t)c0);
+            const uint32_t need = (uint32_t)(nchunks - c0), me = xcc_id();
+            int st = 0;
+            for (int spin = 0; spin < mm.spins; ++spin) {
+              const uint64_t v = __hip_atomic_load(mm.oth_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((uint32_t)(v >> 32) == token) {
+                const uint32_t fld = (uint32_t)v & 0x0fffffffu;
+                if (fld == kProgSkip || (((uint32_t)v >> 28) & 15u) != me) break;  // not swept / another XCD's L2: plain
+                if ((fld & kProgCount) >= need) {
+                  st = 1;
+                  break;
+                }
+              }
+              __builtin_amdgcn_s_sleep(16);
+            }
+            red[0] = st;
+          }
+          __syncthreads();
+          const bool ok = red[0] != 0;
+          __syncthreads();
+          if (ok) {
+            const int m = DIR == 0 ? 16 * c0 : T - 16 * c0;  // the middle slot: both sweeps hold their vector of it
+            const double bm = ld_l2(mm.oth + (int64_t)m * Q + tidc);
+            const double om = ld_l2(mm.oth_offs + m);
+            const double tot = block_reduce_sum_f64(tid < Q ? p * bm : 0.0, (double*)lred);
+            const bool deadz = !(tot > 0.0 && tot < 1.0e300);
+            zlog2 = deadz ? __builtin_inf() : log2(tot) + cum + om;
+            // gamma at the middle slot itself: the forward sweep's, into the beta buffer's row (nobody reads beta_m again:
+            // the partner holds it in registers, and every thread of this workgroup has used its copy -- the reduction's barriers)
+            if (DIR == 0 && tid < Q)
+              reinterpret_cast<float*>(mm.oth + (int64_t)m * Q)[tid] = deadz ? 0.f : (float)(p * bm * exp2(cum + om - zlog2));
+            if constexpr (LIVE) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) pbA[j] = ld_l2(mm.oth + (int64_t)slot_of(c0, j) * Q + tidc);
+              oo_cur = ld_l2(mm.oth_offs + slot_of(c0, tid & 15));
+            }
+            if (tid == 0) {
+              if (DIR == 0)
+                *mm.fmt = kFmtOcc;
+              else
+                __hip_atomic_store(mm.mitm_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // (vmcnt(0) as the BUILTIN, which the compiler's wait-count pass sees: the values just requested are used by
+            // the chunk loop below, whose steady state leaves them pending across its back edge with ~36 younger
+            // operations behind them; entering the loop with them pending and only a handful behind, the static pass
+            // sized every chunk's first wait for THAT path -- vmcnt(12): the previous chunk's stores, 1.4 us a chunk)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            mitm_on = true;
+            cfirst = c0;
+            break;
+          }
+        }
+      }
+      chunk(c, std::true_type{}, std::false_type{});
+    }
+    if constexpr (PUB) {
+      for (int c = cfirst; c < nfull; ++c) chunk(c, std::true_type{}, std::true_type{});
+    }
+    for (int c = nfull; c < nchunks; ++c) chunk(c, std::false_type{}, std::false_type{});
   };
   if (!wave_live)
     sweep(std::integral_constant<int, 7>{}, std::false_type{});
@@ -1493,7 +1650,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
   if (PUB) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) prog_publish(prog, token, (uint32_t)max(nchunks, 1));
+    if (tid == 0) prog_publish(prog, token, (uint32_t)max(nchunks, 1) | (mitm_on ? kProgMitm : 0u));
   }
   // log2 of the total: alpha over the accept states at slot T, beta over the start states at slot 0
   {
@@ -1516,7 +1673,7 @@ __device__ __forceinline__ void prob_chain_body(const wfl_lattice_desc& d, const
                                                 int rows_per_chunk, const float* __restrict__ weights,
                                                 float* __restrict__ alpha, float* __restrict__ beta,
                                                 float* __restrict__ logz, int64_t tail, int nch1, int b, int dir, char* smem,
-                                                uint32_t token) {
+                                                uint32_t token, int mitm_req = 0) {
   const UttView u = make_view(d, ints, floats, b, T);
   double* offs_a = reinterpret_cast<double*>(alpha + tail);  // (tail layout: see chain_kernel)
   double* offs_b = beta ? reinterpret_cast<double*>(beta + tail) : nullptr;
@@ -1540,14 +1697,28 @@ __device__ __forceinline__ void prob_chain_body(const wfl_lattice_desc& d, const
   P.refs = (float*)p;
   const float* fg = xg + xg_main_dev(d, T);
   const float* rmax = fg + xg_main_dev(d, T);
+  MitmArgs mm;
+  if (PUB && beta) {
+    // (the partner: the other direction's rows, offsets and progress word; the backward sweep's own flag sits in the
+    // beta buffer where the alpha buffer keeps the gradient's `bad` words: occ_header)
+    mm.req = mitm_req;
+    mm.oth = reinterpret_cast<double*>(dir == 0 ? beta : alpha) + u.ab_base;
+    mm.oth_offs = (dir == 0 ? offs_b : offs_a) + (int64_t)b * nch1;
+    mm.oth_prog = reinterpret_cast<const uint64_t*>((dir == 0 ? offs_b : offs_a) + prog_offset_doubles(d, nch1)) + b;
+    mm.fmt = fmt + b;
+    mm.mitm_b = occ_header(d, beta, tail, nch1).bad + b;
+  }
   if (dir == 0) {
     if (threadIdx.x == 0) fmt[b] = kFmtProb;
     run_chain_prob<0, MAXT == 128, MAXT <= 512, PUB>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
-                      offs_a + (int64_t)b * nch1, za, wrefs, offs_a + (int64_t)d.B * nch1 + 2 * (int64_t)d.B, prog, token);
+                      offs_a + (int64_t)b * nch1, za, wrefs, offs_a + (int64_t)d.B * nch1 + 2 * (int64_t)d.B, prog, token, mm);
   } else {
-    if (threadIdx.x == 0) zb[d.B + b] = 0.0;  // the certificate's verdict: raised by prob_certify_kernel
+    if (threadIdx.x == 0) {
+      zb[d.B + b] = 0.0;  // the certificate's verdict: raised by prob_certify_kernel
+      if (PUB) __hip_atomic_store(mm.mitm_b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     run_chain_prob<1, MAXT == 128, MAXT <= 512, PUB>(d, u, P, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
-                      offs_b + (int64_t)b * nch1, zb, nullptr, offs_b + (int64_t)d.B * nch1 + 2 * (int64_t)d.B, prog, token);
+                      offs_b + (int64_t)b * nch1, zb, nullptr, offs_b + (int64_t)d.B * nch1 + 2 * (int64_t)d.B, prog, token, mm);
   }
 }
 
@@ -1574,7 +1745,8 @@ __global__ void __launch_bounds__(MAXT)
 // utterance; verdict[b] = 1 sends the utterance to the log-domain launch that follows.
 __global__ void __launch_bounds__(256)
     prob_certify_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T,
-                        const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt) {
+                        const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt,
+                        int pub) {  // pub: the sweeps were prob_chain_pub_kernel's (they may have met in the middle)
   // grid (B, kCertSplit): every wave takes the checked slots s = wave index, + number of waves, ... on its own
   // (wave-level reductions only); a wave that finds a violation raises the utterance's verdict (cleared by the beta
   // sweep of prob_chain_kernel before it started)
@@ -1597,6 +1769,32 @@ __global__ void __launch_bounds__(256)
   const int nchk = (T + 7) / 8 + 1;  // slots 0, 8, 16, ... and T
   const int w0 = blockIdx.y * 4 + (tid >> 6), nw = gridDim.y * 4;
   bool bad = false;
+  // Sweeps that met in the middle (run_chain_prob) stored occupancies, normalised by the Z they formed at the middle slot:
+  // the same identity reads sum_q gamma_s[q] = 1 (at slot T that also ties the middle's Z to the forward sweep's
+  // total, at slot 0 to the backward sweep's).  One sweep that did and one that did not (a crossing that gave up
+  // waiting) leave neither format: re-run in the log domain.
+  const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
+  const bool occ_a = fmt[b] == kFmtOcc;
+  const bool occ_b = pub && occ_header(d, beta, tail, nch1).bad[b] == 1u;
+  if (occ_a != occ_b) {
+    if (tid == 0) *verdict = 1.0;
+    return;
+  }
+  if (occ_a) {
+    const int mid = mitm_middle(T);
+    for (int c = w0; c < nchk; c += nw) {
+      const int t = min(c * 8, T);
+      const float* row = reinterpret_cast<const float*>((t <= mid ? pb : pa) + (int64_t)t * Q);
+      float sacc = 0.f;
+      for (int q = lane; q < Q; q += 64) sacc += row[q];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+      const double dev = (sacc > 0.f && sacc < 3.0e38f) ? fabs(log2((double)sacc)) : 1.0e9;
+      bad = bad || !(dev <= 1.0e-4);
+    }
+    if (bad && lane == 0) *verdict = 1.0;
+    return;
+  }
   for (int c = w0; c < nchk; c += nw) {
     const int t = min(c * 8, T);
     double s = 0.0;
@@ -1855,10 +2053,12 @@ struct OccLive {
   uint32_t token;
   int R;          // frames per chunk of the sweeps
   int force_bad;  // (tests: behave as if the XCC ids differed)
+  int mitm;       // the launch asked its sweeps to meet in the middle (they say in their progress words whether they did)
 };
-__device__ __forceinline__ double ld_l2(const double* p) {
+__device__ __forceinline__ float ld_l2(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
 template <bool LIVE>
 __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const UttView& u, int b, int T, int C,
                                                const float* __restrict__ alpha, const float* __restrict__ beta,
@@ -1878,10 +2078,15 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
   const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
   double zd = 0.0;
   bool dead = false;
+  // gamma: the sweeps met in the middle and stored occupancies (floats) -- slots <= m in the beta buffer's rows, slots > m in
+  // the alpha buffer's (run_chain_prob); nothing to normalise.  LIVE: decided per tile from the progress words.
+  bool gamma = false;
+  const int mid = mitm_middle(T);
   if (!LIVE) {
     zd = reinterpret_cast<const double*>(alpha + tail)[(int64_t)d.B * nch1 + b];  // log2 Z
     const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
-    if (!occ_eligible(u, fmt[b] == kFmtProb)) return;
+    gamma = fmt[b] == kFmtOcc;
+    if (!occ_eligible(u, fmt[b] == kFmtProb || gamma)) return;
     const float z = logz[b];
     dead = !(z > WFL_NEG_INF) || !(z < __builtin_inff());  // no accepting path: zero gradient
   } else if (!occ_eligible(u, true)) {
@@ -1908,14 +2113,22 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
       if (tid == 0) {
         const uint32_t need_a = (uint32_t)((ts0 + nr + live.R - 1) / live.R);
         const uint32_t need_b = (uint32_t)((T - ts0 - 1 + live.R - 1) / live.R);
+        // sweeps that meet in the middle (live.mitm): a sweep's choice is final once its word carries kProgMitm or counts
+        // a chunk beyond its half (the crossing itself publishes the half's count, still without the flag).  Then a slot's
+        // occupancy only needs the sweep that wrote it: slots > m the forward sweep, slots < m the backward one, slot m
+        // the forward sweep's crossing (in L2 with its first chunk beyond).
+        const int nch = T / 16, half_a = nch / 2, half_b = nch - nch / 2;
+        const int s_lo = ts0 + 1, s_hi = ts0 + nr;
+        const uint32_t gneed_a = s_hi >= mid ? (uint32_t)max((s_hi + 15) / 16, half_a + 1) : 0u;
+        const uint32_t gneed_b = s_lo < mid ? (uint32_t)((T - 1 - s_lo) / 16 + 1) : 0u;
         const uint32_t me = xcc_id();
         int st = -2;  // (gave up: ~2 s)
         for (int spin = 0; spin < (1 << 20); ++spin) {
           const uint64_t va = __hip_atomic_load(live.prog_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const uint64_t vb = __hip_atomic_load(live.prog_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((uint32_t)(va >> 32) == live.token && (uint32_t)(vb >> 32) == live.token) {
-            const uint32_t ca = (uint32_t)va & 0x0fffffffu, cb = (uint32_t)vb & 0x0fffffffu;
-            if (ca == kProgSkip || cb == kProgSkip) {
+            const uint32_t fa = (uint32_t)va & 0x0fffffffu, fb = (uint32_t)vb & 0x0fffffffu;
+            if (fa == kProgSkip || fb == kProgSkip) {
               st = 0;  // not swept in the probability domain: the general kernel's utterance
               break;
             }
@@ -1923,9 +2136,24 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
               st = -1;
               break;
             }
-            if (ca >= need_a && cb >= need_b) {
-              st = 1;
-              break;
+            const uint32_t ca = fa & kProgCount, cb = fb & kProgCount;
+            if (!live.mitm) {
+              if (ca >= need_a && cb >= need_b) {
+                st = 1;
+                break;
+              }
+            } else {
+              const bool ma = (fa & kProgMitm) != 0, mb = (fb & kProgMitm) != 0;
+              if ((ma || ca >= (uint32_t)half_a + 1) && (mb || cb >= (uint32_t)half_b + 1)) {  // both have chosen
+                if (ma != mb) {
+                  st = -1;  // (one of them gave up waiting at its crossing: the certificate re-sweeps the utterance)
+                  break;
+                }
+                if (ma ? (ca >= gneed_a && cb >= gneed_b) : (ca >= need_a && cb >= need_b)) {
+                  st = ma ? 2 : 1;
+                  break;
+                }
+              }
             }
           }
           __builtin_amdgcn_s_sleep(64);
@@ -1934,27 +2162,56 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
         *state = st;
       }
       __syncthreads();
-      if (*state != 1) return;
+      if (*state < 1) return;
+      gamma = *state == 2;
       LIVE_T(t_w1);
       LIVE_ADD(1, t_w0, t_w1);
-      // the tile's own log2 Z, from its first slot
-      double part = 0.0;
-      for (int q = tid; q < Q; q += NT)
-        part = fma(ld_l2(alpha_d + (int64_t)(ts0 + 1) * Q + q), ld_l2(beta_d + (int64_t)(ts0 + 1) * Q + q), part);
-      const double tot = block_reduce_sum_f64(part, red);
-      dead = !(tot > 0.0 && tot < 1.0e300);
-      zd = dead ? 0.0 : log2(tot) + ld_l2(offs_a + ts0 + 1) + ld_l2(offs_b + ts0 + 1);
+      if (!gamma) {
+        // the tile's own log2 Z, from its first slot
+        double part = 0.0;
+        for (int q = tid; q < Q; q += NT)
+          part = fma(ld_l2(alpha_d + (int64_t)(ts0 + 1) * Q + q), ld_l2(beta_d + (int64_t)(ts0 + 1) * Q + q), part);
+        const double tot = block_reduce_sum_f64(part, red);
+        dead = !(tot > 0.0 && tot < 1.0e300);
+        zd = dead ? 0.0 : log2(tot) + ld_l2(offs_a + ts0 + 1) + ld_l2(offs_b + ts0 + 1);
+      } else {
+        dead = false;  // (an utterance without a path: its sweeps stored zeros)
+      }
       LIVE_T(t_w2);
       LIVE_ADD(3, t_w1, t_w2);
     }
     LIVE_T(t_p0);
     for (int i = tid; i < nr * Kmax; i += NT) acc[i] = 0.f;
     // frame t's arcs end in slot t + 1 of both sweeps: gamma = p_alpha p_beta 2^(offs_a + offs_b - log2 Z) there
-    if (tid < nr)
+    if (tid < nr && !gamma)
       corr[tid] = LIVE ? exp2(ld_l2(offs_a + ts0 + tid + 1) + ld_l2(offs_b + ts0 + tid + 1) - zd)
                        : exp2(offs_a[ts0 + tid + 1] + offs_b[ts0 + tid + 1] - zd);
     __syncthreads();
-    if (!dead) {
+    if (gamma && !dead) {
+      // occupancies as the sweeps stored them: Q floats at the head of the slot's row (of Q doubles) -- the beta buffer's up
+      // to the middle slot, the alpha buffer's beyond
+      const int n = nr * Q;
+      constexpr int U = 8;
+      for (int i0 = tid; i0 < n; i0 += U * NT) {
+        float gv[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const int i = min(i0 + k * NT, n - 1);
+          const int r = (int)(((float)i + 0.5f) * inv_q), q = i - r * Q, sl = ts0 + 1 + r;
+          const float* row = reinterpret_cast<const float*>((sl <= mid ? beta_d : alpha_d) + (int64_t)sl * Q);
+          gv[k] = LIVE ? ld_l2(row + q) : row[q];
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const int i = i0 + k * NT;
+          const int r = (int)(((float)i + 0.5f) * inv_q), q = i - r * Q;
+          if (i < n) {
+            const int kk = lab[q];
+            if (kk >= 0 && gv[k] != 0.f) atomicAdd(&acc[r * Kmax + kk], gv[k]);
+          }
+        }
+      }
+    } else if (!dead) {
       const double* asrc = alpha_d + (int64_t)(ts0 + 1) * Q;
       const double* bsrc = beta_d + (int64_t)(ts0 + 1) * Q;
       const int n = nr * Q;
@@ -2045,7 +2302,7 @@ __global__ void __launch_bounds__(MAXT)
     prob_chain_pub_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats,
                           const float* __restrict__ xg, int T, int rows_per_chunk, const float* __restrict__ weights,
                           float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ logz, int64_t tail,
-                          int nch1, int Bp, uint32_t token) {
+                          int nch1, int Bp, uint32_t token, int mitm_req) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x % Bp;
   if (b >= d.B) return;
@@ -2054,7 +2311,7 @@ __global__ void __launch_bounds__(MAXT)
   uint32_t* busy = occ_header(d, alpha, tail, nch1).busy + cu_key();
   if (threadIdx.x == 0) __hip_atomic_store(busy, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   prob_chain_body<MAXT, true>(d, ints, floats, xg, T, rows_per_chunk, weights, alpha, beta, logz, tail, nch1, b,
-                              blockIdx.x / Bp, smem, token);
+                              blockIdx.x / Bp, smem, token, mitm_req);
   if (threadIdx.x == 0) __hip_atomic_store(busy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -2138,7 +2395,7 @@ __global__ void __launch_bounds__(256)
                     float* __restrict__ alpha, float* __restrict__ beta, const float* __restrict__ coef,
                     const float* __restrict__ x, const float* __restrict__ row_lse, float* __restrict__ dx, int rows_o,
                     int ntiles, int rows_per_chunk, int64_t tail, int nch1, uint32_t token,
-                    const uint32_t* __restrict__ verdict) {
+                    const uint32_t* __restrict__ verdict, int mitm_req) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint32_t job_s;
   // (the gate in front of this kernel on the side stream: anything but the launch's token means it gave up and the
@@ -2183,7 +2440,7 @@ __global__ void __launch_bounds__(256)
     live.prog_a = reinterpret_cast<const uint64_t*>(ta) + b;
     live.prog_b = reinterpret_cast<const uint64_t*>(tb) + b;
     live.bad = h.bad + b;
-    live.token = token, live.R = rows_per_chunk, live.force_bad = 0;
+    live.token = token, live.R = rows_per_chunk, live.force_bad = 0, live.mitm = mitm_req;
     const int t_begin = tile * rows_o;
     occ_grad_tiles<true>(d, u, b, T, C, alpha, beta, nullptr, coef, nullptr, 0, x, row_lse, dx, t_begin,
                          min(T, t_begin + rows_o), rows_o, tail, nch1, smem, live);
@@ -2233,6 +2490,16 @@ __global__ void __launch_bounds__(256)
   const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
   const float* wrefs = reinterpret_cast<const float*>(fmt + d.B);
   const bool prob = fmt[b] == kFmtProb;
+  if (fmt[b] == kFmtOcc) {
+    // sweeps that met in the middle left occupancies, not both vectors (run_chain_prob): only the occupancy gradient reads
+    // them -- the workgroups beside the sweeps (skip_occ == 2, unless they say otherwise) or occ_grad_kernel in this call
+    // (skip_occ == 1); what neither served is computed right here, the same tiles
+    if (skip_occ == 1 || (skip_occ == 2 && served_beside_the_sweeps(d, alpha, tail, nch1, b)) || !dx) return;
+    const int tb = blockIdx.x * rows_per_block;
+    occ_grad_tiles<false>(d, u, b, T, C, alpha, beta, logz, coef, gout, accumulate, x, row_lse, dx, tb, min(T, tb + rows_per_block),
+                          TS, tail, nch1, smem, OccLive{});
+    return;
+  }
   if (skip_band) {  // band_grad_kernel served this utterance (the same test decides there)
     const int band_ok = band_in_arcs(u, weights, tid).ok;
     if (__syncthreads_and(band_ok) && prob && band_shape(d, u)) return;
@@ -3101,10 +3368,16 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
                                bad_env && atoi(bad_env) == 1 ? 1 : 0, ls.host, verdict, nt_o, ls.max_spins);
           };
           if (serial_test) launch_gate();
+          // the sweeps meet in the middle and store occupancies beyond it (run_chain_prob): whole 16-frame chunks on
+          // both sides; WFL_LATTICE_MITM=0 keeps both vectors everywhere (A/B, tests)
+          // (read per call: tests flip it inside one process)
+          const char* mitm_e = getenv("WFL_LATTICE_MITM");
+          const int mitm_env = (mitm_e && atoi(mitm_e) == 0) ? 0 : 1;
+          const int mitm_req = (mitm_env && T % 16 == 0 && T >= 64 && !weights) ? 1 : 0;
           auto launch_pub = [&](auto kern) {
             if (plds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)kern, (int)plds);
             hipLaunchKernelGGL(kern, dim3((unsigned)(2 * Bp)), dim3(nt), plds, main_s, *d, ints, floats, xg, T, rpc, weights,
-                               alpha, beta, logz, tail, nch1, Bp, token);
+                               alpha, beta, logz, tail, nch1, Bp, token, mitm_req);
           };
           if (nt <= 256)
             launch_pub(prob_chain_pub_kernel<256>);
@@ -3115,7 +3388,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
           const int64_t jobs = (int64_t)d->B * nt_o;
           const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>(jobs, (int64_t)fused_wgs * device_cus()));
           hipLaunchKernelGGL(occ_live_kernel, dim3(wgs), dim3(256), olds, side->stream, *d, ints, floats, T, g->C, alpha, beta,
-                             g->coef, g->x, g->row_lse, g->dx, rows_o, nt_o, rpc, tail, nch1, token, verdict);
+                             g->coef, g->x, g->row_lse, g->dx, rows_o, nt_o, rpc, tail, nch1, token, verdict, mitm_req);
           WFL_HIP_CHECK(hipEventRecord(side->join, side->stream));
           join_side = side;  // (joined below, behind the certificate: it and the log-domain launch overlap the gradient's tail)
           g->done = 1;
@@ -3132,7 +3405,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
         launch_prob(prob_chain_kernel<1024>);
       if (beta)
         hipLaunchKernelGGL(prob_certify_kernel, dim3((unsigned)d->B, 8u), dim3(256), 0, (hipStream_t)stream, *d, ints,
-                           floats, T, alpha, beta, tail, nch1, nt);
+                           floats, T, alpha, beta, tail, nch1, nt, (g && g->done) ? 1 : 0);
     }
     // ... then the log-domain sweeps of the rest (and of utterances whose two sweeps disagree: the certificate)
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,

@@ -1112,13 +1112,14 @@ def test_transducer_native_call_is_the_python_sequence(crit, monkeypatch, leaf):
     np.testing.assert_allclose(native[1], python[1], rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("B,T", [(6, 200), (70, 48)])
+@pytest.mark.parametrize("B,T", [(6, 200), (70, 48), (6, 208), (9, 64)])
 def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(crit, monkeypatch, B, T):
     """csrc/lattice_kernels.hip wfl_lattice_forward_grad: the emission gradient computed by the persistent workgroups
     that follow the two sweeps (tile-local log Z, L1-bypassing reads of alpha / beta) against the gradient kernel that
     runs after them in backward -- through `loss.backward()` (the buffer becomes .grad as it is) and through the
     autograd engine with a grad_output that is not 1 (the buffer is scaled).  B = 70: more utterances than the gate
-    kernel's wave has lanes, not a multiple of the 8 XCDs."""
+    kernel's wave has lanes, not a multiple of the 8 XCDs.  T = 208 and 64: whole 16-frame chunks, so the sweeps meet in
+    the middle and the workgroups read occupancies (csrc/lattice_kernels.hip run_chain_prob, "meeting the partner")."""
     tr = crit["transducer"]
     tokens, g2i, x, tg = _word_piece_batch(B, T, 11)
     m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
@@ -1307,7 +1308,7 @@ import numpy as np
 from gtn_applications_amd import engine as E
 from gtn_applications_amd.criterions import transducer as tr
 from test_gpu_parity import _word_piece_batch
-tokens, g2i, x, tg = _word_piece_batch(6, 200, 11)
+tokens, g2i, x, tg = _word_piece_batch(6, %(T)d, 11)
 m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
 out = []
 for step in range(14):
@@ -1321,7 +1322,8 @@ print("RESULT " + json.dumps(out))
 """
 
 
-def test_transducer_gradient_beside_the_sweeps_gate_gives_up_cleanly_and_reports_it(crit, tmp_path):
+@pytest.mark.parametrize("T", [200, 208])  # (208: whole chunks -- the sweeps meet in the middle and leave occupancies)
+def test_transducer_gradient_beside_the_sweeps_gate_gives_up_cleanly_and_reports_it(crit, tmp_path, T):
     """A stack that runs the kernels of different streams one after the other (a counter-collecting profiler, a
     debugger): the gate kernel in front of the gradient workgroups cannot see the sweeps.  WFL_LATTICE_FUSED_SERIAL=1
     puts it in front of them on the caller's stream (what such a stack does to the launch order).  It must give up
@@ -1335,7 +1337,7 @@ def test_transducer_gradient_beside_the_sweeps_gate_gives_up_cleanly_and_reports
     import time
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = _GATE_SCRIPT % dict(root=root, tests=os.path.join(root, "tests"))
+    script = _GATE_SCRIPT % dict(root=root, tests=os.path.join(root, "tests"), T=T)
 
     def run(env_extra, name):
         env = dict(os.environ)
@@ -1364,12 +1366,13 @@ def test_transducer_gradient_beside_the_sweeps_gate_gives_up_cleanly_and_reports
     assert d["gate_spins"] <= 1 << 12, d  # the bound: milliseconds per give-up, not seconds
 
 
-def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificate(crit, monkeypatch):
+@pytest.mark.parametrize("T", [150, 160])  # (160: whole chunks -- occupancies; the rest launch forms the rows from them)
+def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificate(crit, monkeypatch, T):
     """WFL_LATTICE_FUSED_BADXCD=1 makes the gate kernel report every utterance as swept on two XCDs (what a different
     workgroup-to-XCD dealing would look like): no gradient workgroup may touch them, the certificate sends them to the
     log-domain sweeps and wfl_lattice_grad_rest writes their rows -- same loss, same gradient."""
     tr = crit["transducer"]
-    tokens, g2i, x, tg = _word_piece_batch(5, 150, 12)
+    tokens, g2i, x, tg = _word_piece_batch(5, T, 12)
     m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
 
     def run():
@@ -1383,6 +1386,49 @@ def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificat
     loss, dx = run()
     assert loss == pytest.approx(ref_loss, rel=2e-5)
     close(dx, ref_dx.cpu().numpy(), rtol=2e-3, atol=2e-6, msg="fall-back")  # (fp32 log-domain sweeps against fp64 probabilities)
+
+
+def _sweep_formats(loss, B, T):
+    """fmt[b] of the numerator sweeps behind a Transducer loss (0 log domain, 1 probability domain, 2 met in the middle)"""
+    import ctypes
+
+    from gtn_applications_amd import _native as N
+
+    num = loss.grad_fn.aux[2]
+    off = ctypes.c_int64()
+    N.check(N.lib.wfl_lattice_formats_offset(ctypes.byref(num.pack.desc), T, ctypes.byref(off)))
+    torch.cuda.synchronize()
+    return num.alpha[off.value:off.value + B].view(torch.int32).cpu().tolist()
+
+
+@pytest.mark.parametrize("B,T", [(5, 64), (7, 160), (3, 400)])
+def test_transducer_sweeps_that_meet_in_the_middle_equal_the_full_sweeps(crit, monkeypatch, B, T):
+    """csrc/lattice_kernels.hip run_chain_prob: with whole 16-frame chunks the two sweeps of an utterance store their own
+    vector up to the middle slot and state occupancies (floats, normalised by the Z formed at the middle) beyond it,
+    reading the partner's vectors from L2 -- WFL_LATTICE_MITM=0 keeps both vectors everywhere.  The forward sweep's
+    arithmetic is untouched: the loss bit for bit; the gradient to the rounding of float occupancies; the formats say
+    which one ran.  A T that is not a multiple of 16 keeps the full sweeps."""
+    tr = crit["transducer"]
+    tokens, g2i, x, tg = _word_piece_batch(B, T, 17)
+    m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
+
+    def run():
+        xi = x.clone().requires_grad_(True)
+        loss = m(xi, tg)
+        fm = _sweep_formats(loss, B, T)
+        loss.backward()
+        return loss.item(), xi.grad.clone(), fm
+
+    monkeypatch.setenv("WFL_LATTICE_MITM", "0")
+    ref = run()
+    monkeypatch.setenv("WFL_LATTICE_MITM", "1")
+    got = run()
+    assert ref[2] == [1] * B and got[2] == [2] * B, (ref[2], got[2])
+    assert got[0] == ref[0]
+    close(got[1], ref[1].cpu().numpy(), rtol=1e-4, atol=1e-7, msg="occupancies")
+    xo, to = x[:, :T - 3].contiguous(), tg
+    xi = xo.clone().requires_grad_(True)
+    assert _sweep_formats(m(xi, to), B, T - 3) == [1] * B
 
 
 def test_transducer_equals_ctc(crit, lit):
