@@ -1,6 +1,6 @@
 import os, sys, ctypes, random
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from gtn_applications_amd import engine as E, _native as N
 from gtn_applications_amd.criterions import transducer
 import bench
