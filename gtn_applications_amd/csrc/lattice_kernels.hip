@@ -887,11 +887,6 @@ __device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {  // NT
 }
 
 // What a sweep needs of its partner (the other direction of the same utterance, same launch) to meet it in the middle.
-#ifdef WFL_MITM_FAKE_LOADS  // (timing experiment: every partner load hits the same few lines)
-#define WFL_MITM_SLOT(s) ((s) & 1)
-#else
-#define WFL_MITM_SLOT(s) (s)
-#endif
 struct MitmArgs {
   int req = 0;                       // the launch asks for it (wfl_lattice_forward_grad, T a multiple of 16, ...)
   double* oth = nullptr;             // the partner's score rows of this utterance ([T+1][Q] doubles)
@@ -1232,7 +1227,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         // the partner's values for the second half of this chunk (its first half came with the chunk before, at frame 7),
         // and its offset for the next chunk's frames: L1-bypassing loads (another CU wrote them during this launch)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pbB[j] = ld_l2(mm.oth + (int64_t)WFL_MITM_SLOT(slot_of(c, 8 + j)) * Q + tidc);
+        for (int j = 0; j < 8; ++j) pbB[j] = ld_l2(mm.oth + (int64_t)slot_of(c, 8 + j) * Q + tidc);
         oo_next = ld_l2(mm.oth_offs + slot_of(min(c + 1, nchunks - 1), tid & 15));
       }
       // (`path`: 0 behind the sixteen straight-line frames, 1 a wave without a state, 2 behind a frame loop)
@@ -1409,7 +1404,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
             pof += pfstep;
             if (i == 7) {  // the first half of the NEXT chunk (the last chunk asks for itself again: not consumed)
 #pragma unroll
-              for (int j = 0; j < 8; ++j) pbA[j] = ld_l2(mm.oth + (int64_t)WFL_MITM_SLOT(slot_of(cn, j)) * Q + tidc);
+              for (int j = 0; j < 8; ++j) pbA[j] = ld_l2(mm.oth + (int64_t)slot_of(cn, j) * Q + tidc);
             }
           };
 #pragma unroll
