@@ -1933,6 +1933,42 @@ def test_ctc_loss_backward_without_the_engine_equals_the_engine(monkeypatch):
             torch.testing.assert_close(got.grad, 2 * want.grad)
 
 
+def test_ctc_targets_recognised_by_object_identity_track_in_place_edits():
+    """csrc/torch_ops.cpp LastBatch: a target list handed over again (ctc_benchmark.py:26-31 reuses one list) is recognised
+    by the identity of its int objects instead of being flattened and hashed again.  Ints are immutable, so the only way
+    to change such a batch is to put OTHER objects into the lists -- which the comparison sees: after every in-place
+    edit (a label replaced, a row replaced by an equal / a different one, a row shortened, the outer list edited) the
+    loss must equal what a fresh copy of the edited batch gives."""
+    from gtn_applications_amd.criterions import ctc
+
+    g = torch.Generator().manual_seed(13)
+    B, T, C, L = 6, 80, 300, 9  # (labels beyond CPython's cached small ints too)
+    x = torch.randn(B, T, C, generator=g).cuda().requires_grad_(True)
+    tg = [[int(v) for v in row] for row in torch.randint(C - 1, (B, L), generator=g).tolist()]
+
+    def loss_of(t):
+        return ctc.CTCLoss(x, t, C - 1, "none").item()
+
+    def fresh():  # the same labels as tuples of new int objects: nothing for the identity check to recognise
+        return loss_of(tuple(tuple(int(str(v)) for v in row) for row in tg))
+
+    for _ in range(3):  # first call stages, second hits the content cache and remembers the objects, third is recognised
+        assert loss_of(tg) == fresh()
+    tg[2][4] = (tg[2][4] + 7) % (C - 1)
+    assert loss_of(tg) == fresh()
+    assert loss_of(tg) == fresh()
+    tg[1] = list(tg[1])  # an equal row, another list object
+    assert loss_of(tg) == fresh()
+    tg[3] = [5, 299 - 1, 17]
+    assert loss_of(tg) == fresh()
+    assert loss_of(tg) == fresh()
+    tg[0].pop()
+    assert loss_of(tg) == fresh()
+    tg[5], tg[4] = tg[4], tg[5]
+    assert loss_of(tg) == fresh()
+    assert loss_of(tg) == fresh()
+
+
 def test_ctc_loss_backward_started_at_non_leaf_emissions_equals_the_engine(monkeypatch):
     """Emissions that are a producer's output (train.py:262-266; ctc_benchmark.py:22): `loss.backward()` starts the
     autograd engine AT the emissions' edge with the forward launch's gradient (csrc/torch_ops.cpp ctc_fast_backward),
