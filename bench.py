@@ -83,8 +83,10 @@ PHASE_KERNEL_NAMES = {
     "lattice_gather/shared": ["gather_kernel"],
     "lattice_chain/shared": ["prob_chain_kernel", "prob_certify_kernel", "chain_kernel"],
     "lattice_grad/shared": ["grad_kernel"],
-    "dense_chain": ["dense_fast_chain_kernel", "dense_chain_kernel"],
-    "dense_grad": ["dense_mfma_grad_kernel", "dense_fast_grad_kernel", "dense_grad_kernel", "dense_reduce_kernel"],
+    "dense_chain": ["dense_fast_chain_kernel", "dense_chain_kernel", "wide_resident_sweep_kernel", "wide_frame_mfma_kernel",
+                    "wide_rows_kernel", "wide_prep_kernel", "wide_scan_kernel"],
+    "dense_grad": ["dense_mfma_grad_kernel", "dense_fast_grad_kernel", "dense_grad_kernel", "dense_reduce_kernel",
+                   "wide_grad_x_kernel", "wide_grad_w_kernel", "wide_reduce_w_kernel"],
 }
 PHASE_KERNELS = {k: " + ".join(v) + (" (transitions graph)" if k.endswith("/shared") else "")
                  for k, v in PHASE_KERNEL_NAMES.items()}
