@@ -701,7 +701,8 @@ def main():
                     "bound of the step's GPU time); dominant_kernel divides the same bytes by that group alone; traffic = "
                     "HBM bytes of all the step's kernels from the committed PMC passes",
         }
-        if args.workload == "ctc" and rank == 0 and "launch_clock" in wl:
+        # (not under --no-extras: the profiling runs want the timed steps' launches and nothing else in their statistics)
+        if args.workload == "ctc" and rank == 0 and "launch_clock" in wl and not args.no_extras:
             # the single longest kernel by itself: the group's bracket also holds the (normally empty) repair launch
             lc = wl["launch_clock"]()
             if lc:
