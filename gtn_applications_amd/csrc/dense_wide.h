@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(64 * kWideMfmaWaves) wide_frame_mfma_kernel(co
 // fold theirs into one LDS word per frame with ds_max (four words in rotation: written in frame n, read in n + 1,
 // cleared in n + 2).
 // Nothing in the frame is conditional: every lane takes part in loads and stores -- lane l of a group works on row
-// l % NR, so up to four lanes compute, and store, the same value -- because emission scores are requested kWideAhead frames
+// l % NR (l / 4 for NR = 4), so up to four lanes compute, and store, the same value -- because emission scores are requested kWideAhead frames
 // ahead and loads and stores share ONE in-order counter (vmcnt): behind a test the compiler's static wait-count pass
 // must assume the path that skipped the later loads, and waits for the youngest of them instead of the oldest
 // (csrc/lattice_kernels.hip, the comment above the chunk loop of run_chain_prob, has the long version).
@@ -290,6 +290,24 @@ __device__ __forceinline__ float group16_max(float v) {  // v >= 0; every lane o
   return v;
 }
 typedef float wide_v2f __attribute__((ext_vector_type(2)));
+// Four rows' sums over a row of 16 lanes, scattered: lane i ends with the total of row i / 4 (its quad's row).  A
+// reduce-scatter over the cross-lane network -- every step halves what a lane still carries -- in 11 instructions where
+// four all-reductions take 29: mirror (i <-> 15 - i: lanes 0-7 keep rows 0, 1, lanes 8-15 rows 2, 3), half mirror
+// (i <-> 7 - i in each half: the lower quad of a half keeps its first row, the upper quad the second), then the quad's
+// four lanes add up.  (Lane 0 of the row collects lanes {0, 15, 7, 8}, lane 1 {1, 14, 6, 9}, ...: every lane once.)
+__device__ __forceinline__ float group16_scatter4(const float (&t)[4], int l16) {
+  auto dpp = [](float v, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  const bool hi = (l16 & 8) != 0, mid = (l16 & 4) != 0;
+  const float ka = hi ? t[2] : t[0], kb = hi ? t[3] : t[1], sa = hi ? t[0] : t[2], sb = hi ? t[1] : t[3];
+  const float ra = ka + dpp(sa, std::integral_constant<int, 0x140>{});
+  const float rb = kb + dpp(sb, std::integral_constant<int, 0x140>{});
+  float r = (mid ? rb : ra) + dpp(mid ? ra : rb, std::integral_constant<int, 0x141>{});
+  r += dpp(r, std::integral_constant<int, 0xB1>{});
+  r += dpp(r, std::integral_constant<int, 0x4E>{});
+  return r;
+}
 
 template <int NR>
 __global__ void __launch_bounds__(1024) wide_resident_sweep_kernel(const float* __restrict__ x, int B, int T, int C, WideWs w,
@@ -338,7 +356,7 @@ __global__ void __launch_bounds__(1024) wide_resident_sweep_kernel(const float* 
   // ---- the row this lane finishes: l16 % NR of the group's (lanes NR .. 15 duplicate lanes 0 .. NR-1: same value to the
   // same address).  A lane whose row does not exist (rows C .. 64 NR - 1) stores into the sweep's LAST frame instead, at a
   // column of its own -- that frame is written for good by the last step, behind a wait for every earlier store
-  const int rsel = l16 % NR;
+  const int rsel = NR == 4 ? l16 >> 2 : l16 % NR;  // (NR = 4: the quad's row, where group16_scatter4 leaves the totals)
   const int myrow = row0 + rsel;
   const bool live = myrow < C;
   const int rowc = min(myrow, C - 1);
@@ -410,10 +428,14 @@ __global__ void __launch_bounds__(1024) wide_resident_sweep_kernel(const float* 
       }
     }
     float mine = 0.f;
+    if constexpr (NR == 4) {
+      mine = group16_scatter4(tot, l16);
+    } else {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const float s = group16_sum(tot[r]);
-      mine = rsel == r ? s : mine;
+      for (int r = 0; r < NR; ++r) {
+        const float s = group16_sum(tot[r]);
+        mine = rsel == r ? s : mine;
+      }
     }
     const float inv = dprev > 0.f ? 1.f / dprev : 0.f;  // (a dead utterance stays dead: as the per-frame launch)
     const float e = __expf(wide_clean(xv) + rm - mx);
@@ -572,8 +594,8 @@ __global__ void __launch_bounds__(256) wide_grad_w_kernel(const float* __restric
                                                           float* __restrict__ partial) {
   __shared__ float Us[kWideTK][kWideTM + 4];
   __shared__ float Vs[kWideTK][kWideTN + 4];
-  __shared__ float ku[kWideTK], kv[kWideTK];
-  __shared__ int64_t krow[kWideTK];
+  __shared__ float ku[2][kWideTK], kv[2][kWideTK];  // the rows' scalars, double-buffered: chunk n + 1's are formed while chunk
+  __shared__ int64_t krow[2][kWideTK];              // n's operands are on their way
   const int i0 = blockIdx.x * kWideTM, j0 = blockIdx.y * kWideTN;
   const int64_t K = (int64_t)B * (T - 1);
   const int nsplit = (int)gridDim.z;
@@ -581,36 +603,48 @@ __global__ void __launch_bounds__(256) wide_grad_w_kernel(const float* __restric
   const int64_t kbeg = (int64_t)blockIdx.z * per, kend = min(K, kbeg + per);
   const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
   float acc[4][4] = {};
-  for (int64_t k0 = kbeg; k0 < kend; k0 += kWideTK) {
-    if (tid < kWideTK) {
-      const int64_t k = k0 + tid;
-      float su = 0.f, sv = 0.f;
-      int64_t row = 0;
-      if (k < kend) {
-        const int b = (int)(k / (T - 1)), t = 1 + (int)(k % (T - 1));
-        row = (int64_t)b * T + t;
-        const float ma = w.maxa[row - 1], mb = w.maxb[row], lz = logz[b];
-        if (ma > 0.f && mb > 0.f && lz > -3.0e38f) {
-          sv = 1.f / ma;
-          su = (coef_w ? coef_w[b] : 1.f) * (float)exp(w.cuma[row - 1] + (double)w.mxp[row] + w.cb[row] - (double)lz) / mb;
-        }
+  // the scalars of a chunk's rows (threads 0 .. 15): a double-precision exponential each.  In front of the chunk's loads
+  // they were a serial stage of every chunk -- scalars, barrier, loads, barrier, products, barrier: ~4 us a chunk
+  // whatever the class count; now the NEXT chunk's are formed behind this chunk's loads, in their shadow.
+  auto scalars = [&](int64_t k0, int buf) {
+    const int64_t k = k0 + tid;
+    float su = 0.f, sv = 0.f;
+    int64_t row = 1;  // (a valid row for the clamped loads of rows past the slab: scaled by zero)
+    if (k < kend) {
+      const int b = (int)(k / (T - 1)), t = 1 + (int)(k % (T - 1));
+      row = (int64_t)b * T + t;
+      const float ma = w.maxa[row - 1], mb = w.maxb[row], lz = logz[b];
+      if (ma > 0.f && mb > 0.f && lz > -3.0e38f) {
+        sv = 1.f / ma;
+        su = (coef_w ? coef_w[b] : 1.f) * (float)exp(w.cuma[row - 1] + (double)w.mxp[row] + w.cb[row] - (double)lz) / mb;
       }
-      ku[tid] = su, kv[tid] = sv, krow[tid] = row;
     }
-    __syncthreads();
-    // 16 rows x 64 columns per operand: thread -> (row = tid / 16, columns (tid % 16) + 16 q)
-    {
-      const int kr = tid >> 4, c = tid & 15;
-      const int64_t row = krow[kr];
-      const float su = ku[kr], sv = kv[kr], ref = w.mxp[row];
+    ku[buf][tid] = su, kv[buf][tid] = sv, krow[buf][tid] = row;
+  };
+  if (tid < kWideTK) scalars(kbeg, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += kWideTK, cur ^= 1) {
+    // 16 rows x 64 columns per operand: thread -> (row = tid / 16, columns (tid % 16) + 16 q); every load first, from
+    // clamped addresses
+    const int kr = tid >> 4, c = tid & 15;
+    const int64_t row = krow[cur][kr];
+    float rb[4], rx[4], ra[4], rr[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + c + 16 * q, j = j0 + c + 16 * q;
-        float u = 0.f, v = 0.f;
-        if (su != 0.f && i < C) u = su * beta[row * C + i] * __expf(wide_clean(x[row * C + i]) + w.rm[i] - ref);
-        if (sv != 0.f && j < C) v = sv * alpha[(row - 1) * C + j];
-        Us[kr][c + 16 * q] = u, Vs[kr][c + 16 * q] = v;
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int i = min(i0 + c + 16 * q, C - 1), j = min(j0 + c + 16 * q, C - 1);
+      rb[q] = beta[row * C + i], rx[q] = x[row * C + i], rr[q] = w.rm[i], ra[q] = alpha[(row - 1) * C + j];
+    }
+    const float ref = w.mxp[row];
+    if (tid < kWideTK && k0 + kWideTK < kend) scalars(k0 + kWideTK, cur ^ 1);
+    const float su = ku[cur][kr], sv = kv[cur][kr];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + c + 16 * q, j = j0 + c + 16 * q;
+      float u = 0.f, v = 0.f;
+      if (su != 0.f && i < C) u = su * rb[q] * __expf(wide_clean(rx[q]) + rr[q] - ref);
+      if (sv != 0.f && j < C) v = sv * ra[q];
+      Us[kr][c + 16 * q] = u, Vs[kr][c + 16 * q] = v;
     }
     __syncthreads();
 #pragma unroll
