@@ -775,6 +775,10 @@ constexpr uint32_t kProgMitm = 1u << 27, kProgCount = kProgMitm - 1u;
 constexpr int kFmtOcc = 2;  // fmt[b]: probability-domain sweeps that met in the middle (see run_chain_prob)
 // the middle slot of sweeps that met in the middle (run_chain_prob: T a multiple of 16)
 __host__ __device__ inline int mitm_middle(int T) { return 16 * ((T / 16) / 2); }
+// chunks each sweep stores as plain vectors before it switches to occupancies: the forward sweep up to the middle slot,
+// the backward sweep down to the first chunk boundary of ITS chunking (T - 16 c) at or below the middle
+__host__ __device__ inline int mitm_plain_chunks_a(int T) { return (T / 16) / 2; }
+__host__ __device__ inline int mitm_plain_chunks_b(int T) { return T / 16 - (T / 16) / 2 + (T % 16 != 0 ? 1 : 0); }
 __device__ __forceinline__ uint32_t xcc_id() {
   uint32_t v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
@@ -887,6 +891,31 @@ __device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {  // NT
 }
 
 // What a sweep needs of its partner (the other direction of the same utterance, same launch) to meet it in the middle.
+// Slots s_lo .. s_lo + cnt - 1 (cnt <= 16), of which BOTH sweeps of an utterance have stored their vectors (doubles, rows
+// of Q), as occupancies (floats) into the first half of `dst`'s rows -- this sweep's own rows or the partner's:
+// everything is read first (the floats of a row overwrite other threads' doubles of the same row), eight slots at a
+// time.  Workgroup-wide: barriers inside.  zlog2 = +inf: no accepting path, zeros.
+__device__ __noinline__ void mitm_gamma_rows(const double* own, const double* oth, const double* offs, const double* oth_offs,
+                                             double* dst, int s_lo, int cnt, int Q, double zlog2) {
+  const int tid = threadIdx.x, tidc = min(tid, Q - 1);
+  for (int b0 = 0; b0 < cnt; b0 += 8) {
+    double av[8], bv[8], ex[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int sl = s_lo + min(b0 + j, cnt - 1);
+      av[j] = ld_l2(own + (int64_t)sl * Q + tidc);
+      bv[j] = ld_l2(oth + (int64_t)sl * Q + tidc);
+      ex[j] = ld_l2(offs + sl) + ld_l2(oth_offs + sl);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (b0 + j < cnt && tid < Q)
+        reinterpret_cast<float*>(dst + (int64_t)(s_lo + b0 + j) * Q)[tid] =
+            zlog2 == __builtin_inf() ? 0.f : (float)(av[j] * bv[j] * exp2(ex[j] - zlog2));
+    }
+  }
+}
 struct MitmArgs {
   int req = 0;                       // the launch asks for it (wfl_lattice_forward_grad, T a multiple of 16, ...)
   double* oth = nullptr;             // the partner's score rows of this utterance ([T+1][Q] doubles)
@@ -1194,6 +1223,13 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
   bool mitm_on = false;
   const int tidc = min(tid, Q - 1);
   auto slot_of = [&](int c, int i) { return DIR == 0 ? c * 16 + i + 1 : T - c * 16 - 1 - i; };
+  // chunks whose sixteen frames run as straight-line code (nchunks is 0 when the banded sweep above has done the work)
+  const int nfull = (UNR && R == 16) ? min(T / 16, nchunks) : 0;
+  // (MITM) slots of which BOTH sweeps have stored their vectors, as occupancies: mitm_gamma_rows, a real call -- inlined
+  // at its two sites in each of the eight copies of the sweep it cost the kernel 9 VGPRs and 200 more spilled SGPRs
+  auto gamma_rows = [&](int s_lo, int cnt, double* dst) {
+    mitm_gamma_rows(out + u.ab_base, mm.oth, offs, mm.oth_offs, dst, s_lo, cnt, Q, zlog2);
+  };
   auto sweep = [&](auto sel_, auto live_) {
     constexpr int SEL = decltype(sel_)::value;
     constexpr bool LIVE = decltype(live_)::value;
@@ -1228,7 +1264,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
         // and its offset for the next chunk's frames: L1-bypassing loads (another CU wrote them during this launch)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pbB[j] = ld_l2(mm.oth + (int64_t)slot_of(c, 8 + j) * Q + tidc);
-        oo_next = ld_l2(mm.oth_offs + slot_of(min(c + 1, nchunks - 1), tid & 15));
+        oo_next = ld_l2(mm.oth_offs + slot_of(min(c + 1, nfull - 1), tid & 15));
       }
       // (`path`: 0 behind the sixteen straight-line frames, 1 a wave without a state, 2 behind a frame loop)
       auto hand_over = [&](auto path) {
@@ -1387,7 +1423,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
           // (past the middle: occupancies, floats, into the first half of the same rows)
           float* pof = mine ? reinterpret_cast<float*>(orow) + tid : reinterpret_cast<float*>(dump) + (tid & (kDumpDoubles - 1));
           const int64_t pfstep = 2 * pstep;
-          const int cn = min(c + 1, nchunks - 1);
+          const int cn = min(c + 1, nfull - 1);  // (occupancy chunks are whole chunks)
           const double* bA = par ? lbuf1 : lbuf0;  // read by the even frames of the chunk, written by the odd ones
           const double* bB = par ? lbuf0 : lbuf1;
           const int fstep = DIR == 0 ? Kmax : -Kmax;
@@ -1546,14 +1582,16 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       e_hand += clock64() - eE;
 #endif
     };
-    // chunks whose sixteen frames run as straight-line code (nchunks is 0 when the banded sweep above has done the work)
-    const int nfull = (UNR && R == 16) ? min(T / 16, nchunks) : 0;
-    // meeting in the middle: the launch asks, a uniform-label acceptor, whole chunks only (T a multiple of 16: the two
-    // sweeps' chunk boundaries coincide), at least two chunks a side.  c0: this sweep's chunks up to the middle slot.
+    // meeting in the middle: the launch asks, a uniform-label acceptor, at least two whole chunks a side.  c0: the chunks
+    // this sweep stores as plain vectors.  The forward sweep's reach m_f = 16 c0 (the middle slot); the backward sweep's
+    // chunks end at T - 16 c, so it goes on to m_b = the first such boundary <= m_f: with T a multiple of 16 the two
+    // coincide, otherwise both sweeps hold plain vectors of slots m_b .. m_f and the forward sweep turns all of them
+    // into occupancies at its crossing (gamma_rows).  The occupancy half is whole chunks; a last, partial chunk stores
+    // plain vectors as ever and is turned into occupancies afterwards (below).
     // (every wave of the workgroup takes the same decision and the crossing's barriers: `uniform` is block-uniform, the
     // waves without a state -- SEL 7 -- included)
-    const bool mitm_try = PUB && uniform && mm.req != 0 && nfull == nchunks && nchunks >= 4;
-    const int c0 = DIR == 0 ? nchunks / 2 : nchunks - nchunks / 2;
+    const bool mitm_try = PUB && uniform && mm.req != 0 && nfull >= 4;
+    const int c0 = DIR == 0 ? mitm_plain_chunks_a(T) : mitm_plain_chunks_b(T);
     int cfirst = nfull;  // (first chunk of the occupancy half, if it comes to that)
     for (int c = 0; c < nfull; ++c) {
       if constexpr (PUB) {
@@ -1564,7 +1602,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
           int* red = (int*)lred;
           if (tid == 0) {
             prog_publish(prog, token, (uint32_t)c0);
-            const uint32_t need = (uint32_t)(nchunks - c0), me = xcc_id();
+            const uint32_t need = (uint32_t)(DIR == 0 ? mitm_plain_chunks_b(T) : mitm_plain_chunks_a(T)), me = xcc_id();
             int st = 0;
             for (int spin = 0; spin < mm.spins; ++spin) {
               const uint64_t v = __hip_atomic_load(mm.oth_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1594,6 +1632,8 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
             // the partner holds it in registers, and every thread of this workgroup has used its copy -- the reduction's barriers)
             if (DIR == 0 && tid < Q)
               reinterpret_cast<float*>(mm.oth + (int64_t)m * Q)[tid] = deadz ? 0.f : (float)(p * bm * exp2(cum + om - zlog2));
+            // (T not a multiple of 16: slots m_b .. m - 1 as well, from the two sweeps' stored vectors)
+            if (DIR == 0 && (T & 15) != 0) gamma_rows(m - 16 + (T & 15), 16 - (T & 15), mm.oth);
             if constexpr (LIVE) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) pbA[j] = ld_l2(mm.oth + (int64_t)slot_of(c0, j) * Q + tidc);
@@ -1622,6 +1662,15 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
       for (int c = cfirst; c < nfull; ++c) chunk(c, std::true_type{}, std::true_type{});
     }
     for (int c = nfull; c < nchunks; ++c) chunk(c, std::false_type{}, std::false_type{});
+    if constexpr (PUB) {
+      if (mitm_on && nfull < nchunks) {
+        // the last, partial chunk (alpha: slots 16 nfull + 1 .. T, beta: T % 16 - 1 .. 0) was stored as plain vectors:
+        // occupancies in their place, once its stores -- vectors and offsets -- are in L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        gamma_rows(DIR == 0 ? 16 * nfull + 1 : 0, T - 16 * nfull, out + u.ab_base);
+      }
+    }
   };
   if (!wave_live)
     sweep(std::integral_constant<int, 7>{}, std::false_type{});
@@ -2112,10 +2161,12 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
         // a chunk beyond its half (the crossing itself publishes the half's count, still without the flag).  Then a slot's
         // occupancy only needs the sweep that wrote it: slots > m the forward sweep, slots < m the backward one, slot m
         // the forward sweep's crossing (in L2 with its first chunk beyond).
-        const int nch = T / 16, half_a = nch / 2, half_b = nch - nch / 2;
+        // (T not a multiple of 16: the backward sweep's occupancies end below m_b = T - 16 half_b <= m, slots m_b .. m
+        // are the forward sweep's crossing too; a sweep's last, partial chunk comes with its final count)
+        const int half_a = mitm_plain_chunks_a(T), half_b = mitm_plain_chunks_b(T), mid_b = T - 16 * half_b;
         const int s_lo = ts0 + 1, s_hi = ts0 + nr;
-        const uint32_t gneed_a = s_hi >= mid ? (uint32_t)max((s_hi + 15) / 16, half_a + 1) : 0u;
-        const uint32_t gneed_b = s_lo < mid ? (uint32_t)((T - 1 - s_lo) / 16 + 1) : 0u;
+        const uint32_t gneed_a = s_hi >= mid_b ? (uint32_t)max((s_hi + 15) / 16, half_a + 1) : 0u;
+        const uint32_t gneed_b = s_lo < mid_b ? (uint32_t)((T - 1 - s_lo) / 16 + 1) : 0u;
         const uint32_t me = xcc_id();
         int st = -2;  // (gave up: ~2 s)
         for (int spin = 0; spin < (1 << 20); ++spin) {
@@ -3363,12 +3414,15 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
                                bad_env && atoi(bad_env) == 1 ? 1 : 0, ls.host, verdict, nt_o, ls.max_spins);
           };
           if (serial_test) launch_gate();
-          // the sweeps meet in the middle and store occupancies beyond it (run_chain_prob): whole 16-frame chunks on
-          // both sides; WFL_LATTICE_MITM=0 keeps both vectors everywhere (A/B, tests)
-          // (read per call: tests flip it inside one process)
+          // the sweeps meet in the middle and store occupancies beyond it (run_chain_prob), from kMitmFrames frames on:
+          // the crossing and the conversion of the partial chunks are a fixed cost on the sweeps' path, the gradient
+          // workgroups' saving grows with T (step at the Transducer benchmark's batch: 320 frames 0.176 either way, 480
+          // frames 0.235 -> 0.229 ms, 800 frames 0.352 -> 0.337).  WFL_LATTICE_MITM=0 keeps both vectors everywhere,
+          // =2 meets from 64 frames on (A/B, tests; read per call: tests flip it inside one process)
+          constexpr int kMitmFrames = 320;
           const char* mitm_e = getenv("WFL_LATTICE_MITM");
-          const int mitm_env = (mitm_e && atoi(mitm_e) == 0) ? 0 : 1;
-          const int mitm_req = (mitm_env && T % 16 == 0 && T >= 64 && !weights) ? 1 : 0;
+          const int mitm_env = mitm_e ? atoi(mitm_e) : 1;
+          const int mitm_req = (mitm_env != 0 && T >= (mitm_env == 2 ? 64 : kMitmFrames) && !weights) ? 1 : 0;
           auto launch_pub = [&](auto kern) {
             if (plds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)kern, (int)plds);
             hipLaunchKernelGGL(kern, dim3((unsigned)(2 * Bp)), dim3(nt), plds, main_s, *d, ints, floats, xg, T, rpc, weights,

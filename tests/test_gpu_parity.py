@@ -1112,15 +1112,17 @@ def test_transducer_native_call_is_the_python_sequence(crit, monkeypatch, leaf):
     np.testing.assert_allclose(native[1], python[1], rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("B,T", [(6, 200), (70, 48), (6, 208), (9, 64)])
-def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(crit, monkeypatch, B, T):
+@pytest.mark.parametrize("B,T,mitm", [(6, 200, "0"), (70, 48, "1"), (6, 208, "2"), (9, 64, "2"), (6, 200, "2"), (3, 330, "1")])
+def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(crit, monkeypatch, B, T, mitm):
     """csrc/lattice_kernels.hip wfl_lattice_forward_grad: the emission gradient computed by the persistent workgroups
     that follow the two sweeps (tile-local log Z, L1-bypassing reads of alpha / beta) against the gradient kernel that
     runs after them in backward -- through `loss.backward()` (the buffer becomes .grad as it is) and through the
     autograd engine with a grad_output that is not 1 (the buffer is scaled).  B = 70: more utterances than the gate
-    kernel's wave has lanes, not a multiple of the 8 XCDs.  T = 208 and 64: whole 16-frame chunks, so the sweeps meet in
-    the middle and the workgroups read occupancies (csrc/lattice_kernels.hip run_chain_prob, "meeting the partner")."""
+    kernel's wave has lanes, not a multiple of the 8 XCDs.  mitm = WFL_LATTICE_MITM: "2" the sweeps meet in the middle
+    from 64 frames on and the workgroups read occupancies (csrc/lattice_kernels.hip run_chain_prob, "meeting the
+    partner"), "1" (the default) from 320 frames on, "0" never."""
     tr = crit["transducer"]
+    monkeypatch.setenv("WFL_LATTICE_MITM", mitm)
     tokens, g2i, x, tg = _word_piece_batch(B, T, 11)
     m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
 
@@ -1322,8 +1324,8 @@ print("RESULT " + json.dumps(out))
 """
 
 
-@pytest.mark.parametrize("T", [200, 208])  # (208: whole chunks -- the sweeps meet in the middle and leave occupancies)
-def test_transducer_gradient_beside_the_sweeps_gate_gives_up_cleanly_and_reports_it(crit, tmp_path, T):
+@pytest.mark.parametrize("T,mitm", [(200, "0"), (200, "2"), (208, "2")])  # ("2": the sweeps meet in the middle and leave occupancies)
+def test_transducer_gradient_beside_the_sweeps_gate_gives_up_cleanly_and_reports_it(crit, tmp_path, T, mitm):
     """A stack that runs the kernels of different streams one after the other (a counter-collecting profiler, a
     debugger): the gate kernel in front of the gradient workgroups cannot see the sweeps.  WFL_LATTICE_FUSED_SERIAL=1
     puts it in front of them on the caller's stream (what such a stack does to the launch order).  It must give up
@@ -1342,6 +1344,7 @@ def test_transducer_gradient_beside_the_sweeps_gate_gives_up_cleanly_and_reports
     def run(env_extra, name):
         env = dict(os.environ)
         env.update(env_extra)
+        env["WFL_LATTICE_MITM"] = mitm
         t0 = time.time()
         res = subprocess.run([sys.executable, "-c", script, str(tmp_path / name)], capture_output=True, text=True, env=env,
                              timeout=600)
@@ -1366,12 +1369,13 @@ def test_transducer_gradient_beside_the_sweeps_gate_gives_up_cleanly_and_reports
     assert d["gate_spins"] <= 1 << 12, d  # the bound: milliseconds per give-up, not seconds
 
 
-@pytest.mark.parametrize("T", [150, 160])  # (160: whole chunks -- occupancies; the rest launch forms the rows from them)
-def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificate(crit, monkeypatch, T):
+@pytest.mark.parametrize("T,mitm", [(150, "0"), (150, "2"), (160, "2")])  # ("2": occupancies; the rest launch forms the rows from them)
+def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificate(crit, monkeypatch, T, mitm):
     """WFL_LATTICE_FUSED_BADXCD=1 makes the gate kernel report every utterance as swept on two XCDs (what a different
     workgroup-to-XCD dealing would look like): no gradient workgroup may touch them, the certificate sends them to the
     log-domain sweeps and wfl_lattice_grad_rest writes their rows -- same loss, same gradient."""
     tr = crit["transducer"]
+    monkeypatch.setenv("WFL_LATTICE_MITM", mitm)
     tokens, g2i, x, tg = _word_piece_batch(5, T, 12)
     m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
 
@@ -1401,13 +1405,16 @@ def _sweep_formats(loss, B, T):
     return num.alpha[off.value:off.value + B].view(torch.int32).cpu().tolist()
 
 
-@pytest.mark.parametrize("B,T", [(5, 64), (7, 160), (3, 400)])
+@pytest.mark.parametrize("B,T", [(5, 64), (7, 160), (3, 400), (5, 65), (6, 79), (4, 97), (7, 203), (3, 250), (2, 401),
+                                 (3, 175), (4, 72), (4, 137), (4, 119)])
 def test_transducer_sweeps_that_meet_in_the_middle_equal_the_full_sweeps(crit, monkeypatch, B, T):
-    """csrc/lattice_kernels.hip run_chain_prob: with whole 16-frame chunks the two sweeps of an utterance store their own
-    vector up to the middle slot and state occupancies (floats, normalised by the Z formed at the middle) beyond it,
-    reading the partner's vectors from L2 -- WFL_LATTICE_MITM=0 keeps both vectors everywhere.  The forward sweep's
-    arithmetic is untouched: the loss bit for bit; the gradient to the rounding of float occupancies; the formats say
-    which one ran.  A T that is not a multiple of 16 keeps the full sweeps."""
+    """csrc/lattice_kernels.hip run_chain_prob: from 64 frames on the two sweeps of an utterance store their own vector up
+    to the middle slot and state occupancies (floats, normalised by the Z formed at the middle) beyond it, reading the
+    partner's vectors from L2 -- WFL_LATTICE_MITM=0 keeps both vectors everywhere.  The forward sweep's arithmetic is
+    untouched: the loss bit for bit; the gradient to the rounding of float occupancies; the formats say which one ran.
+    T not a multiple of 16: the sweeps' chunk boundaries differ by T % 16, the slots both hold are converted at the
+    forward sweep's crossing and each sweep's last, partial chunk after it was stored (gamma_rows).  Shorter
+    utterances keep the full sweeps."""
     tr = crit["transducer"]
     tokens, g2i, x, tg = _word_piece_batch(B, T, 17)
     m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
@@ -1421,14 +1428,16 @@ def test_transducer_sweeps_that_meet_in_the_middle_equal_the_full_sweeps(crit, m
 
     monkeypatch.setenv("WFL_LATTICE_MITM", "0")
     ref = run()
-    monkeypatch.setenv("WFL_LATTICE_MITM", "1")
+    monkeypatch.setenv("WFL_LATTICE_MITM", "2")  # (from 64 frames on; by default from 320)
     got = run()
     assert ref[2] == [1] * B and got[2] == [2] * B, (ref[2], got[2])
+    monkeypatch.delenv("WFL_LATTICE_MITM")
+    assert run()[2] == [2 if T >= 320 else 1] * B
     assert got[0] == ref[0]
     close(got[1], ref[1].cpu().numpy(), rtol=1e-4, atol=1e-7, msg="occupancies")
-    xo, to = x[:, :T - 3].contiguous(), tg
+    xo = x[:, :63].contiguous()
     xi = xo.clone().requires_grad_(True)
-    assert _sweep_formats(m(xi, to), B, T - 3) == [1] * B
+    assert _sweep_formats(m(xi, tg), B, 63) == [1] * B
 
 
 def test_transducer_equals_ctc(crit, lit):
