@@ -882,15 +882,27 @@ __device__ __forceinline__ double block_reduce_sum_f64(double v, double* red) {
 
 // Is utterance `u` one for the probability-domain chains?  (block-uniform; both directions must agree, so both
 // degrees are checked by both workgroups)
+// Epsilon arcs (back-off transition models): at most kEpsDeg into and out of a state -- they live in the owning thread's
+// registers -- in at most kProbMaxLev topological levels (a barrier per level and frame: run_chain_prob, eps_closure).
+constexpr int kEpsDeg = 4;
+constexpr int kProbMaxLev = 8;
 __device__ __forceinline__ bool prob_eligible(const UttView& u, int NT) {  // NT: threads of the CHAIN workgroups
-  int bad = (u.Q > NT) | (u.E > 0) | (u.nlev > 1);
+  int bad = (u.Q > NT) | (u.nlev > kProbMaxLev);
   if (!bad)
-    for (int q = threadIdx.x; q < u.Q; q += blockDim.x)
+    for (int q = threadIdx.x; q < u.Q; q += blockDim.x) {
       bad |= (u.in_ptr[q + 1] - u.in_ptr[q] > kLeanDeg) | (u.out_ptr[q + 1] - u.out_ptr[q] > kLeanDeg);
+      if (u.E > 0) bad |= (u.ein_ptr[q + 1] - u.ein_ptr[q] > kEpsDeg) | (u.eout_ptr[q + 1] - u.eout_ptr[q] > kEpsDeg);
+    }
   return !__syncthreads_or(bad);
 }
+// the factor of an epsilon arc in the probability domain (sweeps, certificate and gradient form the same float)
+__device__ __forceinline__ double eps_factor(const UttView& u, const float* __restrict__ weights, int e) {
+  float w = u.eps_w[e];
+  const int wid = u.eps_wid[e];
+  if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+  return (double)fast_exp(nan_to_neg(w));
+}
 
-// What a sweep needs of its partner (the other direction of the same utterance, same launch) to meet it in the middle.
 // Slots s_lo .. s_lo + cnt - 1 (cnt <= 16), of which BOTH sweeps of an utterance have stored their vectors (doubles, rows
 // of Q), as occupancies (floats) into the first half of `dst`'s rows -- this sweep's own rows or the partner's:
 // everything is read first (the floats of a row overwrite other threads' doubles of the same row), eight slots at a
@@ -916,6 +928,7 @@ __device__ __noinline__ void mitm_gamma_rows(const double* own, const double* ot
     }
   }
 }
+// What a sweep needs of its partner (the other direction of the same utterance, same launch) to meet it in the middle.
 struct MitmArgs {
   int req = 0;                       // the launch asks for it (wfl_lattice_forward_grad, T a multiple of 16, ...)
   double* oth = nullptr;             // the partner's score rows of this utterance ([T+1][Q] doubles)
@@ -988,7 +1001,7 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     else
       band_ok = 0;
   }
-  const bool banded = BAND && NT == 128 && Q <= 64 && (Kmax & 3) == 0 && Kmax <= 64 && __syncthreads_and(band_ok);
+  const bool banded = BAND && NT == 128 && Q <= 64 && (Kmax & 3) == 0 && Kmax <= 64 && __syncthreads_and(band_ok && u.E == 0);
   // "uniform-label" acceptors: every arc INTO a state carries the same emission column (CTC-like chains, force
   // alignment, token-level alignment graphs: the label belongs to the destination state).  Then the frame's factor is
   // applied once per state by its owner -- after the sum (alpha), or before publishing (beta: the owner publishes
@@ -1000,7 +1013,30 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
     if (i0 < i1) my_slot = u.arc_slot[i0];
     for (int k = i0 + 1; k < i1; ++k) uni_ok &= u.arc_slot[k] == my_slot;
   }
-  const bool uniform = __builtin_amdgcn_readfirstlane(__syncthreads_and(uni_ok)) != 0;
+  const bool uniform = __builtin_amdgcn_readfirstlane(__syncthreads_and(uni_ok && u.E == 0)) != 0;
+  // ---- epsilon arcs into (forward) / out of (backward) this thread's state, in registers; states are numbered level by
+  // level (u.lvl_ptr), an epsilon arc leads from a lower level to a higher one.  After the labelled arcs of a frame the
+  // levels are closed one after the other, a barrier each (eps_closure): the same order as run_chain's closure.
+  const int nlev = u.nlev;
+  const bool eps_on = u.E > 0 && nlev > 1;  // (block-uniform)
+  int esrc[kEpsDeg], my_lev = 0, ne = 0;
+  double ewf[kEpsDeg];
+#pragma unroll
+  for (int i = 0; i < kEpsDeg; ++i) esrc[i] = 0, ewf[i] = 0.0;
+  if (eps_on && tid < Q) {
+    const int32_t* eptr = DIR == 0 ? u.ein_ptr : u.eout_ptr;
+    const int e0 = eptr[tid], e1 = eptr[tid + 1];
+    ne = e1 - e0;
+#pragma unroll
+    for (int i = 0; i < kEpsDeg; ++i)
+      if (e0 + i < e1) {
+        const int e = DIR == 0 ? e0 + i : u.eout_arc[e0 + i];
+        esrc[i] = DIR == 0 ? u.eps_src[e] : u.eps_dst[e];
+        ewf[i] = eps_factor(u, weights, e);
+      }
+    for (int l = 1; l < nlev; ++l)
+      if (tid >= u.lvl_ptr[l]) my_lev = l;
+  }
   const bool wave_live = __builtin_amdgcn_readfirstlane((int)((tid & ~63) < Q)) != 0;  // (waves without a state only take part in the barriers)
 
   const int t_first = DIR == 0 ? 0 : T;
@@ -1008,10 +1044,27 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
   if (tid < Q) p = (DIR == 0 ? u.start_w[tid] : u.accept_w[tid]) > WFL_NEG_INF ? 1.0 : 0.0;  // (boundary weights are 0 / -inf)
   double cum = 0.0;  // log2 of everything factored out of the stored probabilities so far
   double* cur = (t_first & 1) ? lbuf1 : lbuf0;
-  if (tid < Q) {
-    cur[tid] = p;
-    out[u.ab_base + (int64_t)t_first * Q + tid] = p;
+  // `vec` holds the frame's vector after its labelled arcs, this thread's entry = p, a barrier since: level by level,
+  // p += sum over the epsilon arcs of vec[other end] x factor.  Ends behind a barrier.  (workgroup-wide)
+  auto eps_closure = [&](double* vec) {
+    for (int step = 1; step < nlev; ++step) {
+      const int lev = DIR == 0 ? step : nlev - 1 - step;
+      if (my_lev == lev && ne > 0) {
+        double sum = p;
+#pragma unroll
+        for (int k = 0; k < kEpsDeg; ++k) sum = fma(vec[esrc[k]], ewf[k], sum);
+        p = sum;
+        vec[tid] = p;
+      }
+      lds_barrier();
+    }
+  };
+  if (tid < Q) cur[tid] = p;
+  if (eps_on) {
+    lds_barrier();
+    eps_closure(cur);
   }
+  if (tid < Q) out[u.ab_base + (int64_t)t_first * Q + tid] = p;
   if (tid == 0) offs[t_first] = 0.0;
 
   if constexpr (BAND) if (banded) {
@@ -1357,11 +1410,15 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
             }
             p = acc0 + acc1;
             to[tid] = p;
+            if (eps_on) {  // (block-uniform; LDS and barriers only -- no memory operation on either side of the test)
+              lds_barrier();
+              eps_closure(to);
+            }
             WFL_SWEEP_STORE(po, p);
             po += pstep;
 #pragma unroll
             for (int k = 0; k < DEG; ++k) c[k] = cn[k];
-            lds_barrier();
+            if (!eps_on) lds_barrier();
           }
           hand_over(PathUnrolled{});
           return;
@@ -1380,15 +1437,17 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
             acc1 = fma(ps[k + 1], c[k + 1], acc1);
           }
           p = acc0 + acc1;
-          if (tid < Q) {
-            to[tid] = p;
-            WFL_SWEEP_STORE(orow + tid, p);
+          if (tid < Q) to[tid] = p;
+          if (eps_on) {
+            lds_barrier();
+            eps_closure(to);
           }
+          if (tid < Q) WFL_SWEEP_STORE(orow + tid, p);
 #pragma unroll
           for (int k = 0; k < DEG; ++k) c[k] = cn[k];
           orow = DIR == 0 ? orow + Q : orow - Q;
           par ^= 1;
-          lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
+          if (!eps_on) lds_barrier();  // (not __syncthreads: the stores of this frame's scores need not have landed)
         }
         hand_over(PathLoop{});
       };
@@ -1547,7 +1606,11 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
 #endif
       if constexpr (!LIVE) {  // only the barriers (the frame loops below: one per frame, one more in front of beta's)
         if (DIR == 1 && uniform) lds_barrier();
-        for (int i = 0; i < n; ++i) lds_barrier();
+        for (int i = 0; i < n; ++i) {
+          lds_barrier();
+          if (eps_on)
+            for (int step = 1; step < nlev; ++step) lds_barrier();  // (eps_closure's)
+        }
         hand_over(PathIdle{});
       } else if constexpr (SEL == 0)
         frames_uniform(std::integral_constant<int, 2>{});
@@ -1790,7 +1853,8 @@ __global__ void __launch_bounds__(MAXT)
 __global__ void __launch_bounds__(256)
     prob_certify_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T,
                         const float* __restrict__ alpha, float* __restrict__ beta, int64_t tail, int nch1, int chain_nt,
-                        int pub) {  // pub: the sweeps were prob_chain_pub_kernel's (they may have met in the middle)
+                        int pub,  // pub: the sweeps were prob_chain_pub_kernel's (they may have met in the middle)
+                        const float* __restrict__ weights) {
   // grid (B, kCertSplit): every wave takes the checked slots s = wave index, + number of waves, ... on its own
   // (wave-level reductions only); a wave that finds a violation raises the utterance's verdict (cleared by the beta
   // sweep of prob_chain_kernel before it started)
@@ -1839,10 +1903,19 @@ __global__ void __launch_bounds__(256)
     if (bad && lane == 0) *verdict = 1.0;
     return;
   }
+  // With epsilon arcs a path may pass through several states of a slot; it ARRIVES in exactly one -- by a labelled arc,
+  // or at the start: alpha before the closure, i.e. minus what the epsilon arcs into the state brought (a positive
+  // double minus part of itself; the back-off state, all of whose mass comes that way, leaves rounding dust).
+  const bool eps = u.E > 0;
   for (int c = w0; c < nchk; c += nw) {
     const int t = min(c * 8, T);
     double s = 0.0;
-    for (int q = lane; q < Q; q += 64) s = fma(pa[(int64_t)t * Q + q], pb[(int64_t)t * Q + q], s);
+    for (int q = lane; q < Q; q += 64) {
+      double a = pa[(int64_t)t * Q + q];
+      if (eps)
+        for (int e = u.ein_ptr[q]; e < u.ein_ptr[q + 1]; ++e) a -= pa[(int64_t)t * Q + u.eps_src[e]] * eps_factor(u, weights, e);
+      s = fma(a, pb[(int64_t)t * Q + q], s);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const double dev = (s > 0.0 && s < 1.0e300) ? fabs(log2(s) + offs_a[t] + offs_b[t] - za) : 1.0e9;
@@ -2645,6 +2718,8 @@ __global__ void __launch_bounds__(256)
           // gamma_t(arc) = p_alpha[t][src] wf f_t[slot] p_beta[t+1][dst] * 2^(offs_a[t] + offs_b[t+1] + (r_t + wref) log2e - log2 Z)
           if (tid < nr)
             corr_d[tid] = exp2(offs_a[sl] + offs_b[sl + 1] + ((double)rmaxp[sl] + (double)wref) * kLog2e_d - zd);
+          // an epsilon arc at slot t: p_alpha[t][src] factor p_beta[t][dst] * 2^(offs_a[t] + offs_b[t] - log2 Z)
+          if (E > 0) corr_eps[tid] = exp2(offs_a[sl] + offs_b[sl] - zd);
         } else {
           const double oa = offs_a[sl == 0 ? 0 : 1 + (sl - 1) / R];
           corr_eps[tid] = oa + offs_b[sl == T ? 0 : 1 + (T - 1 - sl) / R] - zd;
@@ -2715,12 +2790,17 @@ __global__ void __launch_bounds__(256)
           if (wsum != 0.f) dwacc[a] += wsum;  // this thread owns dwacc[a]
         }
       }
-      if (dW && E > 0 && !prob) {  // (probability-domain utterances have no epsilon arcs)
+      if (dW && E > 0) {
         const int nslots = nr + ((ts0 + nr == T) ? 1 : 0);  // epsilon slots t = ts0 .. (T included once)
         for (int i = tid; i < nslots * E; i += NT) {
           const int r = i / E, e = i - r * E;
           const int wid = u.eps_wid[e];
           if (wid < 0) continue;
+          if (prob) {
+            const double g = ald[r * d.max_states + u.eps_src[e]] * bed[r * d.max_states + u.eps_dst[e]] * (corr_eps[r] * eps_factor(u, weights, e));
+            if (g != 0.0) atomicAdd(&dwacc[A + e], (float)g);
+            continue;
+          }
           const float w = u.eps_w[e] + (weights ? nan_to_neg(weights[wid]) : 0.f);
           const float v = (float)(ald[r * d.max_states + u.eps_src[e]] + bed[r * d.max_states + u.eps_dst[e]] + (corr_eps[r] + (double)w));
           if (v > WFL_NEG_INF) atomicAdd(&dwacc[A + e], fast_exp(v));
@@ -3454,7 +3534,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
         launch_prob(prob_chain_kernel<1024>);
       if (beta)
         hipLaunchKernelGGL(prob_certify_kernel, dim3((unsigned)d->B, 8u), dim3(256), 0, (hipStream_t)stream, *d, ints,
-                           floats, T, alpha, beta, tail, nch1, nt, (g && g->done) ? 1 : 0);
+                           floats, T, alpha, beta, tail, nch1, nt, (g && g->done) ? 1 : 0, weights);
     }
     // ... then the log-domain sweeps of the rest (and of utterances whose two sweeps disagree: the certificate)
     hipLaunchKernelGGL(k, grid, dim3(nt), lds, (hipStream_t)stream, *d, ints, floats, xg, T, rpc, weights, alpha,

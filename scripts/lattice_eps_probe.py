@@ -27,4 +27,10 @@ for _ in range(20):
     st = E.lattice_forward(x, pack, weights=params, need_beta=True)
 e1.record()
 torch.cuda.synchronize()
+import ctypes
+from gtn_applications_amd import _native as NL
+off = ctypes.c_int64()
+NL.check(NL.lib.wfl_lattice_formats_offset(ctypes.byref(pack.desc), T, ctypes.byref(off)))
+fm = st.alpha[off.value:off.value + B].view(torch.int32).cpu().tolist()
+print("formats (0 log domain, 1 probability domain):", sorted(set(fm)), "probability-domain utterances:", fm.count(1), "of", B)
 print(f"B={B}: states {pack.desc.max_states} arcs {pack.desc.max_arcs} eps {pack.desc.max_eps}: lattice_forward {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call")

@@ -160,6 +160,54 @@ def test_ngram_transitions_at_the_reference_benchmark_size(kind, ngram):
         assert got[b].tolist() == [k for k, _ in itertools.groupby(frames[b].tolist()) if k != blank], (name, b)
 
 
+def _numerator_formats(loss, B, T):
+    """fmt[b] of the numerator sweeps behind a Transducer loss: 0 log domain, 1 probability domain"""
+    import ctypes
+
+    from gtn_applications_amd import _native as N
+
+    num = loss.grad_fn.aux[2]
+    off = ctypes.c_int64()
+    N.check(N.lib.wfl_lattice_formats_offset(ctypes.byref(num.pack.desc), T, ctypes.byref(off)))
+    torch.cuda.synchronize()
+    return num.alpha[off.value:off.value + B].view(torch.int32).cpu().tolist()
+
+
+@pytest.mark.parametrize("kind", ["ctc", "asg"])
+def test_epsilon_acceptors_are_swept_in_the_probability_domain(kind):
+    """csrc/lattice_kernels.hip run_chain_prob / eps_closure: the bigram model's alignment acceptors as the reference
+    builds them (transducer.py:262-290: alignments o make_transitions_graph(2, N), epsilon arcs into and out of the
+    back-off state) through the GENERAL lattice path -- TransducerLossFunction.apply, none of the module's short cuts.
+    Their numerator sweeps run in the fp64 probability domain with an in-frame epsilon closure (formats say so), pass
+    the certificate (alpha before the closure x beta = Z at every 8th slot), and loss, emission gradient and
+    transition-parameter gradient -- epsilon arcs' included -- meet the float64 epsilon-aware recurrence."""
+    from gtn_applications_amd.criterions import transducer as TR
+
+    N, T, L, B = 81, 250, 44, 8
+    rs = np.random.RandomState(300 + (kind == "asg"))
+    kw = dict(blank="optional", allow_repeats=False) if kind == "ctc" else {}
+    C = N + (1 if kind == "ctc" else 0)
+    x = rs.randn(B, T, C).astype(np.float32)
+    targets = rs.randint(0, N, size=(B, L)).tolist()
+    crit = TR.Transducer([(i,) for i in range(N)], {i: i for i in range(N)}, ngram=2, reduction="mean", **kw)
+    params = (0.3 * rs.randn(crit.transition_params.numel())).astype(np.float32)
+    want_loss, _, want_dx, want_dp, counts = _oracle(crit, x, targets, params)
+    with torch.no_grad():
+        crit.transition_params.copy_(torch.from_numpy(params))
+    crit.cuda()
+    crit.transition_params.grad = None
+    crit.tokens.arc_sort(True)
+    xg = torch.from_numpy(x).cuda().requires_grad_(True)
+    loss = TR.TransducerLossFunction.apply(xg, [torch.tensor(t) for t in targets], crit.tokens, crit.lexicon,
+                                           crit.transition_params, crit.transitions, crit.reduction)
+    assert _numerator_formats(loss, B, T) == [1] * B
+    loss.backward()
+    name = f"ngram2_{kind}_general"
+    check(name + "_loss", [loss.item()], [want_loss], 0.0)
+    check(name + "_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / (L * B))
+    check_dparams(name + "_dparams", crit.transition_params.grad.cpu().numpy(), want_dp, counts, 1.0 / (L * B))
+
+
 def test_backoff_transitions_at_benchmark_length(golden_dir):
     """tests/transducer_test.py:534-566's pruned back-off model (8 nodes, 36 arcs, epsilon back-off arcs between inner
     nodes: in-frame epsilon closure over several levels) at T = 250, B = 16, with targets of its three tokens."""
