@@ -394,6 +394,21 @@ __device__ __forceinline__ double row16_sum(double v) {
   v += __shfl_xor(v, 8, 16);
   return v;
 }
+// the same through DPP (no LDS crossbar round trips: the shuffles above are eight dependent ds_bpermute): every lane of
+// the row receives the row's sum.  quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror -- after each step the
+// partial sums are uniform over twice as many lanes, whichever lane of the other group a lane reads.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double row16_sum_dpp(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  return v;
+}
 __device__ __forceinline__ int row16_min(int v) {
   v = min(v, __shfl_xor(v, 1, 16));
   v = min(v, __shfl_xor(v, 2, 16));
@@ -1772,6 +1787,358 @@ __device__ __forceinline__ void run_chain_prob(const wfl_lattice_desc& d, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stage 2, probability domain, ANY acceptor that fits LDS (round 6).  What run_chain_prob does not take -- states
+// with more than kLeanDeg labelled or kEpsDeg epsilon arcs on a side, more than kProbMaxLev closure levels, more states than
+// threads: the transition models themselves (the DENOMINATOR of a Transducer with `transitions=`: 8 states and 36 arcs
+// for the reference's pruned back-off model, thousands of arcs for a word-piece n-gram) -- went to the log-domain
+// run_chain: a log-add per arc and a closure whose levels are chains of double-precision exp / log, 2.8 us a frame
+// for the 8-state model.  Here the same acceptor layout in LDS (arcs in this direction's CSR order, epsilon arcs,
+// levels), double PROBABILITIES, one multiply-add per arc:
+//   * a state with at most kProbRowDeg arcs is relaxed by one thread, the others by a row of 16 lanes each (a lane takes
+//     every 16th arc, the row meets through row16_sum);
+//   * epsilon closure level by level as in run_chain, an LDS-only barrier per level;
+//   * offsets per slot in log2 units and the power-of-two renormalisation of run_chain_prob (at every chunk), the same
+//     stored format (fmt[b] = kFmtProb), so the certificate and the gradient kernels read it like any other.
+// Not tuned beyond that: no register-resident arcs, no straight-line chunks.
+// ------------------------------------------------------------------------------------------------
+constexpr int kProbRowDeg = 6;  // most labelled arcs a single thread takes
+constexpr int kProbEpsDeg = 8;  // most epsilon arcs a single thread takes
+// (inlined into its kernel: a function that is really called knows nothing of its caller's launch bounds and is compiled
+// for 1024 threads, i.e. 128 VGPRs -- 127 spill instructions, some of them in the frame loop, where a scratch load
+// waits for the frame's global stores)
+template <int DIR>
+__device__ __forceinline__ void run_chain_prob_general_body(const wfl_lattice_desc& d, const UttView& u, char* smem, int T, int R,
+                                                    const float* __restrict__ fg, const float* __restrict__ rmax,
+                                                    const float* __restrict__ weights, double* __restrict__ out,
+                                                    float* __restrict__ logz, int b, double* __restrict__ offs,
+                                                    double* __restrict__ z64, float* __restrict__ wref_out) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int Q = u.Q, A = u.A, E = u.E, nlev = u.nlev, Kmax = d.max_labels;
+  // (carved like chain_kernel's ChainLds: chain_lds_bytes has room for exactly this)
+  char* sp = smem;
+  int2* arcs = (int2*)sp;
+  sp += (size_t)d.max_arcs * 8;
+  int2* eps = (int2*)sp;
+  sp += (size_t)d.max_eps * 8;
+  int* ptr = (int*)sp;
+  sp += (size_t)(d.max_states + 1) * 4;
+  int* eptr = (int*)sp;
+  sp += (size_t)(d.max_states + 1) * 4;
+  double* buf0 = (double*)sp;
+  sp += (size_t)d.max_states * 8;
+  double* buf1 = (double*)sp;
+  sp += (size_t)d.max_states * 8;
+  float* rows = (float*)sp;
+  sp += (size_t)2 * R * Kmax * 4;
+  float* red = (float*)sp;
+  sp += 64 * 4;
+  int* lvl = (int*)sp;
+  sp += (size_t)(d.max_levels + 1) * 4;
+  int* heavy = (int*)sp;  // [Q] states relaxed by a row, heavy[Q] = their count; then the same for the closure
+  sp += (size_t)(d.max_states + 1) * 4;
+  float* refs = (float*)sp;  // [2][R] per-frame references of the chunk's rows
+
+  // ---- the reference of the labelled arcs' weights (every frame multiplies by e^wref once more: part of the offset)
+  float wmx = WFL_NEG_INF;
+  for (int k = tid; k < A; k += NT) {
+    float w = u.arc_w[k];
+    const int wid = u.arc_wid[k];
+    if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+    wmx = fmaxf(wmx, nan_to_neg(w));
+  }
+  float wref = block_reduce_max(wmx, red);
+  if (!(wref > WFL_NEG_INF)) wref = 0.f;
+  if (wref_out && tid == 0) wref_out[b] = wref;
+  // ---- stage the acceptor in this direction's CSR order; weights as factors (the gradient kernel forms the same floats)
+  for (int k = tid; k < A; k += NT) {
+    const int a = DIR == 0 ? k : u.out_arc[k];
+    const int other = DIR == 0 ? u.arc_src[a] : u.arc_dst[a];
+    float w = u.arc_w[a];
+    const int wid = u.arc_wid[a];
+    if (weights && wid >= 0) w += nan_to_neg(weights[wid]);
+    arcs[k] = make_int2(other | (u.arc_slot[a] << 16), __float_as_int(fast_exp(nan_to_neg(w) - wref)));
+  }
+  for (int k = tid; k < E; k += NT) {
+    const int e = DIR == 0 ? k : u.eout_arc[k];
+    eps[k] = make_int2(DIR == 0 ? u.eps_src[e] : u.eps_dst[e], __float_as_int((float)eps_factor(u, weights, e)));
+  }
+  for (int q = tid; q <= Q; q += NT) {
+    ptr[q] = DIR == 0 ? u.in_ptr[q] : u.out_ptr[q];
+    eptr[q] = DIR == 0 ? u.ein_ptr[q] : u.eout_ptr[q];
+  }
+  for (int l = tid; l <= nlev; l += NT) lvl[l] = u.lvl_ptr[l];
+  if (tid == 0) heavy[Q] = 0;
+  __syncthreads();
+  for (int q = tid; q < Q; q += NT)
+    if (ptr[q + 1] - ptr[q] > kProbRowDeg) heavy[atomicAdd(&heavy[Q], 1)] = q;
+  int eh = 0;
+  for (int q = tid; q < Q; q += NT) eh |= (eptr[q + 1] - eptr[q]) > kProbEpsDeg;
+  const bool eps_heavy = __syncthreads_or(eh) != 0;
+  const int n_heavy = heavy[Q];
+  const int grow = tid >> 4, nrows = NT >> 4, r16 = tid & 15;
+  // The common case in registers: this thread's own state (q = tid) with its few arcs, this row's first state of many
+  // arcs with four arcs per lane, this thread's epsilon arcs and level -- in the frame loop they cost one round of
+  // LDS reads (the vector and the row) instead of a chain of four (list -> pointers -> arcs -> vector).  What does
+  // not fit (more states than threads, more rows than the workgroup has, arcs beyond 64 a row) takes the loops over
+  // the LDS copy.  (absent arcs: factor 0, entry 0)
+  const int2 none = make_int2(0, 0);
+  const int lk0 = tid < Q ? ptr[tid] : 0, lk1 = tid < Q ? ptr[tid + 1] : 0;
+  const bool light0 = tid < Q && lk1 - lk0 <= kProbRowDeg;
+  int2 la[kProbRowDeg];
+#pragma unroll
+  for (int i = 0; i < kProbRowDeg; ++i) la[i] = (light0 && lk0 + i < lk1) ? arcs[lk0 + i] : none;
+  const int hq0 = grow < n_heavy ? heavy[grow] : -1;
+  const int hk0 = hq0 >= 0 ? ptr[hq0] : 0, hk1 = hq0 >= 0 ? ptr[hq0 + 1] : 0;
+  int2 ha[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ha[j] = hk0 + r16 + 16 * j < hk1 ? arcs[hk0 + r16 + 16 * j] : none;
+  const int ek0 = tid < Q ? eptr[tid] : 0, ek1 = tid < Q ? eptr[tid + 1] : 0;
+  const bool elight0 = ek1 > ek0 && ek1 - ek0 <= kProbEpsDeg;
+  int2 ea[kProbEpsDeg];
+#pragma unroll
+  for (int i = 0; i < kProbEpsDeg; ++i) ea[i] = (elight0 && ek0 + i < ek1) ? eps[ek0 + i] : none;
+  // (no wave-uniform bounds on those slots: a test between two groups of LDS reads makes each group its own round trip --
+  // measured: the relaxation 740 -> 1200-1800 cycles a frame)
+  const int wh = __builtin_amdgcn_readfirstlane(wave_all_max_int(hq0 >= 0 ? 1 : 0));
+  const bool eheavy0 = ek1 - ek0 > kProbEpsDeg;  // this thread's state is closed by a row: its value is read back
+  int my_lev = 0;
+  for (int l = 1; l < nlev; ++l)
+    if (tid >= lvl[l]) my_lev = l;
+  auto term = [](const double* vec, const float* row, int2 a) {
+    return vec[a.x & 0xffff] * ((double)__int_as_float(a.y) * (double)row[(unsigned)a.x >> 16]);
+  };
+
+  // epsilon closure of `vals` (run_chain's order of levels); enters and ends behind a barrier
+  // (`mine`: the value of this thread's own state q = tid, kept in a register across the levels)
+  auto closure = [&](double* vals, double& mine) {
+    for (int step = 1; step < nlev; ++step) {
+      const int lev = DIR == 0 ? step : nlev - 1 - step;
+      if (elight0 && my_lev == lev) {
+        double v0 = mine, v1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < kProbEpsDeg; i += 2) {
+          v0 = fma(vals[ea[i].x], (double)__int_as_float(ea[i].y), v0);
+          v1 = fma(vals[ea[i + 1].x], (double)__int_as_float(ea[i + 1].y), v1);
+        }
+        mine = v0 + v1;
+        vals[tid] = mine;
+      }
+      for (int q = max(lvl[lev], NT) + tid; q < lvl[lev + 1]; q += NT) {  // (more states than threads)
+        const int k0 = eptr[q], k1 = eptr[q + 1];
+        if (k1 - k0 > kProbEpsDeg || k1 == k0) continue;
+        double v = vals[q];
+        for (int k = k0; k < k1; ++k) v = fma(vals[eps[k].x], (double)__int_as_float(eps[k].y), v);
+        vals[q] = v;
+      }
+      if (eps_heavy) {
+        for (int q0 = lvl[lev]; q0 < lvl[lev + 1]; q0 += nrows) {  // (uniform trip count: the rows of a wave meet)
+          const int q = q0 + grow;
+          const bool on = q < lvl[lev + 1];
+          const int k0 = on ? eptr[q] : 0, k1 = on ? eptr[q + 1] : 0;
+          double part = 0.0;
+          if (k1 - k0 > kProbEpsDeg)
+            for (int k = k0 + r16; k < k1; k += 16) part = fma(vals[eps[k].x], (double)__int_as_float(eps[k].y), part);
+          part = row16_sum_dpp(part);
+          if (k1 - k0 > kProbEpsDeg && r16 == 0) vals[q] += part;
+        }
+      }
+      lds_barrier();
+    }
+    if (eheavy0 && nlev > 1) mine = vals[tid];
+  };
+
+  const int t_first = DIR == 0 ? 0 : T;
+  double* cur = (t_first & 1) ? buf1 : buf0;
+  for (int q = tid; q < Q; q += NT) cur[q] = (DIR == 0 ? u.start_w[q] : u.accept_w[q]) > WFL_NEG_INF ? 1.0 : 0.0;
+  lds_barrier();
+  {
+    double mine = tid < Q ? cur[tid] : 0.0;
+    closure(cur, mine);
+  }
+  for (int q = tid; q < Q; q += NT) out[u.ab_base + (int64_t)t_first * Q + q] = cur[q];
+  if (tid == 0) offs[t_first] = 0.0;
+  double cum = 0.0;  // log2 of everything factored out of the stored probabilities so far
+
+  const int nchunks = (T + R - 1) / R;
+  auto chunk_frames = [&](int c, int& f0, int& n) {  // frames [f0, f0 + n) in ascending order
+    const int s0 = c * R;
+    n = min(R, T - s0);
+    f0 = DIR == 0 ? s0 : T - s0 - n;
+  };
+  if (T > 0) {
+    int f0, n;
+    chunk_frames(0, f0, n);
+    const float* src = fg + u.xg_base + (int64_t)f0 * Kmax;
+    for (int e = tid; e < n * Kmax; e += NT) rows[e] = src[e];
+    if (tid < n) refs[tid] = rmax[(int64_t)b * T + f0 + tid];
+  }
+  __syncthreads();
+#ifdef WFL_GENERAL_TIMERS
+  long long gen_t[6] = {0, 0, 0, 0, 0, 0};
+#define GEN_T(v) const long long v = clock64()
+#define GEN_ADD(k, a, b_) gen_t[k] += (b_) - (a)
+#else
+#define GEN_T(v)
+#define GEN_ADD(k, a, b_)
+#endif
+  for (int c = 0; c < nchunks; ++c) {
+    GEN_T(gc0);
+    int f0, n;
+    chunk_frames(c, f0, n);
+    const float* tile = rows + (size_t)(c & 1) * R * Kmax;
+    const float* rtile = refs + (size_t)(c & 1) * R;
+    float pre[kPre], rpre = 0.f;
+    int pf0 = 0, pn = 0;
+    if (c + 1 < nchunks) {  // the next chunk's rows: HBM -> registers now, -> LDS behind this chunk's frames
+      chunk_frames(c + 1, pf0, pn);
+      const float* src = fg + u.xg_base + (int64_t)pf0 * Kmax;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) pre[j] = src[e];
+      }
+      if (tid < pn) rpre = rmax[(int64_t)b * T + pf0 + tid];
+    }
+    if (c > 0) {  // power-of-two renormalisation of the vector the chunk starts from (exact)
+      double* fromb = ((DIR == 0 ? f0 : f0 + n) & 1) ? buf1 : buf0;
+      int ex = -(1 << 30);
+      for (int q = tid; q < Q; q += NT)
+        if (fromb[q] > 0.0) ex = max(ex, __builtin_amdgcn_frexp_exp(fromb[q]) - 1);
+      const float emf = block_reduce_max((float)ex, red);  // (|ex| < 2^24: exact as a float)
+      if (emf > -1.0e9f && emf < 2000.f) {
+        const int emax = (int)emf;
+        for (int q = tid; q < Q; q += NT) fromb[q] = ldexp(fromb[q], -emax);
+        cum += (double)emax;
+      }
+      __syncthreads();
+    }
+    for (int i = 0; i < n; ++i) {
+      // forward: consume frame t, produce slot t + 1.  backward: consume frame t, produce slot t.
+      const int t = DIR == 0 ? f0 + i : f0 + n - 1 - i;
+      const int slot_from = DIR == 0 ? t : t + 1, slot_to = DIR == 0 ? t + 1 : t;
+      const double* from = (slot_from & 1) ? buf1 : buf0;
+      double* to = (slot_to & 1) ? buf1 : buf0;
+      const float* row = tile + (size_t)(t - f0) * Kmax;
+      GEN_T(g0);
+      double mine = 0.0;
+      if (light0) {
+        double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < kProbRowDeg; i += 2) v0 += term(from, row, la[i]), v1 += term(from, row, la[i + 1]);
+        mine = v0 + v1;
+        to[tid] = mine;
+      }
+      if (wh > 0) {  // (wave-uniform: some row of this wave has a state)
+        double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) v0 += term(from, row, ha[j]), v1 += term(from, row, ha[j + 1]);
+        for (int k = hk0 + r16 + 64; k < hk1; k += 16) v0 += term(from, row, arcs[k]);
+        const double v = row16_sum_dpp(v0 + v1);
+        if (hq0 >= 0 && r16 == 0) to[hq0] = v;
+      }
+      for (int q = tid + NT; q < Q; q += NT) {  // (more states than threads)
+        const int k0 = ptr[q], k1 = ptr[q + 1];
+        if (k1 - k0 > kProbRowDeg) continue;
+        double v0 = 0.0, v1 = 0.0;
+        int k = k0;
+        for (; k + 1 < k1; k += 2) {
+          const int2 a0 = arcs[k], a1 = arcs[k + 1];
+          v0 = fma(from[a0.x & 0xffff], (double)__int_as_float(a0.y) * (double)row[(unsigned)a0.x >> 16], v0);
+          v1 = fma(from[a1.x & 0xffff], (double)__int_as_float(a1.y) * (double)row[(unsigned)a1.x >> 16], v1);
+        }
+        if (k < k1) {
+          const int2 a0 = arcs[k];
+          v0 = fma(from[a0.x & 0xffff], (double)__int_as_float(a0.y) * (double)row[(unsigned)a0.x >> 16], v0);
+        }
+        to[q] = v0 + v1;
+      }
+      for (int h0 = nrows; h0 < n_heavy; h0 += nrows) {  // (more states of many arcs than rows; uniform trip count)
+        const int hq = h0 + grow;
+        const int q = hq < n_heavy ? heavy[hq] : -1;
+        const int k0 = q >= 0 ? ptr[q] : 0, k1 = q >= 0 ? ptr[q + 1] : 0;
+        double v0 = 0.0, v1 = 0.0;
+        int k = k0 + r16;
+        for (; k + 16 < k1; k += 32) {
+          const int2 a0 = arcs[k], a1 = arcs[k + 16];
+          v0 = fma(from[a0.x & 0xffff], (double)__int_as_float(a0.y) * (double)row[(unsigned)a0.x >> 16], v0);
+          v1 = fma(from[a1.x & 0xffff], (double)__int_as_float(a1.y) * (double)row[(unsigned)a1.x >> 16], v1);
+        }
+        if (k < k1) {
+          const int2 a0 = arcs[k];
+          v0 = fma(from[a0.x & 0xffff], (double)__int_as_float(a0.y) * (double)row[(unsigned)a0.x >> 16], v0);
+        }
+        const double v = row16_sum_dpp(v0 + v1);
+        if (q >= 0 && r16 == 0) to[q] = v;
+      }
+      GEN_T(g1);
+      lds_barrier();
+      GEN_T(g2);
+      if (!light0 && tid < Q) mine = to[tid];  // (a row's lane 0 wrote it)
+      closure(to, mine);
+      GEN_T(g3);
+      cum += ((double)rtile[t - f0] + (double)wref) * kLog2e_d;
+      if (tid == 0) offs[slot_to] = cum;
+      double* orow = out + u.ab_base + (int64_t)slot_to * Q;
+      if (tid < Q) orow[tid] = mine;
+      for (int q = tid + NT; q < Q; q += NT) orow[q] = to[q];
+      GEN_T(g4);
+      GEN_ADD(0, g0, g1);
+      GEN_ADD(1, g1, g2);
+      GEN_ADD(2, g2, g3);
+      GEN_ADD(3, g3, g4);
+    }
+    GEN_T(g5);
+    if (c + 1 < nchunks) {
+      float* dst = rows + (size_t)((c + 1) & 1) * R * Kmax;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const int e = tid + j * NT;
+        if (e < pn * Kmax) dst[e] = pre[j];
+      }
+      if (tid < pn) refs[(size_t)((c + 1) & 1) * R + tid] = rpre;
+      __syncthreads();
+    }
+    GEN_T(g6);
+    GEN_ADD(4, g5, g6);
+    GEN_ADD(5, gc0, g5);
+  }
+#ifdef WFL_GENERAL_TIMERS
+  if (tid == 0 && b == 0) printf("general dir %d: relax %lld barrier %lld closure %lld store %lld hand-over %lld chunk-total %lld\n", DIR, gen_t[0], gen_t[1], gen_t[2], gen_t[3], gen_t[4], gen_t[5]);
+#endif
+  // log2 of the total: alpha over the accept states at slot T, beta over the start states at slot 0
+  {
+    const double* fin = ((DIR == 0 ? T : 0) & 1) ? buf1 : buf0;
+    double part = 0.0;
+    for (int q = tid; q < Q; q += NT)
+      if ((DIR == 0 ? u.accept_w[q] : u.start_w[q]) > WFL_NEG_INF) part += fin[q];
+    const double tot = block_reduce_sum_f64(part, (double*)red);
+    if (tid == 0) {
+      const bool ok = tot > 0.0 && tot < 1.0e300;
+      const double z2 = ok ? log2(tot) + cum : (tot == 0.0 ? -__builtin_inf() : __builtin_nan(""));
+      z64[b] = z2;
+      if (DIR == 0 && logz) logz[b] = (float)(z2 * 0.6931471805599453094);
+    }
+  }
+}
+
+// (the 1024-thread kernel has 128 VGPRs either way: there the general sweep stays a call, and its spills its own)
+template <int DIR, bool INLINE>
+__device__ __forceinline__ void run_chain_prob_general(const wfl_lattice_desc& d, const UttView& u, char* smem, int T, int R,
+                                                       const float* __restrict__ fg, const float* __restrict__ rmax,
+                                                       const float* __restrict__ weights, double* __restrict__ out,
+                                                       float* __restrict__ logz, int b, double* __restrict__ offs,
+                                                       double* __restrict__ z64, float* __restrict__ wref_out) {
+  if constexpr (INLINE) {
+    run_chain_prob_general_body<DIR>(d, u, smem, T, R, fg, rmax, weights, out, logz, b, offs, z64, wref_out);
+  } else {
+    auto call = [&]() __attribute__((noinline)) {
+      run_chain_prob_general_body<DIR>(d, u, smem, T, R, fg, rmax, weights, out, logz, b, offs, z64, wref_out);
+    };
+    call();
+  }
+}
+
 // The probability-domain sweeps as their own kernel (their register budget is not the general path's): utterances it
 // does not take are left to the log-domain launch that follows (chain_kernel, mode 2).
 template <int MAXT, bool PUB>
@@ -1789,8 +2156,26 @@ __device__ __forceinline__ void prob_chain_body(const wfl_lattice_desc& d, const
   int32_t* fmt = reinterpret_cast<int32_t*>(za + d.B);
   float* wrefs = reinterpret_cast<float*>(fmt + d.B);
   uint64_t* prog = PUB ? reinterpret_cast<uint64_t*>((dir == 0 ? offs_a : offs_b) + prog_offset_doubles(d, nch1)) + b : nullptr;
+  const float* fg = xg + xg_main_dev(d, T);
+  const float* rmax = fg + xg_main_dev(d, T);
   if (!prob_eligible(u, blockDim.x)) {
-    if (PUB && threadIdx.x == 0) prog_publish(prog, token, kProgSkip);
+    if (PUB) {  // (the launch with the gradient beside the sweeps: left to the log-domain launch that follows)
+      if (threadIdx.x == 0) {
+        prog_publish(prog, token, kProgSkip);
+        if (dir == 0) fmt[b] = kFmtLog;
+      }
+      return;
+    }
+    // any other acceptor that fits LDS: the general probability-domain sweep (same stored format, same certificate)
+    if (dir == 0) {
+      if (threadIdx.x == 0) fmt[b] = kFmtProb;
+      run_chain_prob_general<0, MAXT != 1024>(d, u, smem, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(alpha), logz, b,
+                                offs_a + (int64_t)b * nch1, za, wrefs);
+    } else {
+      if (threadIdx.x == 0) zb[d.B + b] = 0.0;
+      run_chain_prob_general<1, MAXT != 1024>(d, u, smem, T, rows_per_chunk, fg, rmax, weights, reinterpret_cast<double*>(beta), nullptr, b,
+                                offs_b + (int64_t)b * nch1, zb, nullptr);
+    }
     return;
   }
   if (PUB && threadIdx.x == 0) prog_publish(prog, token, 0u);  // "resident" (occ_gate_kernel waits for it)
@@ -1802,8 +2187,6 @@ __device__ __forceinline__ void prob_chain_body(const wfl_lattice_desc& d, const
   P.red = (float*)p, p += 64 * 4;
   P.rows = (float*)p, p += prob_rows_floats(d, rows_per_chunk, blockDim.x) * 4;
   P.refs = (float*)p;
-  const float* fg = xg + xg_main_dev(d, T);
-  const float* rmax = fg + xg_main_dev(d, T);
   MitmArgs mm;
   if (PUB && beta) {
     // (the partner: the other direction's rows, offsets and progress word; the backward sweep's own flag sits in the
@@ -1866,7 +2249,8 @@ __global__ void __launch_bounds__(256)
   const double za = (reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * nch1)[b];
   const double zbv = (tail_b + (int64_t)d.B * nch1)[b];
   double* verdict = tail_b + (int64_t)d.B * (nch1 + 1) + b;
-  if (!prob_eligible(u, chain_nt)) {
+  const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
+  if (fmt[b] != kFmtProb && fmt[b] != kFmtOcc) {
     if (tid == 0) *verdict = 1.0;  // (not swept in the probability domain at all: the log-domain launch takes it)
     return;
   }
@@ -1881,7 +2265,6 @@ __global__ void __launch_bounds__(256)
   // the same identity reads sum_q gamma_s[q] = 1 (at slot T that also ties the middle's Z to the forward sweep's
   // total, at slot 0 to the backward sweep's).  One sweep that did and one that did not (a crossing that gave up
   // waiting) leave neither format: re-run in the log domain.
-  const int32_t* fmt = reinterpret_cast<const int32_t*>(reinterpret_cast<const double*>(alpha + tail) + (int64_t)d.B * (nch1 + 1));
   const bool occ_a = fmt[b] == kFmtOcc;
   const bool occ_b = pub && occ_header(d, beta, tail, nch1).bad[b] == 1u;
   if (occ_a != occ_b) {
@@ -1947,7 +2330,7 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
   //       2 = the launch after prob_chain_kernel: the log-domain sweeps of what that launch left -- utterances whose
   //           acceptor it does not take, and those whose two probability-domain sweeps disagree about Z
   if (SR == WFL_SEMIRING_LOG && mode == 2) {
-    if (prob_eligible(u, blockDim.x)) {
+    if (fmt[b] == kFmtProb || fmt[b] == kFmtOcc) {  // swept in the probability domain by the launch before
       if (!zb) return;                 // (forward only: nothing to compare)
       if (zb[d.B + b] == 0.0) return;  // certified by prob_certify_kernel
     }
@@ -1985,7 +2368,7 @@ static size_t chain_lds_bytes(const wfl_lattice_desc& d, int rows_per_chunk) {
                       (size_t)2 * nt * 4 + 64;
   return std::max(prob, (size_t)d.max_arcs * 8 + (size_t)d.max_eps * 8 + (size_t)(d.max_states + 1) * 8 + (size_t)d.max_states * 16 +
          (size_t)2 * rows_per_chunk * d.max_labels * 4 + 64 * 4 + (size_t)(d.max_levels + 1) * 4 +
-         (size_t)(d.max_states + 1) * 4 + 64);
+         (size_t)(d.max_states + 1) * 4 + (size_t)2 * rows_per_chunk * 4 + 64);
 }
 
 // ------------------------------------------------------------------------------------------------

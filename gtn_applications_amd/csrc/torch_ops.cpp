@@ -758,6 +758,27 @@ std::pair<std::vector<at::Tensor>, bool> lattice_loss_forward(const at::Tensor& 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ctc_fast_backward", &ctc_fast_backward,
         "loss.backward() of a CtcStep loss without the autograd engine (false: not the plain case, use the engine)");
+  m.def(
+      "order_after",
+      [](int64_t waiter, int64_t signaller, int dev) {
+        order_after(reinterpret_cast<hipStream_t>(waiter), reinterpret_cast<hipStream_t>(signaller), dev);
+      },
+      "waiter's later work after signaller's earlier work (raw stream handles): a pooled device-scope event");
+  m.def(
+      "order_mark",
+      [](int64_t signaller, int dev) {
+        hipEvent_t e = event_ring(dev).take();
+        TORCH_CHECK(hipEventRecord(e, reinterpret_cast<hipStream_t>(signaller)) == hipSuccess, "hipEventRecord");
+        return reinterpret_cast<int64_t>(e);
+      },
+      "a pooled device-scope event recorded behind signaller's work so far (its handle: valid for the next 31 takes)");
+  m.def(
+      "order_wait",
+      [](int64_t waiter, int64_t event) {
+        TORCH_CHECK(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(waiter), reinterpret_cast<hipEvent_t>(event), 0) == hipSuccess,
+                    "hipStreamWaitEvent");
+      },
+      "waiter's later work after the event of order_mark");
   m.def("built_for_torch", &built_for_torch, "torch version whose headers this module was compiled against");
   m.def("ctc_step", &ctc_step, "CTC loss + eager gradient in one pipelined launch (C++ autograd node)");
   m.def("asg_forward", &asg_forward, "every launch of an ASG step's forward in one native call (criterions/asg.py)");

@@ -479,6 +479,31 @@ def lattice_viterbi(x, pack, weights=None):
 
 
 _SIDE_STREAMS = {}
+_ORDER = False
+
+
+def _order_module():
+    """csrc/torch_ops.cpp's stream-ordering entry points (a ring of device-scope events), or None if it is not built."""
+    global _ORDER
+    if _ORDER is False:
+        try:
+            from . import _wfl_torch as mod
+            _ORDER = mod if hasattr(mod, "order_mark") else None
+        except ImportError:
+            _ORDER = None
+    return _ORDER
+
+
+def _order_after(waiter, signaller):
+    """`waiter`'s later work after `signaller`'s earlier work.  torch's Stream.wait_stream creates and records an event
+    per call; between the criteria's forked streams that record held the host for ~0.4 ms a call whenever the GPU had
+    work queued (a Transducer step with a back-off model: 1.17 ms, 1.1 of them host, against 0.41 with the ring of
+    device-scope events csrc/torch_ops.cpp keeps: order_event_flags) -- the host could not run ahead of the GPU."""
+    mod = _order_module()
+    if mod is None:
+        waiter.wait_stream(signaller)
+    else:
+        mod.order_after(waiter.cuda_stream, signaller.cuda_stream, waiter.device.index)
 
 
 class side_stream:
@@ -496,7 +521,7 @@ class side_stream:
         self.ctx = None
 
     def __enter__(self):
-        self.side.wait_stream(self.cur)
+        _order_after(self.side, self.cur)
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self
@@ -508,20 +533,26 @@ class side_stream:
     def join(self, *tensors):
         """The current stream waits for everything launched on the side stream so far."""
         cur = torch.cuda.current_stream(self.side.device)
-        cur.wait_stream(self.side)
+        _order_after(cur, self.side)
         for t in tensors:
             if t is not None:
                 t.record_stream(cur)
 
     def mark(self):
         """Event after what has been launched on the side stream so far (call inside the block)."""
+        mod = _order_module()
+        if mod is not None:
+            return mod.order_mark(self.side.cuda_stream, self.side.device.index)
         ev = torch.cuda.Event()
         ev.record(self.side)
         return ev
 
     def join_at(self, ev, *tensors):
         """The current stream waits for the side stream only up to `ev` (work launched after it keeps overlapping)."""
-        self.cur.wait_event(ev)
+        if isinstance(ev, int):
+            _order_module().order_wait(self.cur.cuda_stream, ev)
+        else:
+            self.cur.wait_event(ev)
         for t in tensors:
             if t is not None:
                 t.record_stream(self.cur)

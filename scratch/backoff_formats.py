@@ -18,3 +18,9 @@ off = ctypes.c_int64()
 N.check(N.lib.wfl_lattice_formats_offset(ctypes.byref(num.pack.desc), T, ctypes.byref(off)))
 torch.cuda.synchronize()
 print("backoff formats", num.alpha[off.value:off.value + B].view(torch.int32).cpu().tolist(), "states", num.pack.desc.max_states, "arcs", num.pack.desc.max_arcs, "eps", num.pack.desc.max_eps, "levels", num.pack.desc.max_levels)
+den = TR._transitions_pack(crit.transitions, B, Nn + 1, x.device)
+print("denominator pack: states", den.desc.max_states, "arcs", den.desc.max_arcs, "eps", den.desc.max_eps, "levels", den.desc.max_levels, "labels", den.desc.max_labels)
+import numpy as np
+a = crit.transitions.arrays()
+indeg = np.bincount(a["dst"], minlength=den.desc.max_states)
+print("in-degrees (labelled + eps)", indeg.tolist())
