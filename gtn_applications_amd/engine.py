@@ -421,10 +421,10 @@ def lattice_forward(x, pack, weights=None, need_beta=True, semiring=N.SEMIRING_L
 
 
 def lattice_formats(st):
-    """int32 [B] (device): how each utterance of a log-semiring forward pass was swept -- 1: fp64 probability domain,
-    0: fp32 log domain (acceptor with epsilon arcs / in- or out-degree above 8 / more than 1024 states, or the
-    certificate's repair: the two probability-domain sweeps disagreed about Z).  Diagnostics and tests
-    (wfl_lattice_formats_offset)."""
+    """int32 [B] (device): how each utterance of a log-semiring forward pass was swept -- 1: fp64 probability domain
+    (2: its sweeps met in the middle and left occupancies), 0: log domain (the certificate's repair: the two
+    probability-domain sweeps disagreed about Z; an acceptor outside the lean sweeps' shape in the launch that has the
+    gradient beside the sweeps; WFL_LATTICE_DOMAIN=log).  Diagnostics and tests (wfl_lattice_formats_offset)."""
     B = st.pack.desc.B
     pos = ctypes.c_int64()
     N.check(N.lib.wfl_lattice_formats_offset(st.pack._desc_ref, st.T, ctypes.byref(pos)))

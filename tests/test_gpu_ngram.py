@@ -173,16 +173,22 @@ def _numerator_formats(loss, B, T):
     return num.alpha[off.value:off.value + B].view(torch.int32).cpu().tolist()
 
 
+@pytest.mark.parametrize("dense_den", [True, False])
 @pytest.mark.parametrize("kind", ["ctc", "asg"])
-def test_epsilon_acceptors_are_swept_in_the_probability_domain(kind):
+def test_epsilon_acceptors_are_swept_in_the_probability_domain(kind, dense_den, monkeypatch):
     """csrc/lattice_kernels.hip run_chain_prob / eps_closure: the bigram model's alignment acceptors as the reference
     builds them (transducer.py:262-290: alignments o make_transitions_graph(2, N), epsilon arcs into and out of the
     back-off state) through the GENERAL lattice path -- TransducerLossFunction.apply, none of the module's short cuts.
     Their numerator sweeps run in the fp64 probability domain with an in-frame epsilon closure (formats say so), pass
     the certificate (alpha before the closure x beta = Z at every 8th slot), and loss, emission gradient and
-    transition-parameter gradient -- epsilon arcs' included -- meet the float64 epsilon-aware recurrence."""
+    transition-parameter gradient -- epsilon arcs' included -- meet the float64 epsilon-aware recurrence.
+    dense_den = False: the DENOMINATOR -- the bigram model itself, 83 states with 81 arcs into each and the back-off
+    state's epsilon arcs -- takes the lattice engine as well instead of the dense short cut: run_chain_prob_general
+    (rows of 16 lanes per state, more such states than the workgroup has rows)."""
+    from gtn_applications_amd import engine as E
     from gtn_applications_amd.criterions import transducer as TR
 
+    monkeypatch.setattr(TR, "_DENSE_NGRAM", dense_den)
     N, T, L, B = 81, 250, 44, 8
     rs = np.random.RandomState(300 + (kind == "asg"))
     kw = dict(blank="optional", allow_repeats=False) if kind == "ctc" else {}
@@ -201,8 +207,10 @@ def test_epsilon_acceptors_are_swept_in_the_probability_domain(kind):
     loss = TR.TransducerLossFunction.apply(xg, [torch.tensor(t) for t in targets], crit.tokens, crit.lexicon,
                                            crit.transition_params, crit.transitions, crit.reduction)
     assert _numerator_formats(loss, B, T) == [1] * B
+    if not dense_den:
+        assert E.lattice_formats(loss.grad_fn.aux[3]).tolist() == [1] * B
     loss.backward()
-    name = f"ngram2_{kind}_general"
+    name = f"ngram2_{kind}_general" + ("" if dense_den else "_lattice_den")
     check(name + "_loss", [loss.item()], [want_loss], 0.0)
     check(name + "_dx", xg.grad.cpu().numpy(), want_dx, 1.0 / (L * B))
     check_dparams(name + "_dparams", crit.transition_params.grad.cpu().numpy(), want_dp, counts, 1.0 / (L * B))

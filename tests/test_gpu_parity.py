@@ -1703,6 +1703,78 @@ def test_lattice_probability_domain_is_the_default_and_matches_log_domain(crit):
     np.testing.assert_allclose(logd[1:], got[1:], rtol=2e-6)
 
 
+def _random_acceptor(rs, Q, C, n_eps, hubs):
+    """(Graph, src, dst, lab) of an acceptor the lean sweeps do not take: a self-loop and one to three arcs from earlier
+    states into every state, `hubs` states that collect (and send) 100 arcs, `n_eps` epsilon arcs p -> q with p < q
+    (acyclic: chains of them give several closure levels, one state collects twelve)."""
+    from gtn_applications_amd import graph as G
+
+    src, dst, lab = [], [], []
+    for q in range(Q):
+        src.append(q), dst.append(q), lab.append(int(rs.randint(C)))
+        for _ in range(int(rs.randint(1, 4))):
+            if q:
+                src.append(int(rs.randint(max(0, q - 40), q))), dst.append(q), lab.append(int(rs.randint(C)))
+    for h in hubs:
+        for p_ in rs.randint(0, h, size=100).tolist():
+            src.append(p_), dst.append(h), lab.append(int(rs.randint(C)))
+        for q_ in rs.randint(h + 1, Q, size=100).tolist():
+            src.append(h), dst.append(q_), lab.append(int(rs.randint(C)))
+    eps_into = min(Q - 1, 60)
+    for p_ in sorted(set(rs.randint(0, eps_into, size=12).tolist())):  # (one state closed by a row of lanes)
+        src.append(p_), dst.append(eps_into), lab.append(-1)
+    for _ in range(n_eps):
+        p_ = int(rs.randint(0, Q - 1))
+        src.append(p_), dst.append(int(rs.randint(p_ + 1, min(Q, p_ + 30)))), lab.append(-1)
+    g = G.Graph(True)
+    for q in range(Q):
+        g.add_node(q % 50 == 0, q % 7 == 3)
+    for s_, d_, l_ in zip(src, dst, lab):
+        g.add_arc(s_, d_, G.epsilon if l_ < 0 else l_)
+    return g, src, dst, lab
+
+
+@pytest.mark.parametrize("Q,T", [(1100, 10), (40, 70), (300, 33)])
+def test_general_probability_sweep_on_random_acceptors(crit, Q, T):
+    """csrc/lattice_kernels.hip run_chain_prob_general: acceptors outside the lean sweeps' shape -- states of 100 arcs (a
+    row of 16 lanes each, more of them than the workgroup has rows, more than 64 arcs a row), epsilon arcs over several
+    levels (one state with twelve), more states than the workgroup has threads (1100), learnable weights on every arc
+    -- are swept in the fp64 probability domain too: formats say so, and log Z, the emission gradient and every arc's
+    weight gradient (epsilon arcs' included) meet the float64 epsilon-aware recurrence."""
+    from gtn_applications_amd import engine as E
+
+    rs = np.random.RandomState(Q + T)
+    C, B = 12, 2
+    graphs, arcs = [], []
+    for b in range(B):
+        g, src, dst, lab = _random_acceptor(rs, Q - 3 * b, C, n_eps=25, hubs=[Q // 3, Q // 2] + list(range(Q // 2 + 1, Q // 2 + 9)))
+        graphs.append(g)
+        arcs.append((src, dst, lab))
+    n = [len(a[0]) for a in arcs]
+    W = (0.4 * rs.randn(sum(n))).astype(np.float32)
+    wids = [np.arange(n[0]), n[0] + np.arange(n[1])]
+    x = rs.randn(B, T, C).astype(np.float32)
+    xd, Wd = dev(x), dev(W)
+    pack = E.PackedLattice.from_graphs(graphs, C, xd.device, wids=wids)
+    st = E.lattice_forward(xd, pack, weights=Wd, need_beta=True)
+    assert E.lattice_formats(st).tolist() == [1] * B
+    coef = torch.ones(B, device="cuda")
+    dx, dW = torch.full_like(xd, float("nan")), torch.zeros_like(Wd)
+    E.lattice_grad(st, coef, coef_w=coef, dx=dx, dW=dW)
+    got = st.logz.cpu().numpy()
+    for b in range(B):
+        src, dst, lab = arcs[b]
+        Qb = Q - 3 * b
+        start = [q for q in range(Qb) if q % 50 == 0]
+        accept = [q for q in range(Qb) if q % 7 == 3]
+        score, gx, garc = OR.lattice_forward_backward_eps(x[b].astype(np.float64), src, dst, lab,
+                                                          W[wids[b]].astype(np.float64), start, accept, Qb)
+        assert np.isfinite(score)
+        assert got[b] == pytest.approx(score, rel=RTOL, abs=1e-5)
+        close(dx[b], gx, msg=f"utterance {b}")
+        close(dW[wids[b][0]:wids[b][-1] + 1], garc, atol=5e-5, msg=f"arc weights of utterance {b}")
+
+
 @pytest.mark.parametrize("T", [1, 2, 15, 16, 17, 33, 130])
 def test_banded_sweep_awkward_sizes(crit, T):
     """The ASG force-alignment lattices run the register-resident banded sweep (chain wave + loader wave, chunks of
