@@ -2407,6 +2407,9 @@ __device__ __forceinline__ bool band_shape(const wfl_lattice_desc& d, const UttV
 // The dense gradient rows of a tile: base value (0, the existing gradient, or -cf * softmax(x) for the fused
 // log-softmax backward) plus the accumulator of the column's label slot (`acc` [nr][Kmax], found through `colmap`);
 // the rows never pass through LDS.  Shared by the general gradient kernel and the state-occupancy one.
+// RU: rows of a trip (wide rows); NOACC: the caller never accumulates into an existing gradient (the workgroups beside the
+// sweeps) -- no registers for it, so their trips take eight rows where the others take four: twice the bytes in flight
+template <int RU_ = 4, bool NOACC = false>
 __device__ __forceinline__ void stream_grad_rows(int b, int ts0, int nr, int T, int C, int Kmax, int tid, int NT,
                                                  float* __restrict__ dx, const float* __restrict__ x,
                                                  const float* __restrict__ row_lse, int accumulate, bool dead, float cf,
@@ -2432,7 +2435,7 @@ __device__ __forceinline__ void stream_grad_rows(int b, int ts0, int nr, int T, 
     // computed and stored: trip by trip, a tile of 32 rows was eight dependent round trips to HBM plus eight more for
     // the heads and tails (55 us of a workgroup's 77 per tile at the Transducer benchmark).
     const int64_t e0 = ((int64_t)b * T + ts0) * C;
-    constexpr int RU = 4;
+    constexpr int RU = RU_;
     const int njb = ((C >> 2) + NT - 1) / NT, ntrips = ((nr + RU - 1) / RU) * njb;
     auto row_head = [&](int r) { return (int)((4 - ((e0 + (int64_t)r * C) & 3)) & 3); };
     struct Trip {
@@ -2448,7 +2451,7 @@ __device__ __forceinline__ void stream_grad_rows(int b, int ts0, int nr, int T, 
         const int c = head + 4 * min(j, nvec - 1);
         t.have[q] = make_float4(0.f, 0.f, 0.f, 0.f), t.xv[q] = t.have[q];
         t.l[q] = soft ? lse[r] : 0.f;
-        if (accumulate) t.have[q] = *reinterpret_cast<const float4*>(gdst + (int64_t)r * C + c);
+        if (!NOACC && accumulate) t.have[q] = *reinterpret_cast<const float4*>(gdst + (int64_t)r * C + c);
         if (soft) t.xv[q] = *reinterpret_cast<const float4*>(xsrc + (int64_t)r * C + c);
       }
     };
@@ -2542,7 +2545,14 @@ __device__ __forceinline__ bool occ_eligible(const UttView& u, bool prob) {
 __device__ unsigned long long g_live[16];  // cycles (s_memtime) summed over workgroups: 0 busy-wait 1 job wait 2 setup 3 zloc 4 products 5 rows 6 jobs 7 polls
 #define LIVE_T(v) const unsigned long long v = wall_clock64()
 #define LIVE_ADD(k, a, b) if (threadIdx.x == 0) atomicAdd(&g_live[k], (b) - (a))
+// a timeline of the last launch (100 MHz wall clock; scripts/live_timeline.py): per tile {utterance << 16 | first
+// frame, wait began, wait over, occupancies accumulated, rows written}; per sweep {began, ended}
+__device__ unsigned long long g_tl[4096][5];
+__device__ unsigned int g_tl_n;
+__device__ unsigned long long g_sweep[512][2];
+#define LIVE_TILE(b, t, a0, a1, a2, a3) if (threadIdx.x == 0) { const unsigned int i_ = atomicAdd(&g_tl_n, 1u); if (i_ < 4096) { g_tl[i_][0] = ((unsigned long long)(b) << 16) | (unsigned)(t); g_tl[i_][1] = a0; g_tl[i_][2] = a1; g_tl[i_][3] = a2; g_tl[i_][4] = a3; } }
 #else
+#define LIVE_TILE(b, t, a0, a1, a2, a3)
 #define LIVE_T(v)
 #define LIVE_ADD(k, a, b)
 #endif
@@ -2751,12 +2761,15 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
     }
     __syncthreads();
     LIVE_T(t_p1);
+    // (eight rows a trip for the workgroups beside the sweeps -- stream_grad_rows<8, true>, twice the bytes in flight for the
+    // same registers -- changes nothing: a tile's rows 23.9 us either way, the step 0.342 against 0.338 ms)
     stream_grad_rows(b, ts0, nr, T, C, Kmax, tid, NT, dx, x, row_lse, accumulate, dead, cf, acc, colmap);
     LIVE_T(t_p2);
     if (LIVE) {
       LIVE_ADD(4, t_p0, t_p1);
       LIVE_ADD(5, t_p1, t_p2);
       LIVE_ADD(6, 0ull, 1ull);
+      LIVE_TILE(b, ts0, t_w0, t_p0, t_p1, t_p2);
     }
   }
 }
@@ -2812,8 +2825,14 @@ __global__ void __launch_bounds__(MAXT)
   // the gradient workgroups leave a CU alone while a sweep runs on it (occ_live_kernel)
   uint32_t* busy = occ_header(d, alpha, tail, nch1).busy + cu_key();
   if (threadIdx.x == 0) __hip_atomic_store(busy, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef WFL_LIVE_STATS
+  if (threadIdx.x == 0 && blockIdx.x < 512) g_sweep[blockIdx.x][0] = wall_clock64();
+#endif
   prob_chain_body<MAXT, true>(d, ints, floats, xg, T, rows_per_chunk, weights, alpha, beta, logz, tail, nch1, b,
                               blockIdx.x / Bp, smem, token, mitm_req);
+#ifdef WFL_LIVE_STATS
+  if (threadIdx.x == 0 && blockIdx.x < 512) g_sweep[blockIdx.x][1] = wall_clock64();
+#endif
   if (threadIdx.x == 0) __hip_atomic_store(busy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -4081,6 +4100,14 @@ int wfl_lattice_backtrace(const wfl_lattice_desc* d, const int32_t* ints, const 
 }
 
 #ifdef WFL_LIVE_STATS
+int wfl_debug_live_timeline(unsigned long long* tiles, unsigned int* ntiles, unsigned long long* sweeps) {
+  int rc = (int)hipMemcpyFromSymbol(tiles, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * 4096 * 5);
+  rc |= (int)hipMemcpyFromSymbol(ntiles, HIP_SYMBOL(g_tl_n), sizeof(unsigned int));
+  rc |= (int)hipMemcpyFromSymbol(sweeps, HIP_SYMBOL(g_sweep), sizeof(unsigned long long) * 512 * 2);
+  unsigned int z = 0;
+  rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_n), &z, sizeof(z));
+  return rc;
+}
 int wfl_debug_live_stats(unsigned long long* out, int reset) {
   int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_live), sizeof(unsigned long long) * 16);
   if (reset) {
