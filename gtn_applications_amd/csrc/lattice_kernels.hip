@@ -27,6 +27,27 @@
 
 namespace wfl {
 
+#ifdef WFL_LIVE_STATS
+// wall clock (100 MHz) at the first and last workgroup of the launches around the sweeps: [k][0] first begin, [k][1] last end
+// k: 0 certificate, 1 log-domain launch, 2 gradient kernel of the rest, 3 gather
+__device__ unsigned long long g_marks[8][2];
+__device__ __forceinline__ unsigned long long wall_clock64_early() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t));
+  return t;
+}
+#define WFL_MARK_BEGIN(k) if (threadIdx.x == 0) atomicMin(&g_marks[k][0], wall_clock64_early())
+#define WFL_MARK_END(k) if (threadIdx.x == 0) atomicMax(&g_marks[k][1], wall_clock64_early())
+// a log of launches: workgroup (0, 0) of a kernel appends {id, wall clock} (ids: scripts/live_timeline.py)
+__device__ unsigned long long g_log[512][2];
+__device__ unsigned int g_log_n;
+#define WFL_LOG(k) if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { const unsigned int i_ = atomicAdd(&g_log_n, 1u) & 511u; g_log[i_][0] = (k); g_log[i_][1] = wall_clock64_early(); }
+#else
+#define WFL_MARK_BEGIN(k)
+#define WFL_MARK_END(k)
+#define WFL_LOG(k)
+#endif
+
 struct UttView {
   int Q, A, E, K, nlev;
   int a0, e0;
@@ -172,6 +193,7 @@ __global__ void __launch_bounds__(256) gather_lse_kernel(wfl_lattice_desc d, con
                                                           const float* __restrict__ x, int T, int C,
                                                           float* __restrict__ xg, float* __restrict__ row_lse,
                                                           float* __restrict__ fg, float* __restrict__ rmax) {
+  WFL_LOG(1);
   __shared__ float srow[4][64 * NV];   // a wave's current row
   __shared__ int16_t slab[1024];       // the utterance's label columns (wfl_lattice_forward: at most 1024 per utterance)
   const int b = blockIdx.y;
@@ -809,6 +831,7 @@ __device__ __forceinline__ void prog_publish(uint64_t* w, uint32_t token, uint32
 __host__ __device__ inline int64_t prog_offset_doubles(const wfl_lattice_desc& d, int nch1) {  // from the tail's start
   return (int64_t)d.B * nch1 + 2 * (int64_t)d.B + 1024 + 1;
 }
+constexpr int kLiveTile = 32;  // frames per job of the gradient beside the sweeps (at least: T / tiles, rounded up)
 // header of the in-flight gradient, behind the progress words and `bad` of the alpha tail (int32 units)
 struct OccHeader {
   uint32_t* bad;    // [B]
@@ -817,6 +840,8 @@ struct OccHeader {
   int32_t* list;    // [8][B]
   uint32_t* busy;   // [8][256]  == token while a sweep runs on CU (xcc, HW_ID[15:8])
   uint32_t* meta;   // [2]       the launch's token and its tiles per utterance (for served_beside_the_sweeps)
+  uint32_t* next_base;  // [8]   next base-row job of XCD x (occ_live_kernel, first phase)
+  uint32_t* based;  // [B][tiles] == token once the tile's base rows are written
 };
 // Did the gradient workgroups that ran beside the sweeps write utterance b's rows?  Not if one of them gave up on it
 // (`bad`), nor if jobs of its XCD were left undrawn (an XCD that hosted sweeps but no gradient workgroup).  Read by the
@@ -837,6 +862,8 @@ __device__ __forceinline__ OccHeader occ_header(const wfl_lattice_desc& d, float
   h.list = h.nx + 16;
   h.busy = reinterpret_cast<uint32_t*>(h.list + 8 * (int64_t)d.B);
   h.meta = h.busy + 8 * 256;
+  h.next_base = h.meta + 2;
+  h.based = h.next_base + 8;
   return h;
 }
 
@@ -2242,6 +2269,8 @@ __global__ void __launch_bounds__(256)
   // (wave-level reductions only); a wave that finds a violation raises the utterance's verdict (cleared by the beta
   // sweep of prob_chain_kernel before it started)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  WFL_MARK_BEGIN(0);
+  WFL_LOG(10);
   const UttView u = make_view(d, ints, floats, b, T);
   const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
   double* tail_b = reinterpret_cast<double*>(beta + tail);
@@ -2314,6 +2343,8 @@ __global__ void chain_kernel(wfl_lattice_desc d, const int32_t* __restrict__ int
                              int32_t* __restrict__ bptr, float* __restrict__ logz, int64_t tail, int nch1, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, dir = blockIdx.y;
+  WFL_MARK_BEGIN(1);
+  WFL_LOG(11);
   const UttView u = make_view(d, ints, floats, b, T);
   // behind the score arrays (wfl_lattice_workspace reserves the room):
   //   alpha + tail: double offs[B][nch1], double Z[B] (ln Z; log2 Z for probability-domain utterances),
@@ -2413,7 +2444,8 @@ template <int RU_ = 4, bool NOACC = false>
 __device__ __forceinline__ void stream_grad_rows(int b, int ts0, int nr, int T, int C, int Kmax, int tid, int NT,
                                                  float* __restrict__ dx, const float* __restrict__ x,
                                                  const float* __restrict__ row_lse, int accumulate, bool dead, float cf,
-                                                 const float* acc, const int16_t* colmap) {
+                                                 const float* acc, const int16_t* colmap, bool base_only = false) {
+  // (base_only: the rows' base values alone -- the label columns' addends follow: occ_grad_tiles, "while it waits")
   // fused log_softmax backward (ctc.py:107, transducer.py:186-187): with g = cf * posteriors the
   // gradient w.r.t. the raw scores is g - softmax * sum_c g, and the posteriors of a frame sum to
   // one, so the base value of a row is -cf * softmax(x)
@@ -2424,6 +2456,7 @@ __device__ __forceinline__ void stream_grad_rows(int b, int ts0, int nr, int T, 
   auto value = [&](int r, int c, float have, float xv, float l) {
     float v = have;
     if (soft && l > WFL_NEG_INF) v -= cf * fast_exp(nan_to_neg(xv) - l);
+    if (base_only) return v;
     const int k = colmap[c];
     if (k >= 0 && !dead) v += cf * acc[r * Kmax + k];
     return v;
@@ -2492,7 +2525,7 @@ __device__ __forceinline__ void stream_grad_rows(int b, int ts0, int nr, int T, 
     // narrow rows: a lane owns a column (its label slot looked up once), a wave owns every fourth row
     const int lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
     for (int c = lane; c < C; c += 64) {
-      const int k = dead ? -1 : colmap[c];
+      const int k = (dead || base_only) ? -1 : colmap[c];
 #pragma unroll 4
       for (int r = wv; r < nr; r += nw) {
         const int i = r * C + c;
@@ -2550,6 +2583,7 @@ __device__ unsigned long long g_live[16];  // cycles (s_memtime) summed over wor
 __device__ unsigned long long g_tl[4096][5];
 __device__ unsigned int g_tl_n;
 __device__ unsigned long long g_sweep[512][2];
+__device__ unsigned long long g_wg[1024][4];  // gradient workgroup: began, its CU free, last job drawn, jobs done
 #define LIVE_TILE(b, t, a0, a1, a2, a3) if (threadIdx.x == 0) { const unsigned int i_ = atomicAdd(&g_tl_n, 1u); if (i_ < 4096) { g_tl[i_][0] = ((unsigned long long)(b) << 16) | (unsigned)(t); g_tl[i_][1] = a0; g_tl[i_][2] = a1; g_tl[i_][3] = a2; g_tl[i_][4] = a3; } }
 #else
 #define LIVE_TILE(b, t, a0, a1, a2, a3)
@@ -2564,9 +2598,66 @@ struct OccLive {
   int R;          // frames per chunk of the sweeps
   int force_bad;  // (tests: behave as if the XCC ids differed)
   int mitm;       // the launch asked its sweeps to meet in the middle (they say in their progress words whether they did)
+  const uint32_t* based;  // the tile's word in OccHeader::based (null: the tile writes whole rows itself)
 };
 __device__ __forceinline__ float ld_l2(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Have the sweeps of the launch reached frames ts0 .. ts0 + nr - 1 of the tile's utterance?  1 / 2: yes (full vectors /
+// occupancies), 0: not this launch's (the general kernel's utterance), -1: cannot be served, -2: not within max_spins polls.
+// One thread.
+__device__ __forceinline__ int live_tile_state(const OccLive& live, int T, int ts0, int nr, int max_spins) {
+  const uint32_t need_a = (uint32_t)((ts0 + nr + live.R - 1) / live.R);
+  const uint32_t need_b = (uint32_t)((T - ts0 - 1 + live.R - 1) / live.R);
+  // sweeps that meet in the middle (live.mitm): a sweep's choice is final once its word carries kProgMitm or counts
+  // a chunk beyond its half (the crossing itself publishes the half's count, still without the flag).  Then a slot's
+  // occupancy only needs the sweep that wrote it: slots > m the forward sweep, slots < m the backward one, slot m
+  // the forward sweep's crossing (in L2 with its first chunk beyond).
+  // (T not a multiple of 16: the backward sweep's occupancies end below m_b = T - 16 half_b <= m, slots m_b .. m
+  // are the forward sweep's crossing too; a sweep's last, partial chunk comes with its final count)
+  const int half_a = mitm_plain_chunks_a(T), half_b = mitm_plain_chunks_b(T), mid_b = T - 16 * half_b;
+  const int s_lo = ts0 + 1, s_hi = ts0 + nr;
+  const uint32_t gneed_a = s_hi >= mid_b ? (uint32_t)max((s_hi + 15) / 16, half_a + 1) : 0u;
+  const uint32_t gneed_b = s_lo < mid_b ? (uint32_t)((T - 1 - s_lo) / 16 + 1) : 0u;
+  const uint32_t me = xcc_id();
+  int st = -2;
+  for (int spin = 0; spin < max_spins; ++spin) {
+    const uint64_t va = __hip_atomic_load(live.prog_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t vb = __hip_atomic_load(live.prog_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(va >> 32) == live.token && (uint32_t)(vb >> 32) == live.token) {
+      const uint32_t fa = (uint32_t)va & 0x0fffffffu, fb = (uint32_t)vb & 0x0fffffffu;
+      if (fa == kProgSkip || fb == kProgSkip) {
+        st = 0;  // not swept in the probability domain: the general kernel's utterance
+        break;
+      }
+      if ((((uint32_t)va >> 28) & 15u) != me || (((uint32_t)vb >> 28) & 15u) != me || live.force_bad) {
+        st = -1;
+        break;
+      }
+      const uint32_t ca = fa & kProgCount, cb = fb & kProgCount;
+      if (!live.mitm) {
+        if (ca >= need_a && cb >= need_b) {
+          st = 1;
+          break;
+        }
+      } else {
+        const bool ma = (fa & kProgMitm) != 0, mb = (fb & kProgMitm) != 0;
+        if ((ma || ca >= (uint32_t)half_a + 1) && (mb || cb >= (uint32_t)half_b + 1)) {  // both have chosen
+          if (ma != mb) {
+            st = -1;  // (one of them gave up waiting at its crossing: the certificate re-sweeps the utterance)
+            break;
+          }
+          if (ma ? (ca >= gneed_a && cb >= gneed_b) : (ca >= need_a && cb >= need_b)) {
+            st = ma ? 2 : 1;
+            break;
+          }
+        }
+      }
+    }
+    if (spin + 1 < max_spins) __builtin_amdgcn_s_sleep(64);
+  }
+  return st;
 }
 
 template <bool LIVE>
@@ -2584,6 +2675,7 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
   double* corr = (double*)(acc + (((size_t)TS * Kmax + 1) & ~(size_t)1));  // [TS]
   int16_t* lab = (int16_t*)(corr + TS);                       // [Qmax]: label slot of the state (-1: no in-arc)
   int16_t* colmap = lab + ((d.max_states + 3) & ~3);          // [C]
+  int32_t* colk = reinterpret_cast<int32_t*>(colmap + ((C + 3) & ~3));  // [Kmax]: the column of a label slot
   const double* offs_a = reinterpret_cast<const double*>(alpha + tail) + (int64_t)b * nch1;
   const double* offs_b = reinterpret_cast<const double*>(beta + tail) + (int64_t)b * nch1;
   double zd = 0.0;
@@ -2610,71 +2702,38 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
   for (int c = tid; c < C; c += NT) colmap[c] = -1;
   for (int q = tid; q < Q; q += NT) lab[q] = u.in_ptr[q] < u.in_ptr[q + 1] ? (int16_t)u.arc_slot[u.in_ptr[q]] : (int16_t)-1;
   __syncthreads();
-  for (int k = tid; k < K; k += NT) colmap[u.labels[k]] = (int16_t)k;
+  for (int k = tid; k < K; k += NT) colmap[u.labels[k]] = (int16_t)k, colk[k] = u.labels[k];
   const float inv_q = 1.f / (float)max(Q, 1);
   for (int ts0 = t_begin; ts0 < t_end; ts0 += TS) {
     const int nr = min(TS, t_end - ts0);
+    bool prewritten = false;
     __syncthreads();
     LIVE_T(t_w0);
     if (LIVE) LIVE_ADD(2, t_s0, t_w0);
     if (LIVE) {
       // frames ts0 .. ts0 + nr - 1 need slots ts0 + 1 .. ts0 + nr of both sweeps: the forward sweep has stored slots
       // <= chunks * R, the backward sweep slots >= T - chunks * R
+      // st: 1 / 2 ready (full vectors / occupancies), 0 not this launch's, -1 cannot be served, -2 not yet
+      auto poll = [&](int max_spins) { return live_tile_state(live, T, ts0, nr, max_spins); };
+      // The rows' base values, -cf softmax(x), are written by the first phase of occ_live_kernel -- any workgroup of this
+      // XCD, before the sweeps have reached the tile; here only the label columns' occupancies are added to them.  So the
+      // tile also waits for its word in `based` (it is drawn only after every base job has been: no deadlock).
       if (tid == 0) {
-        const uint32_t need_a = (uint32_t)((ts0 + nr + live.R - 1) / live.R);
-        const uint32_t need_b = (uint32_t)((T - ts0 - 1 + live.R - 1) / live.R);
-        // sweeps that meet in the middle (live.mitm): a sweep's choice is final once its word carries kProgMitm or counts
-        // a chunk beyond its half (the crossing itself publishes the half's count, still without the flag).  Then a slot's
-        // occupancy only needs the sweep that wrote it: slots > m the forward sweep, slots < m the backward one, slot m
-        // the forward sweep's crossing (in L2 with its first chunk beyond).
-        // (T not a multiple of 16: the backward sweep's occupancies end below m_b = T - 16 half_b <= m, slots m_b .. m
-        // are the forward sweep's crossing too; a sweep's last, partial chunk comes with its final count)
-        const int half_a = mitm_plain_chunks_a(T), half_b = mitm_plain_chunks_b(T), mid_b = T - 16 * half_b;
-        const int s_lo = ts0 + 1, s_hi = ts0 + nr;
-        const uint32_t gneed_a = s_hi >= mid_b ? (uint32_t)max((s_hi + 15) / 16, half_a + 1) : 0u;
-        const uint32_t gneed_b = s_lo < mid_b ? (uint32_t)((T - 1 - s_lo) / 16 + 1) : 0u;
-        const uint32_t me = xcc_id();
-        int st = -2;  // (gave up: ~2 s)
-        for (int spin = 0; spin < (1 << 20); ++spin) {
-          const uint64_t va = __hip_atomic_load(live.prog_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint64_t vb = __hip_atomic_load(live.prog_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(va >> 32) == live.token && (uint32_t)(vb >> 32) == live.token) {
-            const uint32_t fa = (uint32_t)va & 0x0fffffffu, fb = (uint32_t)vb & 0x0fffffffu;
-            if (fa == kProgSkip || fb == kProgSkip) {
-              st = 0;  // not swept in the probability domain: the general kernel's utterance
-              break;
-            }
-            if ((((uint32_t)va >> 28) & 15u) != me || (((uint32_t)vb >> 28) & 15u) != me || live.force_bad) {
-              st = -1;
-              break;
-            }
-            const uint32_t ca = fa & kProgCount, cb = fb & kProgCount;
-            if (!live.mitm) {
-              if (ca >= need_a && cb >= need_b) {
-                st = 1;
-                break;
-              }
-            } else {
-              const bool ma = (fa & kProgMitm) != 0, mb = (fb & kProgMitm) != 0;
-              if ((ma || ca >= (uint32_t)half_a + 1) && (mb || cb >= (uint32_t)half_b + 1)) {  // both have chosen
-                if (ma != mb) {
-                  st = -1;  // (one of them gave up waiting at its crossing: the certificate re-sweeps the utterance)
-                  break;
-                }
-                if (ma ? (ca >= gneed_a && cb >= gneed_b) : (ca >= need_a && cb >= need_b)) {
-                  st = ma ? 2 : 1;
-                  break;
-                }
-              }
-            }
+        int st = poll(1 << 20);  // (gives up after ~2 s)
+        if (st >= 1 && live.based) {
+          bool seen = false;
+          for (int spin = 0; spin < (1 << 20) && !seen; ++spin) {
+            seen = __hip_atomic_load(live.based, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == live.token;
+            if (!seen) __builtin_amdgcn_s_sleep(32);
           }
-          __builtin_amdgcn_s_sleep(64);
+          if (!seen) st = -2;
         }
         if (st < 0) __hip_atomic_store(live.bad, live.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *state = st;
       }
       __syncthreads();
       if (*state < 1) return;
+      prewritten = live.based != nullptr;
       gamma = *state == 2;
       LIVE_T(t_w1);
       LIVE_ADD(1, t_w0, t_w1);
@@ -2703,7 +2762,7 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
       // occupancies as the sweeps stored them: Q floats at the head of the slot's row (of Q doubles) -- the beta buffer's up
       // to the middle slot, the alpha buffer's beyond
       const int n = nr * Q;
-      constexpr int U = 8;
+      constexpr int U = 16;  // (8: a tile's occupancies 12.8 us in five rounds of loads)
       for (int i0 = tid; i0 < n; i0 += U * NT) {
         float gv[U];
 #pragma unroll
@@ -2763,7 +2822,33 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
     LIVE_T(t_p1);
     // (eight rows a trip for the workgroups beside the sweeps -- stream_grad_rows<8, true>, twice the bytes in flight for the
     // same registers -- changes nothing: a tile's rows 23.9 us either way, the step 0.342 against 0.338 ms)
-    stream_grad_rows(b, ts0, nr, T, C, Kmax, tid, NT, dx, x, row_lse, accumulate, dead, cf, acc, colmap);
+    if (LIVE && prewritten && !dead) {
+      // the base values are this workgroup's own, in L2: + cf x the occupancy of the row's label columns (the same two
+      // roundings as the single pass: -cf softmax, then + cf acc)
+      // (sixteen elements a thread at a time, all their loads in flight together: a load behind a store to the same
+      // array is a load the compiler must wait for -- one round trip to L2 per element, 15 us for a tile's 6 000)
+      float* gdst = dx + ((int64_t)b * T + ts0) * C;
+      const float inv_k = 1.f / (float)max(K, 1);
+      const int n = nr * K;
+      constexpr int UP = 16;
+      for (int i0 = tid; i0 < n; i0 += UP * NT) {
+        float* pv[UP];
+        float have[UP], add[UP];
+#pragma unroll
+        for (int j = 0; j < UP; ++j) {
+          const int i = min(i0 + j * NT, n - 1);
+          const int r = (int)(((float)i + 0.5f) * inv_k), k = i - r * K;
+          pv[j] = gdst + (int64_t)r * C + colk[k];
+          add[j] = i0 + j * NT < n ? cf * acc[r * Kmax + k] : 0.f;
+          have[j] = ld_l2(pv[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < UP; ++j)
+          if (add[j] != 0.f) *pv[j] = have[j] + add[j];
+      }
+    } else {
+      stream_grad_rows(b, ts0, nr, T, C, Kmax, tid, NT, dx, x, row_lse, accumulate, dead, cf, acc, colmap);
+    }
     LIVE_T(t_p2);
     if (LIVE) {
       LIVE_ADD(4, t_p0, t_p1);
@@ -2776,7 +2861,7 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
 // LDS of occ_grad_tiles (bytes)
 static size_t occ_lds_bytes(const wfl_lattice_desc& d, int TS, int C) {
   return 18 * 8 + (((size_t)TS * d.max_labels + 1) & ~(size_t)1) * 4 + 8 * (size_t)TS +
-         2 * (((size_t)d.max_states + 3) & ~(size_t)3) + 2 * (size_t)C + 16;
+         2 * (((size_t)d.max_states + 3) & ~(size_t)3) + 2 * (((size_t)C + 3) & ~(size_t)3) + 4 * (size_t)d.max_labels + 16;
 }
 
 __global__ void __launch_bounds__(256)
@@ -2827,11 +2912,13 @@ __global__ void __launch_bounds__(MAXT)
   if (threadIdx.x == 0) __hip_atomic_store(busy, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef WFL_LIVE_STATS
   if (threadIdx.x == 0 && blockIdx.x < 512) g_sweep[blockIdx.x][0] = wall_clock64();
+  WFL_LOG(2);
 #endif
   prob_chain_body<MAXT, true>(d, ints, floats, xg, T, rows_per_chunk, weights, alpha, beta, logz, tail, nch1, b,
                               blockIdx.x / Bp, smem, token, mitm_req);
 #ifdef WFL_LIVE_STATS
   if (threadIdx.x == 0 && blockIdx.x < 512) g_sweep[blockIdx.x][1] = wall_clock64();
+  WFL_LOG(3);
 #endif
   if (threadIdx.x == 0) __hip_atomic_store(busy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -2900,7 +2987,7 @@ __global__ void __launch_bounds__(64)
       count[x] += __popcll(m);
     }
   }
-  if (lane < 8) h.next[lane] = 0;
+  if (lane < 8) h.next[lane] = 0, h.next_base[lane] = 0;
   if (lane == 0) h.meta[0] = token, h.meta[1] = (uint32_t)ntiles;
 #pragma unroll
   for (int x = 0; x < 8; ++x)
@@ -2911,7 +2998,7 @@ __global__ void __launch_bounds__(64)
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)  // (three waves a SIMD, i.e. three workgroups a CU: at most 168 VGPRs -- at 169 a third fewer)
     occ_live_kernel(wfl_lattice_desc d, const int32_t* __restrict__ ints, const float* __restrict__ floats, int T, int C,
                     float* __restrict__ alpha, float* __restrict__ beta, const float* __restrict__ coef,
                     const float* __restrict__ x, const float* __restrict__ row_lse, float* __restrict__ dx, int rows_o,
@@ -2944,24 +3031,73 @@ __global__ void __launch_bounds__(256)
   LIVE_T(t_b1);
   LIVE_ADD(0, t_b0, t_b1);
 #endif
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) job_s = __hip_atomic_fetch_add(h.next + me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const uint32_t job = job_s;
-    if (nx <= 0 || job >= (uint32_t)nx * (uint32_t)ntiles) return;
-    const int r = (int)(job / (uint32_t)nx), b = h.list[me * d.B + (int)(job % (uint32_t)nx)];
-    int tile;
-    if (r < 2 * pair)
-      tile = (r & 1) ? mid - 1 - (r >> 1) : mid + (r >> 1);
-    else
-      tile = nhi > nlo ? mid + pair + (r - 2 * pair) : mid - 1 - pair - (r - 2 * pair);
-    const UttView u = make_view(d, ints, floats, b, T);
+#ifdef WFL_LIVE_STATS
+  unsigned long long njobs_done = 0;
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg[blockIdx.x][0] = t_b0, g_wg[blockIdx.x][1] = t_b1;
+#endif
+  if (nx <= 0) return;
+  auto tile_of = [&](uint32_t job, int& b) {  // job -> (tile, utterance), tiles in middle-out order
+    const int r = (int)(job / (uint32_t)nx);
+    b = h.list[me * d.B + (int)(job % (uint32_t)nx)];
+    if (r < 2 * pair) return (r & 1) ? mid - 1 - (r >> 1) : mid + (r >> 1);
+    return nhi > nlo ? mid + pair + (r - 2 * pair) : mid - 1 - pair - (r - 2 * pair);
+  };
+  // ---- first phase: the rows' base values.  A row of the gradient is -cf softmax(x) plus the occupancies of a few label
+  // columns (16 of 1001 at the Transducer benchmark), and only the latter wait for the sweeps: the workgroups stream the
+  // former -- all of the step's gradient traffic but a line per (frame, label) -- while the sweeps are in their first
+  // half and there is nothing else for them to do (the first occupancies appear at the crossing, 85 us into the launch),
+  // and mark each tile in `based`.  With whole rows written per tile behind the sweeps the gradient ran at the capacity
+  // of its workgroups from the crossing on and was 80 us behind when the sweeps ended (B = 64: 858 of 1 600 tiles,
+  // profiles/r06_live_timeline.txt).
+  const uint32_t total = (uint32_t)nx * (uint32_t)ntiles;
+  auto live_of = [&](int b, int tile) {
     OccLive live;
     live.prog_a = reinterpret_cast<const uint64_t*>(ta) + b;
     live.prog_b = reinterpret_cast<const uint64_t*>(tb) + b;
     live.bad = h.bad + b;
     live.token = token, live.R = rows_per_chunk, live.force_bad = 0, live.mitm = mitm_req;
+    live.based = h.based + (int64_t)b * ntiles + tile;
+    return live;
+  };
+  // ---- first phase: the rows' base values.  A row of the gradient is -cf softmax(x) plus the occupancies of its label
+  // columns, and only the latter wait for the sweeps: the workgroups stream the former -- the step's gradient traffic --
+  // while the sweeps are in their first half and there is nothing else for them to do (the first occupancies appear at
+  // the crossing, 85 us into the launch), and mark each tile in `based`.  With whole rows written per tile behind the
+  // sweeps the gradient ran at the capacity of its workgroups from the crossing on and was 80 us behind when the sweeps
+  // ended (B = 64: 858 of 1 600 tiles; profiles/r06_live_timeline.txt).
+  // (Every base job is drawn before any occupancy job: a tile that waits for its base rows waits for a workgroup that
+  // is writing them.  Occupancy jobs first where they are ready -- a look at the head job, then a ticket or a
+  // compare-and-swap -- was built twice: the looks cost more than the order gains, 0.40 ms and 2.1 ms a step.)
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) job_s = __hip_atomic_fetch_add(h.next_base + me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t job = job_s;
+    if (job >= total) break;
+    int b;
+    const int tile = tile_of(job, b);
+    const int t_begin = tile * rows_o, nr = min(T, t_begin + rows_o) - t_begin;
+    stream_grad_rows(b, t_begin, nr, T, C, d.max_labels, threadIdx.x, blockDim.x, dx, x, row_lse, 0, false, coef ? coef[b] : 1.f,
+                     nullptr, nullptr, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this thread's rows are in L2 ...)
+    __syncthreads();                                   // (... and every thread's)
+    if (threadIdx.x == 0)
+      __hip_atomic_store(h.based + (int64_t)b * ntiles + tile, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- second phase: the occupancies of the tiles' label columns, added to their base rows, tile by tile behind the sweeps
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) job_s = __hip_atomic_fetch_add(h.next + me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t job = job_s;
+#ifdef WFL_LIVE_STATS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg[blockIdx.x][2] = wall_clock64(), g_wg[blockIdx.x][3] = njobs_done++;
+#endif
+    if (job >= total) return;
+    int b;
+    const int tile = tile_of(job, b);
+    const UttView u = make_view(d, ints, floats, b, T);
+    const OccLive live = live_of(b, tile);
     const int t_begin = tile * rows_o;
     occ_grad_tiles<true>(d, u, b, T, C, alpha, beta, nullptr, coef, nullptr, 0, x, row_lse, dx, t_begin,
                          min(T, t_begin + rows_o), rows_o, tail, nch1, smem, live);
@@ -2978,6 +3114,8 @@ __global__ void __launch_bounds__(256)
                 int R, int skip_band, int skip_occ) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;
+  WFL_MARK_BEGIN(2);
+  WFL_LOG(12);
   const UttView u = make_view(d, ints, floats, b, T);
   const int Q = u.Q, A = u.A, E = u.E, K = u.K, Kmax = d.max_labels;
   // The dense rows never pass through LDS: posteriors are accumulated per (frame, distinct label)
@@ -3423,6 +3561,7 @@ __global__ void reduce_loss_kernel(const float* __restrict__ vals, const float* 
                                    const float* __restrict__ scale, int B, float sign, int accumulate,
                                    float* __restrict__ out) {
   __shared__ float red[64];
+  WFL_LOG(13);
   float s = 0.f;
   for (int b = threadIdx.x; b < B; b += blockDim.x)
     s += sign * (scale ? scale[b] : 1.f) * (minus ? vals[b] - minus[b] : vals[b]);
@@ -3608,7 +3747,9 @@ int wfl_lattice_workspace(const wfl_lattice_desc* d, int T, int64_t* xg_elems, i
     ab_tail(*d, T, tail, nch1);
     // (+ kDumpDoubles doubles behind the tail: where the lanes without a state of the unrolled sweeps "store")
     // (+ behind that: a progress word per utterance, and -- alpha only -- `bad` and the OccHeader lists)
-    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2 + 2 * kDumpDoubles + 12 * (int64_t)d->B + 32 + 2048 + 4;
+    // (... + the in-flight gradient's header: OccHeader, its per-tile words last)
+    *ab_elems = tail + 2 * ((int64_t)d->B * nch1 + d->B) + 2 * (int64_t)d->B + 2 + 2 * kDumpDoubles + 12 * (int64_t)d->B + 32 + 2048 + 4 +
+                16 + (int64_t)d->B * (T / kLiveTile + 2);
   }
   return WFL_OK;
 }
@@ -3845,7 +3986,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
       // label acceptors without epsilon arcs, full 16-frame chunks (the sweeps' publication counts on them).
       // WFL_LATTICE_FUSED_BADXCD=1: every utterance is reported as swept on two XCDs (tests of the fall-back).
       constexpr int fused_env = 1;
-      constexpr int fused_tile = 32;  // frames per gradient job (16 / 24 / 48 re-measured in round 5 with the sweeps at 160 us: all within 1 %)
+      constexpr int fused_tile = kLiveTile;  // frames per gradient job (16 / 24 / 48 re-measured in round 5 with the sweeps at 160 us: all within 1 %)
       // persistent gradient workgroups per CU: as many as are resident at once (four waves of 130 VGPRs each: three per
       // CU).  More only queue behind those and start when the jobs are gone; measured at the Transducer benchmark with
       // the sweeps at 160 us: 2 -> 0.399 ms, 3 -> 0.362, 4 -> 0.364, 5 (the value until then) -> 0.369, 8 -> 0.37
@@ -4106,6 +4247,23 @@ int wfl_debug_live_timeline(unsigned long long* tiles, unsigned int* ntiles, uns
   rc |= (int)hipMemcpyFromSymbol(sweeps, HIP_SYMBOL(g_sweep), sizeof(unsigned long long) * 512 * 2);
   unsigned int z = 0;
   rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_n), &z, sizeof(z));
+  return rc;
+}
+int wfl_debug_live_workgroups(unsigned long long* wgs) {
+  return (int)hipMemcpyFromSymbol(wgs, HIP_SYMBOL(g_wg), sizeof(unsigned long long) * 1024 * 4);
+}
+int wfl_debug_log(unsigned long long* log, unsigned int* n) {  // read and reset
+  int rc = (int)hipMemcpyFromSymbol(log, HIP_SYMBOL(g_log), sizeof(unsigned long long) * 1024);
+  rc |= (int)hipMemcpyFromSymbol(n, HIP_SYMBOL(g_log_n), sizeof(unsigned int));
+  unsigned int z = 0;
+  rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_log_n), &z, sizeof(z));
+  return rc;
+}
+int wfl_debug_marks(unsigned long long* marks) {  // read and reset
+  int rc = (int)hipMemcpyFromSymbol(marks, HIP_SYMBOL(g_marks), sizeof(unsigned long long) * 16);
+  unsigned long long z[16];
+  for (int i = 0; i < 8; ++i) z[2 * i] = ~0ull, z[2 * i + 1] = 0ull;
+  rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_marks), z, sizeof(z));
   return rc;
 }
 int wfl_debug_live_stats(unsigned long long* out, int reset) {
