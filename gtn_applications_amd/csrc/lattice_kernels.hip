@@ -3003,7 +3003,7 @@ __global__ void __launch_bounds__(256, 3)  // (three waves a SIMD, i.e. three wo
                     float* __restrict__ alpha, float* __restrict__ beta, const float* __restrict__ coef,
                     const float* __restrict__ x, const float* __restrict__ row_lse, float* __restrict__ dx, int rows_o,
                     int ntiles, int rows_per_chunk, int64_t tail, int nch1, uint32_t token,
-                    const uint32_t* __restrict__ verdict, int mitm_req) {
+                    const uint32_t* __restrict__ verdict, int mitm_req, int two_phase) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ uint32_t job_s;
   // (the gate in front of this kernel on the side stream: anything but the launch's token means it gave up and the
@@ -3056,7 +3056,7 @@ __global__ void __launch_bounds__(256, 3)  // (three waves a SIMD, i.e. three wo
     live.prog_b = reinterpret_cast<const uint64_t*>(tb) + b;
     live.bad = h.bad + b;
     live.token = token, live.R = rows_per_chunk, live.force_bad = 0, live.mitm = mitm_req;
-    live.based = h.based + (int64_t)b * ntiles + tile;
+    live.based = two_phase ? h.based + (int64_t)b * ntiles + tile : nullptr;
     return live;
   };
   // ---- first phase: the rows' base values.  A row of the gradient is -cf softmax(x) plus the occupancies of its label
@@ -3068,7 +3068,9 @@ __global__ void __launch_bounds__(256, 3)  // (three waves a SIMD, i.e. three wo
   // (Every base job is drawn before any occupancy job: a tile that waits for its base rows waits for a workgroup that
   // is writing them.  Occupancy jobs first where they are ready -- a look at the head job, then a ticket or a
   // compare-and-swap -- was built twice: the looks cost more than the order gains, 0.40 ms and 2.1 ms a step.)
-  for (;;) {
+  // (two_phase = 0, WFL_LATTICE_TWO_PHASE=0: whole rows per tile behind the sweeps as until round 6 -- 13 us a step slower at
+  // the Transducer benchmark, 200 MB less traffic: the label columns' lines are not read and written a second time)
+  for (; two_phase;) {
     __syncthreads();
     if (threadIdx.x == 0) job_s = __hip_atomic_fetch_add(h.next_base + me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -4046,6 +4048,10 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
           const char* mitm_e = getenv("WFL_LATTICE_MITM");
           const int mitm_env = mitm_e ? atoi(mitm_e) : 1;
           const int mitm_req = (mitm_env != 0 && T >= (mitm_env == 2 ? 64 : kMitmFrames) && !weights) ? 1 : 0;
+          // the gradient workgroups write the rows' base values first and add the occupancies behind the sweeps
+          // (occ_live_kernel); WFL_LATTICE_TWO_PHASE=0: whole rows per tile (read per call)
+          const char* tp_e = getenv("WFL_LATTICE_TWO_PHASE");
+          const int two_phase = (tp_e && atoi(tp_e) == 0) ? 0 : 1;
           auto launch_pub = [&](auto kern) {
             if (plds > 48 * 1024) (void)wfl::set_max_dynamic_lds((const void*)kern, (int)plds);
             hipLaunchKernelGGL(kern, dim3((unsigned)(2 * Bp)), dim3(nt), plds, main_s, *d, ints, floats, xg, T, rpc, weights,
@@ -4060,7 +4066,7 @@ static int lattice_forward_impl(const wfl_lattice_desc* d, const int32_t* ints, 
           const int64_t jobs = (int64_t)d->B * nt_o;
           const unsigned wgs = (unsigned)std::max<int64_t>(8, std::min<int64_t>(jobs, (int64_t)fused_wgs * device_cus()));
           hipLaunchKernelGGL(occ_live_kernel, dim3(wgs), dim3(256), olds, side->stream, *d, ints, floats, T, g->C, alpha, beta,
-                             g->coef, g->x, g->row_lse, g->dx, rows_o, nt_o, rpc, tail, nch1, token, verdict, mitm_req);
+                             g->coef, g->x, g->row_lse, g->dx, rows_o, nt_o, rpc, tail, nch1, token, verdict, mitm_req, two_phase);
           WFL_HIP_CHECK(hipEventRecord(side->join, side->stream));
           join_side = side;  // (joined below, behind the certificate: it and the log-domain launch overlap the gradient's tail)
           g->done = 1;

@@ -1112,7 +1112,8 @@ def test_transducer_native_call_is_the_python_sequence(crit, monkeypatch, leaf):
     np.testing.assert_allclose(native[1], python[1], rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("B,T,mitm", [(6, 200, "0"), (70, 48, "1"), (6, 208, "2"), (9, 64, "2"), (6, 200, "2"), (3, 330, "1")])
+@pytest.mark.parametrize("B,T,mitm", [(6, 200, "0"), (70, 48, "1"), (6, 208, "2"), (9, 64, "2"), (6, 200, "2"), (3, 330, "1"),
+                                      (6, 200, "0/one-phase"), (6, 208, "2/one-phase")])
 def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(crit, monkeypatch, B, T, mitm):
     """csrc/lattice_kernels.hip wfl_lattice_forward_grad: the emission gradient computed by the persistent workgroups
     that follow the two sweeps (tile-local log Z, L1-bypassing reads of alpha / beta) against the gradient kernel that
@@ -1122,7 +1123,10 @@ def test_transducer_gradient_beside_the_sweeps_equals_the_gradient_in_backward(c
     from 64 frames on and the workgroups read occupancies (csrc/lattice_kernels.hip run_chain_prob, "meeting the
     partner"), "1" (the default) from 320 frames on, "0" never."""
     tr = crit["transducer"]
-    monkeypatch.setenv("WFL_LATTICE_MITM", mitm)
+    # ("/one-phase": WFL_LATTICE_TWO_PHASE=0, whole rows per tile instead of base rows first and occupancies added behind
+    # the sweeps -- csrc/lattice_kernels.hip occ_live_kernel)
+    monkeypatch.setenv("WFL_LATTICE_MITM", mitm.split("/")[0])
+    monkeypatch.setenv("WFL_LATTICE_TWO_PHASE", "0" if mitm.endswith("one-phase") else "1")
     tokens, g2i, x, tg = _word_piece_batch(B, T, 11)
     m = tr.Transducer(tokens, g2i, blank="optional", allow_repeats=False, reduction="mean")
 
