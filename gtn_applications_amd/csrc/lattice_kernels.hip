@@ -2762,7 +2762,7 @@ __device__ __forceinline__ void occ_grad_tiles(const wfl_lattice_desc& d, const 
       // occupancies as the sweeps stored them: Q floats at the head of the slot's row (of Q doubles) -- the beta buffer's up
       // to the middle slot, the alpha buffer's beyond
       const int n = nr * Q;
-      constexpr int U = 16;  // (8: a tile's occupancies 12.8 us in five rounds of loads)
+      constexpr int U = 8;  // (16: no different -- 0.3136 against 0.3107 ms a step)
       for (int i0 = tid; i0 < n; i0 += U * NT) {
         float gv[U];
 #pragma unroll
