@@ -1909,22 +1909,38 @@ __device__ __forceinline__ void run_chain_prob_general_body(const wfl_lattice_de
   // LDS reads (the vector and the row) instead of a chain of four (list -> pointers -> arcs -> vector).  What does
   // not fit (more states than threads, more rows than the workgroup has, arcs beyond 64 a row) takes the loops over
   // the LDS copy.  (absent arcs: factor 0, entry 0)
-  const int2 none = make_int2(0, 0);
+  // (decoded once: source entry, row slot and the factor as a double -- two waves that each run alone on their SIMD
+  // issue an instruction every ~5 cycles, and the masks, shifts and conversions were a third of a frame's)
+  struct RegArc {
+    int src, slot;
+    double fac;
+  };
+  auto decode = [](bool on, int2 a) {
+    RegArc r;
+    r.src = on ? (a.x & 0xffff) : 0, r.slot = on ? (int)((unsigned)a.x >> 16) : 0;
+    r.fac = on ? (double)__int_as_float(a.y) : 0.0;
+    return r;
+  };
   const int lk0 = tid < Q ? ptr[tid] : 0, lk1 = tid < Q ? ptr[tid + 1] : 0;
   const bool light0 = tid < Q && lk1 - lk0 <= kProbRowDeg;
-  int2 la[kProbRowDeg];
+  RegArc la[kProbRowDeg];
 #pragma unroll
-  for (int i = 0; i < kProbRowDeg; ++i) la[i] = (light0 && lk0 + i < lk1) ? arcs[lk0 + i] : none;
+  for (int i = 0; i < kProbRowDeg; ++i) la[i] = decode(light0 && lk0 + i < lk1, arcs[min(lk0 + i, max(A - 1, 0))]);
   const int hq0 = grow < n_heavy ? heavy[grow] : -1;
   const int hk0 = hq0 >= 0 ? ptr[hq0] : 0, hk1 = hq0 >= 0 ? ptr[hq0 + 1] : 0;
-  int2 ha[4];
+  RegArc ha[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) ha[j] = hk0 + r16 + 16 * j < hk1 ? arcs[hk0 + r16 + 16 * j] : none;
+  for (int j = 0; j < 4; ++j) ha[j] = decode(hk0 + r16 + 16 * j < hk1, arcs[min(hk0 + r16 + 16 * j, max(A - 1, 0))]);
   const int ek0 = tid < Q ? eptr[tid] : 0, ek1 = tid < Q ? eptr[tid + 1] : 0;
   const bool elight0 = ek1 > ek0 && ek1 - ek0 <= kProbEpsDeg;
-  int2 ea[kProbEpsDeg];
+  int ea_src[kProbEpsDeg];
+  double ea_fac[kProbEpsDeg];
 #pragma unroll
-  for (int i = 0; i < kProbEpsDeg; ++i) ea[i] = (elight0 && ek0 + i < ek1) ? eps[ek0 + i] : none;
+  for (int i = 0; i < kProbEpsDeg; ++i) {
+    const bool on = elight0 && ek0 + i < ek1;
+    const int2 a = eps[min(ek0 + i, max(E - 1, 0))];
+    ea_src[i] = on ? a.x : 0, ea_fac[i] = on ? (double)__int_as_float(a.y) : 0.0;
+  }
   // (no wave-uniform bounds on those slots: a test between two groups of LDS reads makes each group its own round trip --
   // measured: the relaxation 740 -> 1200-1800 cycles a frame)
   const int wh = __builtin_amdgcn_readfirstlane(wave_all_max_int(hq0 >= 0 ? 1 : 0));
@@ -1932,7 +1948,8 @@ __device__ __forceinline__ void run_chain_prob_general_body(const wfl_lattice_de
   int my_lev = 0;
   for (int l = 1; l < nlev; ++l)
     if (tid >= lvl[l]) my_lev = l;
-  auto term = [](const double* vec, const float* row, int2 a) {
+  auto term = [](const double* vec, const float* row, const RegArc& a) { return vec[a.src] * (a.fac * (double)row[a.slot]); };
+  auto term_lds = [](const double* vec, const float* row, int2 a) {
     return vec[a.x & 0xffff] * ((double)__int_as_float(a.y) * (double)row[(unsigned)a.x >> 16]);
   };
 
@@ -1945,8 +1962,8 @@ __device__ __forceinline__ void run_chain_prob_general_body(const wfl_lattice_de
         double v0 = mine, v1 = 0.0;
 #pragma unroll
         for (int i = 0; i < kProbEpsDeg; i += 2) {
-          v0 = fma(vals[ea[i].x], (double)__int_as_float(ea[i].y), v0);
-          v1 = fma(vals[ea[i + 1].x], (double)__int_as_float(ea[i + 1].y), v1);
+          v0 = fma(vals[ea_src[i]], ea_fac[i], v0);
+          v1 = fma(vals[ea_src[i + 1]], ea_fac[i + 1], v1);
         }
         mine = v0 + v1;
         vals[tid] = mine;
@@ -2047,6 +2064,7 @@ __device__ __forceinline__ void run_chain_prob_general_body(const wfl_lattice_de
       const double* from = (slot_from & 1) ? buf1 : buf0;
       double* to = (slot_to & 1) ? buf1 : buf0;
       const float* row = tile + (size_t)(t - f0) * Kmax;
+      const float ref_t = rtile[t - f0];  // (read here: its LDS round trip is off the frame's chain of them)
       GEN_T(g0);
       double mine = 0.0;
       if (light0) {
@@ -2060,7 +2078,7 @@ __device__ __forceinline__ void run_chain_prob_general_body(const wfl_lattice_de
         double v0 = 0.0, v1 = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; j += 2) v0 += term(from, row, ha[j]), v1 += term(from, row, ha[j + 1]);
-        for (int k = hk0 + r16 + 64; k < hk1; k += 16) v0 += term(from, row, arcs[k]);
+        for (int k = hk0 + r16 + 64; k < hk1; k += 16) v0 += term_lds(from, row, arcs[k]);
         const double v = row16_sum_dpp(v0 + v1);
         if (hq0 >= 0 && r16 == 0) to[hq0] = v;
       }
@@ -2104,11 +2122,12 @@ __device__ __forceinline__ void run_chain_prob_general_body(const wfl_lattice_de
       if (!light0 && tid < Q) mine = to[tid];  // (a row's lane 0 wrote it)
       closure(to, mine);
       GEN_T(g3);
-      cum += ((double)rtile[t - f0] + (double)wref) * kLog2e_d;
+      cum += ((double)ref_t + (double)wref) * kLog2e_d;
       if (tid == 0) offs[slot_to] = cum;
       double* orow = out + u.ab_base + (int64_t)slot_to * Q;
       if (tid < Q) orow[tid] = mine;
-      for (int q = tid + NT; q < Q; q += NT) orow[q] = to[q];
+      if (Q > NT)
+        for (int q = tid + NT; q < Q; q += NT) orow[q] = to[q];
       GEN_T(g4);
       GEN_ADD(0, g0, g1);
       GEN_ADD(1, g1, g2);
