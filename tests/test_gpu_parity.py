@@ -1396,6 +1396,34 @@ def test_transducer_gradient_beside_the_sweeps_falls_back_through_the_certificat
     close(dx, ref_dx.cpu().numpy(), rtol=2e-3, atol=2e-6, msg="fall-back")  # (fp32 log-domain sweeps against fp64 probabilities)
 
 
+def test_transducer_two_phase_gradient_over_many_steps_back_to_back(crit, monkeypatch):
+    """csrc/lattice_kernels.hip occ_live_kernel: the gradient workgroups beside the sweeps write the rows' base values
+    while the sweeps are in their first half and add the label columns' occupancies behind them -- tiles of one launch
+    wait for words (`based`) that workgroups of the same launch write, launches follow each other without a host
+    synchronisation, buffers come back from the caching allocator.  120 steps back to back on two alternating batches
+    against WFL_LATTICE_TWO_PHASE=0 (whole rows per tile): the loss bit for bit, the gradient to the order of the LDS
+    float additions."""
+    tr = crit["transducer"]
+    batches = [_word_piece_batch(12, 416, 31 + k) for k in range(2)]
+    m = tr.Transducer(batches[0][0], batches[0][1], blank="optional", allow_repeats=False, reduction="mean")
+
+    def run(k):
+        x = batches[k][2].clone().requires_grad_(True)
+        loss = m(x.view_as(x), batches[k][3])
+        loss.backward()
+        return loss.detach(), x.grad
+
+    monkeypatch.setenv("WFL_LATTICE_TWO_PHASE", "0")
+    ref = [run(k) for k in range(2)]
+    torch.cuda.synchronize()
+    monkeypatch.setenv("WFL_LATTICE_TWO_PHASE", "1")
+    got = [(it & 1,) + run(it & 1) for it in range(120)]
+    torch.cuda.synchronize()
+    for k, loss, dx in got:
+        assert float(loss) == float(ref[k][0])
+        close(dx, ref[k][1].cpu().numpy(), rtol=1e-5, atol=1e-9, msg="two phases")
+
+
 def _sweep_formats(loss, B, T):
     """fmt[b] of the numerator sweeps behind a Transducer loss (0 log domain, 1 probability domain, 2 met in the middle)"""
     import ctypes
