@@ -524,8 +524,10 @@ def timed_loop(step, steps, warmup, fence, collect_events):
     """-> (seconds of the timed region, ms per step of the dominant kernel group measured INSIDE it, ms per step of every
     group measured during warm-up).  HIP events around every launch perturb the step (each record is a packet on the
     stream, ~5 us on the critical path), so the timed region brackets only the dominant group -- found during the
-    warm-up steps, which bracket them all -- and only every 8th of its launches (every 4th below 32 steps, all of them
-    below 8)."""
+    warm-up steps, which bracket them all -- and only three of its launches, a third of the run apart (measured at the
+    CTC benchmark, 20 steps: every 4th launch bracketed 0.0472-0.0486 ms a step, every 10th 0.0455-0.0458).  (The
+    cyclic garbage collector is left alone: a collection right before the timed region made the 20 steps after it 15 us
+    slower each, switching it off for the region leaves every step's cycles and their device buffers alive.)"""
     from gtn_applications_amd import engine as E
 
     def collect(events, n):
@@ -551,7 +553,8 @@ def timed_loop(step, steps, warmup, fence, collect_events):
     E.PHASE_EVENTS = [] if collect_events else None
     E.PHASE_ONLY = {max(warm, key=warm.get)} if warm else None
     # bracket every 8th (short runs: 4th) launch of the dominant group
-    E.PHASE_STRIDE = (8 if steps >= 32 else 4 if steps >= 8 else 1) if warm else 1
+    # bracket three launches of the dominant group in the timed region (every launch of a run of fewer than four steps)
+    E.PHASE_STRIDE = max(1, steps // 3) if warm else 1
     E._PHASE_COUNT.clear()
     if collect_events and not warm:
         E.prealloc_events(16 * steps)
