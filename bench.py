@@ -552,7 +552,6 @@ def timed_loop(step, steps, warmup, fence, collect_events):
     # (--warmup 0: nothing to calibrate on, every group is bracketed inside the timed region)
     E.PHASE_EVENTS = [] if collect_events else None
     E.PHASE_ONLY = {max(warm, key=warm.get)} if warm else None
-    # bracket every 8th (short runs: 4th) launch of the dominant group
     # bracket three launches of the dominant group in the timed region (every launch of a run of fewer than four steps)
     E.PHASE_STRIDE = max(1, steps // 3) if warm else 1
     E._PHASE_COUNT.clear()
