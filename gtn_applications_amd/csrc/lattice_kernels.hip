@@ -832,6 +832,8 @@ __host__ __device__ inline int64_t prog_offset_doubles(const wfl_lattice_desc& d
   return (int64_t)d.B * nch1 + 2 * (int64_t)d.B + 1024 + 1;
 }
 constexpr int kLiveTile = 32;  // frames per job of the gradient beside the sweeps (at least: T / tiles, rounded up)
+                               // (40 / 48 / 56 / 64 with the gradient in two phases, same box, three runs each: 0.324-0.326 / 0.307-0.317 /
+                               //  0.307-0.310 / 0.335-0.337 against 0.309-0.335 -- inside the runs' own spread)
 // header of the in-flight gradient, behind the progress words and `bad` of the alpha tail (int32 units)
 struct OccHeader {
   uint32_t* bad;    // [B]
